@@ -1,0 +1,317 @@
+/*
+ * mlgpu.h — C-ABI of the MI355X-native DSPVector engine.
+ *
+ * This is the drop-in boundary for the mldsp.h hot path of madronalabs/madronalib
+ * (reference include/mldsp.h:7-16). The reference has no FFI of its own: it is a
+ * header-only C++ template library whose "operator interface" is
+ *   B1  the functor protocol  `DSPVector T::operator()(const DSPVector in)` +
+ *       `static Coeffs T::makeCoeffs(...)` + `void T::clear()`
+ *       (e.g. source/DSP/MLDSPFilters.h:199-240, source/DSP/MLDSPGens.h:395-402),
+ *   B2  the voice-bank protocol `Bank<T,ROWS>` (source/DSP/MLDSPFunctional.h:321-360),
+ *   B3  the C-style process callback `SignalProcessFn = void(*)(AudioContext*, void*)`
+ *       (source/app/MLSignalProcessBuffer.h:18).
+ * Every entry point below cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types cross this boundary.
+ *  - every function returns an mlgpu_status (0 = OK). The reference has no error
+ *    channel (it silently returns: source/app/MLSignalProcessBuffer.cpp:42-44).
+ *  - "d_" pointers are device (HBM) pointers on the engine's GPU, "h_" are host.
+ *  - one caller thread per engine (mirrors the single audio thread of the reference);
+ *    no locks, no allocation inside mlgpu_bank_process / mlgpu_op_apply.
+ *  - all work is enqueued on the engine's HIP stream; mlgpu_engine_sync waits for it.
+ *  - there is NO CPU fallback: without a gfx950 device every compute entry fails
+ *    with MLGPU_ERR_NO_DEVICE.
+ *
+ * Element type is float32 (int32/uint32 for the integer ops) exactly as in the
+ * reference (source/DSP/MLDSPOps.h:115-123). One DSPVector = 64 floats.
+ */
+#ifndef MLGPU_H
+#define MLGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLGPU_FLOATS_PER_DSPVECTOR 64 /* kFloatsPerDSPVector, source/DSP/MLDSPMath.h:8-9 */
+#define MLGPU_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------- */
+/* status codes                                                              */
+
+typedef enum mlgpu_status
+{
+  MLGPU_OK = 0,
+  MLGPU_ERR_INVALID = 1,     /* null pointer, bad enum, bad size */
+  MLGPU_ERR_NO_DEVICE = 2,   /* no HIP device / not gfx950 */
+  MLGPU_ERR_HIP = 3,         /* a HIP runtime call failed; see mlgpu_last_error */
+  MLGPU_ERR_OOM = 4,         /* device or host allocation failed */
+  MLGPU_ERR_UNSUPPORTED = 5, /* valid request this build has no kernel for */
+  MLGPU_ERR_RANGE = 6        /* index out of range (proc, coeff, state, voice) */
+} mlgpu_status;
+
+/* ------------------------------------------------------------------------- */
+/* signal layouts in HBM                                                     */
+/*
+ * A "signal" is S = 64*T samples for each of V voices.
+ *  QUAD        [S/4][V][4]  device-native: the 4-sample SIMD group of the reference
+ *                           (SIMDVectorFloat, MLDSPMathSSE.h:51) of voice v is one
+ *                           16-byte word; consecutive lanes (voices) are adjacent, so a
+ *                           wavefront moves 1 KiB per memory instruction.
+ *  ROWS        [T][V][64]   the reference's DSPVectorArray<V> per vector step
+ *                           (row-major [ROWS][64], MLDSPOps.h:283-310).
+ *  VOICE_MAJOR [V][S]       each voice's whole stream contiguous (host / oracle order).
+ * For T == 1, ROWS and VOICE_MAJOR coincide.
+ */
+typedef enum mlgpu_layout
+{
+  MLGPU_LAYOUT_QUAD = 0,
+  MLGPU_LAYOUT_ROWS = 1,
+  MLGPU_LAYOUT_VOICE_MAJOR = 2
+} mlgpu_layout;
+
+/* ------------------------------------------------------------------------- */
+/* stateless elementwise ops  (reference: source/DSP/MLDSPOps.h)             */
+/*
+ * Operands are flat arrays of n 4-byte elements (a DSPVectorArray<ROWS> is
+ * n = 64*ROWS elements); elementwise ops are layout-agnostic. Unused operand
+ * pointers must be NULL. Integer-typed operands/results are int32 bit patterns
+ * (the reference stores them in float-typed storage too: MLDSPOps.h:370-498).
+ */
+typedef enum mlgpu_op
+{
+  /* unary float -> float   MLDSPOps.h:584-614, 825 */
+  MLGPU_OP_SQRT = 0,
+  MLGPU_OP_SQRT_APPROX = 1, /* x*rsqrt(x): hardware-approximate, 2^-11 rel */
+  MLGPU_OP_ABS = 2,
+  MLGPU_OP_SIGN = 3,
+  MLGPU_OP_SIGN_BIT = 4,
+  MLGPU_OP_SIN = 5,
+  MLGPU_OP_COS = 6,
+  MLGPU_OP_LOG = 7,
+  MLGPU_OP_EXP = 8,
+  MLGPU_OP_LOG2 = 9,
+  MLGPU_OP_EXP2 = 10,
+  MLGPU_OP_SIN_APPROX = 11,
+  MLGPU_OP_COS_APPROX = 12,
+  MLGPU_OP_EXP_APPROX = 13,
+  MLGPU_OP_LOG_APPROX = 14,
+  MLGPU_OP_LOG2_APPROX = 15,
+  MLGPU_OP_EXP2_APPROX = 16,
+  MLGPU_OP_FRACTIONAL_PART = 17,
+  /* float -> int32         MLDSPOps.h:796-797 */
+  MLGPU_OP_ROUND_FLOAT_TO_INT = 18,
+  MLGPU_OP_TRUNCATE_FLOAT_TO_INT = 19,
+  /* int32 -> float         MLDSPOps.h:819-820 */
+  MLGPU_OP_INT_TO_FLOAT = 20,
+  MLGPU_OP_UNSIGNED_INT_TO_FLOAT = 21,
+  /* fused pair used by the config-2 bench: expApprox(sinApprox(x)) */
+  MLGPU_OP_EXP_APPROX_OF_SIN_APPROX = 22,
+
+  /* binary float,float -> float   MLDSPOps.h:640-649 */
+  MLGPU_OP_ADD = 32,
+  MLGPU_OP_SUBTRACT = 33,
+  MLGPU_OP_MULTIPLY = 34,
+  MLGPU_OP_DIVIDE = 35,
+  MLGPU_OP_DIVIDE_APPROX = 36, /* a*rcp(b): hardware-approximate, 2^-11 rel */
+  MLGPU_OP_POW = 37,
+  MLGPU_OP_POW_APPROX = 38,
+  MLGPU_OP_MIN = 39, /* SSE semantics (a<b)?a:b */
+  MLGPU_OP_MAX = 40, /* SSE semantics (a>b)?a:b */
+  /* binary int32,int32 -> int32   MLDSPOps.h:713-714 */
+  MLGPU_OP_ADD_INT32 = 41,
+  MLGPU_OP_SUBTRACT_INT32 = 42,
+  /* binary float,float -> int32 mask   MLDSPOps.h:851-856 */
+  MLGPU_OP_EQUAL = 43,
+  MLGPU_OP_NOT_EQUAL = 44,
+  MLGPU_OP_GREATER_THAN = 45,
+  MLGPU_OP_GREATER_THAN_OR_EQUAL = 46,
+  MLGPU_OP_LESS_THAN = 47,
+  MLGPU_OP_LESS_THAN_OR_EQUAL = 48,
+
+  /* ternary   MLDSPOps.h:744-748, 886, 917 */
+  MLGPU_OP_LERP = 64,         /* lerp(a, b, mix) = a + mix*(b - a) */
+  MLGPU_OP_INVERSE_LERP = 65, /* (x - a)/(b - a) with operands (a, b, x) */
+  MLGPU_OP_CLAMP = 66,        /* clamp(x, lo, hi) = min(max(x, lo), hi) */
+  MLGPU_OP_WITHIN = 67,       /* mask: lo <= x < hi */
+  MLGPU_OP_SELECT = 68,       /* select(a, b, maskInt): bitwise (m&a)|(~m&b) */
+  MLGPU_OP_SELECT_INT = 69
+} mlgpu_op;
+
+/* ------------------------------------------------------------------------- */
+/* stateful processors (reference: MLDSPGens.h, MLDSPFilters.h)              */
+/*
+ * A processor has NC per-voice coefficients (float) and NS per-voice state words
+ * (float or uint32 bit patterns), in the order listed. Its audio-rate input is the
+ * previous processor's output (or the bank input for processor 0): for generators the
+ * input is cyclesPerSample (f/sr), exactly the argument of the reference's operator().
+ */
+typedef enum mlgpu_proc
+{
+  /* generators, MLDSPGens.h */
+  MLGPU_PROC_PHASOR_GEN = 0,  /* :177-217  C{}            S{omega32:u32} */
+  MLGPU_PROC_SINE_GEN = 1,    /* :373-381  C{}            S{omega32:u32}; clear() -> 0xC0000000 */
+  MLGPU_PROC_SAW_GEN = 2,     /* :395-402  C{}            S{omega32:u32} */
+  MLGPU_PROC_PULSE_GEN = 3,   /* :383-393  C{width}       S{omega32:u32} (width per voice, constant) */
+  MLGPU_PROC_NOISE_GEN = 4,   /* :109-148  C{}            S{seed:u32}; no input */
+  MLGPU_PROC_TICK_GEN = 5,    /* :24-47    C{}            S{omega} */
+  MLGPU_PROC_IMPULSE_GEN = 6, /* :53-104   C{}            S{omega, outputCounter:i32}; 17-tap table in LDS */
+  MLGPU_PROC_ONE_SHOT_GEN = 7,/* :221-282  C{}            S{omega32:u32, gate:u32, omegaPrev:u32} */
+  /* SVF family, MLDSPFilters.h */
+  MLGPU_PROC_LOPASS = 16,     /* :51-153   C{g0,g1,g2}    S{ic1eq,ic2eq} */
+  MLGPU_PROC_HIPASS = 17,     /* :155-197  C{g0,g1,g2,k}  S{ic1eq,ic2eq} */
+  MLGPU_PROC_BANDPASS = 18,   /* :199-240  C{g0,g1,g2}    S{ic1eq,ic2eq} */
+  MLGPU_PROC_LO_SHELF = 19,   /* :242-319  C{a1,a2,a3,m1,m2}    S{ic1eq,ic2eq} */
+  MLGPU_PROC_HI_SHELF = 20,   /* :321-400  C{a1,a2,a3,m0,m1,m2} S{ic1eq,ic2eq} */
+  MLGPU_PROC_BELL = 21,       /* :402-442  C{a1,a2,a3,m1} S{ic1eq,ic2eq} */
+  /* one-state recurrences, MLDSPFilters.h */
+  MLGPU_PROC_ONE_POLE = 32,   /* :446-481  C{a0,b1}       S{y1} */
+  MLGPU_PROC_DC_BLOCKER = 33, /* :489-513  C{c}           S{x1,y1} */
+  MLGPU_PROC_DIFFERENTIATOR = 34, /* :517-535 C{}         S{x1} */
+  MLGPU_PROC_INTEGRATOR = 35, /* :539-558  C{leak}        S{y1} */
+  MLGPU_PROC_PEAK = 36,       /* :562-615  C{a0,b1,peakHoldSamples:i32} S{y1,peakHoldCounter:i32}; sqrtApprox: 2^-11 rel */
+  MLGPU_PROC_RMS = 37,        /* :619-653  C{a0,b1}       S{y1}; sqrtApprox: 2^-11 rel */
+  MLGPU_PROC_ADSR = 38,       /* :657-797  C{ka,kd,s,kr}  S{y,y1,x1,threshold,target,k,amp,segment:i32} */
+  /* stateless per-voice scaling: `x * DSPVector(gain)`, MLDSPOps.h:157,345-348 */
+  MLGPU_PROC_GAIN = 48        /*           C{gain}        S{} */
+} mlgpu_proc;
+
+/* ------------------------------------------------------------------------- */
+/* engine                                                                    */
+
+typedef struct mlgpu_engine mlgpu_engine;
+
+/* Create an engine bound to HIP device `device` with its own non-blocking stream. */
+int mlgpu_engine_create(int device, mlgpu_engine** out);
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch's current stream). */
+int mlgpu_engine_create_on_stream(int device, void* hip_stream, mlgpu_engine** out);
+int mlgpu_engine_destroy(mlgpu_engine* e);
+/* Block until all enqueued work is done. */
+int mlgpu_engine_sync(mlgpu_engine* e);
+/* The hipStream_t work is enqueued on (for HIP-event timing by the caller). */
+void* mlgpu_engine_stream(mlgpu_engine* e);
+int mlgpu_engine_device(mlgpu_engine* e);
+/* Human-readable text for the last failure on this engine (never NULL). */
+const char* mlgpu_last_error(mlgpu_engine* e);
+const char* mlgpu_status_string(int status);
+int mlgpu_abi_version(void);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int mlgpu_device_count(void);
+/* Device facts used by the bench (name, CU count, memory bytes). */
+int mlgpu_device_info(int device, char* name, size_t name_len, int* cu_count, uint64_t* mem_bytes);
+
+/* device memory owned by the caller, allocated on the engine's device */
+int mlgpu_alloc(mlgpu_engine* e, size_t bytes, void** d_out);
+int mlgpu_free(mlgpu_engine* e, void* d_ptr);
+int mlgpu_upload(mlgpu_engine* e, void* d_dst, const void* h_src, size_t bytes);
+int mlgpu_download(mlgpu_engine* e, void* h_dst, const void* d_src, size_t bytes);
+int mlgpu_fill32(mlgpu_engine* e, void* d_dst, uint32_t value, size_t n_elems);
+
+/* HIP-event timing on the engine's stream (events are created lazily, reused). */
+int mlgpu_timer_start(mlgpu_engine* e);
+int mlgpu_timer_stop_ms(mlgpu_engine* e, float* ms_out); /* records + waits */
+
+/* ------------------------------------------------------------------------- */
+/* stateless ops                                                             */
+
+/* out[i] = op(a[i] [, b[i] [, c[i]]]) for i < n_elems.
+ * Replaces the DEFINE_OP1/OP2/OP3/... families of MLDSPOps.h:570-917. */
+int mlgpu_op_apply(mlgpu_engine* e, int op, const void* d_a, const void* d_b, const void* d_c,
+                   void* d_out, size_t n_elems);
+
+/* ROWS x 1-row broadcast forms add1..max1 (MLDSPOps.h:655-687): b has 64 elements
+ * and repeats for every row of a. `op` is one of MLGPU_OP_ADD..MLGPU_OP_MAX. */
+int mlgpu_op_apply_rows1(mlgpu_engine* e, int op, const void* d_a, const void* d_b64, void* d_out,
+                         size_t n_rows);
+
+/* Horizontal per-row reductions sum/mean/max/min (MLDSPOps.h:995-1035), one float
+ * per row of 64, association order and FLT_MIN/FLT_MAX seeds as the reference. */
+typedef enum mlgpu_rowop
+{
+  MLGPU_ROWOP_SUM = 0,
+  MLGPU_ROWOP_MEAN = 1,
+  MLGPU_ROWOP_MAX = 2,
+  MLGPU_ROWOP_MIN = 3
+} mlgpu_rowop;
+int mlgpu_row_reduce(mlgpu_engine* e, int rowop, const float* d_rows, float* d_out, size_t n_rows);
+
+/* Re-lay a V-voice, T-vector signal between layouts (pure data movement; replaces the
+ * row plumbing a host would do with row()/setRowVector, MLDSPOps.h:283-310). */
+int mlgpu_layout_convert(mlgpu_engine* e, const float* d_src, int src_layout, float* d_dst,
+                         int dst_layout, size_t n_voices, size_t n_vectors);
+
+/* ------------------------------------------------------------------------- */
+/* voice banks                                                               */
+/*
+ * mlgpu_bank is the runtime-sized counterpart of `Bank<T,ROWS>`
+ * (MLDSPFunctional.h:321-360) where T is a chain of reference processors applied in
+ * order, e.g. {SAW_GEN, BANDPASS, GAIN} is `bp(saw(freq)) * gain`
+ * (SURVEY §3.2). One wavefront lane runs one voice; the DSPVector is walked serially
+ * with the voice's state in registers; state lives in HBM (SoA) between calls.
+ */
+typedef struct mlgpu_bank mlgpu_bank;
+
+int mlgpu_bank_create(mlgpu_engine* e, const int32_t* procs, int n_procs, size_t n_voices,
+                      mlgpu_bank** out);
+int mlgpu_bank_destroy(mlgpu_bank* b);
+size_t mlgpu_bank_num_voices(mlgpu_bank* b);
+int mlgpu_bank_num_procs(mlgpu_bank* b);
+/* NC / NS of processor `proc_idx` (see mlgpu_proc). Negative = error. */
+int mlgpu_bank_num_coeffs(mlgpu_bank* b, int proc_idx);
+int mlgpu_bank_num_state(mlgpu_bank* b, int proc_idx);
+
+/* T::clear() on every processor of every voice (Bank::clear, MLDSPFunctional.h:351-357):
+ * filters -> zero state, SineGen -> phase 0xC0000000 (MLDSPGens.h:375,379), etc.
+ * A freshly created bank is in the default-constructed state of the reference objects
+ * (all zero; ADSR segment = off) which differs from clear() only for SineGen. */
+int mlgpu_bank_clear(mlgpu_bank* b);
+
+/* `coeffs` member of the reference objects. Per-voice array of n_voices floats for one
+ * coefficient, or one value broadcast to all voices. */
+int mlgpu_bank_set_coeff(mlgpu_bank* b, int proc_idx, int coeff_idx, const float* h_per_voice);
+int mlgpu_bank_set_coeff_uniform(mlgpu_bank* b, int proc_idx, int coeff_idx, float value);
+
+/* Raw state access (checkpoint / resume; the reference's state is plain POD members). */
+int mlgpu_bank_get_state(mlgpu_bank* b, int proc_idx, int state_idx, uint32_t* h_per_voice);
+int mlgpu_bank_set_state(mlgpu_bank* b, int proc_idx, int state_idx, const uint32_t* h_per_voice);
+int mlgpu_bank_set_state_uniform(mlgpu_bank* b, int proc_idx, int state_idx, uint32_t value);
+
+/* Bank input when no signal is streamed: voice v's processor 0 sees DSPVector(h[v])
+ * (the implicit float->DSPVector broadcast, MLDSPOps.h:157), e.g. a per-voice freq. */
+int mlgpu_bank_set_input_const(mlgpu_bank* b, const float* h_per_voice);
+
+/* Process n_vectors DSPVectors for every voice.
+ *   d_in   input signal in `in_layout`, or NULL to use the per-voice input constant.
+ *   d_out  output signal in `out_layout` (64*n_vectors*n_voices floats).
+ * Replaces Bank::operator() (MLDSPFunctional.h:328-337) called n_vectors times.
+ * Chains that match a fused kernel run as ONE launch; other chains run processor by
+ * processor through the bank's HBM scratch signal (still on the GPU). */
+int mlgpu_bank_process(mlgpu_bank* b, size_t n_vectors, const float* d_in, int in_layout,
+                       float* d_out, int out_layout);
+/* 1 if the chain maps to a single fused kernel, 0 if it runs processor by processor. */
+int mlgpu_bank_is_fused(mlgpu_bank* b);
+/* Name of the device kernel that dominates mlgpu_bank_process (for profile lookup). */
+const char* mlgpu_bank_kernel_name(mlgpu_bank* b);
+
+/* ------------------------------------------------------------------------- */
+/* coefficient makers — host-side, glibc libm, formulas of the reference     */
+/* (kept on the host so device code never has to match libm: SURVEY App. A 11) */
+
+void mlgpu_lopass_make_coeffs(float omega, float k, float out3[3]);    /* MLDSPFilters.h:85-95 */
+void mlgpu_hipass_make_coeffs(float omega, float k, float out4[4]);    /* :168-178 */
+void mlgpu_bandpass_make_coeffs(float omega, float k, float out3[3]);  /* :212-222 */
+void mlgpu_loshelf_make_coeffs(float omega, float k, float A, float out5[5]); /* :270-281 */
+void mlgpu_hishelf_make_coeffs(float omega, float k, float A, float out6[6]); /* :350-362 */
+void mlgpu_bell_make_coeffs(float omega, float k, float A, float out4[4]);    /* :415-425 */
+void mlgpu_onepole_make_coeffs(float omega, float out2[2]);            /* :458-462 */
+float mlgpu_dcblocker_make_coeffs(float omega);                        /* :498 */
+void mlgpu_adsr_calc_coeffs(float a, float d, float s, float r, float sr, float out4[4]); /* :679-686 */
+float mlgpu_db_to_gain(float dB);                                      /* :30 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLGPU_H */

@@ -1,0 +1,1120 @@
+/*
+ * oracle/ml_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, scalar, CPU restatement of the madronalib mldsp.h hot path:
+ * the SSE elementwise math, the generators and the IIR filters, each function citing the
+ * reference file:line it follows (paths relative to /root/reference).
+ *
+ * Parity pinning: PINNED. tests/test_oracle_vs_ref.py checks every function here
+ * bit-for-bit against the compiled reference itself (oracle/_ref/libmlref.so, built from
+ * the reference headers by oracle/Makefile) when that library is present, and
+ * tests/test_oracle_golden.py checks it against the committed golden vectors in
+ * tests/golden/ (generated from the compiled reference by tests/golden/make_golden.py)
+ * plus the reference's own test assertions (Tests/dspOpsTest.cpp:103-104,154,164;
+ * Tests/dspGensTest.cpp:31).  Exceptions, by nature: sqrtApprox/divideApprox and the
+ * Peak/RMS outputs use x86 rcpps/rsqrtps (12-bit hardware tables) in the reference; here
+ * they are computed exactly and compared with a 2^-11 relative tolerance.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Build: gcc -std=c11 -O2 -ffp-contract=off (oracle/Makefile). x86-64 scalar float math
+ * is SSE scalar math, i.e. lane-for-lane the same IEEE single operations as the
+ * reference's 4-wide SSE2 code, provided the compiler never fuses mul+add (hence
+ * -ffp-contract=off and no -march=native).
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../include/mlgpu.h"
+
+#define VEC 64 /* kFloatsPerDSPVector, source/DSP/MLDSPMath.h:8-9 */
+
+/* ------------------------------------------------------------------------- */
+/* bit casts and SSE-semantics primitives (source/DSP/MLDSPMathSSE.h:73-135)  */
+
+static inline uint32_t f2u(float f)
+{
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+static inline float u2f(uint32_t u)
+{
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+/* _mm_min_ps / _mm_max_ps: (a<b)?a:b and (a>b)?a:b — returns b if either is NaN. */
+static inline float sse_min(float a, float b) { return (a < b) ? a : b; }
+static inline float sse_max(float a, float b) { return (a > b) ? a : b; }
+
+/* _mm_cvtps_epi32: round to nearest even; NaN / out of range -> 0x80000000. */
+static inline int32_t sse_cvt(float x)
+{
+  if (!(x < 2147483648.0f) || !(x >= -2147483648.0f)) return INT32_MIN;
+  return (int32_t)nearbyintf(x); /* default rounding mode = RNE, as MXCSR default */
+}
+/* _mm_cvttps_epi32: truncate; NaN / out of range -> 0x80000000. */
+static inline int32_t sse_cvtt(float x)
+{
+  if (!(x < 2147483648.0f) || !(x >= -2147483648.0f)) return INT32_MIN;
+  return (int32_t)x;
+}
+/* vecUnsignedIntToFloat, MLDSPMathSSE.h:130-135: drops the LSB on purpose. */
+static inline float uint_to_float(uint32_t v)
+{
+  float hi = (float)(int32_t)(v >> 1);
+  return hi + hi;
+}
+static inline float fabs_bits(float x) { return u2f(f2u(x) & 0x7FFFFFFFu); } /* vecAbs :86 */
+/* vecSign :88-90 */
+static inline float sign_ps(float x)
+{
+  uint32_t s = (f2u(x) & 0x80000000u) | 0x3F800000u;
+  int neq = !(x == -0.0f); /* cmpneq: true when unordered */
+  return u2f(neq ? s : 0u);
+}
+/* vecSignBit :92 */
+static inline float signbit_ps(float x) { return u2f((f2u(x) & 0x80000000u) | 0x3F800000u); }
+
+/* ------------------------------------------------------------------------- */
+/* precise transcendentals: cephes / Pommier, MLDSPMathSSE.h:292-636          */
+
+static float vec_log(float x) /* :308-373 */
+{
+  const int invalid = (x <= 0.0f);
+  x = sse_max(x, u2f(0x00800000u)); /* cut off denormalized stuff */
+  int32_t emm0 = (int32_t)(f2u(x) >> 23);
+  x = u2f((f2u(x) & ~0x7f800000u) | f2u(0.5f));
+  emm0 -= 0x7f;
+  float e = (float)emm0;
+  e = e + 1.0f;
+  const int mask = (x < 0.707106781186547524f);
+  float tmp = mask ? x : 0.0f;
+  x = x - 1.0f;
+  e = e - (mask ? 1.0f : 0.0f);
+  x = x + tmp;
+  float z = x * x;
+  float y = 7.0376836292E-2f;
+  y = y * x;
+  y = y + -1.1514610310E-1f;
+  y = y * x;
+  y = y + 1.1676998740E-1f;
+  y = y * x;
+  y = y + -1.2420140846E-1f;
+  y = y * x;
+  y = y + 1.4249322787E-1f;
+  y = y * x;
+  y = y + -1.6668057665E-1f;
+  y = y * x;
+  y = y + 2.0000714765E-1f;
+  y = y * x;
+  y = y + -2.4999993993E-1f;
+  y = y * x;
+  y = y + 3.3333331174E-1f;
+  y = y * x;
+  y = y * z;
+  tmp = e * -2.12194440e-4f;
+  y = y + tmp;
+  tmp = z * 0.5f;
+  y = y - tmp;
+  tmp = e * 0.693359375f;
+  x = x + y;
+  x = x + tmp;
+  if (invalid) return u2f(0xFFFFFFFFu); /* x | all-ones: negative arg will be NaN */
+  return x;
+}
+
+static float vec_exp(float x) /* :389-440 */
+{
+  x = sse_min(x, 88.3762626647949f);
+  x = sse_max(x, -88.3762626647949f);
+  float fx = x * 1.44269504088896341f;
+  fx = fx + 0.5f;
+  int32_t emm0 = sse_cvtt(fx);
+  float tmp = (float)emm0;
+  float mask = (tmp > fx) ? 1.0f : 0.0f;
+  fx = tmp - mask;
+  tmp = fx * 0.693359375f;
+  float z = fx * -2.12194440e-4f;
+  x = x - tmp;
+  x = x - z;
+  z = x * x;
+  float y = 1.9875691500E-4f;
+  y = y * x;
+  y = y + 1.3981999507E-3f;
+  y = y * x;
+  y = y + 8.3334519073E-3f;
+  y = y * x;
+  y = y + 4.1665795894E-2f;
+  y = y * x;
+  y = y + 1.6666665459E-1f;
+  y = y * x;
+  y = y + 5.0000001201E-1f;
+  y = y * z;
+  y = y + x;
+  y = y + 1.0f;
+  emm0 = sse_cvtt(fx);
+  emm0 = (int32_t)((uint32_t)emm0 + 0x7fu);
+  uint32_t p = (uint32_t)emm0 << 23;
+  return y * u2f(p);
+}
+
+/* shared tail of vecSin/vecCos: both polynomials evaluated, then masked (:520-557) */
+static inline float sincos_poly(float x, int poly_mask, uint32_t sign_bit)
+{
+  float z = x * x;
+  float y = 2.443315711809948E-005f;
+  y = y * z;
+  y = y + -1.388731625493765E-003f;
+  y = y * z;
+  y = y + 4.166664568298827E-002f;
+  y = y * z;
+  y = y * z;
+  float tmp = z * 0.5f;
+  y = y - tmp;
+  y = y + 1.0f;
+  float y2 = -1.9515295891E-4f;
+  y2 = y2 * z;
+  y2 = y2 + 8.3321608736E-3f;
+  y2 = y2 * z;
+  y2 = y2 + -1.6666654611E-1f;
+  y2 = y2 * z;
+  y2 = y2 * x;
+  y2 = y2 + x;
+  y2 = poly_mask ? y2 : 0.0f;  /* _mm_and_ps(mask, y2) */
+  y = poly_mask ? 0.0f : y;    /* _mm_andnot_ps(mask, y) */
+  y = y + y2;
+  return u2f(f2u(y) ^ sign_bit);
+}
+
+static float vec_sin(float x) /* :479-559 */
+{
+  uint32_t sign_bit = f2u(x) & 0x80000000u;
+  x = fabs_bits(x);
+  float y = x * 1.27323954473516f;
+  int32_t emm2 = sse_cvtt(y);
+  emm2 = (int32_t)(((uint32_t)emm2 + 1u) & ~1u);
+  y = (float)emm2;
+  uint32_t emm0 = ((uint32_t)emm2 & 4u) << 29;
+  int poly_mask = (((uint32_t)emm2 & 2u) == 0u);
+  sign_bit ^= emm0;
+  float xmm1 = y * -0.78515625f;
+  float xmm2 = y * -2.4187564849853515625e-4f;
+  float xmm3 = y * -3.77489497744594108e-8f;
+  x = x + xmm1;
+  x = x + xmm2;
+  x = x + xmm3;
+  return sincos_poly(x, poly_mask, sign_bit);
+}
+
+static float vec_cos(float x) /* :562-636 */
+{
+  x = fabs_bits(x);
+  float y = x * 1.27323954473516f;
+  int32_t emm2 = sse_cvtt(y);
+  emm2 = (int32_t)(((uint32_t)emm2 + 1u) & ~1u);
+  y = (float)emm2;
+  emm2 = (int32_t)((uint32_t)emm2 - 2u);
+  uint32_t emm0 = (~(uint32_t)emm2 & 4u) << 29;
+  int poly_mask = (((uint32_t)emm2 & 2u) == 0u);
+  float xmm1 = y * -0.78515625f;
+  float xmm2 = y * -2.4187564849853515625e-4f;
+  float xmm3 = y * -3.77489497744594108e-8f;
+  x = x + xmm1;
+  x = x + xmm2;
+  x = x + xmm3;
+  return sincos_poly(x, poly_mask, emm0);
+}
+
+/* ------------------------------------------------------------------------- */
+/* approximate transcendentals, MLDSPMathSSE.h:752-864                        */
+
+static float vec_sin_approx(float x) /* :752-772 */
+{
+  float x2 = x * x;
+  return x * (0.99997937679290771484375f +
+              x2 * (-0.166624367237091064453125f +
+                    x2 * (8.30897875130176544189453125e-3f +
+                          x2 * (-1.92649182281456887722015380859375e-4f +
+                                x2 * 2.147840177713078446686267852783203125e-6f))));
+}
+static float vec_cos_approx(float x) /* :774-792 */
+{
+  float x2 = x * x;
+  return 0.999959766864776611328125f +
+         x2 * (-0.4997930824756622314453125f +
+               x2 * (4.1496001183986663818359375e-2f +
+                     x2 * (-1.33926304988563060760498046875e-3f +
+                           x2 * 1.8791708498611114919185638427734375e-5f)));
+}
+static float vec_exp_approx(float x) /* :793-829 */
+{
+  float val2 = x * 12102203.1615614f + 1065353216.f;
+  float val3 = sse_min(val2, 2139095040.f);
+  float val4 = sse_max(val3, 0.0f);
+  uint32_t val4i = (uint32_t)sse_cvtt(val4);
+  float xu = u2f(val4i & 0x7F800000u);
+  float b = u2f((val4i & 0x7FFFFFu) | 0x3F800000u);
+  return xu * (0.510397365625862338668154f +
+               b * (0.310670891004095530771135f +
+                    b * (0.168143436463395944830000f +
+                         b * (-2.88093587581985443087955e-3f +
+                              b * 1.3671023382430374383648148e-2f))));
+}
+static float vec_log_approx(float val) /* :831-864 */
+{
+  uint32_t vi = f2u(val);
+  int32_t expi = (int32_t)(vi >> 23);
+  float addcst = (val > 0.0f) ? -89.970756366f : FLT_MIN;
+  float x = u2f((vi & 0x7FFFFFu) | 0x3F800000u);
+  float poly = x * (3.529304993f +
+                    x * (-2.461222105f +
+                         x * (1.130626167f + x * (-0.288739945f + x * 3.110401639e-2f))));
+  float addCstResult = addcst + 0.69314718055995f * (float)expi;
+  return poly + addCstResult;
+}
+
+#define K_LOG_TWO 0.69314718055994529f   /* MLDSPOps.h:601 */
+#define K_LOG_TWO_R 1.4426950408889634f  /* MLDSPOps.h:602 */
+
+/* ------------------------------------------------------------------------- */
+/* elementwise op dispatch, MLDSPOps.h:570-917                                */
+
+static uint32_t op_scalar(int op, uint32_t ua, uint32_t ub, uint32_t uc, int* ok)
+{
+  const float a = u2f(ua), b = u2f(ub), c = u2f(uc);
+  *ok = 1;
+  switch (op)
+  {
+    case MLGPU_OP_SQRT: return f2u(sqrtf(a));                      /* :584 */
+    case MLGPU_OP_SQRT_APPROX: return f2u(a * (1.0f / sqrtf(a)));  /* :585 x*rsqrtps(x): 2^-11 */
+    case MLGPU_OP_ABS: return f2u(fabs_bits(a));                   /* :586 */
+    case MLGPU_OP_SIGN: return f2u(sign_ps(a));                    /* :589 */
+    case MLGPU_OP_SIGN_BIT: return f2u(signbit_ps(a));             /* :592 */
+    case MLGPU_OP_SIN: return f2u(vec_sin(a));                     /* :595 */
+    case MLGPU_OP_COS: return f2u(vec_cos(a));
+    case MLGPU_OP_LOG: return f2u(vec_log(a));
+    case MLGPU_OP_EXP: return f2u(vec_exp(a));
+    case MLGPU_OP_LOG2: return f2u(vec_log(a) * K_LOG_TWO_R);      /* :603 */
+    case MLGPU_OP_EXP2: return f2u(vec_exp(K_LOG_TWO * a));        /* :604 */
+    case MLGPU_OP_SIN_APPROX: return f2u(vec_sin_approx(a));       /* :607 */
+    case MLGPU_OP_COS_APPROX: return f2u(vec_cos_approx(a));
+    case MLGPU_OP_EXP_APPROX: return f2u(vec_exp_approx(a));
+    case MLGPU_OP_LOG_APPROX: return f2u(vec_log_approx(a));
+    case MLGPU_OP_LOG2_APPROX: return f2u(vec_log_approx(a) * K_LOG_TWO_R); /* :613 */
+    case MLGPU_OP_EXP2_APPROX: return f2u(vec_exp_approx(K_LOG_TWO * a));   /* :614 */
+    case MLGPU_OP_FRACTIONAL_PART: return f2u(a - (float)sse_cvtt(a));      /* :825 */
+    case MLGPU_OP_ROUND_FLOAT_TO_INT: return (uint32_t)sse_cvt(a);          /* :796 */
+    case MLGPU_OP_TRUNCATE_FLOAT_TO_INT: return (uint32_t)sse_cvtt(a);      /* :797 */
+    case MLGPU_OP_INT_TO_FLOAT: return f2u((float)(int32_t)ua);             /* :819 */
+    case MLGPU_OP_UNSIGNED_INT_TO_FLOAT: return f2u(uint_to_float(ua));     /* :820 */
+    case MLGPU_OP_EXP_APPROX_OF_SIN_APPROX: return f2u(vec_exp_approx(vec_sin_approx(a)));
+    case MLGPU_OP_ADD: return f2u(a + b);                          /* :640-643 */
+    case MLGPU_OP_SUBTRACT: return f2u(a - b);
+    case MLGPU_OP_MULTIPLY: return f2u(a * b);
+    case MLGPU_OP_DIVIDE: return f2u(a / b);
+    case MLGPU_OP_DIVIDE_APPROX: return f2u(a * (1.0f / b));       /* :645 a*rcpps(b): 2^-11 */
+    case MLGPU_OP_POW: return f2u(vec_exp(vec_log(a) * b));        /* :646 */
+    case MLGPU_OP_POW_APPROX: return f2u(vec_exp_approx(vec_log_approx(a) * b)); /* :647 */
+    case MLGPU_OP_MIN: return f2u(sse_min(a, b));                  /* :648 */
+    case MLGPU_OP_MAX: return f2u(sse_max(a, b));                  /* :649 */
+    case MLGPU_OP_ADD_INT32: return ua + ub;                       /* :714 */
+    case MLGPU_OP_SUBTRACT_INT32: return ua - ub;                  /* :713 */
+    case MLGPU_OP_EQUAL: return (a == b) ? 0xFFFFFFFFu : 0u;       /* :851-856 */
+    case MLGPU_OP_NOT_EQUAL: return (a != b) ? 0xFFFFFFFFu : 0u;
+    case MLGPU_OP_GREATER_THAN: return (a > b) ? 0xFFFFFFFFu : 0u;
+    case MLGPU_OP_GREATER_THAN_OR_EQUAL: return (a >= b) ? 0xFFFFFFFFu : 0u;
+    case MLGPU_OP_LESS_THAN: return (a < b) ? 0xFFFFFFFFu : 0u;
+    case MLGPU_OP_LESS_THAN_OR_EQUAL: return (a <= b) ? 0xFFFFFFFFu : 0u;
+    case MLGPU_OP_LERP: return f2u(a + (c * (b - a)));             /* :744 */
+    case MLGPU_OP_INVERSE_LERP: return f2u((c - a) / (b - a));     /* :745 */
+    case MLGPU_OP_CLAMP: return f2u(sse_min(sse_max(a, b), c));    /* :747 */
+    case MLGPU_OP_WITHIN: return ((a >= b) && (a < c)) ? 0xFFFFFFFFu : 0u; /* :748 */
+    case MLGPU_OP_SELECT:                                          /* :886 */
+    case MLGPU_OP_SELECT_INT: return (uc & ua) | (~uc & ub);       /* :917 */
+    default: *ok = 0; return 0;
+  }
+}
+
+int mlorc_op_apply(int op, const void* va, const void* vb, const void* vc, void* vout, size_t n)
+{
+  const uint32_t* a = (const uint32_t*)va;
+  const uint32_t* b = (const uint32_t*)vb;
+  const uint32_t* c = (const uint32_t*)vc;
+  uint32_t* out = (uint32_t*)vout;
+  int ok = 1;
+  for (size_t i = 0; i < n; ++i)
+  {
+    out[i] = op_scalar(op, a ? a[i] : 0, b ? b[i] : 0, c ? c[i] : 0, &ok);
+    if (!ok) return MLGPU_ERR_INVALID;
+  }
+  return MLGPU_OK;
+}
+
+/* add1..max1: second operand is one row, repeated (MLDSPOps.h:655-687) */
+int mlorc_op_apply_rows1(int op, const float* a, const float* b64, float* out, size_t n_rows)
+{
+  int ok = 1;
+  for (size_t r = 0; r < n_rows; ++r)
+    for (int i = 0; i < VEC; ++i)
+    {
+      out[r * VEC + i] = u2f(op_scalar(op, f2u(a[r * VEC + i]), f2u(b64[i]), 0, &ok));
+      if (!ok) return MLGPU_ERR_INVALID;
+    }
+  return MLGPU_OK;
+}
+
+/* horizontal ops, MLDSPOps.h:995-1035 with vecSumH/MaxH/MinH (MLDSPMathSSE.h:246-265):
+ * per 4-group (x0 op x2) op (x1 op x3), then sequentially over the 16 groups. */
+int mlorc_row_reduce(int rowop, const float* rows, float* out, size_t n_rows)
+{
+  for (size_t r = 0; r < n_rows; ++r)
+  {
+    const float* x = rows + r * VEC;
+    float acc;
+    switch (rowop)
+    {
+      case MLGPU_ROWOP_SUM:
+      case MLGPU_ROWOP_MEAN:
+        acc = 0.f;
+        for (int g = 0; g < 16; ++g)
+        {
+          const float* q = x + 4 * g;
+          float t0 = q[0] + q[2], t1 = q[1] + q[3];
+          acc += (t0 + t1);
+        }
+        out[r] = (rowop == MLGPU_ROWOP_MEAN) ? acc * (1.0f / VEC) : acc; /* :1007-1011 */
+        break;
+      case MLGPU_ROWOP_MAX:
+        acc = FLT_MIN; /* sic: smallest positive normal, MLDSPOps.h:1016 */
+        for (int g = 0; g < 16; ++g)
+        {
+          const float* q = x + 4 * g;
+          float t0 = sse_max(q[0], q[2]), t1 = sse_max(q[1], q[3]);
+          float h = sse_max(t0, t1);
+          acc = (acc > h) ? acc : h; /* ml::max scalar, MLDSPScalarMath.h: (a > b) ? a : b */
+        }
+        out[r] = acc;
+        break;
+      case MLGPU_ROWOP_MIN:
+        acc = FLT_MAX;
+        for (int g = 0; g < 16; ++g)
+        {
+          const float* q = x + 4 * g;
+          float t0 = sse_min(q[0], q[2]), t1 = sse_min(q[1], q[3]);
+          float h = sse_min(t0, t1);
+          acc = (acc < h) ? acc : h;
+        }
+        out[r] = acc;
+        break;
+      default: return MLGPU_ERR_INVALID;
+    }
+  }
+  return MLGPU_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* generators, source/DSP/MLDSPGens.h                                         */
+
+/* constants of phasorToSine (:316-338). const_math::sqrt(2.0f) is itself an
+ * approximation: the reference's sqrt2 is 0x3fb50505, not the correctly rounded
+ * 0x3fb504f3; all five constants below are the reference's constexpr results. */
+#define K_SQRT2 0x3fb50505u
+#define K_SINE_DOMAIN 0x40b50505u /* sqrt2 * 4 */
+#define K_SINE_SCALE 0x3f87c3b6u  /* 1 / (sqrt2 - sqrt2^3/6) */
+#define K_SINE_FLIP 0x40350505u   /* sqrt2 * 2 */
+#define K_ONE_SIXTH 0x3e2aaaabu
+
+#define K_STEPS_PER_CYCLE 4294967296.0f            /* :184 2^32 */
+#define K_CYCLES_PER_STEP 2.3283064365386963e-10f  /* :185 2^-32 */
+
+/* PhasorGen::operator(), :187-203 */
+static void phasor64(uint32_t* omega32, const float* cps, float* out)
+{
+  for (int n = 0; n < VEC; ++n)
+  {
+    float steps = cps[n] * K_STEPS_PER_CYCLE;
+    int32_t istep = sse_cvt(steps); /* roundFloatToInt */
+    *omega32 += (uint32_t)istep;
+    out[n] = uint_to_float(*omega32) * K_CYCLES_PER_STEP;
+  }
+}
+
+/* polyBLEP, :285-311 */
+static inline float poly_blep(float t, float dt)
+{
+  float c = 0.f;
+  if (t < dt)
+  {
+    t = t / dt;
+    c = t + t - t * t - 1.0f;
+  }
+  else if (t > 1.0f - dt)
+  {
+    t = (t - 1.0f) / dt;
+    c = t * t + t + t + 1.0f;
+  }
+  return c;
+}
+
+/* phasorToSine, :316-338 */
+static inline float phasor_to_sine(float p)
+{
+  const float sqrt2 = u2f(K_SQRT2);
+  float omega = p * u2f(K_SINE_DOMAIN) + (-sqrt2);
+  float tri = (omega > sqrt2) ? (u2f(K_SINE_FLIP) - omega) : omega;
+  /* scaleV * triangleV * (oneV - triangleV * triangleV * oneSixthV): left-assoc */
+  return (u2f(K_SINE_SCALE) * tri) * (1.0f - (tri * tri) * u2f(K_ONE_SIXTH));
+}
+/* phasorToSaw, :362-369 */
+static inline float phasor_to_saw(float p, float freq)
+{
+  float saw = p * 2.f - 1.f;
+  return saw - poly_blep(p, freq);
+}
+/* phasorToPulse, :342-358 */
+static inline float phasor_to_pulse(float p, float freq, float width)
+{
+  float pulse = (p >= width) ? -1.f : 1.f; /* select(-1, 1, omega >= width) */
+  pulse = pulse + poly_blep(p, freq);
+  float d = p - width + 1.0f;
+  float down = d - (float)sse_cvtt(d); /* fractionalPart */
+  pulse = pulse - poly_blep(down, freq);
+  return pulse;
+}
+
+/* NoiseGen::operator(), :135-145 */
+static void noise64(uint32_t* seed, float* out)
+{
+  for (int i = 0; i < VEC; ++i)
+  {
+    *seed = *seed * 0x0019660Du + 0x3C6EF35Fu;
+    uint32_t temp = ((*seed >> 9) & 0x007FFFFFu) | 0x3F800000u;
+    out[i] = u2f(temp) * 2.f - 3.f;
+  }
+}
+
+/* TickGen::operator(), :29-46 */
+static void tick64(float* omega, const float* cps, float* out)
+{
+  for (int n = 0; n < VEC; ++n)
+  {
+    out[n] = 0.f;
+    *omega += cps[n];
+    if (*omega > 1.0f)
+    {
+      *omega -= 1.0f;
+      out[n] = 1.0f;
+    }
+  }
+}
+
+/* ImpulseGen table, :65-78 with makeWindow (MLDSPUtils.h:22-26), dspwindows::blackman
+ * (:34-35), projections::linear (MLDSPProjections.h:147-167), normalize (MLDSPOps.h:1041). */
+#define IMPULSE_TABLE_SIZE 17
+static float g_impulse_table[VEC];
+static int g_impulse_table_ready = 0;
+static const float kTwoPiF = 6.2831853071795864769252867f; /* MLDSPScalarMath.h:23 */
+static const float kPiF = 3.1415926535897932384626433f;    /* :24 */
+
+static void build_impulse_table(void)
+{
+  float window[VEC], sinc[VEC], prod[VEC];
+  memset(window, 0, sizeof(window));
+  for (int i = 0; i < IMPULSE_TABLE_SIZE; ++i)
+  {
+    /* linear({0, size-1}, {0, 1}): m = (b2-b1)/(a2-a1); m*(x-a1)+b1 */
+    float m = (1.f - 0.f) / ((IMPULSE_TABLE_SIZE - 1.f) - 0.f);
+    float x = m * ((float)i - 0.f) + 0.f;
+    window[i] = 0.42f - 0.5f * cosf(kTwoPiF * x) + 0.08f * cosf(2.f * kTwoPiF * x);
+  }
+  const float omega = 0.25f;
+  for (int n = 0; n < VEC; ++n)
+  {
+    int i = n - (IMPULSE_TABLE_SIZE - 1) / 2;
+    float pi_x = kTwoPiF * omega * i;
+    sinc[n] = (i == 0) ? 1.f : sinf(pi_x) / pi_x;
+  }
+  for (int n = 0; n < VEC; ++n) prod[n] = sinc[n] * window[n];
+  float s;
+  mlorc_row_reduce(MLGPU_ROWOP_SUM, prod, &s, 1);
+  for (int n = 0; n < VEC; ++n) g_impulse_table[n] = prod[n] / s;
+  g_impulse_table_ready = 1;
+}
+void mlorc_impulse_table(float* out17)
+{
+  if (!g_impulse_table_ready) build_impulse_table();
+  memcpy(out17, g_impulse_table, IMPULSE_TABLE_SIZE * sizeof(float));
+}
+
+/* ImpulseGen::operator(), :81-103 */
+static void impulse64(float* omega, int32_t* counter, const float* cps, float* out)
+{
+  if (!g_impulse_table_ready) build_impulse_table();
+  for (int n = 0; n < VEC; ++n)
+  {
+    out[n] = 0.f;
+    *omega += cps[n];
+    if (*omega > 1.0f)
+    {
+      *omega -= 1.0f;
+      *counter = 0;
+    }
+    if (*counter < IMPULSE_TABLE_SIZE)
+    {
+      out[n] = g_impulse_table[*counter];
+      (*counter)++;
+    }
+  }
+}
+
+/* OneShotGen::operator(), :238-258 */
+static void oneshot64(uint32_t* omega32, uint32_t* gate, uint32_t* prev, const float* cps,
+                      float* out)
+{
+  for (int n = 0; n < VEC; ++n)
+  {
+    float steps = cps[n] * K_STEPS_PER_CYCLE;
+    int32_t istep = sse_cvt(steps);
+    *omega32 += (uint32_t)istep * *gate;
+    if (*omega32 < *prev)
+    {
+      *gate = 0;
+      *omega32 = 0;
+    }
+    *prev = *omega32;
+    out[n] = uint_to_float(*omega32) * K_CYCLES_PER_STEP;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* filters, source/DSP/MLDSPFilters.h                                         */
+
+/* Lopass :118-133, Hipass :180-196, Bandpass :224-239 share the core */
+static void svf64(int kind, const float* C, float* ic1, float* ic2, const float* in, float* out)
+{
+  const float g0 = C[0], g1 = C[1], g2 = C[2];
+  for (int n = 0; n < VEC; ++n)
+  {
+    float v0 = in[n];
+    float t0 = v0 - *ic2;
+    float t1 = g0 * t0 + g1 * *ic1;
+    float t2 = g2 * t0 + g0 * *ic1;
+    float v1 = t1 + *ic1;
+    float v2 = t2 + *ic2;
+    *ic1 += 2.0f * t1;
+    *ic2 += 2.0f * t2;
+    if (kind == MLGPU_PROC_LOPASS)
+      out[n] = v2;
+    else if (kind == MLGPU_PROC_BANDPASS)
+      out[n] = v1;
+    else
+      out[n] = v0 - C[3] * v1 - v2; /* Hipass, k = C[3] */
+  }
+}
+
+/* LoShelf :288-302, HiShelf :369-383, Bell :427-441 share the core */
+static void shelf64(int kind, const float* C, float* ic1, float* ic2, const float* in, float* out)
+{
+  const float a1 = C[0], a2 = C[1], a3 = C[2];
+  for (int n = 0; n < VEC; ++n)
+  {
+    float v0 = in[n];
+    float v3 = v0 - *ic2;
+    float v1 = a1 * *ic1 + a2 * v3;
+    float v2 = *ic2 + a2 * *ic1 + a3 * v3;
+    *ic1 = 2 * v1 - *ic1;
+    *ic2 = 2 * v2 - *ic2;
+    if (kind == MLGPU_PROC_LO_SHELF)
+      out[n] = v0 + C[3] * v1 + C[4] * v2; /* m1, m2 */
+    else if (kind == MLGPU_PROC_HI_SHELF)
+      out[n] = C[3] * v0 + C[4] * v1 + C[5] * v2; /* m0, m1, m2 */
+    else
+      out[n] = v0 + C[3] * v1; /* Bell, m1 */
+  }
+}
+
+/* OnePole :466-475 */
+static void onepole64(const float* C, float* y1, const float* in, float* out)
+{
+  for (int n = 0; n < VEC; ++n)
+  {
+    *y1 = C[0] * in[n] + C[1] * *y1;
+    out[n] = *y1;
+  }
+}
+/* DCBlocker :500-512 */
+static void dcblock64(const float* C, float* x1, float* y1, const float* in, float* out)
+{
+  for (int n = 0; n < VEC; ++n)
+  {
+    const float x0 = in[n];
+    const float y0 = x0 - *x1 + C[0] * *y1;
+    *y1 = y0;
+    *x1 = x0;
+    out[n] = y0;
+  }
+}
+/* Differentiator :522-534 */
+static void diff64(float* x1, const float* in, float* out)
+{
+  out[0] = in[0] - *x1;
+  for (int n = 1; n < VEC; ++n) out[n] = in[n] - in[n - 1];
+  *x1 = in[VEC - 1];
+}
+/* Integrator :547-557 */
+static void integ64(const float* C, float* y1, const float* in, float* out)
+{
+  for (int n = 0; n < VEC; ++n)
+  {
+    *y1 -= *y1 * C[0];
+    *y1 += in[n];
+    out[n] = *y1;
+  }
+}
+/* Peak :582-614 (sqrtApprox computed exactly here: 2^-11 tolerance vs rsqrtps) */
+static void peak64(const float* C, float* y1, int32_t* counter, const float* in, float* out)
+{
+  const int32_t hold = (int32_t)f2u(C[2]);
+  float vy[VEC];
+  for (int n = 0; n < VEC; ++n)
+  {
+    float xsq = in[n] * in[n];
+    if (xsq > *y1)
+    {
+      *y1 = xsq;
+      *counter = hold;
+    }
+    else if (*counter <= 0)
+    {
+      *y1 = C[0] * xsq + C[1] * *y1;
+    }
+    vy[n] = *y1;
+  }
+  if (*counter > 0) *counter -= VEC;
+  for (int n = 0; n < VEC; ++n) out[n] = (vy[n] > 1e-20f) ? vy[n] * (1.0f / sqrtf(vy[n])) : 0.f;
+}
+/* RMS :637-652 */
+static void rms64(const float* C, float* y1, const float* in, float* out)
+{
+  for (int n = 0; n < VEC; ++n)
+  {
+    float xsq = in[n] * in[n];
+    *y1 = C[0] * xsq + C[1] * *y1;
+    out[n] = (*y1 > 1e-20f) ? *y1 * (1.0f / sqrtf(*y1)) : 0.f;
+  }
+}
+
+/* ADSR::processSample :704-786 ; state words: y,y1,x1,threshold,target,k,amp,segment */
+enum { ADSR_A = 0, ADSR_D = 1, ADSR_S = 2, ADSR_R = 3, ADSR_OFF = 4 };
+static float adsr_sample(const float* C, uint32_t* S, float x)
+{
+  float y = u2f(S[0]), y1 = u2f(S[1]), x1 = u2f(S[2]), threshold = u2f(S[3]);
+  float target = u2f(S[4]), k = u2f(S[5]), amp = u2f(S[6]);
+  int32_t segment = (int32_t)S[7];
+  const float bias = 0.1f;
+
+  if ((segment == ADSR_OFF) && (x == 0.f)) return 0.f;
+
+  int crossed = ((y1 > threshold) != (y > threshold));
+  int recalc = 0;
+  if (crossed && (segment < ADSR_OFF))
+  {
+    segment++;
+    recalc = 1;
+  }
+  int trigOn = (x1 == 0.f) && (x > 0.f);
+  int trigOff = (x1 > 0.f) && (x == 0.f);
+  if (trigOn)
+  {
+    segment = ADSR_A;
+    amp = x;
+    recalc = 1;
+  }
+  else if (trigOff)
+  {
+    segment = ADSR_R;
+    recalc = 1;
+  }
+  if (recalc)
+  {
+    float startEnv = 0.f, endEnv = 0.f;
+    switch (segment)
+    {
+      case ADSR_A: startEnv = 0.f; endEnv = 1.f; k = C[0]; break;
+      case ADSR_D: startEnv = 1.f; endEnv = C[2]; k = C[1]; break;
+      case ADSR_S: startEnv = C[2]; endEnv = C[2]; k = 0.f; y1 = C[2]; y = C[2]; break;
+      case ADSR_R: startEnv = C[2]; endEnv = 0.f; k = C[3]; break;
+      case ADSR_OFF: startEnv = 0.f; endEnv = 0.f; k = 0.f; y1 = 0.f; y = 0.f; break;
+    }
+    float segmentBias = (endEnv - startEnv) * bias;
+    threshold = endEnv;
+    target = endEnv + segmentBias;
+  }
+  x1 = x;
+  y1 = y;
+  y = y + k * (target - y);
+  S[0] = f2u(y); S[1] = f2u(y1); S[2] = f2u(x1); S[3] = f2u(threshold);
+  S[4] = f2u(target); S[5] = f2u(k); S[6] = f2u(amp); S[7] = (uint32_t)segment;
+  return y * amp;
+}
+
+/* ------------------------------------------------------------------------- */
+/* chains of processors                                                      */
+
+int mlorc_proc_num_coeffs(int kind)
+{
+  switch (kind)
+  {
+    case MLGPU_PROC_PHASOR_GEN: case MLGPU_PROC_SINE_GEN: case MLGPU_PROC_SAW_GEN:
+    case MLGPU_PROC_NOISE_GEN: case MLGPU_PROC_TICK_GEN: case MLGPU_PROC_IMPULSE_GEN:
+    case MLGPU_PROC_ONE_SHOT_GEN: case MLGPU_PROC_DIFFERENTIATOR: return 0;
+    case MLGPU_PROC_PULSE_GEN: case MLGPU_PROC_DC_BLOCKER: case MLGPU_PROC_INTEGRATOR:
+    case MLGPU_PROC_GAIN: return 1;
+    case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_RMS: return 2;
+    case MLGPU_PROC_LOPASS: case MLGPU_PROC_BANDPASS: case MLGPU_PROC_PEAK: return 3;
+    case MLGPU_PROC_HIPASS: case MLGPU_PROC_BELL: case MLGPU_PROC_ADSR: return 4;
+    case MLGPU_PROC_LO_SHELF: return 5;
+    case MLGPU_PROC_HI_SHELF: return 6;
+    default: return -1;
+  }
+}
+int mlorc_proc_num_state(int kind)
+{
+  switch (kind)
+  {
+    case MLGPU_PROC_GAIN: return 0;
+    case MLGPU_PROC_PHASOR_GEN: case MLGPU_PROC_SINE_GEN: case MLGPU_PROC_SAW_GEN:
+    case MLGPU_PROC_PULSE_GEN: case MLGPU_PROC_NOISE_GEN: case MLGPU_PROC_TICK_GEN:
+    case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_DIFFERENTIATOR: case MLGPU_PROC_INTEGRATOR:
+    case MLGPU_PROC_RMS: return 1;
+    case MLGPU_PROC_IMPULSE_GEN: case MLGPU_PROC_LOPASS: case MLGPU_PROC_HIPASS:
+    case MLGPU_PROC_BANDPASS: case MLGPU_PROC_LO_SHELF: case MLGPU_PROC_HI_SHELF:
+    case MLGPU_PROC_BELL: case MLGPU_PROC_DC_BLOCKER: case MLGPU_PROC_PEAK: return 2;
+    case MLGPU_PROC_ONE_SHOT_GEN: return 3;
+    case MLGPU_PROC_ADSR: return 8;
+    default: return -1;
+  }
+}
+
+/* state after T::clear() (and after default construction, which differs for SineGen and ADSR) */
+static void proc_state_init(int kind, uint32_t* S, int cleared)
+{
+  int ns = mlorc_proc_num_state(kind);
+  for (int i = 0; i < ns; ++i) S[i] = 0;
+  if (kind == MLGPU_PROC_SINE_GEN && cleared) S[0] = 0xC0000000u; /* kZeroPhase, MLDSPGens.h:375 */
+  if (kind == MLGPU_PROC_ADSR) S[7] = ADSR_OFF;                   /* MLDSPFilters.h:700,702 */
+}
+
+int mlorc_chain_clear(const int32_t* procs, int n_procs, size_t V, uint32_t* state)
+{
+  int s = 0;
+  uint32_t sbuf[16];
+  for (int p = 0; p < n_procs; ++p)
+  {
+    int ns = mlorc_proc_num_state(procs[p]);
+    if (ns < 0) return MLGPU_ERR_INVALID;
+    proc_state_init(procs[p], sbuf, 1);
+    for (int i = 0; i < ns; ++i)
+      for (size_t v = 0; v < V; ++v) state[(size_t)(s + i) * V + v] = sbuf[i];
+    s += ns;
+  }
+  return MLGPU_OK;
+}
+int mlorc_chain_default_state(const int32_t* procs, int n_procs, size_t V, uint32_t* state)
+{
+  int s = 0;
+  uint32_t sbuf[16];
+  for (int p = 0; p < n_procs; ++p)
+  {
+    int ns = mlorc_proc_num_state(procs[p]);
+    if (ns < 0) return MLGPU_ERR_INVALID;
+    proc_state_init(procs[p], sbuf, 0);
+    for (int i = 0; i < ns; ++i)
+      for (size_t v = 0; v < V; ++v) state[(size_t)(s + i) * V + v] = sbuf[i];
+    s += ns;
+  }
+  return MLGPU_OK;
+}
+
+static void proc_process64(int kind, const float* C, uint32_t* S, const float* in, float* out)
+{
+  float f0, f1;
+  switch (kind)
+  {
+    case MLGPU_PROC_PHASOR_GEN: phasor64(&S[0], in, out); break;
+    case MLGPU_PROC_SINE_GEN: /* :380 */
+      phasor64(&S[0], in, out);
+      for (int n = 0; n < VEC; ++n) out[n] = phasor_to_sine(out[n]);
+      break;
+    case MLGPU_PROC_SAW_GEN: /* :401 */
+    {
+      float ph[VEC];
+      phasor64(&S[0], in, ph);
+      for (int n = 0; n < VEC; ++n) out[n] = phasor_to_saw(ph[n], in[n]);
+      break;
+    }
+    case MLGPU_PROC_PULSE_GEN: /* :390-393 */
+    {
+      float ph[VEC];
+      phasor64(&S[0], in, ph);
+      for (int n = 0; n < VEC; ++n) out[n] = phasor_to_pulse(ph[n], in[n], C[0]);
+      break;
+    }
+    case MLGPU_PROC_NOISE_GEN: noise64(&S[0], out); break;
+    case MLGPU_PROC_TICK_GEN:
+      f0 = u2f(S[0]);
+      tick64(&f0, in, out);
+      S[0] = f2u(f0);
+      break;
+    case MLGPU_PROC_IMPULSE_GEN:
+      f0 = u2f(S[0]);
+      impulse64(&f0, (int32_t*)&S[1], in, out);
+      S[0] = f2u(f0);
+      break;
+    case MLGPU_PROC_ONE_SHOT_GEN: oneshot64(&S[0], &S[1], &S[2], in, out); break;
+    case MLGPU_PROC_LOPASS: case MLGPU_PROC_HIPASS: case MLGPU_PROC_BANDPASS:
+      f0 = u2f(S[0]); f1 = u2f(S[1]);
+      svf64(kind, C, &f0, &f1, in, out);
+      S[0] = f2u(f0); S[1] = f2u(f1);
+      break;
+    case MLGPU_PROC_LO_SHELF: case MLGPU_PROC_HI_SHELF: case MLGPU_PROC_BELL:
+      f0 = u2f(S[0]); f1 = u2f(S[1]);
+      shelf64(kind, C, &f0, &f1, in, out);
+      S[0] = f2u(f0); S[1] = f2u(f1);
+      break;
+    case MLGPU_PROC_ONE_POLE:
+      f0 = u2f(S[0]);
+      onepole64(C, &f0, in, out);
+      S[0] = f2u(f0);
+      break;
+    case MLGPU_PROC_DC_BLOCKER:
+      f0 = u2f(S[0]); f1 = u2f(S[1]);
+      dcblock64(C, &f0, &f1, in, out);
+      S[0] = f2u(f0); S[1] = f2u(f1);
+      break;
+    case MLGPU_PROC_DIFFERENTIATOR:
+      f0 = u2f(S[0]);
+      diff64(&f0, in, out);
+      S[0] = f2u(f0);
+      break;
+    case MLGPU_PROC_INTEGRATOR:
+      f0 = u2f(S[0]);
+      integ64(C, &f0, in, out);
+      S[0] = f2u(f0);
+      break;
+    case MLGPU_PROC_PEAK:
+      f0 = u2f(S[0]);
+      peak64(C, &f0, (int32_t*)&S[1], in, out);
+      S[0] = f2u(f0);
+      break;
+    case MLGPU_PROC_RMS:
+      f0 = u2f(S[0]);
+      rms64(C, &f0, in, out);
+      S[0] = f2u(f0);
+      break;
+    case MLGPU_PROC_ADSR:
+      for (int n = 0; n < VEC; ++n) out[n] = adsr_sample(C, S, in[n]);
+      break;
+    case MLGPU_PROC_GAIN: /* x * DSPVector(gain), MLDSPOps.h:157,345-348 */
+      for (int n = 0; n < VEC; ++n) out[n] = in[n] * C[0];
+      break;
+    default: break;
+  }
+}
+
+typedef struct
+{
+  const int32_t* procs;
+  int n_procs;
+  size_t V, T, v0, v1;
+  const float* coeffs;
+  uint32_t* state;
+  const float* in_signal;
+  const float* in_const;
+  float* out;
+} chain_job;
+
+static void* chain_worker(void* arg)
+{
+  chain_job* j = (chain_job*)arg;
+  int cOff[64], sOff[64], c = 0, s = 0;
+  for (int p = 0; p < j->n_procs; ++p)
+  {
+    cOff[p] = c;
+    sOff[p] = s;
+    c += mlorc_proc_num_coeffs(j->procs[p]);
+    s += mlorc_proc_num_state(j->procs[p]);
+  }
+  const size_t S = j->T * VEC;
+  float C[64][8];
+  uint32_t St[64][8];
+  for (size_t v = j->v0; v < j->v1; ++v)
+  {
+    for (int p = 0; p < j->n_procs; ++p)
+    {
+      int nc = mlorc_proc_num_coeffs(j->procs[p]), ns = mlorc_proc_num_state(j->procs[p]);
+      for (int i = 0; i < nc; ++i) C[p][i] = j->coeffs[(size_t)(cOff[p] + i) * j->V + v];
+      for (int i = 0; i < ns; ++i) St[p][i] = j->state[(size_t)(sOff[p] + i) * j->V + v];
+    }
+    for (size_t t = 0; t < j->T; ++t)
+    {
+      float x[VEC], y[VEC];
+      if (j->in_signal)
+        memcpy(x, j->in_signal + v * S + t * VEC, sizeof(x));
+      else
+        for (int n = 0; n < VEC; ++n) x[n] = j->in_const ? j->in_const[v] : 0.f;
+      for (int p = 0; p < j->n_procs; ++p)
+      {
+        proc_process64(j->procs[p], C[p], St[p], x, y);
+        memcpy(x, y, sizeof(x));
+      }
+      if (j->out) memcpy(j->out + v * S + t * VEC, x, sizeof(x));
+    }
+    for (int p = 0; p < j->n_procs; ++p)
+    {
+      int ns = mlorc_proc_num_state(j->procs[p]);
+      for (int i = 0; i < ns; ++i) j->state[(size_t)(sOff[p] + i) * j->V + v] = St[p][i];
+    }
+  }
+  return NULL;
+}
+
+/* same contract as mlref_chain_process (oracle/ref_wrapper.cpp):
+ * coeffs [totalNC][V], state [totalNS][V] in/out, in_signal [V][64T] or NULL,
+ * in_const [V] or NULL, out [V][64T] or NULL. */
+int mlorc_chain_process(const int32_t* procs, int n_procs, size_t V, size_t T, const float* coeffs,
+                        uint32_t* state, const float* in_signal, const float* in_const, float* out,
+                        int n_threads)
+{
+  if (n_procs < 1 || n_procs > 64) return MLGPU_ERR_INVALID;
+  for (int p = 0; p < n_procs; ++p)
+    if (mlorc_proc_num_coeffs(procs[p]) < 0) return MLGPU_ERR_INVALID;
+  if (!g_impulse_table_ready) build_impulse_table();
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  chain_job jobs[256];
+  pthread_t th[256];
+  size_t per = (V + (size_t)n_threads - 1) / (size_t)n_threads;
+  int used = 0;
+  for (int i = 0; i < n_threads; ++i)
+  {
+    size_t a = per * (size_t)i, b = per * (size_t)(i + 1);
+    if (a > V) a = V;
+    if (b > V) b = V;
+    if (a >= b) continue;
+    chain_job j = {procs, n_procs, V, T, a, b, coeffs, state, in_signal, in_const, out};
+    jobs[used] = j;
+    if (n_threads == 1)
+      chain_worker(&jobs[used]);
+    else
+      pthread_create(&th[used], NULL, chain_worker, &jobs[used]);
+    used++;
+  }
+  if (n_threads > 1)
+    for (int i = 0; i < used; ++i) pthread_join(th[i], NULL);
+  return MLGPU_OK;
+}
+
+/* wall-clock seconds of one mlorc_chain_process call (CPU baseline, kind "port") */
+double mlorc_chain_time(const int32_t* procs, int n_procs, size_t V, size_t T, const float* coeffs,
+                        uint32_t* state, const float* in_signal, const float* in_const, float* out,
+                        int n_threads)
+{
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  mlorc_chain_process(procs, n_procs, V, T, coeffs, state, in_signal, in_const, out, n_threads);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ------------------------------------------------------------------------- */
+/* coefficient makers (host libm), source/DSP/MLDSPFilters.h                  */
+
+static void svf_coeffs(float omega, float k, float* o) /* :85-95 == :168-177 == :212-221 */
+{
+  float piOmega = kPiF * omega;
+  float s1 = sinf(piOmega);
+  float s2 = sinf(2.0f * piOmega);
+  float nrm = 1.0f / (2.f + k * s2);
+  o[0] = s2 * nrm;
+  o[1] = (-2.f * s1 * s1 - k * s2) * nrm;
+  o[2] = (2.0f * s1 * s1) * nrm;
+}
+void mlorc_lopass_make_coeffs(float omega, float k, float* o) { svf_coeffs(omega, k, o); }
+void mlorc_bandpass_make_coeffs(float omega, float k, float* o) { svf_coeffs(omega, k, o); }
+void mlorc_hipass_make_coeffs(float omega, float k, float* o)
+{
+  svf_coeffs(omega, k, o);
+  o[3] = k;
+}
+void mlorc_loshelf_make_coeffs(float omega, float k, float A, float* r) /* :270-281 */
+{
+  float piOmega = kPiF * omega;
+  float g = tanf(piOmega) / sqrtf(A);
+  r[0] = 1.f / (1.f + g * (g + k));
+  r[1] = g * r[0];
+  r[2] = g * r[1];
+  r[3] = k * (A - 1.f);
+  r[4] = (A * A - 1.f);
+}
+void mlorc_hishelf_make_coeffs(float omega, float k, float A, float* r) /* :350-362 */
+{
+  float piOmega = kPiF * omega;
+  float g = tanf(piOmega) * sqrtf(A);
+  r[0] = 1.f / (1.f + g * (g + k));
+  r[1] = g * r[0];
+  r[2] = g * r[1];
+  r[3] = A * A;
+  r[4] = k * (1.f - A) * A;
+  r[5] = (1.f - A * A);
+}
+void mlorc_bell_make_coeffs(float omega, float k, float A, float* r) /* :415-425 */
+{
+  float kc = k / A;
+  float piOmega = kPiF * omega;
+  float g = tanf(piOmega);
+  float a1 = 1.f / (1.f + g * (g + kc));
+  float a2 = g * a1;
+  float a3 = g * a2;
+  float m1 = kc * (A * A - 1.f);
+  r[0] = a1; r[1] = a2; r[2] = a3; r[3] = m1;
+}
+void mlorc_onepole_make_coeffs(float omega, float* o) /* :458-462 */
+{
+  float x = expf(-omega * kTwoPiF);
+  o[0] = 1.f - x;
+  o[1] = x;
+}
+float mlorc_dcblocker_make_coeffs(float omega) { return cosf(omega); } /* :498 */
+void mlorc_adsr_calc_coeffs(float a, float d, float s, float r, float sr, float* o) /* :679-686 */
+{
+  const float minSegmentTime = 0.0002f;
+  const float invSr = 1.0f / sr;
+  o[0] = kTwoPiF * invSr / ((a > minSegmentTime) ? a : minSegmentTime);
+  o[1] = kTwoPiF * invSr / ((d > minSegmentTime) ? d : minSegmentTime);
+  o[2] = s;
+  o[3] = kTwoPiF * invSr / ((r > minSegmentTime) ? r : minSegmentTime);
+}
+float mlorc_db_to_gain(float dB) { return powf(10.f, dB / 40.f); } /* :30 */
+
+/* rangeClosed / rangeOpen, MLDSPOps.h:967-980: columnIndex()*interval + start */
+void mlorc_range_closed(float start, float end, float* out64)
+{
+  float interval = (end - start) / (VEC - 1.f);
+  for (int i = 0; i < VEC; ++i) out64[i] = (float)i * interval + start;
+}
+void mlorc_range_open(float start, float end, float* out64)
+{
+  float interval = (end - start) / (VEC);
+  for (int i = 0; i < VEC; ++i) out64[i] = (float)i * interval + start;
+}

@@ -1,0 +1,898 @@
+// oracle/ref_wrapper.cpp — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// A thin extern "C" harness around the UNMODIFIED reference headers, compiled from the
+// sources where they lie under /root/reference (see oracle/Makefile; flags pinned to
+// -std=c++17 -O2, no -march/-mfma). The resulting oracle/_ref/libmlref.so
+// is the ground truth that (1) pins the plain-C restatement in oracle/ml_oracle.c,
+// (2) generates tests/golden/*, and (3) is the "reference" CPU baseline timed by bench.py.
+// Nothing in the product (madronalib_amd/, include/) links or loads this file.
+//
+// No reference source is copied here: this file only #includes the reference's public
+// headers and calls their objects. State of the reference objects is private in places,
+// so the harness is compiled with g++'s -fno-access-control (a test-only switch).
+
+// standard headers first, so the access hack below never touches them
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <iterator>
+#include <memory>
+#include <thread>
+#include <type_traits>
+#include <vector>
+#include <emmintrin.h>
+#include <float.h>
+
+#include "mldsp.h"
+
+#include "../include/mlgpu.h"
+
+using namespace ml;
+
+namespace
+{
+inline uint32_t f2u(float f)
+{
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+inline float u2f(uint32_t u)
+{
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+// ---------------------------------------------------------------------------
+// one reference processor of a chain, behind a tiny virtual interface
+
+struct RefProc
+{
+  virtual ~RefProc() {}
+  virtual int nc() const = 0;
+  virtual int ns() const = 0;
+  virtual void setCoeffs(const float* c) = 0;     // c[nc]
+  virtual void setState(const uint32_t* s) = 0;   // s[ns]
+  virtual void getState(uint32_t* s) const = 0;
+  virtual void clear() = 0;                        // T::clear() semantics
+  virtual DSPVector process(const DSPVector& in) = 0;
+};
+
+struct RPhasor : RefProc
+{
+  PhasorGen g;
+  int nc() const override { return 0; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override { g.mOmega32 = s[0]; }
+  void getState(uint32_t* s) const override { s[0] = g.mOmega32; }
+  void clear() override { g.clear(); }
+  DSPVector process(const DSPVector& in) override { return g(in); }
+};
+struct RSine : RefProc
+{
+  SineGen g;
+  int nc() const override { return 0; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override { g._phasor.mOmega32 = s[0]; }
+  void getState(uint32_t* s) const override { s[0] = g._phasor.mOmega32; }
+  void clear() override { g.clear(); }
+  DSPVector process(const DSPVector& in) override { return g(in); }
+};
+struct RSaw : RefProc
+{
+  SawGen g;
+  int nc() const override { return 0; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override { g._phasor.mOmega32 = s[0]; }
+  void getState(uint32_t* s) const override { s[0] = g._phasor.mOmega32; }
+  void clear() override { g.clear(); }
+  DSPVector process(const DSPVector& in) override { return g(in); }
+};
+struct RPulse : RefProc
+{
+  PulseGen g;
+  float width{0.5f};
+  int nc() const override { return 1; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float* c) override { width = c[0]; }
+  void setState(const uint32_t* s) override { g._phasor.mOmega32 = s[0]; }
+  void getState(uint32_t* s) const override { s[0] = g._phasor.mOmega32; }
+  void clear() override { g.clear(); }
+  DSPVector process(const DSPVector& in) override { return g(in, DSPVector(width)); }
+};
+struct RNoise : RefProc
+{
+  NoiseGen g;
+  int nc() const override { return 0; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override { g.mSeed = s[0]; }
+  void getState(uint32_t* s) const override { s[0] = g.mSeed; }
+  void clear() override { g.reset(); }
+  DSPVector process(const DSPVector&) override { return g(); }
+};
+struct RTick : RefProc
+{
+  TickGen g;
+  int nc() const override { return 0; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override { g.mOmega = u2f(s[0]); }
+  void getState(uint32_t* s) const override { s[0] = f2u(g.mOmega); }
+  void clear() override { g.mOmega = 0; }
+  DSPVector process(const DSPVector& in) override { return g(in); }
+};
+struct RImpulse : RefProc
+{
+  ImpulseGen g;
+  int nc() const override { return 0; }
+  int ns() const override { return 2; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override
+  {
+    g._omega = u2f(s[0]);
+    g._outputCounter = (int)s[1];
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(g._omega);
+    s[1] = (uint32_t)g._outputCounter;
+  }
+  void clear() override
+  {
+    g._omega = 0;
+    g._outputCounter = 0;
+  }
+  DSPVector process(const DSPVector& in) override { return g(in); }
+};
+struct ROneShot : RefProc
+{
+  OneShotGen g;
+  int nc() const override { return 0; }
+  int ns() const override { return 3; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override
+  {
+    g.mOmega32 = s[0];
+    g.mGate = s[1];
+    g.mOmegaPrev = s[2];
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = g.mOmega32;
+    s[1] = g.mGate;
+    s[2] = g.mOmegaPrev;
+  }
+  void clear() override
+  {
+    g.mOmega32 = 0;
+    g.mGate = 0;
+    g.mOmegaPrev = 0;
+  }
+  DSPVector process(const DSPVector& in) override { return g(in); }
+};
+
+template <class F, int NC>
+struct RSvf : RefProc
+{
+  F f;
+  int nc() const override { return NC; }
+  int ns() const override { return 2; }
+  void setState(const uint32_t* s) override
+  {
+    f.ic1eq = u2f(s[0]);
+    f.ic2eq = u2f(s[1]);
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(f.ic1eq);
+    s[1] = f2u(f.ic2eq);
+  }
+  void clear() override
+  {
+    f.ic1eq = 0;
+    f.ic2eq = 0;
+  }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+struct RLopass : RSvf<Lopass, 3>
+{
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1], c[2]}; }
+};
+struct RHipass : RSvf<Hipass, 4>
+{
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1], c[2], c[3]}; }
+};
+struct RBandpass : RSvf<Bandpass, 3>
+{
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1], c[2]}; }
+};
+struct RLoShelf : RSvf<LoShelf, 5>
+{
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1], c[2], c[3], c[4]}; }
+};
+struct RHiShelf : RSvf<HiShelf, 6>
+{
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1], c[2], c[3], c[4], c[5]}; }
+};
+struct RBell : RSvf<Bell, 4>
+{
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1], c[2], c[3]}; }
+};
+
+struct ROnePole : RefProc
+{
+  OnePole f;
+  int nc() const override { return 2; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1]}; }
+  void setState(const uint32_t* s) override { f.y1 = u2f(s[0]); }
+  void getState(uint32_t* s) const override { s[0] = f2u(f.y1); }
+  void clear() override { f.clear(); }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+struct RDCBlocker : RefProc
+{
+  DCBlocker f;
+  int nc() const override { return 1; }
+  int ns() const override { return 2; }
+  void setCoeffs(const float* c) override { f.coeffs = c[0]; }
+  void setState(const uint32_t* s) override
+  {
+    f.x1 = u2f(s[0]);
+    f.y1 = u2f(s[1]);
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(f.x1);
+    s[1] = f2u(f.y1);
+  }
+  void clear() override
+  {
+    f.x1 = 0;
+    f.y1 = 0;
+  }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+struct RDifferentiator : RefProc
+{
+  Differentiator f;
+  int nc() const override { return 0; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override { f._x1 = u2f(s[0]); }
+  void getState(uint32_t* s) const override { s[0] = f2u(f._x1); }
+  void clear() override { f._x1 = 0; }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+struct RIntegrator : RefProc
+{
+  Integrator f;
+  int nc() const override { return 1; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float* c) override { f.mLeak = c[0]; }
+  void setState(const uint32_t* s) override { f.y1 = u2f(s[0]); }
+  void getState(uint32_t* s) const override { s[0] = f2u(f.y1); }
+  void clear() override { f.y1 = 0; }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+struct RPeak : RefProc
+{
+  Peak f;
+  int nc() const override { return 3; }
+  int ns() const override { return 2; }
+  void setCoeffs(const float* c) override
+  {
+    f.coeffs = {c[0], c[1]};
+    f.peakHoldSamples = (int)f2u(c[2]);
+  }
+  void setState(const uint32_t* s) override
+  {
+    f.y1 = u2f(s[0]);
+    f.peakHoldCounter = (int)s[1];
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(f.y1);
+    s[1] = (uint32_t)f.peakHoldCounter;
+  }
+  void clear() override
+  {
+    f.y1 = 0;
+    f.peakHoldCounter = 0;
+  }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+struct RRms : RefProc
+{
+  RMS f;
+  int nc() const override { return 2; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1]}; }
+  void setState(const uint32_t* s) override { f.y1 = u2f(s[0]); }
+  void getState(uint32_t* s) const override { s[0] = f2u(f.y1); }
+  void clear() override { f.y1 = 0; }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+struct RAdsr : RefProc
+{
+  ADSR f;
+  int nc() const override { return 4; }
+  int ns() const override { return 8; }
+  void setCoeffs(const float* c) override { f.coeffs = {c[0], c[1], c[2], c[3]}; }
+  void setState(const uint32_t* s) override
+  {
+    f.y = u2f(s[0]);
+    f.y1 = u2f(s[1]);
+    f.x1 = u2f(s[2]);
+    f.threshold = u2f(s[3]);
+    f.target = u2f(s[4]);
+    f.k = u2f(s[5]);
+    f.amp = u2f(s[6]);
+    f.segment = (int)s[7];
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(f.y);
+    s[1] = f2u(f.y1);
+    s[2] = f2u(f.x1);
+    s[3] = f2u(f.threshold);
+    s[4] = f2u(f.target);
+    s[5] = f2u(f.k);
+    s[6] = f2u(f.amp);
+    s[7] = (uint32_t)f.segment;
+  }
+  void clear() override { f.clear(); }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+struct RGain : RefProc
+{
+  float gain{1.f};
+  int nc() const override { return 1; }
+  int ns() const override { return 0; }
+  void setCoeffs(const float* c) override { gain = c[0]; }
+  void setState(const uint32_t*) override {}
+  void getState(uint32_t*) const override {}
+  void clear() override {}
+  DSPVector process(const DSPVector& in) override { return in * gain; }  // x * DSPVector(gain)
+};
+
+RefProc* makeProc(int kind)
+{
+  switch (kind)
+  {
+    case MLGPU_PROC_PHASOR_GEN: return new RPhasor;
+    case MLGPU_PROC_SINE_GEN: return new RSine;
+    case MLGPU_PROC_SAW_GEN: return new RSaw;
+    case MLGPU_PROC_PULSE_GEN: return new RPulse;
+    case MLGPU_PROC_NOISE_GEN: return new RNoise;
+    case MLGPU_PROC_TICK_GEN: return new RTick;
+    case MLGPU_PROC_IMPULSE_GEN: return new RImpulse;
+    case MLGPU_PROC_ONE_SHOT_GEN: return new ROneShot;
+    case MLGPU_PROC_LOPASS: return new RLopass;
+    case MLGPU_PROC_HIPASS: return new RHipass;
+    case MLGPU_PROC_BANDPASS: return new RBandpass;
+    case MLGPU_PROC_LO_SHELF: return new RLoShelf;
+    case MLGPU_PROC_HI_SHELF: return new RHiShelf;
+    case MLGPU_PROC_BELL: return new RBell;
+    case MLGPU_PROC_ONE_POLE: return new ROnePole;
+    case MLGPU_PROC_DC_BLOCKER: return new RDCBlocker;
+    case MLGPU_PROC_DIFFERENTIATOR: return new RDifferentiator;
+    case MLGPU_PROC_INTEGRATOR: return new RIntegrator;
+    case MLGPU_PROC_PEAK: return new RPeak;
+    case MLGPU_PROC_RMS: return new RRms;
+    case MLGPU_PROC_ADSR: return new RAdsr;
+    case MLGPU_PROC_GAIN: return new RGain;
+    default: return nullptr;
+  }
+}
+
+// run voices [v0, v1) of a chain
+void runVoices(const int32_t* procs, int nProcs, size_t V, size_t T, size_t v0, size_t v1,
+               const float* coeffs, uint32_t* state, const float* inSignal, const float* inConst,
+               float* out)
+{
+  std::vector<std::unique_ptr<RefProc>> chain;
+  std::vector<int> cOff(nProcs), sOff(nProcs);
+  int c = 0, s = 0;
+  for (int p = 0; p < nProcs; ++p)
+  {
+    chain.emplace_back(makeProc(procs[p]));
+    cOff[p] = c;
+    sOff[p] = s;
+    c += chain[p]->nc();
+    s += chain[p]->ns();
+  }
+  const size_t S = T * kFloatsPerDSPVector;
+  float cbuf[16];
+  uint32_t sbuf[16];
+  for (size_t v = v0; v < v1; ++v)
+  {
+    for (int p = 0; p < nProcs; ++p)
+    {
+      for (int i = 0; i < chain[p]->nc(); ++i) cbuf[i] = coeffs[(size_t)(cOff[p] + i) * V + v];
+      for (int i = 0; i < chain[p]->ns(); ++i) sbuf[i] = state[(size_t)(sOff[p] + i) * V + v];
+      chain[p]->setCoeffs(cbuf);
+      chain[p]->setState(sbuf);
+    }
+    for (size_t t = 0; t < T; ++t)
+    {
+      DSPVector x;
+      if (inSignal)
+        load(x, inSignal + v * S + t * kFloatsPerDSPVector);
+      else if (inConst)
+        x = DSPVector(inConst[v]);
+      for (int p = 0; p < nProcs; ++p) x = chain[p]->process(x);
+      if (out) store(x, out + v * S + t * kFloatsPerDSPVector);
+    }
+    for (int p = 0; p < nProcs; ++p)
+    {
+      chain[p]->getState(sbuf);
+      for (int i = 0; i < chain[p]->ns(); ++i) state[(size_t)(sOff[p] + i) * V + v] = sbuf[i];
+    }
+  }
+}
+
+template <class Fn>
+void parallelFor(size_t V, int nThreads, Fn fn)
+{
+  if (nThreads <= 1)
+  {
+    fn(0, V);
+    return;
+  }
+  std::vector<std::thread> th;
+  size_t per = (V + nThreads - 1) / nThreads;
+  for (int i = 0; i < nThreads; ++i)
+  {
+    size_t a = std::min(V, per * i), b = std::min(V, per * (i + 1));
+    if (a < b) th.emplace_back([=]() { fn(a, b); });
+  }
+  for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+extern "C"
+{
+  // ---- elementwise ops through the reference's own DSPVector functions ----
+  int mlref_op_apply(int op, const void* va, const void* vb, const void* vc, void* vout,
+                     size_t nElems)
+  {
+    if (nElems % kFloatsPerDSPVector) return MLGPU_ERR_INVALID;
+    const float* a = (const float*)va;
+    const float* b = (const float*)vb;
+    const float* c = (const float*)vc;
+    float* out = (float*)vout;
+    size_t nVec = nElems / kFloatsPerDSPVector;
+    for (size_t i = 0; i < nVec; ++i)
+    {
+      DSPVector x1, x2, x3, y;
+      DSPVectorInt i1, i2, i3, yi;
+      const size_t o = i * kFloatsPerDSPVector;
+      if (a)
+      {
+        load(x1, a + o);
+        std::memcpy(i1.getBuffer(), a + o, 256);
+      }
+      if (b)
+      {
+        load(x2, b + o);
+        std::memcpy(i2.getBuffer(), b + o, 256);
+      }
+      if (c)
+      {
+        load(x3, c + o);
+        std::memcpy(i3.getBuffer(), c + o, 256);
+      }
+      bool intOut = false;
+      switch (op)
+      {
+        case MLGPU_OP_SQRT: y = sqrt(x1); break;
+        case MLGPU_OP_SQRT_APPROX: y = sqrtApprox(x1); break;
+        case MLGPU_OP_ABS: y = abs(x1); break;
+        case MLGPU_OP_SIGN: y = sign(x1); break;
+        case MLGPU_OP_SIGN_BIT: y = signBit(x1); break;
+        case MLGPU_OP_SIN: y = sin(x1); break;
+        case MLGPU_OP_COS: y = cos(x1); break;
+        case MLGPU_OP_LOG: y = log(x1); break;
+        case MLGPU_OP_EXP: y = exp(x1); break;
+        case MLGPU_OP_LOG2: y = log2(x1); break;
+        case MLGPU_OP_EXP2: y = exp2(x1); break;
+        case MLGPU_OP_SIN_APPROX: y = sinApprox(x1); break;
+        case MLGPU_OP_COS_APPROX: y = cosApprox(x1); break;
+        case MLGPU_OP_EXP_APPROX: y = expApprox(x1); break;
+        case MLGPU_OP_LOG_APPROX: y = logApprox(x1); break;
+        case MLGPU_OP_LOG2_APPROX: y = log2Approx(x1); break;
+        case MLGPU_OP_EXP2_APPROX: y = exp2Approx(x1); break;
+        case MLGPU_OP_FRACTIONAL_PART: y = fractionalPart(x1); break;
+        case MLGPU_OP_ROUND_FLOAT_TO_INT:
+          yi = roundFloatToInt(x1);
+          intOut = true;
+          break;
+        case MLGPU_OP_TRUNCATE_FLOAT_TO_INT:
+          yi = truncateFloatToInt(x1);
+          intOut = true;
+          break;
+        case MLGPU_OP_INT_TO_FLOAT: y = intToFloat(i1); break;
+        case MLGPU_OP_UNSIGNED_INT_TO_FLOAT: y = unsignedIntToFloat(i1); break;
+        case MLGPU_OP_EXP_APPROX_OF_SIN_APPROX: y = expApprox(sinApprox(x1)); break;
+        case MLGPU_OP_ADD: y = add(x1, x2); break;
+        case MLGPU_OP_SUBTRACT: y = subtract(x1, x2); break;
+        case MLGPU_OP_MULTIPLY: y = multiply(x1, x2); break;
+        case MLGPU_OP_DIVIDE: y = divide(x1, x2); break;
+        case MLGPU_OP_DIVIDE_APPROX: y = divideApprox(x1, x2); break;
+        case MLGPU_OP_POW: y = pow(x1, x2); break;
+        case MLGPU_OP_POW_APPROX: y = powApprox(x1, x2); break;
+        case MLGPU_OP_MIN: y = min(x1, x2); break;
+        case MLGPU_OP_MAX: y = max(x1, x2); break;
+        case MLGPU_OP_ADD_INT32:
+          yi = addInt32(i1, i2);
+          intOut = true;
+          break;
+        case MLGPU_OP_SUBTRACT_INT32:
+          yi = subtractInt32(i1, i2);
+          intOut = true;
+          break;
+        case MLGPU_OP_EQUAL:
+          yi = equal(x1, x2);
+          intOut = true;
+          break;
+        case MLGPU_OP_NOT_EQUAL:
+          yi = notEqual(x1, x2);
+          intOut = true;
+          break;
+        case MLGPU_OP_GREATER_THAN:
+          yi = greaterThan(x1, x2);
+          intOut = true;
+          break;
+        case MLGPU_OP_GREATER_THAN_OR_EQUAL:
+          yi = greaterThanOrEqual(x1, x2);
+          intOut = true;
+          break;
+        case MLGPU_OP_LESS_THAN:
+          yi = lessThan(x1, x2);
+          intOut = true;
+          break;
+        case MLGPU_OP_LESS_THAN_OR_EQUAL:
+          yi = lessThanOrEqual(x1, x2);
+          intOut = true;
+          break;
+        case MLGPU_OP_LERP: y = lerp(x1, x2, x3); break;
+        case MLGPU_OP_INVERSE_LERP: y = inverseLerp(x1, x2, x3); break;
+        case MLGPU_OP_CLAMP: y = clamp(x1, x2, x3); break;
+        case MLGPU_OP_WITHIN: y = within(x1, x2, x3); break;
+        case MLGPU_OP_SELECT: y = select(x1, x2, i3); break;
+        case MLGPU_OP_SELECT_INT:
+          yi = select(i1, i2, i3);
+          intOut = true;
+          break;
+        default: return MLGPU_ERR_INVALID;
+      }
+      if (intOut)
+        std::memcpy(out + o, yi.getConstBuffer(), 256);
+      else
+        store(y, out + o);
+    }
+    return MLGPU_OK;
+  }
+
+  int mlref_op_apply_rows1(int op, const float* a, const float* b64, float* out, size_t nRows)
+  {
+    DSPVector x2;
+    load(x2, b64);
+    for (size_t r = 0; r < nRows; ++r)
+    {
+      DSPVector x1, y;
+      load(x1, a + r * 64);
+      switch (op)
+      {
+        case MLGPU_OP_ADD: y = add1(x1, x2); break;
+        case MLGPU_OP_SUBTRACT: y = subtract1(x1, x2); break;
+        case MLGPU_OP_MULTIPLY: y = multiply1(x1, x2); break;
+        case MLGPU_OP_DIVIDE: y = divide1(x1, x2); break;
+        case MLGPU_OP_DIVIDE_APPROX: y = divideApprox1(x1, x2); break;
+        case MLGPU_OP_POW: y = pow1(x1, x2); break;
+        case MLGPU_OP_POW_APPROX: y = powApprox1(x1, x2); break;
+        case MLGPU_OP_MIN: y = min1(x1, x2); break;
+        case MLGPU_OP_MAX: y = max1(x1, x2); break;
+        default: return MLGPU_ERR_INVALID;
+      }
+      store(y, out + r * 64);
+    }
+    return MLGPU_OK;
+  }
+
+  int mlref_row_reduce(int rowop, const float* rows, float* out, size_t nRows)
+  {
+    for (size_t r = 0; r < nRows; ++r)
+    {
+      DSPVector x;
+      load(x, rows + r * 64);
+      switch (rowop)
+      {
+        case MLGPU_ROWOP_SUM: out[r] = sum(x); break;
+        case MLGPU_ROWOP_MEAN: out[r] = mean(x); break;
+        case MLGPU_ROWOP_MAX: out[r] = max(x); break;
+        case MLGPU_ROWOP_MIN: out[r] = min(x); break;
+        default: return MLGPU_ERR_INVALID;
+      }
+    }
+    return MLGPU_OK;
+  }
+
+  // ---- chains of reference processors ----
+  int mlref_proc_num_coeffs(int kind)
+  {
+    std::unique_ptr<RefProc> p(makeProc(kind));
+    return p ? p->nc() : -1;
+  }
+  int mlref_proc_num_state(int kind)
+  {
+    std::unique_ptr<RefProc> p(makeProc(kind));
+    return p ? p->ns() : -1;
+  }
+
+  // state <- T::clear() for each processor; state is [totalNS][V]
+  int mlref_chain_clear(const int32_t* procs, int nProcs, size_t V, uint32_t* state)
+  {
+    int s = 0;
+    uint32_t sbuf[16];
+    for (int p = 0; p < nProcs; ++p)
+    {
+      std::unique_ptr<RefProc> rp(makeProc(procs[p]));
+      if (!rp) return MLGPU_ERR_INVALID;
+      rp->clear();
+      rp->getState(sbuf);
+      // ADSR::clear() only sets segment=off; the other words keep their values. For a
+      // fresh object they are zero, which is what we report.
+      for (int i = 0; i < rp->ns(); ++i)
+        for (size_t v = 0; v < V; ++v) state[(size_t)(s + i) * V + v] = sbuf[i];
+      s += rp->ns();
+    }
+    return MLGPU_OK;
+  }
+
+  // default-constructed state of the reference objects (== what a new bank holds)
+  int mlref_chain_default_state(const int32_t* procs, int nProcs, size_t V, uint32_t* state)
+  {
+    int s = 0;
+    uint32_t sbuf[16];
+    for (int p = 0; p < nProcs; ++p)
+    {
+      std::unique_ptr<RefProc> rp(makeProc(procs[p]));
+      if (!rp) return MLGPU_ERR_INVALID;
+      rp->getState(sbuf);
+      for (int i = 0; i < rp->ns(); ++i)
+        for (size_t v = 0; v < V; ++v) state[(size_t)(s + i) * V + v] = sbuf[i];
+      s += rp->ns();
+    }
+    return MLGPU_OK;
+  }
+
+  // coeffs [totalNC][V], state [totalNS][V] (in/out), inSignal [V][64T] or NULL,
+  // inConst [V] or NULL, out [V][64T] (may be NULL for timing runs)
+  int mlref_chain_process(const int32_t* procs, int nProcs, size_t V, size_t T,
+                          const float* coeffs, uint32_t* state, const float* inSignal,
+                          const float* inConst, float* out, int nThreads)
+  {
+    for (int p = 0; p < nProcs; ++p)
+    {
+      std::unique_ptr<RefProc> rp(makeProc(procs[p]));
+      if (!rp) return MLGPU_ERR_INVALID;
+    }
+    parallelFor(V, nThreads, [=](size_t a, size_t b)
+                { runVoices(procs, nProcs, V, T, a, b, coeffs, state, inSignal, inConst, out); });
+    return MLGPU_OK;
+  }
+
+  // ---- CPU baselines: the bench chains written exactly as user code would ----
+  // config 3: y = bp(saw(freq)) * gain  (SURVEY §3.2). Each thread owns a contiguous
+  // range of voices as an array of {SawGen, Bandpass}; loops vectors x voices.
+  // Returns seconds of wall time for T vectors over V voices. `sink` receives a checksum
+  // so the work cannot be optimised away; out may be NULL.
+  double mlref_bench_saw_bandpass_gain(size_t V, size_t T, const float* freq, const float* g0,
+                                       const float* g1, const float* g2, float gain,
+                                       int nThreads, float* out, double* sink)
+  {
+    struct Voice
+    {
+      SawGen saw;
+      Bandpass bp;
+    };
+    std::vector<Voice> voices(V);
+    for (size_t v = 0; v < V; ++v)
+    {
+      voices[v].saw.clear();
+      voices[v].bp.coeffs = {g0[v], g1[v], g2[v]};
+    }
+    std::vector<double> partial(std::max(1, nThreads), 0.0);
+    const size_t S = T * kFloatsPerDSPVector;
+    auto t0 = std::chrono::steady_clock::now();
+    std::atomic<int> tid{0};
+    parallelFor(V, nThreads,
+                [&](size_t a, size_t b)
+                {
+                  int me = tid.fetch_add(1);
+                  double acc = 0;
+                  for (size_t t = 0; t < T; ++t)
+                  {
+                    for (size_t v = a; v < b; ++v)
+                    {
+                      DSPVector y = voices[v].bp(voices[v].saw(DSPVector(freq[v]))) * gain;
+                      if (out) store(y, out + v * S + t * kFloatsPerDSPVector);
+                      acc += y[63];
+                    }
+                  }
+                  partial[me] = acc;
+                });
+    auto t1 = std::chrono::steady_clock::now();
+    double s = 0;
+    for (double p : partial) s += p;
+    if (sink) *sink = s;
+    return std::chrono::duration<double>(t1 - t0).count();
+  }
+
+  // config 4: 8 cascaded Lopass sections over a noise input (NoiseGen seeded per channel).
+  double mlref_bench_lopass_cascade8(size_t V, size_t T, const float* coeffs /*[8][3]*/,
+                                     int nThreads, double* sink)
+  {
+    struct Chan
+    {
+      NoiseGen noise;
+      Lopass lp[8];
+    };
+    std::vector<Chan> ch(V);
+    for (size_t v = 0; v < V; ++v)
+    {
+      ch[v].noise.setSeed((uint32_t)v);
+      for (int i = 0; i < 8; ++i) ch[v].lp[i].coeffs = {coeffs[i * 3], coeffs[i * 3 + 1], coeffs[i * 3 + 2]};
+    }
+    std::vector<double> partial(std::max(1, nThreads), 0.0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::atomic<int> tid{0};
+    parallelFor(V, nThreads,
+                [&](size_t a, size_t b)
+                {
+                  int me = tid.fetch_add(1);
+                  double acc = 0;
+                  for (size_t t = 0; t < T; ++t)
+                  {
+                    for (size_t v = a; v < b; ++v)
+                    {
+                      DSPVector y = ch[v].noise();
+                      for (int i = 0; i < 8; ++i) y = ch[v].lp[i](y);
+                      acc += y[63];
+                    }
+                  }
+                  partial[me] = acc;
+                });
+    auto t1 = std::chrono::steady_clock::now();
+    double s = 0;
+    for (double p : partial) s += p;
+    if (sink) *sink = s;
+    return std::chrono::duration<double>(t1 - t0).count();
+  }
+
+  // config 2: elementwise op over n elements, nThreads; returns seconds.
+  double mlref_bench_op(int op, const float* in, float* out, size_t nElems, int nThreads, int reps)
+  {
+    size_t nVec = nElems / kFloatsPerDSPVector;
+    auto t0 = std::chrono::steady_clock::now();
+    parallelFor(nVec, nThreads,
+                [&](size_t a, size_t b)
+                {
+                  for (int r = 0; r < reps; ++r)
+                    mlref_op_apply(op, in + a * 64, nullptr, nullptr, out + a * 64, (b - a) * 64);
+                });
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
+  }
+
+  // ---- coefficient makers straight from the reference ----
+  void mlref_lopass_make_coeffs(float omega, float k, float* o)
+  {
+    auto c = Lopass::makeCoeffs(omega, k);
+    o[0] = c[0];
+    o[1] = c[1];
+    o[2] = c[2];
+  }
+  void mlref_hipass_make_coeffs(float omega, float k, float* o)
+  {
+    auto c = Hipass::makeCoeffs(omega, k);
+    o[0] = c.g0;
+    o[1] = c.g1;
+    o[2] = c.g2;
+    o[3] = c.k;
+  }
+  void mlref_bandpass_make_coeffs(float omega, float k, float* o)
+  {
+    auto c = Bandpass::makeCoeffs(omega, k);
+    o[0] = c.g0;
+    o[1] = c.g1;
+    o[2] = c.g2;
+  }
+  void mlref_loshelf_make_coeffs(float omega, float k, float A, float* o)
+  {
+    auto c = LoShelf::makeCoeffs({omega, k, A});
+    for (int i = 0; i < 5; ++i) o[i] = c[i];
+  }
+  void mlref_hishelf_make_coeffs(float omega, float k, float A, float* o)
+  {
+    auto c = HiShelf::makeCoeffs({omega, k, A});
+    for (int i = 0; i < 6; ++i) o[i] = c[i];
+  }
+  void mlref_bell_make_coeffs(float omega, float k, float A, float* o)
+  {
+    auto c = Bell::makeCoeffs(omega, k, A);
+    o[0] = c.a1;
+    o[1] = c.a2;
+    o[2] = c.a3;
+    o[3] = c.m1;
+  }
+  void mlref_onepole_make_coeffs(float omega, float* o)
+  {
+    auto c = OnePole::makeCoeffs(omega);
+    o[0] = c.a0;
+    o[1] = c.b1;
+  }
+  float mlref_dcblocker_make_coeffs(float omega) { return DCBlocker::makeCoeffs(omega); }
+  void mlref_adsr_calc_coeffs(float a, float d, float s, float r, float sr, float* o)
+  {
+    auto c = ADSR::calcCoeffs(a, d, s, r, sr);
+    o[0] = c.ka;
+    o[1] = c.kd;
+    o[2] = c.s;
+    o[3] = c.kr;
+  }
+  float mlref_db_to_gain(float dB) { return dBToGain(dB); }
+
+  // the ImpulseGen windowed-sinc table as the reference's constructor builds it
+  void mlref_impulse_table(float* out17)
+  {
+    ImpulseGen g;
+    for (int i = 0; i < 17; ++i) out17[i] = g._table[i];
+  }
+
+  // rangeClosed / rangeOpen helpers for the anchor tests
+  void mlref_range_closed(float a, float b, float* out64) { store(rangeClosed(a, b), out64); }
+  void mlref_range_open(float a, float b, float* out64) { store(rangeOpen(a, b), out64); }
+
+  // ---- DSPBuffer (MLDSPBuffer.h) for pinning the host ring restatement ----
+  void* mlref_dspbuffer_create(int size)
+  {
+    auto* b = new DSPBuffer();
+    b->resize(size);
+    return b;
+  }
+  void mlref_dspbuffer_destroy(void* p) { delete (DSPBuffer*)p; }
+  size_t mlref_dspbuffer_read_available(void* p) { return ((DSPBuffer*)p)->getReadAvailable(); }
+  size_t mlref_dspbuffer_write_available(void* p) { return ((DSPBuffer*)p)->getWriteAvailable(); }
+  void mlref_dspbuffer_write(void* p, const float* src, size_t n) { ((DSPBuffer*)p)->write(src, n); }
+  size_t mlref_dspbuffer_read(void* p, float* dst, size_t n) { return ((DSPBuffer*)p)->read(dst, n); }
+  void mlref_dspbuffer_discard(void* p, size_t n) { ((DSPBuffer*)p)->discard(n); }
+  void mlref_dspbuffer_clear(void* p) { ((DSPBuffer*)p)->clear(); }
+  void mlref_dspbuffer_write_overlap_add(void* p, const float* src, size_t n, size_t overlap)
+  {
+    ((DSPBuffer*)p)->writeWithOverlapAdd(src, n, overlap);
+  }
+  void mlref_dspbuffer_read_overlap(void* p, float* dst, size_t n, size_t overlap)
+  {
+    ((DSPBuffer*)p)->readWithOverlap(dst, n, overlap);
+  }
+  void mlref_dspbuffer_peek_most_recent(void* p, float* dst, size_t n)
+  {
+    ((DSPBuffer*)p)->peekMostRecent(dst, n);
+  }
+}

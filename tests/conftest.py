@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from cpu_checkers import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from cpu_checkers import Ref, ref_available
+    if not ref_available():
+        pytest.skip("compiled reference (oracle/_ref/libmlref.so) not available here")
+    return Ref()

@@ -1,0 +1,249 @@
+"""ctypes front-ends for the two CPU checkers (TEST INFRASTRUCTURE ONLY).
+
+  Oracle()  -> oracle/libmloracle.so   plain-C restatement (oracle/ml_oracle.c), prefix mlorc_
+  Ref()     -> oracle/_ref/libmlref.so the compiled reference (oracle/ref_wrapper.cpp), prefix mlref_
+
+Both expose the same calls so a test can run either one. Signals are VOICE_MAJOR
+[V][64*T] float32; coeffs/state are SoA [slot][V] exactly like the GPU bank.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def _ptr(a, t):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(t)
+
+
+def build_oracle():
+    """Compile oracle/libmloracle.so (gcc only; works on the GPU box too)."""
+    so = os.path.join(ORACLE_DIR, "libmloracle.so")
+    src = os.path.join(ORACLE_DIR, "ml_oracle.c")
+    hdr = os.path.join(ROOT, "include", "mlgpu.h")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libmloracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def build_ref():
+    """Compile oracle/_ref/libmlref.so when /root/reference is present; else use a prebuilt one."""
+    so = os.path.join(ORACLE_DIR, "_ref", "libmlref.so")
+    if os.path.isdir("/root/reference/source/DSP"):
+        src = os.path.join(ORACLE_DIR, "ref_wrapper.cpp")
+        if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "_ref/libmlref.so"], stdout=subprocess.DEVNULL)
+    return so if os.path.exists(so) else None
+
+
+class _Checker:
+    prefix = None
+
+    def __init__(self, path):
+        self.lib = ctypes.CDLL(path)
+        self.path = path
+        L, p = self.lib, self.prefix
+        sz = ctypes.c_size_t
+        f = ctypes.c_float
+
+        def fn(name, res, args):
+            h = getattr(L, p + name)
+            h.restype = res
+            h.argtypes = args
+            return h
+
+        self._op_apply = fn("op_apply", ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, sz])
+        self._op_rows1 = fn("op_apply_rows1", ctypes.c_int, [ctypes.c_int, c_f32p, c_f32p, c_f32p, sz])
+        self._row_reduce = fn("row_reduce", ctypes.c_int, [ctypes.c_int, c_f32p, c_f32p, sz])
+        self._nc = fn("proc_num_coeffs", ctypes.c_int, [ctypes.c_int])
+        self._ns = fn("proc_num_state", ctypes.c_int, [ctypes.c_int])
+        self._clear = fn("chain_clear", ctypes.c_int, [c_i32p, ctypes.c_int, sz, c_u32p])
+        self._default = fn("chain_default_state", ctypes.c_int, [c_i32p, ctypes.c_int, sz, c_u32p])
+        self._process = fn("chain_process", ctypes.c_int, [c_i32p, ctypes.c_int, sz, sz, c_f32p, c_u32p, c_f32p, c_f32p, c_f32p, ctypes.c_int])
+        self._mk = {
+            "lopass": (fn("lopass_make_coeffs", None, [f, f, c_f32p]), 2, 3),
+            "hipass": (fn("hipass_make_coeffs", None, [f, f, c_f32p]), 2, 4),
+            "bandpass": (fn("bandpass_make_coeffs", None, [f, f, c_f32p]), 2, 3),
+            "loshelf": (fn("loshelf_make_coeffs", None, [f, f, f, c_f32p]), 3, 5),
+            "hishelf": (fn("hishelf_make_coeffs", None, [f, f, f, c_f32p]), 3, 6),
+            "bell": (fn("bell_make_coeffs", None, [f, f, f, c_f32p]), 3, 4),
+            "onepole": (fn("onepole_make_coeffs", None, [f, c_f32p]), 1, 2),
+            "adsr": (fn("adsr_calc_coeffs", None, [f, f, f, f, f, c_f32p]), 5, 4),
+        }
+        self._dcb = fn("dcblocker_make_coeffs", f, [f])
+        self._db2g = fn("db_to_gain", f, [f])
+        self._imp = fn("impulse_table", None, [c_f32p])
+        self._rc = fn("range_closed", None, [f, f, c_f32p])
+        self._ro = fn("range_open", None, [f, f, c_f32p])
+
+    # ---- elementwise ----
+    def op(self, op, a, b=None, c=None):
+        a = np.ascontiguousarray(a)
+        out = np.empty(a.shape, np.uint32)
+        args = [None if x is None else np.ascontiguousarray(x) for x in (a, b, c)]
+        r = self._op_apply(int(op), *[None if x is None else x.ctypes.data_as(ctypes.c_void_p) for x in args],
+                           out.ctypes.data_as(ctypes.c_void_p), a.size)
+        assert r == 0, r
+        return out
+
+    def op_rows1(self, op, a, b64):
+        a = np.ascontiguousarray(a, np.float32)
+        b64 = np.ascontiguousarray(b64, np.float32)
+        out = np.empty_like(a)
+        r = self._op_rows1(int(op), _ptr(a, c_f32p), _ptr(b64, c_f32p), _ptr(out, c_f32p), a.size // 64)
+        assert r == 0
+        return out
+
+    def row_reduce(self, rowop, rows):
+        rows = np.ascontiguousarray(rows, np.float32)
+        out = np.empty(rows.size // 64, np.float32)
+        r = self._row_reduce(int(rowop), _ptr(rows, c_f32p), _ptr(out, c_f32p), rows.size // 64)
+        assert r == 0
+        return out
+
+    # ---- chains ----
+    def num_coeffs(self, kind):
+        return self._nc(int(kind))
+
+    def num_state(self, kind):
+        return self._ns(int(kind))
+
+    def chain_sizes(self, procs):
+        return sum(self.num_coeffs(p) for p in procs), sum(self.num_state(p) for p in procs)
+
+    def chain_clear(self, procs, V):
+        procs = np.asarray(procs, np.int32)
+        _, ns = self.chain_sizes(procs)
+        st = np.zeros((ns, V), np.uint32)
+        assert self._clear(_ptr(procs, c_i32p), len(procs), V, _ptr(st, c_u32p)) == 0
+        return st
+
+    def chain_default_state(self, procs, V):
+        procs = np.asarray(procs, np.int32)
+        _, ns = self.chain_sizes(procs)
+        st = np.zeros((ns, V), np.uint32)
+        assert self._default(_ptr(procs, c_i32p), len(procs), V, _ptr(st, c_u32p)) == 0
+        return st
+
+    def chain_process(self, procs, T, coeffs, state, in_signal=None, in_const=None, n_threads=1, want_out=True):
+        """state is updated in place. Returns out [V][64T] (float32)."""
+        procs = np.ascontiguousarray(procs, np.int32)
+        V = state.shape[1] if state.ndim == 2 and state.shape[0] > 0 else (
+            coeffs.shape[1] if coeffs is not None and coeffs.ndim == 2 and coeffs.shape[0] > 0 else
+            (in_const.shape[0] if in_const is not None else in_signal.shape[0]))
+        coeffs = np.ascontiguousarray(coeffs, np.float32) if coeffs is not None else np.zeros((0, V), np.float32)
+        assert state.dtype == np.uint32 and state.flags["C_CONTIGUOUS"]
+        if in_signal is not None:
+            in_signal = np.ascontiguousarray(in_signal, np.float32)
+            assert in_signal.shape == (V, 64 * T)
+        if in_const is not None:
+            in_const = np.ascontiguousarray(in_const, np.float32)
+        out = np.empty((V, 64 * T), np.float32) if want_out else None
+        r = self._process(_ptr(procs, c_i32p), len(procs), V, T, _ptr(coeffs, c_f32p), _ptr(state, c_u32p),
+                          _ptr(in_signal, c_f32p), _ptr(in_const, c_f32p), _ptr(out, c_f32p), n_threads)
+        assert r == 0, r
+        return out
+
+    # ---- coefficient makers ----
+    def make_coeffs(self, name, *params):
+        fnc, nin, nout = self._mk[name]
+        assert len(params) == nin
+        o = np.zeros(nout, np.float32)
+        fnc(*[float(x) for x in params], _ptr(o, c_f32p))
+        return o
+
+    def dcblocker_coeffs(self, omega):
+        return np.float32(self._dcb(float(omega)))
+
+    def db_to_gain(self, dB):
+        return np.float32(self._db2g(float(dB)))
+
+    def impulse_table(self):
+        o = np.zeros(17, np.float32)
+        self._imp(_ptr(o, c_f32p))
+        return o
+
+    def range_closed(self, a, b):
+        o = np.zeros(64, np.float32)
+        self._rc(float(a), float(b), _ptr(o, c_f32p))
+        return o
+
+    def range_open(self, a, b):
+        o = np.zeros(64, np.float32)
+        self._ro(float(a), float(b), _ptr(o, c_f32p))
+        return o
+
+
+class Oracle(_Checker):
+    prefix = "mlorc_"
+
+    def __init__(self):
+        super().__init__(build_oracle())
+        L = self.lib
+        L.mlorc_chain_time.restype = ctypes.c_double
+        L.mlorc_chain_time.argtypes = [c_i32p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_u32p,
+                                       c_f32p, c_f32p, c_f32p, ctypes.c_int]
+
+    def chain_time(self, procs, T, coeffs, state, in_signal=None, in_const=None, n_threads=1):
+        procs = np.ascontiguousarray(procs, np.int32)
+        V = state.shape[1]
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        return self.lib.mlorc_chain_time(_ptr(procs, c_i32p), len(procs), V, T, _ptr(coeffs, c_f32p),
+                                         _ptr(state, c_u32p), _ptr(in_signal, c_f32p), _ptr(in_const, c_f32p),
+                                         None, n_threads)
+
+
+class Ref(_Checker):
+    prefix = "mlref_"
+
+    def __init__(self, path=None):
+        path = path or build_ref()
+        if path is None:
+            raise FileNotFoundError("oracle/_ref/libmlref.so not built and /root/reference absent")
+        super().__init__(path)
+        L = self.lib
+        sz = ctypes.c_size_t
+        L.mlref_bench_saw_bandpass_gain.restype = ctypes.c_double
+        L.mlref_bench_saw_bandpass_gain.argtypes = [sz, sz, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_float,
+                                                    ctypes.c_int, c_f32p, c_f64p]
+        L.mlref_bench_lopass_cascade8.restype = ctypes.c_double
+        L.mlref_bench_lopass_cascade8.argtypes = [sz, sz, c_f32p, ctypes.c_int, c_f64p]
+        L.mlref_bench_op.restype = ctypes.c_double
+        L.mlref_bench_op.argtypes = [ctypes.c_int, c_f32p, c_f32p, sz, ctypes.c_int, ctypes.c_int]
+
+    def bench_saw_bandpass_gain(self, V, T, freq, g0, g1, g2, gain, n_threads, out=None):
+        sink = ctypes.c_double(0)
+        arrs = [np.ascontiguousarray(x, np.float32) for x in (freq, g0, g1, g2)]
+        s = self.lib.mlref_bench_saw_bandpass_gain(V, T, *[_ptr(a, c_f32p) for a in arrs], float(gain), n_threads,
+                                                    _ptr(out, c_f32p), ctypes.byref(sink))
+        return s, sink.value
+
+    def bench_lopass_cascade8(self, V, T, coeffs8x3, n_threads):
+        sink = ctypes.c_double(0)
+        c = np.ascontiguousarray(coeffs8x3, np.float32)
+        s = self.lib.mlref_bench_lopass_cascade8(V, T, _ptr(c, c_f32p), n_threads, ctypes.byref(sink))
+        return s, sink.value
+
+    def bench_op(self, op, x, n_threads, reps):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        return self.lib.mlref_bench_op(int(op), _ptr(x, c_f32p), _ptr(out, c_f32p), x.size, n_threads, reps)
+
+
+def ref_available():
+    try:
+        return build_ref() is not None
+    except Exception:
+        return False

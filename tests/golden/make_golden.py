@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/libmlref.so).
+
+Run in the build container (where /root/reference exists):   python tests/golden/make_golden.py
+The vectors travel with the repo so the oracle and the HIP path can be checked against the
+reference's own outputs on boxes where /root/reference does not exist.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from cpu_checkers import Ref  # noqa: E402
+from inputs import chain_coeffs, chain_input, op_inputs  # noqa: E402
+from madronalib_amd.constants import Op, Proc, RowOp  # noqa: E402
+
+GOLDEN_CHAINS = {
+    "cfg1_sine_lopass": [Proc.SINE_GEN, Proc.LOPASS],
+    "cfg3_saw_bandpass_gain": [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN],
+    "cfg4_noise_lopass8": [Proc.NOISE_GEN] + [Proc.LOPASS] * 8,
+    "pulse_hipass_onepole": [Proc.PULSE_GEN, Proc.HIPASS, Proc.ONE_POLE],
+    "saw_shelves_bell_dc": [Proc.SAW_GEN, Proc.LO_SHELF, Proc.HI_SHELF, Proc.BELL, Proc.DC_BLOCKER],
+}
+
+
+def main():
+    ref = Ref()
+    # ---- elementwise ops: 512 inputs each ----
+    d = {}
+    for op in Op.UNARY + Op.BINARY + Op.TERNARY:
+        a, b, c = op_inputs(op, 64 * 8)
+        d[f"op{op}_a"] = np.ascontiguousarray(a).view(np.uint32)
+        if b is not None:
+            d[f"op{op}_b"] = np.ascontiguousarray(b).view(np.uint32)
+        if c is not None:
+            d[f"op{op}_c"] = np.ascontiguousarray(c).view(np.uint32)
+        d[f"op{op}_out"] = ref.op(op, a, b, c)
+    rows = (np.random.default_rng(3).standard_normal(64 * 6) * 100).astype(np.float32)
+    rows[64:128] = -np.abs(rows[64:128])
+    d["rows"] = rows
+    for ro in (RowOp.SUM, RowOp.MEAN, RowOp.MAX, RowOp.MIN):
+        d[f"rowop{ro}"] = ref.row_reduce(ro, rows)
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **d)
+
+    # ---- single processors and chains: V=8 voices, T=6 vectors, two consecutive calls ----
+    d = {}
+    cases = {f"proc{k}": [k] for k in Proc.ALL}
+    cases.update(GOLDEN_CHAINS)
+    V, T = 8, 6
+    for name, procs in cases.items():
+        co = chain_coeffs(ref, procs, V, seed=5)
+        sig, const = chain_input(procs, V, T, seed=int(procs[0]))
+        st = ref.chain_clear(procs, V)
+        if procs[0] == Proc.NOISE_GEN:
+            st[0] = np.arange(V, dtype=np.uint32)
+        if procs[0] == Proc.ONE_SHOT_GEN:
+            st[1] = 1
+        d[name + "_procs"] = np.asarray(procs, np.int32)
+        d[name + "_coeffs"] = co
+        d[name + "_state0"] = st.copy()
+        if sig is not None:
+            d[name + "_in_signal"] = sig
+        if const is not None:
+            d[name + "_in_const"] = const
+        d[name + "_out1"] = ref.chain_process(procs, T, co, st, sig, const)
+        d[name + "_state1"] = st.copy()
+        d[name + "_out2"] = ref.chain_process(procs, T, co, st, sig, const)
+        d[name + "_state2"] = st.copy()
+    d["impulse_table"] = ref.impulse_table()
+    np.savez_compressed(os.path.join(HERE, "chains.npz"), **d)
+    for f in ("ops.npz", "chains.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,177 @@
+"""Seeded inputs and comparison helpers shared by the parity tests."""
+import numpy as np
+
+from madronalib_amd.constants import Op, Proc
+
+
+def lcg_noise(seeds, n):
+    """The reference NoiseGen stream (MLDSPGens.h:115,127-128) for each seed: [len(seeds)][n] in [-1,1)."""
+    seed = np.asarray(seeds, np.uint32).copy()
+    out = np.empty((seed.size, n), np.float32)
+    for i in range(n):
+        seed = (seed * np.uint32(0x0019660D) + np.uint32(0x3C6EF35F)).astype(np.uint32)
+        bits = ((seed >> np.uint32(9)) & np.uint32(0x007FFFFF)) | np.uint32(0x3F800000)
+        out[:, i] = bits.view(np.float32) * np.float32(2.0) - np.float32(3.0)
+    return out
+
+
+def ramp_pi(V, S=64):
+    """SURVEY §8d config-2 ramp: x = -pi + 2pi*((v*S+n) mod 4096)/4095."""
+    idx = (np.arange(V * S, dtype=np.int64) % 4096).astype(np.float32)
+    return (np.float32(-np.pi) + np.float32(2 * np.pi) * idx / np.float32(4095.0)).astype(np.float32).reshape(V, S)
+
+
+SPECIALS = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 2.0, 1e-38, -1e-38, 1e-45, 3.4e38, -3.4e38,
+                     np.inf, -np.inf, np.nan, 88.5, -88.5, 100.0, -100.0, 8192.0, 1e9, -1e9, 3e9, -3e9,
+                     2147483520.0, 2147483648.0, -2147483648.0, 0.70710678, 1.5, 2.5, -1.5, -2.5,
+                     1.1754944e-38, 6.2831855, 3.1415927, -3.1415927, 0.78539816, 1e-20, 1e-19, 127.99, -126.5],
+                    dtype=np.float32)
+
+
+def general_floats(n, seed=0):
+    """Mixed-magnitude floats incl. specials; length n (multiple of 64)."""
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal(n).astype(np.float32)
+    scale = np.float32(10.0) ** rng.integers(-6, 7, n).astype(np.float32)
+    a = (a * scale).astype(np.float32)
+    k = min(len(SPECIALS), n)
+    a[:k] = SPECIALS[:k]
+    # a few raw bit patterns (denormals etc.)
+    raw = rng.integers(0, 2**32, max(1, n // 16), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    a[k:k + raw.size] = raw[: max(0, min(raw.size, n - k))]
+    return a
+
+
+def op_inputs(op, n=64 * 64, seed=0):
+    """(a, b, c) operands appropriate for `op` (None where unused)."""
+    rng = np.random.default_rng(seed + int(op))
+    a = general_floats(n, seed + 1)
+    b = general_floats(n, seed + 2)[::-1].copy()
+    c = general_floats(n, seed + 3)
+    if op in (Op.SIN_APPROX, Op.COS_APPROX, Op.EXP_APPROX_OF_SIN_APPROX):
+        a[n // 2:] = rng.uniform(-np.pi, np.pi, n - n // 2).astype(np.float32)
+    if op in (Op.LOG, Op.LOG2, Op.LOG_APPROX, Op.LOG2_APPROX, Op.SQRT, Op.SQRT_APPROX, Op.POW, Op.POW_APPROX):
+        a[n // 2:] = np.abs(a[n // 2:]) + np.float32(1e-30)
+    if op in (Op.POW, Op.POW_APPROX):
+        b[n // 2:] = rng.uniform(-4, 4, n - n // 2).astype(np.float32)
+    if op in Op.INT_INPUT or op == Op.SELECT_INT:
+        a = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        b = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    if op in (Op.SELECT, Op.SELECT_INT):
+        c = np.where(rng.random(n) < 0.5, np.uint32(0xFFFFFFFF), np.uint32(0)).astype(np.uint32)
+        c[:8] = rng.integers(0, 2**32, 8, dtype=np.uint64).astype(np.uint32)  # partial masks are bitwise
+    if op in Op.UNARY:
+        return a, None, None
+    if op in Op.BINARY:
+        return a, b, None
+    return a, b, c
+
+
+def is_float_result(op):
+    return op not in (Op.ROUND_FLOAT_TO_INT, Op.TRUNCATE_FLOAT_TO_INT, Op.ADD_INT32, Op.SUBTRACT_INT32,
+                      Op.EQUAL, Op.NOT_EQUAL, Op.GREATER_THAN, Op.GREATER_THAN_OR_EQUAL, Op.LESS_THAN,
+                      Op.LESS_THAN_OR_EQUAL, Op.WITHIN, Op.SELECT_INT, Op.SELECT)
+
+
+def assert_bits_equal(got, want, float_result=True, what=""):
+    """Bit-exact comparison; for float results any NaN matches any NaN (payloads are not portable)."""
+    g = np.ascontiguousarray(got).view(np.uint32).ravel()
+    w = np.ascontiguousarray(want).view(np.uint32).ravel()
+    assert g.shape == w.shape, (g.shape, w.shape)
+    neq = g != w
+    if float_result:
+        gn = np.isnan(g.view(np.float32))
+        wn = np.isnan(w.view(np.float32))
+        neq &= ~(gn & wn)
+    if neq.any():
+        i = int(np.flatnonzero(neq)[0])
+        raise AssertionError(f"{what}: {int(neq.sum())}/{g.size} words differ; first at {i}: "
+                             f"got 0x{g[i]:08x} ({g.view(np.float32)[i]!r}) want 0x{w[i]:08x} ({w.view(np.float32)[i]!r})")
+
+
+def assert_rel_close(got, want, rel, what=""):
+    """|got-want| <= rel*|want| elementwise; NaN/inf must agree."""
+    g = np.ascontiguousarray(got).view(np.float32).ravel().astype(np.float64)
+    w = np.ascontiguousarray(want).view(np.float32).ravel().astype(np.float64)
+    fin = np.isfinite(w) & np.isfinite(g)
+    assert (np.isnan(g) == np.isnan(w)).all(), what + ": NaN pattern differs"
+    inf = np.isinf(w)
+    assert (g[inf] == w[inf]).all(), what + ": inf pattern differs"
+    err = np.abs(g[fin] - w[fin])
+    tol = rel * np.abs(w[fin]) + 1e-44
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} beyond rel {rel}; worst {float((err / (np.abs(w[fin]) + 1e-300)).max()):.3e}"
+
+
+# ---- chain test cases -------------------------------------------------------------------
+
+def proc_default_coeffs(mk, kind, V, seed=0):
+    """Per-voice coefficient arrays [NC][V] for one processor, from the checker's own makeCoeffs."""
+    rng = np.random.default_rng(seed + kind)
+    P = Proc
+    if kind in (P.LOPASS, P.BANDPASS):
+        name = "lopass" if kind == P.LOPASS else "bandpass"
+        return np.stack([mk.make_coeffs(name, rng.uniform(0.001, 0.45), rng.uniform(0.05, 2.0)) for _ in range(V)], 1)
+    if kind == P.HIPASS:
+        return np.stack([mk.make_coeffs("hipass", rng.uniform(0.001, 0.45), rng.uniform(0.05, 2.0)) for _ in range(V)], 1)
+    if kind == P.LO_SHELF:
+        return np.stack([mk.make_coeffs("loshelf", rng.uniform(0.001, 0.4), rng.uniform(0.3, 2.0), rng.uniform(0.25, 4.0)) for _ in range(V)], 1)
+    if kind == P.HI_SHELF:
+        return np.stack([mk.make_coeffs("hishelf", rng.uniform(0.001, 0.4), rng.uniform(0.3, 2.0), rng.uniform(0.25, 4.0)) for _ in range(V)], 1)
+    if kind == P.BELL:
+        return np.stack([mk.make_coeffs("bell", rng.uniform(0.001, 0.4), rng.uniform(0.3, 2.0), rng.uniform(0.25, 4.0)) for _ in range(V)], 1)
+    if kind in (P.ONE_POLE, P.RMS):
+        return np.stack([mk.make_coeffs("onepole", rng.uniform(0.0005, 0.3)) for _ in range(V)], 1)
+    if kind == P.PEAK:
+        c = np.stack([mk.make_coeffs("onepole", rng.uniform(0.0005, 0.3)) for _ in range(V)], 1)
+        hold = rng.integers(0, 400, V).astype(np.uint32).view(np.float32)[None, :]
+        return np.concatenate([c, hold], 0)
+    if kind == P.DC_BLOCKER:
+        return np.array([[mk.dcblocker_coeffs(rng.uniform(0.01, 0.2)) for _ in range(V)]], np.float32)
+    if kind == P.INTEGRATOR:
+        return rng.uniform(0.0, 0.01, (1, V)).astype(np.float32)
+    if kind == P.ADSR:
+        return np.stack([mk.make_coeffs("adsr", rng.uniform(0.0001, 0.01), rng.uniform(0.001, 0.01),
+                                        rng.uniform(0.1, 0.9), rng.uniform(0.001, 0.01), 48000.0) for _ in range(V)], 1)
+    if kind == P.GAIN:
+        return rng.uniform(-1.5, 1.5, (1, V)).astype(np.float32)
+    if kind == P.PULSE_GEN:
+        return rng.uniform(0.05, 0.95, (1, V)).astype(np.float32)
+    return np.zeros((0, V), np.float32)
+
+
+def chain_coeffs(mk, procs, V, seed=0):
+    parts = [proc_default_coeffs(mk, int(p), V, seed + 17 * i) for i, p in enumerate(procs)]
+    return np.ascontiguousarray(np.concatenate(parts, 0).astype(np.float32)) if parts else np.zeros((0, V), np.float32)
+
+
+def gate_signal(V, S, seed=0):
+    """ADSR input: per-voice gate on/off pattern with random amplitudes."""
+    rng = np.random.default_rng(seed)
+    x = np.zeros((V, S), np.float32)
+    for v in range(V):
+        t = 0
+        on = False
+        while t < S:
+            L = int(rng.integers(20, 400))
+            if on:
+                x[v, t:t + L] = np.float32(rng.uniform(0.2, 1.0))
+            on = not on
+            t += L
+    return x
+
+
+def chain_input(procs, V, T, seed=0):
+    """(in_signal or None, in_const or None) suitable for the head processor of the chain."""
+    rng = np.random.default_rng(seed)
+    head = int(procs[0])
+    S = 64 * T
+    if head == Proc.NOISE_GEN:
+        return None, None
+    if head in Proc.GENERATORS:
+        # cycles per sample: log-spaced 20 Hz..8 kHz at 48 kHz, < 0.5
+        f = (20.0 * (400.0 ** rng.random(V)) / 48000.0).astype(np.float32)
+        return None, f
+    if head == Proc.ADSR:
+        return gate_signal(V, S, seed), None
+    return lcg_noise(np.arange(V, dtype=np.uint32) + np.uint32(seed * 1000), S), None

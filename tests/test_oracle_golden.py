@@ -1,0 +1,140 @@
+"""Pin the plain-C oracle against (a) the committed golden vectors produced by the compiled
+reference, (b) the SURVEY Appendix-B anchors, (c) the reference's own test assertions
+(Tests/dspOpsTest.cpp:103-104,154,164; Tests/dspGensTest.cpp:31). Needs no reference tree."""
+import numpy as np
+import pytest
+
+from golden_cases import ANCHORS, chain_case, chain_case_names, hash31, load_chains, load_ops
+from inputs import assert_bits_equal, assert_rel_close, is_float_result
+from madronalib_amd.constants import Op, Proc, RowOp
+
+HW_REL = 2.0 ** -11 * 1.5
+
+
+@pytest.mark.parametrize("op", Op.UNARY + Op.BINARY + Op.TERNARY)
+def test_ops_golden(oracle, op):
+    d = load_ops()
+    g = lambda k: d[f"op{op}_{k}"] if f"op{op}_{k}" in d.files else None  # noqa: E731
+    got = oracle.op(op, g("a"), g("b"), g("c"))
+    want = d[f"op{op}_out"]
+    if op in Op.HW_APPROX:
+        ok = np.isfinite(want.view(np.float32)) & np.isfinite(got.view(np.float32)) & (want.view(np.float32) != 0)
+        assert_rel_close(got.view(np.float32)[ok], want.view(np.float32)[ok], HW_REL, f"op {op}")
+    else:
+        assert_bits_equal(got, want, is_float_result(op), f"op {op}")
+
+
+def test_row_reduce_golden(oracle):
+    d = load_ops()
+    for ro in (RowOp.SUM, RowOp.MEAN, RowOp.MAX, RowOp.MIN):
+        assert_bits_equal(oracle.row_reduce(ro, d["rows"]), d[f"rowop{ro}"], True, f"rowop {ro}")
+
+
+@pytest.mark.parametrize("name", chain_case_names())
+def test_chains_golden(oracle, name):
+    c = chain_case(load_chains(), name)
+    st = c["state0"].copy()
+    hw = any(p in Proc.HW_APPROX for p in c["procs"])
+    for out_k, st_k in (("out1", "state1"), ("out2", "state2")):
+        got = oracle.chain_process(c["procs"], c[out_k].shape[1] // 64, c["coeffs"], st, c["in_signal"], c["in_const"])
+        if hw:
+            assert_rel_close(got, c[out_k], HW_REL, name)
+        else:
+            assert_bits_equal(got, c[out_k], True, name + " " + out_k)
+        assert_bits_equal(st, c[st_k], False, name + " " + st_k)
+
+
+def test_impulse_table_golden(oracle):
+    assert_bits_equal(oracle.impulse_table(), load_chains()["impulse_table"], True, "ImpulseGen table")
+
+
+# ---- SURVEY Appendix B anchors ----------------------------------------------------------
+
+def test_anchor_cfg1(oracle):
+    a = ANCHORS["cfg1"]
+    co = oracle.make_coeffs("lopass", *a["lopass"]).reshape(3, 1).copy()
+    st = oracle.chain_clear(a["procs"], 1)
+    assert st[0, 0] == 0xC0000000
+    y = oracle.chain_process(a["procs"], 1, co, st, None, np.array([a["freq"]], np.float32))[0]
+    assert list(y[:4]) == a["y0_3"] and y[63] == a["y63"]
+
+
+def test_anchor_cfg3(oracle):
+    a = ANCHORS["cfg3"]
+    co = np.concatenate([oracle.make_coeffs("bandpass", *a["bandpass"]), [a["gain"]]]).astype(np.float32).reshape(4, 1).copy()
+    st = oracle.chain_clear(a["procs"], 1)
+    z = oracle.chain_process(a["procs"], 1, co, st, None, np.array([a["freq"]], np.float32))[0]
+    assert list(z[:4]) == a["z0_3"] and z[63] == a["z63"]
+
+
+def test_anchor_saw_noise_onepole_cfg4(oracle):
+    st = oracle.chain_clear([Proc.SAW_GEN], 1)
+    w = oracle.chain_process([Proc.SAW_GEN], 3, np.zeros((0, 1), np.float32), st, None, np.array([440.0 / 48000.0], np.float32))
+    wb = w.view(np.uint32)[0, 128:]
+    assert (wb[0], wb[63]) == (ANCHORS["saw_vec3"]["w0"], ANCHORS["saw_vec3"]["w63"])
+
+    st = oracle.chain_clear([Proc.NOISE_GEN], 1)
+    n = oracle.chain_process([Proc.NOISE_GEN], 1, np.zeros((0, 1), np.float32), st).view(np.uint32)[0]
+    assert (n[0], n[63]) == (ANCHORS["noise_vec0"]["n0"], ANCHORS["noise_vec0"]["n63"])
+
+    a = ANCHORS["onepole"]
+    c = oracle.make_coeffs("onepole", a["omega"])
+    assert tuple(c.view(np.uint32)) == (a["a0"], a["b1"])
+    imp = np.zeros((1, 64), np.float32)
+    imp[0, 0] = 1.0
+    st = oracle.chain_clear([Proc.ONE_POLE], 1)
+    o = oracle.chain_process([Proc.ONE_POLE], 1, c.reshape(2, 1).copy(), st, imp).view(np.uint32)[0]
+    assert (o[1], o[63]) == (a["o1"], a["o63"])
+
+    procs = [Proc.NOISE_GEN] + [Proc.LOPASS] * 8
+    co = np.concatenate([oracle.make_coeffs("lopass", float(np.float32(0.02) * np.float32(i + 1)), 0.7) for i in range(8)]).reshape(24, 1).copy()
+    st = oracle.chain_clear(procs, 1)
+    y = oracle.chain_process(procs, 4, co, st).view(np.uint32)[0, 192:]
+    a = ANCHORS["cfg4_vec4"]
+    assert (y[0], y[31], y[63]) == (a["y0"], a["y31"], a["y63"])
+
+
+def test_anchor_ramp(oracle):
+    a = oracle.range_closed(-np.pi, np.pi)
+    for op, bits in ANCHORS["ramp_elem5"].items():
+        assert oracle.op(op, a)[5] == bits, op
+    for op, h in ANCHORS["ramp_hash"].items():
+        assert hash31(oracle.op(op, a)) == h, op
+    a2 = (a * a + np.float32(0.1)).astype(np.float32)
+    for op, h in ANCHORS["ramp_hash_log"].items():
+        assert hash31(oracle.op(op, a2)) == h, op
+
+
+# ---- the reference's own assertions -------------------------------------------------------
+
+def test_reference_precision_thresholds(oracle):
+    """Tests/dspOpsTest.cpp:85-105: max|libm - precise| < 2e-6, max|libm - approx| < 2e-4 on
+    rangeClosed(-pi, pi). (For log the reference's max() drops the NaNs of x<=0; we compare x>0.)"""
+    a = oracle.range_closed(-np.pi, np.pi)
+    for precise, approx, native in ((Op.SIN, Op.SIN_APPROX, np.sin), (Op.COS, Op.COS_APPROX, np.cos),
+                                    (Op.EXP, Op.EXP_APPROX, np.exp)):
+        nat = native(a.astype(np.float64))
+        assert np.abs(oracle.op(precise, a).view(np.float32) - nat).max() < 2e-6
+        assert np.abs(oracle.op(approx, a).view(np.float32) - nat).max() < 2e-4
+    pos = a[a > 0]
+    pos = np.resize(pos, 64)
+    assert np.abs(oracle.op(Op.LOG, pos).view(np.float32) - np.log(pos.astype(np.float64))).max() < 2e-6
+    assert np.abs(oracle.op(Op.LOG_APPROX, pos).view(np.float32) - np.log(pos.astype(np.float64))).max() < 2e-4
+    assert np.isnan(oracle.op(Op.LOG, a[a <= 0][:1].repeat(64)).view(np.float32)).all()
+
+
+def test_reference_lerp_and_fractional_part(oracle):
+    """Tests/dspOpsTest.cpp:148-165."""
+    idx = np.arange(64, dtype=np.float32)
+    r = oracle.op(Op.LERP, idx, np.zeros(64, np.float32), np.full(64, 0.5, np.float32)).view(np.float32)
+    assert r[63] == 31.5
+    p = oracle.op(Op.FRACTIONAL_PART, np.full(64, 1.25, np.float32)).view(np.float32)
+    n = oracle.op(Op.FRACTIONAL_PART, np.full(64, -1.25, np.float32)).view(np.float32)
+    assert p[63] == -n[63]
+
+
+def test_reference_sinegen_cycle(oracle):
+    """Tests/dspGensTest.cpp:24-31: SineGen after clear(), one cycle at 1/64, ends within -120 dB of 0."""
+    st = oracle.chain_clear([Proc.SINE_GEN], 1)
+    v = oracle.chain_process([Proc.SINE_GEN], 1, np.zeros((0, 1), np.float32), st, None, np.array([1.0 / 64], np.float32))[0]
+    assert abs(v[63]) < 10.0 ** (-120.0 / 20.0)
