@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — voice-samples/s of the mldsp.h hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one launch of the fused voice-bank kernel over one batch: T DSPVectors for every
+voice of this rank's partition, inputs (per-voice freq, coefficients, state) already resident in
+HBM. Default workload = BASELINE.json configs[2], the configuration the metric
+"voice-samples/sec (SawGen->SVF chain)" is quoted on:
+    262 144 voices per GPU, SawGen -> Bandpass(k=0.5) -> x0.25, per-voice freq 55 Hz..1.76 kHz at
+    48 kHz, scalar-freq mode, free-running (max-throughput) streaming.
+Voices shard embarrassingly: rank g owns voices [g*V, (g+1)*V) — weak scaling, no data-path
+collective (torch.distributed is used only for the barrier and the max-over-ranks time).
+
+Prints ONE JSON line on rank 0 with `roofline` (HBM, algorithmic bytes / HIP-event kernel time on
+the engine's stream) and, at N=1, `cpu_baseline` (the compiled reference oracle/_ref when present,
+else the plain-C port, timed on the host cores over a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def partition(total_voices, world, rank):
+    """Contiguous voice range of `rank`: [lo, hi)."""
+    per = total_voices // world
+    rem = total_voices % world
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def cfg3_params(lo, hi, total):
+    """Per-voice freq and Bandpass coefficients of config 3 for global voices [lo, hi)."""
+    import madronalib_amd as ml
+    v = np.arange(lo, hi, dtype=np.float64)
+    freq = (55.0 * 2.0 ** (5.0 * v / total) / 48000.0).astype(np.float32)
+    om = np.minimum(0.45, 4.0 * freq.astype(np.float64)).astype(np.float32)
+    uniq, inv = np.unique(om, return_inverse=True)
+    table = np.stack([ml.Bandpass.makeCoeffs(float(o), 0.5) for o in uniq])
+    return freq, np.ascontiguousarray(table[inv].T)  # [3][V]
+
+
+def setup_workload(eng, name, V, T, lo, total):
+    """Returns (step_fn, algorithmic_bytes_per_launch, bank, description)."""
+    import madronalib_amd as ml
+    from madronalib_amd.constants import Layout, Op, Proc
+    n = V * T * 64
+    if name == "cfg3":
+        bank = eng.bank([Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN], V)
+        bank.clear()
+        freq, co = cfg3_params(lo, lo + V, total)
+        for i in range(3):
+            bank.set_coeff(1, i, co[i])
+        bank.set_coeff(2, 0, 0.25)
+        bank.set_input_const(freq)
+        outs = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        k = [0]
+
+        def step():
+            bank.process(T, outs[k[0] & 1], Layout.QUAD)
+            k[0] += 1
+        # 4 B/voice-sample out + (4 phase + 8 ic + 12 coeff + 4 gain + 4 freq read, 12 written)/launch
+        alg = 4.0 * n + V * (4 + 8 + 12 + 4 + 4 + 12)
+        desc = "BASELINE configs[2]: 262144 voices/GPU SawGen->Bandpass(k=0.5)->gain 0.25, scalar-freq, free-running"
+        return step, alg, bank, desc, (freq, co)
+    if name == "cfg4":
+        bank = eng.bank([Proc.LOPASS] * 8, V)
+        for i in range(8):
+            bank.set_coeffs(i, ml.Lopass.makeCoeffs(float(np.float32(0.02) * np.float32(i + 1)), 0.7))
+        nb = eng.bank([Proc.NOISE_GEN], V)
+        nb.set_state(0, 0, np.arange(lo, lo + V, dtype=np.uint32))
+        d_x = eng.alloc(4 * n)
+        nb.process(T, d_x, Layout.QUAD)
+        outs = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        k = [0]
+
+        def step():
+            bank.process(T, outs[k[0] & 1], Layout.QUAD, d_x, Layout.QUAD)
+            k[0] += 1
+        alg = 8.0 * n + V * (4 * (24 + 16) + 4 * 16)
+        return step, alg, bank, "BASELINE configs[3]: 131072 channels x 8 cascaded Lopass, streamed noise input", None
+    if name == "cfg2":
+        x = np.tile(np.linspace(-np.pi, np.pi, 4096, dtype=np.float32), (V * 64 * T) // 4096)
+        d_x = eng.to_device(x)
+        d_y = eng.alloc(4 * n)
+
+        def step():
+            eng.op_apply(Op.EXP_APPROX_OF_SIN_APPROX, d_x, None, None, d_y, n)
+        return step, 8.0 * n, None, "BASELINE configs[1]: 65536 voices elementwise expApprox(sinApprox(x))", None
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline_cfg3(total_voices, budget_s=12.0):
+    """The same chain on the host cores over a bounded sample (~10-20 s of CPU work)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_checkers import Oracle, Ref, ref_available
+    from madronalib_amd.constants import Proc
+    cores = os.cpu_count() or 1
+    Vs = 4096 * max(1, min(cores, 64))
+    freq, co = cfg3_params(0, Vs, Vs)
+    kind = "reference" if ref_available() else "port"
+    if kind == "reference":
+        ref = Ref()
+
+        def run(T):
+            s, _ = ref.bench_saw_bandpass_gain(Vs, T, freq, co[0], co[1], co[2], 0.25, cores)
+            return s
+    else:
+        orc = Oracle()
+        procs = [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]
+        coeffs = np.ascontiguousarray(np.concatenate([co, np.full((1, Vs), 0.25, np.float32)], 0))
+
+        def run(T):
+            st = orc.chain_clear(procs, Vs)
+            return orc.chain_time(procs, T, coeffs, st, None, freq, cores)
+    run(4)  # warm-up (page-in, thread start)
+    t_cal = run(16)
+    T = int(max(16, min(4096, 16 * budget_s / max(t_cal, 1e-6) / 3)))
+    times = [run(T) for _ in range(3)]
+    best = min(times)
+    return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": kind,
+            "sample": f"{Vs} voices x {T} DSPVectors of the same chain/params, {cores} threads, best of 3 "
+                      f"({'compiled reference headers, g++ -O2 SSE2' if kind == 'reference' else 'plain-C oracle port, gcc -O2'})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg2"])
+    ap.add_argument("--voices", type=int, default=0, help="voices per GPU (default: the config's)")
+    ap.add_argument("--vectors", type=int, default=32, help="DSPVectors per launch (T)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import madronalib_amd as ml
+    per_gpu = {"cfg3": 262144, "cfg4": 131072, "cfg2": 65536}[args.workload]
+    V = args.voices or per_gpu
+    total = V * world                 # weak scaling: per-GPU work fixed
+    lo, hi = partition(total, world, rank)
+    assert hi - lo == V
+    T = args.vectors if args.workload != "cfg2" else 1
+
+    eng = ml.Engine(local_rank)
+    step, alg_bytes, bank, desc, params = setup_workload(eng, args.workload, V, T, lo, total)
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = eng.timer_stop_ms() / args.steps      # HIP events on the engine's stream
+    eng.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        units = float(total) * T * 64 * args.steps          # voice-samples over all ranks
+        value = units / elapsed
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "voice-samples/sec (SawGen->SVF chain)" if args.workload == "cfg3" else f"voice-samples/sec ({args.workload})",
+            "value": value, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "voices_per_gpu": V, "total_voices": total, "vectors_per_launch": T,
+                       "samples_per_vector": 64, "layout": "QUAD [S/4][V][4]", "parallelism": f"voices x{world} (no collective)",
+                       "realtime_48k_voices": value / 48000.0},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": bank.kernel_name if bank is not None else "op_kernel<EXP_APPROX_OF_SIN_APPROX>",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
+            try:
+                out["cpu_baseline"] = cpu_baseline_cfg3(total)
+            except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {ex}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,349 @@
+"""madronalib_amd — MI355X-native evaluation of madronalib's mldsp.h hot path.
+
+Thin Python host over the C-ABI in include/mlgpu.h (madronalib_amd/csrc/libmlgpu.so). Python
+is used by the tests and bench only; the product is the C-ABI library and the C++ host
+mirror in include/mlgpu/*.hpp. Names follow the reference (source/DSP/MLDSPFilters.h,
+MLDSPGens.h, MLDSPFunctional.h): `Lopass.makeCoeffs`, `Bank`, `clear`, ...
+
+There is no CPU fallback: every compute call goes to a gfx950 kernel or raises MlgpuError.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, RowOp, Status
+
+__all__ = ["Engine", "Bank", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status",
+           "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
+           "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
+
+
+class MlgpuError(RuntimeError):
+    def __init__(self, status, detail=""):
+        L = _lib.load()
+        self.status = status
+        super().__init__(f"mlgpu status {status} ({L.mlgpu_status_string(status).decode()}) {detail}")
+
+
+def device_count():
+    return _lib.load().mlgpu_device_count()
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class DeviceBuffer:
+    """A caller-owned HBM allocation (mlgpu_alloc)."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        engine._check(engine.L.mlgpu_alloc(engine.h, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value or 0
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.engine._check(self.engine.L.mlgpu_upload(self.engine.h, self.ptr, _np_ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype=np.float32, count=None):
+        dtype = np.dtype(dtype)
+        n = self.nbytes // dtype.itemsize if count is None else int(count)
+        out = np.empty(n, dtype)
+        self.engine._check(self.engine.L.mlgpu_download(self.engine.h, _np_ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.engine.L.mlgpu_free(self.engine.h, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One MI355X + one HIP stream (mlgpu_engine)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = _lib.load()
+        h = ctypes.c_void_p()
+        if stream is None:
+            st = self.L.mlgpu_engine_create(int(device), ctypes.byref(h))
+        else:
+            st = self.L.mlgpu_engine_create_on_stream(int(device), ctypes.c_void_p(int(stream)), ctypes.byref(h))
+        if st != 0:
+            raise MlgpuError(st, "(engine_create)")
+        self.h = h
+        self.device = int(device)
+
+    def _check(self, st):
+        if st != 0:
+            raise MlgpuError(st, self.L.mlgpu_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mlgpu_engine_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self._check(self.L.mlgpu_engine_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.L.mlgpu_engine_stream(self.h)
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        cu = ctypes.c_int()
+        mem = ctypes.c_uint64()
+        self._check(self.L.mlgpu_device_info(self.device, name, 256, ctypes.byref(cu), ctypes.byref(mem)))
+        return dict(name=name.value.decode(), cu_count=cu.value, mem_bytes=mem.value)
+
+    # ---- memory ----
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
+
+    def timer_start(self):
+        self._check(self.L.mlgpu_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = ctypes.c_float()
+        self._check(self.L.mlgpu_timer_stop_ms(self.h, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- stateless ops on device buffers ----
+    def op_apply(self, op, a, b, c, out, n_elems):
+        g = lambda x: None if x is None else ctypes.c_void_p(x.ptr)  # noqa: E731
+        self._check(self.L.mlgpu_op_apply(self.h, int(op), g(a), g(b), g(c), g(out), int(n_elems)))
+
+    def op(self, op, a, b=None, c=None):
+        """Host convenience: upload operands, run the op kernel, download the result (uint32 bits)."""
+        a = np.ascontiguousarray(a)
+        n = a.size
+        bufs = [None if x is None else self.to_device(np.ascontiguousarray(x)) for x in (a, b, c)]
+        out = self.alloc(max(4 * n, 16))
+        self.op_apply(op, bufs[0], bufs[1], bufs[2], out, n)
+        return out.download(np.uint32, n).reshape(a.shape)
+
+    def op_rows1(self, op, a, b64):
+        a = np.ascontiguousarray(a, np.float32)
+        da, db = self.to_device(a), self.to_device(np.ascontiguousarray(b64, np.float32))
+        out = self.alloc(a.nbytes)
+        self._check(self.L.mlgpu_op_apply_rows1(self.h, int(op), da.ptr, db.ptr, out.ptr, a.size // 64))
+        return out.download(np.float32, a.size).reshape(a.shape)
+
+    def row_reduce(self, rowop, rows):
+        rows = np.ascontiguousarray(rows, np.float32)
+        d = self.to_device(rows)
+        out = self.alloc(max(16, 4 * (rows.size // 64)))
+        self._check(self.L.mlgpu_row_reduce(self.h, int(rowop), d.ptr, out.ptr, rows.size // 64))
+        return out.download(np.float32, rows.size // 64)
+
+    def layout_convert(self, src, src_layout, dst, dst_layout, n_voices, n_vectors):
+        self._check(self.L.mlgpu_layout_convert(self.h, src.ptr, int(src_layout), dst.ptr, int(dst_layout),
+                                                int(n_voices), int(n_vectors)))
+
+    def bank(self, procs, n_voices):
+        return Bank(self, procs, n_voices)
+
+
+class Bank:
+    """Runtime-sized Bank<T,ROWS> (reference MLDSPFunctional.h:321-360): V voices of one chain."""
+
+    def __init__(self, engine, procs, n_voices):
+        self.engine = engine
+        self.L = engine.L
+        self.procs = [int(p) for p in procs]
+        self.V = int(n_voices)
+        arr = (ctypes.c_int32 * len(self.procs))(*self.procs)
+        h = ctypes.c_void_p()
+        engine._check(self.L.mlgpu_bank_create(engine.h, arr, len(self.procs), self.V, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mlgpu_bank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def fused(self):
+        return bool(self.L.mlgpu_bank_is_fused(self.h))
+
+    @property
+    def kernel_name(self):
+        return self.L.mlgpu_bank_kernel_name(self.h).decode()
+
+    def num_coeffs(self, p):
+        return self.L.mlgpu_bank_num_coeffs(self.h, p)
+
+    def num_state(self, p):
+        return self.L.mlgpu_bank_num_state(self.h, p)
+
+    def clear(self):
+        self.engine._check(self.L.mlgpu_bank_clear(self.h))
+
+    def set_coeff(self, proc_idx, coeff_idx, value):
+        """value: scalar (broadcast) or per-voice array."""
+        if np.isscalar(value):
+            self.engine._check(self.L.mlgpu_bank_set_coeff_uniform(self.h, proc_idx, coeff_idx, float(value)))
+        else:
+            v = np.ascontiguousarray(value, np.float32)
+            assert v.shape == (self.V,)
+            self.engine._check(self.L.mlgpu_bank_set_coeff(self.h, proc_idx, coeff_idx, _np_ptr(v)))
+
+    def set_coeffs(self, proc_idx, coeffs):
+        """coeffs: sequence of NC scalars (broadcast) or array [NC][V] — the reference's `coeffs` member."""
+        for i, c in enumerate(coeffs):
+            self.set_coeff(proc_idx, i, c if np.ndim(c) else float(c))
+
+    def set_all_coeffs(self, coeffs_soa):
+        """coeffs_soa: [totalNC][V] in chain order (same layout the CPU checkers take)."""
+        row = 0
+        for p in range(len(self.procs)):
+            for i in range(self.num_coeffs(p)):
+                self.set_coeff(p, i, np.ascontiguousarray(coeffs_soa[row]))
+                row += 1
+
+    def get_state(self, proc_idx, state_idx):
+        out = np.empty(self.V, np.uint32)
+        self.engine._check(self.L.mlgpu_bank_get_state(self.h, proc_idx, state_idx, _np_ptr(out)))
+        return out
+
+    def set_state(self, proc_idx, state_idx, value):
+        if np.isscalar(value):
+            self.engine._check(self.L.mlgpu_bank_set_state_uniform(self.h, proc_idx, state_idx, int(value)))
+        else:
+            v = np.ascontiguousarray(value, np.uint32)
+            assert v.shape == (self.V,)
+            self.engine._check(self.L.mlgpu_bank_set_state(self.h, proc_idx, state_idx, _np_ptr(v)))
+
+    def get_all_state(self):
+        rows = [self.get_state(p, i) for p in range(len(self.procs)) for i in range(self.num_state(p))]
+        return np.stack(rows) if rows else np.zeros((0, self.V), np.uint32)
+
+    def set_all_state(self, state_soa):
+        row = 0
+        for p in range(len(self.procs)):
+            for i in range(self.num_state(p)):
+                self.set_state(p, i, np.ascontiguousarray(state_soa[row]))
+                row += 1
+
+    def set_input_const(self, per_voice):
+        v = np.ascontiguousarray(per_voice, np.float32)
+        assert v.shape == (self.V,)
+        self.engine._check(self.L.mlgpu_bank_set_input_const(self.h, _np_ptr(v)))
+
+    def process(self, n_vectors, d_out, out_layout=Layout.QUAD, d_in=None, in_layout=Layout.QUAD):
+        """Enqueue n_vectors DSPVectors for every voice. d_in/d_out: DeviceBuffer or raw int pointer."""
+        pin = None if d_in is None else ctypes.c_void_p(d_in.ptr if hasattr(d_in, "ptr") else int(d_in))
+        pout = ctypes.c_void_p(d_out.ptr if hasattr(d_out, "ptr") else int(d_out))
+        self.engine._check(self.L.mlgpu_bank_process(self.h, int(n_vectors), pin, int(in_layout), pout, int(out_layout)))
+
+    def process_host(self, n_vectors, in_signal=None, layout=Layout.QUAD):
+        """Test convenience: in_signal/out are VOICE_MAJOR [V][64T] numpy; the kernel runs in `layout`
+        (conversion done by the device layout kernel)."""
+        eng, V, T = self.engine, self.V, int(n_vectors)
+        nbytes = V * T * 64 * 4
+        d_in = None
+        if in_signal is not None:
+            x = np.ascontiguousarray(in_signal, np.float32)
+            assert x.shape == (V, 64 * T)
+            d_vm = eng.to_device(x)
+            if layout == Layout.VOICE_MAJOR:
+                d_in = d_vm
+            else:
+                d_in = eng.alloc(nbytes)
+                eng.layout_convert(d_vm, Layout.VOICE_MAJOR, d_in, layout, V, T)
+        d_out = eng.alloc(nbytes)
+        self.process(T, d_out, layout, d_in, layout)
+        if layout == Layout.VOICE_MAJOR:
+            res = d_out
+        else:
+            res = eng.alloc(nbytes)
+            eng.layout_convert(d_out, layout, res, Layout.VOICE_MAJOR, V, T)
+        return res.download(np.float32, V * T * 64).reshape(V, 64 * T)
+
+
+# ---- coefficient makers: host libm through the C-ABI (reference: static T::makeCoeffs) ----
+
+def _mk(name, nout, *params):
+    L = _lib.load()
+    out = (ctypes.c_float * nout)()
+    getattr(L, name)(*[float(p) for p in params], out)
+    return np.array(out[:], np.float32)
+
+
+class Lopass:
+    @staticmethod
+    def makeCoeffs(omega, k):
+        return _mk("mlgpu_lopass_make_coeffs", 3, omega, k)
+
+
+class Hipass:
+    @staticmethod
+    def makeCoeffs(omega, k):
+        return _mk("mlgpu_hipass_make_coeffs", 4, omega, k)
+
+
+class Bandpass:
+    @staticmethod
+    def makeCoeffs(omega, k):
+        return _mk("mlgpu_bandpass_make_coeffs", 3, omega, k)
+
+
+class LoShelf:
+    @staticmethod
+    def makeCoeffs(omega, k, A):
+        return _mk("mlgpu_loshelf_make_coeffs", 5, omega, k, A)
+
+
+class HiShelf:
+    @staticmethod
+    def makeCoeffs(omega, k, A):
+        return _mk("mlgpu_hishelf_make_coeffs", 6, omega, k, A)
+
+
+class Bell:
+    @staticmethod
+    def makeCoeffs(omega, k, A):
+        return _mk("mlgpu_bell_make_coeffs", 4, omega, k, A)
+
+
+class OnePole:
+    @staticmethod
+    def makeCoeffs(omega):
+        return _mk("mlgpu_onepole_make_coeffs", 2, omega)
+
+
+class DCBlocker:
+    @staticmethod
+    def makeCoeffs(omega):
+        return np.float32(_lib.load().mlgpu_dcblocker_make_coeffs(float(omega)))
+
+
+class ADSR:
+    @staticmethod
+    def calcCoeffs(a, d, s, r, sr):
+        return _mk("mlgpu_adsr_calc_coeffs", 4, a, d, s, r, sr)
+
+
+def dBToGain(dB):
+    return np.float32(_lib.load().mlgpu_db_to_gain(float(dB)))

@@ -1,0 +1,113 @@
+"""Locate, (re)build and load the C-ABI library madronalib_amd/csrc/libmlgpu.so.
+
+The library is the product: if it is missing and cannot be built, importing any compute
+entry fails loudly — there is no Python/CPU fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmlgpu.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "mlgpu.h")
+
+_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "coeffs.cpp", "mldsp_math.hpp", "mldsp_procs.hpp",
+            "mlgpu_internal.hpp", "Makefile"]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    srcs = [os.path.join(CSRC, s) for s in _SOURCES] + [HEADER]
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 build of libmlgpu.so (cross-compiles without a GPU)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        raise RuntimeError(f"hipcc not found at {hipcc}; cannot build {LIB_PATH}")
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j4", f"HIPCC={hipcc}", "libmlgpu.so"], stdout=out)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Return the ctypes handle to libmlgpu.so, building it first if the sources are newer."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if needs_build():
+        if os.path.exists("/opt/rocm/bin/hipcc") or os.environ.get("HIPCC"):
+            build()
+        elif not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmlgpu.so is not built and hipcc is unavailable; run __graft_entry__.build()")
+    _lib = ctypes.CDLL(LIB_PATH)
+    _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    c = ctypes
+    vp, sz, i, f = c.c_void_p, c.c_size_t, c.c_int, c.c_float
+    fp = c.POINTER(c.c_float)
+    pp = c.POINTER(c.c_void_p)
+
+    def sig(name, res, args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+
+    sig("mlgpu_abi_version", i, [])
+    sig("mlgpu_status_string", c.c_char_p, [i])
+    sig("mlgpu_device_count", i, [])
+    sig("mlgpu_device_info", i, [i, c.c_char_p, sz, c.POINTER(i), c.POINTER(c.c_uint64)])
+    sig("mlgpu_engine_create", i, [i, pp])
+    sig("mlgpu_engine_create_on_stream", i, [i, vp, pp])
+    sig("mlgpu_engine_destroy", i, [vp])
+    sig("mlgpu_engine_sync", i, [vp])
+    sig("mlgpu_engine_stream", vp, [vp])
+    sig("mlgpu_engine_device", i, [vp])
+    sig("mlgpu_last_error", c.c_char_p, [vp])
+    sig("mlgpu_alloc", i, [vp, sz, pp])
+    sig("mlgpu_free", i, [vp, vp])
+    sig("mlgpu_upload", i, [vp, vp, vp, sz])
+    sig("mlgpu_download", i, [vp, vp, vp, sz])
+    sig("mlgpu_fill32", i, [vp, vp, c.c_uint32, sz])
+    sig("mlgpu_timer_start", i, [vp])
+    sig("mlgpu_timer_stop_ms", i, [vp, fp])
+    sig("mlgpu_op_apply", i, [vp, i, vp, vp, vp, vp, sz])
+    sig("mlgpu_op_apply_rows1", i, [vp, i, vp, vp, vp, sz])
+    sig("mlgpu_row_reduce", i, [vp, i, vp, vp, sz])
+    sig("mlgpu_layout_convert", i, [vp, vp, i, vp, i, sz, sz])
+    sig("mlgpu_bank_create", i, [vp, c.POINTER(c.c_int32), i, sz, pp])
+    sig("mlgpu_bank_destroy", i, [vp])
+    sig("mlgpu_bank_num_voices", sz, [vp])
+    sig("mlgpu_bank_num_procs", i, [vp])
+    sig("mlgpu_bank_num_coeffs", i, [vp, i])
+    sig("mlgpu_bank_num_state", i, [vp, i])
+    sig("mlgpu_bank_clear", i, [vp])
+    sig("mlgpu_bank_set_coeff", i, [vp, i, i, vp])
+    sig("mlgpu_bank_set_coeff_uniform", i, [vp, i, i, f])
+    sig("mlgpu_bank_get_state", i, [vp, i, i, vp])
+    sig("mlgpu_bank_set_state", i, [vp, i, i, vp])
+    sig("mlgpu_bank_set_state_uniform", i, [vp, i, i, c.c_uint32])
+    sig("mlgpu_bank_set_input_const", i, [vp, vp])
+    sig("mlgpu_bank_process", i, [vp, sz, vp, i, vp, i])
+    sig("mlgpu_bank_is_fused", i, [vp])
+    sig("mlgpu_bank_kernel_name", c.c_char_p, [vp])
+    sig("mlgpu_lopass_make_coeffs", None, [f, f, fp])
+    sig("mlgpu_hipass_make_coeffs", None, [f, f, fp])
+    sig("mlgpu_bandpass_make_coeffs", None, [f, f, fp])
+    sig("mlgpu_loshelf_make_coeffs", None, [f, f, f, fp])
+    sig("mlgpu_hishelf_make_coeffs", None, [f, f, f, fp])
+    sig("mlgpu_bell_make_coeffs", None, [f, f, f, fp])
+    sig("mlgpu_onepole_make_coeffs", None, [f, fp])
+    sig("mlgpu_dcblocker_make_coeffs", f, [f])
+    sig("mlgpu_adsr_calc_coeffs", None, [f, f, f, f, f, fp])
+    sig("mlgpu_db_to_gain", f, [f])

@@ -1,0 +1,539 @@
+// capi.hip — the extern "C" boundary declared in include/mlgpu.h.
+//
+// Engine = one HIP device + one stream. Bank = V voices of one processor chain with SoA
+// coefficient/state arrays in HBM. Nothing here computes signal values on the host: every
+// compute entry either launches a gfx950 kernel or fails (no CPU fallback by design).
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "mlgpu_internal.hpp"
+
+namespace
+{
+int fail(mlgpu_engine* e, int status, const char* what, hipError_t herr = hipSuccess)
+{
+  if (e)
+  {
+    char buf[512];
+    if (herr != hipSuccess)
+      snprintf(buf, sizeof(buf), "%s: %s (%s)", what, hipGetErrorString(herr), hipGetErrorName(herr));
+    else
+      snprintf(buf, sizeof(buf), "%s", what);
+    e->lastError = buf;
+  }
+  return status;
+}
+
+#define HIP_TRY(e, call)                                            \
+  do                                                                \
+  {                                                                 \
+    hipError_t _err = (call);                                       \
+    if (_err != hipSuccess) return fail((e), MLGPU_ERR_HIP, #call, _err); \
+  } while (0)
+
+int createEngine(int device, hipStream_t stream, bool ownStream, mlgpu_engine** out)
+{
+  if (!out) return MLGPU_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MLGPU_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return MLGPU_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MLGPU_ERR_NO_DEVICE;
+  // the code object in this library is gfx950 only
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MLGPU_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return MLGPU_ERR_HIP;
+  mlgpu_engine* e = new (std::nothrow) mlgpu_engine();
+  if (!e) return MLGPU_ERR_OOM;
+  e->device = device;
+  e->cuCount = prop.multiProcessorCount;
+  if (ownStream)
+  {
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+      delete e;
+      return MLGPU_ERR_HIP;
+    }
+    e->ownsStream = true;
+  }
+  else
+  {
+    e->stream = stream;
+  }
+  float table[17];
+  mlgpu_build_impulse_table(table);
+  if (hipMalloc((void**)&e->d_impulseTable, sizeof(table)) != hipSuccess ||
+      hipMemcpy(e->d_impulseTable, table, sizeof(table), hipMemcpyHostToDevice) != hipSuccess)
+  {
+    if (e->ownsStream) hipStreamDestroy(e->stream);
+    delete e;
+    return MLGPU_ERR_HIP;
+  }
+  *out = e;
+  return MLGPU_OK;
+}
+}  // namespace
+
+struct mlgpu_bank
+{
+  mlgpu_engine* e{nullptr};
+  std::vector<int32_t> kinds;
+  std::vector<int> cOff, sOff, nc, ns;
+  int NC{0}, NS{0};
+  size_t V{0};
+  float* d_coeffs{nullptr};
+  uint32_t* d_state{nullptr};
+  float* d_inConst{nullptr};
+  const ChainEntry* fused{nullptr};
+  std::vector<const ChainEntry*> singles;
+  float* d_scratch[2]{nullptr, nullptr};
+  size_t scratchVectors{0};
+};
+
+extern "C"
+{
+  int mlgpu_abi_version(void) { return MLGPU_ABI_VERSION; }
+
+  const char* mlgpu_status_string(int s)
+  {
+    switch (s)
+    {
+      case MLGPU_OK: return "ok";
+      case MLGPU_ERR_INVALID: return "invalid argument";
+      case MLGPU_ERR_NO_DEVICE: return "no gfx950 (MI355X) HIP device";
+      case MLGPU_ERR_HIP: return "HIP runtime error";
+      case MLGPU_ERR_OOM: return "out of memory";
+      case MLGPU_ERR_UNSUPPORTED: return "unsupported";
+      case MLGPU_ERR_RANGE: return "index out of range";
+      default: return "unknown status";
+    }
+  }
+
+  int mlgpu_device_count(void)
+  {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+  }
+
+  int mlgpu_device_info(int device, char* name, size_t nameLen, int* cuCount, uint64_t* memBytes)
+  {
+    hipDeviceProp_t prop;
+    if (device < 0 || device >= mlgpu_device_count()) return MLGPU_ERR_NO_DEVICE;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MLGPU_ERR_HIP;
+    if (name && nameLen)
+    {
+      snprintf(name, nameLen, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cuCount) *cuCount = prop.multiProcessorCount;
+    if (memBytes) *memBytes = (uint64_t)prop.totalGlobalMem;
+    return MLGPU_OK;
+  }
+
+  int mlgpu_engine_create(int device, mlgpu_engine** out) { return createEngine(device, nullptr, true, out); }
+  int mlgpu_engine_create_on_stream(int device, void* hipStream, mlgpu_engine** out)
+  {
+    return createEngine(device, (hipStream_t)hipStream, false, out);
+  }
+
+  int mlgpu_engine_destroy(mlgpu_engine* e)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->d_impulseTable) hipFree(e->d_impulseTable);
+    if (e->ownsStream) hipStreamDestroy(e->stream);
+    delete e;
+    return MLGPU_OK;
+  }
+
+  int mlgpu_engine_sync(mlgpu_engine* e)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return MLGPU_OK;
+  }
+  void* mlgpu_engine_stream(mlgpu_engine* e) { return e ? (void*)e->stream : nullptr; }
+  int mlgpu_engine_device(mlgpu_engine* e) { return e ? e->device : -1; }
+  const char* mlgpu_last_error(mlgpu_engine* e) { return e ? e->lastError.c_str() : "null engine"; }
+
+  int mlgpu_alloc(mlgpu_engine* e, size_t bytes, void** d_out)
+  {
+    if (!e || !d_out) return MLGPU_ERR_INVALID;
+    *d_out = nullptr;
+    if (bytes == 0) return MLGPU_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipError_t err = hipMalloc(d_out, bytes);
+    if (err == hipErrorOutOfMemory) return fail(e, MLGPU_ERR_OOM, "hipMalloc", err);
+    if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "hipMalloc", err);
+    return MLGPU_OK;
+  }
+  int mlgpu_free(mlgpu_engine* e, void* d_ptr)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (!d_ptr) return MLGPU_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipFree(d_ptr));
+    return MLGPU_OK;
+  }
+  int mlgpu_upload(mlgpu_engine* e, void* d_dst, const void* h_src, size_t bytes)
+  {
+    if (!e || (bytes && (!d_dst || !h_src))) return MLGPU_ERR_INVALID;
+    if (!bytes) return MLGPU_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));  // h_src may be pageable and reused by the caller
+    return MLGPU_OK;
+  }
+  int mlgpu_download(mlgpu_engine* e, void* h_dst, const void* d_src, size_t bytes)
+  {
+    if (!e || (bytes && (!h_dst || !d_src))) return MLGPU_ERR_INVALID;
+    if (!bytes) return MLGPU_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return MLGPU_OK;
+  }
+  int mlgpu_fill32(mlgpu_engine* e, void* d_dst, uint32_t value, size_t n)
+  {
+    if (!e || (n && !d_dst)) return MLGPU_ERR_INVALID;
+    if (!n) return MLGPU_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, mlgpu_launch_fill32((uint32_t*)d_dst, value, n, e->stream));
+    return MLGPU_OK;
+  }
+
+  int mlgpu_timer_start(mlgpu_engine* e)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (!e->ev0)
+    {
+      HIP_TRY(e, hipEventCreate(&e->ev0));
+      HIP_TRY(e, hipEventCreate(&e->ev1));
+    }
+    HIP_TRY(e, hipEventRecord(e->ev0, e->stream));
+    return MLGPU_OK;
+  }
+  int mlgpu_timer_stop_ms(mlgpu_engine* e, float* msOut)
+  {
+    if (!e || !msOut || !e->ev0) return MLGPU_ERR_INVALID;
+    HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(e, hipEventSynchronize(e->ev1));
+    HIP_TRY(e, hipEventElapsedTime(msOut, e->ev0, e->ev1));
+    return MLGPU_OK;
+  }
+
+  // ---- stateless ops ----------------------------------------------------------------------
+
+  int mlgpu_op_apply(mlgpu_engine* e, int op, const void* a, const void* b, const void* c, void* out, size_t n)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    const int arity = op >= 64 ? 3 : (op >= 32 ? 2 : 1);
+    if (n == 0) return MLGPU_OK;
+    if (!a || !out || (arity >= 2 && !b) || (arity >= 3 && !c)) return fail(e, MLGPU_ERR_INVALID, "op_apply: null operand");
+    if ((arity < 2 && b) || (arity < 3 && c)) return fail(e, MLGPU_ERR_INVALID, "op_apply: unused operand must be NULL");
+    if (((uintptr_t)a | (uintptr_t)out | (uintptr_t)b | (uintptr_t)c) & 15)
+      return fail(e, MLGPU_ERR_INVALID, "op_apply: operands must be 16-byte aligned");
+    HIP_TRY(e, hipSetDevice(e->device));
+    bool known = false;
+    hipError_t err = mlgpu_launch_op(op, a, b, c, out, n, e->stream, e->cuCount, &known);
+    if (!known) return fail(e, MLGPU_ERR_INVALID, "op_apply: unknown op");
+    if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "op_apply launch", err);
+    return MLGPU_OK;
+  }
+
+  int mlgpu_op_apply_rows1(mlgpu_engine* e, int op, const void* a, const void* b64, void* out, size_t nRows)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (nRows == 0) return MLGPU_OK;
+    if (!a || !b64 || !out) return fail(e, MLGPU_ERR_INVALID, "op_apply_rows1: null operand");
+    HIP_TRY(e, hipSetDevice(e->device));
+    bool known = false;
+    hipError_t err = mlgpu_launch_op_rows1(op, a, b64, out, nRows, e->stream, e->cuCount, &known);
+    if (!known) return fail(e, MLGPU_ERR_INVALID, "op_apply_rows1: op must be ADD..MAX");
+    if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "op_apply_rows1 launch", err);
+    return MLGPU_OK;
+  }
+
+  int mlgpu_row_reduce(mlgpu_engine* e, int rowop, const float* rows, float* out, size_t nRows)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (nRows == 0) return MLGPU_OK;
+    if (!rows || !out) return fail(e, MLGPU_ERR_INVALID, "row_reduce: null operand");
+    HIP_TRY(e, hipSetDevice(e->device));
+    bool known = false;
+    hipError_t err = mlgpu_launch_row_reduce(rowop, rows, out, nRows, e->stream, &known);
+    if (!known) return fail(e, MLGPU_ERR_INVALID, "row_reduce: unknown rowop");
+    if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "row_reduce launch", err);
+    return MLGPU_OK;
+  }
+
+  int mlgpu_layout_convert(mlgpu_engine* e, const float* src, int srcLayout, float* dst, int dstLayout, size_t V,
+                           size_t T)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (V == 0 || T == 0) return MLGPU_OK;
+    if (!src || !dst || src == dst) return fail(e, MLGPU_ERR_INVALID, "layout_convert: bad pointers (must not alias)");
+    if (srcLayout < 0 || srcLayout > 2 || dstLayout < 0 || dstLayout > 2)
+      return fail(e, MLGPU_ERR_INVALID, "layout_convert: bad layout");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, mlgpu_launch_layout_convert(src, srcLayout, dst, dstLayout, V, T, e->stream));
+    return MLGPU_OK;
+  }
+
+  // ---- banks --------------------------------------------------------------------------------
+
+  int mlgpu_bank_destroy(mlgpu_bank* b)
+  {
+    if (!b) return MLGPU_ERR_INVALID;
+    mlgpu_engine* e = b->e;
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    if (b->d_coeffs) hipFree(b->d_coeffs);
+    if (b->d_state) hipFree(b->d_state);
+    if (b->d_inConst) hipFree(b->d_inConst);
+    if (b->d_scratch[0]) hipFree(b->d_scratch[0]);
+    if (b->d_scratch[1]) hipFree(b->d_scratch[1]);
+    delete b;
+    return MLGPU_OK;
+  }
+
+  int mlgpu_bank_create(mlgpu_engine* e, const int32_t* procs, int nProcs, size_t nVoices, mlgpu_bank** out)
+  {
+    if (!e || !out) return MLGPU_ERR_INVALID;
+    *out = nullptr;
+    if (!procs || nProcs < 1 || nProcs > 64 || nVoices == 0) return fail(e, MLGPU_ERR_INVALID, "bank_create: bad arguments");
+    mlgpu_bank* b = new (std::nothrow) mlgpu_bank();
+    if (!b) return MLGPU_ERR_OOM;
+    b->e = e;
+    b->V = nVoices;
+    for (int p = 0; p < nProcs; ++p)
+    {
+      const int nc = mlgpu_proc_nc(procs[p]), ns = mlgpu_proc_ns(procs[p]);
+      if (nc < 0)
+      {
+        delete b;
+        return fail(e, MLGPU_ERR_INVALID, "bank_create: unknown processor kind");
+      }
+      b->kinds.push_back(procs[p]);
+      b->cOff.push_back(b->NC);
+      b->sOff.push_back(b->NS);
+      b->nc.push_back(nc);
+      b->ns.push_back(ns);
+      b->NC += nc;
+      b->NS += ns;
+      const int32_t k = procs[p];
+      b->singles.push_back(mlgpu_find_chain(&k, 1));
+    }
+    b->fused = mlgpu_find_chain(procs, nProcs);
+    hipError_t err = hipSetDevice(e->device);
+    const size_t V = nVoices;
+    // +1 slot so zero-coefficient / zero-state chains still have a valid base pointer
+    if (err == hipSuccess) err = hipMalloc((void**)&b->d_coeffs, sizeof(float) * V * (size_t)(b->NC + 1));
+    if (err == hipSuccess) err = hipMalloc((void**)&b->d_state, sizeof(uint32_t) * V * (size_t)(b->NS + 1));
+    if (err == hipSuccess) err = hipMalloc((void**)&b->d_inConst, sizeof(float) * V);
+    if (err == hipSuccess && !b->fused)
+    {
+      // unfused chains ping-pong through two QUAD-layout scratch signals, processed in
+      // slices of scratchVectors DSPVectors so each scratch stays <= 256 MiB
+      const size_t bytesPerVector = V * 64 * sizeof(float);
+      b->scratchVectors = std::max<size_t>(1, ((size_t)256 << 20) / bytesPerVector);
+      b->scratchVectors = std::min<size_t>(b->scratchVectors, 64);
+      err = hipMalloc((void**)&b->d_scratch[0], bytesPerVector * b->scratchVectors);
+      if (err == hipSuccess) err = hipMalloc((void**)&b->d_scratch[1], bytesPerVector * b->scratchVectors);
+    }
+    if (err == hipSuccess) err = hipMemsetAsync(b->d_coeffs, 0, sizeof(float) * V * (size_t)(b->NC + 1), e->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(b->d_inConst, 0, sizeof(float) * V, e->stream);
+    if (err != hipSuccess)
+    {
+      const int st = (err == hipErrorOutOfMemory) ? MLGPU_ERR_OOM : MLGPU_ERR_HIP;
+      fail(e, st, "bank_create: device allocation", err);
+      mlgpu_bank_destroy(b);
+      return st;
+    }
+    // default-constructed state of the reference objects
+    for (int p = 0; p < nProcs; ++p)
+    {
+      uint32_t words[16];
+      mlgpu_proc_clear_state(b->kinds[p], words, false);
+      for (int i = 0; i < b->ns[p]; ++i)
+      {
+        err = mlgpu_launch_fill32(b->d_state + (size_t)(b->sOff[p] + i) * V, words[i], V, e->stream);
+        if (err != hipSuccess)
+        {
+          fail(e, MLGPU_ERR_HIP, "bank_create: state init", err);
+          mlgpu_bank_destroy(b);
+          return MLGPU_ERR_HIP;
+        }
+      }
+    }
+    *out = b;
+    return MLGPU_OK;
+  }
+
+  size_t mlgpu_bank_num_voices(mlgpu_bank* b) { return b ? b->V : 0; }
+  int mlgpu_bank_num_procs(mlgpu_bank* b) { return b ? (int)b->kinds.size() : -1; }
+  int mlgpu_bank_num_coeffs(mlgpu_bank* b, int p)
+  {
+    if (!b || p < 0 || p >= (int)b->kinds.size()) return -1;
+    return b->nc[p];
+  }
+  int mlgpu_bank_num_state(mlgpu_bank* b, int p)
+  {
+    if (!b || p < 0 || p >= (int)b->kinds.size()) return -1;
+    return b->ns[p];
+  }
+  int mlgpu_bank_is_fused(mlgpu_bank* b) { return (b && b->fused) ? 1 : 0; }
+  const char* mlgpu_bank_kernel_name(mlgpu_bank* b)
+  {
+    if (!b) return "";
+    return b->fused ? b->fused->kernelName : "chain_kernel<per-processor>";
+  }
+
+  int mlgpu_bank_clear(mlgpu_bank* b)
+  {
+    if (!b) return MLGPU_ERR_INVALID;
+    mlgpu_engine* e = b->e;
+    HIP_TRY(e, hipSetDevice(e->device));
+    for (size_t p = 0; p < b->kinds.size(); ++p)
+    {
+      uint32_t words[16];
+      mlgpu_proc_clear_state(b->kinds[p], words, true);
+      for (int i = 0; i < b->ns[p]; ++i)
+      {
+        // ADSR::clear() only sets segment = off (MLDSPFilters.h:702); its other members keep their values
+        if (b->kinds[p] == MLGPU_PROC_ADSR && i != 7) continue;
+        HIP_TRY(e, mlgpu_launch_fill32(b->d_state + (size_t)(b->sOff[p] + i) * b->V, words[i], b->V, e->stream));
+      }
+    }
+    return MLGPU_OK;
+  }
+
+  static int checkSlot(mlgpu_bank* b, int p, int idx, bool coeff)
+  {
+    if (!b) return MLGPU_ERR_INVALID;
+    if (p < 0 || p >= (int)b->kinds.size()) return fail(b->e, MLGPU_ERR_RANGE, "processor index out of range");
+    const int n = coeff ? b->nc[p] : b->ns[p];
+    if (idx < 0 || idx >= n) return fail(b->e, MLGPU_ERR_RANGE, coeff ? "coefficient index out of range" : "state index out of range");
+    return MLGPU_OK;
+  }
+
+  int mlgpu_bank_set_coeff(mlgpu_bank* b, int p, int idx, const float* h)
+  {
+    int st = checkSlot(b, p, idx, true);
+    if (st) return st;
+    if (!h) return fail(b->e, MLGPU_ERR_INVALID, "set_coeff: null");
+    return mlgpu_upload(b->e, b->d_coeffs + (size_t)(b->cOff[p] + idx) * b->V, h, sizeof(float) * b->V);
+  }
+  int mlgpu_bank_set_coeff_uniform(mlgpu_bank* b, int p, int idx, float value)
+  {
+    int st = checkSlot(b, p, idx, true);
+    if (st) return st;
+    uint32_t u;
+    memcpy(&u, &value, 4);
+    return mlgpu_fill32(b->e, b->d_coeffs + (size_t)(b->cOff[p] + idx) * b->V, u, b->V);
+  }
+  int mlgpu_bank_get_state(mlgpu_bank* b, int p, int idx, uint32_t* h)
+  {
+    int st = checkSlot(b, p, idx, false);
+    if (st) return st;
+    if (!h) return fail(b->e, MLGPU_ERR_INVALID, "get_state: null");
+    return mlgpu_download(b->e, h, b->d_state + (size_t)(b->sOff[p] + idx) * b->V, sizeof(uint32_t) * b->V);
+  }
+  int mlgpu_bank_set_state(mlgpu_bank* b, int p, int idx, const uint32_t* h)
+  {
+    int st = checkSlot(b, p, idx, false);
+    if (st) return st;
+    if (!h) return fail(b->e, MLGPU_ERR_INVALID, "set_state: null");
+    return mlgpu_upload(b->e, b->d_state + (size_t)(b->sOff[p] + idx) * b->V, h, sizeof(uint32_t) * b->V);
+  }
+  int mlgpu_bank_set_state_uniform(mlgpu_bank* b, int p, int idx, uint32_t value)
+  {
+    int st = checkSlot(b, p, idx, false);
+    if (st) return st;
+    return mlgpu_fill32(b->e, b->d_state + (size_t)(b->sOff[p] + idx) * b->V, value, b->V);
+  }
+  int mlgpu_bank_set_input_const(mlgpu_bank* b, const float* h)
+  {
+    if (!b) return MLGPU_ERR_INVALID;
+    if (!h) return fail(b->e, MLGPU_ERR_INVALID, "set_input_const: null");
+    return mlgpu_upload(b->e, b->d_inConst, h, sizeof(float) * b->V);
+  }
+
+  int mlgpu_bank_process(mlgpu_bank* b, size_t T, const float* d_in, int inLayout, float* d_out, int outLayout)
+  {
+    if (!b) return MLGPU_ERR_INVALID;
+    mlgpu_engine* e = b->e;
+    if (T == 0) return MLGPU_OK;
+    if (!d_out) return fail(e, MLGPU_ERR_INVALID, "bank_process: null output");
+    if (outLayout < 0 || outLayout > 2 || (d_in && (inLayout < 0 || inLayout > 2)))
+      return fail(e, MLGPU_ERR_INVALID, "bank_process: bad layout");
+    if ((((uintptr_t)d_out) | ((uintptr_t)d_in)) & 15) return fail(e, MLGPU_ERR_INVALID, "bank_process: signals must be 16-byte aligned");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const size_t V = b->V;
+
+    ChainArgs a;
+    a.V = V;
+    a.impulseTable = e->d_impulseTable;
+    a.inConst = b->d_inConst;
+
+    if (b->fused)
+    {
+      a.coeffs = b->d_coeffs;
+      a.state = b->d_state;
+      a.T = T;
+      a.in = makeView(d_in, inLayout, V, T);
+      a.out = makeView(d_out, outLayout, V, T);
+      hipError_t err = d_in ? b->fused->launchSignal(a, e->stream, e->cuCount) : b->fused->launchConst(a, e->stream, e->cuCount);
+      if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "bank_process launch", err);
+      return MLGPU_OK;
+    }
+
+    // unfused: processor by processor over slices of scratchVectors DSPVectors
+    const SignalView fullIn = makeView(d_in, inLayout, V, T);
+    const SignalView fullOut = makeView(d_out, outLayout, V, T);
+    const int nP = (int)b->kinds.size();
+    for (size_t t0 = 0; t0 < T; t0 += b->scratchVectors)
+    {
+      const size_t Tc = std::min(b->scratchVectors, T - t0);
+      for (int p = 0; p < nP; ++p)
+      {
+        a.coeffs = b->d_coeffs + (size_t)b->cOff[p] * V;
+        a.state = b->d_state + (size_t)b->sOff[p] * V;
+        a.T = Tc;
+        bool hasSignal;
+        if (p == 0)
+        {
+          hasSignal = (d_in != nullptr);
+          a.in = fullIn;
+          if (hasSignal) a.in.base = fullIn.base + t0 * fullIn.strideT;
+        }
+        else
+        {
+          hasSignal = true;
+          a.in = makeView(b->d_scratch[(p - 1) & 1], MLGPU_LAYOUT_QUAD, V, Tc);
+        }
+        if (p == nP - 1)
+        {
+          a.out = fullOut;
+          a.out.base = fullOut.base + t0 * fullOut.strideT;
+        }
+        else
+        {
+          a.out = makeView(b->d_scratch[p & 1], MLGPU_LAYOUT_QUAD, V, Tc);
+        }
+        const ChainEntry* ce = b->singles[p];
+        hipError_t err = hasSignal ? ce->launchSignal(a, e->stream, e->cuCount) : ce->launchConst(a, e->stream, e->cuCount);
+        if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "bank_process launch (unfused)", err);
+      }
+    }
+    return MLGPU_OK;
+  }
+}

@@ -1,0 +1,167 @@
+// chains.hip — voice-bank kernels: one wavefront lane per voice, DSPVectors walked serially.
+//
+// chain_kernel<Chain<K0,K1,...>> evaluates `pN(...p1(p0(x)))` for T DSPVectors of every voice in
+// ONE launch: the lane loads its voice's coefficients and state (SoA, coalesced 4 B/lane),
+// keeps them in VGPRs for the whole launch, produces 4 samples at a time and moves them with
+// one 16-byte access per lane (1 KiB per wavefront per instruction in the QUAD layout), then
+// writes the state back. Intermediate signals between processors never touch memory.
+// HBM traffic per voice-sample = 4 B out (+4 B in when a signal is streamed)
+// + (4*(NC+NS) read + 4*NS written)/(64*T) — DESIGN.md §Kernels.
+//
+// No LDS except the 17-tap ImpulseGen table (a genuinely shared coefficient table, staged once
+// per workgroup); no MFMA: the path is elementwise/recurrent, not a contraction.
+//
+// Compile with -ffp-contract=off (see mldsp_math.hpp).
+#include "mlgpu_internal.hpp"
+#include "mldsp_procs.hpp"
+
+using namespace mldev;
+
+namespace
+{
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChainBlock = 256;
+
+template <class CH, bool HAS_SIGNAL>
+__global__ __launch_bounds__(kChainBlock) void chain_kernel(const ChainArgs a)
+{
+  __shared__ float ldsTable[CH::kHasImpulse ? 32 : 1];
+  if constexpr (CH::kHasImpulse)
+  {
+    if (threadIdx.x < Proc<MLGPU_PROC_IMPULSE_GEN>::kTableSize) ldsTable[threadIdx.x] = a.impulseTable[threadIdx.x];
+    __syncthreads();
+  }
+  const size_t v = (size_t)blockIdx.x * kChainBlock + threadIdx.x;
+  if (v >= a.V) return;
+
+  CH ch;
+  const VoiceMem mem{a.coeffs + v, a.state + v, a.V};
+  const KernelTables tables{ldsTable};
+  ch.load(mem, tables);
+
+  const float xc = (!HAS_SIGNAL && a.inConst) ? a.inConst[v] : 0.f;
+  const f32x4* pin = HAS_SIGNAL ? (const f32x4*)a.in.base + v * a.in.strideV : nullptr;
+  f32x4* pout = (f32x4*)a.out.base + v * a.out.strideV;
+  const size_t inQ = a.in.strideQ, outQ = a.out.strideQ;
+
+  for (size_t t = 0; t < a.T; ++t)
+  {
+    const f32x4* pi = HAS_SIGNAL ? pin + t * a.in.strideT : nullptr;
+    f32x4* po = pout + t * a.out.strideT;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q)
+    {
+      f32x4 x = {xc, xc, xc, xc};
+      if constexpr (HAS_SIGNAL) x = __builtin_nontemporal_load(pi + q * inQ);
+      f32x4 y;
+      y.x = ch.next(x.x);
+      y.y = ch.next(x.y);
+      y.z = ch.next(x.z);
+      y.w = ch.next(x.w);
+      __builtin_nontemporal_store(y, po + q * outQ);
+    }
+    ch.end_vector();
+  }
+  ch.store(mem);
+}
+
+template <bool HAS_SIGNAL, int... KS>
+hipError_t launchChain(const ChainArgs& a, hipStream_t stream, int /*cuCount*/)
+{
+  const unsigned blocks = (unsigned)((a.V + kChainBlock - 1) / kChainBlock);
+  hipLaunchKernelGGL((chain_kernel<Chain<KS...>, HAS_SIGNAL>), dim3(blocks), dim3(kChainBlock), 0, stream, a);
+  return hipGetLastError();
+}
+
+template <int... KS>
+ChainEntry makeEntry(const char* name)
+{
+  ChainEntry e;
+  e.kinds = {KS...};
+  e.launchSignal = &launchChain<true, KS...>;
+  e.launchConst = &launchChain<false, KS...>;
+  e.kernelName = name;
+  e.nc = Chain<KS...>::NC;
+  e.ns = Chain<KS...>::NS;
+  return e;
+}
+
+#define P(x) MLGPU_PROC_##x
+
+const std::vector<ChainEntry>& registry()
+{
+  static const std::vector<ChainEntry> r = {
+      // every reference processor on its own (also the building blocks of unfused chains)
+      makeEntry<P(PHASOR_GEN)>("chain_kernel<PhasorGen>"),
+      makeEntry<P(SINE_GEN)>("chain_kernel<SineGen>"),
+      makeEntry<P(SAW_GEN)>("chain_kernel<SawGen>"),
+      makeEntry<P(PULSE_GEN)>("chain_kernel<PulseGen>"),
+      makeEntry<P(NOISE_GEN)>("chain_kernel<NoiseGen>"),
+      makeEntry<P(TICK_GEN)>("chain_kernel<TickGen>"),
+      makeEntry<P(IMPULSE_GEN)>("chain_kernel<ImpulseGen>"),
+      makeEntry<P(ONE_SHOT_GEN)>("chain_kernel<OneShotGen>"),
+      makeEntry<P(LOPASS)>("chain_kernel<Lopass>"),
+      makeEntry<P(HIPASS)>("chain_kernel<Hipass>"),
+      makeEntry<P(BANDPASS)>("chain_kernel<Bandpass>"),
+      makeEntry<P(LO_SHELF)>("chain_kernel<LoShelf>"),
+      makeEntry<P(HI_SHELF)>("chain_kernel<HiShelf>"),
+      makeEntry<P(BELL)>("chain_kernel<Bell>"),
+      makeEntry<P(ONE_POLE)>("chain_kernel<OnePole>"),
+      makeEntry<P(DC_BLOCKER)>("chain_kernel<DCBlocker>"),
+      makeEntry<P(DIFFERENTIATOR)>("chain_kernel<Differentiator>"),
+      makeEntry<P(INTEGRATOR)>("chain_kernel<Integrator>"),
+      makeEntry<P(PEAK)>("chain_kernel<Peak>"),
+      makeEntry<P(RMS)>("chain_kernel<RMS>"),
+      makeEntry<P(ADSR)>("chain_kernel<ADSR>"),
+      makeEntry<P(GAIN)>("chain_kernel<Gain>"),
+      // fused chains of the BASELINE.json configs
+      makeEntry<P(SINE_GEN), P(LOPASS)>("chain_kernel<SineGen,Lopass>"),                       // config 1
+      makeEntry<P(SAW_GEN), P(BANDPASS), P(GAIN)>("chain_kernel<SawGen,Bandpass,Gain>"),       // config 3
+      makeEntry<P(SAW_GEN), P(BANDPASS)>("chain_kernel<SawGen,Bandpass>"),
+      makeEntry<P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS)>(
+          "chain_kernel<Lopass x8>"),                                                          // config 4
+      makeEntry<P(NOISE_GEN), P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS), P(LOPASS),
+                P(LOPASS)>("chain_kernel<NoiseGen,Lopass x8>"),
+      // other common voices
+      makeEntry<P(PULSE_GEN), P(HIPASS), P(ONE_POLE)>("chain_kernel<PulseGen,Hipass,OnePole>"),
+      makeEntry<P(SAW_GEN), P(LOPASS), P(GAIN)>("chain_kernel<SawGen,Lopass,Gain>"),
+      makeEntry<P(SINE_GEN), P(GAIN)>("chain_kernel<SineGen,Gain>"),
+  };
+  return r;
+}
+}  // namespace
+
+const ChainEntry* mlgpu_find_chain(const int32_t* kinds, int n)
+{
+  for (const ChainEntry& e : registry())
+  {
+    if ((int)e.kinds.size() != n) continue;
+    bool same = true;
+    for (int i = 0; i < n; ++i) same = same && (e.kinds[i] == kinds[i]);
+    if (same) return &e;
+  }
+  return nullptr;
+}
+
+int mlgpu_proc_nc(int kind)
+{
+  const int32_t k = kind;
+  const ChainEntry* e = mlgpu_find_chain(&k, 1);
+  return e ? e->nc : -1;
+}
+int mlgpu_proc_ns(int kind)
+{
+  const int32_t k = kind;
+  const ChainEntry* e = mlgpu_find_chain(&k, 1);
+  return e ? e->ns : -1;
+}
+
+// state words of a default-constructed (cleared == false) or clear()ed reference object
+void mlgpu_proc_clear_state(int kind, uint32_t* words, bool cleared)
+{
+  const int ns = mlgpu_proc_ns(kind);
+  for (int i = 0; i < ns; ++i) words[i] = 0;
+  if (kind == MLGPU_PROC_SINE_GEN && cleared) words[0] = 0xC0000000u;  // kZeroPhase, MLDSPGens.h:375,379
+  if (kind == MLGPU_PROC_ADSR) words[7] = 4;                            // segment{off}, MLDSPFilters.h:700-702
+}

@@ -1,0 +1,284 @@
+// mldsp_math.hpp — per-lane float math of the mldsp.h hot path for gfx950.
+//
+// Hand-written device restatement of the arithmetic in the reference's
+// source/DSP/MLDSPMathSSE.h and the DEFINE_OP* families of source/DSP/MLDSPOps.h.
+// One wavefront lane evaluates one element; there are no cross-lane operations here.
+//
+// Numerical contract: every function returns the same bits as the
+// reference's SSE2 path, except the two hardware-approximate ops (sqrtApprox,
+// divideApprox: v_rsq_f32 / v_rcp_f32 here, rsqrtps / rcpps there; 2^-11 relative).
+// That requires (a) NO mul+add contraction — this translation unit is compiled with
+// -ffp-contract=off and every fused operation is spelled __builtin_fmaf explicitly where
+// it is provably bit-identical; (b) SSE semantics for min/max/convert, restated below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mldev
+{
+#define MLD __device__ __forceinline__
+
+MLD float u2f(uint32_t u) { return __uint_as_float(u); }
+MLD uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// _mm_min_ps / _mm_max_ps (MLDSPMathSSE.h:80-81): (a<b)?a:b / (a>b)?a:b, i.e. the SECOND
+// operand when either is NaN. Not fminf/fmaxf.
+MLD float sse_min(float a, float b) { return (a < b) ? a : b; }
+MLD float sse_max(float a, float b) { return (a > b) ? a : b; }
+
+// _mm_cvttps_epi32 / _mm_cvtps_epi32 (MLDSPMathSSE.h:124-125): NaN and out-of-range give
+// 0x80000000 ("integer indefinite"); v_cvt_i32_f32 would saturate / give 0 instead.
+MLD int32_t sse_cvtt(float x)
+{
+  const bool ok = (x < 2147483648.0f) && (x >= -2147483648.0f);
+  const int32_t r = (int32_t)(ok ? x : 0.0f);
+  return ok ? r : INT32_MIN;
+}
+MLD int32_t sse_cvt(float x)
+{
+  const bool ok = (x < 2147483648.0f) && (x >= -2147483648.0f);
+  const int32_t r = (int32_t)__builtin_rintf(ok ? x : 0.0f);  // v_rndne_f32 + v_cvt_i32_f32
+  return ok ? r : INT32_MIN;
+}
+// truncate when the caller has already bounded x inside int32 range
+MLD int32_t cvtt_inrange(float x) { return (int32_t)x; }
+
+// vecUnsignedIntToFloat, MLDSPMathSSE.h:130-135 (drops the LSB on purpose)
+MLD float uint_to_float(uint32_t v)
+{
+  const float hi = (float)(int32_t)(v >> 1);
+  return hi + hi;
+}
+
+MLD float abs_ps(float x) { return u2f(f2u(x) & 0x7FFFFFFFu); }  // vecAbs :86
+MLD float sign_ps(float x)                                        // vecSign :88-90
+{
+  const uint32_t s = (f2u(x) & 0x80000000u) | 0x3F800000u;
+  return u2f(!(x == -0.0f) ? s : 0u);
+}
+MLD float signbit_ps(float x) { return u2f((f2u(x) & 0x80000000u) | 0x3F800000u); }  // :92
+
+// ---------------------------------------------------------------------------------------
+// precise transcendentals — cephes via Pommier's sse_mathfun, MLDSPMathSSE.h:292-636.
+// Same operation order, separate mul and add.
+
+MLD float vec_log(float x)  // :308-373
+{
+  const bool invalid = (x <= 0.0f);
+  x = sse_max(x, u2f(0x00800000u));
+  int32_t emm0 = (int32_t)(f2u(x) >> 23);
+  x = u2f((f2u(x) & ~0x7f800000u) | 0x3f000000u);
+  emm0 -= 0x7f;
+  float e = (float)emm0;
+  e = e + 1.0f;
+  const bool mask = (x < 0.707106781186547524f);
+  float tmp = mask ? x : 0.0f;
+  x = x - 1.0f;
+  e = e - (mask ? 1.0f : 0.0f);
+  x = x + tmp;
+  const float z = x * x;
+  float y = 7.0376836292E-2f;
+  y = y * x;
+  y = y + -1.1514610310E-1f;
+  y = y * x;
+  y = y + 1.1676998740E-1f;
+  y = y * x;
+  y = y + -1.2420140846E-1f;
+  y = y * x;
+  y = y + 1.4249322787E-1f;
+  y = y * x;
+  y = y + -1.6668057665E-1f;
+  y = y * x;
+  y = y + 2.0000714765E-1f;
+  y = y * x;
+  y = y + -2.4999993993E-1f;
+  y = y * x;
+  y = y + 3.3333331174E-1f;
+  y = y * x;
+  y = y * z;
+  tmp = e * -2.12194440e-4f;
+  y = y + tmp;
+  tmp = z * 0.5f;
+  y = y - tmp;
+  tmp = e * 0.693359375f;
+  x = x + y;
+  x = x + tmp;
+  return invalid ? u2f(0xFFFFFFFFu) : x;  // x | invalid_mask
+}
+
+MLD float vec_exp(float x)  // :389-440
+{
+  x = sse_min(x, 88.3762626647949f);
+  x = sse_max(x, -88.3762626647949f);
+  float fx = x * 1.44269504088896341f;
+  fx = fx + 0.5f;
+  int32_t emm0 = cvtt_inrange(fx);  // |fx| <= 128
+  float tmp = (float)emm0;
+  const float mask = (tmp > fx) ? 1.0f : 0.0f;
+  fx = tmp - mask;
+  tmp = fx * 0.693359375f;
+  float z = fx * -2.12194440e-4f;
+  x = x - tmp;
+  x = x - z;
+  z = x * x;
+  float y = 1.9875691500E-4f;
+  y = y * x;
+  y = y + 1.3981999507E-3f;
+  y = y * x;
+  y = y + 8.3334519073E-3f;
+  y = y * x;
+  y = y + 4.1665795894E-2f;
+  y = y * x;
+  y = y + 1.6666665459E-1f;
+  y = y * x;
+  y = y + 5.0000001201E-1f;
+  y = y * z;
+  y = y + x;
+  y = y + 1.0f;
+  emm0 = cvtt_inrange(fx);
+  const uint32_t p = ((uint32_t)emm0 + 0x7fu) << 23;
+  return y * u2f(p);
+}
+
+// both cephes polynomials evaluated, then masked: :520-557 / :603-633
+MLD float sincos_poly(float x, bool poly_mask, uint32_t sign_bit)
+{
+  const float z = x * x;
+  float y = 2.443315711809948E-005f;
+  y = y * z;
+  y = y + -1.388731625493765E-003f;
+  y = y * z;
+  y = y + 4.166664568298827E-002f;
+  y = y * z;
+  y = y * z;
+  const float tmp = z * 0.5f;
+  y = y - tmp;
+  y = y + 1.0f;
+  float y2 = -1.9515295891E-4f;
+  y2 = y2 * z;
+  y2 = y2 + 8.3321608736E-3f;
+  y2 = y2 * z;
+  y2 = y2 + -1.6666654611E-1f;
+  y2 = y2 * z;
+  y2 = y2 * x;
+  y2 = y2 + x;
+  y2 = poly_mask ? y2 : 0.0f;
+  y = poly_mask ? 0.0f : y;
+  y = y + y2;
+  return u2f(f2u(y) ^ sign_bit);
+}
+
+MLD float vec_sin(float x)  // :479-559
+{
+  uint32_t sign_bit = f2u(x) & 0x80000000u;
+  x = abs_ps(x);
+  float y = x * 1.27323954473516f;
+  int32_t emm2 = sse_cvtt(y);
+  emm2 = (int32_t)(((uint32_t)emm2 + 1u) & ~1u);
+  y = (float)emm2;
+  const uint32_t emm0 = ((uint32_t)emm2 & 4u) << 29;
+  const bool poly_mask = (((uint32_t)emm2 & 2u) == 0u);
+  sign_bit ^= emm0;
+  const float xmm1 = y * -0.78515625f;
+  const float xmm2 = y * -2.4187564849853515625e-4f;
+  const float xmm3 = y * -3.77489497744594108e-8f;
+  x = x + xmm1;
+  x = x + xmm2;
+  x = x + xmm3;
+  return sincos_poly(x, poly_mask, sign_bit);
+}
+
+MLD float vec_cos(float x)  // :562-636
+{
+  x = abs_ps(x);
+  float y = x * 1.27323954473516f;
+  int32_t emm2 = sse_cvtt(y);
+  emm2 = (int32_t)(((uint32_t)emm2 + 1u) & ~1u);
+  y = (float)emm2;
+  emm2 = (int32_t)((uint32_t)emm2 - 2u);
+  const uint32_t emm0 = (~(uint32_t)emm2 & 4u) << 29;
+  const bool poly_mask = (((uint32_t)emm2 & 2u) == 0u);
+  const float xmm1 = y * -0.78515625f;
+  const float xmm2 = y * -2.4187564849853515625e-4f;
+  const float xmm3 = y * -3.77489497744594108e-8f;
+  x = x + xmm1;
+  x = x + xmm2;
+  x = x + xmm3;
+  return sincos_poly(x, poly_mask, emm0);
+}
+
+// ---------------------------------------------------------------------------------------
+// approximate transcendentals — Horner polynomials, MLDSPMathSSE.h:752-864.
+// Valid on [-pi, pi] with no range reduction, exactly like the reference.
+
+MLD float vec_sin_approx(float x)  // :752-772
+{
+  const float x2 = x * x;
+  float p = x2 * 2.147840177713078446686267852783203125e-6f;
+  p = -1.92649182281456887722015380859375e-4f + p;
+  p = x2 * p;
+  p = 8.30897875130176544189453125e-3f + p;
+  p = x2 * p;
+  p = -0.166624367237091064453125f + p;
+  p = x2 * p;
+  p = 0.99997937679290771484375f + p;
+  return x * p;
+}
+MLD float vec_cos_approx(float x)  // :774-792
+{
+  const float x2 = x * x;
+  float p = x2 * 1.8791708498611114919185638427734375e-5f;
+  p = -1.33926304988563060760498046875e-3f + p;
+  p = x2 * p;
+  p = 4.1496001183986663818359375e-2f + p;
+  p = x2 * p;
+  p = -0.4997930824756622314453125f + p;
+  p = x2 * p;
+  return 0.999959766864776611328125f + p;
+}
+MLD float vec_exp_approx(float x)  // :793-829
+{
+  const float val2 = x * 12102203.1615614f + 1065353216.f;
+  const float val3 = sse_min(val2, 2139095040.f);
+  const float val4 = sse_max(val3, 0.0f);
+  const uint32_t val4i = (uint32_t)cvtt_inrange(val4);  // 0 <= val4 <= 2139095040 < 2^31
+  const float xu = u2f(val4i & 0x7F800000u);
+  const float b = u2f((val4i & 0x7FFFFFu) | 0x3F800000u);
+  float p = b * 1.3671023382430374383648148e-2f;
+  p = -2.88093587581985443087955e-3f + p;
+  p = b * p;
+  p = 0.168143436463395944830000f + p;
+  p = b * p;
+  p = 0.310670891004095530771135f + p;
+  p = b * p;
+  p = 0.510397365625862338668154f + p;
+  return xu * p;
+}
+MLD float vec_log_approx(float val)  // :831-864
+{
+  const uint32_t vi = f2u(val);
+  const int32_t expi = (int32_t)(vi >> 23);
+  const float addcst = (val > 0.0f) ? -89.970756366f : 1.17549435e-38f /* FLT_MIN */;
+  const float x = u2f((vi & 0x7FFFFFu) | 0x3F800000u);
+  float p = x * 3.110401639e-2f;
+  p = -0.288739945f + p;
+  p = x * p;
+  p = 1.130626167f + p;
+  p = x * p;
+  p = -2.461222105f + p;
+  p = x * p;
+  p = 3.529304993f + p;
+  p = x * p;
+  const float addCstResult = addcst + 0.69314718055995f * (float)expi;
+  return p + addCstResult;
+}
+
+constexpr float kLogTwo = 0.69314718055994529f;   // MLDSPOps.h:601
+constexpr float kLogTwoR = 1.4426950408889634f;   // MLDSPOps.h:602
+
+// hardware-approximate forms (reference: rsqrtps / rcpps, 12-bit). gfx950 v_rsq_f32 /
+// v_rcp_f32 are ~1 ulp, i.e. well inside the reference's own 1.5*2^-12 error band.
+MLD float sqrt_approx(float x) { return x * __builtin_amdgcn_rsqf(x); }          // :84-85
+MLD float div_approx(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }  // :79
+
+}  // namespace mldev

@@ -1,0 +1,669 @@
+// mldsp_procs.hpp — the stateful processors of mldsp.h as per-lane, per-sample device objects.
+//
+// Each struct restates one reference functor (source/DSP/MLDSPGens.h, MLDSPFilters.h):
+//   load()   coefficients + state  HBM (SoA [slot][V]) -> registers
+//   next(x)  one sample; x is the processor's audio-rate input (cyclesPerSample for
+//            generators, exactly the reference's operator() argument)
+//   end_vector()  bookkeeping the reference does once per 64-sample DSPVector
+//   store()  state registers -> HBM
+// One wavefront lane owns one voice for the whole launch, so state never leaves
+// registers while the DSPVectors are walked serially.
+//
+// Bit-parity notes are marked PARITY. This file must be compiled with -ffp-contract=off.
+#pragma once
+#include "mldsp_math.hpp"
+#include "../../include/mlgpu.h"
+
+namespace mldev
+{
+// coefficient / state views of one voice: element i of this processor lives at base[i*V]
+struct VoiceMem
+{
+  const float* coeffs;  // already offset to (this processor's first slot)*V + v
+  uint32_t* state;      // idem
+  size_t V;
+  MLD float c(int i) const { return coeffs[(size_t)i * V]; }
+  MLD uint32_t s(int i) const { return state[(size_t)i * V]; }
+  MLD void set(int i, uint32_t x) const { state[(size_t)i * V] = x; }
+};
+
+struct KernelTables
+{
+  const float* impulse_table;  // 17 floats, built on the host with libm (MLDSPGens.h:65-78)
+};
+
+constexpr float kStepsPerCycle = 4294967296.0f;            // MLDSPGens.h:184  2^32
+constexpr float kCyclesPerStep = 2.3283064365386963e-10f;  // MLDSPGens.h:185  2^-32
+
+// PARITY: const_math::sqrt(2.0f) in the reference is itself an approximation (0x3fb50505,
+// not 0x3fb504f3); these are the reference's constexpr results (MLDSPGens.h:318-327).
+constexpr uint32_t kSqrt2Bits = 0x3fb50505u;
+constexpr uint32_t kSineDomainBits = 0x40b50505u;
+constexpr uint32_t kSineScaleBits = 0x3f87c3b6u;
+constexpr uint32_t kSineFlipBits = 0x40350505u;
+constexpr uint32_t kOneSixthBits = 0x3e2aaaabu;
+
+// PhasorGen core, MLDSPGens.h:187-203
+MLD float phasor_next(uint32_t& omega32, float cyclesPerSample)
+{
+  const float steps = cyclesPerSample * kStepsPerCycle;
+  const int32_t istep = sse_cvt(steps);  // roundFloatToInt; loop-invariant when cps is
+  omega32 += (uint32_t)istep;
+  return uint_to_float(omega32) * kCyclesPerStep;
+}
+
+// polyBLEP, MLDSPGens.h:285-311. Branch-free restatement: exactly one of the two
+// divisions of the reference is ever taken for a sample, so select the numerator first,
+// divide once (IEEE-correct v_div sequence), then select the polynomial.
+MLD float poly_blep(float t, float dt)
+{
+  const bool lo = (t < dt);
+  const bool hi = !lo && (t > 1.0f - dt);
+  float c = 0.f;
+  if (lo || hi)
+  {
+    const float num = lo ? t : (t - 1.0f);
+    const float q = num / dt;
+    const float qq = q * q;
+    const float q2 = q + q;
+    // lo: t + t - t*t - 1 ; hi: t*t + t + t + 1   (left-assoc as written in the reference)
+    c = lo ? ((q2 - qq) - 1.0f) : (((qq + q) + q) + 1.0f);
+  }
+  return c;
+}
+
+MLD float phasor_to_sine(float p)  // MLDSPGens.h:316-338
+{
+  const float sqrt2 = u2f(kSqrt2Bits);
+  const float omega = p * u2f(kSineDomainBits) + (-sqrt2);
+  const float tri = (omega > sqrt2) ? (u2f(kSineFlipBits) - omega) : omega;
+  return (u2f(kSineScaleBits) * tri) * (1.0f - (tri * tri) * u2f(kOneSixthBits));
+}
+
+template <int KIND>
+struct Proc;
+
+// ---- generators -----------------------------------------------------------------------
+
+template <>
+struct Proc<MLGPU_PROC_PHASOR_GEN>
+{
+  static constexpr int NC = 0, NS = 1;
+  uint32_t omega32;
+  MLD void load(const VoiceMem& m, const KernelTables&) { omega32 = m.s(0); }
+  MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
+  MLD float next(float cps) { return phasor_next(omega32, cps); }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_SINE_GEN>  // MLDSPGens.h:373-381
+{
+  static constexpr int NC = 0, NS = 1;
+  uint32_t omega32;
+  MLD void load(const VoiceMem& m, const KernelTables&) { omega32 = m.s(0); }
+  MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
+  MLD float next(float cps) { return phasor_to_sine(phasor_next(omega32, cps)); }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_SAW_GEN>  // MLDSPGens.h:395-402, phasorToSaw :362-369
+{
+  static constexpr int NC = 0, NS = 1;
+  uint32_t omega32;
+  MLD void load(const VoiceMem& m, const KernelTables&) { omega32 = m.s(0); }
+  MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
+  MLD float next(float cps)
+  {
+    const float p = phasor_next(omega32, cps);
+    const float saw = p * 2.f - 1.f;
+    return saw - poly_blep(p, cps);
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-358
+{
+  static constexpr int NC = 1, NS = 1;
+  uint32_t omega32;
+  float width;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    width = m.c(0);
+    omega32 = m.s(0);
+  }
+  MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
+  MLD float next(float cps)
+  {
+    const float p = phasor_next(omega32, cps);
+    float pulse = (p >= width) ? -1.f : 1.f;
+    pulse = pulse + poly_blep(p, cps);
+    const float d = p - width + 1.0f;
+    const float down = d - (float)sse_cvtt(d);  // fractionalPart
+    pulse = pulse - poly_blep(down, cps);
+    return pulse;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_NOISE_GEN>  // MLDSPGens.h:109-148
+{
+  static constexpr int NC = 0, NS = 1;
+  uint32_t seed;
+  MLD void load(const VoiceMem& m, const KernelTables&) { seed = m.s(0); }
+  MLD void store(const VoiceMem& m) const { m.set(0, seed); }
+  MLD float next(float)
+  {
+    seed = seed * 0x0019660Du + 0x3C6EF35Fu;
+    const uint32_t temp = ((seed >> 9) & 0x007FFFFFu) | 0x3F800000u;
+    return u2f(temp) * 2.f - 3.f;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_TICK_GEN>  // MLDSPGens.h:24-47
+{
+  static constexpr int NC = 0, NS = 1;
+  float omega;
+  MLD void load(const VoiceMem& m, const KernelTables&) { omega = u2f(m.s(0)); }
+  MLD void store(const VoiceMem& m) const { m.set(0, f2u(omega)); }
+  MLD float next(float cps)
+  {
+    float y = 0.f;
+    omega += cps;
+    if (omega > 1.0f)
+    {
+      omega -= 1.0f;
+      y = 1.0f;
+    }
+    return y;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_IMPULSE_GEN>  // MLDSPGens.h:53-104; table staged through LDS by the kernel
+{
+  static constexpr int NC = 0, NS = 2;
+  static constexpr int kTableSize = 17;
+  float omega;
+  int32_t counter;
+  const float* table;  // LDS copy of the 17-tap windowed sinc
+  MLD void load(const VoiceMem& m, const KernelTables& t)
+  {
+    omega = u2f(m.s(0));
+    counter = (int32_t)m.s(1);
+    table = t.impulse_table;
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(omega));
+    m.set(1, (uint32_t)counter);
+  }
+  MLD float next(float cps)
+  {
+    float y = 0.f;
+    omega += cps;
+    if (omega > 1.0f)
+    {
+      omega -= 1.0f;
+      counter = 0;
+    }
+    if (counter < kTableSize)
+    {
+      y = table[counter];
+      counter++;
+    }
+    return y;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_ONE_SHOT_GEN>  // MLDSPGens.h:221-282
+{
+  static constexpr int NC = 0, NS = 3;
+  uint32_t omega32, gate, prev;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    omega32 = m.s(0);
+    gate = m.s(1);
+    prev = m.s(2);
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, omega32);
+    m.set(1, gate);
+    m.set(2, prev);
+  }
+  MLD float next(float cps)
+  {
+    const float steps = cps * kStepsPerCycle;
+    const int32_t istep = sse_cvt(steps);
+    omega32 += (uint32_t)istep * gate;
+    if (omega32 < prev)
+    {
+      gate = 0;
+      omega32 = 0;
+    }
+    prev = omega32;
+    return uint_to_float(omega32) * kCyclesPerStep;
+  }
+  MLD void end_vector() {}
+};
+
+// ---- SVF family (Simper), MLDSPFilters.h:51-442 ------------------------------------------
+//
+// PARITY: `ic1eq += 2.0f * t1` is evaluated as fma(2, t1, ic1eq): 2*t1 is exact in binary
+// floating point (barring overflow, where both forms give inf), so the fused form rounds
+// the same real number once and is bit-identical to mul-then-add — and one VALU op cheaper.
+// Likewise `2 * v1 - ic1eq` == fma(2, v1, -ic1eq).
+
+template <int KIND>
+struct SvfCore
+{
+  static constexpr int NC = (KIND == MLGPU_PROC_HIPASS) ? 4 : 3;
+  static constexpr int NS = 2;
+  float g0, g1, g2, k;
+  float ic1eq, ic2eq;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    g0 = m.c(0);
+    g1 = m.c(1);
+    g2 = m.c(2);
+    k = (KIND == MLGPU_PROC_HIPASS) ? m.c(3) : 0.f;
+    ic1eq = u2f(m.s(0));
+    ic2eq = u2f(m.s(1));
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(ic1eq));
+    m.set(1, f2u(ic2eq));
+  }
+  MLD float next(float v0)
+  {
+    const float t0 = v0 - ic2eq;
+    const float t1 = g0 * t0 + g1 * ic1eq;
+    const float t2 = g2 * t0 + g0 * ic1eq;
+    float y;
+    if (KIND == MLGPU_PROC_LOPASS)
+    {
+      y = t2 + ic2eq;  // v2, :128-131
+    }
+    else if (KIND == MLGPU_PROC_BANDPASS)
+    {
+      y = t1 + ic1eq;  // v1, :234-237
+    }
+    else
+    {
+      const float v1 = t1 + ic1eq;
+      const float v2 = t2 + ic2eq;
+      y = v0 - k * v1 - v2;  // :189-193
+    }
+    ic1eq = __builtin_fmaf(2.0f, t1, ic1eq);
+    ic2eq = __builtin_fmaf(2.0f, t2, ic2eq);
+    return y;
+  }
+  MLD void end_vector() {}
+};
+template <>
+struct Proc<MLGPU_PROC_LOPASS> : SvfCore<MLGPU_PROC_LOPASS>
+{
+};
+template <>
+struct Proc<MLGPU_PROC_HIPASS> : SvfCore<MLGPU_PROC_HIPASS>
+{
+};
+template <>
+struct Proc<MLGPU_PROC_BANDPASS> : SvfCore<MLGPU_PROC_BANDPASS>
+{
+};
+
+template <int KIND>
+struct ShelfCore  // LoShelf :288-302, HiShelf :369-383, Bell :427-441
+{
+  static constexpr int NC = (KIND == MLGPU_PROC_LO_SHELF) ? 5 : (KIND == MLGPU_PROC_HI_SHELF ? 6 : 4);
+  static constexpr int NS = 2;
+  float a1, a2, a3, m0, m1, m2;
+  float ic1eq, ic2eq;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    a1 = m.c(0);
+    a2 = m.c(1);
+    a3 = m.c(2);
+    m0 = m1 = m2 = 0.f;
+    if (KIND == MLGPU_PROC_LO_SHELF)
+    {
+      m1 = m.c(3);
+      m2 = m.c(4);
+    }
+    else if (KIND == MLGPU_PROC_HI_SHELF)
+    {
+      m0 = m.c(3);
+      m1 = m.c(4);
+      m2 = m.c(5);
+    }
+    else
+    {
+      m1 = m.c(3);
+    }
+    ic1eq = u2f(m.s(0));
+    ic2eq = u2f(m.s(1));
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(ic1eq));
+    m.set(1, f2u(ic2eq));
+  }
+  MLD float next(float v0)
+  {
+    const float v3 = v0 - ic2eq;
+    const float v1 = a1 * ic1eq + a2 * v3;
+    const float v2 = ic2eq + a2 * ic1eq + a3 * v3;
+    ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
+    ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
+    if (KIND == MLGPU_PROC_LO_SHELF) return v0 + m1 * v1 + m2 * v2;
+    if (KIND == MLGPU_PROC_HI_SHELF) return m0 * v0 + m1 * v1 + m2 * v2;
+    return v0 + m1 * v1;
+  }
+  MLD void end_vector() {}
+};
+template <>
+struct Proc<MLGPU_PROC_LO_SHELF> : ShelfCore<MLGPU_PROC_LO_SHELF>
+{
+};
+template <>
+struct Proc<MLGPU_PROC_HI_SHELF> : ShelfCore<MLGPU_PROC_HI_SHELF>
+{
+};
+template <>
+struct Proc<MLGPU_PROC_BELL> : ShelfCore<MLGPU_PROC_BELL>
+{
+};
+
+// ---- one-state recurrences, MLDSPFilters.h:446-653 ----------------------------------------
+
+template <>
+struct Proc<MLGPU_PROC_ONE_POLE>  // :446-481
+{
+  static constexpr int NC = 2, NS = 1;
+  float a0, b1, y1;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    a0 = m.c(0);
+    b1 = m.c(1);
+    y1 = u2f(m.s(0));
+  }
+  MLD void store(const VoiceMem& m) const { m.set(0, f2u(y1)); }
+  MLD float next(float x)
+  {
+    y1 = a0 * x + b1 * y1;
+    return y1;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_DC_BLOCKER>  // :489-513
+{
+  static constexpr int NC = 1, NS = 2;
+  float c, x1, y1;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    c = m.c(0);
+    x1 = u2f(m.s(0));
+    y1 = u2f(m.s(1));
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(x1));
+    m.set(1, f2u(y1));
+  }
+  MLD float next(float x0)
+  {
+    const float y0 = x0 - x1 + c * y1;
+    y1 = y0;
+    x1 = x0;
+    return y0;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_DIFFERENTIATOR>  // :517-535
+{
+  static constexpr int NC = 0, NS = 1;
+  float x1;
+  MLD void load(const VoiceMem& m, const KernelTables&) { x1 = u2f(m.s(0)); }
+  MLD void store(const VoiceMem& m) const { m.set(0, f2u(x1)); }
+  MLD float next(float x)
+  {
+    const float y = x - x1;
+    x1 = x;
+    return y;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_INTEGRATOR>  // :539-558
+{
+  static constexpr int NC = 1, NS = 1;
+  float leak, y1;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    leak = m.c(0);
+    y1 = u2f(m.s(0));
+  }
+  MLD void store(const VoiceMem& m) const { m.set(0, f2u(y1)); }
+  MLD float next(float x)
+  {
+    y1 -= y1 * leak;
+    y1 += x;
+    return y1;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_PEAK>  // :562-615; counter decrements once per DSPVector (:607-610)
+{
+  static constexpr int NC = 3, NS = 2;
+  float a0, b1, y1;
+  int32_t hold, counter;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    a0 = m.c(0);
+    b1 = m.c(1);
+    hold = (int32_t)f2u(m.c(2));
+    y1 = u2f(m.s(0));
+    counter = (int32_t)m.s(1);
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(y1));
+    m.set(1, (uint32_t)counter);
+  }
+  MLD float next(float x)
+  {
+    const float xsq = x * x;
+    if (xsq > y1)
+    {
+      y1 = xsq;
+      counter = hold;
+    }
+    else if (counter <= 0)
+    {
+      y1 = a0 * xsq + b1 * y1;
+    }
+    return (y1 > 1e-20f) ? sqrt_approx(y1) : 0.f;
+  }
+  MLD void end_vector()
+  {
+    if (counter > 0) counter -= MLGPU_FLOATS_PER_DSPVECTOR;
+  }
+};
+
+template <>
+struct Proc<MLGPU_PROC_RMS>  // :619-653
+{
+  static constexpr int NC = 2, NS = 1;
+  float a0, b1, y1;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    a0 = m.c(0);
+    b1 = m.c(1);
+    y1 = u2f(m.s(0));
+  }
+  MLD void store(const VoiceMem& m) const { m.set(0, f2u(y1)); }
+  MLD float next(float x)
+  {
+    const float xsq = x * x;
+    y1 = a0 * xsq + b1 * y1;
+    return (y1 > 1e-20f) ? sqrt_approx(y1) : 0.f;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_ADSR>  // :657-797
+{
+  static constexpr int NC = 4, NS = 8;
+  enum { A = 0, D = 1, S = 2, R = 3, off = 4 };
+  float ka, kd, s, kr;
+  float y, y1, x1, threshold, target, k, amp;
+  int32_t segment;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    ka = m.c(0);
+    kd = m.c(1);
+    s = m.c(2);
+    kr = m.c(3);
+    y = u2f(m.s(0));
+    y1 = u2f(m.s(1));
+    x1 = u2f(m.s(2));
+    threshold = u2f(m.s(3));
+    target = u2f(m.s(4));
+    k = u2f(m.s(5));
+    amp = u2f(m.s(6));
+    segment = (int32_t)m.s(7);
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(y));
+    m.set(1, f2u(y1));
+    m.set(2, f2u(x1));
+    m.set(3, f2u(threshold));
+    m.set(4, f2u(target));
+    m.set(5, f2u(k));
+    m.set(6, f2u(amp));
+    m.set(7, (uint32_t)segment);
+  }
+  MLD float next(float x)  // processSample :704-786
+  {
+    if ((segment == off) && (x == 0.f)) return 0.f;
+    const bool crossed = ((y1 > threshold) != (y > threshold));
+    bool recalc = false;
+    if (crossed && (segment < off))
+    {
+      segment++;
+      recalc = true;
+    }
+    const bool trigOn = (x1 == 0.f) && (x > 0.f);
+    const bool trigOff = (x1 > 0.f) && (x == 0.f);
+    if (trigOn)
+    {
+      segment = A;
+      amp = x;
+      recalc = true;
+    }
+    else if (trigOff)
+    {
+      segment = R;
+      recalc = true;
+    }
+    if (recalc)
+    {
+      float startEnv = 0.f, endEnv = 0.f;
+      switch (segment)
+      {
+        case A: startEnv = 0.f; endEnv = 1.f; k = ka; break;
+        case D: startEnv = 1.f; endEnv = s; k = kd; break;
+        case S: startEnv = s; endEnv = s; k = 0.f; y1 = s; y = s; break;
+        case R: startEnv = s; endEnv = 0.f; k = kr; break;
+        default: startEnv = 0.f; endEnv = 0.f; k = 0.f; y1 = 0.f; y = 0.f; break;
+      }
+      const float segmentBias = (endEnv - startEnv) * 0.1f;
+      threshold = endEnv;
+      target = endEnv + segmentBias;
+    }
+    x1 = x;
+    y1 = y;
+    y = y + k * (target - y);
+    return y * amp;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_GAIN>  // x * DSPVector(gain), MLDSPOps.h:157,345-348
+{
+  static constexpr int NC = 1, NS = 0;
+  float gain;
+  MLD void load(const VoiceMem& m, const KernelTables&) { gain = m.c(0); }
+  MLD void store(const VoiceMem&) const {}
+  MLD float next(float x) { return x * gain; }
+  MLD void end_vector() {}
+};
+
+// ---- compile-time chains -------------------------------------------------------------------
+
+template <int... KINDS>
+struct Chain;
+
+template <>
+struct Chain<>
+{
+  static constexpr int NC = 0, NS = 0;
+  static constexpr bool kHasImpulse = false;
+  MLD void load(VoiceMem, const KernelTables&) {}
+  MLD void store(VoiceMem) const {}
+  MLD float next(float x) { return x; }
+  MLD void end_vector() {}
+};
+
+template <int K0, int... KS>
+struct Chain<K0, KS...>
+{
+  Proc<K0> head;
+  Chain<KS...> tail;
+  static constexpr int NC = Proc<K0>::NC + Chain<KS...>::NC;
+  static constexpr int NS = Proc<K0>::NS + Chain<KS...>::NS;
+  static constexpr bool kHasImpulse = (K0 == MLGPU_PROC_IMPULSE_GEN) || Chain<KS...>::kHasImpulse;
+  MLD void load(VoiceMem m, const KernelTables& t)
+  {
+    head.load(m, t);
+    m.coeffs += (size_t)Proc<K0>::NC * m.V;
+    m.state += (size_t)Proc<K0>::NS * m.V;
+    tail.load(m, t);
+  }
+  MLD void store(VoiceMem m) const
+  {
+    head.store(m);
+    m.coeffs += (size_t)Proc<K0>::NC * m.V;
+    m.state += (size_t)Proc<K0>::NS * m.V;
+    tail.store(m);
+  }
+  MLD float next(float x) { return tail.next(head.next(x)); }
+  MLD void end_vector()
+  {
+    head.end_vector();
+    tail.end_vector();
+  }
+};
+
+}  // namespace mldev

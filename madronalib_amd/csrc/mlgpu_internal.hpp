@@ -1,0 +1,83 @@
+// mlgpu_internal.hpp — shared between the translation units of libmlgpu.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mlgpu.h"
+
+struct mlgpu_engine
+{
+  int device{0};
+  hipStream_t stream{nullptr};
+  bool ownsStream{false};
+  int cuCount{256};
+  std::string lastError;
+  float* d_impulseTable{nullptr};  // 17 floats (ImpulseGen windowed sinc), built on the host
+  hipEvent_t ev0{nullptr}, ev1{nullptr};
+};
+
+// signal addressing in float4 units: element (vector t, quad q, voice v) at
+//   base + t*strideT + q*strideQ + v*strideV        (see mlgpu_layout in mlgpu.h)
+struct SignalView
+{
+  float4* base;
+  size_t strideT, strideQ, strideV;
+};
+inline SignalView makeView(const float* p, int layout, size_t V, size_t T)
+{
+  SignalView s;
+  s.base = (float4*)p;
+  switch (layout)
+  {
+    case MLGPU_LAYOUT_QUAD: s.strideT = 16 * V; s.strideQ = V; s.strideV = 1; break;
+    case MLGPU_LAYOUT_ROWS: s.strideT = 16 * V; s.strideQ = 1; s.strideV = 16; break;
+    default: /* VOICE_MAJOR */ s.strideT = 16; s.strideQ = 1; s.strideV = 16 * T; break;
+  }
+  return s;
+}
+
+struct ChainArgs
+{
+  const float* coeffs;  // [NC][V]
+  uint32_t* state;      // [NS][V]
+  const float* inConst; // [V] or nullptr
+  SignalView in;        // base == nullptr when no streamed input
+  SignalView out;
+  size_t V, T;
+  const float* impulseTable;
+};
+
+typedef hipError_t (*ChainLauncher)(const ChainArgs& a, hipStream_t stream, int cuCount);
+
+struct ChainEntry
+{
+  std::vector<int> kinds;
+  ChainLauncher launchSignal;  // streamed input
+  ChainLauncher launchConst;   // per-voice constant (or no) input
+  const char* kernelName;
+  int nc, ns;
+};
+
+// chains.hip
+const ChainEntry* mlgpu_find_chain(const int32_t* kinds, int n);
+int mlgpu_proc_nc(int kind);  // -1 if unknown
+int mlgpu_proc_ns(int kind);
+void mlgpu_proc_clear_state(int kind, uint32_t* words /*[ns]*/, bool cleared);
+
+// ops.hip
+hipError_t mlgpu_launch_op(int op, const void* a, const void* b, const void* c, void* out, size_t n,
+                           hipStream_t stream, int cuCount, bool* known);
+hipError_t mlgpu_launch_op_rows1(int op, const void* a, const void* b64, void* out, size_t nRows,
+                                 hipStream_t stream, int cuCount, bool* known);
+hipError_t mlgpu_launch_row_reduce(int rowop, const float* rows, float* out, size_t nRows,
+                                   hipStream_t stream, bool* known);
+hipError_t mlgpu_launch_layout_convert(const float* src, int srcLayout, float* dst, int dstLayout, size_t V,
+                                       size_t T, hipStream_t stream);
+hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStream_t stream);
+
+// coeffs.cpp
+void mlgpu_build_impulse_table(float* out17);

@@ -1,0 +1,94 @@
+"""CPU-side checks of the C-ABI library: it builds for gfx950, loads, exports every symbol that
+include/mlgpu.h declares, its enums match the Python mirror, the host-side coefficient makers
+match the oracle, and without a GPU every compute entry fails loudly (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from madronalib_amd import _lib, constants
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mlgpu.h")
+
+
+def _header():
+    with open(HEADER) as f:
+        return f.read()
+
+
+def test_library_builds_and_loads():
+    L = _lib.load()
+    assert os.path.exists(_lib.LIB_PATH)
+    assert L.mlgpu_abi_version() == 1
+
+
+def test_every_declared_symbol_is_exported():
+    L = _lib.load()
+    src = re.sub(r"/\*.*?\*/", "", _header(), flags=re.S)
+    names = set(re.findall(r"\b(mlgpu_[a-z0-9_]+)\s*\(", src))
+    assert len(names) > 40
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_code_object_is_gfx950():
+    data = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    assert b"chain_kernel" in data and b"op_kernel" in data
+
+
+def test_python_enums_match_header():
+    h = _header()
+    vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(MLGPU_[A-Z0-9_]+)\s*=\s*(\d+)", h)}
+    for cls, prefix in ((constants.Op, "MLGPU_OP_"), (constants.Proc, "MLGPU_PROC_"), (constants.Layout, "MLGPU_LAYOUT_"),
+                        (constants.RowOp, "MLGPU_ROWOP_"), (constants.Status, "MLGPU_")):
+        for k, v in vars(cls).items():
+            if k.startswith("_") or not isinstance(v, int):
+                continue
+            assert vals[prefix + k] == v, (prefix + k, v)
+    hdr_procs = {v for k, v in vals.items() if k.startswith("MLGPU_PROC_")}
+    assert hdr_procs == set(constants.Proc.ALL)
+
+
+def test_coefficient_makers_match_oracle(oracle):
+    import madronalib_amd as ml
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        om, k, A = rng.uniform(0.0005, 0.49), rng.uniform(0.01, 3), rng.uniform(0.1, 8)
+        assert (ml.Lopass.makeCoeffs(om, k).view(np.uint32) == oracle.make_coeffs("lopass", om, k).view(np.uint32)).all()
+        assert (ml.Hipass.makeCoeffs(om, k).view(np.uint32) == oracle.make_coeffs("hipass", om, k).view(np.uint32)).all()
+        assert (ml.Bandpass.makeCoeffs(om, k).view(np.uint32) == oracle.make_coeffs("bandpass", om, k).view(np.uint32)).all()
+        assert (ml.LoShelf.makeCoeffs(om, k, A).view(np.uint32) == oracle.make_coeffs("loshelf", om, k, A).view(np.uint32)).all()
+        assert (ml.HiShelf.makeCoeffs(om, k, A).view(np.uint32) == oracle.make_coeffs("hishelf", om, k, A).view(np.uint32)).all()
+        assert (ml.Bell.makeCoeffs(om, k, A).view(np.uint32) == oracle.make_coeffs("bell", om, k, A).view(np.uint32)).all()
+        assert (ml.OnePole.makeCoeffs(om).view(np.uint32) == oracle.make_coeffs("onepole", om).view(np.uint32)).all()
+        assert ml.DCBlocker.makeCoeffs(om) == oracle.dcblocker_coeffs(om)
+        assert ml.dBToGain(A) == oracle.db_to_gain(A)
+        a = (rng.uniform(0, .1), rng.uniform(0, .1), rng.random(), rng.uniform(0, .1), 48000.0)
+        assert (ml.ADSR.calcCoeffs(*a).view(np.uint32) == oracle.make_coeffs("adsr", *a).view(np.uint32)).all()
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a gfx950 device the product refuses to run instead of falling back to the CPU."""
+    import madronalib_amd as ml
+    if ml.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(ml.MlgpuError) as ei:
+        ml.Engine(0)
+    assert ei.value.status == ml.Status.ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    """The shipped package must never import, link or load anything under oracle/."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for base in ("madronalib_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(root, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle/|mlorc_|mlref_|libmloracle|libmlref", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

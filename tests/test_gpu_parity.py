@@ -1,0 +1,319 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden vectors of the compiled reference, and — at full
+BASELINE sizes — through size-independent properties. Bit-exact unless stated.
+
+Tolerances (stated once, used below):
+  HW_REL   = 1.5*2^-11 relative for sqrtApprox / divideApprox / Peak / RMS: the reference uses the
+             x86 rcpps/rsqrtps 12-bit tables, which no other hardware reproduces.
+  everything else: 0 ulp (bit-exact; any-NaN == any-NaN for float results).
+"""
+import numpy as np
+import pytest
+
+from golden_cases import ANCHORS, chain_case, chain_case_names, load_chains, load_ops
+from inputs import (assert_bits_equal, assert_rel_close, chain_coeffs, chain_input, is_float_result, lcg_noise,
+                    op_inputs, ramp_pi)
+from madronalib_amd.constants import Layout, Op, Proc, RowOp
+
+pytestmark = pytest.mark.gpu
+
+HW_REL = 2.0 ** -11 * 1.5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import madronalib_amd as ml
+    e = ml.Engine(0)
+    yield e
+    e.close()
+
+
+def _hw_ok(got, want):
+    g, w = got.view(np.float32), want.view(np.float32)
+    return np.isfinite(w) & np.isfinite(g) & (w != 0) & (np.abs(w) > 1e-30)
+
+
+# ---- elementwise ops ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("op", Op.UNARY + Op.BINARY + Op.TERNARY)
+def test_op_vs_oracle(eng, oracle, op):
+    a, b, c = op_inputs(op, 64 * 256 + 4 * 3 + 3, seed=9)  # odd length: exercises the vector + scalar tails
+    want = oracle.op(op, a, b, c)
+    got = eng.op(op, a, b, c)
+    if op in Op.HW_APPROX:
+        ok = _hw_ok(got, want)
+        assert_rel_close(got.view(np.float32)[ok], want.view(np.float32)[ok], HW_REL, f"op {op}")
+    else:
+        assert_bits_equal(got, want, is_float_result(op), f"op {op}")
+
+
+@pytest.mark.parametrize("op", Op.UNARY + Op.BINARY + Op.TERNARY)
+def test_op_vs_golden(eng, op):
+    d = load_ops()
+    g = lambda k: d[f"op{op}_{k}"] if f"op{op}_{k}" in d.files else None  # noqa: E731
+    got = eng.op(op, g("a"), g("b"), g("c"))
+    want = d[f"op{op}_out"]
+    if op in Op.HW_APPROX:
+        ok = _hw_ok(got, want)
+        assert_rel_close(got.view(np.float32)[ok], want.view(np.float32)[ok], HW_REL, f"op {op}")
+    else:
+        assert_bits_equal(got, want, is_float_result(op), f"op {op}")
+
+
+@pytest.mark.parametrize("op", [Op.ADD, Op.SUBTRACT, Op.MULTIPLY, Op.DIVIDE, Op.POW, Op.POW_APPROX, Op.MIN, Op.MAX])
+def test_rows1_vs_oracle(eng, oracle, op):
+    a, b, _ = op_inputs(op, 64 * 40, seed=4)
+    a = np.abs(a) if op in (Op.POW, Op.POW_APPROX) else a
+    assert_bits_equal(eng.op_rows1(op, a, b[:64]), oracle.op_rows1(op, a, b[:64]), True, f"rows1 {op}")
+
+
+@pytest.mark.parametrize("rowop", [RowOp.SUM, RowOp.MEAN, RowOp.MAX, RowOp.MIN])
+def test_row_reduce_vs_oracle(eng, oracle, rowop):
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal(64 * 300).astype(np.float32) * np.float32(100)
+    rows[64:128] = -np.abs(rows[64:128])
+    assert_bits_equal(eng.row_reduce(rowop, rows), oracle.row_reduce(rowop, rows), True, f"rowop {rowop}")
+    d = load_ops()
+    assert_bits_equal(eng.row_reduce(rowop, d["rows"]), d[f"rowop{rowop}"], True, f"rowop {rowop} golden")
+
+
+def test_config2_ramp_and_noise(eng, oracle):
+    """BASELINE config 2 inputs at a size the oracle finishes in seconds."""
+    V = 2048
+    for x in (ramp_pi(V), (lcg_noise(np.arange(V, dtype=np.uint32), 64) * np.float32(np.pi)).astype(np.float32)):
+        for op in (Op.SIN_APPROX, Op.EXP_APPROX, Op.EXP_APPROX_OF_SIN_APPROX, Op.SIN, Op.EXP):
+            assert_bits_equal(eng.op(op, x), oracle.op(op, x), True, f"cfg2 op {op}")
+
+
+def test_config2_full_size_properties(eng):
+    """65 536 voices x 64: fused pair == composition of the two kernels, and idempotent re-run."""
+    V = 65536
+    x = ramp_pi(V)
+    s = eng.op(Op.SIN_APPROX, x)
+    e1 = eng.op(Op.EXP_APPROX, s.view(np.float32))
+    e2 = eng.op(Op.EXP_APPROX_OF_SIN_APPROX, x)
+    assert_bits_equal(e1, e2, True, "fused pair")
+    # the ramp repeats every 4096 elements: so must the result
+    assert (e2.reshape(-1, 4096) == e2.reshape(-1, 4096)[0]).all()
+
+
+def test_layout_convert_roundtrip(eng):
+    V, T = 100, 5  # ragged V (not a multiple of 64)
+    x = np.arange(V * T * 64, dtype=np.float32).reshape(V, T * 64)
+    d_vm = eng.to_device(x)
+    bufs = {Layout.QUAD: eng.alloc(x.nbytes), Layout.ROWS: eng.alloc(x.nbytes), "back": eng.alloc(x.nbytes)}
+    eng.layout_convert(d_vm, Layout.VOICE_MAJOR, bufs[Layout.QUAD], Layout.QUAD, V, T)
+    q = bufs[Layout.QUAD].download(np.float32).reshape(T * 16, V, 4)
+    want_q = x.reshape(V, T * 16, 4).transpose(1, 0, 2)
+    assert (q == want_q).all()
+    eng.layout_convert(bufs[Layout.QUAD], Layout.QUAD, bufs[Layout.ROWS], Layout.ROWS, V, T)
+    r = bufs[Layout.ROWS].download(np.float32).reshape(T, V, 64)
+    assert (r == x.reshape(V, T, 64).transpose(1, 0, 2)).all()
+    eng.layout_convert(bufs[Layout.ROWS], Layout.ROWS, bufs["back"], Layout.VOICE_MAJOR, V, T)
+    assert (bufs["back"].download(np.float32).reshape(V, T * 64) == x).all()
+
+
+# ---- processors and chains ----------------------------------------------------------------
+
+def _run_gpu(eng, procs, V, T, coeffs, state0, sig, const, layout=Layout.QUAD, calls=1):
+    bank = eng.bank(procs, V)
+    bank.set_all_coeffs(coeffs)
+    bank.set_all_state(state0)
+    if const is not None:
+        bank.set_input_const(const)
+    outs = [bank.process_host(T, sig, layout) for _ in range(calls)]
+    st = bank.get_all_state()
+    fused = bank.fused
+    bank.close()
+    return outs, st, fused
+
+
+@pytest.mark.parametrize("layout", [Layout.QUAD, Layout.ROWS, Layout.VOICE_MAJOR])
+@pytest.mark.parametrize("kind", Proc.ALL)
+def test_single_proc_vs_oracle(eng, oracle, kind, layout):
+    V, T = 200, 9  # ragged: 200 voices = 3 full waves + 8 lanes
+    procs = [kind]
+    co = chain_coeffs(oracle, procs, V, seed=5)
+    sig, const = chain_input(procs, V, T, seed=kind)
+    st = oracle.chain_clear(procs, V)
+    if kind == Proc.NOISE_GEN:
+        st[0] = np.arange(V, dtype=np.uint32)
+    if kind == Proc.ONE_SHOT_GEN:
+        st[1] = 1
+    (got,), gst, _ = _run_gpu(eng, procs, V, T, co, st, sig, const, layout)
+    want = oracle.chain_process(procs, T, co, st, sig, const)
+    if kind in Proc.HW_APPROX:
+        assert_rel_close(got, want, HW_REL, f"proc {kind}")
+    else:
+        assert_bits_equal(got, want, True, f"proc {kind} output")
+    assert_bits_equal(gst, st, False, f"proc {kind} final state")
+
+
+CHAINS = {
+    "cfg1_sine_lopass": [Proc.SINE_GEN, Proc.LOPASS],
+    "cfg3_saw_bandpass_gain": [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN],
+    "cfg4_lopass8": [Proc.LOPASS] * 8,
+    "cfg4_noise_lopass8": [Proc.NOISE_GEN] + [Proc.LOPASS] * 8,
+    "pulse_hipass_onepole": [Proc.PULSE_GEN, Proc.HIPASS, Proc.ONE_POLE],
+    # not in the fused catalogue -> runs processor by processor through HBM scratch
+    "unfused_saw_shelves_bell_dc": [Proc.SAW_GEN, Proc.LO_SHELF, Proc.HI_SHELF, Proc.BELL, Proc.DC_BLOCKER],
+    "unfused_noise_adsrgate": [Proc.NOISE_GEN, Proc.ONE_POLE, Proc.INTEGRATOR, Proc.DIFFERENTIATOR],
+}
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
+def test_chain_vs_oracle_with_resume(eng, oracle, name):
+    procs = CHAINS[name]
+    V, T = 300, 70  # T > scratch slice for unfused chains at this V? (slice = 64) -> two slices
+    co = chain_coeffs(oracle, procs, V, seed=11)
+    sig, const = chain_input(procs, V, T, seed=2)
+    st = oracle.chain_clear(procs, V)
+    if procs[0] == Proc.NOISE_GEN:
+        st[0] = np.arange(V, dtype=np.uint32)
+    outs, gst, fused = _run_gpu(eng, procs, V, T, co, st.copy(), sig, const, Layout.QUAD, calls=2)
+    assert fused == (not name.startswith("unfused")), name
+    for got in outs:  # the second call resumes from the carried state
+        want = oracle.chain_process(procs, T, co, st, sig, const, n_threads=4)
+        assert_bits_equal(got, want, True, name)
+    assert_bits_equal(gst, st, False, name + " state")
+
+
+@pytest.mark.parametrize("name", chain_case_names())
+def test_chain_vs_golden(eng, name):
+    c = chain_case(load_chains(), name)
+    V = c["state0"].shape[1] if c["state0"].size else c["coeffs"].shape[1]
+    T = c["out1"].shape[1] // 64
+    outs, gst, _ = _run_gpu(eng, c["procs"], V, T, c["coeffs"], c["state0"], c["in_signal"], c["in_const"], Layout.ROWS, calls=2)
+    hw = any(p in Proc.HW_APPROX for p in c["procs"])
+    for got, k in zip(outs, ("out1", "out2")):
+        if hw:
+            assert_rel_close(got, c[k], HW_REL, name)
+        else:
+            assert_bits_equal(got, c[k], True, f"{name} {k}")
+    assert_bits_equal(gst, c["state2"], False, name + " state2")
+
+
+def test_anchors_cfg1_cfg3(eng):
+    """SURVEY Appendix B anchors through the HIP path (1 voice, 1 DSPVector = BASELINE config 1)."""
+    import madronalib_amd as ml
+    a = ANCHORS["cfg1"]
+    bank = eng.bank(a["procs"], 1)
+    bank.clear()
+    bank.set_coeffs(1, ml.Lopass.makeCoeffs(*a["lopass"]))
+    bank.set_input_const(np.array([a["freq"]], np.float32))
+    y = bank.process_host(1)[0]
+    assert list(y[:4]) == a["y0_3"] and y[63] == a["y63"]
+    a = ANCHORS["cfg3"]
+    bank = eng.bank(a["procs"], 1)
+    bank.clear()
+    bank.set_coeffs(1, ml.Bandpass.makeCoeffs(*a["bandpass"]))
+    bank.set_coeffs(2, [a["gain"]])
+    bank.set_input_const(np.array([a["freq"]], np.float32))
+    z = bank.process_host(1)[0]
+    assert list(z[:4]) == a["z0_3"] and z[63] == a["z63"]
+
+
+def test_default_state_and_clear(eng, oracle):
+    for procs in ([Proc.SINE_GEN, Proc.LOPASS], [Proc.ADSR], [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]):
+        bank = eng.bank(procs, 70)
+        assert_bits_equal(bank.get_all_state(), oracle.chain_default_state(procs, 70), False, "default state")
+        bank.clear()
+        assert_bits_equal(bank.get_all_state(), oracle.chain_clear(procs, 70), False, "clear state")
+
+
+# ---- full BASELINE sizes: size-independent properties --------------------------------------
+
+def _cfg3_setup(eng, V):
+    import madronalib_amd as ml
+    v = np.arange(V, dtype=np.float64)
+    freq = (55.0 * 2.0 ** (5.0 * v / V) / 48000.0).astype(np.float32)
+    # coefficients depend on omega only through a smooth map: make them for 1024 distinct omegas
+    om = np.minimum(0.45, 4.0 * freq.astype(np.float64)).astype(np.float32)
+    uniq, inv = np.unique(om, return_inverse=True)
+    table = np.stack([ml.Bandpass.makeCoeffs(float(o), 0.5) for o in uniq])
+    co = table[inv]  # [V][3]
+    bank = eng.bank([Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN], V)
+    bank.clear()
+    for i in range(3):
+        bank.set_coeff(1, i, np.ascontiguousarray(co[:, i]))
+    bank.set_coeff(2, 0, 0.25)
+    bank.set_input_const(freq)
+    return bank, freq, co
+
+
+def test_config3_full_size(eng, oracle):
+    """262 144 voices: (a) a strided subset of voices equals the oracle bit-for-bit, (b) T vectors in
+    one launch == the same T vectors in two launches (state carry), (c) QUAD and ROWS outputs agree."""
+    V, T = 262144, 4
+    bank, freq, co = _cfg3_setup(eng, V)
+    n = V * T * 64
+    d_q = eng.alloc(4 * n)
+    bank.process(T, d_q, Layout.QUAD)
+    q = d_q.download(np.float32).reshape(T * 16, V, 4)
+    st_one = bank.get_all_state()
+
+    sub = np.arange(0, V, 509)
+    coeffs = np.ascontiguousarray(np.concatenate([co[sub].T, np.full((1, sub.size), 0.25, np.float32)], 0))
+    st = oracle.chain_clear([Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN], sub.size)
+    want = oracle.chain_process([Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN], T, coeffs, st, None, freq[sub], n_threads=4)
+    got = q[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64)
+    assert_bits_equal(got, want, True, "cfg3 subset")
+    assert_bits_equal(st_one[:, sub], st, False, "cfg3 subset state")
+
+    bank.clear()
+    d_r = eng.alloc(4 * n)
+    half = T // 2
+    bank.process(half, d_r, Layout.ROWS)
+    d_r2 = eng.alloc(4 * n // 2)
+    bank.process(T - half, d_r2, Layout.ROWS)
+    r = np.concatenate([d_r.download(np.float32, n // 2), d_r2.download(np.float32)]).reshape(T, V, 64)
+    assert (r.view(np.uint32) == q.reshape(T, 16, V, 4).transpose(0, 2, 1, 3).reshape(T, V, 64).view(np.uint32)).all()
+    assert_bits_equal(bank.get_all_state(), st_one, False, "split launches state")
+
+
+def test_config4_full_size(eng, oracle):
+    """131 072 channels x 8 Lopass sections over streamed noise: subset vs oracle + linearity-free
+    property: processing [x] then [x'] equals processing the concatenation."""
+    import madronalib_amd as ml
+    V, T = 131072, 2
+    procs = [Proc.LOPASS] * 8
+    bank = eng.bank(procs, V)
+    cs = [ml.Lopass.makeCoeffs(float(np.float32(0.02) * np.float32(i + 1)), 0.7) for i in range(8)]
+    for i in range(8):
+        bank.set_coeffs(i, cs[i])
+    # input: NoiseGen bank (seed = channel) on the GPU itself
+    nb = eng.bank([Proc.NOISE_GEN], V)
+    nb.set_state(0, 0, np.arange(V, dtype=np.uint32))
+    d_x = eng.alloc(4 * V * T * 64)
+    nb.process(T, d_x, Layout.QUAD)
+    d_y = eng.alloc(4 * V * T * 64)
+    bank.process(T, d_y, Layout.QUAD, d_x, Layout.QUAD)
+    y = d_y.download(np.float32).reshape(T * 16, V, 4)
+    sub = np.arange(0, V, 257)
+    co = np.ascontiguousarray(np.repeat(np.concatenate(cs)[:, None], sub.size, 1))
+    x_sub = lcg_noise(sub.astype(np.uint32), T * 64)
+    st = oracle.chain_clear(procs, sub.size)
+    want = oracle.chain_process(procs, T, co, st, x_sub, None, n_threads=4)
+    got = y[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64)
+    assert_bits_equal(got, want, True, "cfg4 subset")
+    a = ANCHORS["cfg4_vec4"]
+    # Appendix-B anchor: channel 0, 4th vector needs T >= 4: run two more vectors
+    nb.process(T, d_x, Layout.QUAD)
+    bank.process(T, d_y, Layout.QUAD, d_x, Layout.QUAD)
+    y2 = d_y.download(np.float32).reshape(T * 16, V, 4)[16:, 0, :].reshape(64).view(np.uint32)
+    assert (y2[0], y2[31], y2[63]) == (a["y0"], a["y31"], a["y63"])
+
+
+def test_empty_and_error_paths(eng):
+    import madronalib_amd as ml
+    bank = eng.bank([Proc.LOPASS], 64)
+    out = eng.alloc(64 * 64 * 4)
+    bank.process(0, out)  # zero vectors: no-op
+    with pytest.raises(ml.MlgpuError) as ei:
+        bank.set_coeff(0, 7, 1.0)
+    assert ei.value.status == ml.Status.ERR_RANGE
+    with pytest.raises(ml.MlgpuError):
+        eng.bank([999], 64)
+    with pytest.raises(ml.MlgpuError):
+        eng.bank([Proc.LOPASS], 0)
+    assert eng.op(Op.ADD, np.zeros(0, np.float32), np.zeros(0, np.float32)).size == 0
