@@ -8,6 +8,7 @@ MLDSPGens.h, MLDSPFunctional.h): `Lopass.makeCoeffs`, `Bank`, `clear`, ...
 There is no CPU fallback: every compute call goes to a gfx950 kernel or raises MlgpuError.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -43,6 +44,7 @@ class DeviceBuffer:
         p = ctypes.c_void_p()
         engine._check(engine.L.mlgpu_alloc(engine.h, self.nbytes, ctypes.byref(p)))
         self.ptr = p.value or 0
+        engine._children.add(self)
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
@@ -58,9 +60,11 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.engine.h:
             self.engine.L.mlgpu_free(self.engine.h, self.ptr)
-            self.ptr = 0
+        self.ptr = 0
+
+    close = free
 
     def __del__(self):
         try:
@@ -83,6 +87,13 @@ class Engine:
             raise MlgpuError(st, "(engine_create)")
         self.h = h
         self.device = int(device)
+        self._children = weakref.WeakSet()  # banks and buffers: released before the engine goes away
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _check(self, st):
         if st != 0:
@@ -90,6 +101,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            for child in list(self._children):
+                child.close()
             self.L.mlgpu_engine_destroy(self.h)
             self.h = None
 
@@ -171,11 +184,12 @@ class Bank:
         h = ctypes.c_void_p()
         engine._check(self.L.mlgpu_bank_create(engine.h, arr, len(self.procs), self.V, ctypes.byref(h)))
         self.h = h
+        engine._children.add(self)
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and self.engine.h:
             self.L.mlgpu_bank_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
