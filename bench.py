@@ -3,18 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-A "step" is one launch of the fused voice-bank kernel over one batch: T DSPVectors for every
-voice of this rank's partition, inputs (per-voice freq, coefficients, state) already resident in
-HBM. Default workload = BASELINE.json configs[2], the configuration the metric
+Default workload = BASELINE.json configs[2], the configuration the metric
 "voice-samples/sec (SawGen->SVF chain)" is quoted on:
     262 144 voices per GPU, SawGen -> Bandpass(k=0.5) -> x0.25, per-voice freq 55 Hz..1.76 kHz at
     48 kHz, scalar-freq mode, free-running (max-throughput) streaming.
+A "step" is one pass of the hot path over one batch = ONE SECOND OF AUDIO for every voice of this
+rank's partition: 750 DSPVectors (SURVEY §8d "sustained for >= 1 s of audio"), issued as 25
+launches of the fused voice-bank kernel x 30 DSPVectors each into a ring of two output signals;
+per-voice freq, coefficients and state are resident in HBM and carried from launch to launch.
 Voices shard embarrassingly: rank g owns voices [g*V, (g+1)*V) — weak scaling, no data-path
 collective (torch.distributed is used only for the barrier and the max-over-ranks time).
 
-Prints ONE JSON line on rank 0 with `roofline` (HBM, algorithmic bytes / HIP-event kernel time on
-the engine's stream) and, at N=1, `cpu_baseline` (the compiled reference oracle/_ref when present,
-else the plain-C port, timed on the host cores over a bounded sample of the same workload).
+Prints ONE JSON line on rank 0 with
+  roofline      HBM bound: algorithmic bytes per launch / average launch duration measured with HIP
+                events on the engine's stream over the timed region; `traffic` = HBM bytes per
+                launch from the rocprofv3 PMC passes summarised in profiles/pmc_traffic.json (or null)
+  cpu_baseline  (N=1 only) the compiled reference (oracle/_ref) when present, else the plain-C port,
+                timed on the host cores over a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -29,13 +34,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+WORKLOADS = {
+    # name: (voices per GPU, DSPVectors per launch, launches per step)
+    "cfg3": (262144, 30, 25),   # 750 vectors = 1 s of audio at 48 kHz
+    "cfg4": (131072, 32, 16),   # long-buffer: 512 vectors per step
+    "cfg2": (65536, 1, 64),     # elementwise: 64 vector-steps per step
+}
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
 def partition(total_voices, world, rank):
-    """Contiguous voice range of `rank`: [lo, hi)."""
+    """Contiguous voice range [lo, hi) owned by `rank`."""
     per = total_voices // world
     rem = total_voices % world
     lo = rank * per + min(rank, rem)
@@ -54,7 +66,7 @@ def cfg3_params(lo, hi, total):
 
 
 def setup_workload(eng, name, V, T, lo, total):
-    """Returns (step_fn, algorithmic_bytes_per_launch, bank, description)."""
+    """Returns (launch_fn, algorithmic_bytes_per_launch, kernel_name, description)."""
     import madronalib_amd as ml
     from madronalib_amd.constants import Layout, Op, Proc
     n = V * T * 64
@@ -69,13 +81,15 @@ def setup_workload(eng, name, V, T, lo, total):
         outs = [eng.alloc(4 * n), eng.alloc(4 * n)]
         k = [0]
 
-        def step():
+        def launch():
             bank.process(T, outs[k[0] & 1], Layout.QUAD)
             k[0] += 1
-        # 4 B/voice-sample out + (4 phase + 8 ic + 12 coeff + 4 gain + 4 freq read, 12 written)/launch
+        # 4 B/voice-sample written + per launch and voice
+        # (4 phase + 8 ic + 12 coeff + 4 gain + 4 freq) read and 12 written
         alg = 4.0 * n + V * (4 + 8 + 12 + 4 + 4 + 12)
-        desc = "BASELINE configs[2]: 262144 voices/GPU SawGen->Bandpass(k=0.5)->gain 0.25, scalar-freq, free-running"
-        return step, alg, bank, desc, (freq, co)
+        desc = ("BASELINE configs[2]: 262144 voices/GPU SawGen->Bandpass(k=0.5)->gain 0.25, scalar-freq, "
+                "free-running; step = 1 s of audio (750 DSPVectors) per voice")
+        return launch, alg, bank.kernel_name, desc, bank
     if name == "cfg4":
         bank = eng.bank([Proc.LOPASS] * 8, V)
         for i in range(8):
@@ -87,23 +101,24 @@ def setup_workload(eng, name, V, T, lo, total):
         outs = [eng.alloc(4 * n), eng.alloc(4 * n)]
         k = [0]
 
-        def step():
+        def launch():
             bank.process(T, outs[k[0] & 1], Layout.QUAD, d_x, Layout.QUAD)
             k[0] += 1
         alg = 8.0 * n + V * (4 * (24 + 16) + 4 * 16)
-        return step, alg, bank, "BASELINE configs[3]: 131072 channels x 8 cascaded Lopass, streamed noise input", None
+        return launch, alg, bank.kernel_name, "BASELINE configs[3]: 131072 channels x 8 cascaded Lopass, streamed noise input", bank
     if name == "cfg2":
         x = np.tile(np.linspace(-np.pi, np.pi, 4096, dtype=np.float32), (V * 64 * T) // 4096)
         d_x = eng.to_device(x)
         d_y = eng.alloc(4 * n)
 
-        def step():
+        def launch():
             eng.op_apply(Op.EXP_APPROX_OF_SIN_APPROX, d_x, None, None, d_y, n)
-        return step, 8.0 * n, None, "BASELINE configs[1]: 65536 voices elementwise expApprox(sinApprox(x))", None
+        return launch, 8.0 * n, "op_kernel<EXP_APPROX_OF_SIN_APPROX>", \
+            "BASELINE configs[1]: 65536 voices x 1 DSPVector elementwise expApprox(sinApprox(x)) (32 MiB: Infinity-Cache resident)", (d_x, d_y)
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline_cfg3(total_voices, budget_s=12.0):
+def cpu_baseline_cfg3(budget_s=12.0):
     """The same chain on the host cores over a bounded sample (~10-20 s of CPU work)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_checkers import Oracle, Ref, ref_available
@@ -136,14 +151,29 @@ def cpu_baseline_cfg3(total_voices, budget_s=12.0):
                       f"({'compiled reference headers, g++ -O2 SSE2' if kind == 'reference' else 'plain-C oracle port, gcc -O2'})"}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC summary, if there is one."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        for k, v in d.get("kernels", {}).items():
+            if k in kernel_name or kernel_name in k:
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg2"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--voices", type=int, default=0, help="voices per GPU (default: the config's)")
-    ap.add_argument("--vectors", type=int, default=32, help="DSPVectors per launch (T)")
+    ap.add_argument("--vectors", type=int, default=0, help="DSPVectors per launch (default: the config's)")
+    ap.add_argument("--launches", type=int, default=0, help="launches per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -156,7 +186,7 @@ def main():
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -164,15 +194,20 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import madronalib_amd as ml
-    per_gpu = {"cfg3": 262144, "cfg4": 131072, "cfg2": 65536}[args.workload]
-    V = args.voices or per_gpu
+    dV, dT, dL = WORKLOADS[args.workload]
+    V = args.voices or dV
+    T = args.vectors or dT
+    L = args.launches or dL
     total = V * world                 # weak scaling: per-GPU work fixed
     lo, hi = partition(total, world, rank)
     assert hi - lo == V
-    T = args.vectors if args.workload != "cfg2" else 1
 
     eng = ml.Engine(local_rank)
-    step, alg_bytes, bank, desc, params = setup_workload(eng, args.workload, V, T, lo, total)
+    launch, alg_bytes, kernel_name, desc, _keep = setup_workload(eng, args.workload, V, T, lo, total)
+
+    def step():
+        for _ in range(L):
+            launch()
 
     def barrier():
         eng.sync()
@@ -187,7 +222,7 @@ def main():
     eng.timer_start()
     for _ in range(args.steps):
         step()
-    kernel_ms = eng.timer_stop_ms() / args.steps      # HIP events on the engine's stream
+    kernel_ms = eng.timer_stop_ms() / (args.steps * L)   # HIP events on the engine's stream
     eng.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -198,7 +233,7 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        units = float(total) * T * 64 * args.steps          # voice-samples over all ranks
+        units = float(total) * T * 64 * L * args.steps      # voice-samples over all ranks
         value = units / elapsed
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -207,16 +242,16 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "voices_per_gpu": V, "total_voices": total, "vectors_per_launch": T,
-                       "samples_per_vector": 64, "layout": "QUAD [S/4][V][4]", "parallelism": f"voices x{world} (no collective)",
+                       "launches_per_step": L, "vectors_per_step": T * L, "samples_per_vector": 64,
+                       "layout": "QUAD [S/4][V][4]", "parallelism": f"voices x{world} (no collective)",
                        "realtime_48k_voices": value / 48000.0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": bank.kernel_name if bank is not None else "op_kernel<EXP_APPROX_OF_SIN_APPROX>",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name),
+                         "kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
             try:
-                out["cpu_baseline"] = cpu_baseline_cfg3(total)
+                out["cpu_baseline"] = cpu_baseline_cfg3()
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {ex}"}

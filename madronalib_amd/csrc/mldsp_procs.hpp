@@ -43,33 +43,66 @@ constexpr uint32_t kSineScaleBits = 0x3f87c3b6u;
 constexpr uint32_t kSineFlipBits = 0x40350505u;
 constexpr uint32_t kOneSixthBits = 0x3e2aaaabu;
 
-// PhasorGen core, MLDSPGens.h:187-203
+// PhasorGen core, MLDSPGens.h:187-203.
+// PARITY: unsignedIntToFloat(u)*2^-32 is (hi + hi) * 2^-32 with hi = float(int(u >> 1)); both
+// steps are exact power-of-two scalings of hi (hi is 0 or >= 1, so nothing goes denormal), hence
+// hi * 2^-31 is the same float with one multiply instead of an add and a multiply.
 MLD float phasor_next(uint32_t& omega32, float cyclesPerSample)
 {
   const float steps = cyclesPerSample * kStepsPerCycle;
   const int32_t istep = sse_cvt(steps);  // roundFloatToInt; loop-invariant when cps is
   omega32 += (uint32_t)istep;
-  return uint_to_float(omega32) * kCyclesPerStep;
+  const float hi = (float)(int32_t)(omega32 >> 1);
+  return hi * 4.656612873077392578125e-10f;  // 2^-31
 }
 
-// polyBLEP, MLDSPGens.h:285-311. Branch-free restatement: exactly one of the two
-// divisions of the reference is ever taken for a sample, so select the numerator first,
-// divide once (IEEE-correct v_div sequence), then select the polynomial.
+// Correctly rounded n/d for the polyBLEP operands. This is the Newton-Raphson sequence the
+// compiler itself expands an IEEE f32 division to on gfx9 (v_rcp_f32, one reciprocal refinement,
+// two quotient refinements, all with exact FMA residuals) without the v_div_scale / v_div_fixup
+// range handling, so it returns the same bits as `n / d` whenever no scaling is needed:
+// d in [2^-64, 2^64] and |n| in [2^-31, 2] or 0 here, so quotient and residuals stay normal.
+// Everything that depends only on d (rcp + 2 FMA) is loop-invariant for a per-voice constant
+// frequency and is hoisted by the compiler: 5 VALU ops per sample instead of ~12.
+MLD float div_nr(float n, float d)
+{
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e, r0, r0);
+  const float q0 = n * r1;
+  const float rem0 = __builtin_fmaf(-d, q0, n);
+  const float q1 = __builtin_fmaf(rem0, r1, q0);
+  const float rem1 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(rem1, r1, q1);
+}
+
+// polyBLEP, MLDSPGens.h:285-311, branch-free. Exactly one of the reference's two divisions is
+// ever taken for a sample, so: select the numerator, divide once, evaluate both polynomials,
+// select. Lanes that need no correction compute a value that is discarded (it may be NaN for
+// dt <= 0; v_cndmask does not care).
+// PARITY: `t + t - t*t - 1` == fma(2, t, -(t*t)) - 1 because t + t is exact.
+//
+// A frequency outside [2^-64, 2^64] (absurd, but legal input) needs the full IEEE division.
+// FAST = true promises the caller has excluded that for the whole wavefront (the voice-bank
+// kernel tests the per-voice constant frequency once per launch); FAST = false tests per sample
+// with a wave-uniform ballot (streamed, time-varying frequency).
+MLD bool blep_freq_is_odd(float dt) { return (dt > 0.f) && !((dt >= 0x1p-64f) && (dt <= 0x1p+64f)); }
+
+template <bool FAST>
 MLD float poly_blep(float t, float dt)
 {
   const bool lo = (t < dt);
-  const bool hi = !lo && (t > 1.0f - dt);
-  float c = 0.f;
-  if (lo || hi)
-  {
-    const float num = lo ? t : (t - 1.0f);
-    const float q = num / dt;
-    const float qq = q * q;
-    const float q2 = q + q;
-    // lo: t + t - t*t - 1 ; hi: t*t + t + t + 1   (left-assoc as written in the reference)
-    c = lo ? ((q2 - qq) - 1.0f) : (((qq + q) + q) + 1.0f);
-  }
-  return c;
+  const bool hi = (t > 1.0f - dt);  // only consulted when !lo (the reference's else-if)
+  const float num = lo ? t : (t - 1.0f);
+  float q;
+  if (!FAST && __builtin_amdgcn_ballot_w64(blep_freq_is_odd(dt)) != 0)
+    q = num / dt;
+  else
+    q = div_nr(num, dt);
+  const float qq = q * q;
+  const float clo = __builtin_fmaf(2.0f, q, -qq) - 1.0f;
+  const float chi = ((qq + q) + q) + 1.0f;
+  const float c = lo ? clo : chi;
+  return (lo || hi) ? c : 0.f;
 }
 
 MLD float phasor_to_sine(float p)  // MLDSPGens.h:316-338
@@ -114,12 +147,16 @@ struct Proc<MLGPU_PROC_SAW_GEN>  // MLDSPGens.h:395-402, phasorToSaw :362-369
   uint32_t omega32;
   MLD void load(const VoiceMem& m, const KernelTables&) { omega32 = m.s(0); }
   MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
-  MLD float next(float cps)
+  template <bool FAST>
+  MLD float step(float cps)
   {
     const float p = phasor_next(omega32, cps);
-    const float saw = p * 2.f - 1.f;
-    return saw - poly_blep(p, cps);
+    const float saw = __builtin_fmaf(p, 2.f, -1.f);  // PARITY: p*2 is exact, so one rounding either way
+    return saw - poly_blep<FAST>(p, cps);
   }
+  MLD float next(float cps) { return step<false>(cps); }
+  MLD float next_fast(float cps) { return step<true>(cps); }
+  static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
   MLD void end_vector() {}
 };
 
@@ -135,16 +172,20 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
     omega32 = m.s(0);
   }
   MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
-  MLD float next(float cps)
+  template <bool FAST>
+  MLD float step(float cps)
   {
     const float p = phasor_next(omega32, cps);
     float pulse = (p >= width) ? -1.f : 1.f;
-    pulse = pulse + poly_blep(p, cps);
+    pulse = pulse + poly_blep<FAST>(p, cps);
     const float d = p - width + 1.0f;
     const float down = d - (float)sse_cvtt(d);  // fractionalPart
-    pulse = pulse - poly_blep(down, cps);
+    pulse = pulse - poly_blep<FAST>(down, cps);
     return pulse;
   }
+  MLD float next(float cps) { return step<false>(cps); }
+  MLD float next_fast(float cps) { return step<true>(cps); }
+  static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
   MLD void end_vector() {}
 };
 
@@ -622,6 +663,19 @@ struct Proc<MLGPU_PROC_GAIN>  // x * DSPVector(gain), MLDSPOps.h:157,345-348
 
 // ---- compile-time chains -------------------------------------------------------------------
 
+// Processors with a cheaper evaluation for well-behaved, launch-constant input declare
+// next_fast(x) and input_is_odd(x); the kernel tests input_is_odd once per launch.
+template <class P, class = void>
+struct HasFastPath
+{
+  static constexpr bool value = false;
+};
+template <class P>
+struct HasFastPath<P, decltype((void)&P::input_is_odd)>
+{
+  static constexpr bool value = true;
+};
+
 template <int... KINDS>
 struct Chain;
 
@@ -634,6 +688,13 @@ struct Chain<>
   MLD void store(VoiceMem) const {}
   MLD float next(float x) { return x; }
   MLD void end_vector() {}
+  static constexpr bool kHeadHasFastPath = false;
+  static MLD bool head_input_is_odd(float) { return false; }
+  template <bool FAST>
+  MLD float next_head(float x)
+  {
+    return x;
+  }
 };
 
 template <int K0, int... KS>
@@ -659,6 +720,23 @@ struct Chain<K0, KS...>
     tail.store(m);
   }
   MLD float next(float x) { return tail.next(head.next(x)); }
+  // FAST: the caller has checked head_input_is_odd(x) is false on every lane of the wavefront
+  static constexpr bool kHeadHasFastPath = HasFastPath<Proc<K0>>::value;
+  static MLD bool head_input_is_odd(float x)
+  {
+    if constexpr (kHeadHasFastPath)
+      return Proc<K0>::input_is_odd(x);
+    else
+      return false;
+  }
+  template <bool FAST>
+  MLD float next_head(float x)
+  {
+    if constexpr (FAST && kHeadHasFastPath)
+      return tail.next(head.next_fast(x));
+    else
+      return tail.next(head.next(x));
+  }
   MLD void end_vector()
   {
     head.end_vector();

@@ -58,7 +58,8 @@ struct ChainEntry
   std::vector<int> kinds;
   ChainLauncher launchSignal;  // streamed input
   ChainLauncher launchConst;   // per-voice constant (or no) input
-  const char* kernelName;
+  const char* kernelName;  // prefix of the name a profiler shows for the device kernel
+  const char* alias;       // e.g. "chain_kernel<SawGen,Bandpass,Gain>"
   int nc, ns;
 };
 

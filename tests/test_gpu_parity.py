@@ -213,6 +213,31 @@ def test_anchors_cfg1_cfg3(eng):
     assert list(z[:4]) == a["z0_3"] and z[63] == a["z63"]
 
 
+@pytest.mark.parametrize("kind", [Proc.SAW_GEN, Proc.PULSE_GEN])
+@pytest.mark.parametrize("streamed", [False, True])
+def test_blep_division_domain(eng, oracle, kind, streamed):
+    """The polyBLEP division is evaluated with a hoisted Newton-Raphson reciprocal on the GPU; it must
+    equal the reference's IEEE division for every frequency, including absurd ones (0, negative, tiny,
+    huge, inf, NaN — those take the full IEEE path per wavefront)."""
+    V, T = 16384, 6
+    rng = np.random.default_rng(77)
+    f = np.exp(rng.uniform(np.log(1e-7), np.log(0.49), V)).astype(np.float32)
+    odd = np.array([0.0, -0.0, -0.01, 1e-25, 1e-38, 1e-45, 1e30, np.inf, -np.inf, np.nan, 0.5, 0.7, 1.5, 2.0 ** -64,
+                    2.0 ** -65, 2.0 ** 64, 1.0, 0.25, 1.0 / 3.0, 0.49999997], np.float32)
+    f[1000:1000 + odd.size] = odd          # inside otherwise ordinary wavefronts
+    f[5000:5064] = np.float32(1e-30)       # a whole odd wavefront
+    procs = [kind]
+    co = chain_coeffs(oracle, procs, V, seed=1)
+    st = oracle.chain_clear(procs, V)
+    st[0] = rng.integers(0, 2 ** 32, V, dtype=np.uint64).astype(np.uint32)  # random start phases
+    sig = np.repeat(f[:, None], 64 * T, 1) if streamed else None
+    const = None if streamed else f
+    (got,), gst, _ = _run_gpu(eng, procs, V, T, co, st.copy(), sig, const, Layout.QUAD)
+    want = oracle.chain_process(procs, T, co, st, sig, const, n_threads=8)
+    assert_bits_equal(got, want, True, f"blep kind {kind} streamed {streamed}")
+    assert_bits_equal(gst, st, False, "state")
+
+
 def test_default_state_and_clear(eng, oracle):
     for procs in ([Proc.SINE_GEN, Proc.LOPASS], [Proc.ADSR], [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]):
         bank = eng.bank(procs, 70)

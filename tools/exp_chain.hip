@@ -1,0 +1,297 @@
+// tools/exp_chain.hip — kernel-structure lab for the voice-bank kernel (developer tool, not product).
+// Builds variants of the SawGen->Bandpass->gain loop from the PRODUCT device headers and times
+// them on the config-3 workload; every variant's output is compared bit-for-bit with variant 0.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize tools/exp_chain.hip -o tools/bin/exp_chain
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../madronalib_amd/csrc/mldsp_procs.hpp"
+
+using namespace mldev;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+struct Args
+{
+  const float* coeffs;  // [4][V]: g0,g1,g2,gain
+  uint32_t* state;      // [3][V]
+  const float* freq;    // [V]
+  f32x4* out;           // QUAD
+  size_t V, T;
+};
+
+__device__ __forceinline__ size_t xcd_block(size_t b, size_t nb)
+{
+  const size_t full = nb & ~(size_t)7;
+  return (b < full) ? (b & 7) * (full >> 3) + (b >> 3) : b;
+}
+
+using CH = Chain<MLGPU_PROC_SAW_GEN, MLGPU_PROC_BANDPASS, MLGPU_PROC_GAIN>;
+
+// variant 0: product structure (1 voice per lane)
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_v0(Args a)
+{
+  const size_t v = xcd_block(blockIdx.x, gridDim.x) * BLK + threadIdx.x;
+  if (v >= a.V) return;
+  CH ch;
+  VoiceMem m{a.coeffs + v, a.state + v, a.V};
+  KernelTables tb{nullptr};
+  ch.load(m, tb);
+  const float xc = a.freq[v];
+  f32x4* po = a.out + v;
+  for (size_t r = 0; r < a.T * 16; ++r)
+  {
+    f32x4 y;
+    y.x = ch.next_head<true>(xc);
+    y.y = ch.next_head<true>(xc);
+    y.z = ch.next_head<true>(xc);
+    y.w = ch.next_head<true>(xc);
+    __builtin_nontemporal_store(y, po + r * a.V);
+  }
+  ch.store(m);
+}
+
+// variant 0b: product loop shape: T loop x 16 quads with UNROLL, generic runtime strides
+template <int BLK, int UNROLL, bool NT>
+__global__ __launch_bounds__(BLK) void k_v0b(Args a, size_t strideT, size_t strideQ, size_t strideV)
+{
+  const size_t v = xcd_block(blockIdx.x, gridDim.x) * BLK + threadIdx.x;
+  if (v >= a.V) return;
+  CH ch;
+  VoiceMem m{a.coeffs + v, a.state + v, a.V};
+  KernelTables tb{nullptr};
+  ch.load(m, tb);
+  const float xc = a.freq[v];
+  f32x4* pout = a.out + v * strideV;
+  for (size_t t = 0; t < a.T; ++t)
+  {
+    f32x4* po = pout + t * strideT;
+#pragma unroll UNROLL
+    for (int q = 0; q < 16; ++q)
+    {
+      f32x4 y;
+      y.x = ch.next_head<true>(xc);
+      y.y = ch.next_head<true>(xc);
+      y.z = ch.next_head<true>(xc);
+      y.w = ch.next_head<true>(xc);
+      if (NT) __builtin_nontemporal_store(y, po + q * strideQ); else po[q * strideQ] = y;
+    }
+  }
+  ch.store(m);
+}
+
+// variant 1: two voices per lane (v, v+64 inside a 128-voice group), calls alternated per sample
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_v1(Args a)
+{
+  const size_t g = xcd_block(blockIdx.x, gridDim.x) * BLK + threadIdx.x;  // lane id over V/2
+  const size_t va = (g >> 6) * 128 + (g & 63), vb = va + 64;
+  if (vb >= a.V) return;
+  CH ca, cb;
+  VoiceMem ma{a.coeffs + va, a.state + va, a.V}, mb{a.coeffs + vb, a.state + vb, a.V};
+  KernelTables tb{nullptr};
+  ca.load(ma, tb);
+  cb.load(mb, tb);
+  const float xa = a.freq[va], xb = a.freq[vb];
+  f32x4 *pa = a.out + va, *pb = a.out + vb;
+  for (size_t r = 0; r < a.T * 16; ++r)
+  {
+    f32x4 ya, yb;
+    ya.x = ca.next_head<true>(xa); yb.x = cb.next_head<true>(xb);
+    ya.y = ca.next_head<true>(xa); yb.y = cb.next_head<true>(xb);
+    ya.z = ca.next_head<true>(xa); yb.z = cb.next_head<true>(xb);
+    ya.w = ca.next_head<true>(xa); yb.w = cb.next_head<true>(xb);
+    __builtin_nontemporal_store(ya, pa + r * a.V);
+    __builtin_nontemporal_store(yb, pb + r * a.V);
+  }
+  ca.store(ma);
+  cb.store(mb);
+}
+
+// variant 2: N voices per lane with every arithmetic step written N-wide (explicit instruction-
+// level interleave): hand-expanded SawGen->Bandpass->gain on arrays.
+template <int BLK, int N>
+__global__ __launch_bounds__(BLK) void k_v2(Args a)
+{
+  const size_t g = xcd_block(blockIdx.x, gridDim.x) * BLK + threadIdx.x;
+  const size_t v0 = (g >> 6) * (64 * N) + (g & 63);
+  if (v0 + 64 * (N - 1) >= a.V) return;
+  uint32_t om[N], istep[N];
+  float dt[N], omdt[N], r1[N], ndt[N], g0[N], g1[N], g2[N], gain[N], ic1[N], ic2[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+  {
+    const size_t v = v0 + 64 * i;
+    g0[i] = a.coeffs[v]; g1[i] = a.coeffs[a.V + v]; g2[i] = a.coeffs[2 * a.V + v]; gain[i] = a.coeffs[3 * a.V + v];
+    om[i] = a.state[v]; ic1[i] = u2f(a.state[a.V + v]); ic2[i] = u2f(a.state[2 * a.V + v]);
+    dt[i] = a.freq[v];
+    istep[i] = (uint32_t)sse_cvt(dt[i] * kStepsPerCycle);
+    omdt[i] = 1.0f - dt[i];
+    const float r0 = __builtin_amdgcn_rcpf(dt[i]);
+    const float e = __builtin_fmaf(-dt[i], r0, 1.0f);
+    r1[i] = __builtin_fmaf(e, r0, r0);
+    ndt[i] = -dt[i];
+  }
+  for (size_t r = 0; r < a.T * 16; ++r)
+  {
+    f32x4 y[N];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      float p[N], num[N], q[N], rem[N], qq[N], clo[N], chi[N], c[N], saw[N], x[N], t0[N], t1[N], t2[N], m1[N], m2[N], o[N];
+      bool lo[N], hi[N];
+#define EACH for (int i = 0; i < N; ++i)
+#pragma unroll
+      EACH om[i] += istep[i];
+#pragma unroll
+      EACH p[i] = (float)(int32_t)(om[i] >> 1);
+#pragma unroll
+      EACH p[i] = p[i] * 4.656612873077392578125e-10f;
+#pragma unroll
+      EACH lo[i] = p[i] < dt[i];
+#pragma unroll
+      EACH hi[i] = p[i] > omdt[i];
+#pragma unroll
+      EACH num[i] = p[i] - 1.0f;
+#pragma unroll
+      EACH num[i] = lo[i] ? p[i] : num[i];
+#pragma unroll
+      EACH q[i] = num[i] * r1[i];
+#pragma unroll
+      EACH rem[i] = __builtin_fmaf(ndt[i], q[i], num[i]);
+#pragma unroll
+      EACH q[i] = __builtin_fmaf(rem[i], r1[i], q[i]);
+#pragma unroll
+      EACH rem[i] = __builtin_fmaf(ndt[i], q[i], num[i]);
+#pragma unroll
+      EACH q[i] = __builtin_fmaf(rem[i], r1[i], q[i]);
+#pragma unroll
+      EACH qq[i] = q[i] * q[i];
+#pragma unroll
+      EACH clo[i] = __builtin_fmaf(2.0f, q[i], -qq[i]);
+#pragma unroll
+      EACH chi[i] = qq[i] + q[i];
+#pragma unroll
+      EACH clo[i] = clo[i] - 1.0f;
+#pragma unroll
+      EACH chi[i] = chi[i] + q[i];
+#pragma unroll
+      EACH saw[i] = __builtin_fmaf(p[i], 2.f, -1.f);
+#pragma unroll
+      EACH chi[i] = chi[i] + 1.0f;
+#pragma unroll
+      EACH c[i] = lo[i] ? clo[i] : chi[i];
+#pragma unroll
+      EACH c[i] = (lo[i] || hi[i]) ? c[i] : 0.f;
+#pragma unroll
+      EACH x[i] = saw[i] - c[i];
+      // Bandpass
+#pragma unroll
+      EACH t0[i] = x[i] - ic2[i];
+#pragma unroll
+      EACH m1[i] = g1[i] * ic1[i];
+#pragma unroll
+      EACH m2[i] = g0[i] * ic1[i];
+#pragma unroll
+      EACH t1[i] = g0[i] * t0[i];
+#pragma unroll
+      EACH t2[i] = g2[i] * t0[i];
+#pragma unroll
+      EACH t1[i] = t1[i] + m1[i];
+#pragma unroll
+      EACH t2[i] = t2[i] + m2[i];
+#pragma unroll
+      EACH o[i] = t1[i] + ic1[i];
+#pragma unroll
+      EACH ic1[i] = __builtin_fmaf(2.0f, t1[i], ic1[i]);
+#pragma unroll
+      EACH ic2[i] = __builtin_fmaf(2.0f, t2[i], ic2[i]);
+#pragma unroll
+      EACH y[i][k] = o[i] * gain[i];
+    }
+#pragma unroll
+    EACH __builtin_nontemporal_store(y[i], a.out + v0 + 64 * i + r * a.V);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+  {
+    const size_t v = v0 + 64 * i;
+    a.state[v] = om[i]; a.state[a.V + v] = f2u(ic1[i]); a.state[2 * a.V + v] = f2u(ic2[i]);
+  }
+}
+
+template <class F>
+float timeit(F f, int reps = 8)
+{
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0)); for (int i = 0; i < reps; ++i) f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / reps;
+}
+
+#include <algorithm>
+#include <functional>
+#include <string>
+int main(int argc, char** argv)
+{
+  const size_t V = 262144, T = 32, n = V * T * 64;
+  const int rounds = argc > 1 ? atoi(argv[1]) : 7;
+  std::vector<float> co(4 * V), fr(V);
+  for (size_t v = 0; v < V; ++v)
+  {
+    fr[v] = (float)(55.0 * pow(2.0, 5.0 * v / (double)V) / 48000.0);
+    const float omega = fminf(0.45f, 4.f * fr[v]), k = 0.5f;
+    const float piOmega = 3.14159265f * omega, s1 = sinf(piOmega), s2 = sinf(2.f * piOmega), nrm = 1.f / (2.f + k * s2);
+    co[v] = s2 * nrm; co[V + v] = (-2.f * s1 * s1 - k * s2) * nrm; co[2 * V + v] = (2.f * s1 * s1) * nrm; co[3 * V + v] = 0.25f;
+  }
+  float *dco, *dfr; uint32_t* dst; f32x4 *out0, *out1;
+  CK(hipMalloc(&dco, 16 * V)); CK(hipMalloc(&dfr, 4 * V)); CK(hipMalloc(&dst, 12 * V));
+  CK(hipMalloc(&out0, 4 * n)); CK(hipMalloc(&out1, 4 * n));
+  CK(hipMemcpy(dco, co.data(), 16 * V, hipMemcpyHostToDevice)); CK(hipMemcpy(dfr, fr.data(), 4 * V, hipMemcpyHostToDevice));
+  std::vector<uint32_t> ref(n), got(n);
+  struct Var { std::string name; std::function<void(Args)> launch; std::vector<float> ms; size_t bad; };
+  std::vector<Var> vars;
+  auto add = [&](const char* name, std::function<void(Args)> f) { vars.push_back({name, f, {}, 0}); };
+  add("v0  1v/lane blk256", [&](Args a) { hipLaunchKernelGGL(k_v0<256>, dim3(V / 256), dim3(256), 0, 0, a); });
+  add("v0  1v/lane blk64", [&](Args a) { hipLaunchKernelGGL(k_v0<64>, dim3(V / 64), dim3(64), 0, 0, a); });
+  add("v0b shape unroll4 nt blk256", [&](Args a) { hipLaunchKernelGGL((k_v0b<256, 4, true>), dim3(V / 256), dim3(256), 0, 0, a, 16 * V, V, (size_t)1); });
+  add("v0b shape unroll1 nt blk256", [&](Args a) { hipLaunchKernelGGL((k_v0b<256, 1, true>), dim3(V / 256), dim3(256), 0, 0, a, 16 * V, V, (size_t)1); });
+  add("v0b shape unroll1 plain blk256", [&](Args a) { hipLaunchKernelGGL((k_v0b<256, 1, false>), dim3(V / 256), dim3(256), 0, 0, a, 16 * V, V, (size_t)1); });
+  add("v0b shape unroll1 nt blk64", [&](Args a) { hipLaunchKernelGGL((k_v0b<64, 1, true>), dim3(V / 64), dim3(64), 0, 0, a, 16 * V, V, (size_t)1); });
+  add("v0b shape unroll4 nt blk64", [&](Args a) { hipLaunchKernelGGL((k_v0b<64, 4, true>), dim3(V / 64), dim3(64), 0, 0, a, 16 * V, V, (size_t)1); });
+  add("v1  2v/lane blk64", [&](Args a) { hipLaunchKernelGGL(k_v1<64>, dim3(V / 128), dim3(64), 0, 0, a); });
+  add("v1  2v/lane blk128", [&](Args a) { hipLaunchKernelGGL(k_v1<128>, dim3(V / 256), dim3(128), 0, 0, a); });
+  add("v1  2v/lane blk256", [&](Args a) { hipLaunchKernelGGL(k_v1<256>, dim3(V / 512), dim3(256), 0, 0, a); });
+  add("v2  N=2 explicit blk64", [&](Args a) { hipLaunchKernelGGL((k_v2<64, 2>), dim3(V / 128), dim3(64), 0, 0, a); });
+  // correctness of every variant against variant 0, from cleared state
+  for (size_t i = 0; i < vars.size(); ++i)
+  {
+    Args a{dco, dst, dfr, i == 0 ? out0 : out1, V, T};
+    CK(hipMemset(dst, 0, 12 * V));
+    vars[i].launch(a);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(got.data(), a.out, 4 * n, hipMemcpyDeviceToHost));
+    if (i == 0) ref = got; else for (size_t j = 0; j < n; ++j) vars[i].bad += (got[j] != ref[j]);
+  }
+  // interleaved timing: rounds x (each variant: 10 launches alternating two output buffers)
+  for (int r = 0; r < rounds; ++r)
+    for (auto& v : vars)
+    {
+      int k = 0;
+      Args a0{dco, dst, dfr, out0, V, T}, a1{dco, dst, dfr, out1, V, T};
+      v.ms.push_back(timeit([&] { v.launch((k++ & 1) ? a1 : a0); }, 10));
+    }
+  for (auto& v : vars)
+  {
+    std::sort(v.ms.begin(), v.ms.end());
+    const float mn = v.ms.front(), md = v.ms[v.ms.size() / 2];
+    printf("%-32s min %.4f ms (%.0f GB/s)  median %.4f ms (%.0f GB/s)  mismatches %zu\n", v.name.c_str(), mn,
+           4.0 * n / mn / 1e6, md, 4.0 * n / md / 1e6, v.bad);
+  }
+  return 0;
+}
