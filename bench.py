@@ -46,23 +46,13 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def partition(total_voices, world, rank):
-    """Contiguous voice range [lo, hi) owned by `rank`."""
-    per = total_voices // world
-    rem = total_voices % world
-    lo = rank * per + min(rank, rem)
-    return lo, lo + per + (1 if rank < rem else 0)
+from madronalib_amd.sharding import cfg3_voice_params, max_over_ranks, partition  # noqa: E402
 
 
 def cfg3_params(lo, hi, total):
     """Per-voice freq and Bandpass coefficients of config 3 for global voices [lo, hi)."""
     import madronalib_amd as ml
-    v = np.arange(lo, hi, dtype=np.float64)
-    freq = (55.0 * 2.0 ** (5.0 * v / total) / 48000.0).astype(np.float32)
-    om = np.minimum(0.45, 4.0 * freq.astype(np.float64)).astype(np.float32)
-    uniq, inv = np.unique(om, return_inverse=True)
-    table = np.stack([ml.Bandpass.makeCoeffs(float(o), 0.5) for o in uniq])
-    return freq, np.ascontiguousarray(table[inv].T)  # [3][V]
+    return cfg3_voice_params(lo, hi, total, ml.Bandpass.makeCoeffs)
 
 
 def setup_workload(eng, name, V, T, lo, total):
@@ -226,11 +216,9 @@ def main():
     eng.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.barrier()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist if world > 1 else None, "cuda")
 
     if rank == 0:
         units = float(total) * T * 64 * L * args.steps      # voice-samples over all ranks

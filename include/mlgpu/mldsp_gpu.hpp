@@ -1,0 +1,370 @@
+// mldsp_gpu.hpp — C++17 host mirror of the mldsp.h operator interface over the mlgpu C-ABI.
+//
+// The reference's interface for this path is header-only C++ (include/mldsp.h): value-type
+// functors with `static makeCoeffs(...)`, a public `coeffs` member, `clear()` and
+// `operator()(DSPVector)` (source/DSP/MLDSPFilters.h:199-240, MLDSPGens.h:395-402), composed per
+// voice and replicated with `Bank<T,ROWS>` (MLDSPFunctional.h:321-360). This header keeps those
+// names and argument meanings, but a bank here is runtime-sized and lives on an MI355X:
+//
+//   reference (one voice, CPU)                    this header (V voices, GPU)
+//   ------------------------------------------    -------------------------------------------------
+//   SawGen saw; Bandpass bp;                      VoiceBank<SawGen, Bandpass, Gain> bank(engine, V);
+//   saw.clear();                                  bank.clear();
+//   bp.coeffs = Bandpass::makeCoeffs(om, k);      bank.coeffs<1>(v, Bandpass::makeCoeffs(om, k));
+//   y = bp(saw(DSPVector(f))) * gain;             bank.input(v, f); bank.coeffs<2>(v, {gain});
+//                                                 bank.commit(); bank(T, out);   // T DSPVectors, all voices
+//
+// Everything numeric happens in libmlgpu.so (HIP kernels); this file only forwards. Errors of the
+// C-ABI become ml::gpu::Error exceptions (the reference has no error channel).
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../mlgpu.h"
+
+namespace ml
+{
+namespace gpu
+{
+constexpr size_t kFloatsPerDSPVector = MLGPU_FLOATS_PER_DSPVECTOR;
+
+struct Error : std::runtime_error
+{
+  int status;
+  Error(int st, const std::string& what) : std::runtime_error(what), status(st) {}
+};
+
+class Engine
+{
+  mlgpu_engine* e_{nullptr};
+
+ public:
+  explicit Engine(int device = 0)
+  {
+    const int st = mlgpu_engine_create(device, &e_);
+    if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_engine_create: ") + mlgpu_status_string(st));
+  }
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+  ~Engine()
+  {
+    if (e_) mlgpu_engine_destroy(e_);
+  }
+  mlgpu_engine* handle() const { return e_; }
+  void check(int st) const
+  {
+    if (st != MLGPU_OK) throw Error(st, std::string(mlgpu_status_string(st)) + ": " + mlgpu_last_error(e_));
+  }
+  void sync() const { check(mlgpu_engine_sync(e_)); }
+};
+
+// A V-voice, T-vector float signal in HBM.
+class DeviceSignal
+{
+  const Engine* eng_{nullptr};
+  float* d_{nullptr};
+  size_t voices_{0}, vectors_{0};
+  int layout_{MLGPU_LAYOUT_QUAD};
+
+ public:
+  DeviceSignal() = default;
+  DeviceSignal(const Engine& e, size_t voices, size_t vectors, int layout = MLGPU_LAYOUT_QUAD)
+      : eng_(&e), voices_(voices), vectors_(vectors), layout_(layout)
+  {
+    void* p = nullptr;
+    e.check(mlgpu_alloc(e.handle(), bytes(), &p));
+    d_ = static_cast<float*>(p);
+  }
+  DeviceSignal(DeviceSignal&& o) noexcept { *this = std::move(o); }
+  DeviceSignal& operator=(DeviceSignal&& o) noexcept
+  {
+    std::swap(eng_, o.eng_);
+    std::swap(d_, o.d_);
+    std::swap(voices_, o.voices_);
+    std::swap(vectors_, o.vectors_);
+    std::swap(layout_, o.layout_);
+    return *this;
+  }
+  DeviceSignal(const DeviceSignal&) = delete;
+  DeviceSignal& operator=(const DeviceSignal&) = delete;
+  ~DeviceSignal()
+  {
+    if (d_) mlgpu_free(eng_->handle(), d_);
+  }
+  float* data() const { return d_; }
+  size_t voices() const { return voices_; }
+  size_t vectors() const { return vectors_; }
+  int layout() const { return layout_; }
+  size_t size() const { return voices_ * vectors_ * kFloatsPerDSPVector; }
+  size_t bytes() const { return size() * sizeof(float); }
+
+  // host copies in the reference's DSPVectorArray<V> order: [vector][voice][64]
+  std::vector<float> toRows() const
+  {
+    std::vector<float> h(size());
+    if (layout_ == MLGPU_LAYOUT_ROWS)
+    {
+      eng_->check(mlgpu_download(eng_->handle(), h.data(), d_, bytes()));
+    }
+    else
+    {
+      DeviceSignal tmp(*eng_, voices_, vectors_, MLGPU_LAYOUT_ROWS);
+      eng_->check(mlgpu_layout_convert(eng_->handle(), d_, layout_, tmp.data(), MLGPU_LAYOUT_ROWS, voices_, vectors_));
+      eng_->check(mlgpu_download(eng_->handle(), h.data(), tmp.data(), bytes()));
+    }
+    return h;
+  }
+  void fromRows(const std::vector<float>& h)
+  {
+    if (h.size() != size()) throw Error(MLGPU_ERR_INVALID, "DeviceSignal::fromRows: size mismatch");
+    if (layout_ == MLGPU_LAYOUT_ROWS)
+    {
+      eng_->check(mlgpu_upload(eng_->handle(), d_, h.data(), bytes()));
+    }
+    else
+    {
+      DeviceSignal tmp(*eng_, voices_, vectors_, MLGPU_LAYOUT_ROWS);
+      eng_->check(mlgpu_upload(eng_->handle(), tmp.data(), h.data(), bytes()));
+      eng_->check(mlgpu_layout_convert(eng_->handle(), tmp.data(), MLGPU_LAYOUT_ROWS, d_, layout_, voices_, vectors_));
+    }
+  }
+};
+
+// ---- processor tags: same names, same makeCoeffs signatures as the reference -------------------
+
+struct PhasorGen { static constexpr int kind = MLGPU_PROC_PHASOR_GEN; static constexpr int nCoeffs = 0; };
+struct SineGen { static constexpr int kind = MLGPU_PROC_SINE_GEN; static constexpr int nCoeffs = 0; };
+struct SawGen { static constexpr int kind = MLGPU_PROC_SAW_GEN; static constexpr int nCoeffs = 0; };
+struct PulseGen { static constexpr int kind = MLGPU_PROC_PULSE_GEN; static constexpr int nCoeffs = 1; /* width */ };
+struct NoiseGen { static constexpr int kind = MLGPU_PROC_NOISE_GEN; static constexpr int nCoeffs = 0; };
+struct TickGen { static constexpr int kind = MLGPU_PROC_TICK_GEN; static constexpr int nCoeffs = 0; };
+struct ImpulseGen { static constexpr int kind = MLGPU_PROC_IMPULSE_GEN; static constexpr int nCoeffs = 0; };
+struct OneShotGen { static constexpr int kind = MLGPU_PROC_ONE_SHOT_GEN; static constexpr int nCoeffs = 0; };
+
+struct Lopass  // MLDSPFilters.h:51-153
+{
+  static constexpr int kind = MLGPU_PROC_LOPASS;
+  static constexpr int nCoeffs = 3;
+  using Coeffs = std::array<float, 3>;
+  static Coeffs makeCoeffs(float omega, float k)
+  {
+    Coeffs c;
+    mlgpu_lopass_make_coeffs(omega, k, c.data());
+    return c;
+  }
+};
+struct Hipass  // :155-197
+{
+  static constexpr int kind = MLGPU_PROC_HIPASS;
+  static constexpr int nCoeffs = 4;
+  using Coeffs = std::array<float, 4>;
+  static Coeffs makeCoeffs(float omega, float k)
+  {
+    Coeffs c;
+    mlgpu_hipass_make_coeffs(omega, k, c.data());
+    return c;
+  }
+};
+struct Bandpass  // :199-240
+{
+  static constexpr int kind = MLGPU_PROC_BANDPASS;
+  static constexpr int nCoeffs = 3;
+  using Coeffs = std::array<float, 3>;
+  static Coeffs makeCoeffs(float omega, float k)
+  {
+    Coeffs c;
+    mlgpu_bandpass_make_coeffs(omega, k, c.data());
+    return c;
+  }
+};
+struct LoShelf  // :242-319
+{
+  static constexpr int kind = MLGPU_PROC_LO_SHELF;
+  static constexpr int nCoeffs = 5;
+  using Coeffs = std::array<float, 5>;
+  using params = std::array<float, 3>;  // omega, k, A
+  static Coeffs makeCoeffs(params p)
+  {
+    Coeffs c;
+    mlgpu_loshelf_make_coeffs(p[0], p[1], p[2], c.data());
+    return c;
+  }
+};
+struct HiShelf  // :321-400
+{
+  static constexpr int kind = MLGPU_PROC_HI_SHELF;
+  static constexpr int nCoeffs = 6;
+  using Coeffs = std::array<float, 6>;
+  using params = std::array<float, 3>;
+  static Coeffs makeCoeffs(params p)
+  {
+    Coeffs c;
+    mlgpu_hishelf_make_coeffs(p[0], p[1], p[2], c.data());
+    return c;
+  }
+};
+struct Bell  // :402-442
+{
+  static constexpr int kind = MLGPU_PROC_BELL;
+  static constexpr int nCoeffs = 4;
+  using Coeffs = std::array<float, 4>;
+  static Coeffs makeCoeffs(float omega, float k, float A)
+  {
+    Coeffs c;
+    mlgpu_bell_make_coeffs(omega, k, A, c.data());
+    return c;
+  }
+};
+struct OnePole  // :446-481
+{
+  static constexpr int kind = MLGPU_PROC_ONE_POLE;
+  static constexpr int nCoeffs = 2;
+  using Coeffs = std::array<float, 2>;
+  static Coeffs makeCoeffs(float omega)
+  {
+    Coeffs c;
+    mlgpu_onepole_make_coeffs(omega, c.data());
+    return c;
+  }
+  static Coeffs passthru() { return {1.f, 0.f}; }
+};
+struct DCBlocker  // :489-513
+{
+  static constexpr int kind = MLGPU_PROC_DC_BLOCKER;
+  static constexpr int nCoeffs = 1;
+  using Coeffs = std::array<float, 1>;
+  static Coeffs makeCoeffs(float omega) { return {mlgpu_dcblocker_make_coeffs(omega)}; }
+};
+struct Differentiator { static constexpr int kind = MLGPU_PROC_DIFFERENTIATOR; static constexpr int nCoeffs = 0; };
+struct Integrator { static constexpr int kind = MLGPU_PROC_INTEGRATOR; static constexpr int nCoeffs = 1; /* mLeak */ };
+struct RMS  // :619-653
+{
+  static constexpr int kind = MLGPU_PROC_RMS;
+  static constexpr int nCoeffs = 2;
+  using Coeffs = std::array<float, 2>;
+  static Coeffs makeCoeffs(float omega) { return OnePole::makeCoeffs(omega); }
+};
+struct ADSR  // :657-797
+{
+  static constexpr int kind = MLGPU_PROC_ADSR;
+  static constexpr int nCoeffs = 4;
+  using Coeffs = std::array<float, 4>;
+  static Coeffs calcCoeffs(float a, float d, float s, float r, float sr)
+  {
+    Coeffs c;
+    mlgpu_adsr_calc_coeffs(a, d, s, r, sr, c.data());
+    return c;
+  }
+};
+struct Gain { static constexpr int kind = MLGPU_PROC_GAIN; static constexpr int nCoeffs = 1; };
+
+inline float dBToGain(float dB) { return mlgpu_db_to_gain(dB); }  // MLDSPFilters.h:30
+
+// ---- VoiceBank: runtime-sized Bank<T, ROWS> where T is the chain Procs... -----------------------
+
+template <class... Procs>
+class VoiceBank
+{
+  const Engine& eng_;
+  mlgpu_bank* b_{nullptr};
+  size_t voices_;
+  static constexpr int kNumProcs = sizeof...(Procs);
+  static constexpr std::array<int, sizeof...(Procs)> kNC{Procs::nCoeffs...};
+  std::array<std::vector<float>, sizeof...(Procs)> hostCoeffs_;  // [proc][coeff * V + v]
+  std::vector<float> hostInput_;
+  std::array<bool, sizeof...(Procs)> dirty_{};
+  bool inputDirty_{false};
+
+ public:
+  VoiceBank(const Engine& e, size_t nVoices) : eng_(e), voices_(nVoices)
+  {
+    const int32_t kinds[] = {Procs::kind...};
+    eng_.check(mlgpu_bank_create(e.handle(), kinds, kNumProcs, nVoices, &b_));
+    for (int p = 0; p < kNumProcs; ++p) hostCoeffs_[p].assign((size_t)kNC[p] * nVoices, 0.f);
+    hostInput_.assign(nVoices, 0.f);
+  }
+  VoiceBank(const VoiceBank&) = delete;
+  VoiceBank& operator=(const VoiceBank&) = delete;
+  ~VoiceBank()
+  {
+    if (b_) mlgpu_bank_destroy(b_);
+  }
+
+  size_t voices() const { return voices_; }
+  bool fused() const { return mlgpu_bank_is_fused(b_) != 0; }
+
+  // Bank::clear(), MLDSPFunctional.h:351-357
+  void clear() { eng_.check(mlgpu_bank_clear(b_)); }
+
+  // `bank[v].proc<I>.coeffs = c` of the reference; staged on the host until commit()
+  template <int I, size_t N>
+  void coeffs(size_t voice, const std::array<float, N>& c)
+  {
+    static_assert(I >= 0 && I < kNumProcs, "processor index out of range");
+    static_assert((int)N == kNC[I], "wrong number of coefficients for this processor");
+    for (size_t i = 0; i < N; ++i) hostCoeffs_[I][i * voices_ + voice] = c[i];
+    dirty_[I] = true;
+  }
+  // same coefficients for every voice
+  template <int I, size_t N>
+  void coeffsAll(const std::array<float, N>& c)
+  {
+    static_assert((int)N == kNC[I], "wrong number of coefficients for this processor");
+    for (size_t i = 0; i < N; ++i) eng_.check(mlgpu_bank_set_coeff_uniform(b_, I, (int)i, c[i]));
+    for (size_t i = 0; i < N; ++i) std::fill_n(hostCoeffs_[I].begin() + i * voices_, voices_, c[i]);
+  }
+  // the scalar the head processor sees, i.e. `saw(DSPVector(f))`: per-voice constant input
+  void input(size_t voice, float f)
+  {
+    hostInput_[voice] = f;
+    inputDirty_ = true;
+  }
+  // upload staged coefficients / inputs
+  void commit()
+  {
+    for (int p = 0; p < kNumProcs; ++p)
+    {
+      if (!dirty_[p]) continue;
+      for (int i = 0; i < kNC[p]; ++i) eng_.check(mlgpu_bank_set_coeff(b_, p, i, hostCoeffs_[p].data() + (size_t)i * voices_));
+      dirty_[p] = false;
+    }
+    if (inputDirty_) eng_.check(mlgpu_bank_set_input_const(b_, hostInput_.data()));
+    inputDirty_ = false;
+  }
+
+  // Bank::operator(), MLDSPFunctional.h:328-337, for out.vectors() DSPVectors of every voice.
+  // Generators / chains fed by the per-voice constant input:
+  void operator()(DeviceSignal& out)
+  {
+    commit();
+    eng_.check(mlgpu_bank_process(b_, out.vectors(), nullptr, MLGPU_LAYOUT_QUAD, out.data(), out.layout()));
+  }
+  // Chains fed by a streamed signal (filters):
+  void operator()(const DeviceSignal& in, DeviceSignal& out)
+  {
+    if (in.voices() != voices_ || out.voices() != voices_ || in.vectors() != out.vectors())
+      throw Error(MLGPU_ERR_INVALID, "VoiceBank: signal shape mismatch");
+    commit();
+    eng_.check(mlgpu_bank_process(b_, out.vectors(), in.data(), in.layout(), out.data(), out.layout()));
+  }
+
+  // raw state (checkpoint / resume)
+  std::vector<uint32_t> state(int proc, int idx) const
+  {
+    std::vector<uint32_t> s(voices_);
+    eng_.check(mlgpu_bank_get_state(b_, proc, idx, s.data()));
+    return s;
+  }
+  void setState(int proc, int idx, const std::vector<uint32_t>& s) { eng_.check(mlgpu_bank_set_state(b_, proc, idx, s.data())); }
+  void setStateAll(int proc, int idx, uint32_t v) { eng_.check(mlgpu_bank_set_state_uniform(b_, proc, idx, v)); }
+};
+
+}  // namespace gpu
+}  // namespace ml
