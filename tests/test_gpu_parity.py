@@ -178,6 +178,35 @@ def test_chain_vs_oracle_with_resume(eng, oracle, name):
     assert_bits_equal(gst, st, False, name + " state")
 
 
+CASCADES = {
+    "lopass2": [Proc.LOPASS] * 2, "lopass4": [Proc.LOPASS] * 4, "lopass8": [Proc.LOPASS] * 8,
+    "hipass2": [Proc.HIPASS] * 2, "hipass4": [Proc.HIPASS] * 4,
+    "bandpass2": [Proc.BANDPASS] * 2, "bandpass4": [Proc.BANDPASS] * 4,
+    "noise_lopass8": [Proc.NOISE_GEN] + [Proc.LOPASS] * 8, "saw_lopass4": [Proc.SAW_GEN] + [Proc.LOPASS] * 4,
+}
+
+
+@pytest.mark.parametrize("layout", [Layout.QUAD, Layout.ROWS, Layout.VOICE_MAJOR])
+@pytest.mark.parametrize("T", [1, 2, 9])
+@pytest.mark.parametrize("name", list(CASCADES))
+def test_skewed_cascade_vs_oracle(eng, oracle, name, T, layout):
+    """The stage-skewed cascade kernel fills and drains its pipeline inside every launch: outputs and
+    state must equal the sample-at-a-time oracle for any launch length, layout and across launches."""
+    procs = CASCADES[name]
+    V = 150
+    co = chain_coeffs(oracle, procs, V, seed=21)
+    sig, const = chain_input(procs, V, T, seed=3)
+    st = oracle.chain_clear(procs, V)
+    if procs[0] == Proc.NOISE_GEN:
+        st[0] = np.arange(V, dtype=np.uint32) + 7
+    outs, gst, fused = _run_gpu(eng, procs, V, T, co, st.copy(), sig, const, layout, calls=3)
+    assert fused
+    for got in outs:
+        want = oracle.chain_process(procs, T, co, st, sig, const, n_threads=4)
+        assert_bits_equal(got, want, True, f"{name} T={T}")
+    assert_bits_equal(gst, st, False, name + " state")
+
+
 @pytest.mark.parametrize("name", chain_case_names())
 def test_chain_vs_golden(eng, name):
     c = chain_case(load_chains(), name)
