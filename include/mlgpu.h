@@ -29,7 +29,9 @@
 #ifndef MLGPU_H
 #define MLGPU_H
 
+#ifndef __HIPCC_RTC__ /* hiprtc (the engine's own run-time kernel generator) predefines size_t */
 #include <stddef.h>
+#endif
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -295,6 +297,63 @@ int mlgpu_bank_process(mlgpu_bank* b, size_t n_vectors, const float* d_in, int i
 int mlgpu_bank_is_fused(mlgpu_bank* b);
 /* Name of the device kernel that dominates mlgpu_bank_process (for profile lookup). */
 const char* mlgpu_bank_kernel_name(mlgpu_bank* b);
+
+/* ------------------------------------------------------------------------- */
+/* graphs ("procs")                                                           */
+/*
+ * A run-time defined DAG of processors (MLGPU_PROC_*) and stateless ops (MLGPU_OP_*) per voice,
+ * with named nodes, after the naming convention of the reference's dynamic-graph stub
+ * (source/procs/MLProcMultiply.cpp:12-18,29-32,46: named params / inputs / outputs, a process()
+ * made of mldsp.h calls, registration by name). The reference has no executor; this
+ * one compiles the whole graph into ONE fused gfx950 kernel with hiprtc: every edge is a
+ * register, only graph inputs and outputs touch HBM.
+ *
+ * Build: add nodes in topological order (a node's inputs must already exist; there are no
+ * feedback edges), mark outputs, compile, then set params/coeffs and process.
+ *   input  streamed per-voice signal (one DeviceSignal per input, in the order added)
+ *   param  per-voice constant, seen by its consumers as DSPVector(f) (MLDSPOps.h:157)
+ *   const  one float for all voices
+ *   proc   stateful processor: 1 signal input (generators: cyclesPerSample; NoiseGen: none;
+ *          PulseGen: freq or freq + width, MLDSPGens.h:390)
+ *   op     stateless elementwise op with 1..3 inputs (masks travel as bit patterns)
+ * add_* return the node id (>= 0) or -(mlgpu_status) on error.
+ */
+typedef struct mlgpu_graph mlgpu_graph;
+
+int mlgpu_graph_create(mlgpu_engine* e, size_t n_voices, mlgpu_graph** out);
+int mlgpu_graph_destroy(mlgpu_graph* g);
+int mlgpu_graph_add_input(mlgpu_graph* g, const char* name);
+int mlgpu_graph_add_param(mlgpu_graph* g, const char* name);
+int mlgpu_graph_add_const(mlgpu_graph* g, float value);
+int mlgpu_graph_add_proc(mlgpu_graph* g, int proc_kind, const int* input_nodes, int n_inputs, const char* name);
+int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* input_nodes, int n_inputs, const char* name);
+int mlgpu_graph_add_output(mlgpu_graph* g, int node);
+int mlgpu_graph_node(mlgpu_graph* g, const char* name); /* id of the node called `name`, or < 0 */
+int mlgpu_graph_num_nodes(mlgpu_graph* g);
+/* Generate + compile (hiprtc, gfx950) + load the fused kernel; allocate state/coeffs/params. */
+int mlgpu_graph_compile(mlgpu_graph* g);
+/* The generated HIP source (valid after compile; for inspection). */
+const char* mlgpu_graph_source(mlgpu_graph* g);
+int mlgpu_graph_clear(mlgpu_graph* g); /* T::clear() on every processor node */
+int mlgpu_graph_set_param(mlgpu_graph* g, int param_node, const float* h_per_voice);
+int mlgpu_graph_set_param_uniform(mlgpu_graph* g, int param_node, float value);
+int mlgpu_graph_num_coeffs(mlgpu_graph* g, int proc_node);
+int mlgpu_graph_num_state(mlgpu_graph* g, int proc_node);
+int mlgpu_graph_set_coeff(mlgpu_graph* g, int proc_node, int coeff_idx, const float* h_per_voice);
+int mlgpu_graph_set_coeff_uniform(mlgpu_graph* g, int proc_node, int coeff_idx, float value);
+int mlgpu_graph_get_state(mlgpu_graph* g, int proc_node, int state_idx, uint32_t* h_per_voice);
+int mlgpu_graph_set_state(mlgpu_graph* g, int proc_node, int state_idx, const uint32_t* h_per_voice);
+/* n_vectors DSPVectors for every voice. d_inputs[i] / d_outputs[o]: device signals in the order the
+ * inputs / outputs were added, all in `in_layout` / `out_layout`. */
+int mlgpu_graph_process(mlgpu_graph* g, size_t n_vectors, const float* const* d_inputs, int in_layout,
+                        float* const* d_outputs, int out_layout);
+
+/* Chains without an ahead-of-time kernel are fused with hiprtc when their bank is created
+ * (default on). With jit off they run processor by processor through HBM scratch signals. */
+int mlgpu_engine_set_jit(mlgpu_engine* e, int enabled);
+/* Device-free check that the run-time code generator's output compiles for gfx950 (a chain and a
+ * graph); used by the CPU build check. Writes the compiler log (if any) to `log`. */
+int mlgpu_jit_selftest(char* log, size_t log_len);
 
 /* ------------------------------------------------------------------------- */
 /* coefficient makers — host-side, glibc libm, formulas of the reference     */

@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, RowOp, Status
 
-__all__ = ["Engine", "Bank", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status",
+__all__ = ["Engine", "Bank", "Graph", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status",
            "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
            "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
 
@@ -108,6 +108,10 @@ class Engine:
 
     def sync(self):
         self._check(self.L.mlgpu_engine_sync(self.h))
+
+    def set_jit(self, enabled):
+        """hiprtc fusion of chains that have no ahead-of-time kernel (default on)."""
+        self._check(self.L.mlgpu_engine_set_jit(self.h, 1 if enabled else 0))
 
     @property
     def stream(self):
@@ -294,6 +298,154 @@ class Bank:
             res = eng.alloc(nbytes)
             eng.layout_convert(d_out, layout, res, Layout.VOICE_MAJOR, V, T)
         return res.download(np.float32, V * T * 64).reshape(V, 64 * T)
+
+
+class Graph:
+    """A run-time defined per-voice DAG of processors and ops, fused into one kernel (mlgpu_graph).
+
+    Nodes are named (after the reference's proc convention, source/procs/MLProcMultiply.cpp:12-18) and
+    are added in topological order. `description` form (see patches.py): a list of dicts
+      {"name", "type": "input"|"param"|"const"|"proc"|"op", "kind": Proc.X / Op.X, "inputs": [names], "value"}
+    """
+
+    def __init__(self, engine, n_voices, description=None, outputs=None):
+        self.engine = engine
+        self.L = engine.L
+        self.V = int(n_voices)
+        h = ctypes.c_void_p()
+        engine._check(self.L.mlgpu_graph_create(engine.h, self.V, ctypes.byref(h)))
+        self.h = h
+        self.ids = {}
+        self.inputs, self.outputs = [], []
+        engine._children.add(self)
+        if description is not None:
+            for n in description:
+                self.add(**n)
+            for o in (outputs or [description[-1]["name"]]):
+                self.add_output(o)
+            self.compile()
+
+    def close(self):
+        if getattr(self, "h", None) and self.engine.h:
+            self.L.mlgpu_graph_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _id(self, ref):
+        return self.ids[ref] if isinstance(ref, str) else int(ref)
+
+    def _ret(self, r, name):
+        if r < 0:
+            raise MlgpuError(-r, self.L.mlgpu_last_error(self.engine.h).decode())
+        if name:
+            self.ids[name] = r
+        return r
+
+    def add(self, name, type, kind=None, inputs=(), value=None):
+        bname = name.encode() if name else None
+        ins = [self._id(i) for i in inputs]
+        arr = (ctypes.c_int * max(1, len(ins)))(*ins)
+        if type == "input":
+            self.inputs.append(name)
+            return self._ret(self.L.mlgpu_graph_add_input(self.h, bname), name)
+        if type == "param":
+            return self._ret(self.L.mlgpu_graph_add_param(self.h, bname), name)
+        if type == "const":
+            return self._ret(self.L.mlgpu_graph_add_const(self.h, float(value)), name)
+        if type == "proc":
+            return self._ret(self.L.mlgpu_graph_add_proc(self.h, int(kind), arr, len(ins), bname), name)
+        if type == "op":
+            return self._ret(self.L.mlgpu_graph_add_op(self.h, int(kind), arr, len(ins), bname), name)
+        raise ValueError(type)
+
+    def add_output(self, node):
+        self.outputs.append(node)
+        self.engine._check(self.L.mlgpu_graph_add_output(self.h, self._id(node)))
+
+    def compile(self):
+        self.engine._check(self.L.mlgpu_graph_compile(self.h))
+
+    @property
+    def source(self):
+        return self.L.mlgpu_graph_source(self.h).decode()
+
+    def clear(self):
+        self.engine._check(self.L.mlgpu_graph_clear(self.h))
+
+    def set_param(self, node, value):
+        if np.isscalar(value):
+            self.engine._check(self.L.mlgpu_graph_set_param_uniform(self.h, self._id(node), float(value)))
+        else:
+            v = np.ascontiguousarray(value, np.float32)
+            assert v.shape == (self.V,)
+            self.engine._check(self.L.mlgpu_graph_set_param(self.h, self._id(node), _np_ptr(v)))
+
+    def set_coeff(self, node, idx, value):
+        if np.isscalar(value):
+            self.engine._check(self.L.mlgpu_graph_set_coeff_uniform(self.h, self._id(node), idx, float(value)))
+        else:
+            v = np.ascontiguousarray(value, np.float32)
+            assert v.shape == (self.V,)
+            self.engine._check(self.L.mlgpu_graph_set_coeff(self.h, self._id(node), idx, _np_ptr(v)))
+
+    def set_coeffs(self, node, coeffs):
+        for i, c in enumerate(coeffs):
+            self.set_coeff(node, i, c if np.ndim(c) else float(c))
+
+    def num_state(self, node):
+        return self.L.mlgpu_graph_num_state(self.h, self._id(node))
+
+    def get_state(self, node, idx):
+        out = np.empty(self.V, np.uint32)
+        self.engine._check(self.L.mlgpu_graph_get_state(self.h, self._id(node), idx, _np_ptr(out)))
+        return out
+
+    def set_state(self, node, idx, value):
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, np.uint32), (self.V,)))
+        self.engine._check(self.L.mlgpu_graph_set_state(self.h, self._id(node), idx, _np_ptr(v)))
+
+    def process(self, n_vectors, d_inputs, d_outputs, in_layout=Layout.QUAD, out_layout=Layout.QUAD):
+        """d_inputs / d_outputs: lists of DeviceBuffer in the order inputs / outputs were added."""
+        pi = (ctypes.c_void_p * max(1, len(d_inputs)))(*[b.ptr for b in d_inputs])
+        po = (ctypes.c_void_p * max(1, len(d_outputs)))(*[b.ptr for b in d_outputs])
+        self.engine._check(self.L.mlgpu_graph_process(self.h, int(n_vectors), pi, int(in_layout), po, int(out_layout)))
+
+    def process_host(self, n_vectors, in_signals, layout=Layout.QUAD):
+        """Test convenience: VOICE_MAJOR numpy in ({name: [V][64T]}) -> list of VOICE_MAJOR numpy outs."""
+        eng, V, T = self.engine, self.V, int(n_vectors)
+        nbytes = V * T * 64 * 4
+        d_in = []
+        for name in self.inputs:
+            d_vm = eng.to_device(np.ascontiguousarray(in_signals[name], np.float32))
+            if layout == Layout.VOICE_MAJOR:
+                d_in.append(d_vm)
+            else:
+                d = eng.alloc(nbytes)
+                eng.layout_convert(d_vm, Layout.VOICE_MAJOR, d, layout, V, T)
+                d_in.append(d)
+        d_out = [eng.alloc(nbytes) for _ in self.outputs]
+        self.process(T, d_in, d_out, layout, layout)
+        res = []
+        for d in d_out:
+            if layout != Layout.VOICE_MAJOR:
+                r = eng.alloc(nbytes)
+                eng.layout_convert(d, layout, r, Layout.VOICE_MAJOR, V, T)
+                d = r
+            res.append(d.download(np.float32, V * T * 64).reshape(V, 64 * T))
+        return res
+
+
+def jit_selftest():
+    """Device-free: do the run-time generated chain / graph kernels compile for gfx950?"""
+    L = _lib.load()
+    buf = ctypes.create_string_buffer(1 << 16)
+    st = L.mlgpu_jit_selftest(buf, len(buf))
+    return st, buf.value.decode()
 
 
 # ---- coefficient makers: host libm through the C-ABI (reference: static T::makeCoeffs) ----

@@ -12,8 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmlgpu.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mlgpu.h")
 
-_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "coeffs.cpp", "mldsp_math.hpp", "mldsp_procs.hpp",
-            "mlgpu_internal.hpp", "Makefile"]
+_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "coeffs.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
+            "mldsp_procs.hpp", "mldsp_kernels.hpp", "mlgpu_device_args.hpp", "mlgpu_internal.hpp", "embed.py",
+            "Makefile"]
 
 
 def needs_build():
@@ -101,6 +102,31 @@ def _declare(L):
     sig("mlgpu_bank_process", i, [vp, sz, vp, i, vp, i])
     sig("mlgpu_bank_is_fused", i, [vp])
     sig("mlgpu_bank_kernel_name", c.c_char_p, [vp])
+    ip = c.POINTER(c.c_int)
+    sig("mlgpu_engine_set_jit", i, [vp, i])
+    sig("mlgpu_jit_selftest", i, [c.c_char_p, sz])
+    sig("mlgpu_graph_create", i, [vp, sz, pp])
+    sig("mlgpu_graph_destroy", i, [vp])
+    sig("mlgpu_graph_add_input", i, [vp, c.c_char_p])
+    sig("mlgpu_graph_add_param", i, [vp, c.c_char_p])
+    sig("mlgpu_graph_add_const", i, [vp, f])
+    sig("mlgpu_graph_add_proc", i, [vp, i, ip, i, c.c_char_p])
+    sig("mlgpu_graph_add_op", i, [vp, i, ip, i, c.c_char_p])
+    sig("mlgpu_graph_add_output", i, [vp, i])
+    sig("mlgpu_graph_node", i, [vp, c.c_char_p])
+    sig("mlgpu_graph_num_nodes", i, [vp])
+    sig("mlgpu_graph_compile", i, [vp])
+    sig("mlgpu_graph_source", c.c_char_p, [vp])
+    sig("mlgpu_graph_clear", i, [vp])
+    sig("mlgpu_graph_set_param", i, [vp, i, vp])
+    sig("mlgpu_graph_set_param_uniform", i, [vp, i, f])
+    sig("mlgpu_graph_num_coeffs", i, [vp, i])
+    sig("mlgpu_graph_num_state", i, [vp, i])
+    sig("mlgpu_graph_set_coeff", i, [vp, i, i, vp])
+    sig("mlgpu_graph_set_coeff_uniform", i, [vp, i, i, f])
+    sig("mlgpu_graph_get_state", i, [vp, i, i, vp])
+    sig("mlgpu_graph_set_state", i, [vp, i, i, vp])
+    sig("mlgpu_graph_process", i, [vp, sz, pp, i, pp, i])
     sig("mlgpu_lopass_make_coeffs", None, [f, f, fp])
     sig("mlgpu_hipass_make_coeffs", None, [f, f, fp])
     sig("mlgpu_bandpass_make_coeffs", None, [f, f, fp])

@@ -87,7 +87,10 @@ struct mlgpu_bank
   float* d_coeffs{nullptr};
   uint32_t* d_state{nullptr};
   float* d_inConst{nullptr};
-  const ChainEntry* fused{nullptr};
+  const ChainEntry* fused{nullptr};   // ahead-of-time fused kernel, if the chain is in the catalogue
+  void* jitSignal{nullptr};           // else: fused kernels generated with hiprtc at bank creation
+  void* jitConst{nullptr};
+  std::string jitName;
   std::vector<const ChainEntry*> singles;
   float* d_scratch[2]{nullptr, nullptr};
   size_t scratchVectors{0};
@@ -159,6 +162,12 @@ extern "C"
     return MLGPU_OK;
   }
   void* mlgpu_engine_stream(mlgpu_engine* e) { return e ? (void*)e->stream : nullptr; }
+  int mlgpu_engine_set_jit(mlgpu_engine* e, int enabled)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    e->jitEnabled = enabled != 0;
+    return MLGPU_OK;
+  }
   int mlgpu_engine_device(mlgpu_engine* e) { return e ? e->device : -1; }
   const char* mlgpu_last_error(mlgpu_engine* e) { return e ? e->lastError.c_str() : "null engine"; }
 
@@ -334,12 +343,27 @@ extern "C"
     }
     b->fused = mlgpu_find_chain(procs, nProcs);
     hipError_t err = hipSetDevice(e->device);
+    if (!b->fused && e->jitEnabled && err == hipSuccess)
+    {
+      std::string log;
+      if (!mlgpu_jit_chain(e, procs, nProcs, &b->jitSignal, &b->jitConst, log))
+      {
+        b->jitSignal = b->jitConst = nullptr;  // fall back to processor-by-processor execution
+        e->lastError = "hiprtc chain fusion unavailable: " + log;
+      }
+      else
+      {
+        b->jitName = "mlgpu_chain_signal/mlgpu_chain_const (hiprtc, Chain<";
+        for (int p = 0; p < nProcs; ++p) b->jitName += (p ? ", " : "") + std::to_string(procs[p]);
+        b->jitName += ">)";
+      }
+    }
     const size_t V = nVoices;
     // +1 slot so zero-coefficient / zero-state chains still have a valid base pointer
     if (err == hipSuccess) err = hipMalloc((void**)&b->d_coeffs, sizeof(float) * V * (size_t)(b->NC + 1));
     if (err == hipSuccess) err = hipMalloc((void**)&b->d_state, sizeof(uint32_t) * V * (size_t)(b->NS + 1));
     if (err == hipSuccess) err = hipMalloc((void**)&b->d_inConst, sizeof(float) * V);
-    if (err == hipSuccess && !b->fused)
+    if (err == hipSuccess && !b->fused && !b->jitSignal)
     {
       // unfused chains ping-pong through two QUAD-layout scratch signals, processed in
       // slices of scratchVectors DSPVectors so each scratch stays <= 256 MiB
@@ -390,11 +414,13 @@ extern "C"
     if (!b || p < 0 || p >= (int)b->kinds.size()) return -1;
     return b->ns[p];
   }
-  int mlgpu_bank_is_fused(mlgpu_bank* b) { return (b && b->fused) ? 1 : 0; }
+  int mlgpu_bank_is_fused(mlgpu_bank* b) { return (b && (b->fused || b->jitSignal)) ? 1 : 0; }
   const char* mlgpu_bank_kernel_name(mlgpu_bank* b)
   {
     if (!b) return "";
-    return b->fused ? b->fused->kernelName : "chain_kernel<per-processor>";
+    if (b->fused) return b->fused->kernelName;
+    if (b->jitSignal) return b->jitName.c_str();
+    return "chain_kernel<per-processor>";
   }
 
   int mlgpu_bank_clear(mlgpu_bank* b)
@@ -493,6 +519,18 @@ extern "C"
       a.out = makeView(d_out, outLayout, V, T);
       hipError_t err = d_in ? b->fused->launchSignal(a, e->stream, e->cuCount) : b->fused->launchConst(a, e->stream, e->cuCount);
       if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "bank_process launch", err);
+      return MLGPU_OK;
+    }
+
+    if (b->jitSignal)
+    {
+      a.coeffs = b->d_coeffs;
+      a.state = b->d_state;
+      a.T = T;
+      a.in = makeView(d_in, inLayout, V, T);
+      a.out = makeView(d_out, outLayout, V, T);
+      hipError_t err = mlgpu_jit_chain_launch(d_in ? b->jitSignal : b->jitConst, a, e->stream);
+      if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "bank_process launch (jit)", err);
       return MLGPU_OK;
     }
 

@@ -1,0 +1,616 @@
+// graph.hip — run-time defined DSP graphs ("procs") compiled to ONE fused gfx950 kernel.
+//
+// The reference's dynamic-graph layer is a stub (source/procs/MLProcMultiply.cpp: named
+// inputs/outputs/params, a process() that combines mldsp.h objects, registration by name),
+// so this is the engine's own executor for BASELINE configs[4]: a DAG whose nodes are the same
+// processors (MLGPU_PROC_*) and stateless ops (MLGPU_OP_*) the banks use, with named nodes.
+//
+// Execution model: the graph is translated to HIP source that instantiates the hand-written device
+// building blocks (mldsp_procs.hpp / mldsp_ops.hpp) in topological order inside the voice-bank loop
+// (one lane per voice, state in registers, one 16-byte access per lane per quad) and compiled for
+// gfx950 with hiprtc. Every edge of the graph is a register; only graph inputs and outputs touch
+// HBM. Identical graphs share one compiled module per process. The same generator produces fused
+// kernels for processor chains that have no ahead-of-time instantiation (mlgpu_jit_chain).
+#include <hip/hiprtc.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <new>
+#include <sstream>
+
+#include "mlgpu_internal.hpp"
+
+extern const int mlgpu_embedded_count;
+extern const char* const mlgpu_embedded_names[];
+extern const char* const mlgpu_embedded_sources[];
+
+namespace
+{
+struct CompiledModule
+{
+  hipModule_t module{nullptr};
+  std::map<std::string, hipFunction_t> fns;
+};
+
+std::mutex g_cacheMutex;
+std::map<std::string, CompiledModule> g_cache;  // key: device id + source
+
+// compile `source` for gfx950 and load it on the current device; returns nullptr and fills `log` on failure
+CompiledModule* compileAndLoad(int device, const std::string& source, std::string& log)
+{
+  std::lock_guard<std::mutex> lock(g_cacheMutex);
+  const std::string key = std::to_string(device) + "\n" + source;
+  auto it = g_cache.find(key);
+  if (it != g_cache.end()) return &it->second;
+
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, source.c_str(), "mlgpu_jit.hip", mlgpu_embedded_count, (const char**)mlgpu_embedded_sources,
+                          (const char**)mlgpu_embedded_names) != HIPRTC_SUCCESS)
+  {
+    log = "hiprtcCreateProgram failed";
+    return nullptr;
+  }
+  // same numerics flags as the ahead-of-time build (madronalib_amd/csrc/Makefile)
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  size_t logSize = 0;
+  hiprtcGetProgramLogSize(prog, &logSize);
+  if (logSize > 1)
+  {
+    log.resize(logSize);
+    hiprtcGetProgramLog(prog, &log[0]);
+  }
+  if (r != HIPRTC_SUCCESS)
+  {
+    if (log.empty()) log = hiprtcGetErrorString(r);
+    hiprtcDestroyProgram(&prog);
+    return nullptr;
+  }
+  size_t codeSize = 0;
+  hiprtcGetCodeSize(prog, &codeSize);
+  std::vector<char> code(codeSize);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+
+  CompiledModule cm;
+  const hipError_t e = hipModuleLoadData(&cm.module, code.data());
+  if (e != hipSuccess)
+  {
+    log = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
+    return nullptr;
+  }
+  return &(g_cache[key] = cm);
+}
+
+// compile only (no device needed): used by mlgpu_jit_selftest
+bool compileOnly(const std::string& source, std::string& log)
+{
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, source.c_str(), "mlgpu_jit.hip", mlgpu_embedded_count, (const char**)mlgpu_embedded_sources,
+                          (const char**)mlgpu_embedded_names) != HIPRTC_SUCCESS)
+  {
+    log = "hiprtcCreateProgram failed";
+    return false;
+  }
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  size_t logSize = 0;
+  hiprtcGetProgramLogSize(prog, &logSize);
+  if (logSize > 1)
+  {
+    log.resize(logSize);
+    hiprtcGetProgramLog(prog, &log[0]);
+  }
+  size_t codeSize = 0;
+  if (r == HIPRTC_SUCCESS) hiprtcGetCodeSize(prog, &codeSize);
+  hiprtcDestroyProgram(&prog);
+  if (r != HIPRTC_SUCCESS && log.empty()) log = hiprtcGetErrorString(r);
+  return r == HIPRTC_SUCCESS && codeSize > 0;
+}
+
+hipFunction_t getFunction(CompiledModule* cm, const char* name, std::string& log)
+{
+  auto it = cm->fns.find(name);
+  if (it != cm->fns.end()) return it->second;
+  hipFunction_t f = nullptr;
+  const hipError_t e = hipModuleGetFunction(&f, cm->module, name);
+  if (e != hipSuccess)
+  {
+    log = std::string("hipModuleGetFunction(") + name + "): " + hipGetErrorString(e);
+    return nullptr;
+  }
+  cm->fns[name] = f;
+  return f;
+}
+
+template <class ARGS>
+hipError_t launchJit(hipFunction_t fn, const ARGS& args, size_t V, hipStream_t stream)
+{
+  ARGS copy = args;
+  size_t size = sizeof(ARGS);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  const unsigned blocks = (unsigned)((V + 255) / 256);
+  return hipModuleLaunchKernel(fn, blocks, 1, 1, 256, 1, 1, 0, stream, nullptr, config);
+}
+
+enum NodeType
+{
+  NODE_INPUT = 0,
+  NODE_PARAM = 1,
+  NODE_CONST = 2,
+  NODE_PROC = 3,
+  NODE_OP = 4
+};
+
+struct Node
+{
+  int type;
+  int kind;  // proc kind or op
+  std::vector<int> in;
+  std::string name;
+  float value{0.f};
+  int slot{0};            // input index / param index
+  int cOff{0}, sOff{0}, nc{0}, ns{0};
+};
+
+int opArity(int op) { return op >= 64 ? 3 : (op >= 32 ? 2 : 1); }
+bool opKnown(int op)
+{
+  return (op >= 0 && op <= MLGPU_OP_EXP_APPROX_OF_SIN_APPROX) || (op >= MLGPU_OP_ADD && op <= MLGPU_OP_LESS_THAN_OR_EQUAL) ||
+         (op >= MLGPU_OP_LERP && op <= MLGPU_OP_SELECT_INT);
+}
+
+std::string floatLiteral(float f)
+{
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  char buf[48];
+  snprintf(buf, sizeof(buf), "u2f(0x%08xu)", u);  // exact bits, no decimal round trip
+  return buf;
+}
+}  // namespace
+
+struct mlgpu_graph
+{
+  mlgpu_engine* e{nullptr};
+  size_t V{0};
+  std::vector<Node> nodes;
+  std::vector<int> outputs;
+  int nInputs{0}, nParams{0}, NC{0}, NS{0};
+  bool compiled{false};
+  bool hasImpulse{false};
+  std::string source, log;
+  hipFunction_t fn{nullptr};
+  float* d_coeffs{nullptr};
+  uint32_t* d_state{nullptr};
+  float* d_params{nullptr};
+};
+
+namespace
+{
+int gfail(mlgpu_graph* g, int status, const std::string& what)
+{
+  if (g && g->e) g->e->lastError = what;
+  return status;
+}
+
+std::string generateGraphSource(mlgpu_graph* g)
+{
+  std::ostringstream s;
+  s << "// generated by libmlgpu graph.hip\n#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\nusing namespace mldev;\n";
+  s << "extern \"C\" __global__ __launch_bounds__(256) void mlgpu_graph_kernel(const GraphArgs a)\n{\n";
+  if (g->hasImpulse)
+  {
+    s << "  __shared__ float ldsTable[32];\n  if (threadIdx.x < 17) ldsTable[threadIdx.x] = a.impulseTable[threadIdx.x];\n  __syncthreads();\n";
+    s << "  const KernelTables tables{ldsTable};\n";
+  }
+  else
+  {
+    s << "  const KernelTables tables{nullptr};\n";
+  }
+  s << "  size_t blk = blockIdx.x;\n  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;\n"
+       "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n"
+       "  const size_t v = blk * 256 + threadIdx.x;\n  if (v >= a.V) return;\n";
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+  {
+    const Node& n = g->nodes[i];
+    if (n.type == NODE_PROC)
+    {
+      s << "  Proc<" << n.kind << "> p" << i << ";\n  const VoiceMem m" << i << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v, a.state + (size_t)"
+        << n.sOff << " * a.V + v, a.V};\n  p" << i << ".load(m" << i << ", tables);\n";
+    }
+    else if (n.type == NODE_PARAM)
+    {
+      s << "  const float prm" << n.slot << " = a.params[(size_t)" << n.slot << " * a.V + v];\n";
+    }
+    else if (n.type == NODE_INPUT)
+    {
+      s << "  const f32x4* in" << n.slot << " = (const f32x4*)a.in[" << n.slot << "].base + v * a.in[" << n.slot << "].strideV;\n";
+    }
+  }
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    s << "  f32x4* out" << o << " = (f32x4*)a.out[" << o << "].base + v * a.out[" << o << "].strideV;\n";
+  s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n#pragma unroll 2\n    for (int q = 0; q < 16; ++q)\n    {\n";
+  for (int i = 0; i < g->nInputs; ++i)
+    s << "      const f32x4 xin" << i << " = __builtin_nontemporal_load(in" << i << " + t * a.in[" << i << "].strideT + q * a.in[" << i << "].strideQ);\n";
+  for (size_t o = 0; o < g->outputs.size(); ++o) s << "      f32x4 y" << o << ";\n";
+  s << "#pragma unroll\n      for (int k = 0; k < 4; ++k)\n      {\n";
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+  {
+    const Node& n = g->nodes[i];
+    s << "        const float n" << i << " = ";
+    auto arg = [&](int j) { return "n" + std::to_string(n.in[j]); };
+    switch (n.type)
+    {
+      case NODE_INPUT: s << "xin" << n.slot << "[k]"; break;
+      case NODE_PARAM: s << "prm" << n.slot; break;
+      case NODE_CONST: s << floatLiteral(n.value); break;
+      case NODE_PROC:
+        if (n.kind == MLGPU_PROC_PULSE_GEN && n.in.size() == 2)
+          s << "p" << i << ".next2(" << arg(0) << ", " << arg(1) << ")";
+        else
+          s << "p" << i << ".next(" << (n.in.empty() ? std::string("0.f") : arg(0)) << ")";
+        break;
+      case NODE_OP:
+        s << "apply_f<" << n.kind << ">(" << arg(0);
+        for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
+        s << ")";
+        break;
+    }
+    s << ";";
+    if (!n.name.empty()) s << "  // " << n.name;
+    s << "\n";
+  }
+  for (size_t o = 0; o < g->outputs.size(); ++o) s << "        y" << o << "[k] = n" << g->outputs[o] << ";\n";
+  s << "      }\n";
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    s << "      __builtin_nontemporal_store(y" << o << ", out" << o << " + t * a.out[" << o << "].strideT + q * a.out[" << o << "].strideQ);\n";
+  s << "    }\n";
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+    if (g->nodes[i].type == NODE_PROC) s << "    p" << i << ".end_vector();\n";
+  s << "  }\n";
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+    if (g->nodes[i].type == NODE_PROC) s << "  p" << i << ".store(m" << i << ");\n";
+  s << "}\n";
+  return s.str();
+}
+
+int addNode(mlgpu_graph* g, Node&& n)
+{
+  if (g->compiled) return -gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+  for (int id : n.in)
+    if (id < 0 || id >= (int)g->nodes.size()) return -gfail(g, MLGPU_ERR_RANGE, "graph node input refers to an unknown node");
+  g->nodes.push_back(std::move(n));
+  return (int)g->nodes.size() - 1;
+}
+
+int checkNode(mlgpu_graph* g, int node, int type)
+{
+  if (!g) return MLGPU_ERR_INVALID;
+  if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "node index out of range");
+  if (g->nodes[node].type != type) return gfail(g, MLGPU_ERR_INVALID, "node has the wrong type for this call");
+  return MLGPU_OK;
+}
+}  // namespace
+
+// ---- fused kernels for processor chains without an ahead-of-time instantiation -------------------
+// Generates `chain_kernel_body<Chain<kinds...>, HAS_SIGNAL>` wrappers; used by mlgpu_bank_create.
+static std::string chainSource(const int32_t* kinds, int n)
+{
+  std::ostringstream s;
+  s << "// generated by libmlgpu graph.hip (chain)\n#include \"mldsp_kernels.hpp\"\nusing namespace mldev;\nusing CH = Chain<";
+  for (int i = 0; i < n; ++i) s << (i ? ", " : "") << kinds[i];
+  s << ">;\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void mlgpu_chain_signal(const ChainArgs a) { chain_kernel_body<CH, true>(a); }\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void mlgpu_chain_const(const ChainArgs a) { chain_kernel_body<CH, false>(a); }\n";
+  return s.str();
+}
+
+bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log)
+{
+  const std::string src = chainSource(kinds, n);
+  CompiledModule* cm = compileAndLoad(e->device, src, log);
+  if (!cm) return false;
+  *fnSignal = (void*)getFunction(cm, "mlgpu_chain_signal", log);
+  *fnConst = (void*)getFunction(cm, "mlgpu_chain_const", log);
+  return *fnSignal && *fnConst;
+}
+
+hipError_t mlgpu_jit_chain_launch(void* fn, const ChainArgs& a, hipStream_t stream) { return launchJit((hipFunction_t)fn, a, a.V, stream); }
+
+extern "C"
+{
+  int mlgpu_jit_selftest(char* logOut, size_t logLen)
+  {
+    std::string log, all;
+    bool ok = true;
+    // (1) a chain that has no ahead-of-time instantiation, including the LDS-table ImpulseGen
+    const int32_t chain[] = {MLGPU_PROC_IMPULSE_GEN, MLGPU_PROC_LO_SHELF, MLGPU_PROC_ADSR, MLGPU_PROC_PEAK, MLGPU_PROC_GAIN};
+    ok = compileOnly(chainSource(chain, 5), log) && ok;
+    all += log;
+    // (2) a graph touching every node type
+    mlgpu_graph g;
+    g.V = 64;
+    const int gate = mlgpu_graph_add_input(&g, "gate");
+    const int pitch = mlgpu_graph_add_param(&g, "pitch");
+    const int two = mlgpu_graph_add_const(&g, 2.0f);
+    const int f = mlgpu_graph_add_op(&g, MLGPU_OP_EXP2_APPROX, &pitch, 1, "freq");
+    const int saw = mlgpu_graph_add_proc(&g, MLGPU_PROC_SAW_GEN, &f, 1, "saw");
+    const int pin[2] = {f, gate};
+    const int pulse = mlgpu_graph_add_proc(&g, MLGPU_PROC_PULSE_GEN, pin, 2, "pulse");
+    const int noise = mlgpu_graph_add_proc(&g, MLGPU_PROC_NOISE_GEN, nullptr, 0, "noise");
+    const int env = mlgpu_graph_add_proc(&g, MLGPU_PROC_ADSR, &gate, 1, "env");
+    const int mixIn[2] = {saw, pulse};
+    const int mix = mlgpu_graph_add_op(&g, MLGPU_OP_ADD, mixIn, 2, "mix");
+    const int lerpIn[3] = {mix, noise, two};
+    const int l = mlgpu_graph_add_op(&g, MLGPU_OP_LERP, lerpIn, 3, "lerp");
+    const int lp = mlgpu_graph_add_proc(&g, MLGPU_PROC_LOPASS, &l, 1, "lp");
+    const int vcaIn[2] = {lp, env};
+    const int vca = mlgpu_graph_add_op(&g, MLGPU_OP_MULTIPLY, vcaIn, 2, "vca");
+    ok = (vca > 0) && (mlgpu_graph_add_output(&g, vca) == MLGPU_OK) && ok;
+    log.clear();
+    ok = compileOnly(generateGraphSource(&g), log) && ok;
+    all += log;
+    if (logOut && logLen)
+    {
+      snprintf(logOut, logLen, "%s", all.c_str());
+    }
+    return ok ? MLGPU_OK : MLGPU_ERR_UNSUPPORTED;
+  }
+
+  int mlgpu_graph_create(mlgpu_engine* e, size_t nVoices, mlgpu_graph** out)
+  {
+    if (!e || !out) return MLGPU_ERR_INVALID;
+    *out = nullptr;
+    if (nVoices == 0)
+    {
+      e->lastError = "graph_create: zero voices";
+      return MLGPU_ERR_INVALID;
+    }
+    mlgpu_graph* g = new (std::nothrow) mlgpu_graph();
+    if (!g) return MLGPU_ERR_OOM;
+    g->e = e;
+    g->V = nVoices;
+    *out = g;
+    return MLGPU_OK;
+  }
+
+  int mlgpu_graph_destroy(mlgpu_graph* g)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    hipSetDevice(g->e->device);
+    hipStreamSynchronize(g->e->stream);
+    if (g->d_coeffs) hipFree(g->d_coeffs);
+    if (g->d_state) hipFree(g->d_state);
+    if (g->d_params) hipFree(g->d_params);
+    delete g;
+    return MLGPU_OK;
+  }
+
+  int mlgpu_graph_add_input(mlgpu_graph* g, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (g->nInputs >= MLGPU_GRAPH_MAX_INPUTS) return -gfail(g, MLGPU_ERR_UNSUPPORTED, "too many graph inputs");
+    Node n;
+    n.type = NODE_INPUT;
+    n.kind = 0;
+    n.name = name ? name : "";
+    n.slot = g->nInputs;
+    const int id = addNode(g, std::move(n));
+    if (id >= 0) g->nInputs++;
+    return id;
+  }
+  int mlgpu_graph_add_param(mlgpu_graph* g, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    Node n;
+    n.type = NODE_PARAM;
+    n.kind = 0;
+    n.name = name ? name : "";
+    n.slot = g->nParams;
+    const int id = addNode(g, std::move(n));
+    if (id >= 0) g->nParams++;
+    return id;
+  }
+  int mlgpu_graph_add_const(mlgpu_graph* g, float value)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    Node n;
+    n.type = NODE_CONST;
+    n.kind = 0;
+    n.value = value;
+    return addNode(g, std::move(n));
+  }
+  int mlgpu_graph_add_proc(mlgpu_graph* g, int kind, const int* inputs, int nIn, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    const int nc = mlgpu_proc_nc(kind), ns = mlgpu_proc_ns(kind);
+    if (nc < 0) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: unknown processor kind");
+    const int maxIn = (kind == MLGPU_PROC_PULSE_GEN) ? 2 : 1;
+    const int minIn = (kind == MLGPU_PROC_NOISE_GEN) ? 0 : 1;
+    if (nIn < minIn || nIn > maxIn || (nIn > 0 && !inputs)) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: wrong number of inputs");
+    Node n;
+    n.type = NODE_PROC;
+    n.kind = kind;
+    n.in.assign(inputs, inputs + nIn);
+    n.name = name ? name : "";
+    n.nc = nc;
+    n.ns = ns;
+    n.cOff = g->NC;
+    n.sOff = g->NS;
+    const int id = addNode(g, std::move(n));
+    if (id >= 0)
+    {
+      g->NC += nc;
+      g->NS += ns;
+      if (kind == MLGPU_PROC_IMPULSE_GEN) g->hasImpulse = true;
+    }
+    return id;
+  }
+  int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* inputs, int nIn, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (!opKnown(op)) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_op: unknown op");
+    if (nIn != opArity(op) || !inputs) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_op: wrong number of inputs");
+    Node n;
+    n.type = NODE_OP;
+    n.kind = op;
+    n.in.assign(inputs, inputs + nIn);
+    n.name = name ? name : "";
+    return addNode(g, std::move(n));
+  }
+  int mlgpu_graph_add_output(mlgpu_graph* g, int node)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_add_output: unknown node");
+    if (g->outputs.size() >= MLGPU_GRAPH_MAX_OUTPUTS) return gfail(g, MLGPU_ERR_UNSUPPORTED, "too many graph outputs");
+    g->outputs.push_back(node);
+    return MLGPU_OK;
+  }
+  int mlgpu_graph_node(mlgpu_graph* g, const char* name)
+  {
+    if (!g || !name) return -MLGPU_ERR_INVALID;
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+      if (g->nodes[i].name == name) return (int)i;
+    return -MLGPU_ERR_RANGE;
+  }
+  int mlgpu_graph_num_nodes(mlgpu_graph* g) { return g ? (int)g->nodes.size() : -1; }
+
+  int mlgpu_graph_compile(mlgpu_graph* g)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return MLGPU_OK;
+    if (g->outputs.empty()) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: no outputs");
+    mlgpu_engine* e = g->e;
+    if (hipSetDevice(e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
+    g->source = generateGraphSource(g);
+    CompiledModule* cm = compileAndLoad(e->device, g->source, g->log);
+    if (!cm) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
+    g->fn = getFunction(cm, "mlgpu_graph_kernel", g->log);
+    if (!g->fn) return gfail(g, MLGPU_ERR_HIP, g->log);
+    const size_t V = g->V;
+    hipError_t err = hipMalloc((void**)&g->d_coeffs, sizeof(float) * V * (size_t)(g->NC + 1));
+    if (err == hipSuccess) err = hipMalloc((void**)&g->d_state, sizeof(uint32_t) * V * (size_t)(g->NS + 1));
+    if (err == hipSuccess) err = hipMalloc((void**)&g->d_params, sizeof(float) * V * (size_t)(g->nParams + 1));
+    if (err == hipSuccess) err = hipMemsetAsync(g->d_coeffs, 0, sizeof(float) * V * (size_t)(g->NC + 1), e->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(g->d_params, 0, sizeof(float) * V * (size_t)(g->nParams + 1), e->stream);
+    for (const Node& n : g->nodes)
+    {
+      if (n.type != NODE_PROC) continue;
+      uint32_t words[16];
+      mlgpu_proc_clear_state(n.kind, words, false);
+      for (int i = 0; i < n.ns && err == hipSuccess; ++i)
+        err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * V, words[i], V, e->stream);
+    }
+    if (err != hipSuccess) return gfail(g, err == hipErrorOutOfMemory ? MLGPU_ERR_OOM : MLGPU_ERR_HIP, std::string("graph_compile: ") + hipGetErrorString(err));
+    g->compiled = true;
+    return MLGPU_OK;
+  }
+
+  const char* mlgpu_graph_source(mlgpu_graph* g) { return g ? g->source.c_str() : ""; }
+
+  int mlgpu_graph_clear(mlgpu_graph* g)
+  {
+    if (!g || !g->compiled) return MLGPU_ERR_INVALID;
+    for (const Node& n : g->nodes)
+    {
+      if (n.type != NODE_PROC) continue;
+      uint32_t words[16];
+      mlgpu_proc_clear_state(n.kind, words, true);
+      for (int i = 0; i < n.ns; ++i)
+      {
+        if (n.kind == MLGPU_PROC_ADSR && i != 7) continue;  // ADSR::clear() only resets the segment
+        const hipError_t err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * g->V, words[i], g->V, g->e->stream);
+        if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, hipGetErrorString(err));
+      }
+    }
+    return MLGPU_OK;
+  }
+
+  int mlgpu_graph_set_param(mlgpu_graph* g, int node, const float* h)
+  {
+    int st = checkNode(g, node, NODE_PARAM);
+    if (st) return st;
+    if (!g->compiled || !h) return gfail(g, MLGPU_ERR_INVALID, "graph_set_param: compile first / null");
+    return mlgpu_upload(g->e, g->d_params + (size_t)g->nodes[node].slot * g->V, h, sizeof(float) * g->V);
+  }
+  int mlgpu_graph_set_param_uniform(mlgpu_graph* g, int node, float value)
+  {
+    int st = checkNode(g, node, NODE_PARAM);
+    if (st) return st;
+    if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_set_param: compile first");
+    uint32_t u;
+    memcpy(&u, &value, 4);
+    return mlgpu_fill32(g->e, g->d_params + (size_t)g->nodes[node].slot * g->V, u, g->V);
+  }
+  int mlgpu_graph_num_coeffs(mlgpu_graph* g, int node) { return checkNode(g, node, NODE_PROC) ? -1 : g->nodes[node].nc; }
+  int mlgpu_graph_num_state(mlgpu_graph* g, int node) { return checkNode(g, node, NODE_PROC) ? -1 : g->nodes[node].ns; }
+  int mlgpu_graph_set_coeff(mlgpu_graph* g, int node, int idx, const float* h)
+  {
+    int st = checkNode(g, node, NODE_PROC);
+    if (st) return st;
+    if (!g->compiled || !h) return gfail(g, MLGPU_ERR_INVALID, "graph_set_coeff: compile first / null");
+    if (idx < 0 || idx >= g->nodes[node].nc) return gfail(g, MLGPU_ERR_RANGE, "coefficient index out of range");
+    return mlgpu_upload(g->e, g->d_coeffs + (size_t)(g->nodes[node].cOff + idx) * g->V, h, sizeof(float) * g->V);
+  }
+  int mlgpu_graph_set_coeff_uniform(mlgpu_graph* g, int node, int idx, float value)
+  {
+    int st = checkNode(g, node, NODE_PROC);
+    if (st) return st;
+    if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_set_coeff: compile first");
+    if (idx < 0 || idx >= g->nodes[node].nc) return gfail(g, MLGPU_ERR_RANGE, "coefficient index out of range");
+    uint32_t u;
+    memcpy(&u, &value, 4);
+    return mlgpu_fill32(g->e, g->d_coeffs + (size_t)(g->nodes[node].cOff + idx) * g->V, u, g->V);
+  }
+  int mlgpu_graph_get_state(mlgpu_graph* g, int node, int idx, uint32_t* h)
+  {
+    int st = checkNode(g, node, NODE_PROC);
+    if (st) return st;
+    if (!g->compiled || !h) return gfail(g, MLGPU_ERR_INVALID, "graph_get_state: compile first / null");
+    if (idx < 0 || idx >= g->nodes[node].ns) return gfail(g, MLGPU_ERR_RANGE, "state index out of range");
+    return mlgpu_download(g->e, h, g->d_state + (size_t)(g->nodes[node].sOff + idx) * g->V, sizeof(uint32_t) * g->V);
+  }
+  int mlgpu_graph_set_state(mlgpu_graph* g, int node, int idx, const uint32_t* h)
+  {
+    int st = checkNode(g, node, NODE_PROC);
+    if (st) return st;
+    if (!g->compiled || !h) return gfail(g, MLGPU_ERR_INVALID, "graph_set_state: compile first / null");
+    if (idx < 0 || idx >= g->nodes[node].ns) return gfail(g, MLGPU_ERR_RANGE, "state index out of range");
+    return mlgpu_upload(g->e, g->d_state + (size_t)(g->nodes[node].sOff + idx) * g->V, h, sizeof(uint32_t) * g->V);
+  }
+
+  int mlgpu_graph_process(mlgpu_graph* g, size_t T, const float* const* d_inputs, int inLayout, float* const* d_outputs, int outLayout)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_process: compile first");
+    if (T == 0) return MLGPU_OK;
+    if (inLayout < 0 || inLayout > 2 || outLayout < 0 || outLayout > 2) return gfail(g, MLGPU_ERR_INVALID, "graph_process: bad layout");
+    if ((g->nInputs && !d_inputs) || !d_outputs) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null signal list");
+    GraphArgs a;
+    memset(&a, 0, sizeof(a));
+    a.coeffs = g->d_coeffs;
+    a.state = g->d_state;
+    a.params = g->d_params;
+    a.V = g->V;
+    a.T = T;
+    a.impulseTable = g->e->d_impulseTable;
+    for (int i = 0; i < g->nInputs; ++i)
+    {
+      if (!d_inputs[i] || ((uintptr_t)d_inputs[i] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned input");
+      a.in[i] = makeView(d_inputs[i], inLayout, g->V, T);
+    }
+    for (size_t o = 0; o < g->outputs.size(); ++o)
+    {
+      if (!d_outputs[o] || ((uintptr_t)d_outputs[o] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned output");
+      a.out[o] = makeView(d_outputs[o], outLayout, g->V, T);
+    }
+    if (hipSetDevice(g->e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
+    const hipError_t err = launchJit(g->fn, a, g->V, g->e->stream);
+    if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, std::string("graph_process launch: ") + hipGetErrorString(err));
+    return MLGPU_OK;
+  }
+}

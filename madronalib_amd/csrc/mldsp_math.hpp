@@ -11,7 +11,9 @@
 // -ffp-contract=off and every fused operation is spelled __builtin_fmaf explicitly where
 // it is provably bit-identical; (b) SSE semantics for min/max/convert, restated below.
 #pragma once
+#ifndef __HIPCC_RTC__  // hiprtc pre-includes the HIP runtime header (graph.hip compiles this at run time)
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace mldev

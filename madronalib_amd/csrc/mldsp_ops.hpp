@@ -1,0 +1,81 @@
+// mldsp_ops.hpp — the stateless DSPVector ops of MLDSPOps.h as one per-lane function template.
+//
+// apply<OP>(a, b, c) evaluates one element of the reference's DEFINE_OP1/OP2/OP3/... families
+// (source/DSP/MLDSPOps.h:570-917) on 32-bit patterns (float or int32 as the op demands). Shared by
+// the streaming op kernels (ops.hip) and by run-time generated graph kernels (graph.hip).
+// Compile with -ffp-contract=off (see mldsp_math.hpp).
+#pragma once
+#include "mldsp_math.hpp"
+#ifdef __HIPCC_RTC__
+#include "mlgpu.h"  // provided as an in-memory header by graph.hip
+#else
+#include "../../include/mlgpu.h"
+#endif
+
+namespace mldev
+{
+template <int OP>
+__device__ __forceinline__ uint32_t apply(uint32_t ua, uint32_t ub, uint32_t uc)
+{
+  const float a = u2f(ua), b = u2f(ub), c = u2f(uc);
+  if constexpr (OP == MLGPU_OP_SQRT) return f2u(__builtin_sqrtf(a));  // correctly rounded (hipcc default)
+  else if constexpr (OP == MLGPU_OP_SQRT_APPROX) return f2u(sqrt_approx(a));
+  else if constexpr (OP == MLGPU_OP_ABS) return f2u(abs_ps(a));
+  else if constexpr (OP == MLGPU_OP_SIGN) return f2u(sign_ps(a));
+  else if constexpr (OP == MLGPU_OP_SIGN_BIT) return f2u(signbit_ps(a));
+  else if constexpr (OP == MLGPU_OP_SIN) return f2u(vec_sin(a));
+  else if constexpr (OP == MLGPU_OP_COS) return f2u(vec_cos(a));
+  else if constexpr (OP == MLGPU_OP_LOG) return f2u(vec_log(a));
+  else if constexpr (OP == MLGPU_OP_EXP) return f2u(vec_exp(a));
+  else if constexpr (OP == MLGPU_OP_LOG2) return f2u(vec_log(a) * kLogTwoR);
+  else if constexpr (OP == MLGPU_OP_EXP2) return f2u(vec_exp(kLogTwo * a));
+  else if constexpr (OP == MLGPU_OP_SIN_APPROX) return f2u(vec_sin_approx(a));
+  else if constexpr (OP == MLGPU_OP_COS_APPROX) return f2u(vec_cos_approx(a));
+  else if constexpr (OP == MLGPU_OP_EXP_APPROX) return f2u(vec_exp_approx(a));
+  else if constexpr (OP == MLGPU_OP_LOG_APPROX) return f2u(vec_log_approx(a));
+  else if constexpr (OP == MLGPU_OP_LOG2_APPROX) return f2u(vec_log_approx(a) * kLogTwoR);
+  else if constexpr (OP == MLGPU_OP_EXP2_APPROX) return f2u(vec_exp_approx(kLogTwo * a));
+  else if constexpr (OP == MLGPU_OP_FRACTIONAL_PART) return f2u(a - (float)sse_cvtt(a));
+  else if constexpr (OP == MLGPU_OP_ROUND_FLOAT_TO_INT) return (uint32_t)sse_cvt(a);
+  else if constexpr (OP == MLGPU_OP_TRUNCATE_FLOAT_TO_INT) return (uint32_t)sse_cvtt(a);
+  else if constexpr (OP == MLGPU_OP_INT_TO_FLOAT) return f2u((float)(int32_t)ua);
+  else if constexpr (OP == MLGPU_OP_UNSIGNED_INT_TO_FLOAT) return f2u(uint_to_float(ua));
+  else if constexpr (OP == MLGPU_OP_EXP_APPROX_OF_SIN_APPROX) return f2u(vec_exp_approx(vec_sin_approx(a)));
+  else if constexpr (OP == MLGPU_OP_ADD) return f2u(a + b);
+  else if constexpr (OP == MLGPU_OP_SUBTRACT) return f2u(a - b);
+  else if constexpr (OP == MLGPU_OP_MULTIPLY) return f2u(a * b);
+  else if constexpr (OP == MLGPU_OP_DIVIDE) return f2u(a / b);  // IEEE-correct v_div sequence
+  else if constexpr (OP == MLGPU_OP_DIVIDE_APPROX) return f2u(div_approx(a, b));
+  else if constexpr (OP == MLGPU_OP_POW) return f2u(vec_exp(vec_log(a) * b));
+  else if constexpr (OP == MLGPU_OP_POW_APPROX) return f2u(vec_exp_approx(vec_log_approx(a) * b));
+  else if constexpr (OP == MLGPU_OP_MIN) return f2u(sse_min(a, b));
+  else if constexpr (OP == MLGPU_OP_MAX) return f2u(sse_max(a, b));
+  else if constexpr (OP == MLGPU_OP_ADD_INT32) return ua + ub;
+  else if constexpr (OP == MLGPU_OP_SUBTRACT_INT32) return ua - ub;
+  else if constexpr (OP == MLGPU_OP_EQUAL) return (a == b) ? 0xFFFFFFFFu : 0u;
+  else if constexpr (OP == MLGPU_OP_NOT_EQUAL) return (a != b) ? 0xFFFFFFFFu : 0u;
+  else if constexpr (OP == MLGPU_OP_GREATER_THAN) return (a > b) ? 0xFFFFFFFFu : 0u;
+  else if constexpr (OP == MLGPU_OP_GREATER_THAN_OR_EQUAL) return (a >= b) ? 0xFFFFFFFFu : 0u;
+  else if constexpr (OP == MLGPU_OP_LESS_THAN) return (a < b) ? 0xFFFFFFFFu : 0u;
+  else if constexpr (OP == MLGPU_OP_LESS_THAN_OR_EQUAL) return (a <= b) ? 0xFFFFFFFFu : 0u;
+  else if constexpr (OP == MLGPU_OP_LERP) return f2u(a + (c * (b - a)));
+  else if constexpr (OP == MLGPU_OP_INVERSE_LERP) return f2u((c - a) / (b - a));
+  else if constexpr (OP == MLGPU_OP_CLAMP) return f2u(sse_min(sse_max(a, b), c));
+  else if constexpr (OP == MLGPU_OP_WITHIN) return ((a >= b) && (a < c)) ? 0xFFFFFFFFu : 0u;
+  else /* SELECT, SELECT_INT */ return (uc & ua) | (~uc & ub);
+}
+
+template <int OP>
+constexpr int arity()
+{
+  return OP >= 64 ? 3 : (OP >= 32 ? 2 : 1);
+}
+
+// ops evaluated on floats inside a fused graph: float in, float out (masks travel as bit patterns)
+template <int OP>
+MLD float apply_f(float a, float b = 0.f, float c = 0.f)
+{
+  return u2f(apply<OP>(f2u(a), f2u(b), f2u(c)));
+}
+
+}  // namespace mldev

@@ -12,7 +12,11 @@
 // Bit-parity notes are marked PARITY. This file must be compiled with -ffp-contract=off.
 #pragma once
 #include "mldsp_math.hpp"
+#ifdef __HIPCC_RTC__
+#include "mlgpu.h"  // provided as an in-memory header by graph.hip
+#else
 #include "../../include/mlgpu.h"
+#endif
 
 namespace mldev
 {
@@ -173,18 +177,20 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
   }
   MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
   template <bool FAST>
-  MLD float step(float cps)
+  MLD float step(float cps, float w)
   {
     const float p = phasor_next(omega32, cps);
-    float pulse = (p >= width) ? -1.f : 1.f;
+    float pulse = (p >= w) ? -1.f : 1.f;
     pulse = pulse + poly_blep<FAST>(p, cps);
-    const float d = p - width + 1.0f;
+    const float d = p - w + 1.0f;
     const float down = d - (float)sse_cvtt(d);  // fractionalPart
     pulse = pulse - poly_blep<FAST>(down, cps);
     return pulse;
   }
-  MLD float next(float cps) { return step<false>(cps); }
-  MLD float next_fast(float cps) { return step<true>(cps); }
+  MLD float next(float cps) { return step<false>(cps, width); }
+  MLD float next_fast(float cps) { return step<true>(cps, width); }
+  // graph form: pulse width as an audio-rate input, PulseGen::operator()(freq, width) MLDSPGens.h:390
+  MLD float next2(float cps, float w) { return step<false>(cps, w); }
   static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
   MLD void end_vector() {}
 };

@@ -1,0 +1,41 @@
+// mlgpu_device_args.hpp — plain-old-data kernel argument blocks shared by the ahead-of-time
+// kernels (chains.hip), the run-time generated graph kernels (graph.hip via hiprtc) and the host.
+#pragma once
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#endif
+#include <stdint.h>
+
+// signal addressing in float4 units: element (vector t, quad q, voice v) lives at
+//   base + t*strideT + q*strideQ + v*strideV        (layouts: mlgpu_layout in include/mlgpu.h)
+struct SignalView
+{
+  float4* base;
+  size_t strideT, strideQ, strideV;
+};
+
+struct ChainArgs
+{
+  const float* coeffs;   // [NC][V]
+  uint32_t* state;       // [NS][V]
+  const float* inConst;  // [V] or nullptr
+  SignalView in;         // base == nullptr when no streamed input
+  SignalView out;
+  size_t V, T;
+  const float* impulseTable;
+};
+
+// a fused graph kernel: up to 8 streamed inputs, up to 4 outputs, per-voice constants [P][V]
+#define MLGPU_GRAPH_MAX_INPUTS 8
+#define MLGPU_GRAPH_MAX_OUTPUTS 4
+struct GraphArgs
+{
+  const float* coeffs;  // [NC][V]
+  uint32_t* state;      // [NS][V]
+  const float* params;  // [NP][V] per-voice constants (broadcast as DSPVector(f))
+  SignalView in[MLGPU_GRAPH_MAX_INPUTS];
+  SignalView out[MLGPU_GRAPH_MAX_OUTPUTS];
+  size_t V, T;
+  const float* impulseTable;
+};

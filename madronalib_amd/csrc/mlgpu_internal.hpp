@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/mlgpu.h"
+#include "mlgpu_device_args.hpp"
 
 struct mlgpu_engine
 {
@@ -18,15 +19,9 @@ struct mlgpu_engine
   std::string lastError;
   float* d_impulseTable{nullptr};  // 17 floats (ImpulseGen windowed sinc), built on the host
   hipEvent_t ev0{nullptr}, ev1{nullptr};
+  bool jitEnabled{true};  // fuse unknown chains / graphs with hiprtc (mlgpu_engine_set_jit)
 };
 
-// signal addressing in float4 units: element (vector t, quad q, voice v) at
-//   base + t*strideT + q*strideQ + v*strideV        (see mlgpu_layout in mlgpu.h)
-struct SignalView
-{
-  float4* base;
-  size_t strideT, strideQ, strideV;
-};
 inline SignalView makeView(const float* p, int layout, size_t V, size_t T)
 {
   SignalView s;
@@ -39,17 +34,6 @@ inline SignalView makeView(const float* p, int layout, size_t V, size_t T)
   }
   return s;
 }
-
-struct ChainArgs
-{
-  const float* coeffs;  // [NC][V]
-  uint32_t* state;      // [NS][V]
-  const float* inConst; // [V] or nullptr
-  SignalView in;        // base == nullptr when no streamed input
-  SignalView out;
-  size_t V, T;
-  const float* impulseTable;
-};
 
 typedef hipError_t (*ChainLauncher)(const ChainArgs& a, hipStream_t stream, int cuCount);
 
@@ -79,6 +63,10 @@ hipError_t mlgpu_launch_row_reduce(int rowop, const float* rows, float* out, siz
 hipError_t mlgpu_launch_layout_convert(const float* src, int srcLayout, float* dst, int dstLayout, size_t V,
                                        size_t T, hipStream_t stream);
 hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStream_t stream);
+
+// graph.hip — run-time fused kernels (hiprtc)
+bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);
+hipError_t mlgpu_jit_chain_launch(void* fn, const ChainArgs& a, hipStream_t stream);
 
 // coeffs.cpp
 void mlgpu_build_impulse_table(float* out17);

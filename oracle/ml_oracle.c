@@ -1025,6 +1025,23 @@ int mlorc_chain_process(const int32_t* procs, int n_procs, size_t V, size_t T, c
   return MLGPU_OK;
 }
 
+/* PulseGen with an audio-rate width input, PulseGen::operator()(freq, width) MLDSPGens.h:390-393.
+ * omega32 [V] in/out, freq / width / out [V][64T]. */
+int mlorc_pulse2_process(size_t V, size_t T, uint32_t* omega32, const float* freq, const float* width, float* out)
+{
+  const size_t S = T * VEC;
+  for (size_t v = 0; v < V; ++v)
+    for (size_t t = 0; t < T; ++t)
+    {
+      float ph[VEC];
+      const float* f = freq + v * S + t * VEC;
+      const float* w = width + v * S + t * VEC;
+      phasor64(&omega32[v], f, ph);
+      for (int n = 0; n < VEC; ++n) out[v * S + t * VEC + n] = phasor_to_pulse(ph[n], f[n], w[n]);
+    }
+  return MLGPU_OK;
+}
+
 /* wall-clock seconds of one mlorc_chain_process call (CPU baseline, kind "port") */
 double mlorc_chain_time(const int32_t* procs, int n_procs, size_t V, size_t T, const float* coeffs,
                         uint32_t* state, const float* in_signal, const float* in_const, float* out,

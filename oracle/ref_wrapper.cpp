@@ -697,6 +697,26 @@ extern "C"
     return MLGPU_OK;
   }
 
+  // PulseGen with an audio-rate width input: PulseGen::operator()(freq, width)
+  int mlref_pulse2_process(size_t V, size_t T, uint32_t* omega32, const float* freq, const float* width, float* out)
+  {
+    const size_t S = T * kFloatsPerDSPVector;
+    for (size_t v = 0; v < V; ++v)
+    {
+      PulseGen g;
+      g._phasor.mOmega32 = omega32[v];
+      for (size_t t = 0; t < T; ++t)
+      {
+        DSPVector f, w;
+        load(f, freq + v * S + t * kFloatsPerDSPVector);
+        load(w, width + v * S + t * kFloatsPerDSPVector);
+        store(g(f, w), out + v * S + t * kFloatsPerDSPVector);
+      }
+      omega32[v] = g._phasor.mOmega32;
+    }
+    return MLGPU_OK;
+  }
+
   // ---- CPU baselines: the bench chains written exactly as user code would ----
   // config 3: y = bp(saw(freq)) * gain  (SURVEY §3.2). Each thread owns a contiguous
   // range of voices as an array of {SawGen, Bandpass}; loops vectors x voices.

@@ -171,11 +171,24 @@ def test_chain_vs_oracle_with_resume(eng, oracle, name):
     if procs[0] == Proc.NOISE_GEN:
         st[0] = np.arange(V, dtype=np.uint32)
     outs, gst, fused = _run_gpu(eng, procs, V, T, co, st.copy(), sig, const, Layout.QUAD, calls=2)
-    assert fused == (not name.startswith("unfused")), name
+    assert fused, name  # catalogue kernels ahead of time, everything else fused at run time (hiprtc)
+    st_j = st.copy()
     for got in outs:  # the second call resumes from the carried state
-        want = oracle.chain_process(procs, T, co, st, sig, const, n_threads=4)
+        want = oracle.chain_process(procs, T, co, st_j, sig, const, n_threads=4)
         assert_bits_equal(got, want, True, name)
-    assert_bits_equal(gst, st, False, name + " state")
+    assert_bits_equal(gst, st_j, False, name + " state")
+    if name.startswith("unfused"):
+        # the same chain with run-time fusion switched off: processor by processor through HBM scratch
+        eng.set_jit(False)
+        try:
+            outs, gst, fused = _run_gpu(eng, procs, V, T, co, st.copy(), sig, const, Layout.ROWS, calls=2)
+        finally:
+            eng.set_jit(True)
+        assert not fused
+        for got in outs:
+            want = oracle.chain_process(procs, T, co, st, sig, const, n_threads=4)
+            assert_bits_equal(got, want, True, name + " (unfused)")
+        assert_bits_equal(gst, st, False, name + " (unfused) state")
 
 
 CASCADES = {
