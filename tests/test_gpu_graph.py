@@ -111,9 +111,10 @@ def test_synth16_full_size_subset(eng, oracle):
     states["noise"][0] = seeds[sub]
     (want,) = evaluate(oracle, desc, outs, sub.size, T, {"gate": gate_sub}, p_sub, c_sub, states)
     assert_bits_equal(got, want, True, "synth16 full-size subset")
-    # split launches from a cleared graph
-    g.clear()
-    g.set_state("noise", 0, seeds)
+    # split launches from a fresh graph (ADSR::clear() only resets the segment, MLDSPFilters.h:698, so a
+    # cleared graph is NOT in its initial state; identical source => the compiled module is reused)
+    g.close()
+    g, _, _, _ = build_synth16(eng, oracle, V, params, coeffs, seeds)
     half = T // 2
     hq = V * half * 64
     d_g1, d_g2, d_o1, d_o2 = eng.alloc(4 * hq), eng.alloc(4 * hq), eng.alloc(4 * hq), eng.alloc(4 * hq)
