@@ -39,6 +39,7 @@ WORKLOADS = {
     "cfg3": (262144, 30, 25),   # 750 vectors = 1 s of audio at 48 kHz
     "cfg4": (131072, 32, 16),   # long-buffer: 512 vectors per step
     "cfg2": (65536, 1, 64),     # elementwise: 64 vector-steps per step
+    "cfg5": (262144, 16, 16),   # synth16 graph: 256 vectors per step
 }
 
 
@@ -105,6 +106,30 @@ def setup_workload(eng, name, V, T, lo, total):
             eng.op_apply(Op.EXP_APPROX_OF_SIN_APPROX, d_x, None, None, d_y, n)
         return launch, 8.0 * n, "op_kernel<EXP_APPROX_OF_SIN_APPROX>", \
             "BASELINE configs[1]: 65536 voices x 1 DSPVector elementwise expApprox(sinApprox(x)) (32 MiB: Infinity-Cache resident)", (d_x, d_y)
+    if name == "cfg5":
+        from madronalib_amd import patches
+        from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
+        desc, outs = patches.synth16()
+        g = ml.Graph(eng, V, desc, outs)
+        g.clear()
+        params, coeffs, seeds = cfg5_voice_params(lo, lo + V, total, ml)
+        for k, v in params.items():
+            g.set_param(k, v if np.ndim(v) else float(v))
+        for k, c in coeffs.items():
+            g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+        g.set_state("noise", 0, seeds)
+        d_gate = eng.to_device(cfg5_gate_quad(lo, lo + V, T))
+        outs_d = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        k = [0]
+
+        def launch():
+            g.process(T, [d_gate], [outs_d[k[0] & 1]])
+            k[0] += 1
+        # gate in + audio out per voice-sample; per launch and voice: 5 params + 14 coeffs + 19 state words
+        # read, 19 state words written (patches.synth16: NC = 3+4+2+1+4, NS = 1+1+1+1+2+2+1+2+8)
+        alg = 8.0 * n + V * 4.0 * (5 + 14 + 19 + 19)
+        return launch, alg, "mlgpu_graph_kernel", ("BASELINE configs[4]: 16-node synth patch (run-time graph fused by hiprtc), "
+                                                    "262144 voices/GPU, streamed gate in, audio out"), g
     raise SystemExit(f"unknown workload {name}")
 
 

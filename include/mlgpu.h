@@ -178,7 +178,16 @@ typedef enum mlgpu_proc
   MLGPU_PROC_RMS = 37,        /* :619-653  C{a0,b1}       S{y1}; sqrtApprox: 2^-11 rel */
   MLGPU_PROC_ADSR = 38,       /* :657-797  C{ka,kd,s,kr}  S{y,y1,x1,threshold,target,k,amp,segment:i32} */
   /* stateless per-voice scaling: `x * DSPVector(gain)`, MLDSPOps.h:157,345-348 */
-  MLGPU_PROC_GAIN = 48        /*           C{gain}        S{} */
+  MLGPU_PROC_GAIN = 48,       /*           C{gain}        S{} */
+  /* control-rate -> audio-rate ramps, MLDSPGens.h:404-590. INTERPOLATOR1 and LINEAR_GLIDE take one float per
+   * DSPVector (`operator()(float)`): graph nodes only, fed by a control input / param / const. */
+  MLGPU_PROC_INTERPOLATOR1 = 64, /* :412-423 C{}          S{currentValue} */
+  MLGPU_PROC_LINEAR_GLIDE = 65,  /* :433-515 C{vectorsPerGlide:i32, dyPerVector} S{target, step, vectorsRemaining:i32,
+                                  *          currVec[64]}; defaults 32, 1/32, remaining -1 (:437-441);
+                                  *          setGlideTimeInSamples: mlgpu_linear_glide_make_coeffs;
+                                  *          setValue(f): target = f, vectorsRemaining = 0 */
+  MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE = 66 /* :517-590 C{samplesPerGlide:i32, dyPerSample}
+                                  *          S{curr, step, target, samplesRemaining:i32}; nextSample per sample */
 } mlgpu_proc;
 
 /* ------------------------------------------------------------------------- */
@@ -313,17 +322,37 @@ const char* mlgpu_bank_kernel_name(mlgpu_bank* b);
  *   input  streamed per-voice signal (one DeviceSignal per input, in the order added)
  *   param  per-voice constant, seen by its consumers as DSPVector(f) (MLDSPOps.h:157)
  *   const  one float for all voices
- *   proc   stateful processor: 1 signal input (generators: cyclesPerSample; NoiseGen: none;
- *          PulseGen: freq or freq + width, MLDSPGens.h:390)
+ *   proc   stateful processor: 1 signal input (generators: cyclesPerSample; NoiseGen: none), or one of the
+ *          reference's other operator() forms: PulseGen(freq, width) MLDSPGens.h:390; Lopass(x, omega, k)
+ *          MLDSPFilters.h:136 (coefficients made per sample, libm sinf restated on the device);
+ *          LoShelf(x, a1,a2,a3,m1,m2) :304 and HiShelf(x, a1,a2,a3,m0,m1,m2) :385 (coefficient signals);
+ *          Interpolator1 / LinearGlide: one control / param / const input
+ *   vop    index-dependent generator (mlgpu_vop)
  *   op     stateless elementwise op with 1..3 inputs (masks travel as bit patterns)
  * add_* return the node id (>= 0) or -(mlgpu_status) on error.
  */
 typedef struct mlgpu_graph mlgpu_graph;
 
+/* index-dependent single-vector generators (MLDSPOps.h:962-990); start / end are floats in the reference, so
+ * their inputs must be control / param / const nodes (or ops on those) */
+typedef enum mlgpu_vop
+{
+  MLGPU_VOP_COLUMN_INDEX = 0,       /* columnIndex()                         :965   no inputs */
+  MLGPU_VOP_RANGE_OPEN = 1,         /* rangeOpen(start, end)                 :970-974 */
+  MLGPU_VOP_RANGE_CLOSED = 2,       /* rangeClosed(start, end)               :978-982 */
+  MLGPU_VOP_INTERPOLATE_LINEAR = 3  /* interpolateDSPVectorLinear(start, end) :986-990; one row of
+                                     * interpolateCoeffsLinear (MLDSPFilters.h:34-44) */
+} mlgpu_vop;
+
 int mlgpu_graph_create(mlgpu_engine* e, size_t n_voices, mlgpu_graph** out);
 int mlgpu_graph_destroy(mlgpu_graph* g);
 int mlgpu_graph_add_input(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_param(mlgpu_graph* g, const char* name);
+/* control: streamed, ONE float per DSPVector per voice ([T][V] floats) — what the reference passes as a `float`
+ * argument per process() call (LinearGlide::operator()(float), lerp(a, b, float m) MLDSPOps.h:753, ...).
+ * Audio-rate consumers see it as DSPVector(f). */
+int mlgpu_graph_add_control(mlgpu_graph* g, const char* name);
+int mlgpu_graph_add_vop(mlgpu_graph* g, int vop, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_const(mlgpu_graph* g, float value);
 int mlgpu_graph_add_proc(mlgpu_graph* g, int proc_kind, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* input_nodes, int n_inputs, const char* name);
@@ -347,6 +376,9 @@ int mlgpu_graph_set_state(mlgpu_graph* g, int proc_node, int state_idx, const ui
  * inputs / outputs were added, all in `in_layout` / `out_layout`. */
 int mlgpu_graph_process(mlgpu_graph* g, size_t n_vectors, const float* const* d_inputs, int in_layout,
                         float* const* d_outputs, int out_layout);
+/* Same, for graphs with control inputs: d_controls[i] is the i-th control's [n_vectors][n_voices] floats. */
+int mlgpu_graph_process_ctl(mlgpu_graph* g, size_t n_vectors, const float* const* d_inputs, int in_layout,
+                            const float* const* d_controls, float* const* d_outputs, int out_layout);
 
 /* Chains without an ahead-of-time kernel are fused with hiprtc when their bank is created
  * (default on). With jit off they run processor by processor through HBM scratch signals. */
@@ -369,6 +401,10 @@ void mlgpu_onepole_make_coeffs(float omega, float out2[2]);            /* :458-4
 float mlgpu_dcblocker_make_coeffs(float omega);                        /* :498 */
 void mlgpu_adsr_calc_coeffs(float a, float d, float s, float r, float sr, float out4[4]); /* :679-686 */
 float mlgpu_db_to_gain(float dB);                                      /* :30 */
+/* LinearGlide::setGlideTimeInSamples (MLDSPGens.h:444-449) -> C{vectorsPerGlide:i32 bits, dyPerVector} */
+void mlgpu_linear_glide_make_coeffs(float glide_time_in_samples, float out2[2]);
+/* SampleAccurateLinearGlide::setGlideTimeInSamples (:527-532) -> C{samplesPerGlide:i32 bits, dyPerSample} */
+void mlgpu_sample_accurate_linear_glide_make_coeffs(float glide_time_in_samples, float out2[2]);
 
 #ifdef __cplusplus
 }

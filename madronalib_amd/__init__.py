@@ -13,9 +13,9 @@ import weakref
 import numpy as np
 
 from . import _lib
-from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, RowOp, Status
+from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, RowOp, Status, Vop
 
-__all__ = ["Engine", "Bank", "Graph", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status",
+__all__ = ["Engine", "Bank", "Graph", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "LinearGlide", "SampleAccurateLinearGlide",
            "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
            "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
 
@@ -316,7 +316,7 @@ class Graph:
         engine._check(self.L.mlgpu_graph_create(engine.h, self.V, ctypes.byref(h)))
         self.h = h
         self.ids = {}
-        self.inputs, self.outputs = [], []
+        self.inputs, self.outputs, self.controls = [], [], []
         engine._children.add(self)
         if description is not None:
             for n in description:
@@ -353,6 +353,11 @@ class Graph:
         if type == "input":
             self.inputs.append(name)
             return self._ret(self.L.mlgpu_graph_add_input(self.h, bname), name)
+        if type == "control":
+            self.controls.append(name)
+            return self._ret(self.L.mlgpu_graph_add_control(self.h, bname), name)
+        if type == "vop":
+            return self._ret(self.L.mlgpu_graph_add_vop(self.h, int(kind), arr, len(ins), bname), name)
         if type == "param":
             return self._ret(self.L.mlgpu_graph_add_param(self.h, bname), name)
         if type == "const":
@@ -409,11 +414,13 @@ class Graph:
         v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, np.uint32), (self.V,)))
         self.engine._check(self.L.mlgpu_graph_set_state(self.h, self._id(node), idx, _np_ptr(v)))
 
-    def process(self, n_vectors, d_inputs, d_outputs, in_layout=Layout.QUAD, out_layout=Layout.QUAD):
-        """d_inputs / d_outputs: lists of DeviceBuffer in the order inputs / outputs were added."""
+    def process(self, n_vectors, d_inputs, d_outputs, in_layout=Layout.QUAD, out_layout=Layout.QUAD, d_controls=()):
+        """d_inputs / d_outputs / d_controls: lists of DeviceBuffer in the order inputs / outputs / controls were
+        added; a control buffer holds [n_vectors][V] floats."""
         pi = (ctypes.c_void_p * max(1, len(d_inputs)))(*[b.ptr for b in d_inputs])
         po = (ctypes.c_void_p * max(1, len(d_outputs)))(*[b.ptr for b in d_outputs])
-        self.engine._check(self.L.mlgpu_graph_process(self.h, int(n_vectors), pi, int(in_layout), po, int(out_layout)))
+        pc = (ctypes.c_void_p * max(1, len(d_controls)))(*[b.ptr for b in d_controls])
+        self.engine._check(self.L.mlgpu_graph_process_ctl(self.h, int(n_vectors), pi, int(in_layout), pc, po, int(out_layout)))
 
     def process_host(self, n_vectors, in_signals, layout=Layout.QUAD):
         """Test convenience: VOICE_MAJOR numpy in ({name: [V][64T]}) -> list of VOICE_MAJOR numpy outs."""
@@ -428,8 +435,11 @@ class Graph:
                 d = eng.alloc(nbytes)
                 eng.layout_convert(d_vm, Layout.VOICE_MAJOR, d, layout, V, T)
                 d_in.append(d)
+        # controls: {name: [V][T]} on the host -> [T][V] on the device
+        d_ctl = [eng.to_device(np.ascontiguousarray(np.asarray(in_signals[name], np.float32).reshape(V, T).T))
+                 for name in self.controls]
         d_out = [eng.alloc(nbytes) for _ in self.outputs]
-        self.process(T, d_in, d_out, layout, layout)
+        self.process(T, d_in, d_out, layout, layout, d_ctl)
         res = []
         for d in d_out:
             if layout != Layout.VOICE_MAJOR:
@@ -509,6 +519,19 @@ class ADSR:
     @staticmethod
     def calcCoeffs(a, d, s, r, sr):
         return _mk("mlgpu_adsr_calc_coeffs", 4, a, d, s, r, sr)
+
+
+class LinearGlide:
+    @staticmethod
+    def makeCoeffs(glide_time_in_samples):
+        """setGlideTimeInSamples -> C{vectorsPerGlide as int32 bits, dyPerVector}"""
+        return _mk("mlgpu_linear_glide_make_coeffs", 2, glide_time_in_samples)
+
+
+class SampleAccurateLinearGlide:
+    @staticmethod
+    def makeCoeffs(glide_time_in_samples):
+        return _mk("mlgpu_sample_accurate_linear_glide_make_coeffs", 2, glide_time_in_samples)
 
 
 def dBToGain(dB):

@@ -110,6 +110,11 @@ def _declare(L):
     sig("mlgpu_graph_add_input", i, [vp, c.c_char_p])
     sig("mlgpu_graph_add_param", i, [vp, c.c_char_p])
     sig("mlgpu_graph_add_const", i, [vp, f])
+    sig("mlgpu_graph_add_control", i, [vp, c.c_char_p])
+    sig("mlgpu_graph_add_vop", i, [vp, i, ip, i, c.c_char_p])
+    sig("mlgpu_graph_process_ctl", i, [vp, sz, pp, i, pp, pp, i])
+    sig("mlgpu_linear_glide_make_coeffs", None, [f, fp])
+    sig("mlgpu_sample_accurate_linear_glide_make_coeffs", None, [f, fp])
     sig("mlgpu_graph_add_proc", i, [vp, i, ip, i, c.c_char_p])
     sig("mlgpu_graph_add_op", i, [vp, i, ip, i, c.c_char_p])
     sig("mlgpu_graph_add_output", i, [vp, i])

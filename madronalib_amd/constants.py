@@ -78,6 +78,13 @@ class Op:
     INT_INPUT = (20, 21, 41, 42)
 
 
+class Vop:
+    COLUMN_INDEX = 0
+    RANGE_OPEN = 1
+    RANGE_CLOSED = 2
+    INTERPOLATE_LINEAR = 3
+
+
 class RowOp:
     SUM = 0
     MEAN = 1
@@ -108,8 +115,13 @@ class Proc:
     RMS = 37
     ADSR = 38
     GAIN = 48
+    INTERPOLATOR1 = 64
+    LINEAR_GLIDE = 65
+    SAMPLE_ACCURATE_LINEAR_GLIDE = 66
 
-    ALL = (0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 48)
+    # processors a bank (chain) can hold; INTERPOLATOR1 / LINEAR_GLIDE are vector-rate: graph nodes only
+    ALL = (0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 48, 66)
+    VECTOR_RATE = (64, 65)
     GENERATORS = (0, 1, 2, 3, 4, 5, 6, 7)
     # outputs pass through sqrtApprox (rsqrtps) in the reference: 2^-11 relative tolerance
     HW_APPROX = (36, 37)

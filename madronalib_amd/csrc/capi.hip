@@ -331,6 +331,11 @@ extern "C"
         delete b;
         return fail(e, MLGPU_ERR_INVALID, "bank_create: unknown processor kind");
       }
+      if (mlgpu_proc_is_vector_rate(procs[p]))
+      {
+        delete b;
+        return fail(e, MLGPU_ERR_UNSUPPORTED, "bank_create: Interpolator1 / LinearGlide take one float per DSPVector; use them as graph nodes");
+      }
       b->kinds.push_back(procs[p]);
       b->cOff.push_back(b->NC);
       b->sOff.push_back(b->NS);
@@ -382,10 +387,18 @@ extern "C"
       mlgpu_bank_destroy(b);
       return st;
     }
-    // default-constructed state of the reference objects
+    // default-constructed state (and non-zero default coefficients) of the reference objects
     for (int p = 0; p < nProcs; ++p)
     {
-      uint32_t words[16];
+      float dc[MLGPU_MAX_PROC_COEFFS];
+      mlgpu_proc_default_coeffs(b->kinds[p], dc);
+      for (int i = 0; i < b->nc[p]; ++i)
+      {
+        uint32_t u;
+        memcpy(&u, &dc[i], 4);
+        if (u) mlgpu_launch_fill32((uint32_t*)b->d_coeffs + (size_t)(b->cOff[p] + i) * V, u, V, e->stream);
+      }
+      uint32_t words[MLGPU_MAX_PROC_STATE];
       mlgpu_proc_clear_state(b->kinds[p], words, false);
       for (int i = 0; i < b->ns[p]; ++i)
       {
@@ -430,7 +443,7 @@ extern "C"
     HIP_TRY(e, hipSetDevice(e->device));
     for (size_t p = 0; p < b->kinds.size(); ++p)
     {
-      uint32_t words[16];
+      uint32_t words[MLGPU_MAX_PROC_STATE];
       mlgpu_proc_clear_state(b->kinds[p], words, true);
       for (int i = 0; i < b->ns[p]; ++i)
       {

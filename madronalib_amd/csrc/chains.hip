@@ -12,6 +12,8 @@
 // per workgroup); no MFMA: the path is elementwise/recurrent, not a contraction.
 //
 // Compile with -ffp-contract=off (see mldsp_math.hpp).
+#include <string.h>
+
 #include "mlgpu_internal.hpp"
 #include "mldsp_kernels.hpp"
 
@@ -106,6 +108,7 @@ const std::vector<ChainEntry>& registry()
       makeEntry<P(RMS)>("chain_kernel<RMS>"),
       makeEntry<P(ADSR)>("chain_kernel<ADSR>"),
       makeEntry<P(GAIN)>("chain_kernel<Gain>"),
+      makeEntry<P(SAMPLE_ACCURATE_LINEAR_GLIDE)>("chain_kernel<SampleAccurateLinearGlide>"),
       // fused chains of the BASELINE.json configs
       makeEntry<P(SINE_GEN), P(LOPASS)>("chain_kernel<SineGen,Lopass>"),                       // config 1
       makeEntry<P(SAW_GEN), P(BANDPASS), P(GAIN)>("chain_kernel<SawGen,Bandpass,Gain>"),       // config 3
@@ -141,17 +144,49 @@ const ChainEntry* mlgpu_find_chain(const int32_t* kinds, int n)
   return nullptr;
 }
 
+// vector-rate processors (one float per DSPVector in): graph nodes only, no chain kernel
+static bool graphOnlyInfo(int kind, int* nc, int* ns)
+{
+  switch (kind)
+  {
+    case MLGPU_PROC_INTERPOLATOR1: *nc = Proc<MLGPU_PROC_INTERPOLATOR1>::NC; *ns = Proc<MLGPU_PROC_INTERPOLATOR1>::NS; return true;
+    case MLGPU_PROC_LINEAR_GLIDE: *nc = Proc<MLGPU_PROC_LINEAR_GLIDE>::NC; *ns = Proc<MLGPU_PROC_LINEAR_GLIDE>::NS; return true;
+    default: return false;
+  }
+}
+bool mlgpu_proc_is_vector_rate(int kind)
+{
+  int nc, ns;
+  return graphOnlyInfo(kind, &nc, &ns);
+}
 int mlgpu_proc_nc(int kind)
 {
   const int32_t k = kind;
   const ChainEntry* e = mlgpu_find_chain(&k, 1);
-  return e ? e->nc : -1;
+  int nc = -1, ns = -1;
+  if (!e) graphOnlyInfo(kind, &nc, &ns);
+  return e ? e->nc : nc;
 }
 int mlgpu_proc_ns(int kind)
 {
   const int32_t k = kind;
   const ChainEntry* e = mlgpu_find_chain(&k, 1);
-  return e ? e->ns : -1;
+  int nc = -1, ns = -1;
+  if (!e) graphOnlyInfo(kind, &nc, &ns);
+  return e ? e->ns : ns;
+}
+
+// `coeffs` of a default-constructed reference object where that is not all zeros
+void mlgpu_proc_default_coeffs(int kind, float* c /*[nc]*/)
+{
+  const int nc = mlgpu_proc_nc(kind);
+  for (int i = 0; i < nc; ++i) c[i] = 0.f;
+  if (kind == MLGPU_PROC_LINEAR_GLIDE || kind == MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE)
+  {
+    const int32_t n = 32;  // mVectorsPerGlide{32} / mSamplesPerGlide{32}, MLDSPGens.h:440,522
+    memcpy(&c[0], &n, 4);
+    c[1] = 1.f / 32;       // mDyPerVector / mDyPerSample
+  }
 }
 
 // state words of a default-constructed (cleared == false) or clear()ed reference object
@@ -161,4 +196,6 @@ void mlgpu_proc_clear_state(int kind, uint32_t* words, bool cleared)
   for (int i = 0; i < ns; ++i) words[i] = 0;
   if (kind == MLGPU_PROC_SINE_GEN && cleared) words[0] = 0xC0000000u;  // kZeroPhase, MLDSPGens.h:375,379
   if (kind == MLGPU_PROC_ADSR) words[7] = 4;                            // segment{off}, MLDSPFilters.h:700-702
+  if (kind == MLGPU_PROC_LINEAR_GLIDE) words[2] = 0xFFFFFFFFu;          // mVectorsRemaining{-1}, MLDSPGens.h:441,513
+  if (kind == MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE) words[3] = 0xFFFFFFFFu;  // mSamplesRemaining{-1}, :524,588
 }

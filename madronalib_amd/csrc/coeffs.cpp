@@ -6,6 +6,7 @@
 // and device code never has to reproduce libm. Formulas and
 // operation order follow the cited lines; compiled with -ffp-contract=off like the rest.
 #include <math.h>
+#include <string.h>
 
 #include "mlgpu_internal.hpp"
 
@@ -87,6 +88,23 @@ extern "C"
     o[3] = kTwoPi * invSr / ((r > minSegmentTime) ? r : minSegmentTime);
   }
   float mlgpu_db_to_gain(float dB) { return powf(10.f, dB / 40.f); }  // :30
+
+  // LinearGlide::setGlideTimeInSamples, MLDSPGens.h:444-449: glide time quantized to whole DSPVectors
+  void mlgpu_linear_glide_make_coeffs(float t, float* o)
+  {
+    int32_t vectorsPerGlide = static_cast<int32_t>(t / 64);
+    if (vectorsPerGlide < 1) vectorsPerGlide = 1;
+    memcpy(&o[0], &vectorsPerGlide, 4);
+    o[1] = 1.0f / (vectorsPerGlide + 0.f);
+  }
+  // SampleAccurateLinearGlide::setGlideTimeInSamples, MLDSPGens.h:527-532
+  void mlgpu_sample_accurate_linear_glide_make_coeffs(float t, float* o)
+  {
+    int32_t samplesPerGlide = static_cast<int32_t>(t);
+    if (samplesPerGlide < 1) samplesPerGlide = 1;
+    memcpy(&o[0], &samplesPerGlide, 4);
+    o[1] = 1.0f / samplesPerGlide;
+  }
 }
 
 // ImpulseGen's 17-tap Blackman-windowed sinc, normalised to unit sum: MLDSPGens.h:65-78 with

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <new>
@@ -141,7 +142,18 @@ enum NodeType
   NODE_PARAM = 1,
   NODE_CONST = 2,
   NODE_PROC = 3,
-  NODE_OP = 4
+  NODE_OP = 4,
+  NODE_CONTROL = 5,  // streamed, one float per DSPVector per voice
+  NODE_VOP = 6       // index-dependent vector generator (columnIndex, rangeOpen, ...)
+};
+
+// how often a node's value changes: per voice (params, consts and ops on them), per DSPVector (controls and
+// ops on them), per sample. Decides where the generated code evaluates it.
+enum Rate
+{
+  RATE_VOICE = 0,
+  RATE_VECTOR = 1,
+  RATE_AUDIO = 2
 };
 
 struct Node
@@ -151,7 +163,8 @@ struct Node
   std::vector<int> in;
   std::string name;
   float value{0.f};
-  int slot{0};            // input index / param index
+  int slot{0};            // input index / param index / control index
+  int rate{RATE_AUDIO};
   int cOff{0}, sOff{0}, nc{0}, ns{0};
 };
 
@@ -178,7 +191,7 @@ struct mlgpu_graph
   size_t V{0};
   std::vector<Node> nodes;
   std::vector<int> outputs;
-  int nInputs{0}, nParams{0}, NC{0}, NS{0};
+  int nInputs{0}, nParams{0}, nControls{0}, NC{0}, NS{0};
   bool compiled{false};
   bool hasImpulse{false};
   std::string source, log;
@@ -194,6 +207,51 @@ int gfail(mlgpu_graph* g, int status, const std::string& what)
 {
   if (g && g->e) g->e->lastError = what;
   return status;
+}
+
+// the C++ expression of node i (its inputs are the locals n<j>)
+std::string nodeExpr(const mlgpu_graph* g, size_t i)
+{
+  const Node& n = g->nodes[i];
+  std::ostringstream s;
+  auto arg = [&](size_t j) { return "n" + std::to_string(n.in[j]); };
+  switch (n.type)
+  {
+    case NODE_INPUT: s << "xin" << n.slot << "[k]"; break;
+    case NODE_CONTROL: s << "ctl" << n.slot << "[t * a.V]"; break;
+    case NODE_PARAM: s << "a.params[(size_t)" << n.slot << " * a.V + v]"; break;
+    case NODE_CONST: s << floatLiteral(n.value); break;
+    case NODE_PROC:
+      if (mlgpu_proc_is_vector_rate(n.kind))
+        s << "p" << i << ".next_n(q * 4 + k)";
+      else if ((n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
+      {
+        // launch-constant frequency: the polyBLEP range test was done once per wavefront (odd<i>)
+        s << "p" << i << ".next_u(" << arg(0);
+        if (n.in.size() == 2) s << ", " << arg(1);
+        s << ", odd" << i << ")";
+      }
+      else if (n.kind == MLGPU_PROC_PULSE_GEN && n.in.size() == 2)
+        s << "p" << i << ".next2(" << arg(0) << ", " << arg(1) << ")";
+      else
+      {
+        s << "p" << i << ".next(" << (n.in.empty() ? std::string("0.f") : arg(0));
+        for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
+        s << ")";
+      }
+      break;
+    case NODE_OP:
+      s << "apply_f<" << n.kind << ">(" << arg(0);
+      for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
+      s << ")";
+      break;
+    case NODE_VOP:
+      s << "vop<" << n.kind << ">(q * 4 + k";
+      for (size_t j = 0; j < n.in.size(); ++j) s << ", " << arg(j);
+      s << ")";
+      break;
+  }
+  return s.str();
 }
 
 std::string generateGraphSource(mlgpu_graph* g)
@@ -213,6 +271,12 @@ std::string generateGraphSource(mlgpu_graph* g)
   s << "  size_t blk = blockIdx.x;\n  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;\n"
        "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n"
        "  const size_t v = blk * 256 + threadIdx.x;\n  if (v >= a.V) return;\n";
+  auto emit = [&](size_t i, const char* indent) {
+    s << indent << "const float n" << i << " = " << nodeExpr(g, i) << ";";
+    if (!g->nodes[i].name.empty()) s << "  // " << g->nodes[i].name;
+    s << "\n";
+  };
+  // once per voice: processor state, signal bases, voice-rate nodes
   for (size_t i = 0; i < g->nodes.size(); ++i)
   {
     const Node& n = g->nodes[i];
@@ -221,48 +285,39 @@ std::string generateGraphSource(mlgpu_graph* g)
       s << "  Proc<" << n.kind << "> p" << i << ";\n  const VoiceMem m" << i << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v, a.state + (size_t)"
         << n.sOff << " * a.V + v, a.V};\n  p" << i << ".load(m" << i << ", tables);\n";
     }
-    else if (n.type == NODE_PARAM)
-    {
-      s << "  const float prm" << n.slot << " = a.params[(size_t)" << n.slot << " * a.V + v];\n";
-    }
     else if (n.type == NODE_INPUT)
     {
       s << "  const f32x4* in" << n.slot << " = (const f32x4*)a.in[" << n.slot << "].base + v * a.in[" << n.slot << "].strideV;\n";
     }
+    else if (n.type == NODE_CONTROL)
+    {
+      s << "  const float* ctl" << n.slot << " = a.ctl[" << n.slot << "] + v;\n";
+    }
+    if (n.rate == RATE_VOICE && n.type != NODE_PROC) emit(i, "  ");
+  }
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+  {
+    const Node& n = g->nodes[i];
+    if (n.type == NODE_PROC && (n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
+      s << "  const bool odd" << i << " = __builtin_amdgcn_ballot_w64(blep_freq_is_odd(n" << n.in[0] << ")) != 0;\n";
   }
   for (size_t o = 0; o < g->outputs.size(); ++o)
     s << "  f32x4* out" << o << " = (f32x4*)a.out[" << o << "].base + v * a.out[" << o << "].strideV;\n";
-  s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n#pragma unroll 2\n    for (int q = 0; q < 16; ++q)\n    {\n";
+  s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
+  // once per DSPVector: vector-rate nodes, then the vector-rate processors' begin_vector
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+  {
+    const Node& n = g->nodes[i];
+    if (n.rate == RATE_VECTOR) emit(i, "    ");
+    if (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind)) s << "    p" << i << ".begin_vector(n" << n.in[0] << ");\n";
+  }
+  s << "#pragma unroll 2\n    for (int q = 0; q < 16; ++q)\n    {\n";
   for (int i = 0; i < g->nInputs; ++i)
     s << "      const f32x4 xin" << i << " = __builtin_nontemporal_load(in" << i << " + t * a.in[" << i << "].strideT + q * a.in[" << i << "].strideQ);\n";
   for (size_t o = 0; o < g->outputs.size(); ++o) s << "      f32x4 y" << o << ";\n";
   s << "#pragma unroll\n      for (int k = 0; k < 4; ++k)\n      {\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
-  {
-    const Node& n = g->nodes[i];
-    s << "        const float n" << i << " = ";
-    auto arg = [&](int j) { return "n" + std::to_string(n.in[j]); };
-    switch (n.type)
-    {
-      case NODE_INPUT: s << "xin" << n.slot << "[k]"; break;
-      case NODE_PARAM: s << "prm" << n.slot; break;
-      case NODE_CONST: s << floatLiteral(n.value); break;
-      case NODE_PROC:
-        if (n.kind == MLGPU_PROC_PULSE_GEN && n.in.size() == 2)
-          s << "p" << i << ".next2(" << arg(0) << ", " << arg(1) << ")";
-        else
-          s << "p" << i << ".next(" << (n.in.empty() ? std::string("0.f") : arg(0)) << ")";
-        break;
-      case NODE_OP:
-        s << "apply_f<" << n.kind << ">(" << arg(0);
-        for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
-        s << ")";
-        break;
-    }
-    s << ";";
-    if (!n.name.empty()) s << "  // " << n.name;
-    s << "\n";
-  }
+    if (g->nodes[i].rate == RATE_AUDIO) emit(i, "        ");
   for (size_t o = 0; o < g->outputs.size(); ++o) s << "        y" << o << "[k] = n" << g->outputs[o] << ";\n";
   s << "      }\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
@@ -282,6 +337,16 @@ int addNode(mlgpu_graph* g, Node&& n)
   if (g->compiled) return -gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
   for (int id : n.in)
     if (id < 0 || id >= (int)g->nodes.size()) return -gfail(g, MLGPU_ERR_RANGE, "graph node input refers to an unknown node");
+  switch (n.type)
+  {
+    case NODE_PARAM: case NODE_CONST: n.rate = RATE_VOICE; break;
+    case NODE_CONTROL: n.rate = RATE_VECTOR; break;
+    case NODE_OP:
+      n.rate = RATE_VOICE;
+      for (int id : n.in) n.rate = std::max(n.rate, g->nodes[id].rate);
+      break;
+    default: n.rate = RATE_AUDIO; break;
+  }
   g->nodes.push_back(std::move(n));
   return (int)g->nodes.size() - 1;
 }
@@ -349,7 +414,23 @@ extern "C"
     const int lp = mlgpu_graph_add_proc(&g, MLGPU_PROC_LOPASS, &l, 1, "lp");
     const int vcaIn[2] = {lp, env};
     const int vca = mlgpu_graph_add_op(&g, MLGPU_OP_MULTIPLY, vcaIn, 2, "vca");
-    ok = (vca > 0) && (mlgpu_graph_add_output(&g, vca) == MLGPU_OK) && ok;
+    // control-rate inputs, ramps, index generators, the other operator() forms
+    const int cut = mlgpu_graph_add_control(&g, "cutoff");
+    const int glide = mlgpu_graph_add_proc(&g, MLGPU_PROC_LINEAR_GLIDE, &cut, 1, "glide");
+    const int interp = mlgpu_graph_add_proc(&g, MLGPU_PROC_INTERPOLATOR1, &cut, 1, "interp");
+    const int sg = mlgpu_graph_add_proc(&g, MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE, &gate, 1, "sglide");
+    const int lp3In[3] = {vca, glide, interp};
+    const int lp3 = mlgpu_graph_add_proc(&g, MLGPU_PROC_LOPASS, lp3In, 3, "lpmod");
+    const int rampIn[2] = {pitch, cut};
+    const int ramp = mlgpu_graph_add_vop(&g, MLGPU_VOP_INTERPOLATE_LINEAR, rampIn, 2, "ramp");
+    const int ci = mlgpu_graph_add_vop(&g, MLGPU_VOP_COLUMN_INDEX, nullptr, 0, "idx");
+    const int rc = mlgpu_graph_add_vop(&g, MLGPU_VOP_RANGE_CLOSED, rampIn, 2, "rc");
+    const int ro = mlgpu_graph_add_vop(&g, MLGPU_VOP_RANGE_OPEN, rampIn, 2, "ro");
+    const int lsIn[6] = {lp3, ramp, ci, rc, ro, sg};
+    const int ls = mlgpu_graph_add_proc(&g, MLGPU_PROC_LO_SHELF, lsIn, 6, "loshelf");
+    const int hsIn[7] = {ls, ramp, ci, rc, ro, sg, two};
+    const int hs = mlgpu_graph_add_proc(&g, MLGPU_PROC_HI_SHELF, hsIn, 7, "hishelf");
+    ok = (vca > 0) && (hs > 0) && (mlgpu_graph_add_output(&g, hs) == MLGPU_OK) && ok;
     log.clear();
     ok = compileOnly(generateGraphSource(&g), log) && ok;
     all += log;
@@ -414,6 +495,35 @@ extern "C"
     if (id >= 0) g->nParams++;
     return id;
   }
+  int mlgpu_graph_add_control(mlgpu_graph* g, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (g->nControls >= MLGPU_GRAPH_MAX_CONTROLS) return -gfail(g, MLGPU_ERR_UNSUPPORTED, "too many graph control inputs");
+    Node n;
+    n.type = NODE_CONTROL;
+    n.kind = 0;
+    n.name = name ? name : "";
+    n.slot = g->nControls;
+    const int id = addNode(g, std::move(n));
+    if (id >= 0) g->nControls++;
+    return id;
+  }
+  int mlgpu_graph_add_vop(mlgpu_graph* g, int vop, const int* inputs, int nIn, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (vop < MLGPU_VOP_COLUMN_INDEX || vop > MLGPU_VOP_INTERPOLATE_LINEAR) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_vop: unknown generator");
+    const int want = (vop == MLGPU_VOP_COLUMN_INDEX) ? 0 : 2;
+    if (nIn != want || (nIn > 0 && !inputs)) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_vop: wrong number of inputs");
+    for (int j = 0; j < nIn; ++j)
+      if (inputs[j] < 0 || inputs[j] >= (int)g->nodes.size() || g->nodes[inputs[j]].rate > RATE_VECTOR)
+        return -gfail(g, MLGPU_ERR_INVALID, "graph_add_vop: start / end are floats (a control, param or const node)");
+    Node n;
+    n.type = NODE_VOP;
+    n.kind = vop;
+    if (nIn) n.in.assign(inputs, inputs + nIn);
+    n.name = name ? name : "";
+    return addNode(g, std::move(n));
+  }
   int mlgpu_graph_add_const(mlgpu_graph* g, float value)
   {
     if (!g) return -MLGPU_ERR_INVALID;
@@ -428,13 +538,21 @@ extern "C"
     if (!g) return -MLGPU_ERR_INVALID;
     const int nc = mlgpu_proc_nc(kind), ns = mlgpu_proc_ns(kind);
     if (nc < 0) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: unknown processor kind");
-    const int maxIn = (kind == MLGPU_PROC_PULSE_GEN) ? 2 : 1;
-    const int minIn = (kind == MLGPU_PROC_NOISE_GEN) ? 0 : 1;
-    if (nIn < minIn || nIn > maxIn || (nIn > 0 && !inputs)) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: wrong number of inputs");
+    // forms of operator(): 1 input, plus PulseGen(freq, width) MLDSPGens.h:390, Lopass(x, omega, k) MLDSPFilters.h:136,
+    // LoShelf(x, 5 coefficient signals) :304, HiShelf(x, 6 coefficient signals) :385; NoiseGen has none
+    bool okArity = (nIn == 1);
+    if (kind == MLGPU_PROC_NOISE_GEN) okArity = (nIn == 0 || nIn == 1);
+    if (kind == MLGPU_PROC_PULSE_GEN) okArity = (nIn == 1 || nIn == 2);
+    if (kind == MLGPU_PROC_LOPASS) okArity = (nIn == 1 || nIn == 3);
+    if (kind == MLGPU_PROC_LO_SHELF) okArity = (nIn == 1 || nIn == 6);
+    if (kind == MLGPU_PROC_HI_SHELF) okArity = (nIn == 1 || nIn == 7);
+    if (!okArity || (nIn > 0 && !inputs)) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: wrong number of inputs");
+    if (mlgpu_proc_is_vector_rate(kind) && (inputs[0] < 0 || inputs[0] >= (int)g->nodes.size() || g->nodes[inputs[0]].rate > RATE_VECTOR))
+      return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: Interpolator1 / LinearGlide take one float per DSPVector (a control, param or const node)");
     Node n;
     n.type = NODE_PROC;
     n.kind = kind;
-    n.in.assign(inputs, inputs + nIn);
+    if (nIn) n.in.assign(inputs, inputs + nIn);
     n.name = name ? name : "";
     n.nc = nc;
     n.ns = ns;
@@ -500,7 +618,15 @@ extern "C"
     for (const Node& n : g->nodes)
     {
       if (n.type != NODE_PROC) continue;
-      uint32_t words[16];
+      float dc[MLGPU_MAX_PROC_COEFFS];
+      mlgpu_proc_default_coeffs(n.kind, dc);
+      for (int i = 0; i < n.nc && err == hipSuccess; ++i)
+      {
+        uint32_t u;
+        memcpy(&u, &dc[i], 4);
+        if (u) err = mlgpu_launch_fill32((uint32_t*)g->d_coeffs + (size_t)(n.cOff + i) * V, u, V, e->stream);
+      }
+      uint32_t words[MLGPU_MAX_PROC_STATE];
       mlgpu_proc_clear_state(n.kind, words, false);
       for (int i = 0; i < n.ns && err == hipSuccess; ++i)
         err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * V, words[i], V, e->stream);
@@ -518,7 +644,7 @@ extern "C"
     for (const Node& n : g->nodes)
     {
       if (n.type != NODE_PROC) continue;
-      uint32_t words[16];
+      uint32_t words[MLGPU_MAX_PROC_STATE];
       mlgpu_proc_clear_state(n.kind, words, true);
       for (int i = 0; i < n.ns; ++i)
       {
@@ -585,11 +711,17 @@ extern "C"
 
   int mlgpu_graph_process(mlgpu_graph* g, size_t T, const float* const* d_inputs, int inLayout, float* const* d_outputs, int outLayout)
   {
+    return mlgpu_graph_process_ctl(g, T, d_inputs, inLayout, nullptr, d_outputs, outLayout);
+  }
+
+  int mlgpu_graph_process_ctl(mlgpu_graph* g, size_t T, const float* const* d_inputs, int inLayout, const float* const* d_controls,
+                              float* const* d_outputs, int outLayout)
+  {
     if (!g) return MLGPU_ERR_INVALID;
     if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_process: compile first");
     if (T == 0) return MLGPU_OK;
     if (inLayout < 0 || inLayout > 2 || outLayout < 0 || outLayout > 2) return gfail(g, MLGPU_ERR_INVALID, "graph_process: bad layout");
-    if ((g->nInputs && !d_inputs) || !d_outputs) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null signal list");
+    if ((g->nInputs && !d_inputs) || (g->nControls && !d_controls) || !d_outputs) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null signal list");
     GraphArgs a;
     memset(&a, 0, sizeof(a));
     a.coeffs = g->d_coeffs;
@@ -602,6 +734,11 @@ extern "C"
     {
       if (!d_inputs[i] || ((uintptr_t)d_inputs[i] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned input");
       a.in[i] = makeView(d_inputs[i], inLayout, g->V, T);
+    }
+    for (int i = 0; i < g->nControls; ++i)
+    {
+      if (!d_controls[i]) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null control signal");
+      a.ctl[i] = d_controls[i];
     }
     for (size_t o = 0; o < g->outputs.size(); ++o)
     {

@@ -283,4 +283,87 @@ constexpr float kLogTwoR = 1.4426950408889634f;   // MLDSPOps.h:602
 MLD float sqrt_approx(float x) { return x * __builtin_amdgcn_rsqf(x); }          // :84-85
 MLD float div_approx(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }  // :79
 
+// ---------------------------------------------------------------------------------------
+// libm_sinf — the host libm's sinf, for coefficient code the reference evaluates PER SAMPLE
+// (Lopass::makeCoeffsVec calls sinf twice per sample, MLDSPFilters.h:104-113).
+//
+// The reference's arithmetic here is a third-party dependency that is not under /root/reference:
+// glibc 2.35 libm (sysdeps/ieee754/flt-32/s_sinf.c, the ARM optimized-routines algorithm by
+// Szabolcs Nagy / Wilco Dijkstra): double-precision range reduction by pi/2 (fast path below 120,
+// 192-bit 4/pi table above) and two degree-7/8 minimax polynomials in double. Restated here with
+// the same operation order, every multiply and add separate (this file is built -ffp-contract=off).
+// Constants: __sincosf_table / __inv_pio4 of that release. Pinned by the test suite's identical CPU
+// restatement, which tests/test_oracle_golden.py checks against the host libm over ALL 2^32 inputs:
+// identical everywhere except 12 arguments with 53 < |x| < 120 where the x86-64 FMA ifunc variant of
+// glibc differs in the last bit (the SVF coefficient code only ever passes |x| <= pi).
+MLD float libm_sinf_poly(double x, double x2, bool neg, int n)
+{
+  // polynomial of quadrant table 0; table 1 (n & 2) is the same with the cosine coefficients negated
+  const double c0 = neg ? -0x1p0 : 0x1p0;
+  const double c1 = neg ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2;
+  const double c2 = neg ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5;
+  const double c3 = neg ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10;
+  const double c4 = neg ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+  const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+  if ((n & 1) == 0)
+  {
+    const double x3 = x * x2;
+    const double t1 = s2 + x2 * s3;
+    const double x7 = x3 * x2;
+    const double s = x + x3 * s1;
+    return (float)(s + x7 * t1);
+  }
+  const double x4 = x2 * x2;
+  const double t2 = c3 + x2 * c4;
+  const double t1 = c0 + x2 * c1;
+  const double x6 = x4 * x2;
+  const double c = t1 + x4 * c2;
+  return (float)(c + x6 * t2);
+}
+
+MLD float libm_sinf(float y)
+{
+  const uint32_t top = (f2u(y) >> 20) & 0x7ffu;  // abstop12
+  double x = (double)y;
+  if (top < 0x3f4u)  // |y| < pi/4
+  {
+    if (top < 0x398u) return y;  // |y| < 2^-12
+    return libm_sinf_poly(x, x * x, false, 0);
+  }
+  if (top < 0x42fu)  // |y| < 120
+  {
+    const double r = x * 0x1.45F306DC9C883p+23;  // 2/pi * 2^24
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * 0x1.921FB54442D18p0;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;  // sign[4] = {1,-1,-1,1}
+    return libm_sinf_poly(x * sgn, x * x, (n & 2) != 0, n);
+  }
+  if (top < 0x7f8u)  // finite: 4/pi as a 192-bit integer, three 32x32 partial products
+  {
+    const uint32_t kInvPio4[24] = {0xa2u,       0xa2f9u,     0xa2f983u,   0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u,
+                                   0x6e4e4415u, 0x4e441529u, 0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u,
+                                   0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u, 0x34ddc0dbu, 0xddc0db62u,
+                                   0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+    uint32_t xi = f2u(y);
+    const int sign = (int)(xi >> 31);
+    const uint32_t* arr = &kInvPio4[(xi >> 26) & 15];
+    const int shift = (int)((xi >> 23) & 7);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+    const uint64_t res1 = (uint64_t)xi * arr[4];
+    const uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t nn = (res0 + (1ULL << 61)) >> 62;
+    res0 -= nn << 62;
+    x = (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
+    const int n = (int)nn;
+    const int q = (n + sign) & 3;
+    const double sgn = (q == 1 || q == 2) ? -1.0 : 1.0;
+    return libm_sinf_poly(x * sgn, x * x, ((n + sign) & 2) != 0, n);
+  }
+  return (y - y) / (y - y);  // inf / NaN -> NaN
+}
+
 }  // namespace mldev

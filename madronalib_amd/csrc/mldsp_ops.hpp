@@ -78,4 +78,21 @@ MLD float apply_f(float a, float b = 0.f, float c = 0.f)
   return u2f(apply<OP>(f2u(a), f2u(b), f2u(c)));
 }
 
+// index-dependent single-vector generators, MLDSPOps.h:962-990: element n of columnIndex(),
+// rangeOpen / rangeClosed / interpolateDSPVectorLinear(start, end) = columnIndex() * DSPVector(interval)
+// + DSPVector(offset): multiply, then add. /64 is an exact scaling; /63 is a true IEEE division.
+template <int VOP>
+MLD float vop(int n, float a = 0.f, float b = 0.f)
+{
+  const float idx = (float)n;
+  if constexpr (VOP == MLGPU_VOP_COLUMN_INDEX) return idx;
+  else if constexpr (VOP == MLGPU_VOP_RANGE_OPEN) return idx * ((b - a) / 64.f) + a;
+  else if constexpr (VOP == MLGPU_VOP_RANGE_CLOSED) return idx * ((b - a) / 63.f) + a;
+  else
+  {
+    const float interval = (b - a) / 64.f;
+    return idx * interval + (a + interval);
+  }
+}
+
 }  // namespace mldev

@@ -160,6 +160,8 @@ struct Proc<MLGPU_PROC_SAW_GEN>  // MLDSPGens.h:395-402, phasorToSaw :362-369
   }
   MLD float next(float cps) { return step<false>(cps); }
   MLD float next_fast(float cps) { return step<true>(cps); }
+  // launch-constant cps whose range test `odd` (wave-uniform) was done once by the caller
+  MLD float next_u(float cps, bool odd) { return odd ? step<false>(cps) : step<true>(cps); }
   static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
   MLD void end_vector() {}
 };
@@ -191,6 +193,8 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
   MLD float next_fast(float cps) { return step<true>(cps, width); }
   // graph form: pulse width as an audio-rate input, PulseGen::operator()(freq, width) MLDSPGens.h:390
   MLD float next2(float cps, float w) { return step<false>(cps, w); }
+  MLD float next_u(float cps, bool odd) { return odd ? step<false>(cps, width) : step<true>(cps, width); }
+  MLD float next_u(float cps, float w, bool odd) { return odd ? step<false>(cps, w) : step<true>(cps, w); }
   static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
   MLD void end_vector() {}
 };
@@ -360,6 +364,29 @@ struct SvfCore
 template <>
 struct Proc<MLGPU_PROC_LOPASS> : SvfCore<MLGPU_PROC_LOPASS>
 {
+  // Lopass::operator()(vx, omega, k), MLDSPFilters.h:136-152: coefficients made per sample by
+  // makeCoeffsVec (:97-115) — omega clamped to <= 0.5, k to >= 0.01 (SSE min/max), two libm sinf
+  // calls and one IEEE division per sample. The stored `coeffs` are not used by this form.
+  MLD float next(float v0, float omega, float kq)
+  {
+    omega = sse_min(omega, 0.5f);
+    kq = sse_max(kq, 0.01f);
+    const float piOmega = 3.1415926535897932384626433832795f * omega;  // kPi, MLDSPScalarMath.h
+    const float s1 = libm_sinf(piOmega);
+    const float s2 = libm_sinf(2.0f * piOmega);
+    const float nrm = 1.0f / (2.f + kq * s2);
+    const float c0 = s2 * nrm;
+    const float c1 = (-2.f * s1 * s1 - kq * s2) * nrm;
+    const float c2 = (2.0f * s1 * s1) * nrm;
+    const float t0 = v0 - ic2eq;
+    const float t1 = c0 * t0 + c1 * ic1eq;
+    const float t2 = c2 * t0 + c0 * ic1eq;
+    const float y = t2 + ic2eq;
+    ic1eq = __builtin_fmaf(2.0f, t1, ic1eq);
+    ic2eq = __builtin_fmaf(2.0f, t2, ic2eq);
+    return y;
+  }
+  using SvfCore<MLGPU_PROC_LOPASS>::next;
 };
 template <>
 struct Proc<MLGPU_PROC_HIPASS> : SvfCore<MLGPU_PROC_HIPASS>
@@ -416,6 +443,26 @@ struct ShelfCore  // LoShelf :288-302, HiShelf :369-383, Bell :427-441
     if (KIND == MLGPU_PROC_LO_SHELF) return v0 + m1 * v1 + m2 * v2;
     if (KIND == MLGPU_PROC_HI_SHELF) return m0 * v0 + m1 * v1 + m2 * v2;
     return v0 + m1 * v1;
+  }
+  // operator()(vx, vcoeffs): one coefficient SIGNAL per coefficient (rows of the reference's
+  // DSPVectorArray<COEFFS_SIZE>, e.g. from interpolateCoeffsLinear), LoShelf :304-318, HiShelf :385-399
+  MLD float next(float v0, float ca1, float ca2, float ca3, float cm1, float cm2)  // LoShelf {a1,a2,a3,m1,m2}
+  {
+    const float v3 = v0 - ic2eq;
+    const float v1 = ca1 * ic1eq + ca2 * v3;
+    const float v2 = ic2eq + ca2 * ic1eq + ca3 * v3;
+    ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
+    ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
+    return v0 + cm1 * v1 + cm2 * v2;
+  }
+  MLD float next(float v0, float ca1, float ca2, float ca3, float cm0, float cm1, float cm2)  // HiShelf {a1,a2,a3,m0,m1,m2}
+  {
+    const float v3 = v0 - ic2eq;
+    const float v1 = ca1 * ic1eq + ca2 * v3;
+    const float v2 = ic2eq + ca2 * ic1eq + ca3 * v3;
+    ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
+    ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
+    return cm0 * v0 + cm1 * v1 + cm2 * v2;
   }
   MLD void end_vector() {}
 };
@@ -664,6 +711,161 @@ struct Proc<MLGPU_PROC_GAIN>  // x * DSPVector(gain), MLDSPOps.h:157,345-348
   MLD void load(const VoiceMem& m, const KernelTables&) { gain = m.c(0); }
   MLD void store(const VoiceMem&) const {}
   MLD float next(float x) { return x * gain; }
+  MLD void end_vector() {}
+};
+
+// ---- control-rate -> audio-rate ramps, MLDSPGens.h:404-590 -----------------------------------------
+//
+// Interpolator1 and LinearGlide take ONE float per DSPVector (`operator()(float f)`): they are
+// vector-rate processors. The graph kernel calls begin_vector(f) once per DSPVector and next_n(n) for
+// sample n of it. They exist in graphs only (a bank's input is audio-rate).
+// kUnityRampVec[n] = (n + 1) / 64.f (:409-410) is exact in binary floating point.
+
+template <>
+struct Proc<MLGPU_PROC_INTERPOLATOR1>  // :412-423
+{
+  static constexpr int NC = 0, NS = 1;
+  static constexpr bool kVectorRate = true;
+  float cur, base, dydt;
+  MLD void load(const VoiceMem& m, const KernelTables&) { cur = u2f(m.s(0)); base = cur; dydt = 0.f; }
+  MLD void store(const VoiceMem& m) const { m.set(0, f2u(cur)); }
+  MLD void begin_vector(float f)
+  {
+    dydt = f - cur;
+    base = cur;
+    cur = f;
+  }
+  MLD float next_n(int n) const { return base + ((float)(n + 1) * 0.015625f) * dydt; }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_LINEAR_GLIDE>  // :433-515
+{
+  // C{vectorsPerGlide:i32, dyPerVector}  S{target, step, vectorsRemaining:i32, currVec[64]}
+  // mCurrVec is a 64-float member: it stays in the SoA state array in HBM (slot 3 + n, coalesced across the
+  // wavefront) and is read / updated in place at sample n; mStepVec is always a broadcast, one float.
+  static constexpr int NC = 2, NS = 3 + MLGPU_FLOATS_PER_DSPVECTOR;
+  static constexpr bool kVectorRate = true;
+  enum { kHold = 0, kEnd = 1, kStart = 2, kContinue = 3 };
+  int32_t perGlide, remaining;
+  float dyPerVector, target, step, startValue;
+  int mode;
+  VoiceMem mem;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    mem = m;
+    perGlide = (int32_t)f2u(m.c(0));
+    dyPerVector = m.c(1);
+    target = u2f(m.s(0));
+    step = u2f(m.s(1));
+    remaining = (int32_t)m.s(2);
+    mode = kHold;
+    startValue = 0.f;
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(target));
+    m.set(1, f2u(step));
+    m.set(2, (uint32_t)remaining);
+  }
+  MLD void begin_vector(float f)
+  {
+    if (f != target)
+    {
+      target = f;
+      remaining = perGlide;
+    }
+    if (remaining < 0)
+    {
+      mode = kHold;
+    }
+    else if (remaining == 0)
+    {
+      mode = kEnd;
+      step = 0.f;
+      remaining--;
+    }
+    else if (remaining == perGlide)
+    {
+      mode = kStart;
+      startValue = u2f(mem.s(3 + MLGPU_FLOATS_PER_DSPVECTOR - 1));
+      step = (target - startValue) * dyPerVector;
+      remaining--;
+    }
+    else
+    {
+      mode = kContinue;
+      remaining--;
+    }
+  }
+  MLD float next_n(int n) const
+  {
+    float c;
+    if (mode == kHold) return u2f(mem.s(3 + n));
+    if (mode == kEnd)
+      c = target;
+    else if (mode == kStart)
+      c = startValue + ((float)(n + 1) * 0.015625f) * step;
+    else
+      c = u2f(mem.s(3 + n)) + step;
+    mem.set(3 + n, f2u(c));
+    return c;
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE>  // :517-590, nextSample(f) once per sample
+{
+  // C{samplesPerGlide:i32, dyPerSample}  S{curr, step, target, samplesRemaining:i32}
+  static constexpr int NC = 2, NS = 4;
+  int32_t perGlide, remaining;
+  float dyPerSample, curr, step, target;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    perGlide = (int32_t)f2u(m.c(0));
+    dyPerSample = m.c(1);
+    curr = u2f(m.s(0));
+    step = u2f(m.s(1));
+    target = u2f(m.s(2));
+    remaining = (int32_t)m.s(3);
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(curr));
+    m.set(1, f2u(step));
+    m.set(2, f2u(target));
+    m.set(3, (uint32_t)remaining);
+  }
+  MLD float next(float f)
+  {
+    if (f != target)
+    {
+      target = f;
+      remaining = perGlide;
+    }
+    if (remaining < 0)
+    {
+    }
+    else if (remaining == 0)
+    {
+      curr = target;
+      step = 0.f;
+      remaining--;
+    }
+    else if (remaining == perGlide)
+    {
+      step = (target - curr) * dyPerSample;
+      remaining--;
+    }
+    else
+    {
+      curr += step;
+      remaining--;
+    }
+    return curr;
+  }
   MLD void end_vector() {}
 };
 

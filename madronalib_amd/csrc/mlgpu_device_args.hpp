@@ -29,6 +29,7 @@ struct ChainArgs
 // a fused graph kernel: up to 8 streamed inputs, up to 4 outputs, per-voice constants [P][V]
 #define MLGPU_GRAPH_MAX_INPUTS 8
 #define MLGPU_GRAPH_MAX_OUTPUTS 4
+#define MLGPU_GRAPH_MAX_CONTROLS 8
 struct GraphArgs
 {
   const float* coeffs;  // [NC][V]
@@ -36,6 +37,7 @@ struct GraphArgs
   const float* params;  // [NP][V] per-voice constants (broadcast as DSPVector(f))
   SignalView in[MLGPU_GRAPH_MAX_INPUTS];
   SignalView out[MLGPU_GRAPH_MAX_OUTPUTS];
+  const float* ctl[MLGPU_GRAPH_MAX_CONTROLS];  // control-rate inputs, [T][V]: one float per DSPVector per voice
   size_t V, T;
   const float* impulseTable;
 };

@@ -51,7 +51,11 @@ struct ChainEntry
 const ChainEntry* mlgpu_find_chain(const int32_t* kinds, int n);
 int mlgpu_proc_nc(int kind);  // -1 if unknown
 int mlgpu_proc_ns(int kind);
-void mlgpu_proc_clear_state(int kind, uint32_t* words /*[ns]*/, bool cleared);
+constexpr int MLGPU_MAX_PROC_STATE = 80;  // LinearGlide: 3 + 64
+constexpr int MLGPU_MAX_PROC_COEFFS = 8;
+void mlgpu_proc_clear_state(int kind, uint32_t* words /*[ns <= MLGPU_MAX_PROC_STATE]*/, bool cleared);
+void mlgpu_proc_default_coeffs(int kind, float* c /*[nc <= MLGPU_MAX_PROC_COEFFS]*/);
+bool mlgpu_proc_is_vector_rate(int kind);  // one float per DSPVector in (Interpolator1, LinearGlide): graphs only
 
 // ops.hip
 hipError_t mlgpu_launch_op(int op, const void* a, const void* b, const void* c, void* out, size_t n,

@@ -780,7 +780,9 @@ int mlorc_proc_num_coeffs(int kind)
     case MLGPU_PROC_ONE_SHOT_GEN: case MLGPU_PROC_DIFFERENTIATOR: return 0;
     case MLGPU_PROC_PULSE_GEN: case MLGPU_PROC_DC_BLOCKER: case MLGPU_PROC_INTEGRATOR:
     case MLGPU_PROC_GAIN: return 1;
-    case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_RMS: return 2;
+    case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_RMS: case MLGPU_PROC_LINEAR_GLIDE:
+    case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return 2;
+    case MLGPU_PROC_INTERPOLATOR1: return 0;
     case MLGPU_PROC_LOPASS: case MLGPU_PROC_BANDPASS: case MLGPU_PROC_PEAK: return 3;
     case MLGPU_PROC_HIPASS: case MLGPU_PROC_BELL: case MLGPU_PROC_ADSR: return 4;
     case MLGPU_PROC_LO_SHELF: return 5;
@@ -796,7 +798,9 @@ int mlorc_proc_num_state(int kind)
     case MLGPU_PROC_PHASOR_GEN: case MLGPU_PROC_SINE_GEN: case MLGPU_PROC_SAW_GEN:
     case MLGPU_PROC_PULSE_GEN: case MLGPU_PROC_NOISE_GEN: case MLGPU_PROC_TICK_GEN:
     case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_DIFFERENTIATOR: case MLGPU_PROC_INTEGRATOR:
-    case MLGPU_PROC_RMS: return 1;
+    case MLGPU_PROC_RMS: case MLGPU_PROC_INTERPOLATOR1: return 1;
+    case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return 4;
+    case MLGPU_PROC_LINEAR_GLIDE: return 3 + VEC;
     case MLGPU_PROC_IMPULSE_GEN: case MLGPU_PROC_LOPASS: case MLGPU_PROC_HIPASS:
     case MLGPU_PROC_BANDPASS: case MLGPU_PROC_LO_SHELF: case MLGPU_PROC_HI_SHELF:
     case MLGPU_PROC_BELL: case MLGPU_PROC_DC_BLOCKER: case MLGPU_PROC_PEAK: return 2;
@@ -813,12 +817,14 @@ static void proc_state_init(int kind, uint32_t* S, int cleared)
   for (int i = 0; i < ns; ++i) S[i] = 0;
   if (kind == MLGPU_PROC_SINE_GEN && cleared) S[0] = 0xC0000000u; /* kZeroPhase, MLDSPGens.h:375 */
   if (kind == MLGPU_PROC_ADSR) S[7] = ADSR_OFF;                   /* MLDSPFilters.h:700,702 */
+  if (kind == MLGPU_PROC_LINEAR_GLIDE) S[2] = 0xFFFFFFFFu;        /* mVectorsRemaining{-1}, MLDSPGens.h:441,513 */
+  if (kind == MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE) S[3] = 0xFFFFFFFFu; /* mSamplesRemaining{-1}, :524,588 */
 }
 
 int mlorc_chain_clear(const int32_t* procs, int n_procs, size_t V, uint32_t* state)
 {
   int s = 0;
-  uint32_t sbuf[16];
+  uint32_t sbuf[80];
   for (int p = 0; p < n_procs; ++p)
   {
     int ns = mlorc_proc_num_state(procs[p]);
@@ -833,7 +839,7 @@ int mlorc_chain_clear(const int32_t* procs, int n_procs, size_t V, uint32_t* sta
 int mlorc_chain_default_state(const int32_t* procs, int n_procs, size_t V, uint32_t* state)
 {
   int s = 0;
-  uint32_t sbuf[16];
+  uint32_t sbuf[80];
   for (int p = 0; p < n_procs; ++p)
   {
     int ns = mlorc_proc_num_state(procs[p]);
@@ -845,6 +851,8 @@ int mlorc_chain_default_state(const int32_t* procs, int n_procs, size_t V, uint3
   }
   return MLGPU_OK;
 }
+
+static float sample_glide_next(const float* C, uint32_t* S, float f);
 
 static void proc_process64(int kind, const float* C, uint32_t* S, const float* in, float* out)
 {
@@ -928,8 +936,47 @@ static void proc_process64(int kind, const float* C, uint32_t* S, const float* i
     case MLGPU_PROC_GAIN: /* x * DSPVector(gain), MLDSPOps.h:157,345-348 */
       for (int n = 0; n < VEC; ++n) out[n] = in[n] * C[0];
       break;
+    case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE:
+      for (int n = 0; n < VEC; ++n) out[n] = sample_glide_next(C, S, in[n]);
+      break;
     default: break;
   }
+}
+
+/* SampleAccurateLinearGlide::nextSample, MLDSPGens.h:541-580.
+ * C{samplesPerGlide:i32, dyPerSample}  S{curr, step, target, samplesRemaining:i32} */
+static float sample_glide_next(const float* C, uint32_t* S, float f)
+{
+  const int32_t perGlide = (int32_t)f2u(C[0]);
+  const float dyPerSample = C[1];
+  float curr = u2f(S[0]), step = u2f(S[1]), target = u2f(S[2]);
+  int32_t remaining = (int32_t)S[3];
+  if (f != target)
+  {
+    target = f;
+    remaining = perGlide;
+  }
+  if (remaining < 0)
+  {
+  }
+  else if (remaining == 0)
+  {
+    curr = target;
+    step = 0.f;
+    remaining--;
+  }
+  else if (remaining == perGlide)
+  {
+    step = (target - curr) * dyPerSample;
+    remaining--;
+  }
+  else
+  {
+    curr += step;
+    remaining--;
+  }
+  S[0] = f2u(curr); S[1] = f2u(step); S[2] = f2u(target); S[3] = (uint32_t)remaining;
+  return curr;
 }
 
 typedef struct
@@ -1134,4 +1181,313 @@ void mlorc_range_open(float start, float end, float* out64)
 {
   float interval = (end - start) / (VEC);
   for (int i = 0; i < VEC; ++i) out64[i] = (float)i * interval + start;
+}
+
+/* ------------------------------------------------------------------------- */
+/* host libm sinf, restated                                                   */
+/*
+ * Lopass::makeCoeffsVec (MLDSPFilters.h:97-115) calls sinf PER SAMPLE, so for that form the reference's
+ * arithmetic includes a third-party dependency that is not under /root/reference: glibc 2.35 libm
+ * (Ubuntu GLIBC 2.35-0ubuntu3.11 in this image), sysdeps/ieee754/flt-32/s_sinf.c — the ARM
+ * optimized-routines sinf (Szabolcs Nagy, Wilco Dijkstra): range reduction by pi/2 in double
+ * (fast path |x| < 120; 192 bits of 4/pi above), then a degree-7 sine or degree-8 cosine minimax polynomial
+ * in double, rounded once to float. Constants: __sincosf_table and __inv_pio4 of that release.
+ * Pinned: mlorc_sinf_check compares it with the host libm's sinf over any range of bit patterns;
+ * tests/test_oracle_golden.py runs it over ALL 2^32 inputs (identical except 12 arguments with
+ * 53 < |x| < 120 where glibc's x86-64 FMA ifunc variant rounds differently; none for |x| <= pi,
+ * the only range the SVF coefficient code uses).
+ */
+static float sinf_poly_restated(double x, double x2, int neg, int n)
+{
+  const double c0 = neg ? -0x1p0 : 0x1p0;
+  const double c1 = neg ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2;
+  const double c2 = neg ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5;
+  const double c3 = neg ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10;
+  const double c4 = neg ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+  const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+  if ((n & 1) == 0)
+  {
+    const double x3 = x * x2;
+    const double t1 = s2 + x2 * s3;
+    const double x7 = x3 * x2;
+    const double s = x + x3 * s1;
+    return (float)(s + x7 * t1);
+  }
+  const double x4 = x2 * x2;
+  const double t2 = c3 + x2 * c4;
+  const double t1 = c0 + x2 * c1;
+  const double x6 = x4 * x2;
+  const double c = t1 + x4 * c2;
+  return (float)(c + x6 * t2);
+}
+
+float mlorc_libm_sinf(float y)
+{
+  static const uint32_t inv_pio4[24] = {0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+                                        0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+                                        0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+  const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
+  double x = (double)y;
+  if (top < 0x3f4u) /* |y| < pi/4 */
+  {
+    if (top < 0x398u) return y; /* |y| < 2^-12 */
+    return sinf_poly_restated(x, x * x, 0, 0);
+  }
+  if (top < 0x42fu) /* |y| < 120 */
+  {
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * 0x1.921FB54442D18p0;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    return sinf_poly_restated(x * sgn, x * x, (n & 2) != 0, n);
+  }
+  if (top < 0x7f8u)
+  {
+    uint32_t xi = f2u(y);
+    const int sign = (int)(xi >> 31);
+    const uint32_t* arr = &inv_pio4[(xi >> 26) & 15];
+    const int shift = (int)((xi >> 23) & 7);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+    const uint64_t res1 = (uint64_t)xi * arr[4];
+    const uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t nn = (res0 + (1ULL << 61)) >> 62;
+    res0 -= nn << 62;
+    x = (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
+    const int n = (int)nn;
+    const int q = (n + sign) & 3;
+    const double sgn = (q == 1 || q == 2) ? -1.0 : 1.0;
+    return sinf_poly_restated(x * sgn, x * x, ((n + sign) & 2) != 0, n);
+  }
+  return (y - y) / (y - y);
+}
+
+/* count bit patterns u in [lo, hi] (both signs are covered by the caller's range) where the restatement and the
+ * host libm disagree (any NaN == any NaN); up to `max_list` offending patterns are written to `list`. */
+typedef struct { uint32_t lo, hi; uint64_t bad; uint32_t* list; int max_list, n_list; } sinf_job;
+static void* sinf_worker(void* arg)
+{
+  sinf_job* j = (sinf_job*)arg;
+  for (uint64_t u = j->lo; u <= j->hi; ++u)
+  {
+    const float x = u2f((uint32_t)u);
+    const float a = sinf(x), b = mlorc_libm_sinf(x);
+    if (f2u(a) != f2u(b) && !(a != a && b != b))
+    {
+      if (j->n_list < j->max_list) j->list[j->n_list++] = (uint32_t)u;
+      j->bad++;
+    }
+  }
+  return NULL;
+}
+uint64_t mlorc_sinf_check(uint32_t lo, uint32_t hi, int n_threads, uint32_t* list, int max_list)
+{
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 64) n_threads = 64;
+  sinf_job jobs[64];
+  pthread_t th[64];
+  uint32_t lists[64][32];
+  const uint64_t span = (uint64_t)hi - lo + 1, per = (span + n_threads - 1) / n_threads;
+  int used = 0;
+  for (int i = 0; i < n_threads; ++i)
+  {
+    const uint64_t a = lo + per * i, b = a + per - 1;
+    if (a > hi) break;
+    sinf_job j = {(uint32_t)a, (uint32_t)(b > hi ? hi : b), 0, lists[i], 32, 0};
+    jobs[used] = j;
+    pthread_create(&th[used], NULL, sinf_worker, &jobs[used]);
+    used++;
+  }
+  uint64_t bad = 0;
+  int nl = 0;
+  for (int i = 0; i < used; ++i)
+  {
+    pthread_join(th[i], NULL);
+    bad += jobs[i].bad;
+    for (int k = 0; k < jobs[i].n_list && nl < max_list; ++k) list[nl++] = jobs[i].list[k];
+  }
+  return bad;
+}
+
+/* ------------------------------------------------------------------------- */
+/* the other operator() forms and the control-rate processors (graph nodes)   */
+/*
+ * One processor, V voices, T vectors, n_inputs audio-rate input signals each [V][64T] (a control-rate value is
+ * passed repeated 64 times; vector-rate processors read sample 0 of each vector). coeffs [NC][V], state [NS][V]
+ * in/out. Forms:
+ *   PULSE_GEN 2: (freq, width)                    MLDSPGens.h:390-393
+ *   LOPASS 3: (x, omega, k)                       MLDSPFilters.h:136-152 with makeCoeffsVec :97-115
+ *   LO_SHELF 6: (x, a1,a2,a3,m1,m2)               :304-318
+ *   HI_SHELF 7: (x, a1,a2,a3,m0,m1,m2)            :385-399
+ *   INTERPOLATOR1 1, LINEAR_GLIDE 1 (one float per vector)   MLDSPGens.h:412-423, 433-515
+ *   anything with 1 input: same as mlorc_chain_process of that one processor
+ */
+int mlorc_proc_process_multi(int kind, size_t V, size_t T, const float* coeffs, uint32_t* state,
+                             const float* const* inputs, int n_inputs, float* out)
+{
+  const int nc = mlorc_proc_num_coeffs(kind), ns = mlorc_proc_num_state(kind);
+  if (nc < 0 || n_inputs < 0 || n_inputs > 8) return MLGPU_ERR_INVALID;
+  if (!g_impulse_table_ready) build_impulse_table();
+  const size_t S = T * VEC;
+  float C[8];
+  uint32_t St[80];
+  for (size_t v = 0; v < V; ++v)
+  {
+    for (int i = 0; i < nc; ++i) C[i] = coeffs[(size_t)i * V + v];
+    for (int i = 0; i < ns; ++i) St[i] = state[(size_t)i * V + v];
+    for (size_t t = 0; t < T; ++t)
+    {
+      const float* in[8];
+      for (int i = 0; i < n_inputs; ++i) in[i] = inputs[i] + v * S + t * VEC;
+      float* y = out + v * S + t * VEC;
+      if (kind == MLGPU_PROC_PULSE_GEN && n_inputs == 2)
+      {
+        float ph[VEC];
+        phasor64(&St[0], in[0], ph);
+        for (int n = 0; n < VEC; ++n) y[n] = phasor_to_pulse(ph[n], in[0][n], in[1][n]);
+      }
+      else if (kind == MLGPU_PROC_LOPASS && n_inputs == 3)
+      {
+        float ic1 = u2f(St[0]), ic2 = u2f(St[1]);
+        for (int n = 0; n < VEC; ++n)
+        {
+          const float omega = sse_min(in[1][n], 0.5f);
+          const float k = sse_max(in[2][n], 0.01f);
+          const float piOmega = 3.1415926535897932384626433832795f * omega;
+          const float s1 = sinf(piOmega); /* the HOST libm, exactly what the reference calls */
+          const float s2 = sinf(2.0f * piOmega);
+          const float nrm = 1.0f / (2.f + k * s2);
+          const float g0 = s2 * nrm;
+          const float g1 = (-2.f * s1 * s1 - k * s2) * nrm;
+          const float g2 = (2.0f * s1 * s1) * nrm;
+          const float v0 = in[0][n];
+          const float t0 = v0 - ic2;
+          const float t1 = g0 * t0 + g1 * ic1;
+          const float t2 = g2 * t0 + g0 * ic1;
+          const float v2 = t2 + ic2;
+          ic1 += 2.0f * t1;
+          ic2 += 2.0f * t2;
+          y[n] = v2;
+        }
+        St[0] = f2u(ic1); St[1] = f2u(ic2);
+      }
+      else if ((kind == MLGPU_PROC_LO_SHELF && n_inputs == 6) || (kind == MLGPU_PROC_HI_SHELF && n_inputs == 7))
+      {
+        float ic1 = u2f(St[0]), ic2 = u2f(St[1]);
+        for (int n = 0; n < VEC; ++n)
+        {
+          const float v0 = in[0][n];
+          const float a1 = in[1][n], a2 = in[2][n], a3 = in[3][n];
+          const float v3 = v0 - ic2;
+          const float v1 = a1 * ic1 + a2 * v3;
+          const float v2 = ic2 + a2 * ic1 + a3 * v3;
+          ic1 = 2 * v1 - ic1;
+          ic2 = 2 * v2 - ic2;
+          if (kind == MLGPU_PROC_LO_SHELF)
+            y[n] = v0 + in[4][n] * v1 + in[5][n] * v2;
+          else
+            y[n] = in[4][n] * v0 + in[5][n] * v1 + in[6][n] * v2;
+        }
+        St[0] = f2u(ic1); St[1] = f2u(ic2);
+      }
+      else if (kind == MLGPU_PROC_INTERPOLATOR1 && n_inputs == 1)
+      {
+        const float f = in[0][0], cur = u2f(St[0]);
+        const float dydt = f - cur;
+        for (int n = 0; n < VEC; ++n) y[n] = cur + ((float)(n + 1) / (float)VEC) * dydt; /* kUnityRampVec :409-410 */
+        St[0] = f2u(f);
+      }
+      else if (kind == MLGPU_PROC_LINEAR_GLIDE && n_inputs == 1)
+      {
+        /* C{vectorsPerGlide:i32, dyPerVector}  S{target, step, vectorsRemaining:i32, currVec[64]} */
+        const float f = in[0][0];
+        const int32_t perGlide = (int32_t)f2u(C[0]);
+        float target = u2f(St[0]), step = u2f(St[1]);
+        int32_t remaining = (int32_t)St[2];
+        uint32_t* cur = &St[3];
+        if (f != target)
+        {
+          target = f;
+          remaining = perGlide;
+        }
+        if (remaining < 0)
+        {
+        }
+        else if (remaining == 0)
+        {
+          for (int n = 0; n < VEC; ++n) cur[n] = f2u(target);
+          step = 0.f;
+          remaining--;
+        }
+        else if (remaining == perGlide)
+        {
+          const float currentValue = u2f(cur[VEC - 1]);
+          const float dydv = (target - currentValue) * C[1];
+          step = dydv;
+          for (int n = 0; n < VEC; ++n) cur[n] = f2u(currentValue + ((float)(n + 1) / (float)VEC) * step);
+          remaining--;
+        }
+        else
+        {
+          for (int n = 0; n < VEC; ++n) cur[n] = f2u(u2f(cur[n]) + step);
+          remaining--;
+        }
+        for (int n = 0; n < VEC; ++n) y[n] = u2f(cur[n]);
+        St[0] = f2u(target); St[1] = f2u(step); St[2] = (uint32_t)remaining;
+      }
+      else if (n_inputs <= 1 && kind != MLGPU_PROC_INTERPOLATOR1 && kind != MLGPU_PROC_LINEAR_GLIDE)
+      {
+        float zero[VEC] = {0};
+        proc_process64(kind, C, St, n_inputs ? in[0] : zero, y);
+      }
+      else
+        return MLGPU_ERR_UNSUPPORTED;
+    }
+    for (int i = 0; i < ns; ++i) state[(size_t)i * V + v] = St[i];
+  }
+  return MLGPU_OK;
+}
+
+/* index-dependent generators over a whole signal: a, b are [V][64T] (sample 0 of each vector is the float
+ * argument) or NULL; MLDSPOps.h:962-990 */
+int mlorc_vop(int vop, size_t V, size_t T, const float* a, const float* b, float* out)
+{
+  for (size_t r = 0; r < V * T; ++r)
+  {
+    const float start = a ? a[r * VEC] : 0.f, end = b ? b[r * VEC] : 0.f;
+    float* y = out + r * VEC;
+    float interval;
+    switch (vop)
+    {
+      case MLGPU_VOP_COLUMN_INDEX:
+        for (int i = 0; i < VEC; ++i) y[i] = (float)i;
+        break;
+      case MLGPU_VOP_RANGE_OPEN: mlorc_range_open(start, end, y); break;
+      case MLGPU_VOP_RANGE_CLOSED: mlorc_range_closed(start, end, y); break;
+      case MLGPU_VOP_INTERPOLATE_LINEAR: /* :986-990 */
+        interval = (end - start) / (VEC);
+        for (int i = 0; i < VEC; ++i) y[i] = (float)i * interval + (start + interval);
+        break;
+      default: return MLGPU_ERR_INVALID;
+    }
+  }
+  return MLGPU_OK;
+}
+
+void mlorc_linear_glide_make_coeffs(float t, float* o) /* MLDSPGens.h:444-449 */
+{
+  int32_t n = (int32_t)(t / VEC);
+  if (n < 1) n = 1;
+  memcpy(&o[0], &n, 4);
+  o[1] = 1.0f / (n + 0.f);
+}
+void mlorc_sample_accurate_linear_glide_make_coeffs(float t, float* o) /* :527-532 */
+{
+  int32_t n = (int32_t)t;
+  if (n < 1) n = 1;
+  memcpy(&o[0], &n, 4);
+  o[1] = 1.0f / n;
 }

@@ -368,10 +368,85 @@ struct RGain : RefProc
   DSPVector process(const DSPVector& in) override { return in * gain; }  // x * DSPVector(gain)
 };
 
+struct RSampleGlide : RefProc  // SampleAccurateLinearGlide, nextSample() once per sample
+{
+  SampleAccurateLinearGlide g;
+  int nc() const override { return 2; }
+  int ns() const override { return 4; }
+  void setCoeffs(const float* c) override
+  {
+    g.mSamplesPerGlide = (int32_t)f2u(c[0]);
+    g.mDyPerSample = c[1];
+  }
+  void setState(const uint32_t* s) override
+  {
+    g.mCurrValue = u2f(s[0]);
+    g.mStepValue = u2f(s[1]);
+    g.mTargetValue = u2f(s[2]);
+    g.mSamplesRemaining = (int32_t)s[3];
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(g.mCurrValue);
+    s[1] = f2u(g.mStepValue);
+    s[2] = f2u(g.mTargetValue);
+    s[3] = (uint32_t)g.mSamplesRemaining;
+  }
+  void clear() override { g.clear(); }
+  DSPVector process(const DSPVector& in) override
+  {
+    DSPVector y;
+    for (int n = 0; n < kFloatsPerDSPVector; ++n) y[n] = g.nextSample(in[n]);
+    return y;
+  }
+};
+// the two vector-rate ramps: process() takes the float argument from sample 0 of the input vector
+struct RInterp1 : RefProc
+{
+  Interpolator1 g;
+  int nc() const override { return 0; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override { g.currentValue = u2f(s[0]); }
+  void getState(uint32_t* s) const override { s[0] = f2u(g.currentValue); }
+  void clear() override { g.currentValue = 0; }
+  DSPVector process(const DSPVector& in) override { return g(in[0]); }
+};
+struct RLinearGlide : RefProc
+{
+  LinearGlide g;
+  int nc() const override { return 2; }
+  int ns() const override { return 3 + kFloatsPerDSPVector; }
+  void setCoeffs(const float* c) override
+  {
+    g.mVectorsPerGlide = (int32_t)f2u(c[0]);
+    g.mDyPerVector = c[1];
+  }
+  void setState(const uint32_t* s) override
+  {
+    g.mTargetValue = u2f(s[0]);
+    g.mStepVec = DSPVector(u2f(s[1]));
+    g.mVectorsRemaining = (int32_t)s[2];
+    for (int n = 0; n < kFloatsPerDSPVector; ++n) g.mCurrVec[n] = u2f(s[3 + n]);
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(g.mTargetValue);
+    s[1] = f2u(g.mStepVec[0]);
+    s[2] = (uint32_t)g.mVectorsRemaining;
+    for (int n = 0; n < kFloatsPerDSPVector; ++n) s[3 + n] = f2u(g.mCurrVec[n]);
+  }
+  void clear() override { g.clear(); }
+  DSPVector process(const DSPVector& in) override { return g(in[0]); }
+};
+
 RefProc* makeProc(int kind)
 {
   switch (kind)
   {
+    case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return new RSampleGlide;
+    case MLGPU_PROC_INTERPOLATOR1: return new RInterp1;
+    case MLGPU_PROC_LINEAR_GLIDE: return new RLinearGlide;
     case MLGPU_PROC_PHASOR_GEN: return new RPhasor;
     case MLGPU_PROC_SINE_GEN: return new RSine;
     case MLGPU_PROC_SAW_GEN: return new RSaw;
@@ -416,7 +491,7 @@ void runVoices(const int32_t* procs, int nProcs, size_t V, size_t T, size_t v0, 
   }
   const size_t S = T * kFloatsPerDSPVector;
   float cbuf[16];
-  uint32_t sbuf[16];
+  uint32_t sbuf[80];
   for (size_t v = v0; v < v1; ++v)
   {
     for (int p = 0; p < nProcs; ++p)
@@ -648,7 +723,7 @@ extern "C"
   int mlref_chain_clear(const int32_t* procs, int nProcs, size_t V, uint32_t* state)
   {
     int s = 0;
-    uint32_t sbuf[16];
+    uint32_t sbuf[80];
     for (int p = 0; p < nProcs; ++p)
     {
       std::unique_ptr<RefProc> rp(makeProc(procs[p]));
@@ -668,7 +743,7 @@ extern "C"
   int mlref_chain_default_state(const int32_t* procs, int nProcs, size_t V, uint32_t* state)
   {
     int s = 0;
-    uint32_t sbuf[16];
+    uint32_t sbuf[80];
     for (int p = 0; p < nProcs; ++p)
     {
       std::unique_ptr<RefProc> rp(makeProc(procs[p]));
@@ -883,6 +958,89 @@ extern "C"
   {
     ImpulseGen g;
     for (int i = 0; i < 17; ++i) out17[i] = g._table[i];
+  }
+
+  // ---- the other operator() forms + vector-rate ramps: same contract as mlorc_proc_process_multi ----
+  int mlref_proc_process_multi(int kind, size_t V, size_t T, const float* coeffs, uint32_t* state,
+                               const float* const* inputs, int nInputs, float* out)
+  {
+    const size_t S = T * kFloatsPerDSPVector;
+    float cbuf[16];
+    uint32_t sbuf[80];
+    for (size_t v = 0; v < V; ++v)
+    {
+      std::unique_ptr<RefProc> rp(makeProc(kind));
+      if (!rp) return MLGPU_ERR_INVALID;
+      for (int i = 0; i < rp->nc(); ++i) cbuf[i] = coeffs[(size_t)i * V + v];
+      for (int i = 0; i < rp->ns(); ++i) sbuf[i] = state[(size_t)i * V + v];
+      rp->setCoeffs(cbuf);
+      rp->setState(sbuf);
+      for (size_t t = 0; t < T; ++t)
+      {
+        DSPVector in[8], y;
+        for (int i = 0; i < nInputs; ++i) load(in[i], inputs[i] + v * S + t * kFloatsPerDSPVector);
+        if (kind == MLGPU_PROC_PULSE_GEN && nInputs == 2)
+          y = static_cast<RPulse*>(rp.get())->g(in[0], in[1]);
+        else if (kind == MLGPU_PROC_LOPASS && nInputs == 3)
+          y = static_cast<RLopass*>(rp.get())->f(in[0], in[1], in[2]);
+        else if (kind == MLGPU_PROC_LO_SHELF && nInputs == 6)
+        {
+          DSPVectorArray<5> vc;
+          for (int r = 0; r < 5; ++r) vc.row(r) = in[1 + r];
+          y = static_cast<RLoShelf*>(rp.get())->f(in[0], vc);
+        }
+        else if (kind == MLGPU_PROC_HI_SHELF && nInputs == 7)
+        {
+          DSPVectorArray<6> vc;
+          for (int r = 0; r < 6; ++r) vc.row(r) = in[1 + r];
+          y = static_cast<RHiShelf*>(rp.get())->f(in[0], vc);
+        }
+        else if (nInputs <= 1)
+          y = rp->process(nInputs ? in[0] : DSPVector(0.f));
+        else
+          return MLGPU_ERR_UNSUPPORTED;
+        store(y, out + v * S + t * kFloatsPerDSPVector);
+      }
+      rp->getState(sbuf);
+      for (int i = 0; i < rp->ns(); ++i) state[(size_t)i * V + v] = sbuf[i];
+    }
+    return MLGPU_OK;
+  }
+
+  int mlref_vop(int vop, size_t V, size_t T, const float* a, const float* b, float* out)
+  {
+    for (size_t r = 0; r < V * T; ++r)
+    {
+      const float start = a ? a[r * kFloatsPerDSPVector] : 0.f, end = b ? b[r * kFloatsPerDSPVector] : 0.f;
+      DSPVector y;
+      switch (vop)
+      {
+        case MLGPU_VOP_COLUMN_INDEX: y = columnIndex(); break;
+        case MLGPU_VOP_RANGE_OPEN: y = rangeOpen(start, end); break;
+        case MLGPU_VOP_RANGE_CLOSED: y = rangeClosed(start, end); break;
+        case MLGPU_VOP_INTERPOLATE_LINEAR: y = interpolateDSPVectorLinear(start, end); break;
+        default: return MLGPU_ERR_INVALID;
+      }
+      store(y, out + r * kFloatsPerDSPVector);
+    }
+    return MLGPU_OK;
+  }
+
+  void mlref_linear_glide_make_coeffs(float t, float* o)
+  {
+    LinearGlide g;
+    g.setGlideTimeInSamples(t);
+    const int32_t n = g.mVectorsPerGlide;
+    std::memcpy(&o[0], &n, 4);
+    o[1] = g.mDyPerVector;
+  }
+  void mlref_sample_accurate_linear_glide_make_coeffs(float t, float* o)
+  {
+    SampleAccurateLinearGlide g;
+    g.setGlideTimeInSamples(t);
+    const int32_t n = g.mSamplesPerGlide;
+    std::memcpy(&o[0], &n, 4);
+    o[1] = g.mDyPerSample;
   }
 
   // rangeClosed / rangeOpen helpers for the anchor tests

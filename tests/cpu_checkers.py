@@ -85,6 +85,10 @@ class _Checker:
         self._dcb = fn("dcblocker_make_coeffs", f, [f])
         self._db2g = fn("db_to_gain", f, [f])
         self._imp = fn("impulse_table", None, [c_f32p])
+        self._multi = fn("proc_process_multi", ctypes.c_int, [ctypes.c_int, sz, sz, c_f32p, c_u32p, ctypes.POINTER(c_f32p), ctypes.c_int, c_f32p])
+        self._vop = fn("vop", ctypes.c_int, [ctypes.c_int, sz, sz, c_f32p, c_f32p, c_f32p])
+        self._mk["linear_glide"] = (fn("linear_glide_make_coeffs", None, [f, c_f32p]), 1, 2)
+        self._mk["sample_glide"] = (fn("sample_accurate_linear_glide_make_coeffs", None, [f, c_f32p]), 1, 2)
         self._rc = fn("range_closed", None, [f, f, c_f32p])
         self._ro = fn("range_open", None, [f, f, c_f32p])
 
@@ -156,6 +160,27 @@ class _Checker:
         assert r == 0, r
         return out
 
+    def proc_multi(self, kind, T, coeffs, state, inputs):
+        """One processor in one of its multi-input forms (or a vector-rate ramp). inputs: list of [V][64T] float32
+        (a control-rate value repeated 64 times per vector). state [NS][V] is updated in place."""
+        V = state.shape[1]
+        coeffs = np.ascontiguousarray(coeffs, np.float32) if coeffs is not None else np.zeros((0, V), np.float32)
+        ins = [np.ascontiguousarray(x, np.float32) for x in inputs]
+        for x in ins:
+            assert x.shape == (V, 64 * T), x.shape
+        arr = (c_f32p * max(1, len(ins)))(*[_ptr(x, c_f32p) for x in ins])
+        out = np.empty((V, 64 * T), np.float32)
+        r = self._multi(int(kind), V, T, _ptr(coeffs, c_f32p), _ptr(state, c_u32p), arr, len(ins), _ptr(out, c_f32p))
+        assert r == 0, r
+        return out
+
+    def vop(self, vop, V, T, a=None, b=None):
+        out = np.empty((V, 64 * T), np.float32)
+        a = None if a is None else np.ascontiguousarray(a, np.float32)
+        b = None if b is None else np.ascontiguousarray(b, np.float32)
+        assert self._vop(int(vop), V, T, _ptr(a, c_f32p), _ptr(b, c_f32p), _ptr(out, c_f32p)) == 0
+        return out
+
     # ---- coefficient makers ----
     def make_coeffs(self, name, *params):
         fnc, nin, nout = self._mk[name]
@@ -195,6 +220,21 @@ class Oracle(_Checker):
         L.mlorc_chain_time.restype = ctypes.c_double
         L.mlorc_chain_time.argtypes = [c_i32p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_u32p,
                                        c_f32p, c_f32p, c_f32p, ctypes.c_int]
+
+    def libm_sinf(self, x):
+        """The restated glibc sinf (oracle/ml_oracle.c) on an array."""
+        self.lib.mlorc_libm_sinf.restype = ctypes.c_float
+        self.lib.mlorc_libm_sinf.argtypes = [ctypes.c_float]
+        return np.array([self.lib.mlorc_libm_sinf(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
+
+    def sinf_check(self, lo, hi, n_threads=8):
+        """(mismatch count, offending bit patterns) of restated vs host-libm sinf over bit patterns [lo, hi]."""
+        fnc = self.lib.mlorc_sinf_check
+        fnc.restype = ctypes.c_uint64
+        fnc.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, c_u32p, ctypes.c_int]
+        lst = np.zeros(64, np.uint32)
+        n = fnc(int(lo), int(hi), int(n_threads), _ptr(lst, c_u32p), 64)
+        return int(n), lst[:min(int(n), 64)]
 
     def chain_time(self, procs, T, coeffs, state, in_signal=None, in_const=None, n_threads=1):
         procs = np.ascontiguousarray(procs, np.int32)

@@ -15,8 +15,8 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from cpu_checkers import Ref  # noqa: E402
-from inputs import chain_coeffs, chain_input, op_inputs  # noqa: E402
-from madronalib_amd.constants import Op, Proc, RowOp  # noqa: E402
+from inputs import MULTI_CASES, chain_coeffs, chain_input, multi_case, multi_inputs_audio, op_inputs  # noqa: E402
+from madronalib_amd.constants import Op, Proc, RowOp, Vop  # noqa: E402
 
 GOLDEN_CHAINS = {
     "cfg1_sine_lopass": [Proc.SINE_GEN, Proc.LOPASS],
@@ -72,7 +72,31 @@ def main():
         d[name + "_state2"] = st.copy()
     d["impulse_table"] = ref.impulse_table()
     np.savez_compressed(os.path.join(HERE, "chains.npz"), **d)
-    for f in ("ops.npz", "chains.npz"):
+    # ---- the other operator() forms, vector-rate ramps, index generators: V=6, 2 calls of T=16 vectors ----
+    d = {}
+    V, T = 6, 16
+    for name in MULTI_CASES:
+        case = multi_case(ref, name, V, 2 * T, seed=8)
+        kind = case["kind"]
+        st = ref.chain_clear([kind], V)
+        d[name + "_kind"] = np.int32(kind)
+        d[name + "_coeffs"] = case["coeffs"]
+        d[name + "_state0"] = st.copy()
+        d[name + "_rates"] = np.array([r == "control" for r, _ in case["inputs"]])
+        for i, (_, a) in enumerate(case["inputs"]):
+            d[f"{name}_in{i}"] = a
+        ins = multi_inputs_audio(case, 2 * T)
+        for call in range(2):
+            sl = slice(call * 64 * T, (call + 1) * 64 * T)
+            d[f"{name}_out{call + 1}"] = ref.proc_multi(kind, T, case["coeffs"], st, [np.ascontiguousarray(x[:, sl]) for x in ins])
+            d[f"{name}_state{call + 1}"] = st.copy()
+    rng = np.random.default_rng(12)
+    d["vop_a"] = (rng.standard_normal((V, T)) * 10.0 ** rng.integers(-3, 4, (V, T))).astype(np.float32)
+    d["vop_b"] = (rng.standard_normal((V, T)) * 10.0 ** rng.integers(-3, 4, (V, T))).astype(np.float32)
+    for vop in (Vop.COLUMN_INDEX, Vop.RANGE_OPEN, Vop.RANGE_CLOSED, Vop.INTERPOLATE_LINEAR):
+        d[f"vop{vop}_out"] = ref.vop(vop, V, T, np.repeat(d["vop_a"], 64, 1), np.repeat(d["vop_b"], 64, 1))
+    np.savez_compressed(os.path.join(HERE, "multi.npz"), **d)
+    for f in ("ops.npz", "chains.npz", "multi.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -17,6 +17,18 @@ def load_chains():
     return np.load(os.path.join(HERE, "golden", "chains.npz"))
 
 
+def load_multi():
+    return np.load(os.path.join(HERE, "golden", "multi.npz"))
+
+
+def multi_golden_case(d, name):
+    """A multi-input / vector-rate case of multi.npz: inputs [(rate, array)] as inputs.multi_case returns them."""
+    rates = d[name + "_rates"]
+    ins = [("control" if rates[i] else "audio", d[f"{name}_in{i}"]) for i in range(len(rates))]
+    return dict(kind=int(d[name + "_kind"]), coeffs=d[name + "_coeffs"], state0=d[name + "_state0"], inputs=ins,
+                out=[d[name + "_out1"], d[name + "_out2"]], state=[d[name + "_state1"], d[name + "_state2"]])
+
+
 def chain_case_names(d=None):
     d = d or load_chains()
     return sorted(k[:-6] for k in d.files if k.endswith("_procs"))

@@ -34,6 +34,12 @@ def evaluate(chk, description, outputs, V, T, in_signals, params, coeffs, states
         elif ty == "param":
             p = np.broadcast_to(np.asarray(params[name], np.float32), (V,))
             val[name] = np.ascontiguousarray(np.repeat(p[:, None], S, 1))
+        elif ty == "control":
+            c = np.asarray(in_signals[name], np.float32).reshape(V, T)
+            val[name] = np.ascontiguousarray(np.repeat(c, 64, 1))
+        elif ty == "vop":
+            a = [np.ascontiguousarray(x) for x in ins] + [None, None]
+            val[name] = chk.vop(n["kind"], V, T, a[0], a[1])
         elif ty == "const":
             val[name] = np.full((V, S), np.float32(n["value"]), np.float32)
         elif ty == "op":
@@ -43,8 +49,8 @@ def evaluate(chk, description, outputs, V, T, in_signals, params, coeffs, states
             kind = n["kind"]
             st = states[name]
             co = coeffs.get(name, np.zeros((chk.num_coeffs(kind), V), np.float32))
-            if kind == Proc.PULSE_GEN and len(ins) == 2:
-                val[name] = _pulse2(chk, V, T, st[0], ins[0], ins[1])
+            if len(ins) > 1 or kind in Proc.VECTOR_RATE:
+                val[name] = chk.proc_multi(kind, T, co, st, ins)
             else:
                 sig = ins[0] if ins else None
                 val[name] = chk.chain_process([kind], T, np.ascontiguousarray(co, np.float32), st, sig, None)

@@ -43,13 +43,13 @@ def test_python_enums_match_header():
     h = _header()
     vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(MLGPU_[A-Z0-9_]+)\s*=\s*(\d+)", h)}
     for cls, prefix in ((constants.Op, "MLGPU_OP_"), (constants.Proc, "MLGPU_PROC_"), (constants.Layout, "MLGPU_LAYOUT_"),
-                        (constants.RowOp, "MLGPU_ROWOP_"), (constants.Status, "MLGPU_")):
+                        (constants.RowOp, "MLGPU_ROWOP_"), (constants.Status, "MLGPU_"), (constants.Vop, "MLGPU_VOP_")):
         for k, v in vars(cls).items():
             if k.startswith("_") or not isinstance(v, int):
                 continue
             assert vals[prefix + k] == v, (prefix + k, v)
     hdr_procs = {v for k, v in vals.items() if k.startswith("MLGPU_PROC_")}
-    assert hdr_procs == set(constants.Proc.ALL)
+    assert hdr_procs == set(constants.Proc.ALL) | set(constants.Proc.VECTOR_RATE)
 
 
 def test_coefficient_makers_match_oracle(oracle):

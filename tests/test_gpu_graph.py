@@ -5,9 +5,10 @@ import numpy as np
 import pytest
 
 from graph_oracle import evaluate
-from inputs import assert_bits_equal, gate_signal, lcg_noise
+from golden_cases import load_multi, multi_golden_case
+from inputs import MULTI_CASES, assert_bits_equal, gate_signal, lcg_noise, multi_case, multi_inputs_audio, stepped
 from madronalib_amd import patches
-from madronalib_amd.constants import Layout, Op, Proc
+from madronalib_amd.constants import Layout, Op, Proc, Vop
 
 
 def test_jit_selftest_compiles_without_gpu():
@@ -169,3 +170,165 @@ def test_graph_error_paths(eng):
         g.add("late", "op", Op.ABS, [lp])          # already compiled
     with pytest.raises(ml.MlgpuError):
         g.set_coeff("lp", 5, 1.0)
+
+
+# ---- the other operator() forms, control-rate inputs, vector-rate ramps, index generators ---------------------
+
+def single_node_graph(eng, V, case):
+    """A graph with one processor node fed by the case's inputs (audio inputs / control inputs)."""
+    import madronalib_amd as ml
+    g = ml.Graph(eng, V)
+    names = []
+    for i, (rate, _) in enumerate(case["inputs"]):
+        names.append(f"in{i}")
+        g.add(names[-1], "input" if rate == "audio" else "control")
+    g.add("p", "proc", case["kind"], names)
+    g.add_output("p")
+    g.compile()
+    return g, names
+
+
+def run_case_calls(g, names, case, T, state0, layout):
+    """Two consecutive calls of T vectors; returns outputs and the state after each call."""
+    V = state0.shape[1]
+    for i in range(state0.shape[0]):
+        g.set_state("p", i, state0[i])
+    g.set_coeffs("p", [np.ascontiguousarray(r) for r in case["coeffs"]])
+    outs, states = [], []
+    for call in range(2):
+        sig = {}
+        for nm, (rate, a) in zip(names, case["inputs"]):
+            w = 64 * T if rate == "audio" else T
+            sig[nm] = np.ascontiguousarray(a[:, call * w:(call + 1) * w])
+        (got,) = g.process_host(T, sig, layout)
+        outs.append(got)
+        states.append(np.stack([g.get_state("p", i) for i in range(state0.shape[0])]))
+    return outs, states
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MULTI_CASES)
+def test_multi_input_forms_vs_oracle(eng, oracle, name):
+    V, T = 200, 24
+    case = multi_case(oracle, name, V, 2 * T, seed=21)
+    g, names = single_node_graph(eng, V, case)
+    st = oracle.chain_clear([case["kind"]], V)
+    outs, states = run_case_calls(g, names, case, T, st.copy(), Layout.QUAD)
+    ins = multi_inputs_audio(case, 2 * T)
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        want = oracle.proc_multi(case["kind"], T, case["coeffs"], st, [np.ascontiguousarray(x[:, sl]) for x in ins])
+        assert_bits_equal(outs[call], want, True, f"{name} call {call}")
+        assert_bits_equal(states[call], st, False, f"{name} state after call {call}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MULTI_CASES)
+def test_multi_input_forms_golden(eng, name):
+    """Against the compiled reference's own outputs (tests/golden/multi.npz)."""
+    c = multi_golden_case(load_multi(), name)
+    T = c["out"][0].shape[1] // 64
+    V = c["state0"].shape[1]
+    g, names = single_node_graph(eng, V, c)
+    outs, states = run_case_calls(g, names, c, T, c["state0"].copy(), Layout.VOICE_MAJOR)
+    for call in range(2):
+        assert_bits_equal(outs[call], c["out"][call], True, f"{name} out{call + 1}")
+        assert_bits_equal(states[call], c["state"][call], False, f"{name} state{call + 1}")
+
+
+@pytest.mark.gpu
+def test_vector_generators_and_rates(eng, oracle):
+    """columnIndex / rangeOpen / rangeClosed / interpolateDSPVectorLinear from param, const and control nodes; the
+    float-mix lerp (MLDSPOps.h:753) as LERP with a control third operand; golden from the compiled reference."""
+    import madronalib_amd as ml
+    d = load_multi()
+    V, T = d["vop_a"].shape
+    desc = [dict(name="a", type="control"), dict(name="b", type="control"),
+            dict(name="idx", type="vop", kind=Vop.COLUMN_INDEX, inputs=[]),
+            dict(name="ro", type="vop", kind=Vop.RANGE_OPEN, inputs=["a", "b"]),
+            dict(name="rc", type="vop", kind=Vop.RANGE_CLOSED, inputs=["a", "b"]),
+            dict(name="il", type="vop", kind=Vop.INTERPOLATE_LINEAR, inputs=["a", "b"])]
+    g = ml.Graph(eng, V, desc, ["idx", "ro", "rc", "il"])
+    got = g.process_host(T, {"a": d["vop_a"], "b": d["vop_b"]}, Layout.QUAD)
+    for o, vop in zip(got, (Vop.COLUMN_INDEX, Vop.RANGE_OPEN, Vop.RANGE_CLOSED, Vop.INTERPOLATE_LINEAR)):
+        assert_bits_equal(o, d[f"vop{vop}_out"], True, f"vop {vop}")
+    # voice-rate (param) operands + the scalar-mix lerp
+    V2, T2 = 70, 5
+    rng = np.random.default_rng(5)
+    start, end = rng.standard_normal(V2).astype(np.float32), rng.standard_normal(V2).astype(np.float32)
+    mixc = rng.random((V2, T2)).astype(np.float32)
+    desc = [dict(name="x", type="input"), dict(name="s", type="param"), dict(name="e", type="param"), dict(name="m", type="control"),
+            dict(name="ramp", type="vop", kind=Vop.RANGE_CLOSED, inputs=["s", "e"]),
+            dict(name="y", type="op", kind=Op.LERP, inputs=["x", "ramp", "m"])]
+    g = ml.Graph(eng, V2, desc, ["y"])
+    g.set_param("s", start)
+    g.set_param("e", end)
+    x = lcg_noise(np.arange(V2, dtype=np.uint32), 64 * T2)
+    (got,) = g.process_host(T2, {"x": x, "m": mixc}, Layout.ROWS)
+    ramp = oracle.vop(Vop.RANGE_CLOSED, V2, T2, np.repeat(np.repeat(start[:, None], T2, 1), 64, 1), np.repeat(np.repeat(end[:, None], T2, 1), 64, 1))
+    want = oracle.op(Op.LERP, x, ramp, np.repeat(mixc, 64, 1))
+    assert_bits_equal(got, want.view(np.float32).reshape(V2, -1), True, "lerp(x, ramp, float m)")
+
+
+@pytest.mark.gpu
+def test_glide_patch_vs_oracle(eng, oracle):
+    """A voice driven at control rate: pitch control -> LinearGlide -> exp2Approx -> * base = freq -> SawGen ->
+    Lopass(x, omega = Interpolator1(cutoff control), k param) -> * SampleAccurateLinearGlide(level input)."""
+    import madronalib_amd as ml
+    V, T = 160, 30
+    desc = [dict(name="pitch", type="control"), dict(name="cutoff", type="control"), dict(name="level", type="input"),
+            dict(name="k", type="param"), dict(name="base", type="const", value=110.0 / 48000.0),
+            dict(name="pglide", type="proc", kind=Proc.LINEAR_GLIDE, inputs=["pitch"]),
+            dict(name="ratio", type="op", kind=Op.EXP2_APPROX, inputs=["pglide"]),
+            dict(name="freq", type="op", kind=Op.MULTIPLY, inputs=["ratio", "base"]),
+            dict(name="saw", type="proc", kind=Proc.SAW_GEN, inputs=["freq"]),
+            dict(name="omega", type="proc", kind=Proc.INTERPOLATOR1, inputs=["cutoff"]),
+            dict(name="lp", type="proc", kind=Proc.LOPASS, inputs=["saw", "omega", "k"]),
+            dict(name="lvl", type="proc", kind=Proc.SAMPLE_ACCURATE_LINEAR_GLIDE, inputs=["level"]),
+            dict(name="out", type="op", kind=Op.MULTIPLY, inputs=["lp", "lvl"])]
+    g = ml.Graph(eng, V, desc, ["out"])
+    g.clear()
+    rng = np.random.default_rng(3)
+    kq = rng.uniform(0.2, 1.5, V).astype(np.float32)
+    g.set_param("k", kq)
+    co_pg = np.stack([oracle.make_coeffs("linear_glide", 64.0 * (1 + v % 9)) for v in range(V)], 1)
+    co_lv = np.stack([oracle.make_coeffs("sample_glide", 10.0 + 7 * (v % 40)) for v in range(V)], 1)
+    g.set_coeffs("pglide", [np.ascontiguousarray(r) for r in co_pg])
+    g.set_coeffs("lvl", [np.ascontiguousarray(r) for r in co_lv])
+    states = {n["name"]: oracle.chain_clear([n["kind"]], V) for n in desc if n["type"] == "proc"}
+    coeffs = {"pglide": co_pg, "lvl": co_lv}
+    for call in range(2):
+        sig = {"pitch": stepped(V, T, 40 + call, -1.0, 3.0, 2, 10), "cutoff": stepped(V, T, 50 + call, 0.005, 0.45, 1, 6),
+               "level": stepped(V, 64 * T, 60 + call, 0.0, 1.0, 50, 700)}
+        (got,) = g.process_host(T, sig, Layout.QUAD)
+        (want,) = evaluate(oracle, desc, ["out"], V, T, sig, {"k": kq}, coeffs, states)
+        assert_bits_equal(got, want, True, f"glide patch call {call}")
+    for n in desc:
+        if n["type"] == "proc":
+            for i in range(g.num_state(n["name"])):
+                assert (g.get_state(n["name"], i) == states[n["name"]][i]).all(), (n["name"], i)
+    assert np.abs(got).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_vector_rate_rules(eng):
+    import madronalib_amd as ml
+    with pytest.raises(ml.MlgpuError) as ei:
+        eng.bank([Proc.LINEAR_GLIDE], 64)                      # vector-rate processors are graph nodes
+    assert ei.value.status == ml.Status.ERR_UNSUPPORTED
+    g = ml.Graph(eng, 64)
+    a = g.add("a", "input")
+    c = g.add("c", "control")
+    with pytest.raises(ml.MlgpuError):
+        g.add("bad", "proc", Proc.INTERPOLATOR1, [a])          # needs a float per vector, not an audio signal
+    with pytest.raises(ml.MlgpuError):
+        g.add("bad", "vop", Vop.RANGE_OPEN, [a, c])
+    with pytest.raises(ml.MlgpuError):
+        g.add("bad", "proc", Proc.LOPASS, [a, c])              # Lopass takes 1 or 3 inputs
+    with pytest.raises(ml.MlgpuError):
+        g.add("bad", "proc", Proc.HI_SHELF, [a] * 6)           # HiShelf takes 1 or 7
+    ok = g.add("glide", "proc", Proc.LINEAR_GLIDE, [c])
+    g.add_output(ok)
+    g.compile()
+    with pytest.raises(ml.MlgpuError):
+        g.process(1, [eng.alloc(64 * 64 * 4)], [eng.alloc(64 * 64 * 4)])   # control list missing

@@ -4,9 +4,10 @@ reference, (b) the SURVEY Appendix-B anchors, (c) the reference's own test asser
 import numpy as np
 import pytest
 
-from golden_cases import ANCHORS, chain_case, chain_case_names, hash31, load_chains, load_ops
-from inputs import assert_bits_equal, assert_rel_close, is_float_result
-from madronalib_amd.constants import Op, Proc, RowOp
+from golden_cases import (ANCHORS, chain_case, chain_case_names, hash31, load_chains, load_multi, load_ops,
+                          multi_golden_case)
+from inputs import MULTI_CASES, assert_bits_equal, assert_rel_close, is_float_result, multi_inputs_audio
+from madronalib_amd.constants import Op, Proc, RowOp, Vop
 
 HW_REL = 2.0 ** -11 * 1.5
 
@@ -42,6 +43,43 @@ def test_chains_golden(oracle, name):
         else:
             assert_bits_equal(got, c[out_k], True, name + " " + out_k)
         assert_bits_equal(st, c[st_k], False, name + " " + st_k)
+
+
+@pytest.mark.parametrize("name", MULTI_CASES)
+def test_multi_input_forms_golden(oracle, name):
+    c = multi_golden_case(load_multi(), name)
+    T = c["out"][0].shape[1] // 64
+    ins = multi_inputs_audio(c, 2 * T)
+    st = c["state0"].copy()
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        got = oracle.proc_multi(c["kind"], T, c["coeffs"], st, [np.ascontiguousarray(x[:, sl]) for x in ins])
+        assert_bits_equal(got, c["out"][call], True, f"{name} out{call + 1}")
+        assert_bits_equal(st, c["state"][call], False, f"{name} state{call + 1}")
+
+
+def test_vector_generators_golden(oracle):
+    d = load_multi()
+    V, T = d["vop_a"].shape
+    for vop in (Vop.COLUMN_INDEX, Vop.RANGE_OPEN, Vop.RANGE_CLOSED, Vop.INTERPOLATE_LINEAR):
+        got = oracle.vop(vop, V, T, np.repeat(d["vop_a"], 64, 1), np.repeat(d["vop_b"], 64, 1))
+        assert_bits_equal(got, d[f"vop{vop}_out"], True, f"vop {vop}")
+
+
+def test_restated_libm_sinf_against_host_libm(oracle):
+    """The device's sinf (Lopass::makeCoeffsVec, MLDSPFilters.h:104-113) is glibc 2.35's algorithm restated
+    (mlorc_libm_sinf is the same restatement on the CPU). Checked here against the host libm over ALL 2^32
+    float bit patterns: identical except where glibc's x86-64 FMA ifunc variant rounds differently from the
+    plain-double algorithm — 12 arguments, all with 53 < |x| < 120 — and never for |x| <= pi, the only
+    range the SVF coefficient code uses (omega <= 0.5 after the clamp)."""
+    pi_bits = int(np.float32(3.2).view(np.uint32))
+    n, lst = oracle.sinf_check(0, pi_bits)                      # +x in [0, 3.2]
+    assert n == 0, [hex(x) for x in lst]
+    n, lst = oracle.sinf_check(0x80000000, 0x80000000 + pi_bits)  # -x
+    assert n == 0, [hex(x) for x in lst]
+    n, lst = oracle.sinf_check(0, 0xFFFFFFFF)
+    xs = np.abs(lst.view(np.float32))
+    assert n <= 12 and ((xs > 53.0) & (xs < 120.0)).all(), (n, [hex(x) for x in lst])
 
 
 def test_impulse_table_golden(oracle):

@@ -6,8 +6,9 @@ the GPU box gets the prebuilt .so). Bit-exact except the two hardware-approximat
 import numpy as np
 import pytest
 
-from inputs import (assert_bits_equal, assert_rel_close, chain_coeffs, chain_input, is_float_result, op_inputs)
-from madronalib_amd.constants import Op, Proc, RowOp
+from inputs import (MULTI_CASES, assert_bits_equal, assert_rel_close, chain_coeffs, chain_input, is_float_result,
+                    multi_case, multi_inputs_audio, op_inputs)
+from madronalib_amd.constants import Op, Proc, RowOp, Vop
 
 HW_REL = 2.0 ** -11 * 1.5  # rcpps/rsqrtps: |rel err| <= 1.5 * 2^-12 per Intel; we allow 2^-11 * 1.5
 
@@ -104,3 +105,43 @@ def test_coefficient_makers_match_reference(oracle, ref):
     assert_bits_equal(oracle.impulse_table(), ref.impulse_table(), True, "ImpulseGen table")
     assert_bits_equal(oracle.range_closed(-np.pi, np.pi), ref.range_closed(-np.pi, np.pi), True, "rangeClosed")
     assert_bits_equal(oracle.range_open(0.25, 9.0), ref.range_open(0.25, 9.0), True, "rangeOpen")
+
+
+@pytest.mark.parametrize("name", MULTI_CASES)
+def test_multi_input_forms_match_reference(oracle, ref, name):
+    """PulseGen(freq, width), Lopass(x, omega, k), shelves with coefficient signals, Interpolator1, LinearGlide:
+    two consecutive calls, outputs and final state."""
+    V, T = 12, 40
+    case_r = multi_case(ref, name, V, 2 * T, seed=4)
+    case_o = multi_case(oracle, name, V, 2 * T, seed=4)
+    assert_bits_equal(case_o["coeffs"], case_r["coeffs"], True, name + " coeffs")
+    ins_r, ins_o = multi_inputs_audio(case_r, 2 * T), multi_inputs_audio(case_o, 2 * T)
+    kind = case_r["kind"]
+    st_r, st_o = ref.chain_clear([kind], V), oracle.chain_clear([kind], V)
+    assert_bits_equal(st_o, st_r, False, name + " clear() state")
+    assert_bits_equal(oracle.chain_default_state([kind], V), ref.chain_default_state([kind], V), False, name + " default state")
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        a_r = [np.ascontiguousarray(x[:, sl]) for x in ins_r]
+        a_o = [np.ascontiguousarray(x[:, sl]) for x in ins_o]
+        for x, y in zip(a_r, a_o):
+            assert_bits_equal(y, x, True, name + " inputs")
+        want = ref.proc_multi(kind, T, case_r["coeffs"], st_r, a_r)
+        got = oracle.proc_multi(kind, T, case_o["coeffs"], st_o, a_o)
+        assert_bits_equal(got, want, True, f"{name} call {call}")
+        assert_bits_equal(st_o, st_r, False, f"{name} state after call {call}")
+
+
+@pytest.mark.parametrize("vop", [Vop.COLUMN_INDEX, Vop.RANGE_OPEN, Vop.RANGE_CLOSED, Vop.INTERPOLATE_LINEAR])
+def test_vector_generators_match_reference(oracle, ref, vop):
+    V, T = 9, 17
+    rng = np.random.default_rng(vop)
+    a = np.repeat((rng.standard_normal((V, T)) * 10.0 ** rng.integers(-3, 4, (V, T))).astype(np.float32), 64, 1)
+    b = np.repeat((rng.standard_normal((V, T)) * 10.0 ** rng.integers(-3, 4, (V, T))).astype(np.float32), 64, 1)
+    assert_bits_equal(oracle.vop(vop, V, T, a, b), ref.vop(vop, V, T, a, b), True, f"vop {vop}")
+
+
+def test_glide_coefficient_makers_match_reference(oracle, ref):
+    for t in (0.0, 1.0, 63.9, 64.0, 100.0, 1000.0, 4096.0, 12345.6, -5.0):
+        assert_bits_equal(oracle.make_coeffs("linear_glide", t), ref.make_coeffs("linear_glide", t), False, "LinearGlide")
+        assert_bits_equal(oracle.make_coeffs("sample_glide", t), ref.make_coeffs("sample_glide", t), False, "SampleAccurate")
