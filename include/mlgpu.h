@@ -255,6 +255,49 @@ int mlgpu_layout_convert(mlgpu_engine* e, const float* d_src, int src_layout, fl
                          int dst_layout, size_t n_voices, size_t n_vectors);
 
 /* ------------------------------------------------------------------------- */
+/* row plumbing and routing                                                  */
+/*
+ * Row plumbing (MLDSPOps.h:1057-1343) is data movement between DSPVectorArrays: destination row j of each
+ * group (= one DSPVectorArray; `n_groups` of them per call, e.g. one per voice) is a copy of source row
+ * rule(j) of the same group, or zeros. For j in [0, count):
+ *     dst[g][dst_offset + j*dst_step] = rotate(src[g][rule(j)], sample_rotate)
+ * with src_rows / dst_rows rows per group. sample_rotate: 0, +1 = rotateLeft (y[n] = x[(n+1)%64], :1219-1245),
+ * -1 = rotateRight (:1249-1276). The reference's functions are one or a few calls:
+ *   repeatRows<R>(x)      REPEAT,  count = R*N                       stretchRows<R>(x)  STRETCH, count = R
+ *   zeroPadRows<R>(x)     SHIFT p0 = 0, count = R                    shiftRows(x, k)    SHIFT p0 = k
+ *   rotateRows(x, k)      ROTATE p0 = k                              separateRows<A,B>  STRIDED p0 = A, p1 = 1, count = B-A
+ *   evenRows / oddRows    STRIDED p0 = 0 / 1, p1 = 2                 concatRows(a, b..) one STRIDED call per operand, dst_offset
+ *   shuffleRows(a, b)     STRIDED calls with dst_step = 2 for the interleaved part, 1 for the appended excess
+ */
+typedef enum mlgpu_rows_rule
+{
+  MLGPU_ROWS_REPEAT = 0,  /* rule(j) = j % src_rows                                  :1057-1068 */
+  MLGPU_ROWS_STRETCH = 1, /* rule(j) = roundf(j*(src_rows-1.f)/(count-1.f))          :1073-1083 */
+  MLGPU_ROWS_SHIFT = 2,   /* rule(j) = j - p0; rows from outside [0, src_rows) are 0 :1088-1121 */
+  MLGPU_ROWS_ROTATE = 3,  /* rule(j) = (j - p0) mod src_rows                         :1126-1139 */
+  MLGPU_ROWS_STRIDED = 4  /* rule(j) = p0 + j*p1; outside [0, src_rows) -> 0         :1145-1343 */
+} mlgpu_rows_rule;
+int mlgpu_rows_map(mlgpu_engine* e, int rule, long p0, long p1, int sample_rotate, const float* d_src, size_t src_rows,
+                   float* d_dst, size_t dst_rows, size_t dst_offset, size_t dst_step, size_t count, size_t n_groups);
+/* addRows (MLDSPOps.h:1349-1359): out[g] = ((0 + row 0) + row 1) + ... over each group's rows. */
+int mlgpu_rows_add(mlgpu_engine* e, const float* d_rows, size_t rows_per_group, float* d_out, size_t n_groups);
+/* normalize (MLDSPOps.h:1041-1050): every row divided by its sum(). */
+int mlgpu_rows_normalize(mlgpu_engine* e, const float* d_rows, float* d_out, size_t n_rows);
+/* rowIndex<ROWS>() (MLDSPOps.h:1365-1374): row j of every group filled with (float)j. */
+int mlgpu_rows_index(mlgpu_engine* e, float* d_out, size_t rows_per_group, size_t n_groups);
+
+/* Routing (MLDSPRouting.h:83-234): per-sample selection among n signals by a selector in [0, 1).
+ * Signals are flat arrays of n_elems floats; selector element i % sel_elems is used for element i
+ * (sel_elems = 64: one selector DSPVector for every row, as the reference; sel_elems = n_elems: a selector
+ * per sample). `linear`: multiplexLinear / demultiplexLinear. A negative or NaN selector is undefined
+ * behaviour in the reference (out-of-bounds read); here it selects index 0. n <= MLGPU_ROUTE_MAX_SIGNALS. */
+#define MLGPU_ROUTE_MAX_SIGNALS 8
+int mlgpu_multiplex(mlgpu_engine* e, const float* d_selector, size_t sel_elems, const float* const* d_inputs, int n_inputs,
+                    float* d_out, size_t n_elems, int linear);
+int mlgpu_demultiplex(mlgpu_engine* e, const float* d_selector, size_t sel_elems, const float* d_input,
+                      float* const* d_outputs, int n_outputs, size_t n_elems, int linear);
+
+/* ------------------------------------------------------------------------- */
 /* voice banks                                                               */
 /*
  * mlgpu_bank is the runtime-sized counterpart of `Bank<T,ROWS>`
@@ -354,6 +397,18 @@ int mlgpu_graph_add_param(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_control(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_vop(mlgpu_graph* g, int vop, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_const(mlgpu_graph* g, float value);
+/* routing nodes (MLDSPRouting.h): input_nodes[0] is the selector.
+ *   MLGPU_ROUTE_MULTIPLEX / _LINEAR      input_nodes[1..n] the candidates (n <= 8); `index` ignored
+ *   MLGPU_ROUTE_DEMULTIPLEX / _LINEAR    input_nodes[1] the signal; this node is output `index` of `n_outputs` */
+typedef enum mlgpu_route
+{
+  MLGPU_ROUTE_MULTIPLEX = 0,
+  MLGPU_ROUTE_MULTIPLEX_LINEAR = 1,
+  MLGPU_ROUTE_DEMULTIPLEX = 2,
+  MLGPU_ROUTE_DEMULTIPLEX_LINEAR = 3
+} mlgpu_route;
+int mlgpu_graph_add_route(mlgpu_graph* g, int route, const int* input_nodes, int n_inputs, int index, int n_outputs,
+                          const char* name);
 int mlgpu_graph_add_proc(mlgpu_graph* g, int proc_kind, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_output(mlgpu_graph* g, int node);

@@ -13,9 +13,9 @@ import weakref
 import numpy as np
 
 from . import _lib
-from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, RowOp, Status, Vop
+from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, Route, RowOp, RowsRule, Status, Vop
 
-__all__ = ["Engine", "Bank", "Graph", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "LinearGlide", "SampleAccurateLinearGlide",
+__all__ = ["Engine", "Bank", "Graph", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "LinearGlide", "SampleAccurateLinearGlide",
            "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
            "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
 
@@ -154,6 +154,9 @@ class Engine:
         self.op_apply(op, bufs[0], bufs[1], bufs[2], out, n)
         return out.download(np.uint32, n).reshape(a.shape)
 
+    def op_f32(self, op, a, b=None, c=None):
+        return self.op(op, a, b, c).view(np.float32)
+
     def op_rows1(self, op, a, b64):
         a = np.ascontiguousarray(a, np.float32)
         da, db = self.to_device(a), self.to_device(np.ascontiguousarray(b64, np.float32))
@@ -167,6 +170,53 @@ class Engine:
         out = self.alloc(max(16, 4 * (rows.size // 64)))
         self._check(self.L.mlgpu_row_reduce(self.h, int(rowop), d.ptr, out.ptr, rows.size // 64))
         return out.download(np.float32, rows.size // 64)
+
+    # ---- row plumbing and routing (host convenience: numpy rows [n][64] in, numpy out) ----
+    def rows_map(self, rule, p0, p1, sample_rotate, src, src_rows, dst_rows, dst_offset, dst_step, count, groups, dst=None):
+        """mlgpu_rows_map on host arrays. `dst` (numpy [groups*dst_rows][64]) is updated and returned, so the
+        reference's multi-call functions (concatRows, shuffleRows) can accumulate into one destination."""
+        src = np.ascontiguousarray(src, np.float32).reshape(-1, 64)
+        if dst is None:
+            dst = np.zeros((groups * dst_rows, 64), np.float32)
+        d_src, d_dst = self.to_device(src), self.to_device(dst)
+        self._check(self.L.mlgpu_rows_map(self.h, int(rule), int(p0), int(p1), int(sample_rotate), d_src.ptr, int(src_rows),
+                                          d_dst.ptr, int(dst_rows), int(dst_offset), int(dst_step), int(count), int(groups)))
+        return d_dst.download(np.float32, dst.size).reshape(dst.shape)
+
+    def rows_add(self, rows, rows_per_group, groups):
+        rows = np.ascontiguousarray(rows, np.float32)
+        d, out = self.to_device(rows), self.alloc(groups * 256)
+        self._check(self.L.mlgpu_rows_add(self.h, d.ptr, int(rows_per_group), out.ptr, int(groups)))
+        return out.download(np.float32, groups * 64).reshape(groups, 64)
+
+    def rows_normalize(self, rows):
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 64)
+        d, out = self.to_device(rows), self.alloc(rows.nbytes)
+        self._check(self.L.mlgpu_rows_normalize(self.h, d.ptr, out.ptr, rows.shape[0]))
+        return out.download(np.float32, rows.size).reshape(rows.shape)
+
+    def rows_index(self, rows_per_group, groups):
+        out = self.alloc(groups * rows_per_group * 256)
+        self._check(self.L.mlgpu_rows_index(self.h, out.ptr, int(rows_per_group), int(groups)))
+        return out.download(np.float32, groups * rows_per_group * 64).reshape(-1, 64)
+
+    def multiplex(self, selector, inputs, linear=False):
+        sel = np.ascontiguousarray(selector, np.float32)
+        ins = [np.ascontiguousarray(x, np.float32) for x in inputs]
+        n = ins[0].size
+        d_sel, d_ins, out = self.to_device(sel), [self.to_device(x) for x in ins], self.alloc(4 * n)
+        arr = (ctypes.c_void_p * len(ins))(*[b.ptr for b in d_ins])
+        self._check(self.L.mlgpu_multiplex(self.h, d_sel.ptr, sel.size, arr, len(ins), out.ptr, n, 1 if linear else 0))
+        return out.download(np.float32, n).reshape(ins[0].shape)
+
+    def demultiplex(self, selector, x, n_outputs, linear=False):
+        sel = np.ascontiguousarray(selector, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        d_sel, d_x = self.to_device(sel), self.to_device(x)
+        outs = [self.alloc(4 * x.size) for _ in range(n_outputs)]
+        arr = (ctypes.c_void_p * n_outputs)(*[b.ptr for b in outs])
+        self._check(self.L.mlgpu_demultiplex(self.h, d_sel.ptr, sel.size, d_x.ptr, arr, n_outputs, x.size, 1 if linear else 0))
+        return [o.download(np.float32, x.size).reshape(x.shape) for o in outs]
 
     def layout_convert(self, src, src_layout, dst, dst_layout, n_voices, n_vectors):
         self._check(self.L.mlgpu_layout_convert(self.h, src.ptr, int(src_layout), dst.ptr, int(dst_layout),
@@ -346,7 +396,7 @@ class Graph:
             self.ids[name] = r
         return r
 
-    def add(self, name, type, kind=None, inputs=(), value=None):
+    def add(self, name, type, kind=None, inputs=(), value=None, index=0, n_outputs=0):
         bname = name.encode() if name else None
         ins = [self._id(i) for i in inputs]
         arr = (ctypes.c_int * max(1, len(ins)))(*ins)
@@ -358,6 +408,8 @@ class Graph:
             return self._ret(self.L.mlgpu_graph_add_control(self.h, bname), name)
         if type == "vop":
             return self._ret(self.L.mlgpu_graph_add_vop(self.h, int(kind), arr, len(ins), bname), name)
+        if type == "route":
+            return self._ret(self.L.mlgpu_graph_add_route(self.h, int(kind), arr, len(ins), int(index), int(n_outputs), bname), name)
         if type == "param":
             return self._ret(self.L.mlgpu_graph_add_param(self.h, bname), name)
         if type == "const":

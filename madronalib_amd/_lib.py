@@ -86,6 +86,14 @@ def _declare(L):
     sig("mlgpu_op_apply_rows1", i, [vp, i, vp, vp, vp, sz])
     sig("mlgpu_row_reduce", i, [vp, i, vp, vp, sz])
     sig("mlgpu_layout_convert", i, [vp, vp, i, vp, i, sz, sz])
+    lg = c.c_long
+    sig("mlgpu_rows_map", i, [vp, i, lg, lg, i, vp, sz, vp, sz, sz, sz, sz, sz])
+    sig("mlgpu_rows_add", i, [vp, vp, sz, vp, sz])
+    sig("mlgpu_rows_normalize", i, [vp, vp, vp, sz])
+    sig("mlgpu_rows_index", i, [vp, vp, sz, sz])
+    sig("mlgpu_multiplex", i, [vp, vp, sz, pp, i, vp, sz, i])
+    sig("mlgpu_demultiplex", i, [vp, vp, sz, vp, pp, i, sz, i])
+    sig("mlgpu_graph_add_route", i, [vp, i, c.POINTER(c.c_int), i, i, i, c.c_char_p])
     sig("mlgpu_bank_create", i, [vp, c.POINTER(c.c_int32), i, sz, pp])
     sig("mlgpu_bank_destroy", i, [vp])
     sig("mlgpu_bank_num_voices", sz, [vp])

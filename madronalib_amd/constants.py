@@ -85,6 +85,21 @@ class Vop:
     INTERPOLATE_LINEAR = 3
 
 
+class RowsRule:
+    REPEAT = 0
+    STRETCH = 1
+    SHIFT = 2
+    ROTATE = 3
+    STRIDED = 4
+
+
+class Route:
+    MULTIPLEX = 0
+    MULTIPLEX_LINEAR = 1
+    DEMULTIPLEX = 2
+    DEMULTIPLEX_LINEAR = 3
+
+
 class RowOp:
     SUM = 0
     MEAN = 1

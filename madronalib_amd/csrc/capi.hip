@@ -297,6 +297,80 @@ extern "C"
     return MLGPU_OK;
   }
 
+  // ---- row plumbing and routing ---------------------------------------------------------------
+
+  int mlgpu_rows_map(mlgpu_engine* e, int rule, long p0, long p1, int sampleRotate, const float* src, size_t srcRows, float* dst,
+                     size_t dstRows, size_t dstOffset, size_t dstStep, size_t count, size_t groups)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (count == 0 || groups == 0) return MLGPU_OK;
+    if (!src || !dst || src == dst) return fail(e, MLGPU_ERR_INVALID, "rows_map: bad pointers (must not alias)");
+    if (rule < MLGPU_ROWS_REPEAT || rule > MLGPU_ROWS_STRIDED) return fail(e, MLGPU_ERR_INVALID, "rows_map: unknown rule");
+    if (srcRows == 0 || sampleRotate < -1 || sampleRotate > 1) return fail(e, MLGPU_ERR_INVALID, "rows_map: bad src_rows / sample_rotate");
+    if (dstStep == 0 || dstOffset + (count - 1) * dstStep >= dstRows) return fail(e, MLGPU_ERR_RANGE, "rows_map: destination rows out of range");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, mlgpu_launch_rows_map(rule, p0, p1, sampleRotate, src, srcRows, dst, dstRows, dstOffset, dstStep, count, groups, e->stream));
+    return MLGPU_OK;
+  }
+
+  int mlgpu_rows_add(mlgpu_engine* e, const float* rows, size_t rowsPerGroup, float* out, size_t groups)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (groups == 0) return MLGPU_OK;
+    if (!rows || !out) return fail(e, MLGPU_ERR_INVALID, "rows_add: null operand");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, mlgpu_launch_rows_add(rows, rowsPerGroup, out, groups, e->stream));
+    return MLGPU_OK;
+  }
+
+  int mlgpu_rows_normalize(mlgpu_engine* e, const float* rows, float* out, size_t nRows)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (nRows == 0) return MLGPU_OK;
+    if (!rows || !out) return fail(e, MLGPU_ERR_INVALID, "rows_normalize: null operand");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, mlgpu_launch_rows_normalize(rows, out, nRows, e->stream));
+    return MLGPU_OK;
+  }
+
+  int mlgpu_rows_index(mlgpu_engine* e, float* out, size_t rowsPerGroup, size_t groups)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (groups == 0 || rowsPerGroup == 0) return MLGPU_OK;
+    if (!out) return fail(e, MLGPU_ERR_INVALID, "rows_index: null operand");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, mlgpu_launch_rows_index(out, rowsPerGroup, groups, e->stream));
+    return MLGPU_OK;
+  }
+
+  int mlgpu_multiplex(mlgpu_engine* e, const float* sel, size_t selElems, const float* const* ins, int n, float* out, size_t nElems, int linear)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (nElems == 0) return MLGPU_OK;
+    if (!sel || !ins || !out || selElems == 0) return fail(e, MLGPU_ERR_INVALID, "multiplex: null operand");
+    if (n < 1 || n > MLGPU_ROUTE_MAX_SIGNALS) return fail(e, MLGPU_ERR_UNSUPPORTED, "multiplex: 1..8 inputs");
+    for (int k = 0; k < n; ++k)
+      if (!ins[k]) return fail(e, MLGPU_ERR_INVALID, "multiplex: null input");
+    HIP_TRY(e, hipSetDevice(e->device));
+    float* outs[1] = {out};
+    HIP_TRY(e, mlgpu_launch_route(false, linear != 0, sel, selElems, ins, outs, n, nElems, e->stream));
+    return MLGPU_OK;
+  }
+
+  int mlgpu_demultiplex(mlgpu_engine* e, const float* sel, size_t selElems, const float* in, float* const* outs, int n, size_t nElems, int linear)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (nElems == 0) return MLGPU_OK;
+    if (!sel || !in || !outs || selElems == 0) return fail(e, MLGPU_ERR_INVALID, "demultiplex: null operand");
+    if (n < 1 || n > MLGPU_ROUTE_MAX_SIGNALS) return fail(e, MLGPU_ERR_UNSUPPORTED, "demultiplex: 1..8 outputs");
+    for (int k = 0; k < n; ++k)
+      if (!outs[k]) return fail(e, MLGPU_ERR_INVALID, "demultiplex: null output");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const float* ins[1] = {in};
+    HIP_TRY(e, mlgpu_launch_route(true, linear != 0, sel, selElems, ins, outs, n, nElems, e->stream));
+    return MLGPU_OK;
+  }
+
   // ---- banks --------------------------------------------------------------------------------
 
   int mlgpu_bank_destroy(mlgpu_bank* b)

@@ -144,7 +144,8 @@ enum NodeType
   NODE_PROC = 3,
   NODE_OP = 4,
   NODE_CONTROL = 5,  // streamed, one float per DSPVector per voice
-  NODE_VOP = 6       // index-dependent vector generator (columnIndex, rangeOpen, ...)
+  NODE_VOP = 6,      // index-dependent vector generator (columnIndex, rangeOpen, ...)
+  NODE_ROUTE = 7     // multiplex / demultiplex (MLDSPRouting.h); in[0] is the selector
 };
 
 // how often a node's value changes: per voice (params, consts and ops on them), per DSPVector (controls and
@@ -163,7 +164,8 @@ struct Node
   std::vector<int> in;
   std::string name;
   float value{0.f};
-  int slot{0};            // input index / param index / control index
+  int slot{0};            // input index / param index / control index; demultiplex: output index
+  int nOut{0};            // demultiplex: number of outputs
   int rate{RATE_AUDIO};
   int cOff{0}, sOff{0}, nc{0}, ns{0};
 };
@@ -244,6 +246,17 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i)
       s << "apply_f<" << n.kind << ">(" << arg(0);
       for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
       s << ")";
+      break;
+    case NODE_ROUTE:
+      if (n.kind == MLGPU_ROUTE_MULTIPLEX || n.kind == MLGPU_ROUTE_MULTIPLEX_LINEAR)
+      {
+        s << (n.kind == MLGPU_ROUTE_MULTIPLEX ? "route_multiplex_v(" : "route_multiplex_linear_v(") << arg(0);
+        for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
+        s << ")";
+      }
+      else
+        s << (n.kind == MLGPU_ROUTE_DEMULTIPLEX ? "route_demultiplex(" : "route_demultiplex_linear(") << arg(0) << ", " << arg(1) << ", "
+          << n.slot << ", " << n.nOut << ")";
       break;
     case NODE_VOP:
       s << "vop<" << n.kind << ">(q * 4 + k";
@@ -341,7 +354,7 @@ int addNode(mlgpu_graph* g, Node&& n)
   {
     case NODE_PARAM: case NODE_CONST: n.rate = RATE_VOICE; break;
     case NODE_CONTROL: n.rate = RATE_VECTOR; break;
-    case NODE_OP:
+    case NODE_OP: case NODE_ROUTE:
       n.rate = RATE_VOICE;
       for (int id : n.in) n.rate = std::max(n.rate, g->nodes[id].rate);
       break;
@@ -430,7 +443,15 @@ extern "C"
     const int ls = mlgpu_graph_add_proc(&g, MLGPU_PROC_LO_SHELF, lsIn, 6, "loshelf");
     const int hsIn[7] = {ls, ramp, ci, rc, ro, sg, two};
     const int hs = mlgpu_graph_add_proc(&g, MLGPU_PROC_HI_SHELF, hsIn, 7, "hishelf");
-    ok = (vca > 0) && (hs > 0) && (mlgpu_graph_add_output(&g, hs) == MLGPU_OK) && ok;
+    const int muxIn[4] = {gate, hs, ls, lp3};
+    const int mux = mlgpu_graph_add_route(&g, MLGPU_ROUTE_MULTIPLEX, muxIn, 4, 0, 0, "mux");
+    const int muxl = mlgpu_graph_add_route(&g, MLGPU_ROUTE_MULTIPLEX_LINEAR, muxIn, 4, 0, 0, "muxl");
+    const int dmIn[2] = {gate, mux};
+    const int dm = mlgpu_graph_add_route(&g, MLGPU_ROUTE_DEMULTIPLEX, dmIn, 2, 1, 3, "dm1");
+    const int dmlIn[2] = {gate, muxl};
+    const int dml = mlgpu_graph_add_route(&g, MLGPU_ROUTE_DEMULTIPLEX_LINEAR, dmlIn, 2, 2, 3, "dml2");
+    ok = (vca > 0) && (hs > 0) && (dm > 0) && (dml > 0) && (mlgpu_graph_add_output(&g, hs) == MLGPU_OK) && (mlgpu_graph_add_output(&g, dm) == MLGPU_OK) &&
+         (mlgpu_graph_add_output(&g, dml) == MLGPU_OK) && ok;
     log.clear();
     ok = compileOnly(generateGraphSource(&g), log) && ok;
     all += log;
@@ -522,6 +543,23 @@ extern "C"
     n.kind = vop;
     if (nIn) n.in.assign(inputs, inputs + nIn);
     n.name = name ? name : "";
+    return addNode(g, std::move(n));
+  }
+  int mlgpu_graph_add_route(mlgpu_graph* g, int route, const int* inputs, int nIn, int index, int nOutputs, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (route < MLGPU_ROUTE_MULTIPLEX || route > MLGPU_ROUTE_DEMULTIPLEX_LINEAR || !inputs) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_route: unknown routing node");
+    const bool mux = (route == MLGPU_ROUTE_MULTIPLEX || route == MLGPU_ROUTE_MULTIPLEX_LINEAR);
+    if (mux && (nIn < 2 || nIn > 1 + MLGPU_ROUTE_MAX_SIGNALS)) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_route: multiplex takes a selector and 1..8 signals");
+    if (!mux && (nIn != 2 || nOutputs < 1 || nOutputs > MLGPU_ROUTE_MAX_SIGNALS || index < 0 || index >= nOutputs))
+      return -gfail(g, MLGPU_ERR_INVALID, "graph_add_route: demultiplex takes (selector, signal), 1..8 outputs, 0 <= index < n_outputs");
+    Node n;
+    n.type = NODE_ROUTE;
+    n.kind = route;
+    n.in.assign(inputs, inputs + nIn);
+    n.name = name ? name : "";
+    n.slot = index;
+    n.nOut = nOutputs;
     return addNode(g, std::move(n));
   }
   int mlgpu_graph_add_const(mlgpu_graph* g, float value)

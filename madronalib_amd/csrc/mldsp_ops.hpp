@@ -95,4 +95,70 @@ MLD float vop(int n, float a = 0.f, float b = 0.f)
   }
 }
 
+// ---- routing, MLDSPRouting.h:83-234 (one sample; x[] holds the N candidate inputs) ----------------------
+// The reference converts `inputU * nInputs` to size_t: for a negative or NaN selector that is undefined
+// behaviour there (an out-of-bounds read); here such samples select input 0 / no output. `s - truncf(s)`
+// is fractionalPart without the SSE saturation quirk (truncf is exact for every float).
+#define MLGPU_ROUTE_MAX 8
+MLD int route_index(float u, int n)  // size_t(u * n), clamped into [0, n)
+{
+  const float r = u * (float)n;
+  const int i = (r >= 0.f && r < 2147483648.f) ? (int)r : 0;
+  return (i < n) ? i : 0;
+}
+MLD float route_pick(const float* x, int idx)
+{
+  float y = x[0];
+#pragma unroll
+  for (int k = 1; k < MLGPU_ROUTE_MAX; ++k) y = (idx == k) ? x[k] : y;
+  return y;
+}
+MLD float route_multiplex(float s, const float* x, int n)  // :83-105
+{
+  const float u = s - __builtin_truncf(s);
+  return route_pick(x, route_index(u, n));
+}
+MLD float route_multiplex_linear(float s, const float* x, int n)  // :111-137, scalar lerp a + m*(b - a)
+{
+  const float u = s - __builtin_truncf(s);
+  const float real = u * (float)n;
+  const float ip = __builtin_truncf(real);
+  const float frac = real - ip;
+  int i1 = (ip >= 0.f && ip < 2147483648.f) ? (int)ip : 0;
+  if (i1 >= n) i1 = 0;
+  const int i2 = (i1 + 1) % n;
+  const float a = route_pick(x, i1), b = route_pick(x, i2);
+  return a + frac * (b - a);
+}
+template <class... F>
+MLD float route_multiplex_v(float s, F... xs)
+{
+  const float x[MLGPU_ROUTE_MAX] = {xs...};
+  return route_multiplex(s, x, (int)sizeof...(F));
+}
+template <class... F>
+MLD float route_multiplex_linear_v(float s, F... xs)
+{
+  const float x[MLGPU_ROUTE_MAX] = {xs...};
+  return route_multiplex_linear(s, x, (int)sizeof...(F));
+}
+MLD float route_demultiplex(float s, float x, int j, int n)  // :142-174
+{
+  const float u = s - __builtin_truncf(s);
+  return (route_index(u, n) == j) ? x : 0.f;
+}
+MLD float route_demultiplex_linear(float s, float x, int j, int n)  // :180-234
+{
+  const float u = s - __builtin_truncf(s);
+  const float real = u * (float)n;
+  const float ip = __builtin_truncf(real);
+  int i1 = (ip >= 0.f && ip < 2147483648.f) ? (int)ip : 0;
+  if (i1 >= n) i1 = 0;
+  const float m = real - ip;
+  const int i2 = (i1 + 1) % n;
+  if (j == i1) return x * (1.f - m);
+  if (j == i2) return x * m;
+  return 0.f;
+}
+
 }  // namespace mldev

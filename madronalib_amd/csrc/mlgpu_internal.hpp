@@ -67,6 +67,13 @@ hipError_t mlgpu_launch_row_reduce(int rowop, const float* rows, float* out, siz
 hipError_t mlgpu_launch_layout_convert(const float* src, int srcLayout, float* dst, int dstLayout, size_t V,
                                        size_t T, hipStream_t stream);
 hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStream_t stream);
+hipError_t mlgpu_launch_rows_map(int rule, long p0, long p1, int sampleRotate, const float* src, size_t srcRows, float* dst,
+                                 size_t dstRows, size_t dstOffset, size_t dstStep, size_t count, size_t groups, hipStream_t stream);
+hipError_t mlgpu_launch_rows_add(const float* rows, size_t rowsPerGroup, float* out, size_t groups, hipStream_t stream);
+hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRows, hipStream_t stream);
+hipError_t mlgpu_launch_rows_index(float* out, size_t rowsPerGroup, size_t groups, hipStream_t stream);
+hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,
+                              size_t nElems, hipStream_t stream);
 
 // graph.hip — run-time fused kernels (hiprtc)
 bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);

@@ -6,6 +6,8 @@
 // workgroups over all 256 CUs. No LDS, no MFMA: there is no reuse and no contraction.
 //
 // Compile with -ffp-contract=off (see mldsp_math.hpp).
+#include <string.h>
+
 #include "mlgpu_internal.hpp"
 #include "mldsp_ops.hpp"
 
@@ -198,6 +200,169 @@ __global__ __launch_bounds__(256) void fill32_kernel(uint32_t* dst, uint32_t val
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = value;
 }
+
+// ---------------------------------------------------------------------------------------------
+// row plumbing (MLDSPOps.h:1057-1343): pure data movement between DSPVectorArrays. One lane moves one
+// float4 of a destination row; the source row comes from a small closed-form rule (mlgpu_rows_rule),
+// so no index table has to be uploaded. `groups` independent arrays (e.g. one DSPVectorArray per
+// voice) are processed by one launch.
+struct RowsMapArgs
+{
+  const float4* src;
+  float4* dst;
+  int rule;
+  long p0, p1;
+  int sampleRotate;  // 0, +1 (rotateLeft: y[n] = x[n+1]), -1 (rotateRight: y[n] = x[n-1]), wrapping inside the row
+  size_t srcRows, dstRows, dstOffset, dstStep, count, groups;
+};
+
+__device__ __forceinline__ long rowsSource(const RowsMapArgs& a, long j)
+{
+  const long N = (long)a.srcRows;
+  switch (a.rule)
+  {
+    case MLGPU_ROWS_REPEAT: return j % N;
+    case MLGPU_ROWS_STRETCH:  // int k = roundf((j * (N - 1.f)) / (ROWS - 1.f)), MLDSPOps.h:1080
+      return (a.count < 2) ? 0 : (long)__builtin_roundf(((float)j * ((float)N - 1.f)) / ((float)a.count - 1.f));
+    case MLGPU_ROWS_SHIFT:
+    {
+      const long k = j - a.p0;
+      return (k >= 0 && k < N) ? k : -1;
+    }
+    case MLGPU_ROWS_ROTATE:
+    {
+      long k = (j - a.p0) % N;
+      return k < 0 ? k + N : k;
+    }
+    default:  // MLGPU_ROWS_STRIDED
+    {
+      const long k = a.p0 + j * a.p1;
+      return (k >= 0 && k < N) ? k : -1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_map_kernel(const RowsMapArgs a)
+{
+  const size_t total = a.groups * a.count * 16;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+  {
+    const size_t q = i & 15, j = (i >> 4) % a.count, g = (i >> 4) / a.count;
+    const long s = rowsSource(a, (long)j);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s >= 0)
+    {
+      const float4* row = a.src + (g * a.srcRows + (size_t)s) * 16;
+      if (a.sampleRotate == 0)
+        v = row[q];
+      else
+      {
+        const float* f = (const float*)row;
+        const int n0 = (int)q * 4 + a.sampleRotate;
+        v.x = f[(n0 + 64) & 63];
+        v.y = f[(n0 + 65) & 63];
+        v.z = f[(n0 + 66) & 63];
+        v.w = f[(n0 + 67) & 63];
+      }
+    }
+    a.dst[(g * a.dstRows + a.dstOffset + j * a.dstStep) * 16 + q] = v;
+  }
+}
+
+// addRows, MLDSPOps.h:1349-1359: vy = 0; vy = vy + row_j for j = 0..ROWS-1 (left to right, starting from +0)
+__global__ __launch_bounds__(256) void rows_add_kernel(const float4* rows, float4* out, size_t rowsPerGroup, size_t groups)
+{
+  const size_t total = groups * 16;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+  {
+    const size_t q = i & 15, g = i >> 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t j = 0; j < rowsPerGroup; ++j)
+    {
+      const float4 x = rows[(g * rowsPerGroup + j) * 16 + q];
+      acc.x = acc.x + x.x;
+      acc.y = acc.y + x.y;
+      acc.z = acc.z + x.z;
+      acc.w = acc.w + x.w;
+    }
+    out[i] = acc;
+  }
+}
+
+// normalize, MLDSPOps.h:1041-1050: row / sum(row), sum in the reference's association order; one lane per row
+__global__ __launch_bounds__(256) void rows_normalize_kernel(const float4* rows, float4* out, size_t nRows)
+{
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nRows) return;
+  const float4* p = rows + r * 16;
+  float acc = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+  {
+    const float4 q = p[g];
+    const float t0 = q.x + q.z, t1 = q.y + q.w;
+    acc += (t0 + t1);
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+  {
+    const float4 q = p[g];
+    out[r * 16 + g] = make_float4(q.x / acc, q.y / acc, q.z / acc, q.w / acc);
+  }
+}
+
+// rowIndex<ROWS>(), MLDSPOps.h:1365-1374: row j of every group filled with (float)j
+__global__ __launch_bounds__(256) void rows_index_kernel(float4* out, size_t rowsPerGroup, size_t groups)
+{
+  const size_t total = groups * rowsPerGroup * 16;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+  {
+    const float j = (float)((i >> 4) % rowsPerGroup);
+    out[i] = make_float4(j, j, j, j);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// routing, MLDSPRouting.h:83-234: per-sample selection among N signals by a selector in [0, 1).
+// Scalar per sample in the reference ("TODO SIMD"); here one lane per element, N pointers in the args.
+struct RouteArgs
+{
+  const float* sel;
+  size_t selElems;  // selector index = i % selElems (64: one selector row for every row, as the reference)
+  const float* in[MLGPU_ROUTE_MAX];
+  float* out[MLGPU_ROUTE_MAX];
+  int n;
+  size_t nElems;
+};
+
+template <bool LINEAR>
+__global__ __launch_bounds__(256) void multiplex_kernel(const RouteArgs a)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nElems; i += stride)
+  {
+    const float s = a.sel[i % a.selElems];
+    float x[MLGPU_ROUTE_MAX];
+#pragma unroll
+    for (int k = 0; k < MLGPU_ROUTE_MAX; ++k) x[k] = (k < a.n) ? a.in[k][i] : 0.f;
+    a.out[0][i] = LINEAR ? route_multiplex_linear(s, x, a.n) : route_multiplex(s, x, a.n);
+  }
+}
+
+template <bool LINEAR>
+__global__ __launch_bounds__(256) void demultiplex_kernel(const RouteArgs a)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nElems; i += stride)
+  {
+    const float s = a.sel[i % a.selElems];
+    const float x = a.in[0][i];
+    for (int k = 0; k < a.n; ++k) a.out[k][i] = LINEAR ? route_demultiplex_linear(s, x, k, a.n) : route_demultiplex(s, x, k, a.n);
+  }
+}
 }  // namespace
 
 #define OP_CASE(OP) \
@@ -327,5 +492,78 @@ hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStrea
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(fill32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, value, n);
+  return hipGetLastError();
+}
+
+static unsigned gridFor(size_t items)
+{
+  size_t blocks = (items + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+hipError_t mlgpu_launch_rows_map(int rule, long p0, long p1, int sampleRotate, const float* src, size_t srcRows, float* dst,
+                                 size_t dstRows, size_t dstOffset, size_t dstStep, size_t count, size_t groups, hipStream_t stream)
+{
+  RowsMapArgs a;
+  a.src = (const float4*)src;
+  a.dst = (float4*)dst;
+  a.rule = rule;
+  a.p0 = p0;
+  a.p1 = p1;
+  a.sampleRotate = sampleRotate;
+  a.srcRows = srcRows;
+  a.dstRows = dstRows;
+  a.dstOffset = dstOffset;
+  a.dstStep = dstStep;
+  a.count = count;
+  a.groups = groups;
+  hipLaunchKernelGGL(rows_map_kernel, dim3(gridFor(groups * count * 16)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t mlgpu_launch_rows_add(const float* rows, size_t rowsPerGroup, float* out, size_t groups, hipStream_t stream)
+{
+  hipLaunchKernelGGL(rows_add_kernel, dim3(gridFor(groups * 16)), dim3(256), 0, stream, (const float4*)rows, (float4*)out, rowsPerGroup, groups);
+  return hipGetLastError();
+}
+
+hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRows, hipStream_t stream)
+{
+  hipLaunchKernelGGL(rows_normalize_kernel, dim3((unsigned)((nRows + 255) / 256)), dim3(256), 0, stream, (const float4*)rows, (float4*)out, nRows);
+  return hipGetLastError();
+}
+
+hipError_t mlgpu_launch_rows_index(float* out, size_t rowsPerGroup, size_t groups, hipStream_t stream)
+{
+  hipLaunchKernelGGL(rows_index_kernel, dim3(gridFor(groups * rowsPerGroup * 16)), dim3(256), 0, stream, (float4*)out, rowsPerGroup, groups);
+  return hipGetLastError();
+}
+
+hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,
+                              size_t nElems, hipStream_t stream)
+{
+  RouteArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sel = sel;
+  a.selElems = selElems;
+  a.n = n;
+  a.nElems = nElems;
+  if (demux)
+  {
+    a.in[0] = ins[0];
+    for (int k = 0; k < n; ++k) a.out[k] = outs[k];
+  }
+  else
+  {
+    for (int k = 0; k < n; ++k) a.in[k] = ins[k];
+    a.out[0] = outs[0];
+  }
+  const dim3 grid(gridFor(nElems));
+  if (demux && linear) hipLaunchKernelGGL(demultiplex_kernel<true>, grid, dim3(256), 0, stream, a);
+  else if (demux) hipLaunchKernelGGL(demultiplex_kernel<false>, grid, dim3(256), 0, stream, a);
+  else if (linear) hipLaunchKernelGGL(multiplex_kernel<true>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(multiplex_kernel<false>, grid, dim3(256), 0, stream, a);
   return hipGetLastError();
 }

@@ -1491,3 +1491,140 @@ void mlorc_sample_accurate_linear_glide_make_coeffs(float t, float* o) /* :527-5
   memcpy(&o[0], &n, 4);
   o[1] = 1.0f / n;
 }
+
+/* ------------------------------------------------------------------------- */
+/* row plumbing (MLDSPOps.h:1041-1374) and routing (MLDSPRouting.h:59-234)    */
+/*
+ * Same contracts as mlgpu_rows_map / rows_add / rows_normalize / rows_index / multiplex / demultiplex in
+ * include/mlgpu.h. The reference's functions are templates over compile-time row counts; tests compose these
+ * rule-based calls exactly as the host would (tests/rows_functions.py) and compare with the compiled
+ * reference's own repeatRows / stretchRows / ... instantiations (oracle/ref_wrapper.cpp: mlref_rows_case).
+ */
+static long rows_source(int rule, long p0, long p1, long N, long count, long j)
+{
+  long k;
+  switch (rule)
+  {
+    case MLGPU_ROWS_REPEAT: return j % N;                                          /* :1062-1066 */
+    case MLGPU_ROWS_STRETCH:                                                       /* :1080 */
+      return (count < 2) ? 0 : (long)roundf(((float)j * ((float)N - 1.f)) / ((float)count - 1.f));
+    case MLGPU_ROWS_SHIFT: k = j - p0; return (k >= 0 && k < N) ? k : -1;          /* :1107-1118, :1094-1098 */
+    case MLGPU_ROWS_ROTATE: k = (j - p0) % N; return k < 0 ? k + N : k;            /* :1132-1136 */
+    default: k = p0 + j * p1; return (k >= 0 && k < N) ? k : -1;                   /* separate/even/odd/concat/shuffle */
+  }
+}
+
+int mlorc_rows_map(int rule, long p0, long p1, int sample_rotate, const float* src, size_t src_rows, float* dst,
+                   size_t dst_rows, size_t dst_offset, size_t dst_step, size_t count, size_t groups)
+{
+  if (rule < MLGPU_ROWS_REPEAT || rule > MLGPU_ROWS_STRIDED || src_rows == 0) return MLGPU_ERR_INVALID;
+  for (size_t g = 0; g < groups; ++g)
+    for (size_t j = 0; j < count; ++j)
+    {
+      const long s = rows_source(rule, p0, p1, (long)src_rows, (long)count, (long)j);
+      float* y = dst + (g * dst_rows + dst_offset + j * dst_step) * VEC;
+      if (s < 0)
+      {
+        for (int n = 0; n < VEC; ++n) y[n] = 0.f;
+        continue;
+      }
+      const float* x = src + (g * src_rows + (size_t)s) * VEC;
+      /* rotateLeft: vecShuffleLeft(v1, v2) = {v1[1], v1[2], v1[3], v2[0]} :1219-1245; rotateRight the mirror image */
+      for (int n = 0; n < VEC; ++n) y[n] = x[(n + sample_rotate + VEC) % VEC];
+    }
+  return MLGPU_OK;
+}
+
+int mlorc_rows_add(const float* rows, size_t rows_per_group, float* out, size_t groups) /* :1349-1359 */
+{
+  for (size_t g = 0; g < groups; ++g)
+    for (int n = 0; n < VEC; ++n)
+    {
+      float acc = 0.f;
+      for (size_t j = 0; j < rows_per_group; ++j) acc = acc + rows[(g * rows_per_group + j) * VEC + n];
+      out[g * VEC + n] = acc;
+    }
+  return MLGPU_OK;
+}
+
+int mlorc_rows_normalize(const float* rows, float* out, size_t n_rows) /* :1041-1050, sum() :995-1005 */
+{
+  for (size_t r = 0; r < n_rows; ++r)
+  {
+    const float* x = rows + r * VEC;
+    float sum = 0.f;
+    for (int g = 0; g < 16; ++g)
+    {
+      const float t0 = x[4 * g] + x[4 * g + 2], t1 = x[4 * g + 1] + x[4 * g + 3];
+      sum += (t0 + t1);
+    }
+    for (int n = 0; n < VEC; ++n) out[r * VEC + n] = x[n] / sum;
+  }
+  return MLGPU_OK;
+}
+
+int mlorc_rows_index(float* out, size_t rows_per_group, size_t groups) /* :1365-1374 */
+{
+  for (size_t g = 0; g < groups; ++g)
+    for (size_t j = 0; j < rows_per_group; ++j)
+      for (int n = 0; n < VEC; ++n) out[(g * rows_per_group + j) * VEC + n] = (float)j;
+  return MLGPU_OK;
+}
+
+/* the reference converts a float to size_t; negative / NaN selectors are undefined there (documented: index 0) */
+static int route_index(float u, int n)
+{
+  const float r = u * (float)n;
+  const int i = (r >= 0.f && r < 2147483648.f) ? (int)r : 0;
+  return (i < n) ? i : 0;
+}
+
+int mlorc_multiplex(const float* sel, size_t sel_elems, const float* const* ins, int n, float* out, size_t n_elems, int linear)
+{
+  if (n < 1 || n > 8 || sel_elems == 0) return MLGPU_ERR_INVALID;
+  for (size_t i = 0; i < n_elems; ++i)
+  {
+    const float s = sel[i % sel_elems];
+    const float u = s - truncf(s);
+    if (!linear)
+      out[i] = ins[route_index(u, n)][i]; /* MLDSPRouting.h:94-101 */
+    else
+    { /* :122-133 */
+      const float real = u * (float)n;
+      const float ip = truncf(real);
+      const float frac = real - ip;
+      int i1 = (ip >= 0.f && ip < 2147483648.f) ? (int)ip : 0;
+      if (i1 >= n) i1 = 0;
+      const int i2 = (i1 + 1) % n;
+      const float a = ins[i1][i], b = ins[i2][i];
+      out[i] = a + frac * (b - a);
+    }
+  }
+  return MLGPU_OK;
+}
+
+int mlorc_demultiplex(const float* sel, size_t sel_elems, const float* in, float* const* outs, int n, size_t n_elems, int linear)
+{
+  if (n < 1 || n > 8 || sel_elems == 0) return MLGPU_ERR_INVALID;
+  for (size_t i = 0; i < n_elems; ++i)
+  {
+    const float s = sel[i % sel_elems];
+    const float u = s - truncf(s);
+    if (!linear)
+    { /* :151-173 */
+      const int idx = route_index(u, n);
+      for (int j = 0; j < n; ++j) outs[j][i] = (idx == j) ? in[i] : 0.f;
+    }
+    else
+    { /* :193-233 */
+      const float real = u * (float)n;
+      const float ip = truncf(real);
+      int i1 = (ip >= 0.f && ip < 2147483648.f) ? (int)ip : 0;
+      if (i1 >= n) i1 = 0;
+      const float m = real - ip;
+      const int i2 = (i1 + 1) % n;
+      for (int j = 0; j < n; ++j) outs[j][i] = (j == i1) ? in[i] * (1.f - m) : ((j == i2) ? in[i] * m : 0.f);
+    }
+  }
+  return MLGPU_OK;
+}

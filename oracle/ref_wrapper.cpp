@@ -1043,6 +1043,62 @@ extern "C"
     o[1] = g.mDyPerSample;
   }
 
+  // ---- row plumbing and routing: the reference's own templates at fixed sizes ----
+  // in[k] are DSPVectorArrays (row-major, as many rows as the case needs); out receives the result rows
+  // (for demultiplex cases: the outputs one after the other). Returns the number of output rows, < 0 if unknown.
+  int mlref_rows_case(const char* name, const float* const* in, float* out)
+  {
+    const std::string n(name);
+    auto ld = [&](auto& x, const float* p) { std::memcpy(x.getBuffer(), p, sizeof(float) * kFloatsPerDSPVector * (sizeof(x) / sizeof(DSPVector))); };
+    auto st = [&](const auto& y) {
+      const int rows = (int)(sizeof(y) / sizeof(DSPVector));
+      std::memcpy(out, y.getConstBuffer(), sizeof(float) * kFloatsPerDSPVector * rows);
+      return rows;
+    };
+    DSPVectorArray<1> a1; DSPVectorArray<2> a2; DSPVectorArray<3> a3; DSPVectorArray<4> a4; DSPVectorArray<5> a5; DSPVectorArray<6> a6;
+    if (n == "repeatRows<3>(2)") { ld(a2, in[0]); return st(repeatRows<3>(a2)); }
+    if (n == "stretchRows<7>(3)") { ld(a3, in[0]); return st(stretchRows<7>(a3)); }
+    if (n == "stretchRows<4>(6)") { ld(a6, in[0]); return st(stretchRows<4>(a6)); }
+    if (n == "zeroPadRows<5>(3)") { ld(a3, in[0]); return st(zeroPadRows<5>(a3)); }
+    if (n == "zeroPadRows<2>(3)") { ld(a3, in[0]); return st(zeroPadRows<2>(a3)); }
+    if (n == "shiftRows<5>(+2)") { ld(a5, in[0]); return st(shiftRows(a5, 2)); }
+    if (n == "shiftRows<5>(-1)") { ld(a5, in[0]); return st(shiftRows(a5, -1)); }
+    if (n == "rotateRows<5>(+2)") { ld(a5, in[0]); return st(rotateRows(a5, 2)); }
+    if (n == "rotateRows<5>(-7)") { ld(a5, in[0]); return st(rotateRows(a5, -7)); }
+    if (n == "concatRows(2,3)") { ld(a2, in[0]); ld(a3, in[1]); return st(concatRows(a2, a3)); }
+    if (n == "concatRows(1,2,3)") { ld(a1, in[0]); ld(a2, in[1]); ld(a3, in[2]); return st(concatRows(a1, a2, a3)); }
+    if (n == "concatRows(1,2,3,1)") { ld(a1, in[0]); ld(a2, in[1]); ld(a3, in[2]); DSPVectorArray<1> b1; ld(b1, in[3]); return st(concatRows(a1, a2, a3, b1)); }
+    if (n == "rotateLeft<3>") { ld(a3, in[0]); return st(rotateLeft(a3)); }
+    if (n == "rotateRight<3>") { ld(a3, in[0]); return st(rotateRight(a3)); }
+    if (n == "shuffleRows(2,4)") { ld(a2, in[0]); ld(a4, in[1]); return st(shuffleRows(a2, a4)); }
+    if (n == "shuffleRows(4,1)") { ld(a4, in[0]); ld(a1, in[1]); return st(shuffleRows(a4, a1)); }
+    if (n == "evenRows<5>") { ld(a5, in[0]); return st(evenRows(a5)); }
+    if (n == "oddRows<5>") { ld(a5, in[0]); return st(oddRows(a5)); }
+    if (n == "separateRows<1,4>(6)") { ld(a6, in[0]); return st(separateRows<1, 4>(a6)); }
+    if (n == "addRows<5>") { ld(a5, in[0]); return st(addRows(a5)); }
+    if (n == "rowIndex<4>") { return st(rowIndex<4>()); }
+    if (n == "columnIndex<3>") { return st(columnIndex<3>()); }
+    if (n == "normalize<3>") { ld(a3, in[0]); return st(normalize(a3)); }
+    // routing: in[0] = selector (1 row); signals have 2 rows
+    DSPVector sel;
+    DSPVectorArray<2> x0, x1, x2;
+    if (n == "multiplex(3)x2") { ld(sel, in[0]); ld(x0, in[1]); ld(x1, in[2]); ld(x2, in[3]); return st(multiplex(sel, x0, x1, x2)); }
+    if (n == "multiplexLinear(3)x2") { ld(sel, in[0]); ld(x0, in[1]); ld(x1, in[2]); ld(x2, in[3]); return st(multiplexLinear(sel, x0, x1, x2)); }
+    if (n == "demultiplex(3)x2" || n == "demultiplexLinear(3)x2")
+    {
+      ld(sel, in[0]); ld(x0, in[1]);
+      DSPVectorArray<2> o0, o1, o2;
+      if (n == "demultiplex(3)x2") demultiplex(sel, x0, &o0, &o1, &o2); else demultiplexLinear(sel, x0, &o0, &o1, &o2);
+      return st(concatRows(o0, o1, o2));
+    }
+    if (n == "mix(3)x2")  // gains: 3 rows; three 2-row inputs
+    {
+      ld(a3, in[0]); ld(x0, in[1]); ld(x1, in[2]); ld(x2, in[3]);
+      return st(mix(a3, x0, x1, x2));
+    }
+    return -1;
+  }
+
   // rangeClosed / rangeOpen helpers for the anchor tests
   void mlref_range_closed(float a, float b, float* out64) { store(rangeClosed(a, b), out64); }
   void mlref_range_open(float a, float b, float* out64) { store(rangeOpen(a, b), out64); }

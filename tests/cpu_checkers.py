@@ -221,6 +221,67 @@ class Oracle(_Checker):
         L.mlorc_chain_time.argtypes = [c_i32p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_u32p,
                                        c_f32p, c_f32p, c_f32p, ctypes.c_int]
 
+    # ---- row plumbing / routing: same signatures as madronalib_amd.Engine's host-convenience methods ----
+    def op_f32(self, op, a, b=None, c=None):
+        return self.op(op, a, b, c).view(np.float32)
+
+    def rows_map(self, rule, p0, p1, sample_rotate, src, src_rows, dst_rows, dst_offset, dst_step, count, groups, dst=None):
+        fnc = self.lib.mlorc_rows_map
+        fnc.restype = ctypes.c_int
+        sz, lg = ctypes.c_size_t, ctypes.c_long
+        fnc.argtypes = [ctypes.c_int, lg, lg, ctypes.c_int, c_f32p, sz, c_f32p, sz, sz, sz, sz, sz]
+        src = np.ascontiguousarray(src, np.float32).reshape(-1, 64)
+        if dst is None:
+            dst = np.zeros((groups * dst_rows, 64), np.float32)
+        dst = np.ascontiguousarray(dst, np.float32)
+        r = fnc(int(rule), int(p0), int(p1), int(sample_rotate), _ptr(src, c_f32p), src_rows, _ptr(dst, c_f32p), dst_rows,
+                dst_offset, dst_step, count, groups)
+        assert r == 0, r
+        return dst
+
+    def rows_add(self, rows, rows_per_group, groups):
+        fnc = self.lib.mlorc_rows_add
+        fnc.argtypes = [c_f32p, ctypes.c_size_t, c_f32p, ctypes.c_size_t]
+        rows = np.ascontiguousarray(rows, np.float32)
+        out = np.empty((groups, 64), np.float32)
+        assert fnc(_ptr(rows, c_f32p), rows_per_group, _ptr(out, c_f32p), groups) == 0
+        return out
+
+    def rows_normalize(self, rows):
+        fnc = self.lib.mlorc_rows_normalize
+        fnc.argtypes = [c_f32p, c_f32p, ctypes.c_size_t]
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 64)
+        out = np.empty_like(rows)
+        assert fnc(_ptr(rows, c_f32p), _ptr(out, c_f32p), rows.shape[0]) == 0
+        return out
+
+    def rows_index(self, rows_per_group, groups):
+        fnc = self.lib.mlorc_rows_index
+        fnc.argtypes = [c_f32p, ctypes.c_size_t, ctypes.c_size_t]
+        out = np.empty((groups * rows_per_group, 64), np.float32)
+        assert fnc(_ptr(out, c_f32p), rows_per_group, groups) == 0
+        return out
+
+    def multiplex(self, selector, inputs, linear=False):
+        fnc = self.lib.mlorc_multiplex
+        fnc.argtypes = [c_f32p, ctypes.c_size_t, ctypes.POINTER(c_f32p), ctypes.c_int, c_f32p, ctypes.c_size_t, ctypes.c_int]
+        sel = np.ascontiguousarray(selector, np.float32)
+        ins = [np.ascontiguousarray(x, np.float32) for x in inputs]
+        out = np.empty_like(ins[0])
+        arr = (c_f32p * len(ins))(*[_ptr(x, c_f32p) for x in ins])
+        assert fnc(_ptr(sel, c_f32p), sel.size, arr, len(ins), _ptr(out, c_f32p), out.size, 1 if linear else 0) == 0
+        return out
+
+    def demultiplex(self, selector, x, n_outputs, linear=False):
+        fnc = self.lib.mlorc_demultiplex
+        fnc.argtypes = [c_f32p, ctypes.c_size_t, c_f32p, ctypes.POINTER(c_f32p), ctypes.c_int, ctypes.c_size_t, ctypes.c_int]
+        sel = np.ascontiguousarray(selector, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        outs = [np.empty_like(x) for _ in range(n_outputs)]
+        arr = (c_f32p * n_outputs)(*[_ptr(o, c_f32p) for o in outs])
+        assert fnc(_ptr(sel, c_f32p), sel.size, _ptr(x, c_f32p), arr, n_outputs, x.size, 1 if linear else 0) == 0
+        return outs
+
     def libm_sinf(self, x):
         """The restated glibc sinf (oracle/ml_oracle.c) on an array."""
         self.lib.mlorc_libm_sinf.restype = ctypes.c_float
@@ -262,6 +323,19 @@ class Ref(_Checker):
         L.mlref_bench_lopass_cascade8.argtypes = [sz, sz, c_f32p, ctypes.c_int, c_f64p]
         L.mlref_bench_op.restype = ctypes.c_double
         L.mlref_bench_op.argtypes = [ctypes.c_int, c_f32p, c_f32p, sz, ctypes.c_int, ctypes.c_int]
+
+    def rows_case(self, name, inputs, max_rows=16):
+        """The reference's own row-plumbing / routing template instantiation called `name` (oracle/ref_wrapper.cpp:
+        mlref_rows_case). inputs: list of [rows][64] arrays. Returns the output rows [r][64]."""
+        fnc = self.lib.mlref_rows_case
+        fnc.restype = ctypes.c_int
+        fnc.argtypes = [ctypes.c_char_p, ctypes.POINTER(c_f32p), c_f32p]
+        ins = [np.ascontiguousarray(x, np.float32) for x in inputs]
+        arr = (c_f32p * max(1, len(ins)))(*[_ptr(x, c_f32p) for x in ins])
+        out = np.zeros((max_rows, 64), np.float32)
+        r = fnc(name.encode(), arr, _ptr(out, c_f32p))
+        assert r >= 0, name
+        return out[:r].copy()
 
     def bench_saw_bandpass_gain(self, V, T, freq, g0, g1, g2, gain, n_threads, out=None):
         sink = ctypes.c_double(0)

@@ -96,7 +96,16 @@ def main():
     for vop in (Vop.COLUMN_INDEX, Vop.RANGE_OPEN, Vop.RANGE_CLOSED, Vop.INTERPOLATE_LINEAR):
         d[f"vop{vop}_out"] = ref.vop(vop, V, T, np.repeat(d["vop_a"], 64, 1), np.repeat(d["vop_b"], 64, 1))
     np.savez_compressed(os.path.join(HERE, "multi.npz"), **d)
-    for f in ("ops.npz", "chains.npz", "multi.npz"):
+    # ---- row plumbing and routing: the reference's template instantiations of tests/rows_cases.py ----
+    from rows_cases import ROWS_CASES, case_inputs
+    d = {}
+    for name in ROWS_CASES:
+        ins = case_inputs(name)
+        for i, x in enumerate(ins):
+            d[f"{name}|in{i}"] = x
+        d[f"{name}|out"] = ref.rows_case(name, ins)
+    np.savez_compressed(os.path.join(HERE, "rows.npz"), **d)
+    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -29,6 +29,17 @@ def multi_golden_case(d, name):
                 out=[d[name + "_out1"], d[name + "_out2"]], state=[d[name + "_state1"], d[name + "_state2"]])
 
 
+def load_rows():
+    return np.load(os.path.join(HERE, "golden", "rows.npz"))
+
+
+def rows_golden_case(d, name):
+    ins = []
+    while f"{name}|in{len(ins)}" in d.files:
+        ins.append(d[f"{name}|in{len(ins)}"])
+    return ins, d[f"{name}|out"]
+
+
 def chain_case_names(d=None):
     d = d or load_chains()
     return sorted(k[:-6] for k in d.files if k.endswith("_procs"))

@@ -9,6 +9,9 @@ from golden_cases import (ANCHORS, chain_case, chain_case_names, hash31, load_ch
 from inputs import MULTI_CASES, assert_bits_equal, assert_rel_close, is_float_result, multi_inputs_audio
 from madronalib_amd.constants import Op, Proc, RowOp, Vop
 
+from golden_cases import load_rows, rows_golden_case  # noqa: E402
+from rows_cases import ROWS_CASES, run as run_rows_case  # noqa: E402
+
 HW_REL = 2.0 ** -11 * 1.5
 
 
@@ -80,6 +83,12 @@ def test_restated_libm_sinf_against_host_libm(oracle):
     n, lst = oracle.sinf_check(0, 0xFFFFFFFF)
     xs = np.abs(lst.view(np.float32))
     assert n <= 12 and ((xs > 53.0) & (xs < 120.0)).all(), (n, [hex(x) for x in lst])
+
+
+@pytest.mark.parametrize("name", list(ROWS_CASES))
+def test_row_plumbing_and_routing_golden(oracle, name):
+    ins, want = rows_golden_case(load_rows(), name)
+    assert_bits_equal(run_rows_case(oracle, name, ins), want, True, name)
 
 
 def test_impulse_table_golden(oracle):

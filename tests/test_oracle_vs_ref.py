@@ -145,3 +145,14 @@ def test_glide_coefficient_makers_match_reference(oracle, ref):
     for t in (0.0, 1.0, 63.9, 64.0, 100.0, 1000.0, 4096.0, 12345.6, -5.0):
         assert_bits_equal(oracle.make_coeffs("linear_glide", t), ref.make_coeffs("linear_glide", t), False, "LinearGlide")
         assert_bits_equal(oracle.make_coeffs("sample_glide", t), ref.make_coeffs("sample_glide", t), False, "SampleAccurate")
+
+
+from rows_cases import ROWS_CASES, case_inputs, run as run_rows_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(ROWS_CASES))
+def test_row_plumbing_and_routing_match_reference(oracle, ref, name):
+    """repeatRows ... separateRows, addRows, normalize, rowIndex, mix, (de)multiplex(Linear): the rule-based calls
+    composed as the host does == the reference's own template instantiations."""
+    ins = case_inputs(name)
+    assert_bits_equal(run_rows_case(oracle, name, ins), ref.rows_case(name, ins), True, name)
