@@ -419,6 +419,8 @@ int mlgpu_graph_compile(mlgpu_graph* g);
 /* The generated HIP source (valid after compile; for inspection). */
 const char* mlgpu_graph_source(mlgpu_graph* g);
 int mlgpu_graph_clear(mlgpu_graph* g); /* T::clear() on every processor node */
+int mlgpu_graph_clear_proc(mlgpu_graph* g, int proc_node); /* T::clear() on one processor node */
+int mlgpu_graph_set_state_uniform(mlgpu_graph* g, int proc_node, int state_idx, uint32_t value);
 int mlgpu_graph_set_param(mlgpu_graph* g, int param_node, const float* h_per_voice);
 int mlgpu_graph_set_param_uniform(mlgpu_graph* g, int param_node, float value);
 int mlgpu_graph_num_coeffs(mlgpu_graph* g, int proc_node);

@@ -1,0 +1,988 @@
+// mldsp.h (MI355X drop-in) — source-compatible shim of madronalib's `#include "mldsp.h"` functional surface.
+//
+// Put include/mlgpu/compat on the include path INSTEAD of the reference's include/ + source/DSP and existing
+// proc chains compile unchanged (reference include/mldsp.h:7-16; DSPVector value semantics MLDSPOps.h:94-361;
+// free functions MLDSPOps.h:570-1383; generators MLDSPGens.h; filters MLDSPFilters.h; Bank MLDSPFunctional.h:321).
+// The difference is WHEN the arithmetic happens: here a `DSPVector` is a handle to a node of a per-voice signal
+// graph. Running the user's process function ONCE records ("captures") the graph; ml::gpu::VoiceProgram then
+// compiles it into one fused gfx950 kernel (mlgpu_graph, include/mlgpu.h) and evaluates it for V voices x T
+// DSPVectors per launch, one wavefront lane per voice.
+//
+//   reference (1 voice, CPU, called once per 64 frames)          here (V voices, GPU)
+//   ----------------------------------------------------         -------------------------------------------------
+//   void proc(AudioContext* ctx, void* st) {                      same source, unchanged
+//     auto s = static_cast<State*>(st);
+//     ctx->outputs[0] = s->lp(s->saw(220.f/48000.f)) * 0.1f; }
+//   AudioTask task(&ctx, proc, &state); task.run...               ml::gpu::VoiceProgram prog(engine, V, &ctx, proc, &state);
+//                                                                 prog.process(T, {}, {&out});
+//
+// What can be captured: everything that is data flow on whole DSPVectors — operators, the DEFINE_OP* free
+// functions, compare/select, conversions, row plumbing, index generators, mix/multiplex, every generator and filter
+// object with its makeCoeffs / coeffs / clear() / operator() forms, Bank<T,ROWS>. What cannot: reading or writing
+// single samples on the host (`v[n]`, getBuffer(), sum()/mean()/max()/min() to float) — there is no data on the
+// host. Those members do not exist here, so such code fails to compile rather than silently doing something else.
+// Per-voice variation comes in through ml::gpu::VoiceParam (a per-voice constant), streamed inputs
+// (ctx->inputs[c]) and per-voice coefficients (VoiceProgram::setCoeff).
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <initializer_list>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../mlgpu.h"
+#include "../mldsp_gpu.hpp"
+
+namespace ml
+{
+constexpr size_t kFloatsPerDSPVector = MLGPU_FLOATS_PER_DSPVECTOR;
+constexpr float kPi = 3.1415926535897932384626433832795f;
+constexpr float kTwoPi = kPi * 2.f;
+
+namespace gpu
+{
+// ---- capture context ---------------------------------------------------------------------------------------
+struct Capture
+{
+  const Engine* eng{nullptr};
+  mlgpu_graph* g{nullptr};
+  std::map<uint32_t, int> constNodes;
+  struct Deferred
+  {
+    int node, what, idx;  // what: 0 coeff (float), 1 clear(), 2 state word
+    uint32_t bits;
+  };
+  std::vector<Deferred> deferred;
+
+  static Capture*& current()
+  {
+    static thread_local Capture* c = nullptr;
+    return c;
+  }
+  static Capture& get()
+  {
+    if (!current()) throw std::logic_error("mldsp GPU shim: DSPVector arithmetic outside ml::gpu::VoiceProgram capture");
+    return *current();
+  }
+  int ret(int r) const
+  {
+    if (r < 0) throw Error(-r, std::string("mlgpu_graph: ") + mlgpu_last_error(eng->handle()));
+    return r;
+  }
+  int constant(float f)
+  {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    auto it = constNodes.find(u);
+    if (it != constNodes.end()) return it->second;
+    return constNodes[u] = ret(mlgpu_graph_add_const(g, f));
+  }
+  void deferCoeff(int node, int idx, float v)
+  {
+    Deferred d{node, 0, idx, 0};
+    std::memcpy(&d.bits, &v, 4);
+    deferred.push_back(d);
+  }
+  void deferClear(int node) { deferred.push_back(Deferred{node, 1, 0, 0}); }
+  void deferState(int node, int idx, uint32_t bits) { deferred.push_back(Deferred{node, 2, idx, bits}); }
+};
+
+// one row of a DSPVectorArray: a graph node, or a float literal not yet materialised
+struct Sig
+{
+  int node{-1};
+  float lit{0.f};
+  int id() const { return node >= 0 ? node : Capture::get().constant(lit); }
+};
+
+inline Sig opNode(int op, std::initializer_list<Sig> in)
+{
+  Capture& c = Capture::get();
+  int ids[3];
+  int n = 0;
+  for (const Sig& s : in) ids[n++] = s.id();
+  return Sig{c.ret(mlgpu_graph_add_op(c.g, op, ids, n, nullptr)), 0.f};
+}
+inline Sig vopNode(int vop, std::initializer_list<Sig> in)
+{
+  Capture& c = Capture::get();
+  int ids[2];
+  int n = 0;
+  for (const Sig& s : in) ids[n++] = s.id();
+  return Sig{c.ret(mlgpu_graph_add_vop(c.g, vop, ids, n, nullptr)), 0.f};
+}
+}  // namespace gpu
+
+// ---- DSPVectorArray<ROWS>, DSPVector, DSPVectorArrayInt<ROWS> (MLDSPOps.h:94-498) -------------------------------
+
+template <size_t ROWS>
+class DSPVectorArray;
+template <size_t ROWS>
+DSPVectorArray<ROWS> add(const DSPVectorArray<ROWS>&, const DSPVectorArray<ROWS>&);
+template <size_t ROWS>
+DSPVectorArray<ROWS> subtract(const DSPVectorArray<ROWS>&, const DSPVectorArray<ROWS>&);
+template <size_t ROWS>
+DSPVectorArray<ROWS> multiply(const DSPVectorArray<ROWS>&, const DSPVectorArray<ROWS>&);
+template <size_t ROWS>
+DSPVectorArray<ROWS> divide(const DSPVectorArray<ROWS>&, const DSPVectorArray<ROWS>&);
+
+template <size_t ROWS>
+class DSPVectorArray
+{
+ public:
+  std::array<gpu::Sig, ROWS> sig_;  // implementation detail of the shim
+
+  DSPVectorArray() {}  // zero-filled, MLDSPOps.h:153
+  DSPVectorArray(float k)  // broadcast conversion ctor, MLDSPOps.h:157
+  {
+    for (auto& s : sig_) s = gpu::Sig{-1, k};
+  }
+  explicit DSPVectorArray(gpu::Sig s)
+  {
+    static_assert(ROWS == 1, "a single signal is a DSPVector");
+    sig_[0] = s;
+  }
+  DSPVectorArray& operator=(float k)
+  {
+    for (auto& s : sig_) s = gpu::Sig{-1, k};
+    return *this;
+  }
+
+  DSPVectorArray<1>& row(int j) { return *reinterpret_cast<DSPVectorArray<1>*>(&sig_[j]); }
+  const DSPVectorArray<1>& constRow(int j) const { return *reinterpret_cast<const DSPVectorArray<1>*>(&sig_[j]); }
+  DSPVectorArray<1> getRowVectorUnchecked(size_t j) const { return constRow((int)j); }
+  void setRowVectorUnchecked(size_t j, const DSPVectorArray<1> x) { row((int)j) = x; }
+  template <int J>
+  DSPVectorArray<1> getRowVector() const
+  {
+    static_assert((J >= 0) && (J < (int)ROWS), "getRowVector index out of bounds");
+    return constRow(J);
+  }
+  template <int J>
+  void setRowVector(const DSPVectorArray<1> x)
+  {
+    static_assert((J >= 0) && (J < (int)ROWS), "setRowVector index out of bounds");
+    row(J) = x;
+  }
+
+  DSPVectorArray& operator+=(const DSPVectorArray& x) { return *this = add(*this, x); }
+  DSPVectorArray& operator-=(const DSPVectorArray& x) { return *this = subtract(*this, x); }
+  DSPVectorArray& operator*=(const DSPVectorArray& x) { return *this = multiply(*this, x); }
+  DSPVectorArray& operator/=(const DSPVectorArray& x) { return *this = divide(*this, x); }
+  // in-class friends so either operand converts implicitly from float (MLDSPOps.h:333-352)
+  friend DSPVectorArray operator+(const DSPVectorArray& a, const DSPVectorArray& b) { return add(a, b); }
+  friend DSPVectorArray operator-(const DSPVectorArray& a, const DSPVectorArray& b) { return subtract(a, b); }
+  friend DSPVectorArray operator*(const DSPVectorArray& a, const DSPVectorArray& b) { return multiply(a, b); }
+  friend DSPVectorArray operator/(const DSPVectorArray& a, const DSPVectorArray& b) { return divide(a, b); }
+};
+typedef DSPVectorArray<1> DSPVector;
+
+template <size_t ROWS>
+class DSPVectorArrayInt  // int32 masks / integers travel as bit patterns (MLDSPOps.h:370-498)
+{
+ public:
+  std::array<gpu::Sig, ROWS> sig_;
+  DSPVectorArrayInt() {}
+};
+typedef DSPVectorArrayInt<1> DSPVectorInt;
+
+class DSPVectorDynamic final  // MLDSPOps.h:503-517
+{
+ public:
+  DSPVectorDynamic() = default;
+  explicit DSPVectorDynamic(size_t rows) { data_.resize(rows); }
+  void resize(size_t rows) { data_.resize(rows); }
+  size_t size() const { return data_.size(); }
+  DSPVector& operator[](int j) { return data_[j]; }
+  const DSPVector& operator[](int j) const { return data_[j]; }
+
+ private:
+  std::vector<DSPVector> data_;
+};
+
+// ---- the DEFINE_OP* families (MLDSPOps.h:570-936) -----------------------------------------------------------------
+
+#define MLGPU_SHIM_OP1(name, OP)                                       \
+  template <size_t ROWS>                                               \
+  inline DSPVectorArray<ROWS> name(const DSPVectorArray<ROWS>& a)      \
+  {                                                                    \
+    DSPVectorArray<ROWS> y;                                            \
+    for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(OP, {a.sig_[j]}); \
+    return y;                                                          \
+  }
+MLGPU_SHIM_OP1(sqrt, MLGPU_OP_SQRT)
+MLGPU_SHIM_OP1(sqrtApprox, MLGPU_OP_SQRT_APPROX)
+MLGPU_SHIM_OP1(abs, MLGPU_OP_ABS)
+MLGPU_SHIM_OP1(sign, MLGPU_OP_SIGN)
+MLGPU_SHIM_OP1(signBit, MLGPU_OP_SIGN_BIT)
+MLGPU_SHIM_OP1(sin, MLGPU_OP_SIN)
+MLGPU_SHIM_OP1(cos, MLGPU_OP_COS)
+MLGPU_SHIM_OP1(log, MLGPU_OP_LOG)
+MLGPU_SHIM_OP1(exp, MLGPU_OP_EXP)
+MLGPU_SHIM_OP1(log2, MLGPU_OP_LOG2)
+MLGPU_SHIM_OP1(exp2, MLGPU_OP_EXP2)
+MLGPU_SHIM_OP1(sinApprox, MLGPU_OP_SIN_APPROX)
+MLGPU_SHIM_OP1(cosApprox, MLGPU_OP_COS_APPROX)
+MLGPU_SHIM_OP1(expApprox, MLGPU_OP_EXP_APPROX)
+MLGPU_SHIM_OP1(logApprox, MLGPU_OP_LOG_APPROX)
+MLGPU_SHIM_OP1(log2Approx, MLGPU_OP_LOG2_APPROX)
+MLGPU_SHIM_OP1(exp2Approx, MLGPU_OP_EXP2_APPROX)
+MLGPU_SHIM_OP1(fractionalPart, MLGPU_OP_FRACTIONAL_PART)
+
+#define MLGPU_SHIM_OP2(name, OP)                                                                      \
+  template <size_t ROWS>                                                                              \
+  inline DSPVectorArray<ROWS> name(const DSPVectorArray<ROWS>& a, const DSPVectorArray<ROWS>& b)      \
+  {                                                                                                   \
+    DSPVectorArray<ROWS> y;                                                                           \
+    for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(OP, {a.sig_[j], b.sig_[j]});            \
+    return y;                                                                                         \
+  }
+MLGPU_SHIM_OP2(add, MLGPU_OP_ADD)
+MLGPU_SHIM_OP2(subtract, MLGPU_OP_SUBTRACT)
+MLGPU_SHIM_OP2(multiply, MLGPU_OP_MULTIPLY)
+MLGPU_SHIM_OP2(divide, MLGPU_OP_DIVIDE)
+MLGPU_SHIM_OP2(divideApprox, MLGPU_OP_DIVIDE_APPROX)
+MLGPU_SHIM_OP2(pow, MLGPU_OP_POW)
+MLGPU_SHIM_OP2(powApprox, MLGPU_OP_POW_APPROX)
+MLGPU_SHIM_OP2(min, MLGPU_OP_MIN)
+MLGPU_SHIM_OP2(max, MLGPU_OP_MAX)
+
+// ROWS x 1-row broadcast forms add1..max1 (MLDSPOps.h:655-687)
+#define MLGPU_SHIM_OP2_1(name, OP)                                                                \
+  template <size_t ROWS>                                                                          \
+  inline DSPVectorArray<ROWS> name(const DSPVectorArray<ROWS>& a, const DSPVectorArray<1>& b)     \
+  {                                                                                               \
+    DSPVectorArray<ROWS> y;                                                                       \
+    for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(OP, {a.sig_[j], b.sig_[0]});        \
+    return y;                                                                                     \
+  }
+MLGPU_SHIM_OP2_1(add1, MLGPU_OP_ADD)
+MLGPU_SHIM_OP2_1(subtract1, MLGPU_OP_SUBTRACT)
+MLGPU_SHIM_OP2_1(multiply1, MLGPU_OP_MULTIPLY)
+MLGPU_SHIM_OP2_1(divide1, MLGPU_OP_DIVIDE)
+MLGPU_SHIM_OP2_1(divideApprox1, MLGPU_OP_DIVIDE_APPROX)
+MLGPU_SHIM_OP2_1(pow1, MLGPU_OP_POW)
+MLGPU_SHIM_OP2_1(powApprox1, MLGPU_OP_POW_APPROX)
+MLGPU_SHIM_OP2_1(min1, MLGPU_OP_MIN)
+MLGPU_SHIM_OP2_1(max1, MLGPU_OP_MAX)
+
+#define MLGPU_SHIM_OP3(name, OP)                                                                              \
+  template <size_t ROWS>                                                                                      \
+  inline DSPVectorArray<ROWS> name(const DSPVectorArray<ROWS>& a, const DSPVectorArray<ROWS>& b,              \
+                                   const DSPVectorArray<ROWS>& c)                                             \
+  {                                                                                                           \
+    DSPVectorArray<ROWS> y;                                                                                   \
+    for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(OP, {a.sig_[j], b.sig_[j], c.sig_[j]});         \
+    return y;                                                                                                 \
+  }
+MLGPU_SHIM_OP3(lerp, MLGPU_OP_LERP)                // lerp(a, b, mix)
+MLGPU_SHIM_OP3(inverseLerp, MLGPU_OP_INVERSE_LERP) // inverseLerp(a, b, x)
+MLGPU_SHIM_OP3(clamp, MLGPU_OP_CLAMP)              // clamp(x, lo, hi)
+
+template <size_t ROWS>  // lerp with a float mix, MLDSPOps.h:753-774
+inline DSPVectorArray<ROWS> lerp(const DSPVectorArray<ROWS>& a, const DSPVectorArray<ROWS>& b, float m)
+{
+  return lerp(a, b, DSPVectorArray<ROWS>(m));
+}
+
+template <size_t ROWS>  // within(x, lo, hi) -> mask, MLDSPOps.h:748
+inline DSPVectorArrayInt<ROWS> within(const DSPVectorArray<ROWS>& x, const DSPVectorArray<ROWS>& lo, const DSPVectorArray<ROWS>& hi)
+{
+  DSPVectorArrayInt<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(MLGPU_OP_WITHIN, {x.sig_[j], lo.sig_[j], hi.sig_[j]});
+  return y;
+}
+
+#define MLGPU_SHIM_CMP(name, OP)                                                                        \
+  template <size_t ROWS>                                                                                \
+  inline DSPVectorArrayInt<ROWS> name(const DSPVectorArray<ROWS>& a, const DSPVectorArray<ROWS>& b)     \
+  {                                                                                                     \
+    DSPVectorArrayInt<ROWS> y;                                                                          \
+    for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(OP, {a.sig_[j], b.sig_[j]});              \
+    return y;                                                                                           \
+  }
+MLGPU_SHIM_CMP(equal, MLGPU_OP_EQUAL)
+MLGPU_SHIM_CMP(notEqual, MLGPU_OP_NOT_EQUAL)
+MLGPU_SHIM_CMP(greaterThan, MLGPU_OP_GREATER_THAN)
+MLGPU_SHIM_CMP(greaterThanOrEqual, MLGPU_OP_GREATER_THAN_OR_EQUAL)
+MLGPU_SHIM_CMP(lessThan, MLGPU_OP_LESS_THAN)
+MLGPU_SHIM_CMP(lessThanOrEqual, MLGPU_OP_LESS_THAN_OR_EQUAL)
+
+template <size_t ROWS>  // select(a, b, mask): bitwise, MLDSPOps.h:886
+inline DSPVectorArray<ROWS> select(const DSPVectorArray<ROWS>& a, const DSPVectorArray<ROWS>& b, const DSPVectorArrayInt<ROWS>& m)
+{
+  DSPVectorArray<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(MLGPU_OP_SELECT, {a.sig_[j], b.sig_[j], m.sig_[j]});
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArrayInt<ROWS> select(const DSPVectorArrayInt<ROWS>& a, const DSPVectorArrayInt<ROWS>& b, const DSPVectorArrayInt<ROWS>& m)
+{
+  DSPVectorArrayInt<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(MLGPU_OP_SELECT_INT, {a.sig_[j], b.sig_[j], m.sig_[j]});
+  return y;
+}
+
+#define MLGPU_SHIM_CONV(name, OP, FROM, TO)                       \
+  template <size_t ROWS>                                          \
+  inline TO<ROWS> name(const FROM<ROWS>& a)                       \
+  {                                                               \
+    TO<ROWS> y;                                                   \
+    for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(OP, {a.sig_[j]}); \
+    return y;                                                     \
+  }
+MLGPU_SHIM_CONV(roundFloatToInt, MLGPU_OP_ROUND_FLOAT_TO_INT, DSPVectorArray, DSPVectorArrayInt)
+MLGPU_SHIM_CONV(truncateFloatToInt, MLGPU_OP_TRUNCATE_FLOAT_TO_INT, DSPVectorArray, DSPVectorArrayInt)
+MLGPU_SHIM_CONV(intToFloat, MLGPU_OP_INT_TO_FLOAT, DSPVectorArrayInt, DSPVectorArray)
+MLGPU_SHIM_CONV(unsignedIntToFloat, MLGPU_OP_UNSIGNED_INT_TO_FLOAT, DSPVectorArrayInt, DSPVectorArray)
+
+template <size_t ROWS>
+inline DSPVectorArrayInt<ROWS> addInt32(const DSPVectorArrayInt<ROWS>& a, const DSPVectorArrayInt<ROWS>& b)
+{
+  DSPVectorArrayInt<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(MLGPU_OP_ADD_INT32, {a.sig_[j], b.sig_[j]});
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArrayInt<ROWS> subtractInt32(const DSPVectorArrayInt<ROWS>& a, const DSPVectorArrayInt<ROWS>& b)
+{
+  DSPVectorArrayInt<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(MLGPU_OP_SUBTRACT_INT32, {a.sig_[j], b.sig_[j]});
+  return y;
+}
+
+// n-ary add, right fold a + (b + (c + ...)), MLDSPOps.h:925-936
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> add(const DSPVectorArray<ROWS>& a)
+{
+  return a;
+}
+template <size_t ROWS, typename... Args>
+inline DSPVectorArray<ROWS> add(const DSPVectorArray<ROWS>& first, const DSPVectorArray<ROWS>& second, const DSPVectorArray<ROWS>& third,
+                                Args... args)
+{
+  return add(first, add(second, third, args...));
+}
+
+// ---- index generators (MLDSPOps.h:962-990, 1365-1383) ---------------------------------------------------------------
+inline DSPVector columnIndex() { return DSPVector(gpu::vopNode(MLGPU_VOP_COLUMN_INDEX, {})); }
+inline DSPVector rangeOpen(float start, float end) { return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_OPEN, {gpu::Sig{-1, start}, gpu::Sig{-1, end}})); }
+inline DSPVector rangeClosed(float start, float end)
+{
+  return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_CLOSED, {gpu::Sig{-1, start}, gpu::Sig{-1, end}}));
+}
+inline DSPVector interpolateDSPVectorLinear(float start, float end)
+{
+  return DSPVector(gpu::vopNode(MLGPU_VOP_INTERPOLATE_LINEAR, {gpu::Sig{-1, start}, gpu::Sig{-1, end}}));
+}
+
+// ---- row plumbing (MLDSPOps.h:1057-1383): with rows as separate signals this is wiring, no arithmetic ---------------
+template <size_t ROWS, size_t N>
+inline DSPVectorArray<ROWS * N> repeatRows(const DSPVectorArray<N>& x)
+{
+  DSPVectorArray<ROWS * N> y;
+  for (size_t j = 0, k = 0; j < ROWS * N; ++j)
+  {
+    y.sig_[j] = x.sig_[k];
+    if (++k >= N) k = 0;
+  }
+  return y;
+}
+template <size_t ROWS, size_t N>
+inline DSPVectorArray<ROWS> stretchRows(const DSPVectorArray<N>& x)
+{
+  DSPVectorArray<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = x.sig_[(size_t)roundf((j * (N - 1.f)) / (ROWS - 1.f))];
+  return y;
+}
+template <size_t ROWS, size_t N>
+inline DSPVectorArray<ROWS> zeroPadRows(const DSPVectorArray<N>& x)
+{
+  DSPVectorArray<ROWS> y;
+  for (size_t j = 0; j < (ROWS < N ? ROWS : N); ++j) y.sig_[j] = x.sig_[j];
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> shiftRows(const DSPVectorArray<ROWS>& x, int rowsToShift)
+{
+  DSPVectorArray<ROWS> y;
+  int k = -rowsToShift;
+  for (size_t j = 0; j < ROWS; ++j, ++k)
+    if (k >= 0 && k < (int)ROWS) y.sig_[j] = x.sig_[k];
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> rotateRows(const DSPVectorArray<ROWS>& x, int rowsToRotate)
+{
+  DSPVectorArray<ROWS> y;
+  int k = (-rowsToRotate) % (int)ROWS;
+  if (k < 0) k += (int)ROWS;
+  for (size_t j = 0; j < ROWS; ++j)
+  {
+    y.sig_[j] = x.sig_[k];
+    if (++k >= (int)ROWS) k = 0;
+  }
+  return y;
+}
+template <size_t ROWSA, size_t ROWSB>
+inline DSPVectorArray<ROWSA + ROWSB> concatRows(const DSPVectorArray<ROWSA>& a, const DSPVectorArray<ROWSB>& b)
+{
+  DSPVectorArray<ROWSA + ROWSB> y;
+  for (size_t j = 0; j < ROWSA; ++j) y.sig_[j] = a.sig_[j];
+  for (size_t j = 0; j < ROWSB; ++j) y.sig_[ROWSA + j] = b.sig_[j];
+  return y;
+}
+template <size_t ROWSA, size_t ROWSB, size_t ROWSC>
+inline DSPVectorArray<ROWSA + ROWSB + ROWSC> concatRows(const DSPVectorArray<ROWSA>& a, const DSPVectorArray<ROWSB>& b, const DSPVectorArray<ROWSC>& c)
+{
+  return concatRows(concatRows(a, b), c);
+}
+template <size_t ROWSA, size_t ROWSB, size_t ROWSC, size_t ROWSD>
+inline DSPVectorArray<ROWSA + ROWSB + ROWSC + ROWSD> concatRows(const DSPVectorArray<ROWSA>& a, const DSPVectorArray<ROWSB>& b,
+                                                                const DSPVectorArray<ROWSC>& c, const DSPVectorArray<ROWSD>& d)
+{
+  return concatRows(concatRows(a, b, c), d);
+}
+template <size_t ROWSA, size_t ROWSB>
+inline DSPVectorArray<ROWSA + ROWSB> shuffleRows(const DSPVectorArray<ROWSA> a, const DSPVectorArray<ROWSB> b)
+{
+  DSPVectorArray<ROWSA + ROWSB> y;
+  size_t ja = 0, jb = 0, jy = 0;
+  while ((ja < ROWSA) || (jb < ROWSB))
+  {
+    if (ja < ROWSA) y.sig_[jy++] = a.sig_[ja++];
+    if (jb < ROWSB) y.sig_[jy++] = b.sig_[jb++];
+  }
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<(ROWS + 1) / 2> evenRows(const DSPVectorArray<ROWS>& x)
+{
+  DSPVectorArray<(ROWS + 1) / 2> y;
+  for (size_t j = 0; j < (ROWS + 1) / 2; ++j) y.sig_[j] = x.sig_[j * 2];
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS / 2> oddRows(const DSPVectorArray<ROWS>& x)
+{
+  DSPVectorArray<ROWS / 2> y;
+  for (size_t j = 0; j < ROWS / 2; ++j) y.sig_[j] = x.sig_[j * 2 + 1];
+  return y;
+}
+template <size_t A, size_t B, size_t ROWS>
+inline DSPVectorArray<B - A> separateRows(const DSPVectorArray<ROWS>& x)
+{
+  static_assert(B <= ROWS, "separateRows: range out of bounds");
+  DSPVectorArray<B - A> y;
+  for (size_t j = A; j < B; ++j) y.sig_[j - A] = x.sig_[j];
+  return y;
+}
+template <size_t ROWS>
+inline DSPVector addRows(const DSPVectorArray<ROWS>& x)  // vy = 0; vy = vy + row j
+{
+  DSPVector y{0.f};
+  for (size_t j = 0; j < ROWS; ++j) y = add(y, x.constRow((int)j));
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> rowIndex()
+{
+  DSPVectorArray<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.row((int)j) = DSPVector((float)j);
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> columnIndex()
+{
+  return repeatRows<ROWS>(columnIndex());
+}
+
+// ---- routing (MLDSPRouting.h:59-137) ---------------------------------------------------------------------------
+template <size_t ROWS, size_t INPUTS>
+inline DSPVectorArray<ROWS> mix_n(size_t inputIndex, DSPVectorArray<INPUTS> gains, DSPVectorArray<ROWS> first)
+{
+  return first * repeatRows<ROWS>(gains.getRowVectorUnchecked(inputIndex));
+}
+template <size_t ROWS, size_t INPUTS, typename... Args>
+inline DSPVectorArray<ROWS> mix_n(size_t inputIndex, DSPVectorArray<INPUTS> gains, DSPVectorArray<ROWS> first, Args... args)
+{
+  return first * repeatRows<ROWS>(gains.getRowVectorUnchecked(inputIndex)) + mix_n(inputIndex + 1, gains, args...);
+}
+template <size_t ROWS, size_t INPUTS, typename... Args>
+inline DSPVectorArray<ROWS> mix(DSPVectorArray<INPUTS> gains, DSPVectorArray<ROWS> first, Args... args)
+{
+  return mix_n(0, gains, first, args...);
+}
+namespace gpu
+{
+template <size_t ROWS, typename... Args>
+inline DSPVectorArray<ROWS> routeMux(int route, DSPVector selector, DSPVectorArray<ROWS> first, Args... args)
+{
+  const DSPVectorArray<ROWS> inputs[]{first, args...};
+  constexpr int n = sizeof...(Args) + 1;
+  static_assert(n <= MLGPU_ROUTE_MAX_SIGNALS, "multiplex: at most 8 inputs");
+  Capture& c = Capture::get();
+  DSPVectorArray<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j)
+  {
+    int ids[1 + MLGPU_ROUTE_MAX_SIGNALS];
+    ids[0] = selector.sig_[0].id();
+    for (int k = 0; k < n; ++k) ids[1 + k] = inputs[k].sig_[j].id();
+    y.sig_[j] = Sig{c.ret(mlgpu_graph_add_route(c.g, route, ids, 1 + n, 0, 0, nullptr)), 0.f};
+  }
+  return y;
+}
+}  // namespace gpu
+template <size_t ROWS, typename... Args>
+inline DSPVectorArray<ROWS> multiplex(DSPVector selector, DSPVectorArray<ROWS> first, Args... args)
+{
+  return gpu::routeMux(MLGPU_ROUTE_MULTIPLEX, selector, first, args...);
+}
+template <size_t ROWS, typename... Args>
+inline DSPVectorArray<ROWS> multiplexLinear(DSPVector selector, DSPVectorArray<ROWS> first, Args... args)
+{
+  return gpu::routeMux(MLGPU_ROUTE_MULTIPLEX_LINEAR, selector, first, args...);
+}
+
+// ---- stateful objects ----------------------------------------------------------------------------------------------
+namespace gpu
+{
+// A reference functor becomes ONE processor node the first time its operator() runs inside a capture. Its `coeffs`
+// (a plain public member, as in the reference) are recorded as the node's initial, uniform coefficients; per-voice
+// values are set afterwards with VoiceProgram::setCoeff(object, ...).
+template <int KIND>
+struct ProcNode
+{
+  int node_{-1};
+  bool cleared_{false};
+  uint32_t initState0_{0};
+  bool hasInitState0_{false};
+
+  Sig emit(std::initializer_list<Sig> ins, const float* coeffs, int nc)
+  {
+    Capture& c = Capture::get();
+    if (node_ >= 0)
+      throw std::logic_error("mldsp GPU shim: a stateful object was called twice in one process function (one call = one state update)");
+    int ids[8];
+    int n = 0;
+    for (const Sig& s : ins) ids[n++] = s.id();
+    node_ = c.ret(mlgpu_graph_add_proc(c.g, KIND, ids, n, nullptr));
+    for (int i = 0; i < nc; ++i) c.deferCoeff(node_, i, coeffs[i]);
+    if (cleared_) c.deferClear(node_);
+    if (hasInitState0_) c.deferState(node_, 0, initState0_);
+    return Sig{node_, 0.f};
+  }
+  int node() const { return node_; }
+};
+inline float bitsOf(int32_t i)
+{
+  float f;
+  std::memcpy(&f, &i, 4);
+  return f;
+}
+}  // namespace gpu
+
+// generators, MLDSPGens.h
+class TickGen : public gpu::ProcNode<MLGPU_PROC_TICK_GEN>
+{
+ public:
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector cyclesPerSample) { return DSPVector(emit({cyclesPerSample.sig_[0]}, nullptr, 0)); }
+};
+class ImpulseGen : public gpu::ProcNode<MLGPU_PROC_IMPULSE_GEN>
+{
+ public:
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector cyclesPerSample) { return DSPVector(emit({cyclesPerSample.sig_[0]}, nullptr, 0)); }
+};
+class NoiseGen : public gpu::ProcNode<MLGPU_PROC_NOISE_GEN>
+{
+ public:
+  void reset() { seed(0); }
+  void seed(uint32_t s)  // per-voice seeds: VoiceProgram::setState(noise, 0, seeds)
+  {
+    initState0_ = s;
+    hasInitState0_ = true;
+  }
+  DSPVector operator()() { return DSPVector(emit({}, nullptr, 0)); }
+};
+class PhasorGen : public gpu::ProcNode<MLGPU_PROC_PHASOR_GEN>
+{
+ public:
+  void clear(uint32_t omega = 0)
+  {
+    initState0_ = omega;
+    hasInitState0_ = true;
+  }
+  DSPVector operator()(const DSPVector cyclesPerSample) { return DSPVector(emit({cyclesPerSample.sig_[0]}, nullptr, 0)); }
+};
+class OneShotGen : public gpu::ProcNode<MLGPU_PROC_ONE_SHOT_GEN>
+{
+ public:
+  DSPVector operator()(const DSPVector cyclesPerSample) { return DSPVector(emit({cyclesPerSample.sig_[0]}, nullptr, 0)); }
+};
+class SineGen : public gpu::ProcNode<MLGPU_PROC_SINE_GEN>
+{
+ public:
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector freq) { return DSPVector(emit({freq.sig_[0]}, nullptr, 0)); }
+};
+class SawGen : public gpu::ProcNode<MLGPU_PROC_SAW_GEN>
+{
+ public:
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector freq) { return DSPVector(emit({freq.sig_[0]}, nullptr, 0)); }
+};
+class PulseGen : public gpu::ProcNode<MLGPU_PROC_PULSE_GEN>
+{
+ public:
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector freq, const DSPVector width)
+  {
+    const float w = 0.5f;
+    return DSPVector(emit({freq.sig_[0], width.sig_[0]}, &w, 1));
+  }
+};
+class SampleAccurateLinearGlide : public gpu::ProcNode<MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE>
+{
+  float c_[2]{gpu::bitsOf(32), 1.f / 32};
+
+ public:
+  void setGlideTimeInSamples(float t) { mlgpu_sample_accurate_linear_glide_make_coeffs(t, c_); }
+  void clear() { cleared_ = true; }
+  // the reference's nextSample(float) once per sample == one audio-rate input here
+  DSPVector operator()(const DSPVector target) { return DSPVector(emit({target.sig_[0]}, c_, 2)); }
+};
+class LinearGlide : public gpu::ProcNode<MLGPU_PROC_LINEAR_GLIDE>
+{
+  float c_[2]{gpu::bitsOf(32), 1.f / 32};
+
+ public:
+  void setGlideTimeInSamples(float t) { mlgpu_linear_glide_make_coeffs(t, c_); }
+  void clear() { cleared_ = true; }
+  // `f` is one float per DSPVector: a constant here, or a gpu::VoiceParam / control converted to DSPVector
+  DSPVector operator()(const DSPVector f) { return DSPVector(emit({f.sig_[0]}, c_, 2)); }
+};
+struct Interpolator1 : public gpu::ProcNode<MLGPU_PROC_INTERPOLATOR1>
+{
+  DSPVector operator()(const DSPVector f) { return DSPVector(emit({f.sig_[0]}, nullptr, 0)); }
+};
+
+// filters, MLDSPFilters.h
+inline float dBToGain(float dB) { return mlgpu_db_to_gain(dB); }
+
+template <size_t COEFFS_SIZE>  // MLDSPFilters.h:34-44
+inline DSPVectorArray<COEFFS_SIZE> interpolateCoeffsLinear(const std::array<float, COEFFS_SIZE> c0, const std::array<float, COEFFS_SIZE> c1)
+{
+  DSPVectorArray<COEFFS_SIZE> vy;
+  for (size_t i = 0; i < COEFFS_SIZE; ++i) vy.row((int)i) = interpolateDSPVectorLinear(c0[i], c1[i]);
+  return vy;
+}
+
+struct Lopass : public gpu::ProcNode<MLGPU_PROC_LOPASS>
+{
+  enum coeffNames { g0, g1, g2, nCoeffs };
+  typedef std::array<float, nCoeffs> Coeffs;
+  Coeffs coeffs{};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(float omega, float k)
+  {
+    Coeffs c;
+    mlgpu_lopass_make_coeffs(omega, k, c.data());
+    return c;
+  }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, coeffs.data(), 3)); }
+  DSPVector operator()(const DSPVector vx, const DSPVector omega, const DSPVector k)
+  {
+    return DSPVector(emit({vx.sig_[0], omega.sig_[0], k.sig_[0]}, coeffs.data(), 3));
+  }
+};
+class Hipass : public gpu::ProcNode<MLGPU_PROC_HIPASS>
+{
+ public:
+  typedef std::array<float, 4> Coeffs;
+  Coeffs coeffs{};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(float omega, float k)
+  {
+    Coeffs c;
+    mlgpu_hipass_make_coeffs(omega, k, c.data());
+    return c;
+  }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, coeffs.data(), 4)); }
+};
+class Bandpass : public gpu::ProcNode<MLGPU_PROC_BANDPASS>
+{
+ public:
+  typedef std::array<float, 3> Coeffs;
+  Coeffs coeffs{};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(float omega, float k)
+  {
+    Coeffs c;
+    mlgpu_bandpass_make_coeffs(omega, k, c.data());
+    return c;
+  }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, coeffs.data(), 3)); }
+};
+class LoShelf : public gpu::ProcNode<MLGPU_PROC_LO_SHELF>
+{
+ public:
+  typedef std::array<float, 5> Coeffs;
+  typedef DSPVectorArray<5> _vcoeffs;
+  typedef std::array<float, 3> params;  // omega, k, A
+  Coeffs coeffs{};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(params p)
+  {
+    Coeffs c;
+    mlgpu_loshelf_make_coeffs(p[0], p[1], p[2], c.data());
+    return c;
+  }
+  static _vcoeffs vcoeffs(const params p0, const params p1) { return interpolateCoeffsLinear(makeCoeffs(p0), makeCoeffs(p1)); }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, coeffs.data(), 5)); }
+  DSPVector operator()(const DSPVector vx, const _vcoeffs vc)
+  {
+    return DSPVector(emit({vx.sig_[0], vc.sig_[0], vc.sig_[1], vc.sig_[2], vc.sig_[3], vc.sig_[4]}, coeffs.data(), 5));
+  }
+};
+class HiShelf : public gpu::ProcNode<MLGPU_PROC_HI_SHELF>
+{
+ public:
+  typedef std::array<float, 6> Coeffs;
+  typedef DSPVectorArray<6> _vcoeffs;
+  typedef std::array<float, 3> params;
+  Coeffs coeffs{};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(params p)
+  {
+    Coeffs c;
+    mlgpu_hishelf_make_coeffs(p[0], p[1], p[2], c.data());
+    return c;
+  }
+  static _vcoeffs vcoeffs(const params p0, const params p1) { return interpolateCoeffsLinear(makeCoeffs(p0), makeCoeffs(p1)); }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, coeffs.data(), 6)); }
+  DSPVector operator()(const DSPVector vx, const _vcoeffs vc)
+  {
+    return DSPVector(emit({vx.sig_[0], vc.sig_[0], vc.sig_[1], vc.sig_[2], vc.sig_[3], vc.sig_[4], vc.sig_[5]}, coeffs.data(), 6));
+  }
+};
+class Bell : public gpu::ProcNode<MLGPU_PROC_BELL>
+{
+ public:
+  typedef std::array<float, 4> Coeffs;
+  Coeffs coeffs{};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(float omega, float k, float A)
+  {
+    Coeffs c;
+    mlgpu_bell_make_coeffs(omega, k, A, c.data());
+    return c;
+  }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, coeffs.data(), 4)); }
+};
+struct OnePole : public gpu::ProcNode<MLGPU_PROC_ONE_POLE>
+{
+  typedef std::array<float, 2> Coeffs;
+  Coeffs coeffs{};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(float omega)
+  {
+    Coeffs c;
+    mlgpu_onepole_make_coeffs(omega, c.data());
+    return c;
+  }
+  static Coeffs passthru() { return {1.f, 0.f}; }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, coeffs.data(), 2)); }
+};
+class DCBlocker : public gpu::ProcNode<MLGPU_PROC_DC_BLOCKER>
+{
+ public:
+  typedef float Coeffs;
+  Coeffs coeffs{0.045f};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(float omega) { return mlgpu_dcblocker_make_coeffs(omega); }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, &coeffs, 1)); }
+};
+class Differentiator : public gpu::ProcNode<MLGPU_PROC_DIFFERENTIATOR>
+{
+ public:
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, nullptr, 0)); }
+};
+class Integrator : public gpu::ProcNode<MLGPU_PROC_INTEGRATOR>
+{
+ public:
+  float mLeak{0.f};  // set leak to a value such as 0.001 for stability
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, &mLeak, 1)); }
+};
+class RMS : public gpu::ProcNode<MLGPU_PROC_RMS>
+{
+ public:
+  typedef std::array<float, 2> Coeffs;
+  Coeffs coeffs{};
+  void clear() { cleared_ = true; }
+  static Coeffs makeCoeffs(float omega) { return OnePole::makeCoeffs(omega); }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, coeffs.data(), 2)); }
+};
+struct ADSR : public gpu::ProcNode<MLGPU_PROC_ADSR>
+{
+  struct Coeffs
+  {
+    float ka, kd, s, kr;
+  };
+  Coeffs coeffs{0, 0, 0, 0};
+  void clear() { cleared_ = true; }
+  static Coeffs calcCoeffs(float a, float d, float s, float r, float sr)
+  {
+    float c[4];
+    mlgpu_adsr_calc_coeffs(a, d, s, r, sr, c);
+    return {c[0], c[1], c[2], c[3]};
+  }
+  DSPVector operator()(const DSPVector vx)
+  {
+    const float c[4] = {coeffs.ka, coeffs.kd, coeffs.s, coeffs.kr};
+    return DSPVector(emit({vx.sig_[0]}, c, 4));
+  }
+};
+
+// Bank<T, ROWS>, MLDSPFunctional.h:321-360
+template <typename T, size_t ROWS>
+class Bank
+{
+  std::array<T, ROWS> _processors;
+
+ public:
+  template <typename... Args>
+  DSPVectorArray<ROWS> operator()(Args... args)
+  {
+    DSPVectorArray<ROWS> output;
+    for (size_t i = 0; i < ROWS; ++i) output.row((int)i) = _processors[i](args.constRow((int)i)...);
+    return output;
+  }
+  void clear()
+  {
+    for (auto& p : _processors) p.clear();
+  }
+  T& operator[](size_t n) { return _processors[n]; }
+};
+
+// ---- the process-function boundary (source/app/MLAudioContext.h:60-110, MLSignalProcessBuffer.h:18) -----------------
+class AudioContext
+{
+ public:
+  AudioContext(size_t nInputs, size_t nOutputs) : inputs(nInputs), outputs(nOutputs) {}
+  AudioContext(size_t nInputs, size_t nOutputs, int rate) : inputs(nInputs), outputs(nOutputs), sampleRate_(rate) {}
+  void setSampleRate(int r) { sampleRate_ = r; }
+  double getSampleRate() { return sampleRate_; }
+  DSPVectorDynamic inputs;
+  DSPVectorDynamic outputs;
+
+ private:
+  double sampleRate_{0};
+};
+using SignalProcessFn = void (*)(AudioContext*, void*);
+
+namespace gpu
+{
+// A per-voice constant (`DSPVector(f)` with a different f for every voice): converts to DSPVector.
+class VoiceParam
+{
+  std::string name_;
+  int node_{-1};
+
+ public:
+  explicit VoiceParam(const char* name) : name_(name) {}
+  operator DSPVector()
+  {
+    Capture& c = Capture::get();
+    if (node_ < 0) node_ = c.ret(mlgpu_graph_add_param(c.g, name_.c_str()));
+    return DSPVector(Sig{node_, 0.f});
+  }
+  int node() const { return node_; }
+  const std::string& name() const { return name_; }
+};
+
+// Captures a reference-style process function once and runs it for `voices` voices on the GPU.
+class VoiceProgram
+{
+  const Engine& eng_;
+  mlgpu_graph* g_{nullptr};
+  size_t voices_;
+  size_t nIn_{0}, nOut_{0};
+
+ public:
+  VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state) : eng_(e), voices_(voices)
+  {
+    eng_.check(mlgpu_graph_create(e.handle(), voices, &g_));
+    Capture cap;
+    cap.eng = &e;
+    cap.g = g_;
+    struct Scope
+    {
+      Capture*& slot;
+      Capture* prev;
+      Scope(Capture*& s, Capture* c) : slot(s), prev(s) { slot = c; }
+      ~Scope() { slot = prev; }
+    } scope(Capture::current(), &cap);
+    nIn_ = ctx->inputs.size();
+    nOut_ = ctx->outputs.size();
+    for (size_t c = 0; c < nIn_; ++c)
+      ctx->inputs[(int)c] = DSPVector(Sig{cap.ret(mlgpu_graph_add_input(g_, ("in" + std::to_string(c)).c_str())), 0.f});
+    for (size_t c = 0; c < nOut_; ++c) ctx->outputs[(int)c] = DSPVector(0.f);
+    fn(ctx, state);
+    for (size_t c = 0; c < nOut_; ++c) eng_.check(mlgpu_graph_add_output(g_, ctx->outputs[(int)c].sig_[0].id()));
+    eng_.check(mlgpu_graph_compile(g_));
+    for (const Capture::Deferred& d : cap.deferred)
+    {
+      float f;
+      std::memcpy(&f, &d.bits, 4);
+      if (d.what == 0) eng_.check(mlgpu_graph_set_coeff_uniform(g_, d.node, d.idx, f));
+      else if (d.what == 1) eng_.check(mlgpu_graph_clear_proc(g_, d.node));
+      else eng_.check(mlgpu_graph_set_state_uniform(g_, d.node, d.idx, d.bits));
+    }
+  }
+  VoiceProgram(const VoiceProgram&) = delete;
+  VoiceProgram& operator=(const VoiceProgram&) = delete;
+  ~VoiceProgram()
+  {
+    if (g_) mlgpu_graph_destroy(g_);
+  }
+
+  size_t voices() const { return voices_; }
+  const char* source() const { return mlgpu_graph_source(g_); }  // the generated HIP kernel
+
+  // per-voice values: [voices] floats
+  void setParam(const VoiceParam& p, const std::vector<float>& perVoice) { eng_.check(mlgpu_graph_set_param(g_, p.node(), perVoice.data())); }
+  template <class P>
+  void setCoeff(const P& object, int coeffIdx, const std::vector<float>& perVoice)
+  {
+    eng_.check(mlgpu_graph_set_coeff(g_, object.node(), coeffIdx, perVoice.data()));
+  }
+  template <class P>
+  void setState(const P& object, int stateIdx, const std::vector<uint32_t>& perVoice)
+  {
+    eng_.check(mlgpu_graph_set_state(g_, object.node(), stateIdx, perVoice.data()));
+  }
+
+  // one call = T DSPVectors of every voice (the reference calls the process function T times)
+  void process(const std::vector<const DeviceSignal*>& ins, const std::vector<DeviceSignal*>& outs)
+  {
+    if (ins.size() != nIn_ || outs.size() != nOut_ || outs.empty()) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: wrong number of signals");
+    std::vector<const float*> pi;
+    std::vector<float*> po;
+    for (auto* s : ins) pi.push_back(s->data());
+    for (auto* s : outs) po.push_back(s->data());
+    const int inLayout = ins.empty() ? MLGPU_LAYOUT_QUAD : ins[0]->layout();
+    eng_.check(mlgpu_graph_process(g_, outs[0]->vectors(), pi.data(), inLayout, po.data(), outs[0]->layout()));
+  }
+};
+}  // namespace gpu
+}  // namespace ml

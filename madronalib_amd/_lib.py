@@ -131,6 +131,8 @@ def _declare(L):
     sig("mlgpu_graph_compile", i, [vp])
     sig("mlgpu_graph_source", c.c_char_p, [vp])
     sig("mlgpu_graph_clear", i, [vp])
+    sig("mlgpu_graph_clear_proc", i, [vp, i])
+    sig("mlgpu_graph_set_state_uniform", i, [vp, i, i, c.c_uint32])
     sig("mlgpu_graph_set_param", i, [vp, i, vp])
     sig("mlgpu_graph_set_param_uniform", i, [vp, i, f])
     sig("mlgpu_graph_num_coeffs", i, [vp, i])

@@ -694,6 +694,23 @@ extern "C"
     return MLGPU_OK;
   }
 
+  int mlgpu_graph_clear_proc(mlgpu_graph* g, int node)
+  {
+    int st = checkNode(g, node, NODE_PROC);
+    if (st) return st;
+    if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_clear_proc: compile first");
+    const Node& n = g->nodes[node];
+    uint32_t words[MLGPU_MAX_PROC_STATE];
+    mlgpu_proc_clear_state(n.kind, words, true);
+    for (int i = 0; i < n.ns; ++i)
+    {
+      if (n.kind == MLGPU_PROC_ADSR && i != 7) continue;  // ADSR::clear() only resets the segment
+      const hipError_t err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * g->V, words[i], g->V, g->e->stream);
+      if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, hipGetErrorString(err));
+    }
+    return MLGPU_OK;
+  }
+
   int mlgpu_graph_set_param(mlgpu_graph* g, int node, const float* h)
   {
     int st = checkNode(g, node, NODE_PARAM);
@@ -745,6 +762,15 @@ extern "C"
     if (!g->compiled || !h) return gfail(g, MLGPU_ERR_INVALID, "graph_set_state: compile first / null");
     if (idx < 0 || idx >= g->nodes[node].ns) return gfail(g, MLGPU_ERR_RANGE, "state index out of range");
     return mlgpu_upload(g->e, g->d_state + (size_t)(g->nodes[node].sOff + idx) * g->V, h, sizeof(uint32_t) * g->V);
+  }
+
+  int mlgpu_graph_set_state_uniform(mlgpu_graph* g, int node, int idx, uint32_t value)
+  {
+    int st = checkNode(g, node, NODE_PROC);
+    if (st) return st;
+    if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_set_state: compile first");
+    if (idx < 0 || idx >= g->nodes[node].ns) return gfail(g, MLGPU_ERR_RANGE, "state index out of range");
+    return mlgpu_fill32(g->e, g->d_state + (size_t)(g->nodes[node].sOff + idx) * g->V, value, g->V);
   }
 
   int mlgpu_graph_process(mlgpu_graph* g, size_t T, const float* const* d_inputs, int inLayout, float* const* d_outputs, int outLayout)

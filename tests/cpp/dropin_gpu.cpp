@@ -1,0 +1,41 @@
+// The same user code (dropin_patch.h) compiled against the MI355X shim: captured once, run for V voices.
+#include <cstddef>
+#include <cstdio>
+#include <vector>
+
+#include "madronalib.h"  // include/mlgpu/compat/madronalib.h
+using namespace ml;
+
+#include "dropin_patch.h"
+
+// gate / pitch / outputs: VOICE_MAJOR [V][64T] host arrays. Returns 0, or an mlgpu status.
+extern "C" int dropin_gpu_run(size_t V, size_t T, const float* gate, const float* pitch, float* out0, float* out1, char* err, size_t errLen)
+{
+  try
+  {
+    gpu::Engine eng(0);
+    PatchState state;
+    patchSetup(state);
+    AudioContext ctx(2, 2, 48000);
+    gpu::VoiceProgram prog(eng, V, &ctx, patchProcess, &state);
+    // per-voice noise seeds are all 0 in the reference run too (one fresh NoiseGen per voice)
+    gpu::DeviceSignal dGate(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR), dPitch(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR);
+    gpu::DeviceSignal dOut0(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR), dOut1(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR);
+    eng.check(mlgpu_upload(eng.handle(), dGate.data(), gate, dGate.bytes()));
+    eng.check(mlgpu_upload(eng.handle(), dPitch.data(), pitch, dPitch.bytes()));
+    prog.process({&dGate, &dPitch}, {&dOut0, &dOut1});
+    eng.check(mlgpu_download(eng.handle(), out0, dOut0.data(), dOut0.bytes()));
+    eng.check(mlgpu_download(eng.handle(), out1, dOut1.data(), dOut1.bytes()));
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
