@@ -72,7 +72,9 @@ typedef enum mlgpu_layout
 {
   MLGPU_LAYOUT_QUAD = 0,
   MLGPU_LAYOUT_ROWS = 1,
-  MLGPU_LAYOUT_VOICE_MAJOR = 2
+  MLGPU_LAYOUT_VOICE_MAJOR = 2,
+  /* INPUT signals only: ONE voice's stream [S], read by every voice (e.g. one host audio channel feeding all voices) */
+  MLGPU_LAYOUT_BROADCAST = 3
 } mlgpu_layout;
 
 /* ------------------------------------------------------------------------- */
@@ -433,6 +435,9 @@ int mlgpu_graph_set_state(mlgpu_graph* g, int proc_node, int state_idx, const ui
  * inputs / outputs were added, all in `in_layout` / `out_layout`. */
 int mlgpu_graph_process(mlgpu_graph* g, size_t n_vectors, const float* const* d_inputs, int in_layout,
                         float* const* d_outputs, int out_layout);
+/* Give streamed input `input_index` (order of mlgpu_graph_add_input) its own layout, overriding the in_layout of the
+ * process calls — e.g. MLGPU_LAYOUT_BROADCAST for a host audio channel next to per-voice inputs. -1 removes it. */
+int mlgpu_graph_set_input_layout(mlgpu_graph* g, int input_index, int layout);
 /* Same, for graphs with control inputs: d_controls[i] is the i-th control's [n_vectors][n_voices] floats. */
 int mlgpu_graph_process_ctl(mlgpu_graph* g, size_t n_vectors, const float* const* d_inputs, int in_layout,
                             const float* const* d_controls, float* const* d_outputs, int out_layout);
@@ -443,6 +448,55 @@ int mlgpu_engine_set_jit(mlgpu_engine* e, int enabled);
 /* Device-free check that the run-time code generator's output compiles for gfx950 (a chain and a
  * graph); used by the CPU build check. Writes the compiler log (if any) to `log`. */
 int mlgpu_jit_selftest(char* log, size_t log_len);
+
+/* ------------------------------------------------------------------------- */
+/* host ring and block adaptor                                               */
+/*
+ * mlgpu_dspbuffer — the reference's DSPBuffer (source/DSP/MLDSPBuffer.h:20-384): a single-producer /
+ * single-consumer float ring on the HOST. resize() allocates the power of two >= max(n, 64) and returns it (0 on
+ * failure); a write into a full ring overwrites the oldest samples; read_vector returns 1 and 64 samples, or 0 and
+ * 64 zeros when fewer than 64 samples wait (DSPVector read(), :253-277). One reader thread and one writer thread
+ * may use a ring concurrently without a lock, exactly as in the reference.
+ */
+typedef struct mlgpu_dspbuffer mlgpu_dspbuffer;
+mlgpu_dspbuffer* mlgpu_dspbuffer_create(void);
+void mlgpu_dspbuffer_destroy(mlgpu_dspbuffer* b);
+size_t mlgpu_dspbuffer_resize(mlgpu_dspbuffer* b, int size_in_samples);                     /* :104-133 */
+size_t mlgpu_dspbuffer_size(mlgpu_dspbuffer* b);
+void mlgpu_dspbuffer_clear(mlgpu_dspbuffer* b);                                              /* :96-100 */
+size_t mlgpu_dspbuffer_read_available(mlgpu_dspbuffer* b);                                   /* :136-141 */
+size_t mlgpu_dspbuffer_write_available(mlgpu_dspbuffer* b);                                  /* :144 */
+void mlgpu_dspbuffer_write(mlgpu_dspbuffer* b, const float* src, size_t samples);            /* :147-168 */
+size_t mlgpu_dspbuffer_read(mlgpu_dspbuffer* b, float* dst, size_t samples);                 /* :207-224 */
+int mlgpu_dspbuffer_read_vector(mlgpu_dspbuffer* b, float* dst64);                           /* :253-277 */
+void mlgpu_dspbuffer_discard(mlgpu_dspbuffer* b, size_t samples);                            /* :280-286 */
+void mlgpu_dspbuffer_write_with_overlap_add(mlgpu_dspbuffer* b, const float* src, size_t samples, size_t overlap); /* :289-320 */
+void mlgpu_dspbuffer_read_with_overlap(mlgpu_dspbuffer* b, float* dst, size_t samples, size_t overlap);           /* :323-338 */
+void mlgpu_dspbuffer_peek_most_recent(mlgpu_dspbuffer* b, float* dst, size_t samples);       /* :342-383 */
+
+/*
+ * mlgpu_process_buffer — the reference's SignalProcessBuffer (source/app/MLSignalProcessBuffer.h:22-41, .cpp:36-90):
+ * the host asks for blocks of arbitrary size nFrames <= max_frames; inputs and outputs are buffered in rings and the
+ * processing happens in whole DSPVectors. Where the reference calls `SignalProcessFn(AudioContext*, void*)` once per
+ * 64-frame vector (MLSignalProcessBuffer.h:18), this calls `fn` ONCE per block with all K vectors the block needs,
+ * already in HBM: d_inputs[c] / d_outputs[c] are single-voice signals of K*64 floats on the engine's device (use
+ * MLGPU_LAYOUT_BROADCAST to feed one to every voice of a bank or graph, mlgpu_mixdown to sum voices into one).
+ * `fn` enqueues work on the engine's stream and returns an mlgpu_status; it must not block.
+ * inputs[c] may be NULL (channel not connected); outputs[c] may be NULL (not wanted).
+ */
+typedef struct mlgpu_process_buffer mlgpu_process_buffer;
+typedef int (*mlgpu_process_vectors_fn)(void* user, size_t n_vectors, const float* const* d_inputs, float* const* d_outputs);
+int mlgpu_process_buffer_create(mlgpu_engine* e, size_t n_inputs, size_t n_outputs, size_t max_frames, mlgpu_process_buffer** out);
+int mlgpu_process_buffer_destroy(mlgpu_process_buffer* p);
+int mlgpu_process_buffer_process(mlgpu_process_buffer* p, const float* const* inputs, float* const* outputs, int n_frames,
+                                 mlgpu_process_vectors_fn fn, void* user);
+
+/* Sum the voices of a signal into ONE single-voice signal of 64*n_vectors floats (what a Synth does with
+ * `outputs += voice` in its voice loop, source/app/MLSynth.h:43-57), optionally scaled by per-voice gains
+ * (d_gains may be NULL). Summation order (deterministic, documented in DESIGN.md): pairwise tree inside each group
+ * of 64 consecutive voices, then the groups left to right. */
+int mlgpu_mixdown(mlgpu_engine* e, const float* d_signal, int layout, size_t n_voices, size_t n_vectors, const float* d_gains,
+                  float* d_out);
 
 /* ------------------------------------------------------------------------- */
 /* coefficient makers — host-side, glibc libm, formulas of the reference     */

@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, Route, RowOp, RowsRule, Status, Vop
 
-__all__ = ["Engine", "Bank", "Graph", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "LinearGlide", "SampleAccurateLinearGlide",
+__all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "LinearGlide", "SampleAccurateLinearGlide",
            "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
            "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
 
@@ -218,12 +218,121 @@ class Engine:
         self._check(self.L.mlgpu_demultiplex(self.h, d_sel.ptr, sel.size, d_x.ptr, arr, n_outputs, x.size, 1 if linear else 0))
         return [o.download(np.float32, x.size).reshape(x.shape) for o in outs]
 
+    def mixdown(self, d_signal, layout, n_voices, n_vectors, d_out, d_gains=None):
+        g = lambda x: None if x is None else ctypes.c_void_p(x.ptr if hasattr(x, "ptr") else int(x))  # noqa: E731
+        self._check(self.L.mlgpu_mixdown(self.h, g(d_signal), int(layout), int(n_voices), int(n_vectors), g(d_gains), g(d_out)))
+
     def layout_convert(self, src, src_layout, dst, dst_layout, n_voices, n_vectors):
         self._check(self.L.mlgpu_layout_convert(self.h, src.ptr, int(src_layout), dst.ptr, int(dst_layout),
                                                 int(n_voices), int(n_vectors)))
 
     def bank(self, procs, n_voices):
         return Bank(self, procs, n_voices)
+
+
+class DSPBuffer:
+    """The reference's DSPBuffer (MLDSPBuffer.h): a host SPSC float ring (mlgpu_dspbuffer)."""
+
+    def __init__(self, size):
+        self.L = _lib.load()
+        self.h = ctypes.c_void_p(self.L.mlgpu_dspbuffer_create())
+        self.size = self.L.mlgpu_dspbuffer_resize(self.h, int(size))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.mlgpu_dspbuffer_destroy(self.h)
+            self.h = None
+        except Exception:
+            pass
+
+    def read_available(self):
+        return self.L.mlgpu_dspbuffer_read_available(self.h)
+
+    def write_available(self):
+        return self.L.mlgpu_dspbuffer_write_available(self.h)
+
+    def write(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        self.L.mlgpu_dspbuffer_write(self.h, _np_ptr(x), x.size)
+
+    def read(self, n):
+        out = np.full(n, np.float32(-99.0))
+        got = self.L.mlgpu_dspbuffer_read(self.h, _np_ptr(out), n)
+        return out[:got].copy()
+
+    def read_vector(self):
+        out = np.full(64, np.float32(-99.0))
+        ok = self.L.mlgpu_dspbuffer_read_vector(self.h, _np_ptr(out))
+        return bool(ok), out
+
+    def discard(self, n):
+        self.L.mlgpu_dspbuffer_discard(self.h, n)
+
+    def clear(self):
+        self.L.mlgpu_dspbuffer_clear(self.h)
+
+    def write_with_overlap_add(self, x, overlap):
+        x = np.ascontiguousarray(x, np.float32)
+        self.L.mlgpu_dspbuffer_write_with_overlap_add(self.h, _np_ptr(x), x.size, overlap)
+
+    def read_with_overlap(self, n, overlap):
+        out = np.full(n, np.float32(-99.0))
+        self.L.mlgpu_dspbuffer_read_with_overlap(self.h, _np_ptr(out), n, overlap)
+        return out
+
+    def peek_most_recent(self, n):
+        out = np.full(n, np.float32(-99.0))
+        self.L.mlgpu_dspbuffer_peek_most_recent(self.h, _np_ptr(out), n)
+        return out
+
+
+class ProcessBuffer:
+    """The reference's SignalProcessBuffer (MLSignalProcessBuffer.h) over the engine: host blocks of any size in and
+    out, `fn(n_vectors, d_inputs, d_outputs)` called once per block with single-voice device signals (raw pointers)."""
+
+    _CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p))
+
+    def __init__(self, engine, n_inputs, n_outputs, max_frames):
+        self.engine, self.L = engine, engine.L
+        self.n_in, self.n_out = n_inputs, n_outputs
+        h = ctypes.c_void_p()
+        engine._check(self.L.mlgpu_process_buffer_create(engine.h, n_inputs, n_outputs, max_frames, ctypes.byref(h)))
+        self.h = h
+        engine._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None) and self.engine.h:
+            self.L.mlgpu_process_buffer_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process(self, inputs, n_frames, fn):
+        """inputs: list of n_frames-float arrays (or None). Returns the list of output blocks."""
+        ins = [None if x is None else np.ascontiguousarray(x, np.float32) for x in inputs]
+        outs = [np.zeros(n_frames, np.float32) for _ in range(self.n_out)]
+        pin = (ctypes.c_void_p * max(1, self.n_in))(*[None if x is None else x.ctypes.data for x in ins])
+        pout = (ctypes.c_void_p * max(1, self.n_out))(*[o.ctypes.data for o in outs])
+        err = []
+
+        def cb(_user, n_vectors, d_in, d_out):
+            try:
+                fn(int(n_vectors), [d_in[i] for i in range(self.n_in)], [d_out[i] for i in range(self.n_out)])
+                return 0
+            except MlgpuError as ex:  # pragma: no cover
+                err.append(ex)
+                return ex.status
+        cbf = self._CB(cb)
+        st = self.L.mlgpu_process_buffer_process(self.h, pin, pout, int(n_frames), cbf, None)
+        if err:
+            raise err[0]
+        self.engine._check(st)
+        return outs
 
 
 class Bank:
@@ -466,12 +575,16 @@ class Graph:
         v = np.ascontiguousarray(np.broadcast_to(np.asarray(value, np.uint32), (self.V,)))
         self.engine._check(self.L.mlgpu_graph_set_state(self.h, self._id(node), idx, _np_ptr(v)))
 
+    def set_input_layout(self, input_index, layout):
+        self.engine._check(self.L.mlgpu_graph_set_input_layout(self.h, int(input_index), int(layout)))
+
     def process(self, n_vectors, d_inputs, d_outputs, in_layout=Layout.QUAD, out_layout=Layout.QUAD, d_controls=()):
         """d_inputs / d_outputs / d_controls: lists of DeviceBuffer in the order inputs / outputs / controls were
         added; a control buffer holds [n_vectors][V] floats."""
-        pi = (ctypes.c_void_p * max(1, len(d_inputs)))(*[b.ptr for b in d_inputs])
-        po = (ctypes.c_void_p * max(1, len(d_outputs)))(*[b.ptr for b in d_outputs])
-        pc = (ctypes.c_void_p * max(1, len(d_controls)))(*[b.ptr for b in d_controls])
+        raw = lambda b: b.ptr if hasattr(b, "ptr") else int(b)  # noqa: E731
+        pi = (ctypes.c_void_p * max(1, len(d_inputs)))(*[raw(b) for b in d_inputs])
+        po = (ctypes.c_void_p * max(1, len(d_outputs)))(*[raw(b) for b in d_outputs])
+        pc = (ctypes.c_void_p * max(1, len(d_controls)))(*[raw(b) for b in d_controls])
         self.engine._check(self.L.mlgpu_graph_process_ctl(self.h, int(n_vectors), pi, int(in_layout), pc, po, int(out_layout)))
 
     def process_host(self, n_vectors, in_signals, layout=Layout.QUAD):

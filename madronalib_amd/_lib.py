@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmlgpu.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mlgpu.h")
 
-_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "coeffs.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
+_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "coeffs.cpp", "dspbuffer.cpp", "processbuffer.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
             "mldsp_procs.hpp", "mldsp_kernels.hpp", "mlgpu_device_args.hpp", "mlgpu_internal.hpp", "embed.py",
             "Makefile"]
 
@@ -132,6 +132,25 @@ def _declare(L):
     sig("mlgpu_graph_source", c.c_char_p, [vp])
     sig("mlgpu_graph_clear", i, [vp])
     sig("mlgpu_graph_clear_proc", i, [vp, i])
+    sig("mlgpu_graph_set_input_layout", i, [vp, i, i])
+    sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
+    sig("mlgpu_dspbuffer_create", vp, [])
+    sig("mlgpu_dspbuffer_destroy", None, [vp])
+    sig("mlgpu_dspbuffer_resize", sz, [vp, i])
+    sig("mlgpu_dspbuffer_size", sz, [vp])
+    sig("mlgpu_dspbuffer_clear", None, [vp])
+    sig("mlgpu_dspbuffer_read_available", sz, [vp])
+    sig("mlgpu_dspbuffer_write_available", sz, [vp])
+    sig("mlgpu_dspbuffer_write", None, [vp, vp, sz])
+    sig("mlgpu_dspbuffer_read", sz, [vp, vp, sz])
+    sig("mlgpu_dspbuffer_read_vector", i, [vp, vp])
+    sig("mlgpu_dspbuffer_discard", None, [vp, sz])
+    sig("mlgpu_dspbuffer_write_with_overlap_add", None, [vp, vp, sz, sz])
+    sig("mlgpu_dspbuffer_read_with_overlap", None, [vp, vp, sz, sz])
+    sig("mlgpu_dspbuffer_peek_most_recent", None, [vp, vp, sz])
+    sig("mlgpu_process_buffer_create", i, [vp, sz, sz, sz, pp])
+    sig("mlgpu_process_buffer_destroy", i, [vp])
+    sig("mlgpu_process_buffer_process", i, [vp, pp, pp, i, vp, vp])
     sig("mlgpu_graph_set_state_uniform", i, [vp, i, i, c.c_uint32])
     sig("mlgpu_graph_set_param", i, [vp, i, vp])
     sig("mlgpu_graph_set_param_uniform", i, [vp, i, f])

@@ -20,6 +20,7 @@ class Layout:
     QUAD = 0         # [S/4][V][4]  device native
     ROWS = 1         # [T][V][64]   reference DSPVectorArray<V> per vector
     VOICE_MAJOR = 2  # [V][S]
+    BROADCAST = 3    # [S] one voice's stream read by every voice (inputs only)
 
 
 class Op:

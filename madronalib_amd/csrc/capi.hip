@@ -150,6 +150,7 @@ extern "C"
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->d_impulseTable) hipFree(e->d_impulseTable);
+    if (e->d_mixScratch) hipFree(e->d_mixScratch);
     if (e->ownsStream) hipStreamDestroy(e->stream);
     delete e;
     return MLGPU_OK;
@@ -371,6 +372,28 @@ extern "C"
     return MLGPU_OK;
   }
 
+  int mlgpu_mixdown(mlgpu_engine* e, const float* sig, int layout, size_t V, size_t T, const float* gains, float* out)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (V == 0 || T == 0) return MLGPU_OK;
+    if (!sig || !out || ((uintptr_t)sig & 15) || ((uintptr_t)out & 15)) return fail(e, MLGPU_ERR_INVALID, "mixdown: null / misaligned signal");
+    if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return fail(e, MLGPU_ERR_INVALID, "mixdown: bad layout");
+    HIP_TRY(e, hipSetDevice(e->device));
+    const size_t need = ((V + 63) / 64) * T * 64;
+    if (need > e->mixScratchFloats)
+    {
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      if (e->d_mixScratch) hipFree(e->d_mixScratch);
+      e->d_mixScratch = nullptr;
+      e->mixScratchFloats = 0;
+      const hipError_t err = hipMalloc((void**)&e->d_mixScratch, sizeof(float) * need);
+      if (err != hipSuccess) return fail(e, err == hipErrorOutOfMemory ? MLGPU_ERR_OOM : MLGPU_ERR_HIP, "mixdown: scratch allocation", err);
+      e->mixScratchFloats = need;
+    }
+    HIP_TRY(e, mlgpu_launch_mixdown(sig, layout, V, T, gains, e->d_mixScratch, out, e->stream));
+    return MLGPU_OK;
+  }
+
   // ---- banks --------------------------------------------------------------------------------
 
   int mlgpu_bank_destroy(mlgpu_bank* b)
@@ -586,7 +609,7 @@ extern "C"
     mlgpu_engine* e = b->e;
     if (T == 0) return MLGPU_OK;
     if (!d_out) return fail(e, MLGPU_ERR_INVALID, "bank_process: null output");
-    if (outLayout < 0 || outLayout > 2 || (d_in && (inLayout < 0 || inLayout > 2)))
+    if (outLayout < 0 || outLayout > MLGPU_LAYOUT_VOICE_MAJOR || (d_in && (inLayout < 0 || inLayout > MLGPU_LAYOUT_BROADCAST)))
       return fail(e, MLGPU_ERR_INVALID, "bank_process: bad layout");
     if ((((uintptr_t)d_out) | ((uintptr_t)d_in)) & 15) return fail(e, MLGPU_ERR_INVALID, "bank_process: signals must be 16-byte aligned");
     HIP_TRY(e, hipSetDevice(e->device));

@@ -201,6 +201,7 @@ struct mlgpu_graph
   float* d_coeffs{nullptr};
   uint32_t* d_state{nullptr};
   float* d_params{nullptr};
+  int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1};
 };
 
 namespace
@@ -764,6 +765,15 @@ extern "C"
     return mlgpu_upload(g->e, g->d_state + (size_t)(g->nodes[node].sOff + idx) * g->V, h, sizeof(uint32_t) * g->V);
   }
 
+  int mlgpu_graph_set_input_layout(mlgpu_graph* g, int inputIndex, int layout)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (inputIndex < 0 || inputIndex >= g->nInputs) return gfail(g, MLGPU_ERR_RANGE, "graph_set_input_layout: input index out of range");
+    if (layout < -1 || layout > MLGPU_LAYOUT_BROADCAST) return gfail(g, MLGPU_ERR_INVALID, "graph_set_input_layout: bad layout");
+    g->inLayoutOverride[inputIndex] = layout;
+    return MLGPU_OK;
+  }
+
   int mlgpu_graph_set_state_uniform(mlgpu_graph* g, int node, int idx, uint32_t value)
   {
     int st = checkNode(g, node, NODE_PROC);
@@ -784,7 +794,8 @@ extern "C"
     if (!g) return MLGPU_ERR_INVALID;
     if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_process: compile first");
     if (T == 0) return MLGPU_OK;
-    if (inLayout < 0 || inLayout > 2 || outLayout < 0 || outLayout > 2) return gfail(g, MLGPU_ERR_INVALID, "graph_process: bad layout");
+    if (inLayout < 0 || inLayout > MLGPU_LAYOUT_BROADCAST || outLayout < 0 || outLayout > MLGPU_LAYOUT_VOICE_MAJOR)
+      return gfail(g, MLGPU_ERR_INVALID, "graph_process: bad layout");
     if ((g->nInputs && !d_inputs) || (g->nControls && !d_controls) || !d_outputs) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null signal list");
     GraphArgs a;
     memset(&a, 0, sizeof(a));
@@ -797,7 +808,8 @@ extern "C"
     for (int i = 0; i < g->nInputs; ++i)
     {
       if (!d_inputs[i] || ((uintptr_t)d_inputs[i] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned input");
-      a.in[i] = makeView(d_inputs[i], inLayout, g->V, T);
+      const int lay = (g->inLayoutOverride[i] >= 0) ? g->inLayoutOverride[i] : inLayout;
+      a.in[i] = makeView(d_inputs[i], lay, g->V, T);
     }
     for (int i = 0; i < g->nControls; ++i)
     {

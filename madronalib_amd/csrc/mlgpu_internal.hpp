@@ -20,6 +20,8 @@ struct mlgpu_engine
   float* d_impulseTable{nullptr};  // 17 floats (ImpulseGen windowed sinc), built on the host
   hipEvent_t ev0{nullptr}, ev1{nullptr};
   bool jitEnabled{true};  // fuse unknown chains / graphs with hiprtc (mlgpu_engine_set_jit)
+  float* d_mixScratch{nullptr};  // mixdown partial sums, grown on demand
+  size_t mixScratchFloats{0};
 };
 
 inline SignalView makeView(const float* p, int layout, size_t V, size_t T)
@@ -30,6 +32,7 @@ inline SignalView makeView(const float* p, int layout, size_t V, size_t T)
   {
     case MLGPU_LAYOUT_QUAD: s.strideT = 16 * V; s.strideQ = V; s.strideV = 1; break;
     case MLGPU_LAYOUT_ROWS: s.strideT = 16 * V; s.strideQ = 1; s.strideV = 16; break;
+    case MLGPU_LAYOUT_BROADCAST: s.strideT = 16; s.strideQ = 1; s.strideV = 0; break;
     default: /* VOICE_MAJOR */ s.strideT = 16; s.strideQ = 1; s.strideV = 16 * T; break;
   }
   return s;
@@ -72,6 +75,8 @@ hipError_t mlgpu_launch_rows_map(int rule, long p0, long p1, int sampleRotate, c
 hipError_t mlgpu_launch_rows_add(const float* rows, size_t rowsPerGroup, float* out, size_t groups, hipStream_t stream);
 hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRows, hipStream_t stream);
 hipError_t mlgpu_launch_rows_index(float* out, size_t rowsPerGroup, size_t groups, hipStream_t stream);
+hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
+                                hipStream_t stream);
 hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,
                               size_t nElems, hipStream_t stream);
 

@@ -495,6 +495,79 @@ hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStrea
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// mixdown: sum the voices of a signal into one single-voice signal (a Synth's `outputs += voice`, MLSynth.h:43-57).
+// Stage 1: one wavefront per group of 64 consecutive voices, lane = voice, fixed pairwise tree over the lanes
+// (a[i] += a[i + d] for d = 1, 2, ... 32); stage 2: the groups are added left to right. Missing voices of the last
+// group count as +0. The order is part of the contract so results are reproducible and checkable.
+namespace
+{
+__global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, size_t V, size_t T, const float* gains, float4* partial)
+{
+  const size_t nQuads = T * 16;
+  const size_t group = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t v = group * 64 + lane;
+  const bool live = v < V;
+  const float g = (live && gains) ? gains[v] : 1.f;
+  for (size_t qi = (size_t)blockIdx.y * 4 + wave; qi < nQuads; qi += (size_t)gridDim.y * 4)
+  {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live)
+    {
+      x = sig.base[(qi >> 4) * sig.strideT + (qi & 15) * sig.strideQ + v * sig.strideV];
+      if (gains)
+      {
+        x.x *= g;
+        x.y *= g;
+        x.z *= g;
+        x.w *= g;
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      x.x = x.x + __shfl_down(x.x, d, 64);
+      x.y = x.y + __shfl_down(x.y, d, 64);
+      x.z = x.z + __shfl_down(x.z, d, 64);
+      x.w = x.w + __shfl_down(x.w, d, 64);
+    }
+    if (lane == 0) partial[group * nQuads + qi] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void mixdown_stage2_kernel(const float4* partial, size_t groups, size_t nQuads, float4* out)
+{
+  const size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= nQuads) return;
+  float4 acc = partial[qi];
+  for (size_t g = 1; g < groups; ++g)
+  {
+    const float4 x = partial[g * nQuads + qi];
+    acc.x = acc.x + x.x;
+    acc.y = acc.y + x.y;
+    acc.z = acc.z + x.z;
+    acc.w = acc.w + x.w;
+  }
+  out[qi] = acc;
+}
+}  // namespace
+
+hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
+                                hipStream_t stream)
+{
+  const size_t groups = (V + 63) / 64, nQuads = T * 16;
+  unsigned y = (unsigned)((nQuads + 3) / 4);
+  const size_t wantBlocks = 4096;  // enough workgroups to fill the chip without a grid of millions
+  if ((size_t)y * groups > wantBlocks) y = (unsigned)((wantBlocks + groups - 1) / groups);
+  if (y < 1) y = 1;
+  hipLaunchKernelGGL(mixdown_stage1_kernel, dim3((unsigned)groups, y), dim3(256), 0, stream, makeView(sig, layout, V, T), V, T, gains,
+                     (float4*)partial);
+  hipLaunchKernelGGL(mixdown_stage2_kernel, dim3((unsigned)((nQuads + 255) / 256)), dim3(256), 0, stream, (const float4*)partial, groups, nQuads,
+                     (float4*)out);
+  return hipGetLastError();
+}
+
 static unsigned gridFor(size_t items)
 {
   size_t blocks = (items + 255) / 256;

@@ -28,3 +28,38 @@ extern "C" int dropin_ref_run(size_t V, size_t T, const float* gate, const float
   }
   return 0;
 }
+
+// ---- the reference's SignalProcessBuffer driven with a sequence of host block sizes -----------------------------
+// process function: out0 = Lopass(in0) (stateful), out1 = in0 * 0.5. blocks[i] frames per call; in / out0 / out1
+// hold the concatenated blocks. Pins the behaviour of mlgpu_process_buffer (latency, zero-fill, ring sizes).
+#include "MLSignalProcessBuffer.h"
+namespace
+{
+struct SpbState
+{
+  Lopass lp;
+};
+void spbProcess(AudioContext* ctx, void* st)
+{
+  auto s = static_cast<SpbState*>(st);
+  ctx->outputs[0] = s->lp(ctx->inputs[0]);
+  ctx->outputs[1] = ctx->inputs[0] * 0.5f;
+}
+}  // namespace
+
+extern "C" int spb_ref_run(int maxFrames, const int* blocks, int nBlocks, const float* in, float* out0, float* out1)
+{
+  SpbState state;
+  state.lp.coeffs = Lopass::makeCoeffs(0.05f, 0.9f);
+  AudioContext ctx(1, 2, 48000);
+  SignalProcessBuffer spb(1, 2, maxFrames);
+  size_t pos = 0;
+  for (int b = 0; b < nBlocks; ++b)
+  {
+    const float* ins[1] = {in + pos};
+    float* outs[2] = {out0 + pos, out1 + pos};
+    spb.process(ins, outs, blocks[b], &ctx, spbProcess, &state);
+    pos += blocks[b];
+  }
+  return 0;
+}

@@ -1628,3 +1628,30 @@ int mlorc_demultiplex(const float* sel, size_t sel_elems, const float* in, float
   }
   return MLGPU_OK;
 }
+
+/* mixdown, same contract and the SAME summation order as mlgpu_mixdown (include/mlgpu.h): pairwise tree inside each
+ * group of 64 consecutive voices (a[i] += a[i + d], d = 1, 2, ... 32; voices beyond V count as +0), then the groups
+ * left to right. The reference has no mixdown function — a Synth accumulates voices with `outputs +=` in voice order
+ * (source/app/MLSynth.h:43-57); tests also bound the difference from that sequential order. sig: [V][64T]. */
+int mlorc_mixdown(const float* sig, size_t V, size_t T, const float* gains, float* out)
+{
+  const size_t S = T * VEC, groups = (V + 63) / 64;
+  for (size_t s = 0; s < S; ++s)
+  {
+    float total = 0.f;
+    for (size_t g = 0; g < groups; ++g)
+    {
+      float a[64];
+      for (int i = 0; i < 64; ++i)
+      {
+        const size_t v = g * 64 + (size_t)i;
+        a[i] = (v < V) ? (gains ? sig[v * S + s] * gains[v] : sig[v * S + s]) : 0.f;
+      }
+      for (int d = 1; d < 64; d <<= 1)
+        for (int i = 0; i + d < 64; i += 2 * d) a[i] = a[i] + a[i + d];
+      total = (g == 0) ? a[0] : total + a[0];
+    }
+    out[s] = total;
+  }
+  return MLGPU_OK;
+}

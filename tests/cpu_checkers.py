@@ -282,6 +282,16 @@ class Oracle(_Checker):
         assert fnc(_ptr(sel, c_f32p), sel.size, _ptr(x, c_f32p), arr, n_outputs, x.size, 1 if linear else 0) == 0
         return outs
 
+    def mixdown(self, sig, gains=None):
+        fnc = self.lib.mlorc_mixdown
+        fnc.argtypes = [c_f32p, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p]
+        sig = np.ascontiguousarray(sig, np.float32)
+        V, S = sig.shape
+        g = None if gains is None else np.ascontiguousarray(gains, np.float32)
+        out = np.empty(S, np.float32)
+        assert fnc(_ptr(sig, c_f32p), V, S // 64, _ptr(g, c_f32p), _ptr(out, c_f32p)) == 0
+        return out
+
     def libm_sinf(self, x):
         """The restated glibc sinf (oracle/ml_oracle.c) on an array."""
         self.lib.mlorc_libm_sinf.restype = ctypes.c_float
@@ -324,6 +334,9 @@ class Ref(_Checker):
         L.mlref_bench_op.restype = ctypes.c_double
         L.mlref_bench_op.argtypes = [ctypes.c_int, c_f32p, c_f32p, sz, ctypes.c_int, ctypes.c_int]
 
+    def dspbuffer(self, size):
+        return _RefDSPBuffer(self.lib, size)
+
     def rows_case(self, name, inputs, max_rows=16):
         """The reference's own row-plumbing / routing template instantiation called `name` (oracle/ref_wrapper.cpp:
         mlref_rows_case). inputs: list of [rows][64] arrays. Returns the output rows [r][64]."""
@@ -354,6 +367,63 @@ class Ref(_Checker):
         x = np.ascontiguousarray(x, np.float32)
         out = np.empty_like(x)
         return self.lib.mlref_bench_op(int(op), _ptr(x, c_f32p), _ptr(out, c_f32p), x.size, n_threads, reps)
+
+
+class _RefDSPBuffer:
+    """The reference's own DSPBuffer (MLDSPBuffer.h) behind oracle/ref_wrapper.cpp, same method names as
+    madronalib_amd.DSPBuffer."""
+
+    def __init__(self, lib, size):
+        self.L = lib
+        sz, vp = ctypes.c_size_t, ctypes.c_void_p
+        for name, res, args in [("create", vp, [ctypes.c_int]), ("destroy", None, [vp]), ("read_available", sz, [vp]),
+                                ("write_available", sz, [vp]), ("write", None, [vp, c_f32p, sz]), ("read", sz, [vp, c_f32p, sz]),
+                                ("discard", None, [vp, sz]), ("clear", None, [vp]), ("write_overlap_add", None, [vp, c_f32p, sz, sz]),
+                                ("read_overlap", None, [vp, c_f32p, sz, sz]), ("peek_most_recent", None, [vp, c_f32p, sz])]:
+            f = getattr(lib, "mlref_dspbuffer_" + name)
+            f.restype, f.argtypes = res, args
+        self.h = ctypes.c_void_p(lib.mlref_dspbuffer_create(int(size)))
+
+    def __del__(self):
+        try:
+            self.L.mlref_dspbuffer_destroy(self.h)
+        except Exception:
+            pass
+
+    def read_available(self):
+        return self.L.mlref_dspbuffer_read_available(self.h)
+
+    def write_available(self):
+        return self.L.mlref_dspbuffer_write_available(self.h)
+
+    def write(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        self.L.mlref_dspbuffer_write(self.h, _ptr(x, c_f32p), x.size)
+
+    def read(self, n):
+        out = np.full(n, np.float32(-99.0))
+        got = self.L.mlref_dspbuffer_read(self.h, _ptr(out, c_f32p), n)
+        return out[:got].copy()
+
+    def discard(self, n):
+        self.L.mlref_dspbuffer_discard(self.h, n)
+
+    def clear(self):
+        self.L.mlref_dspbuffer_clear(self.h)
+
+    def write_with_overlap_add(self, x, overlap):
+        x = np.ascontiguousarray(x, np.float32)
+        self.L.mlref_dspbuffer_write_overlap_add(self.h, _ptr(x, c_f32p), x.size, overlap)
+
+    def read_with_overlap(self, n, overlap):
+        out = np.full(n, np.float32(-99.0))
+        self.L.mlref_dspbuffer_read_overlap(self.h, _ptr(out, c_f32p), n, overlap)
+        return out
+
+    def peek_most_recent(self, n):
+        out = np.full(n, np.float32(-99.0))
+        self.L.mlref_dspbuffer_peek_most_recent(self.h, _ptr(out, c_f32p), n)
+        return out
 
 
 def ref_available():

@@ -1,0 +1,116 @@
+"""mlgpu_process_buffer (the engine's SignalProcessBuffer) against the reference's own SignalProcessBuffer driven
+with the same sequence of host block sizes (oracle/_ref/libdropin_ref.so: spb_ref_run), plus mixdown / broadcast."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from inputs import assert_bits_equal, lcg_noise
+from madronalib_amd.constants import Layout, Op, Proc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+c_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import madronalib_amd as ml
+    e = ml.Engine(0)
+    yield e
+    e.close()
+
+
+def _spb_ref(max_frames, blocks, x):
+    so = os.path.join(ROOT, "oracle", "_ref", "libdropin_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libdropin_ref.so not available here")
+    L = ctypes.CDLL(so)
+    L.spb_ref_run.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, c_f32p, c_f32p, c_f32p]
+    o0, o1 = np.zeros_like(x), np.zeros_like(x)
+    arr = (ctypes.c_int * len(blocks))(*blocks)
+    assert L.spb_ref_run(max_frames, arr, len(blocks), x.ctypes.data_as(c_f32p), o0.ctypes.data_as(c_f32p), o1.ctypes.data_as(c_f32p)) == 0
+    return o0, o1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_frames,blocks", [(512, [64] * 10), (512, [100, 28, 64, 1, 511, 512, 3, 200, 64, 64, 77]),
+                                               (1024, [1000, 24, 1024, 5, 5, 5, 900]), (64, [64, 64, 10, 54, 64])])
+def test_block_adaptor_matches_reference_signal_process_buffer(eng, max_frames, blocks):
+    import madronalib_amd as ml
+    total = sum(blocks)
+    x = lcg_noise(np.array([7], np.uint32), total)[0]
+    want0, want1 = _spb_ref(max_frames, blocks, x)
+    # the same process function as a 1-voice graph: out0 = Lopass(in0), out1 = in0 * 0.5
+    desc = [dict(name="x", type="input"), dict(name="half", type="const", value=0.5),
+            dict(name="lp", type="proc", kind=Proc.LOPASS, inputs=["x"]), dict(name="y1", type="op", kind=Op.MULTIPLY, inputs=["x", "half"])]
+    g = ml.Graph(eng, 1, desc, ["lp", "y1"])
+    g.set_coeffs("lp", ml.Lopass.makeCoeffs(0.05, 0.9))
+    pb = ml.ProcessBuffer(eng, 1, 2, max_frames)
+    calls = []
+
+    def fn(n_vectors, d_in, d_out):
+        calls.append(n_vectors)
+        g.process(n_vectors, d_in, d_out, Layout.VOICE_MAJOR, Layout.VOICE_MAJOR)
+
+    got0, got1, pos = [], [], 0
+    for b in blocks:
+        o = pb.process([x[pos:pos + b]], b, fn)
+        got0.append(o[0]), got1.append(o[1])
+        pos += b
+    assert_bits_equal(np.concatenate(got0), want0, True, "SignalProcessBuffer out0")
+    assert_bits_equal(np.concatenate(got1), want1, True, "SignalProcessBuffer out1")
+    assert len(calls) <= len(blocks)           # at most ONE callback per block (the reference: one per 64 frames)
+    assert sum(calls) * 64 >= total
+    with pytest.raises(ml.MlgpuError):
+        pb.process([x[:1]], max_frames + 1, fn)   # larger than max_frames: refused (the reference silently returns)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,T", [(1, 2), (64, 3), (100, 2), (1000, 4), (4097, 1)])
+@pytest.mark.parametrize("layout", [Layout.QUAD, Layout.ROWS, Layout.VOICE_MAJOR])
+def test_mixdown_vs_oracle(eng, oracle, V, T, layout):
+    sig = lcg_noise(np.arange(V, dtype=np.uint32) + 3, 64 * T)
+    gains = np.random.default_rng(V).uniform(-1, 1, V).astype(np.float32)
+    d_vm = eng.to_device(sig)
+    d_sig = d_vm
+    if layout != Layout.VOICE_MAJOR:
+        d_sig = eng.alloc(sig.nbytes)
+        eng.layout_convert(d_vm, Layout.VOICE_MAJOR, d_sig, layout, V, T)
+    d_out = eng.alloc(4 * 64 * T)
+    for g in (None, gains):
+        eng.mixdown(d_sig, layout, V, T, d_out, None if g is None else eng.to_device(g))
+        got = d_out.download(np.float32, 64 * T)
+        assert_bits_equal(got, oracle.mixdown(sig, g), True, f"mixdown V={V}")
+        # vs a Synth's sequential `outputs += voice` (MLSynth.h:43-57): reassociation only
+        seq = np.zeros(64 * T, np.float32)
+        for v in range(V):
+            seq = seq + (sig[v] if g is None else sig[v] * g[v])
+        assert np.abs(got - seq).max() <= 1e-5 * max(1.0, np.sqrt(V)) * np.abs(sig).max()
+
+
+@pytest.mark.gpu
+def test_broadcast_input_layout(eng, oracle):
+    """One host audio channel (a single-voice signal) feeding every voice of a bank and of a graph."""
+    import madronalib_amd as ml
+    V, T = 300, 5
+    x = lcg_noise(np.array([1], np.uint32), 64 * T)
+    co = np.stack([oracle.make_coeffs("lopass", 0.01 + 0.4 * v / V, 0.7) for v in range(V)], 1)
+    st = oracle.chain_clear([Proc.LOPASS], V)
+    want = oracle.chain_process([Proc.LOPASS], T, co, st, np.repeat(x, V, 0))
+    d_x = eng.to_device(x)
+    bank = eng.bank([Proc.LOPASS], V)
+    bank.set_all_coeffs(co)
+    d_out = eng.alloc(4 * V * T * 64)
+    bank.process(T, d_out, Layout.VOICE_MAJOR, d_x, Layout.BROADCAST)
+    assert_bits_equal(d_out.download(np.float32).reshape(V, -1), want, True, "bank, broadcast input")
+    # graph: one broadcast input next to a per-voice input
+    desc = [dict(name="x", type="input"), dict(name="g", type="input"), dict(name="lp", type="proc", kind=Proc.LOPASS, inputs=["x"]),
+            dict(name="y", type="op", kind=Op.MULTIPLY, inputs=["lp", "g"])]
+    gr = ml.Graph(eng, V, desc, ["y"])
+    gr.set_coeffs("lp", [np.ascontiguousarray(r) for r in co])
+    gr.set_input_layout(0, Layout.BROADCAST)
+    gsig = lcg_noise(np.arange(V, dtype=np.uint32) + 50, 64 * T)
+    d_g = eng.to_device(gsig)
+    gr.process(T, [d_x, d_g], [d_out], Layout.VOICE_MAJOR, Layout.VOICE_MAJOR)
+    assert_bits_equal(d_out.download(np.float32).reshape(V, -1), (want * gsig).astype(np.float32), True, "graph, broadcast + per-voice inputs")
