@@ -188,8 +188,16 @@ typedef enum mlgpu_proc
                                   *          currVec[64]}; defaults 32, 1/32, remaining -1 (:437-441);
                                   *          setGlideTimeInSamples: mlgpu_linear_glide_make_coeffs;
                                   *          setValue(f): target = f, vectorsRemaining = 0 */
-  MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE = 66 /* :517-590 C{samplesPerGlide:i32, dyPerSample}
+  MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE = 66, /* :517-590 C{samplesPerGlide:i32, dyPerSample}
                                   *          S{curr, step, target, samplesRemaining:i32}; nextSample per sample */
+  /* delay lines, MLDSPFilters.h:799-1106: per-voice rings in HBM, sized with mlgpu_graph_set_max_delay (graph nodes
+   * only). Valid delays are 0 <= d <= ring length - 64, as in the reference (:817-819). */
+  MLGPU_PROC_INTEGER_DELAY = 80,      /* :801-914   C{}      S{writeIndex:u32, delayInSamples:i32}; forms (x), (x, delay) */
+  MLGPU_PROC_ALLPASS1 = 81,           /* :918-964   C{coeff} S{x1, y1}; coeff from mlgpu_allpass1_make_coeffs */
+  MLGPU_PROC_FRACTIONAL_DELAY = 82,   /* :971-1044  C{}      S{writeIndex, x1, y1, delayInt:i32, allpassCoeff}; forms (x),
+                                       *            (x, delay), (x, delay, changeTicks:int mask); setDelayInSamples:
+                                       *            mlgpu_fractional_delay_make_state -> state words 3, 4 */
+  MLGPU_PROC_PITCHBENDABLE_DELAY = 83 /* :1050-1106 C{}      S{delay1[5], delay2[5]} two rings; form (x, delay) */
 } mlgpu_proc;
 
 /* ------------------------------------------------------------------------- */
@@ -399,6 +407,15 @@ int mlgpu_graph_add_param(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_control(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_vop(mlgpu_graph* g, int vop, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_const(mlgpu_graph* g, float value);
+/* Delay-line memory of a delay node (before compile): IntegerDelay::setMaxDelayInSamples (MLDSPFilters.h:823-831),
+ * i.e. rings of 2^bitsToContain(floor(d) + 64) floats per voice (PitchbendableDelay: two of them). */
+int mlgpu_graph_set_max_delay(mlgpu_graph* g, int proc_node, float max_delay_in_samples);
+/* One-vector feedback: a DSPVector the reference keeps from one process call to the next (Allpass::vy1
+ * MLDSPFilters.h:1115, FDN::mDelayInputVectors :1168, FeedbackDelayFunction::vy1 MLDSPFunctional.h:276, or a user's
+ * own state member). add_feedback returns a node whose value at sample n is what set_feedback's `value_node` had at
+ * sample n of the PREVIOUS DSPVector (zeros at first); set_feedback may name any node, also one added later. */
+int mlgpu_graph_add_feedback(mlgpu_graph* g, const char* name);
+int mlgpu_graph_set_feedback(mlgpu_graph* g, int feedback_node, int value_node);
 /* routing nodes (MLDSPRouting.h): input_nodes[0] is the selector.
  *   MLGPU_ROUTE_MULTIPLEX / _LINEAR      input_nodes[1..n] the candidates (n <= 8); `index` ignored
  *   MLGPU_ROUTE_DEMULTIPLEX / _LINEAR    input_nodes[1] the signal; this node is output `index` of `n_outputs` */
@@ -512,6 +529,9 @@ void mlgpu_onepole_make_coeffs(float omega, float out2[2]);            /* :458-4
 float mlgpu_dcblocker_make_coeffs(float omega);                        /* :498 */
 void mlgpu_adsr_calc_coeffs(float a, float d, float s, float r, float sr, float out4[4]); /* :679-686 */
 float mlgpu_db_to_gain(float dB);                                      /* :30 */
+float mlgpu_allpass1_make_coeffs(float d);                              /* Allpass1::makeCoeffs, :938-943 */
+/* FractionalDelay::setDelayInSamples (:991-1007) -> {delayInt as int32 bits, allpass coefficient} = state words 3, 4 */
+void mlgpu_fractional_delay_make_state(float delay_in_samples, float out2[2]);
 /* LinearGlide::setGlideTimeInSamples (MLDSPGens.h:444-449) -> C{vectorsPerGlide:i32 bits, dyPerVector} */
 void mlgpu_linear_glide_make_coeffs(float glide_time_in_samples, float out2[2]);
 /* SampleAccurateLinearGlide::setGlideTimeInSamples (:527-532) -> C{samplesPerGlide:i32 bits, dyPerSample} */

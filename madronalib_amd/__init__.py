@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, Route, RowOp, RowsRule, Status, Vop
 
-__all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "LinearGlide", "SampleAccurateLinearGlide",
+__all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "Allpass1", "FractionalDelay", "LinearGlide", "SampleAccurateLinearGlide",
            "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
            "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
 
@@ -480,6 +480,9 @@ class Graph:
         if description is not None:
             for n in description:
                 self.add(**n)
+            for n in description:   # feedback sources may be nodes defined after the feedback node
+                if n["type"] == "feedback":
+                    self.set_feedback(n["name"], n["source"])
             for o in (outputs or [description[-1]["name"]]):
                 self.add_output(o)
             self.compile()
@@ -505,7 +508,13 @@ class Graph:
             self.ids[name] = r
         return r
 
-    def add(self, name, type, kind=None, inputs=(), value=None, index=0, n_outputs=0):
+    def set_feedback(self, feedback_node, value_node):
+        self.engine._check(self.L.mlgpu_graph_set_feedback(self.h, self._id(feedback_node), self._id(value_node)))
+
+    def set_max_delay(self, node, max_delay_in_samples):
+        self.engine._check(self.L.mlgpu_graph_set_max_delay(self.h, self._id(node), float(max_delay_in_samples)))
+
+    def add(self, name, type, kind=None, inputs=(), value=None, index=0, n_outputs=0, source=None, max_delay=None):
         bname = name.encode() if name else None
         ins = [self._id(i) for i in inputs]
         arr = (ctypes.c_int * max(1, len(ins)))(*ins)
@@ -523,8 +532,13 @@ class Graph:
             return self._ret(self.L.mlgpu_graph_add_param(self.h, bname), name)
         if type == "const":
             return self._ret(self.L.mlgpu_graph_add_const(self.h, float(value)), name)
+        if type == "feedback":
+            return self._ret(self.L.mlgpu_graph_add_feedback(self.h, bname), name)
         if type == "proc":
-            return self._ret(self.L.mlgpu_graph_add_proc(self.h, int(kind), arr, len(ins), bname), name)
+            r = self._ret(self.L.mlgpu_graph_add_proc(self.h, int(kind), arr, len(ins), bname), name)
+            if max_delay is not None:
+                self.set_max_delay(r, max_delay)
+            return r
         if type == "op":
             return self._ret(self.L.mlgpu_graph_add_op(self.h, int(kind), arr, len(ins), bname), name)
         raise ValueError(type)
@@ -684,6 +698,19 @@ class ADSR:
     @staticmethod
     def calcCoeffs(a, d, s, r, sr):
         return _mk("mlgpu_adsr_calc_coeffs", 4, a, d, s, r, sr)
+
+
+class Allpass1:
+    @staticmethod
+    def makeCoeffs(d):
+        return np.float32(_lib.load().mlgpu_allpass1_make_coeffs(float(d)))
+
+
+class FractionalDelay:
+    @staticmethod
+    def makeState(delay_in_samples):
+        """setDelayInSamples -> (delayInt as int32 bits, allpass coefficient): state words 3 and 4"""
+        return _mk("mlgpu_fractional_delay_make_state", 2, delay_in_samples)
 
 
 class LinearGlide:

@@ -119,6 +119,11 @@ def _declare(L):
     sig("mlgpu_graph_add_param", i, [vp, c.c_char_p])
     sig("mlgpu_graph_add_const", i, [vp, f])
     sig("mlgpu_graph_add_control", i, [vp, c.c_char_p])
+    sig("mlgpu_graph_add_feedback", i, [vp, c.c_char_p])
+    sig("mlgpu_graph_set_feedback", i, [vp, i, i])
+    sig("mlgpu_graph_set_max_delay", i, [vp, i, f])
+    sig("mlgpu_allpass1_make_coeffs", f, [f])
+    sig("mlgpu_fractional_delay_make_state", None, [f, fp])
     sig("mlgpu_graph_add_vop", i, [vp, i, ip, i, c.c_char_p])
     sig("mlgpu_graph_process_ctl", i, [vp, sz, pp, i, pp, pp, i])
     sig("mlgpu_linear_glide_make_coeffs", None, [f, fp])

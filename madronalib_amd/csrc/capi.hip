@@ -428,10 +428,11 @@ extern "C"
         delete b;
         return fail(e, MLGPU_ERR_INVALID, "bank_create: unknown processor kind");
       }
-      if (mlgpu_proc_is_vector_rate(procs[p]))
+      if (mlgpu_proc_is_graph_only(procs[p]))
       {
         delete b;
-        return fail(e, MLGPU_ERR_UNSUPPORTED, "bank_create: Interpolator1 / LinearGlide take one float per DSPVector; use them as graph nodes");
+        return fail(e, MLGPU_ERR_UNSUPPORTED,
+                    "bank_create: Interpolator1 / LinearGlide (one float per DSPVector in) and the delay lines (per-voice rings) are graph nodes");
       }
       b->kinds.push_back(procs[p]);
       b->cOff.push_back(b->NC);
@@ -544,8 +545,8 @@ extern "C"
       mlgpu_proc_clear_state(b->kinds[p], words, true);
       for (int i = 0; i < b->ns[p]; ++i)
       {
-        // ADSR::clear() only sets segment = off (MLDSPFilters.h:702); its other members keep their values
-        if (b->kinds[p] == MLGPU_PROC_ADSR && i != 7) continue;
+        // e.g. ADSR::clear() only sets segment = off (MLDSPFilters.h:702); its other members keep their values
+        if (!((mlgpu_proc_clear_mask(b->kinds[p]) >> i) & 1)) continue;
         HIP_TRY(e, mlgpu_launch_fill32(b->d_state + (size_t)(b->sOff[p] + i) * b->V, words[i], b->V, e->stream));
       }
     }

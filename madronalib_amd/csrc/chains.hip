@@ -109,6 +109,7 @@ const std::vector<ChainEntry>& registry()
       makeEntry<P(ADSR)>("chain_kernel<ADSR>"),
       makeEntry<P(GAIN)>("chain_kernel<Gain>"),
       makeEntry<P(SAMPLE_ACCURATE_LINEAR_GLIDE)>("chain_kernel<SampleAccurateLinearGlide>"),
+      makeEntry<P(ALLPASS1)>("chain_kernel<Allpass1>"),
       // fused chains of the BASELINE.json configs
       makeEntry<P(SINE_GEN), P(LOPASS)>("chain_kernel<SineGen,Lopass>"),                       // config 1
       makeEntry<P(SAW_GEN), P(BANDPASS), P(GAIN)>("chain_kernel<SawGen,Bandpass,Gain>"),       // config 3
@@ -151,13 +152,39 @@ static bool graphOnlyInfo(int kind, int* nc, int* ns)
   {
     case MLGPU_PROC_INTERPOLATOR1: *nc = Proc<MLGPU_PROC_INTERPOLATOR1>::NC; *ns = Proc<MLGPU_PROC_INTERPOLATOR1>::NS; return true;
     case MLGPU_PROC_LINEAR_GLIDE: *nc = Proc<MLGPU_PROC_LINEAR_GLIDE>::NC; *ns = Proc<MLGPU_PROC_LINEAR_GLIDE>::NS; return true;
+    // delay lines own HBM rings that only a graph allocates
+    case MLGPU_PROC_INTEGER_DELAY: *nc = Proc<MLGPU_PROC_INTEGER_DELAY>::NC; *ns = Proc<MLGPU_PROC_INTEGER_DELAY>::NS; return true;
+    case MLGPU_PROC_FRACTIONAL_DELAY: *nc = Proc<MLGPU_PROC_FRACTIONAL_DELAY>::NC; *ns = Proc<MLGPU_PROC_FRACTIONAL_DELAY>::NS; return true;
+    case MLGPU_PROC_PITCHBENDABLE_DELAY: *nc = Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>::NC; *ns = Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>::NS; return true;
     default: return false;
   }
 }
-bool mlgpu_proc_is_vector_rate(int kind)
+bool mlgpu_proc_is_vector_rate(int kind) { return kind == MLGPU_PROC_INTERPOLATOR1 || kind == MLGPU_PROC_LINEAR_GLIDE; }
+bool mlgpu_proc_is_graph_only(int kind)
 {
   int nc, ns;
   return graphOnlyInfo(kind, &nc, &ns);
+}
+int mlgpu_proc_rings(int kind)  // delay rings per voice
+{
+  switch (kind)
+  {
+    case MLGPU_PROC_INTEGER_DELAY: case MLGPU_PROC_FRACTIONAL_DELAY: return 1;
+    case MLGPU_PROC_PITCHBENDABLE_DELAY: return 2;
+    default: return 0;
+  }
+}
+// which state words T::clear() resets (bit i = word i); delay lines keep their write index and delay time
+uint64_t mlgpu_proc_clear_mask(int kind)
+{
+  switch (kind)
+  {
+    case MLGPU_PROC_ADSR: return 1ull << 7;             // only the segment, MLDSPFilters.h:698
+    case MLGPU_PROC_INTEGER_DELAY: return 0;             // only the buffer, :833
+    case MLGPU_PROC_FRACTIONAL_DELAY: return 0x6;        // + Allpass1 x1, y1, :985-989
+    case MLGPU_PROC_PITCHBENDABLE_DELAY: return 0x6 | (0x6 << 5);
+    default: return ~0ull;
+  }
 }
 int mlgpu_proc_nc(int kind)
 {

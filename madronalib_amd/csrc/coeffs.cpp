@@ -89,6 +89,25 @@ extern "C"
   }
   float mlgpu_db_to_gain(float dB) { return powf(10.f, dB / 40.f); }  // :30
 
+  float mlgpu_allpass1_make_coeffs(float d)  // :938-943
+  {
+    const float xm1 = (d - 1.f);
+    return -0.53f * xm1 + 0.24f * xm1 * xm1;
+  }
+  void mlgpu_fractional_delay_make_state(float d, float* o)  // :991-1007
+  {
+    const float fDelayInt = floorf(d);
+    int32_t delayInt = static_cast<int32_t>(fDelayInt);
+    float delayFrac = d - fDelayInt;
+    if ((delayFrac < 0.618f) && (delayInt > 0))
+    {
+      delayFrac += 1.f;
+      delayInt -= 1;
+    }
+    memcpy(&o[0], &delayInt, 4);
+    o[1] = mlgpu_allpass1_make_coeffs(delayFrac);
+  }
+
   // LinearGlide::setGlideTimeInSamples, MLDSPGens.h:444-449: glide time quantized to whole DSPVectors
   void mlgpu_linear_glide_make_coeffs(float t, float* o)
   {

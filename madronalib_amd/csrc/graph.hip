@@ -12,6 +12,7 @@
 // HBM. Identical graphs share one compiled module per process. The same generator produces fused
 // kernels for processor chains that have no ahead-of-time instantiation (mlgpu_jit_chain).
 #include <hip/hiprtc.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -145,7 +146,8 @@ enum NodeType
   NODE_OP = 4,
   NODE_CONTROL = 5,  // streamed, one float per DSPVector per voice
   NODE_VOP = 6,      // index-dependent vector generator (columnIndex, rangeOpen, ...)
-  NODE_ROUTE = 7     // multiplex / demultiplex (MLDSPRouting.h); in[0] is the selector
+  NODE_ROUTE = 7,    // multiplex / demultiplex (MLDSPRouting.h); in[0] is the selector
+  NODE_FEEDBACK = 8  // value of another node one DSPVector ago (64 state words per voice)
 };
 
 // how often a node's value changes: per voice (params, consts and ops on them), per DSPVector (controls and
@@ -166,6 +168,9 @@ struct Node
   float value{0.f};
   int slot{0};            // input index / param index / control index; demultiplex: output index
   int nOut{0};            // demultiplex: number of outputs
+  size_t ringLen{0};      // delay nodes: floats per ring (power of two), 0 = not set
+  size_t memOff{0};       // delay nodes: first ring at d_mem + memOff * V
+  int fbSource{-1};       // feedback nodes: the node whose value is stored for the next vector
   int rate{RATE_AUDIO};
   int cOff{0}, sOff{0}, nc{0}, ns{0};
 };
@@ -201,6 +206,8 @@ struct mlgpu_graph
   float* d_coeffs{nullptr};
   uint32_t* d_state{nullptr};
   float* d_params{nullptr};
+  float* d_mem{nullptr};
+  size_t memFloatsPerVoice{0};
   int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1};
 };
 
@@ -227,6 +234,8 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i)
     case NODE_PROC:
       if (mlgpu_proc_is_vector_rate(n.kind))
         s << "p" << i << ".next_n(q * 4 + k)";
+      else if (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY)
+        s << "p" << i << ".next_i(q * 4 + k, " << arg(0) << ", " << arg(1) << ")";
       else if ((n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
       {
         // launch-constant frequency: the polyBLEP range test was done once per wavefront (odd<i>)
@@ -248,6 +257,7 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i)
       for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
       s << ")";
       break;
+    case NODE_FEEDBACK: s << "u2f(a.state[(size_t)(" << n.sOff << " + q * 4 + k) * a.V + v])"; break;
     case NODE_ROUTE:
       if (n.kind == MLGPU_ROUTE_MULTIPLEX || n.kind == MLGPU_ROUTE_MULTIPLEX_LINEAR)
       {
@@ -297,7 +307,9 @@ std::string generateGraphSource(mlgpu_graph* g)
     if (n.type == NODE_PROC)
     {
       s << "  Proc<" << n.kind << "> p" << i << ";\n  const VoiceMem m" << i << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v, a.state + (size_t)"
-        << n.sOff << " * a.V + v, a.V};\n  p" << i << ".load(m" << i << ", tables);\n";
+        << n.sOff << " * a.V + v, a.V";
+      if (n.ringLen) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v, " << (n.ringLen - 1) << "u";
+      s << "};\n  p" << i << ".load(m" << i << ", tables);\n";
     }
     else if (n.type == NODE_INPUT)
     {
@@ -333,6 +345,10 @@ std::string generateGraphSource(mlgpu_graph* g)
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].rate == RATE_AUDIO) emit(i, "        ");
   for (size_t o = 0; o < g->outputs.size(); ++o) s << "        y" << o << "[k] = n" << g->outputs[o] << ";\n";
+  // feedback: keep this sample's value for the same sample of the next DSPVector (its old value was read above)
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+    if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].fbSource >= 0)
+      s << "        a.state[(size_t)(" << g->nodes[i].sOff << " + q * 4 + k) * a.V + v] = f2u(n" << g->nodes[i].fbSource << ");\n";
   s << "      }\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
     s << "      __builtin_nontemporal_store(y" << o << ", out" << o << " + t * a.out[" << o << "].strideT + q * a.out[" << o << "].strideQ);\n";
@@ -370,6 +386,14 @@ int checkNode(mlgpu_graph* g, int node, int type)
   if (!g) return MLGPU_ERR_INVALID;
   if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "node index out of range");
   if (g->nodes[node].type != type) return gfail(g, MLGPU_ERR_INVALID, "node has the wrong type for this call");
+  return MLGPU_OK;
+}
+// nodes that own state words: processors and feedback nodes (their stored DSPVector, 64 words)
+int checkStateNode(mlgpu_graph* g, int node)
+{
+  if (!g) return MLGPU_ERR_INVALID;
+  if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "node index out of range");
+  if (g->nodes[node].type != NODE_PROC && g->nodes[node].type != NODE_FEEDBACK) return gfail(g, MLGPU_ERR_INVALID, "node has no state");
   return MLGPU_OK;
 }
 }  // namespace
@@ -444,6 +468,26 @@ extern "C"
     const int ls = mlgpu_graph_add_proc(&g, MLGPU_PROC_LO_SHELF, lsIn, 6, "loshelf");
     const int hsIn[7] = {ls, ramp, ci, rc, ro, sg, two};
     const int hs = mlgpu_graph_add_proc(&g, MLGPU_PROC_HI_SHELF, hsIn, 7, "hishelf");
+    // delay lines and one-vector feedback (an Allpass<PitchbendableDelay> written out)
+    const int fb = mlgpu_graph_add_feedback(&g, "vy1");
+    const int idIn[2] = {hs, glide};
+    const int idl = mlgpu_graph_add_proc(&g, MLGPU_PROC_INTEGER_DELAY, idIn, 2, "idelay");
+    const int fdIn[3] = {idl, glide, gate};
+    const int fdl = mlgpu_graph_add_proc(&g, MLGPU_PROC_FRACTIONAL_DELAY, fdIn, 3, "fdelay");
+    const int pbIn[2] = {fdl, glide};
+    const int pbd = mlgpu_graph_add_proc(&g, MLGPU_PROC_PITCHBENDABLE_DELAY, pbIn, 2, "pbdelay");
+    const int ap1 = mlgpu_graph_add_proc(&g, MLGPU_PROC_ALLPASS1, &pbd, 1, "ap1");
+    const int fbmIn[2] = {ap1, fb};
+    const int fbm = mlgpu_graph_add_op(&g, MLGPU_OP_ADD, fbmIn, 2, "fbsum");
+    ok = (fb > 0) && (fbm > 0) && (mlgpu_graph_set_feedback(&g, fb, fbm) == MLGPU_OK) && (mlgpu_graph_set_max_delay(&g, idl, 1000.f) == MLGPU_OK) &&
+         (mlgpu_graph_set_max_delay(&g, fdl, 100.f) == MLGPU_OK) && (mlgpu_graph_set_max_delay(&g, pbd, 3000.f) == MLGPU_OK) &&
+         (mlgpu_graph_add_output(&g, fbm) == MLGPU_OK) && ok;
+    for (Node& nn : g.nodes)  // what graph_compile does before generating code
+      if (nn.type == NODE_PROC && mlgpu_proc_rings(nn.kind))
+      {
+        nn.memOff = g.memFloatsPerVoice;
+        g.memFloatsPerVoice += nn.ringLen * (size_t)mlgpu_proc_rings(nn.kind);
+      }
     const int muxIn[4] = {gate, hs, ls, lp3};
     const int mux = mlgpu_graph_add_route(&g, MLGPU_ROUTE_MULTIPLEX, muxIn, 4, 0, 0, "mux");
     const int muxl = mlgpu_graph_add_route(&g, MLGPU_ROUTE_MULTIPLEX_LINEAR, muxIn, 4, 0, 0, "muxl");
@@ -488,6 +532,7 @@ extern "C"
     if (g->d_coeffs) hipFree(g->d_coeffs);
     if (g->d_state) hipFree(g->d_state);
     if (g->d_params) hipFree(g->d_params);
+    if (g->d_mem) hipFree(g->d_mem);
     delete g;
     return MLGPU_OK;
   }
@@ -546,6 +591,42 @@ extern "C"
     n.name = name ? name : "";
     return addNode(g, std::move(n));
   }
+  int mlgpu_graph_add_feedback(mlgpu_graph* g, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    Node n;
+    n.type = NODE_FEEDBACK;
+    n.kind = 0;
+    n.name = name ? name : "";
+    n.ns = MLGPU_FLOATS_PER_DSPVECTOR;
+    n.sOff = g->NS;
+    const int id = addNode(g, std::move(n));
+    if (id >= 0) g->NS += MLGPU_FLOATS_PER_DSPVECTOR;
+    return id;
+  }
+  int mlgpu_graph_set_feedback(mlgpu_graph* g, int fbNode, int valueNode)
+  {
+    int st = checkNode(g, fbNode, NODE_FEEDBACK);
+    if (st) return st;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (valueNode < 0 || valueNode >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_set_feedback: unknown value node");
+    g->nodes[fbNode].fbSource = valueNode;
+    return MLGPU_OK;
+  }
+  int mlgpu_graph_set_max_delay(mlgpu_graph* g, int node, float maxDelayInSamples)
+  {
+    int st = checkNode(g, node, NODE_PROC);
+    if (st) return st;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (mlgpu_proc_rings(g->nodes[node].kind) == 0) return gfail(g, MLGPU_ERR_INVALID, "graph_set_max_delay: not a delay node");
+    if (!(maxDelayInSamples >= 0.f) || maxDelayInSamples > 16777216.f) return gfail(g, MLGPU_ERR_RANGE, "graph_set_max_delay: 0 .. 2^24 samples");
+    // IntegerDelay::setMaxDelayInSamples, MLDSPFilters.h:823-831
+    const int dMax = (int)floorf(maxDelayInSamples);
+    int bits = 0;
+    while ((1 << bits) < dMax + MLGPU_FLOATS_PER_DSPVECTOR) bits++;
+    g->nodes[node].ringLen = (size_t)1 << bits;
+    return MLGPU_OK;
+  }
   int mlgpu_graph_add_route(mlgpu_graph* g, int route, const int* inputs, int nIn, int index, int nOutputs, const char* name)
   {
     if (!g) return -MLGPU_ERR_INVALID;
@@ -585,6 +666,9 @@ extern "C"
     if (kind == MLGPU_PROC_LOPASS) okArity = (nIn == 1 || nIn == 3);
     if (kind == MLGPU_PROC_LO_SHELF) okArity = (nIn == 1 || nIn == 6);
     if (kind == MLGPU_PROC_HI_SHELF) okArity = (nIn == 1 || nIn == 7);
+    if (kind == MLGPU_PROC_INTEGER_DELAY) okArity = (nIn == 1 || nIn == 2);     // (x), (x, delay) MLDSPFilters.h:834,877
+    if (kind == MLGPU_PROC_FRACTIONAL_DELAY) okArity = (nIn >= 1 && nIn <= 3);  // (x), (x, delay), (x, delay, ticks) :1013-1043
+    if (kind == MLGPU_PROC_PITCHBENDABLE_DELAY) okArity = (nIn == 2);           // (x, delay) :1098
     if (!okArity || (nIn > 0 && !inputs)) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: wrong number of inputs");
     if (mlgpu_proc_is_vector_rate(kind) && (inputs[0] < 0 || inputs[0] >= (int)g->nodes.size() || g->nodes[inputs[0]].rate > RATE_VECTOR))
       return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: Interpolator1 / LinearGlide take one float per DSPVector (a control, param or const node)");
@@ -643,6 +727,16 @@ extern "C"
     if (g->outputs.empty()) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: no outputs");
     mlgpu_engine* e = g->e;
     if (hipSetDevice(e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
+    size_t memFloats = 0;
+    for (Node& n : g->nodes)
+    {
+      if (n.type == NODE_FEEDBACK && n.fbSource < 0) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: feedback node '" + n.name + "' has no source (graph_set_feedback)");
+      if (n.type != NODE_PROC || mlgpu_proc_rings(n.kind) == 0) continue;
+      if (n.ringLen == 0) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: delay node '" + n.name + "' has no memory (graph_set_max_delay)");
+      n.memOff = memFloats;
+      memFloats += n.ringLen * (size_t)mlgpu_proc_rings(n.kind);
+    }
+    g->memFloatsPerVoice = memFloats;
     g->source = generateGraphSource(g);
     CompiledModule* cm = compileAndLoad(e->device, g->source, g->log);
     if (!cm) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
@@ -652,6 +746,9 @@ extern "C"
     hipError_t err = hipMalloc((void**)&g->d_coeffs, sizeof(float) * V * (size_t)(g->NC + 1));
     if (err == hipSuccess) err = hipMalloc((void**)&g->d_state, sizeof(uint32_t) * V * (size_t)(g->NS + 1));
     if (err == hipSuccess) err = hipMalloc((void**)&g->d_params, sizeof(float) * V * (size_t)(g->nParams + 1));
+    if (err == hipSuccess && g->memFloatsPerVoice) err = hipMalloc((void**)&g->d_mem, sizeof(float) * V * g->memFloatsPerVoice);
+    if (err == hipSuccess && g->memFloatsPerVoice) err = hipMemsetAsync(g->d_mem, 0, sizeof(float) * V * g->memFloatsPerVoice, e->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(g->d_state, 0, sizeof(uint32_t) * V * (size_t)(g->NS + 1), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(g->d_coeffs, 0, sizeof(float) * V * (size_t)(g->NC + 1), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(g->d_params, 0, sizeof(float) * V * (size_t)(g->nParams + 1), e->stream);
     for (const Node& n : g->nodes)
@@ -677,39 +774,47 @@ extern "C"
 
   const char* mlgpu_graph_source(mlgpu_graph* g) { return g ? g->source.c_str() : ""; }
 
+  // T::clear() of one node: the state words clear() resets (mlgpu_proc_clear_mask), a delay node's rings, a
+  // feedback node's stored vector
+  static int clearNode(mlgpu_graph* g, const Node& n)
+  {
+    hipError_t err = hipSuccess;
+    if (n.type == NODE_FEEDBACK)
+    {
+      for (int i = 0; i < n.ns && err == hipSuccess; ++i) err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * g->V, 0u, g->V, g->e->stream);
+    }
+    else if (n.type == NODE_PROC)
+    {
+      uint32_t words[MLGPU_MAX_PROC_STATE];
+      mlgpu_proc_clear_state(n.kind, words, true);
+      const uint64_t mask = mlgpu_proc_clear_mask(n.kind);
+      for (int i = 0; i < n.ns && err == hipSuccess; ++i)
+        if ((mask >> (i < 64 ? i : 63)) & 1) err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * g->V, words[i], g->V, g->e->stream);
+      if (err == hipSuccess && n.ringLen)
+        err = mlgpu_launch_fill32((uint32_t*)g->d_mem + n.memOff * g->V, 0u, n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * g->V, g->e->stream);
+    }
+    if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, hipGetErrorString(err));
+    return MLGPU_OK;
+  }
+
   int mlgpu_graph_clear(mlgpu_graph* g)
   {
     if (!g || !g->compiled) return MLGPU_ERR_INVALID;
     for (const Node& n : g->nodes)
     {
-      if (n.type != NODE_PROC) continue;
-      uint32_t words[MLGPU_MAX_PROC_STATE];
-      mlgpu_proc_clear_state(n.kind, words, true);
-      for (int i = 0; i < n.ns; ++i)
-      {
-        if (n.kind == MLGPU_PROC_ADSR && i != 7) continue;  // ADSR::clear() only resets the segment
-        const hipError_t err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * g->V, words[i], g->V, g->e->stream);
-        if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, hipGetErrorString(err));
-      }
+      const int st = clearNode(g, n);
+      if (st) return st;
     }
     return MLGPU_OK;
   }
 
   int mlgpu_graph_clear_proc(mlgpu_graph* g, int node)
   {
-    int st = checkNode(g, node, NODE_PROC);
-    if (st) return st;
+    if (!g) return MLGPU_ERR_INVALID;
+    if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "node index out of range");
+    if (g->nodes[node].type != NODE_PROC && g->nodes[node].type != NODE_FEEDBACK) return gfail(g, MLGPU_ERR_INVALID, "graph_clear_proc: not a processor / feedback node");
     if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_clear_proc: compile first");
-    const Node& n = g->nodes[node];
-    uint32_t words[MLGPU_MAX_PROC_STATE];
-    mlgpu_proc_clear_state(n.kind, words, true);
-    for (int i = 0; i < n.ns; ++i)
-    {
-      if (n.kind == MLGPU_PROC_ADSR && i != 7) continue;  // ADSR::clear() only resets the segment
-      const hipError_t err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * g->V, words[i], g->V, g->e->stream);
-      if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, hipGetErrorString(err));
-    }
-    return MLGPU_OK;
+    return clearNode(g, g->nodes[node]);
   }
 
   int mlgpu_graph_set_param(mlgpu_graph* g, int node, const float* h)
@@ -729,7 +834,7 @@ extern "C"
     return mlgpu_fill32(g->e, g->d_params + (size_t)g->nodes[node].slot * g->V, u, g->V);
   }
   int mlgpu_graph_num_coeffs(mlgpu_graph* g, int node) { return checkNode(g, node, NODE_PROC) ? -1 : g->nodes[node].nc; }
-  int mlgpu_graph_num_state(mlgpu_graph* g, int node) { return checkNode(g, node, NODE_PROC) ? -1 : g->nodes[node].ns; }
+  int mlgpu_graph_num_state(mlgpu_graph* g, int node) { return checkStateNode(g, node) ? -1 : g->nodes[node].ns; }
   int mlgpu_graph_set_coeff(mlgpu_graph* g, int node, int idx, const float* h)
   {
     int st = checkNode(g, node, NODE_PROC);
@@ -750,7 +855,7 @@ extern "C"
   }
   int mlgpu_graph_get_state(mlgpu_graph* g, int node, int idx, uint32_t* h)
   {
-    int st = checkNode(g, node, NODE_PROC);
+    int st = checkStateNode(g, node);
     if (st) return st;
     if (!g->compiled || !h) return gfail(g, MLGPU_ERR_INVALID, "graph_get_state: compile first / null");
     if (idx < 0 || idx >= g->nodes[node].ns) return gfail(g, MLGPU_ERR_RANGE, "state index out of range");
@@ -758,7 +863,7 @@ extern "C"
   }
   int mlgpu_graph_set_state(mlgpu_graph* g, int node, int idx, const uint32_t* h)
   {
-    int st = checkNode(g, node, NODE_PROC);
+    int st = checkStateNode(g, node);
     if (st) return st;
     if (!g->compiled || !h) return gfail(g, MLGPU_ERR_INVALID, "graph_set_state: compile first / null");
     if (idx < 0 || idx >= g->nodes[node].ns) return gfail(g, MLGPU_ERR_RANGE, "state index out of range");
@@ -776,7 +881,7 @@ extern "C"
 
   int mlgpu_graph_set_state_uniform(mlgpu_graph* g, int node, int idx, uint32_t value)
   {
-    int st = checkNode(g, node, NODE_PROC);
+    int st = checkStateNode(g, node);
     if (st) return st;
     if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_set_state: compile first");
     if (idx < 0 || idx >= g->nodes[node].ns) return gfail(g, MLGPU_ERR_RANGE, "state index out of range");
@@ -802,6 +907,7 @@ extern "C"
     a.coeffs = g->d_coeffs;
     a.state = g->d_state;
     a.params = g->d_params;
+    a.mem = g->d_mem;
     a.V = g->V;
     a.T = T;
     a.impulseTable = g->e->d_impulseTable;

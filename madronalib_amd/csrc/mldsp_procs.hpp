@@ -26,6 +26,13 @@ struct VoiceMem
   const float* coeffs;  // already offset to (this processor's first slot)*V + v
   uint32_t* state;      // idem
   size_t V;
+  // delay-line memory of this processor (nullptr for processors without any): rings of `memMask + 1` floats per voice,
+  // SoA [sample][V] like coefficients and state (already offset to + v), so the write of one time step is one coalesced
+  // 256-byte row per wavefront and the reads are coalesced whenever neighbouring voices use the same delay
+  float* mem{nullptr};
+  uint32_t memMask{0};
+  MLD float ring(uint32_t i) const { return mem[(size_t)i * V]; }
+  MLD void ringSet(uint32_t i, float x) const { mem[(size_t)i * V] = x; }
   MLD float c(int i) const { return coeffs[(size_t)i * V]; }
   MLD uint32_t s(int i) const { return state[(size_t)i * V]; }
   MLD void set(int i, uint32_t x) const { state[(size_t)i * V] = x; }
@@ -865,6 +872,188 @@ struct Proc<MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE>  // :517-590, nextSample(f)
       remaining--;
     }
     return curr;
+  }
+  MLD void end_vector() {}
+};
+
+// ---- delay lines, MLDSPFilters.h:799-1106 -----------------------------------------------------------------
+//
+// Per-voice rings live in HBM (VoiceMem::mem). Every form is evaluated per sample as the reference's processSample
+// (:899-914): write x at the write index, read at (write - delay) & mask, advance. For delays inside the ring's
+// valid range 0 <= d <= length - 64 that is identical to the block form of operator()(vx) (:834-875), which writes
+// the whole vector before reading it: a read can then never land on a sample written later in the same vector.
+
+struct RingCore  // IntegerDelay's buffer, index and mask
+{
+  uint32_t w;
+  MLD float sample(const VoiceMem& m, uint32_t ringBase, float x, int32_t d)
+  {
+    m.ringSet(ringBase + w, x);
+    const uint32_t r = (w - (uint32_t)d) & m.memMask;
+    const float y = m.ring(ringBase + r);
+    w = (w + 1) & m.memMask;
+    return y;
+  }
+};
+
+template <>
+struct Proc<MLGPU_PROC_INTEGER_DELAY>  // :801-914   C{}  S{writeIndex:u32, delayInSamples:i32}
+{
+  static constexpr int NC = 0, NS = 2;
+  static constexpr int kRings = 1;
+  RingCore ringc;
+  int32_t delay;
+  VoiceMem mem;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    mem = m;
+    ringc.w = m.s(0);
+    delay = (int32_t)m.s(1);
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, ringc.w);
+    m.set(1, (uint32_t)delay);
+  }
+  MLD float next(float x) { return ringc.sample(mem, 0, x, delay); }
+  MLD float next(float x, float d)  // operator()(x, delay): mIntDelayInSamples = static_cast<int>(delay[n]), :877-897
+  {
+    delay = sse_cvtt(d);
+    return ringc.sample(mem, 0, x, delay);
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_ALLPASS1>  // :918-964  C{coeff}  S{x1, y1}
+{
+  static constexpr int NC = 1, NS = 2;
+  float coeff, x1, y1;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    coeff = m.c(0);
+    x1 = u2f(m.s(0));
+    y1 = u2f(m.s(1));
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(x1));
+    m.set(1, f2u(y1));
+  }
+  MLD float next(float x)
+  {
+    const float y = x1 + (x - y1) * coeff;
+    x1 = x;
+    y1 = y;
+    return y;
+  }
+  MLD void end_vector() {}
+};
+
+// FractionalDelay's arithmetic (:971-1044) on one ring: an IntegerDelay followed by an Allpass1 whose coefficient
+// comes from the fractional part of the delay.
+struct FracCore
+{
+  RingCore ringc;
+  float x1, y1, apCoeff;
+  int32_t delayInt;
+  MLD void loadFrom(const VoiceMem& m, int s0)
+  {
+    ringc.w = m.s(s0);
+    x1 = u2f(m.s(s0 + 1));
+    y1 = u2f(m.s(s0 + 2));
+    delayInt = (int32_t)m.s(s0 + 3);
+    apCoeff = u2f(m.s(s0 + 4));
+  }
+  MLD void storeTo(const VoiceMem& m, int s0) const
+  {
+    m.set(s0, ringc.w);
+    m.set(s0 + 1, f2u(x1));
+    m.set(s0 + 2, f2u(y1));
+    m.set(s0 + 3, (uint32_t)delayInt);
+    m.set(s0 + 4, f2u(apCoeff));
+  }
+  MLD void setDelay(float d)  // setDelayInSamples, :991-1007; Allpass1::makeCoeffs :938-943
+  {
+    const float fDelayInt = __builtin_floorf(d);
+    int32_t di = sse_cvtt(fDelayInt);
+    float frac = d - fDelayInt;
+    if ((frac < 0.618f) && (di > 0))
+    {
+      frac += 1.f;
+      di -= 1;
+    }
+    delayInt = di;
+    const float xm1 = (frac - 1.f);
+    apCoeff = -0.53f * xm1 + 0.24f * xm1 * xm1;
+  }
+  MLD float sample(const VoiceMem& m, uint32_t ringBase, float x)
+  {
+    const float d = ringc.sample(m, ringBase, x, delayInt);
+    const float y = x1 + (d - y1) * apCoeff;
+    x1 = d;
+    y1 = y;
+    return y;
+  }
+};
+
+template <>
+struct Proc<MLGPU_PROC_FRACTIONAL_DELAY>  // :971-1044  C{}  S{writeIndex, x1, y1, delayInt:i32, allpassCoeff}
+{
+  static constexpr int NC = 0, NS = 5;
+  static constexpr int kRings = 1;
+  FracCore f;
+  VoiceMem mem;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    mem = m;
+    f.loadFrom(m, 0);
+  }
+  MLD void store(const VoiceMem& m) const { f.storeTo(m, 0); }
+  MLD float next(float x) { return f.sample(mem, 0, x); }
+  MLD float next(float x, float d)  // varying delay time, :1016-1025
+  {
+    f.setDelay(d);
+    return f.sample(mem, 0, x);
+  }
+  MLD float next(float x, float d, float ticks)  // delay changes only where the int mask vChangeTicks is non-zero, :1029-1043
+  {
+    if (f2u(ticks) != 0u) f.setDelay(d);
+    return f.sample(mem, 0, x);
+  }
+  MLD void end_vector() {}
+};
+
+template <>
+struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 words, delay2: 5 words}; two rings
+{
+  static constexpr int NC = 0, NS = 10;
+  static constexpr int kRings = 2;
+  static constexpr bool kNeedsIndex = true;
+  FracCore f1, f2;
+  VoiceMem mem;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    mem = m;
+    f1.loadFrom(m, 0);
+    f2.loadFrom(m, 5);
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    f1.storeTo(m, 0);
+    f2.storeTo(m, 5);
+  }
+  // n = sample index inside the DSPVector. kFadePeriod = 32; delay 1 may change when n % 32 == 16, delay 2 when
+  // n % 32 == 0; kvFade is the triangle 0..1..0 over the period (:1054-1062); result = lerp(d1, d2, fade) (:1102-1104)
+  MLD float next_i(int n, float x, float d)
+  {
+    const int r = n & 31;
+    if (r == 16) f1.setDelay(d);
+    if (r == 0) f2.setDelay(d);
+    const float y1 = f1.sample(mem, 0, x);
+    const float y2 = f2.sample(mem, mem.memMask + 1, x);
+    const float fade = 2.f * ((r > 16) ? 1.0f - (float)r / 32.f : (float)r / 32.f);
+    return y1 + (fade * (y2 - y1));
   }
   MLD void end_vector() {}
 };

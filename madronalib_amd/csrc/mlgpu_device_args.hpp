@@ -38,6 +38,7 @@ struct GraphArgs
   SignalView in[MLGPU_GRAPH_MAX_INPUTS];
   SignalView out[MLGPU_GRAPH_MAX_OUTPUTS];
   const float* ctl[MLGPU_GRAPH_MAX_CONTROLS];  // control-rate inputs, [T][V]: one float per DSPVector per voice
+  float* mem;  // delay-line rings of all delay nodes, [sample][V] each
   size_t V, T;
   const float* impulseTable;
 };

@@ -58,6 +58,9 @@ constexpr int MLGPU_MAX_PROC_STATE = 80;  // LinearGlide: 3 + 64
 constexpr int MLGPU_MAX_PROC_COEFFS = 8;
 void mlgpu_proc_clear_state(int kind, uint32_t* words /*[ns <= MLGPU_MAX_PROC_STATE]*/, bool cleared);
 void mlgpu_proc_default_coeffs(int kind, float* c /*[nc <= MLGPU_MAX_PROC_COEFFS]*/);
+bool mlgpu_proc_is_graph_only(int kind);   // vector-rate ramps and delay lines: no chain kernel
+int mlgpu_proc_rings(int kind);            // delay rings per voice (0 for processors without delay memory)
+uint64_t mlgpu_proc_clear_mask(int kind);  // state words T::clear() resets
 bool mlgpu_proc_is_vector_rate(int kind);  // one float per DSPVector in (Interpolator1, LinearGlide): graphs only
 
 // ops.hip

@@ -5,6 +5,8 @@
 definition and the parity oracle is the same patch evaluated node by node on the CPU,
 tests/graph_oracle.py).
 """
+import numpy as np
+
 from .constants import Op, Proc
 
 
@@ -44,3 +46,55 @@ def synth16():
         dict(name="out", type="op", kind=Op.CLAMP, inputs=["vca", "lo", "hi"]),               # 17 (output clamp)
     ]
     return d, ["out"]
+
+
+# ---- the reference's feedback composites written out as graphs (what the C++ shim's classes emit) ------------------
+
+def allpass(prefix, x, delay_kind, max_delay, delay=None):
+    """Allpass<DELAY_TYPE> (MLDSPFilters.h:1110-1160): vGain = -mGain; vDelayInput = x - vy1*vGain; y = vDelayInput*vGain
+    + vy1; vy1 = mDelay(vDelayInput [, delay - 64]). mGain is the param `<prefix>gain`; the inner delay's memory is
+    max_delay - 64 (setMaxDelayInSamples, :1123-1126). `delay`: name of the delay-time signal (PitchbendableDelay)."""
+    p = prefix
+    d = [dict(name=p + "gain", type="param"), dict(name=p + "m1", type="const", value=-1.0), dict(name=p + "c64", type="const", value=64.0),
+         dict(name=p + "vy1", type="feedback", source=p + "delay"),
+         dict(name=p + "vgain", type="op", kind=Op.MULTIPLY, inputs=[p + "gain", p + "m1"]),   # DSPVector(-mGain): exact negation
+         dict(name=p + "fb", type="op", kind=Op.MULTIPLY, inputs=[p + "vy1", p + "vgain"]),
+         dict(name=p + "din", type="op", kind=Op.SUBTRACT, inputs=[x, p + "fb"]),
+         dict(name=p + "ff", type="op", kind=Op.MULTIPLY, inputs=[p + "din", p + "vgain"]),
+         dict(name=p + "y", type="op", kind=Op.ADD, inputs=[p + "ff", p + "vy1"])]
+    if delay is None:
+        d.append(dict(name=p + "delay", type="proc", kind=delay_kind, inputs=[p + "din"], max_delay=max_delay - 64.0))
+    else:
+        d.append(dict(name=p + "dt", type="op", kind=Op.SUBTRACT, inputs=[delay, p + "c64"]))
+        d.append(dict(name=p + "delay", type="proc", kind=delay_kind, inputs=[p + "din", p + "dt"], max_delay=max_delay - 64.0))
+    return d, p + "y"
+
+
+def fdn(size, x, max_delay):
+    """FDN<SIZE> (MLDSPFilters.h:1162-1239): SIZE IntegerDelays + OnePoles around a Householder feedback matrix, one
+    DSPVector of feedback latency. Node names: fdn_delay<n>, fdn_filter<n>, param fdn_gain<n>. Outputs (sumL, sumR)."""
+    d = [dict(name="fdn_zero", type="const", value=0.0), dict(name="fdn_k", type="const", value=float(np.float32(2.0) / np.float32(size)))]
+    for n in range(size):
+        d.append(dict(name=f"fdn_gain{n}", type="param"))
+        d.append(dict(name=f"fdn_div{n}", type="feedback", source=f"fdn_next{n}"))
+        d.append(dict(name=f"fdn_delay{n}", type="proc", kind=Proc.INTEGER_DELAY, inputs=[f"fdn_div{n}"], max_delay=max_delay))
+    # sumR / sumL / sumOfDelays start from a zero vector and accumulate with += (:1201-1223)
+    accR, accL, acc = "fdn_zero", "fdn_zero", "fdn_zero"
+    for n in range(size & ~1):
+        tgt = "L" if (n & 1) else "R"
+        prev = accL if (n & 1) else accR
+        d.append(dict(name=f"fdn_sum{tgt}{n}", type="op", kind=Op.ADD, inputs=[prev, f"fdn_delay{n}"]))
+        if n & 1:
+            accL = f"fdn_sum{tgt}{n}"
+        else:
+            accR = f"fdn_sum{tgt}{n}"
+    for n in range(size):
+        d.append(dict(name=f"fdn_sum{n}", type="op", kind=Op.ADD, inputs=[acc, f"fdn_delay{n}"]))
+        acc = f"fdn_sum{n}"
+    d.append(dict(name="fdn_sumk", type="op", kind=Op.MULTIPLY, inputs=[acc, "fdn_k"]))
+    for n in range(size):
+        d.append(dict(name=f"fdn_sub{n}", type="op", kind=Op.SUBTRACT, inputs=[f"fdn_delay{n}", "fdn_sumk"]))
+        d.append(dict(name=f"fdn_filter{n}", type="proc", kind=Proc.ONE_POLE, inputs=[f"fdn_sub{n}"]))
+        d.append(dict(name=f"fdn_fb{n}", type="op", kind=Op.MULTIPLY, inputs=[f"fdn_filter{n}", f"fdn_gain{n}"]))
+        d.append(dict(name=f"fdn_next{n}", type="op", kind=Op.ADD, inputs=[f"fdn_fb{n}", x]))
+    return d, [accL, accR]

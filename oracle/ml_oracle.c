@@ -782,7 +782,9 @@ int mlorc_proc_num_coeffs(int kind)
     case MLGPU_PROC_GAIN: return 1;
     case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_RMS: case MLGPU_PROC_LINEAR_GLIDE:
     case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return 2;
-    case MLGPU_PROC_INTERPOLATOR1: return 0;
+    case MLGPU_PROC_INTERPOLATOR1: case MLGPU_PROC_INTEGER_DELAY: case MLGPU_PROC_FRACTIONAL_DELAY:
+    case MLGPU_PROC_PITCHBENDABLE_DELAY: return 0;
+    case MLGPU_PROC_ALLPASS1: return 1;
     case MLGPU_PROC_LOPASS: case MLGPU_PROC_BANDPASS: case MLGPU_PROC_PEAK: return 3;
     case MLGPU_PROC_HIPASS: case MLGPU_PROC_BELL: case MLGPU_PROC_ADSR: return 4;
     case MLGPU_PROC_LO_SHELF: return 5;
@@ -800,6 +802,9 @@ int mlorc_proc_num_state(int kind)
     case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_DIFFERENTIATOR: case MLGPU_PROC_INTEGRATOR:
     case MLGPU_PROC_RMS: case MLGPU_PROC_INTERPOLATOR1: return 1;
     case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return 4;
+    case MLGPU_PROC_INTEGER_DELAY: case MLGPU_PROC_ALLPASS1: return 2;
+    case MLGPU_PROC_FRACTIONAL_DELAY: return 5;
+    case MLGPU_PROC_PITCHBENDABLE_DELAY: return 10;
     case MLGPU_PROC_LINEAR_GLIDE: return 3 + VEC;
     case MLGPU_PROC_IMPULSE_GEN: case MLGPU_PROC_LOPASS: case MLGPU_PROC_HIPASS:
     case MLGPU_PROC_BANDPASS: case MLGPU_PROC_LO_SHELF: case MLGPU_PROC_HI_SHELF:
@@ -938,6 +943,17 @@ static void proc_process64(int kind, const float* C, uint32_t* S, const float* i
       break;
     case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE:
       for (int n = 0; n < VEC; ++n) out[n] = sample_glide_next(C, S, in[n]);
+      break;
+    case MLGPU_PROC_ALLPASS1: /* MLDSPFilters.h:945-953: y = x1 + (x - y1)*coeffs */
+      f0 = u2f(S[0]); f1 = u2f(S[1]);
+      for (int n = 0; n < VEC; ++n)
+      {
+        const float y = f0 + (in[n] - f1) * C[0];
+        f0 = in[n];
+        f1 = y;
+        out[n] = y;
+      }
+      S[0] = f2u(f0); S[1] = f2u(f1);
       break;
     default: break;
   }
@@ -1652,6 +1668,106 @@ int mlorc_mixdown(const float* sig, size_t V, size_t T, const float* gains, floa
       total = (g == 0) ? a[0] : total + a[0];
     }
     out[s] = total;
+  }
+  return MLGPU_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* delay lines, MLDSPFilters.h:799-1106                                       */
+/*
+ * One delay processor, V voices, T vectors. state [NS][V] in/out; mem [V][rings][len] in/out (len a power of two =
+ * the size IntegerDelay::setMaxDelayInSamples allocated); inputs each [V][64T]. Evaluated per sample like
+ * processSample (:899-914); tests/test_oracle_vs_ref.py checks it against the reference objects' own operator(),
+ * including the block form (:834-875) for constant delays.
+ *   INTEGER_DELAY        S{writeIndex, delay:i32}                          forms (x), (x, delay)
+ *   FRACTIONAL_DELAY     S{writeIndex, x1, y1, delayInt:i32, allpassCoeff} forms (x), (x, delay), (x, delay, ticks)
+ *   PITCHBENDABLE_DELAY  S{delay1[5], delay2[5]}, two rings                form (x, delay)
+ */
+static float ring_sample(float* ring, uint32_t mask, uint32_t* w, float x, int32_t d)
+{
+  ring[*w] = x;
+  const uint32_t r = (*w - (uint32_t)d) & mask;
+  const float y = ring[r];
+  *w = (*w + 1) & mask;
+  return y;
+}
+float mlorc_allpass1_make_coeffs(float d) /* :938-943 */
+{
+  float xm1 = (d - 1.f);
+  return -0.53f * xm1 + 0.24f * xm1 * xm1;
+}
+static void frac_set_delay(uint32_t* S, float d) /* :991-1007 */
+{
+  float fDelayInt = floorf(d);
+  int32_t delayInt = sse_cvtt(fDelayInt);
+  float delayFrac = d - fDelayInt;
+  if ((delayFrac < 0.618f) && (delayInt > 0))
+  {
+    delayFrac += 1.f;
+    delayInt -= 1;
+  }
+  S[3] = (uint32_t)delayInt;
+  S[4] = f2u(mlorc_allpass1_make_coeffs(delayFrac));
+}
+void mlorc_fractional_delay_make_state(float d, float* o)
+{
+  uint32_t S[5];
+  frac_set_delay(S, d);
+  o[0] = u2f(S[3]);
+  o[1] = u2f(S[4]);
+}
+static float frac_sample(float* ring, uint32_t mask, uint32_t* S, float x)
+{
+  const float d = ring_sample(ring, mask, &S[0], x, (int32_t)S[3]);
+  const float x1 = u2f(S[1]), y1 = u2f(S[2]);
+  const float y = x1 + (d - y1) * u2f(S[4]);
+  S[1] = f2u(d);
+  S[2] = f2u(y);
+  return y;
+}
+
+int mlorc_delay_process(int kind, size_t V, size_t T, uint32_t* state, float* mem, size_t len, const float* const* inputs, int n_inputs,
+                        float* out)
+{
+  const int ns = mlorc_proc_num_state(kind);
+  const int rings = (kind == MLGPU_PROC_PITCHBENDABLE_DELAY) ? 2 : 1;
+  if (ns < 0 || len == 0 || (len & (len - 1))) return MLGPU_ERR_INVALID;
+  const uint32_t mask = (uint32_t)(len - 1);
+  const size_t S = T * VEC;
+  uint32_t St[16];
+  for (size_t v = 0; v < V; ++v)
+  {
+    for (int i = 0; i < ns; ++i) St[i] = state[(size_t)i * V + v];
+    float* ring = mem + v * (size_t)rings * len;
+    for (size_t s = 0; s < S; ++s)
+    {
+      const float x = inputs[0][v * S + s];
+      float y;
+      if (kind == MLGPU_PROC_INTEGER_DELAY)
+      {
+        if (n_inputs == 2) St[1] = (uint32_t)sse_cvtt(inputs[1][v * S + s]); /* static_cast<int>(delay[n]) :887 */
+        y = ring_sample(ring, mask, &St[0], x, (int32_t)St[1]);
+      }
+      else if (kind == MLGPU_PROC_FRACTIONAL_DELAY)
+      {
+        if (n_inputs == 2 || (n_inputs == 3 && f2u(inputs[2][v * S + s]) != 0u)) frac_set_delay(St, inputs[1][v * S + s]);
+        y = frac_sample(ring, mask, St, x);
+      }
+      else if (kind == MLGPU_PROC_PITCHBENDABLE_DELAY && n_inputs == 2)
+      {
+        const int r = (int)(s % VEC) % 32;                     /* fadeRamp, :1057 */
+        if (r == 16) frac_set_delay(St, inputs[1][v * S + s]);       /* kvDelay1Changes, :1058 */
+        if (r == 0) frac_set_delay(St + 5, inputs[1][v * S + s]);    /* kvDelay2Changes, :1059 */
+        const float y1 = frac_sample(ring, mask, St, x);
+        const float y2 = frac_sample(ring + len, mask, St + 5, x);
+        const float fade = 2.f * ((r > 16) ? 1.0f - r / (32 + 0.f) : r / (32 + 0.f)); /* fadeFn, :1060-1065 */
+        y = y1 + (fade * (y2 - y1));                          /* lerp, MLDSPOps.h:744 */
+      }
+      else
+        return MLGPU_ERR_UNSUPPORTED;
+      out[v * S + s] = y;
+    }
+    for (int i = 0; i < ns; ++i) state[(size_t)i * V + v] = St[i];
   }
   return MLGPU_OK;
 }

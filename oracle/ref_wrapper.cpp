@@ -440,10 +440,31 @@ struct RLinearGlide : RefProc
   DSPVector process(const DSPVector& in) override { return g(in[0]); }
 };
 
+struct RAllpass1 : RefProc
+{
+  Allpass1 f{0.f};
+  int nc() const override { return 1; }
+  int ns() const override { return 2; }
+  void setCoeffs(const float* c) override { f.coeffs = c[0]; }
+  void setState(const uint32_t* s) override
+  {
+    f.x1 = u2f(s[0]);
+    f.y1 = u2f(s[1]);
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(f.x1);
+    s[1] = f2u(f.y1);
+  }
+  void clear() override { f.clear(); }
+  DSPVector process(const DSPVector& in) override { return f(in); }
+};
+
 RefProc* makeProc(int kind)
 {
   switch (kind)
   {
+    case MLGPU_PROC_ALLPASS1: return new RAllpass1;
     case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return new RSampleGlide;
     case MLGPU_PROC_INTERPOLATOR1: return new RInterp1;
     case MLGPU_PROC_LINEAR_GLIDE: return new RLinearGlide;
@@ -1041,6 +1062,162 @@ extern "C"
     const int32_t n = g.mSamplesPerGlide;
     std::memcpy(&o[0], &n, 4);
     o[1] = g.mDyPerSample;
+  }
+
+  // ---- delay lines: the reference objects themselves, same contract as mlorc_delay_process ----
+  namespace
+  {
+  void loadRing(IntegerDelay& d, size_t len, uint32_t w, int32_t delay, const float* ring)
+  {
+    d.setMaxDelayInSamples((float)(len - kFloatsPerDSPVector));  // allocates exactly `len` samples (:823-831)
+    std::memcpy(d.mBuffer.data(), ring, sizeof(float) * len);
+    d.mWriteIndex = w;
+    d.mIntDelayInSamples = delay;
+  }
+  void storeRing(const IntegerDelay& d, size_t len, uint32_t* w, uint32_t* delay, float* ring)
+  {
+    std::memcpy(ring, d.mBuffer.data(), sizeof(float) * len);
+    *w = (uint32_t)d.mWriteIndex;
+    *delay = (uint32_t)d.mIntDelayInSamples;
+  }
+  void loadFrac(FractionalDelay& f, size_t len, const uint32_t* S, const float* ring)
+  {
+    loadRing(f.mIntegerDelay, len, S[0], (int32_t)S[3], ring);
+    f.mAllpassSection.x1 = u2f(S[1]);
+    f.mAllpassSection.y1 = u2f(S[2]);
+    f.mAllpassSection.coeffs = u2f(S[4]);
+  }
+  void storeFrac(const FractionalDelay& f, size_t len, uint32_t* S, float* ring)
+  {
+    storeRing(f.mIntegerDelay, len, &S[0], &S[3], ring);
+    S[1] = f2u(f.mAllpassSection.x1);
+    S[2] = f2u(f.mAllpassSection.y1);
+    S[4] = f2u(f.mAllpassSection.coeffs);
+  }
+  }  // namespace
+
+  int mlref_delay_process(int kind, size_t V, size_t T, uint32_t* state, float* mem, size_t len, const float* const* inputs, int nInputs,
+                          float* out)
+  {
+    const int ns = (kind == MLGPU_PROC_INTEGER_DELAY) ? 2 : (kind == MLGPU_PROC_FRACTIONAL_DELAY ? 5 : 10);
+    const int rings = (kind == MLGPU_PROC_PITCHBENDABLE_DELAY) ? 2 : 1;
+    const size_t S = T * kFloatsPerDSPVector;
+    uint32_t St[16];
+    for (size_t v = 0; v < V; ++v)
+    {
+      for (int i = 0; i < ns; ++i) St[i] = state[(size_t)i * V + v];
+      float* ring = mem + v * (size_t)rings * len;
+      IntegerDelay idl;
+      FractionalDelay fdl;
+      PitchbendableDelay pdl;
+      if (kind == MLGPU_PROC_INTEGER_DELAY) loadRing(idl, len, St[0], (int32_t)St[1], ring);
+      else if (kind == MLGPU_PROC_FRACTIONAL_DELAY) loadFrac(fdl, len, St, ring);
+      else
+      {
+        loadFrac(pdl.mDelay1, len, St, ring);
+        loadFrac(pdl.mDelay2, len, St + 5, ring + len);
+      }
+      for (size_t t = 0; t < T; ++t)
+      {
+        DSPVector in[3], y;
+        for (int i = 0; i < nInputs; ++i) load(in[i], inputs[i] + v * S + t * kFloatsPerDSPVector);
+        if (kind == MLGPU_PROC_INTEGER_DELAY) y = (nInputs == 1) ? idl(in[0]) : idl(in[0], in[1]);
+        else if (kind == MLGPU_PROC_FRACTIONAL_DELAY)
+        {
+          if (nInputs == 1) y = fdl(in[0]);
+          else if (nInputs == 2) y = fdl(in[0], in[1]);
+          else
+          {
+            DSPVectorInt ticks;
+            for (int n = 0; n < kFloatsPerDSPVector; ++n) ticks[n] = (int32_t)f2u(in[2][n]);
+            y = fdl(in[0], in[1], ticks);
+          }
+        }
+        else y = pdl(in[0], in[1]);
+        store(y, out + v * S + t * kFloatsPerDSPVector);
+      }
+      if (kind == MLGPU_PROC_INTEGER_DELAY) storeRing(idl, len, &St[0], &St[1], ring);
+      else if (kind == MLGPU_PROC_FRACTIONAL_DELAY) storeFrac(fdl, len, St, ring);
+      else
+      {
+        storeFrac(pdl.mDelay1, len, St, ring);
+        storeFrac(pdl.mDelay2, len, St + 5, ring + len);
+      }
+      for (int i = 0; i < ns; ++i) state[(size_t)i * V + v] = St[i];
+    }
+    return MLGPU_OK;
+  }
+  float mlref_allpass1_make_coeffs(float d) { return Allpass1::makeCoeffs(d); }
+  void mlref_fractional_delay_make_state(float d, float* o)
+  {
+    FractionalDelay f;
+    f.setDelayInSamples(d);
+    const int32_t di = f.mIntegerDelay.mIntDelayInSamples;
+    std::memcpy(&o[0], &di, 4);
+    o[1] = f.mAllpassSection.coeffs;
+  }
+
+  // ---- composites built on one-vector feedback: the reference classes run as user code would ----
+  // which: 0 Allpass<IntegerDelay>, 1 Allpass<FractionalDelay> (constant delay d), 2 Allpass<PitchbendableDelay> (delay signal)
+  int mlref_allpass_run(int which, size_t T, float gain, float maxDelay, float d, const float* delaySig, const float* in, float* out)
+  {
+    Allpass<IntegerDelay> a0;
+    Allpass<FractionalDelay> a1;
+    Allpass<PitchbendableDelay> a2;
+    a0.mGain = a1.mGain = a2.mGain = gain;
+    a0.setMaxDelayInSamples(maxDelay);
+    a1.setMaxDelayInSamples(maxDelay);
+    a2.setMaxDelayInSamples(maxDelay);
+    a0.setDelayInSamples(d);
+    a1.setDelayInSamples(d);
+    for (size_t t = 0; t < T; ++t)
+    {
+      DSPVector x, dl, y;
+      load(x, in + t * kFloatsPerDSPVector);
+      if (which == 2) load(dl, delaySig + t * kFloatsPerDSPVector);
+      y = (which == 0) ? a0(x) : (which == 1 ? a1(x) : a2(x, dl));
+      store(y, out + t * kFloatsPerDSPVector);
+    }
+    return MLGPU_OK;
+  }
+  // FDN<4>: delay times, OnePole cutoffs, feedback gains; the class has no way to allocate its IntegerDelays
+  // (MLDSPFilters.h:1163-1181 never calls setMaxDelayInSamples), so the harness does it through the private member
+  int mlref_fdn4_run(size_t T, const float* times, const float* omegas, const float* gains, float maxDelay, const float* in, float* outL,
+                     float* outR)
+  {
+    FDN<4> fdn;
+    for (auto& d : fdn.mDelays) d.setMaxDelayInSamples(maxDelay);
+    fdn.setDelaysInSamples({times[0], times[1], times[2], times[3]});
+    fdn.setFilterCutoffs({omegas[0], omegas[1], omegas[2], omegas[3]});
+    fdn.mFeedbackGains = {gains[0], gains[1], gains[2], gains[3]};
+    for (size_t t = 0; t < T; ++t)
+    {
+      DSPVector x;
+      load(x, in + t * kFloatsPerDSPVector);
+      DSPVectorArray<2> y = fdn(x);
+      store(y.constRow(0), outL + t * kFloatsPerDSPVector);
+      store(y.constRow(1), outR + t * kFloatsPerDSPVector);
+    }
+    return MLGPU_OK;
+  }
+  // FeedbackDelayFunction around fn = Lopass(coeffs): y = fn(x + vy1*gain); vy1 = PitchbendableDelay(y, delay - 64)
+  int mlref_feedback_delay_run(size_t T, float feedbackGain, float maxDelay, const float* lopassCoeffs, const float* delaySig, const float* in,
+                               float* out)
+  {
+    FeedbackDelayFunction f;
+    f.feedbackGain = feedbackGain;
+    f.mDelays[0].setMaxDelayInSamples(maxDelay);
+    Lopass lp;
+    lp.coeffs = {lopassCoeffs[0], lopassCoeffs[1], lopassCoeffs[2]};
+    for (size_t t = 0; t < T; ++t)
+    {
+      DSPVector x, dl;
+      load(x, in + t * kFloatsPerDSPVector);
+      load(dl, delaySig + t * kFloatsPerDSPVector);
+      DSPVector y = f(x, [&](const DSPVector v) { return lp(v); }, dl);
+      store(y, out + t * kFloatsPerDSPVector);
+    }
+    return MLGPU_OK;
   }
 
   // ---- row plumbing and routing: the reference's own templates at fixed sizes ----

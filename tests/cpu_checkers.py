@@ -174,6 +174,33 @@ class _Checker:
         assert r == 0, r
         return out
 
+    def delay_process(self, kind, T, state, mem, inputs):
+        """One delay-line processor. state [NS][V] and mem [V][rings][len] are updated in place; inputs [V][64T]."""
+        fnc = getattr(self.lib, self.prefix + "delay_process")
+        fnc.restype = ctypes.c_int
+        sz = ctypes.c_size_t
+        fnc.argtypes = [ctypes.c_int, sz, sz, c_u32p, c_f32p, sz, ctypes.POINTER(c_f32p), ctypes.c_int, c_f32p]
+        V = state.shape[1]
+        assert mem.dtype == np.float32 and mem.flags["C_CONTIGUOUS"] and mem.shape[0] == V
+        ins = [np.ascontiguousarray(x, np.float32) for x in inputs]
+        arr = (c_f32p * len(ins))(*[_ptr(x, c_f32p) for x in ins])
+        out = np.empty((V, 64 * T), np.float32)
+        r = fnc(int(kind), V, T, _ptr(state, c_u32p), _ptr(mem, c_f32p), mem.shape[-1], arr, len(ins), _ptr(out, c_f32p))
+        assert r == 0, r
+        return out
+
+    def allpass1_coeffs(self, d):
+        fnc = getattr(self.lib, self.prefix + "allpass1_make_coeffs")
+        fnc.restype, fnc.argtypes = ctypes.c_float, [ctypes.c_float]
+        return np.float32(fnc(float(d)))
+
+    def fractional_delay_state(self, d):
+        fnc = getattr(self.lib, self.prefix + "fractional_delay_make_state")
+        fnc.restype, fnc.argtypes = None, [ctypes.c_float, c_f32p]
+        o = np.zeros(2, np.float32)
+        fnc(float(d), _ptr(o, c_f32p))
+        return o
+
     def vop(self, vop, V, T, a=None, b=None):
         out = np.empty((V, 64 * T), np.float32)
         a = None if a is None else np.ascontiguousarray(a, np.float32)
@@ -333,6 +360,35 @@ class Ref(_Checker):
         L.mlref_bench_lopass_cascade8.argtypes = [sz, sz, c_f32p, ctypes.c_int, c_f64p]
         L.mlref_bench_op.restype = ctypes.c_double
         L.mlref_bench_op.argtypes = [ctypes.c_int, c_f32p, c_f32p, sz, ctypes.c_int, ctypes.c_int]
+
+    # ---- composites with one-vector feedback: the reference classes run as user code would (one voice) ----
+    def allpass_run(self, which, gain, max_delay, d, delay_sig, x):
+        fnc = self.lib.mlref_allpass_run
+        fnc.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p]
+        x = np.ascontiguousarray(x, np.float32)
+        ds = None if delay_sig is None else np.ascontiguousarray(delay_sig, np.float32)
+        out = np.empty_like(x)
+        assert fnc(which, x.size // 64, gain, max_delay, d, _ptr(ds, c_f32p), _ptr(x, c_f32p), _ptr(out, c_f32p)) == 0
+        return out
+
+    def fdn4_run(self, times, omegas, gains, max_delay, x):
+        fnc = self.lib.mlref_fdn4_run
+        fnc.argtypes = [ctypes.c_size_t, c_f32p, c_f32p, c_f32p, ctypes.c_float, c_f32p, c_f32p, c_f32p]
+        x = np.ascontiguousarray(x, np.float32)
+        a = [np.ascontiguousarray(v, np.float32) for v in (times, omegas, gains)]
+        oL, oR = np.empty_like(x), np.empty_like(x)
+        assert fnc(x.size // 64, *[_ptr(v, c_f32p) for v in a], max_delay, _ptr(x, c_f32p), _ptr(oL, c_f32p), _ptr(oR, c_f32p)) == 0
+        return oL, oR
+
+    def feedback_delay_run(self, feedback_gain, max_delay, lopass_coeffs, delay_sig, x):
+        fnc = self.lib.mlref_feedback_delay_run
+        fnc.argtypes = [ctypes.c_size_t, ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p]
+        x = np.ascontiguousarray(x, np.float32)
+        co = np.ascontiguousarray(lopass_coeffs, np.float32)
+        ds = np.ascontiguousarray(delay_sig, np.float32)
+        out = np.empty_like(x)
+        assert fnc(x.size // 64, feedback_gain, max_delay, _ptr(co, c_f32p), _ptr(ds, c_f32p), _ptr(x, c_f32p), _ptr(out, c_f32p)) == 0
+        return out
 
     def dspbuffer(self, size):
         return _RefDSPBuffer(self.lib, size)

@@ -105,7 +105,33 @@ def main():
             d[f"{name}|in{i}"] = x
         d[f"{name}|out"] = ref.rows_case(name, ins)
     np.savez_compressed(os.path.join(HERE, "rows.npz"), **d)
-    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz"):
+    # ---- delay lines and the feedback composites ----
+    from graph_oracle import ring_len
+    from inputs import DELAY_CASES, delay_case, lcg_noise
+    d = {}
+    V, T = 6, 10
+    for name in DELAY_CASES:
+        c = delay_case(ref, name, V, 2 * T, seed=5)
+        rings = 2 if c["kind"] == Proc.PITCHBENDABLE_DELAY else 1
+        st, mem = c["state0"].copy(), np.zeros((V, rings, ring_len(c["max_delay"])), np.float32)
+        d[name + "_kind"], d[name + "_max_delay"], d[name + "_state0"] = np.int32(c["kind"]), np.float32(c["max_delay"]), c["state0"]
+        for i, a in enumerate(c["inputs"]):
+            d[f"{name}_in{i}"] = a
+        for call in range(2):
+            sl = slice(call * 64 * T, (call + 1) * 64 * T)
+            d[f"{name}_out{call + 1}"] = ref.delay_process(c["kind"], T, st, mem, [np.ascontiguousarray(a[:, sl]) for a in c["inputs"]])
+            d[f"{name}_state{call + 1}"] = st.copy()
+    T = 30
+    x = lcg_noise(np.array([5], np.uint32), 64 * T)[0]
+    dsig = (150.0 + 60.0 * np.sin(np.arange(64 * T) * 0.003)).astype(np.float32)
+    d["comp_x"], d["comp_dsig"] = x, dsig
+    d["allpass0"] = ref.allpass_run(0, 0.7, 400.0, 101.0, None, x)
+    d["allpass1"] = ref.allpass_run(1, 0.7, 400.0, 77.37, None, x)
+    d["allpass2"] = ref.allpass_run(2, 0.7, 400.0, 0.0, dsig, x)
+    d["fdnL"], d["fdnR"] = ref.fdn4_run([133.0, 201.0, 307.0, 419.0], [0.2, 0.15, 0.1, 0.05], [0.8, 0.75, 0.7, 0.65], 512.0, x * np.float32(0.1))
+    d["fbdelay"] = ref.feedback_delay_run(0.6, 1000.0, ref.make_coeffs("lopass", 0.08, 0.9), dsig + np.float32(150.0), x)
+    np.savez_compressed(os.path.join(HERE, "delays.npz"), **d)
+    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -57,3 +57,72 @@ def evaluate(chk, description, outputs, V, T, in_signals, params, coeffs, states
         else:
             raise ValueError(ty)
     return [val[o] for o in outputs]
+
+
+def ring_len(max_delay):
+    """IntegerDelay::setMaxDelayInSamples (MLDSPFilters.h:823-831): 2^bitsToContain(floor(d) + 64)"""
+    n, bits = int(np.floor(max_delay)) + 64, 0
+    while (1 << bits) < n:
+        bits += 1
+    return 1 << bits
+
+
+def new_stream_state(chk, description, V):
+    """Per-node state for evaluate_stream: processor state words, delay rings, feedback vectors."""
+    st = {}
+    for n in description:
+        if n["type"] == "proc":
+            st[n["name"]] = chk.chain_default_state([n["kind"]], V)
+            if n["kind"] in Proc.DELAYS:
+                rings = 2 if n["kind"] == Proc.PITCHBENDABLE_DELAY else 1
+                st[n["name"] + "/mem"] = np.zeros((V, rings, ring_len(n["max_delay"])), np.float32)
+        elif n["type"] == "feedback":
+            st[n["name"]] = np.zeros((V, 64), np.float32)
+    return st
+
+
+def evaluate_stream(chk, description, outputs, V, T, in_signals, params, coeffs, st):
+    """Vector-by-vector evaluation (graphs with delay lines and one-vector feedback): every DSPVector is evaluated
+    node by node; feedback nodes hand the previous vector's value of their source to this one."""
+    outs = [np.empty((V, 64 * T), np.float32) for _ in outputs]
+    for t in range(T):
+        sl = slice(64 * t, 64 * (t + 1))
+        val = {}
+        for n in description:
+            name, ty = n["name"], n["type"]
+            ins = [val[i] for i in n.get("inputs", [])]
+            if ty == "input":
+                val[name] = np.ascontiguousarray(in_signals[name][:, sl], np.float32)
+            elif ty == "control":
+                c = np.asarray(in_signals[name], np.float32).reshape(V, T)[:, t]
+                val[name] = np.ascontiguousarray(np.repeat(c[:, None], 64, 1))
+            elif ty == "param":
+                p = np.broadcast_to(np.asarray(params[name], np.float32), (V,))
+                val[name] = np.ascontiguousarray(np.repeat(p[:, None], 64, 1))
+            elif ty == "const":
+                val[name] = np.full((V, 64), np.float32(n["value"]), np.float32)
+            elif ty == "feedback":
+                val[name] = st[name].copy()
+            elif ty == "vop":
+                a = [np.ascontiguousarray(x) for x in ins] + [None, None]
+                val[name] = chk.vop(n["kind"], V, 1, a[0], a[1])
+            elif ty == "op":
+                a = [np.ascontiguousarray(x) for x in ins] + [None, None]
+                val[name] = chk.op(n["kind"], a[0], a[1], a[2]).view(np.float32).reshape(V, 64)
+            elif ty == "proc":
+                kind = n["kind"]
+                co = coeffs.get(name, np.zeros((chk.num_coeffs(kind), V), np.float32))
+                if kind in Proc.DELAYS:
+                    val[name] = chk.delay_process(kind, 1, st[name], st[name + "/mem"], ins)
+                elif len(ins) > 1 or kind in Proc.VECTOR_RATE:
+                    val[name] = chk.proc_multi(kind, 1, co, st[name], ins)
+                else:
+                    val[name] = chk.chain_process([kind], 1, np.ascontiguousarray(co, np.float32), st[name], ins[0] if ins else None, None)
+            else:
+                raise ValueError(ty)
+        for n in description:
+            if n["type"] == "feedback":
+                st[n["name"]] = np.ascontiguousarray(val[n["source"]], np.float32).copy()
+        for o, name in zip(outs, outputs):
+            o[:, sl] = val[name]
+    return outs

@@ -137,6 +137,8 @@ def proc_default_coeffs(mk, kind, V, seed=0):
         return rng.uniform(-1.5, 1.5, (1, V)).astype(np.float32)
     if kind == P.PULSE_GEN:
         return rng.uniform(0.05, 0.95, (1, V)).astype(np.float32)
+    if kind == P.ALLPASS1:
+        return np.array([[mk.allpass1_coeffs(rng.uniform(0.618, 1.618)) for _ in range(V)]], np.float32)
     if kind == P.SAMPLE_ACCURATE_LINEAR_GLIDE:
         return np.stack([mk.make_coeffs("sample_glide", rng.uniform(0.0, 300.0)) for _ in range(V)], 1)
     if kind == P.LINEAR_GLIDE:
@@ -250,3 +252,39 @@ def multi_case(mk, name, V, T, seed=0):
 def multi_inputs_audio(case, T):
     """The case's inputs as audio-rate arrays [V][64T] (controls repeated 64 times per vector), for the CPU checkers."""
     return [np.ascontiguousarray(a if r == "audio" else np.repeat(a, 64, 1), np.float32) for r, a in case["inputs"]]
+
+
+DELAY_CASES = ("integer_const", "integer_var", "frac_const", "frac_var", "frac_ticks", "pitchbend")
+
+
+def delay_case(mk, name, V, T, seed=0):
+    """A delay-line processor case: dict(kind, max_delay, state0 [NS][V] uint32, inputs [arrays [V][64T]])."""
+    rng = np.random.default_rng(seed + 303)
+    S = 64 * T
+    P = Proc
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 900 + seed, S)
+    max_delay = 192.0   # ring of 256 samples: valid delays 0 .. 192
+    slow = (100.0 + 80.0 * np.sin(np.arange(S)[None, :] * 0.004 * (1 + np.arange(V)[:, None] % 5))).astype(np.float32)
+    if name == "integer_const":
+        st = np.zeros((2, V), np.uint32)
+        st[1] = rng.integers(0, 193, V).astype(np.uint32)      # incl. 0 (reads the sample just written) and the maximum
+        st[1, :3] = [0, 1, 192]
+        st[0] = rng.integers(0, 256, V).astype(np.uint32)      # arbitrary write positions: wrap-around inside a vector
+        return dict(kind=P.INTEGER_DELAY, max_delay=max_delay, state0=st, inputs=[x])
+    if name == "integer_var":
+        st = np.zeros((2, V), np.uint32)
+        d = stepped(V, S, seed + 1, 0.0, 192.9, 5, 300)
+        return dict(kind=P.INTEGER_DELAY, max_delay=max_delay, state0=st, inputs=[x, d])
+    if name == "frac_const":
+        st = np.zeros((5, V), np.uint32)
+        for v in range(V):
+            st[3:5, v] = mk.fractional_delay_state(rng.uniform(0.0, 190.0) if v > 3 else [0.0, 0.3, 1.0, 64.617][v]).view(np.uint32)
+        return dict(kind=P.FRACTIONAL_DELAY, max_delay=max_delay, state0=st, inputs=[x])
+    if name == "frac_var":
+        return dict(kind=P.FRACTIONAL_DELAY, max_delay=max_delay, state0=np.zeros((5, V), np.uint32), inputs=[x, slow])
+    if name == "frac_ticks":
+        ticks = np.where(rng.random((V, S)) < 0.05, np.uint32(0xFFFFFFFF), np.uint32(0)).astype(np.uint32).view(np.float32)
+        return dict(kind=P.FRACTIONAL_DELAY, max_delay=max_delay, state0=np.zeros((5, V), np.uint32), inputs=[x, slow, ticks])
+    if name == "pitchbend":
+        return dict(kind=P.PITCHBENDABLE_DELAY, max_delay=max_delay, state0=np.zeros((10, V), np.uint32), inputs=[x, slow])
+    raise KeyError(name)

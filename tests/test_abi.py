@@ -49,7 +49,7 @@ def test_python_enums_match_header():
                 continue
             assert vals[prefix + k] == v, (prefix + k, v)
     hdr_procs = {v for k, v in vals.items() if k.startswith("MLGPU_PROC_")}
-    assert hdr_procs == set(constants.Proc.ALL) | set(constants.Proc.VECTOR_RATE)
+    assert hdr_procs == set(constants.Proc.ALL) | set(constants.Proc.GRAPH_ONLY)
 
 
 def test_coefficient_makers_match_oracle(oracle):

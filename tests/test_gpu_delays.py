@@ -1,0 +1,195 @@
+"""GPU parity of the delay lines (IntegerDelay, Allpass1, FractionalDelay, PitchbendableDelay) and of the composites
+built on one-vector feedback (Allpass<>, FDN<>, FeedbackDelayFunction): bit-exact against the CPU oracle and against
+golden outputs of the reference's own classes (tests/golden/delays.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from graph_oracle import evaluate_stream, new_stream_state
+from inputs import DELAY_CASES, assert_bits_equal, delay_case, lcg_noise
+from madronalib_amd import patches
+from madronalib_amd.constants import Layout, Op, Proc
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "delays.npz"))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import madronalib_amd as ml
+    e = ml.Engine(0)
+    yield e
+    e.close()
+
+
+def delay_graph(eng, V, kind, n_inputs, max_delay):
+    import madronalib_amd as ml
+    g = ml.Graph(eng, V)
+    names = [f"in{i}" for i in range(n_inputs)]
+    for nm in names:
+        g.add(nm, "input")
+    g.add("d", "proc", kind, names, max_delay=max_delay)
+    g.add_output("d")
+    g.compile()
+    return g, names
+
+
+def run_delay(g, names, state0, inputs, T, layout):
+    for i in range(state0.shape[0]):
+        g.set_state("d", i, state0[i])
+    outs, states = [], []
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        (y,) = g.process_host(T, {nm: np.ascontiguousarray(a[:, sl]) for nm, a in zip(names, inputs)}, layout)
+        outs.append(y)
+        states.append(np.stack([g.get_state("d", i) for i in range(state0.shape[0])]))
+    return outs, states
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", DELAY_CASES)
+def test_delay_lines_vs_oracle_and_golden(eng, oracle, name):
+    from graph_oracle import ring_len
+    # golden (reference objects)
+    kind, max_delay = int(GOLD[name + "_kind"]), float(GOLD[name + "_max_delay"])
+    ins = []
+    while f"{name}_in{len(ins)}" in GOLD.files:
+        ins.append(GOLD[f"{name}_in{len(ins)}"])
+    V, T = ins[0].shape[0], ins[0].shape[1] // 128
+    g, names = delay_graph(eng, V, kind, len(ins), max_delay)
+    outs, states = run_delay(g, names, GOLD[name + "_state0"], ins, T, Layout.VOICE_MAJOR)
+    for call in range(2):
+        assert_bits_equal(outs[call], GOLD[f"{name}_out{call + 1}"], True, f"{name} golden out{call + 1}")
+        assert_bits_equal(states[call], GOLD[f"{name}_state{call + 1}"], False, f"{name} golden state{call + 1}")
+    # oracle, more voices
+    V, T = 300, 9
+    c = delay_case(oracle, name, V, 2 * T, seed=8)
+    g, names = delay_graph(eng, V, c["kind"], len(c["inputs"]), c["max_delay"])
+    outs, states = run_delay(g, names, c["state0"], c["inputs"], T, Layout.QUAD)
+    rings = 2 if c["kind"] == Proc.PITCHBENDABLE_DELAY else 1
+    st, mem = c["state0"].copy(), np.zeros((V, rings, ring_len(c["max_delay"])), np.float32)
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        want = oracle.delay_process(c["kind"], T, st, mem, [np.ascontiguousarray(a[:, sl]) for a in c["inputs"]])
+        assert_bits_equal(outs[call], want, True, f"{name} call {call}")
+        assert_bits_equal(states[call], st, False, f"{name} state after call {call}")
+    # clear(): the ring is zeroed, write index and delay time stay
+    g.clear()
+    (y,) = g.process_host(1, {nm: np.zeros((V, 64), np.float32) for nm in names} | ({names[1]: np.full((V, 64), 70.0, np.float32)} if len(names) > 1 else {}), Layout.QUAD)
+    assert (y == 0).all()
+
+
+def _composite(eng, oracle, desc, outs, V, T, sig, params, coeffs, state_edit):
+    """Build the graph, run two launches, compare with the streaming oracle; returns the GPU outputs joined."""
+    import madronalib_amd as ml
+    g = ml.Graph(eng, V, desc, outs)
+    for k, v in params.items():
+        g.set_param(k, v if np.ndim(v) else float(v))
+    for k, c in coeffs.items():
+        g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+    st = new_stream_state(oracle, desc, V)
+    state_edit(st)
+    for n in desc:
+        if n["type"] == "proc":
+            for i in range(st[n["name"]].shape[0]):
+                g.set_state(n["name"], i, st[n["name"]][i])
+    got = [[] for _ in outs]
+    want = [[] for _ in outs]
+    half = T // 2
+    for call in range(2):
+        part = {k: np.ascontiguousarray(v[:, call * 64 * half:(call + 1) * 64 * half]) for k, v in sig.items()}
+        ys = g.process_host(half, part, Layout.QUAD)
+        ws = evaluate_stream(oracle, desc, outs, V, half, part, params, coeffs, st)
+        for i in range(len(outs)):
+            got[i].append(ys[i]), want[i].append(ws[i])
+    got = [np.concatenate(x, 1) for x in got]
+    want = [np.concatenate(x, 1) for x in want]
+    for i, o in enumerate(outs):
+        assert_bits_equal(got[i], want[i], True, f"composite output {o}")
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,kind,d", [(0, Proc.INTEGER_DELAY, 101.0), (1, Proc.FRACTIONAL_DELAY, 77.37), (2, Proc.PITCHBENDABLE_DELAY, 0.0)])
+def test_allpass_composites(eng, oracle, which, kind, d):
+    V, T = 70, 30
+    x = np.repeat(GOLD["comp_x"][None, :], V, 0).copy()
+    x[1:] = lcg_noise(np.arange(V - 1, dtype=np.uint32) + 40, 64 * T)
+    dsig = np.repeat(GOLD["comp_dsig"][None, :], V, 0).copy()
+    dsig[1:] += np.linspace(0, 100, V - 1, dtype=np.float32)[:, None]
+    desc = [dict(name="x", type="input")] + ([dict(name="dl", type="input")] if which == 2 else [])
+    sub, out = patches.allpass("ap_", "x", kind, 400.0, "dl" if which == 2 else None)
+    desc += sub
+    gains = np.full(V, 0.7, np.float32)
+    gains[1:] = np.linspace(-0.9, 0.9, V - 1)
+
+    def edit(st):
+        if which == 0:
+            st["ap_delay"][1] = np.uint32(int(d - 64))
+            st["ap_delay"][1, 1:] = np.arange(V - 1, dtype=np.uint32) * 4
+        if which == 1:
+            st["ap_delay"][3:5, :] = oracle.fractional_delay_state(float(np.float32(d) - np.float32(64.0))).view(np.uint32)[:, None]
+    sig = {"x": x, "dl": dsig} if which == 2 else {"x": x}
+    (got,) = _composite(eng, oracle, desc, [out], V, T, sig, {"ap_gain": gains}, {}, edit)
+    assert_bits_equal(got[0], GOLD[f"allpass{which}"], True, f"Allpass<{kind}> voice 0 vs the reference class")
+
+
+@pytest.mark.gpu
+def test_fdn_composite(eng, oracle):
+    V, T = 50, 30
+    x = np.repeat((GOLD["comp_x"] * np.float32(0.1))[None, :], V, 0).copy()
+    x[1:] = lcg_noise(np.arange(V - 1, dtype=np.uint32) + 77, 64 * T) * np.float32(0.1)
+    times, omegas, gains = [133.0, 201.0, 307.0, 419.0], [0.2, 0.15, 0.1, 0.05], [0.8, 0.75, 0.7, 0.65]
+    desc = [dict(name="x", type="input")]
+    sub, outs = patches.fdn(4, "x", 512.0)
+    desc += sub
+    coeffs = {f"fdn_filter{n}": np.repeat(oracle.make_coeffs("onepole", omegas[n]).reshape(2, 1), V, 1) for n in range(4)}
+    params = {f"fdn_gain{n}": np.full(V, gains[n], np.float32) for n in range(4)}
+
+    def edit(st):
+        for n in range(4):
+            st[f"fdn_delay{n}"][1] = np.uint32(max(1, int(times[n] - 64)))
+            st[f"fdn_delay{n}"][1, 1:] += (np.arange(V - 1, dtype=np.uint32) % 37)
+    got = _composite(eng, oracle, desc, outs, V, T, {"x": x}, params, coeffs, edit)
+    assert_bits_equal(got[0][0], GOLD["fdnL"], True, "FDN<4> sumL voice 0 vs the reference class")
+    assert_bits_equal(got[1][0], GOLD["fdnR"], True, "FDN<4> sumR voice 0 vs the reference class")
+
+
+@pytest.mark.gpu
+def test_feedback_delay_function(eng, oracle):
+    V, T = 40, 30
+    x = np.repeat(GOLD["comp_x"][None, :], V, 0).copy()
+    dsig = np.repeat((GOLD["comp_dsig"] + np.float32(150.0))[None, :], V, 0).copy()
+    dsig[1:] += np.linspace(0, 300, V - 1, dtype=np.float32)[:, None]
+    co = oracle.make_coeffs("lopass", 0.08, 0.9)
+    desc = [dict(name="x", type="input"), dict(name="dl", type="input"), dict(name="g", type="const", value=0.6),
+            dict(name="c64", type="const", value=64.0), dict(name="vy1", type="feedback", source="delay"),
+            dict(name="fb", type="op", kind=Op.MULTIPLY, inputs=["vy1", "g"]), dict(name="sum", type="op", kind=Op.ADD, inputs=["x", "fb"]),
+            dict(name="fn", type="proc", kind=Proc.LOPASS, inputs=["sum"]), dict(name="dt", type="op", kind=Op.SUBTRACT, inputs=["dl", "c64"]),
+            dict(name="delay", type="proc", kind=Proc.PITCHBENDABLE_DELAY, inputs=["fn", "dt"], max_delay=1000.0)]
+    (got,) = _composite(eng, oracle, desc, ["fn"], V, T, {"x": x, "dl": dsig}, {}, {"fn": np.repeat(co.reshape(3, 1), V, 1)}, lambda st: None)
+    assert_bits_equal(got[0], GOLD["fbdelay"], True, "FeedbackDelayFunction voice 0 vs the reference class")
+
+
+@pytest.mark.gpu
+def test_delay_rules(eng):
+    import madronalib_amd as ml
+    with pytest.raises(ml.MlgpuError) as ei:
+        eng.bank([Proc.INTEGER_DELAY], 64)                       # delay lines are graph nodes
+    assert ei.value.status == ml.Status.ERR_UNSUPPORTED
+    g = ml.Graph(eng, 64)
+    a = g.add("a", "input")
+    d = g.add("d", "proc", Proc.INTEGER_DELAY, [a])
+    g.add_output(d)
+    with pytest.raises(ml.MlgpuError):
+        g.compile()                                              # no memory: set_max_delay missing
+    with pytest.raises(ml.MlgpuError):
+        g.set_max_delay(a, 100.0)                                # not a delay node
+    g.set_max_delay(d, 100.0)
+    fb = g.add("fb", "feedback")
+    with pytest.raises(ml.MlgpuError):
+        g.compile()                                              # feedback without a source
+    g.set_feedback(fb, d)
+    g.compile()
+    bank = eng.bank([Proc.ALLPASS1], 64)                         # Allpass1 has no ring: fine in a bank
+    assert bank.num_coeffs(0) == 1 and bank.num_state(0) == 2

@@ -156,3 +156,91 @@ def test_row_plumbing_and_routing_match_reference(oracle, ref, name):
     composed as the host does == the reference's own template instantiations."""
     ins = case_inputs(name)
     assert_bits_equal(run_rows_case(oracle, name, ins), ref.rows_case(name, ins), True, name)
+
+
+from graph_oracle import evaluate_stream, new_stream_state, ring_len  # noqa: E402
+from inputs import DELAY_CASES, delay_case, lcg_noise, stepped  # noqa: E402
+from madronalib_amd import patches  # noqa: E402
+
+
+@pytest.mark.parametrize("name", DELAY_CASES)
+def test_delay_lines_match_reference(oracle, ref, name):
+    """IntegerDelay / FractionalDelay / PitchbendableDelay: the per-sample restatement against the reference objects'
+    own operator() forms (incl. the block form for constant delays), outputs, state and ring contents, two calls."""
+    V, T = 10, 12
+    c = delay_case(oracle, name, V, 2 * T, seed=3)
+    cr = delay_case(ref, name, V, 2 * T, seed=3)
+    assert_bits_equal(c["state0"], cr["state0"], False, name + " setDelayInSamples state")
+    rings = 2 if c["kind"] == Proc.PITCHBENDABLE_DELAY else 1
+    L = ring_len(c["max_delay"])
+    st_o, st_r = c["state0"].copy(), c["state0"].copy()
+    mem_o, mem_r = np.zeros((V, rings, L), np.float32), np.zeros((V, rings, L), np.float32)
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        ins = [np.ascontiguousarray(a[:, sl]) for a in c["inputs"]]
+        want = ref.delay_process(c["kind"], T, st_r, mem_r, ins)
+        got = oracle.delay_process(c["kind"], T, st_o, mem_o, ins)
+        assert_bits_equal(got, want, True, f"{name} call {call}")
+        assert_bits_equal(st_o, st_r, False, f"{name} state after call {call}")
+        assert_bits_equal(mem_o, mem_r, True, f"{name} ring contents after call {call}")
+
+
+def test_allpass1_and_delay_coefficients_match_reference(oracle, ref):
+    for d in (0.0, 0.3, 0.618, 0.9999, 1.0, 1.618, 5.5, 63.99, 64.0, 100.617, 1234.25):
+        assert oracle.allpass1_coeffs(d) == ref.allpass1_coeffs(d)
+        assert_bits_equal(oracle.fractional_delay_state(d), ref.fractional_delay_state(d), False, f"setDelayInSamples({d})")
+
+
+@pytest.mark.parametrize("which,kind,d", [(0, Proc.INTEGER_DELAY, 101.0), (1, Proc.FRACTIONAL_DELAY, 77.37), (2, Proc.PITCHBENDABLE_DELAY, 0.0)])
+def test_allpass_composite_matches_reference(oracle, ref, which, kind, d):
+    """Allpass<IntegerDelay / FractionalDelay / PitchbendableDelay> as a graph with a feedback node == the class."""
+    T, gain, max_delay = 30, 0.7, 400.0
+    x = lcg_noise(np.array([5], np.uint32), 64 * T)
+    dsig = (150.0 + 60.0 * np.sin(np.arange(64 * T) * 0.003))[None, :].astype(np.float32)
+    desc = [dict(name="x", type="input")] + ([dict(name="dl", type="input")] if which == 2 else [])
+    sub, out = patches.allpass("ap_", "x", kind, max_delay, "dl" if which == 2 else None)
+    desc += sub
+    st = new_stream_state(oracle, desc, 1)
+    if which == 0:
+        st["ap_delay"][1] = np.uint32(int(d - 64))                 # Allpass::setDelayInSamples(d) -> mDelay.setDelayInSamples(d - 64)
+    if which == 1:
+        st["ap_delay"][3:5, 0] = oracle.fractional_delay_state(float(np.float32(d) - np.float32(64.0))).view(np.uint32)
+    (got,) = evaluate_stream(oracle, desc, [out], 1, T, {"x": x, "dl": dsig}, {"ap_gain": gain}, {}, st)
+    want = ref.allpass_run(which, gain, max_delay, d, dsig[0] if which == 2 else None, x[0])
+    assert_bits_equal(got[0], want, True, f"Allpass<{kind}>")
+
+
+def test_fdn_composite_matches_reference(oracle, ref):
+    T = 40
+    x = lcg_noise(np.array([9], np.uint32), 64 * T) * np.float32(0.1)
+    times, omegas, gains = [133.0, 201.0, 307.0, 419.0], [0.2, 0.15, 0.1, 0.05], [0.8, 0.75, 0.7, 0.65]
+    desc = [dict(name="x", type="input")]
+    sub, outs = patches.fdn(4, "x", 512.0)
+    desc += sub
+    st = new_stream_state(oracle, desc, 1)
+    coeffs = {}
+    for n in range(4):
+        st[f"fdn_delay{n}"][1] = np.uint32(max(1, int(times[n] - 64)))   # setDelaysInSamples, MLDSPFilters.h:1172-1181
+        coeffs[f"fdn_filter{n}"] = oracle.make_coeffs("onepole", omegas[n]).reshape(2, 1)
+    got = evaluate_stream(oracle, desc, outs, 1, T, {"x": x}, {f"fdn_gain{n}": gains[n] for n in range(4)}, coeffs, st)
+    wantL, wantR = ref.fdn4_run(times, omegas, gains, 512.0, x[0])
+    assert_bits_equal(got[0][0], wantL, True, "FDN<4> sumL")
+    assert_bits_equal(got[1][0], wantR, True, "FDN<4> sumR")
+    assert np.abs(wantL).max() > 1e-3
+
+
+def test_feedback_delay_function_matches_reference(oracle, ref):
+    """FeedbackDelayFunction (MLDSPFunctional.h:262-290) around a Lopass."""
+    T, fbGain, max_delay = 36, 0.6, 1000.0
+    x = lcg_noise(np.array([2], np.uint32), 64 * T)
+    dsig = (300.0 + 100.0 * np.sin(np.arange(64 * T) * 0.002))[None, :].astype(np.float32)
+    co = oracle.make_coeffs("lopass", 0.08, 0.9)
+    desc = [dict(name="x", type="input"), dict(name="dl", type="input"), dict(name="g", type="const", value=fbGain),
+            dict(name="c64", type="const", value=64.0), dict(name="vy1", type="feedback", source="delay"),
+            dict(name="fb", type="op", kind=Op.MULTIPLY, inputs=["vy1", "g"]), dict(name="sum", type="op", kind=Op.ADD, inputs=["x", "fb"]),
+            dict(name="fn", type="proc", kind=Proc.LOPASS, inputs=["sum"]), dict(name="dt", type="op", kind=Op.SUBTRACT, inputs=["dl", "c64"]),
+            dict(name="delay", type="proc", kind=Proc.PITCHBENDABLE_DELAY, inputs=["fn", "dt"], max_delay=max_delay)]
+    st = new_stream_state(oracle, desc, 1)
+    (got,) = evaluate_stream(oracle, desc, ["fn"], 1, T, {"x": x, "dl": dsig}, {}, {"fn": co.reshape(3, 1)}, st)
+    want = ref.feedback_delay_run(fbGain, max_delay, co, dsig[0], x[0])
+    assert_bits_equal(got[0], want, True, "FeedbackDelayFunction")
