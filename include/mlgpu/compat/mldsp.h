@@ -59,6 +59,24 @@ struct Capture
     uint32_t bits;
   };
   std::vector<Deferred> deferred;
+  // Two capture passes ("epochs"): a DSPVector that still holds a node of the PREVIOUS pass when it is used is a value
+  // the user code kept from one process call to the next (Allpass::vy1, a state struct's own feedback members, ...).
+  // It becomes a feedback node; its source is the node with the same creation ordinal in the current pass.
+  uint32_t epoch{1};
+  int nextOrd{0};
+  std::vector<int> nodeOfOrd;           // this pass: ordinal -> node
+  std::map<int, int> feedbackOfOrd;     // previous-pass ordinal -> feedback node of this pass
+  int computed(int node)                // register a node created by an op / processor / generator / routing call
+  {
+    nodeOfOrd.push_back(node);
+    return nextOrd++;
+  }
+  int feedbackFor(int ord)
+  {
+    auto it = feedbackOfOrd.find(ord);
+    if (it != feedbackOfOrd.end()) return it->second;
+    return feedbackOfOrd[ord] = ret(mlgpu_graph_add_feedback(g, nullptr));
+  }
 
   static Capture*& current()
   {
@@ -98,8 +116,25 @@ struct Sig
 {
   int node{-1};
   float lit{0.f};
-  int id() const { return node >= 0 ? node : Capture::get().constant(lit); }
+  uint32_t epoch{0};  // capture pass that made `node`
+  int ord{-1};        // creation ordinal among the computed nodes of that pass (-1: input / param / const)
+  Sig() {}
+  Sig(int n, float l) : node(n), lit(l), epoch(n >= 0 ? Capture::get().epoch : 0) {}
+  int id() const
+  {
+    if (node < 0) return Capture::get().constant(lit);
+    Capture& c = Capture::get();
+    if (epoch == c.epoch) return node;
+    if (ord < 0) throw std::logic_error("mldsp GPU shim: a DSPVector kept from an earlier process call holds an input / parameter, not a computed signal");
+    return c.feedbackFor(ord);
+  }
 };
+inline Sig computedSig(int node)
+{
+  Sig s(node, 0.f);
+  s.ord = Capture::get().computed(node);
+  return s;
+}
 
 inline Sig opNode(int op, std::initializer_list<Sig> in)
 {
@@ -107,7 +142,7 @@ inline Sig opNode(int op, std::initializer_list<Sig> in)
   int ids[3];
   int n = 0;
   for (const Sig& s : in) ids[n++] = s.id();
-  return Sig{c.ret(mlgpu_graph_add_op(c.g, op, ids, n, nullptr)), 0.f};
+  return computedSig(c.ret(mlgpu_graph_add_op(c.g, op, ids, n, nullptr)));
 }
 inline Sig vopNode(int vop, std::initializer_list<Sig> in)
 {
@@ -115,7 +150,7 @@ inline Sig vopNode(int vop, std::initializer_list<Sig> in)
   int ids[2];
   int n = 0;
   for (const Sig& s : in) ids[n++] = s.id();
-  return Sig{c.ret(mlgpu_graph_add_vop(c.g, vop, ids, n, nullptr)), 0.f};
+  return computedSig(c.ret(mlgpu_graph_add_vop(c.g, vop, ids, n, nullptr)));
 }
 }  // namespace gpu
 
@@ -141,7 +176,7 @@ class DSPVectorArray
   DSPVectorArray() {}  // zero-filled, MLDSPOps.h:153
   DSPVectorArray(float k)  // broadcast conversion ctor, MLDSPOps.h:157
   {
-    for (auto& s : sig_) s = gpu::Sig{-1, k};
+    for (auto& s : sig_) s = gpu::Sig(-1, k);
   }
   explicit DSPVectorArray(gpu::Sig s)
   {
@@ -150,7 +185,7 @@ class DSPVectorArray
   }
   DSPVectorArray& operator=(float k)
   {
-    for (auto& s : sig_) s = gpu::Sig{-1, k};
+    for (auto& s : sig_) s = gpu::Sig(-1, k);
     return *this;
   }
 
@@ -372,14 +407,14 @@ inline DSPVectorArray<ROWS> add(const DSPVectorArray<ROWS>& first, const DSPVect
 
 // ---- index generators (MLDSPOps.h:962-990, 1365-1383) ---------------------------------------------------------------
 inline DSPVector columnIndex() { return DSPVector(gpu::vopNode(MLGPU_VOP_COLUMN_INDEX, {})); }
-inline DSPVector rangeOpen(float start, float end) { return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_OPEN, {gpu::Sig{-1, start}, gpu::Sig{-1, end}})); }
+inline DSPVector rangeOpen(float start, float end) { return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_OPEN, {gpu::Sig(-1, start), gpu::Sig(-1, end)})); }
 inline DSPVector rangeClosed(float start, float end)
 {
-  return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_CLOSED, {gpu::Sig{-1, start}, gpu::Sig{-1, end}}));
+  return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_CLOSED, {gpu::Sig(-1, start), gpu::Sig(-1, end)}));
 }
 inline DSPVector interpolateDSPVectorLinear(float start, float end)
 {
-  return DSPVector(gpu::vopNode(MLGPU_VOP_INTERPOLATE_LINEAR, {gpu::Sig{-1, start}, gpu::Sig{-1, end}}));
+  return DSPVector(gpu::vopNode(MLGPU_VOP_INTERPOLATE_LINEAR, {gpu::Sig(-1, start), gpu::Sig(-1, end)}));
 }
 
 // ---- row plumbing (MLDSPOps.h:1057-1383): with rows as separate signals this is wiring, no arithmetic ---------------
@@ -534,7 +569,7 @@ inline DSPVectorArray<ROWS> routeMux(int route, DSPVector selector, DSPVectorArr
     int ids[1 + MLGPU_ROUTE_MAX_SIGNALS];
     ids[0] = selector.sig_[0].id();
     for (int k = 0; k < n; ++k) ids[1 + k] = inputs[k].sig_[j].id();
-    y.sig_[j] = Sig{c.ret(mlgpu_graph_add_route(c.g, route, ids, 1 + n, 0, 0, nullptr)), 0.f};
+    y.sig_[j] = computedSig(c.ret(mlgpu_graph_add_route(c.g, route, ids, 1 + n, 0, 0, nullptr)));
   }
   return y;
 }
@@ -560,23 +595,39 @@ template <int KIND>
 struct ProcNode
 {
   int node_{-1};
+  uint32_t nodeEpoch_{0};
   bool cleared_{false};
   uint32_t initState0_{0};
   bool hasInitState0_{false};
+  float maxDelay_{-1.f};                            // delay lines: setMaxDelayInSamples
+  std::vector<std::pair<int, uint32_t>> initState_;  // further state words set before the first call
 
   Sig emit(std::initializer_list<Sig> ins, const float* coeffs, int nc)
   {
     Capture& c = Capture::get();
-    if (node_ >= 0)
+    if (node_ >= 0 && nodeEpoch_ == c.epoch)
       throw std::logic_error("mldsp GPU shim: a stateful object was called twice in one process function (one call = one state update)");
     int ids[8];
     int n = 0;
     for (const Sig& s : ins) ids[n++] = s.id();
     node_ = c.ret(mlgpu_graph_add_proc(c.g, KIND, ids, n, nullptr));
+    nodeEpoch_ = c.epoch;
+    if (maxDelay_ >= 0.f) c.eng->check(mlgpu_graph_set_max_delay(c.g, node_, maxDelay_));
     for (int i = 0; i < nc; ++i) c.deferCoeff(node_, i, coeffs[i]);
     if (cleared_) c.deferClear(node_);
     if (hasInitState0_) c.deferState(node_, 0, initState0_);
-    return Sig{node_, 0.f};
+    for (auto& kv : initState_) c.deferState(node_, kv.first, kv.second);
+    return computedSig(node_);
+  }
+  void presetState(int idx, uint32_t bits)
+  {
+    for (auto& kv : initState_)
+      if (kv.first == idx)
+      {
+        kv.second = bits;
+        return;
+      }
+    initState_.push_back({idx, bits});
   }
   int node() const { return node_; }
 };
@@ -853,6 +904,201 @@ struct ADSR : public gpu::ProcNode<MLGPU_PROC_ADSR>
   }
 };
 
+// ---- delay lines, MLDSPFilters.h:799-1239 ------------------------------------------------------------------------------
+namespace gpu
+{
+inline uint32_t bitsOfFloat(float f)
+{
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+constexpr float kDefaultMaxDelay = 65536.f - 64.f;  // for the two reference classes that cannot size their own delays
+}  // namespace gpu
+
+class IntegerDelay : public gpu::ProcNode<MLGPU_PROC_INTEGER_DELAY>
+{
+ public:
+  IntegerDelay() = default;
+  IntegerDelay(int d)
+  {
+    setMaxDelayInSamples(static_cast<float>(d));
+    setDelayInSamples(d);
+  }
+  void setDelayInSamples(int d) { presetState(1, (uint32_t)d); }
+  void setMaxDelayInSamples(float d) { maxDelay_ = d; }
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, nullptr, 0)); }
+  DSPVector operator()(const DSPVector x, const DSPVector delay) { return DSPVector(emit({x.sig_[0], delay.sig_[0]}, nullptr, 0)); }
+};
+
+class Allpass1 : public gpu::ProcNode<MLGPU_PROC_ALLPASS1>
+{
+ public:
+  typedef float Coeffs;
+  Coeffs coeffs{0.f};
+  Allpass1(float a) : coeffs(a) {}
+  void clear() { cleared_ = true; }
+  static float makeCoeffs(float d) { return mlgpu_allpass1_make_coeffs(d); }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, &coeffs, 1)); }
+};
+
+class FractionalDelay : public gpu::ProcNode<MLGPU_PROC_FRACTIONAL_DELAY>
+{
+ public:
+  FractionalDelay() = default;
+  FractionalDelay(float d)
+  {
+    setMaxDelayInSamples(d);
+    setDelayInSamples(d);
+  }
+  void clear() { cleared_ = true; }
+  void setDelayInSamples(float d)
+  {
+    float st[2];
+    mlgpu_fractional_delay_make_state(d, st);
+    presetState(3, gpu::bitsOfFloat(st[0]));
+    presetState(4, gpu::bitsOfFloat(st[1]));
+  }
+  void setMaxDelayInSamples(float d) { maxDelay_ = floorf(d); }
+  DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, nullptr, 0)); }
+  DSPVector operator()(const DSPVector vx, const DSPVector vDelayInSamples) { return DSPVector(emit({vx.sig_[0], vDelayInSamples.sig_[0]}, nullptr, 0)); }
+  DSPVector operator()(const DSPVector vx, const DSPVector vDelayInSamples, const DSPVectorInt vChangeTicks)
+  {
+    return DSPVector(emit({vx.sig_[0], vDelayInSamples.sig_[0], vChangeTicks.sig_[0]}, nullptr, 0));
+  }
+};
+
+class PitchbendableDelay : public gpu::ProcNode<MLGPU_PROC_PITCHBENDABLE_DELAY>
+{
+ public:
+  PitchbendableDelay() = default;
+  void setMaxDelayInSamples(float d) { maxDelay_ = floorf(d); }
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector vInput, const DSPVector vDelayInSamples)
+  {
+    if (maxDelay_ < 0.f) maxDelay_ = gpu::kDefaultMaxDelay;
+    return DSPVector(emit({vInput.sig_[0], vDelayInSamples.sig_[0]}, nullptr, 0));
+  }
+};
+
+// Allpass<DELAY_TYPE>, MLDSPFilters.h:1110-1160. vy1 is an ordinary DSPVector member kept between calls: the capture
+// turns it into one-vector feedback (see gpu::Capture).
+template <typename DELAY_TYPE>
+class Allpass
+{
+  DELAY_TYPE mDelay;
+  DSPVector vy1{};
+
+ public:
+  float mGain{0.f};
+  void setDelayInSamples(float d) { mDelay.setDelayInSamples(d - kFloatsPerDSPVector); }
+  void setMaxDelayInSamples(float d) { mDelay.setMaxDelayInSamples(d - kFloatsPerDSPVector); }
+  void clear()
+  {
+    mDelay.clear();
+    vy1 = DSPVector();
+  }
+  DSPVector operator()(const DSPVector vInput)
+  {
+    DSPVector vGain(-mGain);
+    DSPVector vDelayInput = vInput - vy1 * vGain;
+    DSPVector y = vDelayInput * vGain + vy1;
+    vy1 = mDelay(vDelayInput);
+    return y;
+  }
+  DSPVector operator()(const DSPVector vInput, const DSPVector vDelayInSamples)
+  {
+    DSPVector vGain(-mGain);
+    DSPVector vDelayInput = vInput - vy1 * vGain;
+    DSPVector y = vDelayInput * vGain + vy1;
+    vy1 = mDelay(vDelayInput, vDelayInSamples - DSPVector(kFloatsPerDSPVector));
+    return y;
+  }
+};
+
+// FDN<SIZE>, MLDSPFilters.h:1162-1239. (The reference class never allocates its IntegerDelays; here each gets a ring that
+// holds the delay time it is given.)
+template <int SIZE>
+class FDN
+{
+  std::array<IntegerDelay, SIZE> mDelays;
+  std::array<OnePole, SIZE> mFilters;
+  std::array<DSPVector, SIZE> mDelayInputVectors{};
+
+ public:
+  std::array<float, SIZE> mFeedbackGains{{0}};
+  void setDelaysInSamples(std::array<float, SIZE> times)
+  {
+    for (int n = 0; n < SIZE; ++n)
+    {
+      int len = times[n] - kFloatsPerDSPVector;  // one DSPVector of feedback latency
+      len = len > 1 ? len : 1;
+      mDelays[n].setMaxDelayInSamples((float)len);
+      mDelays[n].setDelayInSamples(len);
+    }
+  }
+  void setFilterCutoffs(std::array<float, SIZE> omegas)
+  {
+    for (int n = 0; n < SIZE; ++n) mFilters[n].coeffs = OnePole::makeCoeffs(omegas[n]);
+  }
+  DSPVectorArray<2> operator()(const DSPVector x)
+  {
+    for (int n = 0; n < SIZE; ++n) mDelayInputVectors[n] = mDelays[n](mDelayInputVectors[n]);
+    DSPVector sumR, sumL;
+    for (int n = 0; n < (SIZE & (~1)); ++n)
+    {
+      if (n & 1) sumL += mDelayInputVectors[n];
+      else sumR += mDelayInputVectors[n];
+    }
+    DSPVector sumOfDelays;
+    for (int n = 0; n < SIZE; ++n) sumOfDelays += mDelayInputVectors[n];
+    sumOfDelays *= DSPVector(2.0f / SIZE);
+    for (int n = 0; n < SIZE; ++n)
+    {
+      mDelayInputVectors[n] -= (sumOfDelays);
+      mDelayInputVectors[n] = mFilters[n](mDelayInputVectors[n]) * DSPVector(mFeedbackGains[n]);
+      mDelayInputVectors[n] += x;
+    }
+    return concatRows(sumL, sumR);
+  }
+};
+
+// FeedbackDelayFunction(WithTap), MLDSPFunctional.h:262-316
+class FeedbackDelayFunction
+{
+  using ProcessFn = std::function<DSPVector(const DSPVector)>;
+  PitchbendableDelay mDelay;
+  DSPVector vy1;
+
+ public:
+  float feedbackGain{1.f};
+  void setMaxDelayInSamples(float d) { mDelay.setMaxDelayInSamples(d); }  // extension: the reference offers no way to size it
+  DSPVector operator()(const DSPVector vx, ProcessFn fn, const DSPVector vDelayTime)
+  {
+    DSPVector vFnOutput = fn(vx + vy1 * DSPVector(feedbackGain));
+    vy1 = mDelay(vFnOutput, vDelayTime - DSPVector(kFloatsPerDSPVector));
+    return vFnOutput;
+  }
+};
+class FeedbackDelayFunctionWithTap
+{
+  using ProcessFn = std::function<DSPVector(const DSPVector, DSPVector&)>;
+  PitchbendableDelay mDelay;
+  DSPVector vy1;
+
+ public:
+  float feedbackGain{1.f};
+  void setMaxDelayInSamples(float d) { mDelay.setMaxDelayInSamples(d); }
+  DSPVector operator()(const DSPVector vx, ProcessFn fn, const DSPVector vDelayTime)
+  {
+    DSPVector vOutputTap;
+    DSPVector vFeedback = fn(vx + vy1 * DSPVector(feedbackGain), vOutputTap);
+    vy1 = mDelay(vFeedback, vDelayTime - DSPVector(kFloatsPerDSPVector));
+    return vOutputTap;
+  }
+};
+
 // Bank<T, ROWS>, MLDSPFunctional.h:321-360
 template <typename T, size_t ROWS>
 class Bank
@@ -897,14 +1143,16 @@ class VoiceParam
 {
   std::string name_;
   int node_{-1};
+  uint32_t epoch_{0};
 
  public:
   explicit VoiceParam(const char* name) : name_(name) {}
   operator DSPVector()
   {
     Capture& c = Capture::get();
-    if (node_ < 0) node_ = c.ret(mlgpu_graph_add_param(c.g, name_.c_str()));
-    return DSPVector(Sig{node_, 0.f});
+    if (node_ < 0 || epoch_ != c.epoch) node_ = c.ret(mlgpu_graph_add_param(c.g, name_.c_str()));
+    epoch_ = c.epoch;
+    return DSPVector(Sig(node_, 0.f));
   }
   int node() const { return node_; }
   const std::string& name() const { return name_; }
@@ -921,10 +1169,11 @@ class VoiceProgram
  public:
   VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state) : eng_(e), voices_(voices)
   {
-    eng_.check(mlgpu_graph_create(e.handle(), voices, &g_));
+    static uint32_t epochCounter = 0;
+    nIn_ = ctx->inputs.size();
+    nOut_ = ctx->outputs.size();
     Capture cap;
     cap.eng = &e;
-    cap.g = g_;
     struct Scope
     {
       Capture*& slot;
@@ -932,12 +1181,30 @@ class VoiceProgram
       Scope(Capture*& s, Capture* c) : slot(s), prev(s) { slot = c; }
       ~Scope() { slot = prev; }
     } scope(Capture::current(), &cap);
-    nIn_ = ctx->inputs.size();
-    nOut_ = ctx->outputs.size();
-    for (size_t c = 0; c < nIn_; ++c)
-      ctx->inputs[(int)c] = DSPVector(Sig{cap.ret(mlgpu_graph_add_input(g_, ("in" + std::to_string(c)).c_str())), 0.f});
-    for (size_t c = 0; c < nOut_; ++c) ctx->outputs[(int)c] = DSPVector(0.f);
-    fn(ctx, state);
+    // pass 1 records what the process function leaves behind in the user's state (DSPVectors kept for the next call);
+    // pass 2 builds the graph that is compiled, reading those as one-vector feedback
+    for (int pass = 0; pass < 2; ++pass)
+    {
+      if (g_) mlgpu_graph_destroy(g_);
+      g_ = nullptr;
+      eng_.check(mlgpu_graph_create(e.handle(), voices, &g_));
+      cap.g = g_;
+      cap.epoch = ++epochCounter;
+      cap.nextOrd = 0;
+      cap.nodeOfOrd.clear();
+      cap.feedbackOfOrd.clear();
+      cap.constNodes.clear();
+      cap.deferred.clear();
+      for (size_t c = 0; c < nIn_; ++c)
+        ctx->inputs[(int)c] = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g_, ("in" + std::to_string(c)).c_str())), 0.f));
+      for (size_t c = 0; c < nOut_; ++c) ctx->outputs[(int)c] = DSPVector(0.f);
+      fn(ctx, state);
+    }
+    for (auto& kv : cap.feedbackOfOrd)
+    {
+      if (kv.first >= (int)cap.nodeOfOrd.size()) throw std::logic_error("mldsp GPU shim: the process function took different paths in its two capture passes");
+      eng_.check(mlgpu_graph_set_feedback(g_, kv.second, cap.nodeOfOrd[kv.first]));
+    }
     for (size_t c = 0; c < nOut_; ++c) eng_.check(mlgpu_graph_add_output(g_, ctx->outputs[(int)c].sig_[0].id()));
     eng_.check(mlgpu_graph_compile(g_));
     for (const Capture::Deferred& d : cap.deferred)
@@ -957,6 +1224,7 @@ class VoiceProgram
   }
 
   size_t voices() const { return voices_; }
+  mlgpu_graph* graph() const { return g_; }
   const char* source() const { return mlgpu_graph_source(g_); }  // the generated HIP kernel
 
   // per-voice values: [voices] floats

@@ -29,6 +29,27 @@ extern "C" int dropin_ref_run(size_t V, size_t T, const float* gate, const float
   return 0;
 }
 
+#include "../tests/cpp/dropin_reverb.h"
+extern "C" int plate_ref_run(size_t V, size_t T, const float* inL, const float* inR, float* outL, float* outR)
+{
+  const size_t S = T * kFloatsPerDSPVector;
+  for (size_t v = 0; v < V; ++v)
+  {
+    PlateState state;
+    plateSetup(state);
+    AudioContext ctx(2, 2, 48000);
+    for (size_t t = 0; t < T; ++t)
+    {
+      load(ctx.inputs[0], inL + v * S + t * kFloatsPerDSPVector);
+      load(ctx.inputs[1], inR + v * S + t * kFloatsPerDSPVector);
+      plateProcess(&ctx, &state);
+      store(ctx.outputs[0], outL + v * S + t * kFloatsPerDSPVector);
+      store(ctx.outputs[1], outR + v * S + t * kFloatsPerDSPVector);
+    }
+  }
+  return 0;
+}
+
 // ---- the reference's SignalProcessBuffer driven with a sequence of host block sizes -----------------------------
 // process function: out0 = Lopass(in0) (stateful), out1 = in0 * 0.5. blocks[i] frames per call; in / out0 / out1
 // hold the concatenated blocks. Pins the behaviour of mlgpu_process_buffer (latency, zero-fill, ring sizes).

@@ -39,3 +39,47 @@ extern "C" int dropin_gpu_run(size_t V, size_t T, const float* gate, const float
     return -1;
   }
 }
+
+#include "dropin_reverb.h"
+// the plate reverb for V independent instances; launches: how many process calls the T vectors are split into
+extern "C" int plate_gpu_run(size_t V, size_t T, int launches, const float* inL, const float* inR, float* outL, float* outR, char* err, size_t errLen)
+{
+  try
+  {
+    gpu::Engine eng(0);
+    PlateState state;
+    plateSetup(state);
+    AudioContext ctx(2, 2, 48000);
+    gpu::VoiceProgram prog(eng, V, &ctx, plateProcess, &state);
+    const size_t Tl = T / (size_t)launches;
+    // QUAD signals: the T vectors of one launch are contiguous, so consecutive launches are consecutive slices
+    gpu::DeviceSignal vmL(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR), vmR(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR);
+    gpu::DeviceSignal qL(eng, V, T), qR(eng, V, T), oL(eng, V, T), oR(eng, V, T);
+    eng.check(mlgpu_upload(eng.handle(), vmL.data(), inL, vmL.bytes()));
+    eng.check(mlgpu_upload(eng.handle(), vmR.data(), inR, vmR.bytes()));
+    eng.check(mlgpu_layout_convert(eng.handle(), vmL.data(), MLGPU_LAYOUT_VOICE_MAJOR, qL.data(), MLGPU_LAYOUT_QUAD, V, T));
+    eng.check(mlgpu_layout_convert(eng.handle(), vmR.data(), MLGPU_LAYOUT_VOICE_MAJOR, qR.data(), MLGPU_LAYOUT_QUAD, V, T));
+    for (int l = 0; l < launches; ++l)
+    {
+      const size_t off = (size_t)l * Tl * 64 * V;
+      const float* ins[2] = {qL.data() + off, qR.data() + off};
+      float* outs[2] = {oL.data() + off, oR.data() + off};
+      eng.check(mlgpu_graph_process(prog.graph(), Tl, ins, MLGPU_LAYOUT_QUAD, outs, MLGPU_LAYOUT_QUAD));
+    }
+    eng.check(mlgpu_layout_convert(eng.handle(), oL.data(), MLGPU_LAYOUT_QUAD, vmL.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, T));
+    eng.check(mlgpu_layout_convert(eng.handle(), oR.data(), MLGPU_LAYOUT_QUAD, vmR.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, T));
+    eng.check(mlgpu_download(eng.handle(), outL, vmL.data(), vmL.bytes()));
+    eng.check(mlgpu_download(eng.handle(), outR, vmR.data(), vmR.bytes()));
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
