@@ -110,7 +110,7 @@ def setup_workload(eng, name, V, T, lo, total):
         from madronalib_amd import patches
         from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
         desc, outs = patches.synth16()
-        g = ml.Graph(eng, V, desc, outs)
+        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")))
         g.clear()
         params, coeffs, seeds = cfg5_voice_params(lo, lo + V, total, ml)
         for k, v in params.items():

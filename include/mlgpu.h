@@ -433,6 +433,9 @@ int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* input_nodes, int n_inp
 int mlgpu_graph_add_output(mlgpu_graph* g, int node);
 int mlgpu_graph_node(mlgpu_graph* g, const char* name); /* id of the node called `name`, or < 0 */
 int mlgpu_graph_num_nodes(mlgpu_graph* g);
+/* Voices evaluated by one wavefront lane (before compile): 0 = automatic (default), 1, or 2. Two voices per lane interleave
+ * two independent dependency chains, which helps arithmetic-bound graphs; results are identical. */
+int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n);
 /* Generate + compile (hiprtc, gfx950) + load the fused kernel; allocate state/coeffs/params. */
 int mlgpu_graph_compile(mlgpu_graph* g);
 /* The generated HIP source (valid after compile; for inspection). */

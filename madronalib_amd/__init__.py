@@ -467,7 +467,7 @@ class Graph:
       {"name", "type": "input"|"param"|"const"|"proc"|"op", "kind": Proc.X / Op.X, "inputs": [names], "value"}
     """
 
-    def __init__(self, engine, n_voices, description=None, outputs=None):
+    def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0):
         self.engine = engine
         self.L = engine.L
         self.V = int(n_voices)
@@ -477,6 +477,8 @@ class Graph:
         self.ids = {}
         self.inputs, self.outputs, self.controls = [], [], []
         engine._children.add(self)
+        if voices_per_lane:
+            engine._check(self.L.mlgpu_graph_set_voices_per_lane(self.h, int(voices_per_lane)))
         if description is not None:
             for n in description:
                 self.add(**n)

@@ -138,6 +138,7 @@ def _declare(L):
     sig("mlgpu_graph_clear", i, [vp])
     sig("mlgpu_graph_clear_proc", i, [vp, i])
     sig("mlgpu_graph_set_input_layout", i, [vp, i, i])
+    sig("mlgpu_graph_set_voices_per_lane", i, [vp, i])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
     sig("mlgpu_dspbuffer_create", vp, [])
     sig("mlgpu_dspbuffer_destroy", None, [vp])

@@ -208,6 +208,8 @@ struct mlgpu_graph
   float* d_params{nullptr};
   float* d_mem{nullptr};
   size_t memFloatsPerVoice{0};
+  int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
+  int compiledVoicesPerLane{1};
   int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1};
 };
 
@@ -219,35 +221,36 @@ int gfail(mlgpu_graph* g, int status, const std::string& what)
   return status;
 }
 
-// the C++ expression of node i (its inputs are the locals n<j>)
-std::string nodeExpr(const mlgpu_graph* g, size_t i)
+// the C++ expression of node i for lane-group l (its inputs are the locals n<j>_<l>)
+std::string nodeExpr(const mlgpu_graph* g, size_t i, int l)
 {
   const Node& n = g->nodes[i];
   std::ostringstream s;
-  auto arg = [&](size_t j) { return "n" + std::to_string(n.in[j]); };
+  const std::string L = "_" + std::to_string(l);
+  auto arg = [&](size_t j) { return "n" + std::to_string(n.in[j]) + L; };
   switch (n.type)
   {
-    case NODE_INPUT: s << "xin" << n.slot << "[k]"; break;
-    case NODE_CONTROL: s << "ctl" << n.slot << "[t * a.V]"; break;
-    case NODE_PARAM: s << "a.params[(size_t)" << n.slot << " * a.V + v]"; break;
+    case NODE_INPUT: s << "xin" << n.slot << L << "[k]"; break;
+    case NODE_CONTROL: s << "ctl" << n.slot << L << "[t * a.V]"; break;
+    case NODE_PARAM: s << "a.params[(size_t)" << n.slot << " * a.V + v" << L << "]"; break;
     case NODE_CONST: s << floatLiteral(n.value); break;
     case NODE_PROC:
       if (mlgpu_proc_is_vector_rate(n.kind))
-        s << "p" << i << ".next_n(q * 4 + k)";
+        s << "p" << i << L << ".next_n(q * 4 + k)";
       else if (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY)
-        s << "p" << i << ".next_i(q * 4 + k, " << arg(0) << ", " << arg(1) << ")";
+        s << "p" << i << L << ".next_i(q * 4 + k, " << arg(0) << ", " << arg(1) << ")";
       else if ((n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
       {
         // launch-constant frequency: the polyBLEP range test was done once per wavefront (odd<i>)
-        s << "p" << i << ".next_u(" << arg(0);
+        s << "p" << i << L << ".next_u(" << arg(0);
         if (n.in.size() == 2) s << ", " << arg(1);
         s << ", odd" << i << ")";
       }
       else if (n.kind == MLGPU_PROC_PULSE_GEN && n.in.size() == 2)
-        s << "p" << i << ".next2(" << arg(0) << ", " << arg(1) << ")";
+        s << "p" << i << L << ".next2(" << arg(0) << ", " << arg(1) << ")";
       else
       {
-        s << "p" << i << ".next(" << (n.in.empty() ? std::string("0.f") : arg(0));
+        s << "p" << i << L << ".next(" << (n.in.empty() ? std::string("0.f") : arg(0));
         for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
         s << ")";
       }
@@ -257,7 +260,7 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i)
       for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
       s << ")";
       break;
-    case NODE_FEEDBACK: s << "u2f(a.state[(size_t)(" << n.sOff << " + q * 4 + k) * a.V + v])"; break;
+    case NODE_FEEDBACK: s << "u2f(a.state[(size_t)(" << n.sOff << " + q * 4 + k) * a.V + v" << L << "])"; break;
     case NODE_ROUTE:
       if (n.kind == MLGPU_ROUTE_MULTIPLEX || n.kind == MLGPU_ROUTE_MULTIPLEX_LINEAR)
       {
@@ -278,10 +281,31 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i)
   return s.str();
 }
 
+// Voices per lane. A fused voice is ONE dependent chain of VALU instructions per lane, and on gfx950 a wave's
+// back-to-back dependent instructions issue at half rate whatever the occupancy (tools/valubench.hip). With two voices
+// per lane (voice v and v + 256 of the same workgroup: loads and stores stay coalesced) every statement is emitted for
+// both and the two chains interleave. Worth it for arithmetic-heavy graphs; graphs with delay rings or long vector state
+// stay at one voice per lane (their limit is memory latency, and registers are better spent on occupancy).
+int graphVoicesPerLane(const mlgpu_graph* g)
+{
+  if (g->voicesPerLane > 0) return g->voicesPerLane;
+  int audioNodes = 0;
+  for (const Node& n : g->nodes)
+  {
+    if (n.type == NODE_FEEDBACK || (n.type == NODE_PROC && (mlgpu_proc_rings(n.kind) || mlgpu_proc_is_vector_rate(n.kind)))) return 1;
+    if (n.rate == RATE_AUDIO && (n.type == NODE_PROC || n.type == NODE_OP || n.type == NODE_ROUTE)) audioNodes++;
+  }
+  return (audioNodes >= 8 && g->NS + g->NC <= 80) ? 2 : 1;
+}
+
 std::string generateGraphSource(mlgpu_graph* g)
 {
+  const int VL = graphVoicesPerLane(g);
+  g->compiledVoicesPerLane = VL;
   std::ostringstream s;
-  s << "// generated by libmlgpu graph.hip\n#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\nusing namespace mldev;\n";
+  auto sfx = [](int l) { return "_" + std::to_string(l); };
+  s << "// generated by libmlgpu graph.hip (" << VL << " voice" << (VL > 1 ? "s" : "") << " per lane)\n"
+    << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\nusing namespace mldev;\n";
   s << "extern \"C\" __global__ __launch_bounds__(256) void mlgpu_graph_kernel(const GraphArgs a)\n{\n";
   if (g->hasImpulse)
   {
@@ -294,30 +318,39 @@ std::string generateGraphSource(mlgpu_graph* g)
   }
   s << "  size_t blk = blockIdx.x;\n  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;\n"
        "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n"
-       "  const size_t v = blk * 256 + threadIdx.x;\n  if (v >= a.V) return;\n";
+       "  const size_t v_0 = blk * " << 256 * VL << " + threadIdx.x;\n  if (v_0 >= a.V) return;\n";
+  // a lane whose second voice does not exist recomputes its first one: same inputs, same state, same stores
+  for (int l = 1; l < VL; ++l) s << "  const size_t v" << sfx(l) << " = (v_0 + " << 256 * l << " < a.V) ? v_0 + " << 256 * l << " : v_0;\n";
   auto emit = [&](size_t i, const char* indent) {
-    s << indent << "const float n" << i << " = " << nodeExpr(g, i) << ";";
-    if (!g->nodes[i].name.empty()) s << "  // " << g->nodes[i].name;
-    s << "\n";
+    for (int l = 0; l < VL; ++l)
+    {
+      s << indent << "const float n" << i << sfx(l) << " = " << nodeExpr(g, i, l) << ";";
+      if (l == 0 && !g->nodes[i].name.empty()) s << "  // " << g->nodes[i].name;
+      s << "\n";
+    }
   };
   // once per voice: processor state, signal bases, voice-rate nodes
   for (size_t i = 0; i < g->nodes.size(); ++i)
   {
     const Node& n = g->nodes[i];
-    if (n.type == NODE_PROC)
+    for (int l = 0; l < VL; ++l)
     {
-      s << "  Proc<" << n.kind << "> p" << i << ";\n  const VoiceMem m" << i << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v, a.state + (size_t)"
-        << n.sOff << " * a.V + v, a.V";
-      if (n.ringLen) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v, " << (n.ringLen - 1) << "u";
-      s << "};\n  p" << i << ".load(m" << i << ", tables);\n";
-    }
-    else if (n.type == NODE_INPUT)
-    {
-      s << "  const f32x4* in" << n.slot << " = (const f32x4*)a.in[" << n.slot << "].base + v * a.in[" << n.slot << "].strideV;\n";
-    }
-    else if (n.type == NODE_CONTROL)
-    {
-      s << "  const float* ctl" << n.slot << " = a.ctl[" << n.slot << "] + v;\n";
+      const std::string L = sfx(l);
+      if (n.type == NODE_PROC)
+      {
+        s << "  Proc<" << n.kind << "> p" << i << L << ";\n  const VoiceMem m" << i << L << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v" << L
+          << ", a.state + (size_t)" << n.sOff << " * a.V + v" << L << ", a.V";
+        if (n.ringLen) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v" << L << ", " << (n.ringLen - 1) << "u";
+        s << "};\n  p" << i << L << ".load(m" << i << L << ", tables);\n";
+      }
+      else if (n.type == NODE_INPUT)
+      {
+        s << "  const f32x4* in" << n.slot << L << " = (const f32x4*)a.in[" << n.slot << "].base + v" << L << " * a.in[" << n.slot << "].strideV;\n";
+      }
+      else if (n.type == NODE_CONTROL)
+      {
+        s << "  const float* ctl" << n.slot << L << " = a.ctl[" << n.slot << "] + v" << L << ";\n";
+      }
     }
     if (n.rate == RATE_VOICE && n.type != NODE_PROC) emit(i, "  ");
   }
@@ -325,39 +358,54 @@ std::string generateGraphSource(mlgpu_graph* g)
   {
     const Node& n = g->nodes[i];
     if (n.type == NODE_PROC && (n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
-      s << "  const bool odd" << i << " = __builtin_amdgcn_ballot_w64(blep_freq_is_odd(n" << n.in[0] << ")) != 0;\n";
+    {
+      s << "  const bool odd" << i << " = __builtin_amdgcn_ballot_w64(blep_freq_is_odd(n" << n.in[0] << "_0)";
+      for (int l = 1; l < VL; ++l) s << " || blep_freq_is_odd(n" << n.in[0] << sfx(l) << ")";
+      s << ") != 0;\n";
+    }
   }
   for (size_t o = 0; o < g->outputs.size(); ++o)
-    s << "  f32x4* out" << o << " = (f32x4*)a.out[" << o << "].base + v * a.out[" << o << "].strideV;\n";
+    for (int l = 0; l < VL; ++l)
+      s << "  f32x4* out" << o << sfx(l) << " = (f32x4*)a.out[" << o << "].base + v" << sfx(l) << " * a.out[" << o << "].strideV;\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
   // once per DSPVector: vector-rate nodes, then the vector-rate processors' begin_vector
   for (size_t i = 0; i < g->nodes.size(); ++i)
   {
     const Node& n = g->nodes[i];
     if (n.rate == RATE_VECTOR) emit(i, "    ");
-    if (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind)) s << "    p" << i << ".begin_vector(n" << n.in[0] << ");\n";
+    if (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind))
+      for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".begin_vector(n" << n.in[0] << sfx(l) << ");\n";
   }
   s << "#pragma unroll 2\n    for (int q = 0; q < 16; ++q)\n    {\n";
   for (int i = 0; i < g->nInputs; ++i)
-    s << "      const f32x4 xin" << i << " = __builtin_nontemporal_load(in" << i << " + t * a.in[" << i << "].strideT + q * a.in[" << i << "].strideQ);\n";
-  for (size_t o = 0; o < g->outputs.size(); ++o) s << "      f32x4 y" << o << ";\n";
+    for (int l = 0; l < VL; ++l)
+      s << "      const f32x4 xin" << i << sfx(l) << " = __builtin_nontemporal_load(in" << i << sfx(l) << " + t * a.in[" << i << "].strideT + q * a.in["
+        << i << "].strideQ);\n";
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    for (int l = 0; l < VL; ++l) s << "      f32x4 y" << o << sfx(l) << ";\n";
   s << "#pragma unroll\n      for (int k = 0; k < 4; ++k)\n      {\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].rate == RATE_AUDIO) emit(i, "        ");
-  for (size_t o = 0; o < g->outputs.size(); ++o) s << "        y" << o << "[k] = n" << g->outputs[o] << ";\n";
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    for (int l = 0; l < VL; ++l) s << "        y" << o << sfx(l) << "[k] = n" << g->outputs[o] << sfx(l) << ";\n";
   // feedback: keep this sample's value for the same sample of the next DSPVector (its old value was read above)
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].fbSource >= 0)
-      s << "        a.state[(size_t)(" << g->nodes[i].sOff << " + q * 4 + k) * a.V + v] = f2u(n" << g->nodes[i].fbSource << ");\n";
+      for (int l = 0; l < VL; ++l)
+        s << "        a.state[(size_t)(" << g->nodes[i].sOff << " + q * 4 + k) * a.V + v" << sfx(l) << "] = f2u(n" << g->nodes[i].fbSource << sfx(l) << ");\n";
   s << "      }\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
-    s << "      __builtin_nontemporal_store(y" << o << ", out" << o << " + t * a.out[" << o << "].strideT + q * a.out[" << o << "].strideQ);\n";
+    for (int l = 0; l < VL; ++l)
+      s << "      __builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o
+        << "].strideQ);\n";
   s << "    }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
-    if (g->nodes[i].type == NODE_PROC) s << "    p" << i << ".end_vector();\n";
+    if (g->nodes[i].type == NODE_PROC)
+      for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".end_vector();\n";
   s << "  }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
-    if (g->nodes[i].type == NODE_PROC) s << "  p" << i << ".store(m" << i << ");\n";
+    if (g->nodes[i].type == NODE_PROC)
+      for (int l = 0; l < VL; ++l) s << "  p" << i << sfx(l) << ".store(m" << i << sfx(l) << ");\n";
   s << "}\n";
   return s.str();
 }
@@ -726,7 +774,6 @@ extern "C"
     if (g->compiled) return MLGPU_OK;
     if (g->outputs.empty()) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: no outputs");
     mlgpu_engine* e = g->e;
-    if (hipSetDevice(e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
     size_t memFloats = 0;
     for (Node& n : g->nodes)
     {
@@ -738,6 +785,7 @@ extern "C"
     }
     g->memFloatsPerVoice = memFloats;
     g->source = generateGraphSource(g);
+    if (hipSetDevice(e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
     CompiledModule* cm = compileAndLoad(e->device, g->source, g->log);
     if (!cm) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
     g->fn = getFunction(cm, "mlgpu_graph_kernel", g->log);
@@ -870,6 +918,15 @@ extern "C"
     return mlgpu_upload(g->e, g->d_state + (size_t)(g->nodes[node].sOff + idx) * g->V, h, sizeof(uint32_t) * g->V);
   }
 
+  int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (n < 0 || n > 2) return gfail(g, MLGPU_ERR_INVALID, "graph_set_voices_per_lane: 0 (automatic), 1 or 2");
+    g->voicesPerLane = n;
+    return MLGPU_OK;
+  }
+
   int mlgpu_graph_set_input_layout(mlgpu_graph* g, int inputIndex, int layout)
   {
     if (!g) return MLGPU_ERR_INVALID;
@@ -928,7 +985,7 @@ extern "C"
       a.out[o] = makeView(d_outputs[o], outLayout, g->V, T);
     }
     if (hipSetDevice(g->e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
-    const hipError_t err = launchJit(g->fn, a, g->V, g->e->stream);
+    const hipError_t err = launchJit(g->fn, a, (g->V + g->compiledVoicesPerLane - 1) / g->compiledVoicesPerLane, g->e->stream);
     if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, std::string("graph_process launch: ") + hipGetErrorString(err));
     return MLGPU_OK;
   }

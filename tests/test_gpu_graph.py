@@ -42,10 +42,10 @@ def synth16_setup(oracle, V, seed=0):
     return params, coeffs
 
 
-def build_synth16(eng, oracle, V, params, coeffs, seeds):
+def build_synth16(eng, oracle, V, params, coeffs, seeds, voices_per_lane=0):
     import madronalib_amd as ml
     desc, outs = patches.synth16()
-    g = ml.Graph(eng, V, desc, outs)
+    g = ml.Graph(eng, V, desc, outs, voices_per_lane=voices_per_lane)
     g.clear()
     for k, v in params.items():
         g.set_param(k, v if np.ndim(v) else float(v))
@@ -58,12 +58,14 @@ def build_synth16(eng, oracle, V, params, coeffs, seeds):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("vpl", [1, 2])
 @pytest.mark.parametrize("layout", [Layout.QUAD, Layout.ROWS])
-def test_synth16_vs_oracle(eng, oracle, layout):
-    V, T = 300, 24
+def test_synth16_vs_oracle(eng, oracle, layout, vpl):
+    V, T = 300, 24   # 300 voices: with two voices per lane the second half-block is ragged
     params, coeffs = synth16_setup(oracle, V, seed=4)
     seeds = np.arange(V, dtype=np.uint32) * np.uint32(2654435761)
-    g, desc, outs, states = build_synth16(eng, oracle, V, params, coeffs, seeds)
+    g, desc, outs, states = build_synth16(eng, oracle, V, params, coeffs, seeds, vpl)
+    assert f"({vpl} voice" in g.source
     assert "mlgpu_graph_kernel" in g.source and "p10.next" in g.source or "next(" in g.source
     gate = gate_signal(V, 64 * T * 2, seed=9)
     for call in range(2):  # second call resumes from carried state
