@@ -470,6 +470,23 @@ int mlgpu_engine_set_jit(mlgpu_engine* e, int enabled);
 int mlgpu_jit_selftest(char* log, size_t log_len);
 
 /* ------------------------------------------------------------------------- */
+/* sample-rate conversion by powers of two                                   */
+/*
+ * Downsampler / Upsampler (MLDSPFilters.h:1316-1473): a cascade of HalfBandFilters (:1245-1310), one per octave, for every
+ * voice. `up` = 0: every 2^octaves input DSPVectors give one output vector (Downsampler::write returns true, read());
+ * n_vectors_in must be a multiple of 2^octaves. `up` = 1: every input vector gives 2^octaves output vectors
+ * (Upsampler::write, then 2^octaves read()s). State: 9 floats per octave per voice, SoA [octave*9 + i][V], i in
+ * {apa0.x1, apa0.y1, apa1.x1, apa1.y1, apb0.x1, apb0.y1, apb1.x1, apb1.y1, b1}. octaves 0..6 (0 copies).
+ */
+typedef struct mlgpu_resampler mlgpu_resampler;
+int mlgpu_resampler_create(mlgpu_engine* e, size_t n_voices, int octaves, int up, mlgpu_resampler** out);
+int mlgpu_resampler_destroy(mlgpu_resampler* r);
+int mlgpu_resampler_clear(mlgpu_resampler* r);
+int mlgpu_resampler_get_state(mlgpu_resampler* r, float* h_state);
+int mlgpu_resampler_set_state(mlgpu_resampler* r, const float* h_state);
+int mlgpu_resampler_process(mlgpu_resampler* r, size_t n_vectors_in, const float* d_in, int in_layout, float* d_out, int out_layout);
+
+/* ------------------------------------------------------------------------- */
 /* host ring and block adaptor                                               */
 /*
  * mlgpu_dspbuffer — the reference's DSPBuffer (source/DSP/MLDSPBuffer.h:20-384): a single-producer /

@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, Route, RowOp, RowsRule, Status, Vop
 
-__all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "Allpass1", "FractionalDelay", "LinearGlide", "SampleAccurateLinearGlide",
+__all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "Resampler", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "Allpass1", "FractionalDelay", "LinearGlide", "SampleAccurateLinearGlide",
            "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
            "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
 
@@ -333,6 +333,65 @@ class ProcessBuffer:
             raise err[0]
         self.engine._check(st)
         return outs
+
+
+class Resampler:
+    """Downsampler / Upsampler (MLDSPFilters.h:1316-1473) for V voices: a HalfBandFilter cascade, one stage per octave."""
+
+    def __init__(self, engine, n_voices, octaves, up):
+        self.engine, self.L = engine, engine.L
+        self.V, self.octaves, self.up = int(n_voices), int(octaves), bool(up)
+        h = ctypes.c_void_p()
+        engine._check(self.L.mlgpu_resampler_create(engine.h, self.V, self.octaves, 1 if up else 0, ctypes.byref(h)))
+        self.h = h
+        engine._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None) and self.engine.h:
+            self.L.mlgpu_resampler_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        self.engine._check(self.L.mlgpu_resampler_clear(self.h))
+
+    def get_state(self):
+        out = np.zeros((self.octaves * 9, self.V), np.float32)
+        if out.size:
+            self.engine._check(self.L.mlgpu_resampler_get_state(self.h, _np_ptr(out)))
+        return out
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, np.float32)
+        if st.size:
+            self.engine._check(self.L.mlgpu_resampler_set_state(self.h, _np_ptr(st)))
+
+    def process(self, n_vectors_in, d_in, d_out, in_layout=Layout.QUAD, out_layout=Layout.QUAD):
+        self.engine._check(self.L.mlgpu_resampler_process(self.h, int(n_vectors_in), ctypes.c_void_p(d_in.ptr), int(in_layout),
+                                                         ctypes.c_void_p(d_out.ptr), int(out_layout)))
+
+    def process_host(self, x, layout=Layout.QUAD):
+        """x [V][64*Tin] numpy -> [V][64*Tout] numpy (conversion to / from `layout` on the device)."""
+        eng, V = self.engine, self.V
+        x = np.ascontiguousarray(x, np.float32)
+        Tin = x.shape[1] // 64
+        Tout = Tin << self.octaves if self.up else Tin >> self.octaves
+        d_vm = eng.to_device(x)
+        d_in, d_out = d_vm, eng.alloc(4 * V * 64 * Tout)
+        if layout != Layout.VOICE_MAJOR:
+            d_in = eng.alloc(x.nbytes)
+            eng.layout_convert(d_vm, Layout.VOICE_MAJOR, d_in, layout, V, Tin)
+        self.process(Tin, d_in, d_out, layout, layout)
+        res = d_out
+        if layout != Layout.VOICE_MAJOR:
+            res = eng.alloc(4 * V * 64 * Tout)
+            eng.layout_convert(d_out, layout, res, Layout.VOICE_MAJOR, V, Tout)
+        return res.download(np.float32, V * 64 * Tout).reshape(V, 64 * Tout)
 
 
 class Bank:

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmlgpu.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mlgpu.h")
 
-_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "coeffs.cpp", "dspbuffer.cpp", "processbuffer.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
+_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "resample.hip", "coeffs.cpp", "dspbuffer.cpp", "processbuffer.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
             "mldsp_procs.hpp", "mldsp_kernels.hpp", "mlgpu_device_args.hpp", "mlgpu_internal.hpp", "embed.py",
             "Makefile"]
 
@@ -140,6 +140,12 @@ def _declare(L):
     sig("mlgpu_graph_set_input_layout", i, [vp, i, i])
     sig("mlgpu_graph_set_voices_per_lane", i, [vp, i])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
+    sig("mlgpu_resampler_create", i, [vp, sz, i, i, pp])
+    sig("mlgpu_resampler_destroy", i, [vp])
+    sig("mlgpu_resampler_clear", i, [vp])
+    sig("mlgpu_resampler_get_state", i, [vp, vp])
+    sig("mlgpu_resampler_set_state", i, [vp, vp])
+    sig("mlgpu_resampler_process", i, [vp, sz, vp, i, vp, i])
     sig("mlgpu_dspbuffer_create", vp, [])
     sig("mlgpu_dspbuffer_destroy", None, [vp])
     sig("mlgpu_dspbuffer_resize", sz, [vp, i])

@@ -1771,3 +1771,59 @@ int mlorc_delay_process(int kind, size_t V, size_t T, uint32_t* state, float* me
   }
   return MLGPU_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* HalfBandFilter / Downsampler / Upsampler, MLDSPFilters.h:1245-1473         */
+/*
+ * Same contract as mlgpu_resampler_process: state [octaves*9][V] in/out (per octave: apa0 x1 y1, apa1 x1 y1, apb0 x1 y1,
+ * apb1 x1 y1, b1), in [V][64*T_in], out [V][64*T_out]. Written as the stream cascade the block schedule of
+ * Downsampler::write (:1349-1387) / Upsampler::write (:1428-1452) amounts to; tests compare with those classes.
+ */
+static float ap1_step(float* st, float x, float coeff) /* Allpass1::processSample :945-953 */
+{
+  const float y = st[0] + (x - st[1]) * coeff;
+  st[0] = x;
+  st[1] = y;
+  return y;
+}
+static float hb_a(float* f, float x) { return ap1_step(f + 2, ap1_step(f + 0, x, 0.07986642623635751f), 0.5453536510711322f); } /* apa0, apa1 :1307 */
+static float hb_b(float* f, float x) { return ap1_step(f + 6, ap1_step(f + 4, x, 0.28382934487410993f), 0.8344118914807379f); }  /* apb0, apb1 :1308 */
+static float down_rec(float* f, int h, const float* x)
+{
+  if (h == 0) return x[0];
+  const float e = down_rec(f, h - 1, x);
+  const float o = down_rec(f, h - 1, x + (1 << (h - 1)));
+  float* st = f + (h - 1) * 9;
+  const float a0 = hb_a(st, e), b0 = hb_b(st, o);
+  const float y = (a0 + st[8]) * 0.5f; /* :1281-1283 */
+  st[8] = b0;
+  return y;
+}
+static void up_rec(float* f, int h, int total, float x, float* y)
+{
+  if (h == 0)
+  {
+    y[0] = x;
+    return;
+  }
+  float* st = f + (total - h) * 9;
+  const float ya = hb_a(st, x), yb = hb_b(st, x); /* :1254-1255 */
+  up_rec(f, h - 1, total, ya, y);
+  up_rec(f, h - 1, total, yb, y + (1 << (h - 1)));
+}
+int mlorc_resample(int octaves, int up, size_t V, size_t T_in, float* state, const float* in, float* out)
+{
+  if (octaves < 0 || octaves > 6) return MLGPU_ERR_INVALID;
+  const size_t R = (size_t)1 << octaves, Sin = T_in * VEC, Sout = up ? Sin * R : Sin / R;
+  float f[6 * 9];
+  for (size_t v = 0; v < V; ++v)
+  {
+    for (int i = 0; i < octaves * 9; ++i) f[i] = state[(size_t)i * V + v];
+    if (up)
+      for (size_t s = 0; s < Sin; ++s) up_rec(f, octaves, octaves, in[v * Sin + s], out + v * Sout + s * R);
+    else
+      for (size_t s = 0; s < Sout; ++s) out[v * Sout + s] = down_rec(f, octaves, in + v * Sin + s * R);
+    for (int i = 0; i < octaves * 9; ++i) state[(size_t)i * V + v] = f[i];
+  }
+  return MLGPU_OK;
+}

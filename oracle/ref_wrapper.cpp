@@ -1220,6 +1220,64 @@ extern "C"
     return MLGPU_OK;
   }
 
+  // ---- Downsampler / Upsampler: the reference classes driven vector by vector, same contract as mlorc_resample ----
+  namespace
+  {
+  void hbLoad(HalfBandFilter& h, const float* st, size_t V)
+  {
+    h.apa0.x1 = st[0 * V]; h.apa0.y1 = st[1 * V]; h.apa1.x1 = st[2 * V]; h.apa1.y1 = st[3 * V];
+    h.apb0.x1 = st[4 * V]; h.apb0.y1 = st[5 * V]; h.apb1.x1 = st[6 * V]; h.apb1.y1 = st[7 * V];
+    h.b1 = st[8 * V];
+  }
+  void hbStore(const HalfBandFilter& h, float* st, size_t V)
+  {
+    st[0 * V] = h.apa0.x1; st[1 * V] = h.apa0.y1; st[2 * V] = h.apa1.x1; st[3 * V] = h.apa1.y1;
+    st[4 * V] = h.apb0.x1; st[5 * V] = h.apb0.y1; st[6 * V] = h.apb1.x1; st[7 * V] = h.apb1.y1;
+    st[8 * V] = h.b1;
+  }
+  }  // namespace
+  int mlref_resample(int octaves, int up, size_t V, size_t Tin, float* state, const float* in, float* out)
+  {
+    const size_t R = (size_t)1 << octaves, Sin = Tin * kFloatsPerDSPVector, Sout = up ? Sin * R : Sin / R;
+    for (size_t v = 0; v < V; ++v)
+    {
+      if (up)
+      {
+        Upsampler u(octaves);
+        for (int h = 0; h < octaves; ++h) hbLoad(u._filters[h], state + (size_t)h * 9 * V + v, V);
+        size_t o = 0;
+        for (size_t t = 0; t < Tin; ++t)
+        {
+          DSPVector x;
+          load(x, in + v * Sin + t * kFloatsPerDSPVector);
+          if (octaves == 0) { store(x, out + v * Sout + o); o += kFloatsPerDSPVector; continue; }  // Upsampler(0) has no buffers
+          u.write(x);
+          for (size_t r = 0; r < R; ++r, o += kFloatsPerDSPVector) store(u.read(), out + v * Sout + o);
+        }
+        for (int h = 0; h < octaves; ++h) hbStore(u._filters[h], state + (size_t)h * 9 * V + v, V);
+      }
+      else
+      {
+        Downsampler d(octaves);
+        for (int h = 0; h < octaves; ++h) hbLoad(d._filters[h], state + (size_t)h * 9 * V + v, V);
+        size_t o = 0;
+        for (size_t t = 0; t < Tin; ++t)
+        {
+          DSPVector x;
+          load(x, in + v * Sin + t * kFloatsPerDSPVector);
+          if (octaves == 0) { store(x, out + v * Sout + o); o += kFloatsPerDSPVector; continue; }
+          if (d.write(x))
+          {
+            store(d.read(), out + v * Sout + o);
+            o += kFloatsPerDSPVector;
+          }
+        }
+        for (int h = 0; h < octaves; ++h) hbStore(d._filters[h], state + (size_t)h * 9 * V + v, V);
+      }
+    }
+    return MLGPU_OK;
+  }
+
   // ---- row plumbing and routing: the reference's own templates at fixed sizes ----
   // in[k] are DSPVectorArrays (row-major, as many rows as the case needs); out receives the result rows
   // (for demultiplex cases: the outputs one after the other). Returns the number of output rows, < 0 if unknown.

@@ -201,6 +201,19 @@ class _Checker:
         fnc(float(d), _ptr(o, c_f32p))
         return o
 
+    def resample(self, octaves, up, state, x):
+        """Downsampler (up=False) / Upsampler (up=True) cascade. state [octaves*9][V] updated in place; x [V][64*Tin]."""
+        fnc = getattr(self.lib, self.prefix + "resample")
+        fnc.restype = ctypes.c_int
+        fnc.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p]
+        x = np.ascontiguousarray(x, np.float32)
+        V, Sin = x.shape
+        R = 1 << octaves
+        out = np.empty((V, Sin * R if up else Sin // R), np.float32)
+        assert state.dtype == np.float32 and state.flags["C_CONTIGUOUS"]
+        assert fnc(octaves, 1 if up else 0, V, Sin // 64, _ptr(state, c_f32p), _ptr(x, c_f32p), _ptr(out, c_f32p)) == 0
+        return out
+
     def vop(self, vop, V, T, a=None, b=None):
         out = np.empty((V, 64 * T), np.float32)
         a = None if a is None else np.ascontiguousarray(a, np.float32)

@@ -131,7 +131,13 @@ def main():
     d["fdnL"], d["fdnR"] = ref.fdn4_run([133.0, 201.0, 307.0, 419.0], [0.2, 0.15, 0.1, 0.05], [0.8, 0.75, 0.7, 0.65], 512.0, x * np.float32(0.1))
     d["fbdelay"] = ref.feedback_delay_run(0.6, 1000.0, ref.make_coeffs("lopass", 0.08, 0.9), dsig + np.float32(150.0), x)
     np.savez_compressed(os.path.join(HERE, "delays.npz"), **d)
-    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz"):
+    # ---- Downsampler / Upsampler ----
+    d = {"x": lcg_noise(np.arange(4, dtype=np.uint32) + 21, 64 * 8)}
+    for octaves in (1, 3):
+        d[f"down{octaves}"] = ref.resample(octaves, False, np.zeros((octaves * 9, 4), np.float32), d["x"])
+        d[f"up{octaves}"] = ref.resample(octaves, True, np.zeros((octaves * 9, 4), np.float32), d["x"])
+    np.savez_compressed(os.path.join(HERE, "resample.npz"), **d)
+    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz", "resample.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -244,3 +244,17 @@ def test_feedback_delay_function_matches_reference(oracle, ref):
     (got,) = evaluate_stream(oracle, desc, ["fn"], 1, T, {"x": x, "dl": dsig}, {}, {"fn": co.reshape(3, 1)}, st)
     want = ref.feedback_delay_run(fbGain, max_delay, co, dsig[0], x[0])
     assert_bits_equal(got[0], want, True, "FeedbackDelayFunction")
+
+
+@pytest.mark.parametrize("octaves", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("up", [False, True])
+def test_resamplers_match_reference(oracle, ref, octaves, up):
+    """Downsampler / Upsampler: the stream cascade == the reference classes' block schedule; two calls, carried state."""
+    V = 5
+    Tin = 2 * (1 << octaves) if not up else 3
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 70, 64 * Tin * 2)
+    st_o, st_r = np.zeros((octaves * 9, V), np.float32), np.zeros((octaves * 9, V), np.float32)
+    for call in range(2):
+        xs = np.ascontiguousarray(x[:, call * 64 * Tin:(call + 1) * 64 * Tin])
+        assert_bits_equal(oracle.resample(octaves, up, st_o, xs), ref.resample(octaves, up, st_r, xs), True, f"resample call {call}")
+        assert_bits_equal(st_o, st_r, True, "HalfBandFilter state")
