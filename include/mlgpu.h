@@ -470,6 +470,62 @@ int mlgpu_engine_set_jit(mlgpu_engine* e, int enabled);
 int mlgpu_jit_selftest(char* log, size_t log_len);
 
 /* ------------------------------------------------------------------------- */
+/* performance events -> per-voice control signals                            */
+/*
+ * mlgpu_events is EventsToSignals (source/app/MLEventsToSignals.{h,cpp}) for n_instruments independent instruments of
+ * `polyphony` voices each: events in, 8 control signals per voice out — pitch, gate, vox, z, x, y, mod, elapsed time
+ * (VoiceOutputSignals, MLEventsToSignals.h:15-26) — for V = n_instruments * polyphony voices (instrument-major), ready to
+ * be the inputs of a bank or graph. Voice allocation, key states, unison, sustain and the MIDI / MPE channel rules run on
+ * the host; glides, drift and the sample-accurate note timing run on the device.
+ * Usage per host block, as AudioContext / SignalProcessBuffer do (MLSignalProcessBuffer.cpp:47-89): add_event()s with
+ * times in frames from the start of the block, process(n_vectors, start_offset) once or several times, clear_events().
+ * Not reproduced: controller 120 ("all sound off"), which clears the event buffer the reference is iterating (:749-755).
+ */
+typedef enum mlgpu_event_type /* ml::EventType, source/app/MLEvent.h:13-26 */
+{
+  MLGPU_EVENT_NULL = 0,
+  MLGPU_EVENT_NOTE_ON = 1,
+  MLGPU_EVENT_NOTE_RETRIG = 2,
+  MLGPU_EVENT_NOTE_SUSTAIN = 3,
+  MLGPU_EVENT_NOTE_OFF = 4,
+  MLGPU_EVENT_SUSTAIN_PEDAL = 5,
+  MLGPU_EVENT_CONTROLLER = 6,
+  MLGPU_EVENT_PITCH_BEND = 7,
+  MLGPU_EVENT_NOTE_PRESSURE = 8,
+  MLGPU_EVENT_CHANNEL_PRESSURE = 9,
+  MLGPU_EVENT_PROGRAM_CHANGE = 10
+} mlgpu_event_type;
+typedef struct mlgpu_event /* ml::Event, MLEvent.h:31-53 */
+{
+  uint8_t type;        /* mlgpu_event_type */
+  uint8_t channel;
+  uint16_t source_idx; /* key or controller number */
+  int32_t time;        /* onset in frames from the start of the current host block */
+  float value1;        /* note: pitch; controller / bend / pressure: value */
+  float value2;        /* note: velocity */
+} mlgpu_event;
+typedef struct mlgpu_events mlgpu_events;
+int mlgpu_events_create(mlgpu_engine* e, size_t n_instruments, int polyphony /* setPolyphony, 1..16 */, mlgpu_events** out);
+int mlgpu_events_destroy(mlgpu_events* ev);
+int mlgpu_events_clear(mlgpu_events* ev);                                   /* clear(), :330-340 */
+int mlgpu_events_set_sample_rate(mlgpu_events* ev, double sr);
+int mlgpu_events_set_protocol(mlgpu_events* ev, int mpe);                   /* setProtocol("MIDI" / "MPE"); clears */
+int mlgpu_events_set_unison(mlgpu_events* ev, int on);
+int mlgpu_events_set_mod_cc(mlgpu_events* ev, int cc);
+int mlgpu_events_set_pitch_bend_semitones(mlgpu_events* ev, float f);
+int mlgpu_events_set_mpe_pitch_bend_semitones(mlgpu_events* ev, float f);
+int mlgpu_events_set_pitch_glide_seconds(mlgpu_events* ev, float f);
+int mlgpu_events_set_drift_amount(mlgpu_events* ev, float f);
+size_t mlgpu_events_num_voices(mlgpu_events* ev);
+int mlgpu_events_newest_voice(mlgpu_events* ev, size_t instrument);        /* getNewestVoice() */
+int mlgpu_events_add_event(mlgpu_events* ev, size_t instrument, const mlgpu_event* e);   /* addEvent, :367-372 */
+int mlgpu_events_clear_events(mlgpu_events* ev);                            /* clearEvents */
+/* processVector (:376-466) for n_vectors consecutive DSPVectors; start_offset = frame of the first one in the host block.
+ * d_outputs[8]: device signals of V voices x n_vectors vectors in `layout` (any may be NULL = not wanted), in the order
+ * pitch, gate, vox, z, x, y, mod, elapsed time. */
+int mlgpu_events_process(mlgpu_events* ev, size_t n_vectors, int start_offset, float* const* d_outputs, int layout);
+
+/* ------------------------------------------------------------------------- */
 /* sample-rate conversion by powers of two                                   */
 /*
  * Downsampler / Upsampler (MLDSPFilters.h:1316-1473): a cascade of HalfBandFilters (:1245-1310), one per octave, for every

@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, Route, RowOp, RowsRule, Status, Vop
 
-__all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "Resampler", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "Allpass1", "FractionalDelay", "LinearGlide", "SampleAccurateLinearGlide",
+__all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "Resampler", "Events", "Event", "EventType", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "Allpass1", "FractionalDelay", "LinearGlide", "SampleAccurateLinearGlide",
            "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
            "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
 
@@ -333,6 +333,82 @@ class ProcessBuffer:
             raise err[0]
         self.engine._check(st)
         return outs
+
+
+class EventType:  # ml::EventType, source/app/MLEvent.h:13-26
+    NULL, NOTE_ON, NOTE_RETRIG, NOTE_SUSTAIN, NOTE_OFF, SUSTAIN_PEDAL, CONTROLLER, PITCH_BEND, NOTE_PRESSURE, CHANNEL_PRESSURE, PROGRAM_CHANGE = range(11)
+
+
+class Event(ctypes.Structure):  # mlgpu_event == ml::Event
+    _fields_ = [("type", ctypes.c_uint8), ("channel", ctypes.c_uint8), ("source_idx", ctypes.c_uint16), ("time", ctypes.c_int32),
+                ("value1", ctypes.c_float), ("value2", ctypes.c_float)]
+
+
+class Events:
+    """EventsToSignals (source/app/MLEventsToSignals.h) for n_instruments instruments of `polyphony` voices (mlgpu_events)."""
+    ROWS = ("pitch", "gate", "vox", "z", "x", "y", "mod", "time")
+
+    def __init__(self, engine, n_instruments, polyphony, sr=48000.0):
+        self.engine, self.L = engine, engine.L
+        h = ctypes.c_void_p()
+        engine._check(self.L.mlgpu_events_create(engine.h, int(n_instruments), int(polyphony), ctypes.byref(h)))
+        self.h = h
+        self.n_instruments, self.polyphony = int(n_instruments), int(polyphony)
+        self.V = self.n_instruments * self.polyphony
+        engine._children.add(self)
+        self.set_sample_rate(sr)
+
+    def close(self):
+        if getattr(self, "h", None) and self.engine.h:
+            self.L.mlgpu_events_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_sample_rate(self, sr):
+        self.engine._check(self.L.mlgpu_events_set_sample_rate(self.h, float(sr)))
+
+    def configure(self, mpe=None, unison=None, mod_cc=None, pitch_bend=None, mpe_pitch_bend=None, glide_seconds=None, drift=None):
+        c, L, h = self.engine._check, self.L, self.h
+        if mpe is not None:
+            c(L.mlgpu_events_set_protocol(h, 1 if mpe else 0))
+        if unison is not None:
+            c(L.mlgpu_events_set_unison(h, 1 if unison else 0))
+        if mod_cc is not None:
+            c(L.mlgpu_events_set_mod_cc(h, int(mod_cc)))
+        if pitch_bend is not None:
+            c(L.mlgpu_events_set_pitch_bend_semitones(h, float(pitch_bend)))
+        if mpe_pitch_bend is not None:
+            c(L.mlgpu_events_set_mpe_pitch_bend_semitones(h, float(mpe_pitch_bend)))
+        if glide_seconds is not None:
+            c(L.mlgpu_events_set_pitch_glide_seconds(h, float(glide_seconds)))
+        if drift is not None:
+            c(L.mlgpu_events_set_drift_amount(h, float(drift)))
+
+    def add_event(self, instrument, ev):
+        self.engine._check(self.L.mlgpu_events_add_event(self.h, int(instrument), ctypes.byref(ev)))
+
+    def clear_events(self):
+        self.engine._check(self.L.mlgpu_events_clear_events(self.h))
+
+    def newest_voice(self, instrument):
+        return self.L.mlgpu_events_newest_voice(self.h, int(instrument))
+
+    def process(self, n_vectors, start_offset, d_outputs, layout=Layout.QUAD):
+        """d_outputs: 8 DeviceBuffers (or None) in the order of Events.ROWS."""
+        arr = (ctypes.c_void_p * 8)(*[None if b is None else b.ptr for b in d_outputs])
+        self.engine._check(self.L.mlgpu_events_process(self.h, int(n_vectors), int(start_offset), arr, int(layout)))
+
+    def process_host(self, n_vectors, start_offset=0):
+        """Test convenience: returns the 8 rows as numpy [8][V][64 T]."""
+        eng, V, T = self.engine, self.V, int(n_vectors)
+        bufs = [eng.alloc(4 * V * T * 64) for _ in range(8)]
+        self.process(T, start_offset, bufs, Layout.VOICE_MAJOR)
+        return np.stack([b.download(np.float32, V * T * 64).reshape(V, T * 64) for b in bufs])
 
 
 class Resampler:

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmlgpu.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mlgpu.h")
 
-_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "resample.hip", "coeffs.cpp", "dspbuffer.cpp", "processbuffer.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
+_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "resample.hip", "events.hip", "coeffs.cpp", "dspbuffer.cpp", "processbuffer.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
             "mldsp_procs.hpp", "mldsp_kernels.hpp", "mlgpu_device_args.hpp", "mlgpu_internal.hpp", "embed.py",
             "Makefile"]
 
@@ -140,6 +140,22 @@ def _declare(L):
     sig("mlgpu_graph_set_input_layout", i, [vp, i, i])
     sig("mlgpu_graph_set_voices_per_lane", i, [vp, i])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
+    sig("mlgpu_events_create", i, [vp, sz, i, pp])
+    sig("mlgpu_events_destroy", i, [vp])
+    sig("mlgpu_events_clear", i, [vp])
+    sig("mlgpu_events_set_sample_rate", i, [vp, c.c_double])
+    sig("mlgpu_events_set_protocol", i, [vp, i])
+    sig("mlgpu_events_set_unison", i, [vp, i])
+    sig("mlgpu_events_set_mod_cc", i, [vp, i])
+    sig("mlgpu_events_set_pitch_bend_semitones", i, [vp, f])
+    sig("mlgpu_events_set_mpe_pitch_bend_semitones", i, [vp, f])
+    sig("mlgpu_events_set_pitch_glide_seconds", i, [vp, f])
+    sig("mlgpu_events_set_drift_amount", i, [vp, f])
+    sig("mlgpu_events_num_voices", sz, [vp])
+    sig("mlgpu_events_newest_voice", i, [vp, sz])
+    sig("mlgpu_events_add_event", i, [vp, sz, vp])
+    sig("mlgpu_events_clear_events", i, [vp])
+    sig("mlgpu_events_process", i, [vp, sz, i, pp, i])
     sig("mlgpu_resampler_create", i, [vp, sz, i, i, pp])
     sig("mlgpu_resampler_destroy", i, [vp])
     sig("mlgpu_resampler_clear", i, [vp])

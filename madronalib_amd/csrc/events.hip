@@ -1,0 +1,956 @@
+// events.hip — EventsToSignals (source/app/MLEventsToSignals.{h,cpp}) for N independent instruments.
+//
+// The reference turns a time-sorted list of performance events (note on/off, controllers, pitch bend, pressure,
+// sustain pedal) into 8 control signals per voice — pitch, gate, vox, z, x, y, mod, elapsed time
+// (VoiceOutputSignals, MLEventsToSignals.h:15-26) — one DSPVector at a time on the audio thread. Split here as
+// SURVEY §8f-1 prescribes:
+//   HOST   the event routing: key states, voice allocation and stealing, unison, sustain pedal, MIDI / MPE channel
+//          rules (processEvent & co, MLEventsToSignals.cpp:445-870; findFreeVoice / findNearestVoice :892-935).
+//          Integer bookkeeping on a handful of events per block; it produces, per voice, a short list of timed
+//          records ("note on at frame 17 with pitch p, velocity v", "pitch bend is now b", ...).
+//   DEVICE everything per sample: Voice::beginProcess / writeNoteEvent / endProcess (:75-262) — the sample-accurate
+//          pitch glide, event age -> seconds, five vector-rate glides, the drift random walk, channel pressure and
+//          the MPE main-voice sums — one wavefront lane per voice, all state in HBM between launches only.
+// Uploading the signals themselves would cost 8 x 256 B per voice per DSPVector; the records are a few bytes per event.
+//
+// One instrument occupies G = nextpow2(polyphony + 1) consecutive lanes: lane 0 is the MPE main voice (voices[0] in the
+// reference), lanes 1..polyphony the playing voices, so the main voice's signals reach the others with one wave shuffle.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "mlgpu_internal.hpp"
+#include "mldsp_math.hpp"
+
+using namespace mldev;
+
+namespace
+{
+// ---- records ------------------------------------------------------------------------------------------------------
+enum RecType : uint32_t
+{
+  REC_AWAKE = 0,      // the instrument received its first event: processVector stops being a no-op (:383-386)
+  REC_NOTE_ON = 1,    // writeNoteEvent kNoteOn (:129-152):   v1 pitch, v2 velocity, flags bit0 doGlide bit1 doReset
+  REC_NOTE_RETRIG = 2,
+  REC_NOTE_OFF = 3,
+  REC_SET_BEND = 4,   // currentPitchBend = v1 (:700-731)
+  REC_SET_MOD = 5,
+  REC_SET_X = 6,
+  REC_SET_Y = 7,
+  REC_SET_Z = 8,
+  REC_SET_CHANNEL_PRESSURE = 9  // controllers[128].inputValue (MIDI mode, :620-626)
+};
+struct Rec
+{
+  uint32_t vec;    // DSPVector index inside this launch
+  uint32_t typeTimeFlags;  // type | time << 8 | flags << 16
+  float v1, v2;
+};
+inline Rec makeRec(uint32_t vec, uint32_t type, int time, uint32_t flags, float v1, float v2)
+{
+  const uint32_t t = (uint32_t)std::min(std::max(time, 0), 64);  // destTime = clamp(e.time, 0, 64) (:121)
+  return Rec{vec, type | (t << 8) | (flags << 16), v1, v2};
+}
+
+// ---- device state layout (uint32 words per voice, SoA [word][lanes]) --------------------------------------------------
+enum : int
+{
+  S_AWAKE = 0, S_VELOCITY, S_PITCH, S_BEND, S_MOD, S_X, S_Y, S_Z, S_CHANPRESS, S_AGE, S_AGE_STEP, S_INHIBIT_GLIDE,
+  S_PG_CURR, S_PG_STEP, S_PG_TARGET, S_PG_REMAINING, S_PG_PER_GLIDE, S_PG_DY,
+  S_DRIFT_SEED, S_DRIFT_COUNTER, S_DRIFT_VALUE, S_DRIFT_NEXT,
+  S_RECALC,  // Voice::recalcNeeded (:45-54): set by setSampleRate / setPitchGlideInSeconds, consumed by the next beginProcess
+  S_GLIDES  // 7 glides follow: bend, mod, x, y, z, drift, channel pressure
+};
+constexpr int kNumGlides = 7;
+constexpr int kGlideWords = 5 + 64;  // target, step, remaining, isUniform, uniformValue, currVec[64]
+constexpr int kStateWords = S_GLIDES + kNumGlides * kGlideWords;
+
+struct E2SSettings
+{
+  double sr;
+  float pitchBendRange, mpePitchBendRange, driftAmount;
+  int32_t pitchGlideSamples;           // sr * pitchGlideTimeInSeconds (:90)
+  int32_t glideVectors;  float glideDy;        // bend / mod / x / y / z / controllers: sr * 0.02 s (:97-101, 275)
+  int32_t driftGlideVectors;  float driftGlideDy;  // sr * 8 s (:103)
+  int32_t ctlGlideVectors;  float ctlGlideDy;      // SmoothedController: int(sr * 0.02 s) samples (:274-275) — truncated first
+  int32_t mpe;                         // protocol
+};
+
+struct E2SArgs
+{
+  uint32_t* state;            // [kStateWords][lanes]
+  const Rec* recs;            // all records of this launch, grouped by lane, time-ordered inside a lane
+  const uint32_t* recStart;   // [lanes + 1]
+  SignalView out[8];          // pitch, gate, vox, z, x, y, mod, elapsed time: V = instruments * polyphony voices
+  size_t lanes, T;
+  int group, polyphony;
+  E2SSettings s;
+};
+
+// LinearGlide (MLDSPGens.h:433-515) with one shortcut that does not change results: between glides mCurrVec is a
+// broadcast of one value, kept in a register instead of 64 words of HBM.
+struct Glide
+{
+  uint32_t* st;  // this glide's words for this lane (stride = lanes)
+  size_t stride;
+  float target, step, uniformValue, startValue;
+  int32_t remaining;
+  bool isUniform;
+  int mode;  // 0 hold, 1 end, 2 start, 3 continue
+  MLD uint32_t& w(int i) const { return st[(size_t)i * stride]; }
+  MLD void load(uint32_t* base, size_t lanes)
+  {
+    st = base;
+    stride = lanes;
+    target = u2f(w(0));
+    step = u2f(w(1));
+    remaining = (int32_t)w(2);
+    isUniform = w(3) != 0;
+    uniformValue = u2f(w(4));
+  }
+  MLD void store() const
+  {
+    w(0) = f2u(target);
+    w(1) = f2u(step);
+    w(2) = (uint32_t)remaining;
+    w(3) = isUniform ? 1u : 0u;
+    w(4) = f2u(uniformValue);
+  }
+  MLD void beginVector(float f, int32_t perGlide, float dyPerVector)
+  {
+    if (f != target)
+    {
+      target = f;
+      remaining = perGlide;
+    }
+    if (remaining < 0) mode = 0;
+    else if (remaining == 0)
+    {
+      mode = 1;
+      step = 0.f;
+      remaining--;
+    }
+    else if (remaining == perGlide)
+    {
+      mode = 2;
+      startValue = isUniform ? uniformValue : u2f(w(5 + 63));
+      step = (target - startValue) * dyPerVector;
+      remaining--;
+    }
+    else
+    {
+      mode = 3;
+      remaining--;
+    }
+  }
+  MLD float next(int n)
+  {
+    if (mode == 0) return isUniform ? uniformValue : u2f(w(5 + n));
+    if (mode == 1) return target;
+    float c;
+    if (mode == 2) c = startValue + ((float)(n + 1) * 0.015625f) * step;
+    else c = (isUniform ? uniformValue : u2f(w(5 + n))) + step;
+    w(5 + n) = f2u(c);
+    return c;
+  }
+  MLD void endVector()
+  {
+    if (mode == 1)
+    {
+      isUniform = true;
+      uniformValue = target;
+    }
+    else if (mode >= 2)
+      isUniform = false;
+  }
+};
+
+__global__ __launch_bounds__(256) void e2s_kernel(const E2SArgs a)
+{
+  const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = lane < a.lanes;
+  const size_t L = live ? lane : 0;
+  const int slot = (int)(L % (size_t)a.group);           // 0 = MPE main voice, 1..polyphony = playing voices
+  const bool isVoice = live && slot >= 1 && slot <= a.polyphony;
+  const bool active = live && slot <= a.polyphony;       // lanes beyond polyphony are padding
+  const size_t outVoice = (L / (size_t)a.group) * (size_t)a.polyphony + (size_t)(slot > 0 ? slot - 1 : 0);
+  uint32_t* S = a.state + L;
+  const size_t ln = a.lanes;
+#define SW(i) S[(size_t)(i) * ln]
+
+  bool awake = SW(S_AWAKE) != 0;
+  float velocity = u2f(SW(S_VELOCITY)), pitch = u2f(SW(S_PITCH)), bend = u2f(SW(S_BEND)), mod = u2f(SW(S_MOD));
+  float cx = u2f(SW(S_X)), cy = u2f(SW(S_Y)), cz = u2f(SW(S_Z)), chanPress = u2f(SW(S_CHANPRESS));
+  uint32_t age = SW(S_AGE), ageStep = SW(S_AGE_STEP);
+  bool inhibit = SW(S_INHIBIT_GLIDE) != 0, needsRecalc = SW(S_RECALC) != 0;
+  float pgCurr = u2f(SW(S_PG_CURR)), pgStep = u2f(SW(S_PG_STEP)), pgTarget = u2f(SW(S_PG_TARGET)), pgDy = u2f(SW(S_PG_DY));
+  int32_t pgRemaining = (int32_t)SW(S_PG_REMAINING), pgPerGlide = (int32_t)SW(S_PG_PER_GLIDE);
+  uint32_t driftSeed = SW(S_DRIFT_SEED);
+  int32_t driftCounter = (int32_t)SW(S_DRIFT_COUNTER), driftNext = (int32_t)SW(S_DRIFT_NEXT);
+  float driftValue = u2f(SW(S_DRIFT_VALUE));
+  Glide g[kNumGlides];
+#pragma unroll
+  for (int i = 0; i < kNumGlides; ++i) g[i].load(S + (size_t)(S_GLIDES + i * kGlideWords) * ln, ln);
+
+  auto setPitchGlideTime = [&](int32_t t) {  // SampleAccurateLinearGlide::setGlideTimeInSamples, MLDSPGens.h:527-532
+    pgPerGlide = t < 1 ? 1 : t;
+    pgDy = 1.0f / (float)pgPerGlide;
+  };
+  auto pitchGlideNext = [&](float f) {  // nextSample, :541-580
+    if (f != pgTarget)
+    {
+      pgTarget = f;
+      pgRemaining = pgPerGlide;
+    }
+    if (pgRemaining < 0) {}
+    else if (pgRemaining == 0)
+    {
+      pgCurr = pgTarget;
+      pgStep = 0.f;
+      pgRemaining--;
+    }
+    else if (pgRemaining == pgPerGlide)
+    {
+      pgStep = (pgTarget - pgCurr) * pgDy;
+      pgRemaining--;
+    }
+    else
+    {
+      pgCurr += pgStep;
+      pgRemaining--;
+    }
+    return pgCurr;
+  };
+
+  uint32_t cursor = live ? a.recStart[L] : 0;
+  const uint32_t recEnd = live ? a.recStart[L + 1] : 0;
+  const float pitchBendScale = (a.s.mpe && slot != 0) ? a.s.mpePitchBendRange : a.s.pitchBendRange;  // :417-423
+  const double srD = (double)(float)a.s.sr;  // samplesToSeconds(uint32_t, float sr), :13-19
+  const unsigned mainLane = (unsigned)((threadIdx.x & 63) / (unsigned)a.group) * (unsigned)a.group;
+
+  for (size_t t = 0; t < a.T; ++t)
+  {
+    // records of this vector: [cursor, vend)
+    uint32_t vend = cursor;
+    while (vend < recEnd && a.recs[vend].vec == (uint32_t)t) ++vend;
+    if (!awake)
+      for (uint32_t r = cursor; r < vend; ++r)
+        if ((a.recs[r].typeTimeFlags & 0xFF) == REC_AWAKE) awake = true;
+
+    float finalVelocity = velocity;
+    if (awake && active)
+    {
+      // ---- Voice::beginProcess, :75-113 ----
+      if (needsRecalc)
+      {
+        if (!inhibit) setPitchGlideTime(a.s.pitchGlideSamples);
+        needsRecalc = false;
+      }
+      driftCounter += MLGPU_FLOATS_PER_DSPVECTOR;
+      if (driftCounter >= driftNext)
+      {
+        driftSeed = driftSeed * 0x0019660Du + 0x3C6EF35Fu;  // RandomScalarSource::getFloat, MLDSPScalarMath.h:189-202
+        const float d = u2f(((driftSeed >> 9) & 0x007FFFFFu) | 0x3F800000u) * 2.f - 3.f;
+        driftSeed = driftSeed * 0x0019660Du + 0x3C6EF35Fu;
+        const float d2 = u2f(((driftSeed >> 9) & 0x007FFFFFu) | 0x3F800000u) * 2.f - 3.f;
+        const float nextTimeMul = 1.0f + abs_ps(d2);
+        driftValue = d;
+        driftCounter = 0;
+        driftNext = (int32_t)(a.s.sr * (double)nextTimeMul * (double)8.0f);
+      }
+      // ---- values that only matter at the end of the vector: apply them now (endProcess, :218-247) ----
+      for (uint32_t r = cursor; r < vend; ++r)
+      {
+        const Rec rc = a.recs[r];
+        switch (rc.typeTimeFlags & 0xFF)
+        {
+          case REC_SET_BEND: bend = rc.v1; break;
+          case REC_SET_MOD: mod = rc.v1; break;
+          case REC_SET_X: cx = rc.v1; break;
+          case REC_SET_Y: cy = rc.v1; break;
+          case REC_SET_Z: cz = rc.v1; break;
+          case REC_SET_CHANNEL_PRESSURE: chanPress = rc.v1; break;
+          case REC_NOTE_ON: case REC_NOTE_RETRIG: finalVelocity = rc.v2; break;
+          case REC_NOTE_OFF: finalVelocity = 0.f; break;
+          default: break;
+        }
+      }
+      if (finalVelocity == 0.f) cz = 0.f;  // :238-241
+      g[0].beginVector(bend, a.s.glideVectors, a.s.glideDy);
+      g[1].beginVector(mod, a.s.glideVectors, a.s.glideDy);
+      g[2].beginVector(cx, a.s.glideVectors, a.s.glideDy);
+      g[3].beginVector(cy, a.s.glideVectors, a.s.glideDy);
+      g[4].beginVector(cz, a.s.glideVectors, a.s.glideDy);
+      g[5].beginVector(driftValue, a.s.driftGlideVectors, a.s.driftGlideDy);
+      g[6].beginVector(chanPress, a.s.ctlGlideVectors, a.s.ctlGlideDy);  // SmoothedController::process, :268-280
+    }
+
+    // ---- the 64 frames: writeNoteEvent (:115-216) and endProcess (:218-262) walked frame by frame ----
+    uint32_t nc = cursor;      // next note record
+    bool preApplied = false;   // a note event's bookkeeping applies from the frame the previous one ended at
+#pragma unroll 1
+    for (int q = 0; q < 16; ++q)
+    {
+      float oPitch[4], oGate[4], oZ[4], oX[4], oY[4], oMod[4], oTime[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+      {
+        const int n = q * 4 + k;
+        float vPitch = 0.f, vGate = 0.f, vZ = 0.f, vX = 0.f, vY = 0.f, vMod = 0.f, vTime = 0.f;
+        if (awake && active)
+        {
+          bool retrigFrame = false;
+          while (nc < vend)
+          {
+            const Rec rc = a.recs[nc];
+            const uint32_t type = rc.typeTimeFlags & 0xFF;
+            if (type != REC_NOTE_ON && type != REC_NOTE_RETRIG && type != REC_NOTE_OFF)
+            {
+              ++nc;
+              continue;
+            }
+            int dest = (int)((rc.typeTimeFlags >> 8) & 0xFF);
+            const uint32_t flags = rc.typeTimeFlags >> 16;
+            if (!preApplied)
+            {
+              if (type != REC_NOTE_OFF)
+              {
+                if (flags & 2) age = 0;  // doReset
+                ageStep = 1;
+              }
+              if (type == REC_NOTE_ON)
+              {
+                inhibit = !(flags & 1);
+                setPitchGlideTime((flags & 1) ? a.s.pitchGlideSamples : 0);
+              }
+              preApplied = true;
+            }
+            if (type == REC_NOTE_RETRIG)
+            {
+              if (dest == 0) dest = 1;                 // make room for the retrigger frame, :163-167
+              if (n == dest - 1) retrigFrame = true;   // gate 0 for one frame, :171-175
+            }
+            if (dest == n)
+            {
+              if (type == REC_NOTE_OFF) velocity = 0.f;
+              else
+              {
+                pitch = rc.v1;
+                velocity = rc.v2;
+              }
+              ++nc;
+              preApplied = false;
+              continue;
+            }
+            break;
+          }
+          vGate = retrigFrame ? 0.f : velocity;
+          vPitch = pitchGlideNext(pitch);
+          age += ageStep;
+          vTime = (float)((double)age / srD);
+          // A retrigger that lands on the frame where the previous note event of this voice ended (a note-on and a steal of
+          // the same voice on one frame) makes the reference REWRITE frame dest - 1, which that previous event had already
+          // written (:163-175): the glide is stepped and the event age counted once more, with the previous event's new
+          // pitch. Look ahead for exactly that pattern and redo this frame the same way.
+          for (;;)
+          {
+            uint32_t pi = nc;
+            while (pi < vend && ((a.recs[pi].typeTimeFlags & 0xFF) < REC_NOTE_ON || (a.recs[pi].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++pi;
+            if (pi >= vend) break;
+            const Rec P = a.recs[pi];
+            const uint32_t ptype = P.typeTimeFlags & 0xFF;
+            int pdest = (int)((P.typeTimeFlags >> 8) & 0xFF);
+            if (ptype == REC_NOTE_RETRIG && pdest == 0) pdest = 1;
+            if (pdest != n + 1) break;
+            uint32_t ri = pi + 1;
+            while (ri < vend && ((a.recs[ri].typeTimeFlags & 0xFF) < REC_NOTE_ON || (a.recs[ri].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++ri;
+            if (ri >= vend) break;
+            const Rec R = a.recs[ri];
+            int rdest = (int)((R.typeTimeFlags >> 8) & 0xFF);
+            if ((R.typeTimeFlags & 0xFF) != REC_NOTE_RETRIG || rdest != n + 1) break;
+            // P's own bookkeeping, if this frame is the first one it sees
+            if (!preApplied)
+            {
+              const uint32_t pflags = P.typeTimeFlags >> 16;
+              if (ptype != REC_NOTE_OFF)
+              {
+                if (pflags & 2) age = 0;
+                ageStep = 1;
+              }
+              if (ptype == REC_NOTE_ON)
+              {
+                inhibit = !(pflags & 1);
+                setPitchGlideTime((pflags & 1) ? a.s.pitchGlideSamples : 0);
+              }
+            }
+            if (ptype == REC_NOTE_OFF) velocity = 0.f;  // P's new values
+            else
+            {
+              pitch = P.v1;
+              velocity = P.v2;
+            }
+            nc = ri;                                    // R is the current note record now, its bookkeeping done here
+            if ((R.typeTimeFlags >> 16) & 2) age = 0;
+            ageStep = 1;
+            preApplied = true;
+            vGate = 0.f;                                // the retrigger frame
+            vPitch = pitchGlideNext(pitch);
+            age += ageStep;
+            vTime = (float)((double)age / srD);
+          }
+          const float bendSig = g[0].next(n), driftSig = g[5].next(n);
+          vMod = g[1].next(n);
+          vX = g[2].next(n);
+          vY = g[3].next(n);
+          vZ = g[4].next(n);
+          const float press = g[6].next(n);
+          vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
+          vPitch = vPitch + (driftSig * a.s.driftAmount) * 0.02f;           // kDriftScale, :247
+          if (!a.s.mpe) vZ = vZ + press;                                      // MIDI: smoothed channel pressure, :437-445
+        }
+        if (a.s.mpe)  // the main voice's signals are added to every playing voice, :447-458
+        {
+          const float mp = __shfl(vPitch, mainLane, 64), mx = __shfl(vX, mainLane, 64), my = __shfl(vY, mainLane, 64);
+          const float mz = __shfl(vZ, mainLane, 64), mm = __shfl(vMod, mainLane, 64);
+          if (isVoice && awake)
+          {
+            vPitch = vPitch + mp;
+            vX = vX + mx;
+            vY = vY + my;
+            vZ = vZ + mz;
+            vMod = vMod + mm;
+          }
+        }
+        oPitch[k] = vPitch; oGate[k] = vGate; oZ[k] = vZ; oX[k] = vX; oY[k] = vY; oMod[k] = vMod; oTime[k] = vTime;
+      }
+      if (isVoice)
+      {
+        auto put = [&](int row, const float* v) {
+          const SignalView& s = a.out[row];
+          if (!s.base) return;
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+          const f32x4 x = {v[0], v[1], v[2], v[3]};
+          __builtin_nontemporal_store(x, (f32x4*)s.base + t * s.strideT + (size_t)q * s.strideQ + outVoice * s.strideV);
+        };
+        const float vox = (float)(slot - 1);  // row kVoice: DSPVector((float)i - 1), :302
+        const float voxq[4] = {vox, vox, vox, vox};
+        put(0, oPitch); put(1, oGate); put(2, voxq); put(3, oZ); put(4, oX); put(5, oY); put(6, oMod); put(7, oTime);
+      }
+    }
+    if (awake && active)
+    {
+#pragma unroll
+      for (int i = 0; i < kNumGlides; ++i) g[i].endVector();
+    }
+    cursor = vend;
+  }
+
+  if (!live) return;
+  SW(S_AWAKE) = awake ? 1u : 0u;
+  SW(S_VELOCITY) = f2u(velocity); SW(S_PITCH) = f2u(pitch); SW(S_BEND) = f2u(bend); SW(S_MOD) = f2u(mod);
+  SW(S_X) = f2u(cx); SW(S_Y) = f2u(cy); SW(S_Z) = f2u(cz); SW(S_CHANPRESS) = f2u(chanPress);
+  SW(S_AGE) = age; SW(S_AGE_STEP) = ageStep; SW(S_INHIBIT_GLIDE) = inhibit ? 1u : 0u; SW(S_RECALC) = needsRecalc ? 1u : 0u;
+  SW(S_PG_CURR) = f2u(pgCurr); SW(S_PG_STEP) = f2u(pgStep); SW(S_PG_TARGET) = f2u(pgTarget); SW(S_PG_REMAINING) = (uint32_t)pgRemaining;
+  SW(S_PG_PER_GLIDE) = (uint32_t)pgPerGlide; SW(S_PG_DY) = f2u(pgDy);
+  SW(S_DRIFT_SEED) = driftSeed; SW(S_DRIFT_COUNTER) = (uint32_t)driftCounter; SW(S_DRIFT_VALUE) = f2u(driftValue); SW(S_DRIFT_NEXT) = (uint32_t)driftNext;
+#pragma unroll
+  for (int i = 0; i < kNumGlides; ++i) g[i].store();
+#undef SW
+}
+
+// ---- host: the event routing of EventsToSignals ------------------------------------------------------------------------
+constexpr int kMaxVoices = 16;        // EventsToSignals::kMaxVoices, MLEventsToSignals.h:48
+constexpr int kMaxPhysicalKeys = 128;
+constexpr int kNumControllers = 129;
+constexpr int kChannelPressureControllerIdx = 128;
+
+struct KeyState
+{
+  int state{0};  // 0 off, 1 on, 2 sustained
+  float pitch{0.f};
+  uint32_t noteOnIndex{0};
+};
+struct HostVoice
+{
+  size_t creatorKeyIdx{0};
+  float currentVelocity{0.f};
+};
+struct Instrument
+{
+  std::vector<mlgpu_event> events;  // time-sorted (addEvent, :367-372)
+  KeyState keys[kMaxPhysicalKeys];
+  HostVoice voices[kMaxVoices + 1];
+  int lastFreeVoiceFound{-1};
+  int newestVoice{-1};
+  bool sustainPedal{false};
+  uint32_t currentNoteOnIndex{0};
+  bool awake{false}, awakeSent{false};
+};
+}  // namespace
+
+struct mlgpu_events
+{
+  mlgpu_engine* e{nullptr};
+  size_t nInstruments{0};
+  int polyphony{0}, group{1};
+  bool mpe{false}, unison{false};
+  int voiceModCC{16};
+  double sr{0};
+  float pitchBendRange{7.f}, mpePitchBendRange{24.f}, pitchGlideSeconds{0.f}, driftAmount{0.f};
+  std::vector<Instrument> inst;
+  std::vector<std::vector<Rec>> laneRecs;  // per lane, this launch
+  uint32_t* d_state{nullptr};
+  Rec* d_recs{nullptr};
+  uint32_t* d_recStart{nullptr};
+  size_t recCapacity{0};
+  std::vector<Rec> h_recs;
+  std::vector<uint32_t> h_recStart;
+  size_t lanes() const { return nInstruments * (size_t)group; }
+};
+
+namespace
+{
+int efail(mlgpu_events* ev, int st, const std::string& what)
+{
+  if (ev && ev->e) ev->e->lastError = what;
+  return st;
+}
+bool soonerThan(const mlgpu_event& a, const mlgpu_event& b)  // :356-364
+{
+  if (a.time != b.time) return a.time < b.time;
+  return a.type < b.type;
+}
+int keyIndex(const mlgpu_events* ev, const mlgpu_event& e) { return ev->mpe ? e.channel : e.source_idx; }  // getKeyIndex, :21-42
+
+struct Router  // one instrument, one vector
+{
+  mlgpu_events* ev;
+  Instrument& in;
+  size_t instIdx;
+  uint32_t vec;
+  void push(int voice, const Rec& r)
+  {
+    if (voice < 0 || voice > ev->polyphony) return;  // voices the device does not simulate (beyond the polyphony)
+    ev->laneRecs[instIdx * (size_t)ev->group + (size_t)voice].push_back(r);
+  }
+  // Voice::writeNoteEvent's host-visible effects (:115-216): creatorKeyIdx_ and currentVelocity
+  void note(int v, const mlgpu_event& e, uint32_t type, int keyIdx, bool doGlide, bool doReset)
+  {
+    HostVoice& hv = in.voices[v];
+    if (type == MLGPU_EVENT_NOTE_ON || type == MLGPU_EVENT_NOTE_RETRIG)
+    {
+      hv.creatorKeyIdx = (size_t)keyIdx;
+      hv.currentVelocity = e.value2;
+      push(v, makeRec(vec, type == MLGPU_EVENT_NOTE_ON ? REC_NOTE_ON : REC_NOTE_RETRIG, e.time, (doGlide ? 1u : 0u) | (doReset ? 2u : 0u), e.value1, e.value2));
+    }
+    else if (type == MLGPU_EVENT_NOTE_OFF)
+    {
+      hv.creatorKeyIdx = 0;
+      hv.currentVelocity = 0.f;
+      push(v, makeRec(vec, REC_NOTE_OFF, e.time, 0, 0.f, 0.f));
+    }
+    // kNoteSustain and everything else: no change (default:, :211-213)
+  }
+  size_t countHeldNotes() const  // :471-482
+  {
+    size_t n = 0;
+    for (int i = 0; i < kMaxPhysicalKeys; ++i) n += (in.keys[i].state == 1);
+    return n;
+  }
+  int findFreeVoice()  // :892-912
+  {
+    const int highest = ev->polyphony + 1;
+    int t = in.lastFreeVoiceFound;
+    for (int i = 1; i < ev->polyphony + 1; ++i)
+    {
+      t++;
+      if (t >= highest) t = 1;
+      if (in.voices[t].creatorKeyIdx == 0)
+      {
+        in.lastFreeVoiceFound = t;
+        return t;
+      }
+    }
+    return -1;
+  }
+  int findNearestVoice(int note)  // :922-937
+  {
+    int r = 0;
+    size_t minDist = 128;
+    for (int v = 1; v < ev->polyphony + 1; ++v)
+    {
+      const size_t dist = (size_t)std::abs(note - (int)in.voices[v].creatorKeyIdx);
+      if (dist < minDist)
+      {
+        minDist = dist;
+        r = v;
+      }
+    }
+    return r;
+  }
+  void noteOn(const mlgpu_event& e)  // :519-560
+  {
+    const int k = keyIndex(ev, e) & (kMaxPhysicalKeys - 1);
+    in.keys[k].state = 1;
+    in.keys[k].noteOnIndex = in.currentNoteOnIndex++;
+    in.keys[k].pitch = e.value1;
+    if (ev->unison)
+    {
+      const bool firstNote = (countHeldNotes() == 1);
+      for (int v = 1; v < ev->polyphony + 1; ++v) note(v, e, MLGPU_EVENT_NOTE_ON, k, !firstNote, firstNote);
+    }
+    else
+    {
+      int v = findFreeVoice();
+      if (v >= 1) note(v, e, MLGPU_EVENT_NOTE_ON, k, true, true);
+      else
+      {
+        v = findNearestVoice(e.source_idx);  // findVoiceToSteal, :914-918
+        note(v, e, MLGPU_EVENT_NOTE_RETRIG, k, true, true);
+      }
+      in.newestVoice = v;
+    }
+  }
+  void noteOff(const mlgpu_event& e)  // :562-632
+  {
+    const int k = keyIndex(ev, e) & (kMaxPhysicalKeys - 1);
+    in.keys[k].state = in.sustainPedal ? 2 : 0;
+    if (ev->unison)
+    {
+      if (countHeldNotes() == 0)
+      {
+        for (int v = 1; v < ev->polyphony + 1; ++v) note(v, e, MLGPU_EVENT_NOTE_OFF, 0, true, true);
+      }
+      else if ((size_t)k == in.voices[1].creatorKeyIdx)
+      {
+        mlgpu_event f = e;  // change note without retriggering the envelope, keeping the current velocity
+        f.value2 = in.voices[1].currentVelocity;
+        uint32_t maxIdx = 0, mostRecent = 0;
+        for (int i = 0; i < kMaxPhysicalKeys; ++i)
+          if (in.keys[i].state == 1 && in.keys[i].noteOnIndex > maxIdx)
+          {
+            maxIdx = in.keys[i].noteOnIndex;
+            mostRecent = (uint32_t)i;
+          }
+        f.value1 = in.keys[mostRecent].pitch;
+        for (int v = 1; v < ev->polyphony + 1; ++v) note(v, f, MLGPU_EVENT_NOTE_ON, (int)mostRecent, true, true);
+      }
+    }
+    else if (!in.sustainPedal)
+    {
+      for (int v = 1; v < ev->polyphony + 1; ++v)
+        if (in.voices[v].creatorKeyIdx == (size_t)k) note(v, e, MLGPU_EVENT_NOTE_OFF, k, true, true);
+    }
+  }
+  void setAll(uint32_t rec, float val)
+  {
+    for (int v = 1; v < ev->polyphony + 1; ++v) push(v, makeRec(vec, rec, 0, 0, val, 0.f));
+  }
+  void setMatching(uint32_t rec, int channel, float val)
+  {
+    for (int v = 1; v < ev->polyphony + 1; ++v)
+      if (in.voices[v].creatorKeyIdx == (size_t)channel) push(v, makeRec(vec, rec, 0, 0, val, 0.f));
+  }
+  void controller(const mlgpu_event& e)  // :735-822
+  {
+    const float val = e.value1;
+    const size_t ctrl = std::min((size_t)e.source_idx, (size_t)kNumControllers - 1);
+    if (ctrl == kChannelPressureControllerIdx)  // controllers[128].inputValue is what MIDI channel pressure writes too
+      for (int v = 0; v < ev->polyphony + 1; ++v) push(v, makeRec(vec, REC_SET_CHANNEL_PRESSURE, 0, 0, val, 0.f));
+    if (ctrl == 120) return;  // "all sound off" clears the event buffer it is iterating in the reference (:749-755): not reproduced
+    if (ctrl == 123)
+    {
+      if (val == 0)  // all notes off, :757-769
+        for (int v = 0; v < kMaxVoices + 1; ++v) note(v, e, MLGPU_EVENT_NOTE_OFF, 0, false, true);
+      return;
+    }
+    for (int v = 1; v < ev->polyphony + 1; ++v)
+    {
+      if (ev->mpe && in.voices[v].creatorKeyIdx != (size_t)e.channel) continue;
+      if ((int)ctrl == ev->voiceModCC) push(v, makeRec(vec, REC_SET_MOD, 0, 0, val, 0.f));
+      if (ctrl == 73) push(v, makeRec(vec, REC_SET_X, 0, 0, val, 0.f));
+      else if (ctrl == 74) push(v, makeRec(vec, REC_SET_Y, 0, 0, val, 0.f));
+    }
+  }
+  void process(const mlgpu_event& e)  // processEvent, :485-515
+  {
+    switch (e.type)
+    {
+      case MLGPU_EVENT_NOTE_ON: noteOn(e); break;
+      case MLGPU_EVENT_NOTE_OFF: noteOff(e); break;
+      case MLGPU_EVENT_CONTROLLER: controller(e); break;
+      case MLGPU_EVENT_PITCH_BEND:  // :700-731
+        if (!ev->mpe) setAll(REC_SET_BEND, e.value1);
+        else if (e.channel == 1) push(0, makeRec(vec, REC_SET_BEND, 0, 0, e.value1, 0.f));
+        else if (e.channel != 0) setMatching(REC_SET_BEND, e.channel, e.value1);
+        break;
+      case MLGPU_EVENT_NOTE_PRESSURE:  // :676-698: per-key pressure in MIDI mode, ignored in MPE mode
+        if (!ev->mpe) setMatching(REC_SET_Z, e.source_idx, e.value1);
+        break;
+      case MLGPU_EVENT_CHANNEL_PRESSURE:  // :637-674
+        if (!ev->mpe)
+          for (int v = 0; v < ev->polyphony + 1; ++v) push(v, makeRec(vec, REC_SET_CHANNEL_PRESSURE, 0, 0, e.value1, 0.f));
+        else if (e.channel == 1) push(0, makeRec(vec, REC_SET_Z, 0, 0, e.value1, 0.f));
+        else if (e.channel != 0) setMatching(REC_SET_Z, e.channel, e.value1);
+        break;
+      case MLGPU_EVENT_SUSTAIN_PEDAL:  // :824-842
+        in.sustainPedal = (e.value1 > 0.5f);
+        if (!in.sustainPedal)
+          for (int i = 1; i < ev->polyphony + 1; ++i)
+            if (in.keys[in.voices[i].creatorKeyIdx & (kMaxPhysicalKeys - 1)].state == 2)
+            {
+              mlgpu_event off{};
+              off.type = MLGPU_EVENT_NOTE_OFF;
+              note(i, off, MLGPU_EVENT_NOTE_OFF, 0, true, true);
+            }
+        break;
+      default: break;
+    }
+  }
+};
+
+// the state of freshly constructed / reset voices (EventsToSignals ctor :290-305, Voice::reset :58-84)
+void initialState(const mlgpu_events* ev, std::vector<uint32_t>& st)
+{
+  const size_t lanes = ev->lanes();
+  st.assign((size_t)kStateWords * lanes, 0u);
+  auto W = [&](int word, size_t lane) -> uint32_t& { return st[(size_t)word * lanes + lane]; };
+  const uint32_t minusOne = 0xFFFFFFFFu;
+  for (size_t lane = 0; lane < lanes; ++lane)
+  {
+    const int slot = (int)(lane % (size_t)ev->group);
+    W(S_PG_REMAINING, lane) = minusOne;       // SampleAccurateLinearGlide defaults, MLDSPGens.h:519-524
+    W(S_PG_PER_GLIDE, lane) = 32;
+    const float dy = 1.f / 32;
+    memcpy(&W(S_PG_DY, lane), &dy, 4);
+    W(S_DRIFT_SEED, lane) = (uint32_t)(slot * 232);  // driftSource.seed_ = voiceIndex * 232, :60
+    W(S_RECALC, lane) = 1u;
+    for (int gl = 0; gl < kNumGlides; ++gl)
+    {
+      const int base = S_GLIDES + gl * kGlideWords;
+      // reset() calls setValue(0) on bend / mod / x / y / z: remaining = 0; the drift and controller glides are
+      // default-constructed: remaining = -1 (MLDSPGens.h:441)
+      W(base + 2, lane) = (gl <= 4) ? 0u : minusOne;
+      W(base + 3, lane) = 1u;  // mCurrVec is all zeros: uniform
+    }
+  }
+}
+}  // namespace
+
+extern "C"
+{
+  int mlgpu_events_destroy(mlgpu_events* ev)
+  {
+    if (!ev) return MLGPU_ERR_INVALID;
+    hipSetDevice(ev->e->device);
+    hipStreamSynchronize(ev->e->stream);
+    if (ev->d_state) hipFree(ev->d_state);
+    if (ev->d_recs) hipFree(ev->d_recs);
+    if (ev->d_recStart) hipFree(ev->d_recStart);
+    delete ev;
+    return MLGPU_OK;
+  }
+
+  int mlgpu_events_clear(mlgpu_events* ev)  // EventsToSignals::clear, :330-340
+  {
+    if (!ev) return MLGPU_ERR_INVALID;
+    for (Instrument& in : ev->inst)
+    {
+      in.events.clear();
+      for (HostVoice& v : in.voices) v = HostVoice();
+      in.lastFreeVoiceFound = 0;
+    }
+    // Voice::reset keeps the glides' and the drift's running state except what setValue(0) touches; a freshly built
+    // bank and a cleared one differ only there. This implementation resets the device state completely.
+    std::vector<uint32_t> st;
+    initialState(ev, st);
+    if (hipSetDevice(ev->e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
+    return mlgpu_upload(ev->e, ev->d_state, st.data(), st.size() * sizeof(uint32_t));
+  }
+
+  int mlgpu_events_create(mlgpu_engine* e, size_t nInstruments, int polyphony, mlgpu_events** out)
+  {
+    if (!e || !out) return MLGPU_ERR_INVALID;
+    *out = nullptr;
+    if (nInstruments == 0 || polyphony < 1 || polyphony > kMaxVoices)
+    {
+      e->lastError = "events_create: 1+ instruments, polyphony 1..16 (EventsToSignals::kMaxVoices)";
+      return MLGPU_ERR_INVALID;
+    }
+    mlgpu_events* ev = new (std::nothrow) mlgpu_events();
+    if (!ev) return MLGPU_ERR_OOM;
+    ev->e = e;
+    ev->nInstruments = nInstruments;
+    ev->polyphony = polyphony;
+    ev->group = 1;
+    while (ev->group < polyphony + 1) ev->group <<= 1;
+    ev->inst.resize(nInstruments);
+    ev->laneRecs.resize(ev->lanes());
+    hipError_t err = hipSetDevice(e->device);
+    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_state, sizeof(uint32_t) * (size_t)kStateWords * ev->lanes());
+    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_recStart, sizeof(uint32_t) * (ev->lanes() + 1));
+    if (err != hipSuccess)
+    {
+      e->lastError = std::string("events_create: ") + hipGetErrorString(err);
+      mlgpu_events_destroy(ev);
+      return err == hipErrorOutOfMemory ? MLGPU_ERR_OOM : MLGPU_ERR_HIP;
+    }
+    for (Instrument& in : ev->inst) in.lastFreeVoiceFound = -1;
+    const int st = mlgpu_events_clear(ev);
+    for (Instrument& in : ev->inst) in.lastFreeVoiceFound = 0;  // setPolyphony calls clear() (:316-321)
+    if (st != MLGPU_OK)
+    {
+      mlgpu_events_destroy(ev);
+      return st;
+    }
+    *out = ev;
+    return MLGPU_OK;
+  }
+
+  static int markRecalc(mlgpu_events* ev)
+  {
+    if (hipSetDevice(ev->e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
+    return mlgpu_fill32(ev->e, ev->d_state + (size_t)S_RECALC * ev->lanes(), 1u, ev->lanes());
+  }
+  int mlgpu_events_set_sample_rate(mlgpu_events* ev, double sr)
+  {
+    if (!ev) return MLGPU_ERR_INVALID;
+    ev->sr = sr;
+    return markRecalc(ev);
+  }
+  int mlgpu_events_set_protocol(mlgpu_events* ev, int mpe)  // setProtocol clears (:92-96)
+  {
+    if (!ev) return MLGPU_ERR_INVALID;
+    ev->mpe = mpe != 0;
+    return mlgpu_events_clear(ev);
+  }
+  int mlgpu_events_set_unison(mlgpu_events* ev, int on) { return ev ? (ev->unison = on != 0, MLGPU_OK) : MLGPU_ERR_INVALID; }
+  int mlgpu_events_set_mod_cc(mlgpu_events* ev, int cc) { return ev ? (ev->voiceModCC = cc, MLGPU_OK) : MLGPU_ERR_INVALID; }
+  int mlgpu_events_set_pitch_bend_semitones(mlgpu_events* ev, float f) { return ev ? (ev->pitchBendRange = f, MLGPU_OK) : MLGPU_ERR_INVALID; }
+  int mlgpu_events_set_mpe_pitch_bend_semitones(mlgpu_events* ev, float f) { return ev ? (ev->mpePitchBendRange = f, MLGPU_OK) : MLGPU_ERR_INVALID; }
+  int mlgpu_events_set_drift_amount(mlgpu_events* ev, float f) { return ev ? (ev->driftAmount = f, MLGPU_OK) : MLGPU_ERR_INVALID; }
+  int mlgpu_events_set_pitch_glide_seconds(mlgpu_events* ev, float f)
+  {
+    if (!ev) return MLGPU_ERR_INVALID;
+    ev->pitchGlideSeconds = f;
+    return markRecalc(ev);
+  }
+  size_t mlgpu_events_num_voices(mlgpu_events* ev) { return ev ? ev->nInstruments * (size_t)ev->polyphony : 0; }
+  int mlgpu_events_newest_voice(mlgpu_events* ev, size_t instrument) { return (ev && instrument < ev->nInstruments) ? ev->inst[instrument].newestVoice - 1 : -2; }
+
+  int mlgpu_events_add_event(mlgpu_events* ev, size_t instrument, const mlgpu_event* e)  // addEvent, :367-372
+  {
+    if (!ev || !e) return MLGPU_ERR_INVALID;
+    if (instrument >= ev->nInstruments) return efail(ev, MLGPU_ERR_RANGE, "events_add_event: instrument out of range");
+    Instrument& in = ev->inst[instrument];
+    in.awake = true;
+    in.events.insert(std::lower_bound(in.events.begin(), in.events.end(), *e, soonerThan), *e);
+    return MLGPU_OK;
+  }
+  int mlgpu_events_clear_events(mlgpu_events* ev)  // clearEvents, once per host block (MLSignalProcessBuffer.cpp:89)
+  {
+    if (!ev) return MLGPU_ERR_INVALID;
+    for (Instrument& in : ev->inst) in.events.clear();
+    return MLGPU_OK;
+  }
+
+  // processVector (:376-466) for n_vectors consecutive DSPVectors starting at frame start_offset of the event times.
+  int mlgpu_events_process(mlgpu_events* ev, size_t nVectors, int startOffset, float* const* d_outputs, int layout)
+  {
+    if (!ev || !d_outputs) return MLGPU_ERR_INVALID;
+    mlgpu_engine* e = ev->e;
+    if (nVectors == 0) return MLGPU_OK;
+    if (ev->sr == 0) return efail(ev, MLGPU_ERR_INVALID, "events_process: no sample rate (the reference does nothing, :385)");
+    if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return efail(ev, MLGPU_ERR_INVALID, "events_process: bad layout");
+    // ---- route this launch's events into per-voice records ----
+    for (auto& l : ev->laneRecs) l.clear();
+    for (size_t i = 0; i < ev->nInstruments; ++i)
+    {
+      Instrument& in = ev->inst[i];
+      if (!in.awake) continue;
+      for (size_t t = 0; t < nVectors; ++t)
+      {
+        Router r{ev, in, i, (uint32_t)t};
+        if (!in.awakeSent)
+        {
+          for (int v = 0; v < ev->polyphony + 1; ++v) r.push(v, makeRec((uint32_t)t, REC_AWAKE, 0, 0, 0.f, 0.f));
+          in.awakeSent = true;
+        }
+        const int start = startOffset + (int)t * MLGPU_FLOATS_PER_DSPVECTOR, end = start + MLGPU_FLOATS_PER_DSPVECTOR;
+        for (const mlgpu_event& evt : in.events)
+          if (evt.time >= start && evt.time < end)
+          {
+            mlgpu_event local = evt;
+            local.time -= start;
+            r.process(local);
+          }
+      }
+    }
+    const size_t lanes = ev->lanes();
+    ev->h_recStart.assign(lanes + 1, 0);
+    ev->h_recs.clear();
+    for (size_t l = 0; l < lanes; ++l)
+    {
+      ev->h_recStart[l] = (uint32_t)ev->h_recs.size();
+      ev->h_recs.insert(ev->h_recs.end(), ev->laneRecs[l].begin(), ev->laneRecs[l].end());
+    }
+    ev->h_recStart[lanes] = (uint32_t)ev->h_recs.size();
+    if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
+    if (ev->h_recs.size() + 1 > ev->recCapacity)
+    {
+      hipStreamSynchronize(e->stream);
+      if (ev->d_recs) hipFree(ev->d_recs);
+      ev->recCapacity = std::max<size_t>(4096, 2 * (ev->h_recs.size() + 1));
+      if (hipMalloc((void**)&ev->d_recs, sizeof(Rec) * ev->recCapacity) != hipSuccess)
+      {
+        ev->d_recs = nullptr;
+        ev->recCapacity = 0;
+        return efail(ev, MLGPU_ERR_OOM, "events_process: record buffer");
+      }
+    }
+    int st = mlgpu_upload(e, ev->d_recStart, ev->h_recStart.data(), sizeof(uint32_t) * (lanes + 1));
+    if (st == MLGPU_OK && !ev->h_recs.empty()) st = mlgpu_upload(e, ev->d_recs, ev->h_recs.data(), sizeof(Rec) * ev->h_recs.size());
+    if (st != MLGPU_OK) return st;
+
+    E2SArgs a;
+    memset(&a, 0, sizeof(a));
+    a.state = ev->d_state;
+    a.recs = ev->d_recs;
+    a.recStart = ev->d_recStart;
+    const size_t V = ev->nInstruments * (size_t)ev->polyphony;
+    for (int r = 0; r < 8; ++r)
+    {
+      if (d_outputs[r] && ((uintptr_t)d_outputs[r] & 15)) return efail(ev, MLGPU_ERR_INVALID, "events_process: misaligned output");
+      a.out[r] = makeView(d_outputs[r], layout, V, nVectors);
+    }
+    a.lanes = lanes;
+    a.T = nVectors;
+    a.group = ev->group;
+    a.polyphony = ev->polyphony;
+    a.s.sr = ev->sr;
+    a.s.pitchBendRange = ev->pitchBendRange;
+    a.s.mpePitchBendRange = ev->mpePitchBendRange;
+    a.s.driftAmount = ev->driftAmount;
+    a.s.pitchGlideSamples = (int32_t)(ev->sr * ev->pitchGlideSeconds);  // :90
+    float c[2];
+    mlgpu_linear_glide_make_coeffs((float)(ev->sr * 0.02f), c);          // kGlideTimeSeconds / kControllerGlideTimeSeconds
+    memcpy(&a.s.glideVectors, &c[0], 4);
+    a.s.glideDy = c[1];
+    mlgpu_linear_glide_make_coeffs((float)(ev->sr * 8.0f), c);           // kDriftTimeSeconds
+    memcpy(&a.s.driftGlideVectors, &c[0], 4);
+    a.s.driftGlideDy = c[1];
+    mlgpu_linear_glide_make_coeffs((float)(int)(ev->sr * 0.02f), c);    // SmoothedController: int glideTimeInSamples = sr * 0.02f
+    memcpy(&a.s.ctlGlideVectors, &c[0], 4);
+    a.s.ctlGlideDy = c[1];
+    a.s.mpe = ev->mpe ? 1 : 0;
+    hipLaunchKernelGGL(e2s_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process launch: ") + hipGetErrorString(err));
+    // the upload buffers are reused by the next call
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "events_process: sync");
+    return MLGPU_OK;
+  }
+}

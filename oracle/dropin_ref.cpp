@@ -84,3 +84,55 @@ extern "C" int spb_ref_run(int maxFrames, const int* blocks, int nBlocks, const 
   }
   return 0;
 }
+
+// ---- the reference's EventsToSignals driven like AudioContext / SignalProcessBuffer drive it -------------------------
+// events: absolute onset times in frames; the harness cuts time into host blocks of blockFrames (a multiple of 64), adds the
+// events of a block with block-relative times, calls processVector(offset) per 64 frames and clearEvents() per block.
+// out: [8 rows][polyphony voices][nBlocks * blockFrames] in the order of VoiceOutputSignals.
+struct RefEvent
+{
+  uint8_t type, channel;
+  uint16_t sourceIdx;
+  int32_t time;
+  float value1, value2;
+};
+extern "C" int e2s_ref_run(int polyphony, int mpe, int unison, double sr, float glideSeconds, float drift, float bendRange, float mpeBendRange, int modCC,
+                           const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out)
+{
+  EventsToSignals e2s;
+  e2s.setSampleRate(sr);
+  e2s.setPolyphony(polyphony);
+  e2s.setProtocol(mpe ? Symbol("MPE") : Symbol("MIDI"));
+  e2s.setUnison(unison != 0);
+  e2s.setPitchGlideInSeconds(glideSeconds);
+  e2s.setDriftAmount(drift);
+  e2s.setPitchBendInSemitones(bendRange);
+  e2s.setMPEPitchBendInSemitones(mpeBendRange);
+  e2s.setModCC(modCC);
+  const size_t S = (size_t)nBlocks * blockFrames;
+  for (int b = 0; b < nBlocks; ++b)
+  {
+    const int start = b * blockFrames;
+    for (int i = 0; i < nEvents; ++i)
+      if (events[i].time >= start && events[i].time < start + blockFrames)
+      {
+        Event ev;
+        ev.type = events[i].type;
+        ev.channel = events[i].channel;
+        ev.sourceIdx = events[i].sourceIdx;
+        ev.time = events[i].time - start;
+        ev.value1 = events[i].value1;
+        ev.value2 = events[i].value2;
+        e2s.addEvent(ev);
+      }
+    for (int off = 0; off < blockFrames; off += kFloatsPerDSPVector)
+    {
+      e2s.processVector(off);
+      for (int v = 0; v < polyphony; ++v)
+        for (int r = 0; r < kNumVoiceOutputRows; ++r)
+          store(e2s.getVoice(v).outputs.constRow(r), out + ((size_t)r * polyphony + v) * S + start + off);
+    }
+    e2s.clearEvents();
+  }
+  return 0;
+}

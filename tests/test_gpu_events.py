@@ -1,0 +1,147 @@
+"""mlgpu_events (EventsToSignals: host event routing + device signal generation) against the reference's own
+EventsToSignals class (oracle/_ref/libdropin_ref.so: e2s_ref_run) on scripted performances: bit-exact on all 8 rows."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from inputs import assert_bits_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NOTE_ON, NOTE_OFF, SUSTAIN, CTRL, BEND, NOTE_PRESS, CHAN_PRESS = 1, 4, 5, 6, 7, 8, 9
+ROW_NAMES = ("pitch", "gate", "vox", "z", "x", "y", "mod", "time")
+
+
+class RefEvent(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_uint8), ("channel", ctypes.c_uint8), ("sourceIdx", ctypes.c_uint16), ("time", ctypes.c_int32),
+                ("value1", ctypes.c_float), ("value2", ctypes.c_float)]
+
+
+def ref_run(cfg, events, block_frames, n_blocks):
+    so = os.path.join(ROOT, "oracle", "_ref", "libdropin_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libdropin_ref.so not available here")
+    L = ctypes.CDLL(so)
+    L.e2s_ref_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                              ctypes.c_float, ctypes.c_int, ctypes.POINTER(RefEvent), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                              ctypes.POINTER(ctypes.c_float)]
+    P = cfg["polyphony"]
+    out = np.zeros((8, P, n_blocks * block_frames), np.float32)
+    arr = (RefEvent * max(1, len(events)))(*[RefEvent(*e) for e in events])
+    assert L.e2s_ref_run(P, int(cfg.get("mpe", 0)), int(cfg.get("unison", 0)), cfg.get("sr", 48000.0), cfg.get("glide", 0.0), cfg.get("drift", 0.0),
+                         cfg.get("bend", 7.0), cfg.get("mpe_bend", 24.0), cfg.get("mod_cc", 16), arr, len(events), block_frames, n_blocks,
+                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))) == 0
+    return out
+
+
+def gpu_run(eng, cfg, per_instrument_events, block_frames, n_blocks, vectors_per_launch):
+    """per_instrument_events: one event list per instrument. Returns [8][N*P][frames]."""
+    import madronalib_amd as ml
+    N, P = len(per_instrument_events), cfg["polyphony"]
+    ev = ml.Events(eng, N, P, cfg.get("sr", 48000.0))
+    ev.configure(mpe=cfg.get("mpe", 0), unison=cfg.get("unison", 0), mod_cc=cfg.get("mod_cc", 16), pitch_bend=cfg.get("bend", 7.0),
+                 mpe_pitch_bend=cfg.get("mpe_bend", 24.0), glide_seconds=cfg.get("glide", 0.0), drift=cfg.get("drift", 0.0))
+    outs = []
+    for b in range(n_blocks):
+        start = b * block_frames
+        for i, evs in enumerate(per_instrument_events):
+            for e in evs:
+                if start <= e[3] < start + block_frames:
+                    ev.add_event(i, ml.Event(e[0], e[1], e[2], e[3] - start, e[4], e[5]))
+        vecs = block_frames // 64
+        done = 0
+        while done < vecs:       # a block may be processed in several launches
+            n = min(vectors_per_launch, vecs - done)
+            outs.append(ev.process_host(n, done * 64))
+            done += n
+        ev.clear_events()
+    return np.concatenate(outs, 2)
+
+
+def performance(kind, seed, frames, polyphony):
+    """A scripted event list: (type, channel, sourceIdx, time, value1, value2)."""
+    rng = np.random.default_rng(seed)
+    evs, held, t = [], [], int(rng.integers(0, 200))
+    mpe = kind == "mpe"
+    while t < frames - 10:
+        r = rng.random()
+        chan = int(rng.integers(2, 2 + polyphony + 2)) if mpe else 1
+        if r < 0.35 or not held:
+            key = int(rng.integers(30, 90))
+            evs.append((NOTE_ON, chan, key, t, float(np.float32((key - 60) / 12.0)), float(np.float32(rng.uniform(0.1, 1.0)))))
+            held.append((chan, key))
+        elif r < 0.6:
+            c, k = held.pop(int(rng.integers(0, len(held))))
+            evs.append((NOTE_OFF, c, k, t, 0.0, 0.0))
+        elif r < 0.7:
+            evs.append((BEND, chan if rng.random() < 0.7 else 1, 0, t, float(np.float32(rng.uniform(-1, 1))), 0.0))
+        elif r < 0.8:
+            cc = int(rng.choice([16, 73, 74, 1, 128]))
+            evs.append((CTRL, chan, cc, t, float(np.float32(rng.random())), 0.0))
+        elif r < 0.87:
+            if mpe:
+                evs.append((CHAN_PRESS, chan if rng.random() < 0.8 else 1, 0, t, float(np.float32(rng.random())), 0.0))
+            elif held and rng.random() < 0.5:
+                evs.append((NOTE_PRESS, 1, held[-1][1], t, float(np.float32(rng.random())), 0.0))
+            else:
+                evs.append((CHAN_PRESS, 1, 0, t, float(np.float32(rng.random())), 0.0))
+        elif r < 0.93 and kind == "sustain":
+            evs.append((SUSTAIN, 1, 0, t, float(rng.integers(0, 2)), 0.0))
+        elif r < 0.96:
+            evs.append((CTRL, 1, 123, t, 0.0, 0.0))        # all notes off
+            held = []
+        t += int(rng.integers(1, 260)) if rng.random() < 0.9 else 0   # now and then two events on the same frame
+    return evs
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import madronalib_amd as ml
+    e = ml.Engine(0)
+    yield e
+    e.close()
+
+
+SCENARIOS = {
+    "midi_poly4": dict(polyphony=4, glide=0.01, drift=0.5),
+    "midi_steal2": dict(polyphony=2, glide=0.003, drift=0.0),
+    "midi_poly16": dict(polyphony=16, glide=0.02, drift=1.0, bend=2.0),
+    "unison3": dict(polyphony=3, unison=1, glide=0.05, drift=0.2),
+    "sustain": dict(polyphony=4, glide=0.0, drift=0.0),
+    "mpe5": dict(polyphony=5, mpe=1, glide=0.01, drift=0.3, mpe_bend=48.0),
+    "sr44k": dict(polyphony=3, sr=44100.0, glide=0.015, drift=0.7, mod_cc=1),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_events_to_signals_matches_reference(eng, name):
+    cfg = SCENARIOS[name]
+    block, n_blocks = 512, 12
+    kind = "mpe" if cfg.get("mpe") else ("sustain" if name == "sustain" else "midi")
+    instruments = [performance(kind, 100 * k + len(name), block * n_blocks, cfg["polyphony"]) for k in range(5)]
+    got = gpu_run(eng, cfg, instruments, block, n_blocks, vectors_per_launch=3)
+    P = cfg["polyphony"]
+    for k, evs in enumerate(instruments):
+        want = ref_run(cfg, evs, block, n_blocks)
+        for r in range(8):
+            assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"{name}: instrument {k} row {ROW_NAMES[r]}")
+    assert np.abs(got[1]).max() > 0 and np.abs(got[0]).max() > 0
+
+
+@pytest.mark.gpu
+def test_silent_instrument_and_many_instruments(eng):
+    """An instrument that never received an event outputs zeros (and its vox row); 3000 instruments in one launch."""
+    cfg = dict(polyphony=4, glide=0.01, drift=0.4)
+    evs = performance("midi", 7, 512 * 4, 4)
+    N = 3000
+    instruments = [evs if (k % 7 == 0) else [] for k in range(N)]
+    got = gpu_run(eng, cfg, instruments, 512, 4, vectors_per_launch=8)
+    want = ref_run(cfg, evs, 512, 4)
+    for k in (0, 7, 2996):
+        for r in range(8):
+            assert_bits_equal(got[r, k * 4:(k + 1) * 4], want[r], True, f"instrument {k} row {ROW_NAMES[r]}")
+    silent = got[:, 4:8]
+    assert (silent[[0, 1, 3, 4, 5, 6, 7]] == 0).all()
+    assert (silent[2] == np.arange(4, dtype=np.float32)[:, None]).all()
