@@ -152,6 +152,7 @@ static bool graphOnlyInfo(int kind, int* nc, int* ns)
   {
     case MLGPU_PROC_INTERPOLATOR1: *nc = Proc<MLGPU_PROC_INTERPOLATOR1>::NC; *ns = Proc<MLGPU_PROC_INTERPOLATOR1>::NS; return true;
     case MLGPU_PROC_LINEAR_GLIDE: *nc = Proc<MLGPU_PROC_LINEAR_GLIDE>::NC; *ns = Proc<MLGPU_PROC_LINEAR_GLIDE>::NS; return true;
+    case MLGPU_PROC_TEMPO_LOCK: *nc = Proc<MLGPU_PROC_TEMPO_LOCK>::NC; *ns = Proc<MLGPU_PROC_TEMPO_LOCK>::NS; return true;
     // delay lines own HBM rings that only a graph allocates
     case MLGPU_PROC_INTEGER_DELAY: *nc = Proc<MLGPU_PROC_INTEGER_DELAY>::NC; *ns = Proc<MLGPU_PROC_INTEGER_DELAY>::NS; return true;
     case MLGPU_PROC_FRACTIONAL_DELAY: *nc = Proc<MLGPU_PROC_FRACTIONAL_DELAY>::NC; *ns = Proc<MLGPU_PROC_FRACTIONAL_DELAY>::NS; return true;
@@ -159,7 +160,7 @@ static bool graphOnlyInfo(int kind, int* nc, int* ns)
     default: return false;
   }
 }
-bool mlgpu_proc_is_vector_rate(int kind) { return kind == MLGPU_PROC_INTERPOLATOR1 || kind == MLGPU_PROC_LINEAR_GLIDE; }
+bool mlgpu_proc_is_vector_rate(int kind) { return kind == MLGPU_PROC_INTERPOLATOR1 || kind == MLGPU_PROC_LINEAR_GLIDE || kind == MLGPU_PROC_TEMPO_LOCK; }
 bool mlgpu_proc_is_graph_only(int kind)
 {
   int nc, ns;
@@ -180,6 +181,7 @@ uint64_t mlgpu_proc_clear_mask(int kind)
   switch (kind)
   {
     case MLGPU_PROC_ADSR: return 1ull << 7;             // only the segment, MLDSPFilters.h:698
+    case MLGPU_PROC_TEMPO_LOCK: return 0x1;              // clear() { _omega = -1 }, :1487
     case MLGPU_PROC_INTEGER_DELAY: return 0;             // only the buffer, :833
     case MLGPU_PROC_FRACTIONAL_DELAY: return 0x6;        // + Allpass1 x1, y1, :985-989
     case MLGPU_PROC_PITCHBENDABLE_DELAY: return 0x6 | (0x6 << 5);
@@ -223,6 +225,8 @@ void mlgpu_proc_clear_state(int kind, uint32_t* words, bool cleared)
   for (int i = 0; i < ns; ++i) words[i] = 0;
   if (kind == MLGPU_PROC_SINE_GEN && cleared) words[0] = 0xC0000000u;  // kZeroPhase, MLDSPGens.h:375,379
   if (kind == MLGPU_PROC_ADSR) words[7] = 4;                            // segment{off}, MLDSPFilters.h:700-702
+  if (kind == MLGPU_PROC_TEMPO_LOCK) words[0] = 0xBF800000u;            // _omega{-1.f} (and clear()), MLDSPFilters.h:1481,1487
+  if (kind == MLGPU_PROC_TEMPO_LOCK && cleared) words[1] = 0;
   if (kind == MLGPU_PROC_LINEAR_GLIDE) words[2] = 0xFFFFFFFFu;          // mVectorsRemaining{-1}, MLDSPGens.h:441,513
   if (kind == MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE) words[3] = 0xFFFFFFFFu;  // mSamplesRemaining{-1}, :524,588
 }

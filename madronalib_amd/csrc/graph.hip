@@ -373,7 +373,14 @@ std::string generateGraphSource(mlgpu_graph* g)
   {
     const Node& n = g->nodes[i];
     if (n.rate == RATE_VECTOR) emit(i, "    ");
-    if (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind))
+    if (n.type == NODE_PROC && n.kind == MLGPU_PROC_TEMPO_LOCK)
+    {
+      const int slot = g->nodes[n.in[0]].slot;  // the streamed input: first two samples of this vector
+      for (int l = 0; l < VL; ++l)
+        s << "    { const f32x4 x01 = in" << slot << sfx(l) << "[t * a.in[" << slot << "].strideT]; p" << i << sfx(l) << ".begin_vector(x01[0], x01[1], n"
+          << n.in[1] << sfx(l) << ", n" << n.in[2] << sfx(l) << "); }\n";
+    }
+    else if (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".begin_vector(n" << n.in[0] << sfx(l) << ");\n";
   }
   s << "#pragma unroll 2\n    for (int q = 0; q < 16; ++q)\n    {\n";
@@ -717,8 +724,16 @@ extern "C"
     if (kind == MLGPU_PROC_INTEGER_DELAY) okArity = (nIn == 1 || nIn == 2);     // (x), (x, delay) MLDSPFilters.h:834,877
     if (kind == MLGPU_PROC_FRACTIONAL_DELAY) okArity = (nIn >= 1 && nIn <= 3);  // (x), (x, delay), (x, delay, ticks) :1013-1043
     if (kind == MLGPU_PROC_PITCHBENDABLE_DELAY) okArity = (nIn == 2);           // (x, delay) :1098
+    if (kind == MLGPU_PROC_TEMPO_LOCK) okArity = (nIn == 3);                    // (x, dydx, isr) :1492
     if (!okArity || (nIn > 0 && !inputs)) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: wrong number of inputs");
-    if (mlgpu_proc_is_vector_rate(kind) && (inputs[0] < 0 || inputs[0] >= (int)g->nodes.size() || g->nodes[inputs[0]].rate > RATE_VECTOR))
+    if (kind == MLGPU_PROC_TEMPO_LOCK)
+    {
+      for (int j = 0; j < 3; ++j)
+        if (inputs[j] < 0 || inputs[j] >= (int)g->nodes.size()) return -gfail(g, MLGPU_ERR_RANGE, "graph node input refers to an unknown node");
+      if (g->nodes[inputs[0]].type != NODE_INPUT || g->nodes[inputs[1]].rate > RATE_VECTOR || g->nodes[inputs[2]].rate > RATE_VECTOR)
+        return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: TempoLock(x, dydx, isr): x is a streamed input node, dydx and isr floats per vector");
+    }
+    else if (mlgpu_proc_is_vector_rate(kind) && (inputs[0] < 0 || inputs[0] >= (int)g->nodes.size() || g->nodes[inputs[0]].rate > RATE_VECTOR))
       return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: Interpolator1 / LinearGlide take one float per DSPVector (a control, param or const node)");
     Node n;
     n.type = NODE_PROC;

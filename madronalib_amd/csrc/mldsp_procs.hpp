@@ -1058,6 +1058,87 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
   MLD void end_vector() {}
 };
 
+// ---- TempoLock, MLDSPFilters.h:1478-1579 ---------------------------------------------------------------------------
+// operator()(DSPVector x, float dydx, float isr): follows an input clock phasor at the ratio dydx. Per DSPVector it looks
+// only at x[0] and x[1], then writes a phasor ramp; so it is a vector-rate processor whose first input must be a STREAMED
+// graph input (the kernel reads the first two samples of the vector from it), the other two are floats per vector.
+template <>
+struct Proc<MLGPU_PROC_TEMPO_LOCK>  // C{}  S{omega, x1v}
+{
+  static constexpr int NC = 0, NS = 2;
+  float omega, x1v, dydt;
+  bool stopped;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    omega = u2f(m.s(0));
+    x1v = u2f(m.s(1));
+    dydt = 0.f;
+    stopped = false;
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(omega));
+    m.set(1, f2u(x1v));
+  }
+  MLD void begin_vector(float x0, float x1, float dydx, float isr)
+  {
+    stopped = (x0 == -1.0f);  // input phasor inactive: reset and output 0 (:1503-1507)
+    if (stopped)
+    {
+      omega = -1.0f;
+      return;
+    }
+    float dxdt;
+    if (omega > -1.f)
+    {
+      float dx = x0 - x1v;  // already running: average input slope over the last vector
+      if (dx < 0.f) dx += 1.f;
+      dxdt = dx / 64.f;
+      dydt = dxdt * dydx;
+      x1v = x0;
+    }
+    else
+    {
+      dxdt = x1 - x0;  // startup: jump to the input's phase
+      dydt = dxdt * dydx;
+      x1v = x0 - dxdt * 64.f;
+      omega = __builtin_fmodf(x0 * dydx, 1.0f);
+    }
+    bool lock = false;  // lock when the ratio or its reciprocal is close to an integer (:1534-1539)
+    if (abs_ps(dydx - __builtin_roundf(dydx)) < 0.001f) lock = true;
+    const float rdydx = 1.0f / dydx;
+    if (abs_ps(rdydx - __builtin_roundf(rdydx)) < 0.001f) lock = true;
+    if (lock)
+    {
+      float error;
+      if (dydx >= 1.f)
+      {
+        const float ref = x0 * dydx;
+        error = omega - (ref - __builtin_floorf(ref));
+      }
+      else
+      {
+        const float ref = omega / dydx;
+        error = (ref - __builtin_floorf(ref)) - x0;
+      }
+      const float errorDiff = __builtin_roundf(error) - error;
+      float correction = errorDiff * isr * 4.0f;
+      const float lo = -dydt * 0.5f, hi = dydt * 1.0f;
+      correction = (correction < lo) ? lo : (correction > hi ? hi : correction);  // ml::clamp, MLDSPScalarMath.h:68-72
+      dydt += correction;
+    }
+  }
+  MLD float next_n(int)
+  {
+    if (stopped) return 0.f;
+    const float y = omega;
+    omega += dydt;
+    if (omega > 1.0f) omega -= 1.0f;
+    return y;
+  }
+  MLD void end_vector() {}
+};
+
 // ---- compile-time chains -------------------------------------------------------------------
 
 // Processors with a cheaper evaluation for well-behaved, launch-constant input declare

@@ -783,7 +783,7 @@ int mlorc_proc_num_coeffs(int kind)
     case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_RMS: case MLGPU_PROC_LINEAR_GLIDE:
     case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return 2;
     case MLGPU_PROC_INTERPOLATOR1: case MLGPU_PROC_INTEGER_DELAY: case MLGPU_PROC_FRACTIONAL_DELAY:
-    case MLGPU_PROC_PITCHBENDABLE_DELAY: return 0;
+    case MLGPU_PROC_PITCHBENDABLE_DELAY: case MLGPU_PROC_TEMPO_LOCK: return 0;
     case MLGPU_PROC_ALLPASS1: return 1;
     case MLGPU_PROC_LOPASS: case MLGPU_PROC_BANDPASS: case MLGPU_PROC_PEAK: return 3;
     case MLGPU_PROC_HIPASS: case MLGPU_PROC_BELL: case MLGPU_PROC_ADSR: return 4;
@@ -802,7 +802,7 @@ int mlorc_proc_num_state(int kind)
     case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_DIFFERENTIATOR: case MLGPU_PROC_INTEGRATOR:
     case MLGPU_PROC_RMS: case MLGPU_PROC_INTERPOLATOR1: return 1;
     case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return 4;
-    case MLGPU_PROC_INTEGER_DELAY: case MLGPU_PROC_ALLPASS1: return 2;
+    case MLGPU_PROC_INTEGER_DELAY: case MLGPU_PROC_ALLPASS1: case MLGPU_PROC_TEMPO_LOCK: return 2;
     case MLGPU_PROC_FRACTIONAL_DELAY: return 5;
     case MLGPU_PROC_PITCHBENDABLE_DELAY: return 10;
     case MLGPU_PROC_LINEAR_GLIDE: return 3 + VEC;
@@ -822,6 +822,7 @@ static void proc_state_init(int kind, uint32_t* S, int cleared)
   for (int i = 0; i < ns; ++i) S[i] = 0;
   if (kind == MLGPU_PROC_SINE_GEN && cleared) S[0] = 0xC0000000u; /* kZeroPhase, MLDSPGens.h:375 */
   if (kind == MLGPU_PROC_ADSR) S[7] = ADSR_OFF;                   /* MLDSPFilters.h:700,702 */
+  if (kind == MLGPU_PROC_TEMPO_LOCK) S[0] = 0xBF800000u;          /* _omega{-1.f}, MLDSPFilters.h:1481,1487 */
   if (kind == MLGPU_PROC_LINEAR_GLIDE) S[2] = 0xFFFFFFFFu;        /* mVectorsRemaining{-1}, MLDSPGens.h:441,513 */
   if (kind == MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE) S[3] = 0xFFFFFFFFu; /* mSamplesRemaining{-1}, :524,588 */
 }
@@ -1453,6 +1454,68 @@ int mlorc_proc_process_multi(int kind, size_t V, size_t T, const float* coeffs, 
         }
         for (int n = 0; n < VEC; ++n) y[n] = u2f(cur[n]);
         St[0] = f2u(target); St[1] = f2u(step); St[2] = (uint32_t)remaining;
+      }
+      else if (kind == MLGPU_PROC_TEMPO_LOCK && n_inputs == 3)
+      { /* MLDSPFilters.h:1492-1578; in[0] the phasor to follow, in[1][0] = dydx, in[2][0] = isr */
+        float omega = u2f(St[0]), x1v = u2f(St[1]);
+        const float x0 = in[0][0], dydx = in[1][0], isr = in[2][0];
+        float dxdt = 0.f, dydt = 0.f;
+        if (x0 == -1.0f)
+        {
+          omega = -1.0f;
+          for (int n = 0; n < VEC; ++n) y[n] = 0.f;
+        }
+        else
+        {
+          if (omega > -1.f)
+          {
+            float dx = x0 - x1v;
+            if (dx < 0.f) dx += 1.f;
+            dxdt = dx / VEC;
+            dydt = dxdt * dydx;
+            x1v = x0;
+          }
+          else
+          {
+            dxdt = in[0][1] - x0;
+            dydt = dxdt * dydx;
+            x1v = x0 - dxdt * VEC;
+            omega = fmodf(x0 * dydx, 1.0f);
+          }
+          int lock = 0;
+          const float lockDist = 0.001f;
+          if (fabsf(dydx - roundf(dydx)) < lockDist) lock = 1;
+          const float rdydx = 1.0f / dydx;
+          if (fabsf(rdydx - roundf(rdydx)) < lockDist) lock = 1;
+          if (lock)
+          {
+            float ref, refWrap, error;
+            if (dydx >= 1.f)
+            {
+              ref = x0 * dydx;
+              refWrap = ref - floorf(ref);
+              error = omega - refWrap;
+            }
+            else
+            {
+              ref = omega / dydx;
+              refWrap = ref - floorf(ref);
+              error = refWrap - x0;
+            }
+            const float errorDiff = roundf(error) - error;
+            float correction = errorDiff * isr * 4.0f;
+            const float lo = -dydt * 0.5f, hi = dydt * 1.0f;
+            correction = (correction < lo) ? lo : (correction > hi ? hi : correction);
+            dydt += correction;
+          }
+          for (int n = 0; n < VEC; ++n)
+          {
+            y[n] = omega;
+            omega += dydt;
+            if (omega > 1.0f) omega -= 1.0f;
+          }
+        }
+        St[0] = f2u(omega); St[1] = f2u(x1v);
       }
       else if (n_inputs <= 1 && kind != MLGPU_PROC_INTERPOLATOR1 && kind != MLGPU_PROC_LINEAR_GLIDE)
       {

@@ -460,10 +460,31 @@ struct RAllpass1 : RefProc
   DSPVector process(const DSPVector& in) override { return f(in); }
 };
 
+struct RTempoLock : RefProc
+{
+  TempoLock g;
+  int nc() const override { return 0; }
+  int ns() const override { return 2; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override
+  {
+    g._omega = u2f(s[0]);
+    g._x1v = u2f(s[1]);
+  }
+  void getState(uint32_t* s) const override
+  {
+    s[0] = f2u(g._omega);
+    s[1] = f2u(g._x1v);
+  }
+  void clear() override { g.clear(); }
+  DSPVector process(const DSPVector& in) override { return in; }
+};
+
 RefProc* makeProc(int kind)
 {
   switch (kind)
   {
+    case MLGPU_PROC_TEMPO_LOCK: return new RTempoLock;
     case MLGPU_PROC_ALLPASS1: return new RAllpass1;
     case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return new RSampleGlide;
     case MLGPU_PROC_INTERPOLATOR1: return new RInterp1;
@@ -1016,6 +1037,8 @@ extern "C"
           for (int r = 0; r < 6; ++r) vc.row(r) = in[1 + r];
           y = static_cast<RHiShelf*>(rp.get())->f(in[0], vc);
         }
+        else if (kind == MLGPU_PROC_TEMPO_LOCK && nInputs == 3)
+          y = static_cast<RTempoLock*>(rp.get())->g(in[0], in[1][0], in[2][0]);
         else if (nInputs <= 1)
           y = rp->process(nInputs ? in[0] : DSPVector(0.f));
         else

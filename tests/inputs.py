@@ -201,7 +201,7 @@ def stepped(V, S, seed, lo, hi, min_len, max_len):
     return x
 
 
-MULTI_CASES = ("pulse2", "lopass_mod", "loshelf_vc", "hishelf_vc", "interp1", "linear_glide", "linear_glide_long")
+MULTI_CASES = ("pulse2", "lopass_mod", "loshelf_vc", "hishelf_vc", "interp1", "linear_glide", "linear_glide_long", "tempo_lock")
 
 
 def multi_case(mk, name, V, T, seed=0):
@@ -246,6 +246,25 @@ def multi_case(mk, name, V, T, seed=0):
         co = proc_default_coeffs(mk, P.LINEAR_GLIDE, V, seed) if name == "linear_glide" else \
             np.stack([mk.make_coeffs("linear_glide", 64.0 * (3 + v % 30)) for v in range(V)], 1)
         return dict(kind=P.LINEAR_GLIDE, coeffs=co, inputs=[("control", c)])
+    if name == "tempo_lock":
+        # the input clock: stopped (-1) for a few vectors, then a phasor of per-voice rate; ratios that lock (2, 1/2, 3),
+        # one that does not (1.37), changing now and then
+        x = np.full((V, S), -1.0, np.float32)
+        for v in range(V):
+            start = 64 * int(rng.integers(0, 4))
+            rate = np.float32(rng.uniform(0.0002, 0.002))
+            ph = np.float32(rng.random())
+            for i in range(start, S):
+                x[v, i] = ph
+                ph = np.float32(ph + rate)
+                if ph > 1.0:
+                    ph = np.float32(ph - 1.0)
+            if v % 5 == 4:
+                x[v, 64 * (T // 2):64 * (T // 2 + 2)] = -1.0   # the clock stops and restarts
+        ratios = np.array([2.0, 0.5, 3.0, 1.37, 1.0, 0.25], np.float32)
+        dydx = ratios[(np.arange(V)[:, None] + np.arange(T)[None, :] // 7) % len(ratios)].astype(np.float32)
+        isr = np.full((V, T), np.float32(1.0 / 48000.0), np.float32)
+        return dict(kind=P.TEMPO_LOCK, coeffs=np.zeros((0, V), np.float32), inputs=[("audio", x), ("control", dydx), ("control", isr)])
     raise KeyError(name)
 
 
