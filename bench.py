@@ -40,6 +40,10 @@ WORKLOADS = {
     "cfg4": (131072, 32, 16),   # long-buffer: 512 vectors per step
     "cfg2": (65536, 1, 64),     # elementwise: 64 vector-steps per step
     "cfg5": (262144, 16, 16),   # synth16 graph: 256 vectors per step
+    # widened rows, measured to the same bar; not BASELINE configs
+    "events": (262144, 16, 8),  # EventsToSignals: 16384 instruments x 16 voices, 8 control rows out
+    "resample": (262144, 32, 8),  # Downsampler, 2 octaves: 32 vectors in -> 8 out per launch
+    "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
 }
 
 
@@ -130,6 +134,71 @@ def setup_workload(eng, name, V, T, lo, total):
         alg = 8.0 * n + V * 4.0 * (5 + 14 + 19 + 19)
         return launch, alg, "mlgpu_graph_kernel", ("BASELINE configs[4]: 16-node synth patch (run-time graph fused by hiprtc), "
                                                     "262144 voices/GPU, streamed gate in, audio out"), g
+    if name == "events":
+        P = 16
+        N = V // P
+        ev = ml.Events(eng, N, P, 48000.0)
+        ev.configure(glide_seconds=0.01, drift=0.5)
+        rng = np.random.default_rng(lo + 1)
+        held = {}
+        outs = [[eng.alloc(4 * n) for _ in range(8)] for _ in range(2)]
+        k = [0]
+
+        def launch():
+            # a sparse performance: every launch ~2 % of the instruments get a note on or off somewhere in the block
+            for i in rng.integers(0, N, max(1, N // 50)):
+                i = int(i)
+                t = int(rng.integers(0, 64 * T))
+                if held.get(i):
+                    ev.add_event(i, ml.Event(4, 1, held[i].pop(), t, 0.0, 0.0))
+                else:
+                    key = int(rng.integers(36, 84))
+                    held.setdefault(i, []).append(key)
+                    ev.add_event(i, ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
+            ev.process(T, 0, outs[k[0] & 1], Layout.QUAD)
+            ev.clear_events()
+            k[0] += 1
+        # 8 rows x 4 B per voice-sample written; per voice and DSPVector 7 glides x 5 state words read and written, per
+        # voice and launch 23 scalar state words read and written
+        alg = 32.0 * n + V * T * 4.0 * 35 * 2 + V * 4.0 * 23 * 2
+        return launch, alg, "e2s_kernel", ("EventsToSignals: 16384 instruments x 16 voices, 8 control signals out, sparse note events "
+                                           "(host routing + record upload inside the step)"), ev
+    if name == "resample":
+        r = ml.Resampler(eng, V, 2, False)
+        x = eng.bank([Proc.NOISE_GEN], V)
+        x.set_state(0, 0, np.arange(lo, lo + V, dtype=np.uint32))
+        d_x = eng.alloc(4 * n)
+        x.process(T, d_x, Layout.QUAD)
+        d_y = eng.alloc(n)
+
+        def launch():
+            r.process(T, d_x, d_y)
+        alg = 4.0 * n + 1.0 * n + V * 4.0 * 18 * 2
+        return launch, alg, "downsample_kernel<2>", "Downsampler, 2 octaves (two HalfBandFilters per voice), streamed noise in", (r, x)
+    if name == "allpass4":
+        from madronalib_amd import patches
+        desc = [dict(name="x", type="input"), dict(name="dl", type="param")]
+        src = "x"
+        for j in range(4):
+            sub, src = patches.allpass(f"ap{j}_", src, Proc.PITCHBENDABLE_DELAY, 4096.0 - 64.0, "dl")
+            desc += sub
+        g = ml.Graph(eng, V, desc, [src])
+        for j in range(4):
+            g.set_param(f"ap{j}_gain", 0.6)
+        g.set_param("dl", (400.0 + 3000.0 * (np.arange(V) % 97) / 96.0).astype(np.float32))
+        nb = eng.bank([Proc.NOISE_GEN], V)
+        nb.set_state(0, 0, np.arange(lo, lo + V, dtype=np.uint32))
+        d_x = eng.alloc(4 * n)
+        nb.process(T, d_x, Layout.QUAD)
+        outs_d = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        k = [0]
+
+        def launch():
+            g.process(T, [d_x], [outs_d[k[0] & 1]])
+            k[0] += 1
+        # in + out, per allpass: two rings (write + read each) and one feedback vector (read + write)
+        alg = 8.0 * n + 4 * (2 * 8.0 + 8.0) * n
+        return launch, alg, "mlgpu_graph_kernel", "4 x Allpass<PitchbendableDelay> in series, per-voice delay times 400..3400 samples, 16384 voices", (g, nb)
     raise SystemExit(f"unknown workload {name}")
 
 

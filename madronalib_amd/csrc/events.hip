@@ -86,98 +86,102 @@ struct E2SArgs
   const uint32_t* recStart;   // [lanes + 1]
   SignalView out[8];          // pitch, gate, vox, z, x, y, mod, elapsed time: V = instruments * polyphony voices
   size_t lanes, T;
-  int group, polyphony;
+  int group, polyphony, slotBase;  // lane = instrument * group + (voice slot - slotBase)
   E2SSettings s;
 };
 
 // LinearGlide (MLDSPGens.h:433-515) with one shortcut that does not change results: between glides mCurrVec is a
-// broadcast of one value, kept in a register instead of 64 words of HBM.
+// broadcast of one value, kept in a register instead of 64 words of HBM. `st` is this glide's first word for this lane
+// (stride = lanes); it is passed in instead of stored to keep the register count of seven glides down.
 struct Glide
 {
-  uint32_t* st;  // this glide's words for this lane (stride = lanes)
-  size_t stride;
   float target, step, uniformValue, startValue;
   int32_t remaining;
-  bool isUniform;
-  int mode;  // 0 hold, 1 end, 2 start, 3 continue
-  MLD uint32_t& w(int i) const { return st[(size_t)i * stride]; }
-  MLD void load(uint32_t* base, size_t lanes)
+  int modeFlags;  // bits 0-1: mode (0 hold, 1 end, 2 start, 3 continue); bit 2: mCurrVec is uniform
+  MLD bool isUniform() const { return (modeFlags & 4) != 0; }
+  MLD int mode() const { return modeFlags & 3; }
+  MLD void load(const uint32_t* st, size_t stride)
   {
-    st = base;
-    stride = lanes;
-    target = u2f(w(0));
-    step = u2f(w(1));
-    remaining = (int32_t)w(2);
-    isUniform = w(3) != 0;
-    uniformValue = u2f(w(4));
+    target = u2f(st[0]);
+    step = u2f(st[stride]);
+    remaining = (int32_t)st[2 * stride];
+    modeFlags = st[3 * stride] ? 4 : 0;
+    uniformValue = u2f(st[4 * stride]);
+    startValue = 0.f;
   }
-  MLD void store() const
+  MLD void store(uint32_t* st, size_t stride) const
   {
-    w(0) = f2u(target);
-    w(1) = f2u(step);
-    w(2) = (uint32_t)remaining;
-    w(3) = isUniform ? 1u : 0u;
-    w(4) = f2u(uniformValue);
+    st[0] = f2u(target);
+    st[stride] = f2u(step);
+    st[2 * stride] = (uint32_t)remaining;
+    st[3 * stride] = isUniform() ? 1u : 0u;
+    st[4 * stride] = f2u(uniformValue);
   }
-  MLD void beginVector(float f, int32_t perGlide, float dyPerVector)
+  MLD void beginVector(const uint32_t* st, size_t stride, float f, int32_t perGlide, float dyPerVector)
   {
     if (f != target)
     {
       target = f;
       remaining = perGlide;
     }
-    if (remaining < 0) mode = 0;
+    int m;
+    if (remaining < 0) m = 0;
     else if (remaining == 0)
     {
-      mode = 1;
+      m = 1;
       step = 0.f;
       remaining--;
     }
     else if (remaining == perGlide)
     {
-      mode = 2;
-      startValue = isUniform ? uniformValue : u2f(w(5 + 63));
+      m = 2;
+      startValue = isUniform() ? uniformValue : u2f(st[(size_t)(5 + 63) * stride]);
       step = (target - startValue) * dyPerVector;
       remaining--;
     }
     else
     {
-      mode = 3;
+      m = 3;
       remaining--;
     }
+    modeFlags = (modeFlags & 4) | m;
   }
-  MLD float next(int n)
+  MLD float next(uint32_t* st, size_t stride, int n) const
   {
-    if (mode == 0) return isUniform ? uniformValue : u2f(w(5 + n));
-    if (mode == 1) return target;
+    const int m = mode();
+    if (m == 0) return isUniform() ? uniformValue : u2f(st[(size_t)(5 + n) * stride]);
+    if (m == 1) return target;
     float c;
-    if (mode == 2) c = startValue + ((float)(n + 1) * 0.015625f) * step;
-    else c = (isUniform ? uniformValue : u2f(w(5 + n))) + step;
-    w(5 + n) = f2u(c);
+    if (m == 2) c = startValue + ((float)(n + 1) * 0.015625f) * step;
+    else c = (isUniform() ? uniformValue : u2f(st[(size_t)(5 + n) * stride])) + step;
+    st[(size_t)(5 + n) * stride] = f2u(c);
     return c;
   }
   MLD void endVector()
   {
-    if (mode == 1)
+    const int m = mode();
+    if (m == 1)
     {
-      isUniform = true;
+      modeFlags = 4;
       uniformValue = target;
     }
-    else if (mode >= 2)
-      isUniform = false;
+    else if (m >= 2)
+      modeFlags = 0;
+    else
+      modeFlags &= 4;
   }
 };
 
-__global__ __launch_bounds__(256) void e2s_kernel(const E2SArgs a)
+__global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
 {
   const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = lane < a.lanes;
   const size_t L = live ? lane : 0;
-  const int slot = (int)(L % (size_t)a.group);           // 0 = MPE main voice, 1..polyphony = playing voices
+  const int slot = (int)(L % (size_t)a.group) + a.slotBase;  // 0 = MPE main voice (MPE mode only), 1..polyphony = playing voices
   const bool isVoice = live && slot >= 1 && slot <= a.polyphony;
   const bool active = live && slot <= a.polyphony;       // lanes beyond polyphony are padding
   const size_t outVoice = (L / (size_t)a.group) * (size_t)a.polyphony + (size_t)(slot > 0 ? slot - 1 : 0);
-  uint32_t* S = a.state + L;
+  uint32_t* S = a.state + L;  // reassigned before the final stores
   const size_t ln = a.lanes;
 #define SW(i) S[(size_t)(i) * ln]
 
@@ -191,9 +195,9 @@ __global__ __launch_bounds__(256) void e2s_kernel(const E2SArgs a)
   uint32_t driftSeed = SW(S_DRIFT_SEED);
   int32_t driftCounter = (int32_t)SW(S_DRIFT_COUNTER), driftNext = (int32_t)SW(S_DRIFT_NEXT);
   float driftValue = u2f(SW(S_DRIFT_VALUE));
-  Glide g[kNumGlides];
-#pragma unroll
-  for (int i = 0; i < kNumGlides; ++i) g[i].load(S + (size_t)(S_GLIDES + i * kGlideWords) * ln, ln);
+  // the seven glides stay in HBM between uses: each row loop loads the one or two it needs (5 words), so their
+  // registers are not live everywhere
+#define GS(i) (S + (size_t)(S_GLIDES + (i) * kGlideWords) * ln)
 
   auto setPitchGlideTime = [&](int32_t t) {  // SampleAccurateLinearGlide::setGlideTimeInSamples, MLDSPGens.h:527-532
     pgPerGlide = t < 1 ? 1 : t;
@@ -279,28 +283,139 @@ __global__ __launch_bounds__(256) void e2s_kernel(const E2SArgs a)
         }
       }
       if (finalVelocity == 0.f) cz = 0.f;  // :238-241
-      g[0].beginVector(bend, a.s.glideVectors, a.s.glideDy);
-      g[1].beginVector(mod, a.s.glideVectors, a.s.glideDy);
-      g[2].beginVector(cx, a.s.glideVectors, a.s.glideDy);
-      g[3].beginVector(cy, a.s.glideVectors, a.s.glideDy);
-      g[4].beginVector(cz, a.s.glideVectors, a.s.glideDy);
-      g[5].beginVector(driftValue, a.s.driftGlideVectors, a.s.driftGlideDy);
-      g[6].beginVector(chanPress, a.s.ctlGlideVectors, a.s.ctlGlideDy);  // SmoothedController::process, :268-280
+    }
+    const bool on = awake && active;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    auto put = [&](int row, int q, const f32x4 v) {
+      const SignalView& sv = a.out[row];
+      if (sv.base && isVoice) __builtin_nontemporal_store(v, (f32x4*)sv.base + t * sv.strideT + (size_t)q * sv.strideQ + outVoice * sv.strideV);
+    };
+    // MPE: the main voice's signal is added to every playing voice of its instrument (:447-458)
+    auto withMain = [&](float v) {
+      if (!a.s.mpe) return v;
+      const float m = __shfl(v, mainLane, 64);
+      return (isVoice && awake) ? v + m : v;
+    };
+
+    // ---- rows that are one glide each: mod, x, y; z adds the smoothed channel pressure in MIDI mode (:437-445) ----
+    // One short loop per row keeps the live state of the other rows out of the registers.
+    {
+      Glide gl;
+      gl.load(GS(1), ln);
+      if (on) gl.beginVector(GS(1), ln, mod, a.s.glideVectors, a.s.glideDy);
+#pragma unroll 1
+      for (int q = 0; q < 16; ++q)
+      {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.next(GS(1), ln, q * 4 + k) : 0.f);
+        put(6, q, v);
+      }
+      if (on)
+      {
+        gl.endVector();
+        gl.store(GS(1), ln);
+      }
+    }
+    {
+      Glide gl;
+      gl.load(GS(2), ln);
+      if (on) gl.beginVector(GS(2), ln, cx, a.s.glideVectors, a.s.glideDy);
+#pragma unroll 1
+      for (int q = 0; q < 16; ++q)
+      {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.next(GS(2), ln, q * 4 + k) : 0.f);
+        put(4, q, v);
+      }
+      if (on)
+      {
+        gl.endVector();
+        gl.store(GS(2), ln);
+      }
+    }
+    {
+      Glide gl;
+      gl.load(GS(3), ln);
+      if (on) gl.beginVector(GS(3), ln, cy, a.s.glideVectors, a.s.glideDy);
+#pragma unroll 1
+      for (int q = 0; q < 16; ++q)
+      {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.next(GS(3), ln, q * 4 + k) : 0.f);
+        put(5, q, v);
+      }
+      if (on)
+      {
+        gl.endVector();
+        gl.store(GS(3), ln);
+      }
+    }
+    {
+      Glide gz, gp;
+      gz.load(GS(4), ln);
+      gp.load(GS(6), ln);
+      if (on)
+      {
+        gz.beginVector(GS(4), ln, cz, a.s.glideVectors, a.s.glideDy);
+        gp.beginVector(GS(6), ln, chanPress, a.s.ctlGlideVectors, a.s.ctlGlideDy);  // SmoothedController::process, :268-280
+      }
+#pragma unroll 1
+      for (int q = 0; q < 16; ++q)
+      {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          float z = 0.f;
+          if (on)
+          {
+            z = gz.next(GS(4), ln, q * 4 + k);
+            const float press = gp.next(GS(6), ln, q * 4 + k);
+            if (!a.s.mpe) z = z + press;
+          }
+          v[k] = withMain(z);
+        }
+        put(3, q, v);
+      }
+      if (on)
+      {
+        gz.endVector();
+        gp.endVector();
+        gz.store(GS(4), ln);
+        gp.store(GS(6), ln);
+      }
+    }
+    {
+      const float vox = (float)(slot - 1);  // row kVoice: DSPVector((float)i - 1), :302
+      const f32x4 v = {vox, vox, vox, vox};
+#pragma unroll 1
+      for (int q = 0; q < 16; ++q) put(2, q, v);
     }
 
-    // ---- the 64 frames: writeNoteEvent (:115-216) and endProcess (:218-262) walked frame by frame ----
+    // ---- gate, pitch, elapsed time: writeNoteEvent (:115-216) and endProcess (:218-262) walked frame by frame ----
+    Glide gb, gd;
+    gb.load(GS(0), ln);
+    gd.load(GS(5), ln);
+    if (on)
+    {
+      gb.beginVector(GS(0), ln, bend, a.s.glideVectors, a.s.glideDy);
+      gd.beginVector(GS(5), ln, driftValue, a.s.driftGlideVectors, a.s.driftGlideDy);
+    }
     uint32_t nc = cursor;      // next note record
     bool preApplied = false;   // a note event's bookkeeping applies from the frame the previous one ended at
 #pragma unroll 1
     for (int q = 0; q < 16; ++q)
     {
-      float oPitch[4], oGate[4], oZ[4], oX[4], oY[4], oMod[4], oTime[4];
-#pragma unroll
+      f32x4 oPitch = {0.f, 0.f, 0.f, 0.f}, oGate = oPitch, oTime = oPitch;
+#pragma unroll 1
       for (int k = 0; k < 4; ++k)
       {
         const int n = q * 4 + k;
-        float vPitch = 0.f, vGate = 0.f, vZ = 0.f, vX = 0.f, vY = 0.f, vMod = 0.f, vTime = 0.f;
-        if (awake && active)
+        float vPitch = 0.f, vGate = 0.f, vTime = 0.f;
+        if (on)
         {
           bool retrigFrame = false;
           while (nc < vend)
@@ -355,7 +470,7 @@ __global__ __launch_bounds__(256) void e2s_kernel(const E2SArgs a)
           // the same voice on one frame) makes the reference REWRITE frame dest - 1, which that previous event had already
           // written (:163-175): the glide is stepped and the event age counted once more, with the previous event's new
           // pitch. Look ahead for exactly that pattern and redo this frame the same way.
-          for (;;)
+          while (nc < vend)
           {
             uint32_t pi = nc;
             while (pi < vend && ((a.recs[pi].typeTimeFlags & 0xFF) < REC_NOTE_ON || (a.recs[pi].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++pi;
@@ -369,10 +484,9 @@ __global__ __launch_bounds__(256) void e2s_kernel(const E2SArgs a)
             while (ri < vend && ((a.recs[ri].typeTimeFlags & 0xFF) < REC_NOTE_ON || (a.recs[ri].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++ri;
             if (ri >= vend) break;
             const Rec R = a.recs[ri];
-            int rdest = (int)((R.typeTimeFlags >> 8) & 0xFF);
+            const int rdest = (int)((R.typeTimeFlags >> 8) & 0xFF);
             if ((R.typeTimeFlags & 0xFF) != REC_NOTE_RETRIG || rdest != n + 1) break;
-            // P's own bookkeeping, if this frame is the first one it sees
-            if (!preApplied)
+            if (!preApplied)  // P's own bookkeeping, if this frame is the first one it sees
             {
               const uint32_t pflags = P.typeTimeFlags >> 16;
               if (ptype != REC_NOTE_OFF)
@@ -401,54 +515,38 @@ __global__ __launch_bounds__(256) void e2s_kernel(const E2SArgs a)
             age += ageStep;
             vTime = (float)((double)age / srD);
           }
-          const float bendSig = g[0].next(n), driftSig = g[5].next(n);
-          vMod = g[1].next(n);
-          vX = g[2].next(n);
-          vY = g[3].next(n);
-          vZ = g[4].next(n);
-          const float press = g[6].next(n);
+          const float bendSig = gb.next(GS(0), ln, n), driftSig = gd.next(GS(5), ln, n);
           vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
           vPitch = vPitch + (driftSig * a.s.driftAmount) * 0.02f;           // kDriftScale, :247
-          if (!a.s.mpe) vZ = vZ + press;                                      // MIDI: smoothed channel pressure, :437-445
         }
-        if (a.s.mpe)  // the main voice's signals are added to every playing voice, :447-458
-        {
-          const float mp = __shfl(vPitch, mainLane, 64), mx = __shfl(vX, mainLane, 64), my = __shfl(vY, mainLane, 64);
-          const float mz = __shfl(vZ, mainLane, 64), mm = __shfl(vMod, mainLane, 64);
-          if (isVoice && awake)
-          {
-            vPitch = vPitch + mp;
-            vX = vX + mx;
-            vY = vY + my;
-            vZ = vZ + mz;
-            vMod = vMod + mm;
-          }
-        }
-        oPitch[k] = vPitch; oGate[k] = vGate; oZ[k] = vZ; oX[k] = vX; oY[k] = vY; oMod[k] = vMod; oTime[k] = vTime;
+        vPitch = withMain(vPitch);
+        // k is a loop variable here (the body is large): insert with selects instead of a dynamic register index
+        oPitch = {k == 0 ? vPitch : oPitch[0], k == 1 ? vPitch : oPitch[1], k == 2 ? vPitch : oPitch[2], k == 3 ? vPitch : oPitch[3]};
+        oGate = {k == 0 ? vGate : oGate[0], k == 1 ? vGate : oGate[1], k == 2 ? vGate : oGate[2], k == 3 ? vGate : oGate[3]};
+        oTime = {k == 0 ? vTime : oTime[0], k == 1 ? vTime : oTime[1], k == 2 ? vTime : oTime[2], k == 3 ? vTime : oTime[3]};
       }
-      if (isVoice)
-      {
-        auto put = [&](int row, const float* v) {
-          const SignalView& s = a.out[row];
-          if (!s.base) return;
-          typedef float f32x4 __attribute__((ext_vector_type(4)));
-          const f32x4 x = {v[0], v[1], v[2], v[3]};
-          __builtin_nontemporal_store(x, (f32x4*)s.base + t * s.strideT + (size_t)q * s.strideQ + outVoice * s.strideV);
-        };
-        const float vox = (float)(slot - 1);  // row kVoice: DSPVector((float)i - 1), :302
-        const float voxq[4] = {vox, vox, vox, vox};
-        put(0, oPitch); put(1, oGate); put(2, voxq); put(3, oZ); put(4, oX); put(5, oY); put(6, oMod); put(7, oTime);
-      }
+      put(0, q, oPitch);
+      put(1, q, oGate);
+      put(7, q, oTime);
     }
-    if (awake && active)
+    if (on)
     {
-#pragma unroll
-      for (int i = 0; i < kNumGlides; ++i) g[i].endVector();
+      gb.endVector();
+      gd.endVector();
+      gb.store(GS(0), ln);
+      gd.store(GS(5), ln);
     }
     cursor = vend;
   }
 
   if (!live) return;
+  // Recompute the state addresses from a value the optimiser cannot relate to the loads at the top: otherwise ~60 64-bit
+  // per-lane pointers stay live across the whole kernel (it needed more than 256 VGPRs).
+  {
+    size_t Lend = L;
+    asm volatile("" : "+v"(Lend));
+    S = a.state + Lend;
+  }
   SW(S_AWAKE) = awake ? 1u : 0u;
   SW(S_VELOCITY) = f2u(velocity); SW(S_PITCH) = f2u(pitch); SW(S_BEND) = f2u(bend); SW(S_MOD) = f2u(mod);
   SW(S_X) = f2u(cx); SW(S_Y) = f2u(cy); SW(S_Z) = f2u(cz); SW(S_CHANPRESS) = f2u(chanPress);
@@ -456,8 +554,7 @@ __global__ __launch_bounds__(256) void e2s_kernel(const E2SArgs a)
   SW(S_PG_CURR) = f2u(pgCurr); SW(S_PG_STEP) = f2u(pgStep); SW(S_PG_TARGET) = f2u(pgTarget); SW(S_PG_REMAINING) = (uint32_t)pgRemaining;
   SW(S_PG_PER_GLIDE) = (uint32_t)pgPerGlide; SW(S_PG_DY) = f2u(pgDy);
   SW(S_DRIFT_SEED) = driftSeed; SW(S_DRIFT_COUNTER) = (uint32_t)driftCounter; SW(S_DRIFT_VALUE) = f2u(driftValue); SW(S_DRIFT_NEXT) = (uint32_t)driftNext;
-#pragma unroll
-  for (int i = 0; i < kNumGlides; ++i) g[i].store();
+#undef GS
 #undef SW
 }
 
@@ -495,13 +592,15 @@ struct mlgpu_events
 {
   mlgpu_engine* e{nullptr};
   size_t nInstruments{0};
-  int polyphony{0}, group{1};
+  int polyphony{0}, group{1}, slotBase{1};  // MIDI: one lane per playing voice; MPE: pow2 groups with the main voice at lane 0
+  size_t maxLanes{0};
   bool mpe{false}, unison{false};
   int voiceModCC{16};
   double sr{0};
   float pitchBendRange{7.f}, mpePitchBendRange{24.f}, pitchGlideSeconds{0.f}, driftAmount{0.f};
   std::vector<Instrument> inst;
   std::vector<std::vector<Rec>> laneRecs;  // per lane, this launch
+  std::vector<uint32_t> dirtyLanes;        // lanes with records (most have none)
   uint32_t* d_state{nullptr};
   Rec* d_recs{nullptr};
   uint32_t* d_recStart{nullptr};
@@ -534,7 +633,10 @@ struct Router  // one instrument, one vector
   void push(int voice, const Rec& r)
   {
     if (voice < 0 || voice > ev->polyphony) return;  // voices the device does not simulate (beyond the polyphony)
-    ev->laneRecs[instIdx * (size_t)ev->group + (size_t)voice].push_back(r);
+    if (voice < ev->slotBase) return;  // MIDI mode: the MPE main voice is not simulated (its signals are not used, :437-445)
+    std::vector<Rec>& lr = ev->laneRecs[instIdx * (size_t)ev->group + (size_t)(voice - ev->slotBase)];
+    if (lr.empty()) ev->dirtyLanes.push_back((uint32_t)(instIdx * (size_t)ev->group + (size_t)(voice - ev->slotBase)));
+    lr.push_back(r);
   }
   // Voice::writeNoteEvent's host-visible effects (:115-216): creatorKeyIdx_ and currentVelocity
   void note(int v, const mlgpu_event& e, uint32_t type, int keyIdx, bool doGlide, bool doReset)
@@ -721,7 +823,7 @@ void initialState(const mlgpu_events* ev, std::vector<uint32_t>& st)
   const uint32_t minusOne = 0xFFFFFFFFu;
   for (size_t lane = 0; lane < lanes; ++lane)
   {
-    const int slot = (int)(lane % (size_t)ev->group);
+    const int slot = (int)(lane % (size_t)ev->group) + ev->slotBase;
     W(S_PG_REMAINING, lane) = minusOne;       // SampleAccurateLinearGlide defaults, MLDSPGens.h:519-524
     W(S_PG_PER_GLIDE, lane) = 32;
     const float dy = 1.f / 32;
@@ -785,13 +887,16 @@ extern "C"
     ev->e = e;
     ev->nInstruments = nInstruments;
     ev->polyphony = polyphony;
-    ev->group = 1;
-    while (ev->group < polyphony + 1) ev->group <<= 1;
+    int pow2 = 1;
+    while (pow2 < polyphony + 1) pow2 <<= 1;
+    ev->maxLanes = nInstruments * (size_t)pow2;
+    ev->group = polyphony;  // MIDI (the default protocol)
+    ev->slotBase = 1;
     ev->inst.resize(nInstruments);
-    ev->laneRecs.resize(ev->lanes());
+    ev->laneRecs.resize(ev->maxLanes);
     hipError_t err = hipSetDevice(e->device);
-    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_state, sizeof(uint32_t) * (size_t)kStateWords * ev->lanes());
-    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_recStart, sizeof(uint32_t) * (ev->lanes() + 1));
+    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_state, sizeof(uint32_t) * (size_t)kStateWords * ev->maxLanes);
+    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_recStart, sizeof(uint32_t) * (ev->maxLanes + 1));
     if (err != hipSuccess)
     {
       e->lastError = std::string("events_create: ") + hipGetErrorString(err);
@@ -825,6 +930,17 @@ extern "C"
   {
     if (!ev) return MLGPU_ERR_INVALID;
     ev->mpe = mpe != 0;
+    if (ev->mpe)
+    {
+      ev->group = 1;
+      while (ev->group < ev->polyphony + 1) ev->group <<= 1;
+      ev->slotBase = 0;
+    }
+    else
+    {
+      ev->group = ev->polyphony;
+      ev->slotBase = 1;
+    }
     return mlgpu_events_clear(ev);
   }
   int mlgpu_events_set_unison(mlgpu_events* ev, int on) { return ev ? (ev->unison = on != 0, MLGPU_OK) : MLGPU_ERR_INVALID; }
@@ -866,7 +982,8 @@ extern "C"
     if (ev->sr == 0) return efail(ev, MLGPU_ERR_INVALID, "events_process: no sample rate (the reference does nothing, :385)");
     if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return efail(ev, MLGPU_ERR_INVALID, "events_process: bad layout");
     // ---- route this launch's events into per-voice records ----
-    for (auto& l : ev->laneRecs) l.clear();
+    for (uint32_t l : ev->dirtyLanes) ev->laneRecs[l].clear();
+    ev->dirtyLanes.clear();
     for (size_t i = 0; i < ev->nInstruments; ++i)
     {
       Instrument& in = ev->inst[i];
@@ -892,12 +1009,16 @@ extern "C"
     const size_t lanes = ev->lanes();
     ev->h_recStart.assign(lanes + 1, 0);
     ev->h_recs.clear();
-    for (size_t l = 0; l < lanes; ++l)
+    std::sort(ev->dirtyLanes.begin(), ev->dirtyLanes.end());
     {
-      ev->h_recStart[l] = (uint32_t)ev->h_recs.size();
-      ev->h_recs.insert(ev->h_recs.end(), ev->laneRecs[l].begin(), ev->laneRecs[l].end());
+      size_t next = 0;  // lanes without records share their successor's start offset
+      for (uint32_t l : ev->dirtyLanes)
+      {
+        for (; next <= l; ++next) ev->h_recStart[next] = (uint32_t)ev->h_recs.size();
+        ev->h_recs.insert(ev->h_recs.end(), ev->laneRecs[l].begin(), ev->laneRecs[l].end());
+      }
+      for (; next <= lanes; ++next) ev->h_recStart[next] = (uint32_t)ev->h_recs.size();
     }
-    ev->h_recStart[lanes] = (uint32_t)ev->h_recs.size();
     if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
     if (ev->h_recs.size() + 1 > ev->recCapacity)
     {
@@ -929,6 +1050,7 @@ extern "C"
     a.lanes = lanes;
     a.T = nVectors;
     a.group = ev->group;
+    a.slotBase = ev->slotBase;
     a.polyphony = ev->polyphony;
     a.s.sr = ev->sr;
     a.s.pitchBendRange = ev->pitchBendRange;
