@@ -185,7 +185,10 @@ def setup_workload(eng, name, V, T, lo, total):
         g = ml.Graph(eng, V, desc, [src])
         for j in range(4):
             g.set_param(f"ap{j}_gain", 0.6)
-        g.set_param("dl", (400.0 + 3000.0 * (np.arange(V) % 97) / 96.0).astype(np.float32))
+        if os.environ.get("MLGPU_UNIFORM_DELAY"):
+            g.set_param("dl", 1900.0)      # one delay time for every voice: ring reads coalesce
+        else:
+            g.set_param("dl", (400.0 + 3000.0 * (np.arange(V) % 97) / 96.0).astype(np.float32))
         nb = eng.bank([Proc.NOISE_GEN], V)
         nb.set_state(0, 0, np.arange(lo, lo + V, dtype=np.uint32))
         d_x = eng.alloc(4 * n)
