@@ -238,6 +238,25 @@ def cpu_baseline_cfg3(budget_s=12.0):
                       f"({'compiled reference headers, g++ -O2 SSE2' if kind == 'reference' else 'plain-C oracle port, gcc -O2'})"}
 
 
+def cpu_baseline_cfg4(budget_s=10.0):
+    """Config 4 on the host cores: the compiled reference (8 Lopass objects per channel, g++ -O2) when present."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_checkers import Ref, ref_available
+    import madronalib_amd as ml
+    if not ref_available():
+        return {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "compiled reference not available"}
+    ref = Ref()
+    cores = os.cpu_count() or 1
+    Vs = 1024 * max(1, min(cores, 128))
+    co = np.stack([ml.Lopass.makeCoeffs(float(np.float32(0.02) * np.float32(i + 1)), 0.7) for i in range(8)])
+    ref.bench_lopass_cascade8(Vs, 4, co, cores)
+    t_cal, _ = ref.bench_lopass_cascade8(Vs, 16, co, cores)
+    T = int(max(16, min(8192, 16 * budget_s / max(t_cal, 1e-6) / 3)))
+    best = min(ref.bench_lopass_cascade8(Vs, T, co, cores)[0] for _ in range(3))
+    return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
+            "sample": f"{Vs} channels x {T} DSPVectors, 8 cascaded Lopass per channel, {cores} threads, best of 3 (compiled reference headers, g++ -O2 SSE2)"}
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed PMC summary, if there is one."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -334,9 +353,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name),
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg3":
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("cfg3", "cfg4"):
             try:
-                out["cpu_baseline"] = cpu_baseline_cfg3()
+                out["cpu_baseline"] = cpu_baseline_cfg3() if args.workload == "cfg3" else cpu_baseline_cfg4()
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {ex}"}

@@ -77,3 +77,25 @@ def test_two_rank_sharding_equals_unsharded(oracle):
     assert (np.concatenate([ret[r][3] for r in range(world)], 1) == st).all()
     assert ret[0][1] == ret[1][0] == 389
     assert ret[0][4] == ret[1][4] == pytest.approx(0.002)   # MAX over ranks
+
+
+def test_cfg5_parameters_do_not_depend_on_the_sharding():
+    """BASELINE configs[4] (2 097 152 voices over 8 GPUs): every per-voice parameter, coefficient, seed and gate sample is a
+    function of the GLOBAL voice index, so the union of the ranks' shards is the unsharded patch."""
+    import madronalib_amd as ml
+    from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
+    total, world = 4099, 8   # ragged
+    full_p, full_c, full_s = cfg5_voice_params(0, total, total, ml)
+    full_g = cfg5_gate_quad(0, total, 2)
+    for rank in range(world):
+        lo, hi = partition(total, world, rank)
+        p, c, s = cfg5_voice_params(lo, hi, total, ml)
+        for k in full_p:
+            if np.ndim(full_p[k]):
+                assert (p[k] == full_p[k][lo:hi]).all(), k
+            else:
+                assert p[k] == full_p[k]
+        for k in full_c:
+            assert (c[k].view(np.uint32) == full_c[k][:, lo:hi].view(np.uint32)).all(), k
+        assert (s == full_s[lo:hi]).all()
+        assert (cfg5_gate_quad(lo, hi, 2) == full_g[:, lo:hi, :]).all()
