@@ -594,6 +594,12 @@ int mlgpu_process_buffer_process(mlgpu_process_buffer* p, const float* const* in
 int mlgpu_mixdown(mlgpu_engine* e, const float* d_signal, int layout, size_t n_voices, size_t n_vectors, const float* d_gains,
                   float* d_out);
 
+/* Sum every `group_size` consecutive voices into one: out voice g = ((0 + v[g*P]) + v[g*P+1]) + ... in voice order — the
+ * `outputs[c] += ...` accumulation of Synth::processVector (source/app/MLSynth.h:43-57), bit for bit. The result is a signal
+ * of n_groups voices (e.g. one per instrument of an mlgpu_events bank). */
+int mlgpu_mixdown_groups(mlgpu_engine* e, const float* d_signal, int layout, size_t n_groups, size_t group_size, size_t n_vectors,
+                         float* d_out, int out_layout);
+
 /* ------------------------------------------------------------------------- */
 /* coefficient makers — host-side, glibc libm, formulas of the reference     */
 /* (kept on the host so device code never has to match libm: SURVEY App. A 11) */

@@ -1121,6 +1121,56 @@ class Bank
 };
 
 // ---- the process-function boundary (source/app/MLAudioContext.h:60-110, MLSignalProcessBuffer.h:18) -----------------
+
+// rows per voice output signal, source/app/MLEventsToSignals.h:15-26
+enum VoiceOutputSignals
+{
+  kPitch = 0,
+  kGate,
+  kVoice,
+  kZ,
+  kX,
+  kY,
+  kMod,
+  kElapsedTime,
+  kNumVoiceOutputRows
+};
+
+enum EventType  // source/app/MLEvent.h:13-26
+{
+  kNull = 0,
+  kNoteOn,
+  kNoteRetrig,
+  kNoteSustain,
+  kNoteOff,
+  kSustainPedal,
+  kController,
+  kPitchBend,
+  kNotePressure,
+  kChannelPressure,
+  kProgramChange,
+  kNumEventTypes
+};
+struct Event  // MLEvent.h:31-53; same layout as mlgpu_event
+{
+  uint8_t type{kNull};
+  uint8_t channel{0};
+  uint16_t sourceIdx{0};
+  int time{0};
+  float value1{0};
+  float value2{0};
+  explicit operator bool() const { return type != kNull; }
+};
+
+class EventsToSignals
+{
+ public:
+  struct Voice  // what a process function reads of EventsToSignals::Voice (MLEventsToSignals.h:102-168): its output rows
+  {
+    DSPVectorArray<kNumVoiceOutputRows> outputs;
+  };
+};
+
 class AudioContext
 {
  public:
@@ -1128,13 +1178,59 @@ class AudioContext
   AudioContext(size_t nInputs, size_t nOutputs, int rate) : inputs(nInputs), outputs(nOutputs), sampleRate_(rate) {}
   void setSampleRate(int r) { sampleRate_ = r; }
   double getSampleRate() { return sampleRate_; }
+  void setInputPolyphony(int voices) { polyphony_ = voices; }
+  size_t getInputPolyphony() { return (size_t)polyphony_; }
+  // In a capture there is ONE generic voice: whatever index is asked for, the rows are those of "this lane's voice"
+  // (graph inputs fed by mlgpu_events). Per-voice constants belong in the kVoice row, not in the index.
+  const EventsToSignals::Voice& getInputVoice(int)
+  {
+    usesVoice_ = true;
+    return voice_;
+  }
   DSPVectorDynamic inputs;
   DSPVectorDynamic outputs;
 
+  // used by the capture (gpu::VoiceProgram / gpu::SynthProgram)
+  EventsToSignals::Voice voice_;
+  bool usesVoice_{false};
+
  private:
   double sampleRate_{0};
+  int polyphony_{0};
 };
 using SignalProcessFn = void (*)(AudioContext*, void*);
+
+// SignalProcessor / Synth (source/app/MLSignalProcessor.h:121, MLSynth.h:26-94): the parts a DSP subclass overrides.
+// Parameters, published signals and the plug-in adapters of the reference are host-side plumbing and not part of the shim.
+class SignalProcessor
+{
+ public:
+  virtual ~SignalProcessor() = default;
+  virtual void processVector(const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs, void* stateData = nullptr) {}
+  virtual void setSampleRate(double sr) { sampleRate_ = sr; }
+  double getSampleRate() const { return sampleRate_; }
+
+ protected:
+  double sampleRate_{48000.0};
+};
+
+class Synth : public SignalProcessor
+{
+ public:
+  static constexpr int kDefaultNumVoices = 8;
+  Synth(int numVoices = kDefaultNumVoices) : numVoices_(numVoices) {}
+  virtual ~Synth() = default;
+  // per-voice DSP: mix into outputs with += (MLSynth.h:62-72). Captured ONCE for a generic voice (voiceIndex 0 selects the
+  // per-voice objects a subclass keeps in arrays) and run for every voice of every instrument; the voice sum of
+  // Synth::processVector (MLSynth.h:43-57) is mlgpu_mixdown_groups, in the same order.
+  virtual void processVoice(int voiceIndex, const EventsToSignals::Voice& voice, const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs,
+                            AudioContext* audioContext) = 0;
+  virtual bool isVoiceActive(int, const EventsToSignals::Voice&) { return true; }
+  int getNumVoices() const { return numVoices_; }
+
+ protected:
+  int numVoices_;
+};
 
 namespace gpu
 {
@@ -1165,11 +1261,18 @@ class VoiceProgram
   mlgpu_graph* g_{nullptr};
   size_t voices_;
   size_t nIn_{0}, nOut_{0};
+  bool usesVoice_{false};
 
  public:
-  VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state) : eng_(e), voices_(voices)
+  VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state)
+      : VoiceProgram(e, voices, ctx, [fn, state](AudioContext* c) { fn(c, state); })
+  {
+  }
+  // general form: `body` is run twice in capture mode; it reads ctx->inputs / ctx->getInputVoice() and writes ctx->outputs
+  VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, std::function<void(AudioContext*)> body) : eng_(e), voices_(voices)
   {
     static uint32_t epochCounter = 0;
+    ctx->usesVoice_ = false;
     nIn_ = ctx->inputs.size();
     nOut_ = ctx->outputs.size();
     Capture cap;
@@ -1197,9 +1300,15 @@ class VoiceProgram
       cap.deferred.clear();
       for (size_t c = 0; c < nIn_; ++c)
         ctx->inputs[(int)c] = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g_, ("in" + std::to_string(c)).c_str())), 0.f));
+      // the 8 rows of this lane's voice (EventsToSignals) are further streamed inputs, after the audio inputs; the first pass
+      // finds out whether the code reads them at all
+      if (pass == 0 || ctx->usesVoice_)
+        for (int r = 0; r < kNumVoiceOutputRows; ++r)
+          ctx->voice_.outputs.row(r) = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g_, ("voice" + std::to_string(r)).c_str())), 0.f));
       for (size_t c = 0; c < nOut_; ++c) ctx->outputs[(int)c] = DSPVector(0.f);
-      fn(ctx, state);
+      body(ctx);
     }
+    usesVoice_ = ctx->usesVoice_;
     for (auto& kv : cap.feedbackOfOrd)
     {
       if (kv.first >= (int)cap.nodeOfOrd.size()) throw std::logic_error("mldsp GPU shim: the process function took different paths in its two capture passes");
@@ -1241,15 +1350,92 @@ class VoiceProgram
   }
 
   // one call = T DSPVectors of every voice (the reference calls the process function T times)
-  void process(const std::vector<const DeviceSignal*>& ins, const std::vector<DeviceSignal*>& outs)
+  // voiceRows: the 8 signals of mlgpu_events_process for the same voices (needed when the captured code called
+  // getInputVoice(); nullptr otherwise)
+  void process(const std::vector<const DeviceSignal*>& ins, const std::vector<DeviceSignal*>& outs, const float* const* voiceRows = nullptr)
   {
     if (ins.size() != nIn_ || outs.size() != nOut_ || outs.empty()) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: wrong number of signals");
+    if (usesVoice_ && !voiceRows) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: this program reads the voice control rows; pass them");
     std::vector<const float*> pi;
     std::vector<float*> po;
     for (auto* s : ins) pi.push_back(s->data());
+    // rows the code does not read still need a valid pointer: any output buffer of this launch will do
+    if (usesVoice_)
+      for (int r = 0; r < kNumVoiceOutputRows; ++r) pi.push_back(voiceRows[r] ? voiceRows[r] : outs[0]->data());
     for (auto* s : outs) po.push_back(s->data());
     const int inLayout = ins.empty() ? MLGPU_LAYOUT_QUAD : ins[0]->layout();
     eng_.check(mlgpu_graph_process(g_, outs[0]->vectors(), pi.data(), inLayout, po.data(), outs[0]->layout()));
+  }
+};
+
+// A whole polyphonic instrument bank on the GPU: events in, mixed audio out.
+//   mlgpu_events (EventsToSignals for nInstruments x polyphony voices)  ->  the Synth subclass's processVoice, captured once
+//   and fused into one kernel  ->  mlgpu_mixdown_groups (the per-instrument voice sum of Synth::processVector).
+class SynthProgram
+{
+  const Engine& eng_;
+  size_t nInstruments_;
+  int polyphony_;
+  size_t nOut_;
+  AudioContext ctx_;
+  mlgpu_events* ev_{nullptr};
+  VoiceProgram prog_;
+  size_t capacityT_{0};
+  std::vector<DeviceSignal> rows_, voiceOut_;
+
+ public:
+  SynthProgram(const Engine& e, Synth& synth, size_t nInstruments, size_t nOutputs, int sampleRate)
+      : eng_(e),
+        nInstruments_(nInstruments),
+        polyphony_(synth.getNumVoices()),
+        nOut_(nOutputs),
+        ctx_(0, nOutputs, sampleRate),
+        prog_(e, nInstruments * (size_t)synth.getNumVoices(), &ctx_,
+              [&synth](AudioContext* c) { synth.processVoice(0, c->getInputVoice(0), c->inputs, c->outputs, c); })
+  {
+    eng_.check(mlgpu_events_create(e.handle(), nInstruments, polyphony_, &ev_));
+    eng_.check(mlgpu_events_set_sample_rate(ev_, (double)sampleRate));
+  }
+  SynthProgram(const SynthProgram&) = delete;
+  SynthProgram& operator=(const SynthProgram&) = delete;
+  ~SynthProgram()
+  {
+    if (ev_) mlgpu_events_destroy(ev_);
+  }
+  mlgpu_events* events() const { return ev_; }  // protocol, glide, drift, bend range: the mlgpu_events_set_* calls
+  VoiceProgram& program() { return prog_; }
+  size_t voices() const { return nInstruments_ * (size_t)polyphony_; }
+
+  void addInputEvent(size_t instrument, const Event& e)  // AudioContext::addInputEvent
+  {
+    mlgpu_event m{e.type, e.channel, e.sourceIdx, e.time, e.value1, e.value2};
+    eng_.check(mlgpu_events_add_event(ev_, instrument, &m));
+  }
+  void clearInputEvents() { eng_.check(mlgpu_events_clear_events(ev_)); }
+
+  // nVectors DSPVectors starting at frame startOffset of the current host block. mixed[c]: a signal of nInstruments
+  // "voices" x nVectors vectors per output channel (the instruments' outputs).
+  void process(size_t nVectors, int startOffset, const std::vector<DeviceSignal*>& mixed)
+  {
+    if (mixed.size() != nOut_) throw Error(MLGPU_ERR_INVALID, "SynthProgram::process: one mixed signal per output channel");
+    if (nVectors > capacityT_)
+    {
+      rows_.clear();
+      voiceOut_.clear();
+      for (int r = 0; r < kNumVoiceOutputRows; ++r) rows_.emplace_back(eng_, voices(), nVectors);
+      for (size_t c = 0; c < nOut_; ++c) voiceOut_.emplace_back(eng_, voices(), nVectors);
+      capacityT_ = nVectors;
+    }
+    float* rowPtrs[kNumVoiceOutputRows];
+    for (int r = 0; r < kNumVoiceOutputRows; ++r) rowPtrs[r] = rows_[r].data();
+    eng_.check(mlgpu_events_process(ev_, nVectors, startOffset, rowPtrs, MLGPU_LAYOUT_QUAD));
+    std::vector<float*> po;
+    for (auto& s : voiceOut_) po.push_back(s.data());
+    std::vector<const float*> pi(rowPtrs, rowPtrs + kNumVoiceOutputRows);
+    eng_.check(mlgpu_graph_process(prog_.graph(), nVectors, pi.data(), MLGPU_LAYOUT_QUAD, po.data(), MLGPU_LAYOUT_QUAD));
+    for (size_t c = 0; c < nOut_; ++c)
+      eng_.check(mlgpu_mixdown_groups(eng_.handle(), voiceOut_[c].data(), MLGPU_LAYOUT_QUAD, nInstruments_, (size_t)polyphony_, nVectors,
+                                      mixed[c]->data(), mixed[c]->layout()));
   }
 };
 }  // namespace gpu

@@ -140,6 +140,7 @@ def _declare(L):
     sig("mlgpu_graph_set_input_layout", i, [vp, i, i])
     sig("mlgpu_graph_set_voices_per_lane", i, [vp, i])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
+    sig("mlgpu_mixdown_groups", i, [vp, vp, i, sz, sz, sz, vp, i])
     sig("mlgpu_events_create", i, [vp, sz, i, pp])
     sig("mlgpu_events_destroy", i, [vp])
     sig("mlgpu_events_clear", i, [vp])

@@ -394,6 +394,18 @@ extern "C"
     return MLGPU_OK;
   }
 
+  int mlgpu_mixdown_groups(mlgpu_engine* e, const float* sig, int layout, size_t groups, size_t groupSize, size_t T, float* out, int outLayout)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (groups == 0 || groupSize == 0 || T == 0) return MLGPU_OK;
+    if (!sig || !out || ((uintptr_t)sig & 15) || ((uintptr_t)out & 15)) return fail(e, MLGPU_ERR_INVALID, "mixdown_groups: null / misaligned signal");
+    if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR || outLayout < 0 || outLayout > MLGPU_LAYOUT_VOICE_MAJOR)
+      return fail(e, MLGPU_ERR_INVALID, "mixdown_groups: bad layout");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, mlgpu_launch_mixdown_groups(sig, layout, groups, groupSize, T, out, outLayout, e->stream));
+    return MLGPU_OK;
+  }
+
   // ---- banks --------------------------------------------------------------------------------
 
   int mlgpu_bank_destroy(mlgpu_bank* b)

@@ -210,7 +210,7 @@ struct mlgpu_graph
   size_t memFloatsPerVoice{0};
   int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
   int compiledVoicesPerLane{1};
-  int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 };
 
 namespace

@@ -80,6 +80,7 @@ hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRo
 hipError_t mlgpu_launch_rows_index(float* out, size_t rowsPerGroup, size_t groups, hipStream_t stream);
 hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
                                 hipStream_t stream);
+hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream);
 hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,
                               size_t nElems, hipStream_t stream);
 

@@ -553,6 +553,43 @@ __global__ __launch_bounds__(256) void mixdown_stage2_kernel(const float4* parti
 }
 }  // namespace
 
+// grouped mixdown: out[g] = ((0 + v[g*P]) + v[g*P + 1]) + ... — the voices of one instrument summed in voice order, exactly
+// the `outputs[c] += ...` accumulation of Synth::processVector (source/app/MLSynth.h:43-57). One lane per (group, quad).
+namespace
+{
+__global__ __launch_bounds__(256) void mixdown_groups_kernel(SignalView sig, SignalView out, size_t groups, size_t P, size_t T)
+{
+  const size_t total = groups * T * 16;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+  {
+    // enumerate with the group fastest so QUAD-layout accesses coalesce
+    const size_t g = i % groups, qi = i / groups;
+    const size_t t = qi >> 4, q = qi & 15;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t p = 0; p < P; ++p)
+    {
+      const float4 x = sig.base[t * sig.strideT + q * sig.strideQ + (g * P + p) * sig.strideV];
+      acc.x = acc.x + x.x;
+      acc.y = acc.y + x.y;
+      acc.z = acc.z + x.z;
+      acc.w = acc.w + x.w;
+    }
+    out.base[t * out.strideT + q * out.strideQ + g * out.strideV] = acc;
+  }
+}
+}  // namespace
+
+hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream)
+{
+  size_t blocks = (groups * T * 16 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(mixdown_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, makeView(sig, layout, groups * P, T),
+                     makeView(out, outLayout, groups, T), groups, P, T);
+  return hipGetLastError();
+}
+
 hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
                                 hipStream_t stream)
 {

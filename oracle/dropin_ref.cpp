@@ -50,6 +50,51 @@ extern "C" int plate_ref_run(size_t V, size_t T, const float* inL, const float* 
   return 0;
 }
 
+// ---- a Synth subclass run by the reference's own Synth::processVector, AudioContext and EventsToSignals ----
+#include "MLSynth.h"
+#include "../tests/cpp/dropin_synth.h"
+struct SynthRefEvent
+{
+  uint8_t type, channel;
+  uint16_t sourceIdx;
+  int32_t time;
+  float value1, value2;
+};
+// one instrument; events with absolute onset times; host blocks of blockFrames; out: [2][nBlocks * blockFrames]
+extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR)
+{
+  SmallSynth synth;
+  AudioContext ctx(0, 2, 48000);
+  ctx.setInputPolyphony(kSynthVoices);
+  ctx.setInputGlideTimeInSeconds(glideSeconds);
+  ctx.setInputDriftAmount(drift);
+  for (int b = 0; b < nBlocks; ++b)
+  {
+    const int start = b * blockFrames;
+    for (int i = 0; i < nEvents; ++i)
+      if (events[i].time >= start && events[i].time < start + blockFrames)
+      {
+        Event ev;
+        ev.type = events[i].type;
+        ev.channel = events[i].channel;
+        ev.sourceIdx = events[i].sourceIdx;
+        ev.time = events[i].time - start;
+        ev.value1 = events[i].value1;
+        ev.value2 = events[i].value2;
+        ctx.addInputEvent(ev);
+      }
+    for (int off = 0; off < blockFrames; off += kFloatsPerDSPVector)
+    {
+      ctx.processVector(off);
+      synth.processVector(ctx.inputs, ctx.outputs, &ctx);
+      store(ctx.outputs[0], outL + start + off);
+      store(ctx.outputs[1], outR + start + off);
+    }
+    ctx.clearInputEvents();
+  }
+  return 0;
+}
+
 // ---- the reference's SignalProcessBuffer driven with a sequence of host block sizes -----------------------------
 // process function: out0 = Lopass(in0) (stateful), out1 = in0 * 0.5. blocks[i] frames per call; in / out0 / out1
 // hold the concatenated blocks. Pins the behaviour of mlgpu_process_buffer (latency, zero-fill, ring sizes).

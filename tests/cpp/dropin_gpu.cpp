@@ -1,6 +1,7 @@
 // The same user code (dropin_patch.h) compiled against the MI355X shim: captured once, run for V voices.
 #include <cstddef>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "madronalib.h"  // include/mlgpu/compat/madronalib.h
@@ -70,6 +71,74 @@ extern "C" int plate_gpu_run(size_t V, size_t T, int launches, const float* inL,
     eng.check(mlgpu_layout_convert(eng.handle(), oR.data(), MLGPU_LAYOUT_QUAD, vmR.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, T));
     eng.check(mlgpu_download(eng.handle(), outL, vmL.data(), vmL.bytes()));
     eng.check(mlgpu_download(eng.handle(), outR, vmR.data(), vmR.bytes()));
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
+#include <array>
+#include "dropin_synth.h"
+struct SynthGpuEvent
+{
+  uint8_t type, channel;
+  uint16_t sourceIdx;
+  int32_t time;
+  float value1, value2;
+};
+// nInstruments instruments; events[i] belongs to instrument eventInstrument[i]; out: [nInstruments][nBlocks * blockFrames] per channel
+extern "C" int synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
+                             int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, char* err, size_t errLen)
+{
+  try
+  {
+    gpu::Engine eng(0);
+    SmallSynth synth;
+    gpu::SynthProgram prog(eng, synth, nInstruments, 2, 48000);
+    eng.check(mlgpu_events_set_pitch_glide_seconds(prog.events(), glideSeconds));
+    eng.check(mlgpu_events_set_drift_amount(prog.events(), drift));
+    const size_t S = (size_t)nBlocks * blockFrames;
+    for (int b = 0; b < nBlocks; ++b)
+    {
+      const int start = b * blockFrames;
+      for (int i = 0; i < nEvents; ++i)
+        if (events[i].time >= start && events[i].time < start + blockFrames)
+        {
+          Event ev;
+          ev.type = events[i].type;
+          ev.channel = events[i].channel;
+          ev.sourceIdx = events[i].sourceIdx;
+          ev.time = events[i].time - start;
+          ev.value1 = events[i].value1;
+          ev.value2 = events[i].value2;
+          prog.addInputEvent((size_t)eventInstrument[i], ev);
+        }
+      const int vecs = blockFrames / 64;
+      for (int done = 0; done < vecs;)
+      {
+        const int n = (vecs - done < vectorsPerLaunch) ? vecs - done : vectorsPerLaunch;
+        gpu::DeviceSignal mixL(eng, nInstruments, n, MLGPU_LAYOUT_VOICE_MAJOR), mixR(eng, nInstruments, n, MLGPU_LAYOUT_VOICE_MAJOR);
+        prog.process((size_t)n, done * 64, {&mixL, &mixR});
+        std::vector<float> hL(mixL.size()), hR(mixR.size());
+        eng.check(mlgpu_download(eng.handle(), hL.data(), mixL.data(), mixL.bytes()));
+        eng.check(mlgpu_download(eng.handle(), hR.data(), mixR.data(), mixR.bytes()));
+        for (size_t i = 0; i < nInstruments; ++i)
+        {
+          memcpy(outL + i * S + start + (size_t)done * 64, hL.data() + i * (size_t)n * 64, sizeof(float) * (size_t)n * 64);
+          memcpy(outR + i * S + start + (size_t)done * 64, hR.data() + i * (size_t)n * 64, sizeof(float) * (size_t)n * 64);
+        }
+        done += n;
+      }
+      prog.clearInputEvents();
+    }
     return 0;
   }
   catch (const gpu::Error& e)

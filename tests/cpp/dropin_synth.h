@@ -1,0 +1,47 @@
+// USER CODE #3 written against madronalib's public API only: a polyphonic synth as a Synth subclass (source/app/MLSynth.h) —
+// per-voice DSP in processVoice(), driven by the 8 voice control rows of EventsToSignals (pitch, gate, ..., mod).
+// Compiled unchanged against the reference (oracle/dropin_ref.cpp: its own Synth, AudioContext, EventsToSignals) and against
+// include/mlgpu/compat (dropin_gpu.cpp: captured once, every voice of every instrument in one launch).
+constexpr int kSynthVoices = 6;
+
+class SmallSynth : public Synth
+{
+  struct VoiceDSP
+  {
+    SawGen saw;
+    PulseGen pulse;
+    Lopass lp;
+    ADSR env;
+    OnePole smooth;
+  };
+  std::array<VoiceDSP, kSynthVoices> dsp_;
+
+ public:
+  SmallSynth() : Synth(kSynthVoices)
+  {
+    for (auto& d : dsp_)
+    {
+      d.env.coeffs = ADSR::calcCoeffs(0.004f, 0.08f, 0.5f, 0.15f, 48000.f);
+      d.smooth.coeffs = OnePole::makeCoeffs(0.05f);
+      d.saw.clear();
+    }
+  }
+
+  void processVoice(int v, const EventsToSignals::Voice& voice, const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs,
+                    AudioContext* ctx) override
+  {
+    VoiceDSP& d = dsp_[v];
+    const DSPVector pitch = voice.outputs.constRow(kPitch);   // octaves re middle C (the example's event pitches)
+    const DSPVector gate = voice.outputs.constRow(kGate);
+    const DSPVector mod = voice.outputs.constRow(kMod);
+    const DSPVector vox = voice.outputs.constRow(kVoice);
+    const DSPVector freq = exp2Approx(pitch) * (261.6256f / 48000.f);
+    const DSPVector osc = d.saw(freq) + d.pulse(freq * 0.5f, 0.3f + mod * 0.4f) * 0.6f;
+    // brightness follows key pressure (z) and the mod wheel; per-voice stereo position from the voice index row
+    const DSPVector cutoff = clamp(freq * (2.f + 6.f * d.smooth(voice.outputs.constRow(kZ) + mod)), DSPVector(0.001f), DSPVector(0.45f));
+    const DSPVector y = d.lp(osc, cutoff, DSPVector(0.5f)) * d.env(gate);
+    const DSPVector pan = vox * (1.f / kSynthVoices);
+    outputs[0] += y * (1.f - pan);
+    outputs[1] += y * pan;
+  }
+};

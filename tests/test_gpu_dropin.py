@@ -106,3 +106,40 @@ def test_reverb_with_feedback_state_same_source_same_bits(launches):
     assert_bits_equal(gotL, wantL, True, "plate reverb left")
     assert_bits_equal(gotR, wantR, True, "plate reverb right")
     assert np.abs(wantL[:, 64 * 40:]).max() > 1e-4   # the tail is still sounding 20 vectors after the input stopped
+
+
+class _Ev(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_uint8), ("channel", ctypes.c_uint8), ("sourceIdx", ctypes.c_uint16), ("time", ctypes.c_int32),
+                ("value1", ctypes.c_float), ("value2", ctypes.c_float)]
+
+
+@pytest.mark.gpu
+def test_synth_subclass_events_to_audio_same_source_same_bits():
+    """tests/cpp/dropin_synth.h: a Synth subclass (processVoice reading the EventsToSignals voice rows). Reference side: its own
+    Synth::processVector + AudioContext + EventsToSignals, one instrument at a time. GPU side: mlgpu_events -> the captured
+    processVoice for all voices of 40 instruments -> mlgpu_mixdown_groups. MIDI events in, stereo audio out, bit for bit."""
+    from test_gpu_events import performance
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    Lr.synth_ref_run.restype = ctypes.c_int
+    Lr.synth_ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p]
+    Lg.synth_gpu_run.restype = ctypes.c_int
+    Lg.synth_gpu_run.argtypes = [ctypes.c_size_t, ctypes.POINTER(_Ev), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    N, block, n_blocks = 40, 512, 10
+    S = block * n_blocks
+    glide, drift = 0.012, 0.6
+    per_inst = [performance("midi", 900 + k, S, 6) for k in range(N)]
+    wantL, wantR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
+    for k, evs in enumerate(per_inst):
+        arr = (_Ev * max(1, len(evs)))(*[_Ev(*e) for e in evs])
+        assert Lr.synth_ref_run(arr, len(evs), glide, drift, block, n_blocks, wantL[k].ctypes.data_as(c_f32p), wantR[k].ctypes.data_as(c_f32p)) == 0
+    flat = [(e, k) for k, evs in enumerate(per_inst) for e in evs]
+    arr = (_Ev * len(flat))(*[_Ev(*e) for e, _ in flat])
+    inst = (ctypes.c_int * len(flat))(*[k for _, k in flat])
+    gotL, gotR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
+    err = ctypes.create_string_buffer(4096)
+    st = Lg.synth_gpu_run(N, arr, inst, len(flat), glide, drift, block, n_blocks, 3, gotL.ctypes.data_as(c_f32p), gotR.ctypes.data_as(c_f32p), err, 4096)
+    assert st == 0, err.value.decode()
+    assert_bits_equal(gotL, wantL, True, "synth left")
+    assert_bits_equal(gotR, wantR, True, "synth right")
+    assert np.abs(wantL).max() > 0.05
