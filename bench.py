@@ -182,7 +182,7 @@ def setup_workload(eng, name, V, T, lo, total):
         for j in range(4):
             sub, src = patches.allpass(f"ap{j}_", src, Proc.PITCHBENDABLE_DELAY, 4096.0 - 64.0, "dl")
             desc += sub
-        g = ml.Graph(eng, V, desc, [src])
+        g = ml.Graph(eng, V, desc, [src], delay_windows=bool(os.environ.get("MLGPU_DELAY_WINDOWS")))
         for j in range(4):
             g.set_param(f"ap{j}_gain", 0.6)
         if os.environ.get("MLGPU_UNIFORM_DELAY"):

@@ -413,6 +413,12 @@ int mlgpu_graph_add_const(mlgpu_graph* g, float value);
 /* Delay-line memory of a delay node (before compile): IntegerDelay::setMaxDelayInSamples (MLDSPFilters.h:823-831),
  * i.e. rings of 2^bitsToContain(floor(d) + 64) floats per voice (PitchbendableDelay: two of them). */
 int mlgpu_graph_set_max_delay(mlgpu_graph* g, int proc_node, float max_delay_in_samples);
+/* Layout of the delay rings (before compile). 0 (default): [sample][voice] — one coalesced row per time step, best when
+ * neighbouring voices use the same delay times. 1: [256-voice block][sample / 8][voice][8] — a voice moves its samples in
+ * 32-byte sectors through LDS windows, so no bandwidth is wasted when delay times differ from voice to voice (DESIGN.md
+ * §3.6); costs 8 KiB of LDS per ring per workgroup, at most 20 rings per graph. Same results for delay times within
+ * the node's maximum (graph_set_max_delay). */
+int mlgpu_graph_set_delay_layout(mlgpu_graph* g, int windowed);
 /* One-vector feedback: a DSPVector the reference keeps from one process call to the next (Allpass::vy1
  * MLDSPFilters.h:1115, FDN::mDelayInputVectors :1168, FeedbackDelayFunction::vy1 MLDSPFunctional.h:276, or a user's
  * own state member). add_feedback returns a node whose value at sample n is what set_feedback's `value_node` had at
@@ -443,6 +449,10 @@ int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n);
 int mlgpu_graph_compile(mlgpu_graph* g);
 /* The generated HIP source (valid after compile; for inspection). */
 const char* mlgpu_graph_source(mlgpu_graph* g);
+/* Offline code generation: place the rings, generate the kernel source (mlgpu_graph_source) and compile it to a gfx950 code
+ * object with hiprtc, without touching a device. `e` of mlgpu_graph_create may be NULL for a graph used this way
+ * (mlgpu_graph_compile then fails with MLGPU_ERR_INVALID). *code stays valid until the graph is destroyed. */
+int mlgpu_graph_emit(mlgpu_graph* g, const void** code, size_t* code_size);
 int mlgpu_graph_clear(mlgpu_graph* g); /* T::clear() on every processor node */
 int mlgpu_graph_clear_proc(mlgpu_graph* g, int proc_node); /* T::clear() on one processor node */
 int mlgpu_graph_set_state_uniform(mlgpu_graph* g, int proc_node, int state_idx, uint32_t value);

@@ -594,6 +594,20 @@ class Bank:
         return res.download(np.float32, V * T * 64).reshape(V, 64 * T)
 
 
+class OfflineEngine:
+    """Stands in for an Engine where no device is needed: Graph(OfflineEngine(), V, ...).emit() generates a graph's kernel
+    source and gfx950 code object with hiprtc (mlgpu_graph_emit). Such a graph cannot be compiled or run."""
+
+    def __init__(self):
+        self.L = _lib.load()
+        self.h = None
+        self._children = set()
+
+    def _check(self, st):
+        if st != 0:
+            raise MlgpuError(st, "offline graph (no engine): status %d" % st)
+
+
 class Graph:
     """A run-time defined per-voice DAG of processors and ops, fused into one kernel (mlgpu_graph).
 
@@ -602,7 +616,7 @@ class Graph:
       {"name", "type": "input"|"param"|"const"|"proc"|"op", "kind": Proc.X / Op.X, "inputs": [names], "value"}
     """
 
-    def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0):
+    def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0, delay_windows=False):
         self.engine = engine
         self.L = engine.L
         self.V = int(n_voices)
@@ -614,6 +628,8 @@ class Graph:
         engine._children.add(self)
         if voices_per_lane:
             engine._check(self.L.mlgpu_graph_set_voices_per_lane(self.h, int(voices_per_lane)))
+        if delay_windows:
+            engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 1))
         if description is not None:
             for n in description:
                 self.add(**n)
@@ -622,12 +638,19 @@ class Graph:
                     self.set_feedback(n["name"], n["source"])
             for o in (outputs or [description[-1]["name"]]):
                 self.add_output(o)
-            self.compile()
+            if engine.h is not None:
+                self.compile()
 
     def close(self):
-        if getattr(self, "h", None) and self.engine.h:
+        if getattr(self, "h", None) and (self.engine.h or isinstance(self.engine, OfflineEngine)):
             self.L.mlgpu_graph_destroy(self.h)
         self.h = None
+
+    def emit(self):
+        """(kernel source, gfx950 code object bytes) without a device (mlgpu_graph_emit)."""
+        code, size = ctypes.c_void_p(), ctypes.c_size_t()
+        self.engine._check(self.L.mlgpu_graph_emit(self.h, ctypes.byref(code), ctypes.byref(size)))
+        return self.source, ctypes.string_at(code, size.value)
 
     def __del__(self):
         try:
@@ -640,7 +663,7 @@ class Graph:
 
     def _ret(self, r, name):
         if r < 0:
-            raise MlgpuError(-r, self.L.mlgpu_last_error(self.engine.h).decode())
+            raise MlgpuError(-r, self.L.mlgpu_last_error(self.engine.h).decode() if self.engine.h else "offline graph: status %d" % -r)
         if name:
             self.ids[name] = r
         return r

@@ -135,10 +135,12 @@ def _declare(L):
     sig("mlgpu_graph_num_nodes", i, [vp])
     sig("mlgpu_graph_compile", i, [vp])
     sig("mlgpu_graph_source", c.c_char_p, [vp])
+    sig("mlgpu_graph_emit", i, [vp, c.POINTER(vp), c.POINTER(c.c_size_t)])
     sig("mlgpu_graph_clear", i, [vp])
     sig("mlgpu_graph_clear_proc", i, [vp, i])
     sig("mlgpu_graph_set_input_layout", i, [vp, i, i])
     sig("mlgpu_graph_set_voices_per_lane", i, [vp, i])
+    sig("mlgpu_graph_set_delay_layout", i, [vp, i])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
     sig("mlgpu_mixdown_groups", i, [vp, vp, i, sz, sz, sz, vp, i])
     sig("mlgpu_events_create", i, [vp, sz, i, pp])

@@ -87,9 +87,10 @@ CompiledModule* compileAndLoad(int device, const std::string& source, std::strin
 }
 
 // compile only (no device needed): used by mlgpu_jit_selftest
-bool compileOnly(const std::string& source, std::string& log)
+bool compileToCode(const std::string& source, std::vector<char>& code, std::string& log)
 {
   hiprtcProgram prog;
+  code.clear();
   if (hiprtcCreateProgram(&prog, source.c_str(), "mlgpu_jit.hip", mlgpu_embedded_count, (const char**)mlgpu_embedded_sources,
                           (const char**)mlgpu_embedded_names) != HIPRTC_SUCCESS)
   {
@@ -107,9 +108,20 @@ bool compileOnly(const std::string& source, std::string& log)
   }
   size_t codeSize = 0;
   if (r == HIPRTC_SUCCESS) hiprtcGetCodeSize(prog, &codeSize);
+  if (codeSize)
+  {
+    code.resize(codeSize);
+    hiprtcGetCode(prog, code.data());
+  }
   hiprtcDestroyProgram(&prog);
   if (r != HIPRTC_SUCCESS && log.empty()) log = hiprtcGetErrorString(r);
   return r == HIPRTC_SUCCESS && codeSize > 0;
+}
+
+bool compileOnly(const std::string& source, std::string& log)
+{
+  std::vector<char> code;
+  return compileToCode(source, code, log);
 }
 
 hipFunction_t getFunction(CompiledModule* cm, const char* name, std::string& log)
@@ -169,6 +181,7 @@ struct Node
   int slot{0};            // input index / param index / control index; demultiplex: output index
   int nOut{0};            // demultiplex: number of outputs
   size_t ringLen{0};      // delay nodes: floats per ring (power of two), 0 = not set
+  int ringSlot{0};        // delay nodes: index of this node's first ring among all rings of the graph (LDS windows)
   size_t memOff{0};       // delay nodes: first ring at d_mem + memOff * V
   int fbSource{-1};       // feedback nodes: the node whose value is stored for the next vector
   int rate{RATE_AUDIO};
@@ -207,7 +220,11 @@ struct mlgpu_graph
   uint32_t* d_state{nullptr};
   float* d_params{nullptr};
   float* d_mem{nullptr};
+  std::vector<char> emitted;     // mlgpu_graph_emit: the gfx950 code object
   size_t memFloatsPerVoice{0};
+  bool windowedRings{false};     // rings as [block][chunk][lane][8] behind LDS windows (mlgpu_graph_set_delay_layout)
+  int totalRings{0};
+  size_t memVoices() const { return windowedRings ? ((V + 255) & ~(size_t)255) : V; }  // voices the ring memory is laid out for
   int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
   int compiledVoicesPerLane{1};
   int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
@@ -305,8 +322,9 @@ std::string generateGraphSource(mlgpu_graph* g)
   std::ostringstream s;
   auto sfx = [](int l) { return "_" + std::to_string(l); };
   s << "// generated by libmlgpu graph.hip (" << VL << " voice" << (VL > 1 ? "s" : "") << " per lane)\n"
-    << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\nusing namespace mldev;\n";
-  s << "extern \"C\" __global__ __launch_bounds__(256) void mlgpu_graph_kernel(const GraphArgs a)\n{\n";
+    << (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\nusing namespace mldev;\n";
+  // windowed rings: the latency of a sector refill is hidden by other waves only, so keep at least two per SIMD
+  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->windowedRings && g->totalRings) ? ", 2" : "") << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n";
   if (g->hasImpulse)
   {
     s << "  __shared__ float ldsTable[32];\n  if (threadIdx.x < 17) ldsTable[threadIdx.x] = a.impulseTable[threadIdx.x];\n  __syncthreads();\n";
@@ -316,6 +334,7 @@ std::string generateGraphSource(mlgpu_graph* g)
   {
     s << "  const KernelTables tables{nullptr};\n";
   }
+  if (g->windowedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 8 * 256 << "];  // write windows, [ring][8][256 lanes]\n";
   s << "  size_t blk = blockIdx.x;\n  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;\n"
        "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n"
        "  const size_t v_0 = blk * " << 256 * VL << " + threadIdx.x;\n  if (v_0 >= a.V) return;\n";
@@ -340,7 +359,11 @@ std::string generateGraphSource(mlgpu_graph* g)
       {
         s << "  Proc<" << n.kind << "> p" << i << L << ";\n  const VoiceMem m" << i << L << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v" << L
           << ", a.state + (size_t)" << n.sOff << " * a.V + v" << L << ", a.V";
-        if (n.ringLen) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v" << L << ", " << (n.ringLen - 1) << "u";
+        if (n.ringLen && !g->windowedRings) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v" << L << ", " << (n.ringLen - 1) << "u";
+        if (n.ringLen && g->windowedRings)
+          s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (v" << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
+            << " + (v" << L << " & 255) * 8, " << (n.ringLen - 1)
+            << "u, ldsRings + " << (size_t)n.ringSlot * 8 * 256 << " + threadIdx.x";
         s << "};\n  p" << i << L << ".load(m" << i << L << ", tables);\n";
       }
       else if (n.type == NODE_INPUT)
@@ -383,7 +406,7 @@ std::string generateGraphSource(mlgpu_graph* g)
     else if (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".begin_vector(n" << n.in[0] << sfx(l) << ");\n";
   }
-  s << "#pragma unroll 2\n    for (int q = 0; q < 16; ++q)\n    {\n";
+  s << "#pragma unroll " << ((g->windowedRings && g->totalRings) ? 1 : 2) << "\n    for (int q = 0; q < 16; ++q)\n    {\n";
   for (int i = 0; i < g->nInputs; ++i)
     for (int l = 0; l < VL; ++l)
       s << "      const f32x4 xin" << i << sfx(l) << " = __builtin_nontemporal_load(in" << i << sfx(l) << " + t * a.in[" << i << "].strideT + q * a.in["
@@ -541,6 +564,8 @@ extern "C"
       if (nn.type == NODE_PROC && mlgpu_proc_rings(nn.kind))
       {
         nn.memOff = g.memFloatsPerVoice;
+        nn.ringSlot = g.totalRings;
+        g.totalRings += mlgpu_proc_rings(nn.kind);
         g.memFloatsPerVoice += nn.ringLen * (size_t)mlgpu_proc_rings(nn.kind);
       }
     const int muxIn[4] = {gate, hs, ls, lp3};
@@ -555,6 +580,13 @@ extern "C"
     log.clear();
     ok = compileOnly(generateGraphSource(&g), log) && ok;
     all += log;
+    // (3) the same graph with per-voice rings behind LDS windows
+    g.windowedRings = true;
+    g.voicesPerLane = 1;
+    g.totalRings = 20;  // the largest LDS footprint graph_compile accepts (160 KiB)
+    log.clear();
+    ok = compileOnly(generateGraphSource(&g), log) && ok;
+    all += log;
     if (logOut && logLen)
     {
       snprintf(logOut, logLen, "%s", all.c_str());
@@ -564,11 +596,11 @@ extern "C"
 
   int mlgpu_graph_create(mlgpu_engine* e, size_t nVoices, mlgpu_graph** out)
   {
-    if (!e || !out) return MLGPU_ERR_INVALID;
+    if (!out) return MLGPU_ERR_INVALID;  // e == NULL: a graph for mlgpu_graph_emit only (no device)
     *out = nullptr;
     if (nVoices == 0)
     {
-      e->lastError = "graph_create: zero voices";
+      if (e) e->lastError = "graph_create: zero voices";
       return MLGPU_ERR_INVALID;
     }
     mlgpu_graph* g = new (std::nothrow) mlgpu_graph();
@@ -582,8 +614,11 @@ extern "C"
   int mlgpu_graph_destroy(mlgpu_graph* g)
   {
     if (!g) return MLGPU_ERR_INVALID;
-    hipSetDevice(g->e->device);
-    hipStreamSynchronize(g->e->stream);
+    if (g->e)
+    {
+      hipSetDevice(g->e->device);
+      hipStreamSynchronize(g->e->stream);
+    }
     if (g->d_coeffs) hipFree(g->d_coeffs);
     if (g->d_state) hipFree(g->d_state);
     if (g->d_params) hipFree(g->d_params);
@@ -783,23 +818,49 @@ extern "C"
   }
   int mlgpu_graph_num_nodes(mlgpu_graph* g) { return g ? (int)g->nodes.size() : -1; }
 
-  int mlgpu_graph_compile(mlgpu_graph* g)
+  // ring placement + code generation: everything graph_compile does that needs no device
+  static int layoutAndGenerate(mlgpu_graph* g)
   {
-    if (!g) return MLGPU_ERR_INVALID;
-    if (g->compiled) return MLGPU_OK;
+    if (!g->source.empty()) return MLGPU_OK;
     if (g->outputs.empty()) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: no outputs");
-    mlgpu_engine* e = g->e;
     size_t memFloats = 0;
+    g->totalRings = 0;
     for (Node& n : g->nodes)
     {
       if (n.type == NODE_FEEDBACK && n.fbSource < 0) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: feedback node '" + n.name + "' has no source (graph_set_feedback)");
       if (n.type != NODE_PROC || mlgpu_proc_rings(n.kind) == 0) continue;
       if (n.ringLen == 0) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: delay node '" + n.name + "' has no memory (graph_set_max_delay)");
       n.memOff = memFloats;
+      n.ringSlot = g->totalRings;
+      g->totalRings += mlgpu_proc_rings(n.kind);
       memFloats += n.ringLen * (size_t)mlgpu_proc_rings(n.kind);
     }
     g->memFloatsPerVoice = memFloats;
+    if (g->windowedRings && (size_t)g->totalRings * 8 * 256 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: windowed delay layout needs 8 KiB of LDS per ring; at most 20 rings per graph");
     g->source = generateGraphSource(g);
+    return MLGPU_OK;
+  }
+
+  int mlgpu_graph_emit(mlgpu_graph* g, const void** code, size_t* codeSize)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    const int st = layoutAndGenerate(g);
+    if (st != MLGPU_OK) return st;
+    if (g->emitted.empty() && !compileToCode(g->source, g->emitted, g->log)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_emit (hiprtc): " + g->log);
+    if (code) *code = g->emitted.data();
+    if (codeSize) *codeSize = g->emitted.size();
+    return MLGPU_OK;
+  }
+
+  int mlgpu_graph_compile(mlgpu_graph* g)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return MLGPU_OK;
+    mlgpu_engine* e = g->e;
+    if (!e) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: the graph was created without an engine (graph_emit only)");
+    const int st = layoutAndGenerate(g);
+    if (st != MLGPU_OK) return st;
     if (hipSetDevice(e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
     CompiledModule* cm = compileAndLoad(e->device, g->source, g->log);
     if (!cm) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
@@ -809,8 +870,9 @@ extern "C"
     hipError_t err = hipMalloc((void**)&g->d_coeffs, sizeof(float) * V * (size_t)(g->NC + 1));
     if (err == hipSuccess) err = hipMalloc((void**)&g->d_state, sizeof(uint32_t) * V * (size_t)(g->NS + 1));
     if (err == hipSuccess) err = hipMalloc((void**)&g->d_params, sizeof(float) * V * (size_t)(g->nParams + 1));
-    if (err == hipSuccess && g->memFloatsPerVoice) err = hipMalloc((void**)&g->d_mem, sizeof(float) * V * g->memFloatsPerVoice);
-    if (err == hipSuccess && g->memFloatsPerVoice) err = hipMemsetAsync(g->d_mem, 0, sizeof(float) * V * g->memFloatsPerVoice, e->stream);
+    const size_t memV = g->memVoices();
+    if (err == hipSuccess && g->memFloatsPerVoice) err = hipMalloc((void**)&g->d_mem, sizeof(float) * memV * g->memFloatsPerVoice);
+    if (err == hipSuccess && g->memFloatsPerVoice) err = hipMemsetAsync(g->d_mem, 0, sizeof(float) * memV * g->memFloatsPerVoice, e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(g->d_state, 0, sizeof(uint32_t) * V * (size_t)(g->NS + 1), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(g->d_coeffs, 0, sizeof(float) * V * (size_t)(g->NC + 1), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(g->d_params, 0, sizeof(float) * V * (size_t)(g->nParams + 1), e->stream);
@@ -854,7 +916,7 @@ extern "C"
       for (int i = 0; i < n.ns && err == hipSuccess; ++i)
         if ((mask >> (i < 64 ? i : 63)) & 1) err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * g->V, words[i], g->V, g->e->stream);
       if (err == hipSuccess && n.ringLen)
-        err = mlgpu_launch_fill32((uint32_t*)g->d_mem + n.memOff * g->V, 0u, n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * g->V, g->e->stream);
+        err = mlgpu_launch_fill32((uint32_t*)g->d_mem + n.memOff * g->memVoices(), 0u, n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * g->memVoices(), g->e->stream);
     }
     if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, hipGetErrorString(err));
     return MLGPU_OK;
@@ -931,6 +993,14 @@ extern "C"
     if (!g->compiled || !h) return gfail(g, MLGPU_ERR_INVALID, "graph_set_state: compile first / null");
     if (idx < 0 || idx >= g->nodes[node].ns) return gfail(g, MLGPU_ERR_RANGE, "state index out of range");
     return mlgpu_upload(g->e, g->d_state + (size_t)(g->nodes[node].sOff + idx) * g->V, h, sizeof(uint32_t) * g->V);
+  }
+
+  int mlgpu_graph_set_delay_layout(mlgpu_graph* g, int windowed)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    g->windowedRings = windowed != 0;
+    return MLGPU_OK;
   }
 
   int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n)

@@ -33,6 +33,10 @@ struct VoiceMem
   uint32_t memMask{0};
   MLD float ring(uint32_t i) const { return mem[(size_t)i * V]; }
   MLD void ringSet(uint32_t i, float x) const { mem[(size_t)i * V] = x; }
+  // Windowed rings (mlgpu_graph_set_delay_layout, the generated source defines MLGPU_RING_WINDOWS 1): `mem` is this lane's
+  // sector of chunk 0 in the block's [chunk][lane][8] ring storage and `lds` this lane's column of the workgroup's write
+  // windows, [ring][kRingWindow][256 lanes] (RingCore below).
+  float* lds{nullptr};
   MLD float c(int i) const { return coeffs[(size_t)i * V]; }
   MLD uint32_t s(int i) const { return state[(size_t)i * V]; }
   MLD void set(int i, uint32_t x) const { state[(size_t)i * V] = x; }
@@ -883,11 +887,101 @@ struct Proc<MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE>  // :517-590, nextSample(f)
 // valid range 0 <= d <= length - 64 that is identical to the block form of operator()(vx) (:834-875), which writes
 // the whole vector before reading it: a read can then never land on a sample written later in the same vector.
 
+constexpr int kRingWindow = 8;       // floats per LDS window = one 32-byte HBM sector
+constexpr int kRingLdsLanes = 256;   // lanes per workgroup of a graph kernel
+#ifndef MLGPU_RING_WINDOWS
+#define MLGPU_RING_WINDOWS 0
+#endif
+constexpr bool kRingWindows = MLGPU_RING_WINDOWS != 0;  // fixed per generated kernel, so the unused form costs nothing
+
 struct RingCore  // IntegerDelay's buffer, index and mask
 {
   uint32_t w;
-  MLD float sample(const VoiceMem& m, uint32_t ringBase, float x, int32_t d)
+  uint32_t rChunk;  // windowed layout: the 8-sample chunk the read window holds (0xFFFFFFFF: none)
+  float rw[8];      // windowed layout: the read window
+  typedef float f32x4r __attribute__((ext_vector_type(4)));
+
+  // ---- windowed layout: 32-byte sectors per voice, staged through LDS windows ----
+  // When neighbouring voices have different delay times, the [sample][V] layout makes every lane pull a whole cache line
+  // for 4 bytes (measured 10.6x the algorithmic traffic). Here the ring of a 256-voice block is stored as
+  // [chunk = sample / 8][lane][8]: a lane collects 8 written samples in an LDS window and stores them as one 32-byte
+  // sector (the block's sectors of one chunk are contiguous: 8 KiB), and reads a sector at a time into a register window,
+  // so every byte moved is used whatever the delay times are, and equal delay times still coalesce. Same values as the
+  // direct form for delays within the node's maximum: a read is served from the write window, the read window or memory,
+  // whichever holds that sample. m.mem points at this lane's sector of chunk 0 of the node's first ring.
+  MLD float* wbuf(const VoiceMem& m, int ringIdx) const { return m.lds + (size_t)ringIdx * kRingWindow * kRingLdsLanes; }
+  MLD float* chunkMem(const VoiceMem& m, int ringIdx, uint32_t i) const  // the sector holding ring position i
   {
+    return m.mem + ((size_t)ringIdx * (m.memMask + 1) + (size_t)(i & ~(uint32_t)(kRingWindow - 1))) * kRingLdsLanes;
+  }
+  MLD void begin(const VoiceMem& m, int ringIdx)  // launch start: the chunk being written comes back into its window
+  {
+    rChunk = 0xFFFFFFFFu;
+    if (!kRingWindows) return;
+    const f32x4r* src = (const f32x4r*)chunkMem(m, ringIdx, w);
+    float* wb = wbuf(m, ringIdx);
+    const f32x4r a = src[0], b = src[1];
+    wb[0 * kRingLdsLanes] = a[0]; wb[1 * kRingLdsLanes] = a[1]; wb[2 * kRingLdsLanes] = a[2]; wb[3 * kRingLdsLanes] = a[3];
+    wb[4 * kRingLdsLanes] = b[0]; wb[5 * kRingLdsLanes] = b[1]; wb[6 * kRingLdsLanes] = b[2]; wb[7 * kRingLdsLanes] = b[3];
+  }
+  MLD void flush(const VoiceMem& m, int ringIdx, uint32_t chunkStart) const
+  {
+    const float* wb = wbuf(m, ringIdx);
+    f32x4r* dst = (f32x4r*)chunkMem(m, ringIdx, chunkStart);
+    const f32x4r a = {wb[0 * kRingLdsLanes], wb[1 * kRingLdsLanes], wb[2 * kRingLdsLanes], wb[3 * kRingLdsLanes]};
+    const f32x4r b = {wb[4 * kRingLdsLanes], wb[5 * kRingLdsLanes], wb[6 * kRingLdsLanes], wb[7 * kRingLdsLanes]};
+    dst[0] = a;
+    dst[1] = b;
+  }
+  MLD void end(const VoiceMem& m, int ringIdx) const  // launch end: the partly filled write window goes back to memory
+  {
+    if (kRingWindows) flush(m, ringIdx, w & ~(uint32_t)(kRingWindow - 1));
+  }
+  MLD float sampleWindowed(const VoiceMem& m, int ringIdx, float x, int32_t d)
+  {
+    float* wb = wbuf(m, ringIdx);
+    wb[(w & (kRingWindow - 1)) * kRingLdsLanes] = x;
+    const uint32_t r = (w - (uint32_t)d) & m.memMask;
+    const uint32_t rc = r >> 3, wc = w >> 3;
+    float y;
+    if (rc == wc)
+      y = wb[(r & (kRingWindow - 1)) * kRingLdsLanes];  // still in the write window (d < 8)
+    else
+    {
+      if (rc != rChunk)
+      {
+        const f32x4r* src = (const f32x4r*)chunkMem(m, ringIdx, r);
+        const f32x4r a = src[0], b = src[1];
+        rw[0] = a[0]; rw[1] = a[1]; rw[2] = a[2]; rw[3] = a[3];
+        rw[4] = b[0]; rw[5] = b[1]; rw[6] = b[2]; rw[7] = b[3];
+        rChunk = rc;
+      }
+      // the read window lives in registers: a select chain over values (all eight read first, so that no arm of a
+      // conditional holds a load the optimizer could turn into an indexed access)
+      const uint32_t slot = r & (kRingWindow - 1);
+      const float r0 = rw[0], r1 = rw[1], r2 = rw[2], r3 = rw[3], r4 = rw[4], r5 = rw[5], r6 = rw[6], r7 = rw[7];
+      y = r0;
+      y = (slot == 1) ? r1 : y;
+      y = (slot == 2) ? r2 : y;
+      y = (slot == 3) ? r3 : y;
+      y = (slot == 4) ? r4 : y;
+      y = (slot == 5) ? r5 : y;
+      y = (slot == 6) ? r6 : y;
+      y = (slot == 7) ? r7 : y;
+    }
+    if ((w & (kRingWindow - 1)) == kRingWindow - 1)
+    {
+      flush(m, ringIdx, w & ~(uint32_t)(kRingWindow - 1));
+      if (rChunk == wc) rChunk = 0xFFFFFFFFu;  // (cannot hold: the read window never holds the chunk being written)
+    }
+    w = (w + 1) & m.memMask;
+    return y;
+  }
+
+  MLD float sample(const VoiceMem& m, int ringIdx, float x, int32_t d)
+  {
+    if (kRingWindows) return sampleWindowed(m, ringIdx, x, d);
+    const uint32_t ringBase = (uint32_t)ringIdx * (m.memMask + 1);
     m.ringSet(ringBase + w, x);
     const uint32_t r = (w - (uint32_t)d) & m.memMask;
     const float y = m.ring(ringBase + r);
@@ -909,9 +1003,11 @@ struct Proc<MLGPU_PROC_INTEGER_DELAY>  // :801-914   C{}  S{writeIndex:u32, dela
     mem = m;
     ringc.w = m.s(0);
     delay = (int32_t)m.s(1);
+    ringc.begin(m, 0);
   }
   MLD void store(const VoiceMem& m) const
   {
+    ringc.end(m, 0);
     m.set(0, ringc.w);
     m.set(1, (uint32_t)delay);
   }
@@ -987,9 +1083,9 @@ struct FracCore
     const float xm1 = (frac - 1.f);
     apCoeff = -0.53f * xm1 + 0.24f * xm1 * xm1;
   }
-  MLD float sample(const VoiceMem& m, uint32_t ringBase, float x)
+  MLD float sample(const VoiceMem& m, int ringIdx, float x)
   {
-    const float d = ringc.sample(m, ringBase, x, delayInt);
+    const float d = ringc.sample(m, ringIdx, x, delayInt);
     const float y = x1 + (d - y1) * apCoeff;
     x1 = d;
     y1 = y;
@@ -1008,8 +1104,13 @@ struct Proc<MLGPU_PROC_FRACTIONAL_DELAY>  // :971-1044  C{}  S{writeIndex, x1, y
   {
     mem = m;
     f.loadFrom(m, 0);
+    f.ringc.begin(m, 0);
   }
-  MLD void store(const VoiceMem& m) const { f.storeTo(m, 0); }
+  MLD void store(const VoiceMem& m) const
+  {
+    f.ringc.end(m, 0);
+    f.storeTo(m, 0);
+  }
   MLD float next(float x) { return f.sample(mem, 0, x); }
   MLD float next(float x, float d)  // varying delay time, :1016-1025
   {
@@ -1037,9 +1138,13 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
     mem = m;
     f1.loadFrom(m, 0);
     f2.loadFrom(m, 5);
+    f1.ringc.begin(m, 0);
+    f2.ringc.begin(m, 1);
   }
   MLD void store(const VoiceMem& m) const
   {
+    f1.ringc.end(m, 0);
+    f2.ringc.end(m, 1);
     f1.storeTo(m, 0);
     f2.storeTo(m, 5);
   }
@@ -1048,10 +1153,18 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
   MLD float next_i(int n, float x, float d)
   {
     const int r = n & 31;
-    if (r == 16) f1.setDelay(d);
-    if (r == 0) f2.setDelay(d);
+    if ((n & 15) == 0)  // one branch and selects over values: two `if (...) fN.setDelay(d)` get merged by the optimizer
+    {                   // into stores through a selected pointer, which keeps both cores in scratch memory
+      FracCore nd = f1;
+      nd.setDelay(d);
+      const bool first = (r == 16);
+      f1.delayInt = first ? nd.delayInt : f1.delayInt;
+      f1.apCoeff = first ? nd.apCoeff : f1.apCoeff;
+      f2.delayInt = first ? f2.delayInt : nd.delayInt;
+      f2.apCoeff = first ? f2.apCoeff : nd.apCoeff;
+    }
     const float y1 = f1.sample(mem, 0, x);
-    const float y2 = f2.sample(mem, mem.memMask + 1, x);
+    const float y2 = f2.sample(mem, 1, x);
     const float fade = 2.f * ((r > 16) ? 1.0f - (float)r / 32.f : (float)r / 32.f);
     return y1 + (fade * (y2 - y1));
   }

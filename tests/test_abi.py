@@ -92,3 +92,43 @@ def test_product_does_not_reference_oracle():
                     if re.search(r"oracle/|mlorc_|mlref_|libmloracle|libmlref", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def _code_object_notes(code):
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(code)
+        f.flush()
+        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
+
+
+@pytest.mark.parametrize("windows", [False, True])
+def test_offline_graph_emit_keeps_processors_in_registers(windows):
+    """mlgpu_graph_emit generates and compiles a graph's kernel without a device. The delay-line graph must not touch
+    scratch memory (a processor object the optimizer cannot split ends up there: ~15 % slower, seen in round 1) and the
+    windowed form must fit two waves per SIMD; an offline graph refuses to compile for a device."""
+    import madronalib_amd as ml
+    from madronalib_amd import patches
+    from madronalib_amd.constants import Proc
+    desc = [dict(name="x", type="input"), dict(name="dl", type="param")]
+    src = "x"
+    for j in range(4):
+        sub, src = patches.allpass(f"ap{j}_", src, Proc.PITCHBENDABLE_DELAY, 4096.0 - 64.0, "dl")
+        desc += sub
+    g = ml.Graph(ml.OfflineEngine(), 1024, desc, [src], delay_windows=windows)
+    source, code = g.emit()
+    assert "mlgpu_graph_kernel" in source and ("MLGPU_RING_WINDOWS 1" in source) == windows
+    assert code[:4] == b"\x7fELF"
+    notes = _code_object_notes(code)
+    assert "amdgcn-amd-amdhsa--gfx950" in notes
+    vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", notes).group(1)) + int((re.search(r"\.agpr_count:\s+(\d+)", notes) or [0, 0])[1])
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", notes).group(1))
+    lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", notes).group(1))
+    assert vgpr <= 256
+    assert lds == (8 * 8 * 256 * 4 if windows else 0)
+    assert scratch == 0 if not windows else scratch <= 64
+    with pytest.raises(ml.MlgpuError) as ei:
+        g.compile()
+    assert ei.value.status == ml.Status.ERR_INVALID
+    g.close()

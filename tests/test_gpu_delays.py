@@ -22,9 +22,12 @@ def eng():
     e.close()
 
 
-def delay_graph(eng, V, kind, n_inputs, max_delay):
+WINDOWS = [pytest.param(False, id="rows"), pytest.param(True, id="windows")]  # mlgpu_graph_set_delay_layout 0 / 1
+
+
+def delay_graph(eng, V, kind, n_inputs, max_delay, windows=False):
     import madronalib_amd as ml
-    g = ml.Graph(eng, V)
+    g = ml.Graph(eng, V, delay_windows=windows)
     names = [f"in{i}" for i in range(n_inputs)]
     for nm in names:
         g.add(nm, "input")
@@ -47,8 +50,9 @@ def run_delay(g, names, state0, inputs, T, layout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("windows", WINDOWS)
 @pytest.mark.parametrize("name", DELAY_CASES)
-def test_delay_lines_vs_oracle_and_golden(eng, oracle, name):
+def test_delay_lines_vs_oracle_and_golden(eng, oracle, name, windows):
     from graph_oracle import ring_len
     # golden (reference objects)
     kind, max_delay = int(GOLD[name + "_kind"]), float(GOLD[name + "_max_delay"])
@@ -56,7 +60,7 @@ def test_delay_lines_vs_oracle_and_golden(eng, oracle, name):
     while f"{name}_in{len(ins)}" in GOLD.files:
         ins.append(GOLD[f"{name}_in{len(ins)}"])
     V, T = ins[0].shape[0], ins[0].shape[1] // 128
-    g, names = delay_graph(eng, V, kind, len(ins), max_delay)
+    g, names = delay_graph(eng, V, kind, len(ins), max_delay, windows)
     outs, states = run_delay(g, names, GOLD[name + "_state0"], ins, T, Layout.VOICE_MAJOR)
     for call in range(2):
         assert_bits_equal(outs[call], GOLD[f"{name}_out{call + 1}"], True, f"{name} golden out{call + 1}")
@@ -64,7 +68,7 @@ def test_delay_lines_vs_oracle_and_golden(eng, oracle, name):
     # oracle, more voices
     V, T = 300, 9
     c = delay_case(oracle, name, V, 2 * T, seed=8)
-    g, names = delay_graph(eng, V, c["kind"], len(c["inputs"]), c["max_delay"])
+    g, names = delay_graph(eng, V, c["kind"], len(c["inputs"]), c["max_delay"], windows)
     outs, states = run_delay(g, names, c["state0"], c["inputs"], T, Layout.QUAD)
     rings = 2 if c["kind"] == Proc.PITCHBENDABLE_DELAY else 1
     st, mem = c["state0"].copy(), np.zeros((V, rings, ring_len(c["max_delay"])), np.float32)
@@ -79,10 +83,10 @@ def test_delay_lines_vs_oracle_and_golden(eng, oracle, name):
     assert (y == 0).all()
 
 
-def _composite(eng, oracle, desc, outs, V, T, sig, params, coeffs, state_edit):
+def _composite(eng, oracle, desc, outs, V, T, sig, params, coeffs, state_edit, windows=False):
     """Build the graph, run two launches, compare with the streaming oracle; returns the GPU outputs joined."""
     import madronalib_amd as ml
-    g = ml.Graph(eng, V, desc, outs)
+    g = ml.Graph(eng, V, desc, outs, delay_windows=windows)
     for k, v in params.items():
         g.set_param(k, v if np.ndim(v) else float(v))
     for k, c in coeffs.items():
@@ -110,8 +114,9 @@ def _composite(eng, oracle, desc, outs, V, T, sig, params, coeffs, state_edit):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("windows", WINDOWS)
 @pytest.mark.parametrize("which,kind,d", [(0, Proc.INTEGER_DELAY, 101.0), (1, Proc.FRACTIONAL_DELAY, 77.37), (2, Proc.PITCHBENDABLE_DELAY, 0.0)])
-def test_allpass_composites(eng, oracle, which, kind, d):
+def test_allpass_composites(eng, oracle, which, kind, d, windows):
     V, T = 70, 30
     x = np.repeat(GOLD["comp_x"][None, :], V, 0).copy()
     x[1:] = lcg_noise(np.arange(V - 1, dtype=np.uint32) + 40, 64 * T)
@@ -130,12 +135,13 @@ def test_allpass_composites(eng, oracle, which, kind, d):
         if which == 1:
             st["ap_delay"][3:5, :] = oracle.fractional_delay_state(float(np.float32(d) - np.float32(64.0))).view(np.uint32)[:, None]
     sig = {"x": x, "dl": dsig} if which == 2 else {"x": x}
-    (got,) = _composite(eng, oracle, desc, [out], V, T, sig, {"ap_gain": gains}, {}, edit)
+    (got,) = _composite(eng, oracle, desc, [out], V, T, sig, {"ap_gain": gains}, {}, edit, windows)
     assert_bits_equal(got[0], GOLD[f"allpass{which}"], True, f"Allpass<{kind}> voice 0 vs the reference class")
 
 
 @pytest.mark.gpu
-def test_fdn_composite(eng, oracle):
+@pytest.mark.parametrize("windows", WINDOWS)
+def test_fdn_composite(eng, oracle, windows):
     V, T = 50, 30
     x = np.repeat((GOLD["comp_x"] * np.float32(0.1))[None, :], V, 0).copy()
     x[1:] = lcg_noise(np.arange(V - 1, dtype=np.uint32) + 77, 64 * T) * np.float32(0.1)
@@ -150,13 +156,14 @@ def test_fdn_composite(eng, oracle):
         for n in range(4):
             st[f"fdn_delay{n}"][1] = np.uint32(max(1, int(times[n] - 64)))
             st[f"fdn_delay{n}"][1, 1:] += (np.arange(V - 1, dtype=np.uint32) % 37)
-    got = _composite(eng, oracle, desc, outs, V, T, {"x": x}, params, coeffs, edit)
+    got = _composite(eng, oracle, desc, outs, V, T, {"x": x}, params, coeffs, edit, windows)
     assert_bits_equal(got[0][0], GOLD["fdnL"], True, "FDN<4> sumL voice 0 vs the reference class")
     assert_bits_equal(got[1][0], GOLD["fdnR"], True, "FDN<4> sumR voice 0 vs the reference class")
 
 
 @pytest.mark.gpu
-def test_feedback_delay_function(eng, oracle):
+@pytest.mark.parametrize("windows", WINDOWS)
+def test_feedback_delay_function(eng, oracle, windows):
     V, T = 40, 30
     x = np.repeat(GOLD["comp_x"][None, :], V, 0).copy()
     dsig = np.repeat((GOLD["comp_dsig"] + np.float32(150.0))[None, :], V, 0).copy()
@@ -167,7 +174,7 @@ def test_feedback_delay_function(eng, oracle):
             dict(name="fb", type="op", kind=Op.MULTIPLY, inputs=["vy1", "g"]), dict(name="sum", type="op", kind=Op.ADD, inputs=["x", "fb"]),
             dict(name="fn", type="proc", kind=Proc.LOPASS, inputs=["sum"]), dict(name="dt", type="op", kind=Op.SUBTRACT, inputs=["dl", "c64"]),
             dict(name="delay", type="proc", kind=Proc.PITCHBENDABLE_DELAY, inputs=["fn", "dt"], max_delay=1000.0)]
-    (got,) = _composite(eng, oracle, desc, ["fn"], V, T, {"x": x, "dl": dsig}, {}, {"fn": np.repeat(co.reshape(3, 1), V, 1)}, lambda st: None)
+    (got,) = _composite(eng, oracle, desc, ["fn"], V, T, {"x": x, "dl": dsig}, {}, {"fn": np.repeat(co.reshape(3, 1), V, 1)}, lambda st: None, windows)
     assert_bits_equal(got[0], GOLD["fbdelay"], True, "FeedbackDelayFunction voice 0 vs the reference class")
 
 
@@ -191,5 +198,13 @@ def test_delay_rules(eng):
         g.compile()                                              # feedback without a source
     g.set_feedback(fb, d)
     g.compile()
+    g = ml.Graph(eng, 64, delay_windows=True)                    # LDS windows: 8 KiB per ring, 20 rings at most
+    a = g.add("a", "input")
+    for i in range(21):
+        g.add(f"d{i}", "proc", Proc.INTEGER_DELAY, [a], max_delay=100.0)
+    g.add_output("d20")
+    with pytest.raises(ml.MlgpuError) as ei:
+        g.compile()
+    assert ei.value.status == ml.Status.ERR_UNSUPPORTED
     bank = eng.bank([Proc.ALLPASS1], 64)                         # Allpass1 has no ring: fine in a bank
     assert bank.num_coeffs(0) == 1 and bank.num_state(0) == 2
