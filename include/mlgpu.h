@@ -200,8 +200,20 @@ typedef enum mlgpu_proc
   MLGPU_PROC_PITCHBENDABLE_DELAY = 83, /* :1050-1106 C{}      S{delay1[5], delay2[5]} two rings; form (x, delay) */
   /* TempoLock, MLDSPFilters.h:1478-1579: operator()(DSPVector x, float dydx, float isr). Graph node with 3 inputs: x must be a
    * streamed INPUT node (only x[0], x[1] of each vector are read), dydx and isr one float per vector (control / param / const). */
-  MLGPU_PROC_TEMPO_LOCK = 96          /* C{} S{omega (phase, -1 = stopped), x1v}; clear(): omega = -1 */
+  MLGPU_PROC_TEMPO_LOCK = 96,         /* C{} S{omega (phase, -1 = stopped), x1v}; clear(): omega = -1 */
+  /* HalfBandFilter, MLDSPFilters.h:1245-1310: the resampling filter at the edges of a rate region
+   * (mlgpu_graph_begin_region / end_region create these nodes; they cannot be added directly).
+   * S{apa0.x1, apa0.y1, apa1.x1, apa1.y1, apb0.x1, apb0.y1, apb1.x1, apb1.y1, b1} as mlgpu_resampler. */
+  MLGPU_PROC_HALF_BAND = 112,
+  MLGPU_PROC_HALF_BAND_BUFFERED = 113 /* + Downsample2xFunction::mOutputBuffer: S{the 9 above, 64 samples} */
 } mlgpu_proc;
+
+/* rate regions of a graph: Upsample2xFunction / Downsample2xFunction, MLDSPFunctional.h:114-213 */
+typedef enum mlgpu_region
+{
+  MLGPU_REGION_UPSAMPLE_2X = 0,   /* the nodes inside run at twice the rate (two samples per outer sample) */
+  MLGPU_REGION_DOWNSAMPLE_2X = 1  /* the nodes inside run at half the rate; one DSPVector of delay (:165-170) */
+} mlgpu_region;
 
 /* ------------------------------------------------------------------------- */
 /* engine                                                                    */
@@ -424,6 +436,17 @@ int mlgpu_graph_set_delay_layout(mlgpu_graph* g, int windowed);
  * own state member). add_feedback returns a node whose value at sample n is what set_feedback's `value_node` had at
  * sample n of the PREVIOUS DSPVector (zeros at first); set_feedback may name any node, also one added later. */
 int mlgpu_graph_add_feedback(mlgpu_graph* g, const char* name);
+/* Rate regions: `Upsample2xFunction<IN_ROWS>()(fn, vx)` / `Downsample2xFunction<IN_ROWS>()(fn, vx)` with fn written out as
+ * graph nodes. begin_region resamples the n_inputs outer nodes with one HalfBandFilter each and returns, in
+ * region_inputs[], the nodes that carry them inside the region; every audio-rate node added until end_region belongs to fn
+ * and runs at the region's rate, on the same processor objects for both halves as in the reference (fn is one stateful
+ * function called twice per DSPVector, :132-133, resp. once per two, :186). end_region resamples `result` back and returns
+ * the node of the outer graph (negative status on failure). Inside a region: processors, ops, routing and index generators
+ * on the region's inputs and on per-voice floats (params / consts) of the outer graph; no streamed inputs, controls,
+ * vector-rate processors or feedback nodes, and no nesting. A DOWNSAMPLE_2X region adds the reference's one DSPVector of
+ * delay and pairs DSPVectors (2k, 2k + 1) counted from the last mlgpu_graph_clear. */
+int mlgpu_graph_begin_region(mlgpu_graph* g, int region /* mlgpu_region */, const int* inputs, int n_inputs, int* region_inputs);
+int mlgpu_graph_end_region(mlgpu_graph* g, int result, const char* name);
 int mlgpu_graph_set_feedback(mlgpu_graph* g, int feedback_node, int value_node);
 /* routing nodes (MLDSPRouting.h): input_nodes[0] is the selector.
  *   MLGPU_ROUTE_MULTIPLEX / _LINEAR      input_nodes[1..n] the candidates (n <= 8); `index` ignored

@@ -1099,6 +1099,52 @@ class FeedbackDelayFunctionWithTap
   }
 };
 
+// Upsample2xFunction / Downsample2xFunction, MLDSPFunctional.h:114-213: fn runs at twice / half the rate between two
+// HalfBandFilters. Captured as a rate region of the graph (mlgpu_graph_begin_region): fn is called ONCE here, on the
+// resampled inputs, and the kernel evaluates its nodes twice per sample (resp. every second sample) on the same
+// processor objects - what the reference does by calling the one stateful fn twice per DSPVector (resp. once per two).
+namespace gpu
+{
+template <size_t IN_ROWS, class FN>
+inline DSPVectorArray<1> rateRegion(int kind, FN& fn, const DSPVectorArray<IN_ROWS>& vx)
+{
+  Capture& c = Capture::get();
+  int ins[IN_ROWS ? IN_ROWS : 1], inner[IN_ROWS ? IN_ROWS : 1];
+  for (size_t j = 0; j < IN_ROWS; ++j) ins[j] = vx.sig_[j].id();
+  const int st = mlgpu_graph_begin_region(c.g, kind, ins, (int)IN_ROWS, inner);
+  if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_graph_begin_region: ") + mlgpu_last_error(c.eng->handle()));
+  DSPVectorArray<IN_ROWS> resampled;
+  for (size_t j = 0; j < IN_ROWS; ++j) resampled.sig_[j] = computedSig(inner[j]);
+  const DSPVectorArray<1> y = fn(resampled);
+  return DSPVectorArray<1>(computedSig(c.ret(mlgpu_graph_end_region(c.g, y.sig_[0].id(), nullptr))));
+}
+}  // namespace gpu
+
+template <int IN_ROWS>
+class Upsample2xFunction
+{
+  using inputType = const DSPVectorArray<IN_ROWS>;
+  using outputType = DSPVectorArray<1>;
+  using ProcessFn = std::function<outputType(inputType)>;
+
+ public:
+  outputType operator()(ProcessFn fn, inputType vx) { return gpu::rateRegion<IN_ROWS>(MLGPU_REGION_UPSAMPLE_2X, fn, vx); }
+};
+
+template <int IN_ROWS>
+class Downsample2xFunction
+{
+  using inputType = const DSPVectorArray<IN_ROWS>;
+  using outputType = DSPVectorArray<1>;
+  using ProcessFn = std::function<outputType(inputType)>;
+
+ public:
+  outputType operator()(ProcessFn fn, const DSPVectorArray<IN_ROWS> vx = DSPVectorArray<0>())
+  {
+    return gpu::rateRegion<IN_ROWS>(MLGPU_REGION_DOWNSAMPLE_2X, fn, vx);
+  }
+};
+
 // Bank<T, ROWS>, MLDSPFunctional.h:321-360
 template <typename T, size_t ROWS>
 class Bank

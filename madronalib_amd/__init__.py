@@ -13,7 +13,7 @@ import weakref
 import numpy as np
 
 from . import _lib
-from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, Route, RowOp, RowsRule, Status, Vop
+from .constants import FLOATS_PER_DSPVECTOR, Layout, Op, Proc, Region, Route, RowOp, RowsRule, Status, Vop
 
 __all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "Resampler", "Events", "Event", "EventType", "jit_selftest", "DeviceBuffer", "MlgpuError", "Layout", "Op", "Proc", "RowOp", "Status", "Vop", "Route", "RowsRule", "Allpass1", "FractionalDelay", "LinearGlide", "SampleAccurateLinearGlide",
            "Lopass", "Hipass", "Bandpass", "LoShelf", "HiShelf", "Bell", "OnePole", "DCBlocker", "ADSR",
@@ -702,6 +702,21 @@ class Graph:
         if type == "op":
             return self._ret(self.L.mlgpu_graph_add_op(self.h, int(kind), arr, len(ins), bname), name)
         raise ValueError(type)
+
+    def begin_region(self, kind, inputs, names=None):
+        """Open a rate region (Region.UPSAMPLE_2X / DOWNSAMPLE_2X): returns the nodes that carry `inputs` inside it."""
+        ins = [self._id(i) for i in inputs]
+        arr = (ctypes.c_int * max(1, len(ins)))(*ins)
+        out = (ctypes.c_int * max(1, len(ins)))()
+        self.engine._check(self.L.mlgpu_graph_begin_region(self.h, int(kind), arr, len(ins), out))
+        ids = [int(out[j]) for j in range(len(ins))]
+        for nm, r in zip(names or [], ids):
+            self.ids[nm] = r
+        return ids
+
+    def end_region(self, result, name=None):
+        """Close the open region; returns the outer node carrying fn's resampled result."""
+        return self._ret(self.L.mlgpu_graph_end_region(self.h, self._id(result), name.encode() if name else None), name)
 
     def add_output(self, node):
         self.outputs.append(node)

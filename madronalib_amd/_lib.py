@@ -136,6 +136,8 @@ def _declare(L):
     sig("mlgpu_graph_compile", i, [vp])
     sig("mlgpu_graph_source", c.c_char_p, [vp])
     sig("mlgpu_graph_emit", i, [vp, c.POINTER(vp), c.POINTER(c.c_size_t)])
+    sig("mlgpu_graph_begin_region", i, [vp, i, c.POINTER(i), i, c.POINTER(i)])
+    sig("mlgpu_graph_end_region", i, [vp, i, c.c_char_p])
     sig("mlgpu_graph_clear", i, [vp])
     sig("mlgpu_graph_clear_proc", i, [vp, i])
     sig("mlgpu_graph_set_input_layout", i, [vp, i, i])

@@ -101,6 +101,11 @@ class Route:
     DEMULTIPLEX_LINEAR = 3
 
 
+class Region:
+    UPSAMPLE_2X = 0
+    DOWNSAMPLE_2X = 1
+
+
 class RowOp:
     SUM = 0
     MEAN = 1
@@ -139,12 +144,14 @@ class Proc:
     FRACTIONAL_DELAY = 82
     PITCHBENDABLE_DELAY = 83
     TEMPO_LOCK = 96
+    HALF_BAND = 112            # made by Graph.begin_region / end_region only
+    HALF_BAND_BUFFERED = 113
 
     # processors a bank (chain) can hold; INTERPOLATOR1 / LINEAR_GLIDE are vector-rate: graph nodes only
     ALL = (0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 48, 66, 81)
     VECTOR_RATE = (64, 65, 96)
     DELAYS = (80, 82, 83)      # own per-voice rings in HBM: graph nodes only
-    GRAPH_ONLY = (64, 65, 80, 82, 83, 96)
+    GRAPH_ONLY = (64, 65, 80, 82, 83, 96, 112, 113)
     GENERATORS = (0, 1, 2, 3, 4, 5, 6, 7)
     # outputs pass through sqrtApprox (rsqrtps) in the reference: 2^-11 relative tolerance
     HW_APPROX = (36, 37)

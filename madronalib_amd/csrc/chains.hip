@@ -157,6 +157,9 @@ static bool graphOnlyInfo(int kind, int* nc, int* ns)
     case MLGPU_PROC_INTEGER_DELAY: *nc = Proc<MLGPU_PROC_INTEGER_DELAY>::NC; *ns = Proc<MLGPU_PROC_INTEGER_DELAY>::NS; return true;
     case MLGPU_PROC_FRACTIONAL_DELAY: *nc = Proc<MLGPU_PROC_FRACTIONAL_DELAY>::NC; *ns = Proc<MLGPU_PROC_FRACTIONAL_DELAY>::NS; return true;
     case MLGPU_PROC_PITCHBENDABLE_DELAY: *nc = Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>::NC; *ns = Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>::NS; return true;
+    // the resampling filters at the edges of a rate region
+    case MLGPU_PROC_HALF_BAND: *nc = Proc<MLGPU_PROC_HALF_BAND>::NC; *ns = Proc<MLGPU_PROC_HALF_BAND>::NS; return true;
+    case MLGPU_PROC_HALF_BAND_BUFFERED: *nc = Proc<MLGPU_PROC_HALF_BAND_BUFFERED>::NC; *ns = Proc<MLGPU_PROC_HALF_BAND_BUFFERED>::NS; return true;
     default: return false;
   }
 }

@@ -186,6 +186,20 @@ struct Node
   int fbSource{-1};       // feedback nodes: the node whose value is stored for the next vector
   int rate{RATE_AUDIO};
   int cOff{0}, sOff{0}, nc{0}, ns{0};
+  int region{-1};         // the rate region whose function this node belongs to (-1: the outer graph)
+  int role{0};            // ROLE_REGION_IN: HalfBandFilter carrying an outer node into region `region`;
+                          // ROLE_REGION_OUT: HalfBandFilter bringing region `slot`'s result back (an outer node)
+};
+
+enum { ROLE_NONE = 0, ROLE_REGION_IN = 1, ROLE_REGION_OUT = 2 };
+
+// Upsample2xFunction / Downsample2xFunction (MLDSPFunctional.h:114-213) with fn written out as nodes
+struct Region
+{
+  int kind{0};            // mlgpu_region
+  std::vector<int> ins;   // ROLE_REGION_IN nodes
+  int result{-1};         // fn's return value (a node of the region)
+  int out{-1};            // ROLE_REGION_OUT node
 };
 
 int opArity(int op) { return op >= 64 ? 3 : (op >= 32 ? 2 : 1); }
@@ -225,6 +239,9 @@ struct mlgpu_graph
   bool windowedRings{false};     // rings as [block][chunk][lane][8] behind LDS windows (mlgpu_graph_set_delay_layout)
   int totalRings{0};
   size_t memVoices() const { return windowedRings ? ((V + 255) & ~(size_t)255) : V; }  // voices the ring memory is laid out for
+  std::vector<Region> regions;
+  int openRegion{-1};            // between graph_begin_region and graph_end_region
+  size_t vectorCount{0};         // DSPVectors processed since the last clear (GraphArgs::t0)
   int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
   int compiledVoicesPerLane{1};
   int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
@@ -239,12 +256,14 @@ int gfail(mlgpu_graph* g, int status, const std::string& what)
 }
 
 // the C++ expression of node i for lane-group l (its inputs are the locals n<j>_<l>)
-std::string nodeExpr(const mlgpu_graph* g, size_t i, int l)
+// Inside a rate region the values of the region's nodes carry the phase suffix `ph` ("a" / "b" for the two samples an
+// Upsample2x region makes per outer sample) and `idx` is the sample index inside fn's own DSPVector.
+std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& ph = "", const std::string& idx = "q * 4 + k")
 {
   const Node& n = g->nodes[i];
   std::ostringstream s;
   const std::string L = "_" + std::to_string(l);
-  auto arg = [&](size_t j) { return "n" + std::to_string(n.in[j]) + L; };
+  auto arg = [&](size_t j) { return "n" + std::to_string(n.in[j]) + (g->nodes[n.in[j]].region >= 0 ? ph : std::string()) + L; };
   switch (n.type)
   {
     case NODE_INPUT: s << "xin" << n.slot << L << "[k]"; break;
@@ -253,9 +272,9 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l)
     case NODE_CONST: s << floatLiteral(n.value); break;
     case NODE_PROC:
       if (mlgpu_proc_is_vector_rate(n.kind))
-        s << "p" << i << L << ".next_n(q * 4 + k)";
+        s << "p" << i << L << ".next_n(" << idx << ")";
       else if (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY)
-        s << "p" << i << L << ".next_i(q * 4 + k, " << arg(0) << ", " << arg(1) << ")";
+        s << "p" << i << L << ".next_i(" << idx << ", " << arg(0) << ", " << arg(1) << ")";
       else if ((n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
       {
         // launch-constant frequency: the polyBLEP range test was done once per wavefront (odd<i>)
@@ -290,7 +309,7 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l)
           << n.slot << ", " << n.nOut << ")";
       break;
     case NODE_VOP:
-      s << "vop<" << n.kind << ">(q * 4 + k";
+      s << "vop<" << n.kind << ">(" << idx;
       for (size_t j = 0; j < n.in.size(); ++j) s << ", " << arg(j);
       s << ")";
       break;
@@ -413,9 +432,85 @@ std::string generateGraphSource(mlgpu_graph* g)
         << i << "].strideQ);\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l) s << "      f32x4 y" << o << sfx(l) << ";\n";
+  // a Downsample2x region's filter pairs the outer samples (n - 1, n): keep the previous sample of its sources
+  for (const Region& R : g->regions)
+    if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X)
+      for (int in : R.ins)
+        for (int l = 0; l < VL; ++l) s << "      float prev" << in << sfx(l) << " = 0.f;\n";
   s << "#pragma unroll\n      for (int k = 0; k < 4; ++k)\n      {\n";
-  for (size_t i = 0; i < g->nodes.size(); ++i)
-    if (g->nodes[i].rate == RATE_AUDIO) emit(i, "        ");
+  {
+    std::vector<char> done(g->nodes.size(), 0);
+    auto name = [&](int j, const std::string& ph, int l) { return "n" + std::to_string(j) + ph + sfx(l); };
+    auto emitRegion = [&](int r) {
+      const Region& R = g->regions[(size_t)r];
+      if (R.kind == MLGPU_REGION_UPSAMPLE_2X)
+      {
+        // fn on the two samples the HalfBandFilters make of this outer sample (upsampleFirstHalf / SecondHalf in stream order)
+        for (int phase = 0; phase < 2; ++phase)
+        {
+          const std::string ph = phase ? "b" : "a";
+          const std::string idx = "(((q * 4 + k) * 2 + " + std::to_string(phase) + ") & 63)";
+          for (size_t j = 0; j < g->nodes.size(); ++j)
+          {
+            const Node& m = g->nodes[j];
+            if (m.region != r || m.rate != RATE_AUDIO) continue;
+            for (int l = 0; l < VL; ++l)
+            {
+              s << "        const float " << name((int)j, ph, l) << " = ";
+              if (m.role == ROLE_REGION_IN)
+                s << "p" << j << sfx(l) << ".up_" << ph << "(n" << m.in[0] << sfx(l) << ");";
+              else
+                s << nodeExpr(g, j, l, ph, idx) << ";";
+              if (l == 0 && phase == 0 && !m.name.empty()) s << "  // " << m.name << " (2x)";
+              s << "\n";
+            }
+            done[j] = 1;
+          }
+        }
+      }
+      else
+      {
+        // the region's output is what its upsampler made one DSPVector ago; fn itself runs on odd outer samples
+        for (int l = 0; l < VL; ++l) s << "        const float " << name(R.out, "", l) << " = p" << R.out << sfx(l) << ".delayed(q * 4 + k);\n";
+        done[(size_t)R.out] = 1;
+        s << "        if (k & 1)\n        {\n";
+        const std::string idx = "((((q * 4 + k) - 1) >> 1) + 32 * (int)((a.t0 + t) & 1))";
+        for (size_t j = 0; j < g->nodes.size(); ++j)
+        {
+          const Node& m = g->nodes[j];
+          if (m.region != r || m.rate != RATE_AUDIO) continue;
+          for (int l = 0; l < VL; ++l)
+          {
+            s << "          const float " << name((int)j, "", l) << " = ";
+            if (m.role == ROLE_REGION_IN)
+              s << "p" << j << sfx(l) << ".down(prev" << j << sfx(l) << ", n" << m.in[0] << sfx(l) << ");";
+            else
+              s << nodeExpr(g, j, l, "", idx) << ";";
+            if (l == 0 && !m.name.empty()) s << "  // " << m.name << " (1/2x)";
+            s << "\n";
+          }
+          done[j] = 1;
+        }
+        for (int l = 0; l < VL; ++l) s << "          p" << R.out << sfx(l) << ".push(q * 4 + k, " << name(R.result, "", l) << ");\n";
+        s << "        }\n";
+        for (int in : R.ins)
+          for (int l = 0; l < VL; ++l) s << "        prev" << in << sfx(l) << " = n" << g->nodes[(size_t)in].in[0] << sfx(l) << ";\n";
+      }
+    };
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+    {
+      const Node& n = g->nodes[i];
+      if (done[i] || n.rate != RATE_AUDIO) continue;
+      if (n.region >= 0)
+        emitRegion(n.region);
+      else if (n.role == ROLE_REGION_OUT)  // Upsample2x (a Downsample2x region's output was emitted with the region)
+        for (int l = 0; l < VL; ++l)
+          s << "        const float " << name((int)i, "", l) << " = p" << i << sfx(l) << ".down(" << name(n.in[0], "a", l) << ", " << name(n.in[0], "b", l) << ");"
+            << (l == 0 && !n.name.empty() ? "  // " + n.name : std::string()) << "\n";
+      else
+        emit(i, "        ");
+    }
+  }
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l) s << "        y" << o << sfx(l) << "[k] = n" << g->outputs[o] << sfx(l) << ";\n";
   // feedback: keep this sample's value for the same sample of the next DSPVector (its old value was read above)
@@ -428,10 +523,36 @@ std::string generateGraphSource(mlgpu_graph* g)
     for (int l = 0; l < VL; ++l)
       s << "      __builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o
         << "].strideQ);\n";
+  // fn of an Upsample2x region has finished one of its own DSPVectors after outer samples 31 and 63
+  {
+    bool any = false;
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+    {
+      const Node& n = g->nodes[i];
+      if (n.type != NODE_PROC || n.region < 0 || n.role != ROLE_NONE || g->regions[(size_t)n.region].kind != MLGPU_REGION_UPSAMPLE_2X) continue;
+      if (!any) s << "      if (q == 7 || q == 15)\n      {\n";
+      any = true;
+      for (int l = 0; l < VL; ++l) s << "        p" << i << sfx(l) << ".end_vector();\n";
+    }
+    if (any) s << "      }\n";
+  }
   s << "    }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
-    if (g->nodes[i].type == NODE_PROC)
+    if (g->nodes[i].type == NODE_PROC && (g->nodes[i].region < 0 || g->nodes[i].role != ROLE_NONE))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".end_vector();\n";
+  // fn of a Downsample2x region finishes a DSPVector with every second outer one
+  {
+    bool any = false;
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+    {
+      const Node& n = g->nodes[i];
+      if (n.type != NODE_PROC || n.region < 0 || n.role != ROLE_NONE || g->regions[(size_t)n.region].kind != MLGPU_REGION_DOWNSAMPLE_2X) continue;
+      if (!any) s << "    if ((a.t0 + t) & 1)\n    {\n";
+      any = true;
+      for (int l = 0; l < VL; ++l) s << "      p" << i << sfx(l) << ".end_vector();\n";
+    }
+    if (any) s << "    }\n";
+  }
   s << "  }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC)
@@ -455,8 +576,53 @@ int addNode(mlgpu_graph* g, Node&& n)
       break;
     default: n.rate = RATE_AUDIO; break;
   }
+  // rate regions: a region's nodes are visible only inside it, and inside it only the region's own nodes and per-voice
+  // floats of the outer graph are (fn sees its upsampled / downsampled arguments, nothing else moves at its rate)
+  if (n.role == ROLE_NONE)
+  {
+    for (int id : n.in)
+    {
+      const Node& src = g->nodes[(size_t)id];
+      if (src.region >= 0 && src.region != g->openRegion) return -gfail(g, MLGPU_ERR_INVALID, "graph: a node of a closed rate region is used outside it");
+      if (g->openRegion >= 0 && src.region < 0 && src.rate != RATE_VOICE)
+        return -gfail(g, MLGPU_ERR_INVALID, "graph: inside a rate region only the region's inputs and per-voice floats (params, consts) can be used");
+    }
+    if (g->openRegion >= 0)
+    {
+      const bool vectorProc = (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind));
+      if (n.type == NODE_INPUT || n.type == NODE_CONTROL || n.type == NODE_FEEDBACK || vectorProc || n.rate == RATE_VECTOR)
+        return -gfail(g, MLGPU_ERR_UNSUPPORTED, "graph: streamed inputs, controls, vector-rate processors and feedback nodes cannot live inside a rate region");
+      if (n.rate == RATE_AUDIO) n.region = g->openRegion;
+    }
+  }
   g->nodes.push_back(std::move(n));
   return (int)g->nodes.size() - 1;
+}
+
+// a processor node with its coefficient and state slots (the checks of mlgpu_graph_add_proc are the caller's)
+int addProcNode(mlgpu_graph* g, int kind, const int* inputs, int nIn, const char* name, int role = ROLE_NONE, int region = -1, int slot = 0)
+{
+  Node n;
+  n.type = NODE_PROC;
+  n.kind = kind;
+  if (nIn) n.in.assign(inputs, inputs + nIn);
+  n.name = name ? name : "";
+  n.nc = mlgpu_proc_nc(kind);
+  n.ns = mlgpu_proc_ns(kind);
+  n.cOff = g->NC;
+  n.sOff = g->NS;
+  n.role = role;
+  n.region = region;
+  n.slot = slot;
+  const int nc = n.nc, ns = n.ns;
+  const int id = addNode(g, std::move(n));
+  if (id >= 0)
+  {
+    g->NC += nc;
+    g->NS += ns;
+    if (kind == MLGPU_PROC_IMPULSE_GEN) g->hasImpulse = true;
+  }
+  return id;
 }
 
 int checkNode(mlgpu_graph* g, int node, int type)
@@ -748,6 +914,8 @@ extern "C"
     if (!g) return -MLGPU_ERR_INVALID;
     const int nc = mlgpu_proc_nc(kind), ns = mlgpu_proc_ns(kind);
     if (nc < 0) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: unknown processor kind");
+    if (kind == MLGPU_PROC_HALF_BAND || kind == MLGPU_PROC_HALF_BAND_BUFFERED)
+      return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: HalfBandFilter nodes are made by graph_begin_region / graph_end_region");
     // forms of operator(): 1 input, plus PulseGen(freq, width) MLDSPGens.h:390, Lopass(x, omega, k) MLDSPFilters.h:136,
     // LoShelf(x, 5 coefficient signals) :304, HiShelf(x, 6 coefficient signals) :385; NoiseGen has none
     bool okArity = (nIn == 1);
@@ -770,22 +938,59 @@ extern "C"
     }
     else if (mlgpu_proc_is_vector_rate(kind) && (inputs[0] < 0 || inputs[0] >= (int)g->nodes.size() || g->nodes[inputs[0]].rate > RATE_VECTOR))
       return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: Interpolator1 / LinearGlide take one float per DSPVector (a control, param or const node)");
-    Node n;
-    n.type = NODE_PROC;
-    n.kind = kind;
-    if (nIn) n.in.assign(inputs, inputs + nIn);
-    n.name = name ? name : "";
-    n.nc = nc;
-    n.ns = ns;
-    n.cOff = g->NC;
-    n.sOff = g->NS;
-    const int id = addNode(g, std::move(n));
-    if (id >= 0)
+    (void)ns;
+    return addProcNode(g, kind, inputs, nIn, name);
+  }
+
+  int mlgpu_graph_begin_region(mlgpu_graph* g, int region, const int* inputs, int nIn, int* regionInputs)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (region != MLGPU_REGION_UPSAMPLE_2X && region != MLGPU_REGION_DOWNSAMPLE_2X) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: unknown region kind");
+    if (g->openRegion >= 0) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_begin_region: rate regions do not nest");
+    if (nIn < 0 || nIn > 8 || (nIn > 0 && (!inputs || !regionInputs))) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: 0..8 inputs");
+    for (int j = 0; j < nIn; ++j)
     {
-      g->NC += nc;
-      g->NS += ns;
-      if (kind == MLGPU_PROC_IMPULSE_GEN) g->hasImpulse = true;
+      if (inputs[j] < 0 || inputs[j] >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_begin_region: unknown input node");
+      if (g->nodes[(size_t)inputs[j]].region >= 0) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: input belongs to another region");
     }
+    const int r = (int)g->regions.size();
+    Region R;
+    R.kind = region;
+    for (int j = 0; j < nIn; ++j)
+    {
+      // one HalfBandFilter per input row: mUppers[j] (MLDSPFunctional.h:125-130) / mDowners[j] (:181-184)
+      const int id = addProcNode(g, MLGPU_PROC_HALF_BAND, &inputs[j], 1, nullptr, ROLE_REGION_IN, r);
+      if (id < 0) return -id;
+      g->nodes[(size_t)id].rate = RATE_AUDIO;
+      R.ins.push_back(id);
+      regionInputs[j] = id;
+    }
+    g->regions.push_back(R);
+    g->openRegion = r;
+    return MLGPU_OK;
+  }
+
+  int mlgpu_graph_end_region(mlgpu_graph* g, int result, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (g->compiled) return -gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    const int r = g->openRegion;
+    if (r < 0) return -gfail(g, MLGPU_ERR_INVALID, "graph_end_region: no region is open");
+    if (result < 0 || result >= (int)g->nodes.size() || g->nodes[(size_t)result].region != r)
+      return -gfail(g, MLGPU_ERR_INVALID, "graph_end_region: the result must be an audio-rate node of the region");
+    g->openRegion = -1;
+    Region& R = g->regions[(size_t)r];
+    R.result = result;
+    // mDowners[0] (MLDSPFunctional.h:137-141) resp. mUppers[0] + mOutputBuffer (:191-197)
+    const int kind = (R.kind == MLGPU_REGION_UPSAMPLE_2X) ? MLGPU_PROC_HALF_BAND : MLGPU_PROC_HALF_BAND_BUFFERED;
+    const int id = addProcNode(g, kind, &result, 1, name, ROLE_REGION_OUT, -1, r);
+    if (id < 0)
+    {
+      g->openRegion = r;
+      return id;
+    }
+    R.out = id;
     return id;
   }
   int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* inputs, int nIn, const char* name)
@@ -823,6 +1028,12 @@ extern "C"
   {
     if (!g->source.empty()) return MLGPU_OK;
     if (g->outputs.empty()) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: no outputs");
+    if (g->openRegion >= 0) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: a rate region is still open (graph_end_region)");
+    for (int o : g->outputs)
+      if (g->nodes[(size_t)o].region >= 0) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: an output is a node inside a rate region");
+    for (const Node& n : g->nodes)
+      if (n.type == NODE_FEEDBACK && n.fbSource >= 0 && g->nodes[(size_t)n.fbSource].region >= 0)
+        return gfail(g, MLGPU_ERR_INVALID, "graph_compile: a feedback node's source is inside a rate region");
     size_t memFloats = 0;
     g->totalRings = 0;
     for (Node& n : g->nodes)
@@ -930,6 +1141,7 @@ extern "C"
       const int st = clearNode(g, n);
       if (st) return st;
     }
+    g->vectorCount = 0;
     return MLGPU_OK;
   }
 
@@ -1052,6 +1264,7 @@ extern "C"
     a.mem = g->d_mem;
     a.V = g->V;
     a.T = T;
+    a.t0 = g->vectorCount;
     a.impulseTable = g->e->d_impulseTable;
     for (int i = 0; i < g->nInputs; ++i)
     {
@@ -1072,6 +1285,7 @@ extern "C"
     if (hipSetDevice(g->e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
     const hipError_t err = launchJit(g->fn, a, (g->V + g->compiledVoicesPerLane - 1) / g->compiledVoicesPerLane, g->e->stream);
     if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, std::string("graph_process launch: ") + hipGetErrorString(err));
+    g->vectorCount += T;
     return MLGPU_OK;
   }
 }

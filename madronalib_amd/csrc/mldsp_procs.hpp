@@ -1171,6 +1171,90 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
   MLD void end_vector() {}
 };
 
+// ---- HalfBandFilter, MLDSPFilters.h:1245-1310: the edges of a rate region (Upsample2xFunction / Downsample2xFunction) ----
+// Polyphase pair of two-section allpass chains; order 4, rejection 70 dB, transition band 0.1 (:1306-1308).
+//   upsample (:1248-1270):   y[2i] = apa1(apa0(x[i]));  y[2i+1] = apb1(apb0(x[i]))
+//   downsample (:1272-1294): a0 = apa1(apa0(x[2i])); b0 = apb1(apb0(x[2i+1])); y[i] = (a0 + b1) * 0.5; b1 = b0
+struct Ap1Core  // Allpass1::processSample, :945-953
+{
+  float x1, y1;
+  MLD float step(float x, float coeff)
+  {
+    const float y = x1 + (x - y1) * coeff;
+    x1 = x;
+    y1 = y;
+    return y;
+  }
+};
+
+struct HalfBandCore
+{
+  Ap1Core a0, a1, b0, b1ap;
+  float b1;
+  MLD void load(const VoiceMem& m)
+  {
+    a0.x1 = u2f(m.s(0)); a0.y1 = u2f(m.s(1)); a1.x1 = u2f(m.s(2)); a1.y1 = u2f(m.s(3));
+    b0.x1 = u2f(m.s(4)); b0.y1 = u2f(m.s(5)); b1ap.x1 = u2f(m.s(6)); b1ap.y1 = u2f(m.s(7));
+    b1 = u2f(m.s(8));
+  }
+  MLD void store(const VoiceMem& m) const
+  {
+    m.set(0, f2u(a0.x1)); m.set(1, f2u(a0.y1)); m.set(2, f2u(a1.x1)); m.set(3, f2u(a1.y1));
+    m.set(4, f2u(b0.x1)); m.set(5, f2u(b0.y1)); m.set(6, f2u(b1ap.x1)); m.set(7, f2u(b1ap.y1));
+    m.set(8, f2u(b1));
+  }
+  MLD float pathA(float x) { return a1.step(a0.step(x, 0.07986642623635751f), 0.5453536510711322f); }
+  MLD float pathB(float x) { return b1ap.step(b0.step(x, 0.28382934487410993f), 0.8344118914807379f); }
+  MLD float down(float xe, float xo)
+  {
+    const float va = pathA(xe);
+    const float vb = pathB(xo);
+    const float y = (va + b1) * 0.5f;
+    b1 = vb;
+    return y;
+  }
+};
+
+template <>
+struct Proc<MLGPU_PROC_HALF_BAND>
+{
+  static constexpr int NC = 0, NS = 9;
+  HalfBandCore hb;
+  MLD void load(const VoiceMem& m, const KernelTables&) { hb.load(m); }
+  MLD void store(const VoiceMem& m) const { hb.store(m); }
+  MLD float up_a(float x) { return hb.pathA(x); }
+  MLD float up_b(float x) { return hb.pathB(x); }
+  MLD float down(float xe, float xo) { return hb.down(xe, xo); }
+  MLD void end_vector() {}
+};
+
+// The output side of Downsample2xFunction (MLDSPFunctional.h:172-213): mUppers[0] plus the DSPVector that is handed out one
+// process call late (mOutputBuffer and the returned first half together are 64 samples of delay on the upsampled stream).
+// The 64 samples stay in the SoA state array (slot 9 + n, coalesced), read at sample n before the pair (n - 1, n) is
+// replaced.
+template <>
+struct Proc<MLGPU_PROC_HALF_BAND_BUFFERED>
+{
+  static constexpr int NC = 0, NS = 9 + MLGPU_FLOATS_PER_DSPVECTOR;
+  HalfBandCore hb;
+  VoiceMem mem;
+  MLD void load(const VoiceMem& m, const KernelTables&)
+  {
+    mem = m;
+    hb.load(m);
+  }
+  MLD void store(const VoiceMem& m) const { hb.store(m); }
+  MLD float delayed(int n) const { return u2f(mem.s(9 + n)); }
+  MLD void push(int n, float x)  // n odd: the inner sample made from outer samples n - 1 and n
+  {
+    const float ya = hb.pathA(x);
+    const float yb = hb.pathB(x);
+    mem.set(9 + n - 1, f2u(ya));
+    mem.set(9 + n, f2u(yb));
+  }
+  MLD void end_vector() {}
+};
+
 // ---- TempoLock, MLDSPFilters.h:1478-1579 ---------------------------------------------------------------------------
 // operator()(DSPVector x, float dydx, float isr): follows an input clock phasor at the ratio dydx. Per DSPVector it looks
 // only at x[0] and x[1], then writes a phasor ramp; so it is a vector-rate processor whose first input must be a STREAMED

@@ -41,4 +41,5 @@ struct GraphArgs
   float* mem;  // delay-line rings of all delay nodes, [sample][V] each
   size_t V, T;
   const float* impulseTable;
+  size_t t0;  // DSPVectors processed since the last clear (a Downsample2xFunction region pairs vectors 2k, 2k + 1)
 };

@@ -50,6 +50,27 @@ extern "C" int plate_ref_run(size_t V, size_t T, const float* inL, const float* 
   return 0;
 }
 
+#include "../tests/cpp/dropin_oversample.h"
+extern "C" int oversample_ref_run(size_t V, size_t T, const float* in0, const float* in1, float* out0, float* out1)
+{
+  const size_t S = T * kFloatsPerDSPVector;
+  for (size_t v = 0; v < V; ++v)
+  {
+    OversampleState state;
+    oversampleSetup(state);
+    AudioContext ctx(2, 2, 48000);
+    for (size_t t = 0; t < T; ++t)
+    {
+      load(ctx.inputs[0], in0 + v * S + t * kFloatsPerDSPVector);
+      load(ctx.inputs[1], in1 + v * S + t * kFloatsPerDSPVector);
+      oversampleProcess(&ctx, &state);
+      store(ctx.outputs[0], out0 + v * S + t * kFloatsPerDSPVector);
+      store(ctx.outputs[1], out1 + v * S + t * kFloatsPerDSPVector);
+    }
+  }
+  return 0;
+}
+
 // ---- a Synth subclass run by the reference's own Synth::processVector, AudioContext and EventsToSignals ----
 #include "MLSynth.h"
 #include "../tests/cpp/dropin_synth.h"

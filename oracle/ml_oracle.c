@@ -1874,6 +1874,101 @@ static void up_rec(float* f, int h, int total, float x, float* y)
   up_rec(f, h - 1, total, ya, y);
   up_rec(f, h - 1, total, yb, y + (1 << (h - 1)));
 }
+/*
+ * Upsample2xFunction<2> / Downsample2xFunction<2> (MLDSPFunctional.h:114-213) around one stateful function, then a gain,
+ * written in the reference's own block form (whole DSPVectors, mPhase, mInputBuffer, mOutputBuffer):
+ *   fn(v) = Lopass(coeffs)((clamp(v.row(0) * 3, -1, 1) + SawGen(freq)) * v.row(1));   out = F(fn, {x, m}) * 0.5
+ * freq[V], x / m / out [V][64*T]; all objects start default-constructed.
+ */
+typedef struct
+{
+  uint32_t omega32; /* SawGen's PhasorGen, MLDSPGens.h:179 (mOmega32 = 0) */
+  float ic1, ic2;   /* Lopass, MLDSPFilters.h:79 */
+  float freq;
+  const float* co;
+} rate_fn_state;
+static void rate_fn(rate_fn_state* st, const float* v0, const float* v1, float* y)
+{
+  float cps[VEC], ph[VEC], am[VEC];
+  for (int n = 0; n < VEC; ++n) cps[n] = st->freq;
+  phasor64(&st->omega32, cps, ph);
+  for (int n = 0; n < VEC; ++n)
+  {
+    const float drive = v0[n] * 3.0f;
+    const float sat = sse_min(sse_max(drive, -1.0f), 1.0f); /* clamp, MLDSPOps.h:747 */
+    const float mix = sat + phasor_to_saw(ph[n], cps[n]);
+    am[n] = mix * v1[n];
+  }
+  svf64(MLGPU_PROC_LOPASS, st->co, &st->ic1, &st->ic2, am, y);
+}
+static void hb_up_half(float* f, const float* x, int second, float* y) /* upsampleFirstHalf / SecondHalf, MLDSPFilters.h:1248-1270 */
+{
+  int i2 = 0;
+  for (int i = second ? VEC / 2 : 0; i < (second ? VEC : VEC / 2); ++i)
+  {
+    y[i2++] = hb_a(f, x[i]);
+    y[i2++] = hb_b(f, x[i]);
+  }
+}
+static void hb_down2(float* f, const float* x1, const float* x2, float* y) /* downsample(vx1, vx2), :1272-1294 */
+{
+  for (int half = 0; half < 2; ++half)
+  {
+    const float* x = half ? x2 : x1;
+    for (int i = 0; i < VEC / 2; ++i)
+    {
+      const float a0 = hb_a(f, x[2 * i]), b0 = hb_b(f, x[2 * i + 1]);
+      y[half * (VEC / 2) + i] = (a0 + f[8]) * 0.5f;
+      f[8] = b0;
+    }
+  }
+}
+int mlorc_rate_function_run(int up, size_t V, size_t T, const float* freq, const float* lopassCoeffs, const float* x, const float* m, float* out)
+{
+  for (size_t v = 0; v < V; ++v)
+  {
+    rate_fn_state st = {0u, 0.f, 0.f, freq[v], lopassCoeffs};
+    float fin[2][9] = {{0}}, fout[9] = {0};       /* mUppers / mDowners, one HalfBandFilter per row */
+    float inBuf[2][VEC] = {{0}}, outBuf[VEC] = {0}; /* Downsample2xFunction::mInputBuffer, mOutputBuffer */
+    int phase = 0;                                  /* mPhase{false} */
+    for (size_t t = 0; t < T; ++t)
+    {
+      const float* vx = x + (v * T + t) * VEC;
+      const float* vm = m + (v * T + t) * VEC;
+      float y[VEC];
+      if (up) /* :126-143 */
+      {
+        float a0[VEC], a1[VEC], b0[VEC], b1[VEC], o1[VEC], o2[VEC];
+        hb_up_half(fin[0], vx, 0, a0);
+        hb_up_half(fin[0], vx, 1, b0);
+        hb_up_half(fin[1], vm, 0, a1);
+        hb_up_half(fin[1], vm, 1, b1);
+        rate_fn(&st, a0, a1, o1);
+        rate_fn(&st, b0, b1, o2);
+        hb_down2(fout, o1, o2, y);
+      }
+      else if (phase) /* :179-198 */
+      {
+        float d0[VEC], d1[VEC], o[VEC];
+        hb_down2(fin[0], inBuf[0], vx, d0);
+        hb_down2(fin[1], inBuf[1], vm, d1);
+        rate_fn(&st, d0, d1, o);
+        hb_up_half(fout, o, 0, y);
+        hb_up_half(fout, o, 1, outBuf);
+      }
+      else /* :200-206 */
+      {
+        memcpy(inBuf[0], vx, sizeof(float) * VEC);
+        memcpy(inBuf[1], vm, sizeof(float) * VEC);
+        memcpy(y, outBuf, sizeof(float) * VEC);
+      }
+      if (!up) phase = !phase;
+      for (int n = 0; n < VEC; ++n) out[(v * T + t) * VEC + n] = y[n] * 0.5f;
+    }
+  }
+  return MLGPU_OK;
+}
+
 int mlorc_resample(int octaves, int up, size_t V, size_t T_in, float* state, const float* in, float* out)
 {
   if (octaves < 0 || octaves > 6) return MLGPU_ERR_INVALID;

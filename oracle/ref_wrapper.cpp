@@ -1243,6 +1243,37 @@ extern "C"
     return MLGPU_OK;
   }
 
+  // Upsample2xFunction<2> / Downsample2xFunction<2> (MLDSPFunctional.h:114-213) around one stateful function, then a gain:
+  //   fn(v) = Lopass(coeffs)((clamp(v.row(0) * 3, -1, 1) + SawGen(freq)) * v.row(1));   out = F(fn, {x, m}) * 0.5
+  // The objects fn uses live across its calls, as in user code (one fn called twice per vector / once per two vectors).
+  int mlref_rate_function_run(int up, size_t V, size_t T, const float* freq, const float* lopassCoeffs, const float* x, const float* m, float* out)
+  {
+    for (size_t v = 0; v < V; ++v)
+    {
+      Upsample2xFunction<2> upFn;
+      Downsample2xFunction<2> downFn;
+      SawGen saw;
+      Lopass lp;
+      lp.coeffs = {lopassCoeffs[0], lopassCoeffs[1], lopassCoeffs[2]};
+      const float f = freq[v];
+      auto fn = [&](const DSPVectorArray<2> vv) {
+        const DSPVector sat = clamp(vv.constRow(0) * DSPVector(3.0f), DSPVector(-1.0f), DSPVector(1.0f));
+        const DSPVector mix = sat + saw(DSPVector(f));
+        return lp(mix * vv.constRow(1));
+      };
+      for (size_t t = 0; t < T; ++t)
+      {
+        DSPVector vx, vm;
+        load(vx, x + (v * T + t) * kFloatsPerDSPVector);
+        load(vm, m + (v * T + t) * kFloatsPerDSPVector);
+        const DSPVectorArray<2> in = concatRows(vx, vm);
+        const DSPVector y = up ? upFn(fn, in) : downFn(fn, in);
+        store(y * DSPVector(0.5f), out + (v * T + t) * kFloatsPerDSPVector);
+      }
+    }
+    return MLGPU_OK;
+  }
+
   // ---- Downsampler / Upsampler: the reference classes driven vector by vector, same contract as mlorc_resample ----
   namespace
   {

@@ -1,0 +1,43 @@
+// USER CODE #4 written against madronalib's public API only: an oversampled waveshaper (Upsample2xFunction around a
+// stateful function) and a half-rate branch (Downsample2xFunction with two input rows), as MLDSPFunctional.h:104-213
+// documents them. Compiled unchanged against the reference (oracle/dropin_ref.cpp) and against include/mlgpu/compat
+// (dropin_gpu.cpp).
+struct OversampleState
+{
+  Upsample2xFunction<1> upper;
+  Downsample2xFunction<2> downer;
+  Lopass preFilter;  // lives inside the 2x function: sees 128 samples per DSPVector of input
+  SineGen carrier;   // lives inside the half-rate function: advances 32 samples per DSPVector of input
+  OnePole smooth;
+  DCBlocker dc;
+};
+
+inline void oversampleSetup(OversampleState& s)
+{
+  s.preFilter.coeffs = Lopass::makeCoeffs(0.15f, 0.9f);
+  s.smooth.coeffs = OnePole::makeCoeffs(0.1f);
+  s.dc.coeffs = DCBlocker::makeCoeffs(0.002f);
+}
+
+// inputs: [0] audio, [1] modulation.  outputs: [0] shaped, [1] mix
+inline void oversampleProcess(AudioContext* ctx, void* stateData)
+{
+  OversampleState* s = static_cast<OversampleState*>(stateData);
+  const DSPVector in = ctx->inputs[0];
+  const DSPVector mod = ctx->inputs[1];
+
+  DSPVector shaped = s->upper(
+      [&](const DSPVector x)
+      {
+        DSPVector driven = s->preFilter(x * DSPVector(4.0f));
+        return clamp(driven - driven * driven * driven * DSPVector(0.333f), DSPVector(-1.f), DSPVector(1.f));
+      },
+      in);
+
+  DSPVector lofi = s->downer(
+      [&](const DSPVectorArray<2> v) { return s->smooth(v.constRow(0) * s->carrier(DSPVector(0.01f)) + v.constRow(1) * DSPVector(0.1f)); },
+      concatRows(in, mod));
+
+  ctx->outputs[0] = s->dc(shaped);
+  ctx->outputs[1] = lofi * DSPVector(0.5f) + shaped * DSPVector(0.5f);
+}

@@ -214,6 +214,20 @@ class _Checker:
         assert fnc(octaves, 1 if up else 0, V, Sin // 64, _ptr(state, c_f32p), _ptr(x, c_f32p), _ptr(out, c_f32p)) == 0
         return out
 
+    def rate_function_run(self, up, freq, lopass_coeffs, x, m):
+        """Upsample2xFunction<2> / Downsample2xFunction<2> around fn = Lopass((clamp(x*3,-1,1) + SawGen(freq)) * m), * 0.5.
+        freq [V], x / m [V][64*T]; every voice starts from default-constructed objects."""
+        fnc = getattr(self.lib, self.prefix + "rate_function_run")
+        fnc.restype = ctypes.c_int
+        fnc.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p]
+        x = np.ascontiguousarray(x, np.float32)
+        m = np.ascontiguousarray(m, np.float32)
+        fr = np.ascontiguousarray(freq, np.float32)
+        co = np.ascontiguousarray(lopass_coeffs, np.float32)
+        out = np.empty_like(x)
+        assert fnc(1 if up else 0, x.shape[0], x.shape[1] // 64, _ptr(fr, c_f32p), _ptr(co, c_f32p), _ptr(x, c_f32p), _ptr(m, c_f32p), _ptr(out, c_f32p)) == 0
+        return out
+
     def vop(self, vop, V, T, a=None, b=None):
         out = np.empty((V, 64 * T), np.float32)
         a = None if a is None else np.ascontiguousarray(a, np.float32)

@@ -137,7 +137,13 @@ def main():
         d[f"down{octaves}"] = ref.resample(octaves, False, np.zeros((octaves * 9, 4), np.float32), d["x"])
         d[f"up{octaves}"] = ref.resample(octaves, True, np.zeros((octaves * 9, 4), np.float32), d["x"])
     np.savez_compressed(os.path.join(HERE, "resample.npz"), **d)
-    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz", "resample.npz"):
+    # ---- rate regions: Upsample2xFunction / Downsample2xFunction around a stateful fn ----
+    from inputs import region_case
+    x, m, freq = region_case(4, 10)
+    co = ref.make_coeffs("lopass", 0.2, 0.8)
+    np.savez_compressed(os.path.join(HERE, "regions.npz"), x=x, m=m, freq=freq, co=co, up=ref.rate_function_run(True, freq, co, x, m),
+                        down=ref.rate_function_run(False, freq, co, x, m))
+    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz", "resample.npz", "regions.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

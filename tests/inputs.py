@@ -307,3 +307,12 @@ def delay_case(mk, name, V, T, seed=0):
     if name == "pitchbend":
         return dict(kind=P.PITCHBENDABLE_DELAY, max_delay=max_delay, state0=np.zeros((10, V), np.uint32), inputs=[x, slow])
     raise KeyError(name)
+
+
+def region_case(V, T, seed=0):
+    """Inputs of the rate-region cases (Upsample2xFunction / Downsample2xFunction around one stateful fn): noise x, a slow
+    modulator m, per-voice oscillator frequency, Lopass coefficients (omega 0.2, k 0.8 from the caller's makeCoeffs)."""
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + np.uint32(3 + seed), 64 * T)
+    m = (0.5 + 0.5 * np.sin(np.arange(64 * T) * 0.01)[None, :] * np.linspace(0.2, 1.0, V)[:, None]).astype(np.float32)
+    freq = (55.0 * 2.0 ** (6.0 * np.arange(V) / max(1, V)) / 48000.0).astype(np.float32)
+    return x, m, freq

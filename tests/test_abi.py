@@ -43,7 +43,8 @@ def test_python_enums_match_header():
     h = _header()
     vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(MLGPU_[A-Z0-9_]+)\s*=\s*(\d+)", h)}
     for cls, prefix in ((constants.Op, "MLGPU_OP_"), (constants.Proc, "MLGPU_PROC_"), (constants.Layout, "MLGPU_LAYOUT_"),
-                        (constants.RowOp, "MLGPU_ROWOP_"), (constants.Status, "MLGPU_"), (constants.Vop, "MLGPU_VOP_")):
+                        (constants.RowOp, "MLGPU_ROWOP_"), (constants.Status, "MLGPU_"), (constants.Vop, "MLGPU_VOP_"),
+                        (constants.Region, "MLGPU_REGION_"), (constants.Route, "MLGPU_ROUTE_")):
         for k, v in vars(cls).items():
             if k.startswith("_") or not isinstance(v, int):
                 continue

@@ -24,6 +24,8 @@ def _gpu_lib():
     L.dropin_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
     L.plate_gpu_run.restype = ctypes.c_int
     L.plate_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    L.oversample_gpu_run.restype = ctypes.c_int
+    L.oversample_gpu_run.argtypes = L.plate_gpu_run.argtypes
     return L
 
 
@@ -38,6 +40,8 @@ def _ref_lib():
     L.dropin_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
     L.plate_ref_run.restype = ctypes.c_int
     L.plate_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
+    L.oversample_ref_run.restype = ctypes.c_int
+    L.oversample_ref_run.argtypes = L.plate_ref_run.argtypes
     return L
 
 
@@ -106,6 +110,30 @@ def test_reverb_with_feedback_state_same_source_same_bits(launches):
     assert_bits_equal(gotL, wantL, True, "plate reverb left")
     assert_bits_equal(gotR, wantR, True, "plate reverb right")
     assert np.abs(wantL[:, 64 * 40:]).max() > 1e-4   # the tail is still sounding 20 vectors after the input stopped
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launches", [1, 3, 9])
+def test_oversampled_functions_same_source_same_bits(launches):
+    """tests/cpp/dropin_oversample.h: Upsample2xFunction<1> around a stateful waveshaper and Downsample2xFunction<2> around a
+    half-rate modulator — compiled unchanged against the reference and against the shim (rate regions of the fused graph);
+    process calls of 9, 3 and 1 vectors (odd counts: the half-rate function pairs vectors across launches)."""
+    from inputs import lcg_noise
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    V, T = 70, 9
+    in0 = lcg_noise(np.arange(V, dtype=np.uint32) + 5, 64 * T) * np.float32(0.7)
+    in1 = (0.5 * np.sin(np.arange(64 * T)[None, :] * 0.004 * (1 + np.arange(V)[:, None] % 5))).astype(np.float32)
+    want0, want1 = np.zeros_like(in0), np.zeros_like(in0)
+    assert Lr.oversample_ref_run(V, T, in0.ctypes.data_as(c_f32p), in1.ctypes.data_as(c_f32p), want0.ctypes.data_as(c_f32p),
+                                 want1.ctypes.data_as(c_f32p)) == 0
+    got0, got1 = np.zeros_like(in0), np.zeros_like(in0)
+    err = ctypes.create_string_buffer(4096)
+    st = Lg.oversample_gpu_run(V, T, launches, in0.ctypes.data_as(c_f32p), in1.ctypes.data_as(c_f32p), got0.ctypes.data_as(c_f32p),
+                               got1.ctypes.data_as(c_f32p), err, 4096)
+    assert st == 0, err.value.decode()
+    assert_bits_equal(got0, want0, True, "oversampled shaper")
+    assert_bits_equal(got1, want1, True, "half-rate branch + mix")
+    assert np.abs(want0).max() > 0.1 and np.abs(want1[:, 64:]).max() > 0.05
 
 
 class _Ev(ctypes.Structure):

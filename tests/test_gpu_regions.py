@@ -1,0 +1,124 @@
+"""GPU parity of rate regions in a fused graph: Upsample2xFunction / Downsample2xFunction (MLDSPFunctional.h:114-213)
+with the wrapped function written out as graph nodes. Bit-exact against the oracle's block restatement and against golden
+outputs of the reference's own objects (tests/golden/regions.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from inputs import assert_bits_equal, region_case
+from madronalib_amd.constants import Layout, Op, Proc, Region
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regions.npz"))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import madronalib_amd as ml
+    e = ml.Engine(0)
+    yield e
+    e.close()
+
+
+def region_graph(eng, V, kind, freq, co, voices_per_lane=0):
+    """out = F(fn, {x, m}) * 0.5 with fn(v) = Lopass((clamp(v0 * 3, -1, 1) + SawGen(freq)) * v1), as
+    oracle/ref_wrapper.cpp mlref_rate_function_run builds it from the reference's objects."""
+    import madronalib_amd as ml
+    g = ml.Graph(eng, V, voices_per_lane=voices_per_lane)
+    g.add("x", "input")
+    g.add("m", "input")
+    g.add("three", "const", value=3.0)
+    g.add("lo", "const", value=-1.0)
+    g.add("hi", "const", value=1.0)
+    g.add("half", "const", value=0.5)
+    g.add("freq", "param")
+    g.begin_region(kind, ["x", "m"], ["rx", "rm"])
+    g.add("drive", "op", Op.MULTIPLY, ["rx", "three"])
+    g.add("sat", "op", Op.CLAMP, ["drive", "lo", "hi"])
+    g.add("saw", "proc", Proc.SAW_GEN, ["freq"])
+    g.add("mix", "op", Op.ADD, ["sat", "saw"])
+    g.add("am", "op", Op.MULTIPLY, ["mix", "rm"])
+    g.add("lp", "proc", Proc.LOPASS, ["am"])
+    g.end_region("lp", "y")
+    g.add("out", "op", Op.MULTIPLY, ["y", "half"])
+    g.add_output("out")
+    g.compile()
+    g.set_param("freq", freq)
+    g.set_coeffs("lp", [np.full(V, c, np.float32) for c in co])
+    return g
+
+
+def run(g, x, m, splits, layout=Layout.QUAD):
+    outs, t0 = [], 0
+    for n in splits:
+        sl = slice(64 * t0, 64 * (t0 + n))
+        (y,) = g.process_host(n, {"x": np.ascontiguousarray(x[:, sl]), "m": np.ascontiguousarray(m[:, sl])}, layout)
+        outs.append(y)
+        t0 += n
+    return np.concatenate(outs, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,key", [(Region.UPSAMPLE_2X, "up"), (Region.DOWNSAMPLE_2X, "down")])
+def test_rate_regions_golden(eng, kind, key):
+    x, m, freq, co = GOLD["x"], GOLD["m"], GOLD["freq"], GOLD["co"]
+    g = region_graph(eng, x.shape[0], kind, freq, co)
+    assert_bits_equal(run(g, x, m, [10], Layout.VOICE_MAJOR), GOLD[key], True, f"{key} vs the reference objects")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vpl", [1, 2])
+@pytest.mark.parametrize("kind", [Region.UPSAMPLE_2X, Region.DOWNSAMPLE_2X])
+def test_rate_regions_vs_oracle_split_launches(eng, oracle, kind, vpl):
+    """Launch boundaries are invisible, also odd ones (a Downsample2x region pairs vectors 2k, 2k + 1 across launches);
+    clear() restarts the pairing and every object."""
+    V, T = 300, 12
+    x, m, freq = region_case(V, T, seed=9)
+    co = oracle.make_coeffs("lopass", 0.2, 0.8)
+    want = oracle.rate_function_run(kind == Region.UPSAMPLE_2X, freq, co, x, m)
+    g = region_graph(eng, V, kind, freq, co, voices_per_lane=vpl)
+    assert_bits_equal(run(g, x, m, [12]), want, True, "one launch")
+    g.clear()
+    assert_bits_equal(run(g, x, m, [3, 1, 5, 3]), want, True, "odd split launches")
+    g.clear()
+    assert_bits_equal(run(g, x, m, [1] * 12), want, True, "vector by vector")
+
+
+@pytest.mark.gpu
+def test_region_rules(eng):
+    import madronalib_amd as ml
+    g = ml.Graph(eng, 64)
+    g.add("x", "input")
+    g.add("c", "control")
+    g.add("p", "param")
+    with pytest.raises(ml.MlgpuError):
+        g.add("hb", "proc", Proc.HALF_BAND, ["x"])                  # only begin_region / end_region make these
+    with pytest.raises(ml.MlgpuError):
+        g.end_region("x")                                           # no region open
+    (rx,) = g.begin_region(Region.UPSAMPLE_2X, ["x"])
+    with pytest.raises(ml.MlgpuError):
+        g.begin_region(Region.UPSAMPLE_2X, ["x"])                   # no nesting
+    with pytest.raises(ml.MlgpuError):
+        g.add("bad", "op", Op.ADD, [rx, "x"])                       # an outer audio-rate signal does not exist at 2x
+    with pytest.raises(ml.MlgpuError):
+        g.add("bad2", "op", Op.ADD, [rx, "c"])                      # nor does a control
+    with pytest.raises(ml.MlgpuError):
+        g.add("fb", "feedback")
+    ok = g.add("ok", "op", Op.MULTIPLY, [rx, "p"])                  # per-voice floats are fine
+    with pytest.raises(ml.MlgpuError):
+        g.end_region("x")                                           # result must be a node of the region
+    with pytest.raises(ml.MlgpuError):
+        g.add_output(ok) or g.compile()                             # region still open / output inside a region
+    y = g.end_region(ok, "y")
+    with pytest.raises(ml.MlgpuError):
+        g.add("leak", "op", Op.ADD, [ok, "x"])                      # region nodes are invisible outside
+    g2 = ml.Graph(eng, 64)
+    g2.add("x", "input")
+    (r2,) = g2.begin_region(Region.DOWNSAMPLE_2X, ["x"])
+    y2 = g2.end_region(r2, "y")                                     # identity fn: down then up, one vector late
+    g2.add_output(y2)
+    g2.compile()
+    assert g2.num_state(y2) == 9 + 64 and g2.num_state(r2) == 9
+    x = np.random.default_rng(1).standard_normal((64, 128)).astype(np.float32)
+    (out,) = g2.process_host(2, {"x": x}, Layout.QUAD)
+    assert (out[:, :64] == 0).all() and np.abs(out[:, 64:]).max() > 0

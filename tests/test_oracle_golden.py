@@ -185,3 +185,13 @@ def test_reference_sinegen_cycle(oracle):
     st = oracle.chain_clear([Proc.SINE_GEN], 1)
     v = oracle.chain_process([Proc.SINE_GEN], 1, np.zeros((0, 1), np.float32), st, None, np.array([1.0 / 64], np.float32))[0]
     assert abs(v[63]) < 10.0 ** (-120.0 / 20.0)
+
+
+@pytest.mark.parametrize("which", ["up", "down"])
+def test_rate_functions_golden(oracle, which):
+    """tests/golden/regions.npz: outputs of the reference's Upsample2xFunction / Downsample2xFunction objects."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regions.npz"))
+    got = oracle.rate_function_run(which == "up", g["freq"], g["co"], g["x"], g["m"])
+    assert (got.view(np.uint32) == g[which].view(np.uint32)).all()
+    assert np.abs(g[which]).max() > 0.1

@@ -258,3 +258,13 @@ def test_resamplers_match_reference(oracle, ref, octaves, up):
         xs = np.ascontiguousarray(x[:, call * 64 * Tin:(call + 1) * 64 * Tin])
         assert_bits_equal(oracle.resample(octaves, up, st_o, xs), ref.resample(octaves, up, st_r, xs), True, f"resample call {call}")
         assert_bits_equal(st_o, st_r, True, "HalfBandFilter state")
+
+
+@pytest.mark.parametrize("up", [True, False])
+def test_rate_functions_match_reference(oracle, ref, up):
+    """Upsample2xFunction<2> / Downsample2xFunction<2> (MLDSPFunctional.h:114-213) around a stateful fn: the oracle's block
+    restatement == the reference classes, odd vector count included."""
+    from inputs import region_case
+    x, m, freq = region_case(7, 11, seed=4)
+    co = ref.make_coeffs("lopass", 0.2, 0.8)
+    assert_bits_equal(oracle.rate_function_run(up, freq, co, x, m), ref.rate_function_run(up, freq, co, x, m), True, f"rate function up={up}")
