@@ -562,6 +562,30 @@ int mlgpu_events_clear_events(mlgpu_events* ev);                            /* c
 int mlgpu_events_process(mlgpu_events* ev, size_t n_vectors, int start_offset, float* const* d_outputs, int layout);
 
 /* ------------------------------------------------------------------------- */
+/* published signals                                                         */
+/*
+ * SignalProcessor::PublishedSignal (source/app/MLSignalProcessor.h:26-105, MLSignalProcessor.cpp:9-38): a decimated,
+ * frame-major copy of `channels` signals of a few voices for code outside the DSP calculation (displays). write() is
+ * `storePublishedSignal(name, DSPVectorArray<channels>, 64, voice)` for voices first_voice .. first_voice + n_voices - 1 in
+ * rotation, for n_vectors DSPVectors: every (1 << octaves_down)-th frame is kept (no filtering) and the ring receives, per
+ * DSPVector, [voice][kept frame][channel]. The ring is the reference's DSPBuffer of max_frames * channels * max_voices
+ * floats; read / read_latest / peek_latest are its PublishedSignal::read / readLatest / peekLatest (frames of `channels`
+ * floats; the return value counts floats, like the reference's). write() waits for the device (one gather kernel and one
+ * D2H copy through pinned memory per call).
+ */
+typedef struct mlgpu_published_signal mlgpu_published_signal;
+int mlgpu_published_signal_create(mlgpu_engine* e, int max_frames, int max_voices, int channels, int octaves_down, mlgpu_published_signal** out);
+int mlgpu_published_signal_destroy(mlgpu_published_signal* p);
+int mlgpu_published_signal_write(mlgpu_published_signal* p, size_t n_vectors, const float* const* d_channels, int layout, size_t n_voices_total,
+                                 size_t first_voice, size_t n_voices);
+size_t mlgpu_published_signal_num_channels(mlgpu_published_signal* p);      /* getNumChannels */
+size_t mlgpu_published_signal_read_available(mlgpu_published_signal* p);    /* getReadAvailable (floats) */
+size_t mlgpu_published_signal_available_frames(mlgpu_published_signal* p);  /* getAvailableFrames */
+size_t mlgpu_published_signal_read(mlgpu_published_signal* p, float* dest, size_t frames_requested);
+size_t mlgpu_published_signal_read_latest(mlgpu_published_signal* p, float* dest, size_t frames_requested);
+void mlgpu_published_signal_peek_latest(mlgpu_published_signal* p, float* dest, size_t frames_requested);
+
+/* ------------------------------------------------------------------------- */
 /* sample-rate conversion by powers of two                                   */
 /*
  * Downsampler / Upsampler (MLDSPFilters.h:1316-1473): a cascade of HalfBandFilters (:1245-1310), one per octave, for every

@@ -411,6 +411,55 @@ class Events:
         return np.stack([b.download(np.float32, V * T * 64).reshape(V, T * 64) for b in bufs])
 
 
+class PublishedSignal:
+    """SignalProcessor::PublishedSignal (source/app/MLSignalProcessor.h:26-105): a decimated frame-major copy of a few
+    channels of a few voices, for displays. write() takes device signals (DeviceBuffer) of `n_voices_total` voices."""
+
+    def __init__(self, engine, max_frames, max_voices, channels, octaves_down):
+        self.engine, self.L = engine, engine.L
+        self.channels = int(channels)
+        h = ctypes.c_void_p()
+        engine._check(self.L.mlgpu_published_signal_create(engine.h, int(max_frames), int(max_voices), self.channels, int(octaves_down), ctypes.byref(h)))
+        self.h = h
+        engine._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None) and self.engine.h:
+            self.L.mlgpu_published_signal_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def write(self, n_vectors, d_channels, n_voices_total, first_voice=0, n_voices=None, layout=Layout.QUAD):
+        arr = (ctypes.c_void_p * self.channels)(*[ctypes.c_void_p(d.ptr) for d in d_channels])
+        nv = n_voices_total - first_voice if n_voices is None else n_voices
+        self.engine._check(self.L.mlgpu_published_signal_write(self.h, int(n_vectors), arr, int(layout), int(n_voices_total), int(first_voice), int(nv)))
+
+    def read_available(self):
+        return int(self.L.mlgpu_published_signal_read_available(self.h))
+
+    def available_frames(self):
+        return int(self.L.mlgpu_published_signal_available_frames(self.h))
+
+    def _get(self, fn, frames):
+        out = np.zeros(int(frames) * self.channels, np.float32)
+        n = fn(self.h, _np_ptr(out), int(frames))
+        return out, (int(n) if n is not None else None)
+
+    def read(self, frames):
+        return self._get(self.L.mlgpu_published_signal_read, frames)
+
+    def read_latest(self, frames):
+        return self._get(self.L.mlgpu_published_signal_read_latest, frames)
+
+    def peek_latest(self, frames):
+        return self._get(self.L.mlgpu_published_signal_peek_latest, frames)[0]
+
+
 class Resampler:
     """Downsampler / Upsampler (MLDSPFilters.h:1316-1473) for V voices: a HalfBandFilter cascade, one stage per octave."""
 

@@ -167,6 +167,15 @@ def _declare(L):
     sig("mlgpu_resampler_get_state", i, [vp, vp])
     sig("mlgpu_resampler_set_state", i, [vp, vp])
     sig("mlgpu_resampler_process", i, [vp, sz, vp, i, vp, i])
+    sig("mlgpu_published_signal_create", i, [vp, i, i, i, i, pp])
+    sig("mlgpu_published_signal_destroy", i, [vp])
+    sig("mlgpu_published_signal_write", i, [vp, sz, pp, i, sz, sz, sz])
+    sig("mlgpu_published_signal_num_channels", sz, [vp])
+    sig("mlgpu_published_signal_read_available", sz, [vp])
+    sig("mlgpu_published_signal_available_frames", sz, [vp])
+    sig("mlgpu_published_signal_read", sz, [vp, vp, sz])
+    sig("mlgpu_published_signal_read_latest", sz, [vp, vp, sz])
+    sig("mlgpu_published_signal_peek_latest", None, [vp, vp, sz])
     sig("mlgpu_dspbuffer_create", vp, [])
     sig("mlgpu_dspbuffer_destroy", None, [vp])
     sig("mlgpu_dspbuffer_resize", sz, [vp, i])

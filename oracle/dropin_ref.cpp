@@ -202,3 +202,40 @@ extern "C" int e2s_ref_run(int polyphony, int mpe, int unison, double sr, float 
   }
   return 0;
 }
+
+// ---- SignalProcessor::PublishedSignal driven as processors drive it: storePublishedSignal per voice in rotation ----
+// ops[i]: 0 = write the next DSPVector of every voice (2 channels), 1 = read(args[i] frames), 2 = readLatest(args[i]),
+// 3 = peekLatest(args[i]). Results of the read ops are concatenated in `out`; counts[i] = floats the op returned.
+extern "C" int published_ref_run(int maxFrames, int maxVoices, int octavesDown, int nVoices, size_t T, const float* ch0, const float* ch1,
+                                 const int* ops, const int* args, int nOps, float* out, size_t* counts)
+{
+  SignalProcessor::PublishedSignal ps(maxFrames, maxVoices, 2, octavesDown);
+  size_t t = 0, pos = 0;
+  for (int i = 0; i < nOps; ++i)
+  {
+    counts[i] = 0;
+    if (ops[i] == 0)
+    {
+      if (t >= T) return 1;
+      for (int v = 0; v < nVoices; ++v)
+      {
+        DSPVectorArray<2> x;
+        load(x.row(0), ch0 + ((size_t)v * T + t) * kFloatsPerDSPVector);
+        load(x.row(1), ch1 + ((size_t)v * T + t) * kFloatsPerDSPVector);
+        ps.writeQuick(x, kFloatsPerDSPVector, v);
+      }
+      ++t;
+    }
+    else if (ops[i] == 1)
+      counts[i] = ps.read(out + pos, args[i]);
+    else if (ops[i] == 2)
+      counts[i] = ps.readLatest(out + pos, args[i]);
+    else
+    {
+      ps.peekLatest(out + pos, args[i]);
+      counts[i] = (size_t)args[i] * 2;
+    }
+    pos += (size_t)args[i] * 2 * (ops[i] != 0);
+  }
+  return 0;
+}
