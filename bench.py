@@ -139,9 +139,11 @@ def setup_workload(eng, name, V, T, lo, total):
         N = V // P
         ev = ml.Events(eng, N, P, 48000.0)
         ev.configure(glide_seconds=0.01, drift=0.5)
+        rows = [int(r) for r in os.environ.get("MLGPU_EVENT_ROWS", "0,1,2,3,4,5,6,7").split(",")]   # e.g. "0,1": pitch and gate only
+        ev.set_wanted_rows(rows)
         rng = np.random.default_rng(lo + 1)
         held = {}
-        outs = [[eng.alloc(4 * n) for _ in range(8)] for _ in range(2)]
+        outs = [[eng.alloc(4 * n) if r in rows else None for r in range(8)] for _ in range(2)]
         k = [0]
 
         def launch():
@@ -160,8 +162,9 @@ def setup_workload(eng, name, V, T, lo, total):
             k[0] += 1
         # 8 rows x 4 B per voice-sample written; per voice and DSPVector 7 glides x 5 state words read and written, per
         # voice and launch 23 scalar state words read and written
-        alg = 32.0 * n + V * T * 4.0 * 35 * 2 + V * 4.0 * 23 * 2
-        return launch, alg, "e2s_kernel", ("EventsToSignals: 16384 instruments x 16 voices, 8 control signals out, sparse note events "
+        glides = sum({0: 2, 3: 2, 4: 1, 5: 1, 6: 1}.get(r, 0) for r in rows) + (2 if 0 not in rows else 0)   # bend and drift always run
+        alg = 4.0 * len(rows) * n + V * T * 4.0 * 5 * glides * 2 + V * 4.0 * 23 * 2
+        return launch, alg, "e2s_kernel", (f"EventsToSignals: 16384 instruments x 16 voices, {len(rows)} control signals out, sparse note events "
                                            "(host routing + record upload inside the step)"), ev
     if name == "resample":
         r = ml.Resampler(eng, V, 2, False)

@@ -463,7 +463,9 @@ int mlgpu_graph_add_route(mlgpu_graph* g, int route, const int* input_nodes, int
 int mlgpu_graph_add_proc(mlgpu_graph* g, int proc_kind, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_output(mlgpu_graph* g, int node);
-int mlgpu_graph_node(mlgpu_graph* g, const char* name); /* id of the node called `name`, or < 0 */
+int mlgpu_graph_node(mlgpu_graph* g, const char* name);
+/* how many times `node` is referenced: as an input of other nodes, as a feedback source, as a graph output */
+int mlgpu_graph_node_use_count(mlgpu_graph* g, int node); /* id of the node called `name`, or < 0 */
 int mlgpu_graph_num_nodes(mlgpu_graph* g);
 /* Voices evaluated by one wavefront lane (before compile): 0 = automatic (default), 1, or 2. Two voices per lane interleave
  * two independent dependency chains, which helps arithmetic-bound graphs; results are identical. */
@@ -552,6 +554,10 @@ int mlgpu_events_set_pitch_bend_semitones(mlgpu_events* ev, float f);
 int mlgpu_events_set_mpe_pitch_bend_semitones(mlgpu_events* ev, float f);
 int mlgpu_events_set_pitch_glide_seconds(mlgpu_events* ev, float f);
 int mlgpu_events_set_drift_amount(mlgpu_events* ev, float f);
+/* Rows a consumer never reads need not be made: bit r of `mask` = row r of mlgpu_events_process' outputs (pitch, gate, vox,
+ * z, x, y, mod, elapsed time); default all. Rows outside the mask are not computed at all (their glides do not advance:
+ * choose the mask once, before the first process call) and their output pointers must be NULL. */
+int mlgpu_events_set_wanted_rows(mlgpu_events* ev, unsigned mask);
 size_t mlgpu_events_num_voices(mlgpu_events* ev);
 int mlgpu_events_newest_voice(mlgpu_events* ev, size_t instrument);        /* getNewestVoice() */
 int mlgpu_events_add_event(mlgpu_events* ev, size_t instrument, const mlgpu_event* e);   /* addEvent, :367-372 */

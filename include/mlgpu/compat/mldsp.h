@@ -1308,6 +1308,7 @@ class VoiceProgram
   size_t voices_;
   size_t nIn_{0}, nOut_{0};
   bool usesVoice_{false};
+  unsigned voiceRowMask_{0};  // which of the 8 voice control rows the captured code reads: only those are graph inputs
 
  public:
   VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state)
@@ -1348,13 +1349,29 @@ class VoiceProgram
         ctx->inputs[(int)c] = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g_, ("in" + std::to_string(c)).c_str())), 0.f));
       // the 8 rows of this lane's voice (EventsToSignals) are further streamed inputs, after the audio inputs; the first pass
       // finds out whether the code reads them at all
-      if (pass == 0 || ctx->usesVoice_)
-        for (int r = 0; r < kNumVoiceOutputRows; ++r)
-          ctx->voice_.outputs.row(r) = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g_, ("voice" + std::to_string(r)).c_str())), 0.f));
+      int rowNode[kNumVoiceOutputRows];
+      for (int r = 0; r < kNumVoiceOutputRows; ++r)
+      {
+        rowNode[r] = -1;
+        if (pass == 0 || ((voiceRowMask_ >> r) & 1u))
+        {
+          rowNode[r] = cap.ret(mlgpu_graph_add_input(g_, ("voice" + std::to_string(r)).c_str()));
+          ctx->voice_.outputs.row(r) = DSPVector(Sig(rowNode[r], 0.f));
+        }
+        else
+          ctx->voice_.outputs.row(r) = DSPVector(0.f);  // never read (pass 1 saw no use of it)
+      }
       for (size_t c = 0; c < nOut_; ++c) ctx->outputs[(int)c] = DSPVector(0.f);
       body(ctx);
+      if (pass == 0 && ctx->usesVoice_)
+        for (int r = 0; r < kNumVoiceOutputRows; ++r)
+        {
+          bool used = mlgpu_graph_node_use_count(g_, rowNode[r]) > 0;
+          for (size_t c = 0; c < nOut_; ++c) used = used || (ctx->outputs[(int)c].sig_[0].node == rowNode[r]);
+          if (used) voiceRowMask_ |= 1u << r;
+        }
     }
-    usesVoice_ = ctx->usesVoice_;
+    usesVoice_ = voiceRowMask_ != 0;
     for (auto& kv : cap.feedbackOfOrd)
     {
       if (kv.first >= (int)cap.nodeOfOrd.size()) throw std::logic_error("mldsp GPU shim: the process function took different paths in its two capture passes");
@@ -1379,6 +1396,7 @@ class VoiceProgram
   }
 
   size_t voices() const { return voices_; }
+  unsigned voiceRowMask() const { return voiceRowMask_; }  // bit r: the captured code reads voice row r (VoiceOutputSignals)
   mlgpu_graph* graph() const { return g_; }
   const char* source() const { return mlgpu_graph_source(g_); }  // the generated HIP kernel
 
@@ -1406,8 +1424,12 @@ class VoiceProgram
     std::vector<float*> po;
     for (auto* s : ins) pi.push_back(s->data());
     // rows the code does not read still need a valid pointer: any output buffer of this launch will do
-    if (usesVoice_)
-      for (int r = 0; r < kNumVoiceOutputRows; ++r) pi.push_back(voiceRows[r] ? voiceRows[r] : outs[0]->data());
+    for (int r = 0; r < kNumVoiceOutputRows; ++r)
+      if ((voiceRowMask_ >> r) & 1u)
+      {
+        if (!voiceRows[r]) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: the program reads voice row " + std::to_string(r) + "; pass it");
+        pi.push_back(voiceRows[r]);
+      }
     for (auto* s : outs) po.push_back(s->data());
     const int inLayout = ins.empty() ? MLGPU_LAYOUT_QUAD : ins[0]->layout();
     eng_.check(mlgpu_graph_process(g_, outs[0]->vectors(), pi.data(), inLayout, po.data(), outs[0]->layout()));
@@ -1441,6 +1463,7 @@ class SynthProgram
   {
     eng_.check(mlgpu_events_create(e.handle(), nInstruments, polyphony_, &ev_));
     eng_.check(mlgpu_events_set_sample_rate(ev_, (double)sampleRate));
+    eng_.check(mlgpu_events_set_wanted_rows(ev_, prog_.voiceRowMask()));  // rows processVoice never reads are not made
   }
   SynthProgram(const SynthProgram&) = delete;
   SynthProgram& operator=(const SynthProgram&) = delete;
@@ -1468,16 +1491,20 @@ class SynthProgram
     {
       rows_.clear();
       voiceOut_.clear();
-      for (int r = 0; r < kNumVoiceOutputRows; ++r) rows_.emplace_back(eng_, voices(), nVectors);
+      for (int r = 0; r < kNumVoiceOutputRows; ++r) rows_.emplace_back(eng_, ((prog_.voiceRowMask() >> r) & 1u) ? voices() : 1, nVectors);
       for (size_t c = 0; c < nOut_; ++c) voiceOut_.emplace_back(eng_, voices(), nVectors);
       capacityT_ = nVectors;
     }
     float* rowPtrs[kNumVoiceOutputRows];
-    for (int r = 0; r < kNumVoiceOutputRows; ++r) rowPtrs[r] = rows_[r].data();
+    std::vector<const float*> pi;
+    for (int r = 0; r < kNumVoiceOutputRows; ++r)
+    {
+      rowPtrs[r] = ((prog_.voiceRowMask() >> r) & 1u) ? rows_[r].data() : nullptr;
+      if (rowPtrs[r]) pi.push_back(rowPtrs[r]);
+    }
     eng_.check(mlgpu_events_process(ev_, nVectors, startOffset, rowPtrs, MLGPU_LAYOUT_QUAD));
     std::vector<float*> po;
     for (auto& s : voiceOut_) po.push_back(s.data());
-    std::vector<const float*> pi(rowPtrs, rowPtrs + kNumVoiceOutputRows);
     eng_.check(mlgpu_graph_process(prog_.graph(), nVectors, pi.data(), MLGPU_LAYOUT_QUAD, po.data(), MLGPU_LAYOUT_QUAD));
     for (size_t c = 0; c < nOut_; ++c)
       eng_.check(mlgpu_mixdown_groups(eng_.handle(), voiceOut_[c].data(), MLGPU_LAYOUT_QUAD, nInstruments_, (size_t)polyphony_, nVectors,

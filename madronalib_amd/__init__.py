@@ -389,6 +389,11 @@ class Events:
         if drift is not None:
             c(L.mlgpu_events_set_drift_amount(h, float(drift)))
 
+    def set_wanted_rows(self, rows):
+        """rows: iterable of row indices (Events.ROWS order) that will be asked for; the others are not computed."""
+        self.wanted = sorted(set(int(r) for r in rows))
+        self.engine._check(self.L.mlgpu_events_set_wanted_rows(self.h, sum(1 << r for r in self.wanted)))
+
     def add_event(self, instrument, ev):
         self.engine._check(self.L.mlgpu_events_add_event(self.h, int(instrument), ctypes.byref(ev)))
 
@@ -406,9 +411,10 @@ class Events:
     def process_host(self, n_vectors, start_offset=0):
         """Test convenience: returns the 8 rows as numpy [8][V][64 T]."""
         eng, V, T = self.engine, self.V, int(n_vectors)
-        bufs = [eng.alloc(4 * V * T * 64) for _ in range(8)]
+        wanted = getattr(self, "wanted", list(range(8)))
+        bufs = [eng.alloc(4 * V * T * 64) if r in wanted else None for r in range(8)]
         self.process(T, start_offset, bufs, Layout.VOICE_MAJOR)
-        return np.stack([b.download(np.float32, V * T * 64).reshape(V, T * 64) for b in bufs])
+        return np.stack([np.zeros((V, T * 64), np.float32) if b is None else b.download(np.float32, V * T * 64).reshape(V, T * 64) for b in bufs])
 
 
 class PublishedSignal:

@@ -135,6 +135,7 @@ def _declare(L):
     sig("mlgpu_graph_num_nodes", i, [vp])
     sig("mlgpu_graph_compile", i, [vp])
     sig("mlgpu_graph_source", c.c_char_p, [vp])
+    sig("mlgpu_graph_node_use_count", i, [vp, i])
     sig("mlgpu_graph_emit", i, [vp, c.POINTER(vp), c.POINTER(c.c_size_t)])
     sig("mlgpu_graph_begin_region", i, [vp, i, c.POINTER(i), i, c.POINTER(i)])
     sig("mlgpu_graph_end_region", i, [vp, i, c.c_char_p])
@@ -156,6 +157,7 @@ def _declare(L):
     sig("mlgpu_events_set_mpe_pitch_bend_semitones", i, [vp, f])
     sig("mlgpu_events_set_pitch_glide_seconds", i, [vp, f])
     sig("mlgpu_events_set_drift_amount", i, [vp, f])
+    sig("mlgpu_events_set_wanted_rows", i, [vp, c.c_uint])
     sig("mlgpu_events_num_voices", sz, [vp])
     sig("mlgpu_events_newest_voice", i, [vp, sz])
     sig("mlgpu_events_add_event", i, [vp, sz, vp])

@@ -87,6 +87,7 @@ struct E2SArgs
   SignalView out[8];          // pitch, gate, vox, z, x, y, mod, elapsed time: V = instruments * polyphony voices
   size_t lanes, T;
   int group, polyphony, slotBase;  // lane = instrument * group + (voice slot - slotBase)
+  uint32_t rowMask;                // rows that are computed (mlgpu_events_set_wanted_rows); bit r = row r of `out`
   E2SSettings s;
 };
 
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
   const float pitchBendScale = (a.s.mpe && slot != 0) ? a.s.mpePitchBendRange : a.s.pitchBendRange;  // :417-423
   const double srD = (double)(float)a.s.sr;  // samplesToSeconds(uint32_t, float sr), :13-19
   const unsigned mainLane = (unsigned)((threadIdx.x & 63) / (unsigned)a.group) * (unsigned)a.group;
+  const bool wantTime = (a.rowMask & (1u << 7)) != 0;  // the elapsed-time row costs an f64 division per sample
 
   for (size_t t = 0; t < a.T; ++t)
   {
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
         if ((a.recs[r].typeTimeFlags & 0xFF) == REC_AWAKE) awake = true;
 
     float finalVelocity = velocity;
+    bool noteHere = false;  // a note record of this lane falls into this vector
     if (awake && active)
     {
       // ---- Voice::beginProcess, :75-113 ----
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
           case REC_SET_Y: cy = rc.v1; break;
           case REC_SET_Z: cz = rc.v1; break;
           case REC_SET_CHANNEL_PRESSURE: chanPress = rc.v1; break;
-          case REC_NOTE_ON: case REC_NOTE_RETRIG: finalVelocity = rc.v2; break;
-          case REC_NOTE_OFF: finalVelocity = 0.f; break;
+          case REC_NOTE_ON: case REC_NOTE_RETRIG: finalVelocity = rc.v2; noteHere = true; break;
+          case REC_NOTE_OFF: finalVelocity = 0.f; noteHere = true; break;
           default: break;
         }
       }
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
 
     // ---- rows that are one glide each: mod, x, y; z adds the smoothed channel pressure in MIDI mode (:437-445) ----
     // One short loop per row keeps the live state of the other rows out of the registers.
+    if (a.rowMask & (1u << 6))
     {
       Glide gl;
       gl.load(GS(1), ln);
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
         gl.store(GS(1), ln);
       }
     }
+    if (a.rowMask & (1u << 4))
     {
       Glide gl;
       gl.load(GS(2), ln);
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
         gl.store(GS(2), ln);
       }
     }
+    if (a.rowMask & (1u << 5))
     {
       Glide gl;
       gl.load(GS(3), ln);
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
         gl.store(GS(3), ln);
       }
     }
+    if (a.rowMask & (1u << 3))
     {
       Glide gz, gp;
       gz.load(GS(4), ln);
@@ -388,6 +395,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
         gp.store(GS(6), ln);
       }
     }
+    if (a.rowMask & (1u << 2))
     {
       const float vox = (float)(slot - 1);  // row kVoice: DSPVector((float)i - 1), :302
       const f32x4 v = {vox, vox, vox, vox};
@@ -406,6 +414,52 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
     }
     uint32_t nc = cursor;      // next note record
     bool preApplied = false;   // a note event's bookkeeping applies from the frame the previous one ended at
+    // Most vectors of most wavefronts hold no note event at all: then every frame is the same few steps (gate = velocity,
+    // one step of the pitch glide, the event age, bend and drift), written out without the record walk.
+    const bool quietWave = __builtin_amdgcn_ballot_w64(noteHere) == 0;
+    if (quietWave)
+    {
+      // one short loop per row, as above: the gate is the held velocity, the event age advances by ageStep per frame
+      {
+        const float g = on ? velocity : 0.f;
+        const f32x4 v = {g, g, g, g};
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) put(1, q, v);
+      }
+      if (wantTime)
+      {
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q)
+        {
+          f32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = on ? (float)((double)(age + (uint32_t)(q * 4 + k + 1) * ageStep) / srD) : 0.f;
+          put(7, q, v);
+        }
+      }
+      if (on) age += (uint32_t)MLGPU_FLOATS_PER_DSPVECTOR * ageStep;
+#pragma unroll 1
+      for (int q = 0; q < 16; ++q)
+      {
+        f32x4 oPitch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          const int n = q * 4 + k;
+          float vPitch = 0.f;
+          if (on)
+          {
+            vPitch = pitchGlideNext(pitch);
+            const float bendSig = gb.next(GS(0), ln, n), driftSig = gd.next(GS(5), ln, n);
+            vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
+            vPitch = vPitch + (driftSig * a.s.driftAmount) * 0.02f;           // kDriftScale, :247
+          }
+          oPitch[k] = withMain(vPitch);
+        }
+        put(0, q, oPitch);
+      }
+    }
+    else
 #pragma unroll 1
     for (int q = 0; q < 16; ++q)
     {
@@ -465,7 +519,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
           vGate = retrigFrame ? 0.f : velocity;
           vPitch = pitchGlideNext(pitch);
           age += ageStep;
-          vTime = (float)((double)age / srD);
+          if (wantTime) vTime = (float)((double)age / srD);
           // A retrigger that lands on the frame where the previous note event of this voice ended (a note-on and a steal of
           // the same voice on one frame) makes the reference REWRITE frame dest - 1, which that previous event had already
           // written (:163-175): the glide is stepped and the event age counted once more, with the previous event's new
@@ -513,7 +567,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
             vGate = 0.f;                                // the retrigger frame
             vPitch = pitchGlideNext(pitch);
             age += ageStep;
-            vTime = (float)((double)age / srD);
+            if (wantTime) vTime = (float)((double)age / srD);
           }
           const float bendSig = gb.next(GS(0), ln, n), driftSig = gd.next(GS(5), ln, n);
           vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
@@ -602,11 +656,20 @@ struct mlgpu_events
   std::vector<std::vector<Rec>> laneRecs;  // per lane, this launch
   std::vector<uint32_t> dirtyLanes;        // lanes with records (most have none)
   uint32_t* d_state{nullptr};
-  Rec* d_recs{nullptr};
-  uint32_t* d_recStart{nullptr};
-  size_t recCapacity{0};
-  std::vector<Rec> h_recs;
-  std::vector<uint32_t> h_recStart;
+  // Two sets of upload buffers (pinned host + device): the records of launch k + 1 are routed and copied while the kernel of
+  // launch k still runs; a set is reused only after the launch that read it has finished (its event).
+  struct Staging
+  {
+    Rec* h_recs{nullptr};
+    Rec* d_recs{nullptr};
+    uint32_t* h_recStart{nullptr};
+    uint32_t* d_recStart{nullptr};
+    size_t recCapacity{0};
+    hipEvent_t done{nullptr};
+    bool pending{false};
+  } stage[2];
+  int stageIdx{0};
+  uint32_t rowMask{0xFFu};                 // mlgpu_events_set_wanted_rows
   size_t lanes() const { return nInstruments * (size_t)group; }
 };
 
@@ -850,8 +913,14 @@ extern "C"
     hipSetDevice(ev->e->device);
     hipStreamSynchronize(ev->e->stream);
     if (ev->d_state) hipFree(ev->d_state);
-    if (ev->d_recs) hipFree(ev->d_recs);
-    if (ev->d_recStart) hipFree(ev->d_recStart);
+    for (mlgpu_events::Staging& st : ev->stage)
+    {
+      if (st.h_recs) hipHostFree(st.h_recs);
+      if (st.d_recs) hipFree(st.d_recs);
+      if (st.h_recStart) hipHostFree(st.h_recStart);
+      if (st.d_recStart) hipFree(st.d_recStart);
+      if (st.done) hipEventDestroy(st.done);
+    }
     delete ev;
     return MLGPU_OK;
   }
@@ -896,7 +965,12 @@ extern "C"
     ev->laneRecs.resize(ev->maxLanes);
     hipError_t err = hipSetDevice(e->device);
     if (err == hipSuccess) err = hipMalloc((void**)&ev->d_state, sizeof(uint32_t) * (size_t)kStateWords * ev->maxLanes);
-    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_recStart, sizeof(uint32_t) * (ev->maxLanes + 1));
+    for (mlgpu_events::Staging& st : ev->stage)
+    {
+      if (err == hipSuccess) err = hipMalloc((void**)&st.d_recStart, sizeof(uint32_t) * (ev->maxLanes + 1));
+      if (err == hipSuccess) err = hipHostMalloc((void**)&st.h_recStart, sizeof(uint32_t) * (ev->maxLanes + 1));
+      if (err == hipSuccess) err = hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+    }
     if (err != hipSuccess)
     {
       e->lastError = std::string("events_create: ") + hipGetErrorString(err);
@@ -954,6 +1028,12 @@ extern "C"
     ev->pitchGlideSeconds = f;
     return markRecalc(ev);
   }
+  int mlgpu_events_set_wanted_rows(mlgpu_events* ev, unsigned mask)
+  {
+    if (!ev) return MLGPU_ERR_INVALID;
+    ev->rowMask = mask & 0xFFu;
+    return MLGPU_OK;
+  }
   size_t mlgpu_events_num_voices(mlgpu_events* ev) { return ev ? ev->nInstruments * (size_t)ev->polyphony : 0; }
   int mlgpu_events_newest_voice(mlgpu_events* ev, size_t instrument) { return (ev && instrument < ev->nInstruments) ? ev->inst[instrument].newestVoice - 1 : -2; }
 
@@ -988,6 +1068,7 @@ extern "C"
     {
       Instrument& in = ev->inst[i];
       if (!in.awake) continue;
+      if (in.events.empty() && in.awakeSent) continue;  // nothing to route: the voices just keep gliding on the device
       for (size_t t = 0; t < nVectors; ++t)
       {
         Router r{ev, in, i, (uint32_t)t};
@@ -1007,48 +1088,56 @@ extern "C"
       }
     }
     const size_t lanes = ev->lanes();
-    ev->h_recStart.assign(lanes + 1, 0);
-    ev->h_recs.clear();
-    std::sort(ev->dirtyLanes.begin(), ev->dirtyLanes.end());
-    {
-      size_t next = 0;  // lanes without records share their successor's start offset
-      for (uint32_t l : ev->dirtyLanes)
-      {
-        for (; next <= l; ++next) ev->h_recStart[next] = (uint32_t)ev->h_recs.size();
-        ev->h_recs.insert(ev->h_recs.end(), ev->laneRecs[l].begin(), ev->laneRecs[l].end());
-      }
-      for (; next <= lanes; ++next) ev->h_recStart[next] = (uint32_t)ev->h_recs.size();
-    }
     if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
-    if (ev->h_recs.size() + 1 > ev->recCapacity)
+    mlgpu_events::Staging& sg = ev->stage[ev->stageIdx];
+    ev->stageIdx ^= 1;
+    if (sg.pending && hipEventSynchronize(sg.done) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "events_process: waiting for the launch before last");
+    sg.pending = false;
+    size_t nRecs = 0;
+    for (uint32_t l : ev->dirtyLanes) nRecs += ev->laneRecs[l].size();
+    if (nRecs + 1 > sg.recCapacity)
     {
-      hipStreamSynchronize(e->stream);
-      if (ev->d_recs) hipFree(ev->d_recs);
-      ev->recCapacity = std::max<size_t>(4096, 2 * (ev->h_recs.size() + 1));
-      if (hipMalloc((void**)&ev->d_recs, sizeof(Rec) * ev->recCapacity) != hipSuccess)
+      if (sg.h_recs) hipHostFree(sg.h_recs);
+      if (sg.d_recs) hipFree(sg.d_recs);
+      sg.h_recs = sg.d_recs = nullptr;
+      sg.recCapacity = std::max<size_t>(4096, 2 * (nRecs + 1));
+      if (hipMalloc((void**)&sg.d_recs, sizeof(Rec) * sg.recCapacity) != hipSuccess || hipHostMalloc((void**)&sg.h_recs, sizeof(Rec) * sg.recCapacity) != hipSuccess)
       {
-        ev->d_recs = nullptr;
-        ev->recCapacity = 0;
+        sg.recCapacity = 0;
         return efail(ev, MLGPU_ERR_OOM, "events_process: record buffer");
       }
     }
-    int st = mlgpu_upload(e, ev->d_recStart, ev->h_recStart.data(), sizeof(uint32_t) * (lanes + 1));
-    if (st == MLGPU_OK && !ev->h_recs.empty()) st = mlgpu_upload(e, ev->d_recs, ev->h_recs.data(), sizeof(Rec) * ev->h_recs.size());
-    if (st != MLGPU_OK) return st;
+    std::sort(ev->dirtyLanes.begin(), ev->dirtyLanes.end());
+    {
+      size_t next = 0, n = 0;  // lanes without records share their successor's start offset
+      for (uint32_t l : ev->dirtyLanes)
+      {
+        for (; next <= l; ++next) sg.h_recStart[next] = (uint32_t)n;
+        const std::vector<Rec>& lr = ev->laneRecs[l];
+        memcpy(sg.h_recs + n, lr.data(), sizeof(Rec) * lr.size());
+        n += lr.size();
+      }
+      for (; next <= lanes; ++next) sg.h_recStart[next] = (uint32_t)n;
+    }
+    hipError_t cerr = hipMemcpyAsync(sg.d_recStart, sg.h_recStart, sizeof(uint32_t) * (lanes + 1), hipMemcpyHostToDevice, e->stream);
+    if (cerr == hipSuccess && nRecs) cerr = hipMemcpyAsync(sg.d_recs, sg.h_recs, sizeof(Rec) * nRecs, hipMemcpyHostToDevice, e->stream);
+    if (cerr != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process upload: ") + hipGetErrorString(cerr));
 
     E2SArgs a;
     memset(&a, 0, sizeof(a));
     a.state = ev->d_state;
-    a.recs = ev->d_recs;
-    a.recStart = ev->d_recStart;
+    a.recs = sg.d_recs;
+    a.recStart = sg.d_recStart;
     const size_t V = ev->nInstruments * (size_t)ev->polyphony;
     for (int r = 0; r < 8; ++r)
     {
       if (d_outputs[r] && ((uintptr_t)d_outputs[r] & 15)) return efail(ev, MLGPU_ERR_INVALID, "events_process: misaligned output");
+      if (d_outputs[r] && !((ev->rowMask >> r) & 1u)) return efail(ev, MLGPU_ERR_INVALID, "events_process: an output was passed for a row outside events_set_wanted_rows");
       a.out[r] = makeView(d_outputs[r], layout, V, nVectors);
     }
     a.lanes = lanes;
     a.T = nVectors;
+    a.rowMask = ev->rowMask;
     a.group = ev->group;
     a.slotBase = ev->slotBase;
     a.polyphony = ev->polyphony;
@@ -1071,8 +1160,8 @@ extern "C"
     hipLaunchKernelGGL(e2s_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process launch: ") + hipGetErrorString(err));
-    // the upload buffers are reused by the next call
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "events_process: sync");
+    if (hipEventRecord(sg.done, e->stream) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "events_process: event");
+    sg.pending = true;  // no wait here: the host goes on routing the next block while this one runs
     return MLGPU_OK;
   }
 }

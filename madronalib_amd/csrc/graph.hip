@@ -1022,6 +1022,18 @@ extern "C"
     return -MLGPU_ERR_RANGE;
   }
   int mlgpu_graph_num_nodes(mlgpu_graph* g) { return g ? (int)g->nodes.size() : -1; }
+  int mlgpu_graph_node_use_count(mlgpu_graph* g, int node)
+  {
+    if (!g || node < 0 || node >= (int)g->nodes.size()) return -MLGPU_ERR_RANGE;
+    int n = 0;
+    for (const Node& m : g->nodes)
+    {
+      for (int id : m.in) n += (id == node);
+      n += (m.type == NODE_FEEDBACK && m.fbSource == node);
+    }
+    for (int o : g->outputs) n += (o == node);
+    return n;
+  }
 
   // ring placement + code generation: everything graph_compile does that needs no device
   static int layoutAndGenerate(mlgpu_graph* g)

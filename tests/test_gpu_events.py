@@ -35,13 +35,15 @@ def ref_run(cfg, events, block_frames, n_blocks):
     return out
 
 
-def gpu_run(eng, cfg, per_instrument_events, block_frames, n_blocks, vectors_per_launch):
-    """per_instrument_events: one event list per instrument. Returns [8][N*P][frames]."""
+def gpu_run(eng, cfg, per_instrument_events, block_frames, n_blocks, vectors_per_launch, rows=None):
+    """per_instrument_events: one event list per instrument. Returns [8][N*P][frames] (rows not wanted: zeros)."""
     import madronalib_amd as ml
     N, P = len(per_instrument_events), cfg["polyphony"]
     ev = ml.Events(eng, N, P, cfg.get("sr", 48000.0))
     ev.configure(mpe=cfg.get("mpe", 0), unison=cfg.get("unison", 0), mod_cc=cfg.get("mod_cc", 16), pitch_bend=cfg.get("bend", 7.0),
                  mpe_pitch_bend=cfg.get("mpe_bend", 24.0), glide_seconds=cfg.get("glide", 0.0), drift=cfg.get("drift", 0.0))
+    if rows is not None:
+        ev.set_wanted_rows(rows)
     outs = []
     for b in range(n_blocks):
         start = b * block_frames
@@ -128,6 +130,30 @@ def test_events_to_signals_matches_reference(eng, name):
         for r in range(8):
             assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"{name}: instrument {k} row {ROW_NAMES[r]}")
     assert np.abs(got[1]).max() > 0 and np.abs(got[0]).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,rows", [("midi_poly4", [0, 1]), ("mpe5", [0, 1, 3, 6]), ("midi_poly16", [1, 2, 4, 5, 7])])
+def test_wanted_rows_only(eng, name, rows):
+    """mlgpu_events_set_wanted_rows: the rows asked for are the reference's; the others are neither computed nor written,
+    and passing a buffer for one of them is an error."""
+    import madronalib_amd as ml
+    cfg = SCENARIOS[name]
+    block, n_blocks, P = 512, 6, cfg["polyphony"]
+    instruments = [performance("mpe" if cfg.get("mpe") else "midi", 31 * k + 5, block * n_blocks, P) for k in range(3)]
+    got = gpu_run(eng, cfg, instruments, block, n_blocks, vectors_per_launch=4, rows=rows)
+    for k, evs in enumerate(instruments):
+        want = ref_run(cfg, evs, block, n_blocks)
+        for r in range(8):
+            if r in rows:
+                assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"{name}: instrument {k} row {ROW_NAMES[r]}")
+            else:
+                assert (got[r] == 0).all()
+    ev = ml.Events(eng, 2, 4)
+    ev.set_wanted_rows([0, 1])
+    bufs = [eng.alloc(4 * 8 * 64) for _ in range(8)]
+    with pytest.raises(ml.MlgpuError):
+        ev.process(1, 0, bufs)
 
 
 @pytest.mark.gpu
