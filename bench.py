@@ -43,6 +43,7 @@ WORKLOADS = {
     # widened rows, measured to the same bar; not BASELINE configs
     "events": (262144, 16, 8),  # EventsToSignals: 16384 instruments x 16 voices, 8 control rows out
     "resample": (262144, 32, 8),  # Downsampler, 2 octaves: 32 vectors in -> 8 out per launch
+    "synth": (262144, 16, 8),    # events -> synth16 voices (pitch and gate rows streamed) -> per-instrument voice sum
     "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
 }
 
@@ -166,6 +167,53 @@ def setup_workload(eng, name, V, T, lo, total):
         alg = 4.0 * len(rows) * n + V * T * 4.0 * 5 * glides * 2 + V * 4.0 * 23 * 2
         return launch, alg, "e2s_kernel", (f"EventsToSignals: 16384 instruments x 16 voices, {len(rows)} control signals out, sparse note events "
                                            "(host routing + record upload inside the step)"), ev
+    if name == "synth":
+        # A bank of polyphonic instruments end to end, as ml::gpu::SynthProgram runs a Synth subclass: EventsToSignals (only the
+        # rows the voice reads) -> the fused voice graph -> the per-instrument voice sum (Synth::processVector, MLSynth.h:43-57)
+        from madronalib_amd import patches
+        from madronalib_amd.sharding import cfg5_voice_params
+        P = 16
+        N = V // P
+        ev = ml.Events(eng, N, P, 48000.0)
+        ev.configure(glide_seconds=0.01, drift=0.5)
+        ev.set_wanted_rows([0, 1])
+        desc, outs = patches.synth16(pitch_input=True)
+        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")))
+        g.clear()
+        params, coeffs, seeds = cfg5_voice_params(lo, lo + V, total, ml)
+        for k, v in params.items():
+            if k != "pitch":
+                g.set_param(k, v if np.ndim(v) else float(v))
+        for k, c in coeffs.items():
+            g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+        g.set_state("noise", 0, seeds)
+        rows = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        d_voices = eng.alloc(4 * n)
+        d_mix = [eng.alloc(4 * N * T * 64), eng.alloc(4 * N * T * 64)]
+        rng = np.random.default_rng(lo + 1)
+        held = {}
+        k = [0]
+        names = [d["name"] for d in desc if d["type"] == "input"]   # graph input order: gate, pitch
+
+        def launch():
+            for i in rng.integers(0, N, max(1, N // 50)):
+                i = int(i)
+                t = int(rng.integers(0, 64 * T))
+                if held.get(i):
+                    ev.add_event(i, ml.Event(4, 1, held[i].pop(), t, 0.0, 0.0))
+                else:
+                    key = int(rng.integers(36, 84))
+                    held.setdefault(i, []).append(key)
+                    ev.add_event(i, ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
+            ev.process(T, 0, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
+            ev.clear_events()
+            g.process(T, [rows[1] if nm == "gate" else rows[0] for nm in names], [d_voices])
+            eng.mixdown_groups(d_voices, Layout.QUAD, N, P, T, d_mix[k[0] & 1])
+            k[0] += 1
+        # pitch + gate written and read, voice audio written and read, instrument audio written
+        alg = (8.0 + 8.0 + 4.0 + 4.0) * n + 4.0 * N * T * 64
+        return launch, alg, "mlgpu_graph_kernel", ("16384 instruments x 16 voices end to end: note events -> EventsToSignals (pitch, gate) -> 16-node "
+                                                    "voice graph -> per-instrument voice sum"), (ev, g)
     if name == "resample":
         r = ml.Resampler(eng, V, 2, False)
         x = eng.bank([Proc.NOISE_GEN], V)

@@ -222,6 +222,11 @@ class Engine:
         g = lambda x: None if x is None else ctypes.c_void_p(x.ptr if hasattr(x, "ptr") else int(x))  # noqa: E731
         self._check(self.L.mlgpu_mixdown(self.h, g(d_signal), int(layout), int(n_voices), int(n_vectors), g(d_gains), g(d_out)))
 
+    def mixdown_groups(self, d_signal, layout, n_groups, group_size, n_vectors, d_out, out_layout=Layout.QUAD):
+        """Sum every `group_size` consecutive voices (a Synth's voices, MLSynth.h:43-57) into one signal per group."""
+        self._check(self.L.mlgpu_mixdown_groups(self.h, ctypes.c_void_p(d_signal.ptr), int(layout), int(n_groups), int(group_size), int(n_vectors),
+                                                ctypes.c_void_p(d_out.ptr), int(out_layout)))
+
     def layout_convert(self, src, src_layout, dst, dst_layout, n_voices, n_vectors):
         self._check(self.L.mlgpu_layout_convert(self.h, src.ptr, int(src_layout), dst.ptr, int(dst_layout),
                                                 int(n_voices), int(n_vectors)))

@@ -557,13 +557,55 @@ __global__ __launch_bounds__(256) void mixdown_stage2_kernel(const float4* parti
 // the `outputs[c] += ...` accumulation of Synth::processVector (source/app/MLSynth.h:43-57). One lane per (group, quad).
 namespace
 {
+// A wavefront owns 64 consecutive groups of one quad (t, q): it loads their 64 * P float4 with P fully coalesced instructions
+// (lane l takes elements l, l + 64, ...), parks them in its own LDS strip, and lane l then adds up the P voices of group l in
+// voice order. One spare float4 per group keeps the strided reads of the second phase off a single LDS bank. (The first
+// version let every lane read its own group straight from memory: 16-byte accesses at a stride of P * 16 bytes, 1.1 TB/s.)
 __global__ __launch_bounds__(256) void mixdown_groups_kernel(SignalView sig, SignalView out, size_t groups, size_t P, size_t T)
+{
+  extern __shared__ float4 mixLds[];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4* strip = mixLds + (size_t)wave * 64 * (P + 1);
+  const size_t groupBlocks = (groups + 63) / 64;
+  const size_t items = T * 16 * groupBlocks;  // (quad, block of 64 groups), the group block fastest
+  const size_t V = groups * P;
+  const size_t wavesPerBlock = blockDim.x >> 6;
+  for (size_t item = (size_t)blockIdx.x * wavesPerBlock + wave; item < items; item += (size_t)gridDim.x * wavesPerBlock)
+  {
+    const size_t gb = item % groupBlocks, qi = item / groupBlocks;
+    const size_t t = qi >> 4, q = qi & 15;
+    const size_t firstVoice = gb * 64 * P;
+    const float4* src = sig.base + t * sig.strideT + q * sig.strideQ;
+    for (size_t i = 0; i < P; ++i)
+    {
+      const size_t e = i * 64 + lane;
+      if (firstVoice + e < V) strip[e + e / P] = src[(firstVoice + e) * sig.strideV];
+    }
+    // the strip is private to this wavefront and LDS operations of one wavefront complete in order
+    const size_t g = gb * 64 + lane;
+    if (g < groups)
+    {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* mine = strip + (size_t)lane * (P + 1);
+      for (size_t p = 0; p < P; ++p)
+      {
+        const float4 x = mine[p];
+        acc.x = acc.x + x.x;
+        acc.y = acc.y + x.y;
+        acc.z = acc.z + x.z;
+        acc.w = acc.w + x.w;
+      }
+      out.base[t * out.strideT + q * out.strideQ + g * out.strideV] = acc;
+    }
+  }
+}
+// groups too large for an LDS strip: one lane per (group, quad), straight from memory
+__global__ __launch_bounds__(256) void mixdown_groups_direct_kernel(SignalView sig, SignalView out, size_t groups, size_t P, size_t T)
 {
   const size_t total = groups * T * 16;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
   {
-    // enumerate with the group fastest so QUAD-layout accesses coalesce
     const size_t g = i % groups, qi = i / groups;
     const size_t t = qi >> 4, q = qi & 15;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -582,11 +624,22 @@ __global__ __launch_bounds__(256) void mixdown_groups_kernel(SignalView sig, Sig
 
 hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream)
 {
-  size_t blocks = (groups * T * 16 + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const SignalView in = makeView(sig, layout, groups * P, T), ov = makeView(out, outLayout, groups, T);
+  const size_t stripBytes = 64 * (P + 1) * sizeof(float4);  // per wavefront
+  if (stripBytes > 64 * 1024)
+  {
+    size_t blocks = (groups * T * 16 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(mixdown_groups_direct_kernel, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, stream, in, ov, groups, P, T);
+    return hipGetLastError();
+  }
+  size_t waves = 4;  // per workgroup, as many as fit 64 KiB of LDS
+  while (waves > 1 && waves * stripBytes > 64 * 1024) waves >>= 1;
+  const size_t items = T * 16 * ((groups + 63) / 64);
+  size_t blocks = (items + waves - 1) / waves;
+  if (blocks > 256 * 8) blocks = 256 * 8;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(mixdown_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, makeView(sig, layout, groups * P, T),
-                     makeView(out, outLayout, groups, T), groups, P, T);
+  hipLaunchKernelGGL(mixdown_groups_kernel, dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), waves * stripBytes, stream, in, ov, groups, P, T);
   return hipGetLastError();
 }
 

@@ -10,8 +10,9 @@ import numpy as np
 from .constants import Op, Proc
 
 
-def synth16():
-    """16 processor/op nodes per voice:
+def synth16(pitch_input=False):
+    """16 processor/op nodes per voice (pitch_input: `pitch` is a streamed signal, e.g. EventsToSignals' pitch row, instead of
+    a per-voice constant; the oscillators then see a frequency per sample):
          pitch (param, octaves re base) -> exp2Approx -> * baseFreq  = freq (cycles/sample)
          SawGen(freq), PulseGen(freq, width param), LFO SineGen(lfoFreq param), NoiseGen
          osc = saw + pulse * lfo ; pre = osc + noise * noiseLevel
@@ -20,7 +21,7 @@ def synth16():
        inputs: gate (streamed).  params: pitch, baseFreq, width, lfoFreq, noiseLevel."""
     d = [
         dict(name="gate", type="input"),
-        dict(name="pitch", type="param"),
+        dict(name="pitch", type="input" if pitch_input else "param"),
         dict(name="baseFreq", type="param"),
         dict(name="width", type="param"),
         dict(name="lfoFreq", type="param"),

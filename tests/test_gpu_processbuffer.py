@@ -114,3 +114,25 @@ def test_broadcast_input_layout(eng, oracle):
     d_g = eng.to_device(gsig)
     gr.process(T, [d_x, d_g], [d_out], Layout.VOICE_MAJOR, Layout.VOICE_MAJOR)
     assert_bits_equal(d_out.download(np.float32).reshape(V, -1), (want * gsig).astype(np.float32), True, "graph, broadcast + per-voice inputs")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,groups", [(1, 70), (2, 64), (3, 65), (5, 1), (6, 200), (16, 63), (16, 1000), (17, 129), (40, 66), (70, 9)])
+@pytest.mark.parametrize("layout", [Layout.QUAD, Layout.VOICE_MAJOR])
+def test_mixdown_groups_voice_order(eng, P, groups, layout):
+    """mlgpu_mixdown_groups: every P consecutive voices summed in voice order, starting from zero (Synth::processVector,
+    source/app/MLSynth.h:43-57) — the LDS-strip kernel (P <= 62) and the direct one, full and ragged blocks of 64 groups."""
+    from inputs import lcg_noise
+    T, V = 3, groups * P
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 17, 64 * T)
+    d_x, d_q, d_o, d_ov = eng.alloc(4 * V * 64 * T), eng.alloc(4 * V * 64 * T), eng.alloc(4 * groups * 64 * T), eng.alloc(4 * groups * 64 * T)
+    d_x.upload(x)
+    eng.layout_convert(d_x, Layout.VOICE_MAJOR, d_q, layout, V, T)
+    eng.mixdown_groups(d_q, layout, groups, P, T, d_o, layout)
+    eng.layout_convert(d_o, layout, d_ov, Layout.VOICE_MAJOR, groups, T)
+    got = d_ov.download(np.float32, groups * 64 * T).reshape(groups, 64 * T)
+    want = np.zeros((groups, 64 * T), np.float32)
+    xs = x.reshape(groups, P, 64 * T)
+    for p in range(P):
+        want = want + xs[:, p]
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
