@@ -302,63 +302,46 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
 
     // ---- rows that are one glide each: mod, x, y; z adds the smoothed channel pressure in MIDI mode (:437-445) ----
     // One short loop per row keeps the live state of the other rows out of the registers.
-    if (a.rowMask & (1u << 6))
-    {
+    // A glide that is not moving gives one value for the whole vector (hold with a broadcast mCurrVec, or the vector that
+    // ends a glide): when that is so for every lane of the wavefront - controllers rarely move - the row is 16 stores.
+    auto heldValue = [&](const Glide& gl, bool& held) {
+      const int m = gl.mode();
+      held = (m == 1) || (m == 0 && gl.isUniform());
+      return (m == 1) ? gl.target : gl.uniformValue;
+    };
+    auto glideRow = [&](int glideIdx, int row, float value) {
       Glide gl;
-      gl.load(GS(1), ln);
-      if (on) gl.beginVector(GS(1), ln, mod, a.s.glideVectors, a.s.glideDy);
-#pragma unroll 1
-      for (int q = 0; q < 16; ++q)
+      gl.load(GS(glideIdx), ln);
+      if (on) gl.beginVector(GS(glideIdx), ln, value, a.s.glideVectors, a.s.glideDy);
+      bool held;
+      const float hv = heldValue(gl, held);
+      if (__builtin_amdgcn_ballot_w64(on && !held) == 0)
       {
-        f32x4 v;
+        const float c = withMain(on ? hv : 0.f);
+        const f32x4 v = {c, c, c, c};
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) put(row, q, v);
+      }
+      else
+      {
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q)
+        {
+          f32x4 v;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.next(GS(1), ln, q * 4 + k) : 0.f);
-        put(6, q, v);
+          for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.next(GS(glideIdx), ln, q * 4 + k) : 0.f);
+          put(row, q, v);
+        }
       }
       if (on)
       {
         gl.endVector();
-        gl.store(GS(1), ln);
+        gl.store(GS(glideIdx), ln);
       }
-    }
-    if (a.rowMask & (1u << 4))
-    {
-      Glide gl;
-      gl.load(GS(2), ln);
-      if (on) gl.beginVector(GS(2), ln, cx, a.s.glideVectors, a.s.glideDy);
-#pragma unroll 1
-      for (int q = 0; q < 16; ++q)
-      {
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.next(GS(2), ln, q * 4 + k) : 0.f);
-        put(4, q, v);
-      }
-      if (on)
-      {
-        gl.endVector();
-        gl.store(GS(2), ln);
-      }
-    }
-    if (a.rowMask & (1u << 5))
-    {
-      Glide gl;
-      gl.load(GS(3), ln);
-      if (on) gl.beginVector(GS(3), ln, cy, a.s.glideVectors, a.s.glideDy);
-#pragma unroll 1
-      for (int q = 0; q < 16; ++q)
-      {
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.next(GS(3), ln, q * 4 + k) : 0.f);
-        put(5, q, v);
-      }
-      if (on)
-      {
-        gl.endVector();
-        gl.store(GS(3), ln);
-      }
-    }
+    };
+    if (a.rowMask & (1u << 6)) glideRow(1, 6, mod);
+    if (a.rowMask & (1u << 4)) glideRow(2, 4, cx);
+    if (a.rowMask & (1u << 5)) glideRow(3, 5, cy);
     if (a.rowMask & (1u << 3))
     {
       Glide gz, gp;
@@ -369,6 +352,22 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
         gz.beginVector(GS(4), ln, cz, a.s.glideVectors, a.s.glideDy);
         gp.beginVector(GS(6), ln, chanPress, a.s.ctlGlideVectors, a.s.ctlGlideDy);  // SmoothedController::process, :268-280
       }
+      bool heldZ, heldP;
+      const float hz = heldValue(gz, heldZ), hp = heldValue(gp, heldP);
+      if (__builtin_amdgcn_ballot_w64(on && !(heldZ && heldP)) == 0)
+      {
+        float z = 0.f;
+        if (on)
+        {
+          z = hz;
+          if (!a.s.mpe) z = z + hp;
+        }
+        const float c = withMain(z);
+        const f32x4 v = {c, c, c, c};
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) put(3, q, v);
+      }
+      else
 #pragma unroll 1
       for (int q = 0; q < 16; ++q)
       {
