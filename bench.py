@@ -308,6 +308,31 @@ def cpu_baseline_cfg4(budget_s=10.0):
             "sample": f"{Vs} channels x {T} DSPVectors, 8 cascaded Lopass per channel, {cores} threads, best of 3 (compiled reference headers, g++ -O2 SSE2)"}
 
 
+def cpu_baseline_cfg5(budget_s=10.0):
+    """Config 5 on the host cores: the same 16-node voice written with the reference's objects (g++ -O2), one struct per voice."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_checkers import Ref, ref_available
+    import madronalib_amd as ml
+    from madronalib_amd.sharding import cfg5_voice_params
+    if not ref_available():
+        return {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "compiled reference not available"}
+    ref = Ref()
+    cores = os.cpu_count() or 1
+    Vs = 256 * max(1, min(cores, 256))
+    params, coeffs, seeds = cfg5_voice_params(0, Vs, Vs, ml)
+
+    def run(T):
+        gate = np.zeros((Vs, 64 * T), np.float32)
+        gate[:, 64:] = 0.8   # every voice sounds from the second vector on
+        return ref.synth16_run(params, coeffs, seeds, gate, cores)[1]
+    run(4)
+    t_cal = run(16)
+    T = int(max(16, min(1024, 16 * budget_s / max(t_cal, 1e-6) / 3)))
+    best = min(run(T) for _ in range(3))
+    return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
+            "sample": f"{Vs} voices x {T} DSPVectors of the synth16 voice, {cores} threads, best of 3 (reference objects, g++ -O2 SSE2)"}
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed PMC summary, if there is one."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -404,9 +429,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name),
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload in ("cfg3", "cfg4"):
+        baselines = {"cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5}
+        if world == 1 and not args.no_cpu_baseline and args.workload in baselines:
             try:
-                out["cpu_baseline"] = cpu_baseline_cfg3() if args.workload == "cfg3" else cpu_baseline_cfg4()
+                out["cpu_baseline"] = baselines[args.workload]()
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {ex}"}

@@ -922,6 +922,81 @@ extern "C"
     return std::chrono::duration<double>(t1 - t0).count();
   }
 
+  // config 5: the 16-node synth voice of madronalib_amd/patches.py synth16(), written the way user code writes it with the
+  // reference's objects (one struct of processors per voice, one DSPVector at a time). params [5][V] = pitch, baseFreq,
+  // width, lfoFreq, noiseLevel; coefficient arrays [n][V]; gate / out [V][64 T]. All objects start cleared (clear() where
+  // the class has one), NoiseGen seeded per voice. nThreads > 0: voices split over threads; returns seconds.
+  namespace
+  {
+  struct Synth16Voice
+  {
+    SawGen saw;
+    PulseGen pulse;
+    SineGen lfo;
+    NoiseGen noise;
+    Lopass lp;
+    Hipass hp;
+    OnePole smooth;
+    DCBlocker dc;
+    ADSR env;
+    float pitch, baseFreq, width, lfoFreq, noiseLevel;
+    DSPVector process(const DSPVector gate)
+    {
+      const DSPVector ratio = exp2Approx(DSPVector(pitch));
+      const DSPVector freq = ratio * DSPVector(baseFreq);
+      const DSPVector vSaw = saw(freq);
+      const DSPVector vPulse = pulse(freq, DSPVector(width));
+      const DSPVector vLfo = lfo(DSPVector(lfoFreq));
+      const DSPVector vNoise = noise();
+      const DSPVector osc = vSaw + vPulse * vLfo;
+      const DSPVector pre = osc + vNoise * DSPVector(noiseLevel);
+      const DSPVector filtered = dc(smooth(hp(lp(pre))));
+      return clamp(filtered * env(gate), DSPVector(-1.f), DSPVector(1.f));
+    }
+  };
+  }  // namespace
+  double mlref_synth16_run(size_t V, size_t T, const float* params, const float* lpC, const float* hpC, const float* smoothC, const float* dcC,
+                           const float* envC, const uint32_t* seeds, const float* gate, float* out, int nThreads)
+  {
+    std::vector<Synth16Voice> vs(V);
+    for (size_t v = 0; v < V; ++v)
+    {
+      Synth16Voice& s = vs[v];
+      s.saw.clear();
+      s.pulse.clear();
+      s.lfo.clear();
+      s.lp.clear();
+      s.smooth.clear();
+      s.env.clear();
+      s.noise.setSeed(seeds[v]);
+      s.pitch = params[0 * V + v];
+      s.baseFreq = params[1 * V + v];
+      s.width = params[2 * V + v];
+      s.lfoFreq = params[3 * V + v];
+      s.noiseLevel = params[4 * V + v];
+      s.lp.coeffs = {lpC[0 * V + v], lpC[1 * V + v], lpC[2 * V + v]};
+      s.hp.coeffs = {hpC[0 * V + v], hpC[1 * V + v], hpC[2 * V + v], hpC[3 * V + v]};
+      s.smooth.coeffs = {smoothC[0 * V + v], smoothC[1 * V + v]};
+      s.dc.coeffs = dcC[v];
+      s.env.coeffs = {envC[0 * V + v], envC[1 * V + v], envC[2 * V + v], envC[3 * V + v]};
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    parallelFor(V, std::max(1, nThreads),
+                [&](size_t a, size_t b)
+                {
+                  for (size_t t = 0; t < T; ++t)
+                    for (size_t v = a; v < b; ++v)
+                    {
+                      DSPVector g;
+                      load(g, gate + (v * T + t) * kFloatsPerDSPVector);
+                      const DSPVector y = vs[v].process(g);
+                      store(y, out + (v * T + t) * kFloatsPerDSPVector);
+                    }
+                });
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
+  }
+
   // config 2: elementwise op over n elements, nThreads; returns seconds.
   double mlref_bench_op(int op, const float* in, float* out, size_t nElems, int nThreads, int reps)
   {

@@ -417,6 +417,25 @@ class Ref(_Checker):
         assert fnc(x.size // 64, feedback_gain, max_delay, _ptr(co, c_f32p), _ptr(ds, c_f32p), _ptr(x, c_f32p), _ptr(out, c_f32p)) == 0
         return out
 
+    def synth16_run(self, params, coeffs, seeds, gate, n_threads=1):
+        """BASELINE configs[4]: the synth16 voice written with the reference's objects (oracle/ref_wrapper.cpp
+        mlref_synth16_run). params: dict as patches.synth16 names them; coeffs: {lp, hp, smooth, dc, env}: [n][V]; gate
+        [V][64 T]. Returns (out [V][64 T], seconds)."""
+        fnc = self.lib.mlref_synth16_run
+        fnc.restype = ctypes.c_double
+        c_u32p = ctypes.POINTER(ctypes.c_uint32)
+        fnc.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u32p, c_f32p, c_f32p, ctypes.c_int]
+        gate = np.ascontiguousarray(gate, np.float32)
+        V, T = gate.shape[0], gate.shape[1] // 64
+        P = np.ascontiguousarray(np.stack([np.broadcast_to(np.asarray(params[k], np.float32), (V,))
+                                           for k in ("pitch", "baseFreq", "width", "lfoFreq", "noiseLevel")]), np.float32)
+        C = {k: np.ascontiguousarray(coeffs[k], np.float32) for k in ("lp", "hp", "smooth", "dc", "env")}
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        out = np.empty_like(gate)
+        sec = fnc(V, T, _ptr(P, c_f32p), _ptr(C["lp"], c_f32p), _ptr(C["hp"], c_f32p), _ptr(C["smooth"], c_f32p), _ptr(C["dc"], c_f32p),
+                  _ptr(C["env"], c_f32p), seeds.ctypes.data_as(c_u32p), _ptr(gate, c_f32p), _ptr(out, c_f32p), int(n_threads))
+        return out, sec
+
     def dspbuffer(self, size):
         return _RefDSPBuffer(self.lib, size)
 

@@ -143,7 +143,17 @@ def main():
     co = ref.make_coeffs("lopass", 0.2, 0.8)
     np.savez_compressed(os.path.join(HERE, "regions.npz"), x=x, m=m, freq=freq, co=co, up=ref.rate_function_run(True, freq, co, x, m),
                         down=ref.rate_function_run(False, freq, co, x, m))
-    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz", "resample.npz", "regions.npz"):
+    # ---- BASELINE configs[4]: the synth16 voice written with the reference's objects ----
+    from inputs import gate_signal
+    from madronalib_amd.sharding import cfg5_voice_params
+    import madronalib_amd as ml
+    V, T = 6, 12
+    params, coeffs, seeds = cfg5_voice_params(0, V, V, ml)
+    gate = gate_signal(V, 64 * T, seed=21)
+    out, _ = ref.synth16_run(params, coeffs, seeds, gate)
+    np.savez_compressed(os.path.join(HERE, "synth16.npz"), gate=gate, out=out, seeds=seeds, **{"p_" + k: np.asarray(v, np.float32) for k, v in params.items()},
+                        **{"c_" + k: v for k, v in coeffs.items()})
+    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz", "resample.npz", "regions.npz", "synth16.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

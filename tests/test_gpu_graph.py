@@ -81,6 +81,23 @@ def test_synth16_vs_oracle(eng, oracle, layout, vpl):
 
 
 @pytest.mark.gpu
+def test_synth16_golden_reference_objects(eng, oracle):
+    """tests/golden/synth16.npz: the patch run with the reference's own objects (BASELINE configs[4] parameters)."""
+    import os
+    g0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth16.npz"))
+    V, T = g0["gate"].shape[0], g0["gate"].shape[1] // 64
+    params = {k[2:]: (g0[k] if g0[k].ndim else float(g0[k])) for k in g0.files if k.startswith("p_")}
+    coeffs = {k[2:]: g0[k] for k in g0.files if k.startswith("c_")}
+    for vpl in (1, 2):
+        g, _, _, _ = build_synth16(eng, oracle, V, params, coeffs, g0["seeds"], vpl)
+        half = T // 2
+        a = g.process_host(half, {"gate": np.ascontiguousarray(g0["gate"][:, :64 * half])}, Layout.QUAD)[0]
+        b = g.process_host(T - half, {"gate": np.ascontiguousarray(g0["gate"][:, 64 * half:])}, Layout.VOICE_MAJOR)[0]
+        assert_bits_equal(np.concatenate([a, b], 1), g0["out"], True, f"synth16 golden, {vpl} voice(s) per lane")
+        g.close()
+
+
+@pytest.mark.gpu
 def test_synth16_full_size_subset(eng, oracle):
     """BASELINE configs[4] per-GPU size (262 144 voices): a strided subset against the oracle, and
     launch splitting: 2 x T/2 vectors == T vectors."""

@@ -268,3 +268,23 @@ def test_rate_functions_match_reference(oracle, ref, up):
     x, m, freq = region_case(7, 11, seed=4)
     co = ref.make_coeffs("lopass", 0.2, 0.8)
     assert_bits_equal(oracle.rate_function_run(up, freq, co, x, m), ref.rate_function_run(up, freq, co, x, m), True, f"rate function up={up}")
+
+
+def test_synth16_graph_evaluator_matches_reference_objects(oracle, ref):
+    """BASELINE configs[4]: the node-by-node evaluator the GPU graph is checked against (tests/graph_oracle.py) gives the same
+    bits as the patch written in C++ with the reference's own objects (oracle/ref_wrapper.cpp mlref_synth16_run)."""
+    from graph_oracle import evaluate
+    from inputs import gate_signal
+    from madronalib_amd import patches
+    from madronalib_amd.sharding import cfg5_voice_params
+    import madronalib_amd as ml
+    V, T = 50, 20
+    params, coeffs, seeds = cfg5_voice_params(0, V, V, ml)
+    desc, outs = patches.synth16()
+    states = {n["name"]: oracle.chain_clear([n["kind"]], V) for n in desc if n["type"] == "proc"}
+    states["noise"][0] = seeds
+    gate = gate_signal(V, 64 * T, seed=5)
+    (got,) = evaluate(oracle, desc, outs, V, T, {"gate": gate}, params, coeffs, states)
+    want, _ = ref.synth16_run(params, coeffs, seeds, gate)
+    assert_bits_equal(got, want, True, "synth16 evaluator vs reference objects")
+    assert np.abs(want).max() > 0.05
