@@ -308,6 +308,25 @@ def cpu_baseline_cfg4(budget_s=10.0):
             "sample": f"{Vs} channels x {T} DSPVectors, 8 cascaded Lopass per channel, {cores} threads, best of 3 (compiled reference headers, g++ -O2 SSE2)"}
 
 
+def cpu_baseline_cfg2(budget_s=8.0):
+    """Config 2 on the host cores: expApprox(sinApprox(x)) over the same 4 Mi samples with the reference's ops (g++ -O2 SSE2)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_checkers import Ref, ref_available
+    from madronalib_amd.constants import Op
+    if not ref_available():
+        return {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "compiled reference not available"}
+    ref = Ref()
+    cores = os.cpu_count() or 1
+    n = 65536 * 64
+    x = np.tile(np.linspace(-np.pi, np.pi, 4096, dtype=np.float32), n // 4096)
+    ref.bench_op(Op.EXP_APPROX_OF_SIN_APPROX, x, cores, 2)
+    t_cal = ref.bench_op(Op.EXP_APPROX_OF_SIN_APPROX, x, cores, 8)
+    reps = int(max(8, min(20000, 8 * budget_s / max(t_cal, 1e-6) / 3)))
+    best = min(ref.bench_op(Op.EXP_APPROX_OF_SIN_APPROX, x, cores, reps) for _ in range(3))
+    return {"value": n * reps / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
+            "sample": f"65536 voices x 1 DSPVector, {reps} passes, {cores} threads, best of 3 (reference ops, g++ -O2 SSE2; the data stays in the CPU caches)"}
+
+
 def cpu_baseline_cfg5(budget_s=10.0):
     """Config 5 on the host cores: the same 16-node voice written with the reference's objects (g++ -O2), one struct per voice."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -429,7 +448,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name),
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        baselines = {"cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5}
+        baselines = {"cfg2": cpu_baseline_cfg2, "cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5}
         if world == 1 and not args.no_cpu_baseline and args.workload in baselines:
             try:
                 out["cpu_baseline"] = baselines[args.workload]()
