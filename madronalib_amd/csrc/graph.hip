@@ -296,7 +296,7 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
       for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
       s << ")";
       break;
-    case NODE_FEEDBACK: s << "u2f(a.state[(size_t)(" << n.sOff << " + q * 4 + k) * a.V + v" << L << "])"; break;
+    case NODE_FEEDBACK: s << "u2f(a.state[(size_t)(" << n.sOff << " + " << idx << ") * a.V + v" << L << "])"; break;
     case NODE_ROUTE:
       if (n.kind == MLGPU_ROUTE_MULTIPLEX || n.kind == MLGPU_ROUTE_MULTIPLEX_LINEAR)
       {
@@ -466,6 +466,11 @@ std::string generateGraphSource(mlgpu_graph* g)
             }
             done[j] = 1;
           }
+          // fn's own one-vector feedback: slot = the sample index inside fn's DSPVector
+          for (size_t j = 0; j < g->nodes.size(); ++j)
+            if (g->nodes[j].region == r && g->nodes[j].type == NODE_FEEDBACK && g->nodes[j].fbSource >= 0)
+              for (int l = 0; l < VL; ++l)
+                s << "        a.state[(size_t)(" << g->nodes[j].sOff << " + " << idx << ") * a.V + v" << sfx(l) << "] = f2u(" << name(g->nodes[j].fbSource, ph, l) << ");\n";
         }
       }
       else
@@ -491,6 +496,10 @@ std::string generateGraphSource(mlgpu_graph* g)
           }
           done[j] = 1;
         }
+        for (size_t j = 0; j < g->nodes.size(); ++j)
+          if (g->nodes[j].region == r && g->nodes[j].type == NODE_FEEDBACK && g->nodes[j].fbSource >= 0)
+            for (int l = 0; l < VL; ++l)
+              s << "          a.state[(size_t)(" << g->nodes[j].sOff << " + " << idx << ") * a.V + v" << sfx(l) << "] = f2u(" << name(g->nodes[j].fbSource, "", l) << ");\n";
         for (int l = 0; l < VL; ++l) s << "          p" << R.out << sfx(l) << ".push(q * 4 + k, " << name(R.result, "", l) << ");\n";
         s << "        }\n";
         for (int in : R.ins)
@@ -515,7 +524,7 @@ std::string generateGraphSource(mlgpu_graph* g)
     for (int l = 0; l < VL; ++l) s << "        y" << o << sfx(l) << "[k] = n" << g->outputs[o] << sfx(l) << ";\n";
   // feedback: keep this sample's value for the same sample of the next DSPVector (its old value was read above)
   for (size_t i = 0; i < g->nodes.size(); ++i)
-    if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].fbSource >= 0)
+    if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].fbSource >= 0 && g->nodes[i].region < 0)
       for (int l = 0; l < VL; ++l)
         s << "        a.state[(size_t)(" << g->nodes[i].sOff << " + q * 4 + k) * a.V + v" << sfx(l) << "] = f2u(n" << g->nodes[i].fbSource << sfx(l) << ");\n";
   s << "      }\n";
@@ -590,8 +599,8 @@ int addNode(mlgpu_graph* g, Node&& n)
     if (g->openRegion >= 0)
     {
       const bool vectorProc = (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind));
-      if (n.type == NODE_INPUT || n.type == NODE_CONTROL || n.type == NODE_FEEDBACK || vectorProc || n.rate == RATE_VECTOR)
-        return -gfail(g, MLGPU_ERR_UNSUPPORTED, "graph: streamed inputs, controls, vector-rate processors and feedback nodes cannot live inside a rate region");
+      if (n.type == NODE_INPUT || n.type == NODE_CONTROL || vectorProc || n.rate == RATE_VECTOR)
+        return -gfail(g, MLGPU_ERR_UNSUPPORTED, "graph: streamed inputs, controls and vector-rate processors cannot live inside a rate region");
       if (n.rate == RATE_AUDIO) n.region = g->openRegion;
     }
   }
@@ -955,18 +964,17 @@ extern "C"
       if (g->nodes[(size_t)inputs[j]].region >= 0) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: input belongs to another region");
     }
     const int r = (int)g->regions.size();
-    Region R;
-    R.kind = region;
+    g->regions.emplace_back();
+    g->regions.back().kind = region;
     for (int j = 0; j < nIn; ++j)
     {
       // one HalfBandFilter per input row: mUppers[j] (MLDSPFunctional.h:125-130) / mDowners[j] (:181-184)
       const int id = addProcNode(g, MLGPU_PROC_HALF_BAND, &inputs[j], 1, nullptr, ROLE_REGION_IN, r);
-      if (id < 0) return -id;
+      if (id < 0) return -id;  // (cannot happen after the checks above; the region then simply stays without a result)
       g->nodes[(size_t)id].rate = RATE_AUDIO;
-      R.ins.push_back(id);
+      g->regions[(size_t)r].ins.push_back(id);
       regionInputs[j] = id;
     }
-    g->regions.push_back(R);
     g->openRegion = r;
     return MLGPU_OK;
   }
@@ -1044,8 +1052,8 @@ extern "C"
     for (int o : g->outputs)
       if (g->nodes[(size_t)o].region >= 0) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: an output is a node inside a rate region");
     for (const Node& n : g->nodes)
-      if (n.type == NODE_FEEDBACK && n.fbSource >= 0 && g->nodes[(size_t)n.fbSource].region >= 0)
-        return gfail(g, MLGPU_ERR_INVALID, "graph_compile: a feedback node's source is inside a rate region");
+      if (n.type == NODE_FEEDBACK && n.fbSource >= 0 && g->nodes[(size_t)n.fbSource].region != n.region)
+        return gfail(g, MLGPU_ERR_INVALID, "graph_compile: a feedback node and its source must be in the same rate region (or both outside)");
     size_t memFloats = 0;
     g->totalRings = 0;
     for (Node& n : g->nodes)

@@ -1349,6 +1349,32 @@ extern "C"
     return MLGPU_OK;
   }
 
+  // The same two function objects around a function that keeps a DSPVector between ITS calls: fn = Allpass<IntegerDelay>
+  // (gain, delay; its vy1 is one-vector feedback at fn's own rate) followed by a OnePole. x / out [V][64 T].
+  int mlref_rate_allpass_run(int up, size_t V, size_t T, float gain, float maxDelay, float delay, const float* onePoleCoeffs, const float* x, float* out)
+  {
+    for (size_t v = 0; v < V; ++v)
+    {
+      Upsample2xFunction<1> upFn;
+      Downsample2xFunction<1> downFn;
+      Allpass<IntegerDelay> ap;
+      ap.mGain = gain;
+      ap.setMaxDelayInSamples(maxDelay);
+      ap.setDelayInSamples(delay);
+      OnePole lp;
+      lp.coeffs = {onePoleCoeffs[0], onePoleCoeffs[1]};
+      auto fn = [&](const DSPVector vx) { return lp(ap(vx)); };
+      for (size_t t = 0; t < T; ++t)
+      {
+        DSPVector vx;
+        load(vx, x + (v * T + t) * kFloatsPerDSPVector);
+        const DSPVector y = up ? upFn(fn, vx) : downFn(fn, vx);
+        store(y, out + (v * T + t) * kFloatsPerDSPVector);
+      }
+    }
+    return MLGPU_OK;
+  }
+
   // ---- Downsampler / Upsampler: the reference classes driven vector by vector, same contract as mlorc_resample ----
   namespace
   {

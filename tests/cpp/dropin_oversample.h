@@ -7,6 +7,7 @@ struct OversampleState
   Upsample2xFunction<1> upper;
   Downsample2xFunction<2> downer;
   Lopass preFilter;  // lives inside the 2x function: sees 128 samples per DSPVector of input
+  Allpass<IntegerDelay> smear;  // so does this one: its ring and its kept DSPVector (vy1) run at 2x
   SineGen carrier;   // lives inside the half-rate function: advances 32 samples per DSPVector of input
   OnePole smooth;
   DCBlocker dc;
@@ -15,6 +16,9 @@ struct OversampleState
 inline void oversampleSetup(OversampleState& s)
 {
   s.preFilter.coeffs = Lopass::makeCoeffs(0.15f, 0.9f);
+  s.smear.mGain = 0.5f;
+  s.smear.setMaxDelayInSamples(200.f);
+  s.smear.setDelayInSamples(113.f);
   s.smooth.coeffs = OnePole::makeCoeffs(0.1f);
   s.dc.coeffs = DCBlocker::makeCoeffs(0.002f);
 }
@@ -29,7 +33,7 @@ inline void oversampleProcess(AudioContext* ctx, void* stateData)
   DSPVector shaped = s->upper(
       [&](const DSPVector x)
       {
-        DSPVector driven = s->preFilter(x * DSPVector(4.0f));
+        DSPVector driven = s->smear(s->preFilter(x * DSPVector(4.0f)));
         return clamp(driven - driven * driven * driven * DSPVector(0.333f), DSPVector(-1.f), DSPVector(1.f));
       },
       in);

@@ -436,6 +436,16 @@ class Ref(_Checker):
                   _ptr(C["env"], c_f32p), seeds.ctypes.data_as(c_u32p), _ptr(gate, c_f32p), _ptr(out, c_f32p), int(n_threads))
         return out, sec
 
+    def rate_allpass_run(self, up, gain, max_delay, delay, one_pole_coeffs, x):
+        """Upsample2xFunction<1> / Downsample2xFunction<1> around fn = OnePole(Allpass<IntegerDelay>(x)) (mlref_rate_allpass_run)."""
+        fnc = self.lib.mlref_rate_allpass_run
+        fnc.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p]
+        x = np.ascontiguousarray(x, np.float32)
+        co = np.ascontiguousarray(one_pole_coeffs, np.float32)
+        out = np.empty_like(x)
+        assert fnc(1 if up else 0, x.shape[0], x.shape[1] // 64, gain, max_delay, delay, _ptr(co, c_f32p), _ptr(x, c_f32p), _ptr(out, c_f32p)) == 0
+        return out
+
     def dspbuffer(self, size):
         return _RefDSPBuffer(self.lib, size)
 

@@ -141,8 +141,10 @@ def main():
     from inputs import region_case
     x, m, freq = region_case(4, 10)
     co = ref.make_coeffs("lopass", 0.2, 0.8)
+    opc = ref.make_coeffs("onepole", 0.3)
     np.savez_compressed(os.path.join(HERE, "regions.npz"), x=x, m=m, freq=freq, co=co, up=ref.rate_function_run(True, freq, co, x, m),
-                        down=ref.rate_function_run(False, freq, co, x, m))
+                        down=ref.rate_function_run(False, freq, co, x, m), opc=opc,
+                        ap_up=ref.rate_allpass_run(True, 0.6, 300.0, 171.0, opc, x), ap_down=ref.rate_allpass_run(False, 0.6, 300.0, 171.0, opc, x))
     # ---- BASELINE configs[4]: the synth16 voice written with the reference's objects ----
     from inputs import gate_signal
     from madronalib_amd.sharding import cfg5_voice_params

@@ -85,6 +85,47 @@ def test_rate_regions_vs_oracle_split_launches(eng, oracle, kind, vpl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,key", [(Region.UPSAMPLE_2X, "ap_up"), (Region.DOWNSAMPLE_2X, "ap_down")])
+def test_rate_region_with_feedback_and_delay(eng, kind, key):
+    """fn = OnePole(Allpass<IntegerDelay>(x)): a delay ring and a one-vector feedback (Allpass::vy1) that live at fn's own
+    rate, inside the region; golden outputs of the reference objects, split launches included."""
+    import madronalib_amd as ml
+    from madronalib_amd import patches
+    x, opc = GOLD["x"], GOLD["opc"]
+    V, T = x.shape[0], x.shape[1] // 64
+    g = ml.Graph(eng, V)
+    g.add("x", "input")
+    g.begin_region(kind, ["x"], ["rx"])
+    sub, y = patches.allpass("ap_", "rx", Proc.INTEGER_DELAY, 300.0)
+    for n in sub:
+        g.add(**{k: v for k, v in n.items() if k != "source"})
+    for n in sub:
+        if n["type"] == "feedback":
+            g.set_feedback(n["name"], n["source"])
+    g.add("lp", "proc", Proc.ONE_POLE, [y])
+    out = g.end_region("lp", "out")
+    g.add_output(out)
+    g.compile()
+    g.set_param("ap_gain", 0.6)
+    g.set_coeffs("lp", [np.full(V, c, np.float32) for c in opc])
+    g.set_state("ap_delay", 1, np.full(V, 171 - 64, np.uint32))     # Allpass::setDelayInSamples(d): the inner delay gets d - 64
+    got = np.concatenate([g.process_host(n, {"x": np.ascontiguousarray(x[:, 64 * a:64 * (a + n)])}, Layout.QUAD)[0] for a, n in ((0, 3), (3, 1), (4, 6))], 1)
+    assert_bits_equal(got, GOLD[key], True, f"{key} vs the reference objects")
+    assert np.abs(GOLD[key]).max() > 0.1
+    # a feedback node may not cross the region's border
+    g2 = ml.Graph(eng, 64)
+    g2.add("x", "input")
+    fb = g2.add("fb", "feedback")
+    (rx,) = g2.begin_region(kind, ["x"])
+    inner = g2.add("i", "op", Op.ADD, [rx, rx])
+    o = g2.end_region(inner, "o")
+    g2.set_feedback(fb, inner)
+    g2.add_output(o)
+    with pytest.raises(ml.MlgpuError):
+        g2.compile()
+
+
+@pytest.mark.gpu
 def test_region_rules(eng):
     import madronalib_amd as ml
     g = ml.Graph(eng, 64)
@@ -102,8 +143,6 @@ def test_region_rules(eng):
         g.add("bad", "op", Op.ADD, [rx, "x"])                       # an outer audio-rate signal does not exist at 2x
     with pytest.raises(ml.MlgpuError):
         g.add("bad2", "op", Op.ADD, [rx, "c"])                      # nor does a control
-    with pytest.raises(ml.MlgpuError):
-        g.add("fb", "feedback")
     ok = g.add("ok", "op", Op.MULTIPLY, [rx, "p"])                  # per-voice floats are fine
     with pytest.raises(ml.MlgpuError):
         g.end_region("x")                                           # result must be a node of the region
