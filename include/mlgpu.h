@@ -471,6 +471,14 @@ int mlgpu_graph_num_nodes(mlgpu_graph* g);
 /* Voices evaluated by one wavefront lane (before compile): 0 = automatic (default), 1, or 2. Two voices per lane interleave
  * two independent dependency chains, which helps arithmetic-bound graphs; results are identical. */
 int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n);
+/* Online tuning (before compile). The generated kernel exists in up to four forms - one or two voices per lane, one or two
+ * quads per trip of the sample loop - that compute the same bits from the same state, and which one is fastest depends on
+ * the graph (registers, code size against the instruction cache) and on the regime (burst or sustained). With tuning on, the
+ * first process calls of at least 4 Mi voice-samples take turns through the forms (three calls each, timed with events: these
+ * calls wait for the device; a form is compiled when its turn comes), then the fastest stays. Results never differ.
+ * mlgpu_graph_tuning: 1 when settled (or tuning is off), 0 while still measuring; reports the form in use. */
+int mlgpu_graph_set_autotune(mlgpu_graph* g, int on);
+int mlgpu_graph_tuning(mlgpu_graph* g, int* voices_per_lane, int* quads_per_trip);
 /* Generate + compile (hiprtc, gfx950) + load the fused kernel; allocate state/coeffs/params. */
 int mlgpu_graph_compile(mlgpu_graph* g);
 /* The generated HIP source (valid after compile; for inspection). */

@@ -676,7 +676,7 @@ class Graph:
       {"name", "type": "input"|"param"|"const"|"proc"|"op", "kind": Proc.X / Op.X, "inputs": [names], "value"}
     """
 
-    def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0, delay_windows=False):
+    def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0, delay_windows=False, autotune=False):
         self.engine = engine
         self.L = engine.L
         self.V = int(n_voices)
@@ -690,6 +690,8 @@ class Graph:
             engine._check(self.L.mlgpu_graph_set_voices_per_lane(self.h, int(voices_per_lane)))
         if delay_windows:
             engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 1))
+        if autotune:
+            engine._check(self.L.mlgpu_graph_set_autotune(self.h, 1))
         if description is not None:
             for n in description:
                 self.add(**n)
@@ -705,6 +707,12 @@ class Graph:
         if getattr(self, "h", None) and (self.engine.h or isinstance(self.engine, OfflineEngine)):
             self.L.mlgpu_graph_destroy(self.h)
         self.h = None
+
+    def tuning(self):
+        """(settled, voices per lane, quads per trip) of the kernel form in use (mlgpu_graph_tuning)."""
+        vl, u = ctypes.c_int(), ctypes.c_int()
+        r = self.L.mlgpu_graph_tuning(self.h, ctypes.byref(vl), ctypes.byref(u))
+        return bool(r > 0), vl.value, u.value
 
     def emit(self):
         """(kernel source, gfx950 code object bytes) without a device (mlgpu_graph_emit)."""

@@ -144,6 +144,8 @@ def _declare(L):
     sig("mlgpu_graph_set_input_layout", i, [vp, i, i])
     sig("mlgpu_graph_set_voices_per_lane", i, [vp, i])
     sig("mlgpu_graph_set_delay_layout", i, [vp, i])
+    sig("mlgpu_graph_set_autotune", i, [vp, i])
+    sig("mlgpu_graph_tuning", i, [vp, c.POINTER(i), c.POINTER(i)])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
     sig("mlgpu_mixdown_groups", i, [vp, vp, i, sz, sz, sz, vp, i])
     sig("mlgpu_events_create", i, [vp, sz, i, pp])

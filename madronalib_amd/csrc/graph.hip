@@ -40,53 +40,6 @@ std::mutex g_cacheMutex;
 std::map<std::string, CompiledModule> g_cache;  // key: device id + source
 
 // compile `source` for gfx950 and load it on the current device; returns nullptr and fills `log` on failure
-CompiledModule* compileAndLoad(int device, const std::string& source, std::string& log)
-{
-  std::lock_guard<std::mutex> lock(g_cacheMutex);
-  const std::string key = std::to_string(device) + "\n" + source;
-  auto it = g_cache.find(key);
-  if (it != g_cache.end()) return &it->second;
-
-  hiprtcProgram prog;
-  if (hiprtcCreateProgram(&prog, source.c_str(), "mlgpu_jit.hip", mlgpu_embedded_count, (const char**)mlgpu_embedded_sources,
-                          (const char**)mlgpu_embedded_names) != HIPRTC_SUCCESS)
-  {
-    log = "hiprtcCreateProgram failed";
-    return nullptr;
-  }
-  // same numerics flags as the ahead-of-time build (madronalib_amd/csrc/Makefile)
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
-  const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
-  size_t logSize = 0;
-  hiprtcGetProgramLogSize(prog, &logSize);
-  if (logSize > 1)
-  {
-    log.resize(logSize);
-    hiprtcGetProgramLog(prog, &log[0]);
-  }
-  if (r != HIPRTC_SUCCESS)
-  {
-    if (log.empty()) log = hiprtcGetErrorString(r);
-    hiprtcDestroyProgram(&prog);
-    return nullptr;
-  }
-  size_t codeSize = 0;
-  hiprtcGetCodeSize(prog, &codeSize);
-  std::vector<char> code(codeSize);
-  hiprtcGetCode(prog, code.data());
-  hiprtcDestroyProgram(&prog);
-
-  CompiledModule cm;
-  const hipError_t e = hipModuleLoadData(&cm.module, code.data());
-  if (e != hipSuccess)
-  {
-    log = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
-    return nullptr;
-  }
-  return &(g_cache[key] = cm);
-}
-
-// compile only (no device needed): used by mlgpu_jit_selftest
 bool compileToCode(const std::string& source, std::vector<char>& code, std::string& log)
 {
   hiprtcProgram prog;
@@ -118,6 +71,47 @@ bool compileToCode(const std::string& source, std::vector<char>& code, std::stri
   return r == HIPRTC_SUCCESS && codeSize > 0;
 }
 
+// hiprtc results by source: identical graphs (and the size probe of graph_compile) compile once per process
+std::mutex g_codeMutex;
+std::map<std::string, std::vector<char>> g_codeCache;
+bool getCode(const std::string& source, std::vector<char>& code, std::string& log)
+{
+  {
+    std::lock_guard<std::mutex> lock(g_codeMutex);
+    auto it = g_codeCache.find(source);
+    if (it != g_codeCache.end())
+    {
+      code = it->second;
+      return true;
+    }
+  }
+  if (!compileToCode(source, code, log)) return false;
+  std::lock_guard<std::mutex> lock(g_codeMutex);
+  g_codeCache[source] = code;
+  return true;
+}
+
+CompiledModule* compileAndLoad(int device, const std::string& source, std::string& log)
+{
+  std::lock_guard<std::mutex> lock(g_cacheMutex);
+  const std::string key = std::to_string(device) + "\n" + source;
+  auto it = g_cache.find(key);
+  if (it != g_cache.end()) return &it->second;
+
+  std::vector<char> code;
+  if (!getCode(source, code, log)) return nullptr;
+
+  CompiledModule cm;
+  const hipError_t e = hipModuleLoadData(&cm.module, code.data());
+  if (e != hipSuccess)
+  {
+    log = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
+    return nullptr;
+  }
+  return &(g_cache[key] = cm);
+}
+
+// compile only (no device needed): used by mlgpu_jit_selftest
 bool compileOnly(const std::string& source, std::string& log)
 {
   std::vector<char> code;
@@ -244,6 +238,21 @@ struct mlgpu_graph
   size_t vectorCount{0};         // DSPVectors processed since the last clear (GraphArgs::t0)
   int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
   int compiledVoicesPerLane{1};
+  int unrollQ{1};                // quads per trip of the sample loop
+  // Online tuning (mlgpu_graph_set_autotune): every variant (voices per lane x quads per trip) computes the same bits from
+  // the same state arrays, so the first process calls simply take turns, are timed, and the fastest one stays.
+  struct Variant
+  {
+    int vl{1}, unroll{1};
+    hipFunction_t fn{nullptr};
+    bool failed{false};
+    int runs{0};
+    float bestMs{1e30f};
+  };
+  bool autotune{false}, tuned{false};
+  std::vector<Variant> variants;
+  hipEvent_t tuneEv0{nullptr}, tuneEv1{nullptr};
+  int activeVl{1};               // of the kernel in `fn`
   int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 };
 
@@ -317,26 +326,27 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
   return s.str();
 }
 
-// Voices per lane. A fused voice is ONE dependent chain of VALU instructions per lane, and on gfx950 a wave's
-// back-to-back dependent instructions issue at half rate whatever the occupancy (tools/valubench.hip). With two voices
-// per lane (voice v and v + 256 of the same workgroup: loads and stores stay coalesced) every statement is emitted for
-// both and the two chains interleave. Worth it for arithmetic-heavy graphs; graphs with delay rings or long vector state
-// stay at one voice per lane (their limit is memory latency, and registers are better spent on occupancy).
+// Voices per lane and quads per trip of the sample loop. A fused voice is ONE dependent chain of VALU instructions per lane;
+// two voices per lane (voice v and v + 256 of the same workgroup: loads and stores stay coalesced) interleave two chains,
+// two quads per trip give the scheduler a longer window. Both also double the code and cost registers, and on this chip the
+// plain form - one voice, one quad - is the fastest for every graph measured so far (config 5: 0.82 ms per launch against
+// 0.95 with two voices per lane and 0.93 with two quads; a 34 KiB loop body falls off the instruction cache and runs at half
+// speed). So the plain form is the default; mlgpu_graph_set_voices_per_lane forces two voices, and
+// mlgpu_graph_set_autotune lets the first launches try all four forms and keep the fastest.
 int graphVoicesPerLane(const mlgpu_graph* g)
 {
-  if (g->voicesPerLane > 0) return g->voicesPerLane;
-  int audioNodes = 0;
-  for (const Node& n : g->nodes)
+  if (g->voicesPerLane > 0)
   {
-    if (n.type == NODE_FEEDBACK || (n.type == NODE_PROC && (mlgpu_proc_rings(n.kind) || mlgpu_proc_is_vector_rate(n.kind)))) return 1;
-    if (n.rate == RATE_AUDIO && (n.type == NODE_PROC || n.type == NODE_OP || n.type == NODE_ROUTE)) audioNodes++;
+    for (const Node& n : g->nodes)
+      if (n.type == NODE_FEEDBACK || (n.type == NODE_PROC && (mlgpu_proc_rings(n.kind) || mlgpu_proc_is_vector_rate(n.kind)))) return 1;
+    return g->voicesPerLane;
   }
-  return (audioNodes >= 8 && g->NS + g->NC <= 80) ? 2 : 1;
+  return 1;
 }
 
-std::string generateGraphSource(mlgpu_graph* g)
+std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
 {
-  const int VL = graphVoicesPerLane(g);
+  const int VL = forceVl > 0 ? forceVl : graphVoicesPerLane(g);
   g->compiledVoicesPerLane = VL;
   std::ostringstream s;
   auto sfx = [](int l) { return "_" + std::to_string(l); };
@@ -425,7 +435,7 @@ std::string generateGraphSource(mlgpu_graph* g)
     else if (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".begin_vector(n" << n.in[0] << sfx(l) << ");\n";
   }
-  s << "#pragma unroll " << ((g->windowedRings && g->totalRings) ? 1 : 2) << "\n    for (int q = 0; q < 16; ++q)\n    {\n";
+  s << "#pragma unroll " << ((g->windowedRings && g->totalRings) ? 1 : g->unrollQ) << "\n    for (int q = 0; q < 16; ++q)\n    {\n";
   for (int i = 0; i < g->nInputs; ++i)
     for (int l = 0; l < VL; ++l)
       s << "      const f32x4 xin" << i << sfx(l) << " = __builtin_nontemporal_load(in" << i << sfx(l) << " + t * a.in[" << i << "].strideT + q * a.in["
@@ -798,6 +808,8 @@ extern "C"
     if (g->d_state) hipFree(g->d_state);
     if (g->d_params) hipFree(g->d_params);
     if (g->d_mem) hipFree(g->d_mem);
+    if (g->tuneEv0) hipEventDestroy(g->tuneEv0);
+    if (g->tuneEv1) hipEventDestroy(g->tuneEv1);
     delete g;
     return MLGPU_OK;
   }
@@ -1069,7 +1081,11 @@ extern "C"
     g->memFloatsPerVoice = memFloats;
     if (g->windowedRings && (size_t)g->totalRings * 8 * 256 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: windowed delay layout needs 8 KiB of LDS per ring; at most 20 rings per graph");
+    const char* forced = getenv("MLGPU_GRAPH_UNROLL");  // developer knob: quads per trip of the sample loop
+    // delay graphs wait on their ring reads: two quads per trip keep more of them in flight (allpass4: 5.4 vs 4.5 x 10^10)
+    g->unrollQ = forced ? std::max(1, atoi(forced)) : ((g->totalRings && !g->windowedRings) ? 2 : 1);
     g->source = generateGraphSource(g);
+    if (!getCode(g->source, g->emitted, g->log)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
     return MLGPU_OK;
   }
 
@@ -1078,7 +1094,7 @@ extern "C"
     if (!g) return MLGPU_ERR_INVALID;
     const int st = layoutAndGenerate(g);
     if (st != MLGPU_OK) return st;
-    if (g->emitted.empty() && !compileToCode(g->source, g->emitted, g->log)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_emit (hiprtc): " + g->log);
+    if (g->emitted.empty()) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_emit (hiprtc): " + g->log);
     if (code) *code = g->emitted.data();
     if (codeSize) *codeSize = g->emitted.size();
     return MLGPU_OK;
@@ -1097,6 +1113,27 @@ extern "C"
     if (!cm) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
     g->fn = getFunction(cm, "mlgpu_graph_kernel", g->log);
     if (!g->fn) return gfail(g, MLGPU_ERR_HIP, g->log);
+    g->activeVl = g->compiledVoicesPerLane;
+    if (g->autotune)
+    {
+      // candidates: 1 or 2 voices per lane (where the graph allows two and the caller did not force one), 1 or 2 quads per trip
+      const bool twoOk = g->voicesPerLane == 0 && [&] {
+        for (const Node& n : g->nodes)
+          if (n.type == NODE_FEEDBACK || (n.type == NODE_PROC && (mlgpu_proc_rings(n.kind) || mlgpu_proc_is_vector_rate(n.kind)))) return false;
+        return true;
+      }();
+      const bool unrollFree = !(g->windowedRings && g->totalRings);
+      for (int vl = 1; vl <= (twoOk ? 2 : 1); ++vl)
+        for (int u = 1; u <= (unrollFree ? 2 : 1); ++u)
+        {
+          mlgpu_graph::Variant v;
+          v.vl = g->voicesPerLane > 0 ? g->voicesPerLane : vl;
+          v.unroll = u;
+          if (v.vl == g->activeVl && u == g->unrollQ) v.fn = g->fn;  // the default variant is already built
+          g->variants.push_back(v);
+        }
+      g->tuned = g->variants.size() < 2;
+    }
     const size_t V = g->V;
     hipError_t err = hipMalloc((void**)&g->d_coeffs, sizeof(float) * V * (size_t)(g->NC + 1));
     if (err == hipSuccess) err = hipMalloc((void**)&g->d_state, sizeof(uint32_t) * V * (size_t)(g->NS + 1));
@@ -1235,6 +1272,21 @@ extern "C"
     return MLGPU_OK;
   }
 
+  int mlgpu_graph_set_autotune(mlgpu_graph* g, int on)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    g->autotune = on != 0;
+    return MLGPU_OK;
+  }
+  int mlgpu_graph_tuning(mlgpu_graph* g, int* voicesPerLane, int* quadsPerTrip)
+  {
+    if (!g || !g->compiled) return -MLGPU_ERR_INVALID;
+    if (voicesPerLane) *voicesPerLane = g->activeVl;
+    if (quadsPerTrip) *quadsPerTrip = g->unrollQ;
+    return (g->autotune && !g->tuned) ? 0 : 1;
+  }
+
   int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n)
   {
     if (!g) return MLGPU_ERR_INVALID;
@@ -1303,8 +1355,62 @@ extern "C"
       a.out[o] = makeView(d_outputs[o], outLayout, g->V, T);
     }
     if (hipSetDevice(g->e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
-    const hipError_t err = launchJit(g->fn, a, (g->V + g->compiledVoicesPerLane - 1) / g->compiledVoicesPerLane, g->e->stream);
+    // online tuning: launches big enough to time take turns through the variants (3 runs each, the first one discarded)
+    mlgpu_graph::Variant* trial = nullptr;
+    if (g->autotune && !g->tuned && g->V * T * MLGPU_FLOATS_PER_DSPVECTOR >= ((size_t)1 << 22))
+    {
+      for (mlgpu_graph::Variant& v : g->variants)
+        if (!v.failed && v.runs < 3 && (!trial || v.runs < trial->runs)) trial = &v;
+      if (trial && !trial->fn)
+      {
+        const int keepUnroll = g->unrollQ, keepVl = g->compiledVoicesPerLane;
+        g->unrollQ = trial->unroll;
+        const std::string src = generateGraphSource(g, trial->vl);
+        g->unrollQ = keepUnroll;
+        g->compiledVoicesPerLane = keepVl;
+        std::string log;
+        CompiledModule* cm = compileAndLoad(g->e->device, src, log);
+        trial->fn = cm ? getFunction(cm, "mlgpu_graph_kernel", log) : nullptr;
+        if (!trial->fn)
+        {
+          trial->failed = true;
+          trial = nullptr;
+        }
+      }
+      if (!trial)
+      {
+        // every variant has its runs: keep the fastest
+        const mlgpu_graph::Variant* best = nullptr;
+        for (const mlgpu_graph::Variant& v : g->variants)
+          if (!v.failed && v.fn && v.runs >= 2 && (!best || v.bestMs < best->bestMs)) best = &v;
+        if (best)
+        {
+          g->fn = best->fn;
+          g->activeVl = best->vl;
+          g->unrollQ = best->unroll;
+        }
+        g->tuned = true;
+      }
+    }
+    const hipFunction_t fn = trial ? trial->fn : g->fn;
+    const int vl = trial ? trial->vl : g->activeVl;
+    if (trial && !g->tuneEv0 && (hipEventCreate(&g->tuneEv0) != hipSuccess || hipEventCreate(&g->tuneEv1) != hipSuccess))
+      return gfail(g, MLGPU_ERR_HIP, "graph_process: hipEventCreate");
+    if (trial) hipEventRecord(g->tuneEv0, g->e->stream);
+    const hipError_t err = launchJit(fn, a, (g->V + (size_t)vl - 1) / (size_t)vl, g->e->stream);
     if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, std::string("graph_process launch: ") + hipGetErrorString(err));
+    if (trial)
+    {
+      hipEventRecord(g->tuneEv1, g->e->stream);
+      float ms = 0.f;
+      if (hipEventSynchronize(g->tuneEv1) == hipSuccess && hipEventElapsedTime(&ms, g->tuneEv0, g->tuneEv1) == hipSuccess)
+      {
+        if (trial->runs >= 1) trial->bestMs = std::min(trial->bestMs, ms / (float)T);
+        trial->runs++;
+      }
+      else
+        trial->failed = true;
+    }
     g->vectorCount += T;
     return MLGPU_OK;
   }

@@ -351,3 +351,38 @@ def test_vector_rate_rules(eng):
     g.compile()
     with pytest.raises(ml.MlgpuError):
         g.process(1, [eng.alloc(64 * 64 * 4)], [eng.alloc(64 * 64 * 4)])   # control list missing
+
+
+@pytest.mark.gpu
+def test_online_tuning_same_bits_and_settles(eng, oracle):
+    """mlgpu_graph_set_autotune: the first big launches take turns through the kernel forms (voices per lane x quads per
+    trip); every launch gives the reference's bits whichever form ran, and the graph settles on one form."""
+    import madronalib_amd as ml
+    V, T = 16384, 4                   # 4 Mi voice-samples per launch: the smallest launch that is timed
+    params, coeffs = synth16_setup(oracle, 64, seed=8)
+    idx = np.arange(V) % 64
+    P = {k: (v[idx] if np.ndim(v) else v) for k, v in params.items()}
+    C = {k: np.ascontiguousarray(c[:, idx]) for k, c in coeffs.items()}
+    seeds = (np.arange(V, dtype=np.uint32) % 64) + np.uint32(3)
+    desc, outs = patches.synth16()
+    g = ml.Graph(eng, V, desc, outs, autotune=True)
+    g.clear()
+    for k, v in P.items():
+        g.set_param(k, v if np.ndim(v) else float(v))
+    for k, c in C.items():
+        g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+    g.set_state("noise", 0, seeds)
+    states = {n["name"]: oracle.chain_clear([n["kind"]], 64) for n in desc if n["type"] == "proc"}
+    states["noise"][0] = seeds[:64]
+    gate64 = gate_signal(64, 64 * T * 14, seed=2)
+    forms = set()
+    for call in range(14):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        (got,) = g.process_host(T, {"gate": np.ascontiguousarray(gate64[idx][:, sl])}, Layout.QUAD)
+        (want,) = evaluate(oracle, desc, outs, 64, T, {"gate": np.ascontiguousarray(gate64[:, sl])}, params, coeffs, states)
+        assert_bits_equal(got[:64], want, True, f"call {call}")
+        assert (got.reshape(V // 64, 64, -1).view(np.uint32) == want.view(np.uint32)[None]).all()
+        forms.add(g.tuning())
+    settled, vl, quads = g.tuning()
+    assert settled and vl in (1, 2) and quads in (1, 2)
+    assert any(not f[0] for f in forms)    # it did go through a measuring phase
