@@ -175,7 +175,11 @@ struct Glide
 
 __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
 {
-  const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // XCD-aware workgroup -> lane mapping (as the voice-bank kernels): every XCD writes one contiguous eighth of each row
+  size_t blk = blockIdx.x;
+  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
+  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);
+  const size_t lane = blk * 256 + threadIdx.x;
   const bool live = lane < a.lanes;
   const size_t L = live ? lane : 0;
   const int slot = (int)(L % (size_t)a.group) + a.slotBase;  // 0 = MPE main voice (MPE mode only), 1..polyphony = playing voices

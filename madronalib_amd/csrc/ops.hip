@@ -29,8 +29,20 @@ __global__ __launch_bounds__(kOpBlock) void op_kernel(const u32x4* a, const u32x
                                                       size_t n4, size_t n)
 {
   constexpr int AR = arity<OP>();
-  const size_t stride = (size_t)gridDim.x * kOpBlock;
+  // XCD-aware element mapping: workgroup b runs on XCD b % 8; give XCD x the x-th contiguous eighth of the array (each
+  // XCD's L2 then streams one contiguous segment), grid-stride inside it. Any bijection is correct; this is for speed:
+  // expApprox(sinApprox(x)) over 1 GiB 4.99 -> 5.67 TB/s, over 16 MiB (Infinity-Cache resident) 6.15 -> 6.35.
+  size_t stride = (size_t)gridDim.x * kOpBlock;
   size_t i = (size_t)blockIdx.x * kOpBlock + threadIdx.x;
+  size_t end = n4;
+  if ((gridDim.x & 7) == 0 && n4 >= (size_t)gridDim.x * kOpBlock * kOpUnroll)
+  {
+    const size_t per = (n4 / 8) & ~(size_t)(kOpBlock - 1), x = blockIdx.x & 7;
+    stride = (size_t)(gridDim.x >> 3) * kOpBlock;
+    i = x * per + (size_t)(blockIdx.x >> 3) * kOpBlock + threadIdx.x;
+    end = (x == 7) ? n4 : (x + 1) * per;
+  }
+  n4 = end;
   for (; i + (kOpUnroll - 1) * stride < n4; i += kOpUnroll * stride)
   {
     u32x4 va[kOpUnroll], vb[kOpUnroll], vc[kOpUnroll];

@@ -103,24 +103,43 @@ struct ResampleArgs
 
 MLD f32x4* quadPtr(const SignalView& s, size_t v, size_t qi) { return (f32x4*)s.base + (qi >> 4) * s.strideT + (qi & 15) * s.strideQ + v * s.strideV; }
 
+// XCD-aware workgroup -> voice mapping, as the voice-bank kernels (mldsp_kernels.hpp): XCD x works on the x-th contiguous
+// eighth of the voices, so every XCD's L2 streams one contiguous segment of each signal row
+MLD size_t xcdVoice()
+{
+  size_t blk = blockIdx.x;
+  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
+  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);
+  return blk * 256 + threadIdx.x;
+}
+
 template <int H>
 __global__ __launch_bounds__(256) void downsample_kernel(const ResampleArgs a)
 {
-  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t v = xcdVoice();
   if (v >= a.V) return;
   HalfBand f[H > 0 ? H : 1];
 #pragma unroll
   for (int h = 0; h < H; ++h) f[h].load(a.state + (size_t)h * 9 * a.V + v, a.V);
   constexpr int R = 1 << H;  // input quads per output quad
+  // the R input quads of output quad qo + 1 are in flight while quad qo is filtered
+  f32x4 nx[R];
+  if (a.quadsOut)
+  {
+#pragma unroll
+    for (int r = 0; r < R; ++r) nx[r] = __builtin_nontemporal_load(quadPtr(a.in, v, (size_t)r));
+  }
   for (size_t qo = 0; qo < a.quadsOut; ++qo)
   {
     float x[4 * R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
     {
-      const f32x4 q = __builtin_nontemporal_load(quadPtr(a.in, v, qo * R + r));
-      x[4 * r] = q.x; x[4 * r + 1] = q.y; x[4 * r + 2] = q.z; x[4 * r + 3] = q.w;
+      x[4 * r] = nx[r].x; x[4 * r + 1] = nx[r].y; x[4 * r + 2] = nx[r].z; x[4 * r + 3] = nx[r].w;
     }
+    const size_t qn = (qo + 1 < a.quadsOut) ? qo + 1 : qo;  // after the last one: fetch it again (never used)
+#pragma unroll
+    for (int r = 0; r < R; ++r) nx[r] = __builtin_nontemporal_load(quadPtr(a.in, v, qn * R + r));
     f32x4 y;
 #pragma unroll
     for (int k = 0; k < 4; ++k) y[k] = DownCascade<H>::run(f, x + k * R);
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(256) void downsample_kernel(const ResampleArgs a)
 template <int H>
 __global__ __launch_bounds__(256) void upsample_kernel(const ResampleArgs a)
 {
-  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t v = xcdVoice();
   if (v >= a.V) return;
   HalfBand f[H > 0 ? H : 1];
 #pragma unroll
