@@ -147,14 +147,30 @@ struct Glide
     }
     modeFlags = (modeFlags & 4) | m;
   }
-  MLD float next(uint32_t* st, size_t stride, int n) const
+  // mCurrVec[n] is read and rewritten at sample n only, so a quad's four slots can be fetched together (and a quad ahead):
+  // a load per sample in the middle of the load -> add -> store chain made the whole kernel wait out a memory round trip
+  // per sample (62 us per DSPVector per wavefront).
+  MLD bool readsCurrVec() const { return !isUniform() && (mode() == 0 || mode() == 3); }
+  MLD void preload(const uint32_t* st, size_t stride, int q, float cur[4]) const
+  {
+    if (readsCurrVec())
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cur[k] = u2f(st[(size_t)(5 + 4 * q + k) * stride]);
+    }
+  }
+  MLD float next(uint32_t* st, size_t stride, int n) const  // one sample at a time (the record-walking path)
+  {
+    return nextWith(st, stride, n, readsCurrVec() ? u2f(st[(size_t)(5 + n) * stride]) : 0.f);
+  }
+  MLD float nextWith(uint32_t* st, size_t stride, int n, float cur) const  // cur: what preload fetched for slot n
   {
     const int m = mode();
-    if (m == 0) return isUniform() ? uniformValue : u2f(st[(size_t)(5 + n) * stride]);
+    if (m == 0) return isUniform() ? uniformValue : cur;
     if (m == 1) return target;
     float c;
     if (m == 2) c = startValue + ((float)(n + 1) * 0.015625f) * step;
-    else c = (isUniform() ? uniformValue : u2f(st[(size_t)(5 + n) * stride])) + step;
+    else c = (isUniform() ? uniformValue : cur) + step;
     st[(size_t)(5 + n) * stride] = f2u(c);
     return c;
   }
@@ -328,12 +344,16 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
       }
       else
       {
+        float nx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (on) gl.preload(GS(glideIdx), ln, 0, nx);
 #pragma unroll 1
         for (int q = 0; q < 16; ++q)
         {
+          const float cur[4] = {nx[0], nx[1], nx[2], nx[3]};
+          if (on && q < 15) gl.preload(GS(glideIdx), ln, q + 1, nx);
           f32x4 v;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.next(GS(glideIdx), ln, q * 4 + k) : 0.f);
+          for (int k = 0; k < 4; ++k) v[k] = withMain(on ? gl.nextWith(GS(glideIdx), ln, q * 4 + k, cur[k]) : 0.f);
           put(row, q, v);
         }
       }
@@ -375,6 +395,12 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
 #pragma unroll 1
       for (int q = 0; q < 16; ++q)
       {
+        float cz4[4] = {0.f, 0.f, 0.f, 0.f}, cp4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (on)
+        {
+          gz.preload(GS(4), ln, q, cz4);
+          gp.preload(GS(6), ln, q, cp4);
+        }
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -382,8 +408,8 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
           float z = 0.f;
           if (on)
           {
-            z = gz.next(GS(4), ln, q * 4 + k);
-            const float press = gp.next(GS(6), ln, q * 4 + k);
+            z = gz.nextWith(GS(4), ln, q * 4 + k, cz4[k]);
+            const float press = gp.nextWith(GS(6), ln, q * 4 + k, cp4[k]);
             if (!a.s.mpe) z = z + press;
           }
           v[k] = withMain(z);
@@ -441,9 +467,21 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
         }
       }
       if (on) age += (uint32_t)MLGPU_FLOATS_PER_DSPVECTOR * ageStep;
+      float nb[4] = {0.f, 0.f, 0.f, 0.f}, nd[4] = {0.f, 0.f, 0.f, 0.f};  // bend / drift mCurrVec, one quad ahead
+      if (on)
+      {
+        gb.preload(GS(0), ln, 0, nb);
+        gd.preload(GS(5), ln, 0, nd);
+      }
 #pragma unroll 1
       for (int q = 0; q < 16; ++q)
       {
+        const float cb[4] = {nb[0], nb[1], nb[2], nb[3]}, cd[4] = {nd[0], nd[1], nd[2], nd[3]};
+        if (on && q < 15)
+        {
+          gb.preload(GS(0), ln, q + 1, nb);
+          gd.preload(GS(5), ln, q + 1, nd);
+        }
         f32x4 oPitch;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -453,7 +491,7 @@ __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
           if (on)
           {
             vPitch = pitchGlideNext(pitch);
-            const float bendSig = gb.next(GS(0), ln, n), driftSig = gd.next(GS(5), ln, n);
+            const float bendSig = gb.nextWith(GS(0), ln, n, cb[k]), driftSig = gd.nextWith(GS(5), ln, n, cd[k]);
             vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
             vPitch = vPitch + (driftSig * a.s.driftAmount) * 0.02f;           // kDriftScale, :247
           }
