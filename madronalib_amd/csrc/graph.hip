@@ -305,7 +305,12 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
       for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
       s << ")";
       break;
-    case NODE_FEEDBACK: s << "u2f(a.state[(size_t)(" << n.sOff << " + " << idx << ") * a.V + v" << L << "])"; break;
+    case NODE_FEEDBACK:
+      if (n.region < 0)
+        s << "fbv" << i << L << "[k]";  // fetched for the whole quad before the sample loop
+      else
+        s << "u2f(a.state[(size_t)(" << n.sOff << " + " << idx << ") * a.V + v" << L << "])";
+      break;
     case NODE_ROUTE:
       if (n.kind == MLGPU_ROUTE_MULTIPLEX || n.kind == MLGPU_ROUTE_MULTIPLEX_LINEAR)
       {
@@ -447,6 +452,15 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X)
       for (int in : R.ins)
         for (int l = 0; l < VL; ++l) s << "      float prev" << in << sfx(l) << " = 0.f;\n";
+  // A kept DSPVector's slot n is read and rewritten at sample n only: fetch the quad's four slots together, ahead of the
+  // stores of the sample loop (one load per sample between those stores costs a memory round trip per sample).
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+    if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].region < 0)
+      for (int l = 0; l < VL; ++l)
+      {
+        s << "      float fbv" << i << sfx(l) << "[4];\n#pragma unroll\n      for (int kk = 0; kk < 4; ++kk) fbv" << i << sfx(l) << "[kk] = u2f(a.state[(size_t)("
+          << g->nodes[i].sOff << " + q * 4 + kk) * a.V + v" << sfx(l) << "]);\n";
+      }
   s << "#pragma unroll\n      for (int k = 0; k < 4; ++k)\n      {\n";
   {
     std::vector<char> done(g->nodes.size(), 0);
