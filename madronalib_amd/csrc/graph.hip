@@ -461,6 +461,9 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         s << "      float fbv" << i << sfx(l) << "[4];\n#pragma unroll\n      for (int kk = 0; kk < 4; ++kk) fbv" << i << sfx(l) << "[kk] = u2f(a.state[(size_t)("
           << g->nodes[i].sOff << " + q * 4 + kk) * a.V + v" << sfx(l) << "]);\n";
       }
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+    if (g->nodes[i].type == NODE_PROC && (g->nodes[i].kind == MLGPU_PROC_LINEAR_GLIDE || g->nodes[i].kind == MLGPU_PROC_HALF_BAND_BUFFERED))
+      for (int l = 0; l < VL; ++l) s << "      p" << i << sfx(l) << ".begin_quad(q);\n";
   s << "#pragma unroll\n      for (int k = 0; k < 4; ++k)\n      {\n";
   {
     std::vector<char> done(g->nodes.size(), 0);

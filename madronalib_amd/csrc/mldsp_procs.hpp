@@ -810,16 +810,27 @@ struct Proc<MLGPU_PROC_LINEAR_GLIDE>  // :433-515
       remaining--;
     }
   }
+  // mCurrVec slot n is read and rewritten at sample n only: the graph kernel fetches a quad's four slots together
+  // (begin_quad) instead of one load per sample in the middle of the sample loop's stores
+  float cur[4];
+  MLD void begin_quad(int q)
+  {
+    if (mode == kHold || mode == kContinue)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cur[k] = u2f(mem.s(3 + 4 * q + k));
+    }
+  }
   MLD float next_n(int n) const
   {
     float c;
-    if (mode == kHold) return u2f(mem.s(3 + n));
+    if (mode == kHold) return cur[n & 3];
     if (mode == kEnd)
       c = target;
     else if (mode == kStart)
       c = startValue + ((float)(n + 1) * 0.015625f) * step;
     else
-      c = u2f(mem.s(3 + n)) + step;
+      c = cur[n & 3] + step;
     mem.set(3 + n, f2u(c));
     return c;
   }
@@ -1244,7 +1255,13 @@ struct Proc<MLGPU_PROC_HALF_BAND_BUFFERED>
     hb.load(m);
   }
   MLD void store(const VoiceMem& m) const { hb.store(m); }
-  MLD float delayed(int n) const { return u2f(mem.s(9 + n)); }
+  float cur[4];
+  MLD void begin_quad(int q)  // the quad's four delayed samples, fetched before push() rewrites any of them
+  {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cur[k] = u2f(mem.s(9 + 4 * q + k));
+  }
+  MLD float delayed(int n) const { return cur[n & 3]; }
   MLD void push(int n, float x)  // n odd: the inner sample made from outer samples n - 1 and n
   {
     const float ya = hb.pathA(x);
