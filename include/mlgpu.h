@@ -247,6 +247,20 @@ int mlgpu_download(mlgpu_engine* e, void* h_dst, const void* d_src, size_t bytes
 int mlgpu_fill32(mlgpu_engine* e, void* d_dst, uint32_t value, size_t n_elems);
 
 /* HIP-event timing on the engine's stream (events are created lazily, reused). */
+/* Recorded launch sequences (hipGraph). A real-time host calls the same few process functions on the same device buffers
+ * every block, and with small banks those launches are launch-bound (microseconds of kernel behind ~6 us of launch each).
+ * Between begin_recording and end_recording the engine's launches - bank / graph / op / rows / routing / resampler / mixdown /
+ * layout_convert calls - are captured instead of run; mlgpu_sequence_launch replays them all with ONE graph launch, with the
+ * arguments (buffers, vector counts) they were recorded with. Not recordable (MLGPU_ERR_INVALID while recording): calls that
+ * wait for the device or work on the host per call (upload / download / sync, events_process, published_signal_write,
+ * process_buffer), and graphs that count DSPVectors or are still tuning (a DOWNSAMPLE_2X region, autotune not settled). */
+typedef struct mlgpu_sequence mlgpu_sequence;
+int mlgpu_engine_begin_recording(mlgpu_engine* e);
+int mlgpu_engine_end_recording(mlgpu_engine* e, mlgpu_sequence** out);
+int mlgpu_sequence_launch(mlgpu_sequence* s);
+size_t mlgpu_sequence_num_nodes(mlgpu_sequence* s);
+int mlgpu_sequence_destroy(mlgpu_sequence* s);
+
 int mlgpu_timer_start(mlgpu_engine* e);
 int mlgpu_timer_stop_ms(mlgpu_engine* e, float* ms_out); /* records + waits */
 

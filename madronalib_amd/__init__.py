@@ -234,6 +234,55 @@ class Engine:
     def bank(self, procs, n_voices):
         return Bank(self, procs, n_voices)
 
+    def record(self):
+        """Context manager: the launches made inside are captured into a Sequence (one hipGraph launch per replay).
+            with eng.record() as seq: bank.process(...); graph.process(...)
+            seq.launch()"""
+        return _Recording(self)
+
+
+class Sequence:
+    """A recorded launch sequence (mlgpu_sequence)."""
+
+    def __init__(self, engine):
+        self.engine, self.h = engine, None
+
+    def launch(self):
+        self.engine._check(self.engine.L.mlgpu_sequence_launch(self.h))
+
+    @property
+    def num_nodes(self):
+        return int(self.engine.L.mlgpu_sequence_num_nodes(self.h))
+
+    def close(self):
+        if self.h and self.engine.h:
+            self.engine.L.mlgpu_sequence_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Recording:
+    def __init__(self, engine):
+        self.engine, self.seq = engine, Sequence(engine)
+
+    def __enter__(self):
+        self.engine._check(self.engine.L.mlgpu_engine_begin_recording(self.engine.h))
+        return self.seq
+
+    def __exit__(self, exc_type, exc, tb):
+        h = ctypes.c_void_p()
+        st = self.engine.L.mlgpu_engine_end_recording(self.engine.h, ctypes.byref(h))
+        if exc_type is None:
+            self.engine._check(st)
+            self.seq.h = h
+            self.engine._children.add(self.seq)
+        return False
+
 
 class DSPBuffer:
     """The reference's DSPBuffer (MLDSPBuffer.h): a host SPSC float ring (mlgpu_dspbuffer)."""

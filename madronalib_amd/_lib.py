@@ -171,6 +171,11 @@ def _declare(L):
     sig("mlgpu_resampler_get_state", i, [vp, vp])
     sig("mlgpu_resampler_set_state", i, [vp, vp])
     sig("mlgpu_resampler_process", i, [vp, sz, vp, i, vp, i])
+    sig("mlgpu_engine_begin_recording", i, [vp])
+    sig("mlgpu_engine_end_recording", i, [vp, pp])
+    sig("mlgpu_sequence_launch", i, [vp])
+    sig("mlgpu_sequence_num_nodes", sz, [vp])
+    sig("mlgpu_sequence_destroy", i, [vp])
     sig("mlgpu_published_signal_create", i, [vp, i, i, i, i, pp])
     sig("mlgpu_published_signal_destroy", i, [vp])
     sig("mlgpu_published_signal_write", i, [vp, sz, pp, i, sz, sz, sz])

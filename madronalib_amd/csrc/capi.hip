@@ -159,10 +159,72 @@ extern "C"
   int mlgpu_engine_sync(mlgpu_engine* e)
   {
     if (!e) return MLGPU_ERR_INVALID;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "engine_sync: not while recording a sequence");
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return MLGPU_OK;
   }
   void* mlgpu_engine_stream(mlgpu_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+  // ---- recorded launch sequences (hipGraph) ----
+  int mlgpu_engine_begin_recording(mlgpu_engine* e)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "begin_recording: already recording");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed));
+    e->recording = true;
+    return MLGPU_OK;
+  }
+  int mlgpu_engine_end_recording(mlgpu_engine* e, mlgpu_sequence** out)
+  {
+    if (!e || !out) return MLGPU_ERR_INVALID;
+    *out = nullptr;
+    if (!e->recording) return fail(e, MLGPU_ERR_INVALID, "end_recording: not recording");
+    e->recording = false;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(e, hipStreamEndCapture(e->stream, &graph));
+    if (!graph) return fail(e, MLGPU_ERR_HIP, "end_recording: the capture was invalidated (a call that waits for the device ran while recording)");
+    mlgpu_sequence* s = new (std::nothrow) mlgpu_sequence();
+    if (!s)
+    {
+      hipGraphDestroy(graph);
+      return MLGPU_ERR_OOM;
+    }
+    s->e = e;
+    s->graph = graph;
+    const hipError_t err = hipGraphInstantiate(&s->exec, graph, nullptr, nullptr, 0);
+    if (err != hipSuccess)
+    {
+      hipGraphDestroy(graph);
+      delete s;
+      return fail(e, MLGPU_ERR_HIP, "end_recording: hipGraphInstantiate", err);
+    }
+    size_t n = 0;
+    hipGraphGetNodes(graph, nullptr, &n);
+    s->nodes = n;
+    *out = s;
+    return MLGPU_OK;
+  }
+  int mlgpu_sequence_launch(mlgpu_sequence* s)
+  {
+    if (!s) return MLGPU_ERR_INVALID;
+    if (s->e->recording) return fail(s->e, MLGPU_ERR_INVALID, "sequence_launch: the engine is recording");
+    HIP_TRY(s->e, hipSetDevice(s->e->device));
+    HIP_TRY(s->e, hipGraphLaunch(s->exec, s->e->stream));
+    return MLGPU_OK;
+  }
+  size_t mlgpu_sequence_num_nodes(mlgpu_sequence* s) { return s ? s->nodes : 0; }
+  int mlgpu_sequence_destroy(mlgpu_sequence* s)
+  {
+    if (!s) return MLGPU_ERR_INVALID;
+    hipSetDevice(s->e->device);
+    hipStreamSynchronize(s->e->stream);
+    if (s->exec) hipGraphExecDestroy(s->exec);
+    if (s->graph) hipGraphDestroy(s->graph);
+    delete s;
+    return MLGPU_OK;
+  }
   int mlgpu_engine_set_jit(mlgpu_engine* e, int enabled)
   {
     if (!e) return MLGPU_ERR_INVALID;
@@ -195,6 +257,7 @@ extern "C"
   int mlgpu_upload(mlgpu_engine* e, void* d_dst, const void* h_src, size_t bytes)
   {
     if (!e || (bytes && (!d_dst || !h_src))) return MLGPU_ERR_INVALID;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "upload waits for the device: not while recording a sequence");
     if (!bytes) return MLGPU_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->stream));
@@ -204,6 +267,7 @@ extern "C"
   int mlgpu_download(mlgpu_engine* e, void* h_dst, const void* d_src, size_t bytes)
   {
     if (!e || (bytes && (!h_dst || !d_src))) return MLGPU_ERR_INVALID;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "download waits for the device: not while recording a sequence");
     if (!bytes) return MLGPU_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream));

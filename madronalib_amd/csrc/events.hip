@@ -1100,6 +1100,7 @@ extern "C"
     if (!ev || !d_outputs) return MLGPU_ERR_INVALID;
     mlgpu_engine* e = ev->e;
     if (nVectors == 0) return MLGPU_OK;
+    if (e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_process routes events on the host: not while recording a sequence");
     if (ev->sr == 0) return efail(ev, MLGPU_ERR_INVALID, "events_process: no sample rate (the reference does nothing, :385)");
     if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return efail(ev, MLGPU_ERR_INVALID, "events_process: bad layout");
     // ---- route this launch's events into per-voice records ----

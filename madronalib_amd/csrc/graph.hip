@@ -1371,6 +1371,13 @@ extern "C"
       if (!d_outputs[o] || ((uintptr_t)d_outputs[o] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned output");
       a.out[o] = makeView(d_outputs[o], outLayout, g->V, T);
     }
+    if (g->e->recording)
+    {
+      if (g->autotune && !g->tuned) return gfail(g, MLGPU_ERR_INVALID, "graph_process: a graph that is still tuning cannot be recorded into a sequence");
+      for (const Region& R : g->regions)
+        if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X)
+          return gfail(g, MLGPU_ERR_INVALID, "graph_process: a graph with a DOWNSAMPLE_2X region counts DSPVectors and cannot be recorded into a sequence");
+    }
     if (hipSetDevice(g->e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
     // online tuning: launches big enough to time take turns through the variants (3 runs each, the first one discarded)
     mlgpu_graph::Variant* trial = nullptr;

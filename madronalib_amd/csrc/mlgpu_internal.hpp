@@ -22,6 +22,15 @@ struct mlgpu_engine
   bool jitEnabled{true};  // fuse unknown chains / graphs with hiprtc (mlgpu_engine_set_jit)
   float* d_mixScratch{nullptr};  // mixdown partial sums, grown on demand
   size_t mixScratchFloats{0};
+  bool recording{false};  // between mlgpu_engine_begin_recording and _end_recording: launches are captured, not run
+};
+
+struct mlgpu_sequence  // a recorded launch sequence: a hipGraph instantiated once, replayed with one launch
+{
+  mlgpu_engine* e{nullptr};
+  hipGraph_t graph{nullptr};
+  hipGraphExec_t exec{nullptr};
+  size_t nodes{0};
 };
 
 inline SignalView makeView(const float* p, int layout, size_t V, size_t T)

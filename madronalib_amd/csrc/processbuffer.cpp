@@ -108,6 +108,11 @@ extern "C"
   {
     if (!p || !fn) return MLGPU_ERR_INVALID;
     mlgpu_engine* e = p->e;
+    if (e->recording)
+    {
+      e->lastError = "process_buffer_process copies through the host: not while recording a sequence";
+      return MLGPU_ERR_INVALID;
+    }
     const size_t nIn = p->in.size(), nOut = p->out.size();
     // the reference returns silently in these cases (MLSignalProcessBuffer.cpp:42-44)
     if (nOut < 1 || !outputs || nFrames < 0 || (size_t)nFrames > p->maxFrames)

@@ -107,6 +107,11 @@ extern "C"
   {
     if (!p || !d_channels) return MLGPU_ERR_INVALID;
     mlgpu_engine* e = p->e;
+    if (e->recording)
+    {
+      e->lastError = "published_signal_write waits for the device: not while recording a sequence";
+      return MLGPU_ERR_INVALID;
+    }
     if (nVectors == 0 || nVoices == 0) return MLGPU_OK;
     if (firstVoice + nVoices > nVoicesTotal || layout < MLGPU_LAYOUT_QUAD || layout > MLGPU_LAYOUT_BROADCAST)
     {
