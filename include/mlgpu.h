@@ -457,8 +457,9 @@ int mlgpu_graph_add_feedback(mlgpu_graph* g, const char* name);
  * function called twice per DSPVector, :132-133, resp. once per two, :186). end_region resamples `result` back and returns
  * the node of the outer graph (negative status on failure). Inside a region: processors, ops, routing and index generators
  * on the region's inputs and on per-voice floats (params / consts) of the outer graph, and feedback nodes whose source is in
- * the same region (fn's own state kept from one of ITS DSPVectors to the next); no streamed inputs, controls or vector-rate
- * processors, and no nesting. A DOWNSAMPLE_2X region adds the reference's one DSPVector of
+ * the same region (fn's own state kept from one of ITS DSPVectors to the next), and further regions (a 4x oversampled
+ * function is an UPSAMPLE_2X region inside another; up to three deep, their inputs being nodes of the enclosing region); no
+ * streamed inputs, controls or vector-rate processors. A DOWNSAMPLE_2X region adds the reference's one DSPVector of
  * delay and pairs DSPVectors (2k, 2k + 1) counted from the last mlgpu_graph_clear. */
 int mlgpu_graph_begin_region(mlgpu_graph* g, int region /* mlgpu_region */, const int* inputs, int n_inputs, int* region_inputs);
 int mlgpu_graph_end_region(mlgpu_graph* g, int result, const char* name);

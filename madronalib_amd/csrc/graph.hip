@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <new>
@@ -191,6 +192,7 @@ enum { ROLE_NONE = 0, ROLE_REGION_IN = 1, ROLE_REGION_OUT = 2 };
 struct Region
 {
   int kind{0};            // mlgpu_region
+  int parent{-1};         // the region this one is nested in (-1: the outer graph)
   std::vector<int> ins;   // ROLE_REGION_IN nodes
   int result{-1};         // fn's return value (a node of the region)
   int out{-1};            // ROLE_REGION_OUT node
@@ -267,12 +269,21 @@ int gfail(mlgpu_graph* g, int status, const std::string& what)
 // the C++ expression of node i for lane-group l (its inputs are the locals n<j>_<l>)
 // Inside a rate region the values of the region's nodes carry the phase suffix `ph` ("a" / "b" for the two samples an
 // Upsample2x region makes per outer sample) and `idx` is the sample index inside fn's own DSPVector.
+// number of Upsample2x regions on the way from the outer graph down to region r (each adds one phase letter to a value's name)
+int upDepth(const mlgpu_graph* g, int r)
+{
+  int d = 0;
+  for (; r >= 0; r = g->regions[(size_t)r].parent) d += (g->regions[(size_t)r].kind == MLGPU_REGION_UPSAMPLE_2X);
+  return d;
+}
+
 std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& ph = "", const std::string& idx = "q * 4 + k")
 {
   const Node& n = g->nodes[i];
   std::ostringstream s;
   const std::string L = "_" + std::to_string(l);
-  auto arg = [&](size_t j) { return "n" + std::to_string(n.in[j]) + (g->nodes[n.in[j]].region >= 0 ? ph : std::string()) + L; };
+  // an input that lives in an enclosing region (or outside) carries only the phase letters of ITS regions
+  auto arg = [&](size_t j) { return "n" + std::to_string(n.in[j]) + ph.substr(0, (size_t)upDepth(g, g->nodes[n.in[j]].region)) + L; };
   switch (n.type)
   {
     case NODE_INPUT: s << "xin" << n.slot << L << "[k]"; break;
@@ -424,6 +435,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l)
       s << "  f32x4* out" << o << sfx(l) << " = (f32x4*)a.out[" << o << "].base + v" << sfx(l) << " * a.out[" << o << "].strideV;\n";
+  // a Downsample2x region's filter pairs its parent's samples (m - 1, m): the previous sample of each of its sources
+  for (const Region& R : g->regions)
+    if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X)
+      for (int in : R.ins)
+        for (int l = 0; l < VL; ++l) s << "  float prev" << in << sfx(l) << " = 0.f;\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
   // once per DSPVector: vector-rate nodes, then the vector-rate processors' begin_vector
   for (size_t i = 0; i < g->nodes.size(); ++i)
@@ -447,11 +463,6 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         << i << "].strideQ);\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l) s << "      f32x4 y" << o << sfx(l) << ";\n";
-  // a Downsample2x region's filter pairs the outer samples (n - 1, n): keep the previous sample of its sources
-  for (const Region& R : g->regions)
-    if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X)
-      for (int in : R.ins)
-        for (int l = 0; l < VL; ++l) s << "      float prev" << in << sfx(l) << " = 0.f;\n";
   // A kept DSPVector's slot n is read and rewritten at sample n only: fetch the quad's four slots together, ahead of the
   // stores of the sample loop (one load per sample between those stores costs a memory round trip per sample).
   for (size_t i = 0; i < g->nodes.size(); ++i)
@@ -466,86 +477,126 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       for (int l = 0; l < VL; ++l) s << "      p" << i << sfx(l) << ".begin_quad(q);\n";
   s << "#pragma unroll\n      for (int k = 0; k < 4; ++k)\n      {\n";
   {
-    std::vector<char> done(g->nodes.size(), 0);
+    // Rate regions are emitted in place, recursively. A context = where we are in the tree of regions: the phase letters
+    // that name its values, the sample index inside the current function's own DSPVector, and that function's vector count.
+    struct Ctx
+    {
+      std::string sfx, idx, vec, indent;
+    };
     auto name = [&](int j, const std::string& ph, int l) { return "n" + std::to_string(j) + ph + sfx(l); };
-    auto emitRegion = [&](int r) {
+    auto isInside = [&](int r, int ancestor) {  // r == ancestor or nested somewhere inside it
+      for (; r >= 0; r = g->regions[(size_t)r].parent)
+        if (r == ancestor) return true;
+      return false;
+    };
+    auto childUnder = [&](int r, int ancestor) {  // the region directly under `ancestor` that contains r
+      while (g->regions[(size_t)r].parent != ancestor) r = g->regions[(size_t)r].parent;
+      return r;
+    };
+    std::function<void(int, const Ctx&)> emitNodes;   // the nodes of region r (-1: the outer graph) in context c
+    std::function<void(int, const Ctx&)> emitRegion;  // region r, entered from context c of its parent
+    emitNodes = [&](int r, const Ctx& c) {
+      std::vector<char> entered(g->regions.size(), 0);
+      for (size_t j = 0; j < g->nodes.size(); ++j)
+      {
+        const Node& m = g->nodes[j];
+        if (m.rate != RATE_AUDIO) continue;
+        if (m.region != r)
+        {
+          // the first node of a region nested directly here: the whole region goes in at this point
+          if (m.region >= 0 && (r < 0 || isInside(m.region, r)) && m.region != r)
+          {
+            const int child = childUnder(m.region, r);
+            if (!entered[(size_t)child])
+            {
+              entered[(size_t)child] = 1;
+              emitRegion(child, c);
+            }
+          }
+          continue;
+        }
+        if (m.role == ROLE_REGION_IN) continue;  // made by emitRegion
+        if (m.role == ROLE_REGION_OUT)
+        {
+          const Region& R = g->regions[(size_t)m.slot];
+          if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X) continue;  // read before the region's block, see emitRegion
+          for (int l = 0; l < VL; ++l)
+            s << c.indent << "const float " << name((int)j, c.sfx, l) << " = p" << j << sfx(l) << ".down(" << name(m.in[0], c.sfx + "a", l) << ", "
+              << name(m.in[0], c.sfx + "b", l) << ");" << (l == 0 && !m.name.empty() ? "  // " + m.name : std::string()) << "\n";
+          continue;
+        }
+        for (int l = 0; l < VL; ++l)
+          s << c.indent << "const float " << name((int)j, c.sfx, l) << " = " << nodeExpr(g, j, l, c.sfx, c.idx) << ";"
+            << (l == 0 && !m.name.empty() ? "  // " + m.name : std::string()) << "\n";
+      }
+      if (r < 0) return;
+      // fn's own one-vector feedback (slot = the sample index inside fn's DSPVector), then the end of fn's DSPVector
+      for (size_t j = 0; j < g->nodes.size(); ++j)
+        if (g->nodes[j].region == r && g->nodes[j].type == NODE_FEEDBACK && g->nodes[j].fbSource >= 0)
+          for (int l = 0; l < VL; ++l)
+            s << c.indent << "a.state[(size_t)(" << g->nodes[j].sOff << " + " << c.idx << ") * a.V + v" << sfx(l) << "] = f2u(" << name(g->nodes[j].fbSource, c.sfx, l)
+              << ");\n";
+      bool any = false;
+      for (size_t j = 0; j < g->nodes.size(); ++j)
+      {
+        const Node& m = g->nodes[j];
+        if (m.type != NODE_PROC || m.region != r || m.role != ROLE_NONE) continue;
+        if (!any) s << c.indent << "if (" << c.idx << " == 63)\n" << c.indent << "{\n";
+        any = true;
+        for (int l = 0; l < VL; ++l) s << c.indent << "  p" << j << sfx(l) << ".end_vector();\n";
+      }
+      if (any) s << c.indent << "}\n";
+    };
+    emitRegion = [&](int r, const Ctx& c) {
       const Region& R = g->regions[(size_t)r];
       if (R.kind == MLGPU_REGION_UPSAMPLE_2X)
       {
-        // fn on the two samples the HalfBandFilters make of this outer sample (upsampleFirstHalf / SecondHalf in stream order)
+        // fn on the two samples the HalfBandFilters make of this sample (upsampleFirstHalf / SecondHalf in stream order)
         for (int phase = 0; phase < 2; ++phase)
         {
           const std::string ph = phase ? "b" : "a";
-          const std::string idx = "(((q * 4 + k) * 2 + " + std::to_string(phase) + ") & 63)";
-          for (size_t j = 0; j < g->nodes.size(); ++j)
-          {
-            const Node& m = g->nodes[j];
-            if (m.region != r || m.rate != RATE_AUDIO) continue;
+          Ctx cc;
+          cc.sfx = c.sfx + ph;
+          cc.idx = "((2 * (" + c.idx + ") + " + std::to_string(phase) + ") & 63)";
+          cc.vec = "(2 * (" + c.vec + ") + ((2 * (" + c.idx + ") + " + std::to_string(phase) + ") >> 6))";
+          cc.indent = c.indent;
+          for (int in : R.ins)
             for (int l = 0; l < VL; ++l)
-            {
-              s << "        const float " << name((int)j, ph, l) << " = ";
-              if (m.role == ROLE_REGION_IN)
-                s << "p" << j << sfx(l) << ".up_" << ph << "(n" << m.in[0] << sfx(l) << ");";
-              else
-                s << nodeExpr(g, j, l, ph, idx) << ";";
-              if (l == 0 && phase == 0 && !m.name.empty()) s << "  // " << m.name << " (2x)";
-              s << "\n";
-            }
-            done[j] = 1;
-          }
-          // fn's own one-vector feedback: slot = the sample index inside fn's DSPVector
-          for (size_t j = 0; j < g->nodes.size(); ++j)
-            if (g->nodes[j].region == r && g->nodes[j].type == NODE_FEEDBACK && g->nodes[j].fbSource >= 0)
-              for (int l = 0; l < VL; ++l)
-                s << "        a.state[(size_t)(" << g->nodes[j].sOff << " + " << idx << ") * a.V + v" << sfx(l) << "] = f2u(" << name(g->nodes[j].fbSource, ph, l) << ");\n";
+              s << c.indent << "const float " << name(in, cc.sfx, l) << " = p" << in << sfx(l) << ".up_" << ph << "("
+                << name(g->nodes[(size_t)in].in[0], c.sfx.substr(0, (size_t)upDepth(g, g->nodes[(size_t)g->nodes[(size_t)in].in[0]].region)), l) << ");\n";
+          emitNodes(r, cc);
         }
       }
       else
       {
-        // the region's output is what its upsampler made one DSPVector ago; fn itself runs on odd outer samples
-        for (int l = 0; l < VL; ++l) s << "        const float " << name(R.out, "", l) << " = p" << R.out << sfx(l) << ".delayed(q * 4 + k);\n";
-        done[(size_t)R.out] = 1;
-        s << "        if (k & 1)\n        {\n";
-        const std::string idx = "((((q * 4 + k) - 1) >> 1) + 32 * (int)((a.t0 + t) & 1))";
-        for (size_t j = 0; j < g->nodes.size(); ++j)
-        {
-          const Node& m = g->nodes[j];
-          if (m.region != r || m.rate != RATE_AUDIO) continue;
-          for (int l = 0; l < VL; ++l)
-          {
-            s << "          const float " << name((int)j, "", l) << " = ";
-            if (m.role == ROLE_REGION_IN)
-              s << "p" << j << sfx(l) << ".down(prev" << j << sfx(l) << ", n" << m.in[0] << sfx(l) << ");";
-            else
-              s << nodeExpr(g, j, l, "", idx) << ";";
-            if (l == 0 && !m.name.empty()) s << "  // " << m.name << " (1/2x)";
-            s << "\n";
-          }
-          done[j] = 1;
-        }
-        for (size_t j = 0; j < g->nodes.size(); ++j)
-          if (g->nodes[j].region == r && g->nodes[j].type == NODE_FEEDBACK && g->nodes[j].fbSource >= 0)
-            for (int l = 0; l < VL; ++l)
-              s << "          a.state[(size_t)(" << g->nodes[j].sOff << " + " << idx << ") * a.V + v" << sfx(l) << "] = f2u(" << name(g->nodes[j].fbSource, "", l) << ");\n";
-        for (int l = 0; l < VL; ++l) s << "          p" << R.out << sfx(l) << ".push(q * 4 + k, " << name(R.result, "", l) << ");\n";
-        s << "        }\n";
+        // the region's output is what its upsampler made one DSPVector (of the parent's) ago; fn runs on the parent's odd samples
+        const bool top = (R.parent < 0);
+        for (int l = 0; l < VL; ++l)
+          s << c.indent << "const float " << name(R.out, c.sfx, l) << " = p" << R.out << sfx(l) << (top ? ".delayed(" : ".delayedAt(") << c.idx << ");\n";
+        s << c.indent << "if ((" << c.idx << ") & 1)\n" << c.indent << "{\n";
+        Ctx cc;
+        cc.sfx = c.sfx;
+        cc.idx = "((((" + c.idx + ") - 1) >> 1) + 32 * (int)((" + c.vec + ") & 1))";
+        cc.vec = "((" + c.vec + ") >> 1)";
+        cc.indent = c.indent + "  ";
         for (int in : R.ins)
-          for (int l = 0; l < VL; ++l) s << "        prev" << in << sfx(l) << " = n" << g->nodes[(size_t)in].in[0] << sfx(l) << ";\n";
+          for (int l = 0; l < VL; ++l)
+            s << cc.indent << "const float " << name(in, cc.sfx, l) << " = p" << in << sfx(l) << ".down(prev" << in << sfx(l) << ", "
+              << name(g->nodes[(size_t)in].in[0], c.sfx.substr(0, (size_t)upDepth(g, g->nodes[(size_t)g->nodes[(size_t)in].in[0]].region)), l) << ");\n";
+        emitNodes(r, cc);
+        for (int l = 0; l < VL; ++l) s << cc.indent << "p" << R.out << sfx(l) << ".push(" << c.idx << ", " << name(R.result, cc.sfx, l) << ");\n";
+        s << c.indent << "}\n";
+        for (int in : R.ins)
+          for (int l = 0; l < VL; ++l)
+            s << c.indent << "prev" << in << sfx(l) << " = "
+              << name(g->nodes[(size_t)in].in[0], c.sfx.substr(0, (size_t)upDepth(g, g->nodes[(size_t)g->nodes[(size_t)in].in[0]].region)), l) << ";\n";
       }
     };
-    for (size_t i = 0; i < g->nodes.size(); ++i)
-    {
-      const Node& n = g->nodes[i];
-      if (done[i] || n.rate != RATE_AUDIO) continue;
-      if (n.region >= 0)
-        emitRegion(n.region);
-      else if (n.role == ROLE_REGION_OUT)  // Upsample2x (a Downsample2x region's output was emitted with the region)
-        for (int l = 0; l < VL; ++l)
-          s << "        const float " << name((int)i, "", l) << " = p" << i << sfx(l) << ".down(" << name(n.in[0], "a", l) << ", " << name(n.in[0], "b", l) << ");"
-            << (l == 0 && !n.name.empty() ? "  // " + n.name : std::string()) << "\n";
-      else
-        emit(i, "        ");
-    }
+    Ctx outer;
+    outer.idx = "(q * 4 + k)";
+    outer.vec = "(a.t0 + t)";
+    outer.indent = "        ";
+    emitNodes(-1, outer);
   }
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l) s << "        y" << o << sfx(l) << "[k] = n" << g->outputs[o] << sfx(l) << ";\n";
@@ -559,36 +610,10 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     for (int l = 0; l < VL; ++l)
       s << "      __builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o
         << "].strideQ);\n";
-  // fn of an Upsample2x region has finished one of its own DSPVectors after outer samples 31 and 63
-  {
-    bool any = false;
-    for (size_t i = 0; i < g->nodes.size(); ++i)
-    {
-      const Node& n = g->nodes[i];
-      if (n.type != NODE_PROC || n.region < 0 || n.role != ROLE_NONE || g->regions[(size_t)n.region].kind != MLGPU_REGION_UPSAMPLE_2X) continue;
-      if (!any) s << "      if (q == 7 || q == 15)\n      {\n";
-      any = true;
-      for (int l = 0; l < VL; ++l) s << "        p" << i << sfx(l) << ".end_vector();\n";
-    }
-    if (any) s << "      }\n";
-  }
   s << "    }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC && (g->nodes[i].region < 0 || g->nodes[i].role != ROLE_NONE))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".end_vector();\n";
-  // fn of a Downsample2x region finishes a DSPVector with every second outer one
-  {
-    bool any = false;
-    for (size_t i = 0; i < g->nodes.size(); ++i)
-    {
-      const Node& n = g->nodes[i];
-      if (n.type != NODE_PROC || n.region < 0 || n.role != ROLE_NONE || g->regions[(size_t)n.region].kind != MLGPU_REGION_DOWNSAMPLE_2X) continue;
-      if (!any) s << "    if ((a.t0 + t) & 1)\n    {\n";
-      any = true;
-      for (int l = 0; l < VL; ++l) s << "      p" << i << sfx(l) << ".end_vector();\n";
-    }
-    if (any) s << "    }\n";
-  }
   s << "  }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC)
@@ -985,16 +1010,22 @@ extern "C"
     if (!g) return MLGPU_ERR_INVALID;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (region != MLGPU_REGION_UPSAMPLE_2X && region != MLGPU_REGION_DOWNSAMPLE_2X) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: unknown region kind");
-    if (g->openRegion >= 0) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_begin_region: rate regions do not nest");
     if (nIn < 0 || nIn > 8 || (nIn > 0 && (!inputs || !regionInputs))) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: 0..8 inputs");
+    int depth = 0;
+    for (int r = g->openRegion; r >= 0; r = g->regions[(size_t)r].parent) depth++;
+    if (depth >= 3) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_begin_region: rate regions nest three deep at most");
     for (int j = 0; j < nIn; ++j)
     {
       if (inputs[j] < 0 || inputs[j] >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_begin_region: unknown input node");
-      if (g->nodes[(size_t)inputs[j]].region >= 0) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: input belongs to another region");
+      const Node& src = g->nodes[(size_t)inputs[j]];
+      // the inputs of a nested region are signals of the enclosing one (or per-voice floats)
+      if (src.region != g->openRegion && !(src.region < 0 && src.rate == RATE_VOICE))
+        return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: an input must be a node of the enclosing region (or of the outer graph for an outermost region)");
     }
     const int r = (int)g->regions.size();
     g->regions.emplace_back();
     g->regions.back().kind = region;
+    g->regions.back().parent = g->openRegion;
     for (int j = 0; j < nIn; ++j)
     {
       // one HalfBandFilter per input row: mUppers[j] (MLDSPFunctional.h:125-130) / mDowners[j] (:181-184)
@@ -1016,18 +1047,18 @@ extern "C"
     if (r < 0) return -gfail(g, MLGPU_ERR_INVALID, "graph_end_region: no region is open");
     if (result < 0 || result >= (int)g->nodes.size() || g->nodes[(size_t)result].region != r)
       return -gfail(g, MLGPU_ERR_INVALID, "graph_end_region: the result must be an audio-rate node of the region");
-    g->openRegion = -1;
-    Region& R = g->regions[(size_t)r];
-    R.result = result;
-    // mDowners[0] (MLDSPFunctional.h:137-141) resp. mUppers[0] + mOutputBuffer (:191-197)
-    const int kind = (R.kind == MLGPU_REGION_UPSAMPLE_2X) ? MLGPU_PROC_HALF_BAND : MLGPU_PROC_HALF_BAND_BUFFERED;
-    const int id = addProcNode(g, kind, &result, 1, name, ROLE_REGION_OUT, -1, r);
+    const int parent = g->regions[(size_t)r].parent;
+    g->openRegion = parent;
+    g->regions[(size_t)r].result = result;
+    // mDowners[0] (MLDSPFunctional.h:137-141) resp. mUppers[0] + mOutputBuffer (:191-197); the node belongs to the enclosing region
+    const int kind = (g->regions[(size_t)r].kind == MLGPU_REGION_UPSAMPLE_2X) ? MLGPU_PROC_HALF_BAND : MLGPU_PROC_HALF_BAND_BUFFERED;
+    const int id = addProcNode(g, kind, &result, 1, name, ROLE_REGION_OUT, parent, r);
     if (id < 0)
     {
       g->openRegion = r;
       return id;
     }
-    R.out = id;
+    g->regions[(size_t)r].out = id;
     return id;
   }
   int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* inputs, int nIn, const char* name)

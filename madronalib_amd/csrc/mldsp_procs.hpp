@@ -1262,6 +1262,7 @@ struct Proc<MLGPU_PROC_HALF_BAND_BUFFERED>
     for (int k = 0; k < 4; ++k) cur[k] = u2f(mem.s(9 + 4 * q + k));
   }
   MLD float delayed(int n) const { return cur[n & 3]; }
+  MLD float delayedAt(int m) const { return u2f(mem.s(9 + m)); }  // a nested region: m is not the kernel's own sample index
   MLD void push(int n, float x)  // n odd: the inner sample made from outer samples n - 1 and n
   {
     const float ya = hb.pathA(x);

@@ -1375,6 +1375,35 @@ extern "C"
     return MLGPU_OK;
   }
 
+  // Nested rate functions: out = Outer(mid, x) with mid(v) = OnePole(Inner(fn, v)) + v * 0.5 and fn(w) = Lopass(clamp(w * 3, -1, 1));
+  // Outer / Inner each an Upsample2xFunction<1> (up = 1) or a Downsample2xFunction<1> (up = 0). x / out [V][64 T].
+  int mlref_rate_nested_run(int outerUp, int innerUp, size_t V, size_t T, const float* lopassCoeffs, const float* onePoleCoeffs, const float* x, float* out)
+  {
+    for (size_t v = 0; v < V; ++v)
+    {
+      Upsample2xFunction<1> upO, upI;
+      Downsample2xFunction<1> downO, downI;
+      Lopass lp;
+      lp.coeffs = {lopassCoeffs[0], lopassCoeffs[1], lopassCoeffs[2]};
+      OnePole op;
+      op.coeffs = {onePoleCoeffs[0], onePoleCoeffs[1]};
+      auto fn = [&](const DSPVector w) { return lp(clamp(w * DSPVector(3.0f), DSPVector(-1.0f), DSPVector(1.0f))); };
+      auto mid = [&](const DSPVector vv)
+      {
+        const DSPVector inner = innerUp ? upI(fn, vv) : downI(fn, vv);
+        return op(inner) + vv * DSPVector(0.5f);
+      };
+      for (size_t t = 0; t < T; ++t)
+      {
+        DSPVector vx;
+        load(vx, x + (v * T + t) * kFloatsPerDSPVector);
+        const DSPVector y = outerUp ? upO(mid, vx) : downO(mid, vx);
+        store(y, out + (v * T + t) * kFloatsPerDSPVector);
+      }
+    }
+    return MLGPU_OK;
+  }
+
   // ---- Downsampler / Upsampler: the reference classes driven vector by vector, same contract as mlorc_resample ----
   namespace
   {

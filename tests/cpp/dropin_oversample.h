@@ -5,6 +5,7 @@
 struct OversampleState
 {
   Upsample2xFunction<1> upper;
+  Upsample2xFunction<1> quadOuter, quadInner;  // one inside the other: a 4x oversampled hard clipper
   Downsample2xFunction<2> downer;
   Lopass preFilter;  // lives inside the 2x function: sees 128 samples per DSPVector of input
   Allpass<IntegerDelay> smear;  // so does this one: its ring and its kept DSPVector (vy1) run at 2x
@@ -42,6 +43,11 @@ inline void oversampleProcess(AudioContext* ctx, void* stateData)
       [&](const DSPVectorArray<2> v) { return s->smooth(v.constRow(0) * s->carrier(DSPVector(0.01f)) + v.constRow(1) * DSPVector(0.1f)); },
       concatRows(in, mod));
 
+  DSPVector clipped4x = s->quadOuter(
+      [&](const DSPVector x)
+      { return s->quadInner([&](const DSPVector y) { return clamp(y * DSPVector(2.5f), DSPVector(-1.f), DSPVector(1.f)); }, x); },
+      in);
+
   ctx->outputs[0] = s->dc(shaped);
-  ctx->outputs[1] = lofi * DSPVector(0.5f) + shaped * DSPVector(0.5f);
+  ctx->outputs[1] = lofi * DSPVector(0.5f) + shaped * DSPVector(0.5f) + clipped4x * DSPVector(0.25f);
 }

@@ -446,6 +446,18 @@ class Ref(_Checker):
         assert fnc(1 if up else 0, x.shape[0], x.shape[1] // 64, gain, max_delay, delay, _ptr(co, c_f32p), _ptr(x, c_f32p), _ptr(out, c_f32p)) == 0
         return out
 
+    def rate_nested_run(self, outer_up, inner_up, lopass_coeffs, one_pole_coeffs, x):
+        """Outer(mid, x), mid(v) = OnePole(Inner(fn, v)) + v/2, fn(w) = Lopass(clamp(3w, -1, 1)); Outer / Inner are
+        Upsample2xFunction<1> (True) or Downsample2xFunction<1> (False) (mlref_rate_nested_run)."""
+        fnc = self.lib.mlref_rate_nested_run
+        fnc.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
+        x = np.ascontiguousarray(x, np.float32)
+        lp = np.ascontiguousarray(lopass_coeffs, np.float32)
+        op = np.ascontiguousarray(one_pole_coeffs, np.float32)
+        out = np.empty_like(x)
+        assert fnc(1 if outer_up else 0, 1 if inner_up else 0, x.shape[0], x.shape[1] // 64, _ptr(lp, c_f32p), _ptr(op, c_f32p), _ptr(x, c_f32p), _ptr(out, c_f32p)) == 0
+        return out
+
     def dspbuffer(self, size):
         return _RefDSPBuffer(self.lib, size)
 

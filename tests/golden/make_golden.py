@@ -144,7 +144,8 @@ def main():
     opc = ref.make_coeffs("onepole", 0.3)
     np.savez_compressed(os.path.join(HERE, "regions.npz"), x=x, m=m, freq=freq, co=co, up=ref.rate_function_run(True, freq, co, x, m),
                         down=ref.rate_function_run(False, freq, co, x, m), opc=opc,
-                        ap_up=ref.rate_allpass_run(True, 0.6, 300.0, 171.0, opc, x), ap_down=ref.rate_allpass_run(False, 0.6, 300.0, 171.0, opc, x))
+                        ap_up=ref.rate_allpass_run(True, 0.6, 300.0, 171.0, opc, x), ap_down=ref.rate_allpass_run(False, 0.6, 300.0, 171.0, opc, x),
+                        **{f"nested_{'u' if o else 'd'}{'u' if i else 'd'}": ref.rate_nested_run(o, i, co, opc, x) for o in (True, False) for i in (True, False)})
     # ---- BASELINE configs[4]: the synth16 voice written with the reference's objects ----
     from inputs import gate_signal
     from madronalib_amd.sharding import cfg5_voice_params

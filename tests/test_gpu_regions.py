@@ -126,6 +126,40 @@ def test_rate_region_with_feedback_and_delay(eng, kind, key):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("outer,inner,key", [(Region.UPSAMPLE_2X, Region.UPSAMPLE_2X, "nested_uu"), (Region.UPSAMPLE_2X, Region.DOWNSAMPLE_2X, "nested_ud"),
+                                             (Region.DOWNSAMPLE_2X, Region.UPSAMPLE_2X, "nested_du"), (Region.DOWNSAMPLE_2X, Region.DOWNSAMPLE_2X, "nested_dd")])
+def test_nested_rate_regions(eng, outer, inner, key):
+    """out = Outer(mid, x), mid(v) = OnePole(Inner(fn, v)) + v / 2, fn(w) = Lopass(clamp(3 w, -1, 1)): a region inside a region
+    (4x oversampling, and the mixed cases), stateful processors at both inner levels; golden outputs of the reference's
+    function objects nested the same way; launches of 1, 2 and 7 vectors."""
+    import madronalib_amd as ml
+    x, co, opc = GOLD["x"], GOLD["co"], GOLD["opc"]
+    V, T = x.shape[0], x.shape[1] // 64
+    g = ml.Graph(eng, V)
+    g.add("x", "input")
+    g.add("three", "const", value=3.0)
+    g.add("lo", "const", value=-1.0)
+    g.add("hi", "const", value=1.0)
+    g.add("half", "const", value=0.5)
+    (v,) = g.begin_region(outer, ["x"], ["v"])
+    (w,) = g.begin_region(inner, [v], ["w"])
+    g.add("drive", "op", Op.MULTIPLY, [w, "three"])
+    g.add("sat", "op", Op.CLAMP, ["drive", "lo", "hi"])
+    g.add("lp", "proc", Proc.LOPASS, ["sat"])
+    innerOut = g.end_region("lp", "innerOut")
+    g.add("op", "proc", Proc.ONE_POLE, [innerOut])
+    g.add("dry", "op", Op.MULTIPLY, [v, "half"])
+    g.add("mid", "op", Op.ADD, ["op", "dry"])
+    out = g.end_region("mid", "out")
+    g.add_output(out)
+    g.compile()
+    g.set_coeffs("lp", [np.full(V, c, np.float32) for c in co])
+    g.set_coeffs("op", [np.full(V, c, np.float32) for c in opc])
+    got = np.concatenate([g.process_host(n, {"x": np.ascontiguousarray(x[:, 64 * a:64 * (a + n)])}, Layout.QUAD)[0] for a, n in ((0, 1), (1, 2), (3, 7))], 1)
+    assert_bits_equal(got, GOLD[key], True, f"{key} vs the reference objects")
+
+
+@pytest.mark.gpu
 def test_region_rules(eng):
     import madronalib_amd as ml
     g = ml.Graph(eng, 64)
@@ -138,7 +172,7 @@ def test_region_rules(eng):
         g.end_region("x")                                           # no region open
     (rx,) = g.begin_region(Region.UPSAMPLE_2X, ["x"])
     with pytest.raises(ml.MlgpuError):
-        g.begin_region(Region.UPSAMPLE_2X, ["x"])                   # no nesting
+        g.begin_region(Region.UPSAMPLE_2X, ["x"])                   # a nested region takes signals of the enclosing one
     with pytest.raises(ml.MlgpuError):
         g.add("bad", "op", Op.ADD, [rx, "x"])                       # an outer audio-rate signal does not exist at 2x
     with pytest.raises(ml.MlgpuError):
