@@ -522,29 +522,41 @@ __global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, siz
   const size_t v = group * 64 + lane;
   const bool live = v < V;
   const float g = (live && gains) ? gains[v] : 1.f;
-  for (size_t qi = (size_t)blockIdx.y * 4 + wave; qi < nQuads; qi += (size_t)gridDim.y * 4)
+  // four quads per trip: their loads are issued together, then each is reduced
+  const size_t step = (size_t)gridDim.y * 4;
+  for (size_t q0 = (size_t)blockIdx.y * 4 + wave; q0 < nQuads; q0 += 4 * step)
   {
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live)
+    float4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
     {
-      x = sig.base[(qi >> 4) * sig.strideT + (qi & 15) * sig.strideQ + v * sig.strideV];
-      if (gains)
-      {
-        x.x *= g;
-        x.y *= g;
-        x.z *= g;
-        x.w *= g;
-      }
+      const size_t qi = q0 + (size_t)u * step;
+      x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && qi < nQuads) x[u] = sig.base[(qi >> 4) * sig.strideT + (qi & 15) * sig.strideQ + v * sig.strideV];
     }
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
+    for (int u = 0; u < 4; ++u)
     {
-      x.x = x.x + __shfl_down(x.x, d, 64);
-      x.y = x.y + __shfl_down(x.y, d, 64);
-      x.z = x.z + __shfl_down(x.z, d, 64);
-      x.w = x.w + __shfl_down(x.w, d, 64);
+      const size_t qi = q0 + (size_t)u * step;
+      if (qi >= nQuads) break;
+      float4 y = x[u];
+      if (gains)
+      {
+        y.x *= g;
+        y.y *= g;
+        y.z *= g;
+        y.w *= g;
+      }
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1)
+      {
+        y.x = y.x + __shfl_down(y.x, d, 64);
+        y.y = y.y + __shfl_down(y.y, d, 64);
+        y.z = y.z + __shfl_down(y.z, d, 64);
+        y.w = y.w + __shfl_down(y.w, d, 64);
+      }
+      if (lane == 0) partial[group * nQuads + qi] = y;
     }
-    if (lane == 0) partial[group * nQuads + qi] = x;
   }
 }
 
@@ -552,8 +564,24 @@ __global__ __launch_bounds__(256) void mixdown_stage2_kernel(const float4* parti
 {
   const size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (qi >= nQuads) return;
+  // left to right over the groups, as the contract says; the loads of 16 groups are in flight together
   float4 acc = partial[qi];
-  for (size_t g = 1; g < groups; ++g)
+  size_t g = 1;
+  for (; g + 16 <= groups; g += 16)
+  {
+    float4 x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x[u] = partial[(g + u) * nQuads + qi];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+    {
+      acc.x = acc.x + x[u].x;
+      acc.y = acc.y + x[u].y;
+      acc.z = acc.z + x[u].z;
+      acc.w = acc.w + x[u].w;
+    }
+  }
+  for (; g < groups; ++g)
   {
     const float4 x = partial[g * nQuads + qi];
     acc.x = acc.x + x.x;
@@ -665,7 +693,7 @@ hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T
   if (y < 1) y = 1;
   hipLaunchKernelGGL(mixdown_stage1_kernel, dim3((unsigned)groups, y), dim3(256), 0, stream, makeView(sig, layout, V, T), V, T, gains,
                      (float4*)partial);
-  hipLaunchKernelGGL(mixdown_stage2_kernel, dim3((unsigned)((nQuads + 255) / 256)), dim3(256), 0, stream, (const float4*)partial, groups, nQuads,
+  hipLaunchKernelGGL(mixdown_stage2_kernel, dim3((unsigned)((nQuads + 63) / 64)), dim3(64), 0, stream, (const float4*)partial, groups, nQuads,
                      (float4*)out);
   return hipGetLastError();
 }
