@@ -207,6 +207,50 @@ __global__ __launch_bounds__(256) void layout_convert_kernel(SignalView src, Sig
   }
 }
 
+// QUAD <-> a layout whose 16 quads of one (voice, vector) are contiguous (VOICE_MAJOR, ROWS): a transpose. One wavefront per
+// tile of 64 voices x 16 quads, through its own 16 KiB of LDS: both the global reads and the global writes run along the
+// contiguous direction of their side (256-byte voice rows on one, 1 KiB quad rows on the other). The quad index is XOR-ed
+// with the voice index in the LDS address, which keeps both phases free of bank conflicts without padding.
+template <bool TO_QUAD>
+__global__ __launch_bounds__(256) void layout_transpose_kernel(SignalView src, SignalView dst, size_t V, size_t T)
+{
+  __shared__ float4 tiles[4][64 * 16];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4* tile = tiles[wave];
+  const size_t voiceBlocks = (V + 63) / 64, items = T * voiceBlocks;
+  for (size_t item = (size_t)blockIdx.x * 4 + wave; item < items; item += (size_t)gridDim.x * 4)
+  {
+    const size_t t = item / voiceBlocks, v0 = (item % voiceBlocks) * 64;
+    const SignalView& rowSide = TO_QUAD ? src : dst;   // voice rows of 16 quads
+    const SignalView& quadSide = TO_QUAD ? dst : src;  // quad rows of 64 voices
+    if (TO_QUAD)
+    {
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i)
+      {
+        const unsigned vl = 4 * i + (lane >> 4), q = lane & 15;
+        if (v0 + vl < V) tile[vl * 16 + (q ^ (vl & 15))] = rowSide.base[t * rowSide.strideT + q * rowSide.strideQ + (v0 + vl) * rowSide.strideV];
+      }
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q)
+        if (v0 + lane < V) quadSide.base[t * quadSide.strideT + q * quadSide.strideQ + (v0 + lane) * quadSide.strideV] = tile[lane * 16 + (q ^ (lane & 15))];
+    }
+    else
+    {
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q)
+        if (v0 + lane < V) tile[lane * 16 + (q ^ (lane & 15))] = quadSide.base[t * quadSide.strideT + q * quadSide.strideQ + (v0 + lane) * quadSide.strideV];
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i)
+      {
+        const unsigned vl = 4 * i + (lane >> 4), q = lane & 15;
+        if (v0 + vl < V) rowSide.base[t * rowSide.strideT + q * rowSide.strideQ + (v0 + vl) * rowSide.strideV] = tile[vl * 16 + (q ^ (vl & 15))];
+      }
+    }
+    // the tile is private to this wavefront and its LDS operations complete in order: no barrier between tiles
+  }
+}
+
 __global__ __launch_bounds__(256) void fill32_kernel(uint32_t* dst, uint32_t value, size_t n)
 {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -490,6 +534,20 @@ hipError_t mlgpu_launch_layout_convert(const float* src, int srcLayout, float* d
                                        size_t T, hipStream_t stream)
 {
   const size_t total = V * T * 16;
+  const bool toQuad = (dstLayout == MLGPU_LAYOUT_QUAD && srcLayout != MLGPU_LAYOUT_QUAD && srcLayout != MLGPU_LAYOUT_BROADCAST);
+  const bool fromQuad = (srcLayout == MLGPU_LAYOUT_QUAD && dstLayout != MLGPU_LAYOUT_QUAD);
+  if (toQuad || fromQuad)
+  {
+    const size_t items = T * ((V + 63) / 64);
+    size_t blocks = (items + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    if (toQuad)
+      hipLaunchKernelGGL(layout_transpose_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, makeView(src, srcLayout, V, T), makeView(dst, dstLayout, V, T), V, T);
+    else
+      hipLaunchKernelGGL(layout_transpose_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, makeView(src, srcLayout, V, T), makeView(dst, dstLayout, V, T), V, T);
+    return hipGetLastError();
+  }
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
