@@ -1099,6 +1099,40 @@ class FeedbackDelayFunctionWithTap
   }
 };
 
+// map, MLDSPFunctional.h:18-100. The row-wise forms apply f to each row (a captured sub-graph per row). The element-wise
+// forms take a scalar HOST function evaluated per sample: that cannot run on the device, so they refuse at capture time.
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> map(std::function<DSPVector(const DSPVector)> f, const DSPVectorArray<ROWS> x)
+{
+  DSPVectorArray<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.row((int)j) = f(x.constRow((int)j));
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> map(std::function<DSPVector(const DSPVector, int)> f, const DSPVectorArray<ROWS> x)
+{
+  DSPVectorArray<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.row((int)j) = f(x.constRow((int)j), (int)j);
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> map(std::function<DSPVector(const DSPVector, const DSPVector)> f, const DSPVectorArray<ROWS> x)
+{
+  DSPVectorArray<ROWS> y;
+  for (size_t j = 0; j < ROWS; ++j) y.row((int)j) = f(x.constRow((int)j), DSPVector((float)j));  // f(row, j): j converts to DSPVector(float), :95
+  return y;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> map(std::function<float()>, const DSPVectorArray<ROWS>)
+{
+  throw std::logic_error("mldsp GPU shim: map() with a scalar host function is evaluated per sample on the CPU; write it with DSPVector ops");
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> map(std::function<float(float)>, const DSPVectorArray<ROWS>)
+{
+  throw std::logic_error("mldsp GPU shim: map() with a scalar host function is evaluated per sample on the CPU; write it with DSPVector ops");
+}
+
 // Upsample2xFunction / Downsample2xFunction, MLDSPFunctional.h:114-213: fn runs at twice / half the rate between two
 // HalfBandFilters. Captured as a rate region of the graph (mlgpu_graph_begin_region): fn is called ONCE here, on the
 // resampled inputs, and the kernel evaluates its nodes twice per sample (resp. every second sample) on the same

@@ -39,9 +39,12 @@ inline void oversampleProcess(AudioContext* ctx, void* stateData)
       },
       in);
 
+  // map (MLDSPFunctional.h:76-87): a function of (row, row index) applied to each row
+  const DSPVectorArray<2> scaled = map([](const DSPVector v, int row) { return v * DSPVector(row ? 0.5f : 2.f); }, concatRows(in, mod));
+
   DSPVector lofi = s->downer(
       [&](const DSPVectorArray<2> v) { return s->smooth(v.constRow(0) * s->carrier(DSPVector(0.01f)) + v.constRow(1) * DSPVector(0.1f)); },
-      concatRows(in, mod));
+      scaled);
 
   DSPVector clipped4x = s->quadOuter(
       [&](const DSPVector x)
