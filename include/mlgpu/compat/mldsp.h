@@ -656,6 +656,7 @@ class NoiseGen : public gpu::ProcNode<MLGPU_PROC_NOISE_GEN>
 {
  public:
   void reset() { seed(0); }
+  void setSeed(uint32_t s) { seed(s); }  // MLDSPGens.h:115
   void seed(uint32_t s)  // per-voice seeds: VoiceProgram::setState(noise, 0, seeds)
   {
     initState0_ = s;
@@ -663,6 +664,47 @@ class NoiseGen : public gpu::ProcNode<MLGPU_PROC_NOISE_GEN>
   }
   DSPVector operator()() { return DSPVector(emit({}, nullptr, 0)); }
 };
+// phasorToSine / phasorToPulse / phasorToSaw, MLDSPGens.h:313-369: public free functions, here the same expressions over the
+// shim's ops (the reference's scalar polyBLEP loop written with compares and selects: both branches are evaluated, one kept)
+inline DSPVector phasorToSine(DSPVector phasorV)
+{
+  // the reference's constexpr values (MLDSPGens.h:318-327). const_math::sqrt(2.0f) is itself an approximation: 0x3fb50505,
+  // not the correctly rounded 0x3fb504f3; the derived constants follow from it
+  auto bits = [](uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
+  const float sqrt2 = bits(0x3fb50505u), domain = bits(0x40b50505u), scale = bits(0x3f87c3b6u), flip = bits(0x40350505u), oneSixth = bits(0x3e2aaaabu);
+  DSPVector omegaV = phasorV * DSPVector(domain) + DSPVector(-sqrt2);
+  DSPVector triangleV = select(DSPVector(flip) - omegaV, omegaV, greaterThan(omegaV, DSPVector(sqrt2)));
+  return DSPVector(scale) * triangleV * (DSPVector(1.f) - triangleV * triangleV * DSPVector(oneSixth));
+}
+namespace gpu
+{
+inline DSPVector polyBLEP(const DSPVector phase, const DSPVector freq)  // MLDSPGens.h:285-311
+{
+  const DSPVector tl = phase / freq;
+  const DSPVector cl = tl + tl - tl * tl - DSPVector(1.0f);
+  const DSPVector th = (phase - DSPVector(1.0f)) / freq;
+  const DSPVector ch = th * th + th + th + DSPVector(1.0f);
+  return select(cl, select(ch, DSPVector(0.f), greaterThan(phase, DSPVector(1.0f) - freq)), lessThan(phase, freq));
+}
+}  // namespace gpu
+inline DSPVector phasorToPulse(DSPVector omegaV, DSPVector freqV, DSPVector pulseWidthV)
+{
+  DSPVector pulseV = select(DSPVector(-1.f), DSPVector(1.f), greaterThanOrEqual(omegaV, pulseWidthV));
+  pulseV += gpu::polyBLEP(omegaV, freqV);
+  DSPVector omegaVDown = fractionalPart(omegaV - pulseWidthV + DSPVector(1.0f));
+  pulseV -= gpu::polyBLEP(omegaVDown, freqV);
+  return pulseV;
+}
+inline DSPVector phasorToSaw(DSPVector omegaV, DSPVector freqV)
+{
+  DSPVector sawV = omegaV * DSPVector(2.f) - DSPVector(1.f);
+  return sawV - gpu::polyBLEP(omegaV, freqV);
+}
+
 class PhasorGen : public gpu::ProcNode<MLGPU_PROC_PHASOR_GEN>
 {
  public:

@@ -12,6 +12,7 @@ struct OversampleState
   SineGen carrier;   // lives inside the half-rate function: advances 32 samples per DSPVector of input
   OnePole smooth;
   DCBlocker dc;
+  PhasorGen phasor;  // drives the free functions phasorToSine / phasorToSaw / phasorToPulse
 };
 
 inline void oversampleSetup(OversampleState& s)
@@ -51,6 +52,11 @@ inline void oversampleProcess(AudioContext* ctx, void* stateData)
       { return s->quadInner([&](const DSPVector y) { return clamp(y * DSPVector(2.5f), DSPVector(-1.f), DSPVector(1.f)); }, x); },
       in);
 
-  ctx->outputs[0] = s->dc(shaped);
+  // the waveshape functions of MLDSPGens.h:313-369 called directly on a phasor, with a moving frequency and pulse width
+  const DSPVector f = DSPVector(0.004f) + abs(mod) * DSPVector(0.01f);
+  const DSPVector p = s->phasor(f);
+  const DSPVector shapes = phasorToSine(p) + phasorToSaw(p, f) + phasorToPulse(p, f, DSPVector(0.3f) + mod * DSPVector(0.2f));
+
+  ctx->outputs[0] = s->dc(shaped) + shapes * DSPVector(0.1f);
   ctx->outputs[1] = lofi * DSPVector(0.5f) + shaped * DSPVector(0.5f) + clipped4x * DSPVector(0.25f);
 }
