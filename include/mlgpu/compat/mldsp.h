@@ -664,6 +664,8 @@ class NoiseGen : public gpu::ProcNode<MLGPU_PROC_NOISE_GEN>
   }
   DSPVector operator()() { return DSPVector(emit({}, nullptr, 0)); }
 };
+inline DSPVectorInt columnIndexInt() { return truncateFloatToInt(columnIndex()); }  // MLDSPOps.h: 0 .. 63 as integers (exact)
+
 // phasorToSine / phasorToPulse / phasorToSaw, MLDSPGens.h:313-369: public free functions, here the same expressions over the
 // shim's ops (the reference's scalar polyBLEP loop written with compares and selects: both branches are evaluated, one kept)
 inline DSPVector phasorToSine(DSPVector phasorV)
@@ -1233,6 +1235,14 @@ class Bank
   {
     DSPVectorArray<ROWS> output;
     for (size_t i = 0; i < ROWS; ++i) output.row((int)i) = _processors[i](args.constRow((int)i)...);
+    return output;
+  }
+  // each processor gets its arguments by subscripting the inputs (std::array / std::vector of DSPVectors), :341-350
+  template <typename... Args>
+  DSPVectorArray<ROWS> processArrays(Args... args)
+  {
+    DSPVectorArray<ROWS> output;
+    for (size_t i = 0; i < ROWS; ++i) output.row((int)i) = _processors[i](args[i]...);
     return output;
   }
   void clear()
