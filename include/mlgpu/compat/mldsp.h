@@ -918,6 +918,40 @@ class Integrator : public gpu::ProcNode<MLGPU_PROC_INTEGRATOR>
   void clear() { cleared_ = true; }
   DSPVector operator()(const DSPVector vx) { return DSPVector(emit({vx.sig_[0]}, &mLeak, 1)); }
 };
+// Peak with exponential decay, MLDSPFilters.h:562-615. peakHoldSamples travels as the third coefficient word (an int).
+class Peak : public gpu::ProcNode<MLGPU_PROC_PEAK>
+{
+ public:
+  struct Coeffs
+  {
+    float a0, b1;
+  };
+  Coeffs coeffs{0.f, 0.f};
+  int peakHoldSamples{44100};
+  static Coeffs makeCoeffs(float omega)
+  {
+    float c[2];
+    mlgpu_onepole_make_coeffs(omega, c);  // the same formula: x = expf(-omega * kTwoPi); {1 - x, x} (:575-579 == :458-464)
+    return {c[0], c[1]};
+  }
+  static Coeffs passthru() { return {1.f, 0.f}; }
+  DSPVector operator()(const DSPVector vx)
+  {
+    float c[3] = {coeffs.a0, coeffs.b1, 0.f};
+    std::memcpy(&c[2], &peakHoldSamples, 4);
+    return DSPVector(emit({vx.sig_[0]}, c, 3));
+  }
+};
+// TempoLock, MLDSPFilters.h:1478-1579: x must be one of the streamed inputs (only x[0], x[1] of each vector are looked at)
+class TempoLock : public gpu::ProcNode<MLGPU_PROC_TEMPO_LOCK>
+{
+ public:
+  void clear() { cleared_ = true; }
+  DSPVector operator()(DSPVector x, float dydx, float isr)
+  {
+    return DSPVector(emit({x.sig_[0], gpu::Sig(-1, dydx), gpu::Sig(-1, isr)}, nullptr, 0));
+  }
+};
 class RMS : public gpu::ProcNode<MLGPU_PROC_RMS>
 {
  public:

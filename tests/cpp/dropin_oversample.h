@@ -13,6 +13,7 @@ struct OversampleState
   OnePole smooth;
   DCBlocker dc;
   PhasorGen phasor;  // drives the free functions phasorToSine / phasorToSaw / phasorToPulse
+  TempoLock lock;    // follows the second input as if it were a clock phasor, at twice its rate
 };
 
 inline void oversampleSetup(OversampleState& s)
@@ -58,5 +59,5 @@ inline void oversampleProcess(AudioContext* ctx, void* stateData)
   const DSPVector shapes = phasorToSine(p) + phasorToSaw(p, f) + phasorToPulse(p, f, DSPVector(0.3f) + mod * DSPVector(0.2f));
 
   ctx->outputs[0] = s->dc(shaped) + shapes * DSPVector(0.1f);
-  ctx->outputs[1] = lofi * DSPVector(0.5f) + shaped * DSPVector(0.5f) + clipped4x * DSPVector(0.25f);
+  ctx->outputs[1] = lofi * DSPVector(0.5f) + shaped * DSPVector(0.5f) + clipped4x * DSPVector(0.25f) + s->lock(ctx->inputs[1], 2.0f, 1.0f / 48000.f) * DSPVector(0.1f);
 }
