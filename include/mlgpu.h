@@ -164,6 +164,8 @@ typedef enum mlgpu_proc
   MLGPU_PROC_TICK_GEN = 5,    /* :24-47    C{}            S{omega} */
   MLGPU_PROC_IMPULSE_GEN = 6, /* :53-104   C{}            S{omega, outputCounter:i32}; 17-tap table in LDS */
   MLGPU_PROC_ONE_SHOT_GEN = 7,/* :221-282  C{}            S{omega32:u32, gate:u32, omegaPrev:u32} */
+  MLGPU_PROC_TEST_SINE_GEN = 8, /* :151-171 C{}           S{omega}: omega += 2 pi f, wrapped at 2 pi; y = sinf(omega), the host
+                               *                          libm's sinf (glibc 2.35) restated on the device */
   /* SVF family, MLDSPFilters.h */
   MLGPU_PROC_LOPASS = 16,     /* :51-153   C{g0,g1,g2}    S{ic1eq,ic2eq} */
   MLGPU_PROC_HIPASS = 17,     /* :155-197  C{g0,g1,g2,k}  S{ic1eq,ic2eq} */

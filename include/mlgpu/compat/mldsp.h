@@ -717,6 +717,12 @@ class PhasorGen : public gpu::ProcNode<MLGPU_PROC_PHASOR_GEN>
   }
   DSPVector operator()(const DSPVector cyclesPerSample) { return DSPVector(emit({cyclesPerSample.sig_[0]}, nullptr, 0)); }
 };
+class TestSineGen : public gpu::ProcNode<MLGPU_PROC_TEST_SINE_GEN>  // MLDSPGens.h:151-171
+{
+ public:
+  void clear() { cleared_ = true; }
+  DSPVector operator()(const DSPVector freq) { return DSPVector(emit({freq.sig_[0]}, nullptr, 0)); }
+};
 class OneShotGen : public gpu::ProcNode<MLGPU_PROC_ONE_SHOT_GEN>
 {
  public:

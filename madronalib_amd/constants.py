@@ -122,6 +122,7 @@ class Proc:
     TICK_GEN = 5
     IMPULSE_GEN = 6
     ONE_SHOT_GEN = 7
+    TEST_SINE_GEN = 8
     LOPASS = 16
     HIPASS = 17
     BANDPASS = 18
@@ -148,10 +149,10 @@ class Proc:
     HALF_BAND_BUFFERED = 113
 
     # processors a bank (chain) can hold; INTERPOLATOR1 / LINEAR_GLIDE are vector-rate: graph nodes only
-    ALL = (0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 48, 66, 81)
+    ALL = (0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 17, 18, 19, 20, 21, 32, 33, 34, 35, 36, 37, 38, 48, 66, 81)
     VECTOR_RATE = (64, 65, 96)
     DELAYS = (80, 82, 83)      # own per-voice rings in HBM: graph nodes only
     GRAPH_ONLY = (64, 65, 80, 82, 83, 96, 112, 113)
-    GENERATORS = (0, 1, 2, 3, 4, 5, 6, 7)
+    GENERATORS = (0, 1, 2, 3, 4, 5, 6, 7, 8)
     # outputs pass through sqrtApprox (rsqrtps) in the reference: 2^-11 relative tolerance
     HW_APPROX = (36, 37)

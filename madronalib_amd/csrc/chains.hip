@@ -94,6 +94,7 @@ const std::vector<ChainEntry>& registry()
       makeEntry<P(TICK_GEN)>("chain_kernel<TickGen>"),
       makeEntry<P(IMPULSE_GEN)>("chain_kernel<ImpulseGen>"),
       makeEntry<P(ONE_SHOT_GEN)>("chain_kernel<OneShotGen>"),
+      makeEntry<P(TEST_SINE_GEN)>("chain_kernel<TestSineGen>"),
       makeEntry<P(LOPASS)>("chain_kernel<Lopass>"),
       makeEntry<P(HIPASS)>("chain_kernel<Hipass>"),
       makeEntry<P(BANDPASS)>("chain_kernel<Bandpass>"),

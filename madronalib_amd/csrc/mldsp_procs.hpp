@@ -156,6 +156,24 @@ struct Proc<MLGPU_PROC_SINE_GEN>  // MLDSPGens.h:373-381
 };
 
 template <>
+struct Proc<MLGPU_PROC_TEST_SINE_GEN>  // TestSineGen, MLDSPGens.h:151-171: the slow, precise reference oscillator
+{
+  static constexpr int NC = 0, NS = 1;
+  float omega;
+  MLD void load(const VoiceMem& m, const KernelTables&) { omega = u2f(m.s(0)); }
+  MLD void store(const VoiceMem& m) const { m.set(0, f2u(omega)); }
+  MLD float next(float cps)
+  {
+    const float twoPi = 6.2831853071795864769252867f;  // ml::kTwoPi, MLDSPScalarMath.h:23
+    const float step = twoPi * cps;
+    omega += step;
+    if (omega > twoPi) omega -= twoPi;
+    return libm_sinf(omega);
+  }
+  MLD void end_vector() {}
+};
+
+template <>
 struct Proc<MLGPU_PROC_SAW_GEN>  // MLDSPGens.h:395-402, phasorToSaw :362-369
 {
   static constexpr int NC = 0, NS = 1;

@@ -770,6 +770,7 @@ static float adsr_sample(const float* C, uint32_t* S, float x)
 
 /* ------------------------------------------------------------------------- */
 /* chains of processors                                                      */
+float mlorc_libm_sinf(float y);
 
 int mlorc_proc_num_coeffs(int kind)
 {
@@ -777,7 +778,7 @@ int mlorc_proc_num_coeffs(int kind)
   {
     case MLGPU_PROC_PHASOR_GEN: case MLGPU_PROC_SINE_GEN: case MLGPU_PROC_SAW_GEN:
     case MLGPU_PROC_NOISE_GEN: case MLGPU_PROC_TICK_GEN: case MLGPU_PROC_IMPULSE_GEN:
-    case MLGPU_PROC_ONE_SHOT_GEN: case MLGPU_PROC_DIFFERENTIATOR: return 0;
+    case MLGPU_PROC_ONE_SHOT_GEN: case MLGPU_PROC_DIFFERENTIATOR: case MLGPU_PROC_TEST_SINE_GEN: return 0;
     case MLGPU_PROC_PULSE_GEN: case MLGPU_PROC_DC_BLOCKER: case MLGPU_PROC_INTEGRATOR:
     case MLGPU_PROC_GAIN: return 1;
     case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_RMS: case MLGPU_PROC_LINEAR_GLIDE:
@@ -800,7 +801,7 @@ int mlorc_proc_num_state(int kind)
     case MLGPU_PROC_PHASOR_GEN: case MLGPU_PROC_SINE_GEN: case MLGPU_PROC_SAW_GEN:
     case MLGPU_PROC_PULSE_GEN: case MLGPU_PROC_NOISE_GEN: case MLGPU_PROC_TICK_GEN:
     case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_DIFFERENTIATOR: case MLGPU_PROC_INTEGRATOR:
-    case MLGPU_PROC_RMS: case MLGPU_PROC_INTERPOLATOR1: return 1;
+    case MLGPU_PROC_RMS: case MLGPU_PROC_INTERPOLATOR1: case MLGPU_PROC_TEST_SINE_GEN: return 1;
     case MLGPU_PROC_SAMPLE_ACCURATE_LINEAR_GLIDE: return 4;
     case MLGPU_PROC_INTEGER_DELAY: case MLGPU_PROC_ALLPASS1: case MLGPU_PROC_TEMPO_LOCK: return 2;
     case MLGPU_PROC_FRACTIONAL_DELAY: return 5;
@@ -896,6 +897,17 @@ static void proc_process64(int kind, const float* C, uint32_t* S, const float* i
       S[0] = f2u(f0);
       break;
     case MLGPU_PROC_ONE_SHOT_GEN: oneshot64(&S[0], &S[1], &S[2], in, out); break;
+    case MLGPU_PROC_TEST_SINE_GEN: /* TestSineGen::operator(), MLDSPGens.h:158-170; sinf = the libm restated below */
+      f0 = u2f(S[0]);
+      for (int n = 0; n < VEC; ++n)
+      {
+        const float step = 6.2831853071795864769252867f * in[n]; /* ml::kTwoPi, MLDSPScalarMath.h:23 */
+        f0 += step;
+        if (f0 > 6.2831853071795864769252867f) f0 -= 6.2831853071795864769252867f;
+        out[n] = mlorc_libm_sinf(f0);
+      }
+      S[0] = f2u(f0);
+      break;
     case MLGPU_PROC_LOPASS: case MLGPU_PROC_HIPASS: case MLGPU_PROC_BANDPASS:
       f0 = u2f(S[0]); f1 = u2f(S[1]);
       svf64(kind, C, &f0, &f1, in, out);

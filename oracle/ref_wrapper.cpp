@@ -156,6 +156,17 @@ struct RImpulse : RefProc
   }
   DSPVector process(const DSPVector& in) override { return g(in); }
 };
+struct RTestSine : RefProc
+{
+  TestSineGen g;
+  int nc() const override { return 0; }
+  int ns() const override { return 1; }
+  void setCoeffs(const float*) override {}
+  void setState(const uint32_t* s) override { memcpy(&g.mOmega, &s[0], 4); }
+  void getState(uint32_t* s) const override { memcpy(&s[0], &g.mOmega, 4); }
+  void clear() override { g.clear(); }
+  DSPVector process(const DSPVector& in) override { return g(in); }
+};
 struct ROneShot : RefProc
 {
   OneShotGen g;
@@ -497,6 +508,7 @@ RefProc* makeProc(int kind)
     case MLGPU_PROC_TICK_GEN: return new RTick;
     case MLGPU_PROC_IMPULSE_GEN: return new RImpulse;
     case MLGPU_PROC_ONE_SHOT_GEN: return new ROneShot;
+    case MLGPU_PROC_TEST_SINE_GEN: return new RTestSine;
     case MLGPU_PROC_LOPASS: return new RLopass;
     case MLGPU_PROC_HIPASS: return new RHipass;
     case MLGPU_PROC_BANDPASS: return new RBandpass;
