@@ -674,7 +674,24 @@ __global__ __launch_bounds__(256) void mixdown_groups_kernel(SignalView sig, Sig
     const size_t t = qi >> 4, q = qi & 15;
     const size_t firstVoice = gb * 64 * P;
     const float4* src = sig.base + t * sig.strideT + q * sig.strideQ;
-    for (size_t i = 0; i < P; ++i)
+    size_t i = 0;
+    for (; i + 4 <= P; i += 4)  // four loads in flight per lane, then their LDS stores
+    {
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const size_t e = (i + u) * 64 + lane;
+        x[u] = (firstVoice + e < V) ? src[(firstVoice + e) * sig.strideV] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const size_t e = (i + u) * 64 + lane;
+        strip[e + e / P] = x[u];
+      }
+    }
+    for (; i < P; ++i)
     {
       const size_t e = i * 64 + lane;
       if (firstVoice + e < V) strip[e + e / P] = src[(firstVoice + e) * sig.strideV];
