@@ -109,7 +109,7 @@ def setup_workload(eng, name, V, T, lo, total):
 
         def launch():
             eng.op_apply(Op.EXP_APPROX_OF_SIN_APPROX, d_x, None, None, d_y, n)
-        return launch, 8.0 * n, "op_kernel<EXP_APPROX_OF_SIN_APPROX>", \
+        return launch, 8.0 * n, "op_kernel<22>", \
             "BASELINE configs[1]: 65536 voices x 1 DSPVector elementwise expApprox(sinApprox(x)) (32 MiB: Infinity-Cache resident)", (d_x, d_y)
     if name == "cfg5":
         from madronalib_amd import patches
