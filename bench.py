@@ -44,6 +44,7 @@ WORKLOADS = {
     "events": (262144, 16, 8),  # EventsToSignals: 16384 instruments x 16 voices, 8 control rows out
     "resample": (262144, 32, 8),  # Downsampler, 2 octaves: 32 vectors in -> 8 out per launch
     "synth": (262144, 16, 8),    # events -> synth16 voices (pitch and gate rows streamed) -> per-instrument voice sum
+    "strings": (262144, 16, 8),  # a plucked-string model per voice: noise burst -> FractionalDelay (per-voice length) -> OnePole -> feedback
     "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
 }
 
@@ -226,6 +227,38 @@ def setup_workload(eng, name, V, T, lo, total):
             r.process(T, d_x, d_y)
         alg = 4.0 * n + 1.0 * n + V * 4.0 * 18 * 2
         return launch, alg, "downsample_kernel<2>", "Downsampler, 2 octaves (two HalfBandFilters per voice), streamed noise in", (r, x)
+    if name == "strings":
+        # Karplus-Strong: every voice is a delay line whose length is its pitch - the case the windowed ring layout is for
+        desc = [dict(name="x", type="input"), dict(name="g", type="const", value=0.995),
+                dict(name="fb", type="feedback", source="damp"),
+                dict(name="fbg", type="op", kind=Op.MULTIPLY, inputs=["fb", "g"]),
+                dict(name="sum", type="op", kind=Op.ADD, inputs=["x", "fbg"]),
+                dict(name="line", type="proc", kind=Proc.FRACTIONAL_DELAY, inputs=["sum"], max_delay=1024.0),
+                dict(name="damp", type="proc", kind=Proc.ONE_POLE, inputs=["line"])]
+        g = ml.Graph(eng, V, desc, ["damp"], delay_windows=bool(os.environ.get("MLGPU_DELAY_WINDOWS")))
+        g.set_coeffs("damp", ml.OnePole.makeCoeffs(0.3))
+        if os.environ.get("MLGPU_UNIFORM_DELAY"):
+            length = np.full(V, 200.0)
+        else:
+            length = 48000.0 / (55.0 * 2.0 ** (4.0 * ((np.arange(V) * 7919) % V) / V)) - 64.0   # 55 Hz .. 880 Hz, scattered over the voices
+        st = np.stack([ml.FractionalDelay.makeState(float(d)) for d in np.unique(np.round(length, 2))])
+        uniq = {float(d): st[i] for i, d in enumerate(np.unique(np.round(length, 2)))}
+        words = np.stack([uniq[float(d)] for d in np.round(length, 2)], 1).astype(np.float32)   # [2][V]: delayInt bits, allpass coefficient
+        g.set_state("line", 3, words[0].view(np.uint32))
+        g.set_state("line", 4, words[1].view(np.uint32))
+        nb = eng.bank([Proc.NOISE_GEN], V)
+        nb.set_state(0, 0, np.arange(lo, lo + V, dtype=np.uint32))
+        d_x = eng.alloc(4 * n)
+        nb.process(T, d_x, Layout.QUAD)
+        outs_d = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        k = [0]
+
+        def launch():
+            g.process(T, [d_x], [outs_d[k[0] & 1]])
+            k[0] += 1
+        # in + out + one ring (write + read) + the kept DSPVector (read + write)
+        alg = (8.0 + 8.0 + 8.0) * n
+        return launch, alg, "mlgpu_graph_kernel", "plucked strings: FractionalDelay of per-voice length (55..880 Hz) -> OnePole -> feedback, 262144 voices", (g, nb)
     if name == "allpass4":
         from madronalib_amd import patches
         desc = [dict(name="x", type="input"), dict(name="dl", type="param")]
