@@ -45,6 +45,67 @@ constexpr size_t kFloatsPerDSPVector = MLGPU_FLOATS_PER_DSPVECTOR;
 constexpr float kPi = 3.1415926535897932384626433832795f;
 constexpr float kTwoPi = kPi * 2.f;
 
+// Host-side parameter mappings used by process functions to turn knob positions into floats (MLDSPProjections.h:15-200).
+// Plain scalar code on the host, here so that such programs compile; the same formulas with the same libm calls.
+struct Interval
+{
+  float x1, x2;
+};
+inline bool within(float f, const Interval m) { return (f >= m.x1) && (f < m.x2); }
+using Projection = std::function<float(float)>;
+inline Projection compose(Projection a, Projection b)
+{
+  return [=](float x) { return a(b(x)); };
+}
+namespace projections
+{
+inline Projection constant(const float k)
+{
+  return [=](float) { return k; };
+}
+inline Projection log(Interval m)  // [0, 1] -> a logarithmic curve on [a, b], scaled back to [0, 1] (:107-124)
+{
+  const float a = m.x1, b = m.x2;
+  if (b - a == 0.f) return [=](float) { return a; };
+  if (a == 0.f) return [=](float) { return 0.f; };
+  return [=](float x) { return a * (powf((b / a), x) - 1) / (b - a); };
+}
+inline Projection exp(Interval m)  // its inverse (:128-145)
+{
+  const float a = m.x1, b = m.x2;
+  if (b - a == 0.f) return [=](float) { return a; };
+  if (a == 0.f) return [=](float) { return 0.f; };
+  return [=](float x) { return logf((x * (b - a) + a) / a) / logf(b / a); };
+}
+inline Projection linear(const Interval a, const Interval b)  // (:148-169)
+{
+  const float a1 = a.x1, a2 = a.x2, b1 = b.x1, b2 = b.x2;
+  if (a1 - a2 == 0.f) return [=](float) { return b1; };
+  return [=](float x)
+  {
+    const float m = (b2 - b1) / (a2 - a1);
+    return m * (x - a1) + b1;
+  };
+}
+inline Projection add(float f)
+{
+  return [=](float x) { return x + f; };
+}
+inline Projection intervalMap(const Interval a, const Interval b, Projection c)  // (:177-189)
+{
+  return [=](float x)
+  {
+    const float scaleA = 1 / (a.x2 - a.x1);
+    const float offsetA = (-a.x1) / (a.x2 - a.x1);
+    const float scaleB = (b.x2 - b.x1);
+    const float offsetB = b.x1;
+    return c(x * scaleA + offsetA) * scaleB + offsetB;
+  };
+}
+inline Projection unityToLogParam(Interval paramInterval) { return intervalMap({0, 1}, paramInterval, projections::log(paramInterval)); }
+inline Projection logParamToUnity(Interval paramInterval) { return intervalMap(paramInterval, {0, 1}, projections::exp(paramInterval)); }
+}  // namespace projections
+
 namespace gpu
 {
 // ---- capture context ---------------------------------------------------------------------------------------
@@ -1371,6 +1432,21 @@ class AudioContext
   int polyphony_{0};
 };
 using SignalProcessFn = void (*)(AudioContext*, void*);
+
+// AudioTask (source/app/MLAudioTask.h): the RtAudio main loop of the reference's console examples. There is no sound device
+// behind this engine: the class exists so that such a program compiles; run its process function with
+// ml::gpu::VoiceProgram(engine, voices, &ctx, processFn, &state) instead.
+class AudioTask
+{
+ public:
+  AudioTask(AudioContext*, SignalProcessFn, void*) {}
+  int startAudio() { return 0; }
+  void stopAudio() {}
+  int runConsoleApp()
+  {
+    throw std::logic_error("mldsp GPU shim: AudioTask has no audio device; hand the process function to ml::gpu::VoiceProgram");
+  }
+};
 
 // SignalProcessor / Synth (source/app/MLSignalProcessor.h:121, MLSynth.h:26-94): the parts a DSP subclass overrides.
 // Parameters, published signals and the plug-in adapters of the reference are host-side plumbing and not part of the shim.

@@ -1,0 +1,51 @@
+// The reference's own example program examples/audio-and-midi/reverb.cpp (the Aaltoverb algorithm), included UNCHANGED from
+// the reference checkout and compiled against the MI355X shim (include/mlgpu/compat): its process function is captured once
+// and run for V independent reverbs per launch. Built only where the reference checkout exists; the library travels.
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+
+#define main mlgpu_example_reverb_main
+#include "examples/audio-and-midi/reverb.cpp"
+#undef main
+
+extern "C" int example_reverb_gpu_run(size_t V, size_t T, int launches, const float* in0, const float* in1, float* out0, float* out1, char* err, size_t errLen)
+{
+  try
+  {
+    gpu::Engine eng(0);
+    AaltoverbState r;
+    initializeReverb(r);
+    AudioContext ctx(2, 2, kSampleRate);
+    gpu::VoiceProgram prog(eng, V, &ctx, processVector, &r);
+    const size_t Tl = T / (size_t)launches;
+    gpu::DeviceSignal vm0(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR), vm1(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR);
+    gpu::DeviceSignal q0(eng, V, T), q1(eng, V, T), o0(eng, V, T), o1(eng, V, T);
+    eng.check(mlgpu_upload(eng.handle(), vm0.data(), in0, vm0.bytes()));
+    eng.check(mlgpu_upload(eng.handle(), vm1.data(), in1, vm1.bytes()));
+    eng.check(mlgpu_layout_convert(eng.handle(), vm0.data(), MLGPU_LAYOUT_VOICE_MAJOR, q0.data(), MLGPU_LAYOUT_QUAD, V, T));
+    eng.check(mlgpu_layout_convert(eng.handle(), vm1.data(), MLGPU_LAYOUT_VOICE_MAJOR, q1.data(), MLGPU_LAYOUT_QUAD, V, T));
+    for (int l = 0; l < launches; ++l)
+    {
+      const size_t off = (size_t)l * Tl * 64 * V;
+      const float* ins[2] = {q0.data() + off, q1.data() + off};
+      float* outs[2] = {o0.data() + off, o1.data() + off};
+      eng.check(mlgpu_graph_process(prog.graph(), Tl, ins, MLGPU_LAYOUT_QUAD, outs, MLGPU_LAYOUT_QUAD));
+    }
+    eng.check(mlgpu_layout_convert(eng.handle(), o0.data(), MLGPU_LAYOUT_QUAD, vm0.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, T));
+    eng.check(mlgpu_layout_convert(eng.handle(), o1.data(), MLGPU_LAYOUT_QUAD, vm1.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, T));
+    eng.check(mlgpu_download(eng.handle(), out0, vm0.data(), vm0.bytes()));
+    eng.check(mlgpu_download(eng.handle(), out1, vm1.data(), vm1.bytes()));
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
