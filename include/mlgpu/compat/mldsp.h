@@ -1502,6 +1502,14 @@ class VoiceParam
   const std::string& name() const { return name_; }
 };
 
+// how the captured graph is built (all default off): the ring layout for per-voice delay times (mlgpu_graph_set_delay_layout)
+// and online tuning of the kernel form (mlgpu_graph_set_autotune)
+struct VoiceProgramOptions
+{
+  bool delayWindows{false};
+  bool autotune{false};
+};
+
 // Captures a reference-style process function once and runs it for `voices` voices on the GPU.
 class VoiceProgram
 {
@@ -1513,12 +1521,13 @@ class VoiceProgram
   unsigned voiceRowMask_{0};  // which of the 8 voice control rows the captured code reads: only those are graph inputs
 
  public:
-  VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state)
-      : VoiceProgram(e, voices, ctx, [fn, state](AudioContext* c) { fn(c, state); })
+  VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state, VoiceProgramOptions opt = VoiceProgramOptions())
+      : VoiceProgram(e, voices, ctx, [fn, state](AudioContext* c) { fn(c, state); }, opt)
   {
   }
   // general form: `body` is run twice in capture mode; it reads ctx->inputs / ctx->getInputVoice() and writes ctx->outputs
-  VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, std::function<void(AudioContext*)> body) : eng_(e), voices_(voices)
+  VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, std::function<void(AudioContext*)> body, VoiceProgramOptions opt = VoiceProgramOptions())
+      : eng_(e), voices_(voices)
   {
     static uint32_t epochCounter = 0;
     ctx->usesVoice_ = false;
@@ -1540,6 +1549,8 @@ class VoiceProgram
       if (g_) mlgpu_graph_destroy(g_);
       g_ = nullptr;
       eng_.check(mlgpu_graph_create(e.handle(), voices, &g_));
+      if (opt.delayWindows) eng_.check(mlgpu_graph_set_delay_layout(g_, 1));
+      if (opt.autotune) eng_.check(mlgpu_graph_set_autotune(g_, 1));
       cap.g = g_;
       cap.epoch = ++epochCounter;
       cap.nextOrd = 0;

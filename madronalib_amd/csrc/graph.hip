@@ -1434,10 +1434,15 @@ extern "C"
       }
       if (!trial)
       {
-        // every variant has its runs: keep the fastest
+        // every variant has its runs: keep the fastest; the default form stays unless another one is at least 3 % faster
+        // (two timed launches per form are a coarse measurement)
         const mlgpu_graph::Variant* best = nullptr;
         for (const mlgpu_graph::Variant& v : g->variants)
-          if (!v.failed && v.fn && v.runs >= 2 && (!best || v.bestMs < best->bestMs)) best = &v;
+        {
+          if (v.failed || !v.fn || v.runs < 2) continue;
+          const float handicap = (v.fn == g->fn) ? 0.97f : 1.0f;
+          if (!best || v.bestMs * handicap < best->bestMs * ((best->fn == g->fn) ? 0.97f : 1.0f)) best = &v;
+        }
         if (best)
         {
           g->fn = best->fn;

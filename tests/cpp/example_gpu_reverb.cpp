@@ -51,7 +51,8 @@ extern "C" int example_reverb_gpu_run(size_t V, size_t T, int launches, const fl
 }
 
 // throughput of the same captured program: V reverbs x T vectors per launch, `launches` launches timed with the engine's events
-extern "C" int example_reverb_gpu_bench(size_t V, size_t T, int launches, float* msPerLaunch, char* err, size_t errLen)
+extern "C" int example_reverb_gpu_bench(size_t V, size_t T, int launches, int options /* bit 0: windowed rings, bit 1: online tuning */, float* msPerLaunch,
+                                        char* err, size_t errLen)
 {
   try
   {
@@ -59,13 +60,16 @@ extern "C" int example_reverb_gpu_bench(size_t V, size_t T, int launches, float*
     AaltoverbState r;
     initializeReverb(r);
     AudioContext ctx(2, 2, kSampleRate);
-    gpu::VoiceProgram prog(eng, V, &ctx, processVector, &r);
+    gpu::VoiceProgramOptions opt;
+    opt.delayWindows = (options & 1) != 0;
+    opt.autotune = (options & 2) != 0;
+    gpu::VoiceProgram prog(eng, V, &ctx, processVector, &r, opt);
     gpu::DeviceSignal q0(eng, V, T), q1(eng, V, T), o0(eng, V, T), o1(eng, V, T);
     eng.check(mlgpu_fill32(eng.handle(), (uint32_t*)q0.data(), 0x3c23d70au /* 0.01f */, V * T * 64));
     eng.check(mlgpu_fill32(eng.handle(), (uint32_t*)q1.data(), 0xbc23d70au, V * T * 64));
     const float* ins[2] = {q0.data(), q1.data()};
     float* outs[2] = {o0.data(), o1.data()};
-    for (int l = 0; l < 3; ++l) eng.check(mlgpu_graph_process(prog.graph(), T, ins, MLGPU_LAYOUT_QUAD, outs, MLGPU_LAYOUT_QUAD));
+    for (int l = 0; l < 8; ++l) eng.check(mlgpu_graph_process(prog.graph(), T, ins, MLGPU_LAYOUT_QUAD, outs, MLGPU_LAYOUT_QUAD));  // warm-up and tuning
     eng.check(mlgpu_engine_sync(eng.handle()));
     eng.check(mlgpu_timer_start(eng.handle()));
     for (int l = 0; l < launches; ++l) eng.check(mlgpu_graph_process(prog.graph(), T, ins, MLGPU_LAYOUT_QUAD, outs, MLGPU_LAYOUT_QUAD));
