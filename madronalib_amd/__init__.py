@@ -757,6 +757,11 @@ class Graph:
             self.L.mlgpu_graph_destroy(self.h)
         self.h = None
 
+    @property
+    def device_bytes(self):
+        """Device memory the compiled graph owns (mlgpu_graph_device_bytes)."""
+        return int(self.L.mlgpu_graph_device_bytes(self.h))
+
     def tuning(self):
         """(settled, voices per lane, quads per trip) of the kernel form in use (mlgpu_graph_tuning)."""
         vl, u = ctypes.c_int(), ctypes.c_int()

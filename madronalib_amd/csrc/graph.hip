@@ -1327,6 +1327,12 @@ extern "C"
     g->autotune = on != 0;
     return MLGPU_OK;
   }
+  size_t mlgpu_graph_device_bytes(mlgpu_graph* g)
+  {
+    if (!g || !g->compiled) return 0;
+    return sizeof(float) * g->V * (size_t)(g->NC + 1) + sizeof(uint32_t) * g->V * (size_t)(g->NS + 1) + sizeof(float) * g->V * (size_t)(g->nParams + 1) +
+           sizeof(float) * g->memVoices() * g->memFloatsPerVoice;
+  }
   int mlgpu_graph_tuning(mlgpu_graph* g, int* voicesPerLane, int* quadsPerTrip)
   {
     if (!g || !g->compiled) return -MLGPU_ERR_INVALID;

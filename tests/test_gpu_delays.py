@@ -206,5 +206,11 @@ def test_delay_rules(eng):
     with pytest.raises(ml.MlgpuError) as ei:
         g.compile()
     assert ei.value.status == ml.Status.ERR_UNSUPPORTED
+    g3 = ml.Graph(eng, 1000, delay_windows=False)
+    a = g3.add("a", "input")
+    g3.add("d", "proc", Proc.PITCHBENDABLE_DELAY, [a, a], max_delay=1000.0)
+    g3.add_output("d")
+    g3.compile()
+    assert g3.device_bytes == 4 * 1000 * (1 + (10 + 1) + 1 + 2 * 2048)     # coefficient, state and constant slots (+1 spare each), two rings of 2048
     bank = eng.bank([Proc.ALLPASS1], 64)                         # Allpass1 has no ring: fine in a bank
     assert bank.num_coeffs(0) == 1 and bank.num_state(0) == 2
