@@ -225,22 +225,22 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(SignalView src, S
     const SignalView& quadSide = TO_QUAD ? dst : src;  // quad rows of 64 voices
     if (TO_QUAD)
     {
-#pragma unroll 4
+#pragma unroll
       for (int i = 0; i < 16; ++i)
       {
         const unsigned vl = 4 * i + (lane >> 4), q = lane & 15;
         if (v0 + vl < V) tile[vl * 16 + (q ^ (vl & 15))] = rowSide.base[t * rowSide.strideT + q * rowSide.strideQ + (v0 + vl) * rowSide.strideV];
       }
-#pragma unroll 4
+#pragma unroll
       for (int q = 0; q < 16; ++q)
         if (v0 + lane < V) quadSide.base[t * quadSide.strideT + q * quadSide.strideQ + (v0 + lane) * quadSide.strideV] = tile[lane * 16 + (q ^ (lane & 15))];
     }
     else
     {
-#pragma unroll 4
+#pragma unroll
       for (int q = 0; q < 16; ++q)
         if (v0 + lane < V) tile[lane * 16 + (q ^ (lane & 15))] = quadSide.base[t * quadSide.strideT + q * quadSide.strideQ + (v0 + lane) * quadSide.strideV];
-#pragma unroll 4
+#pragma unroll
       for (int i = 0; i < 16; ++i)
       {
         const unsigned vl = 4 * i + (lane >> 4), q = lane & 15;
