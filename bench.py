@@ -150,15 +150,18 @@ def setup_workload(eng, name, V, T, lo, total):
 
         def launch():
             # a sparse performance: every launch ~2 % of the instruments get a note on or off somewhere in the block
+            insts, evs = [], []
             for i in rng.integers(0, N, max(1, N // 50)):
                 i = int(i)
                 t = int(rng.integers(0, 64 * T))
+                insts.append(i)
                 if held.get(i):
-                    ev.add_event(i, ml.Event(4, 1, held[i].pop(), t, 0.0, 0.0))
+                    evs.append(ml.Event(4, 1, held[i].pop(), t, 0.0, 0.0))
                 else:
                     key = int(rng.integers(36, 84))
                     held.setdefault(i, []).append(key)
-                    ev.add_event(i, ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
+                    evs.append(ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
+            ev.add_events(insts, evs)
             ev.process(T, 0, outs[k[0] & 1], Layout.QUAD)
             ev.clear_events()
             k[0] += 1
@@ -197,15 +200,18 @@ def setup_workload(eng, name, V, T, lo, total):
         names = [d["name"] for d in desc if d["type"] == "input"]   # graph input order: gate, pitch
 
         def launch():
+            insts, evs = [], []
             for i in rng.integers(0, N, max(1, N // 50)):
                 i = int(i)
                 t = int(rng.integers(0, 64 * T))
+                insts.append(i)
                 if held.get(i):
-                    ev.add_event(i, ml.Event(4, 1, held[i].pop(), t, 0.0, 0.0))
+                    evs.append(ml.Event(4, 1, held[i].pop(), t, 0.0, 0.0))
                 else:
                     key = int(rng.integers(36, 84))
                     held.setdefault(i, []).append(key)
-                    ev.add_event(i, ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
+                    evs.append(ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
+            ev.add_events(insts, evs)
             ev.process(T, 0, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
             ev.clear_events()
             g.process(T, [rows[1] if nm == "gate" else rows[0] for nm in names], [d_voices])

@@ -590,6 +590,8 @@ int mlgpu_events_set_wanted_rows(mlgpu_events* ev, unsigned mask);
 size_t mlgpu_events_num_voices(mlgpu_events* ev);
 int mlgpu_events_newest_voice(mlgpu_events* ev, size_t instrument);        /* getNewestVoice() */
 int mlgpu_events_add_event(mlgpu_events* ev, size_t instrument, const mlgpu_event* e);   /* addEvent, :367-372 */
+/* the same for a whole block at once: events[i] goes to instrument instruments[i] (nothing is added if one is out of range) */
+int mlgpu_events_add_events(mlgpu_events* ev, const uint32_t* instruments, const mlgpu_event* events, size_t n);
 int mlgpu_events_clear_events(mlgpu_events* ev);                            /* clearEvents */
 /* processVector (:376-466) for n_vectors consecutive DSPVectors; start_offset = frame of the first one in the host block.
  * d_outputs[8]: device signals of V voices x n_vectors vectors in `layout` (any may be NULL = not wanted), in the order

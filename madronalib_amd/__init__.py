@@ -451,6 +451,15 @@ class Events:
     def add_event(self, instrument, ev):
         self.engine._check(self.L.mlgpu_events_add_event(self.h, int(instrument), ctypes.byref(ev)))
 
+    def add_events(self, instruments, events):
+        """A block's events in one call: events[i] (Event) goes to instrument instruments[i]."""
+        n = len(events)
+        if n == 0:
+            return
+        inst = np.ascontiguousarray(instruments, np.uint32)
+        arr = (Event * n)(*events)
+        self.engine._check(self.L.mlgpu_events_add_events(self.h, _np_ptr(inst), ctypes.cast(arr, ctypes.c_void_p), n))
+
     def clear_events(self):
         self.engine._check(self.L.mlgpu_events_clear_events(self.h))
 

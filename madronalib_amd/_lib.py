@@ -164,6 +164,7 @@ def _declare(L):
     sig("mlgpu_events_num_voices", sz, [vp])
     sig("mlgpu_events_newest_voice", i, [vp, sz])
     sig("mlgpu_events_add_event", i, [vp, sz, vp])
+    sig("mlgpu_events_add_events", i, [vp, vp, vp, sz])
     sig("mlgpu_events_clear_events", i, [vp])
     sig("mlgpu_events_process", i, [vp, sz, i, pp, i])
     sig("mlgpu_resampler_create", i, [vp, sz, i, i, pp])

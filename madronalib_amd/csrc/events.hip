@@ -1087,6 +1087,19 @@ extern "C"
     in.events.insert(std::lower_bound(in.events.begin(), in.events.end(), *e, soonerThan), *e);
     return MLGPU_OK;
   }
+  int mlgpu_events_add_events(mlgpu_events* ev, const uint32_t* instruments, const mlgpu_event* events, size_t n)  // a block's events in one call
+  {
+    if (!ev || (n && (!instruments || !events))) return MLGPU_ERR_INVALID;
+    for (size_t i = 0; i < n; ++i)
+      if (instruments[i] >= ev->nInstruments) return efail(ev, MLGPU_ERR_RANGE, "events_add_events: instrument out of range");
+    for (size_t i = 0; i < n; ++i)
+    {
+      Instrument& in = ev->inst[instruments[i]];
+      in.awake = true;
+      in.events.insert(std::lower_bound(in.events.begin(), in.events.end(), events[i], soonerThan), events[i]);
+    }
+    return MLGPU_OK;
+  }
   int mlgpu_events_clear_events(mlgpu_events* ev)  // clearEvents, once per host block (MLSignalProcessBuffer.cpp:89)
   {
     if (!ev) return MLGPU_ERR_INVALID;

@@ -47,10 +47,16 @@ def gpu_run(eng, cfg, per_instrument_events, block_frames, n_blocks, vectors_per
     outs = []
     for b in range(n_blocks):
         start = b * block_frames
+        batch_i, batch_e = [], []
         for i, evs in enumerate(per_instrument_events):
             for e in evs:
                 if start <= e[3] < start + block_frames:
-                    ev.add_event(i, ml.Event(e[0], e[1], e[2], e[3] - start, e[4], e[5]))
+                    if b % 2:      # odd blocks: one call per event; even blocks: the whole block in one call
+                        ev.add_event(i, ml.Event(e[0], e[1], e[2], e[3] - start, e[4], e[5]))
+                    else:
+                        batch_i.append(i)
+                        batch_e.append(ml.Event(e[0], e[1], e[2], e[3] - start, e[4], e[5]))
+        ev.add_events(batch_i, batch_e)
         vecs = block_frames // 64
         done = 0
         while done < vecs:       # a block may be processed in several launches
