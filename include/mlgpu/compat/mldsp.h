@@ -32,6 +32,7 @@
 #include <functional>
 #include <initializer_list>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -120,6 +121,12 @@ struct Capture
     uint32_t bits;
   };
   std::vector<Deferred> deferred;
+  struct Tap  // storePublishedSignal(name, DSPVectorArray<CH>, 64, voice) seen in the captured code
+  {
+    std::string name;
+    std::vector<int> nodes;  // one per channel
+  };
+  std::vector<Tap> taps;
   // Two capture passes ("epochs"): a DSPVector that still holds a node of the PREVIOUS pass when it is used is a value
   // the user code kept from one process call to the next (Allpass::vy1, a state struct's own feedback members, ...).
   // It becomes a feedback node; its source is the node with the same creation ordinal in the current pass.
@@ -1448,8 +1455,22 @@ class AudioTask
   }
 };
 
-// SignalProcessor / Synth (source/app/MLSignalProcessor.h:121, MLSynth.h:26-94): the parts a DSP subclass overrides.
-// Parameters, published signals and the plug-in adapters of the reference are host-side plumbing and not part of the shim.
+// Path (source/app/MLPath.h): here only a name, as published signals use it.
+class Path
+{
+  std::string text_;
+
+ public:
+  Path() = default;
+  Path(const char* t) : text_(t) {}
+  Path(const std::string& t) : text_(t) {}
+  const std::string& text() const { return text_; }
+  bool operator<(const Path& b) const { return text_ < b.text_; }
+  bool operator==(const Path& b) const { return text_ == b.text_; }
+};
+
+// SignalProcessor / Synth (source/app/MLSignalProcessor.h:121, MLSynth.h:26-94): the parts a DSP subclass overrides, and
+// published signals. Parameters and the plug-in adapters of the reference are host-side plumbing and not part of the shim.
 class SignalProcessor
 {
  public:
@@ -1458,8 +1479,59 @@ class SignalProcessor
   virtual void setSampleRate(double sr) { sampleRate_ = sr; }
   double getSampleRate() const { return sampleRate_; }
 
+  // SignalProcessor::PublishedSignal (MLSignalProcessor.h:26-105). publishSignal() records the shape; the ring itself is an
+  // mlgpu_published_signal that gpu::SynthProgram creates for every name the captured code stores to, and fills after each
+  // launch with the voices of one instrument in rotation. The reading side is the reference's.
+  struct PublishedSignal
+  {
+    int maxFrames_, maxVoices_, channels_, octavesDown_;
+    mlgpu_published_signal* handle_{nullptr};  // owned by the gpu::SynthProgram that runs this processor
+    PublishedSignal(int frames, int maxVoices, int channels, int octavesDown)
+        : maxFrames_(frames), maxVoices_(maxVoices), channels_(channels), octavesDown_(octavesDown)
+    {
+    }
+    size_t getNumChannels() const { return (size_t)channels_; }
+    int getAvailableFrames() const { return handle_ ? (int)mlgpu_published_signal_available_frames(handle_) : 0; }
+    int getReadAvailable() const { return handle_ ? (int)mlgpu_published_signal_read_available(handle_) : 0; }
+    size_t read(float* dest, size_t framesRequested) { return handle_ ? mlgpu_published_signal_read(handle_, dest, framesRequested) : 0; }
+    size_t readLatest(float* dest, size_t framesRequested) { return handle_ ? mlgpu_published_signal_read_latest(handle_, dest, framesRequested) : 0; }
+    void peekLatest(float* dest, size_t framesRequested)
+    {
+      if (handle_) mlgpu_published_signal_peek_latest(handle_, dest, framesRequested);
+    }
+  };
+  // stands in for Tree<std::unique_ptr<PublishedSignal>> (MLSignalProcessor.h:135-139, :175): operator[] and iteration
+  using PublishedSignalTree = std::map<Path, std::unique_ptr<PublishedSignal>>;
+  PublishedSignalTree& getPublishedSignals() { return publishedSignals_; }
+  const PublishedSignalTree& getPublishedSignals() const { return publishedSignals_; }
+
  protected:
   double sampleRate_{48000.0};
+  PublishedSignalTree publishedSignals_;
+
+  // MLSignalProcessor.h:184-187
+  void publishSignal(Path signalName, int maxFrames, int maxVoices, int channels, int octavesDown)
+  {
+    publishedSignals_[signalName] = std::make_unique<PublishedSignal>(maxFrames, maxVoices, channels, octavesDown);
+  }
+  // MLSignalProcessor.h:192-200. In a capture the DSPVectorArray's rows become further outputs of the fused kernel; `voice` is
+  // the lane's voice (the reference does not use it either). Only whole DSPVectors (frames == kFloatsPerDSPVector).
+  template <size_t CHANNELS>
+  void storePublishedSignal(Path signalName, const DSPVectorArray<CHANNELS>& inputVec, int frames, int voice)
+  {
+    (void)voice;
+    auto it = publishedSignals_.find(signalName);
+    if (it == publishedSignals_.end() || !it->second) return;  // not published: ignored, as in the reference
+    if (frames != (int)kFloatsPerDSPVector) throw std::logic_error("mldsp GPU shim: storePublishedSignal stores whole DSPVectors (frames == 64)");
+    if ((int)CHANNELS != it->second->channels_) throw std::logic_error("mldsp GPU shim: storePublishedSignal: channel count differs from publishSignal");
+    gpu::Capture& cap = gpu::Capture::get();
+    for (auto& t : cap.taps)
+      if (t.name == signalName.text()) throw std::logic_error("mldsp GPU shim: one storePublishedSignal per name in the captured voice code");
+    gpu::Capture::Tap tap;
+    tap.name = signalName.text();
+    for (size_t c = 0; c < CHANNELS; ++c) tap.nodes.push_back(inputVec.sig_[c].id());
+    cap.taps.push_back(tap);
+  }
 };
 
 class Synth : public SignalProcessor
@@ -1519,6 +1591,7 @@ class VoiceProgram
   size_t nIn_{0}, nOut_{0};
   bool usesVoice_{false};
   unsigned voiceRowMask_{0};  // which of the 8 voice control rows the captured code reads: only those are graph inputs
+  std::vector<Capture::Tap> taps_;  // published signals: graph outputs after the nOut_ audio outputs, in this order
 
  public:
   VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state, VoiceProgramOptions opt = VoiceProgramOptions())
@@ -1558,6 +1631,7 @@ class VoiceProgram
       cap.feedbackOfOrd.clear();
       cap.constNodes.clear();
       cap.deferred.clear();
+      cap.taps.clear();
       for (size_t c = 0; c < nIn_; ++c)
         ctx->inputs[(int)c] = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g_, ("in" + std::to_string(c)).c_str())), 0.f));
       // the 8 rows of this lane's voice (EventsToSignals) are further streamed inputs, after the audio inputs; the first pass
@@ -1591,6 +1665,9 @@ class VoiceProgram
       eng_.check(mlgpu_graph_set_feedback(g_, kv.second, cap.nodeOfOrd[kv.first]));
     }
     for (size_t c = 0; c < nOut_; ++c) eng_.check(mlgpu_graph_add_output(g_, ctx->outputs[(int)c].sig_[0].id()));
+    taps_ = cap.taps;
+    for (const Capture::Tap& t : taps_)
+      for (int node : t.nodes) eng_.check(mlgpu_graph_add_output(g_, node));
     eng_.check(mlgpu_graph_compile(g_));
     for (const Capture::Deferred& d : cap.deferred)
     {
@@ -1611,6 +1688,13 @@ class VoiceProgram
   size_t voices() const { return voices_; }
   unsigned voiceRowMask() const { return voiceRowMask_; }  // bit r: the captured code reads voice row r (VoiceOutputSignals)
   mlgpu_graph* graph() const { return g_; }
+  const std::vector<Capture::Tap>& taps() const { return taps_; }
+  size_t tapChannels() const
+  {
+    size_t n = 0;
+    for (auto& t : taps_) n += t.nodes.size();
+    return n;
+  }
   const char* source() const { return mlgpu_graph_source(g_); }  // the generated HIP kernel
 
   // per-voice values: [voices] floats
@@ -1631,7 +1715,8 @@ class VoiceProgram
   // getInputVoice(); nullptr otherwise)
   void process(const std::vector<const DeviceSignal*>& ins, const std::vector<DeviceSignal*>& outs, const float* const* voiceRows = nullptr)
   {
-    if (ins.size() != nIn_ || outs.size() != nOut_ || outs.empty()) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: wrong number of signals");
+    if (ins.size() != nIn_ || outs.size() != nOut_ + tapChannels() || outs.empty())
+      throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: wrong number of signals (outputs: the audio outputs, then one per published channel)");
     if (usesVoice_ && !voiceRows) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: this program reads the voice control rows; pass them");
     std::vector<const float*> pi;
     std::vector<float*> po;
@@ -1662,7 +1747,9 @@ class SynthProgram
   mlgpu_events* ev_{nullptr};
   VoiceProgram prog_;
   size_t capacityT_{0};
-  std::vector<DeviceSignal> rows_, voiceOut_;
+  std::vector<DeviceSignal> rows_, voiceOut_, tapOut_;
+  std::vector<SignalProcessor::PublishedSignal*> published_;  // one per tap of prog_, in tap order
+  size_t publishedInstrument_{0};
 
  public:
   SynthProgram(const Engine& e, Synth& synth, size_t nInstruments, size_t nOutputs, int sampleRate)
@@ -1677,12 +1764,30 @@ class SynthProgram
     eng_.check(mlgpu_events_create(e.handle(), nInstruments, polyphony_, &ev_));
     eng_.check(mlgpu_events_set_sample_rate(ev_, (double)sampleRate));
     eng_.check(mlgpu_events_set_wanted_rows(ev_, prog_.voiceRowMask()));  // rows processVoice never reads are not made
+    for (const Capture::Tap& t : prog_.taps())
+    {
+      SignalProcessor::PublishedSignal* ps = synth.getPublishedSignals()[Path(t.name)].get();
+      if (ps->handle_) throw Error(MLGPU_ERR_INVALID, "SynthProgram: this Synth's published signals already belong to another SynthProgram");
+      eng_.check(mlgpu_published_signal_create(e.handle(), ps->maxFrames_, ps->maxVoices_, ps->channels_, ps->octavesDown_, &ps->handle_));
+      published_.push_back(ps);
+    }
   }
   SynthProgram(const SynthProgram&) = delete;
   SynthProgram& operator=(const SynthProgram&) = delete;
   ~SynthProgram()
   {
     if (ev_) mlgpu_events_destroy(ev_);
+    for (auto* ps : published_)
+    {
+      mlgpu_published_signal_destroy(ps->handle_);
+      ps->handle_ = nullptr;
+    }
+  }
+  // storePublishedSignal() in processVoice publishes the voices of ONE instrument (a display shows one): this one
+  void setPublishedInstrument(size_t instrument)
+  {
+    if (instrument >= nInstruments_) throw Error(MLGPU_ERR_INVALID, "SynthProgram::setPublishedInstrument: no such instrument");
+    publishedInstrument_ = instrument;
   }
   mlgpu_events* events() const { return ev_; }  // protocol, glide, drift, bend range: the mlgpu_events_set_* calls
   VoiceProgram& program() { return prog_; }
@@ -1704,6 +1809,8 @@ class SynthProgram
     {
       rows_.clear();
       voiceOut_.clear();
+      tapOut_.clear();
+      for (size_t c = 0; c < prog_.tapChannels(); ++c) tapOut_.emplace_back(eng_, voices(), nVectors);
       for (int r = 0; r < kNumVoiceOutputRows; ++r) rows_.emplace_back(eng_, ((prog_.voiceRowMask() >> r) & 1u) ? voices() : 1, nVectors);
       for (size_t c = 0; c < nOut_; ++c) voiceOut_.emplace_back(eng_, voices(), nVectors);
       capacityT_ = nVectors;
@@ -1718,7 +1825,17 @@ class SynthProgram
     eng_.check(mlgpu_events_process(ev_, nVectors, startOffset, rowPtrs, MLGPU_LAYOUT_QUAD));
     std::vector<float*> po;
     for (auto& s : voiceOut_) po.push_back(s.data());
+    for (auto& s : tapOut_) po.push_back(s.data());
     eng_.check(mlgpu_graph_process(prog_.graph(), nVectors, pi.data(), MLGPU_LAYOUT_QUAD, po.data(), MLGPU_LAYOUT_QUAD));
+    // SignalProcessor::storePublishedSignal for each voice of the published instrument in rotation, vector by vector
+    size_t tapCh = 0;
+    for (size_t i = 0; i < published_.size(); ++i)
+    {
+      std::vector<const float*> ch;
+      for (size_t c = 0; c < prog_.taps()[i].nodes.size(); ++c) ch.push_back(tapOut_[tapCh++].data());
+      eng_.check(mlgpu_published_signal_write(published_[i]->handle_, nVectors, ch.data(), MLGPU_LAYOUT_QUAD, voices(),
+                                              publishedInstrument_ * (size_t)polyphony_, (size_t)polyphony_));
+    }
     for (size_t c = 0; c < nOut_; ++c)
       eng_.check(mlgpu_mixdown_groups(eng_.handle(), voiceOut_[c].data(), MLGPU_LAYOUT_QUAD, nInstruments_, (size_t)polyphony_, nVectors,
                                       mixed[c]->data(), mixed[c]->layout()));

@@ -28,7 +28,7 @@ struct ChainArgs
 
 // a fused graph kernel: up to 16 streamed inputs, up to 4 outputs, per-voice constants [P][V]
 #define MLGPU_GRAPH_MAX_INPUTS 16
-#define MLGPU_GRAPH_MAX_OUTPUTS 4
+#define MLGPU_GRAPH_MAX_OUTPUTS 8
 #define MLGPU_GRAPH_MAX_CONTROLS 8
 struct GraphArgs
 {

@@ -82,8 +82,12 @@ struct SynthRefEvent
   float value1, value2;
 };
 // one instrument; events with absolute onset times; host blocks of blockFrames; out: [2][nBlocks * blockFrames]
-extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR)
+// scope / scopeCounts (may be NULL): after every block the UI side reads what the "scope" published signal holds
+// (PublishedSignal::read of up to scopeFramesPerRead frames of 2 channels); scopeCounts[b] = floats read after block b.
+extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR,
+                             float* scope, size_t* scopeCounts, int scopeFramesPerRead)
 {
+  size_t scopePos = 0;
   SmallSynth synth;
   AudioContext ctx(0, 2, 48000);
   ctx.setInputPolyphony(kSynthVoices);
@@ -112,6 +116,11 @@ extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float gli
       store(ctx.outputs[1], outR + start + off);
     }
     ctx.clearInputEvents();
+    if (scope)
+    {
+      scopeCounts[b] = synth.getPublishedSignals()["scope"]->read(scope + scopePos, scopeFramesPerRead);
+      scopePos += scopeCounts[b];
+    }
   }
   return 0;
 }

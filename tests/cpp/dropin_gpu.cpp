@@ -139,13 +139,16 @@ struct SynthGpuEvent
 };
 // nInstruments instruments; events[i] belongs to instrument eventInstrument[i]; out: [nInstruments][nBlocks * blockFrames] per channel
 extern "C" int synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
-                             int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, char* err, size_t errLen)
+                             int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, size_t scopeInstrument, float* scope,
+                             size_t* scopeCounts, int scopeFramesPerRead, char* err, size_t errLen)
 {
   try
   {
     gpu::Engine eng(0);
     SmallSynth synth;
     gpu::SynthProgram prog(eng, synth, nInstruments, 2, 48000);
+    prog.setPublishedInstrument(scopeInstrument);
+    size_t scopePos = 0;
     eng.check(mlgpu_events_set_pitch_glide_seconds(prog.events(), glideSeconds));
     eng.check(mlgpu_events_set_drift_amount(prog.events(), drift));
     const size_t S = (size_t)nBlocks * blockFrames;
@@ -181,6 +184,11 @@ extern "C" int synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, c
         done += n;
       }
       prog.clearInputEvents();
+      if (scope)
+      {
+        scopeCounts[b] = synth.getPublishedSignals()["scope"]->read(scope + scopePos, scopeFramesPerRead);
+        scopePos += scopeCounts[b];
+      }
     }
     return 0;
   }

@@ -25,7 +25,10 @@ class SmallSynth : public Synth
       d.smooth.coeffs = OnePole::makeCoeffs(0.05f);
       d.saw.clear();
     }
+    // a scope for the UI: every 4th frame of each voice's signal and envelope (SignalProcessor::publishSignal)
+    publishSignal("scope", kScopeFrames, kSynthVoices, 2, 2);
   }
+  static constexpr int kScopeFrames = 256;
 
   void processVoice(int v, const EventsToSignals::Voice& voice, const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs,
                     AudioContext* ctx) override
@@ -39,7 +42,9 @@ class SmallSynth : public Synth
     const DSPVector osc = d.saw(freq) + d.pulse(freq * 0.5f, 0.3f + mod * 0.4f) * 0.6f;
     // brightness follows key pressure (z) and the mod wheel; per-voice stereo position from the voice index row
     const DSPVector cutoff = clamp(freq * (2.f + 6.f * d.smooth(voice.outputs.constRow(kZ) + mod)), DSPVector(0.001f), DSPVector(0.45f));
-    const DSPVector y = d.lp(osc, cutoff, DSPVector(0.5f)) * d.env(gate);
+    const DSPVector env = d.env(gate);
+    const DSPVector y = d.lp(osc, cutoff, DSPVector(0.5f)) * env;
+    storePublishedSignal("scope", concatRows(y, env), kFloatsPerDSPVector, v);
     const DSPVector pan = vox * (1.f / kSynthVoices);
     outputs[0] += y * (1.f - pan);
     outputs[1] += y * pan;

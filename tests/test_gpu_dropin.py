@@ -149,25 +149,41 @@ def test_synth_subclass_events_to_audio_same_source_same_bits():
     from test_gpu_events import performance
     Lg, Lr = _gpu_lib(), _ref_lib()
     Lr.synth_ref_run.restype = ctypes.c_int
-    Lr.synth_ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p]
+    c_szp = ctypes.POINTER(ctypes.c_size_t)
+    Lr.synth_ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p,
+                                 c_f32p, c_szp, ctypes.c_int]
     Lg.synth_gpu_run.restype = ctypes.c_int
     Lg.synth_gpu_run.argtypes = [ctypes.c_size_t, ctypes.POINTER(_Ev), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float, ctypes.c_float,
-                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_size_t, c_f32p, c_szp, ctypes.c_int,
+                                 ctypes.c_char_p, ctypes.c_size_t]
     N, block, n_blocks = 40, 512, 10
+    scope_inst, scope_read = 17, 700     # the UI reads up to 700 frames after each block: sometimes all there is, sometimes not
+    scope_cap = n_blocks * scope_read * 2
     S = block * n_blocks
     glide, drift = 0.012, 0.6
     per_inst = [performance("midi", 900 + k, S, 6) for k in range(N)]
     wantL, wantR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
     for k, evs in enumerate(per_inst):
         arr = (_Ev * max(1, len(evs)))(*[_Ev(*e) for e in evs])
-        assert Lr.synth_ref_run(arr, len(evs), glide, drift, block, n_blocks, wantL[k].ctypes.data_as(c_f32p), wantR[k].ctypes.data_as(c_f32p)) == 0
+        if k == scope_inst:
+            want_scope, want_counts = np.zeros(scope_cap, np.float32), np.zeros(n_blocks, np.uint64)
+            sc = (want_scope.ctypes.data_as(c_f32p), want_counts.ctypes.data_as(c_szp), scope_read)
+        else:
+            sc = (None, None, 0)
+        assert Lr.synth_ref_run(arr, len(evs), glide, drift, block, n_blocks, wantL[k].ctypes.data_as(c_f32p), wantR[k].ctypes.data_as(c_f32p), *sc) == 0
     flat = [(e, k) for k, evs in enumerate(per_inst) for e in evs]
     arr = (_Ev * len(flat))(*[_Ev(*e) for e, _ in flat])
     inst = (ctypes.c_int * len(flat))(*[k for _, k in flat])
     gotL, gotR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
     err = ctypes.create_string_buffer(4096)
-    st = Lg.synth_gpu_run(N, arr, inst, len(flat), glide, drift, block, n_blocks, 3, gotL.ctypes.data_as(c_f32p), gotR.ctypes.data_as(c_f32p), err, 4096)
+    got_scope, got_counts = np.zeros(scope_cap, np.float32), np.zeros(n_blocks, np.uint64)
+    st = Lg.synth_gpu_run(N, arr, inst, len(flat), glide, drift, block, n_blocks, 3, gotL.ctypes.data_as(c_f32p), gotR.ctypes.data_as(c_f32p),
+                          scope_inst, got_scope.ctypes.data_as(c_f32p), got_counts.ctypes.data_as(c_szp), scope_read, err, 4096)
     assert st == 0, err.value.decode()
     assert_bits_equal(gotL, wantL, True, "synth left")
     assert_bits_equal(gotR, wantR, True, "synth right")
     assert np.abs(wantL).max() > 0.05
+    # storePublishedSignal("scope", ...) inside processVoice: the published ring of instrument 17, read as a UI would
+    assert np.array_equal(got_counts, want_counts), (got_counts, want_counts)
+    assert want_counts.sum() > 0 and np.abs(want_scope).max() > 0.01
+    assert_bits_equal(got_scope, want_scope, True, "published scope")
