@@ -424,8 +424,9 @@ typedef enum mlgpu_vop
   MLGPU_VOP_COLUMN_INDEX = 0,       /* columnIndex()                         :965   no inputs */
   MLGPU_VOP_RANGE_OPEN = 1,         /* rangeOpen(start, end)                 :970-974 */
   MLGPU_VOP_RANGE_CLOSED = 2,       /* rangeClosed(start, end)               :978-982 */
-  MLGPU_VOP_INTERPOLATE_LINEAR = 3  /* interpolateDSPVectorLinear(start, end) :986-990; one row of
+  MLGPU_VOP_INTERPOLATE_LINEAR = 3, /* interpolateDSPVectorLinear(start, end) :986-990; one row of
                                      * interpolateCoeffsLinear (MLDSPFilters.h:34-44) */
+  MLGPU_VOP_TABLE = 4               /* a constant DSPVector; made by mlgpu_graph_add_const_vector only */
 } mlgpu_vop;
 
 int mlgpu_graph_create(mlgpu_engine* e, size_t n_voices, mlgpu_graph** out);
@@ -438,6 +439,10 @@ int mlgpu_graph_add_param(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_control(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_vop(mlgpu_graph* g, int vop, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_const(mlgpu_graph* g, float value);
+/* A constant DSPVector: the same 64 floats for every voice and every vector — DSPVector(const float*), DSPVector(float (*)(int)),
+ * DSPVector(std::array<float, 64>) (MLDSPOps.h:140-161) evaluated on the host when the graph is built (windows, index maps,
+ * tables). Bit patterns are kept as given. Inside a rate region the vector is the region function's own DSPVector. */
+int mlgpu_graph_add_const_vector(mlgpu_graph* g, const float* values /* [64] */, const char* name);
 /* Delay-line memory of a delay node (before compile): IntegerDelay::setMaxDelayInSamples (MLDSPFilters.h:823-831),
  * i.e. rings of 2^bitsToContain(floor(d) + 64) floats per voice (PitchbendableDelay: two of them). */
 int mlgpu_graph_set_max_delay(mlgpu_graph* g, int proc_node, float max_delay_in_samples);

@@ -161,6 +161,18 @@ struct Capture
     if (r < 0) throw Error(-r, std::string("mlgpu_graph: ") + mlgpu_last_error(eng->handle()));
     return r;
   }
+  // constant DSPVectors of this pass, by contents and by the rate region they are used in (a node belongs to one region)
+  std::map<std::pair<int, std::array<uint32_t, 64>>, int> tableNodes;
+  int regionCounter{0}, curRegion{0};
+  int constantVector(const std::array<float, 64>& t)
+  {
+    std::pair<int, std::array<uint32_t, 64>> key;
+    key.first = curRegion;
+    std::memcpy(key.second.data(), t.data(), sizeof(key.second));
+    auto it = tableNodes.find(key);
+    if (it != tableNodes.end()) return it->second;
+    return tableNodes[key] = ret(mlgpu_graph_add_const_vector(g, t.data(), nullptr));
+  }
   int constant(float f)
   {
     uint32_t u;
@@ -179,17 +191,27 @@ struct Capture
   void deferState(int node, int idx, uint32_t bits) { deferred.push_back(Deferred{node, 2, idx, bits}); }
 };
 
-// one row of a DSPVectorArray: a graph node, or a float literal not yet materialised
+// one row of a DSPVectorArray: a graph node, or a float literal / a table of 64 floats not yet materialised
 struct Sig
 {
   int node{-1};
   float lit{0.f};
+  std::shared_ptr<const std::array<float, 64>> table;  // DSPVector(const float*), DSPVector(fn), load(): host data, may be built
+                                                       // outside a capture (a static window, a member filled in a setup function)
   uint32_t epoch{0};  // capture pass that made `node`
   int ord{-1};        // creation ordinal among the computed nodes of that pass (-1: input / param / const)
   Sig() {}
   Sig(int n, float l) : node(n), lit(l), epoch(n >= 0 ? Capture::get().epoch : 0) {}
+  explicit Sig(const float* p64) : table(std::make_shared<const std::array<float, 64>>(toArray(p64))) {}
+  static std::array<float, 64> toArray(const float* p)
+  {
+    std::array<float, 64> a;
+    std::memcpy(a.data(), p, sizeof(a));
+    return a;
+  }
   int id() const
   {
+    if (node < 0 && table) return Capture::get().constantVector(*table);
     if (node < 0) return Capture::get().constant(lit);
     Capture& c = Capture::get();
     if (epoch == c.epoch) return node;
@@ -250,6 +272,20 @@ class DSPVectorArray
   {
     static_assert(ROWS == 1, "a single signal is a DSPVector");
     sig_[0] = s;
+  }
+  // host data: the same 64 * ROWS floats for every voice and every process call (MLDSPOps.h:140-161). Evaluated on the host,
+  // carried into the kernel as constant tables (mlgpu_graph_add_const_vector).
+  explicit DSPVectorArray(const float* pData)
+  {
+    for (size_t j = 0; j < ROWS; ++j) sig_[j] = gpu::Sig(pData + j * 64);
+  }
+  explicit DSPVectorArray(float* pData) : DSPVectorArray(static_cast<const float*>(pData)) {}
+  DSPVectorArray(std::array<float, 64 * ROWS> a) : DSPVectorArray(a.data()) {}
+  DSPVectorArray(float (*fn)(int))
+  {
+    std::array<float, 64 * ROWS> a;
+    for (size_t i = 0; i < 64 * ROWS; ++i) a[i] = fn((int)i);
+    for (size_t j = 0; j < ROWS; ++j) sig_[j] = gpu::Sig(a.data() + j * 64);
   }
   DSPVectorArray& operator=(float k)
   {
@@ -474,6 +510,13 @@ inline DSPVectorArray<ROWS> add(const DSPVectorArray<ROWS>& first, const DSPVect
 }
 
 // ---- index generators (MLDSPOps.h:962-990, 1365-1383) ---------------------------------------------------------------
+// load (MLDSPOps.h: load(DSPVectorArray&, const float*)): host floats into a vector — a constant table in the captured kernel.
+// store() has no counterpart: a captured DSPVector has no host values; route it to ctx->outputs or a published signal.
+template <size_t ROWS>
+inline void load(DSPVectorArray<ROWS>& vecDest, const float* pSrc)
+{
+  vecDest = DSPVectorArray<ROWS>(pSrc);
+}
 inline DSPVector columnIndex() { return DSPVector(gpu::vopNode(MLGPU_VOP_COLUMN_INDEX, {})); }
 inline DSPVector rangeOpen(float start, float end) { return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_OPEN, {gpu::Sig(-1, start), gpu::Sig(-1, end)})); }
 inline DSPVector rangeClosed(float start, float end)
@@ -1301,8 +1344,12 @@ inline DSPVectorArray<1> rateRegion(int kind, FN& fn, const DSPVectorArray<IN_RO
   if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_graph_begin_region: ") + mlgpu_last_error(c.eng->handle()));
   DSPVectorArray<IN_ROWS> resampled;
   for (size_t j = 0; j < IN_ROWS; ++j) resampled.sig_[j] = computedSig(inner[j]);
+  const int outerRegion = c.curRegion;
+  c.curRegion = ++c.regionCounter;
   const DSPVectorArray<1> y = fn(resampled);
-  return DSPVectorArray<1>(computedSig(c.ret(mlgpu_graph_end_region(c.g, y.sig_[0].id(), nullptr))));
+  const int result = y.sig_[0].id();
+  c.curRegion = outerRegion;
+  return DSPVectorArray<1>(computedSig(c.ret(mlgpu_graph_end_region(c.g, result, nullptr))));
 }
 }  // namespace gpu
 
@@ -1630,6 +1677,8 @@ class VoiceProgram
       cap.nodeOfOrd.clear();
       cap.feedbackOfOrd.clear();
       cap.constNodes.clear();
+      cap.tableNodes.clear();
+      cap.regionCounter = cap.curRegion = 0;
       cap.deferred.clear();
       cap.taps.clear();
       for (size_t c = 0; c < nIn_; ++c)

@@ -823,6 +823,11 @@ class Graph:
             return self._ret(self.L.mlgpu_graph_add_param(self.h, bname), name)
         if type == "const":
             return self._ret(self.L.mlgpu_graph_add_const(self.h, float(value)), name)
+        if type == "const_vector":   # value: 64 floats, the same DSPVector for every voice and vector
+            tbl = np.ascontiguousarray(value, np.float32)
+            if tbl.shape != (64,):
+                raise MlgpuError(Status.ERR_INVALID, "const_vector: 64 floats")
+            return self._ret(self.L.mlgpu_graph_add_const_vector(self.h, tbl.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), bname), name)
         if type == "feedback":
             return self._ret(self.L.mlgpu_graph_add_feedback(self.h, bname), name)
         if type == "proc":

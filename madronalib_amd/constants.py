@@ -84,6 +84,7 @@ class Vop:
     RANGE_OPEN = 1
     RANGE_CLOSED = 2
     INTERPOLATE_LINEAR = 3
+    TABLE = 4           # made by Graph.add(type="const_vector") only
 
 
 class RowsRule:

@@ -182,6 +182,7 @@ struct Node
   int rate{RATE_AUDIO};
   int cOff{0}, sOff{0}, nc{0}, ns{0};
   int region{-1};         // the rate region whose function this node belongs to (-1: the outer graph)
+  std::vector<uint32_t> table;  // MLGPU_VOP_TABLE: the 64 floats of a constant DSPVector (bit patterns)
   int role{0};            // ROLE_REGION_IN: HalfBandFilter carrying an outer node into region `region`;
                           // ROLE_REGION_OUT: HalfBandFilter bringing region `slot`'s result back (an outer node)
 };
@@ -334,6 +335,11 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
           << n.slot << ", " << n.nOut << ")";
       break;
     case NODE_VOP:
+      if (n.kind == MLGPU_VOP_TABLE)
+      {
+        s << "u2f(cv" << i << "[" << idx << "])";  // same index for every lane: a scalar load from constant memory
+        break;
+      }
       s << "vop<" << n.kind << ">(" << idx;
       for (size_t j = 0; j < n.in.size(); ++j) s << ", " << arg(j);
       s << ")";
@@ -368,6 +374,13 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   auto sfx = [](int l) { return "_" + std::to_string(l); };
   s << "// generated by libmlgpu graph.hip (" << VL << " voice" << (VL > 1 ? "s" : "") << " per lane)\n"
     << (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\nusing namespace mldev;\n";
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+    if (g->nodes[i].type == NODE_VOP && g->nodes[i].kind == MLGPU_VOP_TABLE)
+    {
+      s << "__constant__ unsigned cv" << i << "[64] = {";
+      for (int j = 0; j < 64; ++j) s << (j ? ", " : "") << "0x" << std::hex << g->nodes[i].table[j] << std::dec << "u";
+      s << "};\n";
+    }
   // windowed rings: the latency of a sector refill is hidden by other waves only, so keep at least two per SIMD
   s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->windowedRings && g->totalRings) ? ", 2" : "") << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n";
   if (g->hasImpulse)
@@ -907,6 +920,18 @@ extern "C"
     n.type = NODE_VOP;
     n.kind = vop;
     if (nIn) n.in.assign(inputs, inputs + nIn);
+    n.name = name ? name : "";
+    return addNode(g, std::move(n));
+  }
+  int mlgpu_graph_add_const_vector(mlgpu_graph* g, const float* values, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (!values) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_const_vector: 64 floats");
+    Node n;
+    n.type = NODE_VOP;
+    n.kind = MLGPU_VOP_TABLE;
+    n.table.resize(MLGPU_FLOATS_PER_DSPVECTOR);
+    memcpy(n.table.data(), values, sizeof(float) * MLGPU_FLOATS_PER_DSPVECTOR);
     n.name = name ? name : "";
     return addNode(g, std::move(n));
   }

@@ -2,8 +2,12 @@
 // stateful function) and a half-rate branch (Downsample2xFunction with two input rows), as MLDSPFunctional.h:104-213
 // documents them. Compiled unchanged against the reference (oracle/dropin_ref.cpp) and against include/mlgpu/compat
 // (dropin_gpu.cpp).
+// host tables: a fade-in window made by a function of the index, and a comb of gains read from memory
+inline float fadeWindow(int n) { return (n < 16) ? (float)n * (1.f / 16.f) : 1.f - (float)(n - 16) * (0.25f / 48.f); }
 struct OversampleState
 {
+  float combGains[64];
+  DSPVector comb;    // filled by load() in the setup function, outside any capture
   Upsample2xFunction<1> upper;
   Upsample2xFunction<1> quadOuter, quadInner;  // one inside the other: a 4x oversampled hard clipper
   Downsample2xFunction<2> downer;
@@ -24,6 +28,8 @@ inline void oversampleSetup(OversampleState& s)
   s.smear.setDelayInSamples(113.f);
   s.smooth.coeffs = OnePole::makeCoeffs(0.1f);
   s.dc.coeffs = DCBlocker::makeCoeffs(0.002f);
+  for (int n = 0; n < 64; ++n) s.combGains[n] = (n % 5 == 0) ? 1.25f : 0.75f + 0.001f * (float)n;
+  load(s.comb, s.combGains);
 }
 
 // inputs: [0] audio, [1] modulation.  outputs: [0] shaped, [1] mix
@@ -36,7 +42,8 @@ inline void oversampleProcess(AudioContext* ctx, void* stateData)
   DSPVector shaped = s->upper(
       [&](const DSPVector x)
       {
-        DSPVector driven = s->smear(s->preFilter(x * DSPVector(4.0f)));
+        // a table inside the 2x function: applied to each of its two DSPVectors per outer vector
+        DSPVector driven = s->smear(s->preFilter(x * DSPVector(4.0f) * DSPVector(s->combGains)));
         return clamp(driven - driven * driven * driven * DSPVector(0.333f), DSPVector(-1.f), DSPVector(1.f));
       },
       in);
@@ -58,6 +65,7 @@ inline void oversampleProcess(AudioContext* ctx, void* stateData)
   const DSPVector p = s->phasor(f);
   const DSPVector shapes = phasorToSine(p) + phasorToSaw(p, f) + phasorToPulse(p, f, DSPVector(0.3f) + mod * DSPVector(0.2f));
 
-  ctx->outputs[0] = s->dc(shaped) + shapes * DSPVector(0.1f);
+  const DSPVector window(fadeWindow);
+  ctx->outputs[0] = s->dc(shaped) * s->comb + shapes * DSPVector(0.1f) * window;
   ctx->outputs[1] = lofi * DSPVector(0.5f) + shaped * DSPVector(0.5f) + clipped4x * DSPVector(0.25f) + s->lock(ctx->inputs[1], 2.0f, 1.0f / 48000.f) * DSPVector(0.1f);
 }

@@ -42,6 +42,8 @@ def evaluate(chk, description, outputs, V, T, in_signals, params, coeffs, states
             val[name] = chk.vop(n["kind"], V, T, a[0], a[1])
         elif ty == "const":
             val[name] = np.full((V, S), np.float32(n["value"]), np.float32)
+        elif ty == "const_vector":
+            val[name] = np.ascontiguousarray(np.tile(np.asarray(n["value"], np.float32), (V, T)))
         elif ty == "op":
             a = [np.ascontiguousarray(x) for x in ins] + [None, None]
             val[name] = chk.op(n["kind"], a[0], a[1], a[2]).view(np.float32).reshape(V, S)
@@ -101,6 +103,8 @@ def evaluate_stream(chk, description, outputs, V, T, in_signals, params, coeffs,
                 val[name] = np.ascontiguousarray(np.repeat(p[:, None], 64, 1))
             elif ty == "const":
                 val[name] = np.full((V, 64), np.float32(n["value"]), np.float32)
+            elif ty == "const_vector":
+                val[name] = np.ascontiguousarray(np.tile(np.asarray(n["value"], np.float32), (V, 1)))
             elif ty == "feedback":
                 val[name] = st[name].copy()
             elif ty == "vop":

@@ -386,3 +386,34 @@ def test_online_tuning_same_bits_and_settles(eng, oracle):
     settled, vl, quads = g.tuning()
     assert settled and vl in (1, 2) and quads in (1, 2)
     assert any(not f[0] for f in forms)    # it did go through a measuring phase
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vpl", [0, 2])
+def test_const_vector_nodes_keep_their_bits(eng, oracle, vpl):
+    """mlgpu_graph_add_const_vector: DSPVector(const float*) / DSPVector(fn) of MLDSPOps.h:140-161 as a node. Every voice and
+    every vector sees the same 64 floats, bit patterns untouched (NaN payloads, infinities, denormals, -0)."""
+    import madronalib_amd as ml
+    V, T = 300, 5
+    rng = np.random.default_rng(77)
+    tbl = rng.standard_normal(64).astype(np.float32)
+    odd = rng.integers(0, 2**32, 64, dtype=np.uint64).astype(np.uint32)
+    odd[:6] = [0x7fc00123, 0xffc00001, 0x7f800000, 0xff800000, 0x00000001, 0x80000000]
+    desc = [dict(name="x", type="input"),
+            dict(name="win", type="const_vector", value=tbl),
+            dict(name="bits", type="const_vector", value=odd.view(np.float32)),
+            dict(name="y", type="op", kind=Op.MULTIPLY, inputs=["x", "win"]),
+            dict(name="lp", type="proc", kind=Proc.ONE_POLE, inputs=["y"])]
+    g = ml.Graph(eng, V, desc, ["lp", "bits", "y"], voices_per_lane=vpl)
+    g.clear()
+    co = np.full((2, V), 0.25, np.float32)
+    co[1] = 0.75
+    g.set_coeffs("lp", [co[0], co[1]])
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + np.uint32(5), 64 * T)
+    got = g.process_host(T, {"x": x}, Layout.QUAD)
+    from graph_oracle import evaluate
+    states = {"lp": oracle.chain_clear([Proc.ONE_POLE], V)}
+    want = evaluate(oracle, desc, ["lp", "bits", "y"], V, T, {"x": x}, {}, {"lp": co}, states)
+    for o, w, nm in zip(got, want, ("lp", "bits", "y")):
+        assert_bits_equal(o, w, True, nm)
+    assert np.array_equal(got[1].view(np.uint32), np.tile(odd, (V, T)))
