@@ -323,9 +323,16 @@ def cpu_baseline_cfg3(budget_s=12.0):
     T = int(max(16, min(4096, 16 * budget_s / max(t_cal, 1e-6) / 3)))
     times = [run(T) for _ in range(3)]
     best = min(times)
-    return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": kind,
+    one_core = None
+    if kind == "reference":          # one core beside all cores (4096 voices, ~2 s)
+        f1, c1 = cfg3_params(0, 4096, 4096)
+        t1 = ref.bench_saw_bandpass_gain(4096, 16, f1, c1[0], c1[1], c1[2], 0.25, 1)[0]
+        T1 = int(max(16, min(4096, 16 * 1.0 / max(t1, 1e-6))))
+        one_core = 4096 * T1 * 64 / min(ref.bench_saw_bandpass_gain(4096, T1, f1, c1[0], c1[1], c1[2], 0.25, 1)[0] for _ in range(2))
+    return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": kind, "value_one_core": one_core,
             "sample": f"{Vs} voices x {T} DSPVectors of the same chain/params, {cores} threads, best of 3 "
-                      f"({'compiled reference headers, g++ -O2 SSE2' if kind == 'reference' else 'plain-C oracle port, gcc -O2'})"}
+                      f"({'compiled reference headers, g++ -O2 SSE2' if kind == 'reference' else 'plain-C oracle port, gcc -O2'})"
+                      + ("; value_one_core: 4096 voices on one thread" if one_core else "")}
 
 
 def cpu_baseline_cfg4(budget_s=10.0):
@@ -495,6 +502,22 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name),
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if args.workload == "cfg2":
+            # each op and the fused pair, on the ramp and on noise (no data-dependent branches: same rate)
+            from madronalib_amd.constants import Op
+            d_x, d_y = _keep
+            n_el = V * T * 64
+            d_noise = eng.to_device(np.random.default_rng(1).uniform(-np.pi, np.pi, n_el).astype(np.float32))
+            per_op = {}
+            for label, op in (("sinApprox", Op.SIN_APPROX), ("expApprox", Op.EXP_APPROX), ("expApprox(sinApprox)", Op.EXP_APPROX_OF_SIN_APPROX)):
+                for data, src in (("ramp", d_x), ("noise", d_noise)):
+                    for _ in range(8):
+                        eng.op_apply(op, src, None, None, d_y, n_el)
+                    eng.timer_start()
+                    for _ in range(256):
+                        eng.op_apply(op, src, None, None, d_y, n_el)
+                    per_op[f"{label} / {data}"] = n_el * 256 / (eng.timer_stop_ms() * 1e-3)
+            out["config"]["per_op_voice_samples_per_s"] = per_op
         baselines = {"cfg2": cpu_baseline_cfg2, "cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5}
         if world == 1 and not args.no_cpu_baseline and args.workload in baselines:
             try:
