@@ -439,6 +439,16 @@ int mlgpu_graph_add_param(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_control(mlgpu_graph* g, const char* name);
 int mlgpu_graph_add_vop(mlgpu_graph* g, int vop, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_const(mlgpu_graph* g, float value);
+/* Live constants. By default a const node is a literal of the generated kernel. After mlgpu_graph_set_live_constants(g, 1)
+ * (before compile) const nodes are read from a small device table instead — a scalar load per constant and launch — and
+ * mlgpu_graph_set_const changes one between launches (stream-ordered, no recompilation): what a host-side parameter that the
+ * reference's process function turns into `DSPVector(value)` or a `float` argument needs in order to stay adjustable.
+ * mlgpu_graph_update_constants_from(g, other): `other` is a second graph built by the same code with other numbers (it need
+ * not be compiled); when both have the same nodes and wiring, g's constants take other's values, otherwise
+ * MLGPU_ERR_UNSUPPORTED and nothing changes. Same results as a graph compiled with those literals. */
+int mlgpu_graph_set_live_constants(mlgpu_graph* g, int on);
+int mlgpu_graph_set_const(mlgpu_graph* g, int const_node, float value);
+int mlgpu_graph_update_constants_from(mlgpu_graph* g, mlgpu_graph* other);
 /* A constant DSPVector: the same 64 floats for every voice and every vector — DSPVector(const float*), DSPVector(float (*)(int)),
  * DSPVector(std::array<float, 64>) (MLDSPOps.h:140-161) evaluated on the host when the graph is built (windows, index maps,
  * tables). Bit patterns are kept as given. Inside a rate region the vector is the region function's own DSPVector. */

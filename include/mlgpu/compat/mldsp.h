@@ -173,8 +173,10 @@ struct Capture
     if (it != tableNodes.end()) return it->second;
     return tableNodes[key] = ret(mlgpu_graph_add_const_vector(g, t.data(), nullptr));
   }
+  bool dedupeConstants{true};
   int constant(float f)
   {
+    if (!dedupeConstants) return ret(mlgpu_graph_add_const(g, f));
     uint32_t u;
     std::memcpy(&u, &f, 4);
     auto it = constNodes.find(u);
@@ -1627,6 +1629,7 @@ struct VoiceProgramOptions
 {
   bool delayWindows{false};
   bool autotune{false};
+  bool liveConstants{false};  // constants are read from a device table: VoiceProgram::update() can change them (mlgpu_graph_set_live_constants)
 };
 
 // Captures a reference-style process function once and runs it for `voices` voices on the GPU.
@@ -1639,6 +1642,9 @@ class VoiceProgram
   bool usesVoice_{false};
   unsigned voiceRowMask_{0};  // which of the 8 voice control rows the captured code reads: only those are graph inputs
   std::vector<Capture::Tap> taps_;  // published signals: graph outputs after the nOut_ audio outputs, in this order
+  AudioContext* ctx_{nullptr};
+  std::function<void(AudioContext*)> body_;
+  VoiceProgramOptions opt_;
 
  public:
   VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state, VoiceProgramOptions opt = VoiceProgramOptions())
@@ -1647,21 +1653,15 @@ class VoiceProgram
   }
   // general form: `body` is run twice in capture mode; it reads ctx->inputs / ctx->getInputVoice() and writes ctx->outputs
   VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, std::function<void(AudioContext*)> body, VoiceProgramOptions opt = VoiceProgramOptions())
-      : eng_(e), voices_(voices)
+      : eng_(e), voices_(voices), ctx_(ctx), body_(std::move(body)), opt_(opt)
   {
-    static uint32_t epochCounter = 0;
     ctx->usesVoice_ = false;
     nIn_ = ctx->inputs.size();
     nOut_ = ctx->outputs.size();
     Capture cap;
     cap.eng = &e;
-    struct Scope
-    {
-      Capture*& slot;
-      Capture* prev;
-      Scope(Capture*& s, Capture* c) : slot(s), prev(s) { slot = c; }
-      ~Scope() { slot = prev; }
-    } scope(Capture::current(), &cap);
+    cap.dedupeConstants = !opt.liveConstants;  // live: one node per use, so that a later capture with other numbers lines up
+    CaptureScope scope(&cap);
     // pass 1 records what the process function leaves behind in the user's state (DSPVectors kept for the next call);
     // pass 2 builds the graph that is compiled, reading those as one-vector feedback
     for (int pass = 0; pass < 2; ++pass)
@@ -1671,34 +1671,9 @@ class VoiceProgram
       eng_.check(mlgpu_graph_create(e.handle(), voices, &g_));
       if (opt.delayWindows) eng_.check(mlgpu_graph_set_delay_layout(g_, 1));
       if (opt.autotune) eng_.check(mlgpu_graph_set_autotune(g_, 1));
-      cap.g = g_;
-      cap.epoch = ++epochCounter;
-      cap.nextOrd = 0;
-      cap.nodeOfOrd.clear();
-      cap.feedbackOfOrd.clear();
-      cap.constNodes.clear();
-      cap.tableNodes.clear();
-      cap.regionCounter = cap.curRegion = 0;
-      cap.deferred.clear();
-      cap.taps.clear();
-      for (size_t c = 0; c < nIn_; ++c)
-        ctx->inputs[(int)c] = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g_, ("in" + std::to_string(c)).c_str())), 0.f));
-      // the 8 rows of this lane's voice (EventsToSignals) are further streamed inputs, after the audio inputs; the first pass
-      // finds out whether the code reads them at all
+      if (opt.liveConstants) eng_.check(mlgpu_graph_set_live_constants(g_, 1));
       int rowNode[kNumVoiceOutputRows];
-      for (int r = 0; r < kNumVoiceOutputRows; ++r)
-      {
-        rowNode[r] = -1;
-        if (pass == 0 || ((voiceRowMask_ >> r) & 1u))
-        {
-          rowNode[r] = cap.ret(mlgpu_graph_add_input(g_, ("voice" + std::to_string(r)).c_str()));
-          ctx->voice_.outputs.row(r) = DSPVector(Sig(rowNode[r], 0.f));
-        }
-        else
-          ctx->voice_.outputs.row(r) = DSPVector(0.f);  // never read (pass 1 saw no use of it)
-      }
-      for (size_t c = 0; c < nOut_; ++c) ctx->outputs[(int)c] = DSPVector(0.f);
-      body(ctx);
+      capturePass(cap, g_, pass == 0, rowNode);
       if (pass == 0 && ctx->usesVoice_)
         for (int r = 0; r < kNumVoiceOutputRows; ++r)
         {
@@ -1708,15 +1683,8 @@ class VoiceProgram
         }
     }
     usesVoice_ = voiceRowMask_ != 0;
-    for (auto& kv : cap.feedbackOfOrd)
-    {
-      if (kv.first >= (int)cap.nodeOfOrd.size()) throw std::logic_error("mldsp GPU shim: the process function took different paths in its two capture passes");
-      eng_.check(mlgpu_graph_set_feedback(g_, kv.second, cap.nodeOfOrd[kv.first]));
-    }
-    for (size_t c = 0; c < nOut_; ++c) eng_.check(mlgpu_graph_add_output(g_, ctx->outputs[(int)c].sig_[0].id()));
+    finishGraph(cap, g_);
     taps_ = cap.taps;
-    for (const Capture::Tap& t : taps_)
-      for (int node : t.nodes) eng_.check(mlgpu_graph_add_output(g_, node));
     eng_.check(mlgpu_graph_compile(g_));
     for (const Capture::Deferred& d : cap.deferred)
     {
@@ -1727,6 +1695,94 @@ class VoiceProgram
       else eng_.check(mlgpu_graph_set_state_uniform(g_, d.node, d.idx, d.bits));
     }
   }
+
+  // Host-side numbers changed (a parameter the process function turns into `DSPVector(value)`, a float argument of a
+  // LinearGlide, `filter.coeffs = makeCoeffs(...)`): run the process function once more in capture mode and take the new
+  // constants and coefficients into the running kernel. State (phases, filter memories, delay lines) is untouched; nothing is
+  // recompiled. Needs VoiceProgramOptions::liveConstants when constants change (coefficients alone do not); throws
+  // gpu::Error(MLGPU_ERR_UNSUPPORTED) when the function took a different path and built a different graph.
+  void update()
+  {
+    Capture cap;
+    cap.eng = &eng_;
+    cap.dedupeConstants = !opt_.liveConstants;
+    CaptureScope scope(&cap);
+    mlgpu_graph* tmp = nullptr;
+    eng_.check(mlgpu_graph_create(eng_.handle(), voices_, &tmp));
+    struct Guard
+    {
+      mlgpu_graph* g;
+      ~Guard() { mlgpu_graph_destroy(g); }
+    } guard{tmp};
+    int rowNode[kNumVoiceOutputRows];
+    capturePass(cap, tmp, false, rowNode);  // the user's kept DSPVectors hold nodes of the previous capture: feedback, as in pass 2
+    finishGraph(cap, tmp);
+    eng_.check(mlgpu_graph_update_constants_from(g_, tmp));
+    for (const Capture::Deferred& d : cap.deferred)
+      if (d.what == 0)
+      {
+        float f;
+        std::memcpy(&f, &d.bits, 4);
+        eng_.check(mlgpu_graph_set_coeff_uniform(g_, d.node, d.idx, f));
+      }
+  }
+
+ private:
+  struct CaptureScope
+  {
+    Capture* prev;
+    explicit CaptureScope(Capture* c) : prev(Capture::current()) { Capture::current() = c; }
+    ~CaptureScope() { Capture::current() = prev; }
+  };
+  static uint32_t& epochCounter()
+  {
+    static uint32_t n = 0;
+    return n;
+  }
+  // one run of the process function against graph g
+  void capturePass(Capture& cap, mlgpu_graph* g, bool firstPass, int* rowNode)
+  {
+    cap.g = g;
+    cap.epoch = ++epochCounter();
+    cap.nextOrd = 0;
+    cap.nodeOfOrd.clear();
+    cap.feedbackOfOrd.clear();
+    cap.constNodes.clear();
+    cap.tableNodes.clear();
+    cap.regionCounter = cap.curRegion = 0;
+    cap.deferred.clear();
+    cap.taps.clear();
+    for (size_t c = 0; c < nIn_; ++c)
+      ctx_->inputs[(int)c] = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g, ("in" + std::to_string(c)).c_str())), 0.f));
+    // the 8 rows of this lane's voice (EventsToSignals) are further streamed inputs, after the audio inputs; the first pass
+    // finds out whether the code reads them at all
+    for (int r = 0; r < kNumVoiceOutputRows; ++r)
+    {
+      rowNode[r] = -1;
+      if (firstPass || ((voiceRowMask_ >> r) & 1u))
+      {
+        rowNode[r] = cap.ret(mlgpu_graph_add_input(g, ("voice" + std::to_string(r)).c_str()));
+        ctx_->voice_.outputs.row(r) = DSPVector(Sig(rowNode[r], 0.f));
+      }
+      else
+        ctx_->voice_.outputs.row(r) = DSPVector(0.f);  // never read (pass 1 saw no use of it)
+    }
+    for (size_t c = 0; c < nOut_; ++c) ctx_->outputs[(int)c] = DSPVector(0.f);
+    body_(ctx_);
+  }
+  void finishGraph(Capture& cap, mlgpu_graph* g)
+  {
+    for (auto& kv : cap.feedbackOfOrd)
+    {
+      if (kv.first >= (int)cap.nodeOfOrd.size()) throw std::logic_error("mldsp GPU shim: the process function took different paths in its two capture passes");
+      eng_.check(mlgpu_graph_set_feedback(g, kv.second, cap.nodeOfOrd[kv.first]));
+    }
+    for (size_t c = 0; c < nOut_; ++c) eng_.check(mlgpu_graph_add_output(g, ctx_->outputs[(int)c].sig_[0].id()));
+    for (const Capture::Tap& t : cap.taps)
+      for (int node : t.nodes) eng_.check(mlgpu_graph_add_output(g, node));
+  }
+
+ public:
   VoiceProgram(const VoiceProgram&) = delete;
   VoiceProgram& operator=(const VoiceProgram&) = delete;
   ~VoiceProgram()

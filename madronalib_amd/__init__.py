@@ -734,7 +734,8 @@ class Graph:
       {"name", "type": "input"|"param"|"const"|"proc"|"op", "kind": Proc.X / Op.X, "inputs": [names], "value"}
     """
 
-    def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0, delay_windows=False, autotune=False):
+    def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0, delay_windows=False, autotune=False,
+                 live_constants=False):
         self.engine = engine
         self.L = engine.L
         self.V = int(n_voices)
@@ -750,6 +751,8 @@ class Graph:
             engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 1))
         if autotune:
             engine._check(self.L.mlgpu_graph_set_autotune(self.h, 1))
+        if live_constants:
+            self._check(self.L.mlgpu_graph_set_live_constants(self.h, 1))
         if description is not None:
             for n in description:
                 self.add(**n)
@@ -798,6 +801,18 @@ class Graph:
         if name:
             self.ids[name] = r
         return r
+
+    def _check(self, st):
+        if st != 0:
+            raise MlgpuError(st, self.L.mlgpu_last_error(self.engine.h).decode() if self.engine.h else "offline graph: status %d" % st)
+
+    def set_const(self, node, value):
+        """Change a const node (live_constants=True graphs: between launches, no recompilation)."""
+        self._check(self.L.mlgpu_graph_set_const(self.h, self._id(node), float(value)))
+
+    def update_constants_from(self, other):
+        """Take the constants of `other`, a graph with the same nodes and wiring (compiled or not)."""
+        self._check(self.L.mlgpu_graph_update_constants_from(self.h, other.h))
 
     def set_feedback(self, feedback_node, value_node):
         self.engine._check(self.L.mlgpu_graph_set_feedback(self.h, self._id(feedback_node), self._id(value_node)))

@@ -118,6 +118,9 @@ def _declare(L):
     sig("mlgpu_graph_add_input", i, [vp, c.c_char_p])
     sig("mlgpu_graph_add_param", i, [vp, c.c_char_p])
     sig("mlgpu_graph_add_const", i, [vp, f])
+    sig("mlgpu_graph_set_live_constants", i, [vp, i])
+    sig("mlgpu_graph_set_const", i, [vp, i, f])
+    sig("mlgpu_graph_update_constants_from", i, [vp, vp])
     sig("mlgpu_graph_add_const_vector", i, [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_char_p])
     sig("mlgpu_graph_add_control", i, [vp, c.c_char_p])
     sig("mlgpu_graph_add_feedback", i, [vp, c.c_char_p])

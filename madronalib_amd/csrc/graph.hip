@@ -230,6 +230,9 @@ struct mlgpu_graph
   float* d_coeffs{nullptr};
   uint32_t* d_state{nullptr};
   float* d_params{nullptr};
+  float* d_consts{nullptr};      // live constants: [nConsts] floats
+  int nConsts{0};
+  bool liveConsts{false};        // const nodes read d_consts instead of being literals of the generated code
   float* d_mem{nullptr};
   std::vector<char> emitted;     // mlgpu_graph_emit: the gfx950 code object
   size_t memFloatsPerVoice{0};
@@ -290,7 +293,10 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
     case NODE_INPUT: s << "xin" << n.slot << L << "[k]"; break;
     case NODE_CONTROL: s << "ctl" << n.slot << L << "[t * a.V]"; break;
     case NODE_PARAM: s << "a.params[(size_t)" << n.slot << " * a.V + v" << L << "]"; break;
-    case NODE_CONST: s << floatLiteral(n.value); break;
+    case NODE_CONST:
+      if (g->liveConsts) s << "a.consts[" << n.slot << "]";  // wave-uniform: a scalar load, kept in an SGPR
+      else s << floatLiteral(n.value);
+      break;
     case NODE_PROC:
       if (mlgpu_proc_is_vector_rate(n.kind))
         s << "p" << i << L << ".next_n(" << idx << ")";
@@ -862,6 +868,7 @@ extern "C"
     if (g->d_coeffs) hipFree(g->d_coeffs);
     if (g->d_state) hipFree(g->d_state);
     if (g->d_params) hipFree(g->d_params);
+    if (g->d_consts) hipFree(g->d_consts);
     if (g->d_mem) hipFree(g->d_mem);
     if (g->tuneEv0) hipEventDestroy(g->tuneEv0);
     if (g->tuneEv1) hipEventDestroy(g->tuneEv1);
@@ -995,7 +1002,10 @@ extern "C"
     n.type = NODE_CONST;
     n.kind = 0;
     n.value = value;
-    return addNode(g, std::move(n));
+    n.slot = g->nConsts;
+    const int id = addNode(g, std::move(n));
+    if (id >= 0) g->nConsts++;
+    return id;
   }
   int mlgpu_graph_add_proc(mlgpu_graph* g, int kind, const int* inputs, int nIn, const char* name)
   {
@@ -1217,6 +1227,17 @@ extern "C"
     if (err == hipSuccess) err = hipMemsetAsync(g->d_state, 0, sizeof(uint32_t) * V * (size_t)(g->NS + 1), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(g->d_coeffs, 0, sizeof(float) * V * (size_t)(g->NC + 1), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(g->d_params, 0, sizeof(float) * V * (size_t)(g->nParams + 1), e->stream);
+    if (err == hipSuccess && g->liveConsts)
+    {
+      err = hipMalloc((void**)&g->d_consts, sizeof(float) * (size_t)(g->nConsts + 1));
+      for (const Node& n : g->nodes)
+        if (n.type == NODE_CONST && err == hipSuccess)
+        {
+          uint32_t u;
+          memcpy(&u, &n.value, 4);
+          err = mlgpu_launch_fill32((uint32_t*)g->d_consts + n.slot, u, 1, e->stream);
+        }
+    }
     for (const Node& n : g->nodes)
     {
       if (n.type != NODE_PROC) continue;
@@ -1352,6 +1373,58 @@ extern "C"
     g->autotune = on != 0;
     return MLGPU_OK;
   }
+  int mlgpu_graph_set_live_constants(mlgpu_graph* g, int on)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_set_live_constants: before mlgpu_graph_compile");
+    g->liveConsts = on != 0;
+    return MLGPU_OK;
+  }
+  int mlgpu_graph_set_const(mlgpu_graph* g, int node, float value)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (node < 0 || node >= (int)g->nodes.size() || g->nodes[node].type != NODE_CONST) return gfail(g, MLGPU_ERR_INVALID, "graph_set_const: not a const node");
+    if (g->compiled && !g->liveConsts)
+      return gfail(g, MLGPU_ERR_INVALID, "graph_set_const: constants of this graph are literals of its kernel (mlgpu_graph_set_live_constants before compile)");
+    g->nodes[node].value = value;
+    if (!g->compiled) return MLGPU_OK;
+    uint32_t u;
+    memcpy(&u, &value, 4);
+    return mlgpu_fill32(g->e, g->d_consts + g->nodes[node].slot, u, 1);
+  }
+  // Same nodes, same wiring? (what a second capture of the same user code produces when only host-side numbers changed)
+  static const char* structureDifference(const mlgpu_graph* a, const mlgpu_graph* b)
+  {
+    if (a->V != b->V) return "number of voices";
+    if (a->nodes.size() != b->nodes.size()) return "number of nodes";
+    for (size_t i = 0; i < a->nodes.size(); ++i)
+    {
+      const Node &x = a->nodes[i], &y = b->nodes[i];
+      if (x.type != y.type || x.kind != y.kind || x.in != y.in || x.slot != y.slot || x.nOut != y.nOut || x.fbSource != y.fbSource || x.region != y.region ||
+          x.role != y.role || x.rate != y.rate)
+        return "a node or its inputs";
+      if (x.ringLen != y.ringLen) return "a delay line's maximum length";
+      if (x.table != y.table) return "a constant DSPVector";
+      if (x.type == NODE_CONST && !a->liveConsts && memcmp(&x.value, &y.value, 4) != 0) return "a constant (this graph was not compiled with live constants)";
+    }
+    if (a->outputs != b->outputs) return "outputs";
+    if (a->regions.size() != b->regions.size()) return "rate regions";
+    return nullptr;
+  }
+  int mlgpu_graph_update_constants_from(mlgpu_graph* g, mlgpu_graph* other)
+  {
+    if (!g || !other) return MLGPU_ERR_INVALID;
+    if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_update_constants_from: compile the graph first");
+    if (const char* why = structureDifference(g, other)) return gfail(g, MLGPU_ERR_UNSUPPORTED, std::string("graph_update_constants_from: the graphs differ in ") + why);
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+    {
+      Node& n = g->nodes[i];
+      if (n.type != NODE_CONST || memcmp(&n.value, &other->nodes[i].value, 4) == 0) continue;
+      const int st = mlgpu_graph_set_const(g, (int)i, other->nodes[i].value);
+      if (st != MLGPU_OK) return st;
+    }
+    return MLGPU_OK;
+  }
   size_t mlgpu_graph_device_bytes(mlgpu_graph* g)
   {
     if (!g || !g->compiled) return 0;
@@ -1412,6 +1485,7 @@ extern "C"
     a.coeffs = g->d_coeffs;
     a.state = g->d_state;
     a.params = g->d_params;
+    a.consts = g->d_consts;
     a.mem = g->d_mem;
     a.V = g->V;
     a.T = T;

@@ -41,5 +41,6 @@ struct GraphArgs
   float* mem;  // delay-line rings of all delay nodes, [sample][V] each
   size_t V, T;
   const float* impulseTable;
+  const float* consts;  // live constants (mlgpu_graph_set_live_constants): one float per const node, the same for all voices
   size_t t0;  // DSPVectors processed since the last clear (a Downsample2xFunction region pairs vectors 2k, 2k + 1)
 };

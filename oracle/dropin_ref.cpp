@@ -30,7 +30,8 @@ extern "C" int dropin_ref_run(size_t V, size_t T, const float* gate, const float
 }
 
 #include "../tests/cpp/dropin_reverb.h"
-extern "C" int plate_ref_run(size_t V, size_t T, const float* inL, const float* inR, float* outL, float* outR)
+// knobsAt: the vector before which the host turns the knobs (plateTurnKnobs); >= T: never
+extern "C" int plate_ref_run(size_t V, size_t T, size_t knobsAt, const float* inL, const float* inR, float* outL, float* outR)
 {
   const size_t S = T * kFloatsPerDSPVector;
   for (size_t v = 0; v < V; ++v)
@@ -40,6 +41,7 @@ extern "C" int plate_ref_run(size_t V, size_t T, const float* inL, const float* 
     AudioContext ctx(2, 2, 48000);
     for (size_t t = 0; t < T; ++t)
     {
+      if (t == knobsAt) plateTurnKnobs(state);
       load(ctx.inputs[0], inL + v * S + t * kFloatsPerDSPVector);
       load(ctx.inputs[1], inR + v * S + t * kFloatsPerDSPVector);
       plateProcess(&ctx, &state);

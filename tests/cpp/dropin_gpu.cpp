@@ -43,7 +43,9 @@ extern "C" int dropin_gpu_run(size_t V, size_t T, const float* gate, const float
 
 #include "dropin_reverb.h"
 // the plate reverb for V independent instances; launches: how many process calls the T vectors are split into
-extern "C" int plate_gpu_run(size_t V, size_t T, int launches, const float* inL, const float* inR, float* outL, float* outR, char* err, size_t errLen)
+// knobsAt: the vector (a launch boundary) before which the host turns the knobs and calls VoiceProgram::update(); >= T: never
+extern "C" int plate_gpu_run(size_t V, size_t T, int launches, size_t knobsAt, const float* inL, const float* inR, float* outL, float* outR, char* err,
+                             size_t errLen)
 {
   try
   {
@@ -51,7 +53,9 @@ extern "C" int plate_gpu_run(size_t V, size_t T, int launches, const float* inL,
     PlateState state;
     plateSetup(state);
     AudioContext ctx(2, 2, 48000);
-    gpu::VoiceProgram prog(eng, V, &ctx, plateProcess, &state);
+    gpu::VoiceProgramOptions opt;
+    opt.liveConstants = knobsAt < T;  // the knob values become DSPVector(f) constants of the captured code
+    gpu::VoiceProgram prog(eng, V, &ctx, plateProcess, &state, opt);
     const size_t Tl = T / (size_t)launches;
     // QUAD signals: the T vectors of one launch are contiguous, so consecutive launches are consecutive slices
     gpu::DeviceSignal vmL(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR), vmR(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR);
@@ -63,6 +67,11 @@ extern "C" int plate_gpu_run(size_t V, size_t T, int launches, const float* inL,
     for (int l = 0; l < launches; ++l)
     {
       const size_t off = (size_t)l * Tl * 64 * V;
+      if ((size_t)l * Tl == knobsAt)
+      {
+        plateTurnKnobs(state);
+        prog.update();  // the process function runs once more on the host; no recompilation, no state touched
+      }
       const float* ins[2] = {qL.data() + off, qR.data() + off};
       float* outs[2] = {oL.data() + off, oR.data() + off};
       eng.check(mlgpu_graph_process(prog.graph(), Tl, ins, MLGPU_LAYOUT_QUAD, outs, MLGPU_LAYOUT_QUAD));

@@ -12,7 +12,15 @@ struct PlateState
   PitchbendableDelay lineL, lineR;
   OnePole dampL, dampR;
   DSPVector feedbackL, feedbackR;  // written at the end of one call, read at the start of the next
+  float size{0.8f}, feedback{0.55f}, damping{0.2f};  // the knobs: plain floats the host changes whenever it likes
 };
+
+inline void plateTurnKnobs(PlateState& p)
+{
+  p.size = 0.55f;
+  p.feedback = 0.7f;
+  p.damping = 0.1f;
+}
 
 inline void plateSetup(PlateState& p)
 {
@@ -48,8 +56,9 @@ inline void plateProcess(AudioContext* ctx, void* stateData)
   const float sr = 48000.f;
 
   // control-rate parameters arrive as floats and are smoothed to signals
-  DSPVector vSize = p->smoothSize(0.8f);
-  DSPVector vFeedback = p->smoothFeedback(0.55f);
+  DSPVector vSize = p->smoothSize(p->size);
+  DSPVector vFeedback = p->smoothFeedback(p->feedback);
+  p->dampL.coeffs = OnePole::makeCoeffs(p->damping);
   DSPVector vMin(kFloatsPerDSPVector);
   DSPVector sizeInSamples = sr * vSize;
   DSPVector t1 = max(0.0047 * sizeInSamples, vMin);

@@ -51,7 +51,7 @@ extern "C" int example_reverb_gpu_run(size_t V, size_t T, int launches, const fl
 }
 
 // throughput of the same captured program: V reverbs x T vectors per launch, `launches` launches timed with the engine's events
-extern "C" int example_reverb_gpu_bench(size_t V, size_t T, int launches, int options /* bit 0: windowed rings, bit 1: online tuning */, float* msPerLaunch,
+extern "C" int example_reverb_gpu_bench(size_t V, size_t T, int launches, int options /* bit 0: windowed rings, bit 1: online tuning, bit 2: live constants */, float* msPerLaunch,
                                         char* err, size_t errLen)
 {
   try
@@ -63,6 +63,7 @@ extern "C" int example_reverb_gpu_bench(size_t V, size_t T, int launches, int op
     gpu::VoiceProgramOptions opt;
     opt.delayWindows = (options & 1) != 0;
     opt.autotune = (options & 2) != 0;
+    opt.liveConstants = (options & 4) != 0;
     gpu::VoiceProgram prog(eng, V, &ctx, processVector, &r, opt);
     gpu::DeviceSignal q0(eng, V, T), q1(eng, V, T), o0(eng, V, T), o1(eng, V, T);
     eng.check(mlgpu_fill32(eng.handle(), (uint32_t*)q0.data(), 0x3c23d70au /* 0.01f */, V * T * 64));

@@ -23,9 +23,10 @@ def _gpu_lib():
     L.dropin_gpu_run.restype = ctypes.c_int
     L.dropin_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
     L.plate_gpu_run.restype = ctypes.c_int
-    L.plate_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    L.plate_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p,
+                                ctypes.c_size_t]
     L.oversample_gpu_run.restype = ctypes.c_int
-    L.oversample_gpu_run.argtypes = L.plate_gpu_run.argtypes
+    L.oversample_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
     return L
 
 
@@ -39,9 +40,9 @@ def _ref_lib():
     L.dropin_ref_run.restype = ctypes.c_int
     L.dropin_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
     L.plate_ref_run.restype = ctypes.c_int
-    L.plate_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
+    L.plate_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
     L.oversample_ref_run.restype = ctypes.c_int
-    L.oversample_ref_run.argtypes = L.plate_ref_run.argtypes
+    L.oversample_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
     return L
 
 
@@ -87,11 +88,14 @@ def test_same_source_same_bits():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("launches", [1, 5])
-def test_reverb_with_feedback_state_same_source_same_bits(launches):
+@pytest.mark.parametrize("launches,knobs_at", [(1, 60), (5, 60), (5, 24), (10, 6)])
+def test_reverb_with_feedback_state_same_source_same_bits(launches, knobs_at):
     """tests/cpp/dropin_reverb.h: smoothed float parameters (LinearGlide), FractionalDelay, Allpass<IntegerDelay>, seven
     Allpass<PitchbendableDelay>, two PitchbendableDelays and a stereo feedback path kept in DSPVector members of the user's
-    state struct — compiled unchanged against the reference and against the shim; 64 reverbs per launch on the GPU."""
+    state struct — compiled unchanged against the reference and against the shim; 64 reverbs per launch on the GPU.
+    knobs_at < 60: before that vector the host changes three plain floats of the state (size, feedback, damping). The reference
+    just reads them on its next call; the captured program takes them in with VoiceProgram::update() — live constants and
+    coefficients, no recompilation — and the glides, the pitch-bending delays and the tail follow bit for bit."""
     from inputs import lcg_noise
     Lg, Lr = _gpu_lib(), _ref_lib()
     V, T = 64, 60
@@ -100,11 +104,11 @@ def test_reverb_with_feedback_state_same_source_same_bits(launches):
     inL[:, 64 * 20:] = 0   # let the tail ring
     inR[:, 64 * 20:] = 0
     wantL, wantR = np.zeros_like(inL), np.zeros_like(inL)
-    assert Lr.plate_ref_run(V, T, inL.ctypes.data_as(c_f32p), inR.ctypes.data_as(c_f32p), wantL.ctypes.data_as(c_f32p),
+    assert Lr.plate_ref_run(V, T, knobs_at, inL.ctypes.data_as(c_f32p), inR.ctypes.data_as(c_f32p), wantL.ctypes.data_as(c_f32p),
                             wantR.ctypes.data_as(c_f32p)) == 0
     gotL, gotR = np.zeros_like(inL), np.zeros_like(inL)
     err = ctypes.create_string_buffer(4096)
-    st = Lg.plate_gpu_run(V, T, launches, inL.ctypes.data_as(c_f32p), inR.ctypes.data_as(c_f32p), gotL.ctypes.data_as(c_f32p),
+    st = Lg.plate_gpu_run(V, T, launches, knobs_at, inL.ctypes.data_as(c_f32p), inR.ctypes.data_as(c_f32p), gotL.ctypes.data_as(c_f32p),
                           gotR.ctypes.data_as(c_f32p), err, 4096)
     assert st == 0, err.value.decode()
     assert_bits_equal(gotL, wantL, True, "plate reverb left")

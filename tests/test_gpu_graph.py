@@ -417,3 +417,49 @@ def test_const_vector_nodes_keep_their_bits(eng, oracle, vpl):
     for o, w, nm in zip(got, want, ("lp", "bits", "y")):
         assert_bits_equal(o, w, True, nm)
     assert np.array_equal(got[1].view(np.uint32), np.tile(odd, (V, T)))
+
+
+@pytest.mark.gpu
+def test_live_constants_change_between_launches(eng, oracle):
+    """mlgpu_graph_set_live_constants / set_const / update_constants_from: constants read from a device table give the same
+    bits as literals, can be changed between launches without touching state, and a graph with other wiring is refused."""
+    import madronalib_amd as ml
+    V, T = 300, 4
+
+    def description(gain, offset):
+        return [dict(name="x", type="input"), dict(name="g", type="const", value=gain), dict(name="o", type="const", value=offset),
+                dict(name="xg", type="op", kind=Op.MULTIPLY, inputs=["x", "g"]),
+                dict(name="lp", type="proc", kind=Proc.ONE_POLE, inputs=["xg"]),
+                dict(name="y", type="op", kind=Op.ADD, inputs=["lp", "o"])]
+    co = np.stack([np.full(V, 0.25, np.float32), np.full(V, 0.75, np.float32)])
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + np.uint32(9), 64 * T * 3)
+    seg = [np.ascontiguousarray(x[:, 64 * T * i:64 * T * (i + 1)]) for i in range(3)]
+    values = [(0.5, 0.125), (1.75, -0.3), (0.1, 7.0)]
+    states = {"lp": oracle.chain_clear([Proc.ONE_POLE], V)}
+    want = [evaluate(oracle, description(*v), ["y"], V, T, {"x": s}, {}, {"lp": co}, states)[0] for v, s in zip(values, seg)]
+
+    g = ml.Graph(eng, V, description(*values[0]), ["y"], live_constants=True)
+    assert "a.consts[" in g.source
+    g.clear()
+    g.set_coeffs("lp", [co[0], co[1]])
+    (got0,) = g.process_host(T, {"x": seg[0]}, Layout.QUAD)
+    g.set_const("g", values[1][0])
+    g.set_const("o", values[1][1])
+    (got1,) = g.process_host(T, {"x": seg[1]}, Layout.QUAD)
+    other = ml.Graph(ml.OfflineEngine(), V, description(*values[2]), ["y"])     # never compiled: only its numbers are read
+    g.update_constants_from(other)
+    (got2,) = g.process_host(T, {"x": seg[2]}, Layout.QUAD)
+    for got, w, nm in zip((got0, got1, got2), want, ("literal values", "set_const", "update_constants_from")):
+        assert_bits_equal(got, w, True, nm)
+
+    rewired = description(*values[2])
+    rewired[3]["inputs"] = ["x", "o"]
+    with pytest.raises(ml.MlgpuError):
+        g.update_constants_from(ml.Graph(ml.OfflineEngine(), V, rewired, ["y"]))
+    plain = ml.Graph(eng, V, description(*values[0]), ["y"])
+    assert "a.consts[" not in plain.source
+    with pytest.raises(ml.MlgpuError):
+        plain.set_const("g", 2.0)                      # literals of the kernel
+    with pytest.raises(ml.MlgpuError):
+        plain.update_constants_from(other)             # ... so other numbers are another kernel
+    plain.update_constants_from(ml.Graph(ml.OfflineEngine(), V, description(*values[0]), ["y"]))   # the same numbers: nothing to do
