@@ -1857,14 +1857,14 @@ class SynthProgram
   size_t publishedInstrument_{0};
 
  public:
-  SynthProgram(const Engine& e, Synth& synth, size_t nInstruments, size_t nOutputs, int sampleRate)
+  SynthProgram(const Engine& e, Synth& synth, size_t nInstruments, size_t nOutputs, int sampleRate, VoiceProgramOptions opt = VoiceProgramOptions())
       : eng_(e),
         nInstruments_(nInstruments),
         polyphony_(synth.getNumVoices()),
         nOut_(nOutputs),
         ctx_(0, nOutputs, sampleRate),
         prog_(e, nInstruments * (size_t)synth.getNumVoices(), &ctx_,
-              [&synth](AudioContext* c) { synth.processVoice(0, c->getInputVoice(0), c->inputs, c->outputs, c); })
+              [&synth](AudioContext* c) { synth.processVoice(0, c->getInputVoice(0), c->inputs, c->outputs, c); }, opt)
   {
     eng_.check(mlgpu_events_create(e.handle(), nInstruments, polyphony_, &ev_));
     eng_.check(mlgpu_events_set_sample_rate(ev_, (double)sampleRate));
@@ -1896,6 +1896,7 @@ class SynthProgram
   }
   mlgpu_events* events() const { return ev_; }  // protocol, glide, drift, bend range: the mlgpu_events_set_* calls
   VoiceProgram& program() { return prog_; }
+  void update() { prog_.update(); }  // the Synth's host-side numbers changed (coefficients, parameters): VoiceProgram::update()
   size_t voices() const { return nInstruments_ * (size_t)polyphony_; }
 
   void addInputEvent(size_t instrument, const Event& e)  // AudioContext::addInputEvent

@@ -98,6 +98,7 @@ extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float gli
   for (int b = 0; b < nBlocks; ++b)
   {
     const int start = b * blockFrames;
+    if (b == nBlocks / 2) synth.setEnvelope(0.02f, 0.2f, 0.3f, 0.4f);  // the host turns the envelope knobs half way through
     for (int i = 0; i < nEvents; ++i)
       if (events[i].time >= start && events[i].time < start + blockFrames)
       {

@@ -164,6 +164,11 @@ extern "C" int synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, c
     for (int b = 0; b < nBlocks; ++b)
     {
       const int start = b * blockFrames;
+      if (b == nBlocks / 2)
+      {
+        synth.setEnvelope(0.02f, 0.2f, 0.3f, 0.4f);
+        prog.update();  // coefficients only: no live constants needed
+      }
       for (int i = 0; i < nEvents; ++i)
         if (events[i].time >= start && events[i].time < start + blockFrames)
         {

@@ -30,6 +30,12 @@ class SmallSynth : public Synth
   }
   static constexpr int kScopeFrames = 256;
 
+  // a host-side parameter change while notes are sounding (what a plug-in's parameter callback does)
+  void setEnvelope(float a, float d, float s, float r)
+  {
+    for (auto& v : dsp_) v.env.coeffs = ADSR::calcCoeffs(a, d, s, r, 48000.f);
+  }
+
   void processVoice(int v, const EventsToSignals::Voice& voice, const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs,
                     AudioContext* ctx) override
   {

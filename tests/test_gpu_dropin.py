@@ -149,7 +149,9 @@ class _Ev(ctypes.Structure):
 def test_synth_subclass_events_to_audio_same_source_same_bits():
     """tests/cpp/dropin_synth.h: a Synth subclass (processVoice reading the EventsToSignals voice rows). Reference side: its own
     Synth::processVector + AudioContext + EventsToSignals, one instrument at a time. GPU side: mlgpu_events -> the captured
-    processVoice for all voices of 40 instruments -> mlgpu_mixdown_groups. MIDI events in, stereo audio out, bit for bit."""
+    processVoice for all voices of 40 instruments -> mlgpu_mixdown_groups. MIDI events in, stereo audio out, bit for bit.
+    Half way through the host changes the envelope times of every voice (SmallSynth::setEnvelope, as a parameter callback would);
+    the GPU side calls SynthProgram::update() and the sounding notes continue with the new coefficients, like the reference's."""
     from test_gpu_events import performance
     Lg, Lr = _gpu_lib(), _ref_lib()
     Lr.synth_ref_run.restype = ctypes.c_int
