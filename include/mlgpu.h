@@ -495,6 +495,7 @@ int mlgpu_graph_add_route(mlgpu_graph* g, int route, const int* input_nodes, int
                           const char* name);
 int mlgpu_graph_add_proc(mlgpu_graph* g, int proc_kind, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* input_nodes, int n_inputs, const char* name);
+/* Limits per graph: 16 streamed inputs, 8 controls, 8 outputs (MLGPU_ERR_UNSUPPORTED beyond). */
 int mlgpu_graph_add_output(mlgpu_graph* g, int node);
 int mlgpu_graph_node(mlgpu_graph* g, const char* name);
 /* how many times `node` is referenced: as an input of other nodes, as a feedback source, as a graph output */

@@ -135,3 +135,39 @@ def test_offline_graph_emit_keeps_processors_in_registers(windows):
         g.compile()
     assert ei.value.status == ml.Status.ERR_INVALID
     g.close()
+
+
+def test_offline_emit_of_const_vectors_live_constants_and_regions():
+    """Code generation paths that only GPU tests would otherwise reach, compiled here with hiprtc for gfx950: a constant
+    DSPVector (a __constant__ table), live constants (read from the argument table, not literals), a rate region, and the
+    structural comparison behind mlgpu_graph_update_constants_from (no device needed for that either)."""
+    import madronalib_amd as ml
+    from madronalib_amd.constants import Op, Proc, Region
+
+    def build(gain, live, wire_other=False):
+        g = ml.Graph(ml.OfflineEngine(), 512, live_constants=live)
+        g.add("x", "input")
+        g.add("gain", "const", value=gain)
+        g.add("win", "const_vector", value=np.hanning(64).astype(np.float32))
+        g.begin_region(Region.UPSAMPLE_2X, ["x"], ["rx"])
+        g.add("tbl", "const_vector", value=np.linspace(0, 1, 64, dtype=np.float32))
+        g.add("shaped", "op", Op.MULTIPLY, ["rx", "tbl"])
+        g.add("lp", "proc", Proc.LOPASS, ["shaped"])
+        g.end_region("lp", "y")
+        g.add("yw", "op", Op.MULTIPLY, ["y", "win"])
+        g.add("out", "op", Op.MULTIPLY, ["x" if wire_other else "yw", "gain"])
+        g.add_output("out")
+        return g
+
+    g = build(0.5, True)
+    source, code = g.emit()
+    assert code[:4] == b"\x7fELF"
+    assert source.count("__constant__ unsigned cv") == 2 and "a.consts[0]" in source
+    lit_source, lit_code = build(0.5, False).emit()
+    assert "a.consts[" not in lit_source and lit_code[:4] == b"\x7fELF"
+    # set_const before compile changes the value a later compile would start from; never an error
+    g.set_const("gain", 0.25)
+    with pytest.raises(ml.MlgpuError):
+        g.set_const("x", 1.0)                        # not a const node
+    with pytest.raises(ml.MlgpuError):
+        g.update_constants_from(build(0.75, True))   # g itself is not compiled: nothing to update
