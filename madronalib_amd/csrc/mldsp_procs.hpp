@@ -102,11 +102,17 @@ MLD float div_nr(float n, float d)
 // with a wave-uniform ballot (streamed, time-varying frequency).
 MLD bool blep_freq_is_odd(float dt) { return (dt > 0.f) && !((dt >= 0x1p-64f) && (dt <= 0x1p+64f)); }
 
-template <bool FAST>
+template <bool FAST, bool SKIP = false>
 MLD float poly_blep(float t, float dt)
 {
   const bool lo = (t < dt);
   const bool hi = (t > 1.0f - dt);  // only consulted when !lo (the reference's else-if)
+  // A step is near for a fraction 2 * dt of the samples; neighbouring voices have free-running phases, so for low and
+  // middle frequencies most samples find no lane of the wavefront in either zone: one scalar branch skips the division
+  // and both polynomials (the skipped lanes would have selected 0 anyway). SKIP is set only where the whole division is
+  // per sample (a streamed frequency: +12 % on the instrument-bank pipeline); with a launch-constant frequency the
+  // remaining work is too short for a branch to pay (config 3: -7 %), so those paths keep straight-line code.
+  if (SKIP && __builtin_amdgcn_ballot_w64(lo || hi) == 0) return 0.f;
   const float num = lo ? t : (t - 1.0f);
   float q;
   if (!FAST && __builtin_amdgcn_ballot_w64(blep_freq_is_odd(dt)) != 0)
@@ -180,14 +186,14 @@ struct Proc<MLGPU_PROC_SAW_GEN>  // MLDSPGens.h:395-402, phasorToSaw :362-369
   uint32_t omega32;
   MLD void load(const VoiceMem& m, const KernelTables&) { omega32 = m.s(0); }
   MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
-  template <bool FAST>
+  template <bool FAST, bool SKIP = false>
   MLD float step(float cps)
   {
     const float p = phasor_next(omega32, cps);
     const float saw = __builtin_fmaf(p, 2.f, -1.f);  // PARITY: p*2 is exact, so one rounding either way
-    return saw - poly_blep<FAST>(p, cps);
+    return saw - poly_blep<FAST, SKIP>(p, cps);
   }
-  MLD float next(float cps) { return step<false>(cps); }
+  MLD float next(float cps) { return step<false, true>(cps); }
   MLD float next_fast(float cps) { return step<true>(cps); }
   // launch-constant cps whose range test `odd` (wave-uniform) was done once by the caller
   MLD float next_u(float cps, bool odd) { return odd ? step<false>(cps) : step<true>(cps); }
@@ -207,21 +213,21 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
     omega32 = m.s(0);
   }
   MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
-  template <bool FAST>
+  template <bool FAST, bool SKIP = false>
   MLD float step(float cps, float w)
   {
     const float p = phasor_next(omega32, cps);
     float pulse = (p >= w) ? -1.f : 1.f;
-    pulse = pulse + poly_blep<FAST>(p, cps);
+    pulse = pulse + poly_blep<FAST, SKIP>(p, cps);
     const float d = p - w + 1.0f;
     const float down = d - (float)sse_cvtt(d);  // fractionalPart
-    pulse = pulse - poly_blep<FAST>(down, cps);
+    pulse = pulse - poly_blep<FAST, SKIP>(down, cps);
     return pulse;
   }
-  MLD float next(float cps) { return step<false>(cps, width); }
+  MLD float next(float cps) { return step<false, true>(cps, width); }
   MLD float next_fast(float cps) { return step<true>(cps, width); }
   // graph form: pulse width as an audio-rate input, PulseGen::operator()(freq, width) MLDSPGens.h:390
-  MLD float next2(float cps, float w) { return step<false>(cps, w); }
+  MLD float next2(float cps, float w) { return step<false, true>(cps, w); }
   MLD float next_u(float cps, bool odd) { return odd ? step<false>(cps, width) : step<true>(cps, width); }
   MLD float next_u(float cps, float w, bool odd) { return odd ? step<false>(cps, w) : step<true>(cps, w); }
   static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
