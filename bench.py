@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — voice-samples/s of the mldsp.h hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 by itself: starts N rank processes, rank r on GPU r (or `--launcher threads`: N host threads, one engine per
+        device, in this process); under `python -m torch.distributed.run --nproc-per-node N ...` each process is one rank.
+        Asking for more GPUs than are visible is an error, never a silent smaller run.
 
 Default workload = BASELINE.json configs[2], the configuration the metric
 "voice-samples/sec (SawGen->SVF chain)" is quoted on:
@@ -12,12 +15,15 @@ rank's partition: 750 DSPVectors (SURVEY §8d "sustained for >= 1 s of audio"), 
 launches of the fused voice-bank kernel x 30 DSPVectors each into a ring of two output signals;
 per-voice freq, coefficients and state are resident in HBM and carried from launch to launch.
 Voices shard embarrassingly: rank g owns voices [g*V, (g+1)*V) — weak scaling, no data-path
-collective (torch.distributed is used only for the barrier and the max-over-ranks time).
+collective; ranks meet only for the barrier on both sides of the timed region and the max-over-ranks
+time (madronalib_amd/rendezvous.py: files, threads or gloo — never RCCL, there is nothing to reduce).
 
 Prints ONE JSON line on rank 0 with
   roofline      HBM bound: algorithmic bytes per launch / average launch duration measured with HIP
                 events on the engine's stream over the timed region; `traffic` = HBM bytes per
-                launch from the rocprofv3 PMC passes summarised in profiles/pmc_traffic.json (or null)
+                launch from the rocprofv3 PMC passes of exactly this workload and size (profiles/pmc_workloads.json,
+                else null); `valu` = the VALU-issue bound from SQ_INSTS_VALU of the same passes; `bound` names
+                whichever fraction is higher
   cpu_baseline  (N=1 only) the compiled reference (oracle/_ref) when present, else the plain-C port,
                 timed on the host cores over a bounded sample of the same workload.
 """
@@ -53,7 +59,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-from madronalib_amd.sharding import cfg3_voice_params, max_over_ranks, partition  # noqa: E402
+from madronalib_amd.sharding import cfg3_voice_params, partition  # noqa: E402
 
 
 def cfg3_params(lo, hi, total):
@@ -398,18 +404,184 @@ def cpu_baseline_cfg5(budget_s=10.0):
             "sample": f"{Vs} voices x {T} DSPVectors of the synth16 voice, {cores} threads, best of 3 (reference objects, g++ -O2 SSE2)"}
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed PMC summary, if there is one."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+VALU_PEAK_LANE_INST = 256 * 4 * 32 * 2.4e9   # 7.86e13: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
+
+
+def workload_key(name, V, T):
+    """What identifies one measured case in profiles/pmc_workloads.json: the workload, its variant switches and its size."""
+    var = [f"{k.lower().replace('mlgpu_', '')}={os.environ[k]}" for k in ("MLGPU_DELAY_WINDOWS", "MLGPU_UNIFORM_DELAY", "MLGPU_EVENT_ROWS",
+                                                                            "MLGPU_VOICES_PER_LANE", "MLGPU_FTZ") if os.environ.get(k)]
+    return ":".join([name] + var + [f"{V}x{T}"])
+
+
+def pmc_record(key):
+    """PMC counters of the dominant kernel for exactly this case (rocprofv3 --pmc passes of tools/gpu_profile_all.sh,
+    summarised per WORKLOAD in profiles/pmc_workloads.json), or None: a counter cannot be read from inside the run."""
     try:
-        with open(path) as f:
-            d = json.load(f)
-        for k, v in d.get("kernels", {}).items():
-            if k in kernel_name or kernel_name in k:
-                return v.get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", "pmc_workloads.json")) as f:
+            return json.load(f).get("workloads", {}).get(key)
+    except Exception:
+        return None
+
+
+def run_rank(args, rank, local_rank, world, rdv):
+    """One rank = one engine on one device. Returns the result dict on rank 0, None elsewhere."""
+    import madronalib_amd as ml
+    dV, dT, dL = WORKLOADS[args.workload]
+    V = args.voices or dV
+    T = args.vectors or dT
+    L = args.launches or dL
+    total = V * world                 # weak scaling: per-GPU work fixed
+    lo, hi = partition(total, world, rank)
+    assert hi - lo == V
+
+    eng = ml.Engine(local_rank)
+    info = eng.device_info()
+    launch, alg_bytes, kernel_name, desc, _keep = setup_workload(eng, args.workload, V, T, lo, total)
+
+    def step():
+        for _ in range(L):
+            launch()
+
+    def fence():                      # device-wide sync (every stream of this device), then all ranks
+        eng.sync()
+        eng.device_sync()
+        if "torch" in sys.modules and sys.modules["torch"].cuda.is_available():
+            sys.modules["torch"].cuda.synchronize()
+        rdv.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    # a graph that tunes itself over its first launches (mlgpu_graph_set_autotune) finishes that before the clock starts
+    graphs = [o for o in (_keep if isinstance(_keep, tuple) else (_keep,)) if hasattr(o, "tuning")]
+    for g in graphs:
+        for _ in range(16):
+            if g.tuning()[0]:
+                break
+            launch()
+    fence()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = eng.timer_stop_ms() / (args.steps * L)   # HIP events on the engine's stream
+    eng.sync()
+    eng.device_sync()
+    my_elapsed = time.perf_counter() - t0
+    rdv.barrier()
+    elapsed = rdv.max(my_elapsed)
+    ranks = rdv.gather({"rank": rank, "device": local_rank, "pci_bus_id": info["pci_bus_id"], "name": info["name"], "pid": os.getpid(),
+                        "voices": [lo, hi], "ms_per_step": my_elapsed / args.steps * 1e3, "kernel_ms": kernel_ms})
+    if rank != 0:
+        return None
+    buses = [r["pci_bus_id"] for r in ranks]
+    if len(set(buses)) != world:
+        raise SystemExit(f"bench.py: {world} ranks but only {len(set(buses))} distinct GPUs ({buses}): every rank must own its own device")
+
+    units = float(total) * T * 64 * L * args.steps      # voice-samples over all ranks
+    value = units / elapsed
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    units_per_launch = float(V) * T * 64
+    key = workload_key(args.workload, V, T)
+    pmc = pmc_record(key) or {}
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": kernel_name, "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": alg_bytes, "pmc_case": key if pmc else None}
+    if pmc.get("valu_wave_insts_per_launch"):
+        # the second bound (SURVEY 8d "report both bounds"): VALU issue. SQ_INSTS_VALU counts wave-instructions; x64 lanes.
+        ipu = pmc["valu_wave_insts_per_launch"] * 64.0 / units_per_launch
+        lane_rate = ipu * units_per_launch / (kernel_ms * 1e-3)
+        roof["valu"] = {"insts_per_unit": ipu, "achieved_lane_inst_per_s": lane_rate, "peak": VALU_PEAK_LANE_INST,
+                        "frac": lane_rate / VALU_PEAK_LANE_INST,
+                        "source": "SQ_INSTS_VALU per launch (profiles/pmc_workloads.json) x 64 lanes / live launch duration"}
+        if roof["valu"]["frac"] > roof["frac"]:
+            roof["bound"] = "valu"
+    out = {
+        "metric": "voice-samples/sec (SawGen->SVF chain)" if args.workload == "cfg3" else f"voice-samples/sec ({args.workload})",
+        "value": value, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "voices_per_gpu": V, "total_voices": total, "vectors_per_launch": T,
+                   "launches_per_step": L, "vectors_per_step": T * L, "samples_per_vector": 64,
+                   "layout": "QUAD [S/4][V][4]", "parallelism": f"voices x{world} (no collective)", "launcher": rdv.kind,
+                   "realtime_48k_voices": value / 48000.0,
+                   **({"graph_kernel_form": "%d voice(s) per lane, %d quad(s) per trip (tuned online)" % graphs[0].tuning()[1:]} if graphs else {})},
+        "roofline": roof,
+        "ranks": ranks,
+    }
+    if args.workload == "cfg2":
+        # SURVEY 8(d) config 2: each op and the fused pair, on the ramp and on noise (no data-dependent branches: same rate)
+        from madronalib_amd.constants import Op
+        d_x, d_y = _keep
+        n_el = V * T * 64
+        d_noise = eng.to_device(np.random.default_rng(1).uniform(-np.pi, np.pi, n_el).astype(np.float32))
+        per_op = {}
+        reps = max(16, min(256, int(2 ** 34 / (8.0 * n_el))))
+        for label, op in (("sinApprox", Op.SIN_APPROX), ("expApprox", Op.EXP_APPROX), ("expApprox(sinApprox)", Op.EXP_APPROX_OF_SIN_APPROX)):
+            for data, src in (("ramp", d_x), ("noise", d_noise)):
+                for _ in range(8):
+                    eng.op_apply(op, src, None, None, d_y, n_el)
+                eng.timer_start()
+                for _ in range(reps):
+                    eng.op_apply(op, src, None, None, d_y, n_el)
+                per_op[f"{label} / {data}"] = n_el * reps / (eng.timer_stop_ms() * 1e-3)
+        out["config"]["per_op_voice_samples_per_s"] = per_op
+    baselines = {"cfg2": cpu_baseline_cfg2, "cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5}
+    if world == 1 and not args.no_cpu_baseline and args.workload in baselines:
+        try:
+            out["cpu_baseline"] = baselines[args.workload]()
+        except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {ex}"}
+    return out
+
+
+def launch_processes(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start one rank process per GPU ourselves (rank r on device r),
+    lined up through a fresh rendezvous directory; rank 0's JSON line is this process's output."""
+    import subprocess
+    import tempfile
+    rdv_dir = tempfile.mkdtemp(prefix="mlgpu_rdv_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MLGPU_RDV_DIR=rdv_dir)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    try:
+        import shutil
+        shutil.rmtree(rdv_dir, ignore_errors=True)
     except Exception:
         pass
-    return None
+    if any(rcs):
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+
+
+def launch_threads(args):
+    """One process, one host thread + engine + stream per device. ctypes releases the GIL inside every C-ABI
+    call, and a launch is an asynchronous enqueue, so the threads only contend for microseconds per launch."""
+    import threading
+    from madronalib_amd.rendezvous import ThreadRendezvous
+    group = ThreadRendezvous.group(args.gpus)
+    results, errors = [None] * args.gpus, []
+
+    def body(r):
+        try:
+            results[r] = run_rank(args, r, r, args.gpus, group[r])
+        except BaseException as ex:   # noqa: BLE001 - a dead rank must release the others
+            errors.append((r, ex))
+            group[r].abort()
+    threads = [threading.Thread(target=body, args=(r,), name=f"mlgpu-rank{r}") for r in range(args.gpus)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise SystemExit(f"bench.py: rank {errors[0][0]} failed: {errors[0][1]!r}")
+    print(json.dumps(results[0]), flush=True)
 
 
 def main():
@@ -421,113 +593,52 @@ def main():
     ap.add_argument("--voices", type=int, default=0, help="voices per GPU (default: the config's)")
     ap.add_argument("--vectors", type=int, default=0, help="DSPVectors per launch (default: the config's)")
     ap.add_argument("--launches", type=int, default=0, help="launches per step (default: the config's)")
+    ap.add_argument("--launcher", default="processes", choices=["processes", "threads"],
+                    help="how `--gpus N` starts its N ranks when no launcher exported WORLD_SIZE: one process per GPU (default) "
+                         "or one host thread per GPU inside this process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--print-case", action="store_true", help="print the key of this case in profiles/pmc_workloads.json and exit")
     args = ap.parse_args()
+    if args.print_case:
+        dV, dT, _ = WORKLOADS[args.workload]
+        print(workload_key(args.workload, args.voices or dV, args.vectors or dT))
+        return
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
+    from madronalib_amd import _lib, rendezvous
+    have = _lib.load().mlgpu_device_count()
+    if have <= 0:
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    import madronalib_amd as ml
-    dV, dT, dL = WORKLOADS[args.workload]
-    V = args.voices or dV
-    T = args.vectors or dT
-    L = args.launches or dL
-    total = V * world                 # weak scaling: per-GPU work fixed
-    lo, hi = partition(total, world, rank)
-    assert hi - lo == V
-
-    eng = ml.Engine(local_rank)
-    launch, alg_bytes, kernel_name, desc, _keep = setup_workload(eng, args.workload, V, T, lo, total)
-
-    def step():
-        for _ in range(L):
-            launch()
-
-    def barrier():
-        eng.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    # a graph that tunes itself over its first launches (mlgpu_graph_set_autotune) finishes that before the clock starts
-    graphs = [o for o in (_keep if isinstance(_keep, tuple) else (_keep,)) if hasattr(o, "tuning")]
-    for g in graphs:
-        for _ in range(16):
-            if g.tuning()[0]:
-                break
-            launch()
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    for _ in range(args.steps):
-        step()
-    kernel_ms = eng.timer_stop_ms() / (args.steps * L)   # HIP events on the engine's stream
-    eng.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    elapsed = max_over_ranks(elapsed, dist if world > 1 else None, "cuda")
-
-    if rank == 0:
-        units = float(total) * T * 64 * L * args.steps      # voice-samples over all ranks
-        value = units / elapsed
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        out = {
-            "metric": "voice-samples/sec (SawGen->SVF chain)" if args.workload == "cfg3" else f"voice-samples/sec ({args.workload})",
-            "value": value, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "voices_per_gpu": V, "total_voices": total, "vectors_per_launch": T,
-                       "launches_per_step": L, "vectors_per_step": T * L, "samples_per_vector": 64,
-                       "layout": "QUAD [S/4][V][4]", "parallelism": f"voices x{world} (no collective)",
-                       "realtime_48k_voices": value / 48000.0,
-                       **({"graph_kernel_form": "%d voice(s) per lane, %d quad(s) per trip (tuned online)" % graphs[0].tuning()[1:]} if graphs else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name),
-                         "kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
-        }
-        if args.workload == "cfg2":
-            # each op and the fused pair, on the ramp and on noise (no data-dependent branches: same rate)
-            from madronalib_amd.constants import Op
-            d_x, d_y = _keep
-            n_el = V * T * 64
-            d_noise = eng.to_device(np.random.default_rng(1).uniform(-np.pi, np.pi, n_el).astype(np.float32))
-            per_op = {}
-            for label, op in (("sinApprox", Op.SIN_APPROX), ("expApprox", Op.EXP_APPROX), ("expApprox(sinApprox)", Op.EXP_APPROX_OF_SIN_APPROX)):
-                for data, src in (("ramp", d_x), ("noise", d_noise)):
-                    for _ in range(8):
-                        eng.op_apply(op, src, None, None, d_y, n_el)
-                    eng.timer_start()
-                    for _ in range(256):
-                        eng.op_apply(op, src, None, None, d_y, n_el)
-                    per_op[f"{label} / {data}"] = n_el * 256 / (eng.timer_stop_ms() * 1e-3)
-            out["config"]["per_op_voice_samples_per_s"] = per_op
-        baselines = {"cfg2": cpu_baseline_cfg2, "cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5}
-        if world == 1 and not args.no_cpu_baseline and args.workload in baselines:
-            try:
-                out["cpu_baseline"] = baselines[args.workload]()
-            except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {ex}"}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if "WORLD_SIZE" in os.environ:
+        # a rank of a launched job: torch.distributed.run (the driver's form for N > 1) or our own process launcher
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        if local_rank >= have:
+            raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {have} GPU(s) are visible")
+        rdv = rendezvous.from_environment()
+        try:
+            out = run_rank(args, rank, local_rank, world, rdv)
+        except BaseException:
+            if hasattr(rdv, "abort"):
+                rdv.abort()
+            raise
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        rdv.close()
+        return
+    if args.gpus > have:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible: refusing to run fewer ranks than asked for")
+    if args.gpus == 1:
+        print(json.dumps(run_rank(args, 0, 0, 1, rendezvous.SoloRendezvous())), flush=True)
+    elif args.launcher == "threads":
+        launch_threads(args)
+    else:
+        launch_processes(args, sys.argv[1:])
 
 
 if __name__ == "__main__":

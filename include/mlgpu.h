@@ -240,6 +240,12 @@ int mlgpu_abi_version(void);
 int mlgpu_device_count(void);
 /* Device facts used by the bench (name, CU count, memory bytes). */
 int mlgpu_device_info(int device, char* name, size_t name_len, int* cu_count, uint64_t* mem_bytes);
+/* PCI bus id of a device ("0000:05:00.0"): what tells two ranks of a multi-GPU job that they really run on different
+ * GPUs (a device INDEX is relative to each process's HIP_VISIBLE_DEVICES). */
+int mlgpu_device_pci_bus_id(int device, char* buf, size_t buf_len);
+/* Block until everything enqueued on `device` by this process, on any stream, is done (hipDeviceSynchronize): the
+ * device-wide fence a benchmark puts on both sides of its timed region. */
+int mlgpu_device_synchronize(int device);
 
 /* device memory owned by the caller, allocated on the engine's device */
 int mlgpu_alloc(mlgpu_engine* e, size_t bytes, void** d_out);

@@ -18,11 +18,18 @@
 // C-ABI become ml::gpu::Error exceptions (the reference has no error channel).
 #pragma once
 
+#include <algorithm>
 #include <array>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -63,6 +70,117 @@ class Engine
     if (st != MLGPU_OK) throw Error(st, std::string(mlgpu_status_string(st)) + ": " + mlgpu_last_error(e_));
   }
   void sync() const { check(mlgpu_engine_sync(e_)); }
+};
+
+// The GPUs of one node as one voice bank host: voices share nothing (every Bank row / Synth voice owns its
+// state, MLDSPFunctional.h:321-349, source/app/MLSynth.h:49-57), so device g simply owns the contiguous voice range
+// partition(total, size(), g) with its own engine, stream and host thread. There is no collective on the path; time is
+// never split across devices (phases and filter memories are recurrences). The C-ABI is per-engine and thread-compatible
+// (one caller thread per engine, the reference's single audio thread), which is exactly what the worker threads are.
+class DeviceGroup
+{
+  struct Worker
+  {
+    std::unique_ptr<Engine> engine;
+    std::thread thread;
+    std::function<void()> job;
+    std::exception_ptr error;
+    bool busy{false}, quit{false};
+    std::mutex m;
+    std::condition_variable cv;
+  };
+  std::vector<std::unique_ptr<Worker>> workers_;
+
+  static void loop(Worker* w)
+  {
+    std::unique_lock<std::mutex> lock(w->m);
+    for (;;)
+    {
+      w->cv.wait(lock, [w] { return w->busy || w->quit; });
+      if (w->quit) return;
+      lock.unlock();
+      try
+      {
+        w->job();
+      }
+      catch (...)
+      {
+        w->error = std::current_exception();
+      }
+      lock.lock();
+      w->busy = false;
+      w->cv.notify_all();
+    }
+  }
+
+ public:
+  // engines on devices 0 .. nDevices-1; fewer visible devices than asked for is an error, never a smaller group
+  explicit DeviceGroup(int nDevices)
+  {
+    const int have = mlgpu_device_count();
+    if (nDevices < 1 || nDevices > have)
+      throw Error(MLGPU_ERR_NO_DEVICE, "DeviceGroup: " + std::to_string(nDevices) + " device(s) asked for, " + std::to_string(have) + " visible");
+    for (int d = 0; d < nDevices; ++d)
+    {
+      workers_.emplace_back(new Worker());
+      workers_.back()->engine.reset(new Engine(d));
+    }
+    for (auto& w : workers_) w->thread = std::thread(loop, w.get());
+  }
+  DeviceGroup(const DeviceGroup&) = delete;
+  DeviceGroup& operator=(const DeviceGroup&) = delete;
+  ~DeviceGroup()
+  {
+    for (auto& w : workers_)
+    {
+      {
+        std::lock_guard<std::mutex> lock(w->m);
+        w->quit = true;
+      }
+      w->cv.notify_all();
+      if (w->thread.joinable()) w->thread.join();
+    }
+  }
+  int size() const { return (int)workers_.size(); }
+  Engine& engine(int g) { return *workers_.at((size_t)g)->engine; }
+
+  // contiguous voice range [lo, hi) of device `rank`; sizes differ by at most one voice
+  static std::pair<size_t, size_t> partition(size_t totalVoices, int world, int rank)
+  {
+    const size_t per = totalVoices / (size_t)world, rem = totalVoices % (size_t)world;
+    const size_t lo = (size_t)rank * per + std::min<size_t>((size_t)rank, rem);
+    return {lo, lo + per + ((size_t)rank < rem ? 1 : 0)};
+  }
+
+  // fn(rank, engine, lo, hi) on every device's own host thread, all devices at once; returns when all are back
+  // (their launches may still be running: call sync()). The first exception thrown by any fn is rethrown here.
+  template <class F>
+  void forEach(size_t totalVoices, F fn)
+  {
+    const int n = size();
+    for (int g = 0; g < n; ++g)
+    {
+      Worker* w = workers_[(size_t)g].get();
+      const auto span = partition(totalVoices, n, g);
+      std::lock_guard<std::mutex> lock(w->m);
+      w->error = nullptr;
+      w->job = [fn, g, w, span]() mutable { fn(g, *w->engine, span.first, span.second); };
+      w->busy = true;
+      w->cv.notify_all();
+    }
+    std::exception_ptr first;
+    for (auto& w : workers_)
+    {
+      std::unique_lock<std::mutex> lock(w->m);
+      w->cv.wait(lock, [&w] { return !w->busy; });
+      if (w->error && !first) first = w->error;
+    }
+    if (first) std::rethrow_exception(first);
+  }
+  void sync()
+  {
+    for (auto& w : workers_) w->engine->sync();
+  }
 };
 
 // A V-voice, T-vector float signal in HBM.

@@ -122,7 +122,13 @@ class Engine:
         cu = ctypes.c_int()
         mem = ctypes.c_uint64()
         self._check(self.L.mlgpu_device_info(self.device, name, 256, ctypes.byref(cu), ctypes.byref(mem)))
-        return dict(name=name.value.decode(), cu_count=cu.value, mem_bytes=mem.value)
+        pci = ctypes.create_string_buffer(64)
+        self._check(self.L.mlgpu_device_pci_bus_id(self.device, pci, 64))
+        return dict(name=name.value.decode(), cu_count=cu.value, mem_bytes=mem.value, pci_bus_id=pci.value.decode())
+
+    def device_sync(self):
+        """hipDeviceSynchronize on this engine's device (all streams)."""
+        self._check(self.L.mlgpu_device_synchronize(self.device))
 
     # ---- memory ----
     def alloc(self, nbytes):

@@ -43,6 +43,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    alt = os.environ.get("MLGPU_LIB")   # an alternative build of the same ABI (A/B measurements of a kernel variant)
+    if alt:
+        _lib = ctypes.CDLL(alt)
+        _declare(_lib)
+        return _lib
     if needs_build():
         if os.path.exists("/opt/rocm/bin/hipcc") or os.environ.get("HIPCC"):
             build()
@@ -68,6 +73,8 @@ def _declare(L):
     sig("mlgpu_status_string", c.c_char_p, [i])
     sig("mlgpu_device_count", i, [])
     sig("mlgpu_device_info", i, [i, c.c_char_p, sz, c.POINTER(i), c.POINTER(c.c_uint64)])
+    sig("mlgpu_device_pci_bus_id", i, [i, c.c_char_p, sz])
+    sig("mlgpu_device_synchronize", i, [i])
     sig("mlgpu_engine_create", i, [i, pp])
     sig("mlgpu_engine_create_on_stream", i, [i, vp, pp])
     sig("mlgpu_engine_destroy", i, [vp])

@@ -136,6 +136,20 @@ extern "C"
     return MLGPU_OK;
   }
 
+  int mlgpu_device_pci_bus_id(int device, char* buf, size_t bufLen)
+  {
+    if (!buf || bufLen < 13) return MLGPU_ERR_INVALID;
+    if (device < 0 || device >= mlgpu_device_count()) return MLGPU_ERR_NO_DEVICE;
+    return hipDeviceGetPCIBusId(buf, (int)bufLen, device) == hipSuccess ? MLGPU_OK : MLGPU_ERR_HIP;
+  }
+
+  int mlgpu_device_synchronize(int device)
+  {
+    if (device < 0 || device >= mlgpu_device_count()) return MLGPU_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MLGPU_ERR_HIP;
+    return hipDeviceSynchronize() == hipSuccess ? MLGPU_OK : MLGPU_ERR_HIP;
+  }
+
   int mlgpu_engine_create(int device, mlgpu_engine** out) { return createEngine(device, nullptr, true, out); }
   int mlgpu_engine_create_on_stream(int device, void* hipStream, mlgpu_engine** out)
   {

@@ -108,25 +108,51 @@ __global__ __launch_bounds__(kChainBlock) void chain_kernel(const ChainArgs a)
 // launch boundary is invisible (tests: split launches == one launch). Boundary ticks (2N-2 of
 // 64*T) use a slow masked form; the steady loop handles 4 output quads per trip and keeps the next
 // trip's four 16-byte input loads in flight for a whole trip (~1300 VALU instructions).
+//
+// PACKED FP32. The N stage updates of a tick are the same ten operations on N independent operand sets, which is what
+// gfx950's packed FP32 instructions are for: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 produce two IEEE f32 results per
+// lane (each component rounded exactly like the scalar instruction: same bits) and issue at the scalar instructions' rate
+// (tools/valubench.hip). Stages are paired (p, p + N/2): the pair's inputs are then the previous pair's outputs, one
+// 64-bit register pair, except pair 0 = {x, r[N/2 - 1]}. A tick is 10 packed instructions per stage PAIR instead of 10
+// scalar ones per stage. MLGPU_CASCADE_PACKED=0 keeps the scalar form (A/B measurements, profiles/).
+#ifndef MLGPU_CASCADE_PACKED
+#define MLGPU_CASCADE_PACKED 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int KIND, int N>
 struct SvfCascade
 {
+  static_assert(N % 2 == 0, "stages are evaluated in pairs");
   static constexpr int NCK = (KIND == MLGPU_PROC_HIPASS) ? 4 : 3;
   static constexpr int NC = NCK * N, NS = 2 * N;
-  float g0[N], g1[N], g2[N], kk[N], ic1[N], ic2[N], r[N];
+  static constexpr int H = N / 2;
+  // component .x of element p belongs to stage p, .y to stage p + H
+  f32x2 g0[H], g1[H], g2[H], kk[H], ic1[H], ic2[H], r[H];
+
+  template <class ARR>
+  static MLD void put(ARR& arr, int s, float value)
+  {
+    if (s < H)
+      arr[s].x = value;
+    else
+      arr[s - H].y = value;
+  }
+  template <class ARR>
+  static MLD float get(const ARR& arr, int s) { return s < H ? arr[s].x : arr[s - H].y; }
 
   MLD void load(const VoiceMem& m)
   {
 #pragma unroll
     for (int s = 0; s < N; ++s)
     {
-      g0[s] = m.c(NCK * s);
-      g1[s] = m.c(NCK * s + 1);
-      g2[s] = m.c(NCK * s + 2);
-      kk[s] = (KIND == MLGPU_PROC_HIPASS) ? m.c(NCK * s + 3) : 0.f;
-      ic1[s] = u2f(m.s(2 * s));
-      ic2[s] = u2f(m.s(2 * s + 1));
-      r[s] = 0.f;
+      put(g0, s, m.c(NCK * s));
+      put(g1, s, m.c(NCK * s + 1));
+      put(g2, s, m.c(NCK * s + 2));
+      put(kk, s, (KIND == MLGPU_PROC_HIPASS) ? m.c(NCK * s + 3) : 0.f);
+      put(ic1, s, u2f(m.s(2 * s)));
+      put(ic2, s, u2f(m.s(2 * s + 1)));
+      put(r, s, 0.f);
     }
   }
   MLD void store(const VoiceMem& m) const
@@ -134,27 +160,80 @@ struct SvfCascade
 #pragma unroll
     for (int s = 0; s < N; ++s)
     {
-      m.set(2 * s, f2u(ic1[s]));
-      m.set(2 * s + 1, f2u(ic2[s]));
+      m.set(2 * s, f2u(get(ic1, s)));
+      m.set(2 * s + 1, f2u(get(ic2, s)));
     }
   }
   // all stages active; returns stage N-1's output, i.e. the chain output for sample (tick - (N-1))
+#if MLGPU_CASCADE_PACKED
+  MLD float tick(float x)
+  {
+    f32x2 in[H], t0[H], a[H], b[H], c[H], d[H], t1[H], t2[H], v1[H], v2[H];
+    const f32x2 two = {2.0f, 2.0f};
+    in[0] = f32x2{x, r[H - 1].x};
+#pragma unroll
+    for (int p = 1; p < H; ++p) in[p] = r[p - 1];
+#pragma unroll
+    for (int p = 0; p < H; ++p) t0[p] = in[p] - ic2[p];
+#pragma unroll
+    for (int p = 0; p < H; ++p) b[p] = g1[p] * ic1[p];
+#pragma unroll
+    for (int p = 0; p < H; ++p) d[p] = g0[p] * ic1[p];
+#pragma unroll
+    for (int p = 0; p < H; ++p) a[p] = g0[p] * t0[p];
+#pragma unroll
+    for (int p = 0; p < H; ++p) c[p] = g2[p] * t0[p];
+#pragma unroll
+    for (int p = 0; p < H; ++p) t1[p] = a[p] + b[p];
+#pragma unroll
+    for (int p = 0; p < H; ++p) t2[p] = c[p] + d[p];
+    if (KIND == MLGPU_PROC_LOPASS)
+    {
+#pragma unroll
+      for (int p = 0; p < H; ++p) r[p] = t2[p] + ic2[p];
+    }
+    else if (KIND == MLGPU_PROC_BANDPASS)
+    {
+#pragma unroll
+      for (int p = 0; p < H; ++p) r[p] = t1[p] + ic1[p];
+    }
+    else
+    {
+#pragma unroll
+      for (int p = 0; p < H; ++p) v1[p] = t1[p] + ic1[p];
+#pragma unroll
+      for (int p = 0; p < H; ++p) v2[p] = t2[p] + ic2[p];
+#pragma unroll
+      for (int p = 0; p < H; ++p) v1[p] = kk[p] * v1[p];
+#pragma unroll
+      for (int p = 0; p < H; ++p) v1[p] = in[p] - v1[p];
+#pragma unroll
+      for (int p = 0; p < H; ++p) r[p] = v1[p] - v2[p];
+    }
+    // PARITY: fma(2, t, ic) == ic + 2*t (2*t is exact short of overflow; see SvfCore)
+#pragma unroll
+    for (int p = 0; p < H; ++p) ic1[p] = __builtin_elementwise_fma(two, t1[p], ic1[p]);
+#pragma unroll
+    for (int p = 0; p < H; ++p) ic2[p] = __builtin_elementwise_fma(two, t2[p], ic2[p]);
+    return r[H - 1].y;
+  }
+#else
   MLD float tick(float x)
   {
     float in[N], t0[N], a[N], b[N], c[N], d[N], t1[N], t2[N], v1[N], v2[N];
     in[0] = x;
 #pragma unroll
-    for (int s = 1; s < N; ++s) in[s] = r[s - 1];
+    for (int s = 1; s < N; ++s) in[s] = get(r, s - 1);
 #pragma unroll
-    for (int s = 0; s < N; ++s) t0[s] = in[s] - ic2[s];
+    for (int s = 0; s < N; ++s) t0[s] = in[s] - get(ic2, s);
 #pragma unroll
-    for (int s = 0; s < N; ++s) b[s] = g1[s] * ic1[s];
+    for (int s = 0; s < N; ++s) b[s] = get(g1, s) * get(ic1, s);
 #pragma unroll
-    for (int s = 0; s < N; ++s) d[s] = g0[s] * ic1[s];
+    for (int s = 0; s < N; ++s) d[s] = get(g0, s) * get(ic1, s);
 #pragma unroll
-    for (int s = 0; s < N; ++s) a[s] = g0[s] * t0[s];
+    for (int s = 0; s < N; ++s) a[s] = get(g0, s) * t0[s];
 #pragma unroll
-    for (int s = 0; s < N; ++s) c[s] = g2[s] * t0[s];
+    for (int s = 0; s < N; ++s) c[s] = get(g2, s) * t0[s];
 #pragma unroll
     for (int s = 0; s < N; ++s) t1[s] = a[s] + b[s];
 #pragma unroll
@@ -162,58 +241,60 @@ struct SvfCascade
     if (KIND == MLGPU_PROC_LOPASS)
     {
 #pragma unroll
-      for (int s = 0; s < N; ++s) r[s] = t2[s] + ic2[s];
+      for (int s = 0; s < N; ++s) put(r, s, t2[s] + get(ic2, s));
     }
     else if (KIND == MLGPU_PROC_BANDPASS)
     {
 #pragma unroll
-      for (int s = 0; s < N; ++s) r[s] = t1[s] + ic1[s];
+      for (int s = 0; s < N; ++s) put(r, s, t1[s] + get(ic1, s));
     }
     else
     {
 #pragma unroll
-      for (int s = 0; s < N; ++s) v1[s] = t1[s] + ic1[s];
+      for (int s = 0; s < N; ++s) v1[s] = t1[s] + get(ic1, s);
 #pragma unroll
-      for (int s = 0; s < N; ++s) v2[s] = t2[s] + ic2[s];
+      for (int s = 0; s < N; ++s) v2[s] = t2[s] + get(ic2, s);
 #pragma unroll
-      for (int s = 0; s < N; ++s) v1[s] = kk[s] * v1[s];
+      for (int s = 0; s < N; ++s) v1[s] = get(kk, s) * v1[s];
 #pragma unroll
       for (int s = 0; s < N; ++s) v1[s] = in[s] - v1[s];
 #pragma unroll
-      for (int s = 0; s < N; ++s) r[s] = v1[s] - v2[s];
+      for (int s = 0; s < N; ++s) put(r, s, v1[s] - v2[s]);
     }
 #pragma unroll
-    for (int s = 0; s < N; ++s) ic1[s] = __builtin_fmaf(2.0f, t1[s], ic1[s]);
+    for (int s = 0; s < N; ++s) put(ic1, s, __builtin_fmaf(2.0f, t1[s], get(ic1, s)));
 #pragma unroll
-    for (int s = 0; s < N; ++s) ic2[s] = __builtin_fmaf(2.0f, t2[s], ic2[s]);
-    return r[N - 1];
+    for (int s = 0; s < N; ++s) put(ic2, s, __builtin_fmaf(2.0f, t2[s], get(ic2, s)));
+    return get(r, N - 1);
   }
+#endif
   // boundary tick: only stages sLo..sHi (wave-uniform) are active
   MLD float tick_masked(float x, int sLo, int sHi)
   {
     float in[N];
     in[0] = x;
 #pragma unroll
-    for (int s = 1; s < N; ++s) in[s] = r[s - 1];
+    for (int s = 1; s < N; ++s) in[s] = get(r, s - 1);
 #pragma unroll
     for (int s = 0; s < N; ++s)
     {
       if (s >= sLo && s <= sHi)
       {
-        const float t0 = in[s] - ic2[s];
-        const float t1 = g0[s] * t0 + g1[s] * ic1[s];
-        const float t2 = g2[s] * t0 + g0[s] * ic1[s];
+        const float i1 = get(ic1, s), i2 = get(ic2, s);
+        const float t0 = in[s] - i2;
+        const float t1 = get(g0, s) * t0 + get(g1, s) * i1;
+        const float t2 = get(g2, s) * t0 + get(g0, s) * i1;
         if (KIND == MLGPU_PROC_LOPASS)
-          r[s] = t2 + ic2[s];
+          put(r, s, t2 + i2);
         else if (KIND == MLGPU_PROC_BANDPASS)
-          r[s] = t1 + ic1[s];
+          put(r, s, t1 + i1);
         else
-          r[s] = in[s] - kk[s] * (t1 + ic1[s]) - (t2 + ic2[s]);
-        ic1[s] = __builtin_fmaf(2.0f, t1, ic1[s]);
-        ic2[s] = __builtin_fmaf(2.0f, t2, ic2[s]);
+          put(r, s, in[s] - get(kk, s) * (t1 + i1) - (t2 + i2));
+        put(ic1, s, __builtin_fmaf(2.0f, t1, i1));
+        put(ic2, s, __builtin_fmaf(2.0f, t2, i2));
       }
     }
-    return r[N - 1];
+    return get(r, N - 1);
   }
 };
 
@@ -222,6 +303,8 @@ template <class HEAD, int KIND, int N, bool HAS_SIGNAL>
 __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
 {
   static_assert(!HEAD::kHasImpulse, "ImpulseGen heads are not supported by the cascade kernel");
+  // with B == 0 the steady loop's last prefetch (inQuad(q + A + 5 + k)) would read one quad past the input
+  static_assert((N - 1) % 4 != 0, "cascade lengths with (N - 1) % 4 == 0 need a bounded prefetch");
   size_t blk = blockIdx.x;
   const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
   if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);  // XCD-aware, see chain_kernel

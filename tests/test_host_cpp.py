@@ -7,6 +7,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+MULTI = os.path.join(ROOT, "tests", "cpp", "multi_engine_test")
 
 
 def _build():
@@ -20,6 +21,18 @@ def test_host_mirror_compiles():
         pytest.skip("no g++")
     _build()
     assert os.path.exists(EXE)
+    assert os.path.exists(MULTI)
+
+
+def test_multi_engine_program_fails_loudly_without_a_gpu():
+    """No CPU fallback in the multi-device host either: without a GPU the program says so and exits non-zero."""
+    if not os.path.exists(MULTI):
+        _build()
+    from madronalib_amd import _lib
+    if _lib.load().mlgpu_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([MULTI], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no GPU" in r.stdout
 
 
 @pytest.mark.gpu
@@ -27,5 +40,16 @@ def test_host_mirror_program_passes():
     if not os.path.exists(EXE):
         _build()
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "All tests passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_multi_engine_program_passes():
+    """ml::gpu::DeviceGroup (one host thread + engine + stream per device) through the C-ABI: union of the shards ==
+    unsharded, outputs and state; two devices when the box has them, else one device and two engines on two threads."""
+    if not os.path.exists(MULTI):
+        _build()
+    r = subprocess.run([MULTI], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "All tests passed" in r.stdout

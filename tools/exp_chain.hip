@@ -226,6 +226,86 @@ __global__ __launch_bounds__(BLK) void k_v2(Args a)
   }
 }
 
+// variant 3: two voices per lane as PACKED FP32 pairs: every f32 add/mul/fma is one v_pk_* instruction for both voices
+// (same issue cost as the scalar instruction on gfx950, tools/valubench.hip); compares, selects, the integer phase and the
+// conversion stay per voice.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <int BLK, int PAIRDIST>
+__global__ __launch_bounds__(BLK) void k_v3(Args a)
+{
+  const size_t g = xcd_block(blockIdx.x, gridDim.x) * BLK + threadIdx.x;
+  size_t va, vb;
+  if (PAIRDIST == 64) { va = (g >> 6) * 128 + (g & 63); vb = va + 64; }
+  else { va = (g / BLK) * (2 * BLK) + (g % BLK); vb = va + BLK; }
+  if (vb >= a.V) return;
+  u32x2 om, istep;
+  f32x2 dt, omdt, r1, ndt, g0, g1, g2, gain, ic1, ic2;
+  auto ld = [&](const float* p) { return f32x2{p[va], p[vb]}; };
+  g0 = ld(a.coeffs); g1 = ld(a.coeffs + a.V); g2 = ld(a.coeffs + 2 * a.V); gain = ld(a.coeffs + 3 * a.V);
+  om = u32x2{a.state[va], a.state[vb]};
+  ic1 = f32x2{u2f(a.state[a.V + va]), u2f(a.state[a.V + vb])};
+  ic2 = f32x2{u2f(a.state[2 * a.V + va]), u2f(a.state[2 * a.V + vb])};
+  dt = ld(a.freq);
+  istep = u32x2{(uint32_t)sse_cvt(dt.x * kStepsPerCycle), (uint32_t)sse_cvt(dt.y * kStepsPerCycle)};
+  omdt = 1.0f - dt;
+  {
+    const f32x2 r0 = {__builtin_amdgcn_rcpf(dt.x), __builtin_amdgcn_rcpf(dt.y)};
+    const f32x2 e = pkfma(-dt, r0, f32x2{1.0f, 1.0f});
+    r1 = pkfma(e, r0, r0);
+  }
+  ndt = -dt;
+  const f32x2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f}, zero = {0.f, 0.f};
+  f32x4 *pa = a.out + va, *pb = a.out + vb;
+  for (size_t r = 0; r < a.T * 16; ++r)
+  {
+    f32x4 ya, yb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      om += istep;
+      f32x2 p = __builtin_convertvector(__builtin_convertvector(om >> 1, i32x2), f32x2);
+      p = p * 4.656612873077392578125e-10f;
+      const i32x2 lo = p < dt, hi = p > omdt;
+      f32x2 num = p - one;
+      num = lo ? p : num;
+      f32x2 q = num * r1;
+      f32x2 rem = pkfma(ndt, q, num);
+      q = pkfma(rem, r1, q);
+      rem = pkfma(ndt, q, num);
+      q = pkfma(rem, r1, q);
+      const f32x2 qq = q * q;
+      f32x2 clo = pkfma(two, q, -qq);
+      f32x2 chi = qq + q;
+      clo = clo - one;
+      chi = chi + q;
+      const f32x2 saw = pkfma(p, two, -one);
+      chi = chi + one;
+      f32x2 c = lo ? clo : chi;
+      c = (lo | hi) ? c : zero;
+      const f32x2 x = saw - c;
+      const f32x2 t0 = x - ic2;
+      const f32x2 m1 = g1 * ic1, m2 = g0 * ic1;
+      f32x2 t1 = g0 * t0, t2 = g2 * t0;
+      t1 = t1 + m1;
+      t2 = t2 + m2;
+      const f32x2 o = t1 + ic1;
+      ic1 = pkfma(two, t1, ic1);
+      ic2 = pkfma(two, t2, ic2);
+      const f32x2 y = o * gain;
+      ya[k] = y.x;
+      yb[k] = y.y;
+    }
+    __builtin_nontemporal_store(ya, pa + r * a.V);
+    __builtin_nontemporal_store(yb, pb + r * a.V);
+  }
+  a.state[va] = om.x; a.state[vb] = om.y;
+  a.state[a.V + va] = f2u(ic1.x); a.state[a.V + vb] = f2u(ic1.y);
+  a.state[2 * a.V + va] = f2u(ic2.x); a.state[2 * a.V + vb] = f2u(ic2.y);
+}
+
 template <class F>
 float timeit(F f, int reps = 8)
 {
@@ -268,6 +348,11 @@ int main(int argc, char** argv)
   add("v1  2v/lane blk128", [&](Args a) { hipLaunchKernelGGL(k_v1<128>, dim3(V / 256), dim3(128), 0, 0, a); });
   add("v1  2v/lane blk256", [&](Args a) { hipLaunchKernelGGL(k_v1<256>, dim3(V / 512), dim3(256), 0, 0, a); });
   add("v2  N=2 explicit blk64", [&](Args a) { hipLaunchKernelGGL((k_v2<64, 2>), dim3(V / 128), dim3(64), 0, 0, a); });
+  add("v3  2v/lane packed blk64 d64", [&](Args a) { hipLaunchKernelGGL((k_v3<64, 64>), dim3(V / 128), dim3(64), 0, 0, a); });
+  add("v3  2v/lane packed blk128 d64", [&](Args a) { hipLaunchKernelGGL((k_v3<128, 64>), dim3(V / 256), dim3(128), 0, 0, a); });
+  add("v3  2v/lane packed blk256 d64", [&](Args a) { hipLaunchKernelGGL((k_v3<256, 64>), dim3(V / 512), dim3(256), 0, 0, a); });
+  add("v3  2v/lane packed blk256 d256", [&](Args a) { hipLaunchKernelGGL((k_v3<256, 256>), dim3(V / 512), dim3(256), 0, 0, a); });
+  add("v3  2v/lane packed blk128 d128", [&](Args a) { hipLaunchKernelGGL((k_v3<128, 128>), dim3(V / 256), dim3(128), 0, 0, a); });
   // correctness of every variant against variant 0, from cleared state
   for (size_t i = 0; i < vars.size(); ++i)
   {

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Build profiles/pmc_workloads.json: the PMC facts bench.py attaches to a bench line, keyed by WORKLOAD CASE
+(bench.workload_key: workload, variant switches, voices x vectors) — not by kernel name: `mlgpu_graph_kernel` is the name
+of every fused graph, and a strings launch moves 4x the bytes of a config-5 launch.
+
+    tools/pmc_workloads.py <out.json> <case>@<prefix> [...]
+
+<prefix>_traffic.json (tools/pmc_summary.py traffic) and <prefix>_pmc.txt (tools/pmc_summary.py pmc) are the per-run
+summaries tools/gpu_profile_all.sh writes; <case> is e.g. cfg5:262144x16. The dominant kernel of a case is the one with
+the most HBM bytes per launch among kernels launched at least 8 times."""
+import json
+import re
+import sys
+
+
+def parse_pmc_txt(path):
+    out, cur = {}, None
+    try:
+        for line in open(path):
+            m = re.match(r"== (.*?)\s+\((\d+) dispatches, mean duration ([\d.]+) us", line)
+            if m:
+                cur = out.setdefault(m.group(1), {"dispatches": int(m.group(2)), "mean_us_under_pmc": float(m.group(3))})
+                continue
+            m = re.match(r"\s+(\w+)\s+mean\s+([\d.]+)", line)
+            if m and cur is not None:
+                cur[m.group(1)] = float(m.group(2))
+    except OSError:
+        pass
+    return out
+
+
+def main():
+    outp = sys.argv[1]
+    res = {"source": "rocprofv3 --pmc passes (SQ set, FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of `bench.py --workload <w> --steps 2 --warmup 1`, "
+                     "tools/gpu_profile_all.sh; bytes corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950)",
+           "workloads": {}}
+    try:
+        res["workloads"] = json.load(open(outp)).get("workloads", {})
+    except Exception:
+        pass
+    for arg in sys.argv[2:]:
+        case, prefix = arg.rsplit("@", 1)
+        try:
+            traffic = json.load(open(prefix + "_traffic.json")).get("kernels", {})
+        except OSError:
+            print("skip", case, "(no traffic file)")
+            continue
+        cands = {k: v for k, v in traffic.items() if v["launches"] >= 8 and "fill" not in k}
+        if not cands:
+            continue
+        kernel = max(cands, key=lambda k: cands[k]["hbm_bytes_per_launch"])
+        rec = {"kernel": kernel, "hbm_bytes_per_launch": cands[kernel]["hbm_bytes_per_launch"],
+               "fetch_bytes_per_launch_corrected": cands[kernel]["fetch_bytes_per_launch_corrected"],
+               "write_bytes_per_launch": cands[kernel]["write_bytes_per_launch"], "files": prefix.split("/")[-1] + "_{traffic.json,pmc.txt}"}
+        pmc = parse_pmc_txt(prefix + "_pmc.txt")
+        for k, v in pmc.items():
+            if k == kernel or k in kernel or kernel in k:
+                if "SQ_INSTS_VALU" in v:
+                    rec["valu_wave_insts_per_launch"] = v["SQ_INSTS_VALU"]
+                for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
+                    if c in v:
+                        rec[c] = v[c]
+                break
+        res["workloads"][case] = rec
+        print(case, kernel[:60], f"{rec['hbm_bytes_per_launch'] / 1e9:.3f} GB", rec.get("valu_wave_insts_per_launch"))
+    json.dump(res, open(outp, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
