@@ -475,7 +475,7 @@ def run_rank(args, rank, local_rank, world, rdv):
     if rank != 0:
         return None
     buses = [r["pci_bus_id"] for r in ranks]
-    if len(set(buses)) != world:
+    if len(set(buses)) != world and not args.oversubscribe:
         raise SystemExit(f"bench.py: {world} ranks but only {len(set(buses))} distinct GPUs ({buses}): every rank must own its own device")
 
     units = float(total) * T * 64 * L * args.steps      # voice-samples over all ranks
@@ -509,6 +509,8 @@ def run_rank(args, rank, local_rank, world, rdv):
         "roofline": roof,
         "ranks": ranks,
     }
+    if args.oversubscribe:
+        out["oversubscribed"] = f"{world} ranks on {len(set(buses))} GPU(s): launch-path test, not a scaling measurement"
     if args.workload == "cfg2":
         # each op and the fused pair, on the ramp and on noise (no data-dependent branches: same rate)
         from madronalib_amd.constants import Op
@@ -560,7 +562,7 @@ def launch_processes(args, argv):
     sys.stdout.flush()
 
 
-def launch_threads(args):
+def launch_threads(args, have):
     """One process, one host thread + engine + stream per device. ctypes releases the GIL inside every C-ABI
     call, and a launch is an asynchronous enqueue, so the threads only contend for microseconds per launch."""
     import threading
@@ -570,7 +572,7 @@ def launch_threads(args):
 
     def body(r):
         try:
-            results[r] = run_rank(args, r, r, args.gpus, group[r])
+            results[r] = run_rank(args, r, r % have, args.gpus, group[r])
         except BaseException as ex:   # noqa: BLE001 - a dead rank must release the others
             errors.append((r, ex))
             group[r].abort()
@@ -596,6 +598,9 @@ def main():
     ap.add_argument("--launcher", default="processes", choices=["processes", "threads"],
                     help="how `--gpus N` starts its N ranks when no launcher exported WORLD_SIZE: one process per GPU (default) "
                          "or one host thread per GPU inside this process")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY: let ranks share devices (rank r on device r mod visible) so the N>1 launch paths can be exercised on "
+                         "a box with fewer GPUs; the line says so and is not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--print-case", action="store_true", help="print the key of this case in profiles/pmc_workloads.json and exit")
     args = ap.parse_args()
@@ -618,6 +623,8 @@ def main():
         local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
         if world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        if args.oversubscribe:
+            local_rank %= have
         if local_rank >= have:
             raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {have} GPU(s) are visible")
         rdv = rendezvous.from_environment()
@@ -631,12 +638,12 @@ def main():
             print(json.dumps(out), flush=True)
         rdv.close()
         return
-    if args.gpus > have:
+    if args.gpus > have and not args.oversubscribe:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible: refusing to run fewer ranks than asked for")
     if args.gpus == 1:
         print(json.dumps(run_rank(args, 0, 0, 1, rendezvous.SoloRendezvous())), flush=True)
     elif args.launcher == "threads":
-        launch_threads(args)
+        launch_threads(args, have)
     else:
         launch_processes(args, sys.argv[1:])
 

@@ -229,6 +229,15 @@ int mlgpu_engine_create_on_stream(int device, void* hip_stream, mlgpu_engine** o
 int mlgpu_engine_destroy(mlgpu_engine* e);
 /* Block until all enqueued work is done. */
 int mlgpu_engine_sync(mlgpu_engine* e);
+/* Floating-point mode of every kernel this engine launches from now on (stream-ordered with the launches).
+ * Reference: ml::UsingFlushDenormalsToZero (source/DSP/MLDSPUtils.h:51-96) sets MXCSR FZ | DAZ for the scope of a
+ * process function: denormal operands read as zero, denormal results are written as zero (signs kept). on != 0 gives the
+ * kernels the same rule (gfx950 MODE.fp_denorm, set at kernel entry; one code object serves both modes); 0 (the default,
+ * like the reference's default MXCSR) honours denormals. Values that are only moved, selected or bit-manipulated pass
+ * through unchanged in both modes, on both machines. Results are bit-identical to the reference run under the same mode
+ * (tests/test_gpu_denormals.py). Not allowed while a launch sequence is being recorded. */
+int mlgpu_engine_set_flush_denormals(mlgpu_engine* e, int on);
+int mlgpu_engine_get_flush_denormals(mlgpu_engine* e);
 /* The hipStream_t work is enqueued on (for HIP-event timing by the caller). */
 void* mlgpu_engine_stream(mlgpu_engine* e);
 int mlgpu_engine_device(mlgpu_engine* e);

@@ -130,6 +130,7 @@ struct Capture
   // Two capture passes ("epochs"): a DSPVector that still holds a node of the PREVIOUS pass when it is used is a value
   // the user code kept from one process call to the next (Allpass::vy1, a state struct's own feedback members, ...).
   // It becomes a feedback node; its source is the node with the same creation ordinal in the current pass.
+  bool flushDenormals{false};  // the captured code constructed an ml::UsingFlushDenormalsToZero
   uint32_t epoch{1};
   int nextOrd{0};
   std::vector<int> nodeOfOrd;           // this pass: ordinal -> node
@@ -193,6 +194,35 @@ struct Capture
   void deferState(int node, int idx, uint32_t bits) { deferred.push_back(Deferred{node, 2, idx, bits}); }
 };
 
+}  // namespace gpu
+
+// UsingFlushDenormalsToZero (MLDSPUtils.h:51-96): in the reference, MXCSR FZ | DAZ for the lifetime of the object -
+// in practice the first statement of a process function (examples/audio-and-midi/fdtd.cpp:161). Captured code that
+// constructs one makes its whole VoiceProgram run in the engine's flush mode (mlgpu_engine_set_flush_denormals around
+// every launch of that program); the host thread's own MXCSR is set too, as in the reference, so host-side float
+// arithmetic of the process function sees the same mode on both builds.
+struct UsingFlushDenormalsToZero
+{
+#if defined(__SSE__)
+  unsigned MXCRState;
+  UsingFlushDenormalsToZero() : MXCRState(__builtin_ia32_stmxcsr())
+  {
+    __builtin_ia32_ldmxcsr(MXCRState | 0x8040u);
+    if (gpu::Capture::current()) gpu::Capture::current()->flushDenormals = true;
+  }
+  ~UsingFlushDenormalsToZero() { __builtin_ia32_ldmxcsr(MXCRState); }
+#else
+  UsingFlushDenormalsToZero()
+  {
+    if (gpu::Capture::current()) gpu::Capture::current()->flushDenormals = true;
+  }
+#endif
+  UsingFlushDenormalsToZero(const UsingFlushDenormalsToZero&) = delete;
+  UsingFlushDenormalsToZero& operator=(const UsingFlushDenormalsToZero&) = delete;
+};
+
+namespace gpu
+{
 // one row of a DSPVectorArray: a graph node, or a float literal / a table of 64 floats not yet materialised
 struct Sig
 {
@@ -1645,6 +1675,7 @@ class VoiceProgram
   AudioContext* ctx_{nullptr};
   std::function<void(AudioContext*)> body_;
   VoiceProgramOptions opt_;
+  bool flush_{false};  // the process function runs inside an ml::UsingFlushDenormalsToZero scope
 
  public:
   VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state, VoiceProgramOptions opt = VoiceProgramOptions())
@@ -1683,6 +1714,7 @@ class VoiceProgram
         }
     }
     usesVoice_ = voiceRowMask_ != 0;
+    flush_ = cap.flushDenormals;
     finishGraph(cap, g_);
     taps_ = cap.taps;
     eng_.check(mlgpu_graph_compile(g_));
@@ -1791,6 +1823,7 @@ class VoiceProgram
   }
 
   size_t voices() const { return voices_; }
+  bool flushesDenormals() const { return flush_; }  // the captured code holds an ml::UsingFlushDenormalsToZero
   unsigned voiceRowMask() const { return voiceRowMask_; }  // bit r: the captured code reads voice row r (VoiceOutputSignals)
   mlgpu_graph* graph() const { return g_; }
   const std::vector<Capture::Tap>& taps() const { return taps_; }
@@ -1835,7 +1868,12 @@ class VoiceProgram
       }
     for (auto* s : outs) po.push_back(s->data());
     const int inLayout = ins.empty() ? MLGPU_LAYOUT_QUAD : ins[0]->layout();
-    eng_.check(mlgpu_graph_process(g_, outs[0]->vectors(), pi.data(), inLayout, po.data(), outs[0]->layout()));
+    // the mode travels with the launch (a kernel argument), so it is restored as soon as the launch is enqueued
+    const int prevMode = mlgpu_engine_get_flush_denormals(eng_.handle());
+    if (flush_ && !prevMode) eng_.check(mlgpu_engine_set_flush_denormals(eng_.handle(), 1));
+    const int st = mlgpu_graph_process(g_, outs[0]->vectors(), pi.data(), inLayout, po.data(), outs[0]->layout());
+    if (flush_ && !prevMode) mlgpu_engine_set_flush_denormals(eng_.handle(), 0);
+    eng_.check(st);
   }
 };
 

@@ -109,6 +109,13 @@ class Engine:
     def sync(self):
         self._check(self.L.mlgpu_engine_sync(self.h))
 
+    def set_flush_denormals(self, on):
+        """ml::UsingFlushDenormalsToZero for every kernel launched from now on (MLDSPUtils.h:51-96)."""
+        self._check(self.L.mlgpu_engine_set_flush_denormals(self.h, 1 if on else 0))
+
+    def get_flush_denormals(self):
+        return bool(self.L.mlgpu_engine_get_flush_denormals(self.h))
+
     def set_jit(self, enabled):
         """hiprtc fusion of chains that have no ahead-of-time kernel (default on)."""
         self._check(self.L.mlgpu_engine_set_jit(self.h, 1 if enabled else 0))

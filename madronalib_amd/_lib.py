@@ -76,6 +76,8 @@ def _declare(L):
     sig("mlgpu_device_pci_bus_id", i, [i, c.c_char_p, sz])
     sig("mlgpu_device_synchronize", i, [i])
     sig("mlgpu_engine_create", i, [i, pp])
+    sig("mlgpu_engine_set_flush_denormals", i, [vp, i])
+    sig("mlgpu_engine_get_flush_denormals", i, [vp])
     sig("mlgpu_engine_create_on_stream", i, [i, vp, pp])
     sig("mlgpu_engine_destroy", i, [vp])
     sig("mlgpu_engine_sync", i, [vp])

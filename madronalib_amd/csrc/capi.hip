@@ -150,6 +150,15 @@ extern "C"
     return hipDeviceSynchronize() == hipSuccess ? MLGPU_OK : MLGPU_ERR_HIP;
   }
 
+  int mlgpu_engine_set_flush_denormals(mlgpu_engine* e, int on)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "mlgpu_engine_set_flush_denormals: not while recording a launch sequence");
+    e->kflags = on ? (e->kflags | MLGPU_KFLAG_FLUSH_DENORMALS) : (e->kflags & ~MLGPU_KFLAG_FLUSH_DENORMALS);
+    return MLGPU_OK;
+  }
+  int mlgpu_engine_get_flush_denormals(mlgpu_engine* e) { return (e && (e->kflags & MLGPU_KFLAG_FLUSH_DENORMALS)) ? 1 : 0; }
+
   int mlgpu_engine_create(int device, mlgpu_engine** out) { return createEngine(device, nullptr, true, out); }
   int mlgpu_engine_create_on_stream(int device, void* hipStream, mlgpu_engine** out)
   {
@@ -331,7 +340,7 @@ extern "C"
       return fail(e, MLGPU_ERR_INVALID, "op_apply: operands must be 16-byte aligned");
     HIP_TRY(e, hipSetDevice(e->device));
     bool known = false;
-    hipError_t err = mlgpu_launch_op(op, a, b, c, out, n, e->stream, e->cuCount, &known);
+    hipError_t err = mlgpu_launch_op(op, a, b, c, out, n, e->stream, e->cuCount, &known, e->kflags);
     if (!known) return fail(e, MLGPU_ERR_INVALID, "op_apply: unknown op");
     if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "op_apply launch", err);
     return MLGPU_OK;
@@ -344,7 +353,7 @@ extern "C"
     if (!a || !b64 || !out) return fail(e, MLGPU_ERR_INVALID, "op_apply_rows1: null operand");
     HIP_TRY(e, hipSetDevice(e->device));
     bool known = false;
-    hipError_t err = mlgpu_launch_op_rows1(op, a, b64, out, nRows, e->stream, e->cuCount, &known);
+    hipError_t err = mlgpu_launch_op_rows1(op, a, b64, out, nRows, e->stream, e->cuCount, &known, e->kflags);
     if (!known) return fail(e, MLGPU_ERR_INVALID, "op_apply_rows1: op must be ADD..MAX");
     if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "op_apply_rows1 launch", err);
     return MLGPU_OK;
@@ -357,7 +366,7 @@ extern "C"
     if (!rows || !out) return fail(e, MLGPU_ERR_INVALID, "row_reduce: null operand");
     HIP_TRY(e, hipSetDevice(e->device));
     bool known = false;
-    hipError_t err = mlgpu_launch_row_reduce(rowop, rows, out, nRows, e->stream, &known);
+    hipError_t err = mlgpu_launch_row_reduce(rowop, rows, out, nRows, e->stream, &known, e->kflags);
     if (!known) return fail(e, MLGPU_ERR_INVALID, "row_reduce: unknown rowop");
     if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "row_reduce launch", err);
     return MLGPU_OK;
@@ -398,7 +407,7 @@ extern "C"
     if (groups == 0) return MLGPU_OK;
     if (!rows || !out) return fail(e, MLGPU_ERR_INVALID, "rows_add: null operand");
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, mlgpu_launch_rows_add(rows, rowsPerGroup, out, groups, e->stream));
+    HIP_TRY(e, mlgpu_launch_rows_add(rows, rowsPerGroup, out, groups, e->stream, e->kflags));
     return MLGPU_OK;
   }
 
@@ -408,7 +417,7 @@ extern "C"
     if (nRows == 0) return MLGPU_OK;
     if (!rows || !out) return fail(e, MLGPU_ERR_INVALID, "rows_normalize: null operand");
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, mlgpu_launch_rows_normalize(rows, out, nRows, e->stream));
+    HIP_TRY(e, mlgpu_launch_rows_normalize(rows, out, nRows, e->stream, e->kflags));
     return MLGPU_OK;
   }
 
@@ -432,7 +441,7 @@ extern "C"
       if (!ins[k]) return fail(e, MLGPU_ERR_INVALID, "multiplex: null input");
     HIP_TRY(e, hipSetDevice(e->device));
     float* outs[1] = {out};
-    HIP_TRY(e, mlgpu_launch_route(false, linear != 0, sel, selElems, ins, outs, n, nElems, e->stream));
+    HIP_TRY(e, mlgpu_launch_route(false, linear != 0, sel, selElems, ins, outs, n, nElems, e->stream, e->kflags));
     return MLGPU_OK;
   }
 
@@ -446,7 +455,7 @@ extern "C"
       if (!outs[k]) return fail(e, MLGPU_ERR_INVALID, "demultiplex: null output");
     HIP_TRY(e, hipSetDevice(e->device));
     const float* ins[1] = {in};
-    HIP_TRY(e, mlgpu_launch_route(true, linear != 0, sel, selElems, ins, outs, n, nElems, e->stream));
+    HIP_TRY(e, mlgpu_launch_route(true, linear != 0, sel, selElems, ins, outs, n, nElems, e->stream, e->kflags));
     return MLGPU_OK;
   }
 
@@ -468,7 +477,7 @@ extern "C"
       if (err != hipSuccess) return fail(e, err == hipErrorOutOfMemory ? MLGPU_ERR_OOM : MLGPU_ERR_HIP, "mixdown: scratch allocation", err);
       e->mixScratchFloats = need;
     }
-    HIP_TRY(e, mlgpu_launch_mixdown(sig, layout, V, T, gains, e->d_mixScratch, out, e->stream));
+    HIP_TRY(e, mlgpu_launch_mixdown(sig, layout, V, T, gains, e->d_mixScratch, out, e->stream, e->kflags));
     return MLGPU_OK;
   }
 
@@ -480,7 +489,7 @@ extern "C"
     if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR || outLayout < 0 || outLayout > MLGPU_LAYOUT_VOICE_MAJOR)
       return fail(e, MLGPU_ERR_INVALID, "mixdown_groups: bad layout");
     HIP_TRY(e, hipSetDevice(e->device));
-    HIP_TRY(e, mlgpu_launch_mixdown_groups(sig, layout, groups, groupSize, T, out, outLayout, e->stream));
+    HIP_TRY(e, mlgpu_launch_mixdown_groups(sig, layout, groups, groupSize, T, out, outLayout, e->stream, e->kflags));
     return MLGPU_OK;
   }
 
@@ -708,6 +717,7 @@ extern "C"
 
     ChainArgs a;
     a.V = V;
+    a.flags = e->kflags;
     a.impulseTable = e->d_impulseTable;
     a.inConst = b->d_inConst;
 

@@ -88,6 +88,7 @@ struct E2SArgs
   size_t lanes, T;
   int group, polyphony, slotBase;  // lane = instrument * group + (voice slot - slotBase)
   uint32_t rowMask;                // rows that are computed (mlgpu_events_set_wanted_rows); bit r = row r of `out`
+  uint32_t flags;                  // MLGPU_KFLAG_*
   E2SSettings s;
 };
 
@@ -191,6 +192,7 @@ struct Glide
 
 __global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
 {
+  apply_fp_mode(a.flags);
   // XCD-aware workgroup -> lane mapping (as the voice-bank kernels): every XCD writes one contiguous eighth of each row
   size_t blk = blockIdx.x;
   const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
@@ -1193,6 +1195,7 @@ extern "C"
     a.lanes = lanes;
     a.T = nVectors;
     a.rowMask = ev->rowMask;
+    a.flags = e->kflags;
     a.group = ev->group;
     a.slotBase = ev->slotBase;
     a.polyphony = ev->polyphony;

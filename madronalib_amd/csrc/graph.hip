@@ -388,7 +388,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << "};\n";
     }
   // windowed rings: the latency of a sector refill is hidden by other waves only, so keep at least two per SIMD
-  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->windowedRings && g->totalRings) ? ", 2" : "") << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n";
+  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->windowedRings && g->totalRings) ? ", 2" : "") << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n  apply_fp_mode(a.flags);\n";
   if (g->hasImpulse)
   {
     s << "  __shared__ float ldsTable[32];\n  if (threadIdx.x < 17) ldsTable[threadIdx.x] = a.impulseTable[threadIdx.x];\n  __syncthreads();\n";
@@ -1490,6 +1490,7 @@ extern "C"
     a.V = g->V;
     a.T = T;
     a.t0 = g->vectorCount;
+    a.flags = g->e->kflags;
     a.impulseTable = g->e->d_impulseTable;
     for (int i = 0; i < g->nInputs; ++i)
     {

@@ -52,6 +52,7 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
 template <class CH, bool HAS_SIGNAL>
 __device__ __forceinline__ void chain_kernel_body(const ChainArgs& a)
 {
+  apply_fp_mode(a.flags);
   __shared__ float ldsTable[CH::kHasImpulse ? 32 : 1];
   if constexpr (CH::kHasImpulse)
   {
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
   static_assert(!HEAD::kHasImpulse, "ImpulseGen heads are not supported by the cascade kernel");
   // with B == 0 the steady loop's last prefetch (inQuad(q + A + 5 + k)) would read one quad past the input
   static_assert((N - 1) % 4 != 0, "cascade lengths with (N - 1) % 4 == 0 need a bounded prefetch");
+  apply_fp_mode(a.flags);
   size_t blk = blockIdx.x;
   const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
   if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);  // XCD-aware, see chain_kernel

@@ -20,13 +20,45 @@ namespace mldev
 {
 #define MLD __device__ __forceinline__
 
+// Floating-point mode of a kernel. The reference runs its DSP code either with the default MXCSR (denormals honoured: the
+// kernels' default too, MODE.fp_denorm = 3 from the kernel descriptor) or inside an ml::UsingFlushDenormalsToZero scope
+// (MLDSPUtils.h:51-96: MXCSR FZ | DAZ - denormal sources read as zero, denormal results written as zero, signs kept).
+// gfx950's MODE[5:4] = 0 is the same rule for every f32 VALU instruction used here (add, sub, mul, fma, the packed forms,
+// compares, the division expansion, sqrt: tools/ftz_probe.hip compares each with the SSE instruction under FZ | DAZ);
+// moves, selects and bit operations pass denormals through unchanged on both machines. One scalar instruction at kernel
+// entry, wave-uniform: the same code object serves both modes. hwreg(HW_REG_MODE = 1, offset 4, width 2).
+MLD void apply_fp_mode(uint32_t flags)
+{
+  if (flags & 1u /* MLGPU_KFLAG_FLUSH_DENORMALS */) __builtin_amdgcn_s_setreg(1 | (4 << 6) | (1 << 11), 0);
+}
+
 MLD float u2f(uint32_t u) { return __uint_as_float(u); }
 MLD uint32_t f2u(float f) { return __float_as_uint(f); }
 
 // _mm_min_ps / _mm_max_ps (MLDSPMathSSE.h:80-81): (a<b)?a:b / (a>b)?a:b, i.e. the SECOND
 // operand when either is NaN. Not fminf/fmaxf.
-MLD float sse_min(float a, float b) { return (a < b) ? a : b; }
-MLD float sse_max(float a, float b) { return (a > b) ? a : b; }
+// They are arithmetic-class instructions: under MXCSR.DAZ (flush mode) a denormal source is replaced by a signed zero
+// before the comparison, and that zero is what comes back. v_max_f32 x, x (canonicalize) does exactly that in flush
+// mode and is the identity for every non-NaN value in the default mode, so the select below returns what minps/maxps
+// return in either mode (tools/ftz_probe.hip, tests/test_gpu_denormals.py).
+MLD float sse_canon(float x)
+{
+  float r;
+  asm("v_max_f32 %0, %1, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+MLD float sse_min(float a, float b)
+{
+  a = sse_canon(a);
+  b = sse_canon(b);
+  return (a < b) ? a : b;
+}
+MLD float sse_max(float a, float b)
+{
+  a = sse_canon(a);
+  b = sse_canon(b);
+  return (a > b) ? a : b;
+}
 
 // _mm_cvttps_epi32 / _mm_cvtps_epi32 (MLDSPMathSSE.h:124-125): NaN and out-of-range give
 // 0x80000000 ("integer indefinite"); v_cvt_i32_f32 would saturate / give 0 instead.

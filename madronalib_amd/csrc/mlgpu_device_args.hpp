@@ -15,6 +15,9 @@ struct SignalView
   size_t strideT, strideQ, strideV;
 };
 
+// bits of the `flags` word every arithmetic kernel receives
+#define MLGPU_KFLAG_FLUSH_DENORMALS 1u  // run with f32 denormal sources and results flushed (mlgpu_engine_set_flush_denormals)
+
 struct ChainArgs
 {
   const float* coeffs;   // [NC][V]
@@ -24,6 +27,7 @@ struct ChainArgs
   SignalView out;
   size_t V, T;
   const float* impulseTable;
+  uint32_t flags;  // MLGPU_KFLAG_*
 };
 
 // a fused graph kernel: up to 16 streamed inputs, up to 4 outputs, per-voice constants [P][V]
@@ -43,4 +47,5 @@ struct GraphArgs
   const float* impulseTable;
   const float* consts;  // live constants (mlgpu_graph_set_live_constants): one float per const node, the same for all voices
   size_t t0;  // DSPVectors processed since the last clear (a Downsample2xFunction region pairs vectors 2k, 2k + 1)
+  uint32_t flags;  // MLGPU_KFLAG_*
 };

@@ -22,6 +22,7 @@ struct mlgpu_engine
   bool jitEnabled{true};  // fuse unknown chains / graphs with hiprtc (mlgpu_engine_set_jit)
   float* d_mixScratch{nullptr};  // mixdown partial sums, grown on demand
   size_t mixScratchFloats{0};
+  uint32_t kflags{0};  // MLGPU_KFLAG_* handed to every arithmetic kernel (mlgpu_engine_set_flush_denormals)
   bool recording{false};  // between mlgpu_engine_begin_recording and _end_recording: launches are captured, not run
 };
 
@@ -74,24 +75,24 @@ bool mlgpu_proc_is_vector_rate(int kind);  // one float per DSPVector in (Interp
 
 // ops.hip
 hipError_t mlgpu_launch_op(int op, const void* a, const void* b, const void* c, void* out, size_t n,
-                           hipStream_t stream, int cuCount, bool* known);
+                           hipStream_t stream, int cuCount, bool* known, uint32_t flags);
 hipError_t mlgpu_launch_op_rows1(int op, const void* a, const void* b64, void* out, size_t nRows,
-                                 hipStream_t stream, int cuCount, bool* known);
+                                 hipStream_t stream, int cuCount, bool* known, uint32_t flags);
 hipError_t mlgpu_launch_row_reduce(int rowop, const float* rows, float* out, size_t nRows,
-                                   hipStream_t stream, bool* known);
+                                   hipStream_t stream, bool* known, uint32_t flags);
 hipError_t mlgpu_launch_layout_convert(const float* src, int srcLayout, float* dst, int dstLayout, size_t V,
                                        size_t T, hipStream_t stream);
 hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStream_t stream);
 hipError_t mlgpu_launch_rows_map(int rule, long p0, long p1, int sampleRotate, const float* src, size_t srcRows, float* dst,
                                  size_t dstRows, size_t dstOffset, size_t dstStep, size_t count, size_t groups, hipStream_t stream);
-hipError_t mlgpu_launch_rows_add(const float* rows, size_t rowsPerGroup, float* out, size_t groups, hipStream_t stream);
-hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRows, hipStream_t stream);
+hipError_t mlgpu_launch_rows_add(const float* rows, size_t rowsPerGroup, float* out, size_t groups, hipStream_t stream, uint32_t flags);
+hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRows, hipStream_t stream, uint32_t flags);
 hipError_t mlgpu_launch_rows_index(float* out, size_t rowsPerGroup, size_t groups, hipStream_t stream);
 hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
-                                hipStream_t stream);
-hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream);
+                                hipStream_t stream, uint32_t flags);
+hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream, uint32_t flags);
 hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,
-                              size_t nElems, hipStream_t stream);
+                              size_t nElems, hipStream_t stream, uint32_t flags);
 
 // graph.hip — run-time fused kernels (hiprtc)
 bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);

@@ -26,8 +26,9 @@ constexpr int kOpUnroll = 4;
 template <int OP>
 __global__ __launch_bounds__(kOpBlock) void op_kernel(const u32x4* a, const u32x4* b,
                                                       const u32x4* c, u32x4* out,
-                                                      size_t n4, size_t n)
+                                                      size_t n4, size_t n, uint32_t flags)
 {
+  apply_fp_mode(flags);
   constexpr int AR = arity<OP>();
   // XCD-aware element mapping: workgroup b runs on XCD b % 8; give XCD x the x-th contiguous eighth of the array (each
   // XCD's L2 then streams one contiguous segment), grid-stride inside it. Any bijection is correct; this is for speed:
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kOpBlock) void op_kernel(const u32x4* a, const u32x
 
 template <int OP>
 hipError_t launchOp(const void* a, const void* b, const void* c, void* out, size_t n, hipStream_t stream,
-                    int cuCount)
+                    int cuCount, uint32_t flags)
 {
   const size_t n4 = n / 4;
   size_t blocks = (n4 + (size_t)kOpBlock * kOpUnroll - 1) / ((size_t)kOpBlock * kOpUnroll);
@@ -101,7 +102,7 @@ hipError_t launchOp(const void* a, const void* b, const void* c, void* out, size
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(op_kernel<OP>, dim3((unsigned)blocks), dim3(kOpBlock), 0, stream, (const u32x4*)a,
-                     (const u32x4*)b, (const u32x4*)c, (u32x4*)out, n4, n);
+                     (const u32x4*)b, (const u32x4*)c, (u32x4*)out, n4, n, flags);
   return hipGetLastError();
 }
 
@@ -109,8 +110,9 @@ hipError_t launchOp(const void* a, const void* b, const void* c, void* out, size
 template <int OP>
 __global__ __launch_bounds__(kOpBlock) void op_rows1_kernel(const u32x4* a,
                                                             const u32x4* b64,
-                                                            u32x4* out, size_t n4)
+                                                            u32x4* out, size_t n4, uint32_t flags)
 {
+  apply_fp_mode(flags);
   const size_t stride = (size_t)gridDim.x * kOpBlock;
   for (size_t i = (size_t)blockIdx.x * kOpBlock + threadIdx.x; i < n4; i += stride)
   {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(kOpBlock) void op_rows1_kernel(const u32x4* a,
   }
 }
 template <int OP>
-hipError_t launchRows1(const void* a, const void* b, void* out, size_t nRows, hipStream_t stream, int cuCount)
+hipError_t launchRows1(const void* a, const void* b, void* out, size_t nRows, hipStream_t stream, int cuCount, uint32_t flags)
 {
   const size_t n4 = nRows * 16;
   size_t blocks = (n4 + kOpBlock - 1) / kOpBlock;
@@ -133,7 +135,7 @@ hipError_t launchRows1(const void* a, const void* b, void* out, size_t nRows, hi
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(op_rows1_kernel<OP>, dim3((unsigned)blocks), dim3(kOpBlock), 0, stream, (const u32x4*)a,
-                     (const u32x4*)b, (u32x4*)out, n4);
+                     (const u32x4*)b, (u32x4*)out, n4, flags);
   return hipGetLastError();
 }
 
@@ -142,8 +144,9 @@ hipError_t launchRows1(const void* a, const void* b, void* out, size_t nRows, hi
 // per 4-group (x0 op x2) op (x1 op x3), then left-to-right over the 16 groups.
 template <int ROWOP>
 __global__ __launch_bounds__(256) void row_reduce_kernel(const float4* rows, float* out,
-                                                         size_t nRows)
+                                                         size_t nRows, uint32_t flags)
 {
+  apply_fp_mode(flags);
   const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nRows) return;
   const float4* p = rows + r * 16;
@@ -162,12 +165,12 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const float4* rows, flo
     else if (ROWOP == MLGPU_ROWOP_MAX)
     {
       const float h = sse_max(sse_max(q.x, q.z), sse_max(q.y, q.w));
-      acc = (acc > h) ? acc : h;
+      acc = sse_max(acc, h);  // vecMax(acc, h)
     }
     else
     {
       const float h = sse_min(sse_min(q.x, q.z), sse_min(q.y, q.w));
-      acc = (acc < h) ? acc : h;
+      acc = sse_min(acc, h);  // vecMin(acc, h)
     }
   }
   out[r] = (ROWOP == MLGPU_ROWOP_MEAN) ? acc * (1.0f / 64.f) : acc;
@@ -327,8 +330,9 @@ __global__ __launch_bounds__(256) void rows_map_kernel(const RowsMapArgs a)
 }
 
 // addRows, MLDSPOps.h:1349-1359: vy = 0; vy = vy + row_j for j = 0..ROWS-1 (left to right, starting from +0)
-__global__ __launch_bounds__(256) void rows_add_kernel(const float4* rows, float4* out, size_t rowsPerGroup, size_t groups)
+__global__ __launch_bounds__(256) void rows_add_kernel(const float4* rows, float4* out, size_t rowsPerGroup, size_t groups, uint32_t flags)
 {
+  apply_fp_mode(flags);
   const size_t total = groups * 16;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
@@ -348,8 +352,9 @@ __global__ __launch_bounds__(256) void rows_add_kernel(const float4* rows, float
 }
 
 // normalize, MLDSPOps.h:1041-1050: row / sum(row), sum in the reference's association order; one lane per row
-__global__ __launch_bounds__(256) void rows_normalize_kernel(const float4* rows, float4* out, size_t nRows)
+__global__ __launch_bounds__(256) void rows_normalize_kernel(const float4* rows, float4* out, size_t nRows, uint32_t flags)
 {
+  apply_fp_mode(flags);
   const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nRows) return;
   const float4* p = rows + r * 16;
@@ -392,11 +397,13 @@ struct RouteArgs
   float* out[MLGPU_ROUTE_MAX];
   int n;
   size_t nElems;
+  uint32_t flags;
 };
 
 template <bool LINEAR>
 __global__ __launch_bounds__(256) void multiplex_kernel(const RouteArgs a)
 {
+  apply_fp_mode(a.flags);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nElems; i += stride)
   {
@@ -411,6 +418,7 @@ __global__ __launch_bounds__(256) void multiplex_kernel(const RouteArgs a)
 template <bool LINEAR>
 __global__ __launch_bounds__(256) void demultiplex_kernel(const RouteArgs a)
 {
+  apply_fp_mode(a.flags);
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nElems; i += stride)
   {
@@ -422,10 +430,10 @@ __global__ __launch_bounds__(256) void demultiplex_kernel(const RouteArgs a)
 }  // namespace
 
 #define OP_CASE(OP) \
-  case OP: return launchOp<OP>(a, b, c, out, n, stream, cuCount);
+  case OP: return launchOp<OP>(a, b, c, out, n, stream, cuCount, flags);
 
 hipError_t mlgpu_launch_op(int op, const void* a, const void* b, const void* c, void* out, size_t n,
-                           hipStream_t stream, int cuCount, bool* known)
+                           hipStream_t stream, int cuCount, bool* known, uint32_t flags)
 {
   *known = true;
   switch (op)
@@ -481,10 +489,10 @@ hipError_t mlgpu_launch_op(int op, const void* a, const void* b, const void* c, 
 }
 
 #define ROWS1_CASE(OP) \
-  case OP: return launchRows1<OP>(a, b64, out, nRows, stream, cuCount);
+  case OP: return launchRows1<OP>(a, b64, out, nRows, stream, cuCount, flags);
 
 hipError_t mlgpu_launch_op_rows1(int op, const void* a, const void* b64, void* out, size_t nRows,
-                                 hipStream_t stream, int cuCount, bool* known)
+                                 hipStream_t stream, int cuCount, bool* known, uint32_t flags)
 {
   *known = true;
   switch (op)
@@ -503,7 +511,7 @@ hipError_t mlgpu_launch_op_rows1(int op, const void* a, const void* b64, void* o
 }
 
 hipError_t mlgpu_launch_row_reduce(int rowop, const float* rows, float* out, size_t nRows, hipStream_t stream,
-                                   bool* known)
+                                   bool* known, uint32_t flags)
 {
   *known = true;
   const unsigned blocks = (unsigned)((nRows + 255) / 256);
@@ -511,19 +519,19 @@ hipError_t mlgpu_launch_row_reduce(int rowop, const float* rows, float* out, siz
   {
     case MLGPU_ROWOP_SUM:
       hipLaunchKernelGGL(row_reduce_kernel<MLGPU_ROWOP_SUM>, dim3(blocks), dim3(256), 0, stream,
-                         (const float4*)rows, out, nRows);
+                         (const float4*)rows, out, nRows, flags);
       break;
     case MLGPU_ROWOP_MEAN:
       hipLaunchKernelGGL(row_reduce_kernel<MLGPU_ROWOP_MEAN>, dim3(blocks), dim3(256), 0, stream,
-                         (const float4*)rows, out, nRows);
+                         (const float4*)rows, out, nRows, flags);
       break;
     case MLGPU_ROWOP_MAX:
       hipLaunchKernelGGL(row_reduce_kernel<MLGPU_ROWOP_MAX>, dim3(blocks), dim3(256), 0, stream,
-                         (const float4*)rows, out, nRows);
+                         (const float4*)rows, out, nRows, flags);
       break;
     case MLGPU_ROWOP_MIN:
       hipLaunchKernelGGL(row_reduce_kernel<MLGPU_ROWOP_MIN>, dim3(blocks), dim3(256), 0, stream,
-                         (const float4*)rows, out, nRows);
+                         (const float4*)rows, out, nRows, flags);
       break;
     default: *known = false; return hipSuccess;
   }
@@ -572,8 +580,9 @@ hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStrea
 // group count as +0. The order is part of the contract so results are reproducible and checkable.
 namespace
 {
-__global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, size_t V, size_t T, const float* gains, float4* partial)
+__global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, size_t V, size_t T, const float* gains, float4* partial, uint32_t flags)
 {
+  apply_fp_mode(flags);
   const size_t nQuads = T * 16;
   const size_t group = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -618,8 +627,9 @@ __global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, siz
   }
 }
 
-__global__ __launch_bounds__(256) void mixdown_stage2_kernel(const float4* partial, size_t groups, size_t nQuads, float4* out)
+__global__ __launch_bounds__(256) void mixdown_stage2_kernel(const float4* partial, size_t groups, size_t nQuads, float4* out, uint32_t flags)
 {
+  apply_fp_mode(flags);
   const size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (qi >= nQuads) return;
   // left to right over the groups, as the contract says; the loads of 16 groups are in flight together
@@ -659,8 +669,9 @@ namespace
 // (lane l takes elements l, l + 64, ...), parks them in its own LDS strip, and lane l then adds up the P voices of group l in
 // voice order. One spare float4 per group keeps the strided reads of the second phase off a single LDS bank. (The first
 // version let every lane read its own group straight from memory: 16-byte accesses at a stride of P * 16 bytes, 1.1 TB/s.)
-__global__ __launch_bounds__(256) void mixdown_groups_kernel(SignalView sig, SignalView out, size_t groups, size_t P, size_t T)
+__global__ __launch_bounds__(256) void mixdown_groups_kernel(SignalView sig, SignalView out, size_t groups, size_t P, size_t T, uint32_t flags)
 {
+  apply_fp_mode(flags);
   extern __shared__ float4 mixLds[];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4* strip = mixLds + (size_t)wave * 64 * (P + 1);
@@ -715,8 +726,9 @@ __global__ __launch_bounds__(256) void mixdown_groups_kernel(SignalView sig, Sig
   }
 }
 // groups too large for an LDS strip: one lane per (group, quad), straight from memory
-__global__ __launch_bounds__(256) void mixdown_groups_direct_kernel(SignalView sig, SignalView out, size_t groups, size_t P, size_t T)
+__global__ __launch_bounds__(256) void mixdown_groups_direct_kernel(SignalView sig, SignalView out, size_t groups, size_t P, size_t T, uint32_t flags)
 {
+  apply_fp_mode(flags);
   const size_t total = groups * T * 16;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
@@ -737,7 +749,7 @@ __global__ __launch_bounds__(256) void mixdown_groups_direct_kernel(SignalView s
 }
 }  // namespace
 
-hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream)
+hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream, uint32_t flags)
 {
   const SignalView in = makeView(sig, layout, groups * P, T), ov = makeView(out, outLayout, groups, T);
   const size_t stripBytes = 64 * (P + 1) * sizeof(float4);  // per wavefront
@@ -745,7 +757,7 @@ hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t grou
   {
     size_t blocks = (groups * T * 16 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(mixdown_groups_direct_kernel, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, stream, in, ov, groups, P, T);
+    hipLaunchKernelGGL(mixdown_groups_direct_kernel, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, stream, in, ov, groups, P, T, flags);
     return hipGetLastError();
   }
   size_t waves = 4;  // per workgroup, as many as fit 64 KiB of LDS
@@ -754,12 +766,12 @@ hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t grou
   size_t blocks = (items + waves - 1) / waves;
   if (blocks > 256 * 8) blocks = 256 * 8;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(mixdown_groups_kernel, dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), waves * stripBytes, stream, in, ov, groups, P, T);
+  hipLaunchKernelGGL(mixdown_groups_kernel, dim3((unsigned)blocks), dim3((unsigned)(64 * waves)), waves * stripBytes, stream, in, ov, groups, P, T, flags);
   return hipGetLastError();
 }
 
 hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
-                                hipStream_t stream)
+                                hipStream_t stream, uint32_t flags)
 {
   const size_t groups = (V + 63) / 64, nQuads = T * 16;
   unsigned y = (unsigned)((nQuads + 3) / 4);
@@ -767,9 +779,9 @@ hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T
   if ((size_t)y * groups > wantBlocks) y = (unsigned)((wantBlocks + groups - 1) / groups);
   if (y < 1) y = 1;
   hipLaunchKernelGGL(mixdown_stage1_kernel, dim3((unsigned)groups, y), dim3(256), 0, stream, makeView(sig, layout, V, T), V, T, gains,
-                     (float4*)partial);
+                     (float4*)partial, flags);
   hipLaunchKernelGGL(mixdown_stage2_kernel, dim3((unsigned)((nQuads + 63) / 64)), dim3(64), 0, stream, (const float4*)partial, groups, nQuads,
-                     (float4*)out);
+                     (float4*)out, flags);
   return hipGetLastError();
 }
 
@@ -801,15 +813,15 @@ hipError_t mlgpu_launch_rows_map(int rule, long p0, long p1, int sampleRotate, c
   return hipGetLastError();
 }
 
-hipError_t mlgpu_launch_rows_add(const float* rows, size_t rowsPerGroup, float* out, size_t groups, hipStream_t stream)
+hipError_t mlgpu_launch_rows_add(const float* rows, size_t rowsPerGroup, float* out, size_t groups, hipStream_t stream, uint32_t flags)
 {
-  hipLaunchKernelGGL(rows_add_kernel, dim3(gridFor(groups * 16)), dim3(256), 0, stream, (const float4*)rows, (float4*)out, rowsPerGroup, groups);
+  hipLaunchKernelGGL(rows_add_kernel, dim3(gridFor(groups * 16)), dim3(256), 0, stream, (const float4*)rows, (float4*)out, rowsPerGroup, groups, flags);
   return hipGetLastError();
 }
 
-hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRows, hipStream_t stream)
+hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRows, hipStream_t stream, uint32_t flags)
 {
-  hipLaunchKernelGGL(rows_normalize_kernel, dim3((unsigned)((nRows + 255) / 256)), dim3(256), 0, stream, (const float4*)rows, (float4*)out, nRows);
+  hipLaunchKernelGGL(rows_normalize_kernel, dim3((unsigned)((nRows + 255) / 256)), dim3(256), 0, stream, (const float4*)rows, (float4*)out, nRows, flags);
   return hipGetLastError();
 }
 
@@ -820,10 +832,11 @@ hipError_t mlgpu_launch_rows_index(float* out, size_t rowsPerGroup, size_t group
 }
 
 hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,
-                              size_t nElems, hipStream_t stream)
+                              size_t nElems, hipStream_t stream, uint32_t flags)
 {
   RouteArgs a;
   memset(&a, 0, sizeof(a));
+  a.flags = flags;
   a.sel = sel;
   a.selElems = selElems;
   a.n = n;

@@ -99,6 +99,7 @@ struct ResampleArgs
   SignalView in, out;
   float* state;  // [octaves * 9][V]
   size_t V, quadsOut, quadsIn;
+  uint32_t flags;  // MLGPU_KFLAG_*
 };
 
 MLD f32x4* quadPtr(const SignalView& s, size_t v, size_t qi) { return (f32x4*)s.base + (qi >> 4) * s.strideT + (qi & 15) * s.strideQ + v * s.strideV; }
@@ -116,6 +117,7 @@ MLD size_t xcdVoice()
 template <int H>
 __global__ __launch_bounds__(256) void downsample_kernel(const ResampleArgs a)
 {
+  apply_fp_mode(a.flags);
   const size_t v = xcdVoice();
   if (v >= a.V) return;
   HalfBand f[H > 0 ? H : 1];
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256) void downsample_kernel(const ResampleArgs a)
 template <int H>
 __global__ __launch_bounds__(256) void upsample_kernel(const ResampleArgs a)
 {
+  apply_fp_mode(a.flags);
   const size_t v = xcdVoice();
   if (v >= a.V) return;
   HalfBand f[H > 0 ? H : 1];
@@ -278,6 +281,7 @@ extern "C"
     a.out = makeView(d_out, outLayout, r->V, nOut);
     a.state = r->d_state;
     a.V = r->V;
+    a.flags = e->kflags;
     a.quadsIn = nVectorsIn * 16;
     a.quadsOut = nOut * 16;
     if (hipSetDevice(e->device) != hipSuccess) return MLGPU_ERR_HIP;

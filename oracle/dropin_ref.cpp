@@ -73,6 +73,29 @@ extern "C" int oversample_ref_run(size_t V, size_t T, const float* in0, const fl
   return 0;
 }
 
+#include "../tests/cpp/dropin_decay.h"
+extern "C" int decay_ref_run(size_t V, size_t T, int flush, const float* in0, float* out0, float* out1)
+{
+  const size_t S = T * kFloatsPerDSPVector;
+  for (size_t v = 0; v < V; ++v)
+  {
+    DecayState state;
+    decaySetup(state);
+    AudioContext ctx(1, 2, 48000);
+    for (size_t t = 0; t < T; ++t)
+    {
+      load(ctx.inputs[0], in0 + v * S + t * kFloatsPerDSPVector);
+      if (flush)
+        decayProcessFlush(&ctx, &state);
+      else
+        decayProcess(&ctx, &state);
+      store(ctx.outputs[0], out0 + v * S + t * kFloatsPerDSPVector);
+      store(ctx.outputs[1], out1 + v * S + t * kFloatsPerDSPVector);
+    }
+  }
+  return 0;
+}
+
 // ---- a Synth subclass run by the reference's own Synth::processVector, AudioContext and EventsToSignals ----
 #include "MLSynth.h"
 #include "../tests/cpp/dropin_synth.h"

@@ -36,6 +36,22 @@
 
 #define VEC 64 /* kFloatsPerDSPVector, source/DSP/MLDSPMath.h:8-9 */
 
+/* UsingFlushDenormalsToZero (source/DSP/MLDSPUtils.h:51-96): the reference sets the DAZ and FZ bits (0x8040) of MXCSR for
+ * the scope of a process function. This restatement is plain scalar SSE arithmetic (gcc, x86-64), so the same two bits on
+ * the calling thread give it the same mode; worker threads are created per call and inherit the caller's MXCSR. Returns
+ * the previous setting (1 = flushing) so a test can restore it. */
+#if defined(__SSE__)
+#include <xmmintrin.h>
+int mlorc_set_flush_denormals(int on)
+{
+  const unsigned csr = _mm_getcsr();
+  _mm_setcsr(on ? (csr | 0x8040u) : (csr & ~0x8040u));
+  return (csr & 0x8040u) == 0x8040u;
+}
+#else
+int mlorc_set_flush_denormals(int on) { (void)on; return 0; }
+#endif
+
 /* ------------------------------------------------------------------------- */
 /* bit casts and SSE-semantics primitives (source/DSP/MLDSPMathSSE.h:73-135)  */
 
@@ -52,9 +68,27 @@ static inline float u2f(uint32_t u)
   return f;
 }
 
-/* _mm_min_ps / _mm_max_ps: (a<b)?a:b and (a>b)?a:b — returns b if either is NaN. */
-static inline float sse_min(float a, float b) { return (a < b) ? a : b; }
-static inline float sse_max(float a, float b) { return (a > b) ? a : b; }
+/* _mm_min_ps / _mm_max_ps: (a<b)?a:b and (a>b)?a:b — returns b if either is NaN. They are arithmetic-class SSE
+ * instructions: with MXCSR.DAZ set (ml::UsingFlushDenormalsToZero) a denormal source is replaced by a zero of its sign
+ * BEFORE the comparison, so the operand that comes back is the zero, not the denormal (checked against the compiled
+ * reference, tests/test_denormals_cpu.py). A C conditional would hand the denormal through, hence daz(). */
+#if defined(__SSE__)
+static inline float daz(float x)
+{
+  if (_mm_getcsr() & 0x0040u)
+  {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7F800000u) == 0) u &= 0x80000000u;
+    memcpy(&x, &u, 4);
+  }
+  return x;
+}
+#else
+static inline float daz(float x) { return x; }
+#endif
+static inline float sse_min(float a, float b) { a = daz(a); b = daz(b); return (a < b) ? a : b; }
+static inline float sse_max(float a, float b) { a = daz(a); b = daz(b); return (a > b) ? a : b; }
 
 /* _mm_cvtps_epi32: round to nearest even; NaN / out of range -> 0x80000000. */
 static inline int32_t sse_cvt(float x)

@@ -593,6 +593,21 @@ void parallelFor(size_t V, int nThreads, Fn fn)
 
 }  // namespace
 
+// ml::UsingFlushDenormalsToZero (MLDSPUtils.h:51-96) is scoped to a process function; a test brackets the calls it wants
+// in that mode with this pair instead (same MXCSR bits, same thread; threads started by a call inherit them).
+extern "C" int mlref_set_flush_denormals(int on)
+{
+  static thread_local ml::UsingFlushDenormalsToZero* scope = nullptr;
+  const bool was = scope != nullptr;
+  if (on && !scope) scope = new ml::UsingFlushDenormalsToZero();   // the reference's own constructor sets DAZ | FZ
+  if (!on && scope)
+  {
+    delete scope;                                                   // and its destructor restores the previous MXCSR
+    scope = nullptr;
+  }
+  return was ? 1 : 0;
+}
+
 extern "C"
 {
   // ---- elementwise ops through the reference's own DSPVector functions ----

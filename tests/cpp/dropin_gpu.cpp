@@ -137,6 +137,43 @@ extern "C" int oversample_gpu_run(size_t V, size_t T, int launches, const float*
   }
 }
 
+#include "dropin_decay.h"
+// the ringing-out patch for V independent instances in one launch; flush != 0: the process function that opens with
+// UsingFlushDenormalsToZero. *usedFlushMode reports what the captured program found out by itself.
+extern "C" int decay_gpu_run(size_t V, size_t T, int flush, const float* in0, float* out0, float* out1, int* usedFlushMode, char* err, size_t errLen)
+{
+  try
+  {
+    gpu::Engine eng(0);
+    DecayState state;
+    decaySetup(state);
+    AudioContext ctx(1, 2, 48000);
+    gpu::VoiceProgram prog(eng, V, &ctx, flush ? decayProcessFlush : decayProcess, &state);
+    if (usedFlushMode) *usedFlushMode = prog.flushesDenormals() ? 1 : 0;
+    gpu::DeviceSignal vm0(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR), vm1(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR);
+    gpu::DeviceSignal q0(eng, V, T), o0(eng, V, T), o1(eng, V, T);
+    eng.check(mlgpu_upload(eng.handle(), vm0.data(), in0, vm0.bytes()));
+    eng.check(mlgpu_layout_convert(eng.handle(), vm0.data(), MLGPU_LAYOUT_VOICE_MAJOR, q0.data(), MLGPU_LAYOUT_QUAD, V, T));
+    prog.process({&q0}, {&o0, &o1});
+    if (mlgpu_engine_get_flush_denormals(eng.handle())) throw std::logic_error("the engine's mode leaked out of VoiceProgram::process");
+    eng.check(mlgpu_layout_convert(eng.handle(), o0.data(), MLGPU_LAYOUT_QUAD, vm0.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, T));
+    eng.check(mlgpu_layout_convert(eng.handle(), o1.data(), MLGPU_LAYOUT_QUAD, vm1.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, T));
+    eng.check(mlgpu_download(eng.handle(), out0, vm0.data(), vm0.bytes()));
+    eng.check(mlgpu_download(eng.handle(), out1, vm1.data(), vm1.bytes()));
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
 #include <array>
 #include "dropin_synth.h"
 struct SynthGpuEvent

@@ -89,8 +89,25 @@ class _Checker:
         self._vop = fn("vop", ctypes.c_int, [ctypes.c_int, sz, sz, c_f32p, c_f32p, c_f32p])
         self._mk["linear_glide"] = (fn("linear_glide_make_coeffs", None, [f, c_f32p]), 1, 2)
         self._mk["sample_glide"] = (fn("sample_accurate_linear_glide_make_coeffs", None, [f, c_f32p]), 1, 2)
+        self._set_ftz = fn("set_flush_denormals", ctypes.c_int, [ctypes.c_int])
         self._rc = fn("range_closed", None, [f, f, c_f32p])
         self._ro = fn("range_open", None, [f, f, c_f32p])
+
+    # ---- floating-point mode ----
+    def flush_denormals(self, on=True):
+        """Context manager: run the calls inside under ml::UsingFlushDenormalsToZero (MXCSR DAZ | FZ on this thread,
+        MLDSPUtils.h:51-96). Keep the body to checker calls: numpy arithmetic on this thread sees the mode too."""
+        checker = self
+
+        class _Scope:
+            def __enter__(self_inner):
+                self_inner.prev = checker._set_ftz(1 if on else 0)
+                return checker
+
+            def __exit__(self_inner, *exc):
+                checker._set_ftz(self_inner.prev)
+                return False
+        return _Scope()
 
     # ---- elementwise ----
     def op(self, op, a, b=None, c=None):

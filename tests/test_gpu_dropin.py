@@ -25,6 +25,8 @@ def _gpu_lib():
     L.plate_gpu_run.restype = ctypes.c_int
     L.plate_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p,
                                 ctypes.c_size_t]
+    L.decay_gpu_run.restype = ctypes.c_int
+    L.decay_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t]
     L.oversample_gpu_run.restype = ctypes.c_int
     L.oversample_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
     return L
@@ -41,6 +43,8 @@ def _ref_lib():
     L.dropin_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
     L.plate_ref_run.restype = ctypes.c_int
     L.plate_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
+    L.decay_ref_run.restype = ctypes.c_int
+    L.decay_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p]
     L.oversample_ref_run.restype = ctypes.c_int
     L.oversample_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
     return L
@@ -138,6 +142,35 @@ def test_oversampled_functions_same_source_same_bits(launches):
     assert_bits_equal(got0, want0, True, "oversampled shaper")
     assert_bits_equal(got1, want1, True, "half-rate branch + mix")
     assert np.abs(want0).max() > 0.1 and np.abs(want1[:, 64:]).max() > 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flush", [0, 1])
+def test_flush_denormals_scope_same_source_same_bits(flush):
+    """tests/cpp/dropin_decay.h: a process function that opens with `UsingFlushDenormalsToZero f;` (MLDSPUtils.h:51-96, as
+    examples/audio-and-midi/fdtd.cpp:161) around recurrences that ring out for 1500 DSPVectors after a short burst —
+    compiled unchanged against the reference (MXCSR FZ | DAZ inside the scope) and against the shim (the captured program
+    runs in the engine's flush mode); and the same body without the scope, whose tails cross the denormal range."""
+    from inputs import lcg_noise
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    V, T = 48, 1500
+    in0 = np.zeros((V, 64 * T), np.float32)
+    in0[:, :128] = lcg_noise(np.arange(V, dtype=np.uint32) + 3, 128) * np.linspace(0.05, 1.0, V, dtype=np.float32)[:, None]
+    want0, want1 = np.zeros_like(in0), np.zeros_like(in0)
+    assert Lr.decay_ref_run(V, T, flush, in0.ctypes.data_as(c_f32p), want0.ctypes.data_as(c_f32p), want1.ctypes.data_as(c_f32p)) == 0
+    got0, got1 = np.zeros_like(in0), np.zeros_like(in0)
+    err = ctypes.create_string_buffer(4096)
+    used = ctypes.c_int(-1)
+    st = Lg.decay_gpu_run(V, T, flush, in0.ctypes.data_as(c_f32p), got0.ctypes.data_as(c_f32p), got1.ctypes.data_as(c_f32p), ctypes.byref(used), err, 4096)
+    assert st == 0, err.value.decode()
+    assert used.value == flush                      # the capture saw (or did not see) the scope object
+    assert_bits_equal(got0, want0, True, f"low copy of the ringing filter, flush={flush}")
+    assert_bits_equal(got1, want1, True, f"feedback path, flush={flush}")
+    tiny = lambda a: int(((np.abs(a) > 0) & (np.abs(a) < np.float32(1.17549435e-38))).sum())   # noqa: E731
+    if flush:
+        assert tiny(want0) == 0 and tiny(want1) == 0
+    else:
+        assert tiny(want0) > 1000                   # the unflushed tail really lives in the denormal range
 
 
 class _Ev(ctypes.Structure):
