@@ -263,6 +263,12 @@ int mlgpu_upload(mlgpu_engine* e, void* d_dst, const void* h_src, size_t bytes);
 int mlgpu_download(mlgpu_engine* e, void* h_dst, const void* d_src, size_t bytes);
 int mlgpu_fill32(mlgpu_engine* e, void* d_dst, uint32_t value, size_t n_elems);
 
+/* validate(), the reference's debugging check (source/DSP/MLDSPOps.h:1430-1445): a sample is bad when it is NaN or larger
+ * than 1e8 in magnitude. One read-only pass over n floats of a device signal (any layout: the layout only decides what
+ * the index means); *count = how many bad samples, *first_index = flat index of the first one (~0 when none; may be NULL).
+ * Waits for the result. */
+int mlgpu_validate(mlgpu_engine* e, const float* d_signal, size_t n_elems, uint64_t* count, uint64_t* first_index);
+
 /* HIP-event timing on the engine's stream (events are created lazily, reused). */
 /* Recorded launch sequences (hipGraph). A real-time host calls the same few process functions on the same device buffers
  * every block, and with small banks those launches are launch-bound (microseconds of kernel behind ~6 us of launch each).
@@ -383,6 +389,9 @@ int mlgpu_bank_clear(mlgpu_bank* b);
  * coefficient, or one value broadcast to all voices. */
 int mlgpu_bank_set_coeff(mlgpu_bank* b, int proc_idx, int coeff_idx, const float* h_per_voice);
 int mlgpu_bank_set_coeff_uniform(mlgpu_bank* b, int proc_idx, int coeff_idx, float value);
+/* Read one coefficient of every voice back (checkpointing; and what a freshly created bank holds are the `coeffs` of a
+ * default-constructed reference object, e.g. Peak::peakHoldSamples{44100} as an int in slot 2, MLDSPFilters.h:574). */
+int mlgpu_bank_get_coeff(mlgpu_bank* b, int proc_idx, int coeff_idx, float* h_per_voice);
 
 /* Raw state access (checkpoint / resume; the reference's state is plain POD members). */
 int mlgpu_bank_get_state(mlgpu_bank* b, int proc_idx, int state_idx, uint32_t* h_per_voice);
@@ -626,7 +635,13 @@ int mlgpu_events_add_events(mlgpu_events* ev, const uint32_t* instruments, const
 int mlgpu_events_clear_events(mlgpu_events* ev);                            /* clearEvents */
 /* processVector (:376-466) for n_vectors consecutive DSPVectors; start_offset = frame of the first one in the host block.
  * d_outputs[8]: device signals of V voices x n_vectors vectors in `layout` (any may be NULL = not wanted), in the order
- * pitch, gate, vox, z, x, y, mod, elapsed time. */
+ * pitch, gate, vox, z, x, y, mod, elapsed time.
+ * Arguments are checked before any event is consumed; a later failure (allocation, upload, launch) has already advanced the
+ * host-side voice allocator and the object must be reset (mlgpu_events_set_protocol) before it is used again.
+ * BEHAVIOURAL DIFFERENCE: controller 120 ("all sound off") is ignored. The reference calls clear() there
+ * (MLEventsToSignals.cpp:749-755), which empties the event vector the enclosing loop is iterating over (undefined
+ * behaviour, :404-423) - there is no defined result to match. Send controller 123 (all notes off, reproduced) or reset
+ * the object with mlgpu_events_set_protocol to silence an instrument. */
 int mlgpu_events_process(mlgpu_events* ev, size_t n_vectors, int start_offset, float* const* d_outputs, int layout);
 
 /* ------------------------------------------------------------------------- */
@@ -715,7 +730,11 @@ int mlgpu_process_buffer_process(mlgpu_process_buffer* p, const float* const* in
 /* Sum the voices of a signal into ONE single-voice signal of 64*n_vectors floats (what a Synth does with
  * `outputs += voice` in its voice loop, source/app/MLSynth.h:43-57), optionally scaled by per-voice gains
  * (d_gains may be NULL). Summation order (deterministic, documented in DESIGN.md): pairwise tree inside each group
- * of 64 consecutive voices, then the groups left to right. */
+ * of 64 consecutive voices, then the groups left to right.
+ * The partial sums of the first stage need scratch memory: reserve it once at setup with mlgpu_mixdown_reserve for the
+ * largest (voices, vectors) a process call will pass - mlgpu_mixdown itself never allocates and returns
+ * MLGPU_ERR_INVALID when the reservation is too small. */
+int mlgpu_mixdown_reserve(mlgpu_engine* e, size_t max_voices, size_t max_vectors);
 int mlgpu_mixdown(mlgpu_engine* e, const float* d_signal, int layout, size_t n_voices, size_t n_vectors, const float* d_gains,
                   float* d_out);
 

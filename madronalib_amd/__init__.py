@@ -145,6 +145,13 @@ class Engine:
         arr = np.ascontiguousarray(arr)
         return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
 
+    def validate(self, d_signal, n_elems):
+        """ml::validate over a device signal: (number of NaN / |x| > 1e8 samples, flat index of the first or None)."""
+        cnt, first = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.L.mlgpu_validate(self.h, ctypes.c_void_p(d_signal.ptr if hasattr(d_signal, "ptr") else int(d_signal)), int(n_elems),
+                                          ctypes.byref(cnt), ctypes.byref(first)))
+        return cnt.value, (None if cnt.value == 0 else first.value)
+
     def timer_start(self):
         self._check(self.L.mlgpu_timer_start(self.h))
 
@@ -230,6 +237,10 @@ class Engine:
         arr = (ctypes.c_void_p * n_outputs)(*[b.ptr for b in outs])
         self._check(self.L.mlgpu_demultiplex(self.h, d_sel.ptr, sel.size, d_x.ptr, arr, n_outputs, x.size, 1 if linear else 0))
         return [o.download(np.float32, x.size).reshape(x.shape) for o in outs]
+
+    def mixdown_reserve(self, max_voices, max_vectors):
+        """Scratch for mixdown's partial sums: once, at setup (mlgpu_mixdown never allocates)."""
+        self._check(self.L.mlgpu_mixdown_reserve(self.h, int(max_voices), int(max_vectors)))
 
     def mixdown(self, d_signal, layout, n_voices, n_vectors, d_out, d_gains=None):
         g = lambda x: None if x is None else ctypes.c_void_p(x.ptr if hasattr(x, "ptr") else int(x))  # noqa: E731
@@ -651,6 +662,11 @@ class Bank:
             v = np.ascontiguousarray(value, np.float32)
             assert v.shape == (self.V,)
             self.engine._check(self.L.mlgpu_bank_set_coeff(self.h, proc_idx, coeff_idx, _np_ptr(v)))
+
+    def get_coeff(self, proc_idx, coeff_idx):
+        out = np.empty(self.V, np.float32)
+        self.engine._check(self.L.mlgpu_bank_get_coeff(self.h, proc_idx, coeff_idx, _np_ptr(out)))
+        return out
 
     def set_coeffs(self, proc_idx, coeffs):
         """coeffs: sequence of NC scalars (broadcast) or array [NC][V] — the reference's `coeffs` member."""

@@ -84,6 +84,7 @@ def _declare(L):
     sig("mlgpu_engine_stream", vp, [vp])
     sig("mlgpu_engine_device", i, [vp])
     sig("mlgpu_last_error", c.c_char_p, [vp])
+    sig("mlgpu_validate", i, [vp, vp, sz, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)])
     sig("mlgpu_alloc", i, [vp, sz, pp])
     sig("mlgpu_free", i, [vp, vp])
     sig("mlgpu_upload", i, [vp, vp, vp, sz])
@@ -111,6 +112,7 @@ def _declare(L):
     sig("mlgpu_bank_num_state", i, [vp, i])
     sig("mlgpu_bank_clear", i, [vp])
     sig("mlgpu_bank_set_coeff", i, [vp, i, i, vp])
+    sig("mlgpu_bank_get_coeff", i, [vp, i, i, vp])
     sig("mlgpu_bank_set_coeff_uniform", i, [vp, i, i, f])
     sig("mlgpu_bank_get_state", i, [vp, i, i, vp])
     sig("mlgpu_bank_set_state", i, [vp, i, i, vp])
@@ -160,6 +162,7 @@ def _declare(L):
     sig("mlgpu_graph_device_bytes", sz, [vp])
     sig("mlgpu_graph_set_autotune", i, [vp, i])
     sig("mlgpu_graph_tuning", i, [vp, c.POINTER(i), c.POINTER(i)])
+    sig("mlgpu_mixdown_reserve", i, [vp, sz, sz])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
     sig("mlgpu_mixdown_groups", i, [vp, vp, i, sz, sz, sz, vp, i])
     sig("mlgpu_events_create", i, [vp, sz, i, pp])

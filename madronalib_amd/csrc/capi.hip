@@ -65,7 +65,8 @@ int createEngine(int device, hipStream_t stream, bool ownStream, mlgpu_engine** 
   }
   float table[17];
   mlgpu_build_impulse_table(table);
-  if (hipMalloc((void**)&e->d_impulseTable, sizeof(table)) != hipSuccess ||
+  if (hipMalloc((void**)&e->d_validate, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void**)&e->d_impulseTable, sizeof(table)) != hipSuccess ||
       hipMemcpy(e->d_impulseTable, table, sizeof(table), hipMemcpyHostToDevice) != hipSuccess)
   {
     if (e->ownsStream) hipStreamDestroy(e->stream);
@@ -173,6 +174,7 @@ extern "C"
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->d_impulseTable) hipFree(e->d_impulseTable);
+    if (e->d_validate) hipFree(e->d_validate);
     if (e->d_mixScratch) hipFree(e->d_mixScratch);
     if (e->ownsStream) hipStreamDestroy(e->stream);
     delete e;
@@ -241,6 +243,8 @@ extern "C"
   int mlgpu_sequence_destroy(mlgpu_sequence* s)
   {
     if (!s) return MLGPU_ERR_INVALID;
+    // waiting for the stream would invalidate a capture in progress (end_recording then fails with a generic message)
+    if (s->e->recording) return fail(s->e, MLGPU_ERR_INVALID, "sequence_destroy waits for the device: not while recording a sequence");
     hipSetDevice(s->e->device);
     hipStreamSynchronize(s->e->stream);
     if (s->exec) hipGraphExecDestroy(s->exec);
@@ -272,6 +276,7 @@ extern "C"
   {
     if (!e) return MLGPU_ERR_INVALID;
     if (!d_ptr) return MLGPU_OK;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "free waits for the device: not while recording a sequence");
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     HIP_TRY(e, hipFree(d_ptr));
@@ -321,9 +326,28 @@ extern "C"
   int mlgpu_timer_stop_ms(mlgpu_engine* e, float* msOut)
   {
     if (!e || !msOut || !e->ev0) return MLGPU_ERR_INVALID;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "timer_stop waits for the device: not while recording a sequence");
     HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
     HIP_TRY(e, hipEventSynchronize(e->ev1));
     HIP_TRY(e, hipEventElapsedTime(msOut, e->ev0, e->ev1));
+    return MLGPU_OK;
+  }
+
+  int mlgpu_validate(mlgpu_engine* e, const float* d_signal, size_t n, uint64_t* count, uint64_t* firstIndex)
+  {
+    if (!e || !count) return MLGPU_ERR_INVALID;
+    *count = 0;
+    if (firstIndex) *firstIndex = ~(uint64_t)0;
+    if (n == 0) return MLGPU_OK;
+    if (!d_signal || ((uintptr_t)d_signal & 15)) return fail(e, MLGPU_ERR_INVALID, "validate: null / misaligned signal");
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "validate waits for the device: not while recording a sequence");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, mlgpu_launch_validate(d_signal, n, e->d_validate, e->stream, e->cuCount));
+    unsigned long long r[2];
+    HIP_TRY(e, hipMemcpyAsync(r, e->d_validate, sizeof(r), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    *count = r[0];
+    if (firstIndex) *firstIndex = r[1];
     return MLGPU_OK;
   }
 
@@ -459,24 +483,34 @@ extern "C"
     return MLGPU_OK;
   }
 
+  int mlgpu_mixdown_reserve(mlgpu_engine* e, size_t maxVoices, size_t maxVectors)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "mixdown_reserve allocates: not while recording a sequence");
+    const size_t need = ((maxVoices + 63) / 64) * maxVectors * 64;
+    if (need <= e->mixScratchFloats) return MLGPU_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->d_mixScratch) hipFree(e->d_mixScratch);
+    e->d_mixScratch = nullptr;
+    e->mixScratchFloats = 0;
+    const hipError_t err = hipMalloc((void**)&e->d_mixScratch, sizeof(float) * need);
+    if (err != hipSuccess) return fail(e, err == hipErrorOutOfMemory ? MLGPU_ERR_OOM : MLGPU_ERR_HIP, "mixdown_reserve: scratch allocation", err);
+    e->mixScratchFloats = need;
+    return MLGPU_OK;
+  }
+
   int mlgpu_mixdown(mlgpu_engine* e, const float* sig, int layout, size_t V, size_t T, const float* gains, float* out)
   {
     if (!e) return MLGPU_ERR_INVALID;
     if (V == 0 || T == 0) return MLGPU_OK;
     if (!sig || !out || ((uintptr_t)sig & 15) || ((uintptr_t)out & 15)) return fail(e, MLGPU_ERR_INVALID, "mixdown: null / misaligned signal");
     if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return fail(e, MLGPU_ERR_INVALID, "mixdown: bad layout");
+    // a process call never allocates (mlgpu.h: "no allocation inside process"): the partial sums live in scratch the host
+    // reserved at setup
+    if (((V + 63) / 64) * T * 64 > e->mixScratchFloats)
+      return fail(e, MLGPU_ERR_INVALID, "mixdown: call mlgpu_mixdown_reserve(engine, max voices, max vectors) at setup (process calls do not allocate)");
     HIP_TRY(e, hipSetDevice(e->device));
-    const size_t need = ((V + 63) / 64) * T * 64;
-    if (need > e->mixScratchFloats)
-    {
-      HIP_TRY(e, hipStreamSynchronize(e->stream));
-      if (e->d_mixScratch) hipFree(e->d_mixScratch);
-      e->d_mixScratch = nullptr;
-      e->mixScratchFloats = 0;
-      const hipError_t err = hipMalloc((void**)&e->d_mixScratch, sizeof(float) * need);
-      if (err != hipSuccess) return fail(e, err == hipErrorOutOfMemory ? MLGPU_ERR_OOM : MLGPU_ERR_HIP, "mixdown: scratch allocation", err);
-      e->mixScratchFloats = need;
-    }
     HIP_TRY(e, mlgpu_launch_mixdown(sig, layout, V, T, gains, e->d_mixScratch, out, e->stream, e->kflags));
     return MLGPU_OK;
   }
@@ -499,6 +533,7 @@ extern "C"
   {
     if (!b) return MLGPU_ERR_INVALID;
     mlgpu_engine* e = b->e;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "bank_destroy waits for the device: not while recording a sequence");
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
     if (b->d_coeffs) hipFree(b->d_coeffs);
@@ -667,6 +702,13 @@ extern "C"
     if (st) return st;
     if (!h) return fail(b->e, MLGPU_ERR_INVALID, "set_coeff: null");
     return mlgpu_upload(b->e, b->d_coeffs + (size_t)(b->cOff[p] + idx) * b->V, h, sizeof(float) * b->V);
+  }
+  int mlgpu_bank_get_coeff(mlgpu_bank* b, int p, int idx, float* h)
+  {
+    int st = checkSlot(b, p, idx, true);
+    if (st) return st;
+    if (!h) return fail(b->e, MLGPU_ERR_INVALID, "get_coeff: null");
+    return mlgpu_download(b->e, h, b->d_coeffs + (size_t)(b->cOff[p] + idx) * b->V, sizeof(float) * b->V);
   }
   int mlgpu_bank_set_coeff_uniform(mlgpu_bank* b, int p, int idx, float value)
   {

@@ -220,6 +220,11 @@ void mlgpu_proc_default_coeffs(int kind, float* c /*[nc]*/)
     memcpy(&c[0], &n, 4);
     c[1] = 1.f / 32;       // mDyPerVector / mDyPerSample
   }
+  if (kind == MLGPU_PROC_PEAK && nc >= 3)
+  {
+    const int32_t hold = 44100;  // peakHoldSamples{44100}, MLDSPFilters.h:574 (an int travelling in a coefficient slot)
+    memcpy(&c[2], &hold, 4);
+  }
 }
 
 // state words of a default-constructed (cleared == false) or clear()ed reference object

@@ -36,8 +36,12 @@ struct mlgpu_dspbuffer
   size_t rewind(size_t i, size_t n) const { return (i - n) & distanceMask; }
   size_t readAvailable() const
   {
+    // both acquire: the READER calls this to learn how much the writer has published (it must then see the floats the
+    // writer copied before its release store of writeIndex), the WRITER to learn how much the reader has consumed. The
+    // reference loads the write index relaxed here (MLDSPBuffer.h:136-141), which ThreadSanitizer rightly reports as a
+    // race on the ring's floats (tests/cpp/sanitize_host_test.cpp); on x86 both compile to the same plain load.
     const size_t a = readIndex.load(std::memory_order_acquire);
-    const size_t b = writeIndex.load(std::memory_order_relaxed);
+    const size_t b = writeIndex.load(std::memory_order_acquire);
     return (b - a) & distanceMask;
   }
 };
@@ -59,6 +63,7 @@ extern "C"
     if (!b) return 0;
     b->readIndex = 0;
     b->writeIndex = 0;
+    if (sizeInSamples < 0 || sizeInSamples > (1 << 30)) return 0;  // 1 << 31 does not fit the int the size is computed in
     const int bits = bitsToContain(sizeInSamples);
     size_t sz = (size_t)1 << bits;
     if (sz < MLGPU_FLOATS_PER_DSPVECTOR) sz = MLGPU_FLOATS_PER_DSPVECTOR;

@@ -1118,6 +1118,15 @@ extern "C"
     if (e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_process routes events on the host: not while recording a sequence");
     if (ev->sr == 0) return efail(ev, MLGPU_ERR_INVALID, "events_process: no sample rate (the reference does nothing, :385)");
     if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return efail(ev, MLGPU_ERR_INVALID, "events_process: bad layout");
+    // everything that can be refused is refused BEFORE the router consumes the block's note events: after this point the
+    // host-side voice allocator (keys, creatorKeyIdx, sustain pedal, lastFreeVoiceFound) has advanced, and an error return
+    // (allocation, upload, launch) leaves host and device voice state out of step - reset the object with
+    // mlgpu_events_set_protocol / a fresh mlgpu_events if that ever happens.
+    for (int r = 0; r < 8; ++r)
+    {
+      if (d_outputs[r] && ((uintptr_t)d_outputs[r] & 15)) return efail(ev, MLGPU_ERR_INVALID, "events_process: misaligned output");
+      if (d_outputs[r] && !((ev->rowMask >> r) & 1u)) return efail(ev, MLGPU_ERR_INVALID, "events_process: an output was passed for a row outside events_set_wanted_rows");
+    }
     // ---- route this launch's events into per-voice records ----
     for (uint32_t l : ev->dirtyLanes) ev->laneRecs[l].clear();
     ev->dirtyLanes.clear();
@@ -1186,12 +1195,7 @@ extern "C"
     a.recs = sg.d_recs;
     a.recStart = sg.d_recStart;
     const size_t V = ev->nInstruments * (size_t)ev->polyphony;
-    for (int r = 0; r < 8; ++r)
-    {
-      if (d_outputs[r] && ((uintptr_t)d_outputs[r] & 15)) return efail(ev, MLGPU_ERR_INVALID, "events_process: misaligned output");
-      if (d_outputs[r] && !((ev->rowMask >> r) & 1u)) return efail(ev, MLGPU_ERR_INVALID, "events_process: an output was passed for a row outside events_set_wanted_rows");
-      a.out[r] = makeView(d_outputs[r], layout, V, nVectors);
-    }
+    for (int r = 0; r < 8; ++r) a.out[r] = makeView(d_outputs[r], layout, V, nVectors);
     a.lanes = lanes;
     a.T = nVectors;
     a.rowMask = ev->rowMask;

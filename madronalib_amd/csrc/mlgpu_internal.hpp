@@ -22,6 +22,7 @@ struct mlgpu_engine
   bool jitEnabled{true};  // fuse unknown chains / graphs with hiprtc (mlgpu_engine_set_jit)
   float* d_mixScratch{nullptr};  // mixdown partial sums, grown on demand
   size_t mixScratchFloats{0};
+  unsigned long long* d_validate{nullptr};  // {count, first index} of mlgpu_validate, allocated with the engine
   uint32_t kflags{0};  // MLGPU_KFLAG_* handed to every arithmetic kernel (mlgpu_engine_set_flush_denormals)
   bool recording{false};  // between mlgpu_engine_begin_recording and _end_recording: launches are captured, not run
 };
@@ -83,6 +84,7 @@ hipError_t mlgpu_launch_row_reduce(int rowop, const float* rows, float* out, siz
 hipError_t mlgpu_launch_layout_convert(const float* src, int srcLayout, float* dst, int dstLayout, size_t V,
                                        size_t T, hipStream_t stream);
 hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStream_t stream);
+hipError_t mlgpu_launch_validate(const float* x, size_t n, unsigned long long* d_result, hipStream_t stream, int cuCount);
 hipError_t mlgpu_launch_rows_map(int rule, long p0, long p1, int sampleRotate, const float* src, size_t srcRows, float* dst,
                                  size_t dstRows, size_t dstOffset, size_t dstStep, size_t count, size_t groups, hipStream_t stream);
 hipError_t mlgpu_launch_rows_add(const float* rows, size_t rowsPerGroup, float* out, size_t groups, hipStream_t stream, uint32_t flags);

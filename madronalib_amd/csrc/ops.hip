@@ -564,6 +564,62 @@ hipError_t mlgpu_launch_layout_convert(const float* src, int srcLayout, float* d
   return hipGetLastError();
 }
 
+// validate(): ml::validate(DSPVector) (MLDSPOps.h:1430-1445) flags a sample that is NaN or larger than 1e8 in magnitude
+// ("maxUsefulValue"). Here: one pass over a whole signal, result[0] = how many such samples, result[1] = index of the
+// first one (~0 when none). Read-only streaming at 16 B per lane; a wave reduces with DPP-free shuffles, one atomic pair
+// per wave that found something.
+__global__ __launch_bounds__(256) void validate_kernel(const float4* x, size_t n4, size_t n, unsigned long long* result)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned long long count = 0, first = ~0ull;
+  auto bad = [](float v) { return (v != v) || (__builtin_fabsf(v) > 1e8f); };
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+  {
+    const float4 q = x[i];
+    const bool b0 = bad(q.x), b1 = bad(q.y), b2 = bad(q.z), b3 = bad(q.w);
+    if (b0 | b1 | b2 | b3)
+    {
+      count += (unsigned)b0 + (unsigned)b1 + (unsigned)b2 + (unsigned)b3;
+      const unsigned long long at = 4ull * i + (b0 ? 0 : b1 ? 1 : b2 ? 2 : 3);
+      first = at < first ? at : first;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3))   // scalar tail
+  {
+    const size_t t = 4 * n4 + threadIdx.x;
+    if (bad(((const float*)x)[t]))
+    {
+      ++count;
+      first = t < first ? (unsigned long long)t : first;
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(count != 0) == 0) return;   // the common case: nothing to report from this wave
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    count += __shfl_down(count, off, 64);
+    const unsigned long long o = __shfl_down(first, off, 64);
+    first = o < first ? o : first;
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+    atomicAdd(&result[0], count);
+    atomicMin(&result[1], first);
+  }
+}
+
+hipError_t mlgpu_launch_validate(const float* x, size_t n, unsigned long long* d_result, hipStream_t stream, int cuCount)
+{
+  const unsigned long long init[2] = {0ull, ~0ull};
+  hipError_t err = hipMemcpyAsync(d_result, init, sizeof(init), hipMemcpyHostToDevice, stream);
+  if (err != hipSuccess) return err;
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > (size_t)cuCount * 8) blocks = (size_t)cuCount * 8;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(validate_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float4*)x, n4, n, d_result);
+  return hipGetLastError();
+}
+
 hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStream_t stream)
 {
   size_t blocks = (n + 255) / 256;

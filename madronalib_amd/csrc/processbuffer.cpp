@@ -46,6 +46,11 @@ extern "C"
   int mlgpu_process_buffer_destroy(mlgpu_process_buffer* p)
   {
     if (!p) return MLGPU_ERR_INVALID;
+    if (p->e && p->e->recording)
+    {
+      p->e->lastError = "process_buffer_destroy waits for the device: not while recording a sequence";
+      return MLGPU_ERR_INVALID;
+    }
     if (p->e)
     {
       hipSetDevice(p->e->device);
@@ -63,7 +68,8 @@ extern "C"
   {
     if (!e || !out) return MLGPU_ERR_INVALID;
     *out = nullptr;
-    if (maxFrames == 0 || nInputs > 64 || nOutputs > 64)
+    // rings are sized with int arithmetic, as the reference's DSPBuffer (MLDSPBuffer.h:73-100): 2^30 frames is the limit
+    if (maxFrames == 0 || maxFrames > ((size_t)1 << 30) || nInputs > 64 || nOutputs > 64)
     {
       e->lastError = "process_buffer_create: bad sizes";
       return MLGPU_ERR_INVALID;

@@ -384,3 +384,27 @@ def test_empty_and_error_paths(eng):
     with pytest.raises(ml.MlgpuError):
         eng.bank([Proc.LOPASS], 0)
     assert eng.op(Op.ADD, np.zeros(0, np.float32), np.zeros(0, np.float32)).size == 0
+
+
+def test_default_constructed_peak_holds_for_44100_samples(eng, oracle):
+    """A bank installs the coefficients of a default-constructed reference object: Peak's third coefficient is
+    peakHoldSamples{44100} (MLDSPFilters.h:574). A host that only sets makeCoeffs' a0 / b1 must get that hold time."""
+    V, T = 70, 8
+    procs = [Proc.PEAK]
+    bank = eng.bank(procs, V)
+    a0b1 = oracle.make_coeffs("onepole", 0.01)          # Peak::makeCoeffs = the one-pole pair (:576-580)
+    bank.set_coeff(0, 0, float(a0b1[0]))
+    bank.set_coeff(0, 1, float(a0b1[1]))
+    assert (bank.get_coeff(0, 2).view(np.int32) == 44100).all()
+    co = np.zeros((3, V), np.float32)
+    co[0], co[1] = a0b1[0], a0b1[1]
+    co[2] = np.array([44100], np.int32).view(np.float32)[0]
+    st = oracle.chain_clear(procs, V)
+    x = np.zeros((V, 64 * T), np.float32)
+    x[:, :64] = lcg_noise(np.arange(V, dtype=np.uint32) + 1, 64)       # one burst, then the hold
+    got = bank.process_host(T, x, Layout.QUAD)
+    want = oracle.chain_process(procs, T, co, st, x, None)
+    assert_rel_close(got, want, HW_REL, "default Peak")
+    assert_bits_equal(bank.get_all_state(), st, False, "default Peak state")
+    assert (np.abs(got[:, -64:]) > 0).any()                              # still holding at the end (a zero hold would have decayed)
+    bank.close()

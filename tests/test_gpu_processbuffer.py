@@ -78,6 +78,14 @@ def test_mixdown_vs_oracle(eng, oracle, V, T, layout):
         d_sig = eng.alloc(sig.nbytes)
         eng.layout_convert(d_vm, Layout.VOICE_MAJOR, d_sig, layout, V, T)
     d_out = eng.alloc(4 * 64 * T)
+    if (V, T) == (4097, 1) and layout == Layout.QUAD:
+        import madronalib_amd as ml
+        small = ml.Engine(0)            # a fresh engine has reserved nothing: a process call refuses instead of allocating
+        with pytest.raises(ml.MlgpuError) as ei:
+            small.mixdown(d_sig, layout, V, T, d_out)
+        assert ei.value.status == ml.Status.ERR_INVALID and "mixdown_reserve" in str(ei.value)
+        small.close()
+    eng.mixdown_reserve(V, T)           # setup time
     for g in (None, gains):
         eng.mixdown(d_sig, layout, V, T, d_out, None if g is None else eng.to_device(g))
         got = d_out.download(np.float32, 64 * T)

@@ -106,3 +106,21 @@ def test_rows_error_paths(eng):
         eng.rows_map(RowsRule.REPEAT, 0, 0, 2, x, 4, 4, 0, 1, 4, 1)   # sample_rotate must be -1, 0, +1
     with pytest.raises(ml.MlgpuError):
         eng.multiplex(x[0], [x[0]] * 9)                       # at most 8 signals
+
+
+@pytest.mark.gpu
+def test_validate_scan(eng):
+    """mlgpu_validate = ml::validate (MLDSPOps.h:1430-1445) over a whole device signal: NaN or |x| > 1e8."""
+    rng = np.random.default_rng(12)
+    for n in (64, 64 * 1000 + 3, 64 * 40000 + 1):
+        x = (rng.standard_normal(n) * 1e3).astype(np.float32)
+        d = eng.to_device(np.concatenate([x, np.zeros(4, np.float32)]))
+        assert eng.validate(d, n) == (0, None)
+        bad = sorted(rng.choice(n, 7, replace=False).tolist())
+        vals = [np.nan, 1.5e8, -2e8, np.inf, -np.inf, np.nan, 1.0000001e8]
+        for i, v in zip(bad, vals):
+            x[i] = v
+        x[(bad[0] + 1) % n] = 1e8 if (bad[0] + 1) % n not in bad else x[(bad[0] + 1) % n]     # exactly 1e8 is still fine
+        d = eng.to_device(np.concatenate([x, np.zeros(4, np.float32)]))
+        want = int((np.isnan(x) | (np.abs(x) > np.float32(1e8))).sum())
+        assert eng.validate(d, n) == (want, bad[0])

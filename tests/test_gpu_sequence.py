@@ -35,6 +35,7 @@ def make_block(eng, V, T):
     lfo.set_input_const(np.full(V, 3.0 / 48000.0, np.float32))
     bufs = [eng.alloc(4 * n) for _ in range(5)]
     d_mix = eng.alloc(4 * T * 64)
+    eng.mixdown_reserve(V, T)
 
     def block():
         saw.process(T, bufs[0], Layout.QUAD)

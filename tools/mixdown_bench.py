@@ -15,6 +15,7 @@ d_x = eng.alloc(4 * n)
 d_x.upload(np.random.default_rng(0).standard_normal(n).astype(np.float32))
 d_o = eng.alloc(4 * T * 64)
 d_g = eng.alloc(4 * (V // 16) * T * 64)
+eng.mixdown_reserve(V, T)
 for name, fn in (("mixdown", lambda: eng.mixdown(d_x, Layout.QUAD, V, T, d_o)), ("mixdown_groups P=16", lambda: eng.mixdown_groups(d_x, Layout.QUAD, V // 16, 16, T, d_g))):
     for _ in range(3):
         fn()
