@@ -114,6 +114,8 @@ typedef enum mlgpu_op
   MLGPU_OP_UNSIGNED_INT_TO_FLOAT = 21,
   /* fused pair used by the config-2 bench: expApprox(sinApprox(x)) */
   MLGPU_OP_EXP_APPROX_OF_SIN_APPROX = 22,
+  /* the waveshape functions of MLDSPGens.h:313-369 (public free functions over a phasor on [0, 1)) */
+  MLGPU_OP_PHASOR_TO_SINE = 23,   /* phasorToSine(phasor) */
 
   /* binary float,float -> float   MLDSPOps.h:640-649 */
   MLGPU_OP_ADD = 32,
@@ -135,6 +137,7 @@ typedef enum mlgpu_op
   MLGPU_OP_GREATER_THAN_OR_EQUAL = 46,
   MLGPU_OP_LESS_THAN = 47,
   MLGPU_OP_LESS_THAN_OR_EQUAL = 48,
+  MLGPU_OP_PHASOR_TO_SAW = 49,    /* phasorToSaw(phasor, freq): band-limited by polyBLEP */
 
   /* ternary   MLDSPOps.h:744-748, 886, 917 */
   MLGPU_OP_LERP = 64,         /* lerp(a, b, mix) = a + mix*(b - a) */
@@ -142,7 +145,8 @@ typedef enum mlgpu_op
   MLGPU_OP_CLAMP = 66,        /* clamp(x, lo, hi) = min(max(x, lo), hi) */
   MLGPU_OP_WITHIN = 67,       /* mask: lo <= x < hi */
   MLGPU_OP_SELECT = 68,       /* select(a, b, maskInt): bitwise (m&a)|(~m&b) */
-  MLGPU_OP_SELECT_INT = 69
+  MLGPU_OP_SELECT_INT = 69,
+  MLGPU_OP_PHASOR_TO_PULSE = 70   /* phasorToPulse(phasor, freq, pulseWidth) */
 } mlgpu_op;
 
 /* ------------------------------------------------------------------------- */

@@ -40,72 +40,25 @@
 #include "../../mlgpu.h"
 #include "../mldsp_gpu.hpp"
 
+// Host-side scalar helpers (ml::Projection, ml::Interval, projections::*, the scalar clamp / lerp / dBToAmp ...) are not
+// part of the DSPVector engine: they are plain host code that a process function calls with floats (SURVEY §2 lists
+// MLDSPProjections.h / MLDSPScalarMath.h as out of scope). A program that uses them already has madronalib's own headers;
+// when they are on the include path AFTER this directory they are used as they are, so the numbers a process function
+// computes on the host are madronalib's own (the reference's reverb.cpp example builds its decay knob that way).
+#if defined(__has_include)
+#if __has_include("MLDSPProjections.h")
+#include "MLDSPProjections.h"
+#define MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS 1
+#endif
+#endif
+
 namespace ml
 {
 constexpr size_t kFloatsPerDSPVector = MLGPU_FLOATS_PER_DSPVECTOR;
+#ifndef MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS
 constexpr float kPi = 3.1415926535897932384626433832795f;
 constexpr float kTwoPi = kPi * 2.f;
-
-// Host-side parameter mappings used by process functions to turn knob positions into floats (MLDSPProjections.h:15-200).
-// Plain scalar code on the host, here so that such programs compile; the same formulas with the same libm calls.
-struct Interval
-{
-  float x1, x2;
-};
-inline bool within(float f, const Interval m) { return (f >= m.x1) && (f < m.x2); }
-using Projection = std::function<float(float)>;
-inline Projection compose(Projection a, Projection b)
-{
-  return [=](float x) { return a(b(x)); };
-}
-namespace projections
-{
-inline Projection constant(const float k)
-{
-  return [=](float) { return k; };
-}
-inline Projection log(Interval m)  // [0, 1] -> a logarithmic curve on [a, b], scaled back to [0, 1] (:107-124)
-{
-  const float a = m.x1, b = m.x2;
-  if (b - a == 0.f) return [=](float) { return a; };
-  if (a == 0.f) return [=](float) { return 0.f; };
-  return [=](float x) { return a * (powf((b / a), x) - 1) / (b - a); };
-}
-inline Projection exp(Interval m)  // its inverse (:128-145)
-{
-  const float a = m.x1, b = m.x2;
-  if (b - a == 0.f) return [=](float) { return a; };
-  if (a == 0.f) return [=](float) { return 0.f; };
-  return [=](float x) { return logf((x * (b - a) + a) / a) / logf(b / a); };
-}
-inline Projection linear(const Interval a, const Interval b)  // (:148-169)
-{
-  const float a1 = a.x1, a2 = a.x2, b1 = b.x1, b2 = b.x2;
-  if (a1 - a2 == 0.f) return [=](float) { return b1; };
-  return [=](float x)
-  {
-    const float m = (b2 - b1) / (a2 - a1);
-    return m * (x - a1) + b1;
-  };
-}
-inline Projection add(float f)
-{
-  return [=](float x) { return x + f; };
-}
-inline Projection intervalMap(const Interval a, const Interval b, Projection c)  // (:177-189)
-{
-  return [=](float x)
-  {
-    const float scaleA = 1 / (a.x2 - a.x1);
-    const float offsetA = (-a.x1) / (a.x2 - a.x1);
-    const float scaleB = (b.x2 - b.x1);
-    const float offsetB = b.x1;
-    return c(x * scaleA + offsetA) * scaleB + offsetB;
-  };
-}
-inline Projection unityToLogParam(Interval paramInterval) { return intervalMap({0, 1}, paramInterval, projections::log(paramInterval)); }
-inline Projection logParamToUnity(Interval paramInterval) { return intervalMap(paramInterval, {0, 1}, projections::exp(paramInterval)); }
-}  // namespace projections
+#endif
 
 namespace gpu
 {
@@ -809,45 +762,15 @@ class NoiseGen : public gpu::ProcNode<MLGPU_PROC_NOISE_GEN>
 };
 inline DSPVectorInt columnIndexInt() { return truncateFloatToInt(columnIndex()); }  // MLDSPOps.h: 0 .. 63 as integers (exact)
 
-// phasorToSine / phasorToPulse / phasorToSaw, MLDSPGens.h:313-369: public free functions, here the same expressions over the
-// shim's ops (the reference's scalar polyBLEP loop written with compares and selects: both branches are evaluated, one kept)
-inline DSPVector phasorToSine(DSPVector phasorV)
+// phasorToSine / phasorToSaw / phasorToPulse (MLDSPGens.h:313-369, public free functions over a phasor): one stateless op
+// node each. The device evaluates them with the oscillators' own per-lane code - the branch-free polyBLEP with its
+// hoisted Newton-Raphson division (mldsp_procs.hpp) - instead of the twenty-odd elementwise nodes (two IEEE divisions per
+// sample among them) the expression would expand to.
+inline DSPVector phasorToSine(DSPVector phasor) { return DSPVector(gpu::opNode(MLGPU_OP_PHASOR_TO_SINE, {phasor.sig_[0]})); }
+inline DSPVector phasorToSaw(DSPVector phasor, DSPVector freq) { return DSPVector(gpu::opNode(MLGPU_OP_PHASOR_TO_SAW, {phasor.sig_[0], freq.sig_[0]})); }
+inline DSPVector phasorToPulse(DSPVector phasor, DSPVector freq, DSPVector pulseWidth)
 {
-  // the reference's constexpr values (MLDSPGens.h:318-327). const_math::sqrt(2.0f) is itself an approximation: 0x3fb50505,
-  // not the correctly rounded 0x3fb504f3; the derived constants follow from it
-  auto bits = [](uint32_t u) {
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
-  };
-  const float sqrt2 = bits(0x3fb50505u), domain = bits(0x40b50505u), scale = bits(0x3f87c3b6u), flip = bits(0x40350505u), oneSixth = bits(0x3e2aaaabu);
-  DSPVector omegaV = phasorV * DSPVector(domain) + DSPVector(-sqrt2);
-  DSPVector triangleV = select(DSPVector(flip) - omegaV, omegaV, greaterThan(omegaV, DSPVector(sqrt2)));
-  return DSPVector(scale) * triangleV * (DSPVector(1.f) - triangleV * triangleV * DSPVector(oneSixth));
-}
-namespace gpu
-{
-inline DSPVector polyBLEP(const DSPVector phase, const DSPVector freq)  // MLDSPGens.h:285-311
-{
-  const DSPVector tl = phase / freq;
-  const DSPVector cl = tl + tl - tl * tl - DSPVector(1.0f);
-  const DSPVector th = (phase - DSPVector(1.0f)) / freq;
-  const DSPVector ch = th * th + th + th + DSPVector(1.0f);
-  return select(cl, select(ch, DSPVector(0.f), greaterThan(phase, DSPVector(1.0f) - freq)), lessThan(phase, freq));
-}
-}  // namespace gpu
-inline DSPVector phasorToPulse(DSPVector omegaV, DSPVector freqV, DSPVector pulseWidthV)
-{
-  DSPVector pulseV = select(DSPVector(-1.f), DSPVector(1.f), greaterThanOrEqual(omegaV, pulseWidthV));
-  pulseV += gpu::polyBLEP(omegaV, freqV);
-  DSPVector omegaVDown = fractionalPart(omegaV - pulseWidthV + DSPVector(1.0f));
-  pulseV -= gpu::polyBLEP(omegaVDown, freqV);
-  return pulseV;
-}
-inline DSPVector phasorToSaw(DSPVector omegaV, DSPVector freqV)
-{
-  DSPVector sawV = omegaV * DSPVector(2.f) - DSPVector(1.f);
-  return sawV - gpu::polyBLEP(omegaV, freqV);
+  return DSPVector(gpu::opNode(MLGPU_OP_PHASOR_TO_PULSE, {phasor.sig_[0], freq.sig_[0], pulseWidth.sig_[0]}));
 }
 
 class PhasorGen : public gpu::ProcNode<MLGPU_PROC_PHASOR_GEN>
@@ -1209,49 +1132,72 @@ class PitchbendableDelay : public gpu::ProcNode<MLGPU_PROC_PITCHBENDABLE_DELAY>
   }
 };
 
-// Allpass<DELAY_TYPE>, MLDSPFilters.h:1110-1160. vy1 is an ordinary DSPVector member kept between calls: the capture
-// turns it into one-vector feedback (see gpu::Capture).
+// ---- composites around a delay line with one DSPVector of loop latency -------------------------------------------------
+// Allpass<>, FDN<> and FeedbackDelayFunction(WithTap) (MLDSPFilters.h:1110-1239, MLDSPFunctional.h:262-316) all close a loop
+// through "what the delay line returned for the previous DSPVector". In the engine that is a feedback node of the graph
+// (64 state words per voice, read and rewritten in place); gpu::FeedbackLoop is that node as an object: value() is last
+// vector's signal, close(next) names the signal to keep for the next one. The classes below are wiring around it - the
+// arithmetic is the published structure of each filter (Schroeder allpass, Householder feedback matrix), evaluated in the
+// reference's operation order because the outputs are compared bit for bit.
+namespace gpu
+{
+class FeedbackLoop
+{
+  int node_;
+
+ public:
+  FeedbackLoop() : node_(Capture::get().ret(mlgpu_graph_add_feedback(Capture::get().g, nullptr))) {}
+  DSPVector value() const { return DSPVector(Sig(node_, 0.f)); }
+  void close(const DSPVector& next)
+  {
+    Capture& c = Capture::get();
+    const int st = mlgpu_graph_set_feedback(c.g, node_, next.sig_[0].id());
+    if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_graph_set_feedback: ") + mlgpu_last_error(c.eng->handle()));
+  }
+};
+}  // namespace gpu
+
+// Allpass<DELAY_TYPE>: Schroeder allpass, gain g = mGain, around DELAY_TYPE.   w = x + g d ;  y = d - g w ;  d' = line(w)
+// (with -g as the multiplier, as the reference has it). The line is shorter than the nominal delay by the loop's one
+// DSPVector of latency.
 template <typename DELAY_TYPE>
 class Allpass
 {
-  DELAY_TYPE mDelay;
-  DSPVector vy1{};
+  DELAY_TYPE line_;
+  template <class THROUGH_LINE>
+  DSPVector run(const DSPVector& x, THROUGH_LINE throughLine)
+  {
+    gpu::FeedbackLoop loop;
+    const DSPVector d = loop.value(), minusG(-mGain);
+    const DSPVector w = x - d * minusG;
+    const DSPVector y = w * minusG + d;
+    loop.close(throughLine(w));
+    return y;
+  }
 
  public:
   float mGain{0.f};
-  void setDelayInSamples(float d) { mDelay.setDelayInSamples(d - kFloatsPerDSPVector); }
-  void setMaxDelayInSamples(float d) { mDelay.setMaxDelayInSamples(d - kFloatsPerDSPVector); }
-  void clear()
+  void setDelayInSamples(float d) { line_.setDelayInSamples(d - kFloatsPerDSPVector); }
+  void setMaxDelayInSamples(float d) { line_.setMaxDelayInSamples(d - kFloatsPerDSPVector); }
+  void clear() { line_.clear(); }  // the loop's kept DSPVector starts at zero like the line
+  DSPVector operator()(const DSPVector x)
   {
-    mDelay.clear();
-    vy1 = DSPVector();
+    return run(x, [this](const DSPVector& w) { return line_(w); });
   }
-  DSPVector operator()(const DSPVector vInput)
+  DSPVector operator()(const DSPVector x, const DSPVector delayInSamples)
   {
-    DSPVector vGain(-mGain);
-    DSPVector vDelayInput = vInput - vy1 * vGain;
-    DSPVector y = vDelayInput * vGain + vy1;
-    vy1 = mDelay(vDelayInput);
-    return y;
-  }
-  DSPVector operator()(const DSPVector vInput, const DSPVector vDelayInSamples)
-  {
-    DSPVector vGain(-mGain);
-    DSPVector vDelayInput = vInput - vy1 * vGain;
-    DSPVector y = vDelayInput * vGain + vy1;
-    vy1 = mDelay(vDelayInput, vDelayInSamples - DSPVector(kFloatsPerDSPVector));
-    return y;
+    return run(x, [&](const DSPVector& w) { return line_(w, delayInSamples - DSPVector((float)kFloatsPerDSPVector)); });
   }
 };
 
-// FDN<SIZE>, MLDSPFilters.h:1162-1239. (The reference class never allocates its IntegerDelays; here each gets a ring that
-// holds the delay time it is given.)
+// FDN<SIZE>: SIZE delay lines, each followed by a OnePole and a gain, mixed back through the Householder reflection
+// v - (2 / SIZE) sum(v); even lines feed the right output, odd lines the left (whole pairs only). (The reference class
+// never allocates its IntegerDelays; here each gets a ring that holds the delay time it is given.)
 template <int SIZE>
 class FDN
 {
-  std::array<IntegerDelay, SIZE> mDelays;
-  std::array<OnePole, SIZE> mFilters;
-  std::array<DSPVector, SIZE> mDelayInputVectors{};
+  std::array<IntegerDelay, SIZE> lines_;
+  std::array<OnePole, SIZE> damping_;
 
  public:
   std::array<float, SIZE> mFeedbackGains{{0}};
@@ -1259,70 +1205,61 @@ class FDN
   {
     for (int n = 0; n < SIZE; ++n)
     {
-      int len = times[n] - kFloatsPerDSPVector;  // one DSPVector of feedback latency
-      len = len > 1 ? len : 1;
-      mDelays[n].setMaxDelayInSamples((float)len);
-      mDelays[n].setDelayInSamples(len);
+      const int len = std::max(1, (int)(times[n] - kFloatsPerDSPVector));  // the loop itself is one DSPVector long
+      lines_[n].setMaxDelayInSamples((float)len);
+      lines_[n].setDelayInSamples(len);
     }
   }
   void setFilterCutoffs(std::array<float, SIZE> omegas)
   {
-    for (int n = 0; n < SIZE; ++n) mFilters[n].coeffs = OnePole::makeCoeffs(omegas[n]);
+    for (int n = 0; n < SIZE; ++n) damping_[n].coeffs = OnePole::makeCoeffs(omegas[n]);
   }
   DSPVectorArray<2> operator()(const DSPVector x)
   {
-    for (int n = 0; n < SIZE; ++n) mDelayInputVectors[n] = mDelays[n](mDelayInputVectors[n]);
-    DSPVector sumR, sumL;
-    for (int n = 0; n < (SIZE & (~1)); ++n)
-    {
-      if (n & 1) sumL += mDelayInputVectors[n];
-      else sumR += mDelayInputVectors[n];
-    }
-    DSPVector sumOfDelays;
-    for (int n = 0; n < SIZE; ++n) sumOfDelays += mDelayInputVectors[n];
-    sumOfDelays *= DSPVector(2.0f / SIZE);
-    for (int n = 0; n < SIZE; ++n)
-    {
-      mDelayInputVectors[n] -= (sumOfDelays);
-      mDelayInputVectors[n] = mFilters[n](mDelayInputVectors[n]) * DSPVector(mFeedbackGains[n]);
-      mDelayInputVectors[n] += x;
-    }
-    return concatRows(sumL, sumR);
+    std::array<gpu::FeedbackLoop, SIZE> loops;  // what goes into line n on the next DSPVector
+    std::array<DSPVector, SIZE> taps;
+    for (int n = 0; n < SIZE; ++n) taps[n] = lines_[n](loops[n].value());
+    DSPVector left, right, total;  // each accumulates from a zero vector, in line order
+    for (int n = 0; n < (SIZE & ~1); ++n) (n & 1 ? left : right) += taps[n];
+    for (int n = 0; n < SIZE; ++n) total += taps[n];
+    total *= DSPVector(2.0f / SIZE);
+    for (int n = 0; n < SIZE; ++n) loops[n].close(damping_[n](taps[n] - total) * DSPVector(mFeedbackGains[n]) + x);
+    return concatRows(left, right);
   }
 };
 
-// FeedbackDelayFunction(WithTap), MLDSPFunctional.h:262-316
+// FeedbackDelayFunction(WithTap): y = fn(x + feedbackGain * d) ;  d' = PitchbendableDelay(y, time - one DSPVector)
 class FeedbackDelayFunction
 {
   using ProcessFn = std::function<DSPVector(const DSPVector)>;
-  PitchbendableDelay mDelay;
-  DSPVector vy1;
+  PitchbendableDelay line_;
 
  public:
   float feedbackGain{1.f};
-  void setMaxDelayInSamples(float d) { mDelay.setMaxDelayInSamples(d); }  // extension: the reference offers no way to size it
-  DSPVector operator()(const DSPVector vx, ProcessFn fn, const DSPVector vDelayTime)
+  void setMaxDelayInSamples(float d) { line_.setMaxDelayInSamples(d); }  // extension: the reference offers no way to size it
+  DSPVector operator()(const DSPVector x, ProcessFn fn, const DSPVector delayTime)
   {
-    DSPVector vFnOutput = fn(vx + vy1 * DSPVector(feedbackGain));
-    vy1 = mDelay(vFnOutput, vDelayTime - DSPVector(kFloatsPerDSPVector));
-    return vFnOutput;
+    gpu::FeedbackLoop loop;
+    const DSPVector y = fn(x + loop.value() * DSPVector(feedbackGain));
+    loop.close(line_(y, delayTime - DSPVector((float)kFloatsPerDSPVector)));
+    return y;
   }
 };
-class FeedbackDelayFunctionWithTap
+class FeedbackDelayFunctionWithTap  // fn returns what is fed back and hands the listener's signal out through its second argument
 {
   using ProcessFn = std::function<DSPVector(const DSPVector, DSPVector&)>;
-  PitchbendableDelay mDelay;
-  DSPVector vy1;
+  PitchbendableDelay line_;
 
  public:
   float feedbackGain{1.f};
-  void setMaxDelayInSamples(float d) { mDelay.setMaxDelayInSamples(d); }
-  DSPVector operator()(const DSPVector vx, ProcessFn fn, const DSPVector vDelayTime)
+  void setMaxDelayInSamples(float d) { line_.setMaxDelayInSamples(d); }
+  DSPVector operator()(const DSPVector x, ProcessFn fn, const DSPVector delayTime)
   {
-    DSPVector vOutputTap;
-    DSPVector vFeedback = fn(vx + vy1 * DSPVector(feedbackGain), vOutputTap);
-    vy1 = mDelay(vFeedback, vDelayTime - DSPVector(kFloatsPerDSPVector));
-    return vOutputTap;
+    gpu::FeedbackLoop loop;
+    DSPVector tap;
+    const DSPVector fedBack = fn(x + loop.value() * DSPVector(feedbackGain), tap);
+    loop.close(line_(fedBack, delayTime - DSPVector((float)kFloatsPerDSPVector)));
+    return tap;
   }
 };
 

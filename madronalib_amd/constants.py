@@ -47,6 +47,7 @@ class Op:
     INT_TO_FLOAT = 20
     UNSIGNED_INT_TO_FLOAT = 21
     EXP_APPROX_OF_SIN_APPROX = 22
+    PHASOR_TO_SINE = 23
     ADD = 32
     SUBTRACT = 33
     MULTIPLY = 34
@@ -64,16 +65,18 @@ class Op:
     GREATER_THAN_OR_EQUAL = 46
     LESS_THAN = 47
     LESS_THAN_OR_EQUAL = 48
+    PHASOR_TO_SAW = 49
     LERP = 64
     INVERSE_LERP = 65
     CLAMP = 66
     WITHIN = 67
     SELECT = 68
     SELECT_INT = 69
+    PHASOR_TO_PULSE = 70
 
-    UNARY = list(range(0, 23))
-    BINARY = list(range(32, 49))
-    TERNARY = list(range(64, 70))
+    UNARY = list(range(0, 24))
+    BINARY = list(range(32, 50))
+    TERNARY = list(range(64, 71))
     # hardware-approximate in the reference (rcpps / rsqrtps): 2^-11 relative tolerance
     HW_APPROX = (1, 36)
     INT_INPUT = (20, 21, 41, 42)

@@ -202,8 +202,8 @@ struct Region
 int opArity(int op) { return op >= 64 ? 3 : (op >= 32 ? 2 : 1); }
 bool opKnown(int op)
 {
-  return (op >= 0 && op <= MLGPU_OP_EXP_APPROX_OF_SIN_APPROX) || (op >= MLGPU_OP_ADD && op <= MLGPU_OP_LESS_THAN_OR_EQUAL) ||
-         (op >= MLGPU_OP_LERP && op <= MLGPU_OP_SELECT_INT);
+  return (op >= 0 && op <= MLGPU_OP_PHASOR_TO_SINE) || (op >= MLGPU_OP_ADD && op <= MLGPU_OP_PHASOR_TO_SAW) ||
+         (op >= MLGPU_OP_LERP && op <= MLGPU_OP_PHASOR_TO_PULSE);
 }
 
 std::string floatLiteral(float f)

@@ -39,26 +39,17 @@ MLD uint32_t f2u(float f) { return __float_as_uint(f); }
 // operand when either is NaN. Not fminf/fmaxf.
 // They are arithmetic-class instructions: under MXCSR.DAZ (flush mode) a denormal source is replaced by a signed zero
 // before the comparison, and that zero is what comes back. v_max_f32 x, x (canonicalize) does exactly that in flush
-// mode and is the identity for every non-NaN value in the default mode, so the select below returns what minps/maxps
-// return in either mode (tools/ftz_probe.hip, tests/test_gpu_denormals.py).
+// mode and is the identity for every non-NaN value in the default mode (tools/ftz_probe.hip, tests/test_gpu_denormals.py).
 MLD float sse_canon(float x)
 {
   float r;
   asm("v_max_f32 %0, %1, %1" : "=v"(r) : "v"(x));
   return r;
 }
-MLD float sse_min(float a, float b)
-{
-  a = sse_canon(a);
-  b = sse_canon(b);
-  return (a < b) ? a : b;
-}
-MLD float sse_max(float a, float b)
-{
-  a = sse_canon(a);
-  b = sse_canon(b);
-  return (a > b) ? a : b;
-}
+// Canonicalizing the RESULT is enough (one instruction, not two): in flush mode the compare itself already reads a
+// denormal source as a signed zero, so the same operand is selected as under DAZ, and it is then returned flushed.
+MLD float sse_min(float a, float b) { return sse_canon((a < b) ? a : b); }
+MLD float sse_max(float a, float b) { return sse_canon((a > b) ? a : b); }
 
 // _mm_cvttps_epi32 / _mm_cvtps_epi32 (MLDSPMathSSE.h:124-125): NaN and out-of-range give
 // 0x80000000 ("integer indefinite"); v_cvt_i32_f32 would saturate / give 0 instead.

@@ -5,7 +5,7 @@
 // the streaming op kernels (ops.hip) and by run-time generated graph kernels (graph.hip).
 // Compile with -ffp-contract=off (see mldsp_math.hpp).
 #pragma once
-#include "mldsp_math.hpp"
+#include "mldsp_procs.hpp"  // the oscillators' waveshape functions double as stateless ops (pulls in mldsp_math.hpp)
 #ifdef __HIPCC_RTC__
 #include "mlgpu.h"  // provided as an in-memory header by graph.hip
 #else
@@ -41,6 +41,9 @@ __device__ __forceinline__ uint32_t apply(uint32_t ua, uint32_t ub, uint32_t uc)
   else if constexpr (OP == MLGPU_OP_INT_TO_FLOAT) return f2u((float)(int32_t)ua);
   else if constexpr (OP == MLGPU_OP_UNSIGNED_INT_TO_FLOAT) return f2u(uint_to_float(ua));
   else if constexpr (OP == MLGPU_OP_EXP_APPROX_OF_SIN_APPROX) return f2u(vec_exp_approx(vec_sin_approx(a)));
+  else if constexpr (OP == MLGPU_OP_PHASOR_TO_SINE) return f2u(phasor_to_sine(a));
+  else if constexpr (OP == MLGPU_OP_PHASOR_TO_SAW) return f2u(phasor_to_saw<false, true, true>(a, b));
+  else if constexpr (OP == MLGPU_OP_PHASOR_TO_PULSE) return f2u(phasor_to_pulse<false, true, true>(a, b, c));
   else if constexpr (OP == MLGPU_OP_ADD) return f2u(a + b);
   else if constexpr (OP == MLGPU_OP_SUBTRACT) return f2u(a - b);
   else if constexpr (OP == MLGPU_OP_MULTIPLY) return f2u(a * b);

@@ -102,28 +102,110 @@ MLD float div_nr(float n, float d)
 // with a wave-uniform ballot (streamed, time-varying frequency).
 MLD bool blep_freq_is_odd(float dt) { return (dt > 0.f) && !((dt >= 0x1p-64f) && (dt <= 0x1p+64f)); }
 
+// The part of polyBLEP that depends on the frequency alone: the upper zone's edge and which division is safe. With a
+// launch-constant frequency all of it (and the reciprocal inside div_nr) leaves the sample loop; PulseGen's two
+// corrections of one sample share one.
+struct BlepFreq
+{
+  float dt, omdt;
+  bool full;  // wave-uniform: some lane's frequency needs the IEEE division
+  // laneIsOdd: something else about this lane (a phase outside [0, 1]: the stateless op forms take any float) that
+  // div_nr's operand ranges do not cover
+  template <bool FAST>
+  static MLD BlepFreq make(float dt, bool laneIsOdd = false)
+  {
+    BlepFreq f;
+    f.dt = dt;
+    f.omdt = 1.0f - dt;
+    f.full = !FAST && (__builtin_amdgcn_ballot_w64(blep_freq_is_odd(dt) || laneIsOdd) != 0);
+    return f;
+  }
+  MLD bool lo(float t) const { return t < dt; }
+  MLD bool hi(float t) const { return t > omdt; }  // only consulted when !lo (the reference's else-if)
+  // the correction for a phase already known to be in the lower (isLo) or upper zone; garbage (never used) elsewhere
+  MLD float correction(float t, bool isLo) const
+  {
+    const float num = isLo ? t : (t - 1.0f);
+    // PARITY: `t + t - t*t - 1` == fma(2, t, -(t*t)) - 1 while t + t is exact, i.e. short of overflow: |t| <= 1 for every
+    // lane of a wavefront that is not `full` (an oscillator's phase, or an op's operands inside their ranges); a `full`
+    // wavefront (some lane has absurd operands - t may be 3e38, where t + t overflows but 2t - t*t does not) takes the
+    // reference's own operation order along with its division
+    float q, twoq_qq;
+    if (full)
+    {
+      q = num / dt;
+      twoq_qq = (q + q) - q * q;
+    }
+    else
+    {
+      q = div_nr(num, dt);
+      twoq_qq = __builtin_fmaf(2.0f, q, -(q * q));
+    }
+    const float qq = q * q;
+    const float clo = twoq_qq - 1.0f;
+    const float chi = ((qq + q) + q) + 1.0f;
+    return isLo ? clo : chi;
+  }
+};
+
+// A step is near for a fraction 2 * dt of the samples; neighbouring voices have free-running phases, so for low and
+// middle frequencies most samples find no lane of the wavefront in either zone: with SKIP one scalar branch skips the
+// division and both polynomials (the skipped lanes would have selected 0 anyway). SKIP is set only where the whole
+// division is per sample (a streamed frequency: +12 % on the instrument-bank pipeline); with a launch-constant frequency
+// the remaining work is too short for a branch to pay (config 3: -7 %), so those paths keep straight-line code.
+template <bool SKIP>
+MLD float poly_blep(float t, const BlepFreq& f)
+{
+  const bool lo = f.lo(t), hi = f.hi(t);
+  if (SKIP && __builtin_amdgcn_ballot_w64(lo || hi) == 0) return 0.f;
+  const float c = f.correction(t, lo);
+  return (lo || hi) ? c : 0.f;
+}
 template <bool FAST, bool SKIP = false>
 MLD float poly_blep(float t, float dt)
 {
-  const bool lo = (t < dt);
-  const bool hi = (t > 1.0f - dt);  // only consulted when !lo (the reference's else-if)
-  // A step is near for a fraction 2 * dt of the samples; neighbouring voices have free-running phases, so for low and
-  // middle frequencies most samples find no lane of the wavefront in either zone: one scalar branch skips the division
-  // and both polynomials (the skipped lanes would have selected 0 anyway). SKIP is set only where the whole division is
-  // per sample (a streamed frequency: +12 % on the instrument-bank pipeline); with a launch-constant frequency the
-  // remaining work is too short for a branch to pay (config 3: -7 %), so those paths keep straight-line code.
-  if (SKIP && __builtin_amdgcn_ballot_w64(lo || hi) == 0) return 0.f;
-  const float num = lo ? t : (t - 1.0f);
-  float q;
-  if (!FAST && __builtin_amdgcn_ballot_w64(blep_freq_is_odd(dt)) != 0)
-    q = num / dt;
-  else
-    q = div_nr(num, dt);
-  const float qq = q * q;
-  const float clo = __builtin_fmaf(2.0f, q, -qq) - 1.0f;
-  const float chi = ((qq + q) + q) + 1.0f;
-  const float c = lo ? clo : chi;
-  return (lo || hi) ? c : 0.f;
+  return poly_blep<SKIP>(t, BlepFreq::make<FAST>(dt));
+}
+
+// phasorToSaw, MLDSPGens.h:362-369
+// ANY_PHASE: p is a caller's float, not a PhasorGen's output in [0, 1) (the op forms, mldsp_ops.hpp)
+// (div_nr wants |numerator| in [2^-31, 2] or 0: a PhasorGen's phase is a multiple of 2^-31; a caller's float may be 1e-36)
+MLD bool phase_is_odd(float p) { return !(((p >= 0x1p-31f) && (p <= 1.0f)) || (p == 0.f)); }
+
+template <bool FAST, bool SKIP = false, bool ANY_PHASE = false>
+MLD float phasor_to_saw(float p, float cps)
+{
+  // PARITY: p*2 is exact (short of overflow: then the product is inf either way), so one rounding either way
+  const float saw = ANY_PHASE ? (p * 2.f - 1.f) : __builtin_fmaf(p, 2.f, -1.f);
+  return saw - poly_blep<SKIP>(p, BlepFreq::make<FAST>(cps, ANY_PHASE && phase_is_odd(p)));
+}
+
+#ifndef MLGPU_PULSE_SINGLE_BLEP
+#define MLGPU_PULSE_SINGLE_BLEP 1
+#endif
+// phasorToPulse, MLDSPGens.h:342-358: +-1 by pulse width, plus the correction of the rising step at phase 0, minus the
+// correction of the falling step at phase = width (the phase shifted by 1 - width). Written out that is two polyBLEPs per
+// sample - but a lane is almost never inside both zones at once (only when the width is within one sample of 0 or 1), and
+// when no lane of the wavefront is, ONE evaluation serves: the phase of whichever step is near goes in, the result is
+// added or subtracted. Bits: the reference computes (pulse + c_up) - c_down with the idle correction exactly 0.f, and
+// x + 0 == x, x - 0 == x for the +-1 / finite values here, so pulse + c_up or pulse - c_down is the same float.
+template <bool FAST, bool SKIP = false, bool ANY_PHASE = false>
+MLD float phasor_to_pulse(float p, float cps, float w)
+{
+  const float pulse = (p >= w) ? -1.f : 1.f;
+  const float d = p - w + 1.0f;
+  const float down = d - (float)sse_cvtt(d);  // fractionalPart
+  const BlepFreq f = BlepFreq::make<FAST>(cps, ANY_PHASE && (phase_is_odd(p) || phase_is_odd(down)));
+  const bool loUp = f.lo(p), nearUp = loUp || f.hi(p);
+  const bool loDown = f.lo(down), nearDown = loDown || f.hi(down);
+  if (MLGPU_PULSE_SINGLE_BLEP && !(ANY_PHASE && f.full) && __builtin_amdgcn_ballot_w64(nearUp && nearDown) == 0)
+  {
+    if (SKIP && __builtin_amdgcn_ballot_w64(nearUp || nearDown) == 0) return pulse;
+    const float c = f.correction(nearDown ? down : p, nearDown ? loDown : loUp);
+    return nearDown ? (pulse - c) : (nearUp ? (pulse + c) : pulse);
+  }
+  const float cUp = f.correction(p, loUp), cDown = f.correction(down, loDown);
+  return (pulse + (nearUp ? cUp : 0.f)) - (nearDown ? cDown : 0.f);
 }
 
 MLD float phasor_to_sine(float p)  // MLDSPGens.h:316-338
@@ -189,9 +271,7 @@ struct Proc<MLGPU_PROC_SAW_GEN>  // MLDSPGens.h:395-402, phasorToSaw :362-369
   template <bool FAST, bool SKIP = false>
   MLD float step(float cps)
   {
-    const float p = phasor_next(omega32, cps);
-    const float saw = __builtin_fmaf(p, 2.f, -1.f);  // PARITY: p*2 is exact, so one rounding either way
-    return saw - poly_blep<FAST, SKIP>(p, cps);
+    return phasor_to_saw<FAST, SKIP>(phasor_next(omega32, cps), cps);
   }
   MLD float next(float cps) { return step<false, true>(cps); }
   MLD float next_fast(float cps) { return step<true>(cps); }
@@ -216,13 +296,7 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
   template <bool FAST, bool SKIP = false>
   MLD float step(float cps, float w)
   {
-    const float p = phasor_next(omega32, cps);
-    float pulse = (p >= w) ? -1.f : 1.f;
-    pulse = pulse + poly_blep<FAST, SKIP>(p, cps);
-    const float d = p - w + 1.0f;
-    const float down = d - (float)sse_cvtt(d);  // fractionalPart
-    pulse = pulse - poly_blep<FAST, SKIP>(down, cps);
-    return pulse;
+    return phasor_to_pulse<FAST, SKIP>(phasor_next(omega32, cps), cps, w);
   }
   MLD float next(float cps) { return step<false, true>(cps, width); }
   MLD float next_fast(float cps) { return step<true>(cps, width); }

@@ -484,6 +484,9 @@ hipError_t mlgpu_launch_op(int op, const void* a, const void* b, const void* c, 
     OP_CASE(MLGPU_OP_WITHIN)
     OP_CASE(MLGPU_OP_SELECT)
     OP_CASE(MLGPU_OP_SELECT_INT)
+    OP_CASE(MLGPU_OP_PHASOR_TO_SINE)
+    OP_CASE(MLGPU_OP_PHASOR_TO_SAW)
+    OP_CASE(MLGPU_OP_PHASOR_TO_PULSE)
     default: *known = false; return hipSuccess;
   }
 }

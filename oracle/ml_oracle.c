@@ -323,6 +323,11 @@ static float vec_log_approx(float val) /* :831-864 */
 /* ------------------------------------------------------------------------- */
 /* elementwise op dispatch, MLDSPOps.h:570-917                                */
 
+/* the waveshape functions (defined with the generators below) are also elementwise ops */
+static inline float phasor_to_sine(float p);
+static inline float phasor_to_saw(float p, float freq);
+static inline float phasor_to_pulse(float p, float freq, float width);
+
 static uint32_t op_scalar(int op, uint32_t ua, uint32_t ub, uint32_t uc, int* ok)
 {
   const float a = u2f(ua), b = u2f(ub), c = u2f(uc);
@@ -375,6 +380,9 @@ static uint32_t op_scalar(int op, uint32_t ua, uint32_t ub, uint32_t uc, int* ok
     case MLGPU_OP_WITHIN: return ((a >= b) && (a < c)) ? 0xFFFFFFFFu : 0u; /* :748 */
     case MLGPU_OP_SELECT:                                          /* :886 */
     case MLGPU_OP_SELECT_INT: return (uc & ua) | (~uc & ub);       /* :917 */
+    case MLGPU_OP_PHASOR_TO_SINE: return f2u(phasor_to_sine(a));              /* MLDSPGens.h:316-338 */
+    case MLGPU_OP_PHASOR_TO_SAW: return f2u(phasor_to_saw(a, b));             /* :362-369 */
+    case MLGPU_OP_PHASOR_TO_PULSE: return f2u(phasor_to_pulse(a, b, c));      /* :342-358 */
     default: *ok = 0; return 0;
   }
 }

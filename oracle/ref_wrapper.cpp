@@ -722,6 +722,9 @@ extern "C"
           yi = select(i1, i2, i3);
           intOut = true;
           break;
+        case MLGPU_OP_PHASOR_TO_SINE: y = phasorToSine(x1); break;
+        case MLGPU_OP_PHASOR_TO_SAW: y = phasorToSaw(x1, x2); break;
+        case MLGPU_OP_PHASOR_TO_PULSE: y = phasorToPulse(x1, x2, x3); break;
         default: return MLGPU_ERR_INVALID;
       }
       if (intOut)

@@ -54,6 +54,16 @@ def op_inputs(op, n=64 * 64, seed=0):
         a[n // 2:] = np.abs(a[n // 2:]) + np.float32(1e-30)
     if op in (Op.POW, Op.POW_APPROX):
         b[n // 2:] = rng.uniform(-4, 4, n - n // 2).astype(np.float32)
+    if op in (Op.PHASOR_TO_SINE, Op.PHASOR_TO_SAW, Op.PHASOR_TO_PULSE):
+        # second half: what an oscillator feeds them - a phasor on [0, 1), frequencies from tiny to Nyquist (and a few absurd
+        # ones: 0, negative, beyond 2^64, denormal), pulse widths over the whole range incl. the two edges
+        h = n - n // 2
+        a[n // 2:] = rng.random(h).astype(np.float32)
+        a[n // 2:n // 2 + 8] = np.array([0.0, 1.0 - 2.0 ** -24, 0.5, 1e-9, 2.0 ** -31, 0.999, 1e-3, 0.25], np.float32)
+        b[n // 2:] = (10.0 ** rng.uniform(-6, -0.31, h)).astype(np.float32)
+        b[n // 2 + 8:n // 2 + 16] = np.array([0.0, -0.01, 1e20, 3e-42, 0.5, 0.499, 1e-30, 2.0 ** -64], np.float32)
+        c[n // 2:] = rng.random(h).astype(np.float32)
+        c[n // 2 + 16:n // 2 + 24] = np.array([0.0, 1.0, 1e-4, 0.9999, 0.5, 0.5, 2.0, -1.0], np.float32)
     if op in Op.INT_INPUT or op == Op.SELECT_INT:
         a = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
         b = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
