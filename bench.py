@@ -46,6 +46,7 @@ WORKLOADS = {
     "cfg4": (131072, 32, 16),   # long-buffer: 512 vectors per step
     "cfg2": (65536, 1, 64),     # elementwise: 64 vector-steps per step
     "cfg5": (262144, 16, 16),   # synth16 graph: 256 vectors per step
+    "cfg5full": (262144, 16, 16),  # the same voice as SURVEY 8d lists it: + filter ADSR, cutoff exp2Approx, Lopass(x, omega, k)
     # widened rows, measured to the same bar; not BASELINE configs
     "events": (262144, 16, 8),  # EventsToSignals: 16384 instruments x 16 voices, 8 control rows out
     "resample": (262144, 32, 8),  # Downsampler, 2 octaves: 32 vectors in -> 8 out per launch
@@ -118,13 +119,14 @@ def setup_workload(eng, name, V, T, lo, total):
             eng.op_apply(Op.EXP_APPROX_OF_SIN_APPROX, d_x, None, None, d_y, n)
         return launch, 8.0 * n, "op_kernel<22>", \
             "BASELINE configs[1]: 65536 voices x 1 DSPVector elementwise expApprox(sinApprox(x)) (32 MiB: Infinity-Cache resident)", (d_x, d_y)
-    if name == "cfg5":
+    if name in ("cfg5", "cfg5full"):
         from madronalib_amd import patches
         from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
-        desc, outs = patches.synth16()
+        full = name == "cfg5full"
+        desc, outs = patches.synth16(full=full)
         g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=True)
         g.clear()
-        params, coeffs, seeds = cfg5_voice_params(lo, lo + V, total, ml)
+        params, coeffs, seeds = cfg5_voice_params(lo, lo + V, total, ml, full=full)
         for k, v in params.items():
             g.set_param(k, v if np.ndim(v) else float(v))
         for k, c in coeffs.items():
@@ -140,6 +142,11 @@ def setup_workload(eng, name, V, T, lo, total):
         # gate in + audio out per voice-sample; per launch and voice: 5 params + 14 coeffs + 19 state words
         # read, 19 state words written (patches.synth16: NC = 3+4+2+1+4, NS = 1+1+1+1+2+2+1+2+8)
         alg = 8.0 * n + V * 4.0 * (5 + 14 + 19 + 19)
+        if full:   # 9 params; coefficients: hp 4 + smooth 2 + dc 1 + two ADSRs 4 + 4 (the Lopass has none); state: + the second ADSR's 8 words
+            alg = 8.0 * n + V * 4.0 * (9 + 15 + 27 + 27)
+            return launch, alg, "mlgpu_graph_kernel", ("BASELINE configs[4] as SURVEY 8d lists it: 22 processor/op nodes per voice incl. a filter ADSR, the cutoff "
+                                                        "through exp2Approx and Lopass(x, omega, k) with per-sample coefficients (two libm sinf per sample on the "
+                                                        "device); 262144 voices/GPU, streamed gate in, audio out"), g
         return launch, alg, "mlgpu_graph_kernel", ("BASELINE configs[4]: 16-node synth patch (run-time graph fused by hiprtc), "
                                                     "262144 voices/GPU, streamed gate in, audio out"), g
     if name == "events":
@@ -379,7 +386,11 @@ def cpu_baseline_cfg2(budget_s=8.0):
             "sample": f"65536 voices x 1 DSPVector, {reps} passes, {cores} threads, best of 3 (reference ops, g++ -O2 SSE2; the data stays in the CPU caches)"}
 
 
-def cpu_baseline_cfg5(budget_s=10.0):
+def cpu_baseline_cfg5full(budget_s=10.0):
+    return cpu_baseline_cfg5(budget_s, full=True)
+
+
+def cpu_baseline_cfg5(budget_s=10.0, full=False):
     """Config 5 on the host cores: the same 16-node voice written with the reference's objects (g++ -O2), one struct per voice."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_checkers import Ref, ref_available
@@ -390,18 +401,18 @@ def cpu_baseline_cfg5(budget_s=10.0):
     ref = Ref()
     cores = os.cpu_count() or 1
     Vs = 256 * max(1, min(cores, 256))
-    params, coeffs, seeds = cfg5_voice_params(0, Vs, Vs, ml)
+    params, coeffs, seeds = cfg5_voice_params(0, Vs, Vs, ml, full=full)
 
     def run(T):
         gate = np.zeros((Vs, 64 * T), np.float32)
         gate[:, 64:] = 0.8   # every voice sounds from the second vector on
-        return ref.synth16_run(params, coeffs, seeds, gate, cores)[1]
+        return (ref.synth16full_run if full else ref.synth16_run)(params, coeffs, seeds, gate, cores)[1]
     run(4)
     t_cal = run(16)
     T = int(max(16, min(1024, 16 * budget_s / max(t_cal, 1e-6) / 3)))
     best = min(run(T) for _ in range(3))
     return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
-            "sample": f"{Vs} voices x {T} DSPVectors of the synth16 voice, {cores} threads, best of 3 (reference objects, g++ -O2 SSE2)"}
+            "sample": f"{Vs} voices x {T} DSPVectors of the synth16{' (full)' if full else ''} voice, {cores} threads, best of 3 (reference objects, g++ -O2 SSE2)"}
 
 
 VALU_PEAK_LANE_INST = 256 * 4 * 32 * 2.4e9   # 7.86e13: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
@@ -505,7 +516,8 @@ def run_rank(args, rank, local_rank, world, rdv):
                    "launches_per_step": L, "vectors_per_step": T * L, "samples_per_vector": 64,
                    "layout": "QUAD [S/4][V][4]", "parallelism": f"voices x{world} (no collective)", "launcher": rdv.kind,
                    "realtime_48k_voices": value / 48000.0,
-                   **({"graph_kernel_form": "%d voice(s) per lane, %d quad(s) per trip (tuned online)" % graphs[0].tuning()[1:]} if graphs else {})},
+                   **({"graph_kernel_form": "%d voice(s) per lane, %d quad(s) per trip (tuned online)" % graphs[0].tuning()[1:],
+                       "hiprtc": ml.jit_stats()} if graphs else {})},
         "roofline": roof,
         "ranks": ranks,
     }
@@ -528,7 +540,7 @@ def run_rank(args, rank, local_rank, world, rdv):
                     eng.op_apply(op, src, None, None, d_y, n_el)
                 per_op[f"{label} / {data}"] = n_el * reps / (eng.timer_stop_ms() * 1e-3)
         out["config"]["per_op_voice_samples_per_s"] = per_op
-    baselines = {"cfg2": cpu_baseline_cfg2, "cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5}
+    baselines = {"cfg2": cpu_baseline_cfg2, "cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5, "cfg5full": cpu_baseline_cfg5full}
     if world == 1 and not args.no_cpu_baseline and args.workload in baselines:
         try:
             out["cpu_baseline"] = baselines[args.workload]()

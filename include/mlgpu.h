@@ -579,6 +579,12 @@ int mlgpu_engine_set_jit(mlgpu_engine* e, int enabled);
 /* Device-free check that the run-time code generator's output compiles for gfx950 (a chain and a
  * graph); used by the CPU build check. Writes the compiler log (if any) to `log`. */
 int mlgpu_jit_selftest(char* log, size_t log_len);
+/* Run-time fused kernels are cached twice: per process, and on disk (MLGPU_CACHE_DIR, default $XDG_CACHE_HOME/mlgpu or
+ * ~/.cache/mlgpu; "off" disables it), keyed by a hash of the generated source, the compile options, the embedded device
+ * headers and the hiprtc version - so only the first process to build a given graph pays hiprtc (0.3-2 s per kernel).
+ * Counters since the library was loaded (any pointer may be NULL): kernels compiled by hiprtc and the seconds that took,
+ * code objects read from the disk cache and the seconds that took, requests served from memory. */
+int mlgpu_jit_stats(uint64_t* compiles, uint64_t* disk_hits, uint64_t* memory_hits, double* compile_seconds, double* disk_load_seconds);
 
 /* ------------------------------------------------------------------------- */
 /* performance events -> per-voice control signals                            */
@@ -728,6 +734,17 @@ typedef struct mlgpu_process_buffer mlgpu_process_buffer;
 typedef int (*mlgpu_process_vectors_fn)(void* user, size_t n_vectors, const float* const* d_inputs, float* const* d_outputs);
 int mlgpu_process_buffer_create(mlgpu_engine* e, size_t n_inputs, size_t n_outputs, size_t max_frames, mlgpu_process_buffer** out);
 int mlgpu_process_buffer_destroy(mlgpu_process_buffer* p);
+/* Two staging sets, double buffered. on = 0 (default): a process call returns the audio of its own block - H2D copy, the
+ * callback's launches, D2H copy and a wait, i.e. the reference's behaviour exactly. on != 0: the call returns immediately
+ * with what earlier calls computed while its own block travels and runs behind the host's back (the copy of block k + 1
+ * overlaps the kernels of block k; the host thread never waits for a kernel it has just launched). The output stream is
+ * the synchronous one delayed by mlgpu_process_buffer_latency_frames() frames (the largest block, rounded up to whole
+ * DSPVectors, plus one), silence first - a fixed latency a host compensates like any plug-in's. (Its rings are larger than
+ * the reference's, so a host that overdrives those - leftovers of an out-of-phase block plus a full-size one - loses no
+ * samples here, where the reference and the synchronous mode overwrite their oldest ones.) Switch before the first process
+ * call (switching later restarts the output rings). */
+int mlgpu_process_buffer_set_pipelined(mlgpu_process_buffer* p, int on);
+size_t mlgpu_process_buffer_latency_frames(mlgpu_process_buffer* p);
 int mlgpu_process_buffer_process(mlgpu_process_buffer* p, const float* const* inputs, float* const* outputs, int n_frames,
                                  mlgpu_process_vectors_fn fn, void* user);
 

@@ -27,6 +27,15 @@ class MlgpuError(RuntimeError):
         super().__init__(f"mlgpu status {status} ({L.mlgpu_status_string(status).decode()}) {detail}")
 
 
+def jit_stats():
+    """hiprtc work since the library was loaded: kernels compiled (and seconds), disk-cache hits (and seconds), memory hits."""
+    L = _lib.load()
+    a, b, c_ = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    t, u = ctypes.c_double(), ctypes.c_double()
+    L.mlgpu_jit_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c_), ctypes.byref(t), ctypes.byref(u))
+    return dict(compiles=a.value, disk_hits=b.value, memory_hits=c_.value, compile_seconds=t.value, disk_load_seconds=u.value)
+
+
 def device_count():
     return _lib.load().mlgpu_device_count()
 
@@ -389,6 +398,13 @@ class ProcessBuffer:
             self.close()
         except Exception:
             pass
+
+    def set_pipelined(self, on=True):
+        """Double-buffered mode: a call returns at once with what earlier calls computed; fixed delay latency_frames()."""
+        self.engine._check(self.L.mlgpu_process_buffer_set_pipelined(self.h, 1 if on else 0))
+
+    def latency_frames(self):
+        return int(self.L.mlgpu_process_buffer_latency_frames(self.h))
 
     def process(self, inputs, n_frames, fn):
         """inputs: list of n_frames-float arrays (or None). Returns the list of output blocks."""

@@ -85,6 +85,7 @@ def _declare(L):
     sig("mlgpu_engine_device", i, [vp])
     sig("mlgpu_last_error", c.c_char_p, [vp])
     sig("mlgpu_validate", i, [vp, vp, sz, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)])
+    sig("mlgpu_jit_stats", i, [c.POINTER(c.c_uint64)] * 3 + [c.POINTER(c.c_double)] * 2)
     sig("mlgpu_alloc", i, [vp, sz, pp])
     sig("mlgpu_free", i, [vp, vp])
     sig("mlgpu_upload", i, [vp, vp, vp, sz])
@@ -219,6 +220,8 @@ def _declare(L):
     sig("mlgpu_dspbuffer_peek_most_recent", None, [vp, vp, sz])
     sig("mlgpu_process_buffer_create", i, [vp, sz, sz, sz, pp])
     sig("mlgpu_process_buffer_destroy", i, [vp])
+    sig("mlgpu_process_buffer_set_pipelined", i, [vp, i])
+    sig("mlgpu_process_buffer_latency_frames", sz, [vp])
     sig("mlgpu_process_buffer_process", i, [vp, pp, pp, i, vp, vp])
     sig("mlgpu_graph_set_state_uniform", i, [vp, i, i, c.c_uint32])
     sig("mlgpu_graph_set_param", i, [vp, i, vp])

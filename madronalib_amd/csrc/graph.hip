@@ -14,7 +14,12 @@
 #include <hip/hiprtc.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
 
 #include <algorithm>
 #include <functional>
@@ -51,7 +56,7 @@ bool compileToCode(const std::string& source, std::vector<char>& code, std::stri
     log = "hiprtcCreateProgram failed";
     return false;
   }
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};  // == kJitOptions (the disk cache key)
   const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
   size_t logSize = 0;
   hiprtcGetProgramLogSize(prog, &logSize);
@@ -72,9 +77,68 @@ bool compileToCode(const std::string& source, std::vector<char>& code, std::stri
   return r == HIPRTC_SUCCESS && codeSize > 0;
 }
 
-// hiprtc results by source: identical graphs (and the size probe of graph_compile) compile once per process
+// hiprtc results by source. Two levels: in memory (identical graphs and the size probe of graph_compile compile once per
+// process) and on disk (a process that starts again - a plug-in host reloading, the next benchmark run - finds the code
+// object of every graph it has built before and skips hiprtc, which takes 0.3-2 s per kernel). The disk key is a hash of
+// everything that decides the code object: the generated source, the compile options, every embedded device header and
+// the hiprtc version. Files are written to a temporary name and renamed, so concurrent processes (one rank per GPU) can
+// share the directory. MLGPU_CACHE_DIR names it (default $XDG_CACHE_HOME/mlgpu or ~/.cache/mlgpu); MLGPU_CACHE_DIR=off
+// disables the disk level.
 std::mutex g_codeMutex;
 std::map<std::string, std::vector<char>> g_codeCache;
+struct JitStats
+{
+  uint64_t compiles{0}, diskHits{0}, memoryHits{0}, diskWrites{0};
+  double compileSeconds{0}, diskLoadSeconds{0};
+} g_jitStats;
+
+const char* const kJitOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
+
+uint64_t fnv1a(uint64_t h, const void* data, size_t n)
+{
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+  return h;
+}
+
+std::string cacheDir()
+{
+  const char* d = getenv("MLGPU_CACHE_DIR");
+  if (d && !strcmp(d, "off")) return "";
+  std::string dir;
+  if (d && *d)
+    dir = d;
+  else if (const char* x = getenv("XDG_CACHE_HOME"))
+    dir = std::string(x) + "/mlgpu";
+  else if (const char* h = getenv("HOME"))
+    dir = std::string(h) + "/.cache/mlgpu";
+  else
+    return "";
+  // mkdir -p (two levels are enough for the defaults)
+  for (size_t i = 1; i <= dir.size(); ++i)
+    if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0755);
+  return dir;
+}
+
+std::string cacheFile(const std::string& source)
+{
+  static const std::string dir = cacheDir();
+  if (dir.empty()) return "";
+  uint64_t h = 0xcbf29ce484222325ull;
+  h = fnv1a(h, source.data(), source.size());
+  for (const char* o : kJitOptions) h = fnv1a(h, o, strlen(o) + 1);
+  for (int i = 0; i < mlgpu_embedded_count; ++i) h = fnv1a(h, mlgpu_embedded_sources[i], strlen(mlgpu_embedded_sources[i]) + 1);
+  int major = 0, minor = 0;
+  hiprtcVersion(&major, &minor);
+  const int ver[3] = {major, minor, MLGPU_ABI_VERSION};
+  h = fnv1a(h, ver, sizeof(ver));
+  char name[64];
+  snprintf(name, sizeof(name), "/%016llx-%zu.co", (unsigned long long)h, source.size());
+  return dir + name;
+}
+
+bool compileToCode(const std::string& source, std::vector<char>& code, std::string& log);
+
 bool getCode(const std::string& source, std::vector<char>& code, std::string& log)
 {
   {
@@ -83,10 +147,61 @@ bool getCode(const std::string& source, std::vector<char>& code, std::string& lo
     if (it != g_codeCache.end())
     {
       code = it->second;
+      ++g_jitStats.memoryHits;
       return true;
     }
   }
-  if (!compileToCode(source, code, log)) return false;
+  const std::string path = cacheFile(source);
+  bool fromDisk = false;
+  if (!path.empty())
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (FILE* f = fopen(path.c_str(), "rb"))
+    {
+      fseek(f, 0, SEEK_END);
+      const long n = ftell(f);
+      fseek(f, 0, SEEK_SET);
+      // a code object is an ELF file; anything else (a truncated write of a killed process) is ignored and rebuilt
+      if (n > 64)
+      {
+        code.resize((size_t)n);
+        fromDisk = fread(code.data(), 1, (size_t)n, f) == (size_t)n && !memcmp(code.data(), "\177ELF", 4);
+      }
+      fclose(f);
+    }
+    if (fromDisk)
+    {
+      std::lock_guard<std::mutex> lock(g_codeMutex);
+      ++g_jitStats.diskHits;
+      g_jitStats.diskLoadSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
+  if (!fromDisk)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!compileToCode(source, code, log)) return false;
+    {
+      std::lock_guard<std::mutex> lock(g_codeMutex);
+      ++g_jitStats.compiles;
+      g_jitStats.compileSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (!path.empty())
+    {
+      const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+      if (FILE* f = fopen(tmp.c_str(), "wb"))
+      {
+        const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+        fclose(f);
+        if (ok && rename(tmp.c_str(), path.c_str()) == 0)
+        {
+          std::lock_guard<std::mutex> lock(g_codeMutex);
+          ++g_jitStats.diskWrites;
+        }
+        else
+          remove(tmp.c_str());
+      }
+    }
+  }
   std::lock_guard<std::mutex> lock(g_codeMutex);
   g_codeCache[source] = code;
   return true;
@@ -749,6 +864,17 @@ hipError_t mlgpu_jit_chain_launch(void* fn, const ChainArgs& a, hipStream_t stre
 
 extern "C"
 {
+  int mlgpu_jit_stats(uint64_t* compiles, uint64_t* diskHits, uint64_t* memoryHits, double* compileSeconds, double* diskLoadSeconds)
+  {
+    std::lock_guard<std::mutex> lock(g_codeMutex);
+    if (compiles) *compiles = g_jitStats.compiles;
+    if (diskHits) *diskHits = g_jitStats.diskHits;
+    if (memoryHits) *memoryHits = g_jitStats.memoryHits;
+    if (compileSeconds) *compileSeconds = g_jitStats.compileSeconds;
+    if (diskLoadSeconds) *diskLoadSeconds = g_jitStats.diskLoadSeconds;
+    return MLGPU_OK;
+  }
+
   int mlgpu_jit_selftest(char* logOut, size_t logLen)
   {
     std::string log, all;

@@ -102,28 +102,28 @@ MLD float div_nr(float n, float d)
 // with a wave-uniform ballot (streamed, time-varying frequency).
 MLD bool blep_freq_is_odd(float dt) { return (dt > 0.f) && !((dt >= 0x1p-64f) && (dt <= 0x1p+64f)); }
 
-// The part of polyBLEP that depends on the frequency alone: the upper zone's edge and which division is safe. With a
-// launch-constant frequency all of it (and the reciprocal inside div_nr) leaves the sample loop; PulseGen's two
-// corrections of one sample share one.
+// The part of polyBLEP that depends on the frequency alone. With a launch-constant frequency all of it (and the
+// reciprocal inside div_nr) leaves the sample loop; PulseGen's two corrections of one sample share one.
+template <bool FAST>
 struct BlepFreq
 {
   float dt, omdt;
-  bool full;  // wave-uniform: some lane's frequency needs the IEEE division
-  // laneIsOdd: something else about this lane (a phase outside [0, 1]: the stateless op forms take any float) that
-  // div_nr's operand ranges do not cover
-  template <bool FAST>
-  static MLD BlepFreq make(float dt, bool laneIsOdd = false)
+  bool laneIsOdd;  // this lane's operands are outside div_nr's ranges (its frequency; for the op forms also its phase)
+  static MLD BlepFreq make(float dt, bool otherwiseOdd = false)
   {
     BlepFreq f;
     f.dt = dt;
     f.omdt = 1.0f - dt;
-    f.full = !FAST && (__builtin_amdgcn_ballot_w64(blep_freq_is_odd(dt) || laneIsOdd) != 0);
+    f.laneIsOdd = !FAST && (blep_freq_is_odd(dt) || otherwiseOdd);
     return f;
   }
   MLD bool lo(float t) const { return t < dt; }
   MLD bool hi(float t) const { return t > omdt; }  // only consulted when !lo (the reference's else-if)
+  // wave-uniform: does any lane need the IEEE division? Asked only where a correction is really evaluated (after the
+  // skip test), never on the quiet path
+  MLD bool anyLaneOdd() const { return !FAST && (__builtin_amdgcn_ballot_w64(laneIsOdd) != 0); }
   // the correction for a phase already known to be in the lower (isLo) or upper zone; garbage (never used) elsewhere
-  MLD float correction(float t, bool isLo) const
+  MLD float correction(float t, bool isLo, bool full) const
   {
     const float num = isLo ? t : (t - 1.0f);
     // PARITY: `t + t - t*t - 1` == fma(2, t, -(t*t)) - 1 while t + t is exact, i.e. short of overflow: |t| <= 1 for every
@@ -153,18 +153,18 @@ struct BlepFreq
 // division and both polynomials (the skipped lanes would have selected 0 anyway). SKIP is set only where the whole
 // division is per sample (a streamed frequency: +12 % on the instrument-bank pipeline); with a launch-constant frequency
 // the remaining work is too short for a branch to pay (config 3: -7 %), so those paths keep straight-line code.
-template <bool SKIP>
-MLD float poly_blep(float t, const BlepFreq& f)
+template <bool SKIP, bool FAST>
+MLD float poly_blep(float t, const BlepFreq<FAST>& f)
 {
   const bool lo = f.lo(t), hi = f.hi(t);
   if (SKIP && __builtin_amdgcn_ballot_w64(lo || hi) == 0) return 0.f;
-  const float c = f.correction(t, lo);
+  const float c = f.correction(t, lo, f.anyLaneOdd());
   return (lo || hi) ? c : 0.f;
 }
 template <bool FAST, bool SKIP = false>
 MLD float poly_blep(float t, float dt)
 {
-  return poly_blep<SKIP>(t, BlepFreq::make<FAST>(dt));
+  return poly_blep<SKIP>(t, BlepFreq<FAST>::make(dt));
 }
 
 // phasorToSaw, MLDSPGens.h:362-369
@@ -177,7 +177,7 @@ MLD float phasor_to_saw(float p, float cps)
 {
   // PARITY: p*2 is exact (short of overflow: then the product is inf either way), so one rounding either way
   const float saw = ANY_PHASE ? (p * 2.f - 1.f) : __builtin_fmaf(p, 2.f, -1.f);
-  return saw - poly_blep<SKIP>(p, BlepFreq::make<FAST>(cps, ANY_PHASE && phase_is_odd(p)));
+  return saw - poly_blep<SKIP>(p, BlepFreq<FAST>::make(cps, ANY_PHASE && phase_is_odd(p)));
 }
 
 #ifndef MLGPU_PULSE_SINGLE_BLEP
@@ -195,16 +195,18 @@ MLD float phasor_to_pulse(float p, float cps, float w)
   const float pulse = (p >= w) ? -1.f : 1.f;
   const float d = p - w + 1.0f;
   const float down = d - (float)sse_cvtt(d);  // fractionalPart
-  const BlepFreq f = BlepFreq::make<FAST>(cps, ANY_PHASE && (phase_is_odd(p) || phase_is_odd(down)));
+  const BlepFreq<FAST> f = BlepFreq<FAST>::make(cps, ANY_PHASE && (phase_is_odd(p) || phase_is_odd(down)));
   const bool loUp = f.lo(p), nearUp = loUp || f.hi(p);
   const bool loDown = f.lo(down), nearDown = loDown || f.hi(down);
-  if (MLGPU_PULSE_SINGLE_BLEP && !(ANY_PHASE && f.full) && __builtin_amdgcn_ballot_w64(nearUp && nearDown) == 0)
+  if (SKIP && __builtin_amdgcn_ballot_w64(nearUp || nearDown) == 0) return pulse;
+  const bool full = f.anyLaneOdd();
+  // (a `full` wavefront of the op forms may hold non-finite corrections, for which x + 0 == x does not hold: two evaluations)
+  if (MLGPU_PULSE_SINGLE_BLEP && !(ANY_PHASE && full) && __builtin_amdgcn_ballot_w64(nearUp && nearDown) == 0)
   {
-    if (SKIP && __builtin_amdgcn_ballot_w64(nearUp || nearDown) == 0) return pulse;
-    const float c = f.correction(nearDown ? down : p, nearDown ? loDown : loUp);
+    const float c = f.correction(nearDown ? down : p, nearDown ? loDown : loUp, full);
     return nearDown ? (pulse - c) : (nearUp ? (pulse + c) : pulse);
   }
-  const float cUp = f.correction(p, loUp), cDown = f.correction(down, loDown);
+  const float cUp = f.correction(p, loUp, full), cDown = f.correction(down, loDown, full);
   return (pulse + (nearUp ? cUp : 0.f)) - (nearDown ? cDown : 0.f);
 }
 

@@ -10,7 +10,7 @@ import numpy as np
 from .constants import Op, Proc
 
 
-def synth16(pitch_input=False):
+def synth16(pitch_input=False, full=False):
     """16 processor/op nodes per voice (pitch_input: `pitch` is a streamed signal, e.g. EventsToSignals' pitch row, instead of
     a per-voice constant; the oscillators then see a frequency per sample):
          pitch (param, octaves re base) -> exp2Approx -> * baseFreq  = freq (cycles/sample)
@@ -18,7 +18,11 @@ def synth16(pitch_input=False):
          osc = saw + pulse * lfo ; pre = osc + noise * noiseLevel
          Lopass -> Hipass -> OnePole -> DCBlocker
          amp ADSR(gate input) ; out = clamp(filtered * env, -1, 1)
-       inputs: gate (streamed).  params: pitch, baseFreq, width, lfoFreq, noiseLevel."""
+       inputs: gate (streamed).  params: pitch, baseFreq, width, lfoFreq, noiseLevel.
+       full=True is the patch exactly as SURVEY §8d lists it (bench.py --workload cfg5full): a second ADSR (the filter
+       envelope), the cutoff computed per sample as exp2Approx(cutoffOct + envAmount * filterEnv) * cutoffBase, and the Lopass
+       run in its per-sample-coefficient form Lopass(x, omega, k) (MLDSPFilters.h:136-152: two libm sinf per sample, restated
+       on the device). Further params: cutoffOct, envAmount, cutoffBase, resonance (k)."""
     d = [
         dict(name="gate", type="input"),
         dict(name="pitch", type="input" if pitch_input else "param"),
@@ -46,6 +50,18 @@ def synth16(pitch_input=False):
         dict(name="vca", type="op", kind=Op.MULTIPLY, inputs=["dc", "env"]),                  # 16
         dict(name="out", type="op", kind=Op.CLAMP, inputs=["vca", "lo", "hi"]),               # 17 (output clamp)
     ]
+    if full:
+        i = next(j for j, n in enumerate(d) if n["name"] == "lp")
+        d[i:i + 1] = [
+            dict(name="cutoffOct", type="param"), dict(name="envAmount", type="param"), dict(name="cutoffBase", type="param"),
+            dict(name="resonance", type="param"),
+            dict(name="fenv", type="proc", kind=Proc.ADSR, inputs=["gate"]),                        # filter envelope
+            dict(name="envOct", type="op", kind=Op.MULTIPLY, inputs=["fenv", "envAmount"]),
+            dict(name="oct", type="op", kind=Op.ADD, inputs=["cutoffOct", "envOct"]),
+            dict(name="cutRatio", type="op", kind=Op.EXP2_APPROX, inputs=["oct"]),                  # cutoff exp2Approx
+            dict(name="omega", type="op", kind=Op.MULTIPLY, inputs=["cutRatio", "cutoffBase"]),
+            dict(name="lp", type="proc", kind=Proc.LOPASS, inputs=["pre", "omega", "resonance"]),   # Lopass(x, omega, k)
+        ]
     return d, ["out"]
 
 

@@ -29,7 +29,7 @@ def cfg3_voice_params(lo, hi, total, make_bandpass_coeffs):
     return freq, np.ascontiguousarray(table[inv].T.reshape(3, -1))
 
 
-def cfg5_voice_params(lo, hi, total, ml):
+def cfg5_voice_params(lo, hi, total, ml, full=False):
     """BASELINE configs[4] (synth16 patch, madronalib_amd/patches.py) per-voice parameters for GLOBAL voices
     [lo, hi) of `total`. Every value is a pure function of the global voice index, so any sharding of the
     voice range gives the same patch per voice. Coefficients come from small tables (host libm makers are
@@ -55,6 +55,12 @@ def cfg5_voice_params(lo, hi, total, ml):
         env=pick(table(ml.ADSR.calcCoeffs, 47, lambda x: (0.0005 + 0.0095 * x, 0.002 + 0.018 * (1.0 - x), 0.2 + 0.7 * x,
                                                           0.002 + 0.028 * x, 48000.0)), 19, 47))
     seeds = (v.astype(np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+    if full:   # patches.synth16(full=True): the filter envelope and the per-sample cutoff
+        params.update(cutoffOct=(-1.0 + 3.0 * ((v * 23) % 83) / 82.0).astype(np.float32), envAmount=(0.5 + 2.5 * ((v * 31) % 79) / 78.0).astype(np.float32),
+                      cutoffBase=np.float32(400.0 / 48000.0), resonance=(0.3 + 1.2 * ((v * 43) % 73) / 72.0).astype(np.float32))
+        coeffs["fenv"] = pick(table(ml.ADSR.calcCoeffs, 41, lambda x: (0.001 + 0.02 * x, 0.01 + 0.1 * (1.0 - x), 0.1 + 0.6 * x,
+                                                                         0.01 + 0.2 * x, 48000.0)), 29, 41)
+        del coeffs["lp"]   # the Lopass gets omega and k per sample: it has no stored coefficients
     return params, coeffs, seeds
 
 

@@ -1027,6 +1027,77 @@ extern "C"
     return std::chrono::duration<double>(t1 - t0).count();
   }
 
+  // the same voice as SURVEY §8d lists it (patches.synth16(full=True)): a filter envelope, the cutoff per sample through
+  // exp2Approx, and the Lopass in its per-sample-coefficient form (MLDSPFilters.h:136-152). params [9][V] = pitch, baseFreq,
+  // width, lfoFreq, noiseLevel, cutoffOct, envAmount, cutoffBase, resonance.
+  namespace
+  {
+  struct Synth16FullVoice
+  {
+    SawGen saw;
+    PulseGen pulse;
+    SineGen lfo;
+    NoiseGen noise;
+    Lopass lp;
+    Hipass hp;
+    OnePole smooth;
+    DCBlocker dc;
+    ADSR env, fenv;
+    float pitch, baseFreq, width, lfoFreq, noiseLevel, cutoffOct, envAmount, cutoffBase, resonance;
+    DSPVector process(const DSPVector gate)
+    {
+      const DSPVector freq = exp2Approx(DSPVector(pitch)) * DSPVector(baseFreq);
+      const DSPVector vSaw = saw(freq);
+      const DSPVector vPulse = pulse(freq, DSPVector(width));
+      const DSPVector vLfo = lfo(DSPVector(lfoFreq));
+      const DSPVector vNoise = noise();
+      const DSPVector pre = (vSaw + vPulse * vLfo) + vNoise * DSPVector(noiseLevel);
+      const DSPVector omega = exp2Approx(DSPVector(cutoffOct) + fenv(gate) * DSPVector(envAmount)) * DSPVector(cutoffBase);
+      const DSPVector filtered = dc(smooth(hp(lp(pre, omega, DSPVector(resonance)))));
+      return clamp(filtered * env(gate), DSPVector(-1.f), DSPVector(1.f));
+    }
+  };
+  }  // namespace
+  double mlref_synth16full_run(size_t V, size_t T, const float* params, const float* hpC, const float* smoothC, const float* dcC, const float* envC,
+                               const float* fenvC, const uint32_t* seeds, const float* gate, float* out, int nThreads)
+  {
+    std::vector<Synth16FullVoice> vs(V);
+    for (size_t v = 0; v < V; ++v)
+    {
+      Synth16FullVoice& s = vs[v];
+      s.saw.clear();
+      s.pulse.clear();
+      s.lfo.clear();
+      s.lp.clear();
+      s.smooth.clear();
+      s.env.clear();
+      s.fenv.clear();
+      s.noise.setSeed(seeds[v]);
+      float* p[9] = {&s.pitch, &s.baseFreq, &s.width, &s.lfoFreq, &s.noiseLevel, &s.cutoffOct, &s.envAmount, &s.cutoffBase, &s.resonance};
+      for (int i = 0; i < 9; ++i) *p[i] = params[(size_t)i * V + v];
+      s.hp.coeffs = {hpC[0 * V + v], hpC[1 * V + v], hpC[2 * V + v], hpC[3 * V + v]};
+      s.smooth.coeffs = {smoothC[0 * V + v], smoothC[1 * V + v]};
+      s.dc.coeffs = dcC[v];
+      s.env.coeffs = {envC[0 * V + v], envC[1 * V + v], envC[2 * V + v], envC[3 * V + v]};
+      s.fenv.coeffs = {fenvC[0 * V + v], fenvC[1 * V + v], fenvC[2 * V + v], fenvC[3 * V + v]};
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    parallelFor(V, std::max(1, nThreads),
+                [&](size_t a, size_t b)
+                {
+                  for (size_t t = 0; t < T; ++t)
+                    for (size_t v = a; v < b; ++v)
+                    {
+                      DSPVector g;
+                      load(g, gate + (v * T + t) * kFloatsPerDSPVector);
+                      const DSPVector y = vs[v].process(g);
+                      store(y, out + (v * T + t) * kFloatsPerDSPVector);
+                    }
+                });
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
+  }
+
   // config 2: elementwise op over n elements, nThreads; returns seconds.
   double mlref_bench_op(int op, const float* in, float* out, size_t nElems, int nThreads, int reps)
   {

@@ -453,6 +453,24 @@ class Ref(_Checker):
                   _ptr(C["env"], c_f32p), seeds.ctypes.data_as(c_u32p), _ptr(gate, c_f32p), _ptr(out, c_f32p), int(n_threads))
         return out, sec
 
+    def synth16full_run(self, params, coeffs, seeds, gate, n_threads=1):
+        """patches.synth16(full=True) written with the reference's objects (mlref_synth16full_run): the patch SURVEY 8d lists,
+        with the filter envelope and Lopass(x, omega, k). coeffs: {hp, smooth, dc, env, fenv}. Returns (out, seconds)."""
+        fnc = self.lib.mlref_synth16full_run
+        fnc.restype = ctypes.c_double
+        c_u32p = ctypes.POINTER(ctypes.c_uint32)
+        fnc.argtypes = [ctypes.c_size_t, ctypes.c_size_t] + [c_f32p] * 6 + [c_u32p, c_f32p, c_f32p, ctypes.c_int]
+        gate = np.ascontiguousarray(gate, np.float32)
+        V, T = gate.shape[0], gate.shape[1] // 64
+        names = ("pitch", "baseFreq", "width", "lfoFreq", "noiseLevel", "cutoffOct", "envAmount", "cutoffBase", "resonance")
+        P = np.ascontiguousarray(np.stack([np.broadcast_to(np.asarray(params[k], np.float32), (V,)) for k in names]), np.float32)
+        C = {k: np.ascontiguousarray(coeffs[k], np.float32) for k in ("hp", "smooth", "dc", "env", "fenv")}
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        out = np.empty_like(gate)
+        sec = fnc(V, T, _ptr(P, c_f32p), _ptr(C["hp"], c_f32p), _ptr(C["smooth"], c_f32p), _ptr(C["dc"], c_f32p), _ptr(C["env"], c_f32p),
+                  _ptr(C["fenv"], c_f32p), seeds.ctypes.data_as(c_u32p), _ptr(gate, c_f32p), _ptr(out, c_f32p), int(n_threads))
+        return out, sec
+
     def rate_allpass_run(self, up, gain, max_delay, delay, one_pole_coeffs, x):
         """Upsample2xFunction<1> / Downsample2xFunction<1> around fn = OnePole(Allpass<IntegerDelay>(x)) (mlref_rate_allpass_run)."""
         fnc = self.lib.mlref_rate_allpass_run

@@ -27,7 +27,22 @@ GOLDEN_CHAINS = {
 }
 
 
+def synth16full(ref):
+    """tests/golden/synth16full.npz: patches.synth16(full=True) (the patch of SURVEY 8d) run with the reference's own objects."""
+    from inputs import gate_signal
+    from madronalib_amd.sharding import cfg5_voice_params
+    import madronalib_amd as ml
+    V, T = 6, 12
+    params, coeffs, seeds = cfg5_voice_params(0, V, V, ml, full=True)
+    gate = gate_signal(V, 64 * T, seed=21)
+    out, _ = ref.synth16full_run(params, coeffs, seeds, gate)
+    np.savez_compressed(os.path.join(HERE, "synth16full.npz"), gate=gate, out=out, seeds=seeds,
+                        **{"p_" + k: np.asarray(v, np.float32) for k, v in params.items()}, **{"c_" + k: v for k, v in coeffs.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "synth16full":   # add this one file without touching the others
+        return synth16full(Ref())
     ref = Ref()
     # ---- elementwise ops: 512 inputs each ----
     d = {}
@@ -156,7 +171,8 @@ def main():
     out, _ = ref.synth16_run(params, coeffs, seeds, gate)
     np.savez_compressed(os.path.join(HERE, "synth16.npz"), gate=gate, out=out, seeds=seeds, **{"p_" + k: np.asarray(v, np.float32) for k, v in params.items()},
                         **{"c_" + k: v for k, v in coeffs.items()})
-    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz", "resample.npz", "regions.npz", "synth16.npz"):
+    synth16full(ref)
+    for f in ("ops.npz", "chains.npz", "multi.npz", "rows.npz", "delays.npz", "resample.npz", "regions.npz", "synth16.npz", "synth16full.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

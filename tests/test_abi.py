@@ -2,15 +2,19 @@
 include/mlgpu.h declares, its enums match the Python mirror, the host-side coefficient makers
 match the oracle, and without a GPU every compute entry fails loudly (no silent fallback)."""
 import ctypes
+import json
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 from madronalib_amd import _lib, constants
 
-HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mlgpu.h")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mlgpu.h")
 
 
 def _header():
@@ -171,3 +175,42 @@ def test_offline_emit_of_const_vectors_live_constants_and_regions():
         g.set_const("x", 1.0)                        # not a const node
     with pytest.raises(ml.MlgpuError):
         g.update_constants_from(build(0.75, True))   # g itself is not compiled: nothing to update
+
+
+def test_hiprtc_disk_cache_spares_the_second_process(tmp_path):
+    """Run-time fused kernels are cached on disk under MLGPU_CACHE_DIR, keyed by source + options + embedded headers +
+    hiprtc version: the first process compiles, the next one loads the same code object without calling hiprtc; a
+    corrupted entry is ignored and rebuilt; MLGPU_CACHE_DIR=off compiles every time. (No device needed: offline emit.)"""
+    prog = r'''
+import json, sys, time
+import madronalib_amd as ml
+from madronalib_amd.constants import Op, Proc
+g = ml.Graph(ml.OfflineEngine(), 256)
+g.add("x", "input"); g.add("k", "const", value=float(sys.argv[1]))
+g.add("lp", "proc", Proc.LOPASS, ["x"]); g.add("y", "op", Op.MULTIPLY, ["lp", "k"]); g.add_output("y")
+t0 = time.perf_counter(); src, code = g.emit(); dt = time.perf_counter() - t0
+import hashlib
+print(json.dumps(dict(stats=ml.jit_stats(), seconds=dt, sha=hashlib.sha256(code).hexdigest(), n=len(code))))
+'''
+
+    def run(cache_dir, k="0.5"):
+        env = dict(os.environ, MLGPU_CACHE_DIR=str(cache_dir), PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", prog, k], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    cold = run(tmp_path)
+    assert cold["stats"]["compiles"] == 1 and cold["stats"]["disk_hits"] == 0
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".co")]
+    assert len(files) == 1
+    warm = run(tmp_path)
+    assert warm["stats"]["compiles"] == 0 and warm["stats"]["disk_hits"] == 1
+    assert warm["sha"] == cold["sha"] and warm["seconds"] < cold["seconds"]
+    other = run(tmp_path, "0.25")                    # another constant = another source = another entry
+    assert other["stats"]["compiles"] == 1 and len([f for f in os.listdir(tmp_path) if f.endswith(".co")]) == 2
+    with open(os.path.join(tmp_path, files[0]), "r+b") as f:   # a torn write: not an ELF any more
+        f.write(b"garbage!")
+    again = run(tmp_path)
+    assert again["stats"]["compiles"] == 1 and again["sha"] == cold["sha"]
+    off = run("off")
+    assert off["stats"]["compiles"] == 1 and off["stats"]["disk_hits"] == 0
+    print(f"hiprtc cold {cold['seconds']:.2f} s, warm {warm['seconds']:.3f} s")

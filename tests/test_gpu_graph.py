@@ -81,6 +81,50 @@ def test_synth16_vs_oracle(eng, oracle, layout, vpl):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("vpl", [1, 2])
+def test_synth16full_golden_and_oracle(eng, oracle, vpl):
+    """patches.synth16(full=True) = config 5 as SURVEY 8d lists it: Lopass(x, omega, k) with per-sample coefficients (device
+    libm sinf), two ADSRs, the cutoff through exp2Approx. Against the golden of the reference's own objects, and against
+    the oracle evaluator for more voices with a resumed second launch."""
+    import os
+    import madronalib_amd as ml
+    from madronalib_amd.sharding import cfg5_voice_params
+    g0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth16full.npz"))
+    desc, outs = patches.synth16(full=True)
+
+    def build(V, params, coeffs, seeds):
+        g = ml.Graph(eng, V, desc, outs, voices_per_lane=vpl)
+        g.clear()
+        for k, v in params.items():
+            g.set_param(k, v if np.ndim(v) else float(v))
+        for k, c in coeffs.items():
+            g.set_coeffs(k, [np.ascontiguousarray(row) for row in c])
+        g.set_state("noise", 0, seeds)
+        return g
+    V, T = g0["gate"].shape[0], g0["gate"].shape[1] // 64
+    params = {k[2:]: (g0[k] if g0[k].ndim else float(g0[k])) for k in g0.files if k.startswith("p_")}
+    coeffs = {k[2:]: g0[k] for k in g0.files if k.startswith("c_")}
+    g = build(V, params, coeffs, g0["seeds"])
+    half = T // 2
+    a = g.process_host(half, {"gate": np.ascontiguousarray(g0["gate"][:, :64 * half])}, Layout.QUAD)[0]
+    b = g.process_host(T - half, {"gate": np.ascontiguousarray(g0["gate"][:, 64 * half:])}, Layout.VOICE_MAJOR)[0]
+    assert_bits_equal(np.concatenate([a, b], 1), g0["out"], True, "synth16full golden")
+    g.close()
+    V, T = 300, 20
+    params, coeffs, seeds = cfg5_voice_params(1000, 1000 + V, 4096, ml, full=True)
+    g = build(V, params, coeffs, seeds)
+    states = {n["name"]: oracle.chain_clear([n["kind"]], V) for n in desc if n["type"] == "proc"}
+    states["noise"][0] = seeds
+    gate = gate_signal(V, 64 * T * 2, seed=5)
+    for call in range(2):
+        sig = {"gate": np.ascontiguousarray(gate[:, call * 64 * T:(call + 1) * 64 * T])}
+        (got,) = g.process_host(T, sig, Layout.QUAD)
+        (want,) = evaluate(oracle, desc, outs, V, T, sig, params, coeffs, states)
+        assert_bits_equal(got, want, True, f"synth16full call {call}")
+    g.close()
+
+
+@pytest.mark.gpu
 def test_synth16_golden_reference_objects(eng, oracle):
     """tests/golden/synth16.npz: the patch run with the reference's own objects (BASELINE configs[4] parameters)."""
     import os

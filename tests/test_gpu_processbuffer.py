@@ -67,6 +67,67 @@ def test_block_adaptor_matches_reference_signal_process_buffer(eng, max_frames, 
 
 
 @pytest.mark.gpu
+def _overdrives_the_reference_rings(max_frames, blocks):
+    """SignalProcessBuffer's rings hold nextpow2(max_frames) frames; a block that arrives while they still hold leftovers of an
+    out-of-phase one overwrites the oldest samples (MLDSPBuffer.h:162-167) - the reference's own glitch, which the synchronous
+    mode reproduces (previous test) and the pipelined mode, with its larger rings, does not have."""
+    ring, have = 1 << int(np.ceil(np.log2(max(max_frames, 64)))), 0
+    for b in blocks:
+        while have < b:
+            have += 64
+            if have > ring:
+                return True
+        have -= b
+    return False
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_frames,blocks", [(512, [64] * 12), (512, [100, 28, 64, 1, 511, 512, 3, 200, 64, 64, 77, 448, 64, 128]),
+                                               (1024, [1000, 24, 1024, 5, 5, 5, 900, 45, 1024]), (64, [64, 64, 10, 54, 64, 64])])
+def test_pipelined_mode_is_the_synchronous_stream_delayed(eng, max_frames, blocks):
+    """mlgpu_process_buffer_set_pipelined: two staging sets, a call returns before its own block has run. The output stream
+    must be EXACTLY the synchronous mode's (== the reference's SignalProcessBuffer, previous test) delayed by
+    latency_frames(), silence first - for any sequence of host block sizes that does not overdrive the reference's rings."""
+    import madronalib_amd as ml
+    assert not _overdrives_the_reference_rings(max_frames, blocks)
+    total = sum(blocks)
+    x = lcg_noise(np.array([11], np.uint32), total)[0]
+    desc = [dict(name="x", type="input"), dict(name="half", type="const", value=0.5),
+            dict(name="lp", type="proc", kind=Proc.LOPASS, inputs=["x"]), dict(name="y1", type="op", kind=Op.MULTIPLY, inputs=["x", "half"])]
+
+    def run(pipelined):
+        g = ml.Graph(eng, 1, desc, ["lp", "y1"])
+        g.set_coeffs("lp", ml.Lopass.makeCoeffs(0.05, 0.9))
+        pb = ml.ProcessBuffer(eng, 1, 2, max_frames)
+        if pipelined:
+            pb.set_pipelined(True)
+        calls = []
+
+        def fn(n_vectors, d_in, d_out):
+            calls.append(n_vectors)
+            g.process(n_vectors, d_in, d_out, Layout.VOICE_MAJOR, Layout.VOICE_MAJOR)
+        outs, pos = [[], []], 0
+        for b in blocks:
+            o = pb.process([x[pos:pos + b]], b, fn)
+            outs[0].append(o[0]), outs[1].append(o[1])
+            pos += b
+        lat = pb.latency_frames()
+        pb.close()
+        g.close()
+        return np.concatenate(outs[0]), np.concatenate(outs[1]), calls, lat
+    s0, s1, scalls, slat = run(False)
+    p0, p1, pcalls, plat = run(True)
+    assert slat == 0 and plat == 64 * ((max_frames + 63) // 64 + 1)
+    assert pcalls == scalls                                  # the same vectors are computed by the same calls
+    assert (p0[:plat] == 0).all() and (p1[:plat] == 0).all() if total > plat else True
+    n = total - plat
+    if n > 0:
+        assert_bits_equal(p0[plat:], s0[:n], True, "pipelined out0 == synchronous out0 delayed")
+        assert_bits_equal(p1[plat:], s1[:n], True, "pipelined out1 == synchronous out1 delayed")
+    assert np.abs(s0).max() > 0.01
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("V,T", [(1, 2), (64, 3), (100, 2), (1000, 4), (4097, 1)])
 @pytest.mark.parametrize("layout", [Layout.QUAD, Layout.ROWS, Layout.VOICE_MAJOR])
 def test_mixdown_vs_oracle(eng, oracle, V, T, layout):

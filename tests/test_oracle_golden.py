@@ -211,3 +211,23 @@ def test_synth16_golden(oracle):
     states["noise"][0] = g["seeds"]
     (got,) = evaluate(oracle, desc, outs, V, T, {"gate": g["gate"]}, params, coeffs, states)
     assert (got.view(np.uint32) == g["out"].view(np.uint32)).all()
+
+
+def test_synth16full_golden(oracle):
+    """tests/golden/synth16full.npz: the patch SURVEY 8d lists (filter envelope, per-sample cutoff through exp2Approx,
+    Lopass(x, omega, k) with its two libm sinf per sample) run with the reference's own objects; the node-by-node evaluator
+    over the plain-C oracle reproduces it bit for bit."""
+    import os
+    from graph_oracle import evaluate
+    from madronalib_amd import patches
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth16full.npz"))
+    V, T = g["gate"].shape[0], g["gate"].shape[1] // 64
+    params = {k[2:]: (g[k] if g[k].ndim else float(g[k])) for k in g.files if k.startswith("p_")}
+    coeffs = {k[2:]: g[k] for k in g.files if k.startswith("c_")}
+    desc, outs = patches.synth16(full=True)
+    assert sum(n["type"] in ("proc", "op") for n in desc) == 22
+    states = {n["name"]: oracle.chain_clear([n["kind"]], V) for n in desc if n["type"] == "proc"}
+    states["noise"][0] = g["seeds"]
+    (got,) = evaluate(oracle, desc, outs, V, T, {"gate": g["gate"]}, params, coeffs, states)
+    assert (got.view(np.uint32) == g["out"].view(np.uint32)).all()
+    assert np.abs(g["out"]).max() > 0.5
