@@ -523,11 +523,47 @@ int mlgpu_graph_add_route(mlgpu_graph* g, int route, const int* input_nodes, int
                           const char* name);
 int mlgpu_graph_add_proc(mlgpu_graph* g, int proc_kind, const int* input_nodes, int n_inputs, const char* name);
 int mlgpu_graph_add_op(mlgpu_graph* g, int op, const int* input_nodes, int n_inputs, const char* name);
+/*
+ * Processors and ops BY NAME. The reference's dynamic-proc stub registers a class under a string ("multiply",
+ * source/procs/MLProcMultiply.cpp:44-47) and names its params, inputs and outputs with strings (:12-18, :29-32). Every node
+ * kind a graph can hold has such an entry here - the reference's function / class name in lower_snake_case ("multiply",
+ * "saw_gen", "lopass", "exp2_approx", "pitchbendable_delay", ...), its input names, its coefficient names in slot order, its
+ * output name - so a host can describe a whole patch with strings (a preset, a UI) without touching an enum.
+ */
+enum { MLGPU_REGISTRY_OP = 0, MLGPU_REGISTRY_PROC = 1, MLGPU_REGISTRY_VOP = 2 };
+typedef struct mlgpu_registry_entry
+{
+  const char* name;        /* static storage */
+  int node_type;           /* MLGPU_REGISTRY_* */
+  int kind;                /* MLGPU_OP_* / MLGPU_PROC_* / MLGPU_VOP_* */
+  int n_inputs;            /* all inputs, the optional ones of the modulated forms (Lopass: omega, k) last */
+  int n_required_inputs;
+  int n_params;            /* coefficient slots (the `coeffs` member of the reference object) */
+  const char* output_name; /* "out", or "mask" for the compare ops */
+} mlgpu_registry_entry;
+int mlgpu_registry_count(void);
+int mlgpu_registry_get(int index, mlgpu_registry_entry* out);
+int mlgpu_registry_lookup(const char* name, mlgpu_registry_entry* out);       /* MLGPU_ERR_RANGE when unknown; out may be NULL */
+int mlgpu_registry_input_name(const char* name, int index, char* buf, size_t buf_len);
+int mlgpu_registry_param_name(const char* name, int index, char* buf, size_t buf_len);
+int mlgpu_registry_param_index(const char* name, const char* param);          /* coefficient slot, or < 0 */
+/* add the node `node_name` of registered kind `proc_name`; its inputs are the nodes called input_node_names[i] (in the
+ * entry's input order). Returns the node id or -status. */
+int mlgpu_graph_add_named(mlgpu_graph* g, const char* proc_name, const char* node_name, const char* const* input_node_names, int n_inputs);
+/* per-voice tables by name: a processor's coefficient (node name + coefficient name), a param node (its name).
+ * h_per_voice == NULL: `uniform` for every voice. */
+int mlgpu_graph_set_named_coeff(mlgpu_graph* g, const char* node_name, const char* coeff_name, const float* h_per_voice, float uniform);
+int mlgpu_graph_set_param_by_name(mlgpu_graph* g, const char* param_name, const float* h_per_voice, float uniform);
+
 /* Limits per graph: 16 streamed inputs, 8 controls, 8 outputs (MLGPU_ERR_UNSUPPORTED beyond). */
 int mlgpu_graph_add_output(mlgpu_graph* g, int node);
-int mlgpu_graph_node(mlgpu_graph* g, const char* name);
+int mlgpu_graph_node(mlgpu_graph* g, const char* name); /* id of the node called `name`, or < 0 */
+/* (re)name a node - e.g. a constant, which mlgpu_graph_add_const creates nameless - so that it can be wired by name */
+int mlgpu_graph_set_node_name(mlgpu_graph* g, int node, const char* name);
+/* MLGPU_PROC_* / MLGPU_OP_* / MLGPU_VOP_* of a processor / op / generator node (< 0 for inputs, params, constants ...) */
+int mlgpu_graph_node_kind(mlgpu_graph* g, int node);
 /* how many times `node` is referenced: as an input of other nodes, as a feedback source, as a graph output */
-int mlgpu_graph_node_use_count(mlgpu_graph* g, int node); /* id of the node called `name`, or < 0 */
+int mlgpu_graph_node_use_count(mlgpu_graph* g, int node);
 int mlgpu_graph_num_nodes(mlgpu_graph* g);
 /* Voices evaluated by one wavefront lane (before compile): 0 = automatic (default), 1, or 2. Two voices per lane interleave
  * two independent dependency chains, which helps arithmetic-bound graphs; results are identical. */

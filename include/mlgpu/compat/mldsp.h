@@ -45,8 +45,18 @@
 // MLDSPProjections.h / MLDSPScalarMath.h as out of scope). A program that uses them already has madronalib's own headers;
 // when they are on the include path AFTER this directory they are used as they are, so the numbers a process function
 // computes on the host are madronalib's own (the reference's reverb.cpp example builds its decay knob that way).
+// The same goes for the parameter layer (source/app/MLParameters.h: Path, Symbol, Value, ParameterDescription,
+// ParameterTree - names, ranges, normalized <-> real mappings): host-side control plane. With madronalib's source/app on the
+// include path it is used as it is and ml::SignalProcessor below offers the reference's parameter calls over it (buildParams,
+// setDefaultParams, setParamFromNormalizedValue, getParameterTree().getRealFloatValue...: what the reference's params.cpp
+// example uses); the floats a process function reads from it become constants of the captured kernel, refreshed by
+// gpu::VoiceProgram::update() when the host changes a parameter.
 #if defined(__has_include)
-#if __has_include("MLDSPProjections.h")
+#if __has_include("MLParameters.h")
+#include "MLParameters.h"  // brings MLDSPProjections.h with it
+#define MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS 1
+#define MLGPU_COMPAT_HAS_MADRONALIB_APP_HEADERS 1
+#elif __has_include("MLDSPProjections.h")
 #include "MLDSPProjections.h"
 #define MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS 1
 #endif
@@ -1471,6 +1481,7 @@ class AudioTask
   }
 };
 
+#ifndef MLGPU_COMPAT_HAS_MADRONALIB_APP_HEADERS
 // Path (source/app/MLPath.h): here only a name, as published signals use it.
 class Path
 {
@@ -1484,6 +1495,16 @@ class Path
   bool operator<(const Path& b) const { return text_ < b.text_; }
   bool operator==(const Path& b) const { return text_ == b.text_; }
 };
+namespace gpu
+{
+inline std::string pathText(const Path& p) { return p.text(); }
+}  // namespace gpu
+#else
+namespace gpu
+{
+inline std::string pathText(const Path& p) { return std::string(pathToText(p).getText()); }  // madronalib's own Path
+}  // namespace gpu
+#endif
 
 // SignalProcessor / Synth (source/app/MLSignalProcessor.h:121, MLSynth.h:26-94): the parts a DSP subclass overrides, and
 // published signals. Parameters and the plug-in adapters of the reference are host-side plumbing and not part of the shim.
@@ -1516,10 +1537,41 @@ class SignalProcessor
       if (handle_) mlgpu_published_signal_peek_latest(handle_, dest, framesRequested);
     }
   };
-  // stands in for Tree<std::unique_ptr<PublishedSignal>> (MLSignalProcessor.h:135-139, :175): operator[] and iteration
-  using PublishedSignalTree = std::map<Path, std::unique_ptr<PublishedSignal>>;
+  // stands in for Tree<std::unique_ptr<PublishedSignal>> (MLSignalProcessor.h:135-139, :175): operator[], find and iteration,
+  // keyed by the path's text (so it works with this header's own Path and with madronalib's)
+  class PublishedSignalTree
+  {
+    std::map<std::string, std::unique_ptr<PublishedSignal>> m_;
+
+   public:
+    std::unique_ptr<PublishedSignal>& operator[](const Path& p) { return m_[gpu::pathText(p)]; }
+    auto find(const Path& p) { return m_.find(gpu::pathText(p)); }
+    auto begin() { return m_.begin(); }
+    auto end() { return m_.end(); }
+    auto begin() const { return m_.begin(); }
+    auto end() const { return m_.end(); }
+    size_t size() const { return m_.size(); }
+  };
   PublishedSignalTree& getPublishedSignals() { return publishedSignals_; }
   const PublishedSignalTree& getPublishedSignals() const { return publishedSignals_; }
+
+#ifdef MLGPU_COMPAT_HAS_MADRONALIB_APP_HEADERS
+  // the parameter calls of the reference's SignalProcessor (MLSignalProcessor.h:127-170), over madronalib's own ParameterTree
+  ParameterTree& getParameterTree() { return params_; }
+  const ParameterTree& getParameterTree() const { return params_; }
+  size_t getParameterCount() const { return params_.descriptions.size(); }
+  void setParamFromNormalizedValue(Path pname, float val) { params_.setFromNormalizedValue(pname, val); }
+  void setParamFromRealValue(Path pname, float val) { params_.setFromRealValue(pname, val); }
+  void buildParams(const ParameterDescriptionList& paramList) { buildParameterTree(paramList, params_); }
+  void setDefaultParams() { setDefaults(params_); }
+  float getRealFloatParam(Path pname) { return params_.getRealFloatValueAtPath(pname); }
+  float getNormalizedFloatParam(Path pname) { return params_.getNormalizedFloatValueAtPath(pname); }
+
+ protected:
+  ParameterTree params_;
+
+ public:
+#endif
 
  protected:
   double sampleRate_{48000.0};
@@ -1542,9 +1594,9 @@ class SignalProcessor
     if ((int)CHANNELS != it->second->channels_) throw std::logic_error("mldsp GPU shim: storePublishedSignal: channel count differs from publishSignal");
     gpu::Capture& cap = gpu::Capture::get();
     for (auto& t : cap.taps)
-      if (t.name == signalName.text()) throw std::logic_error("mldsp GPU shim: one storePublishedSignal per name in the captured voice code");
+      if (t.name == gpu::pathText(signalName)) throw std::logic_error("mldsp GPU shim: one storePublishedSignal per name in the captured voice code");
     gpu::Capture::Tap tap;
-    tap.name = signalName.text();
+    tap.name = gpu::pathText(signalName);
     for (size_t c = 0; c < CHANNELS; ++c) tap.nodes.push_back(inputVec.sig_[c].id());
     cap.taps.push_back(tap);
   }
@@ -1846,7 +1898,7 @@ class SynthProgram
     eng_.check(mlgpu_events_set_wanted_rows(ev_, prog_.voiceRowMask()));  // rows processVoice never reads are not made
     for (const Capture::Tap& t : prog_.taps())
     {
-      SignalProcessor::PublishedSignal* ps = synth.getPublishedSignals()[Path(t.name)].get();
+      SignalProcessor::PublishedSignal* ps = synth.getPublishedSignals()[Path(t.name.c_str())].get();
       if (ps->handle_) throw Error(MLGPU_ERR_INVALID, "SynthProgram: this Synth's published signals already belong to another SynthProgram");
       eng_.check(mlgpu_published_signal_create(e.handle(), ps->maxFrames_, ps->maxVoices_, ps->channels_, ps->octavesDown_, &ps->handle_));
       published_.push_back(ps);

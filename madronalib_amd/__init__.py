@@ -36,6 +36,32 @@ def jit_stats():
     return dict(compiles=a.value, disk_hits=b.value, memory_hits=c_.value, compile_seconds=t.value, disk_load_seconds=u.value)
 
 
+class _RegistryEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("node_type", ctypes.c_int), ("kind", ctypes.c_int), ("n_inputs", ctypes.c_int),
+                ("n_required_inputs", ctypes.c_int), ("n_params", ctypes.c_int), ("output_name", ctypes.c_char_p)]
+
+
+def registry():
+    """Every processor / op a graph can hold, by name: {name: dict(node_type, kind, inputs [names], required_inputs, params
+    [coefficient names], output)} (mlgpu_registry_*; the naming convention of source/procs/MLProcMultiply.cpp)."""
+    L = _lib.load()
+    out = {}
+    buf = ctypes.create_string_buffer(64)
+    for i in range(L.mlgpu_registry_count()):
+        e = _RegistryEntry()
+        assert L.mlgpu_registry_get(i, ctypes.byref(e)) == 0
+        ins, pars = [], []
+        for k in range(e.n_inputs):
+            assert L.mlgpu_registry_input_name(e.name, k, buf, 64) == 0
+            ins.append(buf.value.decode())
+        for k in range(e.n_params):
+            assert L.mlgpu_registry_param_name(e.name, k, buf, 64) == 0
+            pars.append(buf.value.decode())
+        out[e.name.decode()] = dict(node_type=e.node_type, kind=e.kind, inputs=ins, required_inputs=e.n_required_inputs, params=pars,
+                                    output=e.output_name.decode())
+    return out
+
+
 def device_count():
     return _lib.load().mlgpu_device_count()
 
@@ -840,6 +866,29 @@ class Graph:
     def _id(self, ref):
         return self.ids[ref] if isinstance(ref, str) else int(ref)
 
+    # ---- everything by name (the registry: mlgpu_registry_*, source/procs/MLProcMultiply.cpp:12-18,44-47) ----
+    def add_named(self, proc_name, node_name, input_names=()):
+        """Add a node of registered kind `proc_name` ("multiply", "saw_gen", "lopass", ...) whose inputs are existing nodes, by name."""
+        arr = (ctypes.c_char_p * max(1, len(input_names)))(*[n.encode() for n in input_names])
+        return self._ret(self.L.mlgpu_graph_add_named(self.h, proc_name.encode(), node_name.encode(), arr, len(input_names)), node_name)
+
+    def set_named_coeff(self, node_name, coeff_name, value):
+        """`node.coeffs.<coeff_name> = value` (scalar: every voice; array: per voice)."""
+        if np.ndim(value):
+            v = np.ascontiguousarray(value, np.float32)
+            assert v.shape == (self.V,)
+            self._check(self.L.mlgpu_graph_set_named_coeff(self.h, node_name.encode(), coeff_name.encode(), _np_ptr(v), 0.0))
+        else:
+            self._check(self.L.mlgpu_graph_set_named_coeff(self.h, node_name.encode(), coeff_name.encode(), None, float(value)))
+
+    def set_param_by_name(self, name, value):
+        if np.ndim(value):
+            v = np.ascontiguousarray(value, np.float32)
+            assert v.shape == (self.V,)
+            self._check(self.L.mlgpu_graph_set_param_by_name(self.h, name.encode(), _np_ptr(v), 0.0))
+        else:
+            self._check(self.L.mlgpu_graph_set_param_by_name(self.h, name.encode(), None, float(value)))
+
     def _ret(self, r, name):
         if r < 0:
             raise MlgpuError(-r, self.L.mlgpu_last_error(self.engine.h).decode() if self.engine.h else "offline graph: status %d" % -r)
@@ -882,7 +931,10 @@ class Graph:
         if type == "param":
             return self._ret(self.L.mlgpu_graph_add_param(self.h, bname), name)
         if type == "const":
-            return self._ret(self.L.mlgpu_graph_add_const(self.h, float(value)), name)
+            r = self._ret(self.L.mlgpu_graph_add_const(self.h, float(value)), name)
+            if name:
+                self.L.mlgpu_graph_set_node_name(self.h, r, name.encode())   # so that add_named can wire it by name
+            return r
         if type == "const_vector":   # value: 64 floats, the same DSPVector for every voice and vector
             tbl = np.ascontiguousarray(value, np.float32)
             if tbl.shape != (64,):

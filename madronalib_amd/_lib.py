@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmlgpu.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mlgpu.h")
 
-_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "resample.hip", "events.hip", "coeffs.cpp", "dspbuffer.cpp", "processbuffer.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
+_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "resample.hip", "events.hip", "coeffs.cpp", "dspbuffer.cpp", "processbuffer.cpp", "registry.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
             "mldsp_procs.hpp", "mldsp_kernels.hpp", "mlgpu_device_args.hpp", "mlgpu_internal.hpp", "embed.py",
             "Makefile"]
 
@@ -86,6 +86,17 @@ def _declare(L):
     sig("mlgpu_last_error", c.c_char_p, [vp])
     sig("mlgpu_validate", i, [vp, vp, sz, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)])
     sig("mlgpu_jit_stats", i, [c.POINTER(c.c_uint64)] * 3 + [c.POINTER(c.c_double)] * 2)
+    sig("mlgpu_registry_count", i, [])
+    sig("mlgpu_registry_get", i, [i, vp])
+    sig("mlgpu_registry_lookup", i, [c.c_char_p, vp])
+    sig("mlgpu_registry_input_name", i, [c.c_char_p, i, c.c_char_p, sz])
+    sig("mlgpu_registry_param_name", i, [c.c_char_p, i, c.c_char_p, sz])
+    sig("mlgpu_registry_param_index", i, [c.c_char_p, c.c_char_p])
+    sig("mlgpu_graph_add_named", i, [vp, c.c_char_p, c.c_char_p, c.POINTER(c.c_char_p), i])
+    sig("mlgpu_graph_set_named_coeff", i, [vp, c.c_char_p, c.c_char_p, vp, f])
+    sig("mlgpu_graph_set_param_by_name", i, [vp, c.c_char_p, vp, f])
+    sig("mlgpu_graph_node_kind", i, [vp, i])
+    sig("mlgpu_graph_set_node_name", i, [vp, i, c.c_char_p])
     sig("mlgpu_alloc", i, [vp, sz, pp])
     sig("mlgpu_free", i, [vp, vp])
     sig("mlgpu_upload", i, [vp, vp, vp, sz])

@@ -1251,6 +1251,18 @@ extern "C"
     return -MLGPU_ERR_RANGE;
   }
   int mlgpu_graph_num_nodes(mlgpu_graph* g) { return g ? (int)g->nodes.size() : -1; }
+  int mlgpu_graph_set_node_name(mlgpu_graph* g, int node, const char* name)
+  {
+    if (!g || !name || node < 0 || node >= (int)g->nodes.size()) return MLGPU_ERR_RANGE;
+    g->nodes[(size_t)node].name = name;
+    return MLGPU_OK;
+  }
+  int mlgpu_graph_node_kind(mlgpu_graph* g, int node)
+  {
+    if (!g || node < 0 || node >= (int)g->nodes.size()) return -MLGPU_ERR_RANGE;
+    const Node& n = g->nodes[(size_t)node];
+    return (n.type == NODE_PROC || n.type == NODE_OP || n.type == NODE_VOP) ? n.kind : -MLGPU_ERR_INVALID;
+  }
   int mlgpu_graph_node_use_count(mlgpu_graph* g, int node)
   {
     if (!g || node < 0 || node >= (int)g->nodes.size()) return -MLGPU_ERR_RANGE;

@@ -24,6 +24,8 @@ def _libs():
     Lg.example_reverb_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
     Lr.example_sine_ref_run.argtypes = [ctypes.c_size_t, c_f32p, c_f32p]
     Lg.example_sine_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    Lr.example_params_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
+    Lg.example_params_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
     return Lg, Lr
 
 
@@ -32,7 +34,7 @@ def test_example_libraries_load_where_built():
     if not os.path.exists(gpu_so):
         pytest.skip("not built here")
     L = ctypes.CDLL(gpu_so)
-    assert hasattr(L, "example_reverb_gpu_run") and hasattr(L, "example_sine_gpu_run")
+    assert hasattr(L, "example_reverb_gpu_run") and hasattr(L, "example_sine_gpu_run") and hasattr(L, "example_params_gpu_run")
 
 
 @pytest.mark.gpu
@@ -70,3 +72,26 @@ def test_reference_sine_example_same_source_same_bits():
     for v in (0, 1, V - 1):
         assert_bits_equal(got0[v], want0, True, f"sine example left, voice {v}")
         assert_bits_equal(got1[v], want1, True, f"sine example right, voice {v}")
+
+
+@pytest.mark.gpu
+def test_reference_params_example_same_source_same_bits():
+    """params.cpp: a SignalProcessor subclass whose process function reads freq1 / freq2 (log ranges) / gain from its
+    ParameterTree every vector (a run-time Path and two hashed ones). The shim defers to madronalib's own host-side
+    parameter layer; the captured kernel takes parameter changes through VoiceProgram::update(). Four settings in a row, the
+    oscillators' phases carried across the changes."""
+    Lg, Lr = _libs()
+    V, S, T = 70, 4, 9
+    steps = np.array([[0, 0, 0], [0.3, 0.9, 1.0], [1.0, 0.0, 0.5], [0.51, 0.49, 0.25]], np.float32)
+    want0, want1, wr = np.zeros(64 * S * T, np.float32), np.zeros(64 * S * T, np.float32), np.zeros((S, 3), np.float32)
+    assert Lr.example_params_ref_run(S, T, steps.ctypes.data_as(c_f32p), want0.ctypes.data_as(c_f32p), want1.ctypes.data_as(c_f32p), wr.ctypes.data_as(c_f32p)) == 0
+    got0, got1, gr = np.zeros((V, 64 * S * T), np.float32), np.zeros((V, 64 * S * T), np.float32), np.zeros((S, 3), np.float32)
+    err = ctypes.create_string_buffer(4096)
+    st = Lg.example_params_gpu_run(V, S, T, steps.ctypes.data_as(c_f32p), got0.ctypes.data_as(c_f32p), got1.ctypes.data_as(c_f32p), gr.ctypes.data_as(c_f32p), err, 4096)
+    assert st == 0, err.value.decode()
+    assert_bits_equal(gr, wr, True, "real parameter values (the log and linear projections are madronalib's own on both sides)")
+    assert wr[0, 1] == np.float32(633.95734) or abs(wr[0, 1] - 633.957) < 1e-2      # freq2 at normalized 0.6 of 40..4000 Hz, log
+    for v in (0, 1, V - 1):
+        assert_bits_equal(got0[v], want0, True, f"params example left, voice {v}")
+        assert_bits_equal(got1[v], want1, True, f"params example right, voice {v}")
+    assert np.abs(want0).max() > 0.05
