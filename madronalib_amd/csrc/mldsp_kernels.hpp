@@ -119,6 +119,9 @@ __global__ __launch_bounds__(kChainBlock) void chain_kernel(const ChainArgs a)
 #ifndef MLGPU_CASCADE_PACKED
 #define MLGPU_CASCADE_PACKED 1
 #endif
+#ifndef MLGPU_CASCADE_QUADS_PER_TRIP
+#define MLGPU_CASCADE_QUADS_PER_TRIP 4
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int KIND, int N>
@@ -304,7 +307,7 @@ template <class HEAD, int KIND, int N, bool HAS_SIGNAL>
 __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
 {
   static_assert(!HEAD::kHasImpulse, "ImpulseGen heads are not supported by the cascade kernel");
-  // with B == 0 the steady loop's last prefetch (inQuad(q + A + 5 + k)) would read one quad past the input
+  // with B == 0 the steady loop's last prefetch (inQuad(q + A + QT + 1 + k)) would read one quad past the input
   static_assert((N - 1) % 4 != 0, "cascade lengths with (N - 1) % 4 == 0 need a bounded prefetch");
   apply_fp_mode(a.flags);
   size_t blk = blockIdx.x;
@@ -338,28 +341,33 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
   // prologue: ticks 0..D-1, stages 0..i active
   for (int i = 0; i < D; ++i) c.tick_masked(head.next(inAt((size_t)i)), 0, i);
 
-  // steady state: output quad q <- ticks D+4q .. D+4q+3, inputs x[4(q+A)+B+j]
+  // steady state: output quad q <- ticks D+4q .. D+4q+3, inputs x[4(q+A)+B+j]. A trip is QT output quads; the QT input
+  // loads of the NEXT trip are issued at the top of a trip and consumed a whole trip (QT * 4 ticks of arithmetic) later.
+  // QT = 4 (4 KiB of loads in flight per wave) is the measured optimum on config 4: QT = 8 takes all 256 registers and runs
+  // 0.570 ms against 0.477, QT = 16 0.491 (round 2, 131 072 channels x 32 DSPVectors) - the kernel is not waiting for its
+  // loads; it sits at 92-94 % of what the same access pattern reaches with no arithmetic at all (tools/copybench.hip).
+  constexpr int QT = MLGPU_CASCADE_QUADS_PER_TRIP;
   const size_t Q = (S - D) / 4;
   size_t q = 0;
   if constexpr (HAS_SIGNAL)
   {
-    f32x4 w[5];  // input quads q+A .. q+A+4 of the current trip (4 output quads)
-    if (Q >= 4)
+    f32x4 w[QT + 1];  // input quads q+A .. q+A+QT of the current trip
+    if (Q >= QT)
     {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) w[k] = __builtin_nontemporal_load(inQuad((size_t)(A + k)));
+      for (int k = 0; k < QT + 1; ++k) w[k] = __builtin_nontemporal_load(inQuad((size_t)(A + k)));
     }
-    for (; q + 4 <= Q; q += 4)
+    for (; q + QT <= Q; q += QT)
     {
-      const bool more = (q + 8 <= Q);
-      f32x4 nx[4];
+      const bool more = (q + 2 * QT <= Q);
+      f32x4 nx[QT];
       if (more)
       {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) nx[k] = __builtin_nontemporal_load(inQuad(q + A + 5 + k));
+        for (int k = 0; k < QT; ++k) nx[k] = __builtin_nontemporal_load(inQuad(q + A + QT + 1 + k));
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < QT; ++g)
       {
         f32x4 y;
 #pragma unroll
@@ -373,9 +381,9 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
       }
       if (more)
       {
-        w[0] = w[4];
+        w[0] = w[QT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k + 1] = nx[k];
+        for (int k = 0; k < QT; ++k) w[k + 1] = nx[k];
       }
     }
   }
