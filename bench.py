@@ -56,6 +56,15 @@ WORKLOADS = {
 }
 
 
+# What the dominant kernel of the workload being set up reads with wide coalesced loads, per launch, when that is NOT all of
+# its reads (the delay-ring graphs read 32-byte sectors at per-voice positions besides their streamed signals). rocprofv3's
+# FETCH_SIZE tallies a 128-byte request of a coalesced 16 B / lane stream at 64 B (the guide's "doubles on gfx950") but a
+# scattered sector read at its true 64 B (tools/fetchcal.hip: 1 GiB read once = 0.50 GiB counted as a stream, 0.97 GiB as
+# 64-byte sectors, 1.91 GiB as scattered 32-byte sectors - the half line that comes along is real traffic). So
+#   fetched bytes = raw + min(raw, coalesced / 2)      (everything coalesced: 2 x raw, the guide's rule)
+META = {"coalesced_read_bytes": None}
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -277,6 +286,8 @@ def setup_workload(eng, name, V, T, lo, total):
             k[0] += 1
         # in + out + one ring (write + read) + the kept DSPVector (read + write)
         alg = (8.0 + 8.0 + 8.0) * n
+        if not os.environ.get("MLGPU_UNIFORM_DELAY"):
+            META["coalesced_read_bytes"] = 8.0 * n      # x and the kept DSPVector stream in; the ring is read sector by sector
         return launch, alg, "mlgpu_graph_kernel", "plucked strings: FractionalDelay of per-voice length (55..880 Hz) -> OnePole -> feedback, 262144 voices", (g, nb)
     if name == "allpass4":
         from madronalib_amd import patches
@@ -304,6 +315,8 @@ def setup_workload(eng, name, V, T, lo, total):
             k[0] += 1
         # in + out, per allpass: two rings (write + read each) and one feedback vector (read + write)
         alg = 8.0 * n + 4 * (2 * 8.0 + 8.0) * n
+        if not os.environ.get("MLGPU_UNIFORM_DELAY"):
+            META["coalesced_read_bytes"] = (4.0 + 4 * 4.0) * n   # x and four kept DSPVectors
         return launch, alg, "mlgpu_graph_kernel", "4 x Allpass<PitchbendableDelay> in series, per-voice delay times 400..3400 samples, 16384 voices", (g, nb)
     raise SystemExit(f"unknown workload {name}")
 
@@ -495,8 +508,12 @@ def run_rank(args, rank, local_rank, world, rdv):
     units_per_launch = float(V) * T * 64
     key = workload_key(args.workload, V, T)
     pmc = pmc_record(key) or {}
+    traffic = None
+    if pmc.get("fetch_bytes_per_launch_raw") is not None:
+        raw, co = pmc["fetch_bytes_per_launch_raw"], META["coalesced_read_bytes"]
+        traffic = pmc["write_bytes_per_launch"] + (2.0 * raw if co is None else raw + min(raw, 0.5 * co))
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc.get("hbm_bytes_per_launch"), "kernel": kernel_name, "kernel_ms": kernel_ms,
+            "traffic": traffic, "kernel": kernel_name, "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes, "pmc_case": key if pmc else None}
     if pmc.get("valu_wave_insts_per_launch"):
         # the second bound (SURVEY 8d "report both bounds"): VALU issue. SQ_INSTS_VALU counts wave-instructions; x64 lanes.

@@ -25,6 +25,18 @@
  *
  * Element type is float32 (int32/uint32 for the integer ops) exactly as in the
  * reference (source/DSP/MLDSPOps.h:115-123). One DSPVector = 64 floats.
+ *
+ * Numerical contract (what "the same result as the reference" means for every compute entry below):
+ *  - every op, generator and filter returns the bits of the reference's SSE2 build, outputs and final state, for every
+ *    input including infinities, denormals and out-of-range conversions, in both floating-point modes
+ *    (mlgpu_engine_set_flush_denormals) - with two stated exceptions:
+ *  - a float result that is NaN is "some NaN": payloads and signs of NaNs are not reproduced (x86 and gfx950 propagate
+ *    them differently), so parity tests compare any NaN == any NaN; integer and mask results are exact;
+ *  - the hardware-approximate operations - MLGPU_OP_SQRT_APPROX, MLGPU_OP_DIVIDE_APPROX and the OUTPUTS of MLGPU_PROC_PEAK
+ *    and MLGPU_PROC_RMS (their state is exact) - use v_rsq_f32 / v_rcp_f32 where the reference uses x86 rsqrtps / rcpps
+ *    (12-bit tables no other hardware reproduces): relative error <= 1.5 * 2^-11 against the reference;
+ *  - a state-variable filter whose internal state has passed FLT_MAX / 2 (1.7e38: a filter that has blown up) may reach
+ *    infinity one sample later than the reference does (a fused 2 t + s where the reference rounds 2 t first).
  */
 #ifndef MLGPU_H
 #define MLGPU_H

@@ -421,9 +421,12 @@ struct Proc<MLGPU_PROC_ONE_SHOT_GEN>  // MLDSPGens.h:221-282
 // ---- SVF family (Simper), MLDSPFilters.h:51-442 ------------------------------------------
 //
 // PARITY: `ic1eq += 2.0f * t1` is evaluated as fma(2, t1, ic1eq): 2*t1 is exact in binary
-// floating point (barring overflow, where both forms give inf), so the fused form rounds
-// the same real number once and is bit-identical to mul-then-add — and one VALU op cheaper.
-// Likewise `2 * v1 - ic1eq` == fma(2, v1, -ic1eq).
+// floating point while it is finite, so the fused form rounds the same real number once and is
+// bit-identical to mul-then-add — and one VALU op cheaper. Likewise `2 * v1 - ic1eq` ==
+// fma(2, v1, -ic1eq). The one place the two differ: |t1| > FLT_MAX / 2 (1.7e38) with ic1eq of the
+// opposite sign - there 2*t1 alone overflows to inf in the reference while the exact sum is still
+// finite (tools/ftz_probe.hip shows the pair 7f7fffff / ff7fffff). A filter in that state is one
+// doubling away from inf either way; the public contract (mlgpu.h) names the case.
 
 template <int KIND>
 struct SvfCore

@@ -50,7 +50,8 @@ def main():
             continue
         kernel = max(cands, key=lambda k: cands[k]["hbm_bytes_per_launch"])
         rec = {"kernel": kernel, "hbm_bytes_per_launch": cands[kernel]["hbm_bytes_per_launch"],
-               "fetch_bytes_per_launch_corrected": cands[kernel]["fetch_bytes_per_launch_corrected"],
+               "fetch_bytes_per_launch_raw": cands[kernel]["fetch_bytes_per_launch_corrected"] / 2.0,   # FETCH_SIZE x 1024, as counted
+               "fetch_bytes_per_launch_corrected": cands[kernel]["fetch_bytes_per_launch_corrected"],   # x 2: right when every read is a coalesced stream
                "write_bytes_per_launch": cands[kernel]["write_bytes_per_launch"], "files": prefix.split("/")[-1] + "_{traffic.json,pmc.txt}"}
         pmc = parse_pmc_txt(prefix + "_pmc.txt")
         for k, v in pmc.items():
