@@ -130,18 +130,13 @@ struct BlepFreq
     // lane of a wavefront that is not `full` (an oscillator's phase, or an op's operands inside their ranges); a `full`
     // wavefront (some lane has absurd operands - t may be 3e38, where t + t overflows but 2t - t*t does not) takes the
     // reference's own operation order along with its division
-    float q, twoq_qq;
+    float q;
     if (full)
-    {
       q = num / dt;
-      twoq_qq = (q + q) - q * q;
-    }
     else
-    {
       q = div_nr(num, dt);
-      twoq_qq = __builtin_fmaf(2.0f, q, -(q * q));
-    }
     const float qq = q * q;
+    const float twoq_qq = full ? ((q + q) - qq) : __builtin_fmaf(2.0f, q, -qq);   // `full` is wave-uniform: a scalar branch
     const float clo = twoq_qq - 1.0f;
     const float chi = ((qq + q) + q) + 1.0f;
     return isLo ? clo : chi;
