@@ -1,7 +1,7 @@
 // tools/exp_chain.hip — kernel-structure lab for the voice-bank kernel (developer tool, not product).
 // Builds variants of the SawGen->Bandpass->gain loop from the PRODUCT device headers and times
 // them on the config-3 workload; every variant's output is compared bit-for-bit with variant 0.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize tools/exp_chain.hip -o tools/bin/exp_chain
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp tools/exp_chain.hip -o tools/bin/exp_chain
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -306,6 +306,98 @@ __global__ __launch_bounds__(BLK) void k_v3(Args a)
   a.state[2 * a.V + va] = f2u(ic2.x); a.state[2 * a.V + vb] = f2u(ic2.y);
 }
 
+// variants 4..7: the product's arithmetic written out for one voice per lane, UN quads per trip, to try instruction-level
+// changes one at a time (every one must give variant 0's bits):
+//   SCALED  the phase stays the integer-valued float k = float(omega32 >> 1); dt, 1 - dt and the reciprocal are scaled by 2^31
+//           once per launch instead (every operand of the polyBLEP scales by an exact power of two, so every rounding is the
+//           same), saw = fma(k, 2^-30, -1): one multiply per sample less
+//   SADDR   the store address = a wave-uniform 64-bit base (scalar adds) + a 32-bit per-lane offset, so no vector instruction
+//           is spent on addresses (needs the signal to be < 4 GiB)
+//   VCCSEL  the first select right behind its compare (mask in VCC: a full-rate v_cndmask_b32_e32) via inline asm
+template <int BLK, int UN, bool SCALED, bool SADDR, bool VCCSEL>
+__global__ __launch_bounds__(BLK) void k_v4(Args a)
+{
+  const size_t v = xcd_block(blockIdx.x, gridDim.x) * BLK + threadIdx.x;
+  if (v >= a.V) return;
+  const float g0 = a.coeffs[v], g1 = a.coeffs[a.V + v], g2 = a.coeffs[2 * a.V + v], gain = a.coeffs[3 * a.V + v];
+  uint32_t om = a.state[v];
+  float ic1 = u2f(a.state[a.V + v]), ic2 = u2f(a.state[2 * a.V + v]);
+  const float dt = a.freq[v];
+  const uint32_t istep = (uint32_t)sse_cvt(dt * kStepsPerCycle);
+  const float r0 = __builtin_amdgcn_rcpf(dt);
+  const float e = __builtin_fmaf(-dt, r0, 1.0f);
+  const float r1u = __builtin_fmaf(e, r0, r0);
+  const float K = 2147483648.0f, IK = 4.656612873077392578125e-10f;      // 2^31, 2^-31
+  // operands of the per-sample code, scaled or not
+  const float dtS = SCALED ? dt * K : dt, omdtS = SCALED ? (1.0f - dt) * K : (1.0f - dt), ndtS = -dtS;
+  const float r1S = SCALED ? r1u * IK : r1u;          // num' * r1' = num * r1
+  const float oneS = SCALED ? K : 1.0f;
+  const float sawMul = SCALED ? 9.31322574615478515625e-10f : 2.0f;     // 2^-30 : 2
+  const uint32_t laneOff = (uint32_t)(v * 16);
+  const char* base = (const char*)a.out;
+  f32x4* po = a.out + v;
+  for (size_t r = 0; r < a.T * 16; r += UN)
+  {
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+    {
+      f32x4 y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+      {
+        om += istep;
+        float p = (float)(int32_t)(om >> 1);
+        if (!SCALED) p = p * IK;
+        const bool hi = p > omdtS;
+        const float pm1 = p - oneS;
+        float num;
+        bool lo;
+        if (VCCSEL)
+        {
+          // v_cmp -> vcc, v_cndmask reads vcc at once (full rate); the mask is copied out for the later selects
+          unsigned long long m;
+          asm volatile("v_cmp_lt_f32 vcc, %2, %3\n\tv_cndmask_b32 %0, %4, %2, vcc\n\ts_mov_b64 %1, vcc" : "=v"(num), "=s"(m) : "v"(p), "v"(dtS), "v"(pm1) : "vcc");
+          lo = (m >> (threadIdx.x & 63)) & 1;
+        }
+        else
+        {
+          lo = p < dtS;
+          num = lo ? p : pm1;
+        }
+        float q = num * r1S;
+        float rem = __builtin_fmaf(ndtS, q, num);
+        q = __builtin_fmaf(rem, r1S, q);
+        rem = __builtin_fmaf(ndtS, q, num);
+        q = __builtin_fmaf(rem, r1S, q);
+        const float qq = q * q;
+        const float clo = __builtin_fmaf(2.0f, q, -qq) - 1.0f;
+        const float chi = ((qq + q) + q) + 1.0f;
+        float c = lo ? clo : chi;
+        c = (lo || hi) ? c : 0.f;
+        const float saw = __builtin_fmaf(p, sawMul, -1.0f);
+        const float x = saw - c;
+        const float t0 = x - ic2;
+        const float m1 = g1 * ic1, m2 = g0 * ic1;
+        const float t1 = g0 * t0 + m1, t2 = g2 * t0 + m2;
+        const float o = t1 + ic1;
+        ic1 = __builtin_fmaf(2.0f, t1, ic1);
+        ic2 = __builtin_fmaf(2.0f, t2, ic2);
+        y[k] = o * gain;
+      }
+      if (SADDR)
+      {
+        const char* rowBase = base + (r + u) * a.V * 16;      // wave-uniform: scalar arithmetic
+        __builtin_nontemporal_store(y, (f32x4*)(rowBase + laneOff));
+      }
+      else
+        __builtin_nontemporal_store(y, po + (r + u) * a.V);
+    }
+  }
+  a.state[v] = om;
+  a.state[a.V + v] = f2u(ic1);
+  a.state[2 * a.V + v] = f2u(ic2);
+}
+
 template <class F>
 float timeit(F f, int reps = 8)
 {
@@ -353,6 +445,12 @@ int main(int argc, char** argv)
   add("v3  2v/lane packed blk256 d64", [&](Args a) { hipLaunchKernelGGL((k_v3<256, 64>), dim3(V / 512), dim3(256), 0, 0, a); });
   add("v3  2v/lane packed blk256 d256", [&](Args a) { hipLaunchKernelGGL((k_v3<256, 256>), dim3(V / 512), dim3(256), 0, 0, a); });
   add("v3  2v/lane packed blk128 d128", [&](Args a) { hipLaunchKernelGGL((k_v3<128, 128>), dim3(V / 256), dim3(128), 0, 0, a); });
+  add("v4  written out, 4 quads/trip", [&](Args a) { hipLaunchKernelGGL((k_v4<256, 4, false, false, false>), dim3(V / 256), dim3(256), 0, 0, a); });
+  add("v4  written out, 2 quads/trip", [&](Args a) { hipLaunchKernelGGL((k_v4<256, 2, false, false, false>), dim3(V / 256), dim3(256), 0, 0, a); });
+  add("v5  + scaled phase", [&](Args a) { hipLaunchKernelGGL((k_v4<256, 4, true, false, false>), dim3(V / 256), dim3(256), 0, 0, a); });
+  add("v6  + scalar store base", [&](Args a) { hipLaunchKernelGGL((k_v4<256, 4, true, true, false>), dim3(V / 256), dim3(256), 0, 0, a); });
+  add("v6b scalar store base only", [&](Args a) { hipLaunchKernelGGL((k_v4<256, 4, false, true, false>), dim3(V / 256), dim3(256), 0, 0, a); });
+  add("v7  + vcc select", [&](Args a) { hipLaunchKernelGGL((k_v4<256, 4, true, true, true>), dim3(V / 256), dim3(256), 0, 0, a); });
   // correctness of every variant against variant 0, from cleared state
   for (size_t i = 0; i < vars.size(); ++i)
   {
