@@ -396,6 +396,34 @@ int upDepth(const mlgpu_graph* g, int r)
   return d;
 }
 
+// clamp(x, lo, hi) whose bounds are literal constants of the kernel (not NaN, not zero, lo <= hi) and whose x is produced by
+// an arithmetic instruction - a node that can never hand a signaling NaN on: then two hardware instructions give what the
+// six of the general form do (clamp_const_bounds, mldsp_math.hpp). Inputs, parameters, feedback vectors, delay lines,
+// selects and the bit-twiddling approximations carry raw bit patterns and keep the general form.
+bool clampHasConstBounds(const mlgpu_graph* g, const Node& n)
+{
+  if (n.in.size() != 3 || g->liveConsts) return false;
+  const Node &x = g->nodes[(size_t)n.in[0]], &lo = g->nodes[(size_t)n.in[1]], &hi = g->nodes[(size_t)n.in[2]];
+  if (lo.type != NODE_CONST || hi.type != NODE_CONST) return false;
+  if (!(lo.value <= hi.value) || lo.value == 0.f || hi.value == 0.f) return false;  // (a NaN bound fails the comparison)
+  if (x.type == NODE_OP)
+    switch (x.kind)
+    {
+      case MLGPU_OP_ADD: case MLGPU_OP_SUBTRACT: case MLGPU_OP_MULTIPLY: case MLGPU_OP_DIVIDE: case MLGPU_OP_LERP: case MLGPU_OP_INVERSE_LERP: return true;
+      default: return false;
+    }
+  if (x.type == NODE_PROC)
+    switch (x.kind)
+    {
+      case MLGPU_PROC_SINE_GEN: case MLGPU_PROC_SAW_GEN: case MLGPU_PROC_PULSE_GEN: case MLGPU_PROC_NOISE_GEN:
+      case MLGPU_PROC_LOPASS: case MLGPU_PROC_HIPASS: case MLGPU_PROC_BANDPASS: case MLGPU_PROC_LO_SHELF: case MLGPU_PROC_HI_SHELF: case MLGPU_PROC_BELL:
+      case MLGPU_PROC_ONE_POLE: case MLGPU_PROC_DC_BLOCKER: case MLGPU_PROC_INTEGRATOR: case MLGPU_PROC_DIFFERENTIATOR: case MLGPU_PROC_GAIN:
+        return true;  // every output sample is the result of an add / sub / mul / fma
+      default: return false;
+    }
+  return false;
+}
+
 std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& ph = "", const std::string& idx = "q * 4 + k")
 {
   const Node& n = g->nodes[i];
@@ -434,6 +462,11 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
       }
       break;
     case NODE_OP:
+      if (n.kind == MLGPU_OP_CLAMP && clampHasConstBounds(g, n))
+      {
+        s << "clamp_const_bounds(" << arg(0) << ", " << arg(1) << ", " << arg(2) << ")";  // two instructions (mldsp_math.hpp)
+        break;
+      }
       s << "apply_f<" << n.kind << ">(" << arg(0);
       for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
       s << ")";

@@ -51,6 +51,20 @@ MLD float sse_canon(float x)
 MLD float sse_min(float a, float b) { return sse_canon((a < b) ? a : b); }
 MLD float sse_max(float a, float b) { return sse_canon((a > b) ? a : b); }
 
+// clamp(x, lo, hi) = min(max(x, lo), hi) (MLDSPOps.h:747) in TWO instructions instead of six, for the common case the graph
+// generator can prove: lo and hi are constants of the kernel, neither NaN nor zero, lo <= hi, and x is the result of an
+// arithmetic instruction (so never a signaling NaN). v_max_f32 / v_min_f32 differ from maxps / minps only (a) when the SECOND
+// operand is NaN, (b) when the operands compare equal with different bits, i.e. +0 against -0, and (c) for a signaling NaN in
+// the first operand (quieted instead of replaced) - all excluded here; a quiet NaN x gives lo on both machines, a denormal x
+// is flushed in flush mode exactly as sse_max's canonicalization would.
+MLD float clamp_const_bounds(float x, float lo, float hi)
+{
+  float m, r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(lo));
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(m), "v"(hi));
+  return r;
+}
+
 // _mm_cvttps_epi32 / _mm_cvtps_epi32 (MLDSPMathSSE.h:124-125): NaN and out-of-range give
 // 0x80000000 ("integer indefinite"); v_cvt_i32_f32 would saturate / give 0 instead.
 MLD int32_t sse_cvtt(float x)

@@ -507,3 +507,39 @@ def test_live_constants_change_between_launches(eng, oracle):
     with pytest.raises(ml.MlgpuError):
         plain.update_constants_from(other)             # ... so other numbers are another kernel
     plain.update_constants_from(ml.Graph(ml.OfflineEngine(), V, description(*values[0]), ["y"]))   # the same numbers: nothing to do
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flush", [False, True])
+def test_clamp_with_constant_bounds_two_instruction_form(eng, oracle, flush):
+    """clamp(x, lo, hi) with literal, non-zero bounds on an arithmetic result is emitted as v_max_f32 + v_min_f32
+    (clamp_const_bounds) instead of two compare / select / canonicalize triples. Same bits as the reference's
+    min(max(x, lo), hi) for every x an arithmetic instruction can produce - infinities, quiet NaNs, +-0, denormals - in both
+    floating-point modes; clamps the proof does not cover (a raw input, a zero bound) keep the general form and match too."""
+    import madronalib_amd as ml
+    from inputs import general_floats
+    V, T = 128, 2
+    a = general_floats(V * 64 * T, seed=31).reshape(V, 64 * T)
+    b = general_floats(V * 64 * T, seed=32)[::-1].reshape(V, 64 * T).copy()
+    a[0, :8] = [np.inf, -np.inf, 0.0, -0.0, 1e-30, -1e-30, 3e38, -3e38]
+    b[0, :8] = [0.0, 0.0, -1.0, 1.0, 1e-15, 1e-15, 10.0, 10.0]          # inf*0 = NaN, +-0, denormal products, overflow
+    desc = [dict(name="a", type="input"), dict(name="b", type="input"),
+            dict(name="lo", type="const", value=-0.75), dict(name="hi", type="const", value=2.5), dict(name="z", type="const", value=0.0),
+            dict(name="one", type="const", value=1.0),
+            dict(name="m", type="op", kind=Op.MULTIPLY, inputs=["a", "b"]),
+            dict(name="fast", type="op", kind=Op.CLAMP, inputs=["m", "lo", "hi"]),        # two-instruction form
+            dict(name="raw", type="op", kind=Op.CLAMP, inputs=["a", "lo", "hi"]),         # raw input: general form
+            dict(name="zero", type="op", kind=Op.CLAMP, inputs=["m", "z", "one"])]        # zero bound: general form
+    outs = ["fast", "raw", "zero"]
+    g = ml.Graph(eng, V, desc, outs)
+    assert g.source.count("clamp_const_bounds(") == 1
+    eng.set_flush_denormals(flush)
+    try:
+        got = g.process_host(T, {"a": a, "b": b}, Layout.QUAD)
+    finally:
+        eng.set_flush_denormals(False)
+    with oracle.flush_denormals(flush):
+        want = evaluate(oracle, desc, outs, V, T, {"a": a, "b": b}, {}, {}, {})
+    for i, o in enumerate(outs):
+        assert_bits_equal(got[i], want[i], True, f"clamp {o} flush={flush}")
+    g.close()
