@@ -51,6 +51,15 @@ MLD float sse_canon(float x)
 MLD float sse_min(float a, float b) { return sse_canon((a < b) ? a : b); }
 MLD float sse_max(float a, float b) { return sse_canon((a > b) ? a : b); }
 
+// lane l of the result = bit l of `mask` ? a : b, for a wave-uniform 64-bit lane mask (a ballot, or scalar logic on ballots):
+// one v_cndmask_b32 that reads the SGPR pair, where `(mask >> lane) & 1` would be 64-bit vector shifts.
+MLD float lane_select(uint64_t mask, float a, float b)
+{
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  return r;
+}
+
 // clamp(x, lo, hi) = min(max(x, lo), hi) (MLDSPOps.h:747) in TWO instructions instead of six, for the common case the graph
 // generator can prove: lo and hi are constants of the kernel, neither NaN nor zero, lo <= hi, and x is the result of an
 // arithmetic instruction (so never a signaling NaN). v_max_f32 / v_min_f32 differ from maxps / minps only (a) when the SECOND

@@ -754,6 +754,7 @@ struct Proc<MLGPU_PROC_ADSR>  // :657-797
     k = u2f(m.s(5));
     amp = u2f(m.s(6));
     segment = (int32_t)m.s(7);
+    derive_masks();
   }
   MLD void store(const VoiceMem& m) const
   {
@@ -766,48 +767,74 @@ struct Proc<MLGPU_PROC_ADSR>  // :657-797
     m.set(6, f2u(amp));
     m.set(7, (uint32_t)segment);
   }
-  MLD float next(float x)  // processSample :704-786
+  // processSample (:704-786) is a little state machine: most of its code runs only on the sample where a voice changes
+  // segment (gate on, gate off, the envelope crossing its segment's end). Evaluated as the reference writes it, every sample
+  // of every wavefront walks those divergent branches and seven compares: 59 ns per wavefront-sample, the most expensive
+  // node of the synth voice (tools/node_costs.py). Here one wave-uniform test decides whether ANY lane might change segment
+  // at this sample, from lane masks carried across samples (ballots; scalar instructions cost as much as vector ones on this
+  // chip - tools/instbench.hip - so the test is two compares and a handful of scalar operations):
+  //   gate on / gate off need x == 0 to differ from last sample's  (a superset of the reference's two edge tests),
+  //   a crossing needs y > threshold to have changed at the last update (its test of y1 and y, made one sample early).
+  // If it might, the reference's tests run first for every lane (change_segment) and re-parameterize the one-pole. Either
+  // way the sample ends with `x1 = x; y1 = y; y += k (target - y); return y amp`, selected away on the idle lanes (segment
+  // off and x == 0 on entry: the reference returns 0 and touches nothing). Same values, same state, bit for bit.
+  uint64_t mXZero, mAbove, mCrossed, mOff;
+  MLD void derive_masks()
   {
-    if ((segment == off) && (x == 0.f)) return 0.f;
-    const bool crossed = ((y1 > threshold) != (y > threshold));
-    bool recalc = false;
-    if (crossed && (segment < off))
-    {
-      segment++;
-      recalc = true;
-    }
-    const bool trigOn = (x1 == 0.f) && (x > 0.f);
-    const bool trigOff = (x1 > 0.f) && (x == 0.f);
-    if (trigOn)
-    {
-      segment = A;
-      amp = x;
-      recalc = true;
-    }
-    else if (trigOff)
-    {
-      segment = R;
-      recalc = true;
-    }
-    if (recalc)
-    {
-      float startEnv = 0.f, endEnv = 0.f;
-      switch (segment)
-      {
-        case A: startEnv = 0.f; endEnv = 1.f; k = ka; break;
-        case D: startEnv = 1.f; endEnv = s; k = kd; break;
-        case S: startEnv = s; endEnv = s; k = 0.f; y1 = s; y = s; break;
-        case R: startEnv = s; endEnv = 0.f; k = kr; break;
-        default: startEnv = 0.f; endEnv = 0.f; k = 0.f; y1 = 0.f; y = 0.f; break;
-      }
-      const float segmentBias = (endEnv - startEnv) * 0.1f;
-      threshold = endEnv;
-      target = endEnv + segmentBias;
-    }
-    x1 = x;
-    y1 = y;
-    y = y + k * (target - y);
-    return y * amp;
+    mOff = __builtin_amdgcn_ballot_w64(segment == off);
+    mXZero = __builtin_amdgcn_ballot_w64(x1 == 0.f);
+    mAbove = __builtin_amdgcn_ballot_w64(y > threshold);
+    mCrossed = __builtin_amdgcn_ballot_w64(y1 > threshold) ^ mAbove;
+  }
+  MLD float next(float x)
+  {
+    const uint64_t xz = __builtin_amdgcn_ballot_w64(x == 0.f);
+    const uint64_t maybe = (xz ^ mXZero) | mCrossed;
+    const uint64_t idle = mOff & xz;
+    if (__builtin_expect(maybe != 0, 0)) change_segment(x);
+    const float yn = y + k * (target - y);
+    x1 = lane_select(idle, x1, x);
+    y1 = lane_select(idle, y1, y);
+    y = lane_select(idle, y, yn);
+    // (an idle lane keeps y: its bit of `above` stays, its bit of mCrossed clears - a crossing only counts before off)
+    const uint64_t above = __builtin_amdgcn_ballot_w64(y > threshold);
+    mXZero = xz;
+    mCrossed = mAbove ^ above;
+    mAbove = above;
+    return lane_select(idle, 0.f, yn * amp);
+  }
+  // processSample :711-775 for the lanes that are not idle at this sample: crossing / gate on / gate off -> new segment,
+  // coefficient, target, threshold (and y, y1 where the reference resets them). Written with selects instead of the
+  // reference's branches and switch - the same tests in the same order, the same two arithmetic expressions - so that next()
+  // holds wave-uniform branches only (a divergent branch in here makes the compiler thread flags and register copies through
+  // the quiet path). Rare; the whole wavefront walks it.
+  MLD void change_segment(float x)
+  {
+    const bool active = !((segment == off) && (x == 0.f));
+    const bool crossed = active && ((y1 > threshold) != (y > threshold)) && (segment < off);
+    const bool trigOn = active && (x1 == 0.f) && (x > 0.f);
+    const bool trigOff = active && !trigOn && (x1 > 0.f) && (x == 0.f);
+    const bool recalc = crossed || trigOn || trigOff;
+    int32_t seg = segment + (crossed ? 1 : 0);
+    seg = trigOn ? (int32_t)A : (trigOff ? (int32_t)R : seg);
+    amp = trigOn ? x : amp;
+    const bool isA = (seg == A), isD = (seg == D), isS = (seg == S), isR = (seg == R);
+    const float startEnv = isA ? 0.f : (isD ? 1.f : ((isS || isR) ? s : 0.f));
+    const float endEnv = isA ? 1.f : ((isD || isS) ? s : 0.f);
+    const float kNew = isA ? ka : (isD ? kd : (isR ? kr : 0.f));
+    const bool resetY = recalc && !(isA || isD || isR);  // S, and the default case (off)
+    const float yNew = isS ? s : 0.f;
+    const float segmentBias = (endEnv - startEnv) * 0.1f;
+    const float targetNew = endEnv + segmentBias;
+    k = recalc ? kNew : k;
+    threshold = recalc ? endEnv : threshold;
+    target = recalc ? targetNew : target;
+    y1 = resetY ? yNew : y1;
+    y = resetY ? yNew : y;
+    segment = seg;
+    // (a lane that has just gone off is not idle at this sample: next() took its idle mask before)
+    mOff = __builtin_amdgcn_ballot_w64(segment == off);
+    mAbove = __builtin_amdgcn_ballot_w64(y > threshold);
   }
   MLD void end_vector() {}
 };

@@ -65,6 +65,14 @@ __device__ inline float sum1(f2 x) { return x.x + x.y; }
 #define I_SUB(r) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(r) : "v"(b));
 #define I_FMAC(r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));
 #define I_MAD_U32(r) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));
+#define I_SAND(r) asm volatile("s_and_b64 s[20:21], s[20:21], s[28:29]\n s_xor_b64 s[22:23], s[22:23], s[28:29]\n s_or_b64 s[24:25], s[24:25], s[28:29]\n s_andn2_b64 s[26:27], s[26:27], s[28:29]" : : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");
+#define I_MIX11(r) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_and_b64 s[20:21], s[20:21], s[28:29]" : "+v"(r) : "v"(c), "v"(b) : "s20", "s21", "scc");
+#define I_MIX13(r) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_and_b64 s[20:21], s[20:21], s[28:29]\n s_xor_b64 s[22:23], s[22:23], s[28:29]\n s_or_b64 s[24:25], s[24:25], s[28:29]" : "+v"(r) : "v"(c), "v"(b) : "s20", "s21", "s22", "s23", "s24", "s25", "scc");
+#define I_BRANCH(r) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_cmp_eq_u64 exec, 0\n s_cbranch_scc1 8" : "+v"(r) : "v"(c), "v"(b) : "scc");
+DEFK(k_sand, I_SAND, float, FINIT)
+DEFK(k_mix11, I_MIX11, float, FINIT)
+DEFK(k_mix13, I_MIX13, float, FINIT)
+DEFK(k_branch, I_BRANCH, float, FINIT)
 DEFK(k_mul_lit, I_MUL_LIT, float, FINIT)
 DEFK(k_mul_sgpr, I_MUL_SGPR, float, FINIT)
 DEFK(k_fma_sgpr, I_FMA_SGPR, float, FINIT)
@@ -134,5 +142,9 @@ int main()
   run("v_fma_f32 x,2.0,-1.0", k_fma_inl, out, 1); run("v_add_f32 -1.0,x", k_add_inl, out, 1); run("v_sub_f32", k_sub, out, 1); run("v_fmac_f32", k_fmac, out, 1);
   run("v_add3_u32", k_add3, out, 1); run("v_cvt_f32_u32", k_cvtu, out, 1); run("v_cmp_lt_f32 -> sgpr", k_cmp64, out, 1);
   run("v_cndmask_b32 sgpr mask", k_cnd64, out, 1); run("v_ldexp_f32", k_ldexp, out, 1); run("v_bfi_b32", k_bfi, out, 1);
+  // the scalar pipe: 64-bit mask logic alone, interleaved with VALU (different waves can issue the two in the same cycle), and a
+  // never-taken scalar compare-and-branch after every VALU instruction (exec is never 0)
+  run("s_and/xor/or/andn2_b64", k_sand, out, 4); run("v_fma + 1 s_and_b64 (per pair)", k_mix11, out, 1); run("v_fma + 3 SALU (per group)", k_mix13, out, 1);
+  run("v_fma + s_cmp + s_cbranch", k_branch, out, 1);
   return 0;
 }
