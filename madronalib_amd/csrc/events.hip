@@ -190,7 +190,10 @@ struct Glide
   }
 };
 
-__global__ __launch_bounds__(256, 4) void e2s_kernel(const E2SArgs a)
+#ifndef MLGPU_E2S_WAVES
+#define MLGPU_E2S_WAVES 4
+#endif
+__global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs a)
 {
   apply_fp_mode(a.flags);
   // XCD-aware workgroup -> lane mapping (as the voice-bank kernels): every XCD writes one contiguous eighth of each row

@@ -326,3 +326,38 @@ def region_case(V, T, seed=0):
     m = (0.5 + 0.5 * np.sin(np.arange(64 * T) * 0.01)[None, :] * np.linspace(0.2, 1.0, V)[:, None]).astype(np.float32)
     freq = (55.0 * 2.0 ** (6.0 * np.arange(V) / max(1, V)) / 48000.0).astype(np.float32)
     return x, m, freq
+
+
+def hostile_gate(V, S, seed):
+    """ADSR gates the segment logic was not written for: negative and -0 levels, NaN, +-inf, denormals, levels that change
+    without passing through zero, single-sample blips - between ordinary on/off stretches."""
+    rng = np.random.default_rng(seed)
+    odd = np.array([-0.0, -0.5, np.nan, np.inf, -np.inf, 1e-40, -1e-40, 3.0e38, 1.0e-38], np.float32)
+    x = np.zeros((V, S), np.float32)
+    for v in range(V):
+        t = 0
+        while t < S:
+            L = int(rng.integers(1, 300))
+            r = rng.random()
+            if r < 0.35:
+                val = np.float32(0.0)
+            elif r < 0.75:
+                val = np.float32(rng.uniform(0.05, 1.5))
+            else:
+                val = odd[rng.integers(0, len(odd))]
+            x[v, t:t + L] = val
+            t += L
+    return x
+
+
+def hostile_adsr_state(clean, rng):
+    """ADSR state [8][V] the envelope itself never produces: an off segment with a nonzero y, k or target, segments past off, NaN
+    thresholds (words: y, y1, x1, threshold, target, k, amp, segment); every fifth voice keeps the clear() state."""
+    st = clean.copy()
+    V = st.shape[1]
+    vals = np.array([0.0, -0.0, 0.3, -0.3, 1.0, 1.1, 1e-40, np.nan, np.inf, 2.0], np.float32)
+    for w in range(7):
+        st[w] = vals[rng.integers(0, len(vals), V)].view(np.uint32)
+    st[7] = rng.integers(0, 7, V).astype(np.uint32)
+    st[:, ::5] = clean[:, ::5]
+    return st

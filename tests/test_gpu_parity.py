@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from golden_cases import ANCHORS, chain_case, chain_case_names, load_chains, load_ops
-from inputs import (assert_bits_equal, assert_rel_close, chain_coeffs, chain_input, is_float_result, lcg_noise,
+from inputs import (hostile_adsr_state, hostile_gate, assert_bits_equal, assert_rel_close, chain_coeffs, chain_input, is_float_result, lcg_noise,
                     op_inputs, ramp_pi)
 from madronalib_amd.constants import Layout, Op, Proc, RowOp
 
@@ -408,3 +408,31 @@ def test_default_constructed_peak_holds_for_44100_samples(eng, oracle):
     assert_bits_equal(bank.get_all_state(), st, False, "default Peak state")
     assert (np.abs(got[:, -64:]) > 0).any()                              # still holding at the end (a zero hold would have decayed)
     bank.close()
+
+
+@pytest.mark.parametrize("flush", [False, True])
+@pytest.mark.parametrize("garbage_state", [False, True])
+def test_adsr_hostile_gates_and_states(eng, oracle, flush, garbage_state):
+    """The ADSR's quiet path decides from carried lane masks whether any lane may change segment (mldsp_procs.hpp); this drives
+    it with every gate value its tests could mishandle, from states the envelope itself never produces (an off segment with a
+    nonzero y, k or target; segments past off; NaN thresholds), in both floating-point modes, over several launches."""
+    V, T, calls = 200, 12, 3
+    procs = [Proc.ADSR]
+    rng = np.random.default_rng(77 + garbage_state)
+    co = chain_coeffs(oracle, procs, V, seed=3)
+    st = hostile_adsr_state(oracle.chain_clear(procs, V), rng) if garbage_state else oracle.chain_clear(procs, V)
+    eng.set_flush_denormals(flush)
+    try:
+        bank = eng.bank(procs, V)
+        bank.set_all_coeffs(co)
+        bank.set_all_state(st)
+        for c in range(calls):
+            gate = hostile_gate(V, 64 * T, seed=100 * c + int(garbage_state))
+            got = bank.process_host(T, gate, Layout.QUAD)
+            with oracle.flush_denormals(flush):
+                want = oracle.chain_process(procs, T, co, st, gate, None, n_threads=8)
+            assert_bits_equal(got, want, True, f"hostile ADSR call {c} flush={flush} garbage={garbage_state}")
+            assert_bits_equal(bank.get_all_state(), st, False, f"hostile ADSR state call {c}")
+        bank.close()
+    finally:
+        eng.set_flush_denormals(False)

@@ -65,6 +65,25 @@ def test_single_proc_matches_reference(oracle, ref, kind):
     assert_bits_equal(st_o, st_r, False, f"proc {kind} final state")
 
 
+@pytest.mark.parametrize("garbage_state", [False, True])
+def test_adsr_hostile_gates_match_reference(oracle, ref, garbage_state):
+    """Pins the oracle's ADSR on the inputs tests/test_gpu_parity.py::test_adsr_hostile_gates_and_states drives the device with:
+    negative / -0 / NaN / inf / denormal gates, and states the envelope never produces, set into the reference's own object."""
+    from inputs import hostile_adsr_state, hostile_gate
+    V, T = 48, 12
+    procs = [Proc.ADSR]
+    co = chain_coeffs(ref, procs, V, seed=3)
+    rng = np.random.default_rng(78)
+    st_r = hostile_adsr_state(ref.chain_clear(procs, V), rng) if garbage_state else ref.chain_clear(procs, V)
+    st_o = st_r.copy()
+    for c in range(3):
+        gate = hostile_gate(V, 64 * T, seed=100 * c + 1)
+        want = ref.chain_process(procs, T, co, st_r, gate, None)
+        got = oracle.chain_process(procs, T, co, st_o, gate, None)
+        assert_bits_equal(got, want, True, f"hostile ADSR call {c}")
+        assert_bits_equal(st_o, st_r, False, f"hostile ADSR state call {c}")
+
+
 CHAINS = {
     "cfg1_sine_lopass": [Proc.SINE_GEN, Proc.LOPASS],
     "cfg3_saw_bandpass_gain": [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN],
