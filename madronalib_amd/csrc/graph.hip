@@ -360,6 +360,7 @@ struct mlgpu_graph
   int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
   int compiledVoicesPerLane{1};
   int unrollQ{1};                // quads per trip of the sample loop
+  int minWaves{0};               // wavefronts per SIMD the kernel's register budget must allow (0: the compiler's choice), generateBudgeted
   // Online tuning (mlgpu_graph_set_autotune): every variant (voices per lane x quads per trip) computes the same bits from
   // the same state arrays, so the first process calls simply take turns, are timed, and the fastest one stays.
   struct Variant
@@ -536,7 +537,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << "};\n";
     }
   // windowed rings: the latency of a sector refill is hidden by other waves only, so keep at least two per SIMD
-  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->windowedRings && g->totalRings) ? ", 2" : "") << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n  apply_fp_mode(a.flags);\n";
+  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->windowedRings && g->totalRings) ? ", 2" : (g->minWaves ? ", " + std::to_string(g->minWaves) : std::string())) << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n  apply_fp_mode(a.flags);\n";
   if (g->hasImpulse)
   {
     s << "  __shared__ float ldsTable[32];\n  if (threadIdx.x < 17) ldsTable[threadIdx.x] = a.impulseTable[threadIdx.x];\n  __syncthreads();\n";
@@ -787,6 +788,52 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       for (int l = 0; l < VL; ++l) s << "  p" << i << sfx(l) << ".store(m" << i << sfx(l) << ");\n";
   s << "}\n";
   return s.str();
+}
+
+// Registers and scratch bytes per lane of the (only) kernel of a code object, read from its metadata note (msgpack: the key
+// string, then an unsigned integer).
+static bool codeObjectNumber(const std::vector<char>& code, const char* key, long& value)
+{
+  const size_t klen = strlen(key);
+  for (size_t i = 0; i + klen + 1 < code.size(); ++i)
+  {
+    if (memcmp(code.data() + i, key, klen) != 0) continue;
+    const unsigned char* p = (const unsigned char*)code.data() + i + klen;
+    const size_t left = code.size() - (i + klen);
+    if (p[0] <= 0x7f) { value = p[0]; return true; }
+    if (p[0] == 0xcc && left >= 2) { value = p[1]; return true; }
+    if (p[0] == 0xcd && left >= 3) { value = (p[1] << 8) | p[2]; return true; }
+    if (p[0] == 0xce && left >= 5) { value = ((long)p[1] << 24) | (p[2] << 16) | (p[3] << 8) | p[4]; return true; }
+  }
+  return false;
+}
+
+// Source + code object of the graph kernel for `vl` voices per lane, with the register budget chosen: a voice bank is launched
+// as whole blocks of four wavefronts, one per SIMD, and the bank sizes that matter are a few blocks per CU - so a kernel
+// that needs 129..192 VGPRs (three wavefronts per SIMD, or two) runs its blocks in two rounds where one that fits 128 runs
+// them in one. If the kernel is in that band it is generated again with a 4-wavefront bound, and the bounded one is kept when
+// what it spills is small (the patch of SURVEY 8d: 170 VGPRs -> 128 + 156 bytes of scratch per lane, 1.82 -> 1.46 ms).
+// MLGPU_GRAPH_MIN_WAVES=0 / N overrides (developer knob).
+static bool generateBudgeted(mlgpu_graph* g, int vl, std::string& source, std::vector<char>& code, std::string& log)
+{
+  const char* knob = getenv("MLGPU_GRAPH_MIN_WAVES");
+  g->minWaves = knob ? atoi(knob) : 0;
+  source = generateGraphSource(g, vl);
+  if (!getCode(source, code, log)) return false;
+  long vgprs = 0;
+  if (knob || (g->windowedRings && g->totalRings) || !codeObjectNumber(code, ".vgpr_count", vgprs) || vgprs <= 128 || vgprs > 192) return true;
+  g->minWaves = 4;
+  const std::string bounded = generateGraphSource(g, vl);
+  g->minWaves = 0;
+  std::vector<char> boundedCode;
+  std::string boundedLog;
+  long scratch = 0;
+  if (getCode(bounded, boundedCode, boundedLog) && codeObjectNumber(boundedCode, ".private_segment_fixed_size", scratch) && scratch <= 512)
+  {
+    source = bounded;
+    code.swap(boundedCode);
+  }
+  return true;
 }
 
 int addNode(mlgpu_graph* g, Node&& n)
@@ -1338,8 +1385,7 @@ extern "C"
     const char* forced = getenv("MLGPU_GRAPH_UNROLL");  // developer knob: quads per trip of the sample loop
     // delay graphs wait on their ring reads: two quads per trip keep more of them in flight (allpass4: 5.4 vs 4.5 x 10^10)
     g->unrollQ = forced ? std::max(1, atoi(forced)) : ((g->totalRings && !g->windowedRings) ? 2 : 1);
-    g->source = generateGraphSource(g);
-    if (!getCode(g->source, g->emitted, g->log)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
+    if (!generateBudgeted(g, 0, g->source, g->emitted, g->log)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
     return MLGPU_OK;
   }
 
@@ -1697,11 +1743,12 @@ extern "C"
       {
         const int keepUnroll = g->unrollQ, keepVl = g->compiledVoicesPerLane;
         g->unrollQ = trial->unroll;
-        const std::string src = generateGraphSource(g, trial->vl);
+        std::string src, log;
+        std::vector<char> code;
+        const bool built = generateBudgeted(g, trial->vl, src, code, log);
         g->unrollQ = keepUnroll;
         g->compiledVoicesPerLane = keepVl;
-        std::string log;
-        CompiledModule* cm = compileAndLoad(g->e->device, src, log);
+        CompiledModule* cm = built ? compileAndLoad(g->e->device, src, log) : nullptr;
         trial->fn = cm ? getFunction(cm, "mlgpu_graph_kernel", log) : nullptr;
         if (!trial->fn)
         {
