@@ -214,8 +214,11 @@ __global__ __launch_bounds__(256) void layout_convert_kernel(SignalView src, Sig
 // tile of 64 voices x 16 quads, through its own 16 KiB of LDS: both the global reads and the global writes run along the
 // contiguous direction of their side (256-byte voice rows on one, 1 KiB quad rows on the other). The quad index is XOR-ed
 // with the voice index in the LDS address, which keeps both phases free of bank conflicts without padding.
+// Tile order: with VOICE_MAJOR on the row side a voice's DSPVectors are adjacent (256 bytes each), so neighbouring wavefronts take
+// neighbouring vectors of the same 64 voices (vectorsFirst) and each voice's stretch of DRAM is visited once, 1 KiB or more at a
+// time, instead of once per vector 256 bytes at a time; with ROWS the 64 voices of one vector are one contiguous 16 KiB already.
 template <bool TO_QUAD>
-__global__ __launch_bounds__(256) void layout_transpose_kernel(SignalView src, SignalView dst, size_t V, size_t T)
+__global__ __launch_bounds__(256) void layout_transpose_kernel(SignalView src, SignalView dst, size_t V, size_t T, bool vectorsFirst)
 {
   __shared__ float4 tiles[4][64 * 16];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void layout_transpose_kernel(SignalView src, S
   const size_t voiceBlocks = (V + 63) / 64, items = T * voiceBlocks;
   for (size_t item = (size_t)blockIdx.x * 4 + wave; item < items; item += (size_t)gridDim.x * 4)
   {
-    const size_t t = item / voiceBlocks, v0 = (item % voiceBlocks) * 64;
+    const size_t t = vectorsFirst ? item % T : item / voiceBlocks, v0 = (vectorsFirst ? item / T : item % voiceBlocks) * 64;
     const SignalView& rowSide = TO_QUAD ? src : dst;   // voice rows of 16 quads
     const SignalView& quadSide = TO_QUAD ? dst : src;  // quad rows of 64 voices
     if (TO_QUAD)
@@ -553,10 +556,11 @@ hipError_t mlgpu_launch_layout_convert(const float* src, int srcLayout, float* d
     size_t blocks = (items + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
+    const bool vectorsFirst = (toQuad ? srcLayout : dstLayout) == MLGPU_LAYOUT_VOICE_MAJOR;
     if (toQuad)
-      hipLaunchKernelGGL(layout_transpose_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, makeView(src, srcLayout, V, T), makeView(dst, dstLayout, V, T), V, T);
+      hipLaunchKernelGGL(layout_transpose_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, makeView(src, srcLayout, V, T), makeView(dst, dstLayout, V, T), V, T, vectorsFirst);
     else
-      hipLaunchKernelGGL(layout_transpose_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, makeView(src, srcLayout, V, T), makeView(dst, dstLayout, V, T), V, T);
+      hipLaunchKernelGGL(layout_transpose_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, makeView(src, srcLayout, V, T), makeView(dst, dstLayout, V, T), V, T, vectorsFirst);
     return hipGetLastError();
   }
   size_t blocks = (total + 255) / 256;
