@@ -62,6 +62,57 @@ __global__ __launch_bounds__(256) void k_bank(const f32x4* a, f32x4* b, size_t V
   for (int k = 0; k < PF; ++k) if (r + k < rows) __builtin_nontemporal_store(w[k], pb + (r + k) * V);
 }
 
+
+// the same pattern with the loads and the stores in different wavefronts: a block of 256 threads takes 128 voices, its first
+// two wavefronts load (one trip of PF rows ahead) and hand the rows over through LDS, its last two store. A wavefront that
+// both loads and stores waits, at every s_waitcnt for a prefetched row, for its older stores to be acknowledged as well (one
+// counter, in order); here the loaders never wait for a store. Twice the wavefronts for the same voices.
+template <int PF, bool XCD>
+__global__ __launch_bounds__(256) void k_bank_split(const f32x4* a, f32x4* b, size_t V, size_t rows)
+{
+  __shared__ f32x4 hand[2][PF][128];
+  size_t blk = blockIdx.x;
+  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
+  if (XCD && blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);
+  const unsigned l = threadIdx.x & 127;
+  const bool loader = threadIdx.x < 128;
+  const size_t v = blk * 128 + l;
+  const f32x4* pa = a + v;
+  f32x4* pb = b + v;
+  const size_t trips = rows / PF;
+  f32x4 w[PF];
+  if (loader)
+  {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) w[k] = __builtin_nontemporal_load(pa + (size_t)k * V);
+  }
+  for (size_t t = 0; t <= trips; ++t)
+  {
+    if (loader)
+    {
+      f32x4 nx[PF];
+      if (t + 1 < trips)
+      {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) nx[k] = __builtin_nontemporal_load(pa + ((t + 1) * PF + k) * V);
+      }
+      if (t < trips)
+      {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) hand[t & 1][k][l] = w[k] * 1.0001f;
+      }
+#pragma unroll
+      for (int k = 0; k < PF; ++k) w[k] = nx[k];
+    }
+    else if (t > 0)
+    {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) __builtin_nontemporal_store(hand[(t - 1) & 1][k][l], pb + ((t - 1) * PF + k) * V);
+    }
+    __syncthreads();
+  }
+}
+
 template <class F>
 double sustain(F launch)
 {
@@ -100,6 +151,9 @@ int main()
 #define BANK(PF, XCD) snprintf(name, sizeof(name), "bank pattern V=%zu rows=%zu prefetch=" #PF " xcd=" #XCD, V, rows); \
     rep(name, sustain([&] { hipLaunchKernelGGL((k_bank<PF, XCD>), dim3((unsigned)(V / 256)), dim3(256), 0, 0, a, b, V, rows); }))
     BANK(4, true); BANK(8, true); BANK(16, true); BANK(4, false);
+#define SPLIT(PF) snprintf(name, sizeof(name), "bank pattern, loads / stores in separate waves V=%zu prefetch=" #PF, V); \
+    rep(name, sustain([&] { hipLaunchKernelGGL((k_bank_split<PF, true>), dim3((unsigned)(V / 128)), dim3(256), 0, 0, a, b, V, rows); }))
+    SPLIT(4); SPLIT(8); SPLIT(16);
   }
   return 0;
 }
