@@ -141,6 +141,32 @@ def test_offline_graph_emit_keeps_processors_in_registers(windows):
     g.close()
 
 
+def test_register_budget_of_generated_kernels(monkeypatch):
+    """graph.hip: generateBudgeted — a generated kernel that comes out with 129..192 VGPRs (three or two wavefronts per SIMD: the
+    blocks of a voice bank then run in two rounds) is generated again with a four-wavefront bound and kept when its scratch is
+    small; a kernel that fits anyway is left alone; MLGPU_GRAPH_MIN_WAVES=0 switches the policy off. Decided from the code
+    objects' metadata, so it needs no device."""
+    import madronalib_amd as ml
+    from madronalib_amd import patches
+
+    def build(full):
+        desc, outs = patches.synth16(full=full)
+        g = ml.Graph(ml.OfflineEngine(), 1024, desc, outs)
+        source, code = g.emit()
+        g.close()
+        notes = _code_object_notes(code)
+        return (re.search(r"__launch_bounds__\([^)]*\)", source).group(0), int(re.search(r"\.vgpr_count:\s+(\d+)", notes).group(1)),
+                int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", notes).group(1)))
+    monkeypatch.delenv("MLGPU_GRAPH_MIN_WAVES", raising=False)
+    bounds, vgpr, scratch = build(False)      # the 16-node voice fits four wavefronts per SIMD as it is
+    assert bounds == "__launch_bounds__(256)" and vgpr <= 128 and scratch == 0
+    bounds, vgpr, scratch = build(True)       # the 22-node patch does not: bounded, with a little scratch
+    assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and 0 < scratch <= 512
+    monkeypatch.setenv("MLGPU_GRAPH_MIN_WAVES", "0")
+    bounds, vgpr, scratch = build(True)
+    assert bounds == "__launch_bounds__(256)" and 128 < vgpr <= 192 and scratch == 0
+
+
 def test_offline_emit_of_const_vectors_live_constants_and_regions():
     """Code generation paths that only GPU tests would otherwise reach, compiled here with hiprtc for gfx950: a constant
     DSPVector (a __constant__ table), live constants (read from the argument table, not literals), a rate region, and the
