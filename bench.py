@@ -654,6 +654,9 @@ def main():
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
         if args.oversubscribe:
             local_rank %= have
+        isolated = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"))
+        if local_rank >= have and have == 1 and isolated:
+            local_rank = 0   # the launcher gave every rank its own device through a *_VISIBLE_DEVICES mask (checked below by PCI bus id)
         if local_rank >= have:
             raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {have} GPU(s) are visible")
         rdv = rendezvous.from_environment()
