@@ -449,7 +449,8 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
       else if ((n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
       {
         // launch-constant frequency: the polyBLEP range test was done once per wavefront (odd<i>)
-        s << "p" << i << L << ".next_u(" << arg(0);
+        const bool widthSignal = n.in.size() == 2 && g->nodes[n.in[1]].rate != RATE_VOICE;
+        s << "p" << i << L << (widthSignal ? ".next_uw(" : ".next_u(") << arg(0);
         if (n.in.size() == 2) s << ", " << arg(1);
         s << ", odd" << i << ")";
       }
@@ -597,6 +598,13 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     {
       s << "  const bool odd" << i << " = __builtin_amdgcn_ballot_w64(blep_freq_is_odd(n" << n.in[0] << "_0)";
       for (int l = 1; l < VL; ++l) s << " || blep_freq_is_odd(n" << n.in[0] << sfx(l) << ")";
+      // a PulseGen whose width is per voice too (its own coefficient, or a voice-rate node): the width's range joins the test
+      if (n.kind == MLGPU_PROC_PULSE_GEN && (n.in.size() == 1 || g->nodes[n.in[1]].rate == RATE_VOICE))
+        for (int l = 0; l < VL; ++l)
+        {
+          if (n.in.size() == 1) s << " || pulse_width_is_odd(p" << i << sfx(l) << ".width)";
+          else s << " || pulse_width_is_odd(n" << n.in[1] << sfx(l) << ")";
+        }
       s << ") != 0;\n";
     }
   }

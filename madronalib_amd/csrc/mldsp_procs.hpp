@@ -184,12 +184,17 @@ MLD float phasor_to_saw(float p, float cps)
 // when no lane of the wavefront is, ONE evaluation serves: the phase of whichever step is near goes in, the result is
 // added or subtracted. Bits: the reference computes (pulse + c_up) - c_down with the idle correction exactly 0.f, and
 // x + 0 == x, x - 0 == x for the +-1 / finite values here, so pulse + c_up or pulse - c_down is the same float.
-template <bool FAST, bool SKIP = false, bool ANY_PHASE = false>
+// REGULAR_W: the caller has excluded, for the whole wavefront, a pulse width of 2^30 or more in magnitude (or NaN): with a
+// PhasorGen's p in [0, 1) the shifted phase then fits an int32 and cvttps2dq's out-of-range result never comes up - one
+// conversion instead of the six instructions of sse_cvtt.
+MLD bool pulse_width_is_odd(float w) { return !(abs_ps(w) < 0x1p30f); }
+
+template <bool FAST, bool SKIP = false, bool ANY_PHASE = false, bool REGULAR_W = false>
 MLD float phasor_to_pulse(float p, float cps, float w)
 {
   const float pulse = (p >= w) ? -1.f : 1.f;
   const float d = p - w + 1.0f;
-  const float down = d - (float)sse_cvtt(d);  // fractionalPart
+  const float down = d - (float)(REGULAR_W ? (int32_t)d : sse_cvtt(d));  // fractionalPart
   const BlepFreq<FAST> f = BlepFreq<FAST>::make(cps, ANY_PHASE && (phase_is_odd(p) || phase_is_odd(down)));
   const bool loUp = f.lo(p), nearUp = loUp || f.hi(p);
   const bool loDown = f.lo(down), nearDown = loDown || f.hi(down);
@@ -290,17 +295,21 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
     omega32 = m.s(0);
   }
   MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
-  template <bool FAST, bool SKIP = false>
+  template <bool FAST, bool SKIP = false, bool REGULAR_W = false>
   MLD float step(float cps, float w)
   {
-    return phasor_to_pulse<FAST, SKIP>(phasor_next(omega32, cps), cps, w);
+    return phasor_to_pulse<FAST, SKIP, false, REGULAR_W>(phasor_next(omega32, cps), cps, w);
   }
   MLD float next(float cps) { return step<false, true>(cps, width); }
   MLD float next_fast(float cps) { return step<true>(cps, width); }
   // graph form: pulse width as an audio-rate input, PulseGen::operator()(freq, width) MLDSPGens.h:390
   MLD float next2(float cps, float w) { return step<false, true>(cps, w); }
-  MLD float next_u(float cps, bool odd) { return odd ? step<false>(cps, width) : step<true>(cps, width); }
-  MLD float next_u(float cps, float w, bool odd) { return odd ? step<false>(cps, w) : step<true>(cps, w); }
+  // launch-constant frequency AND width: `odd` (wave-uniform, tested once by the caller) covers both - some lane's frequency is
+  // outside the fast division's ranges or some lane's width is outside pulse_width_is_odd's
+  MLD float next_u(float cps, bool odd) { return odd ? step<false>(cps, width) : step<true, false, true>(cps, width); }
+  MLD float next_u(float cps, float w, bool odd) { return odd ? step<false>(cps, w) : step<true, false, true>(cps, w); }
+  // launch-constant frequency, the width a signal: `odd` is about the frequency alone
+  MLD float next_uw(float cps, float w, bool odd) { return odd ? step<false>(cps, w) : step<true>(cps, w); }
   static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
   MLD void end_vector() {}
 };
@@ -769,8 +778,8 @@ struct Proc<MLGPU_PROC_ADSR>  // :657-797
   }
   // processSample (:704-786) is a little state machine: most of its code runs only on the sample where a voice changes
   // segment (gate on, gate off, the envelope crossing its segment's end). Evaluated as the reference writes it, every sample
-  // of every wavefront walks those divergent branches and seven compares: 59 ns per wavefront-sample, the most expensive
-  // node of the synth voice (tools/node_costs.py). Here one wave-uniform test decides whether ANY lane might change segment
+  // of every wavefront walks those divergent branches and seven compares: about 27 ns per wavefront-sample, the second most
+  // expensive node of the synth voice (tools/node_costs.py: 12.9 now). Here one wave-uniform test decides whether ANY lane might change segment
   // at this sample, from lane masks carried across samples (ballots; scalar instructions cost as much as vector ones on this
   // chip - tools/instbench.hip - so the test is two compares and a handful of scalar operations):
   //   gate on / gate off need x == 0 to differ from last sample's  (a superset of the reference's two edge tests),

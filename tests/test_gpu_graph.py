@@ -543,3 +543,40 @@ def test_clamp_with_constant_bounds_two_instruction_form(eng, oracle, flush):
     for i, o in enumerate(outs):
         assert_bits_equal(got[i], want[i], True, f"clamp {o} flush={flush}")
     g.close()
+
+
+@pytest.mark.parametrize("vpl", [1, 2])
+def test_pulse_gen_with_absurd_widths(eng, oracle, vpl):
+    """PulseGen with a per-voice frequency and a per-voice width takes, per wavefront, either a fast path that assumes a width
+    below 2^30 in magnitude (the shifted phase then fits an int32: one conversion instead of the emulation of cvttps2dq's
+    out-of-range result) or the general one. Wavefronts of both kinds, widths as a param, as the processor's coefficient and as
+    a signal (never the width-regular path), against the oracle."""
+    import madronalib_amd as ml
+    V, T = 256, 3
+    rng = np.random.default_rng(9)
+    freq = (20.0 * (400.0 ** rng.random(V)) / 48000.0).astype(np.float32)
+    width = rng.uniform(0.05, 0.95, V).astype(np.float32)
+    # voices 0..63 stay regular (a fast wavefront); the others get absurd widths scattered in
+    odd = np.array([3.0e9, -5.0e9, 2.0 ** 30, -(2.0 ** 30), 2.0 ** 31, np.inf, -np.inf, np.nan, 1.0e20, -0.0, 0.0, 1.0, 1.5, -0.25, 2.0 ** 29], np.float32)
+    width[64::3] = odd[rng.integers(0, len(odd), len(width[64::3]))]
+    wsig = np.repeat(width[:, None], 64 * T, 1)
+    desc = [dict(name="f", type="param"), dict(name="w", type="param"), dict(name="ws", type="input"),
+            dict(name="pp", type="proc", kind=Proc.PULSE_GEN, inputs=["f", "w"]),      # width per voice: the regular-width test applies
+            dict(name="pc", type="proc", kind=Proc.PULSE_GEN, inputs=["f"]),           # width = the processor's coefficient
+            dict(name="ps", type="proc", kind=Proc.PULSE_GEN, inputs=["f", "ws"])]     # width a signal
+    outs = ["pp", "pc", "ps"]
+    g = ml.Graph(eng, V, desc, outs, voices_per_lane=vpl)
+    assert g.source.count("pulse_width_is_odd(") == 2 * vpl and ".next_uw(" in g.source
+    g.set_param("f", freq)
+    g.set_param("w", width)
+    g.set_coeffs("pc", [width])
+    phases = rng.integers(0, 2 ** 32, V, dtype=np.uint64).astype(np.uint32)
+    for nm in outs:
+        g.set_state(nm, 0, phases)
+    states = {nm: np.ascontiguousarray(phases[None, :].copy()) for nm in outs}
+    for call in range(2):
+        got = g.process_host(T, {"ws": wsig}, Layout.QUAD)
+        want = evaluate(oracle, desc, outs, V, T, {"ws": wsig}, {"f": freq, "w": width}, {"pc": width[None, :]}, states)
+        for i, o in enumerate(outs):
+            assert_bits_equal(got[i], want[i], True, f"pulse {o} call {call} vpl={vpl}")
+    g.close()

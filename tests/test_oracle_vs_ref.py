@@ -151,6 +151,26 @@ def test_multi_input_forms_match_reference(oracle, ref, name):
         assert_bits_equal(st_o, st_r, False, f"{name} state after call {call}")
 
 
+def test_pulse_gen_absurd_widths_match_reference(oracle, ref):
+    """PulseGen(freq, width) with widths whose shifted phase leaves the int32 range (fractionalPart through cvttps2dq's
+    0x80000000), NaN and infinite widths: pins the oracle on what tests/test_gpu_graph.py::test_pulse_gen_with_absurd_widths
+    drives the device with."""
+    V, T = 16, 6
+    rng = np.random.default_rng(9)
+    f = (20.0 * (400.0 ** rng.random(V)) / 48000.0).astype(np.float32)
+    w = np.array([3.0e9, -5.0e9, 2.0 ** 30, -(2.0 ** 30), 2.0 ** 31, np.inf, -np.inf, np.nan, 1.0e20, -0.0, 0.0, 1.0, 1.5, -0.25, 2.0 ** 29, 0.3], np.float32)
+    freq, width = np.repeat(f[:, None], 64 * T, 1), np.repeat(w[:, None], 64 * T, 1)
+    co = np.full((1, V), 0.5, np.float32)
+    st_r = ref.chain_clear([Proc.PULSE_GEN], V)
+    st_r[0] = rng.integers(0, 2 ** 32, V, dtype=np.uint64).astype(np.uint32)
+    st_o = st_r.copy()
+    for call in range(2):
+        want = ref.proc_multi(Proc.PULSE_GEN, T, co, st_r, [freq, width])
+        got = oracle.proc_multi(Proc.PULSE_GEN, T, co, st_o, [freq, width])
+        assert_bits_equal(got, want, True, f"pulse absurd widths call {call}")
+        assert_bits_equal(st_o, st_r, False, "state")
+
+
 @pytest.mark.parametrize("vop", [Vop.COLUMN_INDEX, Vop.RANGE_OPEN, Vop.RANGE_CLOSED, Vop.INTERPOLATE_LINEAR])
 def test_vector_generators_match_reference(oracle, ref, vop):
     V, T = 9, 17
