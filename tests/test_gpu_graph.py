@@ -545,6 +545,7 @@ def test_clamp_with_constant_bounds_two_instruction_form(eng, oracle, flush):
     g.close()
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("vpl", [1, 2])
 def test_pulse_gen_with_absurd_widths(eng, oracle, vpl):
     """PulseGen with a per-voice frequency and a per-voice width takes, per wavefront, either a fast path that assumes a width
