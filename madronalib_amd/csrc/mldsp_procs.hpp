@@ -114,14 +114,14 @@ struct BlepFreq
     BlepFreq f;
     f.dt = dt;
     f.omdt = 1.0f - dt;
-    f.laneIsOdd = !FAST && (blep_freq_is_odd(dt) || otherwiseOdd);
+    f.laneIsOdd = (!FAST && blep_freq_is_odd(dt)) || otherwiseOdd;  // FAST vouches for the frequency, not for the caller's phase
     return f;
   }
   MLD bool lo(float t) const { return t < dt; }
   MLD bool hi(float t) const { return t > omdt; }  // only consulted when !lo (the reference's else-if)
   // wave-uniform: does any lane need the IEEE division? Asked only where a correction is really evaluated (after the
   // skip test), never on the quiet path
-  MLD bool anyLaneOdd() const { return !FAST && (__builtin_amdgcn_ballot_w64(laneIsOdd) != 0); }
+  MLD bool anyLaneOdd() const { return __builtin_amdgcn_ballot_w64(laneIsOdd) != 0; }  // (a FAST caller with no phase of its own: constant false)
   // the correction for a phase already known to be in the lower (isLo) or upper zone; garbage (never used) elsewhere
   MLD float correction(float t, bool isLo, bool full) const
   {
@@ -195,7 +195,10 @@ MLD float phasor_to_pulse(float p, float cps, float w)
   const float pulse = (p >= w) ? -1.f : 1.f;
   const float d = p - w + 1.0f;
   const float down = d - (float)(REGULAR_W ? (int32_t)d : sse_cvtt(d));  // fractionalPart
-  const BlepFreq<FAST> f = BlepFreq<FAST>::make(cps, ANY_PHASE && (phase_is_odd(p) || phase_is_odd(down)));
+  // a regular width leaves `down` a multiple of 2^-24 inside (-1, 1): div_nr's ground. Any other width (2^30 and up, inf, NaN)
+  // makes it huge, infinite or NaN, and the reference's own division has to produce whatever comes out of that.
+  const bool downOdd = ANY_PHASE ? phase_is_odd(down) : (!REGULAR_W && !(abs_ps(down) <= 2.0f));
+  const BlepFreq<FAST> f = BlepFreq<FAST>::make(cps, (ANY_PHASE && phase_is_odd(p)) || downOdd);
   const bool loUp = f.lo(p), nearUp = loUp || f.hi(p);
   const bool loDown = f.lo(down), nearDown = loDown || f.hi(down);
   if (SKIP && __builtin_amdgcn_ballot_w64(nearUp || nearDown) == 0) return pulse;
