@@ -436,3 +436,58 @@ def test_adsr_hostile_gates_and_states(eng, oracle, flush, garbage_state):
         bank.close()
     finally:
         eng.set_flush_denormals(False)
+
+
+def _hostile_signal(V, S, seed):
+    """[V][S]: ordinary noise with stretches of special values (inf, NaN, denormals, huge, -0) and raw bit patterns mixed in."""
+    from inputs import general_floats
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + np.uint32(seed), S)
+    g = general_floats(V * S, seed).reshape(V, S)
+    rng = np.random.default_rng(seed)
+    mask = rng.random((V, S)) < 0.05
+    x[mask] = g[mask]
+    x[1::7, S // 3:S // 3 + 40] = g[1::7, :40]      # whole stretches too, so that a recurrence has to live with them
+    return np.ascontiguousarray(x)
+
+
+SVF_KINDS = (Proc.LOPASS, Proc.HIPASS, Proc.BANDPASS, Proc.LO_SHELF, Proc.HI_SHELF, Proc.BELL)
+
+
+def _below_the_svf_overflow_regime(x):
+    """The state-variable filters' `ic += 2 t` is one fused instruction on the device: the same float unless 2 t overflows while
+    the sum does not, |t| > 1.7e38 (include/mlgpu.h, numerical contract: a filter that has blown up may reach inf / NaN a few
+    samples apart). Finite inputs are kept below 1e15 for them; infinities and NaNs stay."""
+    big = np.isfinite(x) & (np.abs(x) > 1e15)
+    y = x.copy()
+    y[big] = np.float32(1e15) * np.sign(x[big])
+    return y
+
+
+@pytest.mark.parametrize("kind", [k for k in Proc.ALL if k not in Proc.HW_APPROX and k != Proc.NOISE_GEN])
+def test_single_proc_hostile_input(eng, oracle, kind):
+    """Every processor with inputs nobody would send on purpose: infinities, NaNs, denormals, 1e38, raw bit patterns - as the
+    signal of a filter, the gate of an envelope, the frequency of an oscillator. The reference computes *something* for each of
+    them; so must the device, bit for bit (any NaN equals any NaN), output and final state, over two launches."""
+    V, T = 200, 6
+    procs = [kind]
+    co = chain_coeffs(oracle, procs, V, seed=5)
+    sig = _hostile_signal(V, 64 * T * 2, seed=int(kind) + 3)
+    if kind in SVF_KINDS:
+        sig = _below_the_svf_overflow_regime(sig)
+    st = oracle.chain_clear(procs, V)
+    if kind == Proc.ONE_SHOT_GEN:
+        st[1] = 1
+    bank = eng.bank(procs, V)
+    bank.set_all_coeffs(co)
+    bank.set_all_state(st)
+    for call in range(2):
+        part = np.ascontiguousarray(sig[:, call * 64 * T:(call + 1) * 64 * T])
+        got = bank.process_host(T, part, Layout.QUAD)
+        want = oracle.chain_process(procs, T, co, st, part, None, n_threads=8)
+        assert_bits_equal(got, want, True, f"hostile proc {kind} call {call}")
+        gst = bank.get_all_state()
+        # state words are floats or integers; a float NaN may differ in payload between the two machines
+        g32, w32 = gst.view(np.uint32), st.view(np.uint32)
+        bothnan = np.isnan(g32.view(np.float32)) & np.isnan(w32.view(np.float32))
+        assert ((g32 == w32) | bothnan).all(), f"hostile proc {kind} state call {call}"
+    bank.close()

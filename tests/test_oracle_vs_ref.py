@@ -65,6 +65,32 @@ def test_single_proc_matches_reference(oracle, ref, kind):
     assert_bits_equal(st_o, st_r, False, f"proc {kind} final state")
 
 
+@pytest.mark.parametrize("kind", [k for k in Proc.ALL if k not in Proc.HW_APPROX and k != Proc.NOISE_GEN])
+def test_single_proc_hostile_input_matches_reference(oracle, ref, kind):
+    """Pins the oracle on infinities, NaNs, denormals, huge values and raw bit patterns as the input of every processor
+    (tests/test_gpu_parity.py::test_single_proc_hostile_input drives the device with the same kind of signal)."""
+    from inputs import general_floats, lcg_noise
+    V, T = 24, 8
+    procs = [kind]
+    co = chain_coeffs(ref, procs, V, seed=5)
+    S = 64 * T
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + np.uint32(kind + 3), S)
+    g = general_floats(V * S, int(kind) + 3).reshape(V, S)
+    rng = np.random.default_rng(int(kind) + 3)
+    mask = rng.random((V, S)) < 0.05
+    x[mask] = g[mask]
+    x[1::7, S // 3:S // 3 + 40] = g[1::7, :40]
+    st_r = ref.chain_clear(procs, V)
+    if kind == Proc.ONE_SHOT_GEN:
+        st_r[1] = 1
+    st_o = st_r.copy()
+    want = ref.chain_process(procs, T, co, st_r, x, None)
+    got = oracle.chain_process(procs, T, co, st_o, x, None)
+    assert_bits_equal(got, want, True, f"hostile proc {kind}")
+    bothnan = np.isnan(st_o.view(np.float32)) & np.isnan(st_r.view(np.float32))
+    assert ((st_o == st_r) | bothnan).all(), f"hostile proc {kind} state"
+
+
 @pytest.mark.parametrize("garbage_state", [False, True])
 def test_adsr_hostile_gates_match_reference(oracle, ref, garbage_state):
     """Pins the oracle's ADSR on the inputs tests/test_gpu_parity.py::test_adsr_hostile_gates_and_states drives the device with:
