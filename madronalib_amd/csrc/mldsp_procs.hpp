@@ -1149,7 +1149,7 @@ struct Proc<MLGPU_PROC_INTEGER_DELAY>  // :801-914   C{}  S{writeIndex:u32, dela
   MLD void load(const VoiceMem& m, const KernelTables&)
   {
     mem = m;
-    ringc.w = m.s(0);
+    ringc.w = m.s(0) & m.memMask;  // (a write index a host set out of range cannot leave the ring)
     delay = (int32_t)m.s(1);
     ringc.begin(m, 0);
   }
@@ -1203,7 +1203,7 @@ struct FracCore
   int32_t delayInt;
   MLD void loadFrom(const VoiceMem& m, int s0)
   {
-    ringc.w = m.s(s0);
+    ringc.w = m.s(s0) & m.memMask;
     x1 = u2f(m.s(s0 + 1));
     y1 = u2f(m.s(s0 + 2));
     delayInt = (int32_t)m.s(s0 + 3);

@@ -581,3 +581,45 @@ def test_pulse_gen_with_absurd_widths(eng, oracle, vpl):
         for i, o in enumerate(outs):
             assert_bits_equal(got[i], want[i], True, f"pulse {o} call {call} vpl={vpl}")
     g.close()
+
+
+HOSTILE_MULTI = ("pulse2", "interp1", "linear_glide", "linear_glide_long", "tempo_lock")
+
+
+def hostile_multi_case(mk, name, V, T, seed):
+    """A multi-input case with 4 % of every input replaced by special values and raw bit patterns (and whole stretches on some
+    voices): frequencies and widths of a PulseGen, the targets of glides and interpolators, a TempoLock's phasor and ratios."""
+    from inputs import general_floats
+    case = multi_case(mk, name, V, T, seed=seed)
+    rng = np.random.default_rng(seed + 77)
+    ins = []
+    for rate, a in case["inputs"]:
+        a = a.copy()
+        g = general_floats(a.size + (-a.size) % 64, seed + len(ins))[:a.size].reshape(a.shape)
+        mask = rng.random(a.shape) < 0.04
+        a[mask] = g[mask]
+        w = min(24, a.shape[1] // 3)
+        a[2::9, a.shape[1] // 2:a.shape[1] // 2 + w] = g[2::9, :w]
+        ins.append((rate, np.ascontiguousarray(a)))
+    case["inputs"] = ins
+    return case
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", HOSTILE_MULTI)
+def test_multi_input_forms_hostile_inputs(eng, oracle, name):
+    """The multi-input / vector-rate forms with infinities, NaNs, denormals, huge values and raw bit patterns in every input
+    (tests/test_oracle_vs_ref.py pins the oracle on the same cases against the reference's objects)."""
+    V, T = 200, 12
+    case = hostile_multi_case(oracle, name, V, 2 * T, seed=33)
+    g, names = single_node_graph(eng, V, case)
+    st = oracle.chain_clear([case["kind"]], V)
+    outs, states = run_case_calls(g, names, case, T, st.copy(), Layout.QUAD)
+    ins = multi_inputs_audio(case, 2 * T)
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        want = oracle.proc_multi(case["kind"], T, case["coeffs"], st, [np.ascontiguousarray(x[:, sl]) for x in ins])
+        assert_bits_equal(outs[call], want, True, f"hostile {name} call {call}")
+        g32, w32 = states[call].view(np.uint32), st.view(np.uint32)
+        bothnan = np.isnan(g32.view(np.float32)) & np.isnan(w32.view(np.float32))
+        assert ((g32 == w32) | bothnan).all(), f"hostile {name} state after call {call}"

@@ -177,6 +177,24 @@ def test_multi_input_forms_match_reference(oracle, ref, name):
         assert_bits_equal(st_o, st_r, False, f"{name} state after call {call}")
 
 
+@pytest.mark.parametrize("name", ("pulse2", "interp1", "linear_glide", "linear_glide_long", "tempo_lock"))
+def test_multi_input_forms_hostile_inputs_match_reference(oracle, ref, name):
+    """Pins the oracle on tests/test_gpu_graph.py::test_multi_input_forms_hostile_inputs' kind of input."""
+    from test_gpu_graph import hostile_multi_case
+    V, T = 18, 12
+    case_r = hostile_multi_case(ref, name, V, T, seed=33)
+    case_o = hostile_multi_case(oracle, name, V, T, seed=33)
+    ins_r, ins_o = multi_inputs_audio(case_r, T), multi_inputs_audio(case_o, T)
+    kind = case_r["kind"]
+    st_r = ref.chain_clear([kind], V)
+    st_o = st_r.copy()
+    want = ref.proc_multi(kind, T, case_r["coeffs"], st_r, ins_r)
+    got = oracle.proc_multi(kind, T, case_o["coeffs"], st_o, ins_o)
+    assert_bits_equal(got, want, True, f"hostile {name}")
+    bothnan = np.isnan(st_o.view(np.float32)) & np.isnan(st_r.view(np.float32))
+    assert ((st_o == st_r) | bothnan).all(), f"hostile {name} state"
+
+
 def test_pulse_gen_absurd_widths_match_reference(oracle, ref):
     """PulseGen(freq, width) with widths whose shifted phase leaves the int32 range (fractionalPart through cvttps2dq's
     0x80000000), NaN and infinite widths: pins the oracle on what tests/test_gpu_graph.py::test_pulse_gen_with_absurd_widths
