@@ -22,6 +22,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -187,7 +188,8 @@ bool getCode(const std::string& source, std::vector<char>& code, std::string& lo
     }
     if (!path.empty())
     {
-      const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+      static std::atomic<unsigned> serial{0};  // two host threads (a DeviceGroup) may build the same kernel at the same time
+      const std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
       if (FILE* f = fopen(tmp.c_str(), "wb"))
       {
         const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
