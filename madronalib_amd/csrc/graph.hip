@@ -152,6 +152,20 @@ bool getCode(const std::string& source, std::vector<char>& code, std::string& lo
       return true;
     }
   }
+  // One build at a time: the host threads of a DeviceGroup ask for the same kernels at the same moment, and the second one
+  // should find the first one's result instead of running hiprtc again beside it.
+  static std::mutex buildMutex;
+  std::lock_guard<std::mutex> building(buildMutex);
+  {
+    std::lock_guard<std::mutex> lock(g_codeMutex);
+    auto it = g_codeCache.find(source);
+    if (it != g_codeCache.end())
+    {
+      code = it->second;
+      ++g_jitStats.memoryHits;
+      return true;
+    }
+  }
   const std::string path = cacheFile(source);
   bool fromDisk = false;
   if (!path.empty())

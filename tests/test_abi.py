@@ -240,3 +240,28 @@ print(json.dumps(dict(stats=ml.jit_stats(), seconds=dt, sha=hashlib.sha256(code)
     off = run("off")
     assert off["stats"]["compiles"] == 1 and off["stats"]["disk_hits"] == 0
     print(f"hiprtc cold {cold['seconds']:.2f} s, warm {warm['seconds']:.3f} s")
+
+
+def test_concurrent_builds_of_one_kernel_compile_once():
+    """The host threads of a multi-device program ask for the same kernel at the same time (ml::gpu::DeviceGroup, bench.py
+    --launcher threads): one of them runs hiprtc, the others get its code object."""
+    prog = r'''
+import json, threading
+import madronalib_amd as ml
+from madronalib_amd.constants import Op, Proc
+codes = [None] * 4
+def build(i):
+    g = ml.Graph(ml.OfflineEngine(), 256)
+    g.add("x", "input"); g.add("k", "const", value=0.625)
+    g.add("hp", "proc", Proc.HIPASS, ["x"]); g.add("y", "op", Op.MULTIPLY, ["hp", "k"]); g.add_output("y")
+    codes[i] = g.emit()[1]
+threads = [threading.Thread(target=build, args=(i,)) for i in range(4)]
+[t.start() for t in threads]; [t.join() for t in threads]
+print(json.dumps(dict(stats=ml.jit_stats(), same=all(c == codes[0] for c in codes), n=len(codes[0]))))
+'''
+    env = dict(os.environ, MLGPU_CACHE_DIR="off", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["same"] and out["n"] > 1000
+    assert out["stats"]["compiles"] == 1 and out["stats"]["memory_hits"] == 3, out["stats"]
