@@ -185,6 +185,7 @@ extern "C"
   {
     if (!e) return MLGPU_ERR_INVALID;
     if (e->recording) return fail(e, MLGPU_ERR_INVALID, "engine_sync: not while recording a sequence");
+    HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return MLGPU_OK;
   }
@@ -206,6 +207,7 @@ extern "C"
     if (!e || !out) return MLGPU_ERR_INVALID;
     *out = nullptr;
     if (!e->recording) return fail(e, MLGPU_ERR_INVALID, "end_recording: not recording");
+    hipSetDevice(e->device);
     e->recording = false;
     hipGraph_t graph = nullptr;
     HIP_TRY(e, hipStreamEndCapture(e->stream, &graph));
@@ -327,6 +329,7 @@ extern "C"
   {
     if (!e || !msOut || !e->ev0) return MLGPU_ERR_INVALID;
     if (e->recording) return fail(e, MLGPU_ERR_INVALID, "timer_stop waits for the device: not while recording a sequence");
+    HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
     HIP_TRY(e, hipEventSynchronize(e->ev1));
     HIP_TRY(e, hipEventElapsedTime(msOut, e->ev0, e->ev1));

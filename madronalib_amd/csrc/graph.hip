@@ -1506,7 +1506,7 @@ extern "C"
   // feedback node's stored vector
   static int clearNode(mlgpu_graph* g, const Node& n)
   {
-    hipError_t err = hipSuccess;
+    hipError_t err = hipSetDevice(g->e->device);  // (a host thread may drive engines on several devices in turn)
     if (n.type == NODE_FEEDBACK)
     {
       for (int i = 0; i < n.ns && err == hipSuccess; ++i) err = mlgpu_launch_fill32(g->d_state + (size_t)(n.sOff + i) * g->V, 0u, g->V, g->e->stream);
