@@ -177,3 +177,35 @@ def test_silent_instrument_and_many_instruments(eng):
     silent = got[:, 4:8]
     assert (silent[[0, 1, 3, 4, 5, 6, 7]] == 0).all()
     assert (silent[2] == np.arange(4, dtype=np.float32)[:, None]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["midi_poly4", "mpe5", "unison3"])
+def test_events_with_hostile_values(eng, name):
+    """The same performances with a third of the event VALUES replaced by what no controller sends: NaN and infinite pitches,
+    velocities that are zero, negative, NaN or 3e38, bends and pressures of 1e30, denormals, -0. (Indices stay legal: the
+    reference indexes its key and controller tables with them unchecked.) All 8 rows, bit for bit against the reference's own
+    class; any NaN equals any NaN."""
+    cfg = SCENARIOS[name]
+    block, n_blocks = 512, 10
+    kind = "mpe" if cfg.get("mpe") else "midi"
+    odd = [float("nan"), float("inf"), float("-inf"), 0.0, -0.0, -0.5, 3.0e38, -3.0e38, 1.0e30, 1.0e-40, -1.0e-40, 2.0, 1.0e-38]
+    instruments = []
+    for k in range(4):
+        rng = np.random.default_rng(900 + k)
+        evs = []
+        for e in performance(kind, 300 * k + len(name), block * n_blocks, cfg["polyphony"]):
+            e = list(e)
+            if e[0] != CTRL or e[2] not in (123,):      # leave "all notes off" alone
+                if rng.random() < 0.33:
+                    e[4] = odd[int(rng.integers(0, len(odd)))]
+                if rng.random() < 0.33 and e[0] == NOTE_ON:
+                    e[5] = odd[int(rng.integers(0, len(odd)))]
+            evs.append(tuple(e))
+        instruments.append(evs)
+    got = gpu_run(eng, cfg, instruments, block, n_blocks, vectors_per_launch=4)
+    P = cfg["polyphony"]
+    for k, evs in enumerate(instruments):
+        want = ref_run(cfg, evs, block, n_blocks)
+        for r in range(8):
+            assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"hostile {name}: instrument {k} row {ROW_NAMES[r]}")
