@@ -51,6 +51,7 @@ WORKLOADS = {
     "events": (262144, 16, 8),  # EventsToSignals: 16384 instruments x 16 voices, 8 control rows out
     "resample": (262144, 32, 8),  # Downsampler, 2 octaves: 32 vectors in -> 8 out per launch
     "synth": (262144, 16, 8),    # events -> synth16 voices (pitch and gate rows streamed) -> per-instrument voice sum
+    "synthfused": (262144, 16, 8),  # the same with pitch and gate computed inside the voice kernel (event rows as source nodes)
     "strings": (262144, 16, 8),  # a plucked-string model per voice: noise burst -> FractionalDelay (per-voice length) -> OnePole -> feedback
     "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
 }
@@ -193,7 +194,8 @@ def setup_workload(eng, name, V, T, lo, total):
         alg = 4.0 * len(rows) * n + V * T * 4.0 * 5 * glides * 2 + V * 4.0 * 23 * 2
         return launch, alg, "e2s_kernel", (f"EventsToSignals: 16384 instruments x 16 voices, {len(rows)} control signals out, sparse note events "
                                            "(host routing + record upload inside the step)"), ev
-    if name == "synth":
+    if name in ("synth", "synthfused"):
+        fusedRows = name == "synthfused"
         # A bank of polyphonic instruments end to end, as ml::gpu::SynthProgram runs a Synth subclass: EventsToSignals (only the
         # rows the voice reads) -> the fused voice graph -> the per-instrument voice sum (Synth::processVector, MLSynth.h:43-57)
         from madronalib_amd import patches
@@ -203,8 +205,10 @@ def setup_workload(eng, name, V, T, lo, total):
         ev = ml.Events(eng, N, P, 48000.0)
         ev.configure(glide_seconds=0.01, drift=0.5)
         ev.set_wanted_rows([0, 1])
-        desc, outs = patches.synth16(pitch_input=True)
+        desc, outs = patches.synth16(pitch_input=True, event_rows=fusedRows)
         g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=True)
+        if fusedRows:
+            g.bind_events(ev)
         g.clear()
         params, coeffs, seeds = cfg5_voice_params(lo, lo + V, total, ml)
         for k, v in params.items():
@@ -234,15 +238,20 @@ def setup_workload(eng, name, V, T, lo, total):
                     held.setdefault(i, []).append(key)
                     evs.append(ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
             ev.add_events(insts, evs)
-            ev.process(T, 0, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
-            ev.clear_events()
-            g.process(T, [rows[1] if nm == "gate" else rows[0] for nm in names], [d_voices])
+            if fusedRows:
+                g.process_events(T, 0, [], [d_voices])
+                ev.clear_events()
+            else:
+                ev.process(T, 0, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
+                ev.clear_events()
+                g.process(T, [rows[1] if nm == "gate" else rows[0] for nm in names], [d_voices])
             eng.mixdown_groups(d_voices, Layout.QUAD, N, P, T, d_mix[k[0] & 1])
             k[0] += 1
         # pitch + gate written and read, voice audio written and read, instrument audio written
-        alg = (8.0 + 8.0 + 4.0 + 4.0) * n + 4.0 * N * T * 64
+        alg = ((0.0 if fusedRows else 8.0 + 8.0) + 4.0 + 4.0) * n + 4.0 * N * T * 64
         return launch, alg, "mlgpu_graph_kernel", ("16384 instruments x 16 voices end to end: note events -> EventsToSignals (pitch, gate) -> 16-node "
-                                                    "voice graph -> per-instrument voice sum"), (ev, g)
+                                                    "voice graph -> per-instrument voice sum"
+                                                    + ("; pitch and gate computed inside the voice kernel, never written" if fusedRows else "")), (ev, g)
     if name == "resample":
         r = ml.Resampler(eng, V, 2, False)
         x = eng.bank([Proc.NOISE_GEN], V)

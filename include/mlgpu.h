@@ -702,6 +702,21 @@ int mlgpu_events_clear_events(mlgpu_events* ev);                            /* c
  * the object with mlgpu_events_set_protocol to silence an instrument. */
 int mlgpu_events_process(mlgpu_events* ev, size_t n_vectors, int start_offset, float* const* d_outputs, int layout);
 
+/*
+ * The pitch and gate rows as SOURCE NODES of a voice graph: a Synth's voices read voice.outputs.row(kPitch / kGate) straight
+ * from EventsToSignals (source/app/MLSynth.h:43-57, MLEventsToSignals.h:15-26); here the graph kernel computes those two rows
+ * itself, frame by frame, from the same records and the same per-voice state as mlgpu_events_process - the rows never exist in
+ * memory. MIDI protocol; instruments x polyphony must equal the graph's voices; voice v of the graph is voice v of the object
+ * (instrument v / polyphony, voice v % polyphony). Per block: mlgpu_events_add_event(s), then mlgpu_graph_process_events with
+ * the block's frame offset (what mlgpu_events_process takes), then mlgpu_events_clear_events as usual. A block may be processed
+ * by either call: both leave the state the other expects (rows a call does not compute keep their glides where they are, as
+ * with mlgpu_events_set_wanted_rows).
+ */
+int mlgpu_graph_add_event_row(mlgpu_graph* g, int row /* 0 pitch, 1 gate */, const char* name); /* before compile; node id */
+int mlgpu_graph_bind_events(mlgpu_graph* g, mlgpu_events* ev);
+int mlgpu_graph_process_events(mlgpu_graph* g, size_t n_vectors, int start_offset, const float* const* d_inputs, int in_layout,
+                               const float* const* d_controls, float* const* d_outputs, int out_layout);
+
 /* ------------------------------------------------------------------------- */
 /* published signals                                                         */
 /*

@@ -924,6 +924,8 @@ class Graph:
         if type == "control":
             self.controls.append(name)
             return self._ret(self.L.mlgpu_graph_add_control(self.h, bname), name)
+        if type == "event_row":   # kind: 0 pitch, 1 gate of the Events object bound with bind_events()
+            return self._ret(self.L.mlgpu_graph_add_event_row(self.h, int(kind), bname), name)
         if type == "vop":
             return self._ret(self.L.mlgpu_graph_add_vop(self.h, int(kind), arr, len(ins), bname), name)
         if type == "route":
@@ -1023,6 +1025,19 @@ class Graph:
         po = (ctypes.c_void_p * max(1, len(d_outputs)))(*[raw(b) for b in d_outputs])
         pc = (ctypes.c_void_p * max(1, len(d_controls)))(*[raw(b) for b in d_controls])
         self.engine._check(self.L.mlgpu_graph_process_ctl(self.h, int(n_vectors), pi, int(in_layout), pc, po, int(out_layout)))
+
+    def bind_events(self, events):
+        """The Events object whose pitch / gate rows the graph's event_row nodes compute (MIDI protocol, same number of voices)."""
+        self.engine._check(self.L.mlgpu_graph_bind_events(self.h, events.h))
+        self._events = events
+
+    def process_events(self, n_vectors, start_offset, d_inputs, d_outputs, in_layout=Layout.QUAD, out_layout=Layout.QUAD, d_controls=()):
+        """process() for a graph with event rows: the block's events (Events.add_events) starting at frame start_offset."""
+        raw = lambda b: b.ptr if hasattr(b, "ptr") else int(b)  # noqa: E731
+        pi = (ctypes.c_void_p * max(1, len(d_inputs)))(*[raw(b) for b in d_inputs])
+        po = (ctypes.c_void_p * max(1, len(d_outputs)))(*[raw(b) for b in d_outputs])
+        pc = (ctypes.c_void_p * max(1, len(d_controls)))(*[raw(b) for b in d_controls])
+        self.engine._check(self.L.mlgpu_graph_process_events(self.h, int(n_vectors), int(start_offset), pi, int(in_layout), pc, po, int(out_layout)))
 
     def process_host(self, n_vectors, in_signals, layout=Layout.QUAD):
         """Test convenience: VOICE_MAJOR numpy in ({name: [V][64T]}) -> list of VOICE_MAJOR numpy outs."""

@@ -24,171 +24,18 @@
 
 #include "mlgpu_internal.hpp"
 #include "mldsp_math.hpp"
+#include "mldsp_events.hpp"
 
 using namespace mldev;
+using namespace mlev;
 
 namespace
 {
-// ---- records ------------------------------------------------------------------------------------------------------
-enum RecType : uint32_t
-{
-  REC_AWAKE = 0,      // the instrument received its first event: processVector stops being a no-op (:383-386)
-  REC_NOTE_ON = 1,    // writeNoteEvent kNoteOn (:129-152):   v1 pitch, v2 velocity, flags bit0 doGlide bit1 doReset
-  REC_NOTE_RETRIG = 2,
-  REC_NOTE_OFF = 3,
-  REC_SET_BEND = 4,   // currentPitchBend = v1 (:700-731)
-  REC_SET_MOD = 5,
-  REC_SET_X = 6,
-  REC_SET_Y = 7,
-  REC_SET_Z = 8,
-  REC_SET_CHANNEL_PRESSURE = 9  // controllers[128].inputValue (MIDI mode, :620-626)
-};
-struct Rec
-{
-  uint32_t vec;    // DSPVector index inside this launch
-  uint32_t typeTimeFlags;  // type | time << 8 | flags << 16
-  float v1, v2;
-};
 inline Rec makeRec(uint32_t vec, uint32_t type, int time, uint32_t flags, float v1, float v2)
 {
   const uint32_t t = (uint32_t)std::min(std::max(time, 0), 64);  // destTime = clamp(e.time, 0, 64) (:121)
   return Rec{vec, type | (t << 8) | (flags << 16), v1, v2};
 }
-
-// ---- device state layout (uint32 words per voice, SoA [word][lanes]) --------------------------------------------------
-enum : int
-{
-  S_AWAKE = 0, S_VELOCITY, S_PITCH, S_BEND, S_MOD, S_X, S_Y, S_Z, S_CHANPRESS, S_AGE, S_AGE_STEP, S_INHIBIT_GLIDE,
-  S_PG_CURR, S_PG_STEP, S_PG_TARGET, S_PG_REMAINING, S_PG_PER_GLIDE, S_PG_DY,
-  S_DRIFT_SEED, S_DRIFT_COUNTER, S_DRIFT_VALUE, S_DRIFT_NEXT,
-  S_RECALC,  // Voice::recalcNeeded (:45-54): set by setSampleRate / setPitchGlideInSeconds, consumed by the next beginProcess
-  S_GLIDES  // 7 glides follow: bend, mod, x, y, z, drift, channel pressure
-};
-constexpr int kNumGlides = 7;
-constexpr int kGlideWords = 5 + 64;  // target, step, remaining, isUniform, uniformValue, currVec[64]
-constexpr int kStateWords = S_GLIDES + kNumGlides * kGlideWords;
-
-struct E2SSettings
-{
-  double sr;
-  float pitchBendRange, mpePitchBendRange, driftAmount;
-  int32_t pitchGlideSamples;           // sr * pitchGlideTimeInSeconds (:90)
-  int32_t glideVectors;  float glideDy;        // bend / mod / x / y / z / controllers: sr * 0.02 s (:97-101, 275)
-  int32_t driftGlideVectors;  float driftGlideDy;  // sr * 8 s (:103)
-  int32_t ctlGlideVectors;  float ctlGlideDy;      // SmoothedController: int(sr * 0.02 s) samples (:274-275) — truncated first
-  int32_t mpe;                         // protocol
-};
-
-struct E2SArgs
-{
-  uint32_t* state;            // [kStateWords][lanes]
-  const Rec* recs;            // all records of this launch, grouped by lane, time-ordered inside a lane
-  const uint32_t* recStart;   // [lanes + 1]
-  SignalView out[8];          // pitch, gate, vox, z, x, y, mod, elapsed time: V = instruments * polyphony voices
-  size_t lanes, T;
-  int group, polyphony, slotBase;  // lane = instrument * group + (voice slot - slotBase)
-  uint32_t rowMask;                // rows that are computed (mlgpu_events_set_wanted_rows); bit r = row r of `out`
-  uint32_t flags;                  // MLGPU_KFLAG_*
-  E2SSettings s;
-};
-
-// LinearGlide (MLDSPGens.h:433-515) with one shortcut that does not change results: between glides mCurrVec is a
-// broadcast of one value, kept in a register instead of 64 words of HBM. `st` is this glide's first word for this lane
-// (stride = lanes); it is passed in instead of stored to keep the register count of seven glides down.
-struct Glide
-{
-  float target, step, uniformValue, startValue;
-  int32_t remaining;
-  int modeFlags;  // bits 0-1: mode (0 hold, 1 end, 2 start, 3 continue); bit 2: mCurrVec is uniform
-  MLD bool isUniform() const { return (modeFlags & 4) != 0; }
-  MLD int mode() const { return modeFlags & 3; }
-  MLD void load(const uint32_t* st, size_t stride)
-  {
-    target = u2f(st[0]);
-    step = u2f(st[stride]);
-    remaining = (int32_t)st[2 * stride];
-    modeFlags = st[3 * stride] ? 4 : 0;
-    uniformValue = u2f(st[4 * stride]);
-    startValue = 0.f;
-  }
-  MLD void store(uint32_t* st, size_t stride) const
-  {
-    st[0] = f2u(target);
-    st[stride] = f2u(step);
-    st[2 * stride] = (uint32_t)remaining;
-    st[3 * stride] = isUniform() ? 1u : 0u;
-    st[4 * stride] = f2u(uniformValue);
-  }
-  MLD void beginVector(const uint32_t* st, size_t stride, float f, int32_t perGlide, float dyPerVector)
-  {
-    if (f != target)
-    {
-      target = f;
-      remaining = perGlide;
-    }
-    int m;
-    if (remaining < 0) m = 0;
-    else if (remaining == 0)
-    {
-      m = 1;
-      step = 0.f;
-      remaining--;
-    }
-    else if (remaining == perGlide)
-    {
-      m = 2;
-      startValue = isUniform() ? uniformValue : u2f(st[(size_t)(5 + 63) * stride]);
-      step = (target - startValue) * dyPerVector;
-      remaining--;
-    }
-    else
-    {
-      m = 3;
-      remaining--;
-    }
-    modeFlags = (modeFlags & 4) | m;
-  }
-  // mCurrVec[n] is read and rewritten at sample n only, so a quad's four slots can be fetched together (and a quad ahead):
-  // a load per sample in the middle of the load -> add -> store chain made the whole kernel wait out a memory round trip
-  // per sample (62 us per DSPVector per wavefront).
-  MLD bool readsCurrVec() const { return !isUniform() && (mode() == 0 || mode() == 3); }
-  MLD void preload(const uint32_t* st, size_t stride, int q, float cur[4]) const
-  {
-    if (readsCurrVec())
-    {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) cur[k] = u2f(st[(size_t)(5 + 4 * q + k) * stride]);
-    }
-  }
-  MLD float next(uint32_t* st, size_t stride, int n) const  // one sample at a time (the record-walking path)
-  {
-    return nextWith(st, stride, n, readsCurrVec() ? u2f(st[(size_t)(5 + n) * stride]) : 0.f);
-  }
-  MLD float nextWith(uint32_t* st, size_t stride, int n, float cur) const  // cur: what preload fetched for slot n
-  {
-    const int m = mode();
-    if (m == 0) return isUniform() ? uniformValue : cur;
-    if (m == 1) return target;
-    float c;
-    if (m == 2) c = startValue + ((float)(n + 1) * 0.015625f) * step;
-    else c = (isUniform() ? uniformValue : cur) + step;
-    st[(size_t)(5 + n) * stride] = f2u(c);
-    return c;
-  }
-  MLD void endVector()
-  {
-    const int m = mode();
-    if (m == 1)
-    {
-      modeFlags = 4;
-      uniformValue = target;
-    }
-    else if (m >= 2)
-      modeFlags = 0;
-    else
-      modeFlags &= 4;
-  }
-};
 
 #ifndef MLGPU_E2S_WAVES
 #define MLGPU_E2S_WAVES 4
@@ -1112,24 +959,13 @@ extern "C"
     return MLGPU_OK;
   }
 
-  // processVector (:376-466) for n_vectors consecutive DSPVectors starting at frame start_offset of the event times.
-  int mlgpu_events_process(mlgpu_events* ev, size_t nVectors, int startOffset, float* const* d_outputs, int layout)
+  // Everything of processVector (:376-466) that happens on the host for nVectors DSPVectors starting at frame startOffset of the
+  // event times: the block's events routed into per-voice records, the records uploaded (asynchronously, into the staging set
+  // that is free), the settings the device needs. The caller launches the kernel that consumes them - e2s_kernel, or a voice
+  // graph whose pitch and gate rows are source nodes (graph.hip) - and then calls launched().
+  static int prepare(mlgpu_events* ev, size_t nVectors, int startOffset, EventsDev& dev, mlgpu_events::Staging*& sgOut)
   {
-    if (!ev || !d_outputs) return MLGPU_ERR_INVALID;
     mlgpu_engine* e = ev->e;
-    if (nVectors == 0) return MLGPU_OK;
-    if (e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_process routes events on the host: not while recording a sequence");
-    if (ev->sr == 0) return efail(ev, MLGPU_ERR_INVALID, "events_process: no sample rate (the reference does nothing, :385)");
-    if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return efail(ev, MLGPU_ERR_INVALID, "events_process: bad layout");
-    // everything that can be refused is refused BEFORE the router consumes the block's note events: after this point the
-    // host-side voice allocator (keys, creatorKeyIdx, sustain pedal, lastFreeVoiceFound) has advanced, and an error return
-    // (allocation, upload, launch) leaves host and device voice state out of step - reset the object with
-    // mlgpu_events_set_protocol / a fresh mlgpu_events if that ever happens.
-    for (int r = 0; r < 8; ++r)
-    {
-      if (d_outputs[r] && ((uintptr_t)d_outputs[r] & 15)) return efail(ev, MLGPU_ERR_INVALID, "events_process: misaligned output");
-      if (d_outputs[r] && !((ev->rowMask >> r) & 1u)) return efail(ev, MLGPU_ERR_INVALID, "events_process: an output was passed for a row outside events_set_wanted_rows");
-    }
     // ---- route this launch's events into per-voice records ----
     for (uint32_t l : ev->dirtyLanes) ev->laneRecs[l].clear();
     ev->dirtyLanes.clear();
@@ -1159,6 +995,7 @@ extern "C"
     const size_t lanes = ev->lanes();
     if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
     mlgpu_events::Staging& sg = ev->stage[ev->stageIdx];
+    sgOut = &sg;
     ev->stageIdx ^= 1;
     if (sg.pending && hipEventSynchronize(sg.done) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "events_process: waiting for the launch before last");
     sg.pending = false;
@@ -1192,11 +1029,64 @@ extern "C"
     if (cerr == hipSuccess && nRecs) cerr = hipMemcpyAsync(sg.d_recs, sg.h_recs, sizeof(Rec) * nRecs, hipMemcpyHostToDevice, e->stream);
     if (cerr != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process upload: ") + hipGetErrorString(cerr));
 
+    memset(&dev.s, 0, sizeof(dev.s));
+    dev.s.sr = ev->sr;
+    dev.s.pitchBendRange = ev->pitchBendRange;
+    dev.s.mpePitchBendRange = ev->mpePitchBendRange;
+    dev.s.driftAmount = ev->driftAmount;
+    dev.s.pitchGlideSamples = (int32_t)(ev->sr * ev->pitchGlideSeconds);  // :90
+    float c[2];
+    mlgpu_linear_glide_make_coeffs((float)(ev->sr * 0.02f), c);          // kGlideTimeSeconds / kControllerGlideTimeSeconds
+    memcpy(&dev.s.glideVectors, &c[0], 4);
+    dev.s.glideDy = c[1];
+    mlgpu_linear_glide_make_coeffs((float)(ev->sr * 8.0f), c);           // kDriftTimeSeconds
+    memcpy(&dev.s.driftGlideVectors, &c[0], 4);
+    dev.s.driftGlideDy = c[1];
+    mlgpu_linear_glide_make_coeffs((float)(int)(ev->sr * 0.02f), c);    // SmoothedController: int glideTimeInSamples = sr * 0.02f
+    memcpy(&dev.s.ctlGlideVectors, &c[0], 4);
+    dev.s.ctlGlideDy = c[1];
+    dev.s.mpe = ev->mpe ? 1 : 0;
+    dev.state = ev->d_state;
+    dev.recs = sg.d_recs;
+    dev.recStart = sg.d_recStart;
+    dev.lanes = lanes;
+    return MLGPU_OK;
+  }
+  static int launched(mlgpu_events* ev, mlgpu_events::Staging& sg)
+  {
+    if (hipEventRecord(sg.done, ev->e->stream) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "events_process: event");
+    sg.pending = true;  // no wait here: the host goes on routing the next block while this one runs
+    return MLGPU_OK;
+  }
+
+  // processVector (:376-466) for n_vectors consecutive DSPVectors starting at frame start_offset of the event times.
+  int mlgpu_events_process(mlgpu_events* ev, size_t nVectors, int startOffset, float* const* d_outputs, int layout)
+  {
+    if (!ev || !d_outputs) return MLGPU_ERR_INVALID;
+    mlgpu_engine* e = ev->e;
+    if (nVectors == 0) return MLGPU_OK;
+    if (e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_process routes events on the host: not while recording a sequence");
+    if (ev->sr == 0) return efail(ev, MLGPU_ERR_INVALID, "events_process: no sample rate (the reference does nothing, :385)");
+    if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return efail(ev, MLGPU_ERR_INVALID, "events_process: bad layout");
+    // everything that can be refused is refused BEFORE the router consumes the block's note events: after this point the
+    // host-side voice allocator (keys, creatorKeyIdx, sustain pedal, lastFreeVoiceFound) has advanced, and an error return
+    // (allocation, upload, launch) leaves host and device voice state out of step - reset the object with
+    // mlgpu_events_set_protocol / a fresh mlgpu_events if that ever happens.
+    for (int r = 0; r < 8; ++r)
+    {
+      if (d_outputs[r] && ((uintptr_t)d_outputs[r] & 15)) return efail(ev, MLGPU_ERR_INVALID, "events_process: misaligned output");
+      if (d_outputs[r] && !((ev->rowMask >> r) & 1u)) return efail(ev, MLGPU_ERR_INVALID, "events_process: an output was passed for a row outside events_set_wanted_rows");
+    }
+    EventsDev dev;
+    mlgpu_events::Staging* sg = nullptr;
+    const int pst = prepare(ev, nVectors, startOffset, dev, sg);
+    if (pst != MLGPU_OK) return pst;
     E2SArgs a;
     memset(&a, 0, sizeof(a));
-    a.state = ev->d_state;
-    a.recs = sg.d_recs;
-    a.recStart = sg.d_recStart;
+    a.state = dev.state;
+    a.recs = (const Rec*)dev.recs;
+    a.recStart = dev.recStart;
+    const size_t lanes = dev.lanes;
     const size_t V = ev->nInstruments * (size_t)ev->polyphony;
     for (int r = 0; r < 8; ++r) a.out[r] = makeView(d_outputs[r], layout, V, nVectors);
     a.lanes = lanes;
@@ -1206,27 +1096,31 @@ extern "C"
     a.group = ev->group;
     a.slotBase = ev->slotBase;
     a.polyphony = ev->polyphony;
-    a.s.sr = ev->sr;
-    a.s.pitchBendRange = ev->pitchBendRange;
-    a.s.mpePitchBendRange = ev->mpePitchBendRange;
-    a.s.driftAmount = ev->driftAmount;
-    a.s.pitchGlideSamples = (int32_t)(ev->sr * ev->pitchGlideSeconds);  // :90
-    float c[2];
-    mlgpu_linear_glide_make_coeffs((float)(ev->sr * 0.02f), c);          // kGlideTimeSeconds / kControllerGlideTimeSeconds
-    memcpy(&a.s.glideVectors, &c[0], 4);
-    a.s.glideDy = c[1];
-    mlgpu_linear_glide_make_coeffs((float)(ev->sr * 8.0f), c);           // kDriftTimeSeconds
-    memcpy(&a.s.driftGlideVectors, &c[0], 4);
-    a.s.driftGlideDy = c[1];
-    mlgpu_linear_glide_make_coeffs((float)(int)(ev->sr * 0.02f), c);    // SmoothedController: int glideTimeInSamples = sr * 0.02f
-    memcpy(&a.s.ctlGlideVectors, &c[0], 4);
-    a.s.ctlGlideDy = c[1];
-    a.s.mpe = ev->mpe ? 1 : 0;
+    a.s = dev.s;
     hipLaunchKernelGGL(e2s_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process launch: ") + hipGetErrorString(err));
-    if (hipEventRecord(sg.done, e->stream) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "events_process: event");
-    sg.pending = true;  // no wait here: the host goes on routing the next block while this one runs
-    return MLGPU_OK;
+    return launched(ev, *sg);
   }
+
+  // for graph.hip: a graph whose event rows are bound to this object (mlgpu_graph_bind_events)
+  int mlgpu_events_prepare_for_graph(mlgpu_events* ev, size_t nVectors, int startOffset, EventsDev* dev, void** staging)
+  {
+    if (!ev || !dev || !staging) return MLGPU_ERR_INVALID;
+    if (nVectors == 0) return MLGPU_OK;
+    if (ev->e->recording) return efail(ev, MLGPU_ERR_INVALID, "events route on the host: not while recording a sequence");
+    if (ev->sr == 0) return efail(ev, MLGPU_ERR_INVALID, "events: no sample rate (the reference does nothing, :385)");
+    if (ev->mpe) return efail(ev, MLGPU_ERR_UNSUPPORTED, "events as graph source nodes: MIDI protocol only (one lane per voice)");
+    mlgpu_events::Staging* sg = nullptr;
+    const int st = prepare(ev, nVectors, startOffset, *dev, sg);
+    *staging = sg;
+    return st;
+  }
+  int mlgpu_events_launched_by_graph(mlgpu_events* ev, void* staging)
+  {
+    if (!ev || !staging) return MLGPU_ERR_INVALID;
+    return launched(ev, *(mlgpu_events::Staging*)staging);
+  }
+  int mlgpu_events_is_midi(mlgpu_events* ev) { return (ev && !ev->mpe) ? 1 : 0; }
+  mlgpu_engine* mlgpu_events_engine(mlgpu_events* ev) { return ev ? ev->e : nullptr; }
 }

@@ -285,7 +285,8 @@ enum NodeType
   NODE_CONTROL = 5,  // streamed, one float per DSPVector per voice
   NODE_VOP = 6,      // index-dependent vector generator (columnIndex, rangeOpen, ...)
   NODE_ROUTE = 7,    // multiplex / demultiplex (MLDSPRouting.h); in[0] is the selector
-  NODE_FEEDBACK = 8  // value of another node one DSPVector ago (64 state words per voice)
+  NODE_FEEDBACK = 8,  // value of another node one DSPVector ago (64 state words per voice)
+  NODE_EVENT_ROW = 9  // a row of the bound EventsToSignals object, computed in this kernel (slot: 0 pitch, 1 gate)
 };
 
 // how often a node's value changes: per voice (params, consts and ops on them), per DSPVector (controls and
@@ -376,6 +377,9 @@ struct mlgpu_graph
   int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
   int compiledVoicesPerLane{1};
   int unrollQ{1};                // quads per trip of the sample loop
+  mlgpu_events* events{nullptr}; // mlgpu_graph_bind_events: the object the NODE_EVENT_ROW nodes read
+  bool hasEventRows{false};
+  int eventOffset{-1};           // frame offset of the block being processed (mlgpu_graph_process_events), -1: none pending
   int minWaves{0};               // wavefronts per SIMD the kernel's register budget must allow (0: the compiler's choice), generateBudgeted
   // Online tuning (mlgpu_graph_set_autotune): every variant (voices per lane x quads per trip) computes the same bits from
   // the same state arrays, so the first process calls simply take turns, are timed, and the fastest one stays.
@@ -452,6 +456,7 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
   {
     case NODE_INPUT: s << "xin" << n.slot << L << "[k]"; break;
     case NODE_CONTROL: s << "ctl" << n.slot << L << "[t * a.V]"; break;
+    case NODE_EVENT_ROW: s << (n.slot == 0 ? "evP" : "evG") << L << "[k]"; break;
     case NODE_PARAM: s << "a.params[(size_t)" << n.slot << " * a.V + v" << L << "]"; break;
     case NODE_CONST:
       if (g->liveConsts) s << "a.consts[" << n.slot << "]";  // wave-uniform: a scalar load, kept in an SGPR
@@ -545,7 +550,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   std::ostringstream s;
   auto sfx = [](int l) { return "_" + std::to_string(l); };
   s << "// generated by libmlgpu graph.hip (" << VL << " voice" << (VL > 1 ? "s" : "") << " per lane)\n"
-    << (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\nusing namespace mldev;\n";
+    << (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\n" << (g->hasEventRows ? "#include \"mldsp_events.hpp\"\n" : "") << "using namespace mldev;\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_VOP && g->nodes[i].kind == MLGPU_VOP_TABLE)
     {
@@ -632,7 +637,12 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X)
       for (int in : R.ins)
         for (int l = 0; l < VL; ++l) s << "  float prev" << in << sfx(l) << " = 0.f;\n";
+  // EventsToSignals rows computed here: one EventsVoice per voice (lane == voice index: MIDI protocol)
+  if (g->hasEventRows)
+    for (int l = 0; l < VL; ++l) s << "  mlev::EventsVoice ev" << sfx(l) << ";\n  ev" << sfx(l) << ".load(a.events, v" << sfx(l) << ");\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
+  if (g->hasEventRows)
+    for (int l = 0; l < VL; ++l) s << "    ev" << sfx(l) << ".begin_vector(t);\n";
   // once per DSPVector: vector-rate nodes, then the vector-rate processors' begin_vector
   for (size_t i = 0; i < g->nodes.size(); ++i)
   {
@@ -655,6 +665,9 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         << i << "].strideQ);\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l) s << "      f32x4 y" << o << sfx(l) << ";\n";
+  if (g->hasEventRows)
+    for (int l = 0; l < VL; ++l)
+      s << "      mlev::EventsVoice::f32x4e evP" << sfx(l) << ", evG" << sfx(l) << ";\n      ev" << sfx(l) << ".quad(q, evP" << sfx(l) << ", evG" << sfx(l) << ");\n";
   // A kept DSPVector's slot n is read and rewritten at sample n only: fetch the quad's four slots together, ahead of the
   // stores of the sample loop (one load per sample between those stores costs a memory round trip per sample).
   for (size_t i = 0; i < g->nodes.size(); ++i)
@@ -806,7 +819,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC && (g->nodes[i].region < 0 || g->nodes[i].role != ROLE_NONE))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".end_vector();\n";
+  if (g->hasEventRows)
+    for (int l = 0; l < VL; ++l) s << "    ev" << sfx(l) << ".end_vector();\n";
   s << "  }\n";
+  if (g->hasEventRows)
+    for (int l = 0; l < VL; ++l) s << "  ev" << sfx(l) << ".store();\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC)
       for (int l = 0; l < VL; ++l) s << "  p" << i << sfx(l) << ".store(m" << i << sfx(l) << ");\n";
@@ -833,11 +850,13 @@ static bool codeObjectNumber(const std::vector<char>& code, const char* key, lon
 }
 
 // Source + code object of the graph kernel for `vl` voices per lane, with the register budget chosen: a voice bank is launched
-// as whole blocks of four wavefronts, one per SIMD, and the bank sizes that matter are a few blocks per CU - so a kernel
-// that needs 129..192 VGPRs (three wavefronts per SIMD, or two) runs its blocks in two rounds where one that fits 128 runs
-// them in one. If the kernel is in that band it is generated again with a 4-wavefront bound, and the bounded one is kept when
-// what it spills is small (the patch of SURVEY 8d: 170 VGPRs -> 128 + 156 bytes of scratch per lane, 1.82 -> 1.46 ms).
-// MLGPU_GRAPH_MIN_WAVES=0 / N overrides (developer knob).
+// as whole blocks of four wavefronts, one per SIMD, and a big bank is a few blocks per CU - so a kernel that needs more than
+// 128 VGPRs (three, two or one wavefront per SIMD) runs its blocks in rounds where one that fits 128 runs them all at once. If
+// the bank is big enough for that to matter (65 536 voices: a block per CU) and the kernel is above 128, it is generated again
+// with a 4-wavefront bound, and the bounded one is kept when what it spills is moderate (the patch of SURVEY 8d: 170 VGPRs ->
+// 128 + 156 bytes of scratch per lane, 1.82 -> 1.46 ms; the voice with its EventsToSignals rows inside: 259 -> 128 + 528 bytes,
+// 3.13 -> 1.56 ms, where bounds of two and three wavefronts give 1.96 and 1.85). MLGPU_GRAPH_MIN_WAVES=0 / N overrides
+// (developer knob).
 static bool generateBudgeted(mlgpu_graph* g, int vl, std::string& source, std::vector<char>& code, std::string& log)
 {
   const char* knob = getenv("MLGPU_GRAPH_MIN_WAVES");
@@ -845,14 +864,14 @@ static bool generateBudgeted(mlgpu_graph* g, int vl, std::string& source, std::v
   source = generateGraphSource(g, vl);
   if (!getCode(source, code, log)) return false;
   long vgprs = 0;
-  if (knob || (g->windowedRings && g->totalRings) || !codeObjectNumber(code, ".vgpr_count", vgprs) || vgprs <= 128 || vgprs > 192) return true;
+  if (knob || (g->windowedRings && g->totalRings) || g->V < 65536 || !codeObjectNumber(code, ".vgpr_count", vgprs) || vgprs <= 128) return true;
   g->minWaves = 4;
   const std::string bounded = generateGraphSource(g, vl);
   g->minWaves = 0;
   std::vector<char> boundedCode;
   std::string boundedLog;
   long scratch = 0;
-  if (getCode(bounded, boundedCode, boundedLog) && codeObjectNumber(boundedCode, ".private_segment_fixed_size", scratch) && scratch <= 512)
+  if (getCode(bounded, boundedCode, boundedLog) && codeObjectNumber(boundedCode, ".private_segment_fixed_size", scratch) && scratch <= 640)
   {
     source = bounded;
     code.swap(boundedCode);
@@ -889,7 +908,7 @@ int addNode(mlgpu_graph* g, Node&& n)
     if (g->openRegion >= 0)
     {
       const bool vectorProc = (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind));
-      if (n.type == NODE_INPUT || n.type == NODE_CONTROL || vectorProc || n.rate == RATE_VECTOR)
+      if (n.type == NODE_INPUT || n.type == NODE_CONTROL || n.type == NODE_EVENT_ROW || vectorProc || n.rate == RATE_VECTOR)
         return -gfail(g, MLGPU_ERR_UNSUPPORTED, "graph: streamed inputs, controls and vector-rate processors cannot live inside a rate region");
       if (n.rate == RATE_AUDIO) n.region = g->openRegion;
     }
@@ -1143,6 +1162,32 @@ extern "C"
     const int id = addNode(g, std::move(n));
     if (id >= 0) g->nControls++;
     return id;
+  }
+  // a row of an EventsToSignals object computed inside this graph's kernel instead of read from memory (0: pitch, 1: gate)
+  int mlgpu_graph_add_event_row(mlgpu_graph* g, int row, const char* name)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (row != 0 && row != 1) return -gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_add_event_row: rows 0 (pitch) and 1 (gate) can be source nodes");
+    for (const Node& m : g->nodes)
+      if (m.type == NODE_EVENT_ROW && m.slot == row) return -gfail(g, MLGPU_ERR_INVALID, "graph_add_event_row: this row is a node already");
+    Node n;
+    n.type = NODE_EVENT_ROW;
+    n.kind = 0;
+    n.name = name ? name : "";
+    n.slot = row;
+    const int id = addNode(g, std::move(n));
+    if (id >= 0) g->hasEventRows = true;
+    return id;
+  }
+  int mlgpu_graph_bind_events(mlgpu_graph* g, mlgpu_events* ev)
+  {
+    if (!g || !ev) return MLGPU_ERR_INVALID;
+    if (!g->hasEventRows) return gfail(g, MLGPU_ERR_INVALID, "graph_bind_events: the graph has no event rows (graph_add_event_row)");
+    if (mlgpu_events_engine(ev) != g->e) return gfail(g, MLGPU_ERR_INVALID, "graph_bind_events: the events object belongs to another engine");
+    if (!mlgpu_events_is_midi(ev)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_bind_events: MIDI protocol only (one lane per voice)");
+    if (mlgpu_events_num_voices(ev) != g->V) return gfail(g, MLGPU_ERR_INVALID, "graph_bind_events: instruments x polyphony must equal the graph's voices");
+    g->events = ev;
+    return MLGPU_OK;
   }
   int mlgpu_graph_add_vop(mlgpu_graph* g, int vop, const int* inputs, int nIn, const char* name)
   {
@@ -1443,7 +1488,7 @@ extern "C"
       // candidates: 1 or 2 voices per lane (where the graph allows two and the caller did not force one), 1 or 2 quads per trip
       const bool twoOk = g->voicesPerLane == 0 && [&] {
         for (const Node& n : g->nodes)
-          if (n.type == NODE_FEEDBACK || (n.type == NODE_PROC && (mlgpu_proc_rings(n.kind) || mlgpu_proc_is_vector_rate(n.kind)))) return false;
+          if (n.type == NODE_FEEDBACK || n.type == NODE_EVENT_ROW || (n.type == NODE_PROC && (mlgpu_proc_rings(n.kind) || mlgpu_proc_is_vector_rate(n.kind)))) return false;
         return true;
       }();
       const bool unrollFree = !(g->windowedRings && g->totalRings);
@@ -1711,6 +1756,18 @@ extern "C"
   {
     return mlgpu_graph_process_ctl(g, T, d_inputs, inLayout, nullptr, d_outputs, outLayout);
   }
+  // a graph with event rows: T DSPVectors starting at frame startOffset of the bound object's event times (as mlgpu_events_process)
+  int mlgpu_graph_process_events(mlgpu_graph* g, size_t T, int startOffset, const float* const* d_inputs, int inLayout, const float* const* d_controls,
+                                 float* const* d_outputs, int outLayout)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (!g->hasEventRows) return gfail(g, MLGPU_ERR_INVALID, "graph_process_events: the graph has no event rows");
+    if (startOffset < 0) return gfail(g, MLGPU_ERR_INVALID, "graph_process_events: negative frame offset");
+    g->eventOffset = startOffset;
+    const int st = mlgpu_graph_process_ctl(g, T, d_inputs, inLayout, d_controls, d_outputs, outLayout);
+    g->eventOffset = -1;
+    return st;
+  }
 
   int mlgpu_graph_process_ctl(mlgpu_graph* g, size_t T, const float* const* d_inputs, int inLayout, const float* const* d_controls,
                               float* const* d_outputs, int outLayout)
@@ -1804,9 +1861,25 @@ extern "C"
     const int vl = trial ? trial->vl : g->activeVl;
     if (trial && !g->tuneEv0 && (hipEventCreate(&g->tuneEv0) != hipSuccess || hipEventCreate(&g->tuneEv1) != hipSuccess))
       return gfail(g, MLGPU_ERR_HIP, "graph_process: hipEventCreate");
+    // event rows: the host half of the EventsToSignals block (routing the block's events into records, their upload) goes first,
+    // on the same stream; the kernel then walks the records itself
+    void* eventStaging = nullptr;
+    if (g->hasEventRows)
+    {
+      if (!g->events) return gfail(g, MLGPU_ERR_INVALID, "graph_process: the graph has event rows but no events object (graph_bind_events)");
+      if (g->eventOffset < 0) return gfail(g, MLGPU_ERR_INVALID, "graph_process: a graph with event rows is run with mlgpu_graph_process_events");
+      const int est = mlgpu_events_prepare_for_graph(g->events, T, g->eventOffset, &a.events, &eventStaging);
+      g->eventOffset = -1;
+      if (est != MLGPU_OK) return gfail(g, est, "graph_process: the events object refused the block (see its last error)");
+    }
     if (trial) hipEventRecord(g->tuneEv0, g->e->stream);
     const hipError_t err = launchJit(fn, a, (g->V + (size_t)vl - 1) / (size_t)vl, g->e->stream);
     if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, std::string("graph_process launch: ") + hipGetErrorString(err));
+    if (eventStaging)
+    {
+      const int est = mlgpu_events_launched_by_graph(g->events, eventStaging);
+      if (est != MLGPU_OK) return gfail(g, est, "graph_process: events bookkeeping after the launch");
+    }
     if (trial)
     {
       hipEventRecord(g->tuneEv1, g->e->stream);

@@ -30,6 +30,28 @@ struct ChainArgs
   uint32_t flags;  // MLGPU_KFLAG_*
 };
 
+// EventsToSignals settings the device needs (events.hip, mldsp_events.hpp)
+struct E2SSettings
+{
+  double sr;
+  float pitchBendRange, mpePitchBendRange, driftAmount;
+  int32_t pitchGlideSamples;           // sr * pitchGlideTimeInSeconds (:90)
+  int32_t glideVectors;  float glideDy;        // bend / mod / x / y / z / controllers: sr * 0.02 s (:97-101, 275)
+  int32_t driftGlideVectors;  float driftGlideDy;  // sr * 8 s (:103)
+  int32_t ctlGlideVectors;  float ctlGlideDy;      // SmoothedController: int(sr * 0.02 s) samples (:274-275) — truncated first
+  int32_t mpe;                         // protocol
+};
+
+// the EventsToSignals object whose pitch / gate rows are source nodes of a graph (mlgpu_graph_bind_events); state == nullptr: none
+struct EventsDev
+{
+  uint32_t* state;           // [kStateWords][lanes]
+  const void* recs;          // mlev::Rec: this launch's records, grouped by lane, time-ordered inside a lane
+  const uint32_t* recStart;  // [lanes + 1]
+  size_t lanes;
+  E2SSettings s;
+};
+
 // a fused graph kernel: up to 16 streamed inputs, up to 4 outputs, per-voice constants [P][V]
 #define MLGPU_GRAPH_MAX_INPUTS 16
 #define MLGPU_GRAPH_MAX_OUTPUTS 8
@@ -48,4 +70,5 @@ struct GraphArgs
   const float* consts;  // live constants (mlgpu_graph_set_live_constants): one float per const node, the same for all voices
   size_t t0;  // DSPVectors processed since the last clear (a Downsample2xFunction region pairs vectors 2k, 2k + 1)
   uint32_t flags;  // MLGPU_KFLAG_*
+  EventsDev events;
 };

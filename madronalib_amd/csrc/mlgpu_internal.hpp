@@ -102,3 +102,12 @@ hipError_t mlgpu_jit_chain_launch(void* fn, const ChainArgs& a, hipStream_t stre
 
 // coeffs.cpp
 void mlgpu_build_impulse_table(float* out17);
+
+// events.hip, for graph.hip: the host half of an EventsToSignals block (routing, record upload) for a graph kernel that computes
+// the pitch and gate rows itself (mlgpu_graph_bind_events)
+struct mlgpu_events;
+extern "C" int mlgpu_events_prepare_for_graph(mlgpu_events* ev, size_t nVectors, int startOffset, EventsDev* dev, void** staging);
+extern "C" int mlgpu_events_launched_by_graph(mlgpu_events* ev, void* staging);
+extern "C" int mlgpu_events_is_midi(mlgpu_events* ev);
+extern "C" mlgpu_engine* mlgpu_events_engine(mlgpu_events* ev);
+

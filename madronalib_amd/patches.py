@@ -10,9 +10,10 @@ import numpy as np
 from .constants import Op, Proc
 
 
-def synth16(pitch_input=False, full=False):
+def synth16(pitch_input=False, full=False, event_rows=False):
     """16 processor/op nodes per voice (pitch_input: `pitch` is a streamed signal, e.g. EventsToSignals' pitch row, instead of
-    a per-voice constant; the oscillators then see a frequency per sample):
+    a per-voice constant; the oscillators then see a frequency per sample; event_rows: gate and pitch are computed in the kernel
+    from a bound Events object's records instead of read from memory):
          pitch (param, octaves re base) -> exp2Approx -> * baseFreq  = freq (cycles/sample)
          SawGen(freq), PulseGen(freq, width param), LFO SineGen(lfoFreq param), NoiseGen
          osc = saw + pulse * lfo ; pre = osc + noise * noiseLevel
@@ -24,8 +25,9 @@ def synth16(pitch_input=False, full=False):
        run in its per-sample-coefficient form Lopass(x, omega, k) (MLDSPFilters.h:136-152: two libm sinf per sample, restated
        on the device). Further params: cutoffOct, envAmount, cutoffBase, resonance (k)."""
     d = [
-        dict(name="gate", type="input"),
-        dict(name="pitch", type="input" if pitch_input else "param"),
+        # event_rows: gate and pitch are rows of an EventsToSignals object computed inside the voice kernel (Graph.bind_events)
+        dict(name="gate", type="event_row", kind=1) if event_rows else dict(name="gate", type="input"),
+        dict(name="pitch", type="event_row", kind=0) if event_rows else dict(name="pitch", type="input" if pitch_input else "param"),
         dict(name="baseFreq", type="param"),
         dict(name="width", type="param"),
         dict(name="lfoFreq", type="param"),

@@ -142,29 +142,33 @@ def test_offline_graph_emit_keeps_processors_in_registers(windows):
 
 
 def test_register_budget_of_generated_kernels(monkeypatch):
-    """graph.hip: generateBudgeted — a generated kernel that comes out with 129..192 VGPRs (three or two wavefronts per SIMD: the
-    blocks of a voice bank then run in two rounds) is generated again with a four-wavefront bound and kept when its scratch is
-    small; a kernel that fits anyway is left alone; MLGPU_GRAPH_MIN_WAVES=0 switches the policy off. Decided from the code
-    objects' metadata, so it needs no device."""
+    """graph.hip: generateBudgeted — for a bank big enough to fill the chip (65 536 voices and up), a generated kernel that comes
+    out above 128 VGPRs (three, two or one wavefront per SIMD: the bank's blocks then run in rounds) is generated again with a
+    four-wavefront bound and kept when its scratch is moderate; a kernel that fits anyway is left alone, and so is any kernel of
+    a small bank; MLGPU_GRAPH_MIN_WAVES=0 switches the policy off. Decided from the code objects' metadata: no device needed."""
     import madronalib_amd as ml
     from madronalib_amd import patches
 
-    def build(full):
-        desc, outs = patches.synth16(full=full)
-        g = ml.Graph(ml.OfflineEngine(), 1024, desc, outs)
+    def build(V, **kw):
+        desc, outs = patches.synth16(**kw)
+        g = ml.Graph(ml.OfflineEngine(), V, desc, outs)
         source, code = g.emit()
         g.close()
         notes = _code_object_notes(code)
         return (re.search(r"__launch_bounds__\([^)]*\)", source).group(0), int(re.search(r"\.vgpr_count:\s+(\d+)", notes).group(1)),
                 int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", notes).group(1)))
     monkeypatch.delenv("MLGPU_GRAPH_MIN_WAVES", raising=False)
-    bounds, vgpr, scratch = build(False)      # the 16-node voice fits four wavefronts per SIMD as it is
+    bounds, vgpr, scratch = build(262144)                      # the 16-node voice fits four wavefronts per SIMD as it is
     assert bounds == "__launch_bounds__(256)" and vgpr <= 128 and scratch == 0
-    bounds, vgpr, scratch = build(True)       # the 22-node patch does not: bounded, with a little scratch
-    assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and 0 < scratch <= 512
+    bounds, vgpr, scratch = build(262144, full=True)           # the 22-node patch does not: bounded, with a little scratch
+    assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and 0 < scratch <= 640
+    bounds, vgpr, scratch = build(262144, pitch_input=True, event_rows=True)   # EventsToSignals' rows inside: far above, bounded too
+    assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and 0 < scratch <= 640
+    bounds, vgpr, scratch = build(1024, full=True)             # a small bank does not fill the chip: the compiler's choice stands
+    assert bounds == "__launch_bounds__(256)" and vgpr > 128 and scratch == 0
     monkeypatch.setenv("MLGPU_GRAPH_MIN_WAVES", "0")
-    bounds, vgpr, scratch = build(True)
-    assert bounds == "__launch_bounds__(256)" and 128 < vgpr <= 192 and scratch == 0
+    bounds, vgpr, scratch = build(262144, full=True)
+    assert bounds == "__launch_bounds__(256)" and vgpr > 128 and scratch == 0
 
 
 def test_offline_emit_of_const_vectors_live_constants_and_regions():

@@ -209,3 +209,96 @@ def test_events_with_hostile_values(eng, name):
         want = ref_run(cfg, evs, block, n_blocks)
         for r in range(8):
             assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"hostile {name}: instrument {k} row {ROW_NAMES[r]}")
+
+
+def _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch, switch_at=None):
+    """The config-5 voice driven by EventsToSignals two ways, from fresh objects: (a) e2s_kernel writes pitch and gate, the voice
+    graph reads them; (b) the voice graph computes the two rows itself (event_row nodes). switch_at: from that block on, (b) goes
+    back to the two-kernel form - the two forms share the events object's state. Returns (audio_a, audio_b) [V][frames]."""
+    import madronalib_amd as ml
+    from madronalib_amd import patches
+    from madronalib_amd.constants import Layout
+    from madronalib_amd.sharding import cfg5_voice_params
+    N, P = len(instruments), cfg["polyphony"]
+    V = N * P
+    outs = []
+    for fused in (False, True):
+        ev = ml.Events(eng, N, P, cfg.get("sr", 48000.0))
+        ev.configure(mpe=0, unison=cfg.get("unison", 0), mod_cc=cfg.get("mod_cc", 16), pitch_bend=cfg.get("bend", 7.0),
+                     glide_seconds=cfg.get("glide", 0.0), drift=cfg.get("drift", 0.0))
+        ev.set_wanted_rows([0, 1])
+        params, coeffs, seeds = cfg5_voice_params(0, V, V, ml)
+        graphs = {}
+        for form in ((True, False) if fused else (False,)):
+            desc, outn = patches.synth16(pitch_input=True, event_rows=form)
+            g = ml.Graph(eng, V, desc, outn)
+            g.clear()
+            for k, v in params.items():
+                if k != "pitch":
+                    g.set_param(k, v if np.ndim(v) else float(v))
+            for k, c in coeffs.items():
+                g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+            g.set_state("noise", 0, seeds)
+            if form:
+                assert "mlev::EventsVoice" in g.source and not g.inputs
+                g.bind_events(ev)
+            graphs[form] = g
+        n = V * vectors_per_launch * 64
+        rows = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        d_out = eng.alloc(4 * n)
+        chunks = []
+        for b in range(n_blocks):
+            start = b * block
+            bi, be = [], []
+            for i, evs in enumerate(instruments):
+                for e in evs:
+                    if start <= e[3] < start + block:
+                        bi.append(i)
+                        be.append(ml.Event(e[0], e[1], e[2], e[3] - start, e[4], e[5]))
+            ev.add_events(bi, be)
+            use_fused = fused and (switch_at is None or b < switch_at)
+            if fused and not use_fused and b == switch_at:   # the plain graph takes over the voice state of the fused one
+                for nd in [d["name"] for d in patches.synth16(pitch_input=True)[0] if d["type"] == "proc"]:
+                    for i in range(graphs[False].num_state(nd)):
+                        graphs[False].set_state(nd, i, graphs[True].get_state(nd, i))
+            done = 0
+            while done < block // 64:
+                T = min(vectors_per_launch, block // 64 - done)
+                if use_fused:
+                    graphs[True].process_events(T, done * 64, [], [d_out], out_layout=Layout.VOICE_MAJOR)
+                else:
+                    g = graphs[False]
+                    ev.process(T, done * 64, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
+                    g.process(T, [rows[1] if nm == "gate" else rows[0] for nm in g.inputs], [d_out], out_layout=Layout.VOICE_MAJOR)
+                chunks.append(d_out.download(np.float32, V * T * 64).reshape(V, T * 64).copy())
+                done += T
+            ev.clear_events()
+        outs.append(np.concatenate(chunks, 1))
+        for g in graphs.values():
+            g.close()
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["midi_poly4", "midi_steal2", "midi_poly16", "unison3", "sustain"])
+def test_event_rows_inside_the_voice_graph(eng, name):
+    """EventsToSignals' pitch and gate rows as source nodes of the voice graph (mlgpu_graph_add_event_row / bind_events /
+    process_events): the same audio, bit for bit, as e2s_kernel writing the rows and the graph reading them - which is itself
+    bit-exact against the reference's class (above) - on the scripted performances, with several launches per block."""
+    cfg = SCENARIOS[name]
+    block, n_blocks = 512, 8
+    kind = "sustain" if name == "sustain" else "midi"
+    instruments = [performance(kind, 100 * k + len(name), block * n_blocks, cfg["polyphony"]) for k in range(6)]
+    a, b = _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch=3)
+    assert_bits_equal(b, a, True, f"{name}: fused event rows vs two kernels")
+    assert np.abs(a).max() > 0
+
+
+@pytest.mark.gpu
+def test_event_rows_and_events_kernel_share_their_state(eng):
+    """A block may be processed by either form: half way through, the fused graph hands over to e2s_kernel + plain graph."""
+    cfg = SCENARIOS["midi_poly4"]
+    block, n_blocks = 512, 8
+    instruments = [performance("midi", 40 * k + 7, block * n_blocks, cfg["polyphony"]) for k in range(5)]
+    a, b = _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch=4, switch_at=4)
+    assert_bits_equal(b, a, True, "fused for four blocks, then two kernels")
