@@ -1649,6 +1649,10 @@ struct VoiceProgramOptions
   bool delayWindows{false};
   bool autotune{false};
   bool liveConstants{false};  // constants are read from a device table: VoiceProgram::update() can change them (mlgpu_graph_set_live_constants)
+  // SynthProgram: if processVoice reads no voice row but pitch and gate, the voice kernel computes those two rows itself from the
+  // events' records (mlgpu_graph_add_event_row) instead of reading them from memory - a quarter faster end to end. MIDI protocol
+  // only (mlgpu_events_set_protocol(..., 1) makes process() fail), hence opt-in.
+  bool eventRowsInKernel{false};
 };
 
 // Captures a reference-style process function once and runs it for `voices` voices on the GPU.
@@ -1782,7 +1786,8 @@ class VoiceProgram
       rowNode[r] = -1;
       if (firstPass || ((voiceRowMask_ >> r) & 1u))
       {
-        rowNode[r] = cap.ret(mlgpu_graph_add_input(g, ("voice" + std::to_string(r)).c_str()));
+        rowNode[r] = (!firstPass && eventRowsInKernel()) ? cap.ret(mlgpu_graph_add_event_row(g, r, ("voice" + std::to_string(r)).c_str()))
+                                                         : cap.ret(mlgpu_graph_add_input(g, ("voice" + std::to_string(r)).c_str()));
         ctx_->voice_.outputs.row(r) = DSPVector(Sig(rowNode[r], 0.f));
       }
       else
@@ -1814,6 +1819,8 @@ class VoiceProgram
   size_t voices() const { return voices_; }
   bool flushesDenormals() const { return flush_; }  // the captured code holds an ml::UsingFlushDenormalsToZero
   unsigned voiceRowMask() const { return voiceRowMask_; }  // bit r: the captured code reads voice row r (VoiceOutputSignals)
+  // the voice rows are computed inside the kernel (VoiceProgramOptions::eventRowsInKernel and nothing but pitch / gate is read)
+  bool eventRowsInKernel() const { return opt_.eventRowsInKernel && voiceRowMask_ != 0 && (voiceRowMask_ & ~3u) == 0; }
   mlgpu_graph* graph() const { return g_; }
   const std::vector<Capture::Tap>& taps() const { return taps_; }
   size_t tapChannels() const
@@ -1896,6 +1903,7 @@ class SynthProgram
     eng_.check(mlgpu_events_create(e.handle(), nInstruments, polyphony_, &ev_));
     eng_.check(mlgpu_events_set_sample_rate(ev_, (double)sampleRate));
     eng_.check(mlgpu_events_set_wanted_rows(ev_, prog_.voiceRowMask()));  // rows processVoice never reads are not made
+    if (prog_.eventRowsInKernel()) eng_.check(mlgpu_graph_bind_events(prog_.graph(), ev_));
     for (const Capture::Tap& t : prog_.taps())
     {
       SignalProcessor::PublishedSignal* ps = synth.getPublishedSignals()[Path(t.name.c_str())].get();
@@ -1944,22 +1952,29 @@ class SynthProgram
       voiceOut_.clear();
       tapOut_.clear();
       for (size_t c = 0; c < prog_.tapChannels(); ++c) tapOut_.emplace_back(eng_, voices(), nVectors);
-      for (int r = 0; r < kNumVoiceOutputRows; ++r) rows_.emplace_back(eng_, ((prog_.voiceRowMask() >> r) & 1u) ? voices() : 1, nVectors);
+      for (int r = 0; r < kNumVoiceOutputRows; ++r)
+        rows_.emplace_back(eng_, (!prog_.eventRowsInKernel() && ((prog_.voiceRowMask() >> r) & 1u)) ? voices() : 1, nVectors);
       for (size_t c = 0; c < nOut_; ++c) voiceOut_.emplace_back(eng_, voices(), nVectors);
       capacityT_ = nVectors;
     }
+    const bool inKernel = prog_.eventRowsInKernel();
     float* rowPtrs[kNumVoiceOutputRows];
     std::vector<const float*> pi;
     for (int r = 0; r < kNumVoiceOutputRows; ++r)
     {
-      rowPtrs[r] = ((prog_.voiceRowMask() >> r) & 1u) ? rows_[r].data() : nullptr;
+      rowPtrs[r] = (!inKernel && ((prog_.voiceRowMask() >> r) & 1u)) ? rows_[r].data() : nullptr;
       if (rowPtrs[r]) pi.push_back(rowPtrs[r]);
     }
-    eng_.check(mlgpu_events_process(ev_, nVectors, startOffset, rowPtrs, MLGPU_LAYOUT_QUAD));
     std::vector<float*> po;
     for (auto& s : voiceOut_) po.push_back(s.data());
     for (auto& s : tapOut_) po.push_back(s.data());
-    eng_.check(mlgpu_graph_process(prog_.graph(), nVectors, pi.data(), MLGPU_LAYOUT_QUAD, po.data(), MLGPU_LAYOUT_QUAD));
+    if (inKernel)  // the voice kernel walks the block's event records itself: pitch and gate never exist in memory
+      eng_.check(mlgpu_graph_process_events(prog_.graph(), nVectors, startOffset, nullptr, MLGPU_LAYOUT_QUAD, nullptr, po.data(), MLGPU_LAYOUT_QUAD));
+    else
+    {
+      eng_.check(mlgpu_events_process(ev_, nVectors, startOffset, rowPtrs, MLGPU_LAYOUT_QUAD));
+      eng_.check(mlgpu_graph_process(prog_.graph(), nVectors, pi.data(), MLGPU_LAYOUT_QUAD, po.data(), MLGPU_LAYOUT_QUAD));
+    }
     // SignalProcessor::storePublishedSignal for each voice of the published instrument in rotation, vector by vector
     size_t tapCh = 0;
     for (size_t i = 0; i < published_.size(); ++i)

@@ -109,11 +109,12 @@ struct SynthRefEvent
 // one instrument; events with absolute onset times; host blocks of blockFrames; out: [2][nBlocks * blockFrames]
 // scope / scopeCounts (may be NULL): after every block the UI side reads what the "scope" published signal holds
 // (PublishedSignal::read of up to scopeFramesPerRead frames of 2 channels); scopeCounts[b] = floats read after block b.
-extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR,
-                             float* scope, size_t* scopeCounts, int scopeFramesPerRead)
+template <class SYNTH>
+static int synth_ref_run_t(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR,
+                           float* scope, size_t* scopeCounts, int scopeFramesPerRead)
 {
   size_t scopePos = 0;
-  SmallSynth synth;
+  SYNTH synth;
   AudioContext ctx(0, 2, 48000);
   ctx.setInputPolyphony(kSynthVoices);
   ctx.setInputGlideTimeInSeconds(glideSeconds);
@@ -149,6 +150,16 @@ extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float gli
     }
   }
   return 0;
+}
+
+extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR,
+                             float* scope, size_t* scopeCounts, int scopeFramesPerRead)
+{
+  return synth_ref_run_t<SmallSynth>(events, nEvents, glideSeconds, drift, blockFrames, nBlocks, outL, outR, scope, scopeCounts, scopeFramesPerRead);
+}
+extern "C" int lean_synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR)
+{
+  return synth_ref_run_t<LeanSynth>(events, nEvents, glideSeconds, drift, blockFrames, nBlocks, outL, outR, nullptr, nullptr, 0);
 }
 
 // ---- the reference's SignalProcessBuffer driven with a sequence of host block sizes -----------------------------

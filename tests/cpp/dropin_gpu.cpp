@@ -184,15 +184,19 @@ struct SynthGpuEvent
   float value1, value2;
 };
 // nInstruments instruments; events[i] belongs to instrument eventInstrument[i]; out: [nInstruments][nBlocks * blockFrames] per channel
-extern "C" int synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
-                             int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, size_t scopeInstrument, float* scope,
-                             size_t* scopeCounts, int scopeFramesPerRead, char* err, size_t errLen)
+template <class SYNTH>
+static int synth_gpu_run_t(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
+                           int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, size_t scopeInstrument, float* scope,
+                           size_t* scopeCounts, int scopeFramesPerRead, char* err, size_t errLen, bool eventRowsInKernel, int* rowsInKernel)
 {
   try
   {
     gpu::Engine eng(0);
-    SmallSynth synth;
-    gpu::SynthProgram prog(eng, synth, nInstruments, 2, 48000);
+    SYNTH synth;
+    gpu::VoiceProgramOptions opt;
+    opt.eventRowsInKernel = eventRowsInKernel;
+    gpu::SynthProgram prog(eng, synth, nInstruments, 2, 48000, opt);
+    if (rowsInKernel) *rowsInKernel = prog.program().eventRowsInKernel() ? 1 : 0;
     prog.setPublishedInstrument(scopeInstrument);
     size_t scopePos = 0;
     eng.check(mlgpu_events_set_pitch_glide_seconds(prog.events(), glideSeconds));
@@ -254,3 +258,20 @@ extern "C" int synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, c
     return -1;
   }
 }
+
+extern "C" int synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
+                             int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, size_t scopeInstrument, float* scope,
+                             size_t* scopeCounts, int scopeFramesPerRead, char* err, size_t errLen)
+{
+  return synth_gpu_run_t<SmallSynth>(nInstruments, events, eventInstrument, nEvents, glideSeconds, drift, blockFrames, nBlocks, vectorsPerLaunch, outL, outR,
+                                     scopeInstrument, scope, scopeCounts, scopeFramesPerRead, err, errLen, false, nullptr);
+}
+// the pitch-and-gate-only synth; eventRowsInKernel: the voice kernel computes the two rows itself; *rowsInKernel: whether it did
+extern "C" int lean_synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
+                                  int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, int eventRowsInKernel, int* rowsInKernel,
+                                  char* err, size_t errLen)
+{
+  return synth_gpu_run_t<LeanSynth>(nInstruments, events, eventInstrument, nEvents, glideSeconds, drift, blockFrames, nBlocks, vectorsPerLaunch, outL, outR, 0,
+                                    nullptr, nullptr, 0, err, errLen, eventRowsInKernel != 0, rowsInKernel);
+}
+

@@ -56,3 +56,41 @@ class SmallSynth : public Synth
     outputs[1] += y * pan;
   }
 };
+
+// USER CODE #3b: a Synth whose voices read nothing but pitch and gate (most do). On the GPU side such a voice kernel can compute
+// the two rows itself from the events' records (gpu::VoiceProgramOptions::eventRowsInKernel): same source, same bits either way.
+class LeanSynth : public Synth
+{
+  struct VoiceDSP
+  {
+    SawGen saw;
+    Lopass lp;
+    ADSR env;
+  };
+  std::array<VoiceDSP, kSynthVoices> dsp_;
+
+ public:
+  LeanSynth() : Synth(kSynthVoices)
+  {
+    for (auto& d : dsp_)
+    {
+      d.env.coeffs = ADSR::calcCoeffs(0.004f, 0.08f, 0.5f, 0.15f, 48000.f);
+      d.lp.coeffs = Lopass::makeCoeffs(0.12f, 0.8f);
+      d.saw.clear();
+    }
+  }
+  void setEnvelope(float a, float d, float s, float r)
+  {
+    for (auto& v : dsp_) v.env.coeffs = ADSR::calcCoeffs(a, d, s, r, 48000.f);
+  }
+  void processVoice(int v, const EventsToSignals::Voice& voice, const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs,
+                    AudioContext* ctx) override
+  {
+    VoiceDSP& d = dsp_[v];
+    const DSPVector freq = exp2Approx(voice.outputs.constRow(kPitch)) * (261.6256f / 48000.f);
+    const DSPVector y = d.lp(d.saw(freq)) * d.env(voice.outputs.constRow(kGate));
+    outputs[0] += y;
+    outputs[1] += y * 0.5f;
+  }
+};
+

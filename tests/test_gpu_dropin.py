@@ -226,3 +226,41 @@ def test_synth_subclass_events_to_audio_same_source_same_bits():
     assert np.array_equal(got_counts, want_counts), (got_counts, want_counts)
     assert want_counts.sum() > 0 and np.abs(want_scope).max() > 0.01
     assert_bits_equal(got_scope, want_scope, True, "published scope")
+
+
+@pytest.mark.gpu
+def test_lean_synth_rows_in_kernel_same_bits():
+    """tests/cpp/dropin_synth.h: LeanSynth reads nothing but pitch and gate. With gpu::VoiceProgramOptions::eventRowsInKernel the
+    captured voice kernel computes the two rows itself from the events' records (mlgpu_graph_add_event_row) - no events kernel,
+    no row buffers. Both GPU forms against the reference's own Synth / AudioContext / EventsToSignals, bit for bit, with the
+    envelope change half way through."""
+    from test_gpu_events import performance
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    Lr.lean_synth_ref_run.restype = ctypes.c_int
+    Lr.lean_synth_ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p]
+    Lg.lean_synth_gpu_run.restype = ctypes.c_int
+    Lg.lean_synth_gpu_run.argtypes = [ctypes.c_size_t, ctypes.POINTER(_Ev), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                      ctypes.c_char_p, ctypes.c_size_t]
+    N, block, n_blocks = 24, 512, 10
+    S = block * n_blocks
+    glide, drift = 0.012, 0.6
+    per_inst = [performance("midi", 700 + k, S, 6) for k in range(N)]
+    wantL, wantR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
+    for k, evs in enumerate(per_inst):
+        arr = (_Ev * max(1, len(evs)))(*[_Ev(*e) for e in evs])
+        assert Lr.lean_synth_ref_run(arr, len(evs), glide, drift, block, n_blocks, wantL[k].ctypes.data_as(c_f32p), wantR[k].ctypes.data_as(c_f32p)) == 0
+    flat = [(e, k) for k, evs in enumerate(per_inst) for e in evs]
+    arr = (_Ev * len(flat))(*[_Ev(*e) for e, _ in flat])
+    inst = (ctypes.c_int * len(flat))(*[k for _, k in flat])
+    for in_kernel in (0, 1):
+        gotL, gotR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
+        err = ctypes.create_string_buffer(4096)
+        did = ctypes.c_int(-1)
+        st = Lg.lean_synth_gpu_run(N, arr, inst, len(flat), glide, drift, block, n_blocks, 3, gotL.ctypes.data_as(c_f32p), gotR.ctypes.data_as(c_f32p),
+                                   in_kernel, ctypes.byref(did), err, 4096)
+        assert st == 0, err.value.decode()
+        assert did.value == in_kernel
+        assert_bits_equal(gotL, wantL, True, f"lean synth left (rows in kernel: {in_kernel})")
+        assert_bits_equal(gotR, wantR, True, f"lean synth right (rows in kernel: {in_kernel})")
+    assert np.abs(wantL).max() > 0.05
