@@ -599,6 +599,7 @@ const char* mlgpu_graph_source(mlgpu_graph* g);
  * object with hiprtc, without touching a device. `e` of mlgpu_graph_create may be NULL for a graph used this way
  * (mlgpu_graph_compile then fails with MLGPU_ERR_INVALID). *code stays valid until the graph is destroyed. */
 int mlgpu_graph_emit(mlgpu_graph* g, const void** code, size_t* code_size);
+const char* mlgpu_graph_last_error(mlgpu_graph* g);  /* the text of this graph's last failure (also for graphs without an engine: the hiprtc log) */
 int mlgpu_graph_clear(mlgpu_graph* g); /* T::clear() on every processor node */
 int mlgpu_graph_clear_proc(mlgpu_graph* g, int proc_node); /* T::clear() on one processor node */
 int mlgpu_graph_set_state_uniform(mlgpu_graph* g, int proc_node, int state_idx, uint32_t value);

@@ -854,7 +854,7 @@ class Graph:
     def emit(self):
         """(kernel source, gfx950 code object bytes) without a device (mlgpu_graph_emit)."""
         code, size = ctypes.c_void_p(), ctypes.c_size_t()
-        self.engine._check(self.L.mlgpu_graph_emit(self.h, ctypes.byref(code), ctypes.byref(size)))
+        self._check(self.L.mlgpu_graph_emit(self.h, ctypes.byref(code), ctypes.byref(size)))
         return self.source, ctypes.string_at(code, size.value)
 
     def __del__(self):
@@ -898,7 +898,7 @@ class Graph:
 
     def _check(self, st):
         if st != 0:
-            raise MlgpuError(st, self.L.mlgpu_last_error(self.engine.h).decode() if self.engine.h else "offline graph: status %d" % st)
+            raise MlgpuError(st, self.L.mlgpu_last_error(self.engine.h).decode() if self.engine.h else self.L.mlgpu_graph_last_error(self.h).decode())
 
     def set_const(self, node, value):
         """Change a const node (live_constants=True graphs: between launches, no recompilation)."""

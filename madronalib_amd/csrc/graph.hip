@@ -377,6 +377,7 @@ struct mlgpu_graph
   int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
   int compiledVoicesPerLane{1};
   int unrollQ{1};                // quads per trip of the sample loop
+  std::string lastError;         // mlgpu_graph_last_error
   mlgpu_events* events{nullptr}; // mlgpu_graph_bind_events: the object the NODE_EVENT_ROW nodes read
   bool hasEventRows{false};
   int eventOffset{-1};           // frame offset of the block being processed (mlgpu_graph_process_events), -1: none pending
@@ -403,6 +404,7 @@ namespace
 int gfail(mlgpu_graph* g, int status, const std::string& what)
 {
   if (g && g->e) g->e->lastError = what;
+  if (g) g->lastError = what;  // a graph created without an engine (offline code generation) has nowhere else to keep it
   return status;
 }
 
@@ -1457,6 +1459,8 @@ extern "C"
     if (!generateBudgeted(g, 0, g->source, g->emitted, g->log)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
     return MLGPU_OK;
   }
+
+  const char* mlgpu_graph_last_error(mlgpu_graph* g) { return g ? g->lastError.c_str() : ""; }
 
   int mlgpu_graph_emit(mlgpu_graph* g, const void** code, size_t* codeSize)
   {

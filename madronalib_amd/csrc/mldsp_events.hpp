@@ -336,6 +336,7 @@ struct EventsVoice
     preApplied = false;
     quiet = __builtin_amdgcn_ballot_w64(noteHere) == 0;
     pitchForm = 0;
+    mDriftMoves = mDriftRamps = 0;
     if (quiet)
     {
       gateHeld = on ? velocity : 0.f;

@@ -55,8 +55,13 @@ MLD float sse_max(float a, float b) { return sse_canon((a > b) ? a : b); }
 // one v_cndmask_b32 that reads the SGPR pair, where `(mask >> lane) & 1` would be 64-bit vector shifts.
 MLD float lane_select(uint64_t mask, float a, float b)
 {
+  // (the "s" constraint needs a value the compiler KNOWS to be uniform; a mask that reaches here through a struct member and a
+  // few branches may have lost that mark. readfirstlane restores it and folds away where it was never lost.)
+  // (the builtin returns int: without the casts the low half would be sign-extended over the high one)
+  const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32) |
+                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask);
   float r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
   return r;
 }
 
