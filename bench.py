@@ -206,7 +206,11 @@ def setup_workload(eng, name, V, T, lo, total):
         ev.configure(glide_seconds=0.01, drift=0.5)
         ev.set_wanted_rows([0, 1])
         desc, outs = patches.synth16(pitch_input=True, event_rows=fusedRows)
-        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=True)
+        # MLGPU_BENCH_MIXDOWN=graph: the per-instrument voice sum is made inside the voice kernel (mlgpu_graph_set_output_group_sum)
+        # instead of by mlgpu_mixdown_groups
+        sumInKernel = os.environ.get("MLGPU_BENCH_MIXDOWN", "kernel") == "graph"
+        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=True,
+                     output_groups={0: P} if sumInKernel else None)
         if fusedRows:
             g.bind_events(ev)
         g.clear()
@@ -238,6 +242,17 @@ def setup_workload(eng, name, V, T, lo, total):
                     held.setdefault(i, []).append(key)
                     evs.append(ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
             ev.add_events(insts, evs)
+            if sumInKernel and fusedRows:
+                g.process_events(T, 0, [], [d_mix[k[0] & 1]])
+                ev.clear_events()
+                k[0] += 1
+                return
+            if sumInKernel:
+                ev.process(T, 0, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
+                ev.clear_events()
+                g.process(T, [rows[1] if nm == "gate" else rows[0] for nm in names], [d_mix[k[0] & 1]])
+                k[0] += 1
+                return
             if fusedRows:
                 g.process_events(T, 0, [], [d_voices])
                 ev.clear_events()
@@ -248,10 +263,11 @@ def setup_workload(eng, name, V, T, lo, total):
             eng.mixdown_groups(d_voices, Layout.QUAD, N, P, T, d_mix[k[0] & 1])
             k[0] += 1
         # pitch + gate written and read, voice audio written and read, instrument audio written
-        alg = ((0.0 if fusedRows else 8.0 + 8.0) + 4.0 + 4.0) * n + 4.0 * N * T * 64
+        alg = ((0.0 if fusedRows else 8.0 + 8.0) + (0.0 if sumInKernel else 4.0 + 4.0)) * n + 4.0 * N * T * 64
         return launch, alg, "mlgpu_graph_kernel", ("16384 instruments x 16 voices end to end: note events -> EventsToSignals (pitch, gate) -> 16-node "
                                                     "voice graph -> per-instrument voice sum"
-                                                    + ("; pitch and gate computed inside the voice kernel, never written" if fusedRows else "")), (ev, g)
+                                                    + ("; pitch and gate computed inside the voice kernel, never written" if fusedRows else "")
+                                                    + ("; the voice sum made inside the voice kernel" if sumInKernel else "")), (ev, g)
     if name == "resample":
         r = ml.Resampler(eng, V, 2, False)
         x = eng.bank([Proc.NOISE_GEN], V)

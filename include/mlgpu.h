@@ -703,6 +703,11 @@ int mlgpu_events_clear_events(mlgpu_events* ev);                            /* c
  * the object with mlgpu_events_set_protocol to silence an instrument. */
 int mlgpu_events_process(mlgpu_events* ev, size_t n_vectors, int start_offset, float* const* d_outputs, int layout);
 
+/* Synth::processVector's per-instrument voice sum (source/app/MLSynth.h:43-57) inside the voice kernel: output `output_index`
+ * becomes a signal of voices / group channels, channel c = ((0 + voice[c group]) + voice[c group + 1]) + ... in that order (the
+ * bits of mlgpu_mixdown_groups), written once; groups of 2, 4, 8 or 16 adjacent voices. Before compile. */
+int mlgpu_graph_set_output_group_sum(mlgpu_graph* g, int output_index, int group);
+
 /*
  * The pitch and gate rows as SOURCE NODES of a voice graph: a Synth's voices read voice.outputs.row(kPitch / kGate) straight
  * from EventsToSignals (source/app/MLSynth.h:43-57, MLEventsToSignals.h:15-26); here the graph kernel computes those two rows

@@ -806,7 +806,7 @@ class Graph:
     """
 
     def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0, delay_windows=False, autotune=False,
-                 live_constants=False):
+                 live_constants=False, output_groups=None):
         self.engine = engine
         self.L = engine.L
         self.V = int(n_voices)
@@ -832,6 +832,8 @@ class Graph:
                     self.set_feedback(n["name"], n["source"])
             for o in (outputs or [description[-1]["name"]]):
                 self.add_output(o)
+            for idx, group in (output_groups or {}).items():   # {output index: voices per group}: set_output_group_sum
+                self.set_output_group_sum(idx, group)
             if engine.h is not None:
                 self.compile()
 
@@ -971,6 +973,10 @@ class Graph:
     def add_output(self, node):
         self.outputs.append(node)
         self.engine._check(self.L.mlgpu_graph_add_output(self.h, self._id(node)))
+
+    def set_output_group_sum(self, output_index, group):
+        """Output `output_index` becomes the in-order sum of groups of `group` adjacent voices (V / group channels)."""
+        self._check(self.L.mlgpu_graph_set_output_group_sum(self.h, int(output_index), int(group)))
 
     def compile(self):
         self.engine._check(self.L.mlgpu_graph_compile(self.h))

@@ -354,6 +354,7 @@ struct mlgpu_graph
   size_t V{0};
   std::vector<Node> nodes;
   std::vector<int> outputs;
+  int outputGroup[MLGPU_GRAPH_MAX_OUTPUTS] = {0, 0, 0, 0, 0, 0, 0, 0};  // > 0: the output is the in-order sum of groups of that many adjacent voices
   int nInputs{0}, nParams{0}, nControls{0}, NC{0}, NS{0};
   bool compiled{false};
   bool hasImpulse{false};
@@ -633,7 +634,12 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   }
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l)
-      s << "  f32x4* out" << o << sfx(l) << " = (f32x4*)a.out[" << o << "].base + v" << sfx(l) << " * a.out[" << o << "].strideV;\n";
+    {
+      if (g->outputGroup[o])
+        s << "  f32x4* out" << o << sfx(l) << " = (f32x4*)a.out[" << o << "].base + (v" << sfx(l) << " / " << g->outputGroup[o] << ") * a.out[" << o << "].strideV;\n";
+      else
+        s << "  f32x4* out" << o << sfx(l) << " = (f32x4*)a.out[" << o << "].base + v" << sfx(l) << " * a.out[" << o << "].strideV;\n";
+    }
   // a Downsample2x region's filter pairs its parent's samples (m - 1, m): the previous sample of each of its sources
   for (const Region& R : g->regions)
     if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X)
@@ -806,7 +812,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     emitNodes(-1, outer);
   }
   for (size_t o = 0; o < g->outputs.size(); ++o)
-    for (int l = 0; l < VL; ++l) s << "        y" << o << sfx(l) << "[k] = n" << g->outputs[o] << sfx(l) << ";\n";
+    for (int l = 0; l < VL; ++l)
+    {
+      if (g->outputGroup[o]) s << "        y" << o << sfx(l) << "[k] = group_sum_in_order<" << g->outputGroup[o] << ">(n" << g->outputs[o] << sfx(l) << ");\n";
+      else s << "        y" << o << sfx(l) << "[k] = n" << g->outputs[o] << sfx(l) << ";\n";
+    }
   // feedback: keep this sample's value for the same sample of the next DSPVector (its old value was read above)
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].fbSource >= 0 && g->nodes[i].region < 0)
@@ -815,8 +825,8 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   s << "      }\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l)
-      s << "      __builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o
-        << "].strideQ);\n";
+      s << "      " << (g->outputGroup[o] ? "if ((threadIdx.x & " + std::to_string(g->outputGroup[o] - 1) + ") == " + std::to_string(g->outputGroup[o] - 1) + ") " : std::string())
+        << "__builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o << "].strideQ);\n";
   s << "    }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC && (g->nodes[i].region < 0 || g->nodes[i].role != ROLE_NONE))
@@ -855,7 +865,8 @@ static bool codeObjectNumber(const std::vector<char>& code, const char* key, lon
 // as whole blocks of four wavefronts, one per SIMD, and a big bank is a few blocks per CU - so a kernel that needs more than
 // 128 VGPRs (three, two or one wavefront per SIMD) runs its blocks in rounds where one that fits 128 runs them all at once. If
 // the bank is big enough for that to matter (65 536 voices: a block per CU) and the kernel is above 128, it is generated again
-// with a 4-wavefront bound, and the bounded one is kept when what it spills is moderate (the patch of SURVEY 8d: 170 VGPRs ->
+// with a bound of four wavefronts per SIMD - then three, then two - and the first build that spills moderately (up to 640 bytes
+// of scratch per lane) is kept (the patch of SURVEY 8d: 170 VGPRs ->
 // 128 + 156 bytes of scratch per lane, 1.82 -> 1.46 ms; the voice with its EventsToSignals rows inside: 259 -> 128 + 528 bytes,
 // 3.13 -> 1.56 ms, where bounds of two and three wavefronts give 1.96 and 1.85). MLGPU_GRAPH_MIN_WAVES=0 / N overrides
 // (developer knob).
@@ -867,16 +878,22 @@ static bool generateBudgeted(mlgpu_graph* g, int vl, std::string& source, std::v
   if (!getCode(source, code, log)) return false;
   long vgprs = 0;
   if (knob || (g->windowedRings && g->totalRings) || g->V < 65536 || !codeObjectNumber(code, ".vgpr_count", vgprs) || vgprs <= 128) return true;
-  g->minWaves = 4;
-  const std::string bounded = generateGraphSource(g, vl);
-  g->minWaves = 0;
-  std::vector<char> boundedCode;
-  std::string boundedLog;
-  long scratch = 0;
-  if (getCode(bounded, boundedCode, boundedLog) && codeObjectNumber(boundedCode, ".private_segment_fixed_size", scratch) && scratch <= 640)
+  // the tightest bound whose build spills moderately: four wavefronts per SIMD, else three, else two
+  for (int waves = 4; waves >= 2; --waves)
   {
-    source = bounded;
-    code.swap(boundedCode);
+    if (waves * vgprs <= 512 + 7 * waves) break;  // the unbounded kernel already allows that many
+    g->minWaves = waves;
+    const std::string bounded = generateGraphSource(g, vl);
+    g->minWaves = 0;
+    std::vector<char> boundedCode;
+    std::string boundedLog;
+    long scratch = 0;
+    if (getCode(bounded, boundedCode, boundedLog) && codeObjectNumber(boundedCode, ".private_segment_fixed_size", scratch) && scratch <= 640)
+    {
+      source = bounded;
+      code.swap(boundedCode);
+      break;
+    }
   }
   return true;
 }
@@ -1394,6 +1411,19 @@ extern "C"
     g->outputs.push_back(node);
     return MLGPU_OK;
   }
+  // Synth::processVector's voice sum (source/app/MLSynth.h:43-57) as an output mode: output `index` becomes a signal of
+  // voices / group channels, channel c = ((0 + voice[c * group]) + voice[c * group + 1]) + ... in that order
+  int mlgpu_graph_set_output_group_sum(mlgpu_graph* g, int index, int group)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (index < 0 || index >= (int)g->outputs.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_set_output_group_sum: no such output");
+    if (group != 0 && group != 2 && group != 4 && group != 8 && group != 16)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_set_output_group_sum: groups of 2, 4, 8 or 16 voices (other sizes: mlgpu_mixdown_groups)");
+    if (group && g->V % (size_t)group) return gfail(g, MLGPU_ERR_INVALID, "graph_set_output_group_sum: the voices are not a whole number of groups");
+    g->outputGroup[index] = group;
+    return MLGPU_OK;
+  }
   int mlgpu_graph_node(mlgpu_graph* g, const char* name)
   {
     if (!g || !name) return -MLGPU_ERR_INVALID;
@@ -1808,7 +1838,7 @@ extern "C"
     for (size_t o = 0; o < g->outputs.size(); ++o)
     {
       if (!d_outputs[o] || ((uintptr_t)d_outputs[o] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned output");
-      a.out[o] = makeView(d_outputs[o], outLayout, g->V, T);
+      a.out[o] = makeView(d_outputs[o], outLayout, g->outputGroup[o] ? g->V / (size_t)g->outputGroup[o] : g->V, T);
     }
     if (g->e->recording)
     {

@@ -65,6 +65,31 @@ MLD float lane_select(uint64_t mask, float a, float b)
   return r;
 }
 
+// The sum of G adjacent lanes (G = 2, 4, 8, 16: a group never leaves its DPP row of 16) in the order Synth::processVector adds its
+// voices (source/app/MLSynth.h:43-57): ((((0 + x0) + x1) + ...) + x[G-1]). The result is in the LAST lane of each group; the
+// other lanes hold partial sums of no meaning. A lane shift is a modifier of the add, not an instruction of its own.
+template <int SH>
+MLD float row_shr(float x)
+{
+  return u2f((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f2u(x), 0x110 + SH, 0xF, 0xF, true));
+}
+template <int G, int I>
+struct GroupSumStep
+{
+  static MLD float run(float acc, float x) { return GroupSumStep<G, I - 1>::run(acc + row_shr<I>(x), x); }
+};
+template <int G>
+struct GroupSumStep<G, 0>
+{
+  static MLD float run(float acc, float x) { return acc + x; }
+};
+template <int G>
+MLD float group_sum_in_order(float x)
+{
+  static_assert(G == 2 || G == 4 || G == 8 || G == 16, "a group is a power of two inside one row of 16 lanes");
+  return GroupSumStep<G, G - 2>::run(0.f + row_shr<G - 1>(x), x);
+}
+
 // clamp(x, lo, hi) = min(max(x, lo), hi) (MLDSPOps.h:747) in TWO instructions instead of six, for the common case the graph
 // generator can prove: lo and hi are constants of the kernel, neither NaN nor zero, lo <= hi, and x is the result of an
 // arithmetic instruction (so never a signaling NaN). v_max_f32 / v_min_f32 differ from maxps / minps only (a) when the SECOND

@@ -623,3 +623,38 @@ def test_multi_input_forms_hostile_inputs(eng, oracle, name):
         g32, w32 = states[call].view(np.uint32), st.view(np.uint32)
         bothnan = np.isnan(g32.view(np.float32)) & np.isnan(w32.view(np.float32))
         assert ((g32 == w32) | bothnan).all(), f"hostile {name} state after call {call}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group", [2, 4, 8, 16])
+@pytest.mark.parametrize("vpl", [1, 2])
+def test_voice_sum_inside_the_graph_kernel(eng, oracle, group, vpl):
+    """mlgpu_graph_set_output_group_sum: an output that is the sum of groups of adjacent voices in the order Synth::processVector
+    adds them ((0 + v0) + v1 + ...), made with lane shifts inside the voice kernel - the bits mlgpu_mixdown_groups gives for the
+    same voices, next to an ordinary output of the same graph. Values of mixed sign and magnitude so that the order matters."""
+    import madronalib_amd as ml
+    V, T = 512 + 2 * 16 * vpl * 8, 3          # not a whole number of workgroups
+    rng = np.random.default_rng(group)
+    x = (rng.standard_normal((V, 64 * T)) * 10.0 ** rng.integers(-3, 4, (V, 1))).astype(np.float32)
+    x[3, :8] = [np.inf, -np.inf, np.nan, -0.0, 0.0, 1e-40, 3e38, -3e38]
+    desc = [dict(name="x", type="input"), dict(name="k", type="const", value=0.75), dict(name="y", type="op", kind=Op.MULTIPLY, inputs=["x", "k"])]
+    g = ml.Graph(eng, V, desc, ["y", "y"], voices_per_lane=vpl, output_groups={1: group})
+    assert f"group_sum_in_order<{group}>" in g.source
+    n = V * T * 64
+    d_x = eng.to_device(x)
+    d_q = eng.alloc(4 * n)
+    eng.layout_convert(d_x, Layout.VOICE_MAJOR, d_q, Layout.QUAD, V, T)
+    d_all, d_sum, d_ref = eng.alloc(4 * n), eng.alloc(4 * n // group), eng.alloc(4 * n // group)
+    g.process(T, [d_q], [d_all, d_sum], out_layout=Layout.VOICE_MAJOR)
+    eng.mixdown_groups(d_all, Layout.VOICE_MAJOR, V // group, group, T, d_ref, Layout.VOICE_MAJOR)
+    got = d_sum.download(np.float32, n // group)
+    want = d_ref.download(np.float32, n // group)
+    assert_bits_equal(got, want, True, f"voice sum of {group}, {vpl} voices per lane")
+    # and the host's own sequential sum (float32, voice by voice)
+    y = (x * np.float32(0.75)).reshape(V // group, group, 64 * T)
+    acc = np.zeros((V // group, 64 * T), np.float32)
+    with np.errstate(all="ignore"):
+        for p in range(group):
+            acc = acc + y[:, p]
+    assert_bits_equal(got.reshape(V // group, 64 * T), acc, True, "voice sum vs numpy")
+    g.close()
