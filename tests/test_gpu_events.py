@@ -302,3 +302,47 @@ def test_event_rows_and_events_kernel_share_their_state(eng):
     instruments = [performance("midi", 40 * k + 7, block * n_blocks, cfg["polyphony"]) for k in range(5)]
     a, b = _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch=4, switch_at=4)
     assert_bits_equal(b, a, True, "fused for four blocks, then two kernels")
+
+
+@pytest.mark.gpu
+def test_event_rows_error_paths(eng):
+    """What the event-row API refuses: rows other than pitch / gate, a row twice, running without an events object or through
+    the plain process call, an MPE object, an object with another number of voices, output group sums of other sizes."""
+    import madronalib_amd as ml
+    from madronalib_amd.constants import Op
+    V = 64
+    g = ml.Graph(eng, V)
+    with pytest.raises(ml.MlgpuError):
+        g.add("time", "event_row", 7)
+    g.add("pitch", "event_row", 0)
+    with pytest.raises(ml.MlgpuError):
+        g.add("pitch2", "event_row", 0)
+    g.add("gate", "event_row", 1)
+    g.add("y", "op", Op.MULTIPLY, ["pitch", "gate"])
+    g.add_output("y")
+    with pytest.raises(ml.MlgpuError):
+        g.set_output_group_sum(0, 3)
+    with pytest.raises(ml.MlgpuError):
+        g.set_output_group_sum(1, 4)          # no such output
+    g.compile()
+    d_out = eng.alloc(4 * V * 64)
+    with pytest.raises(ml.MlgpuError):
+        g.process_events(1, 0, [], [d_out])   # nothing bound
+    mpe = ml.Events(eng, V // 4, 4, 48000.0)
+    mpe.configure(mpe=1)
+    with pytest.raises(ml.MlgpuError):
+        g.bind_events(mpe)
+    other = ml.Events(eng, V // 4 + 1, 4, 48000.0)
+    with pytest.raises(ml.MlgpuError):
+        g.bind_events(other)
+    ev = ml.Events(eng, V // 4, 4, 48000.0)
+    g.bind_events(ev)
+    with pytest.raises(ml.MlgpuError):
+        g.process(1, [], [d_out])             # a graph with event rows runs through process_events
+    g.process_events(1, 0, [], [d_out])       # no events yet: the reference's processVector does nothing before the first event
+    assert not np.any(d_out.download(np.float32, V * 64))
+    plain = ml.Graph(eng, V, [dict(name="x", type="input"), dict(name="z", type="op", kind=Op.ADD, inputs=["x", "x"])], ["z"])
+    with pytest.raises(ml.MlgpuError):
+        plain.bind_events(ev)                 # no event rows in it
+    for o in (g, plain):
+        o.close()
