@@ -346,3 +346,60 @@ def test_event_rows_error_paths(eng):
         plain.bind_events(ev)                 # no event rows in it
     for o in (g, plain):
         o.close()
+
+
+@pytest.mark.gpu
+def test_event_rows_full_size(eng):
+    """The instrument bank at bench size - 16 384 instruments x 16 voices = 262 144 voices - with sparse note events: the voice graph
+    with its event rows inside against e2s_kernel + the plain graph, every voice, bit for bit, over three launches."""
+    import madronalib_amd as ml
+    from madronalib_amd import patches
+    from madronalib_amd.constants import Layout
+    from madronalib_amd.sharding import cfg5_voice_params
+    N, P, T, launches = 16384, 16, 2, 3
+    V = N * P
+    rng = np.random.default_rng(5)
+    script = []
+    for _ in range(launches):
+        insts = rng.integers(0, N, N // 40)
+        evs = []
+        for i in insts:
+            key = int(rng.integers(36, 84))
+            kind = NOTE_ON if rng.random() < 0.7 else NOTE_OFF
+            evs.append((int(i), ml.Event(kind, 1, key, int(rng.integers(0, 64 * T)), (key - 60) / 12.0, 0.8 if kind == NOTE_ON else 0.0)))
+        script.append(evs)
+    params, coeffs, seeds = cfg5_voice_params(0, V, V, ml)
+    results = []
+    for fused in (False, True):
+        ev = ml.Events(eng, N, P, 48000.0)
+        ev.configure(glide_seconds=0.01, drift=0.5)
+        ev.set_wanted_rows([0, 1])
+        desc, outn = patches.synth16(pitch_input=True, event_rows=fused)
+        g = ml.Graph(eng, V, desc, outn)
+        g.clear()
+        for k, v in params.items():
+            if k != "pitch":
+                g.set_param(k, v if np.ndim(v) else float(v))
+        for k, c in coeffs.items():
+            g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+        g.set_state("noise", 0, seeds)
+        if fused:
+            g.bind_events(ev)
+        n = V * T * 64
+        rows = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        d_out = eng.alloc(4 * n)
+        outs = []
+        for evs in script:
+            ev.add_events([i for i, _ in evs], [e for _, e in evs])
+            if fused:
+                g.process_events(T, 0, [], [d_out])
+            else:
+                ev.process(T, 0, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
+                g.process(T, [rows[1] if nm == "gate" else rows[0] for nm in g.inputs], [d_out])
+            ev.clear_events()
+            outs.append(d_out.download(np.float32, n).copy())
+        results.append(outs)
+        g.close()
+    for k in range(launches):
+        assert_bits_equal(results[1][k], results[0][k], True, f"full-size instrument bank, launch {k}")
+    assert np.abs(results[0][-1]).max() > 0
