@@ -364,104 +364,8 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
         float vPitch = 0.f, vGate = 0.f, vTime = 0.f;
         if (on)
         {
-          bool retrigFrame = false;
-          while (nc < vend)
-          {
-            const Rec rc = a.recs[nc];
-            const uint32_t type = rc.typeTimeFlags & 0xFF;
-            if (type != REC_NOTE_ON && type != REC_NOTE_RETRIG && type != REC_NOTE_OFF)
-            {
-              ++nc;
-              continue;
-            }
-            int dest = (int)((rc.typeTimeFlags >> 8) & 0xFF);
-            const uint32_t flags = rc.typeTimeFlags >> 16;
-            if (!preApplied)
-            {
-              if (type != REC_NOTE_OFF)
-              {
-                if (flags & 2) age = 0;  // doReset
-                ageStep = 1;
-              }
-              if (type == REC_NOTE_ON)
-              {
-                inhibit = !(flags & 1);
-                setPitchGlideTime((flags & 1) ? a.s.pitchGlideSamples : 0);
-              }
-              preApplied = true;
-            }
-            if (type == REC_NOTE_RETRIG)
-            {
-              if (dest == 0) dest = 1;                 // make room for the retrigger frame, :163-167
-              if (n == dest - 1) retrigFrame = true;   // gate 0 for one frame, :171-175
-            }
-            if (dest == n)
-            {
-              if (type == REC_NOTE_OFF) velocity = 0.f;
-              else
-              {
-                pitch = rc.v1;
-                velocity = rc.v2;
-              }
-              ++nc;
-              preApplied = false;
-              continue;
-            }
-            break;
-          }
-          vGate = retrigFrame ? 0.f : velocity;
-          vPitch = pitchGlideNext(pitch);
-          age += ageStep;
-          if (wantTime) vTime = (float)((double)age / srD);
-          // A retrigger that lands on the frame where the previous note event of this voice ended (a note-on and a steal of
-          // the same voice on one frame) makes the reference REWRITE frame dest - 1, which that previous event had already
-          // written (:163-175): the glide is stepped and the event age counted once more, with the previous event's new
-          // pitch. Look ahead for exactly that pattern and redo this frame the same way.
-          while (nc < vend)
-          {
-            uint32_t pi = nc;
-            while (pi < vend && ((a.recs[pi].typeTimeFlags & 0xFF) < REC_NOTE_ON || (a.recs[pi].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++pi;
-            if (pi >= vend) break;
-            const Rec P = a.recs[pi];
-            const uint32_t ptype = P.typeTimeFlags & 0xFF;
-            int pdest = (int)((P.typeTimeFlags >> 8) & 0xFF);
-            if (ptype == REC_NOTE_RETRIG && pdest == 0) pdest = 1;
-            if (pdest != n + 1) break;
-            uint32_t ri = pi + 1;
-            while (ri < vend && ((a.recs[ri].typeTimeFlags & 0xFF) < REC_NOTE_ON || (a.recs[ri].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++ri;
-            if (ri >= vend) break;
-            const Rec R = a.recs[ri];
-            const int rdest = (int)((R.typeTimeFlags >> 8) & 0xFF);
-            if ((R.typeTimeFlags & 0xFF) != REC_NOTE_RETRIG || rdest != n + 1) break;
-            if (!preApplied)  // P's own bookkeeping, if this frame is the first one it sees
-            {
-              const uint32_t pflags = P.typeTimeFlags >> 16;
-              if (ptype != REC_NOTE_OFF)
-              {
-                if (pflags & 2) age = 0;
-                ageStep = 1;
-              }
-              if (ptype == REC_NOTE_ON)
-              {
-                inhibit = !(pflags & 1);
-                setPitchGlideTime((pflags & 1) ? a.s.pitchGlideSamples : 0);
-              }
-            }
-            if (ptype == REC_NOTE_OFF) velocity = 0.f;  // P's new values
-            else
-            {
-              pitch = P.v1;
-              velocity = P.v2;
-            }
-            nc = ri;                                    // R is the current note record now, its bookkeeping done here
-            if ((R.typeTimeFlags >> 16) & 2) age = 0;
-            ageStep = 1;
-            preApplied = true;
-            vGate = 0.f;                                // the retrigger frame
-            vPitch = pitchGlideNext(pitch);
-            age += ageStep;
-            if (wantTime) vTime = (float)((double)age / srD);
-          }
+          note_frame(a.recs, nc, vend, n, preApplied, velocity, pitch, age, ageStep, inhibit, a.s.pitchGlideSamples, wantTime, srD, setPitchGlideTime,
+                     pitchGlideNext, vPitch, vGate, vTime);
           const float bendSig = gb.next(GS(0), ln, n), driftSig = gd.next(GS(5), ln, n);
           vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
           vPitch = vPitch + (driftSig * a.s.driftAmount) * 0.02f;           // kDriftScale, :247

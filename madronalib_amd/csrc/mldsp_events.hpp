@@ -158,6 +158,115 @@ struct Glide
 };
 
 
+// One frame of a vector that holds note records: writeNoteEvent (:115-216) and its neighbours walked frame by frame - the note
+// records that end on frame n are applied, the gate, the sample-accurate pitch glide and the event age take their step. Shared by
+// e2s_kernel (all rows) and EventsVoice (pitch and gate inside a voice graph). The caller's state comes in by reference;
+// setPitchGlideTime(samples) and pitchGlideNext(pitch) are its two glide operations; vTime is written when wantTime.
+template <class SetGlideTime, class GlideNext>
+MLD void note_frame(const Rec* recs, uint32_t& nc, uint32_t vend, int n, bool& preApplied, float& velocity, float& pitch, uint32_t& age, uint32_t& ageStep,
+                    bool& inhibit, int32_t pitchGlideSamples, bool wantTime, double srD, SetGlideTime setPitchGlideTime, GlideNext pitchGlideNext,
+                    float& vPitch, float& vGate, float& vTime)
+{
+  bool retrigFrame = false;
+  while (nc < vend)
+  {
+    const Rec rc = recs[nc];
+    const uint32_t type = rc.typeTimeFlags & 0xFF;
+    if (type != REC_NOTE_ON && type != REC_NOTE_RETRIG && type != REC_NOTE_OFF)
+    {
+      ++nc;
+      continue;
+    }
+    int dest = (int)((rc.typeTimeFlags >> 8) & 0xFF);
+    const uint32_t flags = rc.typeTimeFlags >> 16;
+    if (!preApplied)
+    {
+      if (type != REC_NOTE_OFF)
+      {
+        if (flags & 2) age = 0;  // doReset
+        ageStep = 1;
+      }
+      if (type == REC_NOTE_ON)
+      {
+        inhibit = !(flags & 1);
+        setPitchGlideTime((flags & 1) ? pitchGlideSamples : 0);
+      }
+      preApplied = true;
+    }
+    if (type == REC_NOTE_RETRIG)
+    {
+      if (dest == 0) dest = 1;                 // make room for the retrigger frame, :163-167
+      if (n == dest - 1) retrigFrame = true;   // gate 0 for one frame, :171-175
+    }
+    if (dest == n)
+    {
+      if (type == REC_NOTE_OFF) velocity = 0.f;
+      else
+      {
+        pitch = rc.v1;
+        velocity = rc.v2;
+      }
+      ++nc;
+      preApplied = false;
+      continue;
+    }
+    break;
+  }
+  vGate = retrigFrame ? 0.f : velocity;
+  vPitch = pitchGlideNext(pitch);
+  age += ageStep;
+  if (wantTime) vTime = (float)((double)age / srD);
+  // A retrigger that lands on the frame where the previous note event of this voice ended (a note-on and a steal of
+  // the same voice on one frame) makes the reference REWRITE frame dest - 1, which that previous event had already
+  // written (:163-175): the glide is stepped and the event age counted once more, with the previous event's new
+  // pitch. Look ahead for exactly that pattern and redo this frame the same way.
+  while (nc < vend)
+  {
+    uint32_t pi = nc;
+    while (pi < vend && ((recs[pi].typeTimeFlags & 0xFF) < REC_NOTE_ON || (recs[pi].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++pi;
+    if (pi >= vend) break;
+    const Rec P = recs[pi];
+    const uint32_t ptype = P.typeTimeFlags & 0xFF;
+    int pdest = (int)((P.typeTimeFlags >> 8) & 0xFF);
+    if (ptype == REC_NOTE_RETRIG && pdest == 0) pdest = 1;
+    if (pdest != n + 1) break;
+    uint32_t ri = pi + 1;
+    while (ri < vend && ((recs[ri].typeTimeFlags & 0xFF) < REC_NOTE_ON || (recs[ri].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++ri;
+    if (ri >= vend) break;
+    const Rec R = recs[ri];
+    const int rdest = (int)((R.typeTimeFlags >> 8) & 0xFF);
+    if ((R.typeTimeFlags & 0xFF) != REC_NOTE_RETRIG || rdest != n + 1) break;
+    if (!preApplied)  // P's own bookkeeping, if this frame is the first one it sees
+    {
+      const uint32_t pflags = P.typeTimeFlags >> 16;
+      if (ptype != REC_NOTE_OFF)
+      {
+        if (pflags & 2) age = 0;
+        ageStep = 1;
+      }
+      if (ptype == REC_NOTE_ON)
+      {
+        inhibit = !(pflags & 1);
+        setPitchGlideTime((pflags & 1) ? pitchGlideSamples : 0);
+      }
+    }
+    if (ptype == REC_NOTE_OFF) velocity = 0.f;  // P's new values
+    else
+    {
+      pitch = P.v1;
+      velocity = P.v2;
+    }
+    nc = ri;                                    // R is the current note record now, its bookkeeping done here
+    if ((R.typeTimeFlags >> 16) & 2) age = 0;
+    ageStep = 1;
+    preApplied = true;
+    vGate = 0.f;                                // the retrigger frame
+    vPitch = pitchGlideNext(pitch);
+    age += ageStep;
+    if (wantTime) vTime = (float)((double)age / srD);
+  }
+}
+
 // ---- EventsToSignals inside a fused voice graph ------------------------------------------------------------------------------
 // The pitch and gate rows of one voice, produced a quad of frames at a time for the graph kernel that consumes them, from the
 // same records and the same per-voice state words as e2s_kernel (a launch of either leaves the state the other expects; rows
@@ -456,102 +565,9 @@ struct EventsVoice
       float vPitch = 0.f, vGate = 0.f;
       if (on)
       {
-      bool retrigFrame = false;
-      while (nc < vend)
-      {
-        const Rec rc = recs[nc];
-        const uint32_t type = rc.typeTimeFlags & 0xFF;
-        if (type != REC_NOTE_ON && type != REC_NOTE_RETRIG && type != REC_NOTE_OFF)
-        {
-          ++nc;
-          continue;
-        }
-        int dest = (int)((rc.typeTimeFlags >> 8) & 0xFF);
-        const uint32_t flags = rc.typeTimeFlags >> 16;
-        if (!preApplied)
-        {
-          if (type != REC_NOTE_OFF)
-          {
-            if (flags & 2) age = 0;  // doReset
-            ageStep = 1;
-          }
-          if (type == REC_NOTE_ON)
-          {
-            inhibit = !(flags & 1);
-            setPitchGlideTime((flags & 1) ? s.pitchGlideSamples : 0);
-          }
-          preApplied = true;
-        }
-        if (type == REC_NOTE_RETRIG)
-        {
-          if (dest == 0) dest = 1;                 // make room for the retrigger frame, :163-167
-          if (n == dest - 1) retrigFrame = true;   // gate 0 for one frame, :171-175
-        }
-        if (dest == n)
-        {
-          if (type == REC_NOTE_OFF) velocity = 0.f;
-          else
-          {
-            pitch = rc.v1;
-            velocity = rc.v2;
-          }
-          ++nc;
-          preApplied = false;
-          continue;
-        }
-        break;
-      }
-      vGate = retrigFrame ? 0.f : velocity;
-      vPitch = pitchGlideNext(pitch);
-      age += ageStep;
-      // A retrigger that lands on the frame where the previous note event of this voice ended (a note-on and a steal of
-      // the same voice on one frame) makes the reference REWRITE frame dest - 1, which that previous event had already
-      // written (:163-175): the glide is stepped and the event age counted once more, with the previous event's new
-      // pitch. Look ahead for exactly that pattern and redo this frame the same way.
-      while (nc < vend)
-      {
-        uint32_t pi = nc;
-        while (pi < vend && ((recs[pi].typeTimeFlags & 0xFF) < REC_NOTE_ON || (recs[pi].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++pi;
-        if (pi >= vend) break;
-        const Rec P = recs[pi];
-        const uint32_t ptype = P.typeTimeFlags & 0xFF;
-        int pdest = (int)((P.typeTimeFlags >> 8) & 0xFF);
-        if (ptype == REC_NOTE_RETRIG && pdest == 0) pdest = 1;
-        if (pdest != n + 1) break;
-        uint32_t ri = pi + 1;
-        while (ri < vend && ((recs[ri].typeTimeFlags & 0xFF) < REC_NOTE_ON || (recs[ri].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++ri;
-        if (ri >= vend) break;
-        const Rec R = recs[ri];
-        const int rdest = (int)((R.typeTimeFlags >> 8) & 0xFF);
-        if ((R.typeTimeFlags & 0xFF) != REC_NOTE_RETRIG || rdest != n + 1) break;
-        if (!preApplied)  // P's own bookkeeping, if this frame is the first one it sees
-        {
-          const uint32_t pflags = P.typeTimeFlags >> 16;
-          if (ptype != REC_NOTE_OFF)
-          {
-            if (pflags & 2) age = 0;
-            ageStep = 1;
-          }
-          if (ptype == REC_NOTE_ON)
-          {
-            inhibit = !(pflags & 1);
-            setPitchGlideTime((pflags & 1) ? s.pitchGlideSamples : 0);
-          }
-        }
-        if (ptype == REC_NOTE_OFF) velocity = 0.f;  // P's new values
-        else
-        {
-          pitch = P.v1;
-          velocity = P.v2;
-        }
-        nc = ri;                                    // R is the current note record now, its bookkeeping done here
-        if ((R.typeTimeFlags >> 16) & 2) age = 0;
-        ageStep = 1;
-        preApplied = true;
-        vGate = 0.f;                                // the retrigger frame
-        vPitch = pitchGlideNext(pitch);
-        age += ageStep;
-      }
+      float vTime = 0.f;
+      note_frame(recs, nc, vend, n, preApplied, velocity, pitch, age, ageStep, inhibit, s.pitchGlideSamples, false, 1.0,
+                 [&](int32_t t) { setPitchGlideTime(t); }, [&](float f) { return pitchGlideNext(f); }, vPitch, vGate, vTime);
       const float bendSig = gb.next(gs(0), ln, n), driftSig = gd.next(gs(5), ln, n);
       vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
       vPitch = vPitch + (driftSig * s.driftAmount) * 0.02f;           // kDriftScale, :247
