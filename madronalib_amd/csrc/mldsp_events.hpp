@@ -271,7 +271,7 @@ MLD void note_frame(const Rec* recs, uint32_t& nc, uint32_t vend, int n, bool& p
 // The pitch and gate rows of one voice, produced a quad of frames at a time for the graph kernel that consumes them, from the
 // same records and the same per-voice state words as e2s_kernel (a launch of either leaves the state the other expects; rows
 // that are not computed keep their glides where they are, as with mlgpu_events_set_wanted_rows). MIDI protocol only: one lane
-// per playing voice, lane == voice index. The frame loop of a vector with a note event is e2s_kernel's, statement by statement.
+// per playing voice, lane == voice index. A vector with a note event is walked with note_frame(), as e2s_kernel walks it.
 struct EventsVoice
 {
   typedef float f32x4e __attribute__((ext_vector_type(4)));
