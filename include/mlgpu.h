@@ -31,7 +31,9 @@
  *    input including infinities, denormals and out-of-range conversions, in both floating-point modes
  *    (mlgpu_engine_set_flush_denormals) - with two stated exceptions:
  *  - a float result that is NaN is "some NaN": payloads and signs of NaNs are not reproduced (x86 and gfx950 propagate
- *    them differently), so parity tests compare any NaN == any NaN; integer and mask results are exact;
+ *    them differently), so parity tests compare any NaN == any NaN; integer and mask results are exact. (x86 makes the NaN
+ *    of an invalid operation negative, gfx950 positive: an operation that looks at the BITS of a NaN produced earlier in the
+ *    same computation - sign(), signBit(), an integer reinterpretation - can therefore see the other sign);
  *  - the hardware-approximate operations - MLGPU_OP_SQRT_APPROX, MLGPU_OP_DIVIDE_APPROX and the OUTPUTS of MLGPU_PROC_PEAK
  *    and MLGPU_PROC_RMS (their state is exact) - use v_rsq_f32 / v_rcp_f32 where the reference uses x86 rsqrtps / rcpps
  *    (12-bit tables no other hardware reproduces): relative error <= 1.5 * 2^-11 against the reference;
