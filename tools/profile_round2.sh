@@ -1,6 +1,6 @@
 set -u
 cd $GRAFT_REPO_ROOT
-tools/gpu_profile_all.sh r02 cfg3 cfg4 cfg5 cfg5full synth events resample > gpurun_out/prof_r02_main.log 2>&1
+tools/gpu_profile_all.sh r02 cfg3 cfg4 cfg5 cfg5full synth synthfused events resample > gpurun_out/prof_r02_main.log 2>&1
 mv gpurun_out/profiles_r02 gpurun_out/profiles_r02_main
 EXTRA="--voices 4194304" tools/gpu_profile_all.sh r02 cfg2 > gpurun_out/prof_r02_cfg2.log 2>&1
 mv gpurun_out/profiles_r02 gpurun_out/profiles_r02_cfg2_1GiB
