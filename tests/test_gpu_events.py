@@ -119,6 +119,9 @@ SCENARIOS = {
     "sustain": dict(polyphony=4, glide=0.0, drift=0.0),
     "mpe5": dict(polyphony=5, mpe=1, glide=0.01, drift=0.3, mpe_bend=48.0),
     "sr44k": dict(polyphony=3, sr=44100.0, glide=0.015, drift=0.7, mod_cc=1),
+    "sr8k": dict(polyphony=3, sr=8000.0, glide=0.05, drift=0.3),
+    "sr192k": dict(polyphony=4, sr=192000.0, glide=0.002, drift=0.9),
+    "poly1": dict(polyphony=1, glide=0.01, drift=0.4),
 }
 
 
