@@ -62,3 +62,30 @@ def test_resampler_golden_and_round_trip(eng):
     # sample of slope) and check that the amplitude is preserved
     best = min(np.abs(y[0, 200 + d:900 + d] - s[0, 200:900]).max() for d in range(0, 12))
     assert best < 0.04 and abs(np.abs(y[0, 200:900]).max() - 1.0) < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("octaves,up", [(1, False), (2, False), (1, True), (3, True)])
+def test_resampler_hostile_input(eng, oracle, octaves, up):
+    """The half-band cascades on a signal with infinities, NaNs, denormals, huge values and raw bit patterns mixed in: whatever
+    the reference's allpass sections make of them (any NaN equals any NaN), output and filter state, over two launches."""
+    import madronalib_amd as ml
+    from inputs import general_floats
+    V = 130
+    Tin = 2 * (1 << octaves) if not up else 2
+    S = 64 * Tin * 2
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 5, S)
+    g = general_floats(V * S, 40 + octaves).reshape(V, S)
+    rng = np.random.default_rng(octaves)
+    mask = rng.random((V, S)) < 0.03
+    x[mask] = g[mask]
+    big = np.isfinite(x) & (np.abs(x) > 1e15)     # (as for the state-variable filters: stay below the float range's last octaves)
+    x[big] = np.float32(1e15) * np.sign(x[big])
+    r = ml.Resampler(eng, V, octaves, up)
+    st = np.zeros((octaves * 9, V), np.float32)
+    for call in range(2):
+        xs = np.ascontiguousarray(x[:, call * 64 * Tin:(call + 1) * 64 * Tin])
+        assert_bits_equal(r.process_host(xs, Layout.QUAD), oracle.resample(octaves, up, st, xs), True, f"hostile octaves {octaves} up {up} call {call}")
+        gs, ws = r.get_state().view(np.uint32), st.view(np.uint32)
+        bothnan = np.isnan(gs.view(np.float32)) & np.isnan(ws.view(np.float32))
+        assert ((gs == ws) | bothnan).all(), "HalfBandFilter state"
