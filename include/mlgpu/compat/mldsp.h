@@ -425,10 +425,10 @@ inline DSPVectorArray<ROWS> lerp(const DSPVectorArray<ROWS>& a, const DSPVectorA
   return lerp(a, b, DSPVectorArray<ROWS>(m));
 }
 
-template <size_t ROWS>  // within(x, lo, hi) -> mask, MLDSPOps.h:748
-inline DSPVectorArrayInt<ROWS> within(const DSPVectorArray<ROWS>& x, const DSPVectorArray<ROWS>& lo, const DSPVectorArray<ROWS>& hi)
+template <size_t ROWS>  // within(x, lo, hi): lo <= x < hi as a mask in a FLOAT vector (DEFINE_OP3, MLDSPOps.h:748: all bits set or none)
+inline DSPVectorArray<ROWS> within(const DSPVectorArray<ROWS>& x, const DSPVectorArray<ROWS>& lo, const DSPVectorArray<ROWS>& hi)
 {
-  DSPVectorArrayInt<ROWS> y;
+  DSPVectorArray<ROWS> y;
   for (size_t j = 0; j < ROWS; ++j) y.sig_[j] = gpu::opNode(MLGPU_OP_WITHIN, {x.sig_[j], lo.sig_[j], hi.sig_[j]});
   return y;
 }

@@ -96,6 +96,25 @@ extern "C" int decay_ref_run(size_t V, size_t T, int flush, const float* in0, fl
   return 0;
 }
 
+// ---- every free function of MLDSPOps.h by name (tests/cpp/dropin_ops.h) ----
+#include "../tests/cpp/dropin_ops.h"
+extern "C" int ops_ref_run(size_t V, size_t T, const float* in0, const float* in1, float* outs /* [kOpsOutputs][V][64 T] */)
+{
+  const size_t S = T * kFloatsPerDSPVector;
+  for (size_t v = 0; v < V; ++v)
+  {
+    AudioContext ctx(2, kOpsOutputs, 48000);
+    for (size_t t = 0; t < T; ++t)
+    {
+      load(ctx.inputs[0], in0 + v * S + t * kFloatsPerDSPVector);
+      load(ctx.inputs[1], in1 + v * S + t * kFloatsPerDSPVector);
+      opsProcess(&ctx, nullptr);
+      for (int o = 0; o < kOpsOutputs; ++o) store(ctx.outputs[o], outs + ((size_t)o * V + v) * S + t * kFloatsPerDSPVector);
+    }
+  }
+  return 0;
+}
+
 // ---- a Synth subclass run by the reference's own Synth::processVector, AudioContext and EventsToSignals ----
 #include "MLSynth.h"
 #include "../tests/cpp/dropin_synth.h"

@@ -264,3 +264,43 @@ def test_lean_synth_rows_in_kernel_same_bits():
         assert_bits_equal(gotL, wantL, True, f"lean synth left (rows in kernel: {in_kernel})")
         assert_bits_equal(gotR, wantR, True, f"lean synth right (rows in kernel: {in_kernel})")
     assert np.abs(wantL).max() > 0.05
+
+
+@pytest.mark.gpu
+def test_every_free_function_by_name_same_source_same_bits():
+    """tests/cpp/dropin_ops.h: every free function of MLDSPOps.h that takes whole DSPVectors, called by name with the reference's
+    argument order, compiled unchanged against the reference and against the shim, on general floats (infinities, NaNs, denormals,
+    huge and tiny values). Pins which device operation each name stands for and which argument goes where."""
+    from inputs import general_floats, assert_rel_close
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    K = 8
+    V, T = 96, 3
+    S = 64 * T
+    a = general_floats(V * S, seed=71).reshape(V, S).copy()
+    b = general_floats(V * S, seed=72)[::-1].reshape(V, S).copy()
+    # half of the voices get ordinary audio-range values, so that the transcendental paths see their usual domain as well
+    rng = np.random.default_rng(7)
+    a[::2] = rng.uniform(-2.0, 2.0, (V // 2, S)).astype(np.float32)
+    b[::2] = rng.uniform(-2.0, 2.0, (V // 2, S)).astype(np.float32)
+    want = np.zeros((K, V, S), np.float32)
+    got = np.zeros((K, V, S), np.float32)
+    Lr.ops_ref_run.restype = ctypes.c_int
+    Lr.ops_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p]
+    Lg.ops_gpu_run.restype = ctypes.c_int
+    Lg.ops_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    assert Lr.ops_ref_run(V, T, a.ctypes.data_as(c_f32p), b.ctypes.data_as(c_f32p), want.ctypes.data_as(c_f32p)) == 0
+    err = ctypes.create_string_buffer(4096)
+    assert Lg.ops_gpu_run(V, T, a.ctypes.data_as(c_f32p), b.ctypes.data_as(c_f32p), got.ctypes.data_as(c_f32p), err, 4096) == 0, err.value.decode()
+    names = ["arithmetic, min / max / clamp", "sin cos exp log", "exp2 log2 pow", "approximations", "sqrt abs sign signBit fractionalPart within lerp inverseLerp",
+             "comparisons + selects", "conversions, int arithmetic, index vectors, rows", "hardware approximations"]
+    for k in range(K - 1):
+        assert_bits_equal(got[k], want[k], True, f"ops drop-in output {k} ({names[k]})")
+    # the last output is a sum of two hardware-approximate terms: each is within 1.5 * 2^-11 of the reference's (rsqrtps / rcpps
+    # tables against v_rsq_f32 / v_rcp_f32), so the sum is within that of the terms' magnitudes
+    with np.errstate(all="ignore"):
+        a64, b64 = np.abs(a.astype(np.float64)), np.abs(b.astype(np.float64))
+        scale = np.sqrt(a64 + 0.01) + 0.5 * b64 / (a64 + 1.0)
+        fin = np.isfinite(want[K - 1]) & np.isfinite(got[K - 1]) & np.isfinite(scale)
+        err = np.abs(got[K - 1].astype(np.float64) - want[K - 1].astype(np.float64))
+    assert (err[fin] <= 2.0 * 1.5 * 2.0 ** -11 * scale[fin] + 1e-30).all(), names[K - 1]
+    assert (np.isfinite(want[K - 1]) == np.isfinite(got[K - 1])).mean() > 0.99
