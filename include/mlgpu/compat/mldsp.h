@@ -802,6 +802,13 @@ class TestSineGen : public gpu::ProcNode<MLGPU_PROC_TEST_SINE_GEN>  // MLDSPGens
 class OneShotGen : public gpu::ProcNode<MLGPU_PROC_ONE_SHOT_GEN>
 {
  public:
+  // MLDSPGens.h:229 - before the first call: every voice starts triggered. Afterwards: VoiceProgram::trigger(shot[, which voices])
+  void trigger()
+  {
+    presetState(0, 0);
+    presetState(1, 1);
+    presetState(2, 0);
+  }
   DSPVector operator()(const DSPVector cyclesPerSample) { return DSPVector(emit({cyclesPerSample.sig_[0]}, nullptr, 0)); }
 };
 class SineGen : public gpu::ProcNode<MLGPU_PROC_SINE_GEN>
@@ -1842,6 +1849,25 @@ class VoiceProgram
   void setState(const P& object, int stateIdx, const std::vector<uint32_t>& perVoice)
   {
     eng_.check(mlgpu_graph_set_state(g_, object.node(), stateIdx, perVoice.data()));
+  }
+
+  // OneShotGen::trigger() between two process() calls: for every voice, or for the voices whose flag is set
+  void trigger(const ::ml::OneShotGen& shot)
+  {
+    eng_.check(mlgpu_graph_set_state_uniform(g_, shot.node(), 0, 0));
+    eng_.check(mlgpu_graph_set_state_uniform(g_, shot.node(), 1, 1));
+    eng_.check(mlgpu_graph_set_state_uniform(g_, shot.node(), 2, 0));
+  }
+  void trigger(const ::ml::OneShotGen& shot, const std::vector<uint8_t>& whichVoices)
+  {
+    std::vector<uint32_t> w(whichVoices.size());
+    for (int idx = 0; idx < 3; ++idx)
+    {
+      eng_.check(mlgpu_graph_get_state(g_, shot.node(), idx, w.data()));
+      for (size_t v = 0; v < w.size(); ++v)
+        if (whichVoices[v]) w[v] = idx == 1 ? 1u : 0u;
+      eng_.check(mlgpu_graph_set_state(g_, shot.node(), idx, w.data()));
+    }
   }
 
   // one call = T DSPVectors of every voice (the reference calls the process function T times)

@@ -115,6 +115,27 @@ extern "C" int ops_ref_run(size_t V, size_t T, const float* in0, const float* in
   return 0;
 }
 
+// ---- the stateful objects the other drop-ins do not touch, by name (tests/cpp/dropin_objects.h) ----
+#include "../tests/cpp/dropin_objects.h"
+extern "C" int objects_ref_run(size_t V, size_t T, const float* in0, const float* in1, float* outs /* [kObjectsOutputs][V][64 T] */)
+{
+  const size_t S = T * kFloatsPerDSPVector;
+  for (size_t v = 0; v < V; ++v)
+  {
+    ObjectsState state;
+    objectsSetup(state);
+    AudioContext ctx(2, kObjectsOutputs, 48000);
+    for (size_t t = 0; t < T; ++t)
+    {
+      load(ctx.inputs[0], in0 + v * S + t * kFloatsPerDSPVector);
+      load(ctx.inputs[1], in1 + v * S + t * kFloatsPerDSPVector);
+      objectsProcess(&ctx, &state);
+      for (int o = 0; o < kObjectsOutputs; ++o) store(ctx.outputs[o], outs + ((size_t)o * V + v) * S + t * kFloatsPerDSPVector);
+    }
+  }
+  return 0;
+}
+
 // ---- a Synth subclass run by the reference's own Synth::processVector, AudioContext and EventsToSignals ----
 #include "MLSynth.h"
 #include "../tests/cpp/dropin_synth.h"

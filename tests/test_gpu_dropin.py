@@ -304,3 +304,40 @@ def test_every_free_function_by_name_same_source_same_bits():
         err = np.abs(got[K - 1].astype(np.float64) - want[K - 1].astype(np.float64))
     assert (err[fin] <= 2.0 * 1.5 * 2.0 ** -11 * scale[fin] + 1e-30).all(), names[K - 1]
     assert (np.isfinite(want[K - 1]) == np.isfinite(got[K - 1])).mean() > 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launches", [1, 3])
+def test_every_stateful_object_by_name_same_source_same_bits(launches):
+    """tests/cpp/dropin_objects.h: the generators, filters and delay lines no other drop-in source uses - TickGen, ImpulseGen,
+    PhasorGen, OneShotGen (trigger()), TestSineGen, TempoLock, Bandpass, HiShelf, Integrator (mLeak), Differentiator, Peak
+    (peakHoldSamples), RMS, LinearGlide, Interpolator1, IntegerDelay (fixed and modulated), FractionalDelay, PitchbendableDelay -
+    constructed, configured and called the way user code does, compiled unchanged against the reference and against the shim.
+    Pins the shim's class surface: names, setters, coefficient makers, operator() forms and the state each starts from."""
+    from inputs import assert_rel_close
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    K = 8
+    V, T = 80, 12
+    S = 64 * T
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1.0, 1.0, (V, S)).astype(np.float32)
+    x[:, 64 * 5:64 * 7] = 0.0                                    # a silence: Peak's hold and RMS's decay
+    phase = rng.uniform(0.0, 1.0, (V, 1))
+    slow = np.mod(phase + np.arange(S)[None, :] / 700.0, 1.0).astype(np.float32)      # a transport phasor, wrapping once
+    want = np.zeros((K, V, S), np.float32)
+    got = np.zeros((K, V, S), np.float32)
+    Lr.objects_ref_run.restype = ctypes.c_int
+    Lr.objects_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p]
+    Lg.objects_gpu_run.restype = ctypes.c_int
+    Lg.objects_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    assert Lr.objects_ref_run(V, T, x.ctypes.data_as(c_f32p), slow.ctypes.data_as(c_f32p), want.ctypes.data_as(c_f32p)) == 0
+    err = ctypes.create_string_buffer(4096)
+    assert Lg.objects_gpu_run(V, T, launches, x.ctypes.data_as(c_f32p), slow.ctypes.data_as(c_f32p), got.ctypes.data_as(c_f32p), err, 4096) == 0, err.value.decode()
+    names = ["TickGen + ImpulseGen + OneShotGen", "PhasorGen + TestSineGen + TempoLock", "Bandpass + HiShelf", "Integrator + Differentiator", "Peak", "RMS",
+             "LinearGlide + Interpolator1", "IntegerDelay (fixed, modulated) + FractionalDelay + PitchbendableDelay"]
+    for k in range(K):
+        assert np.abs(want[k]).max() > 1e-3, names[k]
+        if k in (4, 5):        # sqrtApprox inside: 1.5 * 2^-11 relative (test_gpu_parity.HW_REL)
+            assert_rel_close(got[k], want[k], 1.5 * 2.0 ** -11, f"objects drop-in output {k} ({names[k]})")
+        else:
+            assert_bits_equal(got[k], want[k], True, f"objects drop-in output {k} ({names[k]})")
