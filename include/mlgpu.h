@@ -705,6 +705,26 @@ int mlgpu_events_clear_events(mlgpu_events* ev);                            /* c
  * the object with mlgpu_events_set_protocol to silence an instrument. */
 int mlgpu_events_process(mlgpu_events* ev, size_t n_vectors, int start_offset, float* const* d_outputs, int layout);
 
+/* Smoothed controller signals: what a process function reads through AudioContext::getInputController(n)
+ * (source/app/MLAudioContext.cpp:129 -> EventsToSignals::SmoothedController, MLEventsToSignals.h:170-180, .cpp:264-281, 431-436).
+ * One signal per INSTRUMENT per watched controller number (0..128; 128 is what MIDI channel pressure writes too, :650),
+ * made on the device from the controller events of each DSPVector: output = LinearGlide(20 ms)(value of the last controller
+ * event so far); zeros while the instrument has not seen any event (:386). watch_controllers reserves the signals for launches
+ * of up to max_vectors DSPVectors (it allocates: call it at set-up time; n = 0 releases them); a smoother that starts being
+ * watched later than the first event starts settled on its controller's current value. From then on every
+ * mlgpu_events_process / mlgpu_graph_process_events call also advances the controller signals by the same DSPVectors.
+ * mlgpu_events_controller_signal(ev, slot): the device signal of numbers[slot] for the DSPVectors of the LAST such call - QUAD
+ * layout over nInstruments "voices" ([16 n_vectors][nInstruments][4] floats), valid until the next one; the pointer itself
+ * does not change between calls. Feed it to a voice graph as an input with mlgpu_graph_set_input_group(g, input, polyphony). */
+#define MLGPU_EVENTS_MAX_WATCHED_CONTROLLERS 32
+int mlgpu_events_watch_controllers(mlgpu_events* ev, const int* numbers, int n, size_t max_vectors);
+const float* mlgpu_events_controller_signal(mlgpu_events* ev, int slot);
+
+/* A streamed input shared by groups of adjacent voices: input `input_index` (the order of mlgpu_graph_add_input) is a signal of
+ * voices / group rows, voice v reads row v / group - one controller or transport signal per instrument of `group` voices
+ * (group = voices: one row for the whole bank). voices must be a multiple of group. Before compile. */
+int mlgpu_graph_set_input_group(mlgpu_graph* g, int input_index, int group);
+
 /* Synth::processVector's per-instrument voice sum (source/app/MLSynth.h:43-57) inside the voice kernel: output `output_index`
  * becomes a signal of voices / group channels, channel c = ((0 + voice[c group]) + voice[c group + 1]) + ... in that order (the
  * bits of mlgpu_mixdown_groups), written once; groups of 2, 4, 8 or 16 adjacent voices. Before compile. */

@@ -537,6 +537,31 @@ class Events:
         arr = (ctypes.c_void_p * 8)(*[None if b is None else b.ptr for b in d_outputs])
         self.engine._check(self.L.mlgpu_events_process(self.h, int(n_vectors), int(start_offset), arr, int(layout)))
 
+    def watch_controllers(self, numbers, max_vectors):
+        """The smoothed controller signals (AudioContext::getInputController) to make from now on, one per instrument per number,
+        for launches of up to max_vectors DSPVectors; every process call advances them."""
+        numbers = [int(n) for n in numbers]
+        arr = (ctypes.c_int * max(1, len(numbers)))(*numbers)
+        self.engine._check(self.L.mlgpu_events_watch_controllers(self.h, arr, len(numbers), int(max_vectors)))
+        self.watched = numbers
+
+    def controller_signal(self, slot):
+        """Device pointer of watched controller `slot`'s signal for the last process call: QUAD over n_instruments rows."""
+        p = self.L.mlgpu_events_controller_signal(self.h, int(slot))
+        if not p:
+            raise MlgpuError(Status.ERR_RANGE, "no such watched controller")
+        return p
+
+    def controllers_host(self, n_vectors):
+        """Test convenience: the watched controllers' signals of the last process call as numpy [slot][instrument][64 T]."""
+        N, T = self.n_instruments, int(n_vectors)
+        out = []
+        for slot in range(len(self.watched)):
+            q = np.empty(16 * T * N * 4, np.float32)
+            self.engine._check(self.L.mlgpu_download(self.engine.h, _np_ptr(q), self.controller_signal(slot), q.nbytes))
+            out.append(q.reshape(16 * T, N, 4).transpose(1, 0, 2).reshape(N, 64 * T))
+        return np.stack(out) if out else np.zeros((0, N, 64 * T), np.float32)
+
     def process_host(self, n_vectors, start_offset=0):
         """Test convenience: returns the 8 rows as numpy [8][V][64 T]."""
         eng, V, T = self.engine, self.V, int(n_vectors)
@@ -806,7 +831,7 @@ class Graph:
     """
 
     def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0, delay_windows=False, autotune=False,
-                 live_constants=False, output_groups=None):
+                 live_constants=False, output_groups=None, input_groups=None):
         self.engine = engine
         self.L = engine.L
         self.V = int(n_voices)
@@ -834,6 +859,8 @@ class Graph:
                 self.add_output(o)
             for idx, group in (output_groups or {}).items():   # {output index: voices per group}: set_output_group_sum
                 self.set_output_group_sum(idx, group)
+            for idx, group in (input_groups or {}).items():    # {input index: voices per row}: set_input_group
+                self.set_input_group(idx, group)
             if engine.h is not None:
                 self.compile()
 
@@ -977,6 +1004,11 @@ class Graph:
     def set_output_group_sum(self, output_index, group):
         """Output `output_index` becomes the in-order sum of groups of `group` adjacent voices (V / group channels)."""
         self._check(self.L.mlgpu_graph_set_output_group_sum(self.h, int(output_index), int(group)))
+
+    def set_input_group(self, input_index, group):
+        """Input `input_index` is a signal of V / group rows: voice v reads row v // group (one controller or transport signal per
+        instrument of `group` voices)."""
+        self._check(self.L.mlgpu_graph_set_input_group(self.h, int(input_index), int(group)))
 
     def compile(self):
         self.engine._check(self.L.mlgpu_graph_compile(self.h))

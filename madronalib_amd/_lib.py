@@ -155,6 +155,7 @@ def _declare(L):
     sig("mlgpu_graph_process_ctl", i, [vp, sz, pp, i, pp, pp, i])
     sig("mlgpu_graph_last_error", c.c_char_p, [vp])
     sig("mlgpu_graph_set_output_group_sum", i, [vp, i, i])
+    sig("mlgpu_graph_set_input_group", i, [vp, i, i])
     sig("mlgpu_graph_add_event_row", i, [vp, i, c.c_char_p])
     sig("mlgpu_graph_bind_events", i, [vp, vp])
     sig("mlgpu_graph_process_events", i, [vp, sz, i, pp, i, pp, pp, i])
@@ -200,6 +201,8 @@ def _declare(L):
     sig("mlgpu_events_add_events", i, [vp, vp, vp, sz])
     sig("mlgpu_events_clear_events", i, [vp])
     sig("mlgpu_events_process", i, [vp, sz, i, pp, i])
+    sig("mlgpu_events_watch_controllers", i, [vp, ctypes.POINTER(ctypes.c_int), i, sz])
+    sig("mlgpu_events_controller_signal", vp, [vp, i])
     sig("mlgpu_resampler_create", i, [vp, sz, i, i, pp])
     sig("mlgpu_resampler_destroy", i, [vp])
     sig("mlgpu_resampler_clear", i, [vp])

@@ -412,6 +412,82 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
 // ---- host: the event routing of EventsToSignals ------------------------------------------------------------------------
 constexpr int kMaxVoices = 16;        // EventsToSignals::kMaxVoices, MLEventsToSignals.h:48
 constexpr int kMaxPhysicalKeys = 128;
+// ---- smoothed controller signals (SmoothedController, MLEventsToSignals.h:170-180, .cpp:264-281; read by a process function
+// through AudioContext::getInputController, MLAudioContext.cpp:129) ----------------------------------------------------------
+// One signal per instrument per WATCHED controller number (mlgpu_events_watch_controllers): one lane per (slot, instrument).
+// Per DSPVector of an awake instrument: output = glide(inputValue), inputValue = the value of the last controller event of
+// that vector or before (:744, :431-436). The records are (vector, value) pairs; lanes without records just keep gliding.
+struct CtlRec
+{
+  uint32_t vecKind;  // vector index inside this launch << 1 | kind (0: inputValue = value, 1: the instrument woke up)
+  float value;
+};
+enum : int { C_AWAKE = 0, C_INPUT, C_GLIDE, kCtlWords = C_GLIDE + kGlideWords };
+struct CtlArgs
+{
+  uint32_t* state;           // [kCtlWords][lanes]
+  const CtlRec* recs;
+  const uint32_t* recStart;  // [lanes + 1]
+  float* out;                // [slot][16 maxVectors][nInstruments][4]: slot s is a QUAD signal of nInstruments voices
+  size_t nInstruments, lanes, T, slotStride;
+  int32_t glideVectors;
+  float glideDy;
+};
+__global__ __launch_bounds__(256) void ctl_kernel(const CtlArgs a)
+{
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (lane >= a.lanes) return;
+  const size_t slot = lane / a.nInstruments, inst = lane - slot * a.nInstruments, ln = a.lanes;
+  uint32_t* st = a.state + lane;
+  uint32_t* gs = st + (size_t)C_GLIDE * ln;
+  bool awake = st[(size_t)C_AWAKE * ln] != 0;
+  float input = u2f(st[(size_t)C_INPUT * ln]);
+  uint32_t r = a.recStart[lane];
+  const uint32_t rend = a.recStart[lane + 1];
+  f32x4* out = (f32x4*)(a.out + slot * a.slotStride) + inst;
+  Glide gl;
+  gl.load(gs, ln);
+  for (size_t t = 0; t < a.T; ++t)
+  {
+    for (; r < rend && (a.recs[r].vecKind >> 1) == (uint32_t)t; ++r)
+    {
+      if (a.recs[r].vecKind & 1u) awake = true;
+      else input = a.recs[r].value;
+    }
+    f32x4* o = out + t * 16 * a.nInstruments;
+    if (!awake)  // processVector returns before anything is computed (:386): the outputs keep their initial zeros
+    {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 16; ++q) o[(size_t)q * a.nInstruments] = z;
+      continue;
+    }
+    gl.beginVector(gs, ln, input, a.glideVectors, a.glideDy);
+    const int m = gl.mode();
+    if ((m == 1) || (m == 0 && gl.isUniform()))  // not moving: one value for the whole vector
+    {
+      const float c = (m == 1) ? gl.target : gl.uniformValue;
+      const f32x4 v = {c, c, c, c};
+      for (int q = 0; q < 16; ++q) o[(size_t)q * a.nInstruments] = v;
+    }
+    else
+      for (int q = 0; q < 16; ++q)
+      {
+        float cur[4] = {0.f, 0.f, 0.f, 0.f};
+        gl.preload(gs, ln, q, cur);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = gl.nextWith(gs, ln, q * 4 + k, cur[k]);
+        o[(size_t)q * a.nInstruments] = v;
+      }
+    gl.endVector();
+  }
+  gl.store(gs, ln);
+  st[(size_t)C_AWAKE * ln] = awake ? 1u : 0u;
+  st[(size_t)C_INPUT * ln] = f2u(input);
+}
+
+
 constexpr int kNumControllers = 129;
 constexpr int kChannelPressureControllerIdx = 128;
 
@@ -436,6 +512,7 @@ struct Instrument
   bool sustainPedal{false};
   uint32_t currentNoteOnIndex{0};
   bool awake{false}, awakeSent{false};
+  std::vector<float> ctlInput;  // controllers[n].inputValue (:744), from the first controller event on
 };
 }  // namespace
 
@@ -466,6 +543,29 @@ struct mlgpu_events
     bool pending{false};
   } stage[2];
   int stageIdx{0};
+  // watched controllers (mlgpu_events_watch_controllers): lane = slot * nInstruments + instrument
+  std::vector<int> watched;
+  int slotOf[kNumControllers];
+  size_t ctlMaxVectors{0};
+  float* d_ctlOut{nullptr};
+  uint32_t* d_ctlState{nullptr};
+  std::vector<std::vector<CtlRec>> ctlLaneRecs;
+  std::vector<uint32_t> ctlDirty;
+  struct CtlStaging
+  {
+    CtlRec* h_recs{nullptr};
+    CtlRec* d_recs{nullptr};
+    uint32_t* h_recStart{nullptr};
+    uint32_t* d_recStart{nullptr};
+    size_t recCapacity{0};
+  } ctlStage[2];
+  size_t ctlLanes() const { return watched.size() * nInstruments; }
+  void pushCtl(size_t instrument, int slot, uint32_t vec, uint32_t kind, float value)
+  {
+    const size_t l = (size_t)slot * nInstruments + instrument;
+    if (ctlLaneRecs[l].empty()) ctlDirty.push_back((uint32_t)l);
+    ctlLaneRecs[l].push_back(CtlRec{(vec << 1) | kind, value});
+  }
   uint32_t rowMask{0xFFu};                 // mlgpu_events_set_wanted_rows
   size_t lanes() const { return nInstruments * (size_t)group; }
 };
@@ -616,10 +716,17 @@ struct Router  // one instrument, one vector
     for (int v = 1; v < ev->polyphony + 1; ++v)
       if (in.voices[v].creatorKeyIdx == (size_t)channel) push(v, makeRec(vec, rec, 0, 0, val, 0.f));
   }
+  void setControllerInput(size_t ctrl, float val)  // controllers[ctrl].inputValue = val (:650, :744)
+  {
+    if (in.ctlInput.empty()) in.ctlInput.assign(kNumControllers, 0.f);  // kept from the first controller event on, watched or not
+    in.ctlInput[ctrl] = val;
+    if (ev->slotOf[ctrl] >= 0) ev->pushCtl(instIdx, ev->slotOf[ctrl], vec, 0u, val);
+  }
   void controller(const mlgpu_event& e)  // :735-822
   {
     const float val = e.value1;
     const size_t ctrl = std::min((size_t)e.source_idx, (size_t)kNumControllers - 1);
+    setControllerInput(ctrl, val);
     if (ctrl == kChannelPressureControllerIdx)  // controllers[128].inputValue is what MIDI channel pressure writes too
       for (int v = 0; v < ev->polyphony + 1; ++v) push(v, makeRec(vec, REC_SET_CHANNEL_PRESSURE, 0, 0, val, 0.f));
     if (ctrl == 120) return;  // "all sound off" clears the event buffer it is iterating in the reference (:749-755): not reproduced
@@ -654,7 +761,10 @@ struct Router  // one instrument, one vector
         break;
       case MLGPU_EVENT_CHANNEL_PRESSURE:  // :637-674
         if (!ev->mpe)
+        {
+          setControllerInput(kChannelPressureControllerIdx, e.value1);
           for (int v = 0; v < ev->polyphony + 1; ++v) push(v, makeRec(vec, REC_SET_CHANNEL_PRESSURE, 0, 0, e.value1, 0.f));
+        }
         else if (e.channel == 1) push(0, makeRec(vec, REC_SET_Z, 0, 0, e.value1, 0.f));
         else if (e.channel != 0) setMatching(REC_SET_Z, e.channel, e.value1);
         break;
@@ -702,6 +812,26 @@ void initialState(const mlgpu_events* ev, std::vector<uint32_t>& st)
 }
 }  // namespace
 
+static void freeControllers(mlgpu_events* ev)
+{
+  if (ev->d_ctlOut) hipFree(ev->d_ctlOut);
+  if (ev->d_ctlState) hipFree(ev->d_ctlState);
+  ev->d_ctlOut = nullptr;
+  ev->d_ctlState = nullptr;
+  for (mlgpu_events::CtlStaging& st : ev->ctlStage)
+  {
+    if (st.h_recs) hipHostFree(st.h_recs);
+    if (st.d_recs) hipFree(st.d_recs);
+    if (st.h_recStart) hipHostFree(st.h_recStart);
+    if (st.d_recStart) hipFree(st.d_recStart);
+    st = mlgpu_events::CtlStaging();
+  }
+  ev->watched.clear();
+  ev->ctlLaneRecs.clear();
+  ev->ctlDirty.clear();
+  ev->ctlMaxVectors = 0;
+  for (int& x : ev->slotOf) x = -1;
+}
 extern "C"
 {
   int mlgpu_events_destroy(mlgpu_events* ev)
@@ -710,6 +840,7 @@ extern "C"
     hipSetDevice(ev->e->device);
     hipStreamSynchronize(ev->e->stream);
     if (ev->d_state) hipFree(ev->d_state);
+    freeControllers(ev);
     for (mlgpu_events::Staging& st : ev->stage)
     {
       if (st.h_recs) hipHostFree(st.h_recs);
@@ -751,6 +882,7 @@ extern "C"
     mlgpu_events* ev = new (std::nothrow) mlgpu_events();
     if (!ev) return MLGPU_ERR_OOM;
     ev->e = e;
+    for (int& x : ev->slotOf) x = -1;
     ev->nInstruments = nInstruments;
     ev->polyphony = polyphony;
     int pow2 = 1;
@@ -863,6 +995,60 @@ extern "C"
     return MLGPU_OK;
   }
 
+  // The controller lanes of one launch: their records uploaded into the staging set of this launch (free once the launch
+  // before last has finished, which prepare() has just waited for), then ctl_kernel on the engine's stream - ahead of the
+  // kernel that reads the signals.
+  static int processControllers(mlgpu_events* ev, size_t nVectors, int stageIdx)
+  {
+    mlgpu_engine* e = ev->e;
+    mlgpu_events::CtlStaging& sg = ev->ctlStage[stageIdx];
+    const size_t lanes = ev->ctlLanes();
+    size_t nRecs = 0;
+    for (uint32_t l : ev->ctlDirty) nRecs += ev->ctlLaneRecs[l].size();
+    if (nRecs + 1 > sg.recCapacity)
+    {
+      if (sg.h_recs) hipHostFree(sg.h_recs);
+      if (sg.d_recs) hipFree(sg.d_recs);
+      sg.h_recs = sg.d_recs = nullptr;
+      sg.recCapacity = std::max<size_t>(1024, 2 * (nRecs + 1));
+      if (hipMalloc((void**)&sg.d_recs, sizeof(CtlRec) * sg.recCapacity) != hipSuccess || hipHostMalloc((void**)&sg.h_recs, sizeof(CtlRec) * sg.recCapacity) != hipSuccess)
+      {
+        sg.recCapacity = 0;
+        return efail(ev, MLGPU_ERR_OOM, "events_process: controller record buffer");
+      }
+    }
+    std::sort(ev->ctlDirty.begin(), ev->ctlDirty.end());
+    size_t next = 0, n = 0;
+    for (uint32_t l : ev->ctlDirty)
+    {
+      for (; next <= l; ++next) sg.h_recStart[next] = (uint32_t)n;
+      const std::vector<CtlRec>& lr = ev->ctlLaneRecs[l];
+      memcpy(sg.h_recs + n, lr.data(), sizeof(CtlRec) * lr.size());
+      n += lr.size();
+    }
+    for (; next <= lanes; ++next) sg.h_recStart[next] = (uint32_t)n;
+    hipError_t err = hipMemcpyAsync(sg.d_recStart, sg.h_recStart, sizeof(uint32_t) * (lanes + 1), hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess && nRecs) err = hipMemcpyAsync(sg.d_recs, sg.h_recs, sizeof(CtlRec) * nRecs, hipMemcpyHostToDevice, e->stream);
+    if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process controller upload: ") + hipGetErrorString(err));
+    CtlArgs a;
+    a.state = ev->d_ctlState;
+    a.recs = sg.d_recs;
+    a.recStart = sg.d_recStart;
+    a.out = ev->d_ctlOut;
+    a.nInstruments = ev->nInstruments;
+    a.lanes = lanes;
+    a.T = nVectors;
+    a.slotStride = 64 * ev->ctlMaxVectors * ev->nInstruments;
+    float c[2];
+    mlgpu_linear_glide_make_coeffs((float)(int)(ev->sr * 0.02f), c);  // int glideTimeInSamples = sr * kControllerGlideTimeSeconds (:275)
+    memcpy(&a.glideVectors, &c[0], 4);
+    a.glideDy = c[1];
+    hipLaunchKernelGGL(ctl_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
+    err = hipGetLastError();
+    if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process controller launch: ") + hipGetErrorString(err));
+    return MLGPU_OK;
+  }
+
   // Everything of processVector (:376-466) that happens on the host for nVectors DSPVectors starting at frame startOffset of the
   // event times: the block's events routed into per-voice records, the records uploaded (asynchronously, into the staging set
   // that is free), the settings the device needs. The caller launches the kernel that consumes them - e2s_kernel, or a voice
@@ -873,6 +1059,10 @@ extern "C"
     // ---- route this launch's events into per-voice records ----
     for (uint32_t l : ev->dirtyLanes) ev->laneRecs[l].clear();
     ev->dirtyLanes.clear();
+    for (uint32_t l : ev->ctlDirty) ev->ctlLaneRecs[l].clear();
+    ev->ctlDirty.clear();
+    if (!ev->watched.empty() && nVectors > ev->ctlMaxVectors)
+      return efail(ev, MLGPU_ERR_RANGE, "events_process: more DSPVectors than events_watch_controllers reserved the controller signals for");
     for (size_t i = 0; i < ev->nInstruments; ++i)
     {
       Instrument& in = ev->inst[i];
@@ -884,6 +1074,7 @@ extern "C"
         if (!in.awakeSent)
         {
           for (int v = 0; v < ev->polyphony + 1; ++v) r.push(v, makeRec((uint32_t)t, REC_AWAKE, 0, 0, 0.f, 0.f));
+          for (size_t sl = 0; sl < ev->watched.size(); ++sl) ev->pushCtl(i, (int)sl, (uint32_t)t, 1u, 0.f);
           in.awakeSent = true;
         }
         const int start = startOffset + (int)t * MLGPU_FLOATS_PER_DSPVECTOR, end = start + MLGPU_FLOATS_PER_DSPVECTOR;
@@ -932,6 +1123,9 @@ extern "C"
     hipError_t cerr = hipMemcpyAsync(sg.d_recStart, sg.h_recStart, sizeof(uint32_t) * (lanes + 1), hipMemcpyHostToDevice, e->stream);
     if (cerr == hipSuccess && nRecs) cerr = hipMemcpyAsync(sg.d_recs, sg.h_recs, sizeof(Rec) * nRecs, hipMemcpyHostToDevice, e->stream);
     if (cerr != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process upload: ") + hipGetErrorString(cerr));
+
+    const int cst = ev->watched.empty() ? MLGPU_OK : processControllers(ev, nVectors, ev->stageIdx ^ 1);
+    if (cst != MLGPU_OK) return cst;
 
     memset(&dev.s, 0, sizeof(dev.s));
     dev.s.sr = ev->sr;
@@ -1024,6 +1218,67 @@ extern "C"
   {
     if (!ev || !staging) return MLGPU_ERR_INVALID;
     return launched(ev, *(mlgpu_events::Staging*)staging);
+  }
+  int mlgpu_events_watch_controllers(mlgpu_events* ev, const int* numbers, int n, size_t maxVectors)
+  {
+    if (!ev || n < 0 || (n > 0 && !numbers)) return MLGPU_ERR_INVALID;
+    mlgpu_engine* e = ev->e;
+    if (e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_watch_controllers allocates: not while recording a sequence");
+    if (n > MLGPU_EVENTS_MAX_WATCHED_CONTROLLERS) return efail(ev, MLGPU_ERR_RANGE, "events_watch_controllers: at most MLGPU_EVENTS_MAX_WATCHED_CONTROLLERS");
+    if (n > 0 && maxVectors == 0) return efail(ev, MLGPU_ERR_INVALID, "events_watch_controllers: max_vectors = the longest launch, at least 1");
+    for (int i = 0; i < n; ++i)
+    {
+      if (numbers[i] < 0 || numbers[i] >= kNumControllers) return efail(ev, MLGPU_ERR_RANGE, "events_watch_controllers: controller numbers 0..128");
+      for (int j = 0; j < i; ++j)
+        if (numbers[j] == numbers[i]) return efail(ev, MLGPU_ERR_INVALID, "events_watch_controllers: a controller number twice");
+    }
+    if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
+    hipStreamSynchronize(e->stream);
+    freeControllers(ev);
+    if (n == 0) return MLGPU_OK;
+    ev->watched.assign(numbers, numbers + n);
+    for (int i = 0; i < n; ++i) ev->slotOf[numbers[i]] = i;
+    ev->ctlMaxVectors = maxVectors;
+    const size_t lanes = ev->ctlLanes();
+    ev->ctlLaneRecs.resize(lanes);
+    hipError_t err = hipMalloc((void**)&ev->d_ctlOut, sizeof(float) * 64 * maxVectors * lanes);
+    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_ctlState, sizeof(uint32_t) * (size_t)kCtlWords * lanes);
+    for (mlgpu_events::CtlStaging& st : ev->ctlStage)
+    {
+      if (err == hipSuccess) err = hipMalloc((void**)&st.d_recStart, sizeof(uint32_t) * (lanes + 1));
+      if (err == hipSuccess) err = hipHostMalloc((void**)&st.h_recStart, sizeof(uint32_t) * (lanes + 1));
+    }
+    if (err == hipSuccess) err = hipMemsetAsync(ev->d_ctlOut, 0, sizeof(float) * 64 * maxVectors * lanes, e->stream);
+    if (err != hipSuccess)
+    {
+      freeControllers(ev);
+      return efail(ev, err == hipErrorOutOfMemory ? MLGPU_ERR_OOM : MLGPU_ERR_HIP, std::string("events_watch_controllers: ") + hipGetErrorString(err));
+    }
+    // A smoother that starts being watched now starts settled on its controller's current value (the reference's has been
+    // running all along: the same thing 20 ms after the controller last moved); an instrument that has not seen an event yet
+    // is asleep and gives zeros (:386).
+    std::vector<uint32_t> st((size_t)kCtlWords * lanes, 0u);
+    auto W = [&](int word, size_t lane) -> uint32_t& { return st[(size_t)word * lanes + lane]; };
+    for (int sl = 0; sl < n; ++sl)
+      for (size_t i = 0; i < ev->nInstruments; ++i)
+      {
+        const size_t lane = (size_t)sl * ev->nInstruments + i;
+        const float v = ev->inst[i].ctlInput.empty() ? 0.f : ev->inst[i].ctlInput[(size_t)numbers[sl]];
+        uint32_t bits;
+        memcpy(&bits, &v, 4);
+        W(C_AWAKE, lane) = ev->inst[i].awakeSent ? 1u : 0u;
+        W(C_INPUT, lane) = bits;
+        W(C_GLIDE + 0, lane) = bits;         // target
+        W(C_GLIDE + 2, lane) = 0xFFFFFFFFu;  // remaining = -1: holding (MLDSPGens.h:441)
+        W(C_GLIDE + 3, lane) = 1u;           // mCurrVec is one value
+        W(C_GLIDE + 4, lane) = bits;
+      }
+    return mlgpu_upload(e, ev->d_ctlState, st.data(), st.size() * sizeof(uint32_t));
+  }
+  const float* mlgpu_events_controller_signal(mlgpu_events* ev, int slot)
+  {
+    if (!ev || slot < 0 || (size_t)slot >= ev->watched.size()) return nullptr;
+    return ev->d_ctlOut + (size_t)slot * 64 * ev->ctlMaxVectors * ev->nInstruments;
   }
   int mlgpu_events_is_midi(mlgpu_events* ev) { return (ev && !ev->mpe) ? 1 : 0; }
   mlgpu_engine* mlgpu_events_engine(mlgpu_events* ev) { return ev ? ev->e : nullptr; }

@@ -354,6 +354,7 @@ struct mlgpu_graph
   size_t V{0};
   std::vector<Node> nodes;
   std::vector<int> outputs;
+  int inputGroup[MLGPU_GRAPH_MAX_INPUTS] = {};  // > 1: the input has one row per that many adjacent voices (mlgpu_graph_set_input_group)
   int outputGroup[MLGPU_GRAPH_MAX_OUTPUTS] = {0, 0, 0, 0, 0, 0, 0, 0};  // > 0: the output is the in-order sum of groups of that many adjacent voices
   int nInputs{0}, nParams{0}, nControls{0}, NC{0}, NS{0};
   bool compiled{false};
@@ -606,7 +607,8 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       }
       else if (n.type == NODE_INPUT)
       {
-        s << "  const f32x4* in" << n.slot << L << " = (const f32x4*)a.in[" << n.slot << "].base + v" << L << " * a.in[" << n.slot << "].strideV;\n";
+        const std::string row = g->inputGroup[n.slot] > 1 ? "(v" + std::string(L) + " / " + std::to_string(g->inputGroup[n.slot]) + ")" : "v" + std::string(L);
+        s << "  const f32x4* in" << n.slot << L << " = (const f32x4*)a.in[" << n.slot << "].base + " << row << " * a.in[" << n.slot << "].strideV;\n";
       }
       else if (n.type == NODE_CONTROL)
       {
@@ -1777,6 +1779,16 @@ extern "C"
     return MLGPU_OK;
   }
 
+  int mlgpu_graph_set_input_group(mlgpu_graph* g, int inputIndex, int group)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (inputIndex < 0 || inputIndex >= g->nInputs) return gfail(g, MLGPU_ERR_RANGE, "graph_set_input_group: input index out of range");
+    if (group < 1 || (size_t)group > g->V || g->V % (size_t)group) return gfail(g, MLGPU_ERR_INVALID, "graph_set_input_group: the voices are not a whole number of groups");
+    g->inputGroup[inputIndex] = group;
+    return MLGPU_OK;
+  }
+
   int mlgpu_graph_set_state_uniform(mlgpu_graph* g, int node, int idx, uint32_t value)
   {
     int st = checkStateNode(g, node);
@@ -1828,7 +1840,7 @@ extern "C"
     {
       if (!d_inputs[i] || ((uintptr_t)d_inputs[i] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned input");
       const int lay = (g->inLayoutOverride[i] >= 0) ? g->inLayoutOverride[i] : inLayout;
-      a.in[i] = makeView(d_inputs[i], lay, g->V, T);
+      a.in[i] = makeView(d_inputs[i], lay, g->inputGroup[i] > 1 ? g->V / (size_t)g->inputGroup[i] : g->V, T);
     }
     for (int i = 0; i < g->nControls; ++i)
     {

@@ -248,8 +248,8 @@ struct RefEvent
   int32_t time;
   float value1, value2;
 };
-extern "C" int e2s_ref_run(int polyphony, int mpe, int unison, double sr, float glideSeconds, float drift, float bendRange, float mpeBendRange, int modCC,
-                           const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out)
+static int e2sRefRun(int polyphony, int mpe, int unison, double sr, float glideSeconds, float drift, float bendRange, float mpeBendRange, int modCC,
+                     const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out, const int* ctlNumbers, int nCtl, float* ctlOut)
 {
   EventsToSignals e2s;
   e2s.setSampleRate(sr);
@@ -283,10 +283,25 @@ extern "C" int e2s_ref_run(int polyphony, int mpe, int unison, double sr, float 
       for (int v = 0; v < polyphony; ++v)
         for (int r = 0; r < kNumVoiceOutputRows; ++r)
           store(e2s.getVoice(v).outputs.constRow(r), out + ((size_t)r * polyphony + v) * S + start + off);
+      // what AudioContext::getInputController(n) hands a process function (MLAudioContext.cpp:129)
+      for (int c = 0; c < nCtl; ++c) store(e2s.getController((size_t)ctlNumbers[c]).output, ctlOut + (size_t)c * S + start + off);
     }
     e2s.clearEvents();
   }
   return 0;
+}
+extern "C" int e2s_ref_run(int polyphony, int mpe, int unison, double sr, float glideSeconds, float drift, float bendRange, float mpeBendRange, int modCC,
+                           const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out)
+{
+  return e2sRefRun(polyphony, mpe, unison, sr, glideSeconds, drift, bendRange, mpeBendRange, modCC, events, nEvents, blockFrames, nBlocks, out, nullptr, 0, nullptr);
+}
+// the same performance, and the smoothed signals of controllers ctlNumbers[] next to the voice rows: ctlOut [nCtl][frames]
+extern "C" int e2s_ref_run_controllers(int polyphony, int mpe, int unison, double sr, float glideSeconds, float drift, float bendRange, float mpeBendRange,
+                                       int modCC, const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out, const int* ctlNumbers,
+                                       int nCtl, float* ctlOut)
+{
+  return e2sRefRun(polyphony, mpe, unison, sr, glideSeconds, drift, bendRange, mpeBendRange, modCC, events, nEvents, blockFrames, nBlocks, out, ctlNumbers, nCtl,
+                   ctlOut);
 }
 
 // ---- SignalProcessor::PublishedSignal driven as processors drive it: storePublishedSignal per voice in rotation ----

@@ -35,7 +35,29 @@ def ref_run(cfg, events, block_frames, n_blocks):
     return out
 
 
-def gpu_run(eng, cfg, per_instrument_events, block_frames, n_blocks, vectors_per_launch, rows=None):
+def ref_run_controllers(cfg, events, block_frames, n_blocks, numbers):
+    """(voice rows [8][P][frames], controller signals [len(numbers)][frames]) of the reference's EventsToSignals."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libdropin_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libdropin_ref.so not available here")
+    L = ctypes.CDLL(so)
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.e2s_ref_run_controllers.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                          ctypes.c_float, ctypes.c_int, ctypes.POINTER(RefEvent), ctypes.c_int, ctypes.c_int, ctypes.c_int, fp,
+                                          ctypes.POINTER(ctypes.c_int), ctypes.c_int, fp]
+    P = cfg["polyphony"]
+    out = np.zeros((8, P, n_blocks * block_frames), np.float32)
+    ctl = np.zeros((len(numbers), n_blocks * block_frames), np.float32)
+    arr = (RefEvent * max(1, len(events)))(*[RefEvent(*e) for e in events])
+    nums = (ctypes.c_int * len(numbers))(*numbers)
+    assert L.e2s_ref_run_controllers(P, int(cfg.get("mpe", 0)), int(cfg.get("unison", 0)), cfg.get("sr", 48000.0), cfg.get("glide", 0.0), cfg.get("drift", 0.0),
+                                     cfg.get("bend", 7.0), cfg.get("mpe_bend", 24.0), cfg.get("mod_cc", 16), arr, len(events), block_frames, n_blocks,
+                                     out.ctypes.data_as(fp), nums, len(numbers), ctl.ctypes.data_as(fp)) == 0
+    return out, ctl
+
+
+def gpu_run(eng, cfg, per_instrument_events, block_frames, n_blocks, vectors_per_launch, rows=None, watch=None, watch_from_block=0):
+    """watch: controller numbers; then returns (rows, controller signals [len(watch)][N][frames]; zeros before watch_from_block)."""
     """per_instrument_events: one event list per instrument. Returns [8][N*P][frames] (rows not wanted: zeros)."""
     import madronalib_amd as ml
     N, P = len(per_instrument_events), cfg["polyphony"]
@@ -44,8 +66,10 @@ def gpu_run(eng, cfg, per_instrument_events, block_frames, n_blocks, vectors_per
                  mpe_pitch_bend=cfg.get("mpe_bend", 24.0), glide_seconds=cfg.get("glide", 0.0), drift=cfg.get("drift", 0.0))
     if rows is not None:
         ev.set_wanted_rows(rows)
-    outs = []
+    outs, ctl = [], []
     for b in range(n_blocks):
+        if watch is not None and b == watch_from_block:
+            ev.watch_controllers(watch, vectors_per_launch)
         start = b * block_frames
         batch_i, batch_e = [], []
         for i, evs in enumerate(per_instrument_events):
@@ -62,8 +86,12 @@ def gpu_run(eng, cfg, per_instrument_events, block_frames, n_blocks, vectors_per
         while done < vecs:       # a block may be processed in several launches
             n = min(vectors_per_launch, vecs - done)
             outs.append(ev.process_host(n, done * 64))
+            if watch is not None:
+                ctl.append(ev.controllers_host(n) if b >= watch_from_block else np.zeros((len(watch), N, 64 * n), np.float32))
             done += n
         ev.clear_events()
+    if watch is not None:
+        return np.concatenate(outs, 2), np.concatenate(ctl, 2)
     return np.concatenate(outs, 2)
 
 
@@ -406,3 +434,117 @@ def test_event_rows_full_size(eng):
     for k in range(launches):
         assert_bits_equal(results[1][k], results[0][k], True, f"full-size instrument bank, launch {k}")
     assert np.abs(results[0][-1]).max() > 0
+
+
+# ---- smoothed controller signals (AudioContext::getInputController) ------------------------------------------------------------
+
+WATCHED = [16, 128, 74, 5, 1]      # 5 is never sent: its signal stays at zero
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["midi_poly4", "mpe5", "sr44k", "sr8k", "poly1"])
+def test_controller_signals_match_reference(eng, name):
+    """mlgpu_events_watch_controllers / controller_signal against EventsToSignals::getController(n).output of the reference's
+    class on the scripted performances (controllers 1, 16, 73, 74, 128, MIDI channel pressure -> 128), several launches per block,
+    one instrument that never receives an event (asleep: zeros); the voice rows are the same as without watching."""
+    cfg = SCENARIOS[name]
+    block, n_blocks = 512, 10
+    kind = "mpe" if cfg.get("mpe") else "midi"
+    instruments = [performance(kind, 100 * k + len(name), block * n_blocks, cfg["polyphony"]) for k in range(4)] + [[]]
+    rows, ctl = gpu_run(eng, cfg, instruments, block, n_blocks, vectors_per_launch=3, watch=WATCHED)
+    P = cfg["polyphony"]
+    moved = 0
+    for k, evs in enumerate(instruments):
+        want_rows, want_ctl = ref_run_controllers(cfg, evs, block, n_blocks, WATCHED)
+        for r in range(8):
+            assert_bits_equal(rows[r, k * P:(k + 1) * P], want_rows[r], True, f"{name}: instrument {k} row {ROW_NAMES[r]}")
+        for c, num in enumerate(WATCHED):
+            assert_bits_equal(ctl[c, k], want_ctl[c], True, f"{name}: instrument {k} controller {num}")
+        moved += int(np.abs(np.diff(want_ctl, axis=1)).max() > 0)
+    assert moved >= 3 and not ctl[:, -1].any() and not ctl[3].any()
+
+
+@pytest.mark.gpu
+def test_controllers_watched_later_start_settled(eng):
+    """A smoother that starts being watched after its controller last moved (more than the 20 ms glide ago) continues exactly
+    like the reference's, which has been running all along."""
+    cfg = SCENARIOS["midi_poly4"]
+    block, n_blocks = 512, 8
+    evs = [(NOTE_ON, 1, 60, 10, 0.0, 0.8), (CTRL, 1, 74, 100, 0.625, 0.0), (CTRL, 1, 16, 300, 0.25, 0.0),
+           (CTRL, 1, 74, 5 * 512 + 77, 0.125, 0.0), (CHAN_PRESS, 1, 0, 6 * 512 + 3, 0.5, 0.0)]
+    rows, ctl = gpu_run(eng, cfg, [evs], block, n_blocks, vectors_per_launch=8, watch=[74, 16, 128], watch_from_block=4)
+    _, want = ref_run_controllers(cfg, evs, block, n_blocks, [74, 16, 128])
+    assert_bits_equal(ctl[:, 0, 4 * block:], want[:, 4 * block:], True, "controllers watched from block 4 on")
+    assert want[0, 4 * block] == np.float32(0.625) and want[0, -1] == np.float32(0.125) and want[2, -1] == np.float32(0.5)
+
+
+@pytest.mark.gpu
+def test_watch_controllers_error_paths(eng):
+    import madronalib_amd as ml
+    ev = ml.Events(eng, 3, 4)
+    for bad in ([1, 1], [129], [-1], list(range(33))):
+        with pytest.raises(ml.MlgpuError):
+            ev.watch_controllers(bad, 4)
+    with pytest.raises(ml.MlgpuError):
+        ev.watch_controllers([1], 0)
+    with pytest.raises(ml.MlgpuError):
+        ev.controller_signal(0)
+    ev.watch_controllers([7, 1], 2)
+    with pytest.raises(ml.MlgpuError) as ei:
+        ev.process_host(3)                       # more vectors than the controller signals were reserved for
+    assert ei.value.status == ml.Status.ERR_RANGE
+    ev.process_host(2)
+    assert ev.controllers_host(2).shape == (2, 3, 128)
+    ev.watch_controllers([], 0)                  # releases them
+    ev.process_host(3)
+    ev.close()
+
+
+@pytest.mark.gpu
+def test_controller_signal_as_a_group_input_of_the_voice_graph(eng):
+    """What a process function that calls ctx->getInputController(n) becomes: the controller's signal - one row per instrument -
+    read by every voice of that instrument (mlgpu_graph_set_input_group), here multiplied with the gate row computed in the same
+    kernel (event rows) and, in a second graph, with the gate row e2s_kernel wrote. Both equal reference gate x reference
+    controller signal (one multiply: bit-exact)."""
+    import madronalib_amd as ml
+    from madronalib_amd.constants import Layout, Op
+    cfg = SCENARIOS["midi_poly4"]
+    P, N, block, n_blocks, T = 4, 6, 512, 6, 4
+    V = N * P
+    instruments = [performance("midi", 31 * k + 5, block * n_blocks, P) for k in range(N)]
+    want = np.zeros((V, block * n_blocks), np.float32)
+    for k, evs in enumerate(instruments):
+        rows, ctl = ref_run_controllers(cfg, evs, block, n_blocks, [74])
+        want[k * P:(k + 1) * P] = rows[1] * ctl[0][None, :]
+    for fused in (True, False):
+        ev = ml.Events(eng, N, P)
+        ev.configure(glide_seconds=cfg["glide"], drift=cfg["drift"])
+        ev.set_wanted_rows([0, 1])
+        ev.watch_controllers([74], T)
+        desc = [dict(name="gate", type="event_row", kind=1) if fused else dict(name="gate", type="input"), dict(name="cc74", type="input"),
+                dict(name="out", type="op", kind=Op.MULTIPLY, inputs=["gate", "cc74"])]
+        g = ml.Graph(eng, V, desc, ["out"], input_groups={(0 if fused else 1): P})
+        if fused:
+            g.bind_events(ev)
+        d_out, d_gate, d_pitch = eng.alloc(4 * V * T * 64), eng.alloc(4 * V * T * 64), eng.alloc(4 * V * T * 64)
+        chunks = []
+        for b in range(n_blocks):
+            bi, be = [], []
+            for i, evs in enumerate(instruments):
+                for e in evs:
+                    if b * block <= e[3] < (b + 1) * block:
+                        bi.append(i)
+                        be.append(ml.Event(e[0], e[1], e[2], e[3] - b * block, e[4], e[5]))
+            ev.add_events(bi, be)
+            for done in range(0, block // 64, T):
+                if fused:
+                    g.process_events(T, done * 64, [ev.controller_signal(0)], [d_out], out_layout=Layout.VOICE_MAJOR)
+                else:
+                    ev.process(T, done * 64, [d_pitch, d_gate] + [None] * 6, Layout.QUAD)
+                    g.process(T, [d_gate, ev.controller_signal(0)], [d_out], out_layout=Layout.VOICE_MAJOR)
+                chunks.append(d_out.download(np.float32, V * T * 64).reshape(V, T * 64).copy())
+            ev.clear_events()
+        assert_bits_equal(np.concatenate(chunks, 1), want, True, f"gate x controller 74, fused={fused}")
+        g.close()
+        ev.close()
+    assert np.abs(want).max() > 0

@@ -658,3 +658,42 @@ def test_voice_sum_inside_the_graph_kernel(eng, oracle, group, vpl):
             acc = acc + y[:, p]
     assert_bits_equal(got.reshape(V // group, 64 * T), acc, True, "voice sum vs numpy")
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group,vpl", [(1, 0), (4, 0), (16, 0), (3, 0), (4, 2), (192, 0)])
+def test_input_shared_by_groups_of_voices(eng, group, vpl):
+    """mlgpu_graph_set_input_group: an input with one row per `group` adjacent voices (a controller or transport signal per
+    instrument); voice v reads row v // group. QUAD and VOICE_MAJOR, one and two voices per lane, a group that is not a power
+    of two, one row for the whole bank."""
+    import madronalib_amd as ml
+    V, T = 192, 5
+    rng = np.random.default_rng(group)
+    x = rng.standard_normal((V, 64 * T)).astype(np.float32)
+    c = rng.standard_normal((V // group, 64 * T)).astype(np.float32)
+    desc = [dict(name="x", type="input"), dict(name="c", type="input"), dict(name="y", type="op", kind=Op.MULTIPLY, inputs=["x", "c"])]
+    want = x * np.repeat(c, group, axis=0)
+    for layout in (Layout.QUAD, Layout.VOICE_MAJOR):
+        g = ml.Graph(eng, V, desc, ["y"], voices_per_lane=vpl, input_groups={1: group})
+        def dev(a):
+            rows = a.shape[0]
+            if layout == Layout.QUAD:
+                a = a.reshape(rows, 16 * T, 4).transpose(1, 0, 2)
+            return eng.to_device(np.ascontiguousarray(a))
+        d_y = eng.alloc(4 * V * T * 64)
+        g.process(T, [dev(x), dev(c)], [d_y], in_layout=layout, out_layout=Layout.VOICE_MAJOR)
+        assert_bits_equal(d_y.download(np.float32, V * T * 64).reshape(V, 64 * T), want, True, f"group {group} layout {layout}")
+        g.close()
+    g = ml.Graph(eng, V, desc, ["y"])
+    g_err = ml.Graph(eng, V, None)
+    for n in desc[:2]:
+        g_err.add(**n)
+    for bad in (0, 5, V + 1):
+        with pytest.raises(ml.MlgpuError):
+            g_err.set_input_group(1, bad)
+    with pytest.raises(ml.MlgpuError):
+        g_err.set_input_group(2, 4)
+    with pytest.raises(ml.MlgpuError):
+        g.set_input_group(1, 4)                    # already compiled
+    g.close()
+    g_err.close()
