@@ -711,7 +711,8 @@ int mlgpu_events_process(mlgpu_events* ev, size_t n_vectors, int start_offset, f
  * made on the device from the controller events of each DSPVector: output = LinearGlide(20 ms)(value of the last controller
  * event so far); zeros while the instrument has not seen any event (:386). watch_controllers reserves the signals for launches
  * of up to max_vectors DSPVectors (it allocates: call it at set-up time; n = 0 releases them); a smoother that starts being
- * watched later than the first event starts settled on its controller's current value. From then on every
+ * watched later than the first event starts settled on its controller's current value; calling it again with the same numbers
+ * only changes max_vectors (the smoothers go on, the signal pointers change). From then on every
  * mlgpu_events_process / mlgpu_graph_process_events call also advances the controller signals by the same DSPVectors.
  * mlgpu_events_controller_signal(ev, slot): the device signal of numbers[slot] for the DSPVectors of the LAST such call - QUAD
  * layout over nInstruments "voices" ([16 n_vectors][nInstruments][4] floats), valid until the next one; the pointer itself

@@ -110,6 +110,16 @@ struct Capture
     return feedbackOfOrd[ord] = ret(mlgpu_graph_add_feedback(g, nullptr));
   }
 
+  // Context signals - one row per instrument, not per voice: AudioContext::getInputController(n), getBeatPhase(). Each becomes
+  // a streamed graph input shared by the `contextGroup` adjacent voices of an instrument (mlgpu_graph_set_input_group), added
+  // where the captured code first asks for it.
+  static constexpr int kBeatPhase = 1000;
+  int inputCount{0};               // graph inputs added so far in this pass
+  size_t contextGroup{1};
+  std::vector<int> contextInputs;  // this pass, in input order: a controller number, or kBeatPhase
+  std::map<int, int> contextNode;
+  int contextInput(int code);
+
   static Capture*& current()
   {
     static thread_local Capture* c = nullptr;
@@ -156,6 +166,19 @@ struct Capture
   void deferClear(int node) { deferred.push_back(Deferred{node, 1, 0, 0}); }
   void deferState(int node, int idx, uint32_t bits) { deferred.push_back(Deferred{node, 2, idx, bits}); }
 };
+inline int Capture::contextInput(int code)
+{
+  auto it = contextNode.find(code);
+  if (it != contextNode.end()) return it->second;
+  const std::string name = code == kBeatPhase ? std::string("beatPhase") : "controller" + std::to_string(code);
+  const int node = ret(mlgpu_graph_add_input(g, name.c_str()));
+  int st = mlgpu_graph_set_input_group(g, inputCount, (int)contextGroup);
+  if (st == MLGPU_OK) st = mlgpu_graph_set_input_layout(g, inputCount, MLGPU_LAYOUT_QUAD);  // whatever layout the audio inputs come in
+  if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_graph: ") + mlgpu_last_error(eng->handle()));
+  ++inputCount;
+  contextInputs.push_back(code);
+  return contextNode[code] = node;
+}
 
 }  // namespace gpu
 
@@ -1460,6 +1483,15 @@ class AudioContext
     usesVoice_ = true;
     return voice_;
   }
+  // Context signals (MLAudioContext.h:82,91): in a capture each is a graph input with one row per instrument, fed by
+  // mlgpu_events_controller_signal / mlgpu_transport_beat_phase (gpu::SynthProgram does that; gpu::VoiceProgram::process takes the
+  // pointers in the order of VoiceProgram::contextInputs()).
+  DSPVector getInputController(size_t n) const
+  {
+    if (n > 128) n = 128;
+    return DSPVector(gpu::Sig(gpu::Capture::get().contextInput((int)n), 0.f));
+  }
+  DSPVector getBeatPhase() { return DSPVector(gpu::Sig(gpu::Capture::get().contextInput(gpu::Capture::kBeatPhase), 0.f)); }
   DSPVectorDynamic inputs;
   DSPVectorDynamic outputs;
 
@@ -1660,6 +1692,9 @@ struct VoiceProgramOptions
   // events' records (mlgpu_graph_add_event_row) instead of reading them from memory - a quarter faster end to end. MIDI protocol
   // only (mlgpu_events_set_protocol(..., 1) makes process() fail), hence opt-in.
   bool eventRowsInKernel{false};
+  // Context signals (AudioContext::getInputController / getBeatPhase) have one row per this many adjacent voices: the
+  // instrument's polyphony. 0: ctx->getInputPolyphony() if that was set, else one row for the whole bank.
+  size_t voicesPerContext{0};
 };
 
 // Captures a reference-style process function once and runs it for `voices` voices on the GPU.
@@ -1672,6 +1707,7 @@ class VoiceProgram
   bool usesVoice_{false};
   unsigned voiceRowMask_{0};  // which of the 8 voice control rows the captured code reads: only those are graph inputs
   std::vector<Capture::Tap> taps_;  // published signals: graph outputs after the nOut_ audio outputs, in this order
+  std::vector<int> contextInputs_;  // context signals the code reads: graph inputs after the audio inputs and the voice rows
   AudioContext* ctx_{nullptr};
   std::function<void(AudioContext*)> body_;
   VoiceProgramOptions opt_;
@@ -1692,6 +1728,8 @@ class VoiceProgram
     Capture cap;
     cap.eng = &e;
     cap.dedupeConstants = !opt.liveConstants;  // live: one node per use, so that a later capture with other numbers lines up
+    cap.contextGroup = contextGroup();
+    if (voices % cap.contextGroup) throw Error(MLGPU_ERR_INVALID, "VoiceProgram: the voices are not a whole number of instruments (voicesPerContext)");
     CaptureScope scope(&cap);
     // pass 1 records what the process function leaves behind in the user's state (DSPVectors kept for the next call);
     // pass 2 builds the graph that is compiled, reading those as one-vector feedback
@@ -1717,6 +1755,7 @@ class VoiceProgram
     flush_ = cap.flushDenormals;
     finishGraph(cap, g_);
     taps_ = cap.taps;
+    contextInputs_ = cap.contextInputs;
     eng_.check(mlgpu_graph_compile(g_));
     for (const Capture::Deferred& d : cap.deferred)
     {
@@ -1738,6 +1777,7 @@ class VoiceProgram
     Capture cap;
     cap.eng = &eng_;
     cap.dedupeConstants = !opt_.liveConstants;
+    cap.contextGroup = contextGroup();
     CaptureScope scope(&cap);
     mlgpu_graph* tmp = nullptr;
     eng_.check(mlgpu_graph_create(eng_.handle(), voices_, &tmp));
@@ -1784,7 +1824,10 @@ class VoiceProgram
     cap.regionCounter = cap.curRegion = 0;
     cap.deferred.clear();
     cap.taps.clear();
-    for (size_t c = 0; c < nIn_; ++c)
+    cap.contextInputs.clear();
+    cap.contextNode.clear();
+    cap.inputCount = 0;
+    for (size_t c = 0; c < nIn_; ++c, ++cap.inputCount)
       ctx_->inputs[(int)c] = DSPVector(Sig(cap.ret(mlgpu_graph_add_input(g, ("in" + std::to_string(c)).c_str())), 0.f));
     // the 8 rows of this lane's voice (EventsToSignals) are further streamed inputs, after the audio inputs; the first pass
     // finds out whether the code reads them at all
@@ -1793,8 +1836,12 @@ class VoiceProgram
       rowNode[r] = -1;
       if (firstPass || ((voiceRowMask_ >> r) & 1u))
       {
-        rowNode[r] = (!firstPass && eventRowsInKernel()) ? cap.ret(mlgpu_graph_add_event_row(g, r, ("voice" + std::to_string(r)).c_str()))
-                                                         : cap.ret(mlgpu_graph_add_input(g, ("voice" + std::to_string(r)).c_str()));
+        if (!firstPass && eventRowsInKernel()) rowNode[r] = cap.ret(mlgpu_graph_add_event_row(g, r, ("voice" + std::to_string(r)).c_str()));
+        else
+        {
+          rowNode[r] = cap.ret(mlgpu_graph_add_input(g, ("voice" + std::to_string(r)).c_str()));
+          ++cap.inputCount;
+        }
         ctx_->voice_.outputs.row(r) = DSPVector(Sig(rowNode[r], 0.f));
       }
       else
@@ -1829,6 +1876,14 @@ class VoiceProgram
   // the voice rows are computed inside the kernel (VoiceProgramOptions::eventRowsInKernel and nothing but pitch / gate is read)
   bool eventRowsInKernel() const { return opt_.eventRowsInKernel && voiceRowMask_ != 0 && (voiceRowMask_ & ~3u) == 0; }
   mlgpu_graph* graph() const { return g_; }
+  // the context signals the captured code reads, in the order process() takes them: a controller number (0..128), or
+  // Capture::kBeatPhase; each is a signal of voices() / contextGroup() rows
+  const std::vector<int>& contextInputs() const { return contextInputs_; }
+  size_t contextGroup() const
+  {
+    if (opt_.voicesPerContext) return opt_.voicesPerContext;
+    return ctx_->getInputPolyphony() ? ctx_->getInputPolyphony() : voices_;
+  }
   const std::vector<Capture::Tap>& taps() const { return taps_; }
   size_t tapChannels() const
   {
@@ -1873,8 +1928,12 @@ class VoiceProgram
   // one call = T DSPVectors of every voice (the reference calls the process function T times)
   // voiceRows: the 8 signals of mlgpu_events_process for the same voices (needed when the captured code called
   // getInputVoice(); nullptr otherwise)
-  void process(const std::vector<const DeviceSignal*>& ins, const std::vector<DeviceSignal*>& outs, const float* const* voiceRows = nullptr)
+  // contextSignals: one device signal (QUAD, voices() / contextGroup() rows) per entry of contextInputs()
+  void process(const std::vector<const DeviceSignal*>& ins, const std::vector<DeviceSignal*>& outs, const float* const* voiceRows = nullptr,
+               const float* const* contextSignals = nullptr)
   {
+    if (!contextInputs_.empty() && !contextSignals)
+      throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: this program reads context signals (controllers / beat phase); pass them");
     if (ins.size() != nIn_ || outs.size() != nOut_ + tapChannels() || outs.empty())
       throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: wrong number of signals (outputs: the audio outputs, then one per published channel)");
     if (usesVoice_ && !voiceRows) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: this program reads the voice control rows; pass them");
@@ -1888,6 +1947,11 @@ class VoiceProgram
         if (!voiceRows[r]) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: the program reads voice row " + std::to_string(r) + "; pass it");
         pi.push_back(voiceRows[r]);
       }
+    for (size_t c = 0; c < contextInputs_.size(); ++c)
+    {
+      if (!contextSignals[c]) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::process: null context signal");
+      pi.push_back(contextSignals[c]);
+    }
     for (auto* s : outs) po.push_back(s->data());
     const int inLayout = ins.empty() ? MLGPU_LAYOUT_QUAD : ins[0]->layout();
     // the mode travels with the launch (a kernel argument), so it is restored as soon as the launch is enqueued
@@ -1915,6 +1979,12 @@ class SynthProgram
   std::vector<DeviceSignal> rows_, voiceOut_, tapOut_;
   std::vector<SignalProcessor::PublishedSignal*> published_;  // one per tap of prog_, in tap order
   size_t publishedInstrument_{0};
+  std::vector<int> controllers_;  // controller numbers processVoice reads through ctx->getInputController(n)
+  static VoiceProgramOptions perInstrument(VoiceProgramOptions o, int polyphony)
+  {
+    o.voicesPerContext = (size_t)polyphony;
+    return o;
+  }
 
  public:
   SynthProgram(const Engine& e, Synth& synth, size_t nInstruments, size_t nOutputs, int sampleRate, VoiceProgramOptions opt = VoiceProgramOptions())
@@ -1924,8 +1994,13 @@ class SynthProgram
         nOut_(nOutputs),
         ctx_(0, nOutputs, sampleRate),
         prog_(e, nInstruments * (size_t)synth.getNumVoices(), &ctx_,
-              [&synth](AudioContext* c) { synth.processVoice(0, c->getInputVoice(0), c->inputs, c->outputs, c); }, opt)
+              [&synth](AudioContext* c) { synth.processVoice(0, c->getInputVoice(0), c->inputs, c->outputs, c); }, perInstrument(opt, synth.getNumVoices()))
   {
+    for (int code : prog_.contextInputs())
+    {
+      if (code == Capture::kBeatPhase) throw Error(MLGPU_ERR_UNSUPPORTED, "SynthProgram: processVoice reads getBeatPhase(); run it as a VoiceProgram with an mlgpu_transport's signal");
+      controllers_.push_back(code);
+    }
     eng_.check(mlgpu_events_create(e.handle(), nInstruments, polyphony_, &ev_));
     eng_.check(mlgpu_events_set_sample_rate(ev_, (double)sampleRate));
     eng_.check(mlgpu_events_set_wanted_rows(ev_, prog_.voiceRowMask()));  // rows processVoice never reads are not made
@@ -1981,6 +2056,8 @@ class SynthProgram
       for (int r = 0; r < kNumVoiceOutputRows; ++r)
         rows_.emplace_back(eng_, (!prog_.eventRowsInKernel() && ((prog_.voiceRowMask() >> r) & 1u)) ? voices() : 1, nVectors);
       for (size_t c = 0; c < nOut_; ++c) voiceOut_.emplace_back(eng_, voices(), nVectors);
+      // the controllers' smoothers go on when only the reserved length changes
+      if (!controllers_.empty()) eng_.check(mlgpu_events_watch_controllers(ev_, controllers_.data(), (int)controllers_.size(), nVectors));
       capacityT_ = nVectors;
     }
     const bool inKernel = prog_.eventRowsInKernel();
@@ -1991,11 +2068,12 @@ class SynthProgram
       rowPtrs[r] = (!inKernel && ((prog_.voiceRowMask() >> r) & 1u)) ? rows_[r].data() : nullptr;
       if (rowPtrs[r]) pi.push_back(rowPtrs[r]);
     }
+    for (size_t c = 0; c < controllers_.size(); ++c) pi.push_back(mlgpu_events_controller_signal(ev_, (int)c));  // made by the events call below
     std::vector<float*> po;
     for (auto& s : voiceOut_) po.push_back(s.data());
     for (auto& s : tapOut_) po.push_back(s.data());
     if (inKernel)  // the voice kernel walks the block's event records itself: pitch and gate never exist in memory
-      eng_.check(mlgpu_graph_process_events(prog_.graph(), nVectors, startOffset, nullptr, MLGPU_LAYOUT_QUAD, nullptr, po.data(), MLGPU_LAYOUT_QUAD));
+      eng_.check(mlgpu_graph_process_events(prog_.graph(), nVectors, startOffset, pi.data(), MLGPU_LAYOUT_QUAD, nullptr, po.data(), MLGPU_LAYOUT_QUAD));
     else
     {
       eng_.check(mlgpu_events_process(ev_, nVectors, startOffset, rowPtrs, MLGPU_LAYOUT_QUAD));

@@ -1234,6 +1234,18 @@ extern "C"
     }
     if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
     hipStreamSynchronize(e->stream);
+    if (n > 0 && ev->watched == std::vector<int>(numbers, numbers + n))  // the same controllers: only the reserved length changes
+    {
+      if (maxVectors == ev->ctlMaxVectors) return MLGPU_OK;
+      float* fresh = nullptr;
+      const size_t bytes = sizeof(float) * 64 * maxVectors * ev->ctlLanes();
+      if (hipMalloc((void**)&fresh, bytes) != hipSuccess) return efail(ev, MLGPU_ERR_OOM, "events_watch_controllers: controller signals");
+      hipMemsetAsync(fresh, 0, bytes, e->stream);
+      hipFree(ev->d_ctlOut);
+      ev->d_ctlOut = fresh;
+      ev->ctlMaxVectors = maxVectors;
+      return MLGPU_OK;
+    }
     freeControllers(ev);
     if (n == 0) return MLGPU_OK;
     ev->watched.assign(numbers, numbers + n);

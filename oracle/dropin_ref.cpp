@@ -197,6 +197,11 @@ extern "C" int synth_ref_run(const SynthRefEvent* events, int nEvents, float gli
 {
   return synth_ref_run_t<SmallSynth>(events, nEvents, glideSeconds, drift, blockFrames, nBlocks, outL, outR, scope, scopeCounts, scopeFramesPerRead);
 }
+extern "C" int controller_synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL,
+                                        float* outR)
+{
+  return synth_ref_run_t<ControllerSynth>(events, nEvents, glideSeconds, drift, blockFrames, nBlocks, outL, outR, nullptr, nullptr, 0);
+}
 extern "C" int lean_synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR)
 {
   return synth_ref_run_t<LeanSynth>(events, nEvents, glideSeconds, drift, blockFrames, nBlocks, outL, outR, nullptr, nullptr, 0);

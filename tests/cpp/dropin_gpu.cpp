@@ -355,6 +355,14 @@ extern "C" int synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, c
   return synth_gpu_run_t<SmallSynth>(nInstruments, events, eventInstrument, nEvents, glideSeconds, drift, blockFrames, nBlocks, vectorsPerLaunch, outL, outR,
                                      scopeInstrument, scope, scopeCounts, scopeFramesPerRead, err, errLen, false, nullptr);
 }
+// the synth that reads the instrument's controllers through the AudioContext
+extern "C" int controller_synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
+                                        int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, int eventRowsInKernel, int* rowsInKernel,
+                                        char* err, size_t errLen)
+{
+  return synth_gpu_run_t<ControllerSynth>(nInstruments, events, eventInstrument, nEvents, glideSeconds, drift, blockFrames, nBlocks, vectorsPerLaunch, outL, outR,
+                                          0, nullptr, nullptr, 0, err, errLen, eventRowsInKernel != 0, rowsInKernel);
+}
 // the pitch-and-gate-only synth; eventRowsInKernel: the voice kernel computes the two rows itself; *rowsInKernel: whether it did
 extern "C" int lean_synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
                                   int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, int eventRowsInKernel, int* rowsInKernel,

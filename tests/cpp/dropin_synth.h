@@ -94,3 +94,45 @@ class LeanSynth : public Synth
   }
 };
 
+
+// USER CODE #3c: a Synth whose voices also read the instrument's smoothed MIDI controllers through the AudioContext
+// (ctx->getInputController(n), MLAudioContext.h:91): brightness (74) opens the filter, the mod wheel (1) bends the pitch, channel
+// pressure (controller slot 128) swells the level. On the GPU side each controller is one signal per instrument made from the
+// controller events (mlgpu_events_watch_controllers) and read by the instrument's voices.
+class ControllerSynth : public Synth
+{
+  struct VoiceDSP
+  {
+    SawGen saw;
+    Lopass lp;
+    ADSR env;
+  };
+  std::array<VoiceDSP, kSynthVoices> dsp_;
+
+ public:
+  ControllerSynth() : Synth(kSynthVoices)
+  {
+    for (auto& d : dsp_)
+    {
+      d.env.coeffs = ADSR::calcCoeffs(0.004f, 0.08f, 0.5f, 0.15f, 48000.f);
+      d.saw.clear();
+    }
+  }
+  void setEnvelope(float a, float d, float s, float r)
+  {
+    for (auto& v : dsp_) v.env.coeffs = ADSR::calcCoeffs(a, d, s, r, 48000.f);
+  }
+  void processVoice(int v, const EventsToSignals::Voice& voice, const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs,
+                    AudioContext* ctx) override
+  {
+    VoiceDSP& d = dsp_[v];
+    const DSPVector brightness = ctx->getInputController(74);
+    const DSPVector wheel = ctx->getInputController(1);
+    const DSPVector pressure = ctx->getInputController(128);
+    const DSPVector freq = exp2Approx(voice.outputs.constRow(kPitch) + wheel * 0.05f) * (261.6256f / 48000.f);
+    const DSPVector omega = brightness * 0.2f + 0.02f;
+    const DSPVector y = d.lp(d.saw(freq), omega, DSPVector(0.7f)) * d.env(voice.outputs.constRow(kGate)) * (pressure * 0.5f + 0.5f);
+    outputs[0] += y;
+    outputs[1] += y * wheel;
+  }
+};
