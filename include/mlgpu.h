@@ -721,6 +721,26 @@ int mlgpu_events_process(mlgpu_events* ev, size_t n_vectors, int start_offset, f
 int mlgpu_events_watch_controllers(mlgpu_events* ev, const int* numbers, int n, size_t max_vectors);
 const float* mlgpu_events_controller_signal(mlgpu_events* ev, int slot);
 
+/* ---- AudioContext::ProcessTime (source/app/MLAudioContext.h:27-57, MLAudioContext.cpp:16-104) for n independent contexts:
+ * the quarter-note phasor a process function reads through ctx->getBeatPhase(). set_time_and_rate = AudioContext::updateTime ->
+ * ProcessTime::setTimeAndRate (host arithmetic in double, as in the reference; the report refers to the start of the next
+ * process call; NaN / infinite positions and tempi are ignored, :20-26); process = ProcessTime::processVector for n_vectors
+ * DSPVectors on the device (omega_ float, slope double, wrapped above 1; -1 while the host is not playing);
+ * beat_phase = the signal of the last process call, QUAD layout over the n contexts ([16 n_vectors][n][4] floats; the pointer
+ * does not change): feed it to a voice graph as an input with mlgpu_graph_set_input_group(g, input, voices per context).
+ * index MLGPU_TRANSPORT_ALL: every context (one host application, many instruments). */
+typedef struct mlgpu_transport mlgpu_transport;
+#define MLGPU_TRANSPORT_ALL ((size_t)-1)
+int mlgpu_transport_create(mlgpu_engine* e, size_t n, size_t max_vectors, mlgpu_transport** out);
+int mlgpu_transport_destroy(mlgpu_transport* t);
+int mlgpu_transport_reserve(mlgpu_transport* t, size_t max_vectors);  /* another launch length; the phasors go on, the signal pointer changes */
+int mlgpu_transport_clear(mlgpu_transport* t, size_t index);  /* ProcessTime::clear */
+int mlgpu_transport_set_time_and_rate(mlgpu_transport* t, size_t index, double ppq_pos, double bpm, int is_playing, double sample_rate);
+int mlgpu_transport_process(mlgpu_transport* t, size_t n_vectors);
+const float* mlgpu_transport_beat_phase(mlgpu_transport* t);
+uint64_t mlgpu_transport_samples_since_start(mlgpu_transport* t, size_t index);  /* ProcessTime::samplesSinceStart */
+double mlgpu_transport_bpm(mlgpu_transport* t, size_t index);
+
 /* A streamed input shared by groups of adjacent voices: input `input_index` (the order of mlgpu_graph_add_input) is a signal of
  * voices / group rows, voice v reads row v / group - one controller or transport signal per instrument of `group` voices
  * (group = voices: one row for the whole bank). voices must be a multiple of group. Before compile. */

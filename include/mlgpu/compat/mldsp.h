@@ -1980,6 +1980,7 @@ class SynthProgram
   std::vector<SignalProcessor::PublishedSignal*> published_;  // one per tap of prog_, in tap order
   size_t publishedInstrument_{0};
   std::vector<int> controllers_;  // controller numbers processVoice reads through ctx->getInputController(n)
+  mlgpu_transport* transport_{nullptr};  // there when processVoice reads ctx->getBeatPhase(): one ProcessTime per instrument
   static VoiceProgramOptions perInstrument(VoiceProgramOptions o, int polyphony)
   {
     o.voicesPerContext = (size_t)polyphony;
@@ -1997,10 +1998,8 @@ class SynthProgram
               [&synth](AudioContext* c) { synth.processVoice(0, c->getInputVoice(0), c->inputs, c->outputs, c); }, perInstrument(opt, synth.getNumVoices()))
   {
     for (int code : prog_.contextInputs())
-    {
-      if (code == Capture::kBeatPhase) throw Error(MLGPU_ERR_UNSUPPORTED, "SynthProgram: processVoice reads getBeatPhase(); run it as a VoiceProgram with an mlgpu_transport's signal");
-      controllers_.push_back(code);
-    }
+      if (code != Capture::kBeatPhase) controllers_.push_back(code);
+      else eng_.check(mlgpu_transport_create(e.handle(), nInstruments, 1, &transport_));  // reserved at the first process call
     eng_.check(mlgpu_events_create(e.handle(), nInstruments, polyphony_, &ev_));
     eng_.check(mlgpu_events_set_sample_rate(ev_, (double)sampleRate));
     eng_.check(mlgpu_events_set_wanted_rows(ev_, prog_.voiceRowMask()));  // rows processVoice never reads are not made
@@ -2018,6 +2017,7 @@ class SynthProgram
   ~SynthProgram()
   {
     if (ev_) mlgpu_events_destroy(ev_);
+    if (transport_) mlgpu_transport_destroy(transport_);
     for (auto* ps : published_)
     {
       mlgpu_published_signal_destroy(ps->handle_);
@@ -2041,6 +2041,14 @@ class SynthProgram
     eng_.check(mlgpu_events_add_event(ev_, instrument, &m));
   }
   void clearInputEvents() { eng_.check(mlgpu_events_clear_events(ev_)); }
+  // AudioContext::updateTime for one instrument's context, or for all of them (one host application behind the whole bank);
+  // without effect when processVoice does not read ctx->getBeatPhase()
+  void updateTime(size_t instrument, double ppqPos, double bpm, bool isPlaying, double sampleRate)
+  {
+    if (transport_) eng_.check(mlgpu_transport_set_time_and_rate(transport_, instrument, ppqPos, bpm, isPlaying ? 1 : 0, sampleRate));
+  }
+  void updateTime(double ppqPos, double bpm, bool isPlaying, double sampleRate) { updateTime(MLGPU_TRANSPORT_ALL, ppqPos, bpm, isPlaying, sampleRate); }
+  mlgpu_transport* transport() const { return transport_; }
 
   // nVectors DSPVectors starting at frame startOffset of the current host block. mixed[c]: a signal of nInstruments
   // "voices" x nVectors vectors per output channel (the instruments' outputs).
@@ -2058,6 +2066,7 @@ class SynthProgram
       for (size_t c = 0; c < nOut_; ++c) voiceOut_.emplace_back(eng_, voices(), nVectors);
       // the controllers' smoothers go on when only the reserved length changes
       if (!controllers_.empty()) eng_.check(mlgpu_events_watch_controllers(ev_, controllers_.data(), (int)controllers_.size(), nVectors));
+      if (transport_) eng_.check(mlgpu_transport_reserve(transport_, nVectors));
       capacityT_ = nVectors;
     }
     const bool inKernel = prog_.eventRowsInKernel();
@@ -2068,7 +2077,12 @@ class SynthProgram
       rowPtrs[r] = (!inKernel && ((prog_.voiceRowMask() >> r) & 1u)) ? rows_[r].data() : nullptr;
       if (rowPtrs[r]) pi.push_back(rowPtrs[r]);
     }
-    for (size_t c = 0; c < controllers_.size(); ++c) pi.push_back(mlgpu_events_controller_signal(ev_, (int)c));  // made by the events call below
+    {
+      size_t slot = 0;  // in the order processVoice first asked for them
+      for (int code : prog_.contextInputs())
+        pi.push_back(code == Capture::kBeatPhase ? mlgpu_transport_beat_phase(transport_) : mlgpu_events_controller_signal(ev_, (int)slot++));  // controllers: made by the events call below
+    }
+    if (transport_) eng_.check(mlgpu_transport_process(transport_, nVectors));
     std::vector<float*> po;
     for (auto& s : voiceOut_) po.push_back(s.data());
     for (auto& s : tapOut_) po.push_back(s.data());

@@ -571,6 +571,57 @@ class Events:
         return np.stack([np.zeros((V, T * 64), np.float32) if b is None else b.download(np.float32, V * T * 64).reshape(V, T * 64) for b in bufs])
 
 
+class Transport:
+    """AudioContext::ProcessTime (source/app/MLAudioContext.cpp:16-104) for n contexts (mlgpu_transport): the quarter-note phasor
+    behind ctx->getBeatPhase(). index None = every context."""
+    ALL = (1 << 64) - 1
+
+    def __init__(self, engine, n, max_vectors):
+        self.engine, self.L = engine, engine.L
+        h = ctypes.c_void_p()
+        engine._check(self.L.mlgpu_transport_create(engine.h, int(n), int(max_vectors), ctypes.byref(h)))
+        self.h, self.n = h, int(n)
+        engine._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None) and self.engine.h:
+            self.L.mlgpu_transport_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update_time(self, ppq_pos, bpm, is_playing, sample_rate, index=None):
+        """AudioContext::updateTime: what the host reports for the start of the next process call."""
+        self.engine._check(self.L.mlgpu_transport_set_time_and_rate(self.h, self.ALL if index is None else int(index), float(ppq_pos), float(bpm),
+                                                                   int(bool(is_playing)), float(sample_rate)))
+
+    def clear(self, index=None):
+        self.engine._check(self.L.mlgpu_transport_clear(self.h, self.ALL if index is None else int(index)))
+
+    def process(self, n_vectors):
+        self.engine._check(self.L.mlgpu_transport_process(self.h, int(n_vectors)))
+
+    @property
+    def beat_phase(self):
+        """Device pointer of the last process call's signal: QUAD over the n contexts."""
+        return self.L.mlgpu_transport_beat_phase(self.h)
+
+    def samples_since_start(self, index=0):
+        return int(self.L.mlgpu_transport_samples_since_start(self.h, int(index)))
+
+    def process_host(self, n_vectors):
+        """Test convenience: process, then the signal as numpy [n][64 T]."""
+        T = int(n_vectors)
+        self.process(T)
+        q = np.empty(16 * T * self.n * 4, np.float32)
+        self.engine._check(self.L.mlgpu_download(self.engine.h, _np_ptr(q), self.beat_phase, q.nbytes))
+        return q.reshape(16 * T, self.n, 4).transpose(1, 0, 2).reshape(self.n, 64 * T)
+
+
 class PublishedSignal:
     """SignalProcessor::PublishedSignal (source/app/MLSignalProcessor.h:26-105): a decimated frame-major copy of a few
     channels of a few voices, for displays. write() takes device signals (DeviceBuffer) of `n_voices_total` voices."""

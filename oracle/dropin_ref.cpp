@@ -159,9 +159,12 @@ static int synth_ref_run_t(const SynthRefEvent* events, int nEvents, float glide
   ctx.setInputPolyphony(kSynthVoices);
   ctx.setInputGlideTimeInSeconds(glideSeconds);
   ctx.setInputDriftAmount(drift);
+  HostTransport host;
   for (int b = 0; b < nBlocks; ++b)
   {
     const int start = b * blockFrames;
+    host.beforeBlock(b);
+    ctx.updateTime(host.ppq, host.bpm, host.playing, 48000.);
     if (b == nBlocks / 2) synth.setEnvelope(0.02f, 0.2f, 0.3f, 0.4f);  // the host turns the envelope knobs half way through
     for (int i = 0; i < nEvents; ++i)
       if (events[i].time >= start && events[i].time < start + blockFrames)
@@ -183,6 +186,7 @@ static int synth_ref_run_t(const SynthRefEvent* events, int nEvents, float glide
       store(ctx.outputs[1], outR + start + off);
     }
     ctx.clearInputEvents();
+    host.afterBlock(blockFrames);
     if (scope)
     {
       scopeCounts[b] = synth.getPublishedSignals()["scope"]->read(scope + scopePos, scopeFramesPerRead);
@@ -201,6 +205,10 @@ extern "C" int controller_synth_ref_run(const SynthRefEvent* events, int nEvents
                                         float* outR)
 {
   return synth_ref_run_t<ControllerSynth>(events, nEvents, glideSeconds, drift, blockFrames, nBlocks, outL, outR, nullptr, nullptr, 0);
+}
+extern "C" int tempo_synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR)
+{
+  return synth_ref_run_t<TempoSynth>(events, nEvents, glideSeconds, drift, blockFrames, nBlocks, outL, outR, nullptr, nullptr, 0);
 }
 extern "C" int lean_synth_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, int blockFrames, int nBlocks, float* outL, float* outR)
 {
@@ -307,6 +315,35 @@ extern "C" int e2s_ref_run_controllers(int polyphony, int mpe, int unison, doubl
 {
   return e2sRefRun(polyphony, mpe, unison, sr, glideSeconds, drift, bendRange, mpeBendRange, modCC, events, nEvents, blockFrames, nBlocks, out, ctlNumbers, nCtl,
                    ctlOut);
+}
+
+// ---- AudioContext's transport (ProcessTime, MLAudioContext.cpp:16-104) driven as a plug-in wrapper drives it: updateTime()
+// with what the host reports before a block, processVector() per 64 frames, getBeatPhase() read by the process function ----
+struct TransportStep
+{
+  int kind;  // 0: updateTime(ppq, bpm, playing, sr)   1: `vectors` x processVector   2: clear()
+  int vectors, playing, pad;
+  double ppq, bpm, sr;
+};
+extern "C" int transport_ref_run(const TransportStep* steps, int nSteps, float* out, uint64_t* samplesSinceStart)
+{
+  AudioContext ctx(0, 1, 48000);
+  size_t pos = 0;
+  for (int i = 0; i < nSteps; ++i)
+  {
+    const TransportStep& st = steps[i];
+    if (st.kind == 0) ctx.updateTime(st.ppq, st.bpm, st.playing != 0, st.sr);
+    else if (st.kind == 2) ctx.clear();
+    else
+      for (int v = 0; v < st.vectors; ++v)
+      {
+        ctx.processVector(v * kFloatsPerDSPVector);
+        store(ctx.getBeatPhase(), out + pos);
+        pos += kFloatsPerDSPVector;
+      }
+    samplesSinceStart[i] = ctx.getTimeInfo().samplesSinceStart;
+  }
+  return 0;
 }
 
 // ---- SignalProcessor::PublishedSignal driven as processors drive it: storePublishedSignal per voice in rotation ----

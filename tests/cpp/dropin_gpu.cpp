@@ -291,9 +291,12 @@ static int synth_gpu_run_t(size_t nInstruments, const SynthGpuEvent* events, con
     eng.check(mlgpu_events_set_pitch_glide_seconds(prog.events(), glideSeconds));
     eng.check(mlgpu_events_set_drift_amount(prog.events(), drift));
     const size_t S = (size_t)nBlocks * blockFrames;
+    HostTransport host;
     for (int b = 0; b < nBlocks; ++b)
     {
       const int start = b * blockFrames;
+      host.beforeBlock(b);
+      prog.updateTime(host.ppq, host.bpm, host.playing, 48000.);  // one host application behind every instrument
       if (b == nBlocks / 2)
       {
         synth.setEnvelope(0.02f, 0.2f, 0.3f, 0.4f);
@@ -328,6 +331,7 @@ static int synth_gpu_run_t(size_t nInstruments, const SynthGpuEvent* events, con
         done += n;
       }
       prog.clearInputEvents();
+      host.afterBlock(blockFrames);
       if (scope)
       {
         scopeCounts[b] = synth.getPublishedSignals()["scope"]->read(scope + scopePos, scopeFramesPerRead);
@@ -362,6 +366,14 @@ extern "C" int controller_synth_gpu_run(size_t nInstruments, const SynthGpuEvent
 {
   return synth_gpu_run_t<ControllerSynth>(nInstruments, events, eventInstrument, nEvents, glideSeconds, drift, blockFrames, nBlocks, vectorsPerLaunch, outL, outR,
                                           0, nullptr, nullptr, 0, err, errLen, eventRowsInKernel != 0, rowsInKernel);
+}
+// the synth with the tempo-synced tremolo (ctx->getBeatPhase() into a TempoLock per voice)
+extern "C" int tempo_synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
+                                   int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, int eventRowsInKernel, int* rowsInKernel,
+                                   char* err, size_t errLen)
+{
+  return synth_gpu_run_t<TempoSynth>(nInstruments, events, eventInstrument, nEvents, glideSeconds, drift, blockFrames, nBlocks, vectorsPerLaunch, outL, outR, 0,
+                                     nullptr, nullptr, 0, err, errLen, eventRowsInKernel != 0, rowsInKernel);
 }
 // the pitch-and-gate-only synth; eventRowsInKernel: the voice kernel computes the two rows itself; *rowsInKernel: whether it did
 extern "C" int lean_synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,

@@ -136,3 +136,65 @@ class ControllerSynth : public Synth
     outputs[1] += y * wheel;
   }
 };
+
+// What the host application reports before each block (AudioContext::updateTime) in the Synth runs of both sides: stopped at
+// first, started at block 1, a tempo change, a stop, a restart somewhere else.
+struct HostTransport
+{
+  double ppq{0.75}, bpm{126.};
+  bool playing{false};
+  void beforeBlock(int b)
+  {
+    if (b == 1) playing = true;
+    if (b == 4) bpm = 97.5;
+    if (b == 6) playing = false;
+    if (b == 7)
+    {
+      playing = true;
+      ppq = 3.5;
+    }
+  }
+  void afterBlock(int blockFrames)
+  {
+    if (playing) ppq += blockFrames * bpm / 60. / 48000.;
+  }
+};
+
+// USER CODE #3d: a Synth with a tempo-synced tremolo: every voice locks an LFO phasor at twice the host's quarter-note phase
+// (ctx->getBeatPhase() into a TempoLock, MLAudioContext.h:82, MLDSPFilters.h:1478). On the GPU side the beat phase is one device
+// signal per instrument (mlgpu_transport) read by that instrument's voices.
+class TempoSynth : public Synth
+{
+  struct VoiceDSP
+  {
+    SawGen saw;
+    ADSR env;
+    TempoLock lock;
+  };
+  std::array<VoiceDSP, kSynthVoices> dsp_;
+
+ public:
+  TempoSynth() : Synth(kSynthVoices)
+  {
+    for (auto& d : dsp_)
+    {
+      d.env.coeffs = ADSR::calcCoeffs(0.004f, 0.08f, 0.5f, 0.15f, 48000.f);
+      d.saw.clear();
+    }
+  }
+  void setEnvelope(float a, float d, float s, float r)
+  {
+    for (auto& v : dsp_) v.env.coeffs = ADSR::calcCoeffs(a, d, s, r, 48000.f);
+  }
+  void processVoice(int v, const EventsToSignals::Voice& voice, const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs,
+                    AudioContext* ctx) override
+  {
+    VoiceDSP& d = dsp_[v];
+    const DSPVector beat = ctx->getBeatPhase();
+    const DSPVector lfo = d.lock(beat, 2.f, 1.f / 48000.f);
+    const DSPVector freq = exp2Approx(voice.outputs.constRow(kPitch)) * (261.6256f / 48000.f);
+    const DSPVector y = d.saw(freq) * d.env(voice.outputs.constRow(kGate)) * (DSPVector(1.f) - lfo * 0.5f);
+    outputs[0] += y;
+    outputs[1] += y * beat;
+  }
+};

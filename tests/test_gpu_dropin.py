@@ -344,18 +344,23 @@ def test_every_stateful_object_by_name_same_source_same_bits(launches):
 
 
 @pytest.mark.gpu
-def test_synth_that_reads_controllers_through_the_context_same_bits():
-    """tests/cpp/dropin_synth.h: ControllerSynth::processVoice calls ctx->getInputController(74 / 1 / 128) - the instrument's smoothed
+@pytest.mark.parametrize("which", ["controller", "tempo"])
+def test_synth_that_reads_context_signals_same_bits(which):
+    """tests/cpp/dropin_synth.h. TempoSynth::processVoice locks a tremolo LFO to ctx->getBeatPhase() with a TempoLock per voice,
+    while the host (HostTransport, both sides) starts, changes tempo, stops and restarts elsewhere: the beat phase is one device
+    signal per instrument (mlgpu_transport) behind SynthProgram::updateTime.
+    ControllerSynth::processVoice calls ctx->getInputController(74 / 1 / 128) - the instrument's smoothed
     MIDI controllers (brightness into a per-sample filter cutoff, mod wheel into the pitch, channel pressure into the level). The
     shim turns each into one device signal per instrument (mlgpu_events_watch_controllers) read by that instrument's voices
     (mlgpu_graph_set_input_group). Against the reference's own Synth / AudioContext / EventsToSignals, bit for bit, with the
     voice rows read from memory and computed in the kernel."""
     from test_gpu_events import performance
     Lg, Lr = _gpu_lib(), _ref_lib()
-    Lr.controller_synth_ref_run.restype = ctypes.c_int
-    Lr.controller_synth_ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p]
-    Lg.controller_synth_gpu_run.restype = ctypes.c_int
-    Lg.controller_synth_gpu_run.argtypes = [ctypes.c_size_t, ctypes.POINTER(_Ev), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float, ctypes.c_float,
+    ref_run, gpu_run = getattr(Lr, which + "_synth_ref_run"), getattr(Lg, which + "_synth_gpu_run")
+    ref_run.restype = ctypes.c_int
+    ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p]
+    gpu_run.restype = ctypes.c_int
+    gpu_run.argtypes = [ctypes.c_size_t, ctypes.POINTER(_Ev), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                             ctypes.c_char_p, ctypes.c_size_t]
     N, block, n_blocks = 20, 512, 10
@@ -365,7 +370,7 @@ def test_synth_that_reads_controllers_through_the_context_same_bits():
     wantL, wantR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
     for k, evs in enumerate(per_inst):
         arr = (_Ev * max(1, len(evs)))(*[_Ev(*e) for e in evs])
-        assert Lr.controller_synth_ref_run(arr, len(evs), glide, drift, block, n_blocks, wantL[k].ctypes.data_as(c_f32p), wantR[k].ctypes.data_as(c_f32p)) == 0
+        assert ref_run(arr, len(evs), glide, drift, block, n_blocks, wantL[k].ctypes.data_as(c_f32p), wantR[k].ctypes.data_as(c_f32p)) == 0
     flat = [(e, k) for k, evs in enumerate(per_inst) for e in evs]
     arr = (_Ev * len(flat))(*[_Ev(*e) for e, _ in flat])
     inst = (ctypes.c_int * len(flat))(*[k for _, k in flat])
@@ -373,10 +378,10 @@ def test_synth_that_reads_controllers_through_the_context_same_bits():
         gotL, gotR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
         err = ctypes.create_string_buffer(4096)
         did = ctypes.c_int(-1)
-        st = Lg.controller_synth_gpu_run(N, arr, inst, len(flat), glide, drift, block, n_blocks, 3, gotL.ctypes.data_as(c_f32p), gotR.ctypes.data_as(c_f32p),
+        st = gpu_run(N, arr, inst, len(flat), glide, drift, block, n_blocks, 3, gotL.ctypes.data_as(c_f32p), gotR.ctypes.data_as(c_f32p),
                                          in_kernel, ctypes.byref(did), err, 4096)
         assert st == 0, err.value.decode()
         assert did.value == in_kernel
-        assert_bits_equal(gotL, wantL, True, f"controller synth left (rows in kernel: {in_kernel})")
-        assert_bits_equal(gotR, wantR, True, f"controller synth right (rows in kernel: {in_kernel})")
+        assert_bits_equal(gotL, wantL, True, f"{which} synth left (rows in kernel: {in_kernel})")
+        assert_bits_equal(gotR, wantR, True, f"{which} synth right (rows in kernel: {in_kernel})")
     assert np.abs(wantL).max() > 0.05 and np.abs(wantR).max() > 0.01
