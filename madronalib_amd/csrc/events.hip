@@ -471,15 +471,24 @@ __global__ __launch_bounds__(256) void ctl_kernel(const CtlArgs a)
       for (int q = 0; q < 16; ++q) o[(size_t)q * a.nInstruments] = v;
     }
     else
+    {
+      // mCurrVec[n] of the previous vector feeds sample n only: all 64 loads go out together (there are few controller lanes -
+      // one wavefront per SIMD - so nothing else would hide 16 round trips in a row)
+      float cur[64];
+      if (gl.readsCurrVec())
+      {
+#pragma unroll
+        for (int n = 0; n < 64; ++n) cur[n] = u2f(gs[(size_t)(5 + n) * ln]);
+      }
+#pragma unroll
       for (int q = 0; q < 16; ++q)
       {
-        float cur[4] = {0.f, 0.f, 0.f, 0.f};
-        gl.preload(gs, ln, q, cur);
         f32x4 v;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = gl.nextWith(gs, ln, q * 4 + k, cur[k]);
+        for (int k = 0; k < 4; ++k) v[k] = gl.nextWith(gs, ln, q * 4 + k, cur[q * 4 + k]);
         o[(size_t)q * a.nInstruments] = v;
       }
+    }
     gl.endVector();
   }
   gl.store(gs, ln);
