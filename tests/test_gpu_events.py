@@ -234,12 +234,15 @@ def test_events_with_hostile_values(eng, name):
                     e[5] = odd[int(rng.integers(0, len(odd)))]
             evs.append(tuple(e))
         instruments.append(evs)
-    got = gpu_run(eng, cfg, instruments, block, n_blocks, vectors_per_launch=4)
+    watch = [16, 73, 74, 1, 128]
+    got, ctl = gpu_run(eng, cfg, instruments, block, n_blocks, vectors_per_launch=4, watch=watch)
     P = cfg["polyphony"]
     for k, evs in enumerate(instruments):
-        want = ref_run(cfg, evs, block, n_blocks)
+        want, want_ctl = ref_run_controllers(cfg, evs, block, n_blocks, watch)
         for r in range(8):
             assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"hostile {name}: instrument {k} row {ROW_NAMES[r]}")
+        for c, num in enumerate(watch):     # the smoothed controllers glide towards (and from) infinities and NaNs too
+            assert_bits_equal(ctl[c, k], want_ctl[c], True, f"hostile {name}: instrument {k} controller {num}")
 
 
 def _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch, switch_at=None):
@@ -548,3 +551,20 @@ def test_controller_signal_as_a_group_input_of_the_voice_graph(eng):
         g.close()
         ev.close()
     assert np.abs(want).max() > 0
+
+
+@pytest.mark.gpu
+def test_controller_signals_bank_size(eng):
+    """4096 instruments x 4 controllers = 16 384 controller lanes (many wavefronts, records of many lanes in one upload): eight
+    performances dealt round-robin, every instrument equal to the reference's run of its performance."""
+    cfg = SCENARIOS["midi_poly4"]
+    block, n_blocks, N = 512, 6, 4096
+    base = [performance("midi", 40 + k, block * n_blocks, 4) for k in range(7)] + [[]]
+    watch = [1, 16, 74, 128]
+    _, ctl = gpu_run(eng, cfg, [base[i % 8] for i in range(N)], block, n_blocks, vectors_per_launch=8, watch=watch)
+    for k in range(8):
+        _, want = ref_run_controllers(cfg, base[k], block, n_blocks, watch)
+        for c in range(len(watch)):
+            mine = ctl[c, k::8]
+            assert_bits_equal(mine[0], want[c], True, f"performance {k}, controller {watch[c]}")
+            assert (mine.view(np.uint32) == mine[0].view(np.uint32)[None, :]).all(), f"instruments of performance {k} differ"
