@@ -250,6 +250,43 @@ extern "C" int spb_ref_run(int maxFrames, const int* blocks, int nBlocks, const 
   return 0;
 }
 
+// ---- a plug-in: PluginSynth behind the reference's SignalProcessBuffer, AudioContext and EventsToSignals, host blocks of
+// arbitrary sizes; events[i].time is absolute, handed over relative to the block it falls into ----
+extern "C" int plugin_ref_run(const SynthRefEvent* events, int nEvents, float glideSeconds, float drift, const int* blocks, int nBlocks, int maxFrames,
+                              float* outL, float* outR)
+{
+  PluginSynth synth;
+  AudioContext ctx(0, 2, 48000);
+  ctx.setInputPolyphony(kSynthVoices);
+  ctx.setInputGlideTimeInSeconds(glideSeconds);
+  ctx.setInputDriftAmount(drift);
+  SignalProcessBuffer spb(0, 2, maxFrames);
+  HostTransport host;
+  int pos = 0;
+  for (int b = 0; b < nBlocks; ++b)
+  {
+    host.beforeBlock(b);
+    ctx.updateTime(host.ppq, host.bpm, host.playing, 48000.);
+    for (int i = 0; i < nEvents; ++i)
+      if (events[i].time >= pos && events[i].time < pos + blocks[b])
+      {
+        Event ev;
+        ev.type = events[i].type;
+        ev.channel = events[i].channel;
+        ev.sourceIdx = events[i].sourceIdx;
+        ev.time = events[i].time - pos;
+        ev.value1 = events[i].value1;
+        ev.value2 = events[i].value2;
+        ctx.addInputEvent(ev);
+      }
+    float* outs[2] = {outL + pos, outR + pos};
+    spb.process(nullptr, outs, blocks[b], &ctx, [](AudioContext* c, void* s) { static_cast<PluginSynth*>(s)->processVector(c->inputs, c->outputs, c); }, &synth);
+    host.afterBlock(blocks[b]);
+    pos += blocks[b];
+  }
+  return 0;
+}
+
 // ---- the reference's EventsToSignals driven like AudioContext / SignalProcessBuffer drive it -------------------------
 // events: absolute onset times in frames; the harness cuts time into host blocks of blockFrames (a multiple of 64), adds the
 // events of a block with block-relative times, calls processVector(offset) per 64 frames and clearEvents() per block.

@@ -367,6 +367,100 @@ extern "C" int controller_synth_gpu_run(size_t nInstruments, const SynthGpuEvent
   return synth_gpu_run_t<ControllerSynth>(nInstruments, events, eventInstrument, nEvents, glideSeconds, drift, blockFrames, nBlocks, vectorsPerLaunch, outL, outR,
                                           0, nullptr, nullptr, 0, err, errLen, eventRowsInKernel != 0, rowsInKernel);
 }
+// ---- a bank of plug-ins: nInstruments PluginSynths behind ONE mlgpu_process_buffer (the host's block sizes), their events and
+// time reports per block, the instruments' outputs summed in instrument order into the host's stereo pair ----
+namespace
+{
+struct PluginBank
+{
+  gpu::Engine* eng;
+  gpu::SynthProgram* prog;
+  gpu::DeviceSignal *mixL, *mixR;
+  size_t nInstruments;
+  std::string error;
+};
+int pluginBankVectors(void* user, size_t nVectors, const float* const*, float* const* d_out)
+{
+  PluginBank* pb = static_cast<PluginBank*>(user);
+  try
+  {
+    // event times are relative to the host block, the first DSPVector computed in this call starts at 0 (MLSignalProcessBuffer.cpp:55-66)
+    pb->prog->process(nVectors, 0, {pb->mixL, pb->mixR});
+    pb->eng->check(mlgpu_mixdown_groups(pb->eng->handle(), pb->mixL->data(), pb->mixL->layout(), 1, pb->nInstruments, nVectors, d_out[0], MLGPU_LAYOUT_QUAD));
+    pb->eng->check(mlgpu_mixdown_groups(pb->eng->handle(), pb->mixR->data(), pb->mixR->layout(), 1, pb->nInstruments, nVectors, d_out[1], MLGPU_LAYOUT_QUAD));
+    return MLGPU_OK;
+  }
+  catch (const std::exception& e)
+  {
+    pb->error = e.what();
+    return MLGPU_ERR_INVALID;
+  }
+}
+}  // namespace
+extern "C" int plugin_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
+                              const int* blocks, int nBlocks, int maxFrames, int eventRowsInKernel, float* outL, float* outR, char* err, size_t errLen)
+{
+  mlgpu_process_buffer* spb = nullptr;
+  try
+  {
+    gpu::Engine eng(0);
+    PluginSynth synth;
+    gpu::VoiceProgramOptions opt;
+    opt.eventRowsInKernel = eventRowsInKernel != 0;
+    gpu::SynthProgram prog(eng, synth, nInstruments, 2, 48000, opt);
+    eng.check(mlgpu_events_set_pitch_glide_seconds(prog.events(), glideSeconds));
+    eng.check(mlgpu_events_set_drift_amount(prog.events(), drift));
+    const size_t maxVectors = (size_t)maxFrames / 64 + 2;
+    gpu::DeviceSignal mixL(eng, nInstruments, maxVectors), mixR(eng, nInstruments, maxVectors);
+    PluginBank bank{&eng, &prog, &mixL, &mixR, nInstruments, {}};
+    eng.check(mlgpu_process_buffer_create(eng.handle(), 0, 2, (size_t)maxFrames, &spb));
+    HostTransport host;
+    int pos = 0, st = MLGPU_OK;
+    for (int b = 0; b < nBlocks && st == MLGPU_OK; ++b)
+    {
+      host.beforeBlock(b);
+      prog.updateTime(host.ppq, host.bpm, host.playing, 48000.);
+      for (int i = 0; i < nEvents; ++i)
+        if (events[i].time >= pos && events[i].time < pos + blocks[b])
+        {
+          Event ev;
+          ev.type = events[i].type;
+          ev.channel = events[i].channel;
+          ev.sourceIdx = events[i].sourceIdx;
+          ev.time = events[i].time - pos;
+          ev.value1 = events[i].value1;
+          ev.value2 = events[i].value2;
+          prog.addInputEvent((size_t)eventInstrument[i], ev);
+        }
+      float* outs[2] = {outL + pos, outR + pos};
+      st = mlgpu_process_buffer_process(spb, nullptr, outs, blocks[b], pluginBankVectors, &bank);
+      prog.clearInputEvents();  // SignalProcessBuffer::process ends with context->clearInputEvents() (:89)
+      host.afterBlock(blocks[b]);
+      pos += blocks[b];
+    }
+    mlgpu_process_buffer_destroy(spb);
+    spb = nullptr;
+    if (st != MLGPU_OK)
+    {
+      if (err && errLen) snprintf(err, errLen, "%s / %s", bank.error.c_str(), mlgpu_last_error(eng.handle()));
+      return st;
+    }
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (spb) mlgpu_process_buffer_destroy(spb);
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (spb) mlgpu_process_buffer_destroy(spb);
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
 // the synth with the tempo-synced tremolo (ctx->getBeatPhase() into a TempoLock per voice)
 extern "C" int tempo_synth_gpu_run(size_t nInstruments, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, float glideSeconds, float drift,
                                    int blockFrames, int nBlocks, int vectorsPerLaunch, float* outL, float* outR, int eventRowsInKernel, int* rowsInKernel,

@@ -198,3 +198,41 @@ class TempoSynth : public Synth
     outputs[1] += y * beat;
   }
 };
+
+// USER CODE #3e: what a plug-in wrapper runs - a Synth behind SignalProcessBuffer::process with whatever block sizes the host
+// asks for (MLSignalProcessBuffer.cpp:36-90): note and controller events with block-relative times, the host's time report
+// before every block, ctx->processVector(offset) per 64 frames, clearInputEvents() per block. The voice reads all three kinds of
+// context: its voice rows, a controller, the beat phase.
+class PluginSynth : public Synth
+{
+  struct VoiceDSP
+  {
+    SawGen saw;
+    Lopass lp;
+    ADSR env;
+    TempoLock lock;
+  };
+  std::array<VoiceDSP, kSynthVoices> dsp_;
+
+ public:
+  PluginSynth() : Synth(kSynthVoices)
+  {
+    for (auto& d : dsp_)
+    {
+      d.env.coeffs = ADSR::calcCoeffs(0.004f, 0.08f, 0.5f, 0.15f, 48000.f);
+      d.lp.coeffs = Lopass::makeCoeffs(0.1f, 0.9f);
+      d.saw.clear();
+    }
+  }
+  void processVoice(int v, const EventsToSignals::Voice& voice, const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs,
+                    AudioContext* ctx) override
+  {
+    VoiceDSP& d = dsp_[v];
+    const DSPVector lfo = d.lock(ctx->getBeatPhase(), 4.f, 1.f / 48000.f);
+    const DSPVector level = ctx->getInputController(74) * 0.75f + 0.25f;
+    const DSPVector freq = exp2Approx(voice.outputs.constRow(kPitch)) * (261.6256f / 48000.f);
+    const DSPVector y = d.lp(d.saw(freq)) * d.env(voice.outputs.constRow(kGate)) * level;
+    outputs[0] += y * (DSPVector(1.f) - lfo * 0.5f);
+    outputs[1] += y * lfo;
+  }
+};

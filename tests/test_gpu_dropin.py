@@ -385,3 +385,43 @@ def test_synth_that_reads_context_signals_same_bits(which):
         assert_bits_equal(gotL, wantL, True, f"{which} synth left (rows in kernel: {in_kernel})")
         assert_bits_equal(gotR, wantR, True, f"{which} synth right (rows in kernel: {in_kernel})")
     assert np.abs(wantL).max() > 0.05 and np.abs(wantR).max() > 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_kernel", [0, 1])
+def test_plugin_flow_arbitrary_host_blocks_same_bits(in_kernel):
+    """The whole boundary at once, as a plug-in wrapper drives it: host blocks of arbitrary sizes (1 ... 512 frames) through
+    SignalProcessBuffer, note and controller events with block-relative times, the host's time report before every block,
+    clearInputEvents() after it - tests/cpp/dropin_synth.h: PluginSynth reads voice rows, a controller and the beat phase.
+    Reference: one SignalProcessBuffer + AudioContext + PluginSynth per instrument (oracle/dropin_ref.cpp: plugin_ref_run), summed
+    in instrument order. GPU: every instrument behind one mlgpu_process_buffer and one SynthProgram. Bit for bit - including what
+    the reference does with events of a block in which no DSPVector falls due (they are cleared unprocessed)."""
+    from test_gpu_events import performance
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    c_ip = ctypes.POINTER(ctypes.c_int)
+    Lr.plugin_ref_run.restype = ctypes.c_int
+    Lr.plugin_ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_float, ctypes.c_float, c_ip, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p]
+    Lg.plugin_gpu_run.restype = ctypes.c_int
+    Lg.plugin_gpu_run.argtypes = [ctypes.c_size_t, ctypes.POINTER(_Ev), c_ip, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_ip, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    rng = np.random.default_rng(5)
+    sizes = [64, 100, 37, 512, 1, 200, 64, 333, 17, 480, 31, 33, 128, 7, 250] + [int(x) for x in rng.integers(1, 513, 25)]
+    S, N, glide, drift = int(np.sum(sizes)), 6, 0.01, 0.3
+    blocks = (ctypes.c_int * len(sizes))(*sizes)
+    per_inst = [performance("midi", 1200 + k, S, 6) for k in range(N)]
+    want = np.zeros((2, S), np.float32)
+    for k, evs in enumerate(per_inst):
+        l, r = np.zeros(S, np.float32), np.zeros(S, np.float32)
+        arr = (_Ev * max(1, len(evs)))(*[_Ev(*e) for e in evs])
+        assert Lr.plugin_ref_run(arr, len(evs), glide, drift, blocks, len(sizes), 512, l.ctypes.data_as(c_f32p), r.ctypes.data_as(c_f32p)) == 0
+        want[0], want[1] = want[0] + l, want[1] + r          # ((0 + i0) + i1) + ...: mlgpu_mixdown_groups' order
+    flat = [(e, k) for k, evs in enumerate(per_inst) for e in evs]
+    arr = (_Ev * len(flat))(*[_Ev(*e) for e, _ in flat])
+    inst = (ctypes.c_int * len(flat))(*[k for _, k in flat])
+    gotL, gotR = np.zeros(S, np.float32), np.zeros(S, np.float32)
+    err = ctypes.create_string_buffer(4096)
+    st = Lg.plugin_gpu_run(N, arr, inst, len(flat), glide, drift, blocks, len(sizes), 512, in_kernel, gotL.ctypes.data_as(c_f32p), gotR.ctypes.data_as(c_f32p), err, 4096)
+    assert st == 0, err.value.decode()
+    assert_bits_equal(gotL, want[0], True, "plug-in bank left")
+    assert_bits_equal(gotR, want[1], True, "plug-in bank right")
+    assert np.abs(want[0]).max() > 0.05 and np.abs(want[1]).max() > 0.001
