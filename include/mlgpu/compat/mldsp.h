@@ -702,7 +702,32 @@ inline DSPVectorArray<ROWS> routeMux(int route, DSPVector selector, DSPVectorArr
   }
   return y;
 }
+template <size_t ROWS, typename... Args>
+inline void routeDemux(int route, DSPVector selector, DSPVectorArray<ROWS> input, DSPVectorArray<ROWS>* firstOutput, Args... args)
+{
+  DSPVectorArray<ROWS>* outputs[]{firstOutput, args...};
+  constexpr int n = sizeof...(Args) + 1;
+  static_assert(n <= MLGPU_ROUTE_MAX_SIGNALS, "demultiplex: at most 8 outputs");
+  Capture& c = Capture::get();
+  for (int k = 0; k < n; ++k)
+    for (size_t j = 0; j < ROWS; ++j)
+    {
+      const int ids[2] = {selector.sig_[0].id(), input.sig_[j].id()};
+      outputs[k]->sig_[j] = computedSig(c.ret(mlgpu_graph_add_route(c.g, route, ids, 2, k, n, nullptr)));
+    }
+}
 }  // namespace gpu
+// MLDSPRouting.h:141-236: the input goes to the output the selector names (the others get 0) / is split between two neighbours
+template <size_t ROWS, typename... Args>
+inline void demultiplex(DSPVector selector, DSPVectorArray<ROWS> input, DSPVectorArray<ROWS>* firstOutput, Args... args)
+{
+  gpu::routeDemux(MLGPU_ROUTE_DEMULTIPLEX, selector, input, firstOutput, args...);
+}
+template <size_t ROWS, typename... Args>
+inline void demultiplexLinear(DSPVector selector, DSPVectorArray<ROWS> input, DSPVectorArray<ROWS>* firstOutput, Args... args)
+{
+  gpu::routeDemux(MLGPU_ROUTE_DEMULTIPLEX_LINEAR, selector, input, firstOutput, args...);
+}
 template <size_t ROWS, typename... Args>
 inline DSPVectorArray<ROWS> multiplex(DSPVector selector, DSPVectorArray<ROWS> first, Args... args)
 {

@@ -115,6 +115,27 @@ extern "C" int ops_ref_run(size_t V, size_t T, const float* in0, const float* in
   return 0;
 }
 
+// ---- routing functions and function wrappers by name (tests/cpp/dropin_routing.h) ----
+#include "../tests/cpp/dropin_routing.h"
+extern "C" int routing_ref_run(size_t V, size_t T, const float* in0, const float* in1, const float* in2, float* outs /* [kRoutingOutputs][V][64 T] */)
+{
+  const size_t S = T * kFloatsPerDSPVector;
+  const float* ins[3] = {in0, in1, in2};
+  for (size_t v = 0; v < V; ++v)
+  {
+    RoutingState state;
+    routingSetup(state);
+    AudioContext ctx(3, kRoutingOutputs, 48000);
+    for (size_t t = 0; t < T; ++t)
+    {
+      for (int i = 0; i < 3; ++i) load(ctx.inputs[i], ins[i] + v * S + t * kFloatsPerDSPVector);
+      routingProcess(&ctx, &state);
+      for (int o = 0; o < kRoutingOutputs; ++o) store(ctx.outputs[o], outs + ((size_t)o * V + v) * S + t * kFloatsPerDSPVector);
+    }
+  }
+  return 0;
+}
+
 // ---- the stateful objects the other drop-ins do not touch, by name (tests/cpp/dropin_objects.h) ----
 #include "../tests/cpp/dropin_objects.h"
 extern "C" int objects_ref_run(size_t V, size_t T, const float* in0, const float* in1, float* outs /* [kObjectsOutputs][V][64 T] */)

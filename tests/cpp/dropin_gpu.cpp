@@ -213,6 +213,55 @@ extern "C" int ops_gpu_run(size_t V, size_t T, const float* in0, const float* in
   }
 }
 
+#include "dropin_routing.h"
+extern "C" int routing_gpu_run(size_t V, size_t T, int launches, const float* in0, const float* in1, const float* in2, float* outs, char* err, size_t errLen)
+{
+  try
+  {
+    gpu::Engine eng(0);
+    RoutingState state;
+    routingSetup(state);
+    AudioContext ctx(3, kRoutingOutputs, 48000);
+    gpu::VoiceProgram prog(eng, V, &ctx, routingProcess, &state);
+    const size_t Tl = T / (size_t)launches, S = T * 64, Sl = Tl * 64;
+    gpu::DeviceSignal vm(eng, V, Tl, MLGPU_LAYOUT_VOICE_MAJOR);
+    std::vector<gpu::DeviceSignal> q, o;
+    for (int i = 0; i < 3; ++i) q.emplace_back(eng, V, Tl);
+    for (int i = 0; i < kRoutingOutputs; ++i) o.emplace_back(eng, V, Tl);
+    std::vector<gpu::DeviceSignal*> po;
+    for (auto& y : o) po.push_back(&y);
+    const float* src[3] = {in0, in1, in2};
+    std::vector<float> h(V * Sl);
+    for (int l = 0; l < launches; ++l)
+    {
+      for (int which = 0; which < 3; ++which)
+      {
+        for (size_t v = 0; v < V; ++v) memcpy(h.data() + v * Sl, src[which] + v * S + (size_t)l * Sl, sizeof(float) * Sl);
+        eng.check(mlgpu_upload(eng.handle(), vm.data(), h.data(), vm.bytes()));
+        eng.check(mlgpu_layout_convert(eng.handle(), vm.data(), MLGPU_LAYOUT_VOICE_MAJOR, q[(size_t)which].data(), MLGPU_LAYOUT_QUAD, V, Tl));
+      }
+      prog.process({&q[0], &q[1], &q[2]}, po);
+      for (int i = 0; i < kRoutingOutputs; ++i)
+      {
+        eng.check(mlgpu_layout_convert(eng.handle(), o[(size_t)i].data(), MLGPU_LAYOUT_QUAD, vm.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, Tl));
+        eng.check(mlgpu_download(eng.handle(), h.data(), vm.data(), vm.bytes()));
+        for (size_t v = 0; v < V; ++v) memcpy(outs + ((size_t)i * V + v) * S + (size_t)l * Sl, h.data() + v * Sl, sizeof(float) * Sl);
+      }
+    }
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
 #include "dropin_objects.h"
 extern "C" int objects_gpu_run(size_t V, size_t T, int launches, const float* in0, const float* in1, float* outs /* [kObjectsOutputs][V][64 T] */, char* err,
                                size_t errLen)

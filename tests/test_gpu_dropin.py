@@ -425,3 +425,39 @@ def test_plugin_flow_arbitrary_host_blocks_same_bits(in_kernel):
     assert_bits_equal(gotL, want[0], True, "plug-in bank left")
     assert_bits_equal(gotR, want[1], True, "plug-in bank right")
     assert np.abs(want[0]).max() > 0.05 and np.abs(want[1]).max() > 0.001
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launches", [1, 4])
+def test_routing_and_function_wrappers_by_name_same_source_same_bits(launches):
+    """tests/cpp/dropin_routing.h: mix, multiplex, multiplexLinear, demultiplex, demultiplexLinear (selectors inside and beyond
+    [0, 1), exactly on the boundaries), Bank<SineGen, 3> / Bank<Lopass, 2> with row arguments, operator[] and clear(), map() over rows
+    with and without the row index, the routing functions on two-row arrays - compiled unchanged against the reference and against
+    the shim. (FeedbackDelayFunction cannot run in the reference: see the header.)"""
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    K = 8
+    V, T = 72, 16
+    S = 64 * T
+    rng = np.random.default_rng(41)
+    a = rng.uniform(-1.0, 1.0, (V, S)).astype(np.float32)
+    b = rng.uniform(-1.0, 1.0, (V, S)).astype(np.float32)
+    sel = np.mod(rng.uniform(0, 1, (V, 1)) + np.arange(S)[None, :] / 300.0, 1.0).astype(np.float32)
+    sel[::7] = (sel[::7] * 3.0).astype(np.float32)       # beyond [0, 1): the fractional part counts (a negative selector indexes
+    #                                                      out of bounds in the reference: undefined there, index 0 here, mlgpu.h)
+    sel[:, ::50] = np.float32(1.0 / 3.0)                                  # exactly on a boundary
+    sel[:, 25::50] = np.float32(0.0)
+    want = np.zeros((K, V, S), np.float32)
+    got = np.zeros((K, V, S), np.float32)
+    Lr.routing_ref_run.restype = ctypes.c_int
+    Lr.routing_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p]
+    Lg.routing_gpu_run.restype = ctypes.c_int
+    Lg.routing_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    p = lambda x: x.ctypes.data_as(c_f32p)  # noqa: E731
+    assert Lr.routing_ref_run(V, T, p(a), p(b), p(sel), p(want)) == 0
+    err = ctypes.create_string_buffer(4096)
+    assert Lg.routing_gpu_run(V, T, launches, p(a), p(b), p(sel), p(got), err, 4096) == 0, err.value.decode()
+    names = ["mix", "multiplex", "multiplexLinear", "demultiplex", "demultiplexLinear", "Bank<SineGen,3> + Bank<Lopass,2>", "map (two forms)",
+             "multiplex / mix on two-row arrays"]
+    for k in range(K):
+        assert np.abs(want[k]).max() > 1e-3, names[k]
+        assert_bits_equal(got[k], want[k], True, f"routing drop-in output {k} ({names[k]})")
