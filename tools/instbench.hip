@@ -69,6 +69,28 @@ __device__ inline float sum1(f2 x) { return x.x + x.y; }
 #define I_MIX11(r) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_and_b64 s[20:21], s[20:21], s[28:29]" : "+v"(r) : "v"(c), "v"(b) : "s20", "s21", "scc");
 #define I_MIX13(r) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_and_b64 s[20:21], s[20:21], s[28:29]\n s_xor_b64 s[22:23], s[22:23], s[28:29]\n s_or_b64 s[24:25], s[24:25], s[28:29]" : "+v"(r) : "v"(c), "v"(b) : "s20", "s21", "s22", "s23", "s24", "s25", "scc");
 #define I_BRANCH(r) asm volatile("v_fma_f32 %0, %0, %1, %2\n s_cmp_eq_u64 exec, 0\n s_cbranch_scc1 8" : "+v"(r) : "v"(c), "v"(b) : "scc");
+// double precision (the modulated Lopass' libm sinf runs in double): 64-bit register pairs
+#define DINIT(i) ((double)(fa + threadIdx.x + i))
+__device__ inline float sum1(double x) { return (float)x; }
+#define I_DFMA(r) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r) : "v"(dc), "v"(db));
+#define I_DMUL(r) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(r) : "v"(dc));
+#define I_DADD(r) asm volatile("v_add_f64 %0, %0, %1" : "+v"(r) : "v"(db));
+#define I_DCVT(r) asm volatile("v_cvt_f32_f64 %1, %0\n v_cvt_f64_f32 %0, %1" : "+v"(r), "+v"(tmp));
+#define DEFKD(NAME, INS)                                                                 \
+  __global__ __launch_bounds__(256) void NAME(float* out, int iters, float fa, float fb) \
+  {                                                                                     \
+    double a0 = DINIT(0), a1 = DINIT(1), a2 = DINIT(2), a3 = DINIT(3);                  \
+    double db = fb, dc = fa;                                                            \
+    float tmp = fa;                                                                     \
+    (void)db; (void)dc; (void)tmp;                                                      \
+    for (int it = 0; it < iters; ++it) { REP16(BODY4(INS)) }                            \
+    float t = SUM(a0) + SUM(a1) + SUM(a2) + SUM(a3) + tmp;                              \
+    if (t == 1234.5f) out[0] = t;                                                       \
+  }
+DEFKD(k_dfma, I_DFMA)
+DEFKD(k_dmul, I_DMUL)
+DEFKD(k_dadd, I_DADD)
+DEFKD(k_dcvt, I_DCVT)
 DEFK(k_sand, I_SAND, float, FINIT)
 DEFK(k_mix11, I_MIX11, float, FINIT)
 DEFK(k_mix13, I_MIX13, float, FINIT)
@@ -146,5 +168,6 @@ int main()
   // never-taken scalar compare-and-branch after every VALU instruction (exec is never 0)
   run("s_and/xor/or/andn2_b64", k_sand, out, 4); run("v_fma + 1 s_and_b64 (per pair)", k_mix11, out, 1); run("v_fma + 3 SALU (per group)", k_mix13, out, 1);
   run("v_fma + s_cmp + s_cbranch", k_branch, out, 1);
+  run("v_fma_f64", k_dfma, out, 1); run("v_mul_f64", k_dmul, out, 1); run("v_add_f64", k_dadd, out, 1); run("v_cvt_f32_f64 + v_cvt_f64_f32", k_dcvt, out, 2);
   return 0;
 }
