@@ -398,7 +398,11 @@ struct mlgpu_graph
   std::vector<Variant> variants;
   hipEvent_t tuneEv0{nullptr}, tuneEv1{nullptr};
   int activeVl{1};               // of the kernel in `fn`
-  int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+  int inLayoutOverride[MLGPU_GRAPH_MAX_INPUTS];  // -1: none
+  mlgpu_graph()
+  {
+    for (int& x : inLayoutOverride) x = -1;
+  }
 };
 
 namespace

@@ -53,7 +53,7 @@ struct EventsDev
 };
 
 // a fused graph kernel: up to 16 streamed inputs, up to 4 outputs, per-voice constants [P][V]
-#define MLGPU_GRAPH_MAX_INPUTS 16
+#define MLGPU_GRAPH_MAX_INPUTS 32
 #define MLGPU_GRAPH_MAX_OUTPUTS 8
 #define MLGPU_GRAPH_MAX_CONTROLS 8
 struct GraphArgs

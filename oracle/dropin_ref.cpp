@@ -375,6 +375,39 @@ extern "C" int e2s_ref_run_controllers(int polyphony, int mpe, int unison, doubl
                    ctlOut);
 }
 
+// ---- controllers-to-audio (tests/cpp/dropin_controllers.h): one AudioContext with its controller events ----
+#include "../tests/cpp/dropin_controllers.h"
+extern "C" int ctl_audio_ref_run(const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out)
+{
+  CtlAudioState state;
+  state.sineGens.resize(state.sineControllers.size());
+  AudioContext ctx(0, 2, 48000);
+  for (int b = 0; b < nBlocks; ++b)
+  {
+    const int start = b * blockFrames;
+    for (int i = 0; i < nEvents; ++i)
+      if (events[i].time >= start && events[i].time < start + blockFrames)
+      {
+        Event ev;
+        ev.type = events[i].type;
+        ev.channel = events[i].channel;
+        ev.sourceIdx = events[i].sourceIdx;
+        ev.time = events[i].time - start;
+        ev.value1 = events[i].value1;
+        ev.value2 = events[i].value2;
+        ctx.addInputEvent(ev);
+      }
+    for (int off = 0; off < blockFrames; off += kFloatsPerDSPVector)
+    {
+      ctx.processVector(off);
+      ctlAudioProcess(&ctx, &state);
+      store(ctx.outputs[0], out + start + off);
+    }
+    ctx.clearInputEvents();
+  }
+  return 0;
+}
+
 // ---- AudioContext's transport (ProcessTime, MLAudioContext.cpp:16-104) driven as a plug-in wrapper drives it: updateTime()
 // with what the host reports before a block, processVector() per 64 frames, getBeatPhase() read by the process function ----
 struct TransportStep

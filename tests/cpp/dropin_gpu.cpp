@@ -416,6 +416,71 @@ extern "C" int controller_synth_gpu_run(size_t nInstruments, const SynthGpuEvent
   return synth_gpu_run_t<ControllerSynth>(nInstruments, events, eventInstrument, nEvents, glideSeconds, drift, blockFrames, nBlocks, vectorsPerLaunch, outL, outR,
                                           0, nullptr, nullptr, 0, err, errLen, eventRowsInKernel != 0, rowsInKernel);
 }
+// ---- controllers-to-audio: N instances of the process function, each with its own controllers (one context per voice) ----
+#include "dropin_controllers.h"
+extern "C" int ctl_audio_gpu_run(size_t N, const SynthGpuEvent* events, const int* eventInstrument, int nEvents, int blockFrames, int nBlocks,
+                                 int vectorsPerLaunch, float* out /* [N][nBlocks * blockFrames] */, char* err, size_t errLen)
+{
+  mlgpu_events* ev = nullptr;
+  try
+  {
+    gpu::Engine eng(0);
+    CtlAudioState state;
+    state.sineGens.resize(state.sineControllers.size());
+    AudioContext ctx(0, 2, 48000);
+    gpu::VoiceProgramOptions opt;
+    opt.voicesPerContext = 1;
+    gpu::VoiceProgram prog(eng, N, &ctx, ctlAudioProcess, &state, opt);
+    // the controllers the captured code reads, in the order it first asked for them
+    std::vector<int> numbers = prog.contextInputs();
+    eng.check(mlgpu_events_create(eng.handle(), N, 1, &ev));
+    eng.check(mlgpu_events_set_sample_rate(ev, 48000.));
+    eng.check(mlgpu_events_set_wanted_rows(ev, 0));  // no voice rows: only the controllers
+    eng.check(mlgpu_events_watch_controllers(ev, numbers.data(), (int)numbers.size(), (size_t)vectorsPerLaunch));
+    std::vector<const float*> contextSignals;
+    for (size_t c = 0; c < numbers.size(); ++c) contextSignals.push_back(mlgpu_events_controller_signal(ev, (int)c));
+    float* noRows[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t S = (size_t)nBlocks * blockFrames;
+    for (int b = 0; b < nBlocks; ++b)
+    {
+      const int start = b * blockFrames;
+      for (int i = 0; i < nEvents; ++i)
+        if (events[i].time >= start && events[i].time < start + blockFrames)
+        {
+          mlgpu_event m{events[i].type, events[i].channel, events[i].sourceIdx, events[i].time - start, events[i].value1, events[i].value2};
+          eng.check(mlgpu_events_add_event(ev, (size_t)eventInstrument[i], &m));
+        }
+      const int vecs = blockFrames / 64;
+      for (int done = 0; done < vecs;)
+      {
+        const int n = (vecs - done < vectorsPerLaunch) ? vecs - done : vectorsPerLaunch;
+        gpu::DeviceSignal o0(eng, N, (size_t)n, MLGPU_LAYOUT_VOICE_MAJOR), o1(eng, N, (size_t)n, MLGPU_LAYOUT_VOICE_MAJOR);
+        eng.check(mlgpu_events_process(ev, (size_t)n, done * 64, noRows, MLGPU_LAYOUT_QUAD));
+        prog.process({}, {&o0, &o1}, nullptr, contextSignals.data());
+        std::vector<float> h(o0.size());
+        eng.check(mlgpu_download(eng.handle(), h.data(), o0.data(), o0.bytes()));
+        for (size_t i = 0; i < N; ++i) memcpy(out + i * S + start + (size_t)done * 64, h.data() + i * (size_t)n * 64, sizeof(float) * (size_t)n * 64);
+        done += n;
+      }
+      eng.check(mlgpu_events_clear_events(ev));
+    }
+    mlgpu_events_destroy(ev);
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (ev) mlgpu_events_destroy(ev);
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (ev) mlgpu_events_destroy(ev);
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
 // ---- a bank of plug-ins: nInstruments PluginSynths behind ONE mlgpu_process_buffer (the host's block sizes), their events and
 // time reports per block, the instruments' outputs summed in instrument order into the host's stereo pair ----
 namespace

@@ -461,3 +461,43 @@ def test_routing_and_function_wrappers_by_name_same_source_same_bits(launches):
     for k in range(K):
         assert np.abs(want[k]).max() > 1e-3, names[k]
         assert_bits_equal(got[k], want[k], True, f"routing drop-in output {k} ({names[k]})")
+
+
+@pytest.mark.gpu
+def test_controllers_to_audio_vector_form_same_source_same_bits():
+    """tests/cpp/dropin_controllers.h: the process function of the reference's controllers-to-audio.cpp example (eight sines tuned by
+    eight MIDI controllers, a ninth for the volume) with its per-vector float mapping written on whole vectors. A plain
+    SignalProcessFn that reads ctx->getInputController(n): through gpu::VoiceProgram the nine controllers become context inputs
+    (VoiceProgram::contextInputs) fed from mlgpu_events_controller_signal - here one context per voice, 40 instances with their own
+    controller movements, against one reference AudioContext each."""
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    Lr.ctl_audio_ref_run.restype = ctypes.c_int
+    Lr.ctl_audio_ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p]
+    Lg.ctl_audio_gpu_run.restype = ctypes.c_int
+    Lg.ctl_audio_gpu_run.argtypes = [ctypes.c_size_t, ctypes.POINTER(_Ev), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    N, block, n_blocks = 40, 512, 12
+    S = block * n_blocks
+    CTRL = 6
+    numbers = [19, 23, 27, 31, 49, 53, 57, 61, 62]
+    per_inst = []
+    for k in range(N):
+        rng = np.random.default_rng(3000 + k)
+        evs, t = [(CTRL, 1, 62, int(rng.integers(0, 100)), float(np.float32(rng.uniform(0.3, 1.0))), 0.0)], int(rng.integers(0, 300))
+        while t < S and k != N - 1:             # the last instance only ever gets its volume set
+            evs.append((CTRL, int(rng.integers(1, 17)), int(rng.choice(numbers)), t, float(np.float32(rng.random())), 0.0))
+            t += int(rng.integers(1, 700))
+        per_inst.append(sorted(evs, key=lambda e: e[3]))
+    want = np.zeros((N, S), np.float32)
+    for k, evs in enumerate(per_inst):
+        arr = (_Ev * len(evs))(*[_Ev(*e) for e in evs])
+        assert Lr.ctl_audio_ref_run(arr, len(evs), block, n_blocks, want[k].ctypes.data_as(c_f32p)) == 0
+    flat = [(e, k) for k, evs in enumerate(per_inst) for e in evs]
+    arr = (_Ev * len(flat))(*[_Ev(*e) for e, _ in flat])
+    inst = (ctypes.c_int * len(flat))(*[k for _, k in flat])
+    got = np.zeros((N, S), np.float32)
+    err = ctypes.create_string_buffer(4096)
+    st = Lg.ctl_audio_gpu_run(N, arr, inst, len(flat), block, n_blocks, 3, got.ctypes.data_as(c_f32p), err, 4096)
+    assert st == 0, err.value.decode()
+    assert_bits_equal(got, want, True, "controllers-to-audio")
+    assert np.abs(want).max() > 0.2 and np.abs(want[-1]).max() > 0.01
