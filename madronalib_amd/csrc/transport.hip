@@ -259,7 +259,8 @@ extern "C"
     mlgpu_engine* e = t->e;
     if (nVectors == 0) return MLGPU_OK;
     if (nVectors > t->maxVectors) return tfail(t, MLGPU_ERR_RANGE, "transport_process: more DSPVectors than transport_create reserved");
-    if (e->recording && !t->dirty.empty()) return tfail(t, MLGPU_ERR_INVALID, "transport_process: time reports are uploaded from the host: not while recording a sequence");
+    // the host half (reports waiting to be uploaded, the sample counters the next report is measured against) cannot be replayed
+    if (e->recording) return tfail(t, MLGPU_ERR_INVALID, "transport_process keeps host-side time: not while recording a sequence");
     if (hipSetDevice(e->device) != hipSuccess) return tfail(t, MLGPU_ERR_HIP, "hipSetDevice");
     if (!t->dirty.empty())
     {
