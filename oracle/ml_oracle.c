@@ -2039,3 +2039,118 @@ int mlorc_resample(int octaves, int up, size_t V, size_t T_in, float* state, con
   }
   return MLGPU_OK;
 }
+
+/* ==== AudioContext::ProcessTime (source/app/MLAudioContext.h:27-57, MLAudioContext.cpp:16-104): the quarter-note phasor behind
+ * ctx->getBeatPhase(). A script drives it as a plug-in wrapper does: kind 0 = updateTime(ppq, bpm, playing, sr) -> setTimeAndRate,
+ * kind 1 = `vectors` x processVector, kind 2 = clear(). out: the concatenated phasor; since[i]: samplesSinceStart after step i. ==== */
+typedef struct
+{
+  int kind, vectors, playing, pad;
+  double ppq, bpm, sr;
+} mlorc_transport_step;
+
+int mlorc_transport_run(const mlorc_transport_step* steps, int n_steps, float* out, uint64_t* since)
+{
+  /* ProcessTime's members and their initial values, MLAudioContext.h:44-56 */
+  float omega = 0.f;
+  int playing1 = 0, active1 = 0;
+  double dpdt = 0., ppqPos1 = -1., ppqPhase1 = 0., bpm = 0., sampleRate = 0.;
+  uint64_t samplesSincePreviousTime = 0, samplesSinceStart = 0;
+  size_t pos = 0;
+  (void)active1;
+  (void)bpm;
+  for (int i = 0; i < n_steps; ++i)
+  {
+    const mlorc_transport_step* st = &steps[i];
+    if (st->kind == 0) /* setTimeAndRate, :16-80 */
+    {
+      const double ppqPos = st->ppq, bpmIn = st->bpm;
+      const int isPlaying = st->playing != 0;
+      if (!(isnan(ppqPos) || isinf(ppqPos) || isnan(bpmIn) || isinf(bpmIn))) /* :20-26 */
+      {
+        sampleRate = st->sr;
+        bpm = bpmIn;
+        const int active = (ppqPos1 != ppqPos) && isPlaying;
+        const int justStarted = isPlaying && !playing1;
+        double ppqPhase = 0.;
+        if (active)
+        {
+          ppqPhase = (ppqPos > 0.f) ? ppqPos - floor(ppqPos) : ppqPos;
+          omega = (float)ppqPhase;
+          if (justStarted)
+          {
+            samplesSinceStart = 0;
+            omega = 0.f;
+            const double dsdt = 1. / sampleRate;
+            const double minutesPerSample = dsdt / 60.;
+            dpdt = bpm * minutesPerSample;
+          }
+          else
+          {
+            double dPhase = ppqPhase - ppqPhase1;
+            if (dPhase < 0.) dPhase += 1.;
+            const double x = dPhase / (double)samplesSincePreviousTime;
+            dpdt = (x < 0.) ? 0. : (x > 1. ? 1. : x); /* ml::clamp, MLDSPScalarMath.h:69-72 */
+          }
+        }
+        else
+        {
+          omega = -1.f;
+          dpdt = 0.;
+        }
+        ppqPos1 = ppqPos;
+        ppqPhase1 = ppqPhase;
+        active1 = active;
+        playing1 = isPlaying;
+        samplesSincePreviousTime = 0;
+      }
+    }
+    else if (st->kind == 2) /* clear, :82-87 */
+    {
+      dpdt = 0.;
+      active1 = 0;
+      playing1 = 0;
+    }
+    else
+      for (int v = 0; v < st->vectors; ++v) /* processVector, :91-104 */
+      {
+        for (int n = 0; n < VEC; ++n)
+        {
+          out[pos++] = omega;
+          omega = (float)((double)omega + dpdt); /* float += double */
+          if (omega > 1.f) omega -= 1.f;
+        }
+        samplesSincePreviousTime += VEC;
+        samplesSinceStart += VEC;
+      }
+    since[i] = samplesSinceStart;
+  }
+  return 0;
+}
+
+/* ==== EventsToSignals::SmoothedController (MLEventsToSignals.h:170-180, .cpp:264-281), what AudioContext::getInputController(n)
+ * returns: per DSPVector of an awake instrument output = glide(inputValue), a LinearGlide of int(sr * 0.02) samples; zeros while
+ * the instrument has never seen an event (:386). values[t] = the controller's inputValue during vector t (the last controller event
+ * so far), awake_from = the first vector processed after the instrument's first event. out: n_vectors x 64. ==== */
+int mlorc_smoothed_controller_run(double sr, const float* values, size_t n_vectors, size_t awake_from, float* out)
+{
+  float C[2];
+  uint32_t S[3 + VEC];
+  const int procs[1] = {MLGPU_PROC_LINEAR_GLIDE};
+  mlorc_linear_glide_make_coeffs((float)(int)(sr * 0.02f), C); /* int glideTimeInSamples = sr * kControllerGlideTimeSeconds, :275 */
+  mlorc_chain_default_state(procs, 1, 1, S);
+  for (size_t t = 0; t < n_vectors; ++t)
+  {
+    if (t < awake_from)
+    {
+      for (int n = 0; n < VEC; ++n) out[t * VEC + n] = 0.f;
+      continue;
+    }
+    float in[VEC];
+    for (int n = 0; n < VEC; ++n) in[n] = values[t];
+    const float* ins[1] = {in};
+    const int st = mlorc_proc_process_multi(MLGPU_PROC_LINEAR_GLIDE, 1, 1, C, S, ins, 1, out + t * VEC);
+    if (st) return st;
+  }
+  return 0;
+}

@@ -568,3 +568,16 @@ def test_controller_signals_bank_size(eng):
             mine = ctl[c, k::8]
             assert_bits_equal(mine[0], want[c], True, f"performance {k}, controller {watch[c]}")
             assert (mine.view(np.uint32) == mine[0].view(np.uint32)[None, :]).all(), f"instruments of performance {k} differ"
+
+
+@pytest.mark.gpu
+def test_controller_events_on_the_same_frame(eng):
+    """addEvent inserts with lower_bound (MLEventsToSignals.cpp:372): of two controller events on the same frame the one added LATER is
+    processed FIRST, so the value added first is what the controller ends the vector with."""
+    cfg = SCENARIOS["midi_poly4"]
+    evs = [(NOTE_ON, 1, 60, 0, 0.0, 0.5), (CTRL, 1, 74, 70, 0.25, 0.0), (CTRL, 1, 74, 70, 0.75, 0.0), (CTRL, 1, 74, 70, 0.5, 0.0),
+           (CTRL, 1, 7, 900, 1.0, 0.0), (CTRL, 2, 7, 900, 0.125, 0.0)]
+    _, ctl = gpu_run(eng, cfg, [evs], 512, 5, vectors_per_launch=8, watch=[74, 7])
+    _, want = ref_run_controllers(cfg, evs, 512, 5, [74, 7])
+    assert_bits_equal(ctl[:, 0], want, True, "same-frame controller events")
+    assert want[0, -1] == np.float32(0.25) and want[1, -1] == np.float32(1.0)
