@@ -113,6 +113,45 @@ __global__ __launch_bounds__(256) void k_bank_split(const f32x4* a, f32x4* b, si
   }
 }
 
+// one direction only: what a kernel that only writes (config 3: a generator bank) or only reads can reach. Grid-stride stream
+// (U float4 per lane per trip) and the voice-bank pattern (lane = voice, rows V * 16 B apart, XCD-aware)
+template <int U, bool STORE>
+__global__ __launch_bounds__(256) void k_stream_one_way(f32x4* b, size_t n, float x)
+{
+  const size_t per = (n / 8) & ~(size_t)255, xcd = blockIdx.x & 7, stride = (size_t)(gridDim.x >> 3) * 256;
+  size_t i = xcd * per + (size_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+  const size_t end = (xcd == 7) ? n : (xcd + 1) * per;
+  f32x4 acc = {x, x, x, x};
+  for (; i + (U - 1) * stride < end; i += U * stride)
+  {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      if (STORE) __builtin_nontemporal_store(acc, &b[i + u * stride]);
+      else acc += __builtin_nontemporal_load(&b[i + u * stride]);
+    }
+  }
+  if (!STORE && acc[0] == 1234.5f) b[0] = acc;
+}
+template <bool STORE>
+__global__ __launch_bounds__(256) void k_bank_one_way(f32x4* b, size_t V, size_t rows, float x)
+{
+  size_t blk = blockIdx.x;
+  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
+  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);
+  const size_t v = blk * 256 + threadIdx.x;
+  if (v >= V) return;
+  f32x4* pb = b + v;
+  f32x4 acc = {x, x, x, x};
+#pragma unroll 8
+  for (size_t r = 0; r < rows; ++r)
+  {
+    if (STORE) __builtin_nontemporal_store(acc, pb + r * V);
+    else acc += __builtin_nontemporal_load(pb + r * V);
+  }
+  if (!STORE && acc[0] == 1234.5f) b[0] = acc;
+}
+
 template <class F>
 double sustain(F launch)
 {
@@ -154,6 +193,22 @@ int main()
 #define SPLIT(PF) snprintf(name, sizeof(name), "bank pattern, loads / stores in separate waves V=%zu prefetch=" #PF, V); \
     rep(name, sustain([&] { hipLaunchKernelGGL((k_bank_split<PF, true>), dim3((unsigned)(V / 128)), dim3(256), 0, 0, a, b, V, rows); }))
     SPLIT(4); SPLIT(8); SPLIT(16);
+  }
+  // one direction: 2 GiB (a and b are not adjacent; each 1 GiB is walked on its own, two launches per measurement)
+  auto rep1 = [&](const char* name, double ms) { printf("%-58s %7.3f ms  %7.1f GB/s (one direction)\n", name, ms, 2.0 * bytes / ms / 1e6); fflush(stdout); };
+#define ONEWAY(U, STORE, GRID) rep1((STORE) ? "stores only, stream U=" #U " grid=" #GRID : "loads only, stream U=" #U " grid=" #GRID, sustain([&] { \
+    hipLaunchKernelGGL((k_stream_one_way<U, STORE>), dim3(GRID), dim3(256), 0, 0, a, n, 1.f); hipLaunchKernelGGL((k_stream_one_way<U, STORE>), dim3(GRID), dim3(256), 0, 0, b, n, 1.f); }))
+  ONEWAY(4, true, 2048); ONEWAY(8, true, 2048); ONEWAY(4, true, 4096); ONEWAY(4, false, 2048); ONEWAY(8, false, 2048); ONEWAY(8, false, 4096);
+  for (size_t V : {(size_t)131072, (size_t)262144})
+  {
+    char name[128];
+    const size_t rows = n / V;
+    snprintf(name, sizeof(name), "stores only, bank pattern V=%zu rows=%zu", V, rows);
+    rep1(name, sustain([&] { hipLaunchKernelGGL((k_bank_one_way<true>), dim3((unsigned)(V / 256)), dim3(256), 0, 0, a, V, rows, 1.f);
+                             hipLaunchKernelGGL((k_bank_one_way<true>), dim3((unsigned)(V / 256)), dim3(256), 0, 0, b, V, rows, 1.f); }));
+    snprintf(name, sizeof(name), "loads only, bank pattern V=%zu rows=%zu", V, rows);
+    rep1(name, sustain([&] { hipLaunchKernelGGL((k_bank_one_way<false>), dim3((unsigned)(V / 256)), dim3(256), 0, 0, a, V, rows, 1.f);
+                             hipLaunchKernelGGL((k_bank_one_way<false>), dim3((unsigned)(V / 256)), dim3(256), 0, 0, b, V, rows, 1.f); }));
   }
   return 0;
 }
