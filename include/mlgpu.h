@@ -218,8 +218,9 @@ typedef enum mlgpu_proc
                                        *            (x, delay), (x, delay, changeTicks:int mask); setDelayInSamples:
                                        *            mlgpu_fractional_delay_make_state -> state words 3, 4 */
   MLGPU_PROC_PITCHBENDABLE_DELAY = 83, /* :1050-1106 C{}      S{delay1[5], delay2[5]} two rings; form (x, delay) */
-  /* TempoLock, MLDSPFilters.h:1478-1579: operator()(DSPVector x, float dydx, float isr). Graph node with 3 inputs: x must be a
-   * streamed INPUT node (only x[0], x[1] of each vector are read), dydx and isr one float per vector (control / param / const). */
+  /* TempoLock, MLDSPFilters.h:1478-1579: operator()(DSPVector x, float dydx, float isr). Graph node with 3 inputs: x the phasor to
+   * follow - a streamed INPUT node (only x[0], x[1] of each vector are read, once per vector) or any signal computed in the graph
+   * (taken sample by sample; same results) -, dydx and isr one float per vector (control / param / const). */
   MLGPU_PROC_TEMPO_LOCK = 96,         /* C{} S{omega (phase, -1 = stopped), x1v}; clear(): omega = -1 */
   /* HalfBandFilter, MLDSPFilters.h:1245-1310: the resampling filter at the edges of a rate region
    * (mlgpu_graph_begin_region / end_region create these nodes; they cannot be added directly).

@@ -471,7 +471,9 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
       else s << floatLiteral(n.value);
       break;
     case NODE_PROC:
-      if (mlgpu_proc_is_vector_rate(n.kind))
+      if (n.kind == MLGPU_PROC_TEMPO_LOCK && g->nodes[n.in[0]].type != NODE_INPUT)  // the phasor to follow is computed in this graph
+        s << "p" << i << L << ".next_x(" << idx << ", " << arg(0) << ", " << arg(1) << ", " << arg(2) << ")";
+      else if (mlgpu_proc_is_vector_rate(n.kind))
         s << "p" << i << L << ".next_n(" << idx << ")";
       else if (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY)
         s << "p" << i << L << ".next_i(" << idx << ", " << arg(0) << ", " << arg(1) << ")";
@@ -662,7 +664,10 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   {
     const Node& n = g->nodes[i];
     if (n.rate == RATE_VECTOR) emit(i, "    ");
-    if (n.type == NODE_PROC && n.kind == MLGPU_PROC_TEMPO_LOCK)
+    if (n.type == NODE_PROC && n.kind == MLGPU_PROC_TEMPO_LOCK && g->nodes[n.in[0]].type != NODE_INPUT)
+    {
+    }
+    else if (n.type == NODE_PROC && n.kind == MLGPU_PROC_TEMPO_LOCK)
     {
       const int slot = g->nodes[n.in[0]].slot;  // the streamed input: first two samples of this vector
       for (int l = 0; l < VL; ++l)
@@ -1331,8 +1336,8 @@ extern "C"
     {
       for (int j = 0; j < 3; ++j)
         if (inputs[j] < 0 || inputs[j] >= (int)g->nodes.size()) return -gfail(g, MLGPU_ERR_RANGE, "graph node input refers to an unknown node");
-      if (g->nodes[inputs[0]].type != NODE_INPUT || g->nodes[inputs[1]].rate > RATE_VECTOR || g->nodes[inputs[2]].rate > RATE_VECTOR)
-        return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: TempoLock(x, dydx, isr): x is a streamed input node, dydx and isr floats per vector");
+      if (g->nodes[inputs[1]].rate > RATE_VECTOR || g->nodes[inputs[2]].rate > RATE_VECTOR)
+        return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: TempoLock(x, dydx, isr): dydx and isr are floats per vector");
     }
     else if (mlgpu_proc_is_vector_rate(kind) && (inputs[0] < 0 || inputs[0] >= (int)g->nodes.size() || g->nodes[inputs[0]].rate > RATE_VECTOR))
       return -gfail(g, MLGPU_ERR_INVALID, "graph_add_proc: Interpolator1 / LinearGlide take one float per DSPVector (a control, param or const node)");

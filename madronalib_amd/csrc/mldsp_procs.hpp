@@ -1488,6 +1488,32 @@ struct Proc<MLGPU_PROC_TEMPO_LOCK>  // C{}  S{omega, x1v}
     if (omega > 1.0f) omega -= 1.0f;
     return y;
   }
+  // x computed inside the graph instead of streamed in: the same arithmetic, taken sample by sample. Everything a vector needs
+  // is in x[0] except, in a start-up vector, the slope x[1] - x[0] (:1523) - and that is first used for sample 1: sample 0 of a
+  // start-up vector is the phase jumped to, fmod(x[0] * dydx, 1) (:1526).
+  float x0h;
+  bool starting;
+  MLD float next_x(int n, float x, float dydx, float isr)
+  {
+    if (n == 0)
+    {
+      x0h = x;
+      starting = !(x == -1.0f) && !(omega > -1.f);
+      if (starting)
+      {
+        stopped = false;
+        return __builtin_fmodf(x * dydx, 1.0f);
+      }
+      begin_vector(x, 0.f, dydx, isr);
+    }
+    else if (n == 1 && starting)
+    {
+      begin_vector(x0h, x, dydx, isr);
+      omega += dydt;  // sample 0's step
+      if (omega > 1.0f) omega -= 1.0f;
+    }
+    return next_n(n);
+  }
   MLD void end_vector() {}
 };
 

@@ -13,7 +13,7 @@ struct ObjectsState
   PhasorGen phasor;
   OneShotGen shot;
   TestSineGen testSine;
-  TempoLock lock;
+  TempoLock lock, lockComputed;
   Bandpass bandpass;
   HiShelf hiShelf;
   Integrator integrator;
@@ -56,7 +56,8 @@ inline void objectsProcess(AudioContext* ctx, void* stateData)
   // 0: pulse-like generators
   ctx->outputs[0] = s->tick(freq * 0.25f) + s->impulse(freq) * 0.5f + s->shot(DSPVector(3.f / 48000.f)) * 0.25f;
   // 1: phase generators
-  ctx->outputs[1] = ph + s->testSine(freq * 0.5f) * 0.5f + s->lock(slow, 2.f, 1.f / 48000.f) * 0.25f;
+  // one TempoLock follows the host's phasor (a streamed input), one a phasor computed right here
+  ctx->outputs[1] = ph + s->testSine(freq * 0.5f) * 0.5f + s->lock(slow, 2.f, 1.f / 48000.f) * 0.25f + s->lockComputed(ph, 0.5f, 1.f / 48000.f) * 0.125f;
   // 2: the two second-order sections no other drop-in uses
   ctx->outputs[2] = s->bandpass(x) + s->hiShelf(x) * 0.5f;
   // 3: one-state recurrences

@@ -697,3 +697,36 @@ def test_input_shared_by_groups_of_voices(eng, group, vpl):
         g.set_input_group(1, 4)                    # already compiled
     g.close()
     g_err.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hostile", [False, True])
+def test_tempo_lock_following_a_computed_phasor(eng, oracle, hostile):
+    """TempoLock whose input is a signal computed inside the graph (here the streamed clock times a constant 1: the same values, but
+    not an input node): taken sample by sample - only a start-up vector needs x[1], and first for its sample 1 - with the results
+    of the vector-rate form, i.e. of the reference (the oracle's TempoLock is pinned against it on these cases). Stopped clocks,
+    restarts, locking and non-locking ratios; and with infinities, NaNs and raw bit patterns in the clock."""
+    import madronalib_amd as ml
+    V, T = 200, 16
+    case = (hostile_multi_case if hostile else multi_case)(oracle, "tempo_lock", V, 2 * T, seed=77)
+    g = ml.Graph(eng, V)
+    names = []
+    for i, (rate, _) in enumerate(case["inputs"]):
+        names.append(f"in{i}")
+        g.add(names[-1], "input" if rate == "audio" else "control")
+    g.add("one", "const", value=1.0)
+    g.add("clock", "op", Op.MULTIPLY, [names[0], "one"])
+    g.add("p", "proc", case["kind"], ["clock"] + names[1:])
+    g.add_output("p")
+    g.compile()
+    assert ".next_x(" in g.source
+    st = oracle.chain_clear([case["kind"]], V)
+    outs, states = run_case_calls(g, names, case, T, st.copy(), Layout.QUAD)
+    ins = multi_inputs_audio(case, 2 * T)
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        want = oracle.proc_multi(case["kind"], T, case["coeffs"], st, [np.ascontiguousarray(x[:, sl]) for x in ins])
+        assert_bits_equal(outs[call], want, True, f"computed-input TempoLock call {call} (hostile: {hostile})")
+        g32, w32 = states[call].view(np.uint32), st.view(np.uint32)
+        bothnan = np.isnan(g32.view(np.float32)) & np.isnan(w32.view(np.float32))
+        assert ((g32 == w32) | bothnan).all(), f"computed-input TempoLock state after call {call}"
