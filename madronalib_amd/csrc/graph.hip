@@ -485,6 +485,13 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
         if (n.in.size() == 2) s << ", " << arg(1);
         s << ", odd" << i << ")";
       }
+      else if (n.kind == MLGPU_PROC_PULSE_GEN && (n.in.size() == 1 || g->nodes[n.in[1]].rate == RATE_VOICE))
+      {
+        // streamed frequency, launch-constant width: the width's range test was done once per wavefront (oddw<i>)
+        s << "p" << i << L << ".next_sw(" << arg(0);
+        if (n.in.size() == 2) s << ", " << arg(1);
+        s << ", oddw" << i << ")";
+      }
       else if (n.kind == MLGPU_PROC_PULSE_GEN && n.in.size() == 2)
         s << "p" << i << L << ".next2(" << arg(0) << ", " << arg(1) << ")";
       else
@@ -637,6 +644,17 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
           if (n.in.size() == 1) s << " || pulse_width_is_odd(p" << i << sfx(l) << ".width)";
           else s << " || pulse_width_is_odd(n" << n.in[1] << sfx(l) << ")";
         }
+      s << ") != 0;\n";
+    }
+    else if (n.type == NODE_PROC && n.kind == MLGPU_PROC_PULSE_GEN && (n.in.size() == 1 || g->nodes[n.in[1]].rate == RATE_VOICE))
+    {
+      s << "  const bool oddw" << i << " = __builtin_amdgcn_ballot_w64(";
+      for (int l = 0; l < VL; ++l)
+      {
+        if (l) s << " || ";
+        if (n.in.size() == 1) s << "pulse_width_is_odd(p" << i << sfx(l) << ".width)";
+        else s << "pulse_width_is_odd(n" << n.in[1] << sfx(l) << ")";
+      }
       s << ") != 0;\n";
     }
   }

@@ -184,19 +184,20 @@ MLD float phasor_to_saw(float p, float cps)
 // when no lane of the wavefront is, ONE evaluation serves: the phase of whichever step is near goes in, the result is
 // added or subtracted. Bits: the reference computes (pulse + c_up) - c_down with the idle correction exactly 0.f, and
 // x + 0 == x, x - 0 == x for the +-1 / finite values here, so pulse + c_up or pulse - c_down is the same float.
-// REGULAR_W: the caller has excluded, for the whole wavefront, a pulse width of 2^30 or more in magnitude (or NaN): with a
-// PhasorGen's p in [0, 1) the shifted phase then fits an int32 and cvttps2dq's out-of-range result never comes up - one
-// conversion instead of the six instructions of sse_cvtt.
-MLD bool pulse_width_is_odd(float w) { return !(abs_ps(w) < 0x1p30f); }
+// REGULAR_W: the caller has excluded, for the whole wavefront, every pulse width outside [0, 1] (and NaN): with a PhasorGen's p
+// in [0, 1) the shifted phase d = p - w + 1 is then in [0, 2], where fractionalPart's d - float(trunc(d)) (d, or d - 1: both
+// exact) is what v_fract_f32 returns - one instruction instead of sse_cvtt's six, a conversion back and a subtraction. Any other
+// width takes the general path.
+MLD bool pulse_width_is_odd(float w) { return !(w >= 0.f && w <= 1.0f); }
 
 template <bool FAST, bool SKIP = false, bool ANY_PHASE = false, bool REGULAR_W = false>
 MLD float phasor_to_pulse(float p, float cps, float w)
 {
   const float pulse = (p >= w) ? -1.f : 1.f;
   const float d = p - w + 1.0f;
-  const float down = d - (float)(REGULAR_W ? (int32_t)d : sse_cvtt(d));  // fractionalPart
-  // a regular width leaves `down` a multiple of 2^-24 inside (-1, 1): div_nr's ground. Any other width (2^30 and up, inf, NaN)
-  // makes it huge, infinite or NaN, and the reference's own division has to produce whatever comes out of that.
+  const float down = REGULAR_W ? __builtin_amdgcn_fractf(d) : d - (float)sse_cvtt(d);  // fractionalPart
+  // a regular width leaves `down` inside [0, 1): div_nr's ground. Other widths can make it negative, huge, infinite or NaN, and
+  // the reference's own division has to produce whatever comes out of that.
   const bool downOdd = ANY_PHASE ? phase_is_odd(down) : (!REGULAR_W && !(abs_ps(down) <= 2.0f));
   const BlepFreq<FAST> f = BlepFreq<FAST>::make(cps, (ANY_PHASE && phase_is_odd(p)) || downOdd);
   const bool loUp = f.lo(p), nearUp = loUp || f.hi(p);
@@ -313,6 +314,9 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
   MLD float next_u(float cps, float w, bool odd) { return odd ? step<false>(cps, w) : step<true, false, true>(cps, w); }
   // launch-constant frequency, the width a signal: `odd` is about the frequency alone
   MLD float next_uw(float cps, float w, bool odd) { return odd ? step<false>(cps, w) : step<true>(cps, w); }
+  // the frequency a signal, the width launch-constant: `oddW` (wave-uniform, tested once by the caller) is about the width alone
+  MLD float next_sw(float cps, bool oddW) { return oddW ? step<false, true>(cps, width) : step<false, true, true>(cps, width); }
+  MLD float next_sw(float cps, float w, bool oddW) { return oddW ? step<false, true>(cps, w) : step<false, true, true>(cps, w); }
   static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
   MLD void end_vector() {}
 };
