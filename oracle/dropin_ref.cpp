@@ -138,7 +138,13 @@ extern "C" int routing_ref_run(size_t V, size_t T, const float* in0, const float
 
 // ---- the stateful objects the other drop-ins do not touch, by name (tests/cpp/dropin_objects.h) ----
 #include "../tests/cpp/dropin_objects.h"
+// retriggerAt >= 0: OneShotGen::trigger() is called again before that DSPVector - on every voice, or (everyOther) on the even ones
+extern "C" int objects_ref_run_retrigger(size_t V, size_t T, const float* in0, const float* in1, float* outs, int retriggerAt, int everyOther);
 extern "C" int objects_ref_run(size_t V, size_t T, const float* in0, const float* in1, float* outs /* [kObjectsOutputs][V][64 T] */)
+{
+  return objects_ref_run_retrigger(V, T, in0, in1, outs, -1, 0);
+}
+extern "C" int objects_ref_run_retrigger(size_t V, size_t T, const float* in0, const float* in1, float* outs, int retriggerAt, int everyOther)
 {
   const size_t S = T * kFloatsPerDSPVector;
   for (size_t v = 0; v < V; ++v)
@@ -148,6 +154,7 @@ extern "C" int objects_ref_run(size_t V, size_t T, const float* in0, const float
     AudioContext ctx(2, kObjectsOutputs, 48000);
     for (size_t t = 0; t < T; ++t)
     {
+      if ((int)t == retriggerAt && (!everyOther || (v & 1) == 0)) state.shot.trigger();
       load(ctx.inputs[0], in0 + v * S + t * kFloatsPerDSPVector);
       load(ctx.inputs[1], in1 + v * S + t * kFloatsPerDSPVector);
       objectsProcess(&ctx, &state);

@@ -263,8 +263,16 @@ extern "C" int routing_gpu_run(size_t V, size_t T, int launches, const float* in
 }
 
 #include "dropin_objects.h"
+extern "C" int objects_gpu_run_retrigger(size_t V, size_t T, int launches, const float* in0, const float* in1, float* outs, int retriggerAtLaunch, int everyOther,
+                                         char* err, size_t errLen);
 extern "C" int objects_gpu_run(size_t V, size_t T, int launches, const float* in0, const float* in1, float* outs /* [kObjectsOutputs][V][64 T] */, char* err,
                                size_t errLen)
+{
+  return objects_gpu_run_retrigger(V, T, launches, in0, in1, outs, -1, 0, err, errLen);
+}
+// retriggerAtLaunch >= 0: before that launch the one-shot is triggered again (gpu::VoiceProgram::trigger), on every voice or on the even ones
+extern "C" int objects_gpu_run_retrigger(size_t V, size_t T, int launches, const float* in0, const float* in1, float* outs, int retriggerAtLaunch, int everyOther,
+                                         char* err, size_t errLen)
 {
   try
   {
@@ -283,6 +291,16 @@ extern "C" int objects_gpu_run(size_t V, size_t T, int launches, const float* in
     std::vector<float> h(V * Sl);
     for (int l = 0; l < launches; ++l)  // state carried from launch to launch
     {
+      if (l == retriggerAtLaunch)
+      {
+        if (!everyOther) prog.trigger(state.shot);
+        else
+        {
+          std::vector<uint8_t> which(V);
+          for (size_t v = 0; v < V; ++v) which[v] = (v & 1) == 0;
+          prog.trigger(state.shot, which);
+        }
+      }
       for (int which = 0; which < 2; ++which)
       {
         const float* src = which ? in1 : in0;

@@ -501,3 +501,32 @@ def test_controllers_to_audio_vector_form_same_source_same_bits():
     assert st == 0, err.value.decode()
     assert_bits_equal(got, want, True, "controllers-to-audio")
     assert np.abs(want).max() > 0.2 and np.abs(want[-1]).max() > 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("every_other", [0, 1])
+def test_one_shot_retriggered_between_launches(every_other):
+    """OneShotGen::trigger() called again while the program runs - gpu::VoiceProgram::trigger(shot) for every voice,
+    trigger(shot, flags) for some - against the reference's objects retriggered before the same DSPVector."""
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    V, T, launches = 40, 12, 3
+    S = 64 * T
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1.0, 1.0, (V, S)).astype(np.float32)
+    slow = np.mod(rng.uniform(0, 1, (V, 1)) + np.arange(S)[None, :] / 700.0, 1.0).astype(np.float32)
+    want, got = np.zeros((8, V, S), np.float32), np.zeros((8, V, S), np.float32)
+    Lr.objects_ref_run_retrigger.restype = ctypes.c_int
+    Lr.objects_ref_run_retrigger.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int]
+    Lg.objects_gpu_run_retrigger.restype = ctypes.c_int
+    Lg.objects_gpu_run_retrigger.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                             ctypes.c_size_t]
+    p = lambda a: a.ctypes.data_as(c_f32p)  # noqa: E731
+    assert Lr.objects_ref_run_retrigger(V, T, p(x), p(slow), p(want), 2 * (T // launches), every_other) == 0
+    err = ctypes.create_string_buffer(4096)
+    assert Lg.objects_gpu_run_retrigger(V, T, launches, p(x), p(slow), p(got), 2, every_other, err, 4096) == 0, err.value.decode()
+    assert_bits_equal(got[0], want[0], True, "TickGen + ImpulseGen + OneShotGen, retriggered")
+    plain = np.zeros((8, V, S), np.float32)
+    Lr.objects_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p]
+    assert Lr.objects_ref_run(V, T, p(x), p(slow), p(plain)) == 0
+    changed = np.abs(plain[0] - want[0]).max(axis=1) > 0
+    assert changed[0::2].all() and (changed[1::2].all() if not every_other else not changed[1::2].any())
