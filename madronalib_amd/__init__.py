@@ -605,6 +605,10 @@ class Transport:
     def process(self, n_vectors):
         self.engine._check(self.L.mlgpu_transport_process(self.h, int(n_vectors)))
 
+    def reserve(self, max_vectors):
+        """Another launch length from now on; the phasors go on (the signal pointer changes)."""
+        self.engine._check(self.L.mlgpu_transport_reserve(self.h, int(max_vectors)))
+
     @property
     def beat_phase(self):
         """Device pointer of the last process call's signal: QUAD over the n contexts."""

@@ -581,3 +581,26 @@ def test_controller_events_on_the_same_frame(eng):
     _, want = ref_run_controllers(cfg, evs, 512, 5, [74, 7])
     assert_bits_equal(ctl[:, 0], want, True, "same-frame controller events")
     assert want[0, -1] == np.float32(0.25) and want[1, -1] == np.float32(1.0)
+
+
+@pytest.mark.gpu
+def test_controller_signals_survive_a_longer_reservation(eng):
+    """watch_controllers again with the same numbers only changes the reserved launch length: the smoothers go on mid-glide."""
+    import madronalib_amd as ml
+    cfg = SCENARIOS["midi_poly4"]
+    evs = [(NOTE_ON, 1, 60, 0, 0.0, 0.5), (CTRL, 1, 74, 100, 0.75, 0.0), (CTRL, 1, 1, 130, 0.5, 0.0), (CTRL, 1, 74, 700, 0.125, 0.0)]
+    ev = ml.Events(eng, 1, 4)
+    ev.configure(glide_seconds=cfg["glide"], drift=cfg["drift"])
+    ev.watch_controllers([74, 1], 2)
+    ev.add_events([0] * len(evs), [ml.Event(*e) for e in evs])
+    chunks = []
+    for start, n in ((0, 2), (128, 2), (256, 8), (768, 8), (1280, 4)):       # the glides of frames 100 / 130 are under way at 256
+        if n > 2:
+            ev.watch_controllers([74, 1], 8)
+        ev.process_host(n, start)
+        chunks.append(ev.controllers_host(n))
+    got = np.concatenate(chunks, 2)
+    _, want = ref_run_controllers(cfg, evs, 1536, 1, [74, 1])
+    assert_bits_equal(got[:, 0], want, True, "controllers across a re-reservation")
+    assert 0.125 < want[0, 300] < 0.75 or 0 < want[0, 300] < 0.75      # still gliding when the reservation changed
+    ev.close()

@@ -171,3 +171,23 @@ def test_transport_error_paths(eng):
     assert ei.value.status == ml.Status.ERR_RANGE
     assert not tr.process_host(2).any()          # never reported: omega_{0}, dpdt_{0}
     tr.close()
+
+
+def test_transport_survives_a_longer_reservation(eng):
+    """mlgpu_transport_reserve changes the launch length; the phasors go on."""
+    import madronalib_amd as ml
+    script = [update(0.25, 133.0, True), ("process", 2), ("process", 2), ("process", 16), update(3.9, 90.0, True), ("process", 16), ("process", 1)]
+    want, _ = ref_run(script)
+    tr = ml.Transport(eng, 3, 2)
+    outs = []
+    for s in script:
+        if s[0] == "update":
+            tr.update_time(s[1], s[2], s[3], s[4])
+        else:
+            if s[1] > 2:
+                tr.reserve(16)
+            outs.append(tr.process_host(s[1]))
+    got = np.concatenate(outs, 1)
+    for k in range(3):
+        assert_bits_equal(got[k], want, True, f"context {k} across a re-reservation")
+    tr.close()
