@@ -382,7 +382,7 @@ def cpu_baseline_cfg3(budget_s=12.0):
         one_core = 4096 * T1 * 64 / min(ref.bench_saw_bandpass_gain(4096, T1, f1, c1[0], c1[1], c1[2], 0.25, 1)[0] for _ in range(2))
     return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": kind, "value_one_core": one_core,
             "sample": f"{Vs} voices x {T} DSPVectors of the same chain/params, {cores} threads, best of 3 "
-                      f"({'compiled reference headers, g++ -O2 SSE2' if kind == 'reference' else 'plain-C oracle port, gcc -O2'})"
+                      f"({'compiled reference headers, g++ -O2 -fno-strict-aliasing, SSE2' if kind == 'reference' else 'plain-C oracle port, gcc -O2'})"
                       + ("; value_one_core: 4096 voices on one thread" if one_core else "")}
 
 
@@ -402,11 +402,11 @@ def cpu_baseline_cfg4(budget_s=10.0):
     T = int(max(16, min(8192, 16 * budget_s / max(t_cal, 1e-6) / 3)))
     best = min(ref.bench_lopass_cascade8(Vs, T, co, cores)[0] for _ in range(3))
     return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
-            "sample": f"{Vs} channels x {T} DSPVectors, 8 cascaded Lopass per channel, {cores} threads, best of 3 (compiled reference headers, g++ -O2 SSE2)"}
+            "sample": f"{Vs} channels x {T} DSPVectors, 8 cascaded Lopass per channel, {cores} threads, best of 3 (compiled reference headers, g++ -O2 -fno-strict-aliasing, SSE2)"}
 
 
 def cpu_baseline_cfg2(budget_s=8.0):
-    """Config 2 on the host cores: expApprox(sinApprox(x)) over the same 4 Mi samples with the reference's ops (g++ -O2 SSE2)."""
+    """Config 2 on the host cores: expApprox(sinApprox(x)) over the same 4 Mi samples with the reference's ops (g++ -O2 -fno-strict-aliasing, SSE2)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_checkers import Ref, ref_available
     from madronalib_amd.constants import Op
@@ -421,7 +421,7 @@ def cpu_baseline_cfg2(budget_s=8.0):
     reps = int(max(8, min(20000, 8 * budget_s / max(t_cal, 1e-6) / 3)))
     best = min(ref.bench_op(Op.EXP_APPROX_OF_SIN_APPROX, x, cores, reps) for _ in range(3))
     return {"value": n * reps / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
-            "sample": f"65536 voices x 1 DSPVector, {reps} passes, {cores} threads, best of 3 (reference ops, g++ -O2 SSE2; the data stays in the CPU caches)"}
+            "sample": f"65536 voices x 1 DSPVector, {reps} passes, {cores} threads, best of 3 (reference ops, g++ -O2 -fno-strict-aliasing, SSE2; the data stays in the CPU caches)"}
 
 
 def cpu_baseline_cfg5full(budget_s=10.0):
@@ -450,7 +450,7 @@ def cpu_baseline_cfg5(budget_s=10.0, full=False):
     T = int(max(16, min(1024, 16 * budget_s / max(t_cal, 1e-6) / 3)))
     best = min(run(T) for _ in range(3))
     return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
-            "sample": f"{Vs} voices x {T} DSPVectors of the synth16{' (full)' if full else ''} voice, {cores} threads, best of 3 (reference objects, g++ -O2 SSE2)"}
+            "sample": f"{Vs} voices x {T} DSPVectors of the synth16{' (full)' if full else ''} voice, {cores} threads, best of 3 (reference objects, g++ -O2 -fno-strict-aliasing, SSE2)"}
 
 
 VALU_PEAK_LANE_INST = 256 * 4 * 32 * 2.4e9   # 7.86e13: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
