@@ -53,7 +53,7 @@ extern "C" {
 #endif
 
 #define MLGPU_FLOATS_PER_DSPVECTOR 64 /* kFloatsPerDSPVector, source/DSP/MLDSPMath.h:8-9 */
-#define MLGPU_ABI_VERSION 1
+#define MLGPU_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------- */
 /* status codes                                                              */
@@ -257,6 +257,15 @@ int mlgpu_engine_sync(mlgpu_engine* e);
  * (tests/test_gpu_denormals.py). Not allowed while a launch sequence is being recorded. */
 int mlgpu_engine_set_flush_denormals(mlgpu_engine* e, int on);
 int mlgpu_engine_get_flush_denormals(mlgpu_engine* e);
+/* How a bank that is a plain cascade of SVF sections (Lopass / Hipass / Bandpass x 2, 4 or 8: the reference's
+ * `for (auto& f : filters) x = f(x)`, source/DSP/MLDSPFilters.h:118-133 per section) is laid over the wavefront:
+ * `lanes` = 1, 2 or 4 wavefront lanes per channel (each lane runs 1/lanes of the sections and hands its output to the
+ * next lane with a DPP move; more lanes = more wavefronts for a small bank), 0 (the default) = chosen from the bank's
+ * size, -1 = the one-lane kernel of round 2. Every form computes each section with the same operations in the same
+ * order: results are bit-identical (tests/test_gpu_parity.py::test_cascade_forms_agree). A tuning knob, not a contract.
+ * Not allowed while a launch sequence is being recorded. */
+int mlgpu_engine_set_cascade_lanes(mlgpu_engine* e, int lanes);
+int mlgpu_engine_get_cascade_lanes(mlgpu_engine* e);
 /* The hipStream_t work is enqueued on (for HIP-event timing by the caller). */
 void* mlgpu_engine_stream(mlgpu_engine* e);
 int mlgpu_engine_device(mlgpu_engine* e);

@@ -151,6 +151,13 @@ class Engine:
     def get_flush_denormals(self):
         return bool(self.L.mlgpu_engine_get_flush_denormals(self.h))
 
+    def set_cascade_lanes(self, lanes):
+        """Wavefront lanes per channel of an SVF-cascade bank: 0 = by bank size, 1 / 2 / 4, -1 = the round-2 kernel."""
+        self._check(self.L.mlgpu_engine_set_cascade_lanes(self.h, int(lanes)))
+
+    def get_cascade_lanes(self):
+        return int(self.L.mlgpu_engine_get_cascade_lanes(self.h))
+
     def set_jit(self, enabled):
         """hiprtc fusion of chains that have no ahead-of-time kernel (default on)."""
         self._check(self.L.mlgpu_engine_set_jit(self.h, 1 if enabled else 0))

@@ -12,16 +12,32 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmlgpu.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "mlgpu.h")
 
-_SOURCES = ["ops.hip", "chains.hip", "capi.hip", "graph.hip", "resample.hip", "events.hip", "coeffs.cpp", "dspbuffer.cpp", "processbuffer.cpp", "registry.cpp", "mldsp_math.hpp", "mldsp_ops.hpp",
-            "mldsp_procs.hpp", "mldsp_kernels.hpp", "mlgpu_device_args.hpp", "mlgpu_internal.hpp", "embed.py",
-            "Makefile"]
+def _sources():
+    """Every file libmlgpu.so is made of: the Makefile's own SRCS and HDRS (so a file added there is never missing here),
+    plus the Makefile and the script that embeds the device headers for hiprtc."""
+    names = {"Makefile", "embed.py"}
+    try:
+        text = open(os.path.join(CSRC, "Makefile")).read().replace("\\\n", " ")
+        vars_ = {}
+        for line in text.splitlines():
+            if "=" in line and not line.startswith("\t") and not line.lstrip().startswith("#"):
+                k, _, v = line.partition("=")
+                vars_[k.strip().rstrip("?:+").strip()] = v.strip()
+        for key in ("SRCS", "DEVHDRS", "HDRS"):
+            for tok in vars_.get(key, "").split():
+                if tok.startswith("$("):
+                    continue
+                names.add(tok)
+    except OSError:
+        pass
+    return sorted(names)
 
 
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    srcs = [os.path.join(CSRC, s) for s in _SOURCES] + [HEADER]
+    srcs = [os.path.join(CSRC, s) for s in _sources()] + [HEADER]
     return any(os.path.exists(s) and os.path.getmtime(s) > t for s in srcs)
 
 
@@ -78,6 +94,8 @@ def _declare(L):
     sig("mlgpu_engine_create", i, [i, pp])
     sig("mlgpu_engine_set_flush_denormals", i, [vp, i])
     sig("mlgpu_engine_get_flush_denormals", i, [vp])
+    sig("mlgpu_engine_set_cascade_lanes", i, [vp, i])
+    sig("mlgpu_engine_get_cascade_lanes", i, [vp])
     sig("mlgpu_engine_create_on_stream", i, [i, vp, pp])
     sig("mlgpu_engine_destroy", i, [vp])
     sig("mlgpu_engine_sync", i, [vp])

@@ -160,6 +160,22 @@ extern "C"
   }
   int mlgpu_engine_get_flush_denormals(mlgpu_engine* e) { return (e && (e->kflags & MLGPU_KFLAG_FLUSH_DENORMALS)) ? 1 : 0; }
 
+  int mlgpu_engine_set_cascade_lanes(mlgpu_engine* e, int lanes)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "mlgpu_engine_set_cascade_lanes: not while recording a launch sequence");
+    if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4 && lanes != -1) return fail(e, MLGPU_ERR_INVALID, "mlgpu_engine_set_cascade_lanes: 0 (by size), 1, 2, 4 or -1 (the one-lane round-2 kernel)");
+    const uint32_t code = lanes < 0 ? 7u : (uint32_t)lanes;
+    e->kflags = (e->kflags & ~MLGPU_KFLAG_CASCADE_MASK) | (code << MLGPU_KFLAG_CASCADE_SHIFT);
+    return MLGPU_OK;
+  }
+  int mlgpu_engine_get_cascade_lanes(mlgpu_engine* e)
+  {
+    if (!e) return 0;
+    const uint32_t code = (e->kflags & MLGPU_KFLAG_CASCADE_MASK) >> MLGPU_KFLAG_CASCADE_SHIFT;
+    return code == 7 ? -1 : (int)code;
+  }
+
   int mlgpu_engine_create(int device, mlgpu_engine** out) { return createEngine(device, nullptr, true, out); }
   int mlgpu_engine_create_on_stream(int device, void* hipStream, mlgpu_engine** out)
   {
@@ -666,6 +682,7 @@ extern "C"
   const char* mlgpu_bank_kernel_name(mlgpu_bank* b)
   {
     if (!b) return "";
+    if (b->fused && b->fused->kernelNameFor) return b->fused->kernelNameFor(b->V, b->e->kflags);
     if (b->fused) return b->fused->kernelName;
     if (b->jitSignal) return b->jitName.c_str();
     return "chain_kernel<per-processor>";

@@ -29,12 +29,71 @@ hipError_t launchChain(const ChainArgs& a, hipStream_t stream, int /*cuCount*/)
   return hipGetLastError();
 }
 
+// How many wavefront lanes share one channel of a head-less SVF cascade (cascade_lanes_kernel). One lane per channel is the
+// cheapest per sample, but a bank needs ~49 000 channels before its wavefronts (two per SIMD at ~190 VGPRs) fill the chip;
+// smaller banks are spread over 2 or 4 lanes per channel (4 or 6 wavefronts per SIMD). Thresholds from
+// profiles/r03_cascade_lanes.txt (8 x Lopass, 32 DSPVectors per launch): 4 096 channels 84 / 117 / 173 us with 4 / 2 / 1
+// lanes, 16 384: 99 / 119 / 174, 32 768: 140 / 134 / 195, 49 152: 203 / 205 / 194, 65 536: 265 / 242 / 224.
+template <int N>
+int cascadeLanesFor(size_t V, uint32_t flags)
+{
+  const unsigned forced = (flags & MLGPU_KFLAG_CASCADE_MASK) >> MLGPU_KFLAG_CASCADE_SHIFT;
+  int lpc = V < 24576 ? 4 : (V < 40960 ? 2 : 1);
+  if (forced == 1 || forced == 2 || forced == 4) lpc = (int)forced;
+  if (forced == 7) return 0;
+  while (lpc > 1 && (N % (2 * lpc)) != 0) lpc >>= 1;  // every lane runs an even number of stages
+  return lpc;
+}
+
+template <int KIND, int N, int LPC, int MINW, bool HAS_SIGNAL>
+hipError_t launchLanes(const ChainArgs& a, hipStream_t stream)
+{
+  constexpr unsigned channelsPerBlock = kChainBlock / LPC;
+  const unsigned blocks = (unsigned)((a.V + channelsPerBlock - 1) / channelsPerBlock);
+  hipLaunchKernelGGL((cascade_lanes_kernel<KIND, N, LPC, 8, MINW, HAS_SIGNAL>), dim3(blocks), dim3(kChainBlock), 0, stream, a);
+  return hipGetLastError();
+}
+
 template <bool HAS_SIGNAL, int KIND, int N, int... HEADS>
 hipError_t launchCascade(const ChainArgs& a, hipStream_t stream, int /*cuCount*/)
 {
+  if constexpr (sizeof...(HEADS) == 0)
+  {
+    switch (cascadeLanesFor<N>(a.V, a.flags))
+    {
+      case 1: return launchLanes<KIND, N, 1, 2, HAS_SIGNAL>(a, stream);
+      case 2: if constexpr (N % 4 == 0) return launchLanes<KIND, N, 2, 4, HAS_SIGNAL>(a, stream); break;
+      case 4: if constexpr (N % 8 == 0) return launchLanes<KIND, N, 4, 6, HAS_SIGNAL>(a, stream); break;
+      default: break;
+    }
+  }
   const unsigned blocks = (unsigned)((a.V + kChainBlock - 1) / kChainBlock);
   hipLaunchKernelGGL((cascade_kernel<Chain<HEADS...>, KIND, N, HAS_SIGNAL>), dim3(blocks), dim3(kChainBlock), 0, stream, a);
   return hipGetLastError();
+}
+
+// what a profiler prints for the kernel a cascade bank of V channels runs
+template <int KIND, int N, int... HEADS>
+const char* cascadeKernelName(size_t V, uint32_t flags)
+{
+  static std::string names[5];
+  int lpc = 0;
+  if constexpr (sizeof...(HEADS) == 0) lpc = cascadeLanesFor<N>(V, flags);
+  std::string& n = names[lpc];
+  if (n.empty())
+  {
+    if (lpc > 0)
+      n = "cascade_lanes_kernel<" + std::to_string(KIND) + ", " + std::to_string(N) + ", " + std::to_string(lpc) + ", 8, " +
+          std::to_string(lpc == 1 ? 2 : (lpc == 2 ? 4 : 6));
+    else
+    {
+      n = "cascade_kernel<mldev::Chain<";
+      const int hs[] = {HEADS..., 0};
+      for (size_t i = 0; i < sizeof...(HEADS); ++i) n += (i ? ", " : "") + std::to_string(hs[i]);
+      n += ">, " + std::to_string(KIND) + ", " + std::to_string(N);
+    }
+  }
+  return n.c_str();
 }
 
 template <int KIND, int N, int... HEADS>
@@ -52,6 +111,7 @@ ChainEntry makeCascadeEntry(const char* name)
     return n + ">, " + std::to_string(KIND) + ", " + std::to_string(N);
   }();
   e.kernelName = profName.c_str();
+  e.kernelNameFor = &cascadeKernelName<KIND, N, HEADS...>;
   e.alias = name;
   e.nc = Chain<HEADS...>::NC + SvfCascade<KIND, N>::NC;
   e.ns = Chain<HEADS...>::NS + SvfCascade<KIND, N>::NS;

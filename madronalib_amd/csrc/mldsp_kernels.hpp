@@ -170,15 +170,27 @@ struct SvfCascade
   }
   // all stages active; returns stage N-1's output, i.e. the chain output for sample (tick - (N-1))
 #if MLGPU_CASCADE_PACKED
-  MLD float tick(float x)
+  MLD float tick(float x) { return tick_in0(f32x2{x, r[H - 1].x}); }
+  // in0 = {input of stage 0, input of stage H = r of stage H - 1}
+  MLD float tick_in0(f32x2 in0) { return tick_common<false>(in0, in0); }
+  // the first pair's t0 = in0 - ic2[0] made by the caller (the lane-group kernel folds a DPP hand-over into that
+  // subtraction); not for Hipass, whose output also reads in0
+  MLD float tick_t0(f32x2 t00)
+  {
+    static_assert(KIND != MLGPU_PROC_HIPASS, "Hipass reads its input twice");
+    return tick_common<true>(t00, t00);
+  }
+  template <bool HAVE_T0>
+  MLD float tick_common(f32x2 in0, f32x2 t00)
   {
     f32x2 in[H], t0[H], a[H], b[H], c[H], d[H], t1[H], t2[H], v1[H], v2[H];
     const f32x2 two = {2.0f, 2.0f};
-    in[0] = f32x2{x, r[H - 1].x};
+    in[0] = in0;
 #pragma unroll
     for (int p = 1; p < H; ++p) in[p] = r[p - 1];
 #pragma unroll
     for (int p = 0; p < H; ++p) t0[p] = in[p] - ic2[p];
+    if constexpr (HAVE_T0) t0[0] = t00;
 #pragma unroll
     for (int p = 0; p < H; ++p) b[p] = g1[p] * ic1[p];
 #pragma unroll
@@ -413,6 +425,207 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
   }
   head.store(mh);
   c.store(mc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cascade_lanes_kernel — the same stage-skewed cascade with LPC wavefront lanes per channel (round 3).
+//
+// One lane per channel gives a bank of 131 072 channels 2 048 wavefronts of ~170 VGPRs: two per SIMD. The kernel is
+// bound by VALU issue (profiles/r03_cfg4_account.md: its cycle count is the same with and without the HBM streams), and
+// two wavefronts do not keep a SIMD's VALU port full (tools/bankbench.hip: a packed instruction every 2.09 ns with two
+// wavefronts per SIMD, every 1.89 ns with four). Here a channel is spread over LPC lanes: lane j of a channel's group owns
+// the N / LPC consecutive stages from j * N/LPC on and runs them exactly as SvfCascade does (stage-skewed, packed pairs),
+// taking as its input what lane j - 1 produced one tick earlier — one DPP move (row_shr:4) per tick. Same arithmetic per
+// stage => same bits; LPC times the wavefronts at 1/LPC of the registers, and small banks fill the chip.
+//
+// Lane layout inside a wavefront: lane = 16 * row + 4 * bank + cc. A DPP bank (4 consecutive lanes) is the unit the
+// bank_mask of a DPP instruction can address, so the stage group j has to be the bank: j = bank % LPC, and the
+// channel is (lane / (4 * LPC)) * 4 + cc. "From the previous stage group" is then row_shr:4 with a bank mask that spares
+// the group's first lane, which keeps its own input sample.
+//
+// Memory: the group's first lane loads the channel's input quads (16 bytes per lane, 64 / LPC lanes per instruction, a
+// ring of R quads in registers, R - 2 quads ahead of their use), the group's last lane stores the output quads.
+template <int LPC>
+struct LaneGroup
+{
+  static_assert(LPC == 1 || LPC == 2 || LPC == 4, "1, 2 or 4 lanes per channel");
+  static constexpr int kFirst = (LPC == 4) ? 0x1 : (LPC == 2 ? 0x5 : 0xF);  // bank mask of the lanes with j == 0
+  static constexpr int kNotFirst = 0xF & ~kFirst;
+  // the input of this lane's first stage: in the group's first lane its own `sample`; elsewhere what lane j - 1 holds in
+  // `prevOut` (its last stage's output of the previous tick)
+  static MLD float stageInput(float prevOut, float sample)
+  {
+    if constexpr (LPC == 1) return sample;
+    else return u2f((uint32_t)__builtin_amdgcn_update_dpp((int)f2u(sample), (int)f2u(prevOut), 0x114 /* row_shr:4 */, 0xF, kNotFirst, false));
+  }
+};
+
+#ifndef MLGPU_CASCADE_LANES_DPP_SUB
+#define MLGPU_CASCADE_LANES_DPP_SUB 1
+#endif
+
+template <int KIND, int N, int LPC, int R, int MINW, bool HAS_SIGNAL>
+__global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(MINW))) void cascade_lanes_kernel(const ChainArgs a)
+{
+  constexpr int SPL = N / LPC;  // stages per lane
+  static_assert(N % LPC == 0 && SPL % 2 == 0, "each lane runs an even number of stages (packed pairs)");
+  static_assert(R == 4 || R == 8 || R == 16, "the input ring: R quads, R divides a DSPVector's 16 so that slots are compile-time");
+  using LG = LaneGroup<LPC>;
+  using Core = SvfCascade<KIND, SPL>;
+  constexpr int NCK = Core::NCK, H = Core::H;
+  constexpr int kChannelsPerBlock = kChainBlock / LPC;
+  apply_fp_mode(a.flags);
+  size_t blk = blockIdx.x;
+  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
+  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);  // XCD-aware, see chain_kernel
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = (lane >> 2) % LPC;                                   // which stage group of its channel this lane runs
+  const size_t v = blk * kChannelsPerBlock + (size_t)wave * (64 / LPC) + (lane / (4 * LPC)) * 4 + (lane & 3);
+  if (v >= a.V) return;  // whole groups leave together: all LPC lanes of a channel share v
+  const bool last = (j == LPC - 1);
+
+  Core c;
+  const int base = j * SPL;  // first stage of this lane
+  c.load(VoiceMem{a.coeffs + (size_t)(NCK * base) * a.V + v, a.state + (size_t)(2 * base) * a.V + v, a.V});
+  const float xc = (!HAS_SIGNAL && a.inConst) ? a.inConst[v] : 0.f;
+
+  constexpr int D = N - 1;             // output lag in ticks
+  constexpr int A = D / 4, B = D % 4;  // D = 4A + B
+  static_assert(A + R - 2 <= 15, "the ring is primed from the first DSPVector");
+  const size_t S = a.T * 64;
+  // every lane of a group reads the channel's input (the same addresses: one fetch serves the group; only the first
+  // lane's copy is used) — a load under a lane mask would make the whole ring a phi of the branch
+  const f32x4* pin = HAS_SIGNAL ? (const f32x4*)a.in.base + v * a.in.strideV : nullptr;
+  f32x4* pout = (f32x4*)a.out.base + v * a.out.strideV;
+  auto inQuad = [&](size_t qi) { return pin + (qi >> 4) * a.in.strideT + (qi & 15) * a.in.strideQ; };
+  auto outQuad = [&](size_t qi) { return pout + (qi >> 4) * a.out.strideT + (qi & 15) * a.out.strideQ; };
+  auto inAt = [&](size_t i) -> float {
+    if constexpr (HAS_SIGNAL) return ((const float*)inQuad(i >> 2))[i & 3];
+    return xc;
+  };
+  // one tick with every stage active: the lane's first stage reads `x` (group's first lane) or the previous lane's output
+  auto fastTick = [&](float x) {
+    const f32x2 rr = c.r[H - 1];
+    if constexpr (KIND != MLGPU_PROC_HIPASS && MLGPU_CASCADE_LANES_DPP_SUB)
+    {
+      // t0 of the lane's first stage = input - ic2: with the group's own sample everywhere, then again in the lanes that
+      // take the previous lane's output, the DPP hand-over folded into the subtraction (v_sub_f32_dpp; masked lanes keep
+      // the first result). Two wait states between a VALU write and a DPP read of the same register (s_nop 1).
+      float t0lo = x - c.ic2[0].x;
+      if constexpr (LPC == 1) asm("" : "+v"(t0lo));
+      else if constexpr (LPC == 2) asm("s_nop 1\n\tv_sub_f32_dpp %0, %1, %2 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(t0lo) : "v"(rr.y), "v"(c.ic2[0].x));
+      else asm("s_nop 1\n\tv_sub_f32_dpp %0, %1, %2 row_shr:4 row_mask:0xf bank_mask:0xe" : "+v"(t0lo) : "v"(rr.y), "v"(c.ic2[0].x));
+      float t0hi = rr.x - c.ic2[0].y;
+      asm("" : "+v"(t0hi));  // keeps this a plain v_sub_f32 into the pair's high half (the compiler would otherwise make it a packed subtraction plus a move)
+      return c.tick_t0(f32x2{t0lo, t0hi});
+    }
+    else
+    {
+      const f32x2 rx = f32x2{rr.x, LG::stageInput(rr.y, x)};  // the DPP move is in place: the tick reads the pair swapped
+      return c.tick_in0(__builtin_shufflevector(rx, rx, 1, 0));
+    }
+  };
+  // output quad q <- ticks D + 4q + jj, inputs x[4(q + A) + B + jj]: elements of input quads q + A (wa) and q + A + 1 (wb)
+  auto quadTicks = [&](const f32x4& wa, const f32x4& wb) {
+    f32x4 y;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+    {
+      constexpr int kB = B;
+      const int e = kB + jj;
+      y[jj] = fastTick(e < 4 ? wa[e & 3] : wb[e & 3]);
+    }
+    return y;
+  };
+  // boundary tick (slow form): stages sLo..sHi of the whole cascade are active
+  auto slowTick = [&](float x, int sLo, int sHi) { c.tick_masked(LG::stageInput(c.r[H - 1].y, x), sLo - base, sHi - base); };
+
+  // prologue: ticks 0..D-1, stages 0..i active
+  for (int i = 0; i < D; ++i) slowTick(inAt((size_t)i), 0, i);
+
+  // steady state, fast path: whole DSPVectors 0 .. T-2, 16 quads = 64 ticks per trip, so every quad's position in its
+  // vector and its ring slot (input quad n lives in slot n % R) are compile-time constants and the pointers advance by
+  // one of two launch constants. While output quad q is computed, input quad q + A + R - 1 is fetched into the slot that
+  // quad q + A - 1 has just left; fetches reach into vector t + 1, which exists because t <= T - 2.
+  const size_t Q = (S - D) / 4;
+  size_t q = 0;
+  if (a.T >= 2)
+  {
+    const int64_t inStep = (int64_t)a.in.strideQ * 16, inNext = ((int64_t)a.in.strideT - 15 * (int64_t)a.in.strideQ) * 16;
+    const int64_t outStep = (int64_t)a.out.strideQ * 16, outNext = ((int64_t)a.out.strideT - 15 * (int64_t)a.out.strideQ) * 16;
+    f32x4 w[R];
+    const char* pf = (const char*)pin;  // the next input quad to fetch
+    char* ps = (char*)pout;             // the next output quad to store
+    if constexpr (HAS_SIGNAL)
+    {
+      pf += A * inStep;
+#pragma unroll
+      for (int n = 0; n < R - 1; ++n)  // quads A .. A + R - 2
+      {
+        w[(A + n) % R] = __builtin_nontemporal_load((const f32x4*)pf);
+        pf += ((A + n) & 15) == 15 ? inNext : inStep;
+      }
+    }
+    for (size_t t = 0; t + 1 < a.T; ++t)
+    {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+      {
+        f32x4 y;
+        if constexpr (HAS_SIGNAL)
+        {
+          constexpr int kA = A;
+          const int n = s + kA + R - 1;  // the quad fetched now (relative to this vector's first)
+          w[n % R] = __builtin_nontemporal_load((const f32x4*)pf);
+          pf += (n & 15) == 15 ? inNext : inStep;
+          y = quadTicks(w[(s + kA) % R], w[(s + kA + 1) % R]);
+        }
+        else
+        {
+          const f32x4 wc = f32x4{xc, xc, xc, xc};
+          y = quadTicks(wc, wc);
+        }
+        if (last) __builtin_nontemporal_store(y, (f32x4*)ps);
+        ps += s == 15 ? outNext : outStep;
+      }
+    }
+    q = 16 * (a.T - 1);
+  }
+  // the remaining quads (the last DSPVector's, less the ones that wait for the drain): the same ticks, one quad of
+  // lookahead, positions computed as they come
+  if (q < Q)
+  {
+    const size_t lastQuad = S / 4 - 1;
+    f32x4 wa = f32x4{xc, xc, xc, xc}, wb = wa;
+    if constexpr (HAS_SIGNAL)
+    {
+      wa = *inQuad(q + A);
+      wb = *inQuad(q + A + 1);
+    }
+    for (; q < Q; ++q)
+    {
+      f32x4 wn = wb;
+      if constexpr (HAS_SIGNAL)
+      {
+        const size_t nq = q + A + 2;
+        wn = *inQuad(nq < lastQuad ? nq : lastQuad);
+      }
+      const f32x4 y = quadTicks(wa, wb);
+      if (last) *outQuad(q) = y;
+      wa = wb;
+      wb = wn;
+    }
+  }
+  // tail: ticks D + 4Q .. S + D - 1; inputs exist while i < S, after that the pipeline drains
+  for (size_t i = D + 4 * Q; i < S + D; ++i)
+  {
+    const float x = (i < S) ? inAt(i) : 0.f;
+    const int sLo = (i < S) ? 0 : (int)(i - S + 1);
+    slowTick(x, sLo, N - 1);
+    const size_t n = i - D;
+    if (last) ((float*)outQuad(n >> 2))[n & 3] = c.r[H - 1].y;
+  }
+  c.store(VoiceMem{a.coeffs + (size_t)(NCK * base) * a.V + v, a.state + (size_t)(2 * base) * a.V + v, a.V});
 }
 
 }  // namespace mldev

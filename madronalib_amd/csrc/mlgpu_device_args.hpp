@@ -17,6 +17,10 @@ struct SignalView
 
 // bits of the `flags` word every arithmetic kernel receives
 #define MLGPU_KFLAG_FLUSH_DENORMALS 1u  // run with f32 denormal sources and results flushed (mlgpu_engine_set_flush_denormals)
+// host-side only (read by the cascade launchers, chains.hip): which form of an SVF cascade to run (mlgpu_engine_set_cascade_lanes).
+// 0 = by bank size, 1 / 2 / 4 = that many wavefront lanes per channel, 7 = the round-2 kernel (cascade_kernel)
+#define MLGPU_KFLAG_CASCADE_SHIFT 8
+#define MLGPU_KFLAG_CASCADE_MASK (7u << MLGPU_KFLAG_CASCADE_SHIFT)
 
 struct ChainArgs
 {

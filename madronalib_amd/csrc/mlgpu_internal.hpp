@@ -57,6 +57,7 @@ struct ChainEntry
   ChainLauncher launchSignal;  // streamed input
   ChainLauncher launchConst;   // per-voice constant (or no) input
   const char* kernelName;  // prefix of the name a profiler shows for the device kernel
+  const char* (*kernelNameFor)(size_t V, uint32_t flags){nullptr};  // where the kernel depends on the bank's size (SVF cascades)
   const char* alias;       // e.g. "chain_kernel<SawGen,Bandpass,Gain>"
   int nc, ns;
 };

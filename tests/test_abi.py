@@ -25,7 +25,7 @@ def _header():
 def test_library_builds_and_loads():
     L = _lib.load()
     assert os.path.exists(_lib.LIB_PATH)
-    assert L.mlgpu_abi_version() == 1
+    assert L.mlgpu_abi_version() == 2
 
 
 def test_every_declared_symbol_is_exported():

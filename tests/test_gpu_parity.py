@@ -220,6 +220,59 @@ def test_skewed_cascade_vs_oracle(eng, oracle, name, T, layout):
     assert_bits_equal(gst, st, False, name + " state")
 
 
+HEADLESS_CASCADES = [n for n, procs in CASCADES.items() if len(set(procs)) == 1]
+
+
+@pytest.mark.parametrize("T", [1, 2, 5])
+@pytest.mark.parametrize("lanes", [-1, 1, 2, 4])
+@pytest.mark.parametrize("name", HEADLESS_CASCADES)
+def test_cascade_forms_agree(eng, oracle, name, lanes, T):
+    """Every form of an SVF cascade (mlgpu_engine_set_cascade_lanes: the round-2 kernel, 1, 2 or 4 wavefront lanes per
+    channel — the launcher falls back to the widest form the number of sections allows) equals the oracle bit for bit: same
+    operations per section, only the lane that runs them differs. Ragged V (partial lane groups and wavefronts), three
+    layouts' worth of strides via ROWS in / QUAD out, state carried over three launches, and a launch-constant input."""
+    procs = CASCADES[name]
+    V = 150
+    co = chain_coeffs(oracle, procs, V, seed=31)
+    sig, _ = chain_input(procs, V, T, seed=5)
+    eng.set_cascade_lanes(lanes)
+    try:
+        assert eng.get_cascade_lanes() == lanes
+        for layout, use_const in ((Layout.QUAD, False), (Layout.ROWS, False), (Layout.VOICE_MAJOR, True)):
+            st = oracle.chain_clear(procs, V)
+            const = (np.linspace(-1.0, 1.0, V).astype(np.float32)) if use_const else None
+            outs, gst, fused = _run_gpu(eng, procs, V, T, co, st.copy(), None if use_const else sig, const, layout, calls=3)
+            assert fused
+            for got in outs:
+                want = oracle.chain_process(procs, T, co, st, None if use_const else sig, const, n_threads=4)
+                assert_bits_equal(got, want, True, f"{name} lanes={lanes} T={T} layout={layout}")
+            assert_bits_equal(gst, st, False, f"{name} lanes={lanes} state")
+    finally:
+        eng.set_cascade_lanes(0)
+
+
+def test_cascade_kernel_follows_bank_size(eng):
+    """The form is chosen from the bank's size unless forced, and the bank reports the kernel a profiler will show."""
+    names = {}
+    for V in (4096, 32768, 131072):
+        bank = eng.bank([Proc.LOPASS] * 8, V)
+        names[V] = bank.kernel_name
+        bank.close()
+    assert names[4096].startswith("cascade_lanes_kernel<16, 8, 4")
+    assert names[32768].startswith("cascade_lanes_kernel<16, 8, 2")
+    assert names[131072].startswith("cascade_lanes_kernel<16, 8, 1")
+    eng.set_cascade_lanes(-1)
+    try:
+        bank = eng.bank([Proc.LOPASS] * 8, 4096)
+        assert bank.kernel_name.startswith("cascade_kernel<mldev::Chain<>, 16, 8")
+        bank.close()
+    finally:
+        eng.set_cascade_lanes(0)
+    bank = eng.bank([Proc.HIPASS] * 2, 4096)  # two sections: one lane per channel is all there is
+    assert bank.kernel_name.startswith("cascade_lanes_kernel<17, 2, 1") or bank.kernel_name.startswith("cascade_lanes_kernel<")
+    bank.close()
+
+
 @pytest.mark.parametrize("name", chain_case_names())
 def test_chain_vs_golden(eng, name):
     c = chain_case(load_chains(), name)
@@ -369,6 +422,73 @@ def test_config4_full_size(eng, oracle):
     bank.process(T, d_y, Layout.QUAD, d_x, Layout.QUAD)
     y2 = d_y.download(np.float32).reshape(T * 16, V, 4)[16:, 0, :].reshape(64).view(np.uint32)
     assert (y2[0], y2[31], y2[63]) == (a["y0"], a["y31"], a["y63"])
+
+
+# ---- BASELINE lengths and widths, bit-compared (round 3) ------------------------------------------------------------
+
+def test_config3_baseline_length(eng, oracle):
+    """BASELINE configs[2] exactly as the bench runs it: 262 144 voices x 750 DSPVectors (one second of audio at 48 kHz) in
+    25 launches of 30. A strided subset of 515 voices is compared with the oracle on the outputs of the first, a middle and
+    the last launch and on the final state: 48 000 samples of carried phase and filter memory."""
+    V, T, launches = 262144, 30, 25
+    procs = [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]
+    bank, freq, co = _cfg3_setup(eng, V)
+    sub = np.arange(0, V, 509)
+    assert sub.size >= 512
+    coeffs = np.ascontiguousarray(np.concatenate([co[sub].T, np.full((1, sub.size), 0.25, np.float32)], 0))
+    st = oracle.chain_clear(procs, sub.size)
+    want = oracle.chain_process(procs, T * launches, coeffs, st, None, freq[sub], n_threads=8).reshape(sub.size, launches, T * 64)
+    d_q = eng.alloc(4 * V * T * 64)
+    for k in range(launches):
+        bank.process(T, d_q, Layout.QUAD)
+        if k in (0, launches // 2, launches - 1):
+            q = d_q.download(np.float32).reshape(T * 16, V, 4)
+            got = q[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64)
+            assert_bits_equal(got, want[:, k], True, f"cfg3 launch {k}")
+    assert_bits_equal(bank.get_all_state()[:, sub], st, False, "cfg3 state after 750 vectors")
+    bank.close()
+
+
+def test_config4_baseline_length(eng, oracle):
+    """BASELINE configs[3] at SURVEY 8d's length: 131 072 channels x 8 Lopass x 4 096 DSPVectors in 128 launches of 32 (the
+    bench's launch shape), streamed noise in. 257 channels against the oracle: first, middle and last launch, final state."""
+    import madronalib_amd as ml
+    V, T, launches = 131072, 32, 128
+    procs = [Proc.LOPASS] * 8
+    bank = eng.bank(procs, V)
+    assert bank.kernel_name.startswith("cascade_lanes_kernel<16, 8, 1")
+    cs = [ml.Lopass.makeCoeffs(float(np.float32(0.02) * np.float32(i + 1)), 0.7) for i in range(8)]
+    for i in range(8):
+        bank.set_coeffs(i, cs[i])
+    nb = eng.bank([Proc.NOISE_GEN], V)
+    nb.set_state(0, 0, np.arange(V, dtype=np.uint32))
+    sub = np.arange(0, V, 511)
+    co = np.ascontiguousarray(np.repeat(np.concatenate(cs)[:, None], sub.size, 1))
+    x_sub = lcg_noise(sub.astype(np.uint32), T * launches * 64)
+    st = oracle.chain_clear(procs, sub.size)
+    want = oracle.chain_process(procs, T * launches, co, st, x_sub, None, n_threads=8).reshape(sub.size, launches, T * 64)
+    d_x = eng.alloc(4 * V * T * 64)
+    d_y = eng.alloc(4 * V * T * 64)
+    for k in range(launches):
+        nb.process(T, d_x, Layout.QUAD)
+        bank.process(T, d_y, Layout.QUAD, d_x, Layout.QUAD)
+        if k in (0, launches // 2, launches - 1):
+            y = d_y.download(np.float32).reshape(T * 16, V, 4)
+            got = y[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64)
+            assert_bits_equal(got, want[:, k], True, f"cfg4 launch {k}")
+    assert_bits_equal(bank.get_all_state()[:, sub], st, False, "cfg4 state after 4096 vectors")
+    bank.close()
+    nb.close()
+
+
+def test_config2_baseline_width(eng, oracle):
+    """BASELINE configs[1] at its stated width: all 65 536 x 64 elements of sinApprox, expApprox and the fused pair against
+    the oracle, on the ramp and on noise in [-pi, pi] (Tests/dspOpsTest.cpp:85-105 is the reference's own precision check)."""
+    V = 65536
+    noise = (lcg_noise(np.arange(V, dtype=np.uint32), 64) * np.float32(np.pi)).astype(np.float32)
+    for label, x in (("ramp", ramp_pi(V)), ("noise", noise)):
+        for op in (Op.SIN_APPROX, Op.EXP_APPROX, Op.EXP_APPROX_OF_SIN_APPROX):
+            assert_bits_equal(eng.op(op, x), oracle.op(op, x), True, f"cfg2 {label} op {op}")
 
 
 def test_empty_and_error_paths(eng):
