@@ -456,6 +456,9 @@ def cpu_baseline_cfg5(budget_s=10.0, full=False):
 VALU_PEAK_LANE_INST = 256 * 4 * 32 * 2.4e9   # 7.86e13: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
 
 
+_T_PROCESS = time.perf_counter()   # this rank's process reached bench.py's top level (interpreter + numpy import are before it)
+
+
 def workload_key(name, V, T):
     """What identifies one measured case in profiles/pmc_workloads.json: the workload, its variant switches and its size."""
     var = [f"{k.lower().replace('mlgpu_', '')}={os.environ[k]}" for k in ("MLGPU_DELAY_WINDOWS", "MLGPU_UNIFORM_DELAY", "MLGPU_EVENT_ROWS",
@@ -484,9 +487,22 @@ def run_rank(args, rank, local_rank, world, rdv):
     lo, hi = partition(total, world, rank)
     assert hi - lo == V
 
+    t_rank = time.perf_counter()
     eng = ml.Engine(local_rank)
     info = eng.device_info()
+    t_engine = time.perf_counter()
+    if args.cascade_lanes is not None:
+        eng.set_cascade_lanes(args.cascade_lanes)
+    if args.strict_svf:
+        eng.set_strict_svf(True)
     launch, alg_bytes, kernel_name, desc, _keep = setup_workload(eng, args.workload, V, T, lo, total)
+    launch()
+    eng.sync()
+    t_first = time.perf_counter()
+    # what a rank spends before it can launch (the 8-rank start of a node: N engines, N parameter set-ups, one hiprtc compile
+    # shared through the disk cache): reported per rank so that a slow start is visible, never part of the timed region
+    startup = {"import_s": t_rank - _T_PROCESS, "engine_s": t_engine - t_rank, "setup_to_first_launch_s": t_first - t_engine,
+               "jit": ml.jit_stats()}
 
     def step():
         for _ in range(L):
@@ -508,7 +524,9 @@ def run_rank(args, rank, local_rank, world, rdv):
             if g.tuning()[0]:
                 break
             launch()
+    t_b = time.perf_counter()
     fence()
+    startup["wait_at_first_barrier_s"] = time.perf_counter() - t_b
     t0 = time.perf_counter()
     eng.timer_start()
     for _ in range(args.steps):
@@ -520,7 +538,7 @@ def run_rank(args, rank, local_rank, world, rdv):
     rdv.barrier()
     elapsed = rdv.max(my_elapsed)
     ranks = rdv.gather({"rank": rank, "device": local_rank, "pci_bus_id": info["pci_bus_id"], "name": info["name"], "pid": os.getpid(),
-                        "voices": [lo, hi], "ms_per_step": my_elapsed / args.steps * 1e3, "kernel_ms": kernel_ms})
+                        "voices": [lo, hi], "ms_per_step": my_elapsed / args.steps * 1e3, "kernel_ms": kernel_ms, "startup": startup})
     if rank != 0:
         return None
     buses = [r["pci_bus_id"] for r in ranks]
@@ -533,6 +551,16 @@ def run_rank(args, rank, local_rank, world, rdv):
     units_per_launch = float(V) * T * 64
     key = workload_key(args.workload, V, T)
     pmc = pmc_record(key) or {}
+    # Counters cannot be read inside this run: they come from the rocprofv3 passes of tools/gpu_profile_all.sh. They describe
+    # THIS code only if they were recorded under the same device-source fingerprint (every .hip / .hpp + compiler flags)
+    # and for the kernel this run launched; otherwise they are dropped and the line says so.
+    pmc_stale = None
+    if pmc:
+        same_code = pmc.get("device_source_hash") == ml.device_source_hash()
+        same_kernel = kernel_name in pmc.get("kernel", "") or args.workload not in ("cfg3", "cfg4")
+        if not (same_code and same_kernel):
+            pmc_stale = "recorded for another build of the device code" if not same_code else f"recorded for kernel {pmc.get('kernel', '?')[:60]}"
+            pmc = {}
     traffic = None
     if pmc.get("fetch_bytes_per_launch_raw") is not None:
         raw, co = pmc["fetch_bytes_per_launch_raw"], META["coalesced_read_bytes"]
@@ -540,6 +568,15 @@ def run_rank(args, rank, local_rank, world, rdv):
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "kernel": kernel_name, "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes, "pmc_case": key if pmc else None}
+    if pmc_stale:
+        roof["pmc_stale"] = True
+        roof["pmc_stale_reason"] = pmc_stale
+    if pmc.get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE sums the 8 XCDs: / 8 = shader cycles per launch; over the live launch time = the clock the chip
+        # held under this load (it clocks to its power budget: MI355X_MICROARCH.md, DVFS)
+        cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0
+        roof["clock"] = {"cycles_per_launch": cyc, "ghz_live": cyc / (kernel_ms * 1e-3) / 1e9,
+                         "source": "GRBM_GUI_ACTIVE / 8 XCDs (profiles/pmc_workloads.json) / live launch duration"}
     if pmc.get("valu_wave_insts_per_launch"):
         # the second bound (SURVEY 8d "report both bounds"): VALU issue. SQ_INSTS_VALU counts wave-instructions; x64 lanes.
         ipu = pmc["valu_wave_insts_per_launch"] * 64.0 / units_per_launch
@@ -563,6 +600,8 @@ def run_rank(args, rank, local_rank, world, rdv):
         "roofline": roof,
         "ranks": ranks,
     }
+    if args.sustained and world == 1:
+        out["sustained"] = sustained_run(args, eng, step, launch, L, float(V) * T * 64, value)
     if args.oversubscribe:
         out["oversubscribed"] = f"{world} ranks on {len(set(buses))} GPU(s): launch-path test, not a scaling measurement"
     if args.workload == "cfg2":
@@ -592,24 +631,54 @@ def run_rank(args, rank, local_rank, world, rdv):
     return out
 
 
+def sustained_run(args, eng, step, launch, L, units_per_launch, short_value):
+    """Is the number sustained? Run the timed region's steps back to back for --sustained-seconds, one HIP-event bracket per
+    step (a step is L launches, ~10 ms: the sync between steps is < 0.3 % of it), then time 400 single launches. Reports the
+    rate of every wall second, the step-time distribution and the droop against the short timed region."""
+    def dist(xs):
+        xs = sorted(xs)
+        pick = lambda q: xs[min(len(xs) - 1, int(q * len(xs)))]  # noqa: E731
+        return {"n": len(xs), "min": xs[0], "p01": pick(0.01), "median": pick(0.5), "p99": pick(0.99), "max": xs[-1],
+                "mean": sum(xs) / len(xs)}
+    step_ms, t_end = [], time.perf_counter() + args.sustained_seconds
+    wall0 = time.perf_counter()
+    marks = []
+    while time.perf_counter() < t_end:
+        eng.timer_start()
+        step()
+        step_ms.append(eng.timer_stop_ms())
+        marks.append(time.perf_counter() - wall0)
+    per_second, k0 = [], 0
+    for sec in range(1, int(marks[-1]) + 1):
+        k1 = k0
+        while k1 < len(marks) and marks[k1] <= sec:
+            k1 += 1
+        if k1 > k0:
+            per_second.append(units_per_launch * L * (k1 - k0) / (sum(step_ms[k0:k1]) * 1e-3))
+        k0 = k1
+    launch_ms = []
+    for _ in range(400):
+        eng.timer_start()
+        launch()
+        launch_ms.append(eng.timer_stop_ms())
+    device_rate = units_per_launch * L * len(step_ms) / (sum(step_ms) * 1e-3)
+    res = {"seconds": marks[-1], "steps": len(step_ms), "launches_per_step": L,
+           "rate_device_time": device_rate, "rate_wall": units_per_launch * L * len(step_ms) / marks[-1],
+           "short_region_rate": short_value, "droop_vs_short_region": 1.0 - device_rate / short_value,
+           "per_second_rate": per_second, "per_second_min_over_max": min(per_second) / max(per_second) if per_second else None,
+           "step_ms": dist(step_ms), "single_launch_ms": dist(launch_ms),
+           "note": "rates from HIP events around each step (device time); rate_wall includes the host's sync between steps"}
+    with open(args.sustained, "w") as f:
+        json.dump(res, f, indent=1)
+    return {k: res[k] for k in ("seconds", "rate_device_time", "droop_vs_short_region", "per_second_min_over_max", "step_ms")}
+
+
 def launch_processes(args, argv):
     """`python bench.py --gpus N` with no launcher around it: start one rank process per GPU ourselves (rank r on device r),
-    lined up through a fresh rendezvous directory; rank 0's JSON line is this process's output."""
-    import subprocess
-    import tempfile
-    rdv_dir = tempfile.mkdtemp(prefix="mlgpu_rdv_")
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MLGPU_RDV_DIR=rdv_dir)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    try:
-        import shutil
-        shutil.rmtree(rdv_dir, ignore_errors=True)
-    except Exception:
-        pass
+    lined up through a fresh rendezvous directory; rank 0's JSON line is this process's output. A rank that dies - however it
+    dies - releases the others (madronalib_amd.rendezvous.run_rank_processes)."""
+    from madronalib_amd.rendezvous import run_rank_processes
+    rcs, out0 = run_rank_processes([sys.executable, os.path.abspath(__file__)] + argv, args.gpus)
     if any(rcs):
         raise SystemExit(f"bench.py: rank exit codes {rcs}")
     sys.stdout.write(out0)
@@ -656,6 +725,14 @@ def main():
                     help="TEST ONLY: let ranks share devices (rank r on device r mod visible) so the N>1 launch paths can be exercised on "
                          "a box with fewer GPUs; the line says so and is not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cascade-lanes", type=int, default=None, choices=[-1, 0, 1, 2, 4],
+                    help="force the form of SVF-cascade banks (mlgpu_engine_set_cascade_lanes): A/B runs of config 4")
+    ap.add_argument("--strict-svf", action="store_true",
+                    help="mlgpu_engine_set_strict_svf: SVF memories updated with two instructions instead of one fused (generated kernels)")
+    ap.add_argument("--sustained", metavar="FILE", default=None,
+                    help="after the timed region, run the same steps for --sustained-seconds more and write per-second rates and the "
+                         "distribution of step and launch times to FILE (profiles/r03_cfg3_sustained.json)")
+    ap.add_argument("--sustained-seconds", type=float, default=30.0)
     ap.add_argument("--print-case", action="store_true", help="print the key of this case in profiles/pmc_workloads.json and exit")
     args = ap.parse_args()
     if args.print_case:

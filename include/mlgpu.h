@@ -265,6 +265,16 @@ int mlgpu_engine_get_flush_denormals(mlgpu_engine* e);
  * order: results are bit-identical (tests/test_gpu_parity.py::test_cascade_forms_agree). A tuning knob, not a contract.
  * Not allowed while a launch sequence is being recorded. */
 int mlgpu_engine_set_cascade_lanes(mlgpu_engine* e, int lanes);
+/* Strict SVF arithmetic for the banks and graphs created from now on. The state-variable filters (Lopass, Hipass,
+ * Bandpass, LoShelf, HiShelf, Bell; source/DSP/MLDSPFilters.h:118-133, 189-193, 234-237, 288-302, 369-383, 427-441) update
+ * their memories with `ic += 2.0f * t` / `ic = 2 * v - ic`. By default that is one fused instruction - the same float
+ * unless 2 t alone overflows while the sum does not (|t| > 1.7e38, a filter already blowing up; numerical contract above).
+ * on != 0 spends the second instruction, and such kernels equal the reference bit for bit in that corner too
+ * (tests/test_gpu_parity.py::test_strict_svf_hostile_input). Kernels of a strict engine are generated with hiprtc when the
+ * bank or graph is made (cached on disk); existing banks and graphs keep the arithmetic they were made with. Cost:
+ * profiles/r03_strict_svf.txt. */
+int mlgpu_engine_set_strict_svf(mlgpu_engine* e, int on);
+int mlgpu_engine_get_strict_svf(mlgpu_engine* e);
 int mlgpu_engine_get_cascade_lanes(mlgpu_engine* e);
 /* The hipStream_t work is enqueued on (for HIP-event timing by the caller). */
 void* mlgpu_engine_stream(mlgpu_engine* e);
@@ -273,6 +283,10 @@ int mlgpu_engine_device(mlgpu_engine* e);
 const char* mlgpu_last_error(mlgpu_engine* e);
 const char* mlgpu_status_string(int status);
 int mlgpu_abi_version(void);
+/* SHA-256 (hex) of every device source file of this build and its compiler flags. Measurements that cannot be taken
+ * inside a run (rocprofv3 PMC counters, profiles/pmc_workloads.json) are recorded with it and refused by bench.py when
+ * the loaded library's differs, so a kernel change cannot inherit old counters. */
+const char* mlgpu_device_source_hash(void);
 /* Number of visible HIP devices (0 when there is none); never fails. */
 int mlgpu_device_count(void);
 /* Device facts used by the bench (name, CU count, memory bytes). */

@@ -27,6 +27,11 @@ class MlgpuError(RuntimeError):
         super().__init__(f"mlgpu status {status} ({L.mlgpu_status_string(status).decode()}) {detail}")
 
 
+def device_source_hash():
+    """SHA-256 of the device sources and compiler flags the loaded library was built from (mlgpu_device_source_hash)."""
+    return _lib.load().mlgpu_device_source_hash().decode()
+
+
 def jit_stats():
     """hiprtc work since the library was loaded: kernels compiled (and seconds), disk-cache hits (and seconds), memory hits."""
     L = _lib.load()
@@ -150,6 +155,13 @@ class Engine:
 
     def get_flush_denormals(self):
         return bool(self.L.mlgpu_engine_get_flush_denormals(self.h))
+
+    def set_strict_svf(self, on):
+        """Banks and graphs created from now on update SVF memories with two instructions (`ic + 2 t`) instead of one fused."""
+        self._check(self.L.mlgpu_engine_set_strict_svf(self.h, 1 if on else 0))
+
+    def get_strict_svf(self):
+        return bool(self.L.mlgpu_engine_get_strict_svf(self.h))
 
     def set_cascade_lanes(self, lanes):
         """Wavefront lanes per channel of an SVF-cascade bank: 0 = by bank size, 1 / 2 / 4, -1 = the round-2 kernel."""

@@ -86,6 +86,7 @@ def _declare(L):
         fn.argtypes = args
 
     sig("mlgpu_abi_version", i, [])
+    sig("mlgpu_device_source_hash", c.c_char_p, [])
     sig("mlgpu_status_string", c.c_char_p, [i])
     sig("mlgpu_device_count", i, [])
     sig("mlgpu_device_info", i, [i, c.c_char_p, sz, c.POINTER(i), c.POINTER(c.c_uint64)])
@@ -94,6 +95,8 @@ def _declare(L):
     sig("mlgpu_engine_create", i, [i, pp])
     sig("mlgpu_engine_set_flush_denormals", i, [vp, i])
     sig("mlgpu_engine_get_flush_denormals", i, [vp])
+    sig("mlgpu_engine_set_strict_svf", i, [vp, i])
+    sig("mlgpu_engine_get_strict_svf", i, [vp])
     sig("mlgpu_engine_set_cascade_lanes", i, [vp, i])
     sig("mlgpu_engine_get_cascade_lanes", i, [vp])
     sig("mlgpu_engine_create_on_stream", i, [i, vp, pp])

@@ -11,6 +11,8 @@
 
 #include "mlgpu_internal.hpp"
 
+extern const char mlgpu_device_source_hash_str[];  // embedded_sources.cpp (embed.py)
+
 namespace
 {
 int fail(mlgpu_engine* e, int status, const char* what, hipError_t herr = hipSuccess)
@@ -100,6 +102,7 @@ struct mlgpu_bank
 extern "C"
 {
   int mlgpu_abi_version(void) { return MLGPU_ABI_VERSION; }
+  const char* mlgpu_device_source_hash(void) { return mlgpu_device_source_hash_str; }
 
   const char* mlgpu_status_string(int s)
   {
@@ -159,6 +162,14 @@ extern "C"
     return MLGPU_OK;
   }
   int mlgpu_engine_get_flush_denormals(mlgpu_engine* e) { return (e && (e->kflags & MLGPU_KFLAG_FLUSH_DENORMALS)) ? 1 : 0; }
+
+  int mlgpu_engine_set_strict_svf(mlgpu_engine* e, int on)
+  {
+    if (!e) return MLGPU_ERR_INVALID;
+    e->strictSvf = on != 0;
+    return MLGPU_OK;
+  }
+  int mlgpu_engine_get_strict_svf(mlgpu_engine* e) { return (e && e->strictSvf) ? 1 : 0; }
 
   int mlgpu_engine_set_cascade_lanes(mlgpu_engine* e, int lanes)
   {
@@ -597,13 +608,19 @@ extern "C"
       const int32_t k = procs[p];
       b->singles.push_back(mlgpu_find_chain(&k, 1));
     }
-    b->fused = mlgpu_find_chain(procs, nProcs);
+    // strict mode: the ahead-of-time kernels are the fused-2t build, so every chain is generated (hiprtc, MLGPU_SVF_STRICT 1)
+    b->fused = e->strictSvf ? nullptr : mlgpu_find_chain(procs, nProcs);
     hipError_t err = hipSetDevice(e->device);
-    if (!b->fused && e->jitEnabled && err == hipSuccess)
+    if (!b->fused && (e->jitEnabled || e->strictSvf) && err == hipSuccess)
     {
       std::string log;
       if (!mlgpu_jit_chain(e, procs, nProcs, &b->jitSignal, &b->jitConst, log))
       {
+        if (e->strictSvf)
+        {
+          delete b;
+          return fail(e, MLGPU_ERR_UNSUPPORTED, ("bank_create: strict SVF mode needs hiprtc: " + log).c_str());
+        }
         b->jitSignal = b->jitConst = nullptr;  // fall back to processor-by-processor execution
         e->lastError = "hiprtc chain fusion unavailable: " + log;
       }

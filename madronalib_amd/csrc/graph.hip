@@ -31,6 +31,7 @@
 
 #include "mlgpu_internal.hpp"
 
+extern const char mlgpu_device_source_hash_str[];
 extern const int mlgpu_embedded_count;
 extern const char* const mlgpu_embedded_names[];
 extern const char* const mlgpu_embedded_sources[];
@@ -46,6 +47,24 @@ struct CompiledModule
 std::mutex g_cacheMutex;
 std::map<std::string, CompiledModule> g_cache;  // key: device id + source
 
+// The options every run-time kernel is compiled with (part of the disk cache's key): the ahead-of-time build's own
+// (csrc/Makefile) apart from its scheduling strategy. MLGPU_JIT_EXTRA_OPTS adds space-separated options for A/B
+// measurements, e.g. "-mllvm -amdgpu-sched-strategy=max-ilp" (profiles/r03_jit_maxilp.txt: what it does to config 5).
+const std::vector<std::string>& jitOptions()
+{
+  static const std::vector<std::string> opts = [] {
+    std::vector<std::string> o = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
+    if (const char* extra = getenv("MLGPU_JIT_EXTRA_OPTS"))
+    {
+      std::istringstream in(extra);
+      std::string tok;
+      while (in >> tok) o.push_back(tok);
+    }
+    return o;
+  }();
+  return opts;
+}
+
 // compile `source` for gfx950 and load it on the current device; returns nullptr and fills `log` on failure
 bool compileToCode(const std::string& source, std::vector<char>& code, std::string& log)
 {
@@ -57,8 +76,9 @@ bool compileToCode(const std::string& source, std::vector<char>& code, std::stri
     log = "hiprtcCreateProgram failed";
     return false;
   }
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};  // == kJitOptions (the disk cache key)
-  const hiprtcResult r = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  std::vector<const char*> opts;
+  for (const std::string& o : jitOptions()) opts.push_back(o.c_str());
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   size_t logSize = 0;
   hiprtcGetProgramLogSize(prog, &logSize);
   if (logSize > 1)
@@ -93,7 +113,6 @@ struct JitStats
   double compileSeconds{0}, diskLoadSeconds{0};
 } g_jitStats;
 
-const char* const kJitOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
 
 uint64_t fnv1a(uint64_t h, const void* data, size_t n)
 {
@@ -102,6 +121,9 @@ uint64_t fnv1a(uint64_t h, const void* data, size_t n)
   return h;
 }
 
+// The cache directory, or "" when the disk level is off or the directory cannot be trusted: code objects are loaded into
+// the GPU as they are, so the directory must belong to this user and be writable by nobody else (a directory another user
+// can write to would let them choose the code this process runs).
 std::string cacheDir()
 {
   const char* d = getenv("MLGPU_CACHE_DIR");
@@ -115,27 +137,101 @@ std::string cacheDir()
     dir = std::string(h) + "/.cache/mlgpu";
   else
     return "";
-  // mkdir -p (two levels are enough for the defaults)
+  // mkdir -p; what we create is ours alone
   for (size_t i = 1; i <= dir.size(); ++i)
-    if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0755);
+    if (i == dir.size() || dir[i] == '/') mkdir(dir.substr(0, i).c_str(), 0700);
+  struct stat st;
+  if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return "";
+  if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)))
+  {
+    fprintf(stderr, "mlgpu: kernel cache directory %s is not owned by this user or is writable by others: disk cache off\n", dir.c_str());
+    return "";
+  }
   return dir;
+}
+
+// Everything that decides a code object besides the generated source: compile options, the fingerprint of the device
+// headers of this build (embed.py: the headers hiprtc is given are part of it), the HIP runtime / hiprtc versions with
+// their patch level, and the library's ABI version.
+const std::string& cacheContext()
+{
+  static const std::string ctx = [] {
+    std::string c = "mlgpu-kernel-cache 2\n";
+    for (const std::string& o : jitOptions()) c += o + " ";
+    c += "\ndevice-sources " + std::string(mlgpu_device_source_hash_str);
+    int major = 0, minor = 0, runtime = 0, driver = 0;
+    hiprtcVersion(&major, &minor);
+    if (hipRuntimeGetVersion(&runtime) != hipSuccess) runtime = -1;
+    if (hipDriverGetVersion(&driver) != hipSuccess) driver = -1;
+    c += "\nhiprtc " + std::to_string(major) + "." + std::to_string(minor) + " runtime " + std::to_string(runtime) + " driver " + std::to_string(driver);
+#ifdef HIP_VERSION_GITHASH
+    c += std::string(" built-with ") + HIP_VERSION_GITHASH;
+#endif
+    c += "\nabi " + std::to_string(MLGPU_ABI_VERSION) + "\n";
+    return c;
+  }();
+  return ctx;
 }
 
 std::string cacheFile(const std::string& source)
 {
   static const std::string dir = cacheDir();
   if (dir.empty()) return "";
+  const std::string& ctx = cacheContext();
   uint64_t h = 0xcbf29ce484222325ull;
+  h = fnv1a(h, ctx.data(), ctx.size());
   h = fnv1a(h, source.data(), source.size());
-  for (const char* o : kJitOptions) h = fnv1a(h, o, strlen(o) + 1);
-  for (int i = 0; i < mlgpu_embedded_count; ++i) h = fnv1a(h, mlgpu_embedded_sources[i], strlen(mlgpu_embedded_sources[i]) + 1);
-  int major = 0, minor = 0;
-  hiprtcVersion(&major, &minor);
-  const int ver[3] = {major, minor, MLGPU_ABI_VERSION};
-  h = fnv1a(h, ver, sizeof(ver));
   char name[64];
   snprintf(name, sizeof(name), "/%016llx-%zu.co", (unsigned long long)h, source.size());
   return dir + name;
+}
+
+// A cache file = header line "MLGPUCO2 <context bytes> <source bytes> <code bytes>\n", the context, the generated source,
+// the code object. The file name is only a 64-bit hash: a file is used when its context and its source are byte for byte
+// the ones asked for, so neither a hash collision nor another compiler / library build can hand back a different kernel.
+bool readCacheFile(const std::string& path, const std::string& source, std::vector<char>& code)
+{
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  bool ok = false;
+  char magic[16] = {0};
+  unsigned long long nCtx = 0, nSrc = 0, nCode = 0;
+  const std::string& ctx = cacheContext();
+  if (fscanf(f, "%15s %llu %llu %llu", magic, &nCtx, &nSrc, &nCode) == 4 && fgetc(f) == '\n' && !strcmp(magic, "MLGPUCO2") &&
+      nCtx == ctx.size() && nSrc == source.size() && nCode > 64 && nCode < (1ull << 30))
+  {
+    std::string gotCtx(nCtx, '\0'), gotSrc(nSrc, '\0');
+    code.resize((size_t)nCode);
+    ok = fread(&gotCtx[0], 1, nCtx, f) == nCtx && fread(&gotSrc[0], 1, nSrc, f) == nSrc && fread(code.data(), 1, (size_t)nCode, f) == (size_t)nCode &&
+         fgetc(f) == EOF && gotCtx == ctx && gotSrc == source && !memcmp(code.data(), "\177ELF", 4);
+  }
+  fclose(f);
+  if (!ok) code.clear();
+  return ok;
+}
+
+bool writeCacheFile(const std::string& path, const std::string& source, const std::vector<char>& code)
+{
+  // a temporary file of our own in the same directory (mkstemp: unique whatever shares the directory - other processes,
+  // containers with the same pids, hosts on a network file system), then an atomic rename
+  std::string tmp = path + ".XXXXXX";
+  const int fd = mkstemp(&tmp[0]);
+  if (fd < 0) return false;
+  FILE* f = fdopen(fd, "wb");
+  if (!f)
+  {
+    close(fd);
+    remove(tmp.c_str());
+    return false;
+  }
+  const std::string& ctx = cacheContext();
+  bool ok = fprintf(f, "MLGPUCO2 %zu %zu %zu\n", ctx.size(), source.size(), code.size()) > 0;
+  ok = ok && fwrite(ctx.data(), 1, ctx.size(), f) == ctx.size() && fwrite(source.data(), 1, source.size(), f) == source.size() &&
+       fwrite(code.data(), 1, code.size(), f) == code.size();
+  ok = (fclose(f) == 0) && ok;
+  if (ok && rename(tmp.c_str(), path.c_str()) == 0) return true;
+  remove(tmp.c_str());
+  return false;
 }
 
 bool compileToCode(const std::string& source, std::vector<char>& code, std::string& log);
@@ -171,19 +267,7 @@ bool getCode(const std::string& source, std::vector<char>& code, std::string& lo
   if (!path.empty())
   {
     const auto t0 = std::chrono::steady_clock::now();
-    if (FILE* f = fopen(path.c_str(), "rb"))
-    {
-      fseek(f, 0, SEEK_END);
-      const long n = ftell(f);
-      fseek(f, 0, SEEK_SET);
-      // a code object is an ELF file; anything else (a truncated write of a killed process) is ignored and rebuilt
-      if (n > 64)
-      {
-        code.resize((size_t)n);
-        fromDisk = fread(code.data(), 1, (size_t)n, f) == (size_t)n && !memcmp(code.data(), "\177ELF", 4);
-      }
-      fclose(f);
-    }
+    fromDisk = readCacheFile(path, source, code);  // anything else under that name (a truncated write, another build's file) is ignored and rebuilt
     if (fromDisk)
     {
       std::lock_guard<std::mutex> lock(g_codeMutex);
@@ -200,22 +284,10 @@ bool getCode(const std::string& source, std::vector<char>& code, std::string& lo
       ++g_jitStats.compiles;
       g_jitStats.compileSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
-    if (!path.empty())
+    if (!path.empty() && writeCacheFile(path, source, code))
     {
-      static std::atomic<unsigned> serial{0};  // two host threads (a DeviceGroup) may build the same kernel at the same time
-      const std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
-      if (FILE* f = fopen(tmp.c_str(), "wb"))
-      {
-        const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-        fclose(f);
-        if (ok && rename(tmp.c_str(), path.c_str()) == 0)
-        {
-          std::lock_guard<std::mutex> lock(g_codeMutex);
-          ++g_jitStats.diskWrites;
-        }
-        else
-          remove(tmp.c_str());
-      }
+      std::lock_guard<std::mutex> lock(g_codeMutex);
+      ++g_jitStats.diskWrites;
     }
   }
   std::lock_guard<std::mutex> lock(g_codeMutex);
@@ -359,6 +431,7 @@ struct mlgpu_graph
   int nInputs{0}, nParams{0}, nControls{0}, NC{0}, NS{0};
   bool compiled{false};
   bool hasImpulse{false};
+  bool strictSvf{false};  // the engine's mode when the graph was made (mlgpu_engine_set_strict_svf)
   std::string source, log;
   hipFunction_t fn{nullptr};
   float* d_coeffs{nullptr};
@@ -567,7 +640,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   std::ostringstream s;
   auto sfx = [](int l) { return "_" + std::to_string(l); };
   s << "// generated by libmlgpu graph.hip (" << VL << " voice" << (VL > 1 ? "s" : "") << " per lane)\n"
-    << (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\n" << (g->hasEventRows ? "#include \"mldsp_events.hpp\"\n" : "") << "using namespace mldev;\n";
+    << (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "") << (g->strictSvf ? "#define MLGPU_SVF_STRICT 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\n" << (g->hasEventRows ? "#include \"mldsp_events.hpp\"\n" : "") << "using namespace mldev;\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_VOP && g->nodes[i].kind == MLGPU_VOP_TABLE)
     {
@@ -1010,10 +1083,22 @@ int checkStateNode(mlgpu_graph* g, int node)
 
 // ---- fused kernels for processor chains without an ahead-of-time instantiation -------------------
 // Generates `chain_kernel_body<Chain<kinds...>, HAS_SIGNAL>` wrappers; used by mlgpu_bank_create.
-static std::string chainSource(const int32_t* kinds, int n)
+static std::string chainSource(const int32_t* kinds, int n, bool strictSvf = false)
 {
   std::ostringstream s;
-  s << "// generated by libmlgpu graph.hip (chain)\n#include \"mldsp_kernels.hpp\"\nusing namespace mldev;\nusing CH = Chain<";
+  s << "// generated by libmlgpu graph.hip (chain)\n" << (strictSvf ? "#define MLGPU_SVF_STRICT 1\n" : "") << "#include \"mldsp_kernels.hpp\"\nusing namespace mldev;\n";
+  // a plain cascade of 2, 4 or 8 equal SVF sections keeps its stage-skewed form (one lane per channel; chains.hip picks wider
+  // forms by bank size for the ahead-of-time kernels): strict mode must not cost config 4 its kernel
+  bool cascade = (n == 2 || n == 4 || n == 8) && (kinds[0] == MLGPU_PROC_LOPASS || kinds[0] == MLGPU_PROC_HIPASS || kinds[0] == MLGPU_PROC_BANDPASS);
+  for (int i = 1; i < n; ++i) cascade = cascade && kinds[i] == kinds[0];
+  if (cascade)
+  {
+    for (int sig = 1; sig >= 0; --sig)
+      s << "extern \"C\" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mlgpu_chain_" << (sig ? "signal" : "const")
+        << "(const ChainArgs a) { cascade_lanes_body<" << kinds[0] << ", " << n << ", 1, 8, " << (sig ? "true" : "false") << ">(a); }\n";
+    return s.str();
+  }
+  s << "using CH = Chain<";
   for (int i = 0; i < n; ++i) s << (i ? ", " : "") << kinds[i];
   s << ">;\n"
        "extern \"C\" __global__ __launch_bounds__(256) void mlgpu_chain_signal(const ChainArgs a) { chain_kernel_body<CH, true>(a); }\n"
@@ -1023,7 +1108,7 @@ static std::string chainSource(const int32_t* kinds, int n)
 
 bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log)
 {
-  const std::string src = chainSource(kinds, n);
+  const std::string src = chainSource(kinds, n, e->strictSvf);
   CompiledModule* cm = compileAndLoad(e->device, src, log);
   if (!cm) return false;
   *fnSignal = (void*)getFunction(cm, "mlgpu_chain_signal", log);
@@ -1053,6 +1138,13 @@ extern "C"
     // (1) a chain that has no ahead-of-time instantiation, including the LDS-table ImpulseGen
     const int32_t chain[] = {MLGPU_PROC_IMPULSE_GEN, MLGPU_PROC_LO_SHELF, MLGPU_PROC_ADSR, MLGPU_PROC_PEAK, MLGPU_PROC_GAIN};
     ok = compileOnly(chainSource(chain, 5), log) && ok;
+    all += log;
+    // (1b) the strict-SVF forms: a generic chain and a plain cascade (which keeps its stage-skewed kernel)
+    const int32_t svfChain[] = {MLGPU_PROC_SAW_GEN, MLGPU_PROC_BANDPASS, MLGPU_PROC_HI_SHELF, MLGPU_PROC_GAIN};
+    ok = compileOnly(chainSource(svfChain, 4, true), log) && ok;
+    all += log;
+    const int32_t casc[] = {MLGPU_PROC_HIPASS, MLGPU_PROC_HIPASS, MLGPU_PROC_HIPASS, MLGPU_PROC_HIPASS};
+    ok = compileOnly(chainSource(casc, 4, true), log) && ok;
     all += log;
     // (2) a graph touching every node type
     mlgpu_graph g;
@@ -1149,6 +1241,7 @@ extern "C"
     mlgpu_graph* g = new (std::nothrow) mlgpu_graph();
     if (!g) return MLGPU_ERR_OOM;
     g->e = e;
+    g->strictSvf = e && e->strictSvf;
     g->V = nVoices;
     *out = g;
     return MLGPU_OK;

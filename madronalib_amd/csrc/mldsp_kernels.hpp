@@ -228,9 +228,9 @@ struct SvfCascade
     }
     // PARITY: fma(2, t, ic) == ic + 2*t (2*t is exact short of overflow; see SvfCore)
 #pragma unroll
-    for (int p = 0; p < H; ++p) ic1[p] = __builtin_elementwise_fma(two, t1[p], ic1[p]);
+    for (int p = 0; p < H; ++p) ic1[p] = MLGPU_SVF_STRICT ? ic1[p] + two * t1[p] : __builtin_elementwise_fma(two, t1[p], ic1[p]);
 #pragma unroll
-    for (int p = 0; p < H; ++p) ic2[p] = __builtin_elementwise_fma(two, t2[p], ic2[p]);
+    for (int p = 0; p < H; ++p) ic2[p] = MLGPU_SVF_STRICT ? ic2[p] + two * t2[p] : __builtin_elementwise_fma(two, t2[p], ic2[p]);
     return r[H - 1].y;
   }
 #else
@@ -278,9 +278,9 @@ struct SvfCascade
       for (int s = 0; s < N; ++s) put(r, s, v1[s] - v2[s]);
     }
 #pragma unroll
-    for (int s = 0; s < N; ++s) put(ic1, s, __builtin_fmaf(2.0f, t1[s], get(ic1, s)));
+    for (int s = 0; s < N; ++s) put(ic1, s, svf_acc(get(ic1, s), t1[s]));
 #pragma unroll
-    for (int s = 0; s < N; ++s) put(ic2, s, __builtin_fmaf(2.0f, t2[s], get(ic2, s)));
+    for (int s = 0; s < N; ++s) put(ic2, s, svf_acc(get(ic2, s), t2[s]));
     return get(r, N - 1);
   }
 #endif
@@ -306,8 +306,8 @@ struct SvfCascade
           put(r, s, t1 + i1);
         else
           put(r, s, in[s] - get(kk, s) * (t1 + i1) - (t2 + i2));
-        put(ic1, s, __builtin_fmaf(2.0f, t1, i1));
-        put(ic2, s, __builtin_fmaf(2.0f, t2, i2));
+        put(ic1, s, svf_acc(i1, t1));
+        put(ic2, s, svf_acc(i2, t2));
       }
     }
     return get(r, N - 1);
@@ -464,8 +464,8 @@ struct LaneGroup
 #define MLGPU_CASCADE_LANES_DPP_SUB 1
 #endif
 
-template <int KIND, int N, int LPC, int R, int MINW, bool HAS_SIGNAL>
-__global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(MINW))) void cascade_lanes_kernel(const ChainArgs a)
+template <int KIND, int N, int LPC, int R, bool HAS_SIGNAL>
+__device__ __forceinline__ void cascade_lanes_body(const ChainArgs& a)
 {
   constexpr int SPL = N / LPC;  // stages per lane
   static_assert(N % LPC == 0 && SPL % 2 == 0, "each lane runs an even number of stages (packed pairs)");
@@ -543,15 +543,16 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(MIN
   // prologue: ticks 0..D-1, stages 0..i active
   for (int i = 0; i < D; ++i) slowTick(inAt((size_t)i), 0, i);
 
-  // steady state, fast path: whole DSPVectors 0 .. T-2, 16 quads = 64 ticks per trip, so every quad's position in its
-  // vector and its ring slot (input quad n lives in slot n % R) are compile-time constants and the pointers advance by
-  // one of two launch constants. While output quad q is computed, input quad q + A + R - 1 is fetched into the slot that
-  // quad q + A - 1 has just left; fetches reach into vector t + 1, which exists because t <= T - 2.
+  // steady state: one DSPVector = 16 quads = 64 ticks per trip, so every quad's position in its vector and its ring slot
+  // (input quad n lives in slot n % R) are compile-time constants and the pointers advance by launch constants. While
+  // output quad q is computed, input quad q + A + R - 1 is fetched into the slot that quad q + A - 1 has just left; near
+  // the end of a vector the fetches reach into the next one. The launch's last vector has no next one: there the fetch
+  // pointer is sent back to the start of the same vector (valid addresses, values never used), and its last
+  // kTailQuads output quads - the ones whose ticks reach past the end of the input - are left to the tail below.
   const size_t Q = (S - D) / 4;
-  size_t q = 0;
-  if (a.T >= 2)
+  constexpr int kTailQuads = A + 1;  // 16 T - Q
   {
-    const int64_t inStep = (int64_t)a.in.strideQ * 16, inNext = ((int64_t)a.in.strideT - 15 * (int64_t)a.in.strideQ) * 16;
+    const int64_t inStep = (int64_t)a.in.strideQ * 16, inNext = ((int64_t)a.in.strideT - 15 * (int64_t)a.in.strideQ) * 16, inRewind = -15 * inStep;
     const int64_t outStep = (int64_t)a.out.strideQ * 16, outNext = ((int64_t)a.out.strideT - 15 * (int64_t)a.out.strideQ) * 16;
     f32x4 w[R];
     const char* pf = (const char*)pin;  // the next input quad to fetch
@@ -560,60 +561,43 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(MIN
     {
       pf += A * inStep;
 #pragma unroll
-      for (int n = 0; n < R - 1; ++n)  // quads A .. A + R - 2
+      for (int n = 0; n < R - 1; ++n)  // quads A .. A + R - 2 of the first vector
       {
         w[(A + n) % R] = __builtin_nontemporal_load((const f32x4*)pf);
-        pf += ((A + n) & 15) == 15 ? inNext : inStep;
+        pf += ((A + n) & 15) == 15 ? (a.T == 1 ? inRewind : inNext) : inStep;
       }
     }
-    for (size_t t = 0; t + 1 < a.T; ++t)
-    {
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-      {
-        f32x4 y;
-        if constexpr (HAS_SIGNAL)
-        {
-          constexpr int kA = A;
-          const int n = s + kA + R - 1;  // the quad fetched now (relative to this vector's first)
-          w[n % R] = __builtin_nontemporal_load((const f32x4*)pf);
-          pf += (n & 15) == 15 ? inNext : inStep;
-          y = quadTicks(w[(s + kA) % R], w[(s + kA + 1) % R]);
-        }
-        else
-        {
-          const f32x4 wc = f32x4{xc, xc, xc, xc};
-          y = quadTicks(wc, wc);
-        }
-        if (last) __builtin_nontemporal_store(y, (f32x4*)ps);
-        ps += s == 15 ? outNext : outStep;
-      }
-    }
-    q = 16 * (a.T - 1);
-  }
-  // the remaining quads (the last DSPVector's, less the ones that wait for the drain): the same ticks, one quad of
-  // lookahead, positions computed as they come
-  if (q < Q)
-  {
-    const size_t lastQuad = S / 4 - 1;
-    f32x4 wa = f32x4{xc, xc, xc, xc}, wb = wa;
-    if constexpr (HAS_SIGNAL)
-    {
-      wa = *inQuad(q + A);
-      wb = *inQuad(q + A + 1);
-    }
-    for (; q < Q; ++q)
-    {
-      f32x4 wn = wb;
+    auto quadStep = [&](int s, int64_t inWrap0, int64_t inWrap1) {  // s is a constant after unrolling
+      f32x4 y;
       if constexpr (HAS_SIGNAL)
       {
-        const size_t nq = q + A + 2;
-        wn = *inQuad(nq < lastQuad ? nq : lastQuad);
+        constexpr int kA = A;
+        const int n = s + kA + R - 1;  // the quad fetched now (relative to this vector's first)
+        w[n % R] = __builtin_nontemporal_load((const f32x4*)pf);
+        pf += (n & 15) == 15 ? (n < 16 ? inWrap0 : inWrap1) : inStep;  // leaving vector t (n == 15) or t + 1 (n == 31, R = 16 only)
+        y = quadTicks(w[(s + kA) % R], w[(s + kA + 1) % R]);
       }
-      const f32x4 y = quadTicks(wa, wb);
-      if (last) *outQuad(q) = y;
-      wa = wb;
-      wb = wn;
+      else
+      {
+        const f32x4 wc = f32x4{xc, xc, xc, xc};
+        y = quadTicks(wc, wc);
+      }
+      if (last) __builtin_nontemporal_store(y, (f32x4*)ps);
+      ps += s == 15 ? outNext : outStep;
+    };
+    for (size_t t = 0; t < a.T; ++t)
+    {
+      const bool lastVector = (t + 1 == a.T);
+      // where the fetch pointer goes when it leaves a vector: on to the next one, or - from the launch's last vector - back
+      // to that vector's start
+      const int64_t inWrap0 = (t + 1 < a.T) ? inNext : inRewind, inWrap1 = (t + 2 < a.T) ? inNext : inRewind;
+#pragma unroll
+      for (int s = 0; s < 16 - kTailQuads; ++s) quadStep(s, inWrap0, inWrap1);
+      if (!lastVector)
+      {
+#pragma unroll
+        for (int s = 16 - kTailQuads; s < 16; ++s) quadStep(s, inWrap0, inWrap1);
+      }
     }
   }
   // tail: ticks D + 4Q .. S + D - 1; inputs exist while i < S, after that the pipeline drains
@@ -626,6 +610,13 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(MIN
     if (last) ((float*)outQuad(n >> 2))[n & 3] = c.r[H - 1].y;
   }
   c.store(VoiceMem{a.coeffs + (size_t)(NCK * base) * a.V + v, a.state + (size_t)(2 * base) * a.V + v, a.V});
+}
+
+// MINW = wavefronts per SIMD the register allocation must leave room for: 2 / 4 / 6 for 1 / 2 / 4 lanes per channel
+template <int KIND, int N, int LPC, int R, int MINW, bool HAS_SIGNAL>
+__global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(MINW))) void cascade_lanes_kernel(const ChainArgs a)
+{
+  cascade_lanes_body<KIND, N, LPC, R, HAS_SIGNAL>(a);
 }
 
 }  // namespace mldev

@@ -439,6 +439,28 @@ struct Proc<MLGPU_PROC_ONE_SHOT_GEN>  // MLDSPGens.h:221-282
 // finite (tools/ftz_probe.hip shows the pair 7f7fffff / ff7fffff). A filter in that state is one
 // doubling away from inf either way; the public contract (mlgpu.h) names the case.
 
+// MLGPU_SVF_STRICT 1 (kernels generated for an engine in strict mode, mlgpu_engine_set_strict_svf) spends the second
+// instruction: `ic + 2 * t` and `2 * v - ic` as the reference writes them, identical in the overflow corner too.
+#ifndef MLGPU_SVF_STRICT
+#define MLGPU_SVF_STRICT 0
+#endif
+MLD float svf_acc(float ic, float t)  // ic += 2.0f * t
+{
+#if MLGPU_SVF_STRICT
+  return ic + 2.0f * t;
+#else
+  return __builtin_fmaf(2.0f, t, ic);
+#endif
+}
+MLD float svf_flip(float v, float ic)  // ic = 2 * v - ic
+{
+#if MLGPU_SVF_STRICT
+  return 2.0f * v - ic;
+#else
+  return __builtin_fmaf(2.0f, v, -ic);
+#endif
+}
+
 template <int KIND>
 struct SvfCore
 {
@@ -480,8 +502,8 @@ struct SvfCore
       const float v2 = t2 + ic2eq;
       y = v0 - k * v1 - v2;  // :189-193
     }
-    ic1eq = __builtin_fmaf(2.0f, t1, ic1eq);
-    ic2eq = __builtin_fmaf(2.0f, t2, ic2eq);
+    ic1eq = svf_acc(ic1eq, t1);
+    ic2eq = svf_acc(ic2eq, t2);
     return y;
   }
   MLD void end_vector() {}
@@ -507,8 +529,8 @@ struct Proc<MLGPU_PROC_LOPASS> : SvfCore<MLGPU_PROC_LOPASS>
     const float t1 = c0 * t0 + c1 * ic1eq;
     const float t2 = c2 * t0 + c0 * ic1eq;
     const float y = t2 + ic2eq;
-    ic1eq = __builtin_fmaf(2.0f, t1, ic1eq);
-    ic2eq = __builtin_fmaf(2.0f, t2, ic2eq);
+    ic1eq = svf_acc(ic1eq, t1);
+    ic2eq = svf_acc(ic2eq, t2);
     return y;
   }
   using SvfCore<MLGPU_PROC_LOPASS>::next;
@@ -563,8 +585,8 @@ struct ShelfCore  // LoShelf :288-302, HiShelf :369-383, Bell :427-441
     const float v3 = v0 - ic2eq;
     const float v1 = a1 * ic1eq + a2 * v3;
     const float v2 = ic2eq + a2 * ic1eq + a3 * v3;
-    ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
-    ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
+    ic1eq = svf_flip(v1, ic1eq);
+    ic2eq = svf_flip(v2, ic2eq);
     if (KIND == MLGPU_PROC_LO_SHELF) return v0 + m1 * v1 + m2 * v2;
     if (KIND == MLGPU_PROC_HI_SHELF) return m0 * v0 + m1 * v1 + m2 * v2;
     return v0 + m1 * v1;
@@ -576,8 +598,8 @@ struct ShelfCore  // LoShelf :288-302, HiShelf :369-383, Bell :427-441
     const float v3 = v0 - ic2eq;
     const float v1 = ca1 * ic1eq + ca2 * v3;
     const float v2 = ic2eq + ca2 * ic1eq + ca3 * v3;
-    ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
-    ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
+    ic1eq = svf_flip(v1, ic1eq);
+    ic2eq = svf_flip(v2, ic2eq);
     return v0 + cm1 * v1 + cm2 * v2;
   }
   MLD float next(float v0, float ca1, float ca2, float ca3, float cm0, float cm1, float cm2)  // HiShelf {a1,a2,a3,m0,m1,m2}
@@ -585,8 +607,8 @@ struct ShelfCore  // LoShelf :288-302, HiShelf :369-383, Bell :427-441
     const float v3 = v0 - ic2eq;
     const float v1 = ca1 * ic1eq + ca2 * v3;
     const float v2 = ic2eq + ca2 * ic1eq + ca3 * v3;
-    ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
-    ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
+    ic1eq = svf_flip(v1, ic1eq);
+    ic2eq = svf_flip(v2, ic2eq);
     return cm0 * v0 + cm1 * v1 + cm2 * v2;
   }
   MLD void end_vector() {}

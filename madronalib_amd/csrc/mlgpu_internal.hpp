@@ -20,6 +20,7 @@ struct mlgpu_engine
   float* d_impulseTable{nullptr};  // 17 floats (ImpulseGen windowed sinc), built on the host
   hipEvent_t ev0{nullptr}, ev1{nullptr};
   bool jitEnabled{true};  // fuse unknown chains / graphs with hiprtc (mlgpu_engine_set_jit)
+  bool strictSvf{false};  // banks and graphs made from now on get kernels compiled with MLGPU_SVF_STRICT 1 (mlgpu_engine_set_strict_svf)
   float* d_mixScratch{nullptr};  // mixdown partial sums, grown on demand
   size_t mixScratchFloats{0};
   unsigned long long* d_validate{nullptr};  // {count, first index} of mlgpu_validate, allocated with the engine
@@ -98,7 +99,7 @@ hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t 
                               size_t nElems, hipStream_t stream, uint32_t flags);
 
 // graph.hip — run-time fused kernels (hiprtc)
-bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);
+bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);  // honours e->strictSvf
 hipError_t mlgpu_jit_chain_launch(void* fn, const ChainArgs& a, hipStream_t stream);
 
 // coeffs.cpp

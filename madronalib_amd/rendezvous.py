@@ -163,6 +163,49 @@ class GlooRendezvous:
             self.dist.destroy_process_group()
 
 
+def run_rank_processes(argv, world, env_extra=None, grace_s=10.0, poll_s=0.05):
+    """Start `world` rank processes of one node (rank r = `argv` with RANK / LOCAL_RANK / WORLD_SIZE / MLGPU_RDV_DIR exported),
+    lined up through a fresh rendezvous directory, and WATCH them: the moment any rank ends with a non-zero status - an
+    exception, a refusal, a segfault that never got to write anything - the `abort` file is written so that the ranks waiting in
+    a FileRendezvous leave at once instead of timing out, and what is still running after `grace_s` is killed (these exact
+    children, by pid). Returns (exit codes, rank 0's stdout)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rdv_dir = tempfile.mkdtemp(prefix="mlgpu_rdv_")
+    procs = []
+    try:
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MLGPU_RDV_DIR=rdv_dir, **(env_extra or {}))
+            procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        out0 = []
+        reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)  # never let rank 0 block on a full pipe
+        reader.start()
+        failed_at = None
+        while True:
+            rcs = [p.poll() for p in procs]
+            if all(rc is not None for rc in rcs):
+                break
+            if failed_at is None and any(rc not in (None, 0) for rc in rcs):
+                failed_at = time.monotonic()
+                try:
+                    open(os.path.join(rdv_dir, "abort"), "w").close()
+                except OSError:
+                    pass
+            if failed_at is not None and time.monotonic() - failed_at > grace_s:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            time.sleep(poll_s)
+        reader.join(5.0)
+        return [p.returncode for p in procs], "".join(out0)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(rdv_dir, ignore_errors=True)
+
+
 def from_environment():
     """The rendezvous of a rank process, from what its launcher exported."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -245,6 +245,36 @@ print(json.dumps(dict(stats=ml.jit_stats(), seconds=dt, sha=hashlib.sha256(code)
     assert off["stats"]["compiles"] == 1 and off["stats"]["disk_hits"] == 0
     print(f"hiprtc cold {cold['seconds']:.2f} s, warm {warm['seconds']:.3f} s")
 
+    # An entry is used only when the context (options, device-source fingerprint, hiprtc / runtime versions) and the
+    # generated source stored in it are byte for byte the ones asked for - the file name is only a 64-bit hash.
+    names = sorted(f for f in os.listdir(tmp_path) if f.endswith(".co"))
+    assert len(names) == 2
+    a, b = (os.path.join(tmp_path, n) for n in names)
+    blob_a = open(a, "rb").read()
+    assert blob_a.startswith(b"MLGPUCO2 ") and b"device-sources " in blob_a[:400] and b"\x7fELF" in blob_a
+    # (1) a whole, valid entry of ANOTHER kernel under this kernel's name (what a hash collision would look like)
+    blob_b = open(b, "rb").read()
+    open(a, "wb").write(blob_b)
+    open(b, "wb").write(blob_a)
+    for k in ("0.5", "0.25"):
+        r = run(tmp_path, k)
+        assert r["stats"]["compiles"] == 1 and r["stats"]["disk_hits"] == 0, "a foreign entry must not be loaded"
+    assert run(tmp_path)["sha"] == cold["sha"]
+    # (2) the same entry written by another build of the library or another compiler
+    for path in (a, b):
+        data = open(path, "rb").read()
+        open(path, "wb").write(data.replace(b"device-sources ", b"device-sources f", 1)[:len(data)])
+    r = run(tmp_path)
+    assert r["stats"]["compiles"] == 1 and r["sha"] == cold["sha"]
+    # (3) a directory other users can write to is not trusted with code objects
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    r = run(shared)
+    assert r["stats"]["compiles"] == 1 and not os.listdir(shared)
+    # no stray temporaries left behind
+    assert not [f for f in os.listdir(tmp_path) if ".co." in f]
+
 
 def test_concurrent_builds_of_one_kernel_compile_once():
     """The host threads of a multi-device program ask for the same kernel at the same time (ml::gpu::DeviceGroup, bench.py

@@ -583,6 +583,43 @@ def _below_the_svf_overflow_regime(x):
     return y
 
 
+@pytest.mark.parametrize("procs", [[k] for k in SVF_KINDS] + [[Proc.LOPASS] * 8, [Proc.HIPASS] * 4, [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]],
+                         ids=lambda p: "x".join(str(int(k)) for k in p))
+def test_strict_svf_hostile_input(oracle, procs):
+    """mlgpu_engine_set_strict_svf: with `ic + 2 t` spent as two instructions the state-variable filters follow the
+    reference through the overflow corner as well - the hostile signal goes in UNCLAMPED (1e38, FLT_MAX, raw bit patterns next
+    to infinities and NaNs), outputs and memories bit for bit over two launches. Banks of a strict engine are generated
+    kernels (hiprtc), the plain cascades in their stage-skewed form; the default engine beside it keeps its own kernels."""
+    import madronalib_amd as ml
+    e = ml.Engine(0)
+    try:
+        e.set_strict_svf(True)
+        assert e.get_strict_svf()
+        V, T = 200, 6
+        co = chain_coeffs(oracle, procs, V, seed=5)
+        has_input = procs[0] not in Proc.GENERATORS
+        sig = _hostile_signal(V, 64 * T * 2, seed=7 + len(procs)) if has_input else None
+        _, const = chain_input(procs, V, T, seed=3)
+        st = oracle.chain_clear(procs, V)
+        bank = e.bank(procs, V)
+        assert bank.fused and "hiprtc" in bank.kernel_name
+        bank.set_all_coeffs(co)
+        bank.set_all_state(st)
+        if const is not None:
+            bank.set_input_const(const)
+        for call in range(2):
+            part = np.ascontiguousarray(sig[:, call * 64 * T:(call + 1) * 64 * T]) if has_input else None
+            got = bank.process_host(T, part, Layout.QUAD)
+            want = oracle.chain_process(procs, T, co, st, part, const, n_threads=8)
+            assert_bits_equal(got, want, True, f"strict svf {procs} call {call}")
+            g32, w32 = bank.get_all_state().view(np.uint32), st.view(np.uint32)
+            bothnan = np.isnan(g32.view(np.float32)) & np.isnan(w32.view(np.float32))
+            assert ((g32 == w32) | bothnan).all(), f"strict svf {procs} state call {call}"
+        bank.close()
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("kind", [k for k in Proc.ALL if k not in Proc.HW_APPROX and k != Proc.NOISE_GEN])
 def test_single_proc_hostile_input(eng, oracle, kind):
     """Every processor with inputs nobody would send on purpose: infinities, NaNs, denormals, 1e38, raw bit patterns - as the

@@ -66,6 +66,62 @@ def test_file_rendezvous_abort_releases_waiters():
         assert err and "aborted" in err[0]
 
 
+def test_file_rendezvous_eight_processes():
+    """The width of one node: 8 rank processes through one directory, many collectives back to back."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory(prefix="mlgpu_rdv_test_") as d:
+        ps = [ctx.Process(target=_file_rank, args=(d, r, world, q)) for r in range(world)]
+        for p in ps:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in range(world))
+        for p in ps:
+            p.join(60)
+            assert p.exitcode == 0
+    for rank, got, slowest in res:
+        assert [g["rank"] for g in got] == list(range(world))
+        spans = [g["span"] for g in got]
+        assert spans[0][0] == 0 and spans[-1][1] == 1000 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert slowest == pytest.approx(0.08)
+
+
+_RANK_PROG = r"""
+import os, signal, sys, time
+sys.path.insert(0, {root!r})
+from madronalib_amd import rendezvous
+r = rendezvous.from_environment()
+rank = r.rank
+r.barrier()
+if rank == 5 and {mode!r} == "exception":
+    raise SystemExit(3)                      # a refusal / an exception: the rank ends with a status, nothing else
+if rank == 5 and {mode!r} == "segfault":
+    os.kill(os.getpid(), signal.SIGSEGV)     # dies hard: no abort file, no exit handler
+got = r.gather(rank)
+r.barrier()
+if rank == 0:
+    print("ranks", got)
+"""
+
+
+@pytest.mark.parametrize("mode", ["ok", "exception", "segfault"])
+def test_launcher_releases_every_rank_when_one_dies(mode):
+    """bench.py's own launcher (run_rank_processes) with 8 ranks: all fine -> rank 0's line comes back; rank 5 fails after the
+    first barrier, by exit status or by a segfault that writes nothing -> the seven ranks waiting in the next collective
+    leave within seconds (the launcher writes the abort file), instead of sitting out the rendezvous timeout."""
+    import time
+    prog = _RANK_PROG.format(root=ROOT, mode=mode)
+    t0 = time.monotonic()
+    rcs, out0 = rendezvous.run_rank_processes([sys.executable, "-c", prog], 8, grace_s=20.0)
+    dt = time.monotonic() - t0
+    if mode == "ok":
+        assert rcs == [0] * 8 and "ranks [0, 1, 2, 3, 4, 5, 6, 7]" in out0
+    else:
+        assert rcs[5] != 0
+        assert all(rc != 0 for rc in rcs), rcs          # nobody reports success for a run that lost a rank
+        assert dt < 60, f"ranks were not released ({dt:.0f} s)"
+
+
 def test_thread_rendezvous():
     world = 4
     group = rendezvous.ThreadRendezvous.group(world)

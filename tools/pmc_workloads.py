@@ -38,6 +38,11 @@ def main():
         res["workloads"] = json.load(open(outp)).get("workloads", {})
     except Exception:
         pass
+    # the fingerprint of the device code these counters were measured on (bench.py drops records of another build)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import madronalib_amd as ml
+    device_hash = ml.device_source_hash()
     for arg in sys.argv[2:]:
         case, prefix = arg.rsplit("@", 1)
         try:
@@ -53,9 +58,11 @@ def main():
                "fetch_bytes_per_launch_raw": cands[kernel]["fetch_bytes_per_launch_corrected"] / 2.0,   # FETCH_SIZE x 1024, as counted
                "fetch_bytes_per_launch_corrected": cands[kernel]["fetch_bytes_per_launch_corrected"],   # x 2: right when every read is a coalesced stream
                "write_bytes_per_launch": cands[kernel]["write_bytes_per_launch"], "files": prefix.split("/")[-1] + "_{traffic.json,pmc.txt}"}
+        rec["device_source_hash"] = device_hash
         pmc = parse_pmc_txt(prefix + "_pmc.txt")
         for k, v in pmc.items():
             if k == kernel or k in kernel or kernel in k:
+                rec["mean_us_under_pmc"] = v.get("mean_us_under_pmc")
                 if "SQ_INSTS_VALU" in v:
                     rec["valu_wave_insts_per_launch"] = v["SQ_INSTS_VALU"]
                 for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
