@@ -16,6 +16,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/file.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -264,6 +266,31 @@ bool getCode(const std::string& source, std::vector<char>& code, std::string& lo
   }
   const std::string path = cacheFile(source);
   bool fromDisk = false;
+  // One build per MACHINE too: the ranks of a multi-GPU job start together and all ask for the same kernel. Whoever gets
+  // the advisory lock on <entry>.lock first compiles and writes the entry; the others block in flock(), then find it. The
+  // kernel drops the lock when its holder dies, so a killed rank cannot strand the rest.
+  struct FileLock
+  {
+    int fd{-1};
+    explicit FileLock(const std::string& p)
+    {
+      if (p.empty()) return;
+      fd = open((p + ".lock").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+      if (fd >= 0 && flock(fd, LOCK_EX) != 0)
+      {
+        close(fd);
+        fd = -1;
+      }
+    }
+    ~FileLock()
+    {
+      if (fd >= 0)
+      {
+        flock(fd, LOCK_UN);
+        close(fd);
+      }
+    }
+  } entryLock(path);
   if (!path.empty())
   {
     const auto t0 = std::chrono::steady_clock::now();

@@ -273,7 +273,7 @@ print(json.dumps(dict(stats=ml.jit_stats(), seconds=dt, sha=hashlib.sha256(code)
     r = run(shared)
     assert r["stats"]["compiles"] == 1 and not os.listdir(shared)
     # no stray temporaries left behind
-    assert not [f for f in os.listdir(tmp_path) if ".co." in f]
+    assert not [f for f in os.listdir(tmp_path) if ".co." in f and not f.endswith(".co.lock")]   # <entry>.lock: the cross-process build lock
 
 
 def test_concurrent_builds_of_one_kernel_compile_once():
@@ -299,3 +299,35 @@ print(json.dumps(dict(stats=ml.jit_stats(), same=all(c == codes[0] for c in code
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["same"] and out["n"] > 1000
     assert out["stats"]["compiles"] == 1 and out["stats"]["memory_hits"] == 3, out["stats"]
+
+
+def test_concurrent_rank_processes_compile_once(tmp_path):
+    """The ranks of a multi-GPU job are PROCESSES that start together with a cold cache and ask for the same kernel: whoever
+    takes the entry's lock file first runs hiprtc, the other seven wait in flock() and load what it wrote - one compile per
+    machine, not per rank (profiles/r03_multi_gpu_launch_paths.txt shows the same on a GPU box)."""
+    prog = r'''
+import json, sys, time
+import madronalib_amd as ml
+from madronalib_amd.constants import Op, Proc
+start = float(sys.argv[1])
+while time.time() < start:      # line the processes up so that they really do race
+    time.sleep(0.001)
+g = ml.Graph(ml.OfflineEngine(), 256)
+g.add("x", "input"); g.add("k", "const", value=0.8125)
+g.add("bp", "proc", Proc.BANDPASS, ["x"]); g.add("y", "op", Op.MULTIPLY, ["bp", "k"]); g.add_output("y")
+code = g.emit()[1]
+import hashlib
+print(json.dumps(dict(stats=ml.jit_stats(), sha=hashlib.sha256(code).hexdigest())))
+'''
+    import time
+    env = dict(os.environ, MLGPU_CACHE_DIR=str(tmp_path), PYTHONPATH=ROOT)
+    start = str(time.time() + 3.0)
+    procs = [subprocess.Popen([sys.executable, "-c", prog, start], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for _ in range(8)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        outs.append(json.loads(so.strip().splitlines()[-1]))
+    assert len({o["sha"] for o in outs}) == 1
+    assert sum(o["stats"]["compiles"] for o in outs) == 1, [o["stats"] for o in outs]
+    assert sum(o["stats"]["disk_hits"] for o in outs) == 7
