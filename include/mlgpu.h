@@ -923,6 +923,21 @@ void mlgpu_linear_glide_make_coeffs(float glide_time_in_samples, float out2[2]);
 /* SampleAccurateLinearGlide::setGlideTimeInSamples (:527-532) -> C{samplesPerGlide:i32 bits, dyPerSample} */
 void mlgpu_sample_accurate_linear_glide_make_coeffs(float glide_time_in_samples, float out2[2]);
 
+/* ------------------------------------------------------------------------- */
+/* window tables — host-side: makeWindow(pDest, size, dspwindows::<shape>),   */
+/* source/DSP/MLDSPUtils.h:22-47, for the overlap-add use of mlgpu_dspbuffer  */
+/* (Tests/dspBufferTest.cpp "overlap"). Same floats as the reference's.       */
+enum mlgpu_window
+{
+  MLGPU_WINDOW_RECTANGLE = 0,
+  MLGPU_WINDOW_TRIANGLE = 1,
+  MLGPU_WINDOW_RAISED_COSINE = 2,
+  MLGPU_WINDOW_HAMMING = 3,
+  MLGPU_WINDOW_BLACKMAN = 4,
+  MLGPU_WINDOW_FLAT_TOP = 5
+};
+int mlgpu_make_window(float* dest, size_t size, int shape);
+
 #ifdef __cplusplus
 }
 #endif

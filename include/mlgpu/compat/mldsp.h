@@ -114,6 +114,20 @@ struct Capture
   // a streamed graph input shared by the `contextGroup` adjacent voices of an instrument (mlgpu_graph_set_input_group), added
   // where the captured code first asks for it.
   static constexpr int kBeatPhase = 1000;
+  // Samples of a context signal on the host (`ctrlSig[0]` in the reference's controllers-to-audio.cpp): what the signal
+  // holds in the DSPVector about to be processed, handed over by VoiceProgram::readContextSamples before update() runs the
+  // process function again. Only a program of ONE context can have them (a host float is one number for the whole kernel).
+  const std::map<int, std::array<float, 64>>* hostContext{nullptr};
+  bool hostContextAllowed{false};
+  float hostContextSample(int code, int n) const
+  {
+    if (!hostContextAllowed)
+      throw std::logic_error("mldsp GPU shim: a sample of a context signal was read on the host (v[n]); construct the program with "
+                             "VoiceProgramOptions::hostContextSamples (one context per program) and call readContextSamples() + update() per DSPVector");
+    if (!hostContext) return 0.f;  // before anything was processed: controllers rest at 0, the transport at phase 0
+    auto it = hostContext->find(code);
+    return it == hostContext->end() ? 0.f : it->second[(size_t)(n & 63)];
+  }
   int inputCount{0};               // graph inputs added so far in this pass
   size_t contextGroup{1};
   std::vector<int> contextInputs;  // this pass, in input order: a controller number, or kBeatPhase
@@ -218,6 +232,30 @@ struct Sig
                                                        // outside a capture (a static window, a member filled in a setup function)
   uint32_t epoch{0};  // capture pass that made `node`
   int ord{-1};        // creation ordinal among the computed nodes of that pass (-1: input / param / const)
+  bool hostMutable{false};  // `table` is a buffer the user writes through getBuffer(): copies take their own floats (value semantics)
+  Sig(const Sig& o) : node(o.node), lit(o.lit), table(o.table), epoch(o.epoch), ord(o.ord), hostMutable(o.hostMutable), hostCtx(o.hostCtx)
+  {
+    if (hostMutable && table) table = std::make_shared<const std::array<float, 64>>(*table);
+  }
+  Sig& operator=(const Sig& o)
+  {
+    if (this != &o)
+    {
+      node = o.node; lit = o.lit; table = o.table; epoch = o.epoch; ord = o.ord; hostMutable = o.hostMutable; hostCtx = o.hostCtx;
+      if (hostMutable && table) table = std::make_shared<const std::array<float, 64>>(*table);
+    }
+    return *this;
+  }
+  int hostCtx{-1};    // >= 0: the node is the context signal of that code (a controller number / kBeatPhase): its samples can be read on the host
+  // one sample of this signal as a host float - possible only where the host has the data (MLDSPOps.h:167-168 `operator[]`)
+  float hostSample(int n) const
+  {
+    if (node < 0 && table) return (*table)[(size_t)(n & 63)];
+    if (node < 0) return lit;
+    if (hostCtx >= 0) return Capture::get().hostContextSample(hostCtx, n);
+    throw std::logic_error("mldsp GPU shim: v[n] / getBuffer() on a signal the kernel computes - its samples exist only on the device; "
+                           "keep the step in DSPVector form, or read the signal back after a launch");
+  }
   Sig() {}
   Sig(int n, float l) : node(n), lit(l), epoch(n >= 0 ? Capture::get().epoch : 0) {}
   explicit Sig(const float* p64) : table(std::make_shared<const std::array<float, 64>>(toArray(p64))) {}
@@ -311,6 +349,36 @@ class DSPVectorArray
     return *this;
   }
 
+  // The 64 * ROWS floats of a vector the HOST made (MLDSPOps.h:130-136 getBuffer / getConstBuffer): a default-constructed or
+  // literal vector, host tables. The first call gives the vector its own host buffer; what the host writes there is what the
+  // kernel gets when the vector is next used (as constant tables). A computed signal has no host buffer.
+  float* getBuffer()
+  {
+    bool mine = true;  // already one contiguous host buffer of this vector's own?
+    for (size_t j = 0; j < ROWS; ++j) mine = mine && sig_[j].hostMutable && sig_[j].table && sig_[j].table.get() == sig_[0].table.get() + j;
+    if (!mine)
+    {
+      auto buf = std::make_shared<std::vector<float>>(64 * ROWS);
+      for (size_t i = 0; i < 64 * ROWS; ++i) (*buf)[i] = sig_[i / 64].hostSample((int)(i & 63));
+      for (size_t j = 0; j < ROWS; ++j)
+      {
+        gpu::Sig& t = sig_[j];  // field by field: assigning a mutable Sig would give it a copy of its floats
+        t.node = -1;
+        t.lit = 0.f;
+        t.epoch = 0;
+        t.ord = t.hostCtx = -1;
+        t.hostMutable = true;
+        t.table = std::shared_ptr<const std::array<float, 64>>(buf, reinterpret_cast<const std::array<float, 64>*>(buf->data() + 64 * j));
+      }
+    }
+    return const_cast<float*>(sig_[0].table->data());
+  }
+  const float* getConstBuffer() const { return const_cast<DSPVectorArray*>(this)->getBuffer(); }
+
+  // read access to one sample on the host (the reference's `float operator[](int i) const`, MLDSPOps.h:167-168): literals, host
+  // tables and - in a one-context program - context signals (gpu::Sig::hostSample); there is no writable `float&` form
+  float operator[](int i) const { return sig_[(size_t)i / 64].hostSample(i & 63); }
+
   DSPVectorArray<1>& row(int j) { return *reinterpret_cast<DSPVectorArray<1>*>(&sig_[j]); }
   const DSPVectorArray<1>& constRow(int j) const { return *reinterpret_cast<const DSPVectorArray<1>*>(&sig_[j]); }
   DSPVectorArray<1> getRowVectorUnchecked(size_t j) const { return constRow((int)j); }
@@ -345,7 +413,15 @@ class DSPVectorArrayInt  // int32 masks / integers travel as bit patterns (MLDSP
 {
  public:
   std::array<gpu::Sig, ROWS> sig_;
+  // integers the host knows (columnIndexInt()): what map(float(int), x) hands to its function; empty for computed signals
+  std::array<std::shared_ptr<const std::array<int32_t, 64>>, ROWS> host_;
   DSPVectorArrayInt() {}
+  int32_t hostInt(int n) const
+  {
+    const auto& t = host_[(size_t)n / 64];
+    if (!t) throw std::logic_error("mldsp GPU shim: map(float(int), x) needs integers the host knows (columnIndexInt()); x is a computed signal");
+    return (*t)[(size_t)(n & 63)];
+  }
 };
 typedef DSPVectorArrayInt<1> DSPVectorInt;
 
@@ -818,7 +894,14 @@ class NoiseGen : public gpu::ProcNode<MLGPU_PROC_NOISE_GEN>
   }
   DSPVector operator()() { return DSPVector(emit({}, nullptr, 0)); }
 };
-inline DSPVectorInt columnIndexInt() { return truncateFloatToInt(columnIndex()); }  // MLDSPOps.h: 0 .. 63 as integers (exact)
+inline DSPVectorInt columnIndexInt()  // MLDSPOps.h: 0 .. 63 as integers (exact)
+{
+  DSPVectorInt y = truncateFloatToInt(columnIndex());
+  auto t = std::make_shared<std::array<int32_t, 64>>();
+  for (int i = 0; i < 64; ++i) (*t)[(size_t)i] = i;
+  y.host_[0] = t;
+  return y;
+}
 
 // phasorToSine / phasorToSaw / phasorToPulse (MLDSPGens.h:313-369, public free functions over a phasor): one stateless op
 // node each. The device evaluates them with the oscillators' own per-lane code - the branch-free polyBLEP with its
@@ -1351,10 +1434,25 @@ inline DSPVectorArray<ROWS> map(std::function<DSPVector(const DSPVector, const D
   for (size_t j = 0; j < ROWS; ++j) y.row((int)j) = f(x.constRow((int)j), DSPVector((float)j));  // f(row, j): j converts to DSPVector(float), :95
   return y;
 }
+// map(float()) and map(float(int)) (MLDSPFunctional.h:24-35, 50-60) do not depend on device data: the host evaluates the
+// function - in the reference's element order, so a stateful f() (a counter, a random source) gives the same numbers - and the
+// 64 * ROWS results go into the kernel as constant tables, like DSPVector(const float*). What "the same numbers" cannot
+// cover: the reference calls f once per process call, a captured program once per capture (VoiceProgram::update() repeats it).
 template <size_t ROWS>
-inline DSPVectorArray<ROWS> map(std::function<float()>, const DSPVectorArray<ROWS>)
+inline DSPVectorArray<ROWS> map(std::function<float()> f, const DSPVectorArray<ROWS>)
 {
-  throw std::logic_error("mldsp GPU shim: map() with a scalar host function is evaluated per sample on the CPU; write it with DSPVector ops");
+  std::array<float, 64 * ROWS> a;
+  for (size_t n = 0; n < 64 * ROWS; ++n) a[n] = f();
+  return DSPVectorArray<ROWS>(a.data());
+}
+// the integer argument must be host data too: columnIndexInt() / a literal DSPVectorInt (the shim's DSPVectorArrayInt of a
+// computed signal has no host values)
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> map(std::function<float(int)> f, const DSPVectorArrayInt<ROWS> x)
+{
+  std::array<float, 64 * ROWS> a;
+  for (size_t n = 0; n < 64 * ROWS; ++n) a[n] = f(x.hostInt((int)n));
+  return DSPVectorArray<ROWS>(a.data());
 }
 template <size_t ROWS>
 inline DSPVectorArray<ROWS> map(std::function<float(float)>, const DSPVectorArray<ROWS>)
@@ -1514,9 +1612,21 @@ class AudioContext
   DSPVector getInputController(size_t n) const
   {
     if (n > 128) n = 128;
-    return DSPVector(gpu::Sig(gpu::Capture::get().contextInput((int)n), 0.f));
+    gpu::Sig s(gpu::Capture::get().contextInput((int)n), 0.f);
+    s.hostCtx = (int)n;
+    return DSPVector(s);
   }
-  DSPVector getBeatPhase() { return DSPVector(gpu::Sig(gpu::Capture::get().contextInput(gpu::Capture::kBeatPhase), 0.f)); }
+  DSPVector getBeatPhase()
+  {
+    gpu::Sig s(gpu::Capture::get().contextInput(gpu::Capture::kBeatPhase), 0.f);
+    s.hostCtx = gpu::Capture::kBeatPhase;
+    return DSPVector(s);
+  }
+  // AudioContext::addInputEvent / clearInputEvents (MLAudioContext.h:60-62): events wait here until whoever runs the program
+  // hands them to mlgpu_events (gpu::SynthProgram::addInputEvent does so directly for a bank of instruments)
+  void addInputEvent(const Event& e) { pendingEvents_.push_back(e); }
+  void clearInputEvents() { pendingEvents_.clear(); }
+  std::vector<Event> pendingEvents_;
   DSPVectorDynamic inputs;
   DSPVectorDynamic outputs;
 
@@ -1684,6 +1794,62 @@ class Synth : public SignalProcessor
   int numVoices_;
 };
 
+// ---- host-side helpers of MLDSPUtils.h / MLDSPBuffer.h ------------------------------------------------------------------
+#ifndef MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS
+using Projection = std::function<float(float)>;  // MLDSPProjections.h:33
+#endif
+// mapIndices / makeWindow (MLDSPUtils.h:15-26): pDest[i] = shape(i mapped linearly from [0, size - 1] to [0, 1]) - the
+// mapping spelled out (projections::linear, MLDSPProjections.h:147-167) so that it does not need madronalib's header
+inline void mapIndices(float* pDest, size_t size, Projection p)
+{
+  for (size_t i = 0; i < size; ++i) pDest[i] = p((float)(int)i);
+}
+inline void makeWindow(float* pDest, size_t size, Projection windowShape)
+{
+  const float a2 = size - 1.f;
+  if (0.f - a2 == 0.f)
+  {
+    mapIndices(pDest, size, [=](float) { return windowShape(0.f); });
+    return;
+  }
+  const float m = (1.f - 0.f) / (a2 - 0.f);
+  mapIndices(pDest, size, [=](float x) { return windowShape(m * (x - 0.f) + 0.f); });
+}
+namespace dspwindows  // MLDSPUtils.h:28-47
+{
+const Projection rectangle([](float x) { return (x > 0.75f) ? 0.f : ((x < 0.25f) ? 0.f : 1.f); });
+const Projection triangle([](float x) { return (x > 0.5f) ? (2.f - 2.f * x) : (2.f * x); });
+const Projection raisedCosine([](float x) { return 0.5f - 0.5f * cosf(kTwoPi * x); });
+const Projection hamming([](float x) { return 0.54f - 0.46f * cosf(kTwoPi * x); });
+const Projection blackman([](float x) { return 0.42f - 0.5f * cosf(kTwoPi * x) + 0.08f * cosf(2.f * kTwoPi * x); });
+const Projection flatTop([](float x) {
+  const float a0 = 0.21557895f, a1 = 0.41663158f, a2 = 0.277263158f, a3 = 0.083578947f, a4 = 0.006947368f;
+  return a0 - a1 * cosf(kTwoPi * x) + a2 * cosf(2.f * kTwoPi * x) - a3 * cosf(3.f * kTwoPi * x) + a4 * cosf(4.f * kTwoPi * x);
+});
+}  // namespace dspwindows
+
+// DSPBuffer (MLDSPBuffer.h): the host ring of the C-ABI under the reference's name, with its DSPVector forms - for vectors the
+// host holds (made with getBuffer(), tables, literals); what it reads comes back as host vectors
+class DSPBuffer : public gpu::DSPBuffer
+{
+ public:
+  using gpu::DSPBuffer::DSPBuffer;
+  using gpu::DSPBuffer::read;
+  using gpu::DSPBuffer::write;
+  template <size_t ROWS>
+  void write(const DSPVectorArray<ROWS>& v)  // :171-204
+  {
+    gpu::DSPBuffer::write(v.getConstBuffer(), 64 * ROWS);
+  }
+  template <size_t ROWS>
+  void read(DSPVectorArray<ROWS>& dest)  // :227-277: zeros when fewer samples wait
+  {
+    float* p = dest.getBuffer();
+    if (getReadAvailable() >= 64 * ROWS) gpu::DSPBuffer::read(p, 64 * ROWS);
+    else std::fill(p, p + 64 * ROWS, 0.f);
+  }
+};
+
 namespace gpu
 {
 // A per-voice constant (`DSPVector(f)` with a different f for every voice): converts to DSPVector.
@@ -1720,6 +1886,11 @@ struct VoiceProgramOptions
   // Context signals (AudioContext::getInputController / getBeatPhase) have one row per this many adjacent voices: the
   // instrument's polyphony. 0: ctx->getInputPolyphony() if that was set, else one row for the whole bank.
   size_t voicesPerContext{0};
+  // The process function reads samples of context signals into host floats (`ctrlToFreq(ctrlSig[0])`, the reference's
+  // controllers-to-audio.cpp): allowed for a program of ONE context, run a DSPVector at a time - before each launch
+  // readContextSamples() fetches the signals' next 64 samples and update() runs the function again with them, so its host
+  // floats are what the reference computes for that vector. Needs liveConstants.
+  bool hostContextSamples{false};
 };
 
 // Captures a reference-style process function once and runs it for `voices` voices on the GPU.
@@ -1737,6 +1908,7 @@ class VoiceProgram
   std::function<void(AudioContext*)> body_;
   VoiceProgramOptions opt_;
   bool flush_{false};  // the process function runs inside an ml::UsingFlushDenormalsToZero scope
+  std::map<int, std::array<float, 64>> hostContext_;  // VoiceProgramOptions::hostContextSamples: the context signals' next DSPVector
 
  public:
   VoiceProgram(const Engine& e, size_t voices, AudioContext* ctx, SignalProcessFn fn, void* state, VoiceProgramOptions opt = VoiceProgramOptions())
@@ -1755,6 +1927,9 @@ class VoiceProgram
     cap.dedupeConstants = !opt.liveConstants;  // live: one node per use, so that a later capture with other numbers lines up
     cap.contextGroup = contextGroup();
     if (voices % cap.contextGroup) throw Error(MLGPU_ERR_INVALID, "VoiceProgram: the voices are not a whole number of instruments (voicesPerContext)");
+    if (opt.hostContextSamples && (voices != cap.contextGroup || !opt.liveConstants))
+      throw Error(MLGPU_ERR_INVALID, "VoiceProgram: hostContextSamples needs a program of one context (voices == voicesPerContext) and liveConstants");
+    cap.hostContextAllowed = opt.hostContextSamples;
     CaptureScope scope(&cap);
     // pass 1 records what the process function leaves behind in the user's state (DSPVectors kept for the next call);
     // pass 2 builds the graph that is compiled, reading those as one-vector feedback
@@ -1803,6 +1978,8 @@ class VoiceProgram
     cap.eng = &eng_;
     cap.dedupeConstants = !opt_.liveConstants;
     cap.contextGroup = contextGroup();
+    cap.hostContextAllowed = opt_.hostContextSamples;
+    cap.hostContext = hostContext_.empty() ? nullptr : &hostContext_;
     CaptureScope scope(&cap);
     mlgpu_graph* tmp = nullptr;
     eng_.check(mlgpu_graph_create(eng_.handle(), voices_, &tmp));
@@ -1917,6 +2094,18 @@ class VoiceProgram
     return n;
   }
   const char* source() const { return mlgpu_graph_source(g_); }  // the generated HIP kernel
+
+  // VoiceProgramOptions::hostContextSamples: fetch DSPVector `vector` of every context signal (the pointers process() takes,
+  // device memory, one row: QUAD == plain order) to the host, for the process function to index. One small copy and a wait
+  // per call: the price of running host code on signal values, as the reference does per DSPVector.
+  void readContextSamples(const float* const* contextSignals, size_t vector = 0)
+  {
+    if (!opt_.hostContextSamples) throw Error(MLGPU_ERR_INVALID, "VoiceProgram::readContextSamples: not a hostContextSamples program");
+    for (size_t c = 0; c < contextInputs_.size(); ++c)
+      eng_.check(mlgpu_download(eng_.handle(), hostContext_[contextInputs_[c]].data(), contextSignals[c] + vector * 64, 64 * sizeof(float)));
+  }
+  // the same from host memory (a caller that computes its context signals itself)
+  void setContextSamples(int code, const float* samples64) { std::memcpy(hostContext_[code].data(), samples64, 64 * sizeof(float)); }
 
   // per-voice values: [voices] floats
   void setParam(const VoiceParam& p, const std::vector<float>& perVoice) { eng_.check(mlgpu_graph_set_param(g_, p.node(), perVoice.data())); }

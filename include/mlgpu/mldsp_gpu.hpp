@@ -183,6 +183,39 @@ class DeviceGroup
   }
 };
 
+// DSPBuffer (source/DSP/MLDSPBuffer.h:20-384): the reference's single-producer single-consumer float ring, on the host, with
+// its method names. One reader thread and one writer thread may use it concurrently, as in the reference.
+class DSPBuffer
+{
+  mlgpu_dspbuffer* b_;
+
+ public:
+  DSPBuffer() : b_(mlgpu_dspbuffer_create()) {}
+  explicit DSPBuffer(int sizeInSamples) : DSPBuffer() { resize(sizeInSamples); }
+  ~DSPBuffer() { mlgpu_dspbuffer_destroy(b_); }
+  DSPBuffer(const DSPBuffer&) = delete;
+  DSPBuffer& operator=(const DSPBuffer&) = delete;
+  size_t resize(int sizeInSamples) { return mlgpu_dspbuffer_resize(b_, sizeInSamples); }
+  size_t size() const { return mlgpu_dspbuffer_size(b_); }
+  void clear() { mlgpu_dspbuffer_clear(b_); }
+  size_t getReadAvailable() const { return mlgpu_dspbuffer_read_available(b_); }
+  size_t getWriteAvailable() const { return mlgpu_dspbuffer_write_available(b_); }
+  void write(const float* src, size_t samples) { mlgpu_dspbuffer_write(b_, src, samples); }
+  size_t read(float* dst, size_t samples) { return mlgpu_dspbuffer_read(b_, dst, samples); }
+  bool readVector(float* dst64) { return mlgpu_dspbuffer_read_vector(b_, dst64) != 0; }
+  void discard(size_t samples) { mlgpu_dspbuffer_discard(b_, samples); }
+  void writeWithOverlapAdd(const float* src, size_t samples, int overlap) { mlgpu_dspbuffer_write_with_overlap_add(b_, src, samples, (size_t)overlap); }
+  void readWithOverlap(float* dst, size_t samples, int overlap) { mlgpu_dspbuffer_read_with_overlap(b_, dst, samples, (size_t)overlap); }
+  void peekMostRecent(float* dst, size_t samples) const { mlgpu_dspbuffer_peek_most_recent(b_, dst, samples); }
+  mlgpu_dspbuffer* handle() const { return b_; }
+};
+
+// makeWindow(dest, size, dspwindows::<shape>) (source/DSP/MLDSPUtils.h:22-47) by shape number (mlgpu_window)
+inline void makeWindow(float* dest, size_t size, int shape)
+{
+  if (mlgpu_make_window(dest, size, shape) != MLGPU_OK) throw std::invalid_argument("ml::gpu::makeWindow: unknown window shape");
+}
+
 // A V-voice, T-vector float signal in HBM.
 class DeviceSignal
 {

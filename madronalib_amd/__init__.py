@@ -419,6 +419,18 @@ class DSPBuffer:
         return out
 
 
+WINDOW_SHAPES = {"rectangle": 0, "triangle": 1, "raisedCosine": 2, "hamming": 3, "blackman": 4, "flatTop": 5}
+
+
+def make_window(size, shape="triangle"):
+    """makeWindow(dest, size, dspwindows::<shape>) (source/DSP/MLDSPUtils.h:22-47): a host table of `size` floats."""
+    out = np.empty(int(size), np.float32)
+    st = _lib.load().mlgpu_make_window(_np_ptr(out), int(size), WINDOW_SHAPES[shape] if isinstance(shape, str) else int(shape))
+    if st != 0:
+        raise ValueError(f"make_window: unknown shape {shape!r}")
+    return out
+
+
 class ProcessBuffer:
     """The reference's SignalProcessBuffer (MLSignalProcessBuffer.h) over the engine: host blocks of any size in and
     out, `fn(n_vectors, d_inputs, d_outputs)` called once per block with single-voice device signals (raw pointers)."""

@@ -86,6 +86,7 @@ def _declare(L):
         fn.argtypes = args
 
     sig("mlgpu_abi_version", i, [])
+    sig("mlgpu_make_window", i, [vp, c.c_size_t, i])
     sig("mlgpu_device_source_hash", c.c_char_p, [])
     sig("mlgpu_status_string", c.c_char_p, [i])
     sig("mlgpu_device_count", i, [])

@@ -156,3 +156,37 @@ void mlgpu_build_impulse_table(float* out17)
   }
   for (int n = 0; n < N; ++n) out17[n] = prod[n] / sum;
 }
+
+extern "C"
+{
+  // makeWindow(pDest, size, dspwindows::shape), source/DSP/MLDSPUtils.h:22-47: element i = shape(m * (i - 0) + 0) with
+  // m = (1 - 0) / ((size - 1) - 0) - projections::linear({0, size - 1}, {0, 1}), MLDSPProjections.h:147-167, whose degenerate
+  // interval (size 1) maps everything to 0. Host libm (cosf), like the coefficient makers.
+  int mlgpu_make_window(float* dest, size_t size, int shape)
+  {
+    if (!dest || shape < 0 || shape > MLGPU_WINDOW_FLAT_TOP) return MLGPU_ERR_INVALID;
+    const float a2 = size - 1.f;
+    const bool degenerate = (0.f - a2 == 0.f);
+    const float m = degenerate ? 0.f : (1.f - 0.f) / (a2 - 0.f);
+    for (size_t i = 0; i < size; ++i)
+    {
+      const float x = degenerate ? 0.f : m * ((float)(int)i - 0.f) + 0.f;
+      float w = 0.f;
+      switch (shape)
+      {
+        case MLGPU_WINDOW_RECTANGLE: w = (x > 0.75f) ? 0.f : ((x < 0.25f) ? 0.f : 1.f); break;
+        case MLGPU_WINDOW_TRIANGLE: w = (x > 0.5f) ? (2.f - 2.f * x) : (2.f * x); break;
+        case MLGPU_WINDOW_RAISED_COSINE: w = 0.5f - 0.5f * cosf(kTwoPi * x); break;
+        case MLGPU_WINDOW_HAMMING: w = 0.54f - 0.46f * cosf(kTwoPi * x); break;
+        case MLGPU_WINDOW_BLACKMAN: w = 0.42f - 0.5f * cosf(kTwoPi * x) + 0.08f * cosf(2.f * kTwoPi * x); break;
+        default:
+        {
+          const float a0 = 0.21557895f, a1 = 0.41663158f, a2c = 0.277263158f, a3 = 0.083578947f, a4 = 0.006947368f;
+          w = a0 - a1 * cosf(kTwoPi * x) + a2c * cosf(2.f * kTwoPi * x) - a3 * cosf(3.f * kTwoPi * x) + a4 * cosf(4.f * kTwoPi * x);
+        }
+      }
+      dest[i] = w;
+    }
+    return MLGPU_OK;
+  }
+}

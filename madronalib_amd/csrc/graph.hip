@@ -775,8 +775,13 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   if (g->hasEventRows)
     for (int l = 0; l < VL; ++l) s << "  mlev::EventsVoice ev" << sfx(l) << ";\n  ev" << sfx(l) << ".load(a.events, v" << sfx(l) << ");\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
+  // (Round 3, measured and not kept - profiles/r03_synthfused_variants.txt: a second instance of the vector body, or of the
+  // whole vector loop, for wavefronts without event records - EventsVoice::begin_vector / quad<true>, no record walk, no
+  // note-frame loop - chosen by a wave-uniform test per vector or per launch. The record-free instance does come out
+  // without scratch traffic, but the kernel as a whole needs more registers (322 unbounded, 788 B of scratch at four
+  // wavefronts per SIMD) and the block takes 1.70-2.06 ms against 1.54 for the single body below.)
   if (g->hasEventRows)
-    for (int l = 0; l < VL; ++l) s << "    ev" << sfx(l) << ".begin_vector(t);\n";
+    for (int l = 0; l < VL; ++l) s << "    ev" << sfx(l) << ".scan(t);\n    ev" << sfx(l) << ".begin_vector(t);\n";
   // once per DSPVector: vector-rate nodes, then the vector-rate processors' begin_vector
   for (size_t i = 0; i < g->nodes.size(); ++i)
   {

@@ -272,6 +272,12 @@ MLD void note_frame(const Rec* recs, uint32_t& nc, uint32_t vend, int n, bool& p
 // same records and the same per-voice state words as e2s_kernel (a launch of either leaves the state the other expects; rows
 // that are not computed keep their glides where they are, as with mlgpu_events_set_wanted_rows). MIDI protocol only: one lane
 // per playing voice, lane == voice index. A vector with a note event is walked with note_frame(), as e2s_kernel walks it.
+template <bool B>
+struct BoolTag
+{
+  static constexpr bool value = B;
+};
+
 struct EventsVoice
 {
   typedef float f32x4e __attribute__((ext_vector_type(4)));
@@ -378,13 +384,26 @@ struct EventsVoice
     sw(S_PG_PER_GLIDE) = (uint32_t)pgPerGlide;
   }
 
-  MLD void begin_vector(size_t t)
+  // Records of this lane in DSPVector t: [cursor, vend). The generated kernel asks every lane of the wavefront, and runs
+  // the vector through begin_vector / quad<NO_RECS = true> when no lane has one (the usual case by far: a voice sees a
+  // handful of events per second): that instance has no record walk and no note-frame loop in it, and the registers the
+  // note path needs are not held through the vectors that do not use it.
+  MLD bool scan(size_t t)
   {
     vend = cursor;
     while (vend < recEnd && recs[vend].vec == (uint32_t)t) ++vend;
-    if (!awake)
-      for (uint32_t r = cursor; r < vend; ++r)
-        if ((recs[r].typeTimeFlags & 0xFF) == REC_AWAKE) awake = true;
+    return vend != cursor;
+  }
+  template <bool NO_RECS = false>
+  MLD void begin_vector(size_t t)
+  {
+    (void)t;  // [cursor, vend) comes from scan(t), which the kernel calls first
+    if constexpr (!NO_RECS)
+    {
+      if (!awake)
+        for (uint32_t r = cursor; r < vend; ++r)
+          if ((recs[r].typeTimeFlags & 0xFF) == REC_AWAKE) awake = true;
+    }
     float finalVelocity = velocity;
     bool noteHere = false;
     float driftValue = 0.f;
@@ -416,7 +435,7 @@ struct EventsVoice
       sw(S_DRIFT_COUNTER) = (uint32_t)driftCounter;
       // ---- values that only matter at the end of the vector (endProcess, :218-247); the rows this object does not compute
       //      keep their values in memory ----
-      for (uint32_t r = cursor; r < vend; ++r)
+      for (uint32_t r = cursor; !NO_RECS && r < vend; ++r)
       {
         const Rec rc = recs[r];
         switch (rc.typeTimeFlags & 0xFF)
@@ -443,7 +462,7 @@ struct EventsVoice
     }
     nc = cursor;
     preApplied = false;
-    quiet = __builtin_amdgcn_ballot_w64(noteHere) == 0;
+    quiet = NO_RECS || __builtin_amdgcn_ballot_w64(noteHere) == 0;
     pitchForm = 0;
     mDriftMoves = mDriftRamps = 0;
     if (quiet)
@@ -501,6 +520,7 @@ struct EventsVoice
     }
   }
 
+  template <bool NO_RECS = false>
   MLD void quad(int q, f32x4e& oPitch, f32x4e& oGate)
   {
     const float pitchBendScale = s.pitchBendRange;  // MIDI protocol, :417-423
@@ -531,7 +551,7 @@ struct EventsVoice
       }
       return;
     }
-    if (quiet)
+    if (NO_RECS || quiet)
     {
       const float cb[4] = {nb[0], nb[1], nb[2], nb[3]}, cd[4] = {nd[0], nd[1], nd[2], nd[3]};
       if (on && q < 15)
@@ -558,6 +578,7 @@ struct EventsVoice
     }
     oPitch = f32x4e{0.f, 0.f, 0.f, 0.f};
     oGate = oPitch;
+    if constexpr (NO_RECS) return;  // not reached: a vector without records is quiet
 #pragma unroll 1
     for (int k = 0; k < 4; ++k)
     {

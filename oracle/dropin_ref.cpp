@@ -96,6 +96,26 @@ extern "C" int decay_ref_run(size_t V, size_t T, int flush, const float* in0, fl
   return 0;
 }
 
+// ---- host data (tests/cpp/dropin_hostdata.h) ----
+#include "../tests/cpp/dropin_hostdata.h"
+extern "C" int hostdata_ref_run(size_t V, size_t T, const float* in0, float* outs /* [kHostDataOutputs][V][64 T] */)
+{
+  const size_t S = T * kFloatsPerDSPVector;
+  for (size_t v = 0; v < V; ++v)
+  {
+    HostDataState state;
+    hostDataSetup(&state);
+    AudioContext ctx(1, kHostDataOutputs, 48000);
+    for (size_t t = 0; t < T; ++t)
+    {
+      load(ctx.inputs[0], in0 + v * S + t * kFloatsPerDSPVector);
+      hostDataProcess(&ctx, &state);
+      for (int o = 0; o < kHostDataOutputs; ++o) store(ctx.outputs[o], outs + ((size_t)o * V + v) * S + t * kFloatsPerDSPVector);
+    }
+  }
+  return 0;
+}
+
 // ---- every free function of MLDSPOps.h by name (tests/cpp/dropin_ops.h) ----
 #include "../tests/cpp/dropin_ops.h"
 extern "C" int ops_ref_run(size_t V, size_t T, const float* in0, const float* in1, float* outs /* [kOpsOutputs][V][64 T] */)

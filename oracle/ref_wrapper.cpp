@@ -1623,6 +1623,12 @@ extern "C"
   void mlref_range_closed(float a, float b, float* out64) { store(rangeClosed(a, b), out64); }
   void mlref_range_open(float a, float b, float* out64) { store(rangeOpen(a, b), out64); }
 
+  // ---- makeWindow / dspwindows (MLDSPUtils.h:22-47) ----
+  void mlref_make_window(float* dest, size_t size, int shape)
+  {
+    const Projection shapes[6] = {dspwindows::rectangle, dspwindows::triangle, dspwindows::raisedCosine, dspwindows::hamming, dspwindows::blackman, dspwindows::flatTop};
+    makeWindow(dest, size, shapes[shape]);
+  }
   // ---- DSPBuffer (MLDSPBuffer.h) for pinning the host ring restatement ----
   void* mlref_dspbuffer_create(int size)
   {

@@ -174,6 +174,46 @@ extern "C" int decay_gpu_run(size_t V, size_t T, int flush, const float* in0, fl
   }
 }
 
+// ---- host data: scalar map forms, windows through getBuffer(), DSPBuffer overlap-add, v[n] on host vectors ----
+#include "dropin_hostdata.h"
+extern "C" int hostdata_gpu_run(size_t V, size_t T, const float* in0, float* outs /* [kHostDataOutputs][V][64 T] */, char* err, size_t errLen)
+{
+  try
+  {
+    gpu::Engine eng(0);
+    HostDataState state;
+    hostDataSetup(&state);
+    AudioContext ctx(1, kHostDataOutputs, 48000);
+    gpu::VoiceProgram prog(eng, V, &ctx, hostDataProcess, &state);
+    gpu::DeviceSignal vm(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR), q0(eng, V, T);
+    eng.check(mlgpu_upload(eng.handle(), vm.data(), in0, vm.bytes()));
+    eng.check(mlgpu_layout_convert(eng.handle(), vm.data(), MLGPU_LAYOUT_VOICE_MAJOR, q0.data(), MLGPU_LAYOUT_QUAD, V, T));
+    std::vector<gpu::DeviceSignal> o;
+    std::vector<gpu::DeviceSignal*> po;
+    o.reserve(kHostDataOutputs);
+    for (int i = 0; i < kHostDataOutputs; ++i) o.emplace_back(eng, V, T);
+    for (auto& x : o) po.push_back(&x);
+    prog.process({&q0}, po);
+    const size_t n = V * T * 64;
+    for (int i = 0; i < kHostDataOutputs; ++i)
+    {
+      eng.check(mlgpu_layout_convert(eng.handle(), o[(size_t)i].data(), MLGPU_LAYOUT_QUAD, vm.data(), MLGPU_LAYOUT_VOICE_MAJOR, V, T));
+      eng.check(mlgpu_download(eng.handle(), outs + (size_t)i * n, vm.data(), vm.bytes()));
+    }
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
 #include "dropin_ops.h"
 extern "C" int ops_gpu_run(size_t V, size_t T, const float* in0, const float* in1, float* outs /* [kOpsOutputs][V][64 T] */, char* err, size_t errLen)
 {

@@ -101,3 +101,41 @@ def test_spsc_threads():
     tw.start(), tr.start()
     tw.join(30), tr.join(30)
     assert (np.concatenate(got) == np.arange(total, dtype=np.float32)).all()
+
+
+def test_windows_match_the_reference(ref):
+    """makeWindow(dest, size, dspwindows::shape) for the six shapes and a few sizes (a DSPVector, an odd size, 1): the C-ABI's host
+    tables are the reference's floats (host libm on both sides)."""
+    import ctypes
+    c_f32p = ctypes.POINTER(ctypes.c_float)
+    ref.lib.mlref_make_window.restype = None
+    ref.lib.mlref_make_window.argtypes = [c_f32p, ctypes.c_size_t, ctypes.c_int]
+    for name, shape in ml.WINDOW_SHAPES.items():
+        for size in (64, 37, 256, 2, 1):
+            want = np.empty(size, np.float32)
+            ref.lib.mlref_make_window(want.ctypes.data_as(c_f32p), size, shape)
+            got = ml.make_window(size, name)
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), (name, size)
+    t = ml.make_window(64, "triangle")
+    assert t[0] == 0 and abs(t[31] - t[32]) < 1e-6 and t.max() <= 1.0
+    with pytest.raises(ValueError):
+        ml.make_window(8, 9)
+
+
+def test_overlap_add_of_triangle_windows_is_constant(ref):
+    """Tests/dspBufferTest.cpp "overlap": eight triangle windows of one DSPVector written with half-vector overlap; past the
+    start-up the sums are constant - and every sample equals what the reference's DSPBuffer holds."""
+    w = ml.make_window(64, "triangle")
+    b, rb = ml.DSPBuffer(256), ref.dspbuffer(256)
+    for _ in range(8):
+        b.write_with_overlap_add(w, 32)
+        rb.write_with_overlap_add(w, 32)
+    outs, routs = [], []
+    for _ in range(3):
+        ok, v = b.read_vector()
+        assert ok
+        outs.append(v)
+        routs.append(rb.read(64))
+    assert (outs[1] == outs[2]).all()                       # the reference test's REQUIRE(outputVec == outputVec2)
+    for a, r in zip(outs, routs):
+        assert (np.asarray(a).view(np.uint32) == np.asarray(r).view(np.uint32)).all()

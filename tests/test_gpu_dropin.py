@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from inputs import assert_bits_equal, gate_signal
+from inputs import assert_bits_equal, gate_signal, lcg_noise
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 c_f32p = ctypes.POINTER(ctypes.c_float)
@@ -530,3 +530,27 @@ def test_one_shot_retriggered_between_launches(every_other):
     assert Lr.objects_ref_run(V, T, p(x), p(slow), p(plain)) == 0
     changed = np.abs(plain[0] - want[0]).max(axis=1) > 0
     assert changed[0::2].all() and (changed[1::2].all() if not every_other else not changed[1::2].any())
+
+
+@pytest.mark.gpu
+def test_host_data_forms_same_source_same_bits():
+    """tests/cpp/dropin_hostdata.h: where DSPVector code touches single floats on the host - map(float()) with a stateful function,
+    map(float(int)) over columnIndexInt(), window tables written through getBuffer() in a setup function, the overlap-add use of
+    DSPBuffer (Tests/dspBufferTest.cpp "overlap") read back into a DSPVector, v[n] on host-made vectors. Same source against the
+    reference and against the shim: in the shim these are host-evaluated tables carried into the kernel as constant vectors."""
+    Lg, Lr = _gpu_lib(), _ref_lib()
+    K, V, T = 4, 70, 3
+    S = 64 * T
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 11, S)
+    want = np.zeros((K, V, S), np.float32)
+    got = np.zeros((K, V, S), np.float32)
+    Lr.hostdata_ref_run.restype = ctypes.c_int
+    Lr.hostdata_ref_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p]
+    Lg.hostdata_gpu_run.restype = ctypes.c_int
+    Lg.hostdata_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    assert Lr.hostdata_ref_run(V, T, x.ctypes.data_as(c_f32p), want.ctypes.data_as(c_f32p)) == 0
+    err = ctypes.create_string_buffer(4096)
+    assert Lg.hostdata_gpu_run(V, T, x.ctypes.data_as(c_f32p), got.ctypes.data_as(c_f32p), err, 4096) == 0, err.value.decode()
+    for k, name in enumerate(["window through getBuffer + Lopass", "map(float())", "map(float(int))", "v[n] of host vectors, DSPBuffer overlap-add"]):
+        assert_bits_equal(got[k], want[k], True, f"host-data drop-in output {k} ({name})")
+    assert np.abs(want).max() > 0.1

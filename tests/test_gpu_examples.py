@@ -95,3 +95,40 @@ def test_reference_params_example_same_source_same_bits():
         assert_bits_equal(got0[v], want0, True, f"params example left, voice {v}")
         assert_bits_equal(got1[v], want1, True, f"params example right, voice {v}")
     assert np.abs(want0).max() > 0.05
+
+
+class _CtlEv(ctypes.Structure):
+    _fields_ = [("type", ctypes.c_int), ("channel", ctypes.c_int), ("sourceIdx", ctypes.c_int), ("time", ctypes.c_int),
+                ("value1", ctypes.c_float), ("value2", ctypes.c_float)]
+
+
+@pytest.mark.gpu
+def test_reference_controllers_to_audio_example_unchanged():
+    """controllers-to-audio.cpp, the example that reads a SAMPLE of a signal into a host float: `float freqInHz =
+    ctrlToFreq(ctrlSig[0])` (a std::function projection, 110 * 4^x) per DSPVector, then SineGen(freqInHz / sr). Compiled
+    unchanged against the shim and run through gpu::VoiceProgramOptions::hostContextSamples - controller signals made on the
+    device, their samples fetched, the process function re-run on the host per DSPVector, the captured kernel launched - it gives
+    the reference's floats: 300 vectors of eight sines following eight moving MIDI controllers and a volume controller."""
+    Lg, Lr = _libs()
+    Lr.example_controllers_ref_run.argtypes = [ctypes.POINTER(_CtlEv), ctypes.c_int, ctypes.c_int, c_f32p, c_f32p]
+    Lg.example_controllers_gpu_run.argtypes = [ctypes.POINTER(_CtlEv), ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    CTRL, T = 6, 300
+    numbers = [19, 23, 27, 31, 49, 53, 57, 61]
+    rng = np.random.default_rng(77)
+    evs = [(CTRL, 1, 62, 5, 0.8, 0.0)]
+    t = 40
+    while t < 64 * T:
+        evs.append((CTRL, int(rng.integers(1, 17)), int(rng.choice(numbers + [62])), t, float(np.float32(rng.random())), 0.0))
+        t += int(rng.integers(1, 900))
+    arr = (_CtlEv * len(evs))(*[_CtlEv(*e) for e in evs])
+    want = [np.zeros(64 * T, np.float32) for _ in range(2)]
+    assert Lr.example_controllers_ref_run(arr, len(evs), T, want[0].ctypes.data_as(c_f32p), want[1].ctypes.data_as(c_f32p)) == 0
+    got = [np.zeros(64 * T, np.float32) for _ in range(2)]
+    err = ctypes.create_string_buffer(4096)
+    st = Lg.example_controllers_gpu_run(arr, len(evs), T, got[0].ctypes.data_as(c_f32p), got[1].ctypes.data_as(c_f32p), err, 4096)
+    assert st == 0, err.value.decode()
+    assert_bits_equal(got[0], want[0], True, "controllers-to-audio left")
+    assert_bits_equal(got[1], want[1], True, "controllers-to-audio right")
+    assert np.abs(want[0]).max() > 0.2
+    # the oscillators really do move with their controllers: the spectrum centroid of the first and last second differ
+    assert not np.allclose(want[0][:4096], want[0][-4096:])

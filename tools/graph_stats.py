@@ -23,6 +23,12 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 def description(name):
     if name == "synth16":
         return patches.synth16()
+    if name == "synth16full":
+        return patches.synth16(full=True)
+    if name == "synthvoice":      # the instrument bank's voice: pitch streamed in (bench.py --workload synth)
+        return patches.synth16(pitch_input=True)
+    if name == "synthfused":      # the same with the pitch and gate rows computed inside (bench.py --workload synthfused)
+        return patches.synth16(pitch_input=True, event_rows=True)
     if name == "allpass4":
         desc = [dict(name="x", type="input"), dict(name="dl", type="param")]
         src = "x"
@@ -42,9 +48,12 @@ def main():
     ap.add_argument("--windows", action="store_true")
     ap.add_argument("--vpl", type=int, default=0)
     ap.add_argument("--dump", default=None)
+    ap.add_argument("--voices", type=int, default=1024, help="bank size (>= 65536: the register budget of a bank that fills the chip)")
+    ap.add_argument("--group-sum", type=int, default=0, help="output 0 = the in-order sum of groups of that many voices")
     a = ap.parse_args()
     desc, outs = description(a.graph)
-    g = ml.Graph(ml.OfflineEngine(), 1024, desc, outs, voices_per_lane=a.vpl, delay_windows=a.windows)
+    g = ml.Graph(ml.OfflineEngine(), a.voices, desc, outs, voices_per_lane=a.vpl, delay_windows=a.windows,
+                 output_groups={0: a.group_sum} if a.group_sum else None)
     src, code = g.emit()
     d = a.dump or tempfile.mkdtemp()
     os.makedirs(d, exist_ok=True)
