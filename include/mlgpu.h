@@ -593,7 +593,7 @@ int mlgpu_graph_add_named(mlgpu_graph* g, const char* proc_name, const char* nod
 int mlgpu_graph_set_named_coeff(mlgpu_graph* g, const char* node_name, const char* coeff_name, const float* h_per_voice, float uniform);
 int mlgpu_graph_set_param_by_name(mlgpu_graph* g, const char* param_name, const float* h_per_voice, float uniform);
 
-/* Limits per graph: 16 streamed inputs, 8 controls, 8 outputs (MLGPU_ERR_UNSUPPORTED beyond). */
+/* Limits per graph: 32 streamed inputs, 8 controls, 8 outputs (MLGPU_GRAPH_MAX_INPUTS / _CONTROLS / _OUTPUTS in mlgpu_device_args.hpp; MLGPU_ERR_UNSUPPORTED beyond). */
 int mlgpu_graph_add_output(mlgpu_graph* g, int node);
 int mlgpu_graph_node(mlgpu_graph* g, const char* name); /* id of the node called `name`, or < 0 */
 /* (re)name a node - e.g. a constant, which mlgpu_graph_add_const creates nameless - so that it can be wired by name */

@@ -240,6 +240,7 @@ extern "C"
     HIP_TRY(e, hipStreamEndCapture(e->stream, &graph));
     if (!graph) return fail(e, MLGPU_ERR_HIP, "end_recording: the capture was invalidated (a call that waits for the device ran while recording)");
     mlgpu_sequence* s = new (std::nothrow) mlgpu_sequence();
+    if (s) ++e->liveSequences;
     if (!s)
     {
       hipGraphDestroy(graph);
@@ -278,6 +279,7 @@ extern "C"
     hipStreamSynchronize(s->e->stream);
     if (s->exec) hipGraphExecDestroy(s->exec);
     if (s->graph) hipGraphDestroy(s->graph);
+    if (s->e->liveSequences > 0) --s->e->liveSequences;
     delete s;
     return MLGPU_OK;
   }

@@ -555,7 +555,7 @@ struct mlgpu_events
   // watched controllers (mlgpu_events_watch_controllers): lane = slot * nInstruments + instrument
   std::vector<int> watched;
   int slotOf[kNumControllers];
-  size_t ctlMaxVectors{0};
+  size_t ctlMaxVectors{0}, ctlCapacityVectors{0};  // longest launch allowed / what d_ctlOut was allocated for
   float* d_ctlOut{nullptr};
   uint32_t* d_ctlState{nullptr};
   std::vector<std::vector<CtlRec>> ctlLaneRecs;
@@ -578,6 +578,8 @@ struct mlgpu_events
   uint32_t rowMask{0xFFu};                 // mlgpu_events_set_wanted_rows
   size_t lanes() const { return nInstruments * (size_t)group; }
 };
+
+void mlgpu_graph_forget_events(mlgpu_events* ev);  // graph.hip
 
 namespace
 {
@@ -846,6 +848,10 @@ extern "C"
   int mlgpu_events_destroy(mlgpu_events* ev)
   {
     if (!ev) return MLGPU_ERR_INVALID;
+    // waiting for the stream would invalidate a capture in progress; a recorded sequence may replay launches that read this object
+    if (ev->e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_destroy waits for the device: not while recording a sequence");
+    if (ev->e->liveSequences > 0) return efail(ev, MLGPU_ERR_INVALID, "events_destroy: recorded sequences of this engine may read this object: destroy them first");
+    mlgpu_graph_forget_events(ev);  // graphs bound to this object (mlgpu_graph_bind_events) go back to "no events object"
     hipSetDevice(ev->e->device);
     hipStreamSynchronize(ev->e->stream);
     if (ev->d_state) hipFree(ev->d_state);
@@ -1245,21 +1251,29 @@ extern "C"
     hipStreamSynchronize(e->stream);
     if (n > 0 && ev->watched == std::vector<int>(numbers, numbers + n))  // the same controllers: only the reserved length changes
     {
-      if (maxVectors == ev->ctlMaxVectors) return MLGPU_OK;
+      if (maxVectors <= ev->ctlCapacityVectors)  // the signals' pointers (mlgpu_events_controller_signal) are only ever replaced to grow
+      {
+        ev->ctlMaxVectors = maxVectors;
+        return MLGPU_OK;
+      }
+      if (e->liveSequences > 0)
+        return efail(ev, MLGPU_ERR_INVALID, "events_watch_controllers would move the controller signals that recorded sequences of this engine may read: destroy them first");
       float* fresh = nullptr;
       const size_t bytes = sizeof(float) * 64 * maxVectors * ev->ctlLanes();
       if (hipMalloc((void**)&fresh, bytes) != hipSuccess) return efail(ev, MLGPU_ERR_OOM, "events_watch_controllers: controller signals");
       hipMemsetAsync(fresh, 0, bytes, e->stream);
       hipFree(ev->d_ctlOut);
       ev->d_ctlOut = fresh;
-      ev->ctlMaxVectors = maxVectors;
+      ev->ctlMaxVectors = ev->ctlCapacityVectors = maxVectors;
       return MLGPU_OK;
     }
+    if (e->liveSequences > 0 && ev->d_ctlOut)
+      return efail(ev, MLGPU_ERR_INVALID, "events_watch_controllers would free controller signals that recorded sequences of this engine may read: destroy them first");
     freeControllers(ev);
     if (n == 0) return MLGPU_OK;
     ev->watched.assign(numbers, numbers + n);
     for (int i = 0; i < n; ++i) ev->slotOf[numbers[i]] = i;
-    ev->ctlMaxVectors = maxVectors;
+    ev->ctlMaxVectors = ev->ctlCapacityVectors = maxVectors;
     const size_t lanes = ev->ctlLanes();
     ev->ctlLaneRecs.resize(lanes);
     hipError_t err = hipMalloc((void**)&ev->d_ctlOut, sizeof(float) * 64 * maxVectors * lanes);

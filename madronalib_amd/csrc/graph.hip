@@ -29,11 +29,15 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <set>
 #include <sstream>
 
 #include "mlgpu_internal.hpp"
 
 extern const char mlgpu_device_source_hash_str[];
+struct mlgpu_graph;
+static std::mutex g_boundMutex;
+static std::set<mlgpu_graph*> g_boundGraphs;  // graphs with an events object bound (mlgpu_graph_bind_events)
 extern const int mlgpu_embedded_count;
 extern const char* const mlgpu_embedded_names[];
 extern const char* const mlgpu_embedded_sources[];
@@ -1282,6 +1286,10 @@ extern "C"
   int mlgpu_graph_destroy(mlgpu_graph* g)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    {
+      std::lock_guard<std::mutex> lock(g_boundMutex);
+      g_boundGraphs.erase(g);
+    }
     if (g->e)
     {
       hipSetDevice(g->e->device);
@@ -1352,6 +1360,7 @@ extern "C"
     if (id >= 0) g->hasEventRows = true;
     return id;
   }
+  // (file scope, see below) every graph currently bound to an events object, so that destroying the object can unbind them
   int mlgpu_graph_bind_events(mlgpu_graph* g, mlgpu_events* ev)
   {
     if (!g || !ev) return MLGPU_ERR_INVALID;
@@ -1359,6 +1368,10 @@ extern "C"
     if (mlgpu_events_engine(ev) != g->e) return gfail(g, MLGPU_ERR_INVALID, "graph_bind_events: the events object belongs to another engine");
     if (!mlgpu_events_is_midi(ev)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_bind_events: MIDI protocol only (one lane per voice)");
     if (mlgpu_events_num_voices(ev) != g->V) return gfail(g, MLGPU_ERR_INVALID, "graph_bind_events: instruments x polyphony must equal the graph's voices");
+    {
+      std::lock_guard<std::mutex> lock(g_boundMutex);
+      g_boundGraphs.insert(g);
+    }
     g->events = ev;
     return MLGPU_OK;
   }
@@ -2092,5 +2105,21 @@ extern "C"
     }
     g->vectorCount += T;
     return MLGPU_OK;
+  }
+}
+
+// events.hip, mlgpu_events_destroy: no graph keeps a pointer to an events object that is gone
+void mlgpu_graph_forget_events(mlgpu_events* ev)
+{
+  std::lock_guard<std::mutex> lock(g_boundMutex);
+  for (auto it = g_boundGraphs.begin(); it != g_boundGraphs.end();)
+  {
+    if ((*it)->events == ev)
+    {
+      (*it)->events = nullptr;
+      it = g_boundGraphs.erase(it);
+    }
+    else
+      ++it;
   }
 }

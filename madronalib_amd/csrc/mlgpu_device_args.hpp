@@ -56,7 +56,7 @@ struct EventsDev
   E2SSettings s;
 };
 
-// a fused graph kernel: up to 16 streamed inputs, up to 4 outputs, per-voice constants [P][V]
+// a fused graph kernel: up to MLGPU_GRAPH_MAX_INPUTS (32) streamed inputs, MLGPU_GRAPH_MAX_OUTPUTS (8) outputs, per-voice constants [P][V]
 #define MLGPU_GRAPH_MAX_INPUTS 32
 #define MLGPU_GRAPH_MAX_OUTPUTS 8
 #define MLGPU_GRAPH_MAX_CONTROLS 8

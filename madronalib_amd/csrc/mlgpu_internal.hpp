@@ -26,6 +26,7 @@ struct mlgpu_engine
   unsigned long long* d_validate{nullptr};  // {count, first index} of mlgpu_validate, allocated with the engine
   uint32_t kflags{0};  // MLGPU_KFLAG_* handed to every arithmetic kernel (mlgpu_engine_set_flush_denormals)
   bool recording{false};  // between mlgpu_engine_begin_recording and _end_recording: launches are captured, not run
+  int liveSequences{0};   // recorded sequences not yet destroyed: they hold device pointers, so buffers handed out must not move
 };
 
 struct mlgpu_sequence  // a recorded launch sequence: a hipGraph instantiated once, replayed with one launch

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void transport_kernel(float* omegaState, const
 struct mlgpu_transport
 {
   mlgpu_engine* e{nullptr};
-  size_t n{0}, maxVectors{0}, vectors{0};
+  size_t n{0}, maxVectors{0}, capacityVectors{0}, vectors{0};  // capacityVectors: what d_out was allocated for (>= maxVectors)
   std::vector<TimeState> st;
   std::vector<uint32_t> dirty;
   float* d_omega{nullptr};
@@ -186,7 +186,7 @@ extern "C"
     if (!t) return MLGPU_ERR_OOM;
     t->e = e;
     t->n = n;
-    t->maxVectors = maxVectors;
+    t->maxVectors = t->capacityVectors = maxVectors;
     t->st.resize(n);
     hipError_t err = hipSetDevice(e->device);
     if (err == hipSuccess) err = hipMalloc((void**)&t->d_omega, sizeof(float) * n);
@@ -211,19 +211,28 @@ extern "C"
     return MLGPU_OK;
   }
 
-  int mlgpu_transport_reserve(mlgpu_transport* t, size_t maxVectors)  // longer (or shorter) launches from now on; the phasors go on
+  // Longer (or shorter) launches from now on; the phasors go on. The signal buffer - whose pointer callers hold
+  // (mlgpu_transport_beat_phase) - is only ever replaced to GROW, and never while a recorded sequence could still replay a
+  // launch that reads the old one.
+  int mlgpu_transport_reserve(mlgpu_transport* t, size_t maxVectors)
   {
     if (!t || maxVectors == 0) return MLGPU_ERR_INVALID;
-    if (maxVectors == t->maxVectors) return MLGPU_OK;
+    if (maxVectors <= t->capacityVectors)
+    {
+      t->maxVectors = maxVectors;  // a signal of T vectors is laid out by T, not by the reservation: nothing moves
+      return MLGPU_OK;
+    }
     if (t->e->recording) return tfail(t, MLGPU_ERR_INVALID, "transport_reserve allocates: not while recording a sequence");
+    if (t->e->liveSequences > 0)
+      return tfail(t, MLGPU_ERR_INVALID, "transport_reserve would move the beat-phase signal that recorded sequences of this engine may read: destroy them first");
     if (hipSetDevice(t->e->device) != hipSuccess) return tfail(t, MLGPU_ERR_HIP, "hipSetDevice");
     hipStreamSynchronize(t->e->stream);
     float* fresh = nullptr;
     if (hipMalloc((void**)&fresh, sizeof(float) * 64 * maxVectors * t->n) != hipSuccess) return tfail(t, MLGPU_ERR_OOM, "transport_reserve");
     hipMemsetAsync(fresh, 0, sizeof(float) * 64 * maxVectors * t->n, t->e->stream);
     hipFree(t->d_out);
-    t->d_out = fresh;
-    t->maxVectors = maxVectors;
+    t->d_out = fresh;  // mlgpu_transport_beat_phase returns the new pointer from now on
+    t->maxVectors = t->capacityVectors = maxVectors;
     return MLGPU_OK;
   }
 

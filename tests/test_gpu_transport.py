@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from inputs import assert_bits_equal
+from madronalib_amd.constants import Proc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -191,3 +192,43 @@ def test_transport_survives_a_longer_reservation(eng):
     for k in range(3):
         assert_bits_equal(got[k], want, True, f"context {k} across a re-reservation")
     tr.close()
+
+
+def test_signal_buffers_do_not_move_under_recorded_sequences(eng):
+    """The beat-phase and controller signals are buffers whose device pointers callers hold and recorded sequences replay:
+    a shorter reservation keeps the allocation (same pointer), a longer one is refused while a sequence of the engine is alive,
+    and so is destroying an events object; afterwards both go through."""
+    import madronalib_amd as ml
+    tr = ml.Transport(eng, 4, 8)
+    p0 = tr.beat_phase
+    tr.reserve(2)
+    assert tr.beat_phase == p0                      # shrinking never reallocates
+    tr.reserve(8)
+    assert tr.beat_phase == p0
+    ev = ml.Events(eng, 4, 2, 48000.0)
+    ev.watch_controllers([7, 11], 4)
+    c0 = ev.controller_signal(0)
+    ev.watch_controllers([7, 11], 2)
+    assert ev.controller_signal(0) == c0
+    bank = eng.bank([Proc.SINE_GEN], 64)
+    bank.set_input_const(np.full(64, 0.01, np.float32))
+    out = eng.alloc(4 * 64 * 64)
+    with eng.record() as seq:
+        bank.process(1, out)
+    try:
+        with pytest.raises(ml.MlgpuError) as ei:
+            tr.reserve(32)
+        assert ei.value.status == ml.Status.ERR_INVALID and "sequences" in str(ei.value)
+        with pytest.raises(ml.MlgpuError):
+            ev.watch_controllers([7, 11], 64)
+        with pytest.raises(ml.MlgpuError):
+            ev.watch_controllers([7, 11, 12], 4)     # another set of controllers would free the old signals
+        assert ev.L.mlgpu_events_destroy(ev.h) == ml.Status.ERR_INVALID
+    finally:
+        seq.close()
+    tr.reserve(32)
+    assert tr.process_host(32).shape[1] == 32 * 64
+    ev.watch_controllers([7, 11], 64)
+    ev.close()
+    tr.close()
+    bank.close()
