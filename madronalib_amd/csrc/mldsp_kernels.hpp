@@ -428,23 +428,35 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// cascade_lanes_kernel — the same stage-skewed cascade with LPC wavefront lanes per channel (round 3).
+// cascade_lanes_kernel — the stage-skewed cascade of round 3: LPC = 1, 2 or 4 wavefront lanes per channel.
 //
-// One lane per channel gives a bank of 131 072 channels 2 048 wavefronts of ~170 VGPRs: two per SIMD. The kernel is
-// bound by VALU issue (profiles/r03_cfg4_account.md: its cycle count is the same with and without the HBM streams), and
-// two wavefronts do not keep a SIMD's VALU port full (tools/bankbench.hip: a packed instruction every 2.09 ns with two
-// wavefronts per SIMD, every 1.89 ns with four). Here a channel is spread over LPC lanes: lane j of a channel's group owns
-// the N / LPC consecutive stages from j * N/LPC on and runs them exactly as SvfCascade does (stage-skewed, packed pairs),
-// taking as its input what lane j - 1 produced one tick earlier — one DPP move (row_shr:4) per tick. Same arithmetic per
-// stage => same bits; LPC times the wavefronts at 1/LPC of the registers, and small banks fill the chip.
+// What bounds this kernel (profiles/r03_cfg4_account.md): VALU issue. Its cycle count (GRBM_GUI_ACTIVE) is the same with
+// the HBM streams and with every row collapsed onto one cache-resident row; what the streams cost is clock (the chip holds
+// ~2.1 GHz on the arithmetic alone and ~1.8 GHz with 4.7 TB/s next to it). A packed-FP32 instruction occupies the SIMD for
+// 4 cycles, a plain one for 2, so a tick of 8 sections cannot cost less than 80 multiplies / adds = 160 cycles per
+// wavefront; cascade_kernel spends 216, this one 196 with one lane per channel:
+//   * a whole DSPVector (16 quads, 64 ticks) per trip: every quad's position and ring slot is a compile-time constant, the
+//     pointers advance by launch constants, loads land in the ring slot they are used from (no copies), and the launch's
+//     last vector runs through the same code (its fetches are sent back to valid addresses);
+//   * the first pair's `input - ic2` as two plain subtractions that read the sample and the previous result where they
+//     are, instead of a packed one that needs both moved into a register pair first.
+// LPC > 1 spreads a channel over LPC lanes: lane j of a channel's group owns the N / LPC consecutive sections from j * N/LPC
+// on and runs them exactly as SvfCascade does, taking as its input what lane j - 1 produced one tick earlier - handed over by
+// DPP, folded into the subtraction that consumes it (v_sub_f32_dpp row_shr:4). Same arithmetic per section => same bits.
+// It multiplies the wavefronts of a SMALL bank (4 096 channels: 84 us per 32 DSPVectors instead of 204); at 131 072
+// channels the extra DPP slot per tick and lane costs more than four wavefronts per SIMD gain (0.49 against 0.46 ms), so
+// chains.hip picks LPC from the bank's size.
 //
 // Lane layout inside a wavefront: lane = 16 * row + 4 * bank + cc. A DPP bank (4 consecutive lanes) is the unit the
-// bank_mask of a DPP instruction can address, so the stage group j has to be the bank: j = bank % LPC, and the
-// channel is (lane / (4 * LPC)) * 4 + cc. "From the previous stage group" is then row_shr:4 with a bank mask that spares
-// the group's first lane, which keeps its own input sample.
+// bank_mask of a DPP instruction can address, so the section group j has to be the bank: j = bank % LPC, and the channel is
+// (lane / (4 * LPC)) * 4 + cc. "From the previous group" is then row_shr:4 under a bank mask that spares the group's first
+// lane, which keeps the result computed from its own sample.
+// (Measured and not kept, profiles/r03_cascade_lds_handover.txt: the hand-over through LDS - ds_write2 + ds_read per tick, no
+// VALU instruction - is slower than DPP, 0.505 against 0.491 ms with two lanes per channel.)
 //
-// Memory: the group's first lane loads the channel's input quads (16 bytes per lane, 64 / LPC lanes per instruction, a
-// ring of R quads in registers, R - 2 quads ahead of their use), the group's last lane stores the output quads.
+// Memory: 16 bytes per lane per quad as before. Every lane of a group fetches the channel's input quads (the same
+// addresses: one fetch serves the group, only the first lane's copy is used - a load under a lane mask would make the whole
+// ring a phi of the branch), a ring of R quads in registers, R - 2 quads ahead of their use; the group's last lane stores.
 template <int LPC>
 struct LaneGroup
 {
