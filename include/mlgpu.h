@@ -38,7 +38,13 @@
  *    and MLGPU_PROC_RMS (their state is exact) - use v_rsq_f32 / v_rcp_f32 where the reference uses x86 rsqrtps / rcpps
  *    (12-bit tables no other hardware reproduces): relative error <= 1.5 * 2^-11 against the reference;
  *  - a state-variable filter whose internal state has passed FLT_MAX / 2 (1.7e38: a filter that has blown up) may reach
- *    infinity one sample later than the reference does (a fused 2 t + s where the reference rounds 2 t first).
+ *    infinity one sample later than the reference does (a fused 2 t + s where the reference rounds 2 t first) - unless the
+ *    engine is in strict mode (mlgpu_engine_set_strict_svf), whose kernels spend the second instruction and are exact there too.
+ *
+ * ABI history: MLGPU_ABI_VERSION 2 (round 3). Against version 1: mlgpu_mixdown needs mlgpu_mixdown_reserve first (it used to
+ * grow its scratch on demand), GraphArgs grew (32 inputs, 8 outputs), and the entries added since - strict SVF, cascade
+ * lanes, device-source fingerprint, windows, transports, registry, published signals ... - are only in a version-2 library.
+ * A host checks mlgpu_abi_version() == MLGPU_ABI_VERSION once at load.
  */
 #ifndef MLGPU_H
 #define MLGPU_H
