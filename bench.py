@@ -583,7 +583,10 @@ def run_rank(args, rank, local_rank, world, rdv):
         lane_rate = ipu * units_per_launch / (kernel_ms * 1e-3)
         roof["valu"] = {"insts_per_unit": ipu, "achieved_lane_inst_per_s": lane_rate, "peak": VALU_PEAK_LANE_INST,
                         "frac": lane_rate / VALU_PEAK_LANE_INST,
-                        "source": "SQ_INSTS_VALU per launch (profiles/pmc_workloads.json) x 64 lanes / live launch duration"}
+                        "source": "SQ_INSTS_VALU per launch (profiles/pmc_workloads.json) x 64 lanes / live launch duration",
+                        "note": "an instruction count, not a utilisation: packed FP32, compares, selects and conversions occupy the SIMD "
+                                "twice as long as a plain add / mul / fma (DESIGN 3.11); config 4 at 'frac 0.33' has its VALU port 85 % busy "
+                                "(profiles/r03_cfg4_account.md)"}
         if roof["valu"]["frac"] > roof["frac"]:
             roof["bound"] = "valu"
     out = {
