@@ -51,6 +51,16 @@ DEFK(k_mul_same, "v_mul_f32 v20, v4, v8\n v_mul_f32 v21, v0, v12\n v_mul_f32 v22
 DEFK(k_mul_diff, "v_mul_f32 v20, v4, v9\n v_mul_f32 v21, v0, v13\n v_mul_f32 v22, v4, v17\n v_mul_f32 v23, v8, v13\n")
 DEFK(k_fma_same3, "v_fma_f32 v20, v4, v8, v12\n v_fma_f32 v21, v0, v12, v16\n v_fma_f32 v22, v4, v16, v0\n v_fma_f32 v23, v8, v12, v4\n")
 DEFK(k_fma_diff3, "v_fma_f32 v20, v4, v9, v14\n v_fma_f32 v21, v0, v13, v18\n v_fma_f32 v22, v4, v17, v2\n v_fma_f32 v23, v8, v13, v6\n")
+// two of the three sources in one bank (v4 / v8 / v12 / v16 / v0: bank 0; v9 / v13 / v17: bank 1; v14 / v18 / v2 / v6: bank 2)
+DEFK(k_fma_ab_same, "v_fma_f32 v20, v4, v8, v14\n v_fma_f32 v21, v0, v12, v18\n v_fma_f32 v22, v4, v16, v2\n v_fma_f32 v23, v8, v12, v6\n")
+DEFK(k_fma_ac_same, "v_fma_f32 v20, v4, v9, v8\n v_fma_f32 v21, v0, v13, v12\n v_fma_f32 v22, v4, v17, v16\n v_fma_f32 v23, v8, v13, v12\n")
+DEFK(k_fma_bc_same, "v_fma_f32 v20, v9, v4, v8\n v_fma_f32 v21, v13, v0, v12\n v_fma_f32 v22, v17, v4, v16\n v_fma_f32 v23, v13, v8, v12\n")
+// v_fmac (dst is the addend) with the two factors in one bank / in two
+DEFK(k_fmac_same, "v_fmac_f32 v20, v4, v8\n v_fmac_f32 v21, v0, v12\n v_fmac_f32 v22, v4, v16\n v_fmac_f32 v23, v8, v12\n")
+DEFK(k_fmac_all_same, "v_fmac_f32 v20, v4, v8\n v_fmac_f32 v24, v0, v12\n v_fmac_f32 v28, v4, v16\n v_fmac_f32 v32, v8, v12\n")
+DEFK(k_fmac_diff, "v_fmac_f32 v20, v5, v10\n v_fmac_f32 v21, v2, v15\n v_fmac_f32 v22, v7, v16\n v_fmac_f32 v23, v9, v14\n")
+// fma with an inline constant (2.0) and the other two in one bank / in two
+DEFK(k_fma_const_same, "v_fma_f32 v20, v4, 2.0, v8\n v_fma_f32 v21, v0, 2.0, v12\n v_fma_f32 v22, v4, 2.0, v16\n v_fma_f32 v23, v8, 2.0, v12\n")
 // --- dependent chains of packed ops: 4 / 2 / 1 independent chains
 DEFK(k_pk_dep4, "v_pk_mul_f32 v[20:21], v[20:21], v[10:11]\n v_pk_mul_f32 v[24:25], v[24:25], v[14:15]\n v_pk_mul_f32 v[28:29], v[28:29], v[18:19]\n v_pk_mul_f32 v[32:33], v[32:33], v[14:15]\n")
 DEFK(k_pk_dep2, "v_pk_mul_f32 v[20:21], v[20:21], v[10:11]\n v_pk_mul_f32 v[24:25], v[24:25], v[14:15]\n v_pk_mul_f32 v[20:21], v[20:21], v[18:19]\n v_pk_mul_f32 v[24:25], v[24:25], v[14:15]\n")
@@ -85,7 +95,7 @@ int main()
   float* out; CK(hipMalloc(&out, 64));
   for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k_fma_diff3, dim3(1024), dim3(256), 0, 0, out, 4000, 1.0000001f);
   CK(hipDeviceSynchronize());
-  for (int w : {4, 2, 1})
+  for (int w : {4, 2})
   {
     run("pk_mul srcs same banks", k_pkmul_same, out, w); run("pk_mul srcs diff banks", k_pkmul_diff, out, w);
     run("pk_mul diff, dst other bank", k_pkmul_diff_dst, out, w);
@@ -94,6 +104,9 @@ int main()
     run("pk_add diff", k_pkadd_diff, out, w); run("pk_add op_sel+neg", k_pkadd_opsel, out, w);
     run("mul same bank", k_mul_same, out, w); run("mul diff bank", k_mul_diff, out, w);
     run("fma 3 same bank", k_fma_same3, out, w); run("fma 3 diff banks", k_fma_diff3, out, w);
+    run("fma a,b same bank", k_fma_ab_same, out, w); run("fma a,c same bank", k_fma_ac_same, out, w); run("fma b,c same bank", k_fma_bc_same, out, w);
+    run("fmac factors same bank", k_fmac_same, out, w); run("fmac all same bank", k_fmac_all_same, out, w); run("fmac diff banks", k_fmac_diff, out, w);
+    run("fma x,2.0,y same bank", k_fma_const_same, out, w);
     run("pk_mul 4 chains", k_pk_dep4, out, w); run("pk_mul 2 chains", k_pk_dep2, out, w); run("pk_mul 1 chain", k_pk_dep1, out, w);
     run("v_mov_b32_dpp row_shr:4", k_dpp_shr, out, w); run("v_mov_b32", k_mov, out, w);
   }
