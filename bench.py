@@ -202,7 +202,11 @@ def setup_workload(eng, name, V, T, lo, total):
         from madronalib_amd.sharding import cfg5_voice_params
         P = 16
         N = V // P
-        ev = ml.Events(eng, N, P, 48000.0)
+        # --two-streams: EventsToSignals on an engine (= HIP stream) of its own. The events kernel of block k + 1 (HBM writes)
+        # then runs under the voice kernel of block k (VALU); the two meet at fences around the double-buffered row signals.
+        two = bool(getattr(eng, "_bench_two_streams", False)) and not fusedRows
+        evEng = ml.Engine(eng.device, urgency=int(os.environ.get("MLGPU_BENCH_EVENTS_URGENCY", "1"))) if two else eng
+        ev = ml.Events(evEng, N, P, 48000.0)
         ev.configure(glide_seconds=0.01, drift=0.5)
         ev.set_wanted_rows([0, 1])
         desc, outs = patches.synth16(pitch_input=True, event_rows=fusedRows)
@@ -222,6 +226,9 @@ def setup_workload(eng, name, V, T, lo, total):
             g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
         g.set_state("noise", 0, seeds)
         rows = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        rowSets = [rows, [eng.alloc(4 * n), eng.alloc(4 * n)]] if two else [rows]
+        rowsReady = [evEng.fence() for _ in rowSets]     # the events kernel has written this set
+        rowsFree = [eng.fence() for _ in rowSets]        # the voice kernel has read it
         d_voices = eng.alloc(4 * n)
         d_mix = [eng.alloc(4 * N * T * 64), eng.alloc(4 * N * T * 64)]
         rng = np.random.default_rng(lo + 1)
@@ -256,6 +263,16 @@ def setup_workload(eng, name, V, T, lo, total):
             if fusedRows:
                 g.process_events(T, 0, [], [d_voices])
                 ev.clear_events()
+            elif two:
+                s_ = k[0] & 1
+                rs = rowSets[s_]
+                evEng.wait(rowsFree[s_])                     # block k - 2's voice kernel is done with this set
+                ev.process(T, 0, [rs[0], rs[1]] + [None] * 6, Layout.QUAD)
+                ev.clear_events()
+                evEng.signal(rowsReady[s_])
+                eng.wait(rowsReady[s_])
+                g.process(T, [rs[1] if nm == "gate" else rs[0] for nm in names], [d_voices])
+                eng.signal(rowsFree[s_])
             else:
                 ev.process(T, 0, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
                 ev.clear_events()
@@ -267,7 +284,8 @@ def setup_workload(eng, name, V, T, lo, total):
         return launch, alg, "mlgpu_graph_kernel", ("16384 instruments x 16 voices end to end: note events -> EventsToSignals (pitch, gate) -> 16-node "
                                                     "voice graph -> per-instrument voice sum"
                                                     + ("; pitch and gate computed inside the voice kernel, never written" if fusedRows else "")
-                                                    + ("; the voice sum made inside the voice kernel" if sumInKernel else "")), (ev, g)
+                                                    + ("; the voice sum made inside the voice kernel" if sumInKernel else "")
+                                                    + ("; EventsToSignals on a HIP stream of its own, overlapped with the voice kernel of the block before" if two else "")), (ev, g, evEng, rowSets, rowsReady, rowsFree)
     if name == "resample":
         r = ml.Resampler(eng, V, 2, False)
         x = eng.bank([Proc.NOISE_GEN], V)
@@ -495,6 +513,7 @@ def run_rank(args, rank, local_rank, world, rdv):
         eng.set_cascade_lanes(args.cascade_lanes)
     if args.strict_svf:
         eng.set_strict_svf(True)
+    eng._bench_two_streams = args.two_streams
     launch, alg_bytes, kernel_name, desc, _keep = setup_workload(eng, args.workload, V, T, lo, total)
     launch()
     eng.sync()
@@ -730,6 +749,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cascade-lanes", type=int, default=None, choices=[-1, 0, 1, 2, 4],
                     help="force the form of SVF-cascade banks (mlgpu_engine_set_cascade_lanes): A/B runs of config 4")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="synth: EventsToSignals on an engine (HIP stream) of its own, its kernel for block k + 1 under the voice kernel of block k")
     ap.add_argument("--strict-svf", action="store_true",
                     help="mlgpu_engine_set_strict_svf: SVF memories updated with two instructions instead of one fused (generated kernels)")
     ap.add_argument("--sustained", metavar="FILE", default=None,

@@ -249,6 +249,10 @@ typedef struct mlgpu_engine mlgpu_engine;
 
 /* Create an engine bound to HIP device `device` with its own non-blocking stream. */
 int mlgpu_engine_create(int device, mlgpu_engine** out);
+/* Same, with a stream priority: urgency +1 = the device's greatest priority, 0 = normal (== mlgpu_engine_create), -1 = its least.
+ * For a second engine on the same device whose short, memory-bound launches should slip in beside a long launch of the first (see
+ * mlgpu_fence below): the dispatcher serves the more urgent stream's workgroups first. */
+int mlgpu_engine_create_urgency(int device, int urgency, mlgpu_engine** out);
 /* Same, but enqueue on a caller-owned hipStream_t (e.g. torch's current stream). */
 int mlgpu_engine_create_on_stream(int device, void* hip_stream, mlgpu_engine** out);
 int mlgpu_engine_destroy(mlgpu_engine* e);
@@ -282,6 +286,16 @@ int mlgpu_engine_set_cascade_lanes(mlgpu_engine* e, int lanes);
 int mlgpu_engine_set_strict_svf(mlgpu_engine* e, int on);
 int mlgpu_engine_get_strict_svf(mlgpu_engine* e);
 int mlgpu_engine_get_cascade_lanes(mlgpu_engine* e);
+/* Two engines on one device are two HIP streams: their work overlaps on the GPU (e.g. the HBM-bound events kernel of block
+ * k + 1 under the VALU-bound voice kernel of block k: bench.py --workload synth --two-streams). A fence orders them
+ * where they share a buffer: mlgpu_engine_signal(a, f) marks a point in a's stream, mlgpu_engine_wait(b, f) makes everything b
+ * enqueues afterwards wait for that point (the host never blocks). Waiting for a fence that was never signalled is a no-op -
+ * convenient for the first trip round a ring of buffers. Same device only; not while recording a sequence. */
+typedef struct mlgpu_fence mlgpu_fence;
+int mlgpu_fence_create(mlgpu_engine* e, mlgpu_fence** out);
+int mlgpu_fence_destroy(mlgpu_fence* f);
+int mlgpu_engine_signal(mlgpu_engine* e, mlgpu_fence* f);
+int mlgpu_engine_wait(mlgpu_engine* e, mlgpu_fence* f);
 /* The hipStream_t work is enqueued on (for HIP-event timing by the caller). */
 void* mlgpu_engine_stream(mlgpu_engine* e);
 int mlgpu_engine_device(mlgpu_engine* e);

@@ -116,10 +116,12 @@ class DeviceBuffer:
 class Engine:
     """One MI355X + one HIP stream (mlgpu_engine)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, urgency=0):
         self.L = _lib.load()
         h = ctypes.c_void_p()
-        if stream is None:
+        if stream is None and urgency:
+            st = self.L.mlgpu_engine_create_urgency(int(device), int(urgency), ctypes.byref(h))   # +1 urgent, -1 background
+        elif stream is None:
             st = self.L.mlgpu_engine_create(int(device), ctypes.byref(h))
         else:
             st = self.L.mlgpu_engine_create_on_stream(int(device), ctypes.c_void_p(int(stream)), ctypes.byref(h))
@@ -155,6 +157,16 @@ class Engine:
 
     def get_flush_denormals(self):
         return bool(self.L.mlgpu_engine_get_flush_denormals(self.h))
+
+    def fence(self):
+        """A point another engine of the same device can wait for (mlgpu_fence): `a.signal(f)` ... `b.wait(f)`."""
+        return Fence(self)
+
+    def signal(self, fence):
+        self._check(self.L.mlgpu_engine_signal(self.h, fence.h))
+
+    def wait(self, fence):
+        self._check(self.L.mlgpu_engine_wait(self.h, fence.h))
 
     def set_strict_svf(self, on):
         """Banks and graphs created from now on update SVF memories with two instructions (`ic + 2 t`) instead of one fused."""
@@ -317,6 +329,28 @@ class Engine:
             with eng.record() as seq: bank.process(...); graph.process(...)
             seq.launch()"""
         return _Recording(self)
+
+
+class Fence:
+    """Ordering between two engines (= two HIP streams) of one device; see Engine.signal / Engine.wait."""
+
+    def __init__(self, engine):
+        self.engine, self.L = engine, engine.L
+        h = ctypes.c_void_p()
+        engine._check(self.L.mlgpu_fence_create(engine.h, ctypes.byref(h)))
+        self.h = h
+        engine._children.add(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mlgpu_fence_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Sequence:

@@ -94,8 +94,13 @@ def _declare(L):
     sig("mlgpu_device_pci_bus_id", i, [i, c.c_char_p, sz])
     sig("mlgpu_device_synchronize", i, [i])
     sig("mlgpu_engine_create", i, [i, pp])
+    sig("mlgpu_engine_create_urgency", i, [i, i, pp])
     sig("mlgpu_engine_set_flush_denormals", i, [vp, i])
     sig("mlgpu_engine_get_flush_denormals", i, [vp])
+    sig("mlgpu_fence_create", i, [vp, c.POINTER(vp)])
+    sig("mlgpu_fence_destroy", i, [vp])
+    sig("mlgpu_engine_signal", i, [vp, vp])
+    sig("mlgpu_engine_wait", i, [vp, vp])
     sig("mlgpu_engine_set_strict_svf", i, [vp, i])
     sig("mlgpu_engine_get_strict_svf", i, [vp])
     sig("mlgpu_engine_set_cascade_lanes", i, [vp, i])

@@ -36,7 +36,7 @@ int fail(mlgpu_engine* e, int status, const char* what, hipError_t herr = hipSuc
     if (_err != hipSuccess) return fail((e), MLGPU_ERR_HIP, #call, _err); \
   } while (0)
 
-int createEngine(int device, hipStream_t stream, bool ownStream, mlgpu_engine** out)
+int createEngine(int device, hipStream_t stream, bool ownStream, mlgpu_engine** out, int urgency = 0)
 {
   if (!out) return MLGPU_ERR_INVALID;
   *out = nullptr;
@@ -54,7 +54,13 @@ int createEngine(int device, hipStream_t stream, bool ownStream, mlgpu_engine** 
   e->cuCount = prop.multiProcessorCount;
   if (ownStream)
   {
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    // urgency: the dispatcher hands out a more urgent stream's workgroups first, so a short memory-bound kernel on it is not
+    // starved by a long kernel that fills every CU from a normal stream (HIP: the numerically LOWER priority is the greater one)
+    int least = 0, greatest = 0;
+    if (urgency != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    const int prio = urgency > 0 ? greatest : (urgency < 0 ? least : 0);
+    if ((urgency == 0 ? hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)
+                      : hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio)) != hipSuccess)
     {
       delete e;
       return MLGPU_ERR_HIP;
@@ -188,6 +194,11 @@ extern "C"
   }
 
   int mlgpu_engine_create(int device, mlgpu_engine** out) { return createEngine(device, nullptr, true, out); }
+  int mlgpu_engine_create_urgency(int device, int urgency, mlgpu_engine** out)
+  {
+    if (urgency < -1 || urgency > 1) return MLGPU_ERR_INVALID;
+    return createEngine(device, nullptr, true, out, urgency);
+  }
   int mlgpu_engine_create_on_stream(int device, void* hipStream, mlgpu_engine** out)
   {
     return createEngine(device, (hipStream_t)hipStream, false, out);
@@ -339,6 +350,52 @@ extern "C"
     if (!n) return MLGPU_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, mlgpu_launch_fill32((uint32_t*)d_dst, value, n, e->stream));
+    return MLGPU_OK;
+  }
+
+  // ---- fences: ordering between two engines (= two HIP streams) of one device ----
+  int mlgpu_fence_create(mlgpu_engine* e, mlgpu_fence** out)
+  {
+    if (!e || !out) return MLGPU_ERR_INVALID;
+    *out = nullptr;
+    HIP_TRY(e, hipSetDevice(e->device));
+    mlgpu_fence* f = new (std::nothrow) mlgpu_fence();
+    if (!f) return MLGPU_ERR_OOM;
+    f->device = e->device;
+    if (hipEventCreateWithFlags(&f->ev, hipEventDisableTiming) != hipSuccess)
+    {
+      delete f;
+      return fail(e, MLGPU_ERR_HIP, "fence_create: hipEventCreate");
+    }
+    *out = f;
+    return MLGPU_OK;
+  }
+  int mlgpu_fence_destroy(mlgpu_fence* f)
+  {
+    if (!f) return MLGPU_ERR_INVALID;
+    hipSetDevice(f->device);
+    hipEventDestroy(f->ev);
+    delete f;
+    return MLGPU_OK;
+  }
+  int mlgpu_engine_signal(mlgpu_engine* e, mlgpu_fence* f)
+  {
+    if (!e || !f) return MLGPU_ERR_INVALID;
+    if (f->device != e->device) return fail(e, MLGPU_ERR_INVALID, "engine_signal: the fence belongs to another device");
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "engine_signal: not while recording a sequence (a fence ties two streams together)");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipEventRecord(f->ev, e->stream));
+    f->signalled = true;
+    return MLGPU_OK;
+  }
+  int mlgpu_engine_wait(mlgpu_engine* e, mlgpu_fence* f)
+  {
+    if (!e || !f) return MLGPU_ERR_INVALID;
+    if (f->device != e->device) return fail(e, MLGPU_ERR_INVALID, "engine_wait: the fence belongs to another device");
+    if (e->recording) return fail(e, MLGPU_ERR_INVALID, "engine_wait: not while recording a sequence");
+    if (!f->signalled) return MLGPU_OK;  // nothing to wait for yet (the first trip round a ring of buffers)
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, f->ev, 0));
     return MLGPU_OK;
   }
 

@@ -29,6 +29,13 @@ struct mlgpu_engine
   int liveSequences{0};   // recorded sequences not yet destroyed: they hold device pointers, so buffers handed out must not move
 };
 
+struct mlgpu_fence  // mlgpu_engine_signal / mlgpu_engine_wait: a point in one engine's stream that another engine's stream can wait for
+{
+  int device{0};
+  hipEvent_t ev{nullptr};
+  bool signalled{false};
+};
+
 struct mlgpu_sequence  // a recorded launch sequence: a hipGraph instantiated once, replayed with one launch
 {
   mlgpu_engine* e{nullptr};
