@@ -53,6 +53,7 @@ WORKLOADS = {
     "synth": (262144, 16, 8),    # events -> synth16 voices (pitch and gate rows streamed) -> per-instrument voice sum
     "synthfused": (262144, 16, 8),  # the same with pitch and gate computed inside the voice kernel (event rows as source nodes)
     "strings": (262144, 16, 8),  # a plucked-string model per voice: noise burst -> FractionalDelay (per-voice length) -> OnePole -> feedback
+    "mixgroups": (262144, 8, 16),  # the per-instrument voice sum alone, 16 voices per instrument
     "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
 }
 
@@ -286,6 +287,20 @@ def setup_workload(eng, name, V, T, lo, total):
                                                     + ("; pitch and gate computed inside the voice kernel, never written" if fusedRows else "")
                                                     + ("; the voice sum made inside the voice kernel" if sumInKernel else "")
                                                     + ("; EventsToSignals on a HIP stream of its own, overlapped with the voice kernel of the block before" if two else "")), (ev, g, evEng, rowSets, rowsReady, rowsFree)
+    if name == "mixgroups":
+        # the per-instrument voice sum alone (Synth::processVector, MLSynth.h:43-57): 16 384 instruments x 16 voices
+        P = 16
+        N = V // P
+        src = eng.bank([Proc.NOISE_GEN], V)
+        src.set_state(0, 0, np.arange(lo, lo + V, dtype=np.uint32))
+        d_x = eng.alloc(4 * n)
+        src.process(T, d_x, Layout.QUAD)
+        d_mix = eng.alloc(4 * N * T * 64)
+
+        def launch():
+            eng.mixdown_groups(d_x, Layout.QUAD, N, P, T, d_mix)
+        alg = 4.0 * n + 4.0 * N * T * 64
+        return launch, alg, "mixdown_groups_kernel", "per-instrument voice sum, 16384 instruments x 16 voices, voice signals streamed in", (src,)
     if name == "resample":
         r = ml.Resampler(eng, V, 2, False)
         x = eng.bank([Proc.NOISE_GEN], V)

@@ -186,11 +186,13 @@ def test_broadcast_input_layout(eng, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,groups", [(1, 70), (2, 64), (3, 65), (5, 1), (6, 200), (16, 63), (16, 1000), (17, 129), (40, 66), (70, 9)])
+@pytest.mark.parametrize("P,groups", [(1, 70), (2, 64), (2, 33), (3, 65), (4, 37), (4, 4096), (5, 1), (6, 200), (8, 131), (16, 1), (16, 63), (16, 1000),
+                                      (16, 16385), (17, 129), (32, 10), (40, 66), (70, 9)])
 @pytest.mark.parametrize("layout", [Layout.QUAD, Layout.VOICE_MAJOR])
 def test_mixdown_groups_voice_order(eng, P, groups, layout):
     """mlgpu_mixdown_groups: every P consecutive voices summed in voice order, starting from zero (Synth::processVector,
-    source/app/MLSynth.h:43-57) — the LDS-strip kernel (P <= 62) and the direct one, full and ragged blocks of 64 groups."""
+    source/app/MLSynth.h:43-57) — the LDS-strip kernel (P <= 62) and the direct one, full and ragged blocks of 64 groups, more
+    items than one trip of the grid takes; a group of negative zeros gives +0 like the reference's loop from zero."""
     from inputs import lcg_noise
     T, V = 3, groups * P
     x = lcg_noise(np.arange(V, dtype=np.uint32) + 17, 64 * T)
@@ -205,3 +207,8 @@ def test_mixdown_groups_voice_order(eng, P, groups, layout):
     for p in range(P):
         want = want + xs[:, p]
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    # a group of negative zeros sums to +0 (0 + -0), whichever kernel
+    d_x.upload(np.full(V * 64 * T, -0.0, np.float32))
+    eng.layout_convert(d_x, Layout.VOICE_MAJOR, d_q, layout, V, T)
+    eng.mixdown_groups(d_q, layout, groups, P, T, d_o, layout)
+    assert (d_o.download(np.uint32, groups * 64 * T) == 0).all()
