@@ -54,6 +54,12 @@ $B --workload cfg3 --sustained $O/cfg3_sustained.json --sustained-seconds 30 2>/
   for w in synth synthfused; do for mix in kernel graph; do echo "## $w mixdown=$mix"; MLGPU_BENCH_MIXDOWN=$mix $B --workload $w 2>/dev/null | tail -1 | line; done; done
 } > $O/synth_mixdown.txt 2>&1
 
+# instrument bank: EventsToSignals on a stream of its own (fences), and the voice sum alone
+{ echo "# bench.py --workload synth with and without --two-streams; --workload mixgroups; same box";
+  for i in 1 2; do for m in "" "--two-streams"; do echo "## synth $m"; $B --workload synth $m --steps 30 --warmup 5 2>/dev/null | tail -1 | line; done; done
+  echo "## mixgroups"; $B --workload mixgroups 2>/dev/null | tail -1 | line
+} > $O/two_streams_lines.txt 2>&1
+
 tools/multi_gpu_dry_run.sh $O/multi_gpu_launch_paths.txt 8
 python tools/node_costs.py 2 10 > $O/node_costs.txt 2>&1
 for dd in $O/profiles_*; do python tools/summarize_profiles.py $dd r03 > $dd/summary.md 2>/dev/null; done
