@@ -25,6 +25,7 @@
 // (ctx->inputs[c]) and per-voice coefficients (VoiceProgram::setCoeff).
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -33,6 +34,8 @@
 #include <initializer_list>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -194,6 +197,54 @@ inline int Capture::contextInput(int code)
   return contextNode[code] = node;
 }
 
+
+// ---- immediate mode -----------------------------------------------------------------------------------------
+// DSPVector code that runs OUTSIDE a VoiceProgram capture - the reference's unit tests, an offline tool, a setup function
+// that builds a table with DSPVector arithmetic - is evaluated at once, on the device, for ONE voice: every operator, free
+// function, generator and filter call is one launch of the same kernels the fused programs are made of (mlgpu_op_apply, a
+// one-voice mlgpu_graph around the processor object, mlgpu_row_reduce, ...) and hands back host data, exactly as the
+// reference's value-type DSPVector does. It is slow (a round trip per call) and it is not the product path - that is
+// VoiceProgram - but it is the same arithmetic, so code written against madronalib compiles and gives madronalib's bits
+// before anybody has restructured it. There is no CPU arithmetic behind it: without a device these calls throw.
+struct Eager
+{
+  const Engine* eng{nullptr};
+  float* d{nullptr};  // device scratch, `cap` floats
+  size_t cap{0};
+  int device{0};
+  std::recursive_mutex m;
+  static Eager& get()
+  {
+    static Eager* e = new Eager();  // never destroyed: processor objects with static storage may outlive any static of ours
+    return *e;
+  }
+  const Engine& engine()
+  {
+    if (!eng) eng = new Engine(device);
+    return *eng;
+  }
+  float* scratch(size_t nFloats)
+  {
+    const Engine& e = engine();
+    if (nFloats > cap)
+    {
+      if (d) mlgpu_free(e.handle(), d);
+      d = nullptr;
+      cap = 0;
+      void* p = nullptr;
+      const size_t want = nFloats < 1024 ? 1024 : nFloats;
+      e.check(mlgpu_alloc(e.handle(), want * sizeof(float), &p));
+      d = static_cast<float*>(p);
+      cap = want;
+    }
+    return d;
+  }
+};
+// the engine immediate-mode calls run on (default: one made on device 0 at the first call). Call before any such call.
+inline void setImmediateEngine(const Engine& e) { Eager::get().eng = &e; }
+inline const Engine& immediateEngine() { return Eager::get().engine(); }
+inline bool capturing() { return Capture::current() != nullptr; }
+
 }  // namespace gpu
 
 // UsingFlushDenormalsToZero (MLDSPUtils.h:51-96): in the reference, MXCSR FZ | DAZ for the lifetime of the object -
@@ -258,6 +309,11 @@ struct Sig
   }
   Sig() {}
   Sig(int n, float l) : node(n), lit(l), epoch(n >= 0 ? Capture::get().epoch : 0) {}
+  explicit Sig(std::shared_ptr<const std::array<float, 64>> t) : table(std::move(t)) {}  // immediate mode: a result the host now holds
+  void hostCopy(float* dst64) const
+  {
+    for (int i = 0; i < 64; ++i) dst64[i] = hostSample(i);
+  }
   explicit Sig(const float* p64) : table(std::make_shared<const std::array<float, 64>>(toArray(p64))) {}
   static std::array<float, 64> toArray(const float* p)
   {
@@ -282,8 +338,26 @@ inline Sig computedSig(int node)
   return s;
 }
 
+// immediate mode: out = op(in...) over one DSPVector, on the device (mlgpu_op_apply)
+inline Sig immediateOp(int op, std::initializer_list<Sig> in)
+{
+  Eager& E = Eager::get();
+  std::lock_guard<std::recursive_mutex> lock(E.m);
+  const Engine& e = E.engine();
+  float* d = E.scratch(4 * 64);
+  float host[3 * 64];
+  int n = 0;
+  for (const Sig& s : in) s.hostCopy(host + 64 * n++);
+  e.check(mlgpu_upload(e.handle(), d, host, (size_t)n * 256));
+  e.check(mlgpu_op_apply(e.handle(), op, d, n > 1 ? d + 64 : nullptr, n > 2 ? d + 128 : nullptr, d + 192, 64));
+  auto out = std::make_shared<std::array<float, 64>>();
+  e.check(mlgpu_download(e.handle(), out->data(), d + 192, 256));
+  return Sig(std::shared_ptr<const std::array<float, 64>>(std::move(out)));
+}
+
 inline Sig opNode(int op, std::initializer_list<Sig> in)
 {
+  if (!Capture::current()) return immediateOp(op, in);
   Capture& c = Capture::get();
   int ids[3];
   int n = 0;
@@ -292,6 +366,18 @@ inline Sig opNode(int op, std::initializer_list<Sig> in)
 }
 inline Sig vopNode(int vop, std::initializer_list<Sig> in)
 {
+  if (!Capture::current())
+  {
+    // immediate mode: the reference's own expressions (MLDSPOps.h:965-990) - the interval is host float arithmetic there too
+    auto idx = std::make_shared<std::array<float, 64>>();
+    for (int i = 0; i < 64; ++i) (*idx)[(size_t)i] = (float)i;
+    const Sig column{std::shared_ptr<const std::array<float, 64>>(std::move(idx))};
+    if (vop == MLGPU_VOP_COLUMN_INDEX) return column;
+    const float start = in.begin()->hostSample(0), end = (in.begin() + 1)->hostSample(0);
+    const float interval = (end - start) / (vop == MLGPU_VOP_RANGE_CLOSED ? (64 - 1.f) : 64.f);
+    const float offset = vop == MLGPU_VOP_INTERPOLATE_LINEAR ? start + interval : start;
+    return immediateOp(MLGPU_OP_ADD, {immediateOp(MLGPU_OP_MULTIPLY, {column, Sig(-1, interval)}), Sig(-1, offset)});
+  }
   Capture& c = Capture::get();
   int ids[2];
   int n = 0;
@@ -375,9 +461,30 @@ class DSPVectorArray
   }
   const float* getConstBuffer() const { return const_cast<DSPVectorArray*>(this)->getBuffer(); }
 
-  // read access to one sample on the host (the reference's `float operator[](int i) const`, MLDSPOps.h:167-168): literals, host
-  // tables and - in a one-context program - context signals (gpu::Sig::hostSample); there is no writable `float&` form
-  float operator[](int i) const { return sig_[(size_t)i / 64].hostSample(i & 63); }
+  // one sample on the host (MLDSPOps.h:167-168): literals, host tables, immediate-mode results and - in a one-context program -
+  // context signals (gpu::Sig::hostSample). The writable form gives the vector its own host buffer, like getBuffer().
+  float operator[](size_t i) const { return sig_[i / 64].hostSample((int)(i & 63)); }
+  float& operator[](size_t i)
+  {
+    const gpu::Sig& s = sig_[i / 64];
+    if (s.node >= 0)  // a signal of the kernel (a context signal in a one-context program): readable, not a host buffer
+    {
+      static thread_local float readOnly[8];
+      static thread_local unsigned next;
+      float& r = readOnly[next++ & 7];
+      r = s.hostSample((int)(i & 63));
+      return r;
+    }
+    return getBuffer()[i];
+  }
+  // equality by value (MLDSPOps.h:190-200): host data on both sides
+  bool operator==(const DSPVectorArray& x) const
+  {
+    for (size_t n = 0; n < 64 * ROWS; ++n)
+      if ((*this)[n] != x[n]) return false;
+    return true;
+  }
+  bool operator!=(const DSPVectorArray& x) const { return !(*this == x); }
 
   DSPVectorArray<1>& row(int j) { return *reinterpret_cast<DSPVectorArray<1>*>(&sig_[j]); }
   const DSPVectorArray<1>& constRow(int j) const { return *reinterpret_cast<const DSPVectorArray<1>*>(&sig_[j]); }
@@ -611,6 +718,101 @@ inline void load(DSPVectorArray<ROWS>& vecDest, const float* pSrc)
 {
   vecDest = DSPVectorArray<ROWS>(pSrc);
 }
+template <size_t ROWS>
+inline void loadAligned(DSPVectorArray<ROWS>& vecDest, const float* pSrc)
+{
+  vecDest = DSPVectorArray<ROWS>(pSrc);
+}
+// store (MLDSPOps.h:530-534, 551-562): the vector's floats to host memory - for vectors the host holds (literals, host tables,
+// immediate-mode results); a signal of a captured kernel has no host values (Sig::hostSample says so)
+template <size_t ROWS>
+inline void store(const DSPVectorArray<ROWS>& vecSrc, float* pDest)
+{
+  for (size_t n = 0; n < 64 * ROWS; ++n) pDest[n] = vecSrc[n];
+}
+template <size_t ROWS>
+inline void storeAligned(const DSPVectorArray<ROWS>& vecSrc, float* pDest)
+{
+  store(vecSrc, pDest);
+}
+
+// ---- horizontal operators returning float (MLDSPOps.h:995-1035), normalize (:1041-1050), rotateLeft / rotateRight (:1219-1276) ----
+// A float result is host data, so these exist in immediate mode only (inside a capture there is nothing to return): the
+// reduction runs on the device with the reference's association order and seeds (mlgpu_row_reduce), one row at a time.
+namespace gpu
+{
+inline float immediateReduce(int rowop, const Sig& row, const char* what)
+{
+  if (Capture::current())
+    throw std::logic_error(std::string("mldsp GPU shim: ") + what + "(DSPVector) returns a float to the host; inside a captured process function "
+                           "there is no host value - keep the step in DSPVector form (e.g. divide by a DSPVector) or compute it outside the capture");
+  Eager& E = Eager::get();
+  std::lock_guard<std::recursive_mutex> lock(E.m);
+  const Engine& e = E.engine();
+  float* d = E.scratch(64 + 4);
+  float host[64];
+  row.hostCopy(host);
+  e.check(mlgpu_upload(e.handle(), d, host, 256));
+  e.check(mlgpu_row_reduce(e.handle(), rowop, d, d + 64, 1));
+  float r = 0.f;
+  e.check(mlgpu_download(e.handle(), &r, d + 64, 4));
+  return r;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> immediateRowsMap(const DSPVectorArray<ROWS>& x, int sampleRotate, const char* what)
+{
+  if (Capture::current())
+    throw std::logic_error(std::string("mldsp GPU shim: ") + what + " moves samples across a DSPVector; a captured kernel walks a vector sample by sample - "
+                           "use it outside the capture, or mlgpu_rows_map on a signal in memory");
+  Eager& E = Eager::get();
+  std::lock_guard<std::recursive_mutex> lock(E.m);
+  const Engine& e = E.engine();
+  float* d = E.scratch(2 * 64 * ROWS);
+  std::vector<float> host(64 * ROWS);
+  for (size_t n = 0; n < 64 * ROWS; ++n) host[n] = x[n];
+  e.check(mlgpu_upload(e.handle(), d, host.data(), host.size() * 4));
+  e.check(mlgpu_rows_map(e.handle(), MLGPU_ROWS_REPEAT, 0, 0, sampleRotate, d, ROWS, d + 64 * ROWS, ROWS, 0, 1, ROWS, 1));
+  e.check(mlgpu_download(e.handle(), host.data(), d + 64 * ROWS, host.size() * 4));
+  return DSPVectorArray<ROWS>(static_cast<const float*>(host.data()));
+}
+}  // namespace gpu
+inline float sum(const DSPVector& x) { return gpu::immediateReduce(MLGPU_ROWOP_SUM, x.sig_[0], "sum"); }
+inline float mean(const DSPVector& x) { return gpu::immediateReduce(MLGPU_ROWOP_MEAN, x.sig_[0], "mean"); }
+inline float max(const DSPVector& x) { return gpu::immediateReduce(MLGPU_ROWOP_MAX, x.sig_[0], "max"); }
+inline float min(const DSPVector& x) { return gpu::immediateReduce(MLGPU_ROWOP_MIN, x.sig_[0], "min"); }
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> normalize(const DSPVectorArray<ROWS>& x)
+{
+  DSPVectorArray<ROWS> vy;
+  for (size_t j = 0; j < ROWS; ++j)
+  {
+    const DSPVector row = x.constRow((int)j);
+    vy.row((int)j) = row / DSPVector(sum(row));
+  }
+  return vy;
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> rotateLeft(const DSPVectorArray<ROWS>& x)
+{
+  return gpu::immediateRowsMap(x, +1, "rotateLeft");
+}
+template <size_t ROWS>
+inline DSPVectorArray<ROWS> rotateRight(const DSPVectorArray<ROWS>& x)
+{
+  return gpu::immediateRowsMap(x, -1, "rotateRight");
+}
+template <size_t ROWS>
+inline std::ostream& operator<<(std::ostream& out, const DSPVectorArray<ROWS>& v)  // MLDSPOps.h:1390-1406
+{
+  for (size_t r = 0; r < ROWS; ++r)
+  {
+    if (ROWS > 1) out << "\n    v" << r << ": ";
+    out << "[";
+    for (size_t i = 0; i < 64; ++i) out << v[r * 64 + i] << " ";
+    out << "] ";
+  }
+  return out;
+}
 inline DSPVector columnIndex() { return DSPVector(gpu::vopNode(MLGPU_VOP_COLUMN_INDEX, {})); }
 inline DSPVector rangeOpen(float start, float end) { return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_OPEN, {gpu::Sig(-1, start), gpu::Sig(-1, end)})); }
 inline DSPVector rangeClosed(float start, float end)
@@ -767,6 +969,26 @@ inline DSPVectorArray<ROWS> routeMux(int route, DSPVector selector, DSPVectorArr
   const DSPVectorArray<ROWS> inputs[]{first, args...};
   constexpr int n = sizeof...(Args) + 1;
   static_assert(n <= MLGPU_ROUTE_MAX_SIGNALS, "multiplex: at most 8 inputs");
+  if (!Capture::current())  // immediate mode: mlgpu_multiplex over the rows, one selector DSPVector for all of them
+  {
+    Eager& E = Eager::get();
+    std::lock_guard<std::recursive_mutex> lock(E.m);
+    const Engine& e = E.engine();
+    const size_t rowFloats = 64 * ROWS;
+    float* d = E.scratch(64 + (n + 1) * rowFloats);
+    std::vector<float> host(64 + n * rowFloats);
+    selector.sig_[0].hostCopy(host.data());
+    for (int k = 0; k < n; ++k)
+      for (size_t i = 0; i < rowFloats; ++i) host[64 + k * rowFloats + i] = inputs[k][i];
+    e.check(mlgpu_upload(e.handle(), d, host.data(), host.size() * 4));
+    const float* ins[MLGPU_ROUTE_MAX_SIGNALS];
+    for (int k = 0; k < n; ++k) ins[k] = d + 64 + k * rowFloats;
+    float* out = d + 64 + n * rowFloats;
+    e.check(mlgpu_multiplex(e.handle(), d, 64, ins, n, out, rowFloats, route == MLGPU_ROUTE_MULTIPLEX_LINEAR ? 1 : 0));
+    std::vector<float> res(rowFloats);
+    e.check(mlgpu_download(e.handle(), res.data(), out, rowFloats * 4));
+    return DSPVectorArray<ROWS>(static_cast<const float*>(res.data()));
+  }
   Capture& c = Capture::get();
   DSPVectorArray<ROWS> y;
   for (size_t j = 0; j < ROWS; ++j)
@@ -784,6 +1006,25 @@ inline void routeDemux(int route, DSPVector selector, DSPVectorArray<ROWS> input
   DSPVectorArray<ROWS>* outputs[]{firstOutput, args...};
   constexpr int n = sizeof...(Args) + 1;
   static_assert(n <= MLGPU_ROUTE_MAX_SIGNALS, "demultiplex: at most 8 outputs");
+  if (!Capture::current())
+  {
+    Eager& E = Eager::get();
+    std::lock_guard<std::recursive_mutex> lock(E.m);
+    const Engine& e = E.engine();
+    const size_t rowFloats = 64 * ROWS;
+    float* d = E.scratch(64 + (n + 1) * rowFloats);
+    std::vector<float> host(64 + rowFloats);
+    selector.sig_[0].hostCopy(host.data());
+    for (size_t i = 0; i < rowFloats; ++i) host[64 + i] = input[i];
+    e.check(mlgpu_upload(e.handle(), d, host.data(), host.size() * 4));
+    float* outs[MLGPU_ROUTE_MAX_SIGNALS];
+    for (int k = 0; k < n; ++k) outs[k] = d + 64 + (k + 1) * rowFloats;
+    e.check(mlgpu_demultiplex(e.handle(), d, 64, d + 64, outs, n, rowFloats, route == MLGPU_ROUTE_DEMULTIPLEX_LINEAR ? 1 : 0));
+    std::vector<float> res(n * rowFloats);
+    e.check(mlgpu_download(e.handle(), res.data(), outs[0], res.size() * 4));
+    for (int k = 0; k < n; ++k) *outputs[k] = DSPVectorArray<ROWS>(static_cast<const float*>(res.data() + k * rowFloats));
+    return;
+  }
   Capture& c = Capture::get();
   for (int k = 0; k < n; ++k)
     for (size_t j = 0; j < ROWS; ++j)
@@ -832,8 +1073,100 @@ struct ProcNode
   float maxDelay_{-1.f};                            // delay lines: setMaxDelayInSamples
   std::vector<std::pair<int, uint32_t>> initState_;  // further state words set before the first call
 
+  // immediate mode: the object's own one-voice graph (inputs -> this processor -> output), made at its first call outside a
+  // capture. The processor's state lives in that graph between calls, as it lives in the reference object; a copy of the
+  // object takes the state words along (a delay line's ring is not copied).
+  struct Immediate
+  {
+    mlgpu_graph* g{nullptr};
+    int node{-1}, nIn{0};
+    float* d{nullptr};  // device: nIn inputs, then the output, 64 floats each
+    ~Immediate()
+    {
+      if (g) mlgpu_graph_destroy(g);
+      if (d) mlgpu_free(Eager::get().engine().handle(), d);
+    }
+  };
+  std::shared_ptr<Immediate> imm_;
+  ProcNode() = default;
+  ProcNode(const ProcNode& o) { copyFrom(o); }
+  ProcNode& operator=(const ProcNode& o)
+  {
+    if (this != &o) copyFrom(o);
+    return *this;
+  }
+  void copyFrom(const ProcNode& o)
+  {
+    node_ = o.node_; nodeEpoch_ = o.nodeEpoch_; cleared_ = o.cleared_; initState0_ = o.initState0_; hasInitState0_ = o.hasInitState0_;
+    maxDelay_ = o.maxDelay_; initState_ = o.initState_;
+    imm_.reset();
+    if (o.imm_ && o.imm_->g)  // value semantics: the copy starts from the state the original has now
+    {
+      std::lock_guard<std::recursive_mutex> lock(Eager::get().m);
+      const int ns = mlgpu_graph_num_state(o.imm_->g, o.imm_->node);
+      for (int i = 0; i < ns; ++i)
+      {
+        uint32_t w = 0;
+        Eager::get().engine().check(mlgpu_graph_get_state(o.imm_->g, o.imm_->node, i, &w));
+        presetState(i, w);
+      }
+      cleared_ = hasInitState0_ = false;
+    }
+  }
+  Sig emitImmediate(std::initializer_list<Sig> ins, const float* coeffs, int nc)
+  {
+    Eager& E = Eager::get();
+    std::lock_guard<std::recursive_mutex> lock(E.m);
+    const Engine& e = E.engine();
+    const int n = (int)ins.size();
+    if (!imm_ || imm_->nIn != n)
+    {
+      auto im = std::make_shared<Immediate>();
+      e.check(mlgpu_graph_create(e.handle(), 1, &im->g));
+      auto ret = [&](int r) {
+        if (r < 0) throw Error(-r, std::string("mlgpu_graph (immediate mode): ") + mlgpu_graph_last_error(im->g));
+        return r;
+      };
+      int ids[8];
+      for (int k = 0; k < n; ++k) ids[k] = ret(mlgpu_graph_add_input(im->g, nullptr));
+      im->node = ret(mlgpu_graph_add_proc(im->g, KIND, ids, n, nullptr));
+      if (maxDelay_ >= 0.f) e.check(mlgpu_graph_set_max_delay(im->g, im->node, maxDelay_));
+      e.check(mlgpu_graph_add_output(im->g, im->node));
+      e.check(mlgpu_graph_compile(im->g));
+      void* p = nullptr;
+      e.check(mlgpu_alloc(e.handle(), (size_t)(n + 1) * 256, &p));
+      im->d = static_cast<float*>(p);
+      im->nIn = n;
+      imm_ = im;
+    }
+    Immediate& im = *imm_;
+    for (int i = 0; i < nc; ++i) e.check(mlgpu_graph_set_coeff_uniform(im.g, im.node, i, coeffs[i]));
+    // what was asked of the object since its last call, in the order a capture applies it: clear(), then state words
+    if (cleared_) e.check(mlgpu_graph_clear_proc(im.g, im.node));
+    if (hasInitState0_) e.check(mlgpu_graph_set_state_uniform(im.g, im.node, 0, initState0_));
+    for (auto& kv : initState_) e.check(mlgpu_graph_set_state_uniform(im.g, im.node, kv.first, kv.second));
+    cleared_ = hasInitState0_ = false;
+    initState_.clear();
+    float host[8 * 64];
+    int k = 0;
+    const float* inPtr[8];
+    for (const Sig& sgn : ins)
+    {
+      sgn.hostCopy(host + 64 * k);
+      inPtr[k] = im.d + 64 * k;
+      ++k;
+    }
+    if (n) e.check(mlgpu_upload(e.handle(), im.d, host, (size_t)n * 256));
+    float* outPtr[1] = {im.d + 64 * n};
+    e.check(mlgpu_graph_process(im.g, 1, n ? inPtr : nullptr, MLGPU_LAYOUT_QUAD, outPtr, MLGPU_LAYOUT_QUAD));
+    auto out = std::make_shared<std::array<float, 64>>();
+    e.check(mlgpu_download(e.handle(), out->data(), outPtr[0], 256));
+    return Sig(std::shared_ptr<const std::array<float, 64>>(std::move(out)));
+  }
+
   Sig emit(std::initializer_list<Sig> ins, const float* coeffs, int nc)
   {
+    if (!Capture::current()) return emitImmediate(ins, coeffs, nc);
     Capture& c = Capture::get();
     if (node_ >= 0 && nodeEpoch_ == c.epoch)
       throw std::logic_error("mldsp GPU shim: a stateful object was called twice in one process function (one call = one state update)");
@@ -893,6 +1226,33 @@ class NoiseGen : public gpu::ProcNode<MLGPU_PROC_NOISE_GEN>
     hasInitState0_ = true;
   }
   DSPVector operator()() { return DSPVector(emit({}, nullptr, 0)); }
+  // the scalar members (MLDSPGens.h:115-129): one step of the generator's own state word on the host - the object's seed as it
+  // stands now (what a call outside a capture left in its one-voice graph, or what was set since)
+  void step() { seed(currentSeed() * 0x0019660Du + 0x3C6EF35Fu); }
+  uint32_t getIntSample()
+  {
+    step();
+    return initState0_;
+  }
+  float getSample()
+  {
+    step();
+    const uint32_t bits = ((initState0_ >> 9) & 0x007FFFFFu) | 0x3F800000u;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f * 2.f - 3.f;
+  }
+
+ private:
+  uint32_t currentSeed()
+  {
+    if (hasInitState0_) return initState0_;
+    if (cleared_ || !imm_ || !imm_->g) return 0;
+    uint32_t w = 0;
+    std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+    gpu::Eager::get().engine().check(mlgpu_graph_get_state(imm_->g, imm_->node, 0, &w));
+    return w;
+  }
 };
 inline DSPVectorInt columnIndexInt()  // MLDSPOps.h: 0 .. 63 as integers (exact)
 {
@@ -1291,13 +1651,33 @@ namespace gpu
 {
 class FeedbackLoop
 {
-  int node_;
+  int node_{-1};
+  DSPVector* kept_{nullptr};  // immediate mode: the owner's DSPVector that carries the loop from one call to the next
 
  public:
   FeedbackLoop() : node_(Capture::get().ret(mlgpu_graph_add_feedback(Capture::get().g, nullptr))) {}
-  DSPVector value() const { return DSPVector(Sig(node_, 0.f)); }
+  // `kept` is a member of the object that owns the loop: in immediate mode it IS the loop's memory (the value one call leaves for
+  // the next, zero at first), inside a capture it is not touched
+  explicit FeedbackLoop(DSPVector& kept) : kept_(&kept)
+  {
+    if (Capture::current()) node_ = Capture::get().ret(mlgpu_graph_add_feedback(Capture::get().g, nullptr));
+  }
+  DSPVector value() const
+  {
+    if (!Capture::current())
+    {
+      if (!kept_) throw std::logic_error("mldsp GPU shim: a feedback loop outside a VoiceProgram capture needs its owner's storage");
+      return *kept_;
+    }
+    return DSPVector(Sig(node_, 0.f));
+  }
   void close(const DSPVector& next)
   {
+    if (!Capture::current())
+    {
+      *kept_ = next;
+      return;
+    }
     Capture& c = Capture::get();
     const int st = mlgpu_graph_set_feedback(c.g, node_, next.sig_[0].id());
     if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_graph_set_feedback: ") + mlgpu_last_error(c.eng->handle()));
@@ -1312,10 +1692,11 @@ template <typename DELAY_TYPE>
 class Allpass
 {
   DELAY_TYPE line_;
+  DSPVector kept_;  // immediate mode: what the line gave at the last call (the reference's vy1)
   template <class THROUGH_LINE>
   DSPVector run(const DSPVector& x, THROUGH_LINE throughLine)
   {
-    gpu::FeedbackLoop loop;
+    gpu::FeedbackLoop loop(kept_);
     const DSPVector d = loop.value(), minusG(-mGain);
     const DSPVector w = x - d * minusG;
     const DSPVector y = w * minusG + d;
@@ -1327,7 +1708,11 @@ class Allpass
   float mGain{0.f};
   void setDelayInSamples(float d) { line_.setDelayInSamples(d - kFloatsPerDSPVector); }
   void setMaxDelayInSamples(float d) { line_.setMaxDelayInSamples(d - kFloatsPerDSPVector); }
-  void clear() { line_.clear(); }  // the loop's kept DSPVector starts at zero like the line
+  void clear()  // the loop's kept DSPVector starts at zero like the line
+  {
+    line_.clear();
+    kept_ = DSPVector();
+  }
   DSPVector operator()(const DSPVector x)
   {
     return run(x, [this](const DSPVector& w) { return line_(w); });
@@ -1346,6 +1731,7 @@ class FDN
 {
   std::array<IntegerDelay, SIZE> lines_;
   std::array<OnePole, SIZE> damping_;
+  std::array<DSPVector, SIZE> kept_;  // immediate mode: the loops' memories
 
  public:
   std::array<float, SIZE> mFeedbackGains{{0}};
@@ -1364,7 +1750,9 @@ class FDN
   }
   DSPVectorArray<2> operator()(const DSPVector x)
   {
-    std::array<gpu::FeedbackLoop, SIZE> loops;  // what goes into line n on the next DSPVector
+    std::vector<gpu::FeedbackLoop> loops;  // what goes into line n on the next DSPVector
+    loops.reserve(SIZE);
+    for (int n = 0; n < SIZE; ++n) loops.emplace_back(kept_[n]);
     std::array<DSPVector, SIZE> taps;
     for (int n = 0; n < SIZE; ++n) taps[n] = lines_[n](loops[n].value());
     DSPVector left, right, total;  // each accumulates from a zero vector, in line order
@@ -1381,13 +1769,14 @@ class FeedbackDelayFunction
 {
   using ProcessFn = std::function<DSPVector(const DSPVector)>;
   PitchbendableDelay line_;
+  DSPVector kept_;
 
  public:
   float feedbackGain{1.f};
   void setMaxDelayInSamples(float d) { line_.setMaxDelayInSamples(d); }  // extension: the reference offers no way to size it
   DSPVector operator()(const DSPVector x, ProcessFn fn, const DSPVector delayTime)
   {
-    gpu::FeedbackLoop loop;
+    gpu::FeedbackLoop loop(kept_);
     const DSPVector y = fn(x + loop.value() * DSPVector(feedbackGain));
     loop.close(line_(y, delayTime - DSPVector((float)kFloatsPerDSPVector)));
     return y;
@@ -1397,13 +1786,14 @@ class FeedbackDelayFunctionWithTap  // fn returns what is fed back and hands the
 {
   using ProcessFn = std::function<DSPVector(const DSPVector, DSPVector&)>;
   PitchbendableDelay line_;
+  DSPVector kept_;
 
  public:
   float feedbackGain{1.f};
   void setMaxDelayInSamples(float d) { line_.setMaxDelayInSamples(d); }
   DSPVector operator()(const DSPVector x, ProcessFn fn, const DSPVector delayTime)
   {
-    gpu::FeedbackLoop loop;
+    gpu::FeedbackLoop loop(kept_);
     DSPVector tap;
     const DSPVector fedBack = fn(x + loop.value() * DSPVector(feedbackGain), tap);
     loop.close(line_(fedBack, delayTime - DSPVector((float)kFloatsPerDSPVector)));
@@ -1454,10 +1844,19 @@ inline DSPVectorArray<ROWS> map(std::function<float(int)> f, const DSPVectorArra
   for (size_t n = 0; n < 64 * ROWS; ++n) a[n] = f(x.hostInt((int)n));
   return DSPVectorArray<ROWS>(a.data());
 }
+// map(float(float)) (MLDSPFunctional.h:37-48): the caller's own scalar function over the samples. On host data (immediate mode,
+// tables) that is what it says - f is the user's code, not the library's arithmetic; over a signal a captured kernel computes
+// there are no samples to hand to a host function.
 template <size_t ROWS>
-inline DSPVectorArray<ROWS> map(std::function<float(float)>, const DSPVectorArray<ROWS>)
+inline DSPVectorArray<ROWS> map(std::function<float(float)> f, const DSPVectorArray<ROWS> x)
 {
-  throw std::logic_error("mldsp GPU shim: map() with a scalar host function is evaluated per sample on the CPU; write it with DSPVector ops");
+  for (size_t j = 0; j < ROWS; ++j)
+    if (x.sig_[j].node >= 0)
+      throw std::logic_error("mldsp GPU shim: map() with a scalar host function over a signal the kernel computes - its samples exist only on the "
+                             "device; write the step with DSPVector ops");
+  std::array<float, 64 * ROWS> a;
+  for (size_t n = 0; n < 64 * ROWS; ++n) a[n] = f(x[n]);
+  return DSPVectorArray<ROWS>(a.data());
 }
 
 // Upsample2xFunction / Downsample2xFunction, MLDSPFunctional.h:114-213: fn runs at twice / half the rate between two
@@ -1509,6 +1908,163 @@ class Downsample2xFunction
     return gpu::rateRegion<IN_ROWS>(MLGPU_REGION_DOWNSAMPLE_2X, fn, vx);
   }
 };
+
+// Upsampler / Downsampler (MLDSPFilters.h:1316-1473): the vector-scheduled classes - write a DSPVector, read 2^octaves of them
+// (resp. write 2^octaves, read one). They hand whole DSPVectors back and forth on the caller's schedule, so they exist in
+// immediate mode only: a one-voice mlgpu_resampler per object (the same HalfBandFilter cascade; a Downsampler runs it when the
+// 2^octaves-th vector has arrived - the filters see the same samples in the same order as in the reference's per-write schedule).
+// Inside a captured process function use Upsample2xFunction / Downsample2xFunction, or mlgpu_resampler on device signals.
+namespace gpu
+{
+class ImmediateResampler
+{
+  mlgpu_resampler* r_{nullptr};
+  float* d_{nullptr};
+  int octaves_, up_;
+
+ public:
+  ImmediateResampler(int octaves, bool up) : octaves_(octaves), up_(up ? 1 : 0)
+  {
+    if (octaves < 0 || octaves > 6) throw std::invalid_argument("mldsp GPU shim: Upsampler / Downsampler octaves 0..6");
+  }
+  ImmediateResampler(const ImmediateResampler& o) : octaves_(o.octaves_), up_(o.up_)
+  {
+    if (!o.r_) return;  // value semantics: the copy continues from the original's filter memories
+    std::vector<float> st((size_t)octaves_ * 9);
+    Eager::get().engine().check(mlgpu_resampler_get_state(o.r_, st.data()));
+    make();
+    Eager::get().engine().check(mlgpu_resampler_set_state(r_, st.data()));
+  }
+  ImmediateResampler& operator=(const ImmediateResampler&) = delete;
+  ~ImmediateResampler()
+  {
+    if (r_) mlgpu_resampler_destroy(r_);
+    if (d_) mlgpu_free(Eager::get().engine().handle(), d_);
+  }
+  void make()
+  {
+    const Engine& e = Eager::get().engine();
+    e.check(mlgpu_resampler_create(e.handle(), 1, octaves_, up_, &r_));
+    void* p = nullptr;
+    e.check(mlgpu_alloc(e.handle(), (size_t)((1 << octaves_) + 1) * 256, &p));
+    d_ = static_cast<float*>(p);
+  }
+  void clear()
+  {
+    if (r_) Eager::get().engine().check(mlgpu_resampler_clear(r_));
+  }
+  // nIn DSPVectors in, nIn << octaves (up) or nIn >> octaves (down) out
+  void run(const float* in, size_t nIn, float* out)
+  {
+    if (Capture::current())
+      throw std::logic_error("mldsp GPU shim: Upsampler / Downsampler write() / read() run on the caller's schedule, outside a capture; inside a "
+                             "process function use Upsample2xFunction / Downsample2xFunction");
+    std::lock_guard<std::recursive_mutex> lock(Eager::get().m);
+    const Engine& e = Eager::get().engine();
+    if (!r_) make();
+    const size_t nOut = up_ ? nIn << octaves_ : nIn >> octaves_;
+    float* dIn = up_ ? d_ + 64 * ((size_t)1 << octaves_) : d_;
+    float* dOut = up_ ? d_ : d_ + 64 * ((size_t)1 << octaves_);
+    e.check(mlgpu_upload(e.handle(), dIn, in, nIn * 256));
+    e.check(mlgpu_resampler_process(r_, nIn, dIn, MLGPU_LAYOUT_QUAD, dOut, MLGPU_LAYOUT_QUAD));
+    e.check(mlgpu_download(e.handle(), out, dOut, nOut * 256));
+  }
+};
+}  // namespace gpu
+
+struct Upsampler
+{
+  gpu::ImmediateResampler r_;
+  std::vector<float> out_;
+  int octaves_, readIdx_{0};
+  explicit Upsampler(int octavesUp) : r_(octavesUp, true), out_((size_t)64 << octavesUp, 0.f), octaves_(octavesUp) {}
+  void write(DSPVector x)
+  {
+    float in[64];
+    store(x, in);
+    r_.run(in, 1, out_.data());
+    readIdx_ = 0;
+  }
+  DSPVector read()  // after a write, 1 << octaves reads are available
+  {
+    const DSPVector y(static_cast<const float*>(out_.data() + 64 * (size_t)readIdx_));
+    ++readIdx_;
+    return y;
+  }
+  void clear()
+  {
+    r_.clear();
+    std::fill(out_.begin(), out_.end(), 0.f);
+    readIdx_ = 0;
+  }
+};
+
+class Downsampler
+{
+  gpu::ImmediateResampler r_;
+  std::vector<float> in_;
+  std::array<float, 64> out_{};
+  int octaves_;
+  uint32_t counter_{0};
+
+ public:
+  explicit Downsampler(int octavesDown) : r_(octavesDown, false), in_((size_t)64 << octavesDown, 0.f), octaves_(octavesDown) {}
+  // true when this write completed an output vector (every 2^octaves writes)
+  bool write(DSPVector v)
+  {
+    store(v, in_.data() + 64 * (size_t)counter_);
+    counter_ = (counter_ + 1) & ((1u << octaves_) - 1u);
+    if (counter_ != 0) return false;
+    r_.run(in_.data(), (size_t)1 << octaves_, out_.data());
+    return true;
+  }
+  DSPVector read() { return DSPVector(static_cast<const float*>(out_.data())); }
+  void clear()
+  {
+    r_.clear();
+    out_.fill(0.f);
+    counter_ = 0;
+  }
+};
+
+// ml::Sample (MLDSPSample.h): a host container of audio - channels, a sample rate, the frames interleaved in one float vector -
+// and its free functions. Host data plumbing, the same interface.
+struct Sample
+{
+  size_t channels{0};
+  size_t sampleRate{0};
+  std::vector<float> sampleData;
+  float operator[](size_t i) const { return sampleData[i]; }
+  float& operator[](size_t i) { return sampleData[i]; }
+};
+inline size_t getSize(const Sample& s) { return s.sampleData.size(); }
+inline size_t getFrames(const Sample& s) { return s.channels ? s.sampleData.size() / s.channels : 0; }
+inline const float* getConstFramePtr(const Sample& s, size_t frameIdx = 0) { return s.sampleData.data() + frameIdx * s.channels; }
+inline float* getFramePtr(Sample& s, size_t frameIdx = 0) { return s.sampleData.data() + frameIdx * s.channels; }
+inline float getRate(const Sample& s) { return (float)s.sampleRate; }
+inline float getDuration(const Sample& s) { return s.sampleRate ? getFrames(s) / (float)s.sampleRate : 0.f; }
+inline bool usable(const Sample* pSample) { return pSample && !pSample->sampleData.empty(); }
+inline float* resize(Sample& s, size_t newFrames, size_t newChans = 1)  // nullptr when the allocation fails
+{
+  try
+  {
+    s.sampleData.resize(newFrames * newChans);
+  }
+  catch (const std::exception&)
+  {
+    return nullptr;
+  }
+  s.channels = newChans;
+  return s.sampleData.data();
+}
+inline float findMaximumValue(const Sample& x) { return *std::max_element(x.sampleData.begin(), x.sampleData.end()); }
+inline void normalize(Sample& x)
+{
+  if (x.sampleData.empty()) return;
+  const float ratio = 1.0f / findMaximumValue(x);
+  for (float& f : x.sampleData) f *= ratio;
+}
+inline void clear(Sample& x) { x.sampleData.clear(); }
 
 // Bank<T, ROWS>, MLDSPFunctional.h:321-360
 template <typename T, size_t ROWS>
