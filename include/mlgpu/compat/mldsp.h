@@ -1088,6 +1088,7 @@ struct ProcNode
     }
   };
   std::shared_ptr<Immediate> imm_;
+  static constexpr bool kVectorRateInput = (KIND == MLGPU_PROC_LINEAR_GLIDE || KIND == MLGPU_PROC_INTERPOLATOR1);
   ProcNode() = default;
   ProcNode(const ProcNode& o) { copyFrom(o); }
   ProcNode& operator=(const ProcNode& o)
@@ -1128,7 +1129,8 @@ struct ProcNode
         return r;
       };
       int ids[8];
-      for (int k = 0; k < n; ++k) ids[k] = ret(mlgpu_graph_add_input(im->g, nullptr));
+      // LinearGlide / Interpolator1 take one float per DSPVector (the reference's operator()(float)): a control input
+      for (int k = 0; k < n; ++k) ids[k] = ret(kVectorRateInput ? mlgpu_graph_add_control(im->g, nullptr) : mlgpu_graph_add_input(im->g, nullptr));
       im->node = ret(mlgpu_graph_add_proc(im->g, KIND, ids, n, nullptr));
       if (maxDelay_ >= 0.f) e.check(mlgpu_graph_set_max_delay(im->g, im->node, maxDelay_));
       e.check(mlgpu_graph_add_output(im->g, im->node));
@@ -1158,7 +1160,10 @@ struct ProcNode
     }
     if (n) e.check(mlgpu_upload(e.handle(), im.d, host, (size_t)n * 256));
     float* outPtr[1] = {im.d + 64 * n};
-    e.check(mlgpu_graph_process(im.g, 1, n ? inPtr : nullptr, MLGPU_LAYOUT_QUAD, outPtr, MLGPU_LAYOUT_QUAD));
+    if (kVectorRateInput)  // the control's one float is the first of the 64 uploaded
+      e.check(mlgpu_graph_process_ctl(im.g, 1, nullptr, MLGPU_LAYOUT_QUAD, inPtr, outPtr, MLGPU_LAYOUT_QUAD));
+    else
+      e.check(mlgpu_graph_process(im.g, 1, n ? inPtr : nullptr, MLGPU_LAYOUT_QUAD, outPtr, MLGPU_LAYOUT_QUAD));
     auto out = std::make_shared<std::array<float, 64>>();
     e.check(mlgpu_download(e.handle(), out->data(), outPtr[0], 256));
     return Sig(std::shared_ptr<const std::array<float, 64>>(std::move(out)));

@@ -116,6 +116,20 @@ extern "C" int hostdata_ref_run(size_t V, size_t T, const float* in0, float* out
   return 0;
 }
 
+// ---- imperative code: objects made, called and read on the spot (tests/cpp/dropin_eager.h) ----
+#include "../tests/cpp/dropin_eager.h"
+// returns the number of floats recorded (and copies min(that, cap) of them); names: "name@start;" per block
+extern "C" long immediate_ref_run(float* out, size_t cap, char* names, size_t namesLen)
+{
+  ImmediateLog log;
+  immediateSuite(log);
+  for (size_t i = 0; i < log.data.size() && i < cap; ++i) out[i] = log.data[i];
+  std::string nm;
+  for (size_t i = 0; i < log.names.size(); ++i) nm += log.names[i] + "@" + std::to_string(log.starts[i]) + ";";
+  if (names && namesLen) snprintf(names, namesLen, "%s", nm.c_str());
+  return (long)log.data.size();
+}
+
 // ---- every free function of MLDSPOps.h by name (tests/cpp/dropin_ops.h) ----
 #include "../tests/cpp/dropin_ops.h"
 extern "C" int ops_ref_run(size_t V, size_t T, const float* in0, const float* in1, float* outs /* [kOpsOutputs][V][64 T] */)

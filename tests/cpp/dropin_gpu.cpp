@@ -175,6 +175,27 @@ extern "C" int decay_gpu_run(size_t V, size_t T, int flush, const float* in0, fl
 }
 
 // ---- host data: scalar map forms, windows through getBuffer(), DSPBuffer overlap-add, v[n] on host vectors ----
+#include "dropin_eager.h"
+// the same suite through the shim's immediate mode: every call a launch on the device
+extern "C" long immediate_gpu_run(float* out, size_t cap, char* names, size_t namesLen, char* err, size_t errLen)
+{
+  try
+  {
+    ImmediateLog log;
+    immediateSuite(log);
+    for (size_t i = 0; i < log.data.size() && i < cap; ++i) out[i] = log.data[i];
+    std::string nm;
+    for (size_t i = 0; i < log.names.size(); ++i) nm += log.names[i] + "@" + std::to_string(log.starts[i]) + ";";
+    if (names && namesLen) snprintf(names, namesLen, "%s", nm.c_str());
+    return (long)log.data.size();
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
 #include "dropin_hostdata.h"
 extern "C" int hostdata_gpu_run(size_t V, size_t T, const float* in0, float* outs /* [kHostDataOutputs][V][64 T] */, char* err, size_t errLen)
 {
