@@ -252,21 +252,44 @@ inline bool capturing() { return Capture::current() != nullptr; }
 // constructs one makes its whole VoiceProgram run in the engine's flush mode (mlgpu_engine_set_flush_denormals around
 // every launch of that program); the host thread's own MXCSR is set too, as in the reference, so host-side float
 // arithmetic of the process function sees the same mode on both builds.
+// Outside a capture (immediate mode) the scope puts the immediate-mode engine into flush mode for its lifetime: the launches made
+// inside it run with denormals flushed, like the reference's instructions under the MXCSR bits.
 struct UsingFlushDenormalsToZero
 {
+  int immediateWas_{-1};  // >= 0: the immediate engine's mode to restore
+  void enter()
+  {
+    if (gpu::Capture::current())
+    {
+      gpu::Capture::current()->flushDenormals = true;
+      return;
+    }
+    gpu::Eager& E = gpu::Eager::get();
+    std::lock_guard<std::recursive_mutex> lock(E.m);
+    if (!E.eng && mlgpu_device_count() <= 0) return;  // no device: nothing runs here anyway (the first DSPVector call will say so)
+    const int was = mlgpu_engine_get_flush_denormals(E.engine().handle());
+    E.engine().check(mlgpu_engine_set_flush_denormals(E.engine().handle(), 1));
+    immediateWas_ = was > 0 ? 1 : 0;
+  }
+  void leave()
+  {
+    if (immediateWas_ >= 0) mlgpu_engine_set_flush_denormals(gpu::Eager::get().engine().handle(), immediateWas_);
+  }
 #if defined(__SSE__)
   unsigned MXCRState;
   UsingFlushDenormalsToZero() : MXCRState(__builtin_ia32_stmxcsr())
   {
     __builtin_ia32_ldmxcsr(MXCRState | 0x8040u);
-    if (gpu::Capture::current()) gpu::Capture::current()->flushDenormals = true;
+    enter();
   }
-  ~UsingFlushDenormalsToZero() { __builtin_ia32_ldmxcsr(MXCRState); }
-#else
-  UsingFlushDenormalsToZero()
+  ~UsingFlushDenormalsToZero()
   {
-    if (gpu::Capture::current()) gpu::Capture::current()->flushDenormals = true;
+    leave();
+    __builtin_ia32_ldmxcsr(MXCRState);
   }
+#else
+  UsingFlushDenormalsToZero() { enter(); }
+  ~UsingFlushDenormalsToZero() { leave(); }
 #endif
   UsingFlushDenormalsToZero(const UsingFlushDenormalsToZero&) = delete;
   UsingFlushDenormalsToZero& operator=(const UsingFlushDenormalsToZero&) = delete;
@@ -1088,7 +1111,9 @@ struct ProcNode
     }
   };
   std::shared_ptr<Immediate> imm_;
-  static constexpr bool kVectorRateInput = (KIND == MLGPU_PROC_LINEAR_GLIDE || KIND == MLGPU_PROC_INTERPOLATOR1);
+  // inputs that are one float per DSPVector (the reference's `float` arguments): control inputs of the one-voice graph
+  static constexpr unsigned kControlInputs =
+      (KIND == MLGPU_PROC_LINEAR_GLIDE || KIND == MLGPU_PROC_INTERPOLATOR1) ? 1u : (KIND == MLGPU_PROC_TEMPO_LOCK ? 6u : 0u);
   ProcNode() = default;
   ProcNode(const ProcNode& o) { copyFrom(o); }
   ProcNode& operator=(const ProcNode& o)
@@ -1130,7 +1155,8 @@ struct ProcNode
       };
       int ids[8];
       // LinearGlide / Interpolator1 take one float per DSPVector (the reference's operator()(float)): a control input
-      for (int k = 0; k < n; ++k) ids[k] = ret(kVectorRateInput ? mlgpu_graph_add_control(im->g, nullptr) : mlgpu_graph_add_input(im->g, nullptr));
+      for (int k = 0; k < n; ++k)
+        ids[k] = ret(((kControlInputs >> k) & 1u) ? mlgpu_graph_add_control(im->g, nullptr) : mlgpu_graph_add_input(im->g, nullptr));
       im->node = ret(mlgpu_graph_add_proc(im->g, KIND, ids, n, nullptr));
       if (maxDelay_ >= 0.f) e.check(mlgpu_graph_set_max_delay(im->g, im->node, maxDelay_));
       e.check(mlgpu_graph_add_output(im->g, im->node));
@@ -1150,20 +1176,23 @@ struct ProcNode
     cleared_ = hasInitState0_ = false;
     initState_.clear();
     float host[8 * 64];
-    int k = 0;
-    const float* inPtr[8];
+    int k = 0, nAudio = 0, nCtl = 0;
+    const float *inPtr[8], *ctlPtr[8];
     for (const Sig& sgn : ins)
     {
       sgn.hostCopy(host + 64 * k);
-      inPtr[k] = im.d + 64 * k;
+      if ((kControlInputs >> k) & 1u)
+        ctlPtr[nCtl++] = im.d + 64 * k;  // a control's one float is the first of the 64 uploaded
+      else
+        inPtr[nAudio++] = im.d + 64 * k;
       ++k;
     }
     if (n) e.check(mlgpu_upload(e.handle(), im.d, host, (size_t)n * 256));
     float* outPtr[1] = {im.d + 64 * n};
-    if (kVectorRateInput)  // the control's one float is the first of the 64 uploaded
-      e.check(mlgpu_graph_process_ctl(im.g, 1, nullptr, MLGPU_LAYOUT_QUAD, inPtr, outPtr, MLGPU_LAYOUT_QUAD));
+    if (nCtl)
+      e.check(mlgpu_graph_process_ctl(im.g, 1, nAudio ? inPtr : nullptr, MLGPU_LAYOUT_QUAD, ctlPtr, outPtr, MLGPU_LAYOUT_QUAD));
     else
-      e.check(mlgpu_graph_process(im.g, 1, n ? inPtr : nullptr, MLGPU_LAYOUT_QUAD, outPtr, MLGPU_LAYOUT_QUAD));
+      e.check(mlgpu_graph_process(im.g, 1, nAudio ? inPtr : nullptr, MLGPU_LAYOUT_QUAD, outPtr, MLGPU_LAYOUT_QUAD));
     auto out = std::make_shared<std::array<float, 64>>();
     e.check(mlgpu_download(e.handle(), out->data(), outPtr[0], 256));
     return Sig(std::shared_ptr<const std::array<float, 64>>(std::move(out)));

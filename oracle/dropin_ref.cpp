@@ -198,6 +198,7 @@ extern "C" int objects_ref_run_retrigger(size_t V, size_t T, const float* in0, c
   return 0;
 }
 
+#ifndef MLGPU_IMMEDIATE_BUILD  // everything below drives the reference's app layer (AudioContext events, Synth, SignalProcessBuffer ...)
 // ---- a Synth subclass run by the reference's own Synth::processVector, AudioContext and EventsToSignals ----
 #include "MLSynth.h"
 #include "../tests/cpp/dropin_synth.h"
@@ -514,3 +515,4 @@ extern "C" int published_ref_run(int maxFrames, int maxVoices, int octavesDown, 
   }
   return 0;
 }
+#endif  // MLGPU_IMMEDIATE_BUILD

@@ -81,3 +81,110 @@ def test_reference_unit_tests_need_the_device():
     assert r.returncode != 0
     assert "All tests passed" not in r.stdout
     assert "dsp_ops" in r.stdout and "dsp_gens" in r.stdout
+
+
+# ---- the captured programs' user code, run imperatively -----------------------------------------------------------------------
+# oracle/dropin_ref.cpp drives tests/cpp/dropin_*.h against the reference: one state object per voice, the process function called
+# once per DSPVector with host data in ctx.inputs. Its DSP half compiled against the shim (tests/cpp/libdropin_imm.so) is the same
+# loop in immediate mode. Same exported names, same arguments: outputs must be the reference's bits.
+
+def _imm_lib():
+    so = os.path.join(ROOT, "tests", "cpp", "libdropin_imm.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "include", "mlgpu")], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(so)
+
+
+def _both(name, argtypes):
+    fr, fi = getattr(_ref_lib(), name), getattr(_imm_lib(), name)
+    for f in (fr, fi):
+        f.restype, f.argtypes = ctypes.c_int, argtypes
+    return fr, fi
+
+
+def _p(a):
+    return a.ctypes.data_as(c_f32p)
+
+
+def _noise(V, S, seed):
+    from inputs import lcg_noise
+    return lcg_noise(np.arange(V, dtype=np.uint32) + seed, S)
+
+
+def _same(got, want, what):
+    from inputs import assert_bits_equal
+    assert np.abs(want).max() > 1e-3, what
+    assert_bits_equal(got, want, True, what)
+
+
+def test_patch_process_function_run_imperatively():
+    from test_gpu_dropin import _inputs
+    sz = ctypes.c_size_t
+    fr, fi = _both("dropin_ref_run", [sz, sz, c_f32p, c_f32p, c_f32p, c_f32p])
+    V, T = 3, 12
+    gate, pitch = _inputs(V, T)
+    w0, w1, g0, g1 = (np.zeros_like(gate) for _ in range(4))
+    assert fr(V, T, _p(gate), _p(pitch), _p(w0), _p(w1)) == 0
+    assert fi(V, T, _p(gate), _p(pitch), _p(g0), _p(g1)) == 0
+    _same(g0, w0, "patch, output 0")
+    _same(g1, w1, "patch, output 1")
+
+
+def test_reverb_process_function_run_imperatively():
+    """dropin_reverb.h: LinearGlide-smoothed floats, FractionalDelay, Allpass<IntegerDelay>, seven Allpass<PitchbendableDelay>, a stereo
+    feedback path kept in DSPVector members of the user's state - the loops live in the objects in immediate mode."""
+    sz = ctypes.c_size_t
+    fr, fi = _both("plate_ref_run", [sz, sz, sz, c_f32p, c_f32p, c_f32p, c_f32p])
+    V, T = 2, 30
+    inL, inR = _noise(V, 64 * T, 3), _noise(V, 64 * T, 9)
+    inL[:, 64 * 4:] = 0
+    inR[:, 64 * 4:] = 0
+    wL, wR, gL, gR = (np.zeros_like(inL) for _ in range(4))
+    assert fr(V, T, 12, _p(inL), _p(inR), _p(wL), _p(wR)) == 0
+    assert fi(V, T, 12, _p(inL), _p(inR), _p(gL), _p(gR)) == 0
+    _same(gL, wL, "reverb, left")
+    _same(gR, wR, "reverb, right")
+
+
+@pytest.mark.parametrize("flush", [0, 1])
+def test_decay_process_function_run_imperatively(flush):
+    sz = ctypes.c_size_t
+    fr, fi = _both("decay_ref_run", [sz, sz, ctypes.c_int, c_f32p, c_f32p, c_f32p])
+    V, T = 2, 400
+    x = _noise(V, 64 * T, 21)
+    x[:, 128:] = 0
+    w0, w1, g0, g1 = (np.zeros_like(x) for _ in range(4))
+    assert fr(V, T, flush, _p(x), _p(w0), _p(w1)) == 0
+    assert fi(V, T, flush, _p(x), _p(g0), _p(g1)) == 0
+    from inputs import assert_bits_equal
+    assert_bits_equal(g0, w0, True, f"decay (flush {flush}), output 0")   # tiny on purpose: the tails cross the denormal range
+    assert_bits_equal(g1, w1, True, f"decay (flush {flush}), output 1")
+    tiny = int(((np.abs(w0) > 0) & (np.abs(w0) < np.float32(1.17549435e-38))).sum())
+    assert (tiny == 0) if flush else (tiny > 100)
+
+
+def test_ops_routing_objects_hostdata_run_imperatively():
+    sz = ctypes.c_size_t
+    V, T = 2, 6
+    S = 64 * T
+    a, b, sel = _noise(V, S, 1), _noise(V, S, 2), np.abs(_noise(V, S, 3)) * 0.999
+    # outputs made of hardware-approximate terms (sqrtApprox / divideApprox; Peak, RMS): 1.5 * 2^-11 relative, as in test_gpu_dropin.py
+    approx = {"ops_ref_run": {7}, "objects_ref_run": {4, 5}}
+    for name, args, K in (("ops_ref_run", (a, b), None), ("routing_ref_run", (a, b, sel), None), ("objects_ref_run", (a, np.abs(b)), None),
+                          ("hostdata_ref_run", (a,), 4)):
+        fr, fi = _both(name, [sz, sz] + [c_f32p] * (len(args) + 1))
+        if K is None:   # the number of outputs is a constant of the header: find it by letting the reference fill a large array
+            probe = np.full(64 * V * S, np.float32(12345.0))
+            assert fr(V, T, *[_p(x) for x in args], _p(probe)) == 0
+            K = int(np.flatnonzero(probe != np.float32(12345.0)).max()) // (V * S) + 1
+        want, got = np.zeros((K, V, S), np.float32), np.zeros((K, V, S), np.float32)
+        assert fr(V, T, *[_p(x) for x in args], _p(want)) == 0
+        assert fi(V, T, *[_p(x) for x in args], _p(got)) == 0
+        w, g = want.view(np.uint32), got.view(np.uint32)
+        # NaN results (the ops header divides and takes logs of noise): any NaN == any NaN, the contract of include/mlgpu.h
+        same = (w == g) | (np.isnan(want) & np.isnan(got))
+        bad = [k for k in range(K) if k not in approx.get(name, ()) and not same[k].all()]
+        assert not bad, f"{name}: outputs {bad} differ"
+        for k in approx.get(name, ()):
+            fin = np.isfinite(want[k]) & np.isfinite(got[k])
+            assert (np.abs(got[k][fin] - want[k][fin]) <= 4 * 1.5 * 2.0 ** -11 * (np.abs(want[k][fin]) + np.abs(a).max())).all(), (name, k)
