@@ -1893,56 +1893,6 @@ inline DSPVectorArray<ROWS> map(std::function<float(float)> f, const DSPVectorAr
   return DSPVectorArray<ROWS>(a.data());
 }
 
-// Upsample2xFunction / Downsample2xFunction, MLDSPFunctional.h:114-213: fn runs at twice / half the rate between two
-// HalfBandFilters. Captured as a rate region of the graph (mlgpu_graph_begin_region): fn is called ONCE here, on the
-// resampled inputs, and the kernel evaluates its nodes twice per sample (resp. every second sample) on the same
-// processor objects - what the reference does by calling the one stateful fn twice per DSPVector (resp. once per two).
-namespace gpu
-{
-template <size_t IN_ROWS, class FN>
-inline DSPVectorArray<1> rateRegion(int kind, FN& fn, const DSPVectorArray<IN_ROWS>& vx)
-{
-  Capture& c = Capture::get();
-  int ins[IN_ROWS ? IN_ROWS : 1], inner[IN_ROWS ? IN_ROWS : 1];
-  for (size_t j = 0; j < IN_ROWS; ++j) ins[j] = vx.sig_[j].id();
-  const int st = mlgpu_graph_begin_region(c.g, kind, ins, (int)IN_ROWS, inner);
-  if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_graph_begin_region: ") + mlgpu_last_error(c.eng->handle()));
-  DSPVectorArray<IN_ROWS> resampled;
-  for (size_t j = 0; j < IN_ROWS; ++j) resampled.sig_[j] = computedSig(inner[j]);
-  const int outerRegion = c.curRegion;
-  c.curRegion = ++c.regionCounter;
-  const DSPVectorArray<1> y = fn(resampled);
-  const int result = y.sig_[0].id();
-  c.curRegion = outerRegion;
-  return DSPVectorArray<1>(computedSig(c.ret(mlgpu_graph_end_region(c.g, result, nullptr))));
-}
-}  // namespace gpu
-
-template <int IN_ROWS>
-class Upsample2xFunction
-{
-  using inputType = const DSPVectorArray<IN_ROWS>;
-  using outputType = DSPVectorArray<1>;
-  using ProcessFn = std::function<outputType(inputType)>;
-
- public:
-  outputType operator()(ProcessFn fn, inputType vx) { return gpu::rateRegion<IN_ROWS>(MLGPU_REGION_UPSAMPLE_2X, fn, vx); }
-};
-
-template <int IN_ROWS>
-class Downsample2xFunction
-{
-  using inputType = const DSPVectorArray<IN_ROWS>;
-  using outputType = DSPVectorArray<1>;
-  using ProcessFn = std::function<outputType(inputType)>;
-
- public:
-  outputType operator()(ProcessFn fn, const DSPVectorArray<IN_ROWS> vx = DSPVectorArray<0>())
-  {
-    return gpu::rateRegion<IN_ROWS>(MLGPU_REGION_DOWNSAMPLE_2X, fn, vx);
-  }
-};
-
 // Upsampler / Downsampler (MLDSPFilters.h:1316-1473): the vector-scheduled classes - write a DSPVector, read 2^octaves of them
 // (resp. write 2^octaves, read one). They hand whole DSPVectors back and forth on the caller's schedule, so they exist in
 // immediate mode only: a one-voice mlgpu_resampler per object (the same HalfBandFilter cascade; a Downsampler runs it when the
@@ -1961,19 +1911,34 @@ class ImmediateResampler
   {
     if (octaves < 0 || octaves > 6) throw std::invalid_argument("mldsp GPU shim: Upsampler / Downsampler octaves 0..6");
   }
-  ImmediateResampler(const ImmediateResampler& o) : octaves_(o.octaves_), up_(o.up_)
+  ImmediateResampler(const ImmediateResampler& o) : octaves_(o.octaves_), up_(o.up_) { takeStateOf(o); }
+  ImmediateResampler& operator=(const ImmediateResampler& o)
   {
-    if (!o.r_) return;  // value semantics: the copy continues from the original's filter memories
+    if (this != &o)
+    {
+      release();
+      octaves_ = o.octaves_;
+      up_ = o.up_;
+      takeStateOf(o);
+    }
+    return *this;
+  }
+  ~ImmediateResampler() { release(); }
+  void release()
+  {
+    if (r_) mlgpu_resampler_destroy(r_);
+    if (d_) mlgpu_free(Eager::get().engine().handle(), d_);
+    r_ = nullptr;
+    d_ = nullptr;
+  }
+  void takeStateOf(const ImmediateResampler& o)  // value semantics: the copy continues from the original's filter memories
+  {
+    if (!o.r_ || !octaves_) return;
+    std::lock_guard<std::recursive_mutex> lock(Eager::get().m);
     std::vector<float> st((size_t)octaves_ * 9);
     Eager::get().engine().check(mlgpu_resampler_get_state(o.r_, st.data()));
     make();
     Eager::get().engine().check(mlgpu_resampler_set_state(r_, st.data()));
-  }
-  ImmediateResampler& operator=(const ImmediateResampler&) = delete;
-  ~ImmediateResampler()
-  {
-    if (r_) mlgpu_resampler_destroy(r_);
-    if (d_) mlgpu_free(Eager::get().engine().handle(), d_);
   }
   void make()
   {
@@ -2005,6 +1970,130 @@ class ImmediateResampler
   }
 };
 }  // namespace gpu
+
+
+// HalfBandFilter (MLDSPFilters.h:1245-1310) as an object of its own, immediate mode: one octave of that cascade per direction.
+// upsampleSecondHalf(x) hands out the second half of what upsampleFirstHalf(x) computed (the reference's users call them in
+// that order on the same vector); the upsampling and the downsampling memories are separate, as in every use the reference makes.
+class HalfBandFilter
+{
+  gpu::ImmediateResampler up_{1, true}, down_{1, false};
+  std::array<float, 128> upOut_{};
+
+ public:
+  DSPVector upsampleFirstHalf(const DSPVector vx)
+  {
+    float in[64];
+    store(vx, in);
+    up_.run(in, 1, upOut_.data());
+    return DSPVector(static_cast<const float*>(upOut_.data()));
+  }
+  DSPVector upsampleSecondHalf(const DSPVector) { return DSPVector(static_cast<const float*>(upOut_.data() + 64)); }
+  DSPVector downsample(const DSPVector vx1, const DSPVector vx2)
+  {
+    float in[128], out[64];
+    store(vx1, in);
+    store(vx2, in + 64);
+    down_.run(in, 2, out);
+    return DSPVector(static_cast<const float*>(out));
+  }
+  void clear()
+  {
+    up_.clear();
+    down_.clear();
+    upOut_.fill(0.f);
+  }
+};
+
+// Upsample2xFunction / Downsample2xFunction, MLDSPFunctional.h:114-213: fn runs at twice / half the rate between two
+// HalfBandFilters. Captured as a rate region of the graph (mlgpu_graph_begin_region): fn is called ONCE here, on the
+// resampled inputs, and the kernel evaluates its nodes twice per sample (resp. every second sample) on the same
+// processor objects - what the reference does by calling the one stateful fn twice per DSPVector (resp. once per two).
+namespace gpu
+{
+template <size_t IN_ROWS, class FN>
+inline DSPVectorArray<1> rateRegion(int kind, FN& fn, const DSPVectorArray<IN_ROWS>& vx)
+{
+  Capture& c = Capture::get();
+  int ins[IN_ROWS ? IN_ROWS : 1], inner[IN_ROWS ? IN_ROWS : 1];
+  for (size_t j = 0; j < IN_ROWS; ++j) ins[j] = vx.sig_[j].id();
+  const int st = mlgpu_graph_begin_region(c.g, kind, ins, (int)IN_ROWS, inner);
+  if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_graph_begin_region: ") + mlgpu_last_error(c.eng->handle()));
+  DSPVectorArray<IN_ROWS> resampled;
+  for (size_t j = 0; j < IN_ROWS; ++j) resampled.sig_[j] = computedSig(inner[j]);
+  const int outerRegion = c.curRegion;
+  c.curRegion = ++c.regionCounter;
+  const DSPVectorArray<1> y = fn(resampled);
+  const int result = y.sig_[0].id();
+  c.curRegion = outerRegion;
+  return DSPVectorArray<1>(computedSig(c.ret(mlgpu_graph_end_region(c.g, result, nullptr))));
+}
+}  // namespace gpu
+
+template <int IN_ROWS>
+class Upsample2xFunction
+{
+  using inputType = const DSPVectorArray<IN_ROWS>;
+  using outputType = DSPVectorArray<1>;
+  using ProcessFn = std::function<outputType(inputType)>;
+  // immediate mode: the reference's own schedule (MLDSPFunctional.h:128-151) - both halves of every input row, fn twice, one
+  // DSPVector down - over HalfBandFilters on the device
+  std::array<HalfBandFilter, (IN_ROWS > 0 ? IN_ROWS : 1)> uppers_;
+  HalfBandFilter downer_;
+
+ public:
+  outputType operator()(ProcessFn fn, inputType vx)
+  {
+    if (gpu::Capture::current()) return gpu::rateRegion<IN_ROWS>(MLGPU_REGION_UPSAMPLE_2X, fn, vx);
+    DSPVectorArray<IN_ROWS> in1, in2;
+    for (int j = 0; j < IN_ROWS; ++j)
+    {
+      in1.row(j) = uppers_[(size_t)j].upsampleFirstHalf(vx.constRow(j));
+      in2.row(j) = uppers_[(size_t)j].upsampleSecondHalf(vx.constRow(j));
+    }
+    const outputType out1 = fn(in1);
+    const outputType out2 = fn(in2);
+    return downer_.downsample(out1, out2);
+  }
+};
+
+template <int IN_ROWS>
+class Downsample2xFunction
+{
+  using inputType = const DSPVectorArray<IN_ROWS>;
+  using outputType = DSPVectorArray<1>;
+  using ProcessFn = std::function<outputType(inputType)>;
+
+ public:
+  outputType operator()(ProcessFn fn, const DSPVectorArray<IN_ROWS> vx = DSPVectorArray<0>())
+  {
+    if (gpu::Capture::current()) return gpu::rateRegion<IN_ROWS>(MLGPU_REGION_DOWNSAMPLE_2X, fn, vx);
+    // immediate mode: the reference's two-phase schedule (MLDSPFunctional.h:176-211)
+    outputType vy;
+    if (phase_)
+    {
+      DSPVectorArray<IN_ROWS> down;
+      for (int j = 0; j < IN_ROWS; ++j) down.row(j) = downers_[(size_t)j].downsample(inputBuffer_.constRow(j), vx.constRow(j));
+      const outputType y = fn(down);
+      vy = upper_.upsampleFirstHalf(y);
+      outputBuffer_ = upper_.upsampleSecondHalf(y);
+    }
+    else
+    {
+      inputBuffer_ = vx;
+      vy = outputBuffer_;
+    }
+    phase_ = !phase_;
+    return vy;
+  }
+
+ private:
+  std::array<HalfBandFilter, (IN_ROWS > 0 ? IN_ROWS : 1)> downers_;
+  HalfBandFilter upper_;
+  DSPVectorArray<IN_ROWS> inputBuffer_;
+  outputType outputBuffer_;
+  bool phase_{false};
+};
 
 struct Upsampler
 {

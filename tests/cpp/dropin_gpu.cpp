@@ -196,6 +196,89 @@ extern "C" long immediate_gpu_run(float* out, size_t cap, char* names, size_t na
   }
 }
 
+// ---- the shim's feedback composites the reference cannot run (its FDN and FeedbackDelayFunction have no way to size their delay
+// lines): the same process function captured into a kernel and run imperatively must give the same bits -------------------------
+namespace loopsTest
+{
+constexpr int kOutputs = 4;
+struct State
+{
+  FDN<4> fdn;
+  FeedbackDelayFunction fbd;
+  FeedbackDelayFunctionWithTap fbt;
+  OnePole inLoop, inTapLoop;
+  Allpass<PitchbendableDelay> ap;
+};
+inline void setup(State* s)
+{
+  s->fdn.setDelaysInSamples({{67.f, 73.f, 91.f, 103.f}});
+  s->fdn.setFilterCutoffs({{0.1f, 0.2f, 0.3f, 0.4f}});
+  s->fdn.mFeedbackGains = {{0.5f, 0.55f, 0.6f, 0.65f}};
+  s->fbd.feedbackGain = 0.7f;
+  s->fbd.setMaxDelayInSamples(400.f);
+  s->fbt.feedbackGain = 0.6f;
+  s->fbt.setMaxDelayInSamples(400.f);
+  s->inLoop.coeffs = OnePole::makeCoeffs(0.1f);
+  s->inTapLoop.coeffs = OnePole::makeCoeffs(0.2f);
+  s->ap.setMaxDelayInSamples(500.f);
+  s->ap.mGain = 0.5f;
+}
+inline void process(AudioContext* ctx, void* untyped)
+{
+  State* s = static_cast<State*>(untyped);
+  const DSPVector x = ctx->inputs[0];
+  const DSPVectorArray<2> wet = s->fdn(x);
+  ctx->outputs[0] = wet.constRow(0);
+  ctx->outputs[1] = wet.constRow(1);
+  ctx->outputs[2] = s->fbd(x, [&](const DSPVector in) { return s->inLoop(in) * 0.9f; }, DSPVector(150.f) + x * 20.f);
+  ctx->outputs[3] = s->fbt(x, [&](const DSPVector in, DSPVector& tap) {
+    tap = s->inTapLoop(in);
+    return tap * 0.8f;
+  }, DSPVector(131.f)) + s->ap(x, DSPVector(200.f) + x * 30.f);
+}
+}  // namespace loopsTest
+extern "C" int loops_captured_and_immediate_run(size_t T, const float* in0, float* captured /* [4][64 T] */, float* immediate, char* err, size_t errLen)
+{
+  try
+  {
+    using namespace loopsTest;
+    const size_t S = T * 64;
+    {
+      gpu::Engine eng(0);
+      State state;
+      setup(&state);
+      AudioContext ctx(1, kOutputs, 48000);
+      gpu::VoiceProgram prog(eng, 1, &ctx, process, &state);
+      gpu::DeviceSignal q0(eng, 1, T);
+      eng.check(mlgpu_upload(eng.handle(), q0.data(), in0, q0.bytes()));   // one voice: QUAD is the samples in order
+      std::vector<gpu::DeviceSignal> o;
+      std::vector<gpu::DeviceSignal*> po;
+      o.reserve(kOutputs);
+      for (int i = 0; i < kOutputs; ++i) o.emplace_back(eng, 1, T);
+      for (auto& x : o) po.push_back(&x);
+      prog.process({&q0}, po);
+      for (int i = 0; i < kOutputs; ++i) eng.check(mlgpu_download(eng.handle(), captured + (size_t)i * S, o[(size_t)i].data(), S * 4));
+    }
+    {
+      State state;
+      setup(&state);
+      AudioContext ctx(1, kOutputs, 48000);
+      for (size_t t = 0; t < T; ++t)
+      {
+        load(ctx.inputs[0], in0 + t * 64);
+        process(&ctx, &state);
+        for (int o = 0; o < kOutputs; ++o) store(ctx.outputs[o], immediate + (size_t)o * S + t * 64);
+      }
+    }
+    return 0;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
 #include "dropin_hostdata.h"
 extern "C" int hostdata_gpu_run(size_t V, size_t T, const float* in0, float* outs /* [kHostDataOutputs][V][64 T] */, char* err, size_t errLen)
 {

@@ -188,3 +188,35 @@ def test_ops_routing_objects_hostdata_run_imperatively():
         for k in approx.get(name, ()):
             fin = np.isfinite(want[k]) & np.isfinite(got[k])
             assert (np.abs(got[k][fin] - want[k][fin]) <= 4 * 1.5 * 2.0 ** -11 * (np.abs(want[k][fin]) + np.abs(a).max())).all(), (name, k)
+
+
+def test_oversampled_process_function_run_imperatively():
+    """dropin_oversample.h: Upsample2xFunction / Downsample2xFunction around stateful lambdas. Captured, they are rate regions of one
+    kernel; imperatively, the reference's own schedule over HalfBandFilters on the device."""
+    sz = ctypes.c_size_t
+    fr, fi = _both("oversample_ref_run", [sz, sz, c_f32p, c_f32p, c_f32p, c_f32p])
+    V, T = 2, 9
+    in0, in1 = _noise(V, 64 * T, 5), _noise(V, 64 * T, 6)
+    w0, w1, g0, g1 = (np.zeros_like(in0) for _ in range(4))
+    assert fr(V, T, _p(in0), _p(in1), _p(w0), _p(w1)) == 0
+    assert fi(V, T, _p(in0), _p(in1), _p(g0), _p(g1)) == 0
+    _same(g0, w0, "oversampled, output 0")
+    _same(g1, w1, "oversampled, output 1")
+
+
+def test_feedback_composites_captured_and_immediate_agree():
+    """FDN<4>, FeedbackDelayFunction, FeedbackDelayFunctionWithTap (the reference's own classes cannot size their delay lines, so there
+    is no CPU run to compare with) and Allpass<PitchbendableDelay> with a modulated time: one process function, captured into a kernel
+    (whose arithmetic the other drop-in tests pin against the reference) and run imperatively - same bits."""
+    Lg = _gpu_lib()
+    Lg.loops_captured_and_immediate_run.restype = ctypes.c_int
+    Lg.loops_captured_and_immediate_run.argtypes = [ctypes.c_size_t, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    T = 24
+    x = _noise(1, 64 * T, 41)[0].copy()
+    x[64 * 3:] = 0
+    cap, imm = np.zeros((4, 64 * T), np.float32), np.zeros((4, 64 * T), np.float32)
+    err = ctypes.create_string_buffer(4096)
+    assert Lg.loops_captured_and_immediate_run(T, _p(x), _p(cap), _p(imm), err, 4096) == 0, err.value.decode()
+    for k in range(4):
+        assert np.abs(cap[k][64 * 6:]).max() > 1e-4, k          # the loops ring on after the burst
+        assert (cap[k].view(np.uint32) == imm[k].view(np.uint32)).all(), f"output {k}: captured and immediate differ"
