@@ -18,11 +18,18 @@
 //
 // What can be captured: everything that is data flow on whole DSPVectors — operators, the DEFINE_OP* free
 // functions, compare/select, conversions, row plumbing, index generators, mix/multiplex, every generator and filter
-// object with its makeCoeffs / coeffs / clear() / operator() forms, Bank<T,ROWS>. What cannot: reading or writing
-// single samples on the host (`v[n]`, getBuffer(), sum()/mean()/max()/min() to float) — there is no data on the
-// host. Those members do not exist here, so such code fails to compile rather than silently doing something else.
+// object with its makeCoeffs / coeffs / clear() / operator() forms, Bank<T,ROWS>, the rate functions. What cannot: anything
+// that needs a float of a signal the kernel computes ON THE HOST (`v[n]`, store(), sum()/mean()/max()/min() to float, ==,
+// rotateLeft, map() with a scalar function) — inside a capture those throw and say so.
 // Per-voice variation comes in through ml::gpu::VoiceParam (a per-voice constant), streamed inputs
 // (ctx->inputs[c]) and per-voice coefficients (VoiceProgram::setCoeff).
+//
+// IMMEDIATE MODE. The same calls made OUTSIDE a capture — a unit test, an offline tool, a setup function — run at once, on the
+// device, for one voice: a DSPVector is then host data, as in the reference, every call is one launch (gpu::Eager below), and all of
+// the above exists, host access included. The reference's own unit tests (Tests/dspOpsTest.cpp, dspGensTest.cpp, dspFiltersTest.cpp,
+// dspBufferTest.cpp) compile unchanged against this header — include/mlgpu/compat/dsp forwards madronalib's header names — and pass
+// (tests/test_gpu_immediate.py); a process function written for capture can also be called directly, vector by vector. It is the
+// same arithmetic as the fused kernels, a round trip per call, and no CPU fallback: without a device the calls throw.
 #pragma once
 
 #include <algorithm>

@@ -1,0 +1,35 @@
+"""The source shim's immediate mode without a GPU: the reference's own unit tests compile unchanged against the shim
+(include/mlgpu/Makefile: reftests - madronalib's header names are forwarded by include/mlgpu/compat/dsp) and, with no device, every
+test case that does DSPVector arithmetic fails with the engine's error - there is no CPU arithmetic behind the shim. The GPU half is
+tests/test_gpu_immediate.py."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "reftests_gpu")
+
+
+def test_reference_unit_tests_compile_unchanged_and_fail_loudly_without_a_device():
+    import madronalib_amd as ml
+    if os.path.isdir("/root/reference/Tests"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "include", "mlgpu"), "reftests"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(EXE):
+        pytest.skip("tests/cpp/reftests_gpu is built from the reference's Tests/ where that checkout exists")
+    if ml.device_count() > 0:
+        pytest.skip("a GPU is visible here (tests/test_gpu_immediate.py runs the binary on it)")
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "no gfx950 (MI355X) HIP device" in r.stdout
+    assert "All tests passed" not in r.stdout
+    # the host-only cases (the DSPBuffer ring between two threads, sizes, std::vector<DSPVector>) still pass
+    assert "test cases: 10 |  5 passed | 5 failed" in r.stdout, r.stdout[-600:]
+
+
+def test_forwarding_headers_cover_the_dsp_headers_user_code_includes():
+    have = set(os.listdir(os.path.join(ROOT, "include", "mlgpu", "compat", "dsp")))
+    for h in ("MLDSPOps.h", "MLDSPFilters.h", "MLDSPGens.h", "MLDSPBuffer.h", "MLDSPFunctional.h", "MLDSPUtils.h", "MLDSPRouting.h", "MLDSPSample.h",
+              "MLDSPMath.h"):
+        assert h in have
+        assert '#include "../mldsp.h"' in open(os.path.join(ROOT, "include", "mlgpu", "compat", "dsp", h)).read()
