@@ -90,8 +90,7 @@ def test_reference_unit_tests_need_the_device():
 
 def _imm_lib():
     so = os.path.join(ROOT, "tests", "cpp", "libdropin_imm.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "include", "mlgpu")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "libdropin_imm.so"], stdout=subprocess.DEVNULL)
     return ctypes.CDLL(so)
 
 
