@@ -169,6 +169,46 @@ def test_events_to_signals_matches_reference(eng, name):
     assert np.abs(got[1]).max() > 0 and np.abs(got[0]).max() > 0
 
 
+def sparse_performance(seed, frames, gap):
+    """A few notes and bends with long silences between them: most launches see no event at all."""
+    rng = np.random.default_rng(seed)
+    evs, held, t = [], [], int(rng.integers(0, gap))
+    while t < frames - 10:
+        r = rng.random()
+        if r < 0.45 or not held:
+            key = int(rng.integers(30, 90))
+            evs.append((NOTE_ON, 1, key, t, float(np.float32((key - 60) / 12.0)), float(np.float32(rng.uniform(0.1, 1.0)))))
+            held.append(key)
+        elif r < 0.8:
+            evs.append((NOTE_OFF, 1, held.pop(int(rng.integers(0, len(held)))), t, 0.0, 0.0))
+        elif r < 0.9:
+            evs.append((BEND, 1, 0, t, float(np.float32(rng.uniform(-1, 1))), 0.0))
+        else:
+            evs.append((CTRL, 1, 16, t, float(np.float32(rng.random())), 0.0))
+        t += int(rng.integers(gap // 4, gap))
+    return evs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,vectors_per_launch,rows", [(2000.0, 16, None), (1000.0, 9, [0, 1]), (3000.0, 4, [0, 1, 7]), (2000.0, 13, [0])])
+def test_quiet_blocks_through_drift_glide_changes(eng, sr, vectors_per_launch, rows):
+    """Launches in which nothing happens take e2s_kernel's block path: several DSPVectors of the pitch row per fetch of the drift
+    glide's slots. At a low sample rate the drift glide (8 s per glide, a new target every 8..16 s) starts, continues and ends many
+    times inside such blocks; note events, bends (whose glide keeps moving for a while) and pitch glides in between send single
+    vectors and whole launches down the vector-by-vector path. 2304 DSPVectors, all rows against the reference's class."""
+    cfg = dict(polyphony=4, sr=sr, glide=0.05, drift=0.8)
+    block, n_blocks = 64 * 144, 16
+    instruments = [sparse_performance(300 + k, block * n_blocks, 20000) for k in range(3)] + [[]]
+    got = gpu_run(eng, cfg, instruments, block, n_blocks, vectors_per_launch=vectors_per_launch, rows=rows)
+    P = cfg["polyphony"]
+    for k, evs in enumerate(instruments):
+        want = ref_run(cfg, evs, block, n_blocks)
+        for r in (range(8) if rows is None else rows):
+            assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"sr {sr}: instrument {k} row {ROW_NAMES[r]}")
+    pitch = got[0, :P]
+    assert len(np.unique(np.round(np.diff(pitch[0, ::64]), 9))) > 4     # the drift really moves through several glides
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,rows", [("midi_poly4", [0, 1]), ("mpe5", [0, 1, 3, 6]), ("midi_poly16", [1, 2, 4, 5, 7])])
 def test_wanted_rows_only(eng, name, rows):
