@@ -132,3 +132,26 @@ def test_reference_controllers_to_audio_example_unchanged():
     assert np.abs(want[0]).max() > 0.2
     # the oscillators really do move with their controllers: the spectrum centroid of the first and last second differ
     assert not np.allclose(want[0][:4096], want[0][-4096:])
+
+
+@pytest.mark.gpu
+def test_reference_fdtd_example_unchanged():
+    """fdtd.cpp - the last of the reference's DSP examples. Its process function is not a DSPVector graph: per SAMPLE it reads
+    `freq[i]` and `inputVec[i]` into floats, steps a 16 x 16 finite-difference mesh in host code and writes `outLVec[i]`, inside a
+    flush-denormals scope. Compiled unchanged against the shim it runs as the reference runs it, called once per DSPVector, in
+    immediate mode: ImpulseGen, SineGen and the vector arithmetic on the device, the mesh the program's own loop. 1600 DSPVectors
+    (two ticks of the 2 Hz impulse train with the mesh ringing in between): the reference's floats."""
+    Lg, Lr = _libs()
+    Lr.example_fdtd_ref_run.argtypes = [ctypes.c_size_t, c_f32p, c_f32p]
+    Lg.example_fdtd_gpu_run.argtypes = [ctypes.c_size_t, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    T = 1600
+    want = [np.zeros(64 * T, np.float32) for _ in range(2)]
+    assert Lr.example_fdtd_ref_run(T, want[0].ctypes.data_as(c_f32p), want[1].ctypes.data_as(c_f32p)) == 0
+    got = [np.zeros(64 * T, np.float32) for _ in range(2)]
+    err = ctypes.create_string_buffer(4096)
+    st = Lg.example_fdtd_gpu_run(T, got[0].ctypes.data_as(c_f32p), got[1].ctypes.data_as(c_f32p), err, 4096)
+    assert st == 0, err.value.decode()
+    assert_bits_equal(got[0], want[0], True, "fdtd left pickup")
+    assert_bits_equal(got[1], want[1], True, "fdtd right pickup")
+    assert np.abs(want[0]).max() > 1e-3 and np.isfinite(want[0]).all()
+    assert np.abs(want[0][64 * 1000:]).max() > 0        # still ringing (or struck again) late in the run
