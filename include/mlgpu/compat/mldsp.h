@@ -2577,6 +2577,11 @@ struct VoiceProgramOptions
   // readContextSamples() fetches the signals' next 64 samples and update() runs the function again with them, so its host
   // floats are what the reference computes for that vector. Needs liveConstants.
   bool hostContextSamples{false};
+  // SynthProgram: EventsToSignals on an engine (HIP stream) of its own, so that its kernel for block k + 1 runs beside the voice
+  // kernel of block k (two sets of row signals, fences either way round). Same results; -10 % per block where the events kernel is a
+  // visible part of it. Used when the rows are read from memory and processVoice reads no controller signal (those are made by the
+  // events call into one buffer); otherwise the one-stream order is kept.
+  bool eventsOnOwnStream{false};
 };
 
 // Captures a reference-style process function once and runs it for `voices` voices on the GPU.
@@ -2881,6 +2886,13 @@ class SynthProgram
   size_t publishedInstrument_{0};
   std::vector<int> controllers_;  // controller numbers processVoice reads through ctx->getInputController(n)
   mlgpu_transport* transport_{nullptr};  // there when processVoice reads ctx->getBeatPhase(): one ProcessTime per instrument
+  // VoiceProgramOptions::eventsOnOwnStream
+  bool wantOwnStream_{false};
+  std::unique_ptr<Engine> evEngine_;
+  std::vector<DeviceSignal> rowsB_;                    // the second set of row signals
+  std::unique_ptr<Fence> written_[2], read_[2];        // row set s: written by the events kernel / read by the voice kernel
+  size_t blockCount_{0};
+  const Engine& eventsEngine() const { return evEngine_ ? *evEngine_ : eng_; }
   static VoiceProgramOptions perInstrument(VoiceProgramOptions o, int polyphony)
   {
     o.voicesPerContext = (size_t)polyphony;
@@ -2900,7 +2912,17 @@ class SynthProgram
     for (int code : prog_.contextInputs())
       if (code != Capture::kBeatPhase) controllers_.push_back(code);
       else eng_.check(mlgpu_transport_create(e.handle(), nInstruments, 1, &transport_));  // reserved at the first process call
-    eng_.check(mlgpu_events_create(e.handle(), nInstruments, polyphony_, &ev_));
+    wantOwnStream_ = opt.eventsOnOwnStream && !prog_.eventRowsInKernel() && controllers_.empty() && prog_.voiceRowMask() != 0;
+    if (wantOwnStream_)
+    {
+      evEngine_.reset(new Engine(e.device(), +1));
+      for (int i = 0; i < 2; ++i)
+      {
+        written_[i].reset(new Fence(*evEngine_));
+        read_[i].reset(new Fence(e));
+      }
+    }
+    eng_.check(mlgpu_events_create(eventsEngine().handle(), nInstruments, polyphony_, &ev_));
     eng_.check(mlgpu_events_set_sample_rate(ev_, (double)sampleRate));
     eng_.check(mlgpu_events_set_wanted_rows(ev_, prog_.voiceRowMask()));  // rows processVoice never reads are not made
     if (prog_.eventRowsInKernel()) eng_.check(mlgpu_graph_bind_events(prog_.graph(), ev_));
@@ -2930,6 +2952,7 @@ class SynthProgram
     if (instrument >= nInstruments_) throw Error(MLGPU_ERR_INVALID, "SynthProgram::setPublishedInstrument: no such instrument");
     publishedInstrument_ = instrument;
   }
+  bool eventsOnOwnStream() const { return wantOwnStream_; }  // whether the option took effect (see VoiceProgramOptions)
   mlgpu_events* events() const { return ev_; }  // protocol, glide, drift, bend range: the mlgpu_events_set_* calls
   VoiceProgram& program() { return prog_; }
   void update() { prog_.update(); }  // the Synth's host-side numbers changed (coefficients, parameters): VoiceProgram::update()
@@ -2961,8 +2984,15 @@ class SynthProgram
       voiceOut_.clear();
       tapOut_.clear();
       for (size_t c = 0; c < prog_.tapChannels(); ++c) tapOut_.emplace_back(eng_, voices(), nVectors);
+      rowsB_.clear();
       for (int r = 0; r < kNumVoiceOutputRows; ++r)
         rows_.emplace_back(eng_, (!prog_.eventRowsInKernel() && ((prog_.voiceRowMask() >> r) & 1u)) ? voices() : 1, nVectors);
+      if (wantOwnStream_)
+      {
+        eng_.sync();  // nothing of the old signals is in flight on either stream
+        evEngine_->sync();
+        for (int r = 0; r < kNumVoiceOutputRows; ++r) rowsB_.emplace_back(eng_, ((prog_.voiceRowMask() >> r) & 1u) ? voices() : 1, nVectors);
+      }
       for (size_t c = 0; c < nOut_; ++c) voiceOut_.emplace_back(eng_, voices(), nVectors);
       // the controllers' smoothers go on when only the reserved length changes
       if (!controllers_.empty()) eng_.check(mlgpu_events_watch_controllers(ev_, controllers_.data(), (int)controllers_.size(), nVectors));
@@ -2970,11 +3000,13 @@ class SynthProgram
       capacityT_ = nVectors;
     }
     const bool inKernel = prog_.eventRowsInKernel();
+    const size_t set = wantOwnStream_ ? (blockCount_ & 1) : 0;
+    std::vector<DeviceSignal>& rowSet = set ? rowsB_ : rows_;
     float* rowPtrs[kNumVoiceOutputRows];
     std::vector<const float*> pi;
     for (int r = 0; r < kNumVoiceOutputRows; ++r)
     {
-      rowPtrs[r] = (!inKernel && ((prog_.voiceRowMask() >> r) & 1u)) ? rows_[r].data() : nullptr;
+      rowPtrs[r] = (!inKernel && ((prog_.voiceRowMask() >> r) & 1u)) ? rowSet[r].data() : nullptr;
       if (rowPtrs[r]) pi.push_back(rowPtrs[r]);
     }
     {
@@ -2988,6 +3020,18 @@ class SynthProgram
     for (auto& s : tapOut_) po.push_back(s.data());
     if (inKernel)  // the voice kernel walks the block's event records itself: pitch and gate never exist in memory
       eng_.check(mlgpu_graph_process_events(prog_.graph(), nVectors, startOffset, pi.data(), MLGPU_LAYOUT_QUAD, nullptr, po.data(), MLGPU_LAYOUT_QUAD));
+    else if (wantOwnStream_)
+    {
+      // the events kernel of this block may start as soon as the voice kernel of the block before last has read this row set -
+      // i.e. while the voice kernel of the previous block is still running on the other stream
+      read_[set]->awaitedBy(*evEngine_);
+      evEngine_->check(mlgpu_events_process(ev_, nVectors, startOffset, rowPtrs, MLGPU_LAYOUT_QUAD));
+      written_[set]->signalFrom(*evEngine_);
+      written_[set]->awaitedBy(eng_);
+      eng_.check(mlgpu_graph_process(prog_.graph(), nVectors, pi.data(), MLGPU_LAYOUT_QUAD, po.data(), MLGPU_LAYOUT_QUAD));
+      read_[set]->signalFrom(eng_);
+      ++blockCount_;
+    }
     else
     {
       eng_.check(mlgpu_events_process(ev_, nVectors, startOffset, rowPtrs, MLGPU_LAYOUT_QUAD));

@@ -58,6 +58,14 @@ class Engine
     const int st = mlgpu_engine_create(device, &e_);
     if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_engine_create: ") + mlgpu_status_string(st));
   }
+  // a second engine of a device for short launches that should slip in beside another engine's long ones (mlgpu_engine_create_urgency:
+  // +1 the device's greatest stream priority, -1 its least); order the two with Fence
+  Engine(int device, int urgency)
+  {
+    const int st = mlgpu_engine_create_urgency(device, urgency, &e_);
+    if (st != MLGPU_OK) throw Error(st, std::string("mlgpu_engine_create_urgency: ") + mlgpu_status_string(st));
+  }
+  int device() const { return mlgpu_engine_device(e_); }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
   ~Engine()
@@ -70,6 +78,23 @@ class Engine
     if (st != MLGPU_OK) throw Error(st, std::string(mlgpu_status_string(st)) + ": " + mlgpu_last_error(e_));
   }
   void sync() const { check(mlgpu_engine_sync(e_)); }
+};
+
+// A point in one engine's stream that another engine of the same device can wait for (mlgpu_fence).
+class Fence
+{
+  mlgpu_fence* f_{nullptr};
+
+ public:
+  explicit Fence(const Engine& e) { e.check(mlgpu_fence_create(e.handle(), &f_)); }
+  Fence(const Fence&) = delete;
+  Fence& operator=(const Fence&) = delete;
+  ~Fence()
+  {
+    if (f_) mlgpu_fence_destroy(f_);
+  }
+  void signalFrom(const Engine& e) { e.check(mlgpu_engine_signal(e.handle(), f_)); }  // everything e has enqueued so far
+  void awaitedBy(const Engine& e) { e.check(mlgpu_engine_wait(e.handle(), f_)); }     // e's later launches start after that (no-op before any signal)
 };
 
 // The GPUs of one node as one voice bank host: voices share nothing (every Bank row / Synth voice owns its

@@ -1,6 +1,7 @@
 // The same user code (dropin_patch.h) compiled against the MI355X shim: captured once, run for V voices.
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -495,8 +496,11 @@ static int synth_gpu_run_t(size_t nInstruments, const SynthGpuEvent* events, con
     SYNTH synth;
     gpu::VoiceProgramOptions opt;
     opt.eventRowsInKernel = eventRowsInKernel;
+    opt.eventsOnOwnStream = getenv("MLGPU_TEST_EVENTS_OWN_STREAM") != nullptr;  // the same run with EventsToSignals on a second engine
     gpu::SynthProgram prog(eng, synth, nInstruments, 2, 48000, opt);
     if (rowsInKernel) *rowsInKernel = prog.program().eventRowsInKernel() ? 1 : 0;
+    if (const char* want = getenv("MLGPU_TEST_EVENTS_OWN_STREAM"))  // "1": must have taken effect, "0": must have been declined
+      if ((want[0] == '1') != prog.eventsOnOwnStream()) throw std::logic_error("eventsOnOwnStream: not what this synth should get");
     prog.setPublishedInstrument(scopeInstrument);
     size_t scopePos = 0;
     eng.check(mlgpu_events_set_pitch_glide_seconds(prog.events(), glideSeconds));

@@ -179,13 +179,18 @@ class _Ev(ctypes.Structure):
 
 
 @pytest.mark.gpu
-def test_synth_subclass_events_to_audio_same_source_same_bits():
-    """tests/cpp/dropin_synth.h: a Synth subclass (processVoice reading the EventsToSignals voice rows). Reference side: its own
+@pytest.mark.parametrize("own_stream", [False, True])
+def test_synth_subclass_events_to_audio_same_source_same_bits(own_stream, monkeypatch):
+    """own_stream: VoiceProgramOptions::eventsOnOwnStream - EventsToSignals on a second engine, its kernel for block k + 1 beside the
+    voice kernel of block k, two sets of row signals, fences: the same bits.
+    tests/cpp/dropin_synth.h: a Synth subclass (processVoice reading the EventsToSignals voice rows). Reference side: its own
     Synth::processVector + AudioContext + EventsToSignals, one instrument at a time. GPU side: mlgpu_events -> the captured
     processVoice for all voices of 40 instruments -> mlgpu_mixdown_groups. MIDI events in, stereo audio out, bit for bit.
     Half way through the host changes the envelope times of every voice (SmallSynth::setEnvelope, as a parameter callback would);
     the GPU side calls SynthProgram::update() and the sounding notes continue with the new coefficients, like the reference's."""
     from test_gpu_events import performance
+    if own_stream:
+        monkeypatch.setenv("MLGPU_TEST_EVENTS_OWN_STREAM", "1")
     Lg, Lr = _gpu_lib(), _ref_lib()
     Lr.synth_ref_run.restype = ctypes.c_int
     c_szp = ctypes.POINTER(ctypes.c_size_t)
@@ -344,8 +349,8 @@ def test_every_stateful_object_by_name_same_source_same_bits(launches):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["controller", "tempo"])
-def test_synth_that_reads_context_signals_same_bits(which):
+@pytest.mark.parametrize("which,own_stream", [("controller", None), ("tempo", None), ("controller", "0"), ("tempo", "1")])
+def test_synth_that_reads_context_signals_same_bits(which, own_stream, monkeypatch):
     """tests/cpp/dropin_synth.h. TempoSynth::processVoice locks a tremolo LFO to ctx->getBeatPhase() with a TempoLock per voice,
     while the host (HostTransport, both sides) starts, changes tempo, stops and restarts elsewhere: the beat phase is one device
     signal per instrument (mlgpu_transport) behind SynthProgram::updateTime.
@@ -353,7 +358,10 @@ def test_synth_that_reads_context_signals_same_bits(which):
     MIDI controllers (brightness into a per-sample filter cutoff, mod wheel into the pitch, channel pressure into the level). The
     shim turns each into one device signal per instrument (mlgpu_events_watch_controllers) read by that instrument's voices
     (mlgpu_graph_set_input_group). Against the reference's own Synth / AudioContext / EventsToSignals, bit for bit, with the
-    voice rows read from memory and computed in the kernel."""
+    voice rows read from memory and computed in the kernel.
+    own_stream: the run asks for VoiceProgramOptions::eventsOnOwnStream. "1": it must take effect (TempoSynth reads the beat phase, which
+    the transport makes on the voice stream) - with the rows read from memory; "0": it must be declined (ControllerSynth's controller
+    signals are made by the events call into ONE buffer the voice kernel of the block before may still be reading)."""
     from test_gpu_events import performance
     Lg, Lr = _gpu_lib(), _ref_lib()
     ref_run, gpu_run = getattr(Lr, which + "_synth_ref_run"), getattr(Lg, which + "_synth_gpu_run")
@@ -375,6 +383,10 @@ def test_synth_that_reads_context_signals_same_bits(which):
     arr = (_Ev * len(flat))(*[_Ev(*e) for e, _ in flat])
     inst = (ctypes.c_int * len(flat))(*[k for _, k in flat])
     for in_kernel in (0, 1):
+        if own_stream is not None:
+            if in_kernel:
+                continue     # rows computed inside the voice kernel: there is no events kernel to move
+            monkeypatch.setenv("MLGPU_TEST_EVENTS_OWN_STREAM", own_stream)
         gotL, gotR = np.zeros((N, S), np.float32), np.zeros((N, S), np.float32)
         err = ctypes.create_string_buffer(4096)
         did = ctypes.c_int(-1)
