@@ -109,8 +109,204 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
   const unsigned mainLane = (unsigned)((threadIdx.x & 63) / (unsigned)a.group) * (unsigned)a.group;
   const bool wantTime = (a.rowMask & (1u << 7)) != 0;  // the elapsed-time row costs an f64 division per sample
 
+  // ---- blocks of vectors in which nothing happens ------------------------------------------------------------------------------
+  // The duration of a launch is the duration of its slowest wavefront, and memory operations of a wavefront complete in issue
+  // order: every load behind a store waits for that store's acknowledgement (several microseconds while the chip writes rows at
+  // its ceiling). The general vector loop below has a dozen such round trips per DSPVector - glide state, slots a quad at a
+  // time, records - and a wavefront that carried a note event used to run it for all its vectors, ~40 us each, long after the
+  // others were done (profiles/r03_e2s_latency.txt). So: kBlock vectors at a time, where no lane of the wavefront has a record, the
+  // bend and the wanted controllers are at rest, take this path - ONE round trip: the glide words and all 64 slots of the drift
+  // glide (8 s per glide: always moving) are fetched together, the block is computed in time order in registers (the pitch glide may
+  // be moving: it is stepped sample by sample as ever; what each vector does to the drift glide - hold / end / start / continue -
+  // depends on the drift counter alone), rows are written as they come, the slots go back once. Same operations on the same
+  // values as the general loop; the state variables are this kernel's own, so the two forms alternate freely.
+#ifndef MLGPU_E2S_BLOCK
+#define MLGPU_E2S_BLOCK 4
+#endif
+  constexpr int kBlock = MLGPU_E2S_BLOCK;
+  typedef float f32x4b __attribute__((ext_vector_type(4)));
   for (size_t t = 0; t < a.T; ++t)
   {
+    if (a.blockPath && !a.s.mpe && t + kBlock <= a.T)
+    {
+      const bool onB = awake && active;
+      bool ok = (cursor >= recEnd) || (a.recs[cursor].vec >= (uint32_t)(t + kBlock));
+      float heldBend = 0.f, heldMod = 0.f, heldX = 0.f, heldY = 0.f, heldZ = 0.f;
+      const float czEff = (velocity == 0.f) ? 0.f : cz;  // :238-241 with finalVelocity == velocity
+      if (ok && onB)
+      {
+        auto rests = [&](int gi, float value, float& held) {  // glide gi holds `value` with a broadcast mCurrVec: its vectors change nothing
+          Glide g;
+          g.load(GS(gi), ln);
+          held = g.uniformValue;
+          return g.remaining < 0 && g.isUniform() && g.target == value;
+        };
+        ok = !needsRecalc && rests(0, bend, heldBend);
+        if (a.rowMask & (1u << 6)) ok = ok && rests(1, mod, heldMod);
+        if (a.rowMask & (1u << 4)) ok = ok && rests(2, cx, heldX);
+        if (a.rowMask & (1u << 5)) ok = ok && rests(3, cy, heldY);
+        if (a.rowMask & (1u << 3))
+        {
+          float heldP = 0.f;
+          ok = ok && rests(4, czEff, heldZ) && rests(6, chanPress, heldP);
+          heldZ = heldZ + heldP;  // MIDI mode: z adds the smoothed channel pressure (:437-445)
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0)
+      {
+        uint32_t* gs = GS(5);
+        Glide gd;
+        gd.load(gs, ln);
+        const bool slotsLive = onB && !gd.isUniform();  // mCurrVec is in memory as the block starts
+        if (onB) cz = czEff;
+        auto rowOfOne = [&](int row, float value) {  // one value per lane for the whole block
+          const SignalView& sv = a.out[row];
+          if (!((a.rowMask >> row) & 1u) || !sv.base || !isVoice) return;
+          f32x4b* p = (f32x4b*)sv.base + t * sv.strideT + outVoice * sv.strideV;
+          const f32x4b v = {value, value, value, value};
+          for (int b = 0; b < kBlock; ++b, p += sv.strideT)
+          {
+            f32x4b* pq = p;
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q, pq += sv.strideQ) __builtin_nontemporal_store(v, pq);
+          }
+        };
+        rowOfOne(1, onB ? velocity : 0.f);
+        rowOfOne(2, (float)(slot - 1));
+        rowOfOne(3, onB ? heldZ : 0.f);
+        rowOfOne(4, onB ? heldX : 0.f);
+        rowOfOne(5, onB ? heldY : 0.f);
+        rowOfOne(6, onB ? heldMod : 0.f);
+        if (wantTime && a.out[7].base && isVoice)
+        {
+          const SignalView& sv = a.out[7];
+          f32x4b* p = (f32x4b*)sv.base + t * sv.strideT + outVoice * sv.strideV;
+          uint32_t ageNow = age;
+          for (int b = 0; b < kBlock; ++b, p += sv.strideT)
+          {
+            f32x4b* pq = p;
+            for (int q = 0; q < 16; ++q, pq += sv.strideQ)
+            {
+              f32x4b v;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = onB ? (float)((double)(ageNow + (uint32_t)(q * 4 + k + 1) * ageStep) / srD) : 0.f;
+              __builtin_nontemporal_store(v, pq);
+            }
+            ageNow += (uint32_t)MLGPU_FLOATS_PER_DSPVECTOR * ageStep;
+          }
+        }
+        if (onB) age += (uint32_t)(kBlock * MLGPU_FLOATS_PER_DSPVECTOR) * ageStep;
+        // ---- the pitch row ----
+        // What each of the block's vectors does to the drift glide, worked out first (it needs slot 63 only: what a starting
+        // glide reads). Then the 64 slots in two halves of 32: a half's slots are fetched together, stepped through the kBlock
+        // vectors in registers and written back. The pitch glide is a per-sample recurrence in time order: each half walks it
+        // through the whole block from the block's start state, using the samples of its own half (when it rests, as mostly,
+        // that is a constant).
+        const SignalView& sp = a.out[0];
+        const bool storePitch = sp.base && isVoice;
+        const float bendTerm = (heldBend * pitchBendScale) * (1.f / 12);  // :244
+        float eff63 = slotsLive ? u2f(gs[(size_t)(5 + 63) * ln]) : 0.f;
+        int cm[kBlock];
+        bool cu[kBlock];
+        float cstep[kBlock], cstart[kBlock], ctarget[kBlock], cuval[kBlock];
+        bool wrote = false;
+#pragma unroll
+        for (int b = 0; b < kBlock; ++b)
+        {
+          cm[b] = 0;
+          cu[b] = true;
+          cstep[b] = cstart[b] = ctarget[b] = cuval[b] = 0.f;
+          if (onB)
+          {
+            // the drift part of Voice::beginProcess (:115-126), then the drift glide's own start of a vector
+            driftCounter += MLGPU_FLOATS_PER_DSPVECTOR;
+            if (driftCounter >= driftNext)
+            {
+              driftSeed = driftSeed * 0x0019660Du + 0x3C6EF35Fu;
+              const float d = u2f(((driftSeed >> 9) & 0x007FFFFFu) | 0x3F800000u) * 2.f - 3.f;
+              driftSeed = driftSeed * 0x0019660Du + 0x3C6EF35Fu;
+              const float d2 = u2f(((driftSeed >> 9) & 0x007FFFFFu) | 0x3F800000u) * 2.f - 3.f;
+              const float nextTimeMul = 1.0f + abs_ps(d2);
+              driftValue = d;
+              driftCounter = 0;
+              driftNext = (int32_t)(a.s.sr * (double)nextTimeMul * (double)8.0f);
+            }
+            gd.beginVectorKnown(driftValue, a.s.driftGlideVectors, a.s.driftGlideDy, eff63);
+            cm[b] = gd.mode();
+            cu[b] = gd.isUniform();
+            cstep[b] = gd.step;
+            cstart[b] = gd.startValue;
+            ctarget[b] = gd.target;
+            cuval[b] = gd.uniformValue;
+            // slot 63 after this vector (n = 63: (float)(n + 1) * 0.015625f == 1)
+            if (cm[b] == 2) eff63 = cstart[b] + 1.0f * cstep[b];
+            else if (cm[b] == 3) eff63 = (cu[b] ? cuval[b] : eff63) + cstep[b];
+            wrote = wrote || (cm[b] >= 2);
+            gd.endVector();
+          }
+        }
+        const bool pgMoves = __builtin_amdgcn_ballot_w64(onB && !(pgRemaining < 0 && pgTarget == pitch)) != 0;  // any lane's pitch glide
+        const float pg0Curr = pgCurr, pg0Step = pgStep, pg0Target = pgTarget;  // the pitch glide as the block starts
+        const int32_t pg0Remaining = pgRemaining;
+        constexpr int kHalf = 32;
+#pragma unroll 1
+        for (int h = 0; h < 64; h += kHalf)
+        {
+          float c[kHalf];
+#pragma unroll
+          for (int i = 0; i < kHalf; ++i) c[i] = slotsLive ? u2f(gs[(size_t)(5 + h + i) * ln]) : 0.f;
+          pgCurr = pg0Curr;
+          pgStep = pg0Step;
+          pgTarget = pg0Target;
+          pgRemaining = pg0Remaining;
+          f32x4b* pb = (f32x4b*)sp.base + t * sp.strideT + outVoice * sp.strideV + (size_t)(h / 4) * sp.strideQ;
+#pragma unroll
+          for (int b = 0; b < kBlock; ++b, pb += sp.strideT)
+          {
+            if (onB && pgMoves)
+              for (int n = 0; n < h; ++n) (void)pitchGlideNext(pitch);  // the samples of this vector before this half
+            f32x4b* pq = pb;
+#pragma unroll
+            for (int q = 0; q < kHalf / 4; ++q, pq += sp.strideQ)
+            {
+              f32x4b o;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+              {
+                const int i = q * 4 + k, n = h + i;
+                float vPitch = 0.f;
+                if (onB)
+                {
+                  const int m = cm[b];
+                  float v;
+                  if (m == 0) v = cu[b] ? cuval[b] : c[i];
+                  else if (m == 1) v = ctarget[b];
+                  else
+                  {
+                    if (m == 2) v = cstart[b] + ((float)(n + 1) * 0.015625f) * cstep[b];
+                    else v = (cu[b] ? cuval[b] : c[i]) + cstep[b];
+                    c[i] = v;
+                  }
+                  vPitch = pitchGlideNext(pitch);
+                  vPitch = vPitch + bendTerm;
+                  vPitch = vPitch + (v * a.s.driftAmount) * 0.02f;           // kDriftScale, :247
+                }
+                o[k] = vPitch;
+              }
+              if (storePitch) __builtin_nontemporal_store(o, pq);
+            }
+            if (onB && pgMoves)
+              for (int n = h + kHalf; n < 64; ++n) (void)pitchGlideNext(pitch);  // ... and after it
+          }
+          if (wrote)
+#pragma unroll
+            for (int i = 0; i < kHalf; ++i) gs[(size_t)(5 + h + i) * ln] = f2u(c[i]);
+        }
+        if (onB) gd.store(gs, ln);
+        t += kBlock - 1;
+        continue;
+      }
+    }
     // records of this vector: [cursor, vend)
     uint32_t vend = cursor;
     while (vend < recEnd && a.recs[vend].vec == (uint32_t)t) ++vend;
@@ -1206,6 +1402,8 @@ extern "C"
     a.T = nVectors;
     a.rowMask = ev->rowMask;
     a.flags = e->kflags;
+    static const bool noBlocks = getenv("MLGPU_E2S_NO_BLOCKS") != nullptr;
+    a.blockPath = noBlocks ? 0 : 1;
     a.group = ev->group;
     a.slotBase = ev->slotBase;
     a.polyphony = ev->polyphony;

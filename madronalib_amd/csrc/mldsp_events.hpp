@@ -56,6 +56,7 @@ struct E2SArgs
   int group, polyphony, slotBase;  // lane = instrument * group + (voice slot - slotBase)
   uint32_t rowMask;                // rows that are computed (mlgpu_events_set_wanted_rows); bit r = row r of `out`
   uint32_t flags;                  // MLGPU_KFLAG_*
+  int blockPath;                   // 0: every vector on its own (MLGPU_E2S_NO_BLOCKS in the environment, for A / B measurements)
   E2SSettings s;
 };
 
@@ -85,6 +86,36 @@ struct Glide
     st[2 * stride] = (uint32_t)remaining;
     st[3 * stride] = isUniform() ? 1u : 0u;
     st[4 * stride] = f2u(uniformValue);
+  }
+  // beginVector for a caller that knows what mCurrVec[63] holds (it has the slots in registers): no memory access
+  MLD void beginVectorKnown(float f, int32_t perGlide, float dyPerVector, float slot63)
+  {
+    if (f != target)
+    {
+      target = f;
+      remaining = perGlide;
+    }
+    int m;
+    if (remaining < 0) m = 0;
+    else if (remaining == 0)
+    {
+      m = 1;
+      step = 0.f;
+      remaining--;
+    }
+    else if (remaining == perGlide)
+    {
+      m = 2;
+      startValue = isUniform() ? uniformValue : slot63;
+      step = (target - startValue) * dyPerVector;
+      remaining--;
+    }
+    else
+    {
+      m = 3;
+      remaining--;
+    }
+    modeFlags = (modeFlags & 4) | m;
   }
   MLD void beginVector(const uint32_t* st, size_t stride, float f, int32_t perGlide, float dyPerVector)
   {
