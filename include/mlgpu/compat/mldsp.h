@@ -1113,6 +1113,7 @@ struct ProcNode
     float* d{nullptr};  // device: nIn inputs, then the output, 64 floats each
     ~Immediate()
     {
+      std::lock_guard<std::recursive_mutex> lock(Eager::get().m);  // the immediate engine has one caller at a time
       if (g) mlgpu_graph_destroy(g);
       if (d) mlgpu_free(Eager::get().engine().handle(), d);
     }
@@ -1933,6 +1934,8 @@ class ImmediateResampler
   ~ImmediateResampler() { release(); }
   void release()
   {
+    if (!r_ && !d_) return;
+    std::lock_guard<std::recursive_mutex> lock(Eager::get().m);
     if (r_) mlgpu_resampler_destroy(r_);
     if (d_) mlgpu_free(Eager::get().engine().handle(), d_);
     r_ = nullptr;
