@@ -40,8 +40,14 @@ inline Rec makeRec(uint32_t vec, uint32_t type, int time, uint32_t flags, float 
 #ifndef MLGPU_E2S_WAVES
 #define MLGPU_E2S_WAVES 4
 #endif
-__global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs a)
+// ROWS01: only the pitch and gate rows are wanted (what a Synth's voices usually read): an instance of the kernel without the controller
+// rows, the voice-index row and the elapsed-time row. Those are half of the general loop's code and registers; without them the
+// instance keeps its state in registers instead of scratch, and its loop has fewer memory round trips per DSPVector.
+template <bool ROWS01>
+__global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs aIn)
 {
+  E2SArgs a = aIn;
+  if constexpr (ROWS01) a.rowMask &= 3u;
   apply_fp_mode(a.flags);
   // XCD-aware workgroup -> lane mapping (as the voice-bank kernels): every XCD writes one contiguous eighth of each row
   size_t blk = blockIdx.x;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
   const float pitchBendScale = (a.s.mpe && slot != 0) ? a.s.mpePitchBendRange : a.s.pitchBendRange;  // :417-423
   const double srD = (double)(float)a.s.sr;  // samplesToSeconds(uint32_t, float sr), :13-19
   const unsigned mainLane = (unsigned)((threadIdx.x & 63) / (unsigned)a.group) * (unsigned)a.group;
-  const bool wantTime = (a.rowMask & (1u << 7)) != 0;  // the elapsed-time row costs an f64 division per sample
+  const bool wantTime = !ROWS01 && (a.rowMask & (1u << 7)) != 0;  // the elapsed-time row costs an f64 division per sample
 
   // ---- blocks of vectors in which nothing happens ------------------------------------------------------------------------------
   // The duration of a launch is the duration of its slowest wavefront, and memory operations of a wavefront complete in issue
@@ -142,10 +148,10 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
           return g.remaining < 0 && g.isUniform() && g.target == value;
         };
         ok = !needsRecalc && rests(0, bend, heldBend);
-        if (a.rowMask & (1u << 6)) ok = ok && rests(1, mod, heldMod);
-        if (a.rowMask & (1u << 4)) ok = ok && rests(2, cx, heldX);
-        if (a.rowMask & (1u << 5)) ok = ok && rests(3, cy, heldY);
-        if (a.rowMask & (1u << 3))
+        if (!ROWS01 && (a.rowMask & (1u << 6))) ok = ok && rests(1, mod, heldMod);
+        if (!ROWS01 && (a.rowMask & (1u << 4))) ok = ok && rests(2, cx, heldX);
+        if (!ROWS01 && (a.rowMask & (1u << 5))) ok = ok && rests(3, cy, heldY);
+        if (!ROWS01 && (a.rowMask & (1u << 3)))
         {
           float heldP = 0.f;
           ok = ok && rests(4, czEff, heldZ) && rests(6, chanPress, heldP);
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
         if (onB) cz = czEff;
         auto rowOfOne = [&](int row, float value) {  // one value per lane for the whole block
           const SignalView& sv = a.out[row];
-          if (!((a.rowMask >> row) & 1u) || !sv.base || !isVoice) return;
+          if ((ROWS01 && row > 1) || !((a.rowMask >> row) & 1u) || !sv.base || !isVoice) return;
           f32x4b* p = (f32x4b*)sv.base + t * sv.strideT + outVoice * sv.strideV;
           const f32x4b v = {value, value, value, value};
           for (int b = 0; b < kBlock; ++b, p += sv.strideT)
@@ -411,10 +417,10 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
         gl.store(GS(glideIdx), ln);
       }
     };
-    if (a.rowMask & (1u << 6)) glideRow(1, 6, mod);
-    if (a.rowMask & (1u << 4)) glideRow(2, 4, cx);
-    if (a.rowMask & (1u << 5)) glideRow(3, 5, cy);
-    if (a.rowMask & (1u << 3))
+    if (!ROWS01 && (a.rowMask & (1u << 6))) glideRow(1, 6, mod);
+    if (!ROWS01 && (a.rowMask & (1u << 4))) glideRow(2, 4, cx);
+    if (!ROWS01 && (a.rowMask & (1u << 5))) glideRow(3, 5, cy);
+    if (!ROWS01 && (a.rowMask & (1u << 3)))
     {
       Glide gz, gp;
       gz.load(GS(4), ln);
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
         gp.store(GS(6), ln);
       }
     }
-    if (a.rowMask & (1u << 2))
+    if (!ROWS01 && (a.rowMask & (1u << 2)))
     {
       const float vox = (float)(slot - 1);  // row kVoice: DSPVector((float)i - 1), :302
       const f32x4 v = {vox, vox, vox, vox};
@@ -1408,7 +1414,10 @@ extern "C"
     a.slotBase = ev->slotBase;
     a.polyphony = ev->polyphony;
     a.s = dev.s;
-    hipLaunchKernelGGL(e2s_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
+    if ((a.rowMask & ~3u) == 0)
+      hipLaunchKernelGGL(e2s_kernel<true>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
+    else
+      hipLaunchKernelGGL(e2s_kernel<false>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process launch: ") + hipGetErrorString(err));
     return launched(ev, *sg);
