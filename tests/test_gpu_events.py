@@ -169,6 +169,26 @@ def test_events_to_signals_matches_reference(eng, name):
     assert np.abs(got[1]).max() > 0 and np.abs(got[0]).max() > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,rows", [("midi_poly4", None), ("midi_poly16", [0, 1]), ("unison3", None), ("sustain", [0, 1]), ("sr8k", None),
+                                       ("sr192k", [0, 1, 3]), ("mpe5", None), ("poly1", [0, 1])])
+def test_dense_performances_in_launches_of_eight_vectors(eng, name, rows):
+    """The scripted performances (an event every ~130 frames: notes, bends, controllers, pressure, sustain, all-notes-off) in launches of
+    8 DSPVectors: blocks of 4 vectors take e2s_kernel's block path whenever they happen to be quiet - between moving pitch glides,
+    gliding bends and controllers - and hand over to the general loop and back inside one launch; with only pitch and gate wanted the
+    two-row instance of the kernel runs. (MPE keeps the general loop throughout.) Against the reference's class, bit for bit."""
+    cfg = SCENARIOS[name]
+    block, n_blocks = 512, 12
+    kind = "mpe" if cfg.get("mpe") else ("sustain" if name == "sustain" else "midi")
+    instruments = [performance(kind, 7000 + 100 * k + len(name), block * n_blocks, cfg["polyphony"]) for k in range(4)]
+    got = gpu_run(eng, cfg, instruments, block, n_blocks, vectors_per_launch=8, rows=rows)
+    P = cfg["polyphony"]
+    for k, evs in enumerate(instruments):
+        want = ref_run(cfg, evs, block, n_blocks)
+        for r in (range(8) if rows is None else rows):
+            assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"{name}: instrument {k} row {ROW_NAMES[r]}")
+
+
 def sparse_performance(seed, frames, gap):
     """A few notes and bends with long silences between them: most launches see no event at all."""
     rng = np.random.default_rng(seed)
