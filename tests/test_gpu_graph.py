@@ -192,6 +192,48 @@ def test_synth16_full_size_subset(eng, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("full", [False, True])
+def test_config5_bench_step_subset(eng, oracle, full):
+    """BASELINE configs[4] exactly as bench.py --workload cfg5 / cfg5full runs it - 262 144 voices, the bench's own per-voice parameters,
+    coefficients, noise seeds and gate (madronalib_amd/sharding.py), one bench step = 16 launches of 16 DSPVectors with carried state -
+    against the oracle on 257 voices spread over the range: launches 0, 7 and 15, and every processor's final state."""
+    import madronalib_amd as ml
+    from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
+    V, T, L = 262144, 16, 16
+    desc, outs = patches.synth16(full=full)
+    g = ml.Graph(eng, V, desc, outs)
+    g.clear()
+    params, coeffs, seeds = cfg5_voice_params(0, V, V, ml, full=full)
+    for k, v in params.items():
+        g.set_param(k, v if np.ndim(v) else float(v))
+    for k, c in coeffs.items():
+        g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+    g.set_state("noise", 0, seeds)
+    gate_q = cfg5_gate_quad(0, V, T)                       # the same gate block every launch, as in the bench
+    d_gate = eng.to_device(gate_q)
+    d_out = eng.alloc(4 * V * T * 64)
+    sub = np.concatenate([np.arange(0, V, 1021), [V - 1]])[:257]
+    gate_sub = np.ascontiguousarray(gate_q[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64))
+    p_sub = {k: (v[sub] if np.ndim(v) else v) for k, v in params.items()}
+    c_sub = {k: np.ascontiguousarray(np.asarray(c)[:, sub]) for k, c in coeffs.items()}
+    states = {n["name"]: oracle.chain_clear([n["kind"]], sub.size) for n in desc if n["type"] == "proc"}
+    states["noise"][0] = seeds[sub]
+    for launch in range(L):
+        g.process(T, [d_gate], [d_out])
+        (want,) = evaluate(oracle, desc, outs, sub.size, T, {"gate": gate_sub}, p_sub, c_sub, states)
+        if launch in (0, 7, L - 1):
+            q = d_out.download(np.float32).reshape(T * 16, V, 4)
+            got = q[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64)
+            assert_bits_equal(got, want, True, f"config 5 (full={full}) launch {launch}")
+            assert np.abs(want).max() > 0.01
+    for n in desc:
+        if n["type"] == "proc":
+            for i in range(g.num_state(n["name"])):
+                assert (g.get_state(n["name"], i)[sub] == states[n["name"]][i]).all(), (n["name"], i)
+    g.close()
+
+
+@pytest.mark.gpu
 def test_graph_with_masks_and_two_outputs(eng, oracle):
     """compare -> mask -> select, a 3-input op, a const, two outputs, two inputs."""
     import madronalib_amd as ml
