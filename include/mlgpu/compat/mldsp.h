@@ -2270,13 +2270,285 @@ struct Event  // MLEvent.h:31-53; same layout as mlgpu_event
   explicit operator bool() const { return type != kNull; }
 };
 
+#ifndef MLGPU_COMPAT_HAS_MADRONALIB_APP_HEADERS
+// the little of ml::Symbol that EventsToSignals::setProtocol needs when madronalib's own app headers are not on the include path
+class Symbol
+{
+  std::string text_;
+
+ public:
+  Symbol() = default;
+  Symbol(const char* s) : text_(s ? s : "") {}
+  bool operator==(const Symbol& o) const { return text_ == o.text_; }
+  const std::string& text() const { return text_; }
+};
+#endif
+
+// EventsToSignals (source/app/MLEventsToSignals.h:44-181). Inside a capture only its Voice type matters (the rows a captured
+// processVoice reads are graph inputs fed by mlgpu_events for every instrument at once - gpu::SynthProgram). As an OBJECT - made,
+// configured, fed events and stepped a DSPVector at a time, the way the reference's AudioContext drives it - it works in immediate
+// mode: a one-instrument mlgpu_events on the immediate engine, its eight rows fetched after every processVector(). The smoothed
+// controllers (getController(n).output) come from helper objects, one per number asked for, each of which has been given the
+// object's whole history of calls when it was made - so a number that is first asked for late still has the signal the
+// reference's always-running smoother has.
 class EventsToSignals
 {
  public:
+  static constexpr size_t kMaxVoices{16};
+  static constexpr size_t kNumControllers{129};
+  static constexpr int kChannelPressureControllerIdx{128};
   struct Voice  // what a process function reads of EventsToSignals::Voice (MLEventsToSignals.h:102-168): its output rows
   {
     DSPVectorArray<kNumVoiceOutputRows> outputs;
   };
+  struct SmoothedController  // :170-180: what getController(n) hands out
+  {
+    DSPVector output;
+  };
+
+  EventsToSignals()
+  {
+    if (const char* s = std::getenv("MLGPU_E2S_HISTORY_OPS")) historyLimit_ = (size_t)std::strtoull(s, nullptr, 10);
+  }
+  EventsToSignals(const EventsToSignals&) = delete;
+  EventsToSignals& operator=(const EventsToSignals&) = delete;
+  ~EventsToSignals()
+  {
+    main_.release();
+    for (auto& h : helpers_) h.release();
+  }
+  void setSampleRate(double r) { apply(Op{kSampleRate, r}); }
+  // setPolyphony (:322-327) = clear() + the new voice count. An mlgpu_events has its polyphony from creation: before the first
+  // processVector the object is simply made for n voices; afterwards the same n is clear(), and another n is refused (the
+  // reference's voices keep their pitch glides and drift phases through that change, a new object would not).
+  size_t setPolyphony(size_t n)
+  {
+    n = n < 1 ? 1 : (n > kMaxVoices ? kMaxVoices : n);
+    if (main_.processed && n != polyphony_)
+      throw std::logic_error("mldsp GPU shim: EventsToSignals::setPolyphony to another voice count after processVector() is not supported "
+                             "in immediate mode - set the polyphony before processing");
+    polyphony_ = n;
+    apply(Op{kPolyphony, (double)n});
+    return polyphony_;
+  }
+  size_t getPolyphony() { return polyphony_; }
+  void clear() { apply(Op{kClear, 0.}); }
+  void addEvent(const Event& e)
+  {
+    Op o{kAddEvent, 0.};
+    o.e = e;
+    apply(o);
+  }
+  void clearEvents() { apply(Op{kClearEvents, 0.}); }
+  void setPitchBendInSemitones(float f) { apply(Op{kBend, (double)f}); }
+  void setMPEPitchBendInSemitones(float f) { apply(Op{kMpeBend, (double)f}); }
+  void setPitchGlideInSeconds(float f) { apply(Op{kGlide, (double)f}); }
+  void setDriftAmount(float f) { apply(Op{kDrift, (double)f}); }
+  void setUnison(bool b) { apply(Op{kUnison, b ? 1. : 0.}); }
+  void setProtocol(Symbol p) { apply(Op{kProtocol, (p == Symbol("MPE")) ? 1. : 0.}); }
+  void setModCC(int c) { apply(Op{kModCC, (double)c}); }
+  // the events of [startOffset, startOffset + 64) of the current host block -> this DSPVector of every voice's rows
+  void processVector(int startOffset)
+  {
+    apply(Op{kProcess, (double)startOffset});
+    fetchRows();
+    if (controllersRunning_)
+      for (size_t n = 0; n < kNumControllers; ++n)
+        if (asked_[n]) fetchController(n);
+  }
+  const Voice& getVoice(int n) const { return voices_[(size_t)n]; }
+  int getNewestVoice()
+  {
+    main_.make(polyphony_, -1);
+    return mlgpu_events_newest_voice(main_.ev, 0);
+  }
+  // The reference keeps all 129 controller glides running from the first event on. Here the smoothed controllers are made by
+  // helper objects (mlgpu_events with no voice rows, 32 watched controller numbers each) that start when a controller is first
+  // asked for: they are then given everything this object has been told and has processed so far, so the signal is the
+  // reference's from that vector on, whenever it is first read. An object that never asks keeps that history only up to
+  // kHistoryOps operations (about a minute and a half of DSPVectors; MLGPU_E2S_HISTORY_OPS in the environment sets another bound); then
+  // the helpers are started anyway and the history dropped.
+  // clear() before the first processVector is the reference's; later it is mlgpu_events_clear: a complete reset of the voices, where
+  // the reference's keep the running phase of their pitch glides and drift.
+  const SmoothedController& getController(size_t n)
+  {
+    if (n >= kNumControllers) n = kNumControllers - 1;
+    if (!controllersRunning_) startControllers();
+    if (!asked_[n])
+    {
+      asked_[n] = true;
+      fetchController(n);
+    }
+    return controllers_[n];
+  }
+  static constexpr size_t kHistoryOps{1u << 16};
+
+ private:
+  enum OpKind { kSampleRate, kPolyphony, kClear, kAddEvent, kClearEvents, kBend, kMpeBend, kGlide, kDrift, kUnison, kProtocol, kModCC, kProcess };
+  static constexpr int kWatchedPerHelper{MLGPU_EVENTS_MAX_WATCHED_CONTROLLERS};
+  static constexpr size_t kHelpers{(kNumControllers + kWatchedPerHelper - 1) / kWatchedPerHelper};
+  struct Op
+  {
+    int kind;
+    double x;
+    Event e{};
+  };
+  // one mlgpu_events of one instrument: the object itself (all eight rows, no controllers) or a controller helper (no rows, the
+  // controller numbers [first, first + 32))
+  struct Impl
+  {
+    mlgpu_events* ev{nullptr};
+    float* d{nullptr};  // device: the rows of one DSPVector
+    size_t polyphony{0};
+    bool processed{false};
+    void release()
+    {
+      if (!ev && !d) return;
+      std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+      if (ev) mlgpu_events_destroy(ev);
+      if (d) mlgpu_free(gpu::Eager::get().engine().handle(), d);
+      ev = nullptr;
+      d = nullptr;
+    }
+    // returns whether a new object was made
+    bool make(size_t P, int firstController)
+    {
+      if (ev && (polyphony == P || firstController >= 0)) return false;  // controllers do not depend on the voice count
+      release();
+      const gpu::Engine& e = gpu::Eager::get().engine();
+      e.check(mlgpu_events_create(e.handle(), 1, (int)P, &ev));
+      polyphony = P;
+      if (firstController >= 0)
+      {
+        int numbers[kWatchedPerHelper];
+        int n = 0;
+        for (; n < kWatchedPerHelper && firstController + n < (int)kNumControllers; ++n) numbers[n] = firstController + n;
+        e.check(mlgpu_events_set_wanted_rows(ev, 0));
+        e.check(mlgpu_events_watch_controllers(ev, numbers, n, 1));
+      }
+      else
+      {
+        void* p = nullptr;
+        e.check(mlgpu_alloc(e.handle(), (size_t)kNumVoiceOutputRows * P * 64 * sizeof(float), &p));
+        d = static_cast<float*>(p);
+      }
+      return true;
+    }
+    // firstController < 0: the object itself. `settings`: the last value of every setter, for an object made afresh (a change of
+    // polyphony during set-up); `awake`: an event has been added before (awake_, :374 - it survives clear())
+    void run(const Op& o, int firstController, const std::array<std::pair<bool, double>, kProcess>& settings, bool awake)
+    {
+      if (gpu::Capture::current())
+        throw std::logic_error("mldsp GPU shim: an EventsToSignals object is stepped outside a captured process function (immediate mode); "
+                               "inside one, gpu::SynthProgram feeds the voice rows");
+      std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+      const gpu::Engine& e = gpu::Eager::get().engine();
+      const bool helper = firstController >= 0;
+      const size_t wantP = o.kind == kPolyphony ? (size_t)o.x : (polyphony ? polyphony : 1);
+      if (make(wantP, firstController))
+      {
+        for (int k = 0; k < (int)kProcess; ++k)
+          if (settings[(size_t)k].first && (k == kSampleRate || (k >= kBend && k <= kModCC))) set(e, k, settings[(size_t)k].second);
+        if (awake)
+        {
+          const mlgpu_event none{0, 0, 0, 0, 0.f, 0.f};  // addEvent wakes the object (:374), clearEvents takes the event away again
+          e.check(mlgpu_events_add_event(ev, 0, &none));
+          e.check(mlgpu_events_clear_events(ev));
+        }
+      }
+      switch (o.kind)
+      {
+        case kPolyphony:  // clear(), :324
+        case kClear:      // :331-341: the event buffer and the voices, not the controller smoothers
+          e.check(helper ? mlgpu_events_clear_events(ev) : mlgpu_events_clear(ev));
+          break;
+        case kAddEvent:
+        {
+          const mlgpu_event m{o.e.type, o.e.channel, o.e.sourceIdx, o.e.time, o.e.value1, o.e.value2};
+          e.check(mlgpu_events_add_event(ev, 0, &m));
+          break;
+        }
+        case kClearEvents: e.check(mlgpu_events_clear_events(ev)); break;
+        case kProcess:
+        {
+          float* rows[kNumVoiceOutputRows];
+          for (int r = 0; r < kNumVoiceOutputRows; ++r) rows[r] = helper ? nullptr : d + (size_t)r * polyphony * 64;
+          e.check(mlgpu_events_process(ev, 1, (int)o.x, rows, MLGPU_LAYOUT_VOICE_MAJOR));
+          processed = true;
+          break;
+        }
+        default: set(e, o.kind, o.x); break;
+      }
+    }
+    void set(const gpu::Engine& e, int kind, double x)
+    {
+      switch (kind)
+      {
+        case kSampleRate: e.check(mlgpu_events_set_sample_rate(ev, x)); break;
+        case kBend: e.check(mlgpu_events_set_pitch_bend_semitones(ev, (float)x)); break;
+        case kMpeBend: e.check(mlgpu_events_set_mpe_pitch_bend_semitones(ev, (float)x)); break;
+        case kGlide: e.check(mlgpu_events_set_pitch_glide_seconds(ev, (float)x)); break;
+        case kDrift: e.check(mlgpu_events_set_drift_amount(ev, (float)x)); break;
+        case kUnison: e.check(mlgpu_events_set_unison(ev, x != 0.)); break;
+        case kProtocol: e.check(mlgpu_events_set_protocol(ev, x != 0.)); break;
+        case kModCC: e.check(mlgpu_events_set_mod_cc(ev, (int)x)); break;
+        default: break;
+      }
+    }
+  };
+  void apply(const Op& o)
+  {
+    main_.run(o, -1, settings_, awake_);
+    if (controllersRunning_)
+      for (size_t k = 0; k < kHelpers; ++k) helpers_[k].run(o, (int)k * kWatchedPerHelper, settings_, awake_);
+    else
+    {
+      history_.push_back(o);
+      if (history_.size() >= historyLimit_) startControllers();
+    }
+    if (o.kind < (int)kProcess) settings_[(size_t)o.kind] = {true, o.x};
+    if (o.kind == kAddEvent) awake_ = true;
+  }
+  void startControllers()
+  {
+    static const std::array<std::pair<bool, double>, kProcess> none{};
+    for (size_t k = 0; k < kHelpers; ++k)
+      for (const Op& o : history_) helpers_[k].run(o, (int)k * kWatchedPerHelper, none, false);
+    history_.clear();
+    history_.shrink_to_fit();
+    controllersRunning_ = true;
+  }
+  void fetchRows()
+  {
+    std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+    const gpu::Engine& e = gpu::Eager::get().engine();
+    const size_t P = main_.polyphony;
+    std::vector<float> h((size_t)kNumVoiceOutputRows * P * 64);
+    e.check(mlgpu_download(e.handle(), h.data(), main_.d, h.size() * sizeof(float)));
+    for (size_t v = 0; v < P; ++v)
+      for (int r = 0; r < kNumVoiceOutputRows; ++r)
+        voices_[v].outputs.row(r) = DSPVector(static_cast<const float*>(h.data() + ((size_t)r * P + v) * 64));
+  }
+  void fetchController(size_t n)
+  {
+    Impl& h = helpers_[n / kWatchedPerHelper];
+    if (!h.ev || !h.processed) return;  // nothing processed yet: the controller rests at zero
+    std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+    const gpu::Engine& e = gpu::Eager::get().engine();
+    float host[64];  // one instrument: QUAD is the samples in order
+    e.check(mlgpu_download(e.handle(), host, mlgpu_events_controller_signal(h.ev, (int)(n % kWatchedPerHelper)), sizeof(host)));
+    controllers_[n].output = DSPVector(static_cast<const float*>(host));
+  }
+
+  size_t polyphony_{1}, historyLimit_{kHistoryOps};
+  bool awake_{false}, controllersRunning_{false};
+  std::array<std::pair<bool, double>, kProcess> settings_{};
+  std::vector<Op> history_;
+  Impl main_;
+  std::array<Impl, kHelpers> helpers_;
+  std::array<bool, kNumControllers> asked_{};
+  std::array<Voice, kMaxVoices> voices_;
+  std::array<SmoothedController, kNumControllers> controllers_;
 };
 
 class AudioContext

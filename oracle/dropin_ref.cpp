@@ -350,6 +350,7 @@ extern "C" int plugin_ref_run(const SynthRefEvent* events, int nEvents, float gl
   return 0;
 }
 
+#endif  // MLGPU_IMMEDIATE_BUILD
 // ---- the reference's EventsToSignals driven like AudioContext / SignalProcessBuffer drive it -------------------------
 // events: absolute onset times in frames; the harness cuts time into host blocks of blockFrames (a multiple of 64), adds the
 // events of a block with block-relative times, calls processVector(offset) per 64 frames and clearEvents() per block.
@@ -362,10 +363,25 @@ struct RefEvent
   float value1, value2;
 };
 static int e2sRefRun(int polyphony, int mpe, int unison, double sr, float glideSeconds, float drift, float bendRange, float mpeBendRange, int modCC,
-                     const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out, const int* ctlNumbers, int nCtl, float* ctlOut)
+                     const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out, const int* ctlNumbers, int nCtl, float* ctlOut,
+                     int ctlFromVector = 0)
 {
   EventsToSignals e2s;
   e2s.setSampleRate(sr);
+  if (ctlFromVector < 0)  // a host that settles on its voice count in two steps, with an event in between (setPolyphony = clear(), :322-327)
+  {
+    ctlFromVector = -ctlFromVector;
+    e2s.setPolyphony(polyphony == 16 ? 8 : polyphony + 1);
+    e2s.setPitchBendInSemitones(3.f);
+    Event ev;
+    ev.type = kNoteOn;
+    ev.channel = 1;
+    ev.sourceIdx = 60;
+    ev.time = 0;
+    ev.value1 = 60.f;
+    ev.value2 = 0.8f;
+    e2s.addEvent(ev);
+  }
   e2s.setPolyphony(polyphony);
   e2s.setProtocol(mpe ? Symbol("MPE") : Symbol("MIDI"));
   e2s.setUnison(unison != 0);
@@ -397,7 +413,9 @@ static int e2sRefRun(int polyphony, int mpe, int unison, double sr, float glideS
         for (int r = 0; r < kNumVoiceOutputRows; ++r)
           store(e2s.getVoice(v).outputs.constRow(r), out + ((size_t)r * polyphony + v) * S + start + off);
       // what AudioContext::getInputController(n) hands a process function (MLAudioContext.cpp:129)
-      for (int c = 0; c < nCtl; ++c) store(e2s.getController((size_t)ctlNumbers[c]).output, ctlOut + (size_t)c * S + start + off);
+      // (ctlFromVector > 0: a process function that starts to look at its controllers late - the signals before stay zero here)
+      if ((start + off) / (int)kFloatsPerDSPVector >= ctlFromVector)
+        for (int c = 0; c < nCtl; ++c) store(e2s.getController((size_t)ctlNumbers[c]).output, ctlOut + (size_t)c * S + start + off);
     }
     e2s.clearEvents();
   }
@@ -416,7 +434,15 @@ extern "C" int e2s_ref_run_controllers(int polyphony, int mpe, int unison, doubl
   return e2sRefRun(polyphony, mpe, unison, sr, glideSeconds, drift, bendRange, mpeBendRange, modCC, events, nEvents, blockFrames, nBlocks, out, ctlNumbers, nCtl,
                    ctlOut);
 }
+extern "C" int e2s_ref_run_controllers_from(int polyphony, int mpe, int unison, double sr, float glideSeconds, float drift, float bendRange, float mpeBendRange,
+                                            int modCC, const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out, const int* ctlNumbers,
+                                            int nCtl, float* ctlOut, int ctlFromVector)
+{
+  return e2sRefRun(polyphony, mpe, unison, sr, glideSeconds, drift, bendRange, mpeBendRange, modCC, events, nEvents, blockFrames, nBlocks, out, ctlNumbers, nCtl,
+                   ctlOut, ctlFromVector);
+}
 
+#ifndef MLGPU_IMMEDIATE_BUILD
 // ---- controllers-to-audio (tests/cpp/dropin_controllers.h): one AudioContext with its controller events ----
 #include "../tests/cpp/dropin_controllers.h"
 extern "C" int ctl_audio_ref_run(const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out)

@@ -219,3 +219,81 @@ def test_feedback_composites_captured_and_immediate_agree():
     for k in range(4):
         assert np.abs(cap[k][64 * 6:]).max() > 1e-4, k          # the loops ring on after the burst
         assert (cap[k].view(np.uint32) == imm[k].view(np.uint32)).all(), f"output {k}: captured and immediate differ"
+
+
+@pytest.mark.parametrize("name", ["midi_poly4", "midi_steal2", "unison3", "sustain", "mpe5", "sr44k", "poly1"])
+def test_events_to_signals_object_stepped_imperatively(name):
+    """ml::EventsToSignals as an OBJECT - configured, fed events, processVector() per DSPVector, getVoice(v).outputs and
+    getController(n).output read after every step: oracle/dropin_ref.cpp's driver for the reference's class, compiled against the shim.
+    There it is a one-instrument mlgpu_events per object (and one helper per controller number asked for, given the object's whole
+    history when it is first asked - here at the first vector, in the test below late). All eight rows and five controller signals, the
+    scripted performances of tests/test_gpu_events.py, bit for bit."""
+    from test_gpu_events import SCENARIOS, RefEvent, performance
+    cfg = SCENARIOS[name]
+    Li, Lr = _imm_lib(), _ref_lib()
+    block, n_blocks = 512, 8
+    P = cfg["polyphony"]
+    kind = "mpe" if cfg.get("mpe") else ("sustain" if name == "sustain" else "midi")
+    evs = performance(kind, 4242 + len(name), block * n_blocks, P)
+    arr = (RefEvent * max(1, len(evs)))(*[RefEvent(*e) for e in evs])
+    numbers = [16, 73, 74, 1, 128]
+    nums = (ctypes.c_int * len(numbers))(*numbers)
+    out = {}
+    for tag, L in (("reference", Lr), ("immediate", Li)):
+        f = L.e2s_ref_run_controllers
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                      ctypes.c_int, ctypes.POINTER(RefEvent), ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.POINTER(ctypes.c_int),
+                      ctypes.c_int, c_f32p]
+        rows = np.zeros((8, P, block * n_blocks), np.float32)
+        ctl = np.zeros((len(numbers), block * n_blocks), np.float32)
+        assert f(P, int(cfg.get("mpe", 0)), int(cfg.get("unison", 0)), cfg.get("sr", 48000.0), cfg.get("glide", 0.0), cfg.get("drift", 0.0),
+                 cfg.get("bend", 7.0), cfg.get("mpe_bend", 24.0), cfg.get("mod_cc", 16), arr, len(evs), block, n_blocks, _p(rows), nums,
+                 len(numbers), _p(ctl)) == 0
+        out[tag] = (rows, ctl)
+    from inputs import assert_bits_equal
+    from test_gpu_events import ROW_NAMES
+    for r in range(8):
+        assert_bits_equal(out["immediate"][0][r], out["reference"][0][r], True, f"{name}: row {ROW_NAMES[r]}")
+    for c, n in enumerate(numbers):
+        assert_bits_equal(out["immediate"][1][c], out["reference"][1][c], True, f"{name}: controller {n}")
+    assert np.abs(out["reference"][0][1]).max() > 0 and np.abs(out["reference"][1]).max() > 0
+
+
+@pytest.mark.parametrize("name,from_vector,history_ops", [("midi_poly4", 17, None), ("mpe5", 40, None), ("midi_poly4", 40, 50),
+                                                          ("sr44k", -25, None), ("midi_steal2", -9, 20), ("unison3", -1, 1)])
+def test_events_to_signals_object_controllers_first_read_late(name, from_vector, history_ops, monkeypatch):
+    """A process function that looks at getController(n) for the first time in the middle of a performance: the reference keeps all 129
+    controller glides running from the start; the immediate object makes the signal of a controller number when it is first asked for
+    and gives that helper everything the object has been told and has processed so far - the signal from there on is the reference's.
+    history_ops: the bound on that history (MLGPU_E2S_HISTORY_OPS; when it is reached the controller helpers start by themselves and the
+    history is dropped). from_vector < 0: the host settles on its polyphony in two steps with an event in between (setPolyphony = clear()
+    at set-up time), and reads the controllers from vector -from_vector."""
+    if history_ops is not None:
+        monkeypatch.setenv("MLGPU_E2S_HISTORY_OPS", str(history_ops))
+    from test_gpu_events import SCENARIOS, RefEvent, performance
+    from inputs import assert_bits_equal
+    cfg = SCENARIOS[name]
+    block, n_blocks = 512, 8
+    P = cfg["polyphony"]
+    evs = performance("mpe" if cfg.get("mpe") else "midi", 977 + abs(from_vector), block * n_blocks, P)
+    arr = (RefEvent * max(1, len(evs)))(*[RefEvent(*e) for e in evs])
+    numbers = [74, 1, 16, 128, 11]
+    nums = (ctypes.c_int * len(numbers))(*numbers)
+    out = {}
+    for tag, L in (("reference", _ref_lib()), ("immediate", _imm_lib())):
+        f = L.e2s_ref_run_controllers_from
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                      ctypes.c_int, ctypes.POINTER(RefEvent), ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.POINTER(ctypes.c_int),
+                      ctypes.c_int, c_f32p, ctypes.c_int]
+        rows = np.zeros((8, P, block * n_blocks), np.float32)
+        ctl = np.zeros((len(numbers), block * n_blocks), np.float32)
+        assert f(P, int(cfg.get("mpe", 0)), int(cfg.get("unison", 0)), cfg.get("sr", 48000.0), cfg.get("glide", 0.0), cfg.get("drift", 0.0),
+                 cfg.get("bend", 7.0), cfg.get("mpe_bend", 24.0), cfg.get("mod_cc", 16), arr, len(evs), block, n_blocks, _p(rows), nums,
+                 len(numbers), _p(ctl), from_vector) == 0
+        out[tag] = (rows, ctl)
+    assert_bits_equal(out["immediate"][0], out["reference"][0], True, f"{name}: voice rows")
+    assert_bits_equal(out["immediate"][1], out["reference"][1], True, f"{name}: controllers from vector {from_vector}")
+    first = abs(from_vector)
+    assert np.abs(out["reference"][1][:, first * 64:]).max() > 0 and not out["reference"][1][:, :first * 64].any()

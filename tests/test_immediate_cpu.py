@@ -33,3 +33,26 @@ def test_forwarding_headers_cover_the_dsp_headers_user_code_includes():
               "MLDSPMath.h"):
         assert h in have
         assert '#include "../mldsp.h"' in open(os.path.join(ROOT, "include", "mlgpu", "compat", "dsp", h)).read()
+
+
+def test_events_to_signals_object_needs_the_device_too():
+    """oracle/dropin_ref.cpp's EventsToSignals driver compiled against the shim (tests/cpp/libdropin_imm.so): the symbols are there, and
+    without a device stepping the object ends in the engine's error (a C++ exception out of an extern "C" call: the process dies) - no
+    CPU restatement behind the class."""
+    import sys
+    import madronalib_amd as ml
+    lib = os.path.join(ROOT, "tests", "cpp", "libdropin_imm.so")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    for name in ("e2s_ref_run", "e2s_ref_run_controllers", "e2s_ref_run_controllers_from", "immediate_ref_run"):
+        assert f" T {name}\n" in syms
+    if ml.device_count() > 0:
+        pytest.skip("a GPU is visible here (tests/test_gpu_immediate.py steps the object on it)")
+    code = ("import ctypes, numpy as np\n"
+            f"L = ctypes.CDLL({lib!r})\n"
+            "out = np.zeros((8, 2, 64), np.float32)\n"
+            "L.e2s_ref_run.argtypes = [ctypes.c_int] * 3 + [ctypes.c_double] + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]\n"
+            "print('rc', L.e2s_ref_run(2, 0, 0, 48000.0, 0.0, 0.0, 7.0, 24.0, 16, None, 0, 64, 1, out.ctypes.data))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "rc 0" not in r.stdout
+    assert "no gfx950 (MI355X) HIP device" in r.stderr
