@@ -483,6 +483,7 @@ struct mlgpu_graph
   int voicesPerLane{0};          // 0 = choose at compile (graphVoicesPerLane); 1 or 2 = forced
   int compiledVoicesPerLane{1};
   int unrollQ{1};                // quads per trip of the sample loop
+  int oscTripQ{2};               // quads per trip of the oscillators' sparse polyBLEP (0: per sample; mldsp_procs.hpp: trip_u)
   std::string lastError;         // mlgpu_graph_last_error
   mlgpu_events* events{nullptr}; // mlgpu_graph_bind_events: the object the NODE_EVENT_ROW nodes read
   bool hasEventRows{false};
@@ -557,6 +558,22 @@ bool clampHasConstBounds(const mlgpu_graph* g, const Node& n)
   return false;
 }
 
+// A SawGen / PulseGen of the outer graph whose frequency (and width) are per voice, not per sample: its samples are made a trip of
+// oscTripQ quads at a time (Proc<>::trip_u: the polyBLEP corrections once per zone per trip) into registers the sample loop reads.
+static bool isOscTrip(const mlgpu_graph* g, const Node& n)
+{
+  if (g->oscTripQ <= 0 || n.type != NODE_PROC || n.region >= 0 || n.rate != RATE_AUDIO) return false;
+  if (n.kind != MLGPU_PROC_SAW_GEN && n.kind != MLGPU_PROC_PULSE_GEN) return false;
+  if (n.in.empty() || g->nodes[n.in[0]].rate != RATE_VOICE) return false;
+  return n.kind == MLGPU_PROC_SAW_GEN || n.in.size() == 1 || g->nodes[n.in[1]].rate == RATE_VOICE;
+}
+static bool hasOscTrips(const mlgpu_graph* g)
+{
+  for (const Node& n : g->nodes)
+    if (isOscTrip(g, n)) return true;
+  return false;
+}
+
 std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& ph = "", const std::string& idx = "q * 4 + k")
 {
   const Node& n = g->nodes[i];
@@ -581,6 +598,8 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
         s << "p" << i << L << ".next_n(" << idx << ")";
       else if (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY)
         s << "p" << i << L << ".next_i(" << idx << ", " << arg(0) << ", " << arg(1) << ")";
+      else if (isOscTrip(g, n))
+        s << "osc" << i << L << "[qq * 4 + k]";  // made for the whole trip before the sample loop
       else if ((n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
       {
         // launch-constant frequency: the polyBLEP range test was done once per wavefront (odd<i>)
@@ -749,6 +768,12 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
           else s << " || pulse_width_is_odd(n" << n.in[1] << sfx(l) << ")";
         }
       s << ") != 0;\n";
+      if (isOscTrip(g, n))
+      {
+        s << "  const bool dense" << i << " = odd" << i << " || __builtin_amdgcn_ballot_w64(";
+        for (int l = 0; l < VL; ++l) s << (l ? " || " : "") << "trip_freq_is_dense(n" << n.in[0] << sfx(l) << ", " << g->oscTripQ * 4 << ")";
+        s << ") != 0;\n";
+      }
     }
     else if (n.type == NODE_PROC && n.kind == MLGPU_PROC_PULSE_GEN && (n.in.size() == 1 || g->nodes[n.in[1]].rate == RATE_VOICE))
     {
@@ -804,7 +829,27 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     else if (n.type == NODE_PROC && mlgpu_proc_is_vector_rate(n.kind))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".begin_vector(n" << n.in[0] << sfx(l) << ");\n";
   }
-  s << "#pragma unroll " << ((g->windowedRings && g->totalRings) ? 1 : g->unrollQ) << "\n    for (int q = 0; q < 16; ++q)\n    {\n";
+  const bool oscTrips = hasOscTrips(g);
+  if (oscTrips)
+  {
+    // the quads in trips of oscTripQ: the oscillators' samples of a trip first, then its quads (fully unrolled: qq is a constant)
+    const int tq = g->oscTripQ, unroll = (g->windowedRings && g->totalRings) ? 1 : std::max(1, g->unrollQ / tq);
+    s << "#pragma unroll " << unroll << "\n    for (int q2 = 0; q2 < 16; q2 += " << tq << ")\n    {\n";
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+    {
+      const Node& n = g->nodes[i];
+      if (!isOscTrip(g, n)) continue;
+      for (int l = 0; l < VL; ++l)
+      {
+        s << "    float osc" << i << sfx(l) << "[" << tq * 4 << "];\n    p" << i << sfx(l) << ".trip_u<" << tq * 4 << ">(n" << n.in[0] << sfx(l);
+        if (n.in.size() == 2) s << ", n" << n.in[1] << sfx(l);
+        s << ", odd" << i << ", dense" << i << ", osc" << i << sfx(l) << ");\n";
+      }
+    }
+    s << "#pragma unroll\n    for (int qq = 0; qq < " << tq << "; ++qq)\n    {\n      const int q = q2 + qq;\n";
+  }
+  else
+    s << "#pragma unroll " << ((g->windowedRings && g->totalRings) ? 1 : g->unrollQ) << "\n    for (int q = 0; q < 16; ++q)\n    {\n";
   for (int i = 0; i < g->nInputs; ++i)
     for (int l = 0; l < VL; ++l)
       s << "      const f32x4 xin" << i << sfx(l) << " = __builtin_nontemporal_load(in" << i << sfx(l) << " + t * a.in[" << i << "].strideT + q * a.in["
@@ -966,6 +1011,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << "      " << (g->outputGroup[o] ? "if ((threadIdx.x & " + std::to_string(g->outputGroup[o] - 1) + ") == " + std::to_string(g->outputGroup[o] - 1) + ") " : std::string())
         << "__builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o << "].strideQ);\n";
   s << "    }\n";
+  if (oscTrips) s << "    }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC && (g->nodes[i].region < 0 || g->nodes[i].role != ROLE_NONE))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".end_vector();\n";
@@ -1653,6 +1699,11 @@ extern "C"
     const char* forced = getenv("MLGPU_GRAPH_UNROLL");  // developer knob: quads per trip of the sample loop
     // delay graphs wait on their ring reads: two quads per trip keep more of them in flight (allpass4: 5.4 vs 4.5 x 10^10)
     g->unrollQ = forced ? std::max(1, atoi(forced)) : ((g->totalRings && !g->windowedRings) ? 2 : 1);
+    if (const char* trip = getenv("MLGPU_GRAPH_OSC_TRIP"))  // developer knob: 0 = polyBLEP per sample (A / B), else 1, 2 or 4 quads per trip
+    {
+      const int t = atoi(trip);
+      g->oscTripQ = (t == 1 || t == 2 || t == 4) ? t : 0;
+    }
     if (!generateBudgeted(g, 0, g->source, g->emitted, g->log)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
     return MLGPU_OK;
   }

@@ -214,6 +214,23 @@ MLD float phasor_to_pulse(float p, float cps, float w)
   return (pulse + (nearUp ? cUp : 0.f)) - (nearDown ? cDown : 0.f);
 }
 
+// ---- the corrections of a whole trip of N samples at once ("sparse polyBLEP") ------------------------------------------------
+// With a launch-constant frequency 0 < dt <= 1 / (2 N) an oscillator wraps at most once in N consecutive samples, so at most one
+// sample of the trip lies in the zone after a step (t < dt) and at most one in the zone before it (t > 1 - dt) - and they are the
+// samples with the smallest / the largest phase of the trip. The division and the polynomial are then evaluated once per zone per
+// trip (for the extremes) instead of once per sample, and each sample takes what its own zone tests select: the same operands
+// through the same operations as the per-sample form, so the same bits. "At most one" can fail only next to a rounding knife edge,
+// where a phase comes out within a few 2^-24 of 0 or 1 (the computed phase differs from the exact one, which does advance by
+// the same step every sample, by at most 2^-25 for a PhasorGen's output and 2^-23 for PulseGen's shifted phase): a trip whose
+// extremes come that close - about one in a thousand - is evaluated per sample instead (wave-uniform). DESIGN.md 3.4.
+constexpr float kTripMaxFreq(int n) { return 0.5f / (float)n; }
+constexpr float kTripTiny = 0x1p-22f, kTripNearOne = 1.0f - 0x1p-22f;          // a PhasorGen's phase
+constexpr float kTripTinyShifted = 0x1p-21f, kTripNearOneShifted = 1.0f - 0x1p-21f;  // fractionalPart(p - w + 1)
+MLD bool trip_freq_is_dense(float dt, int n) { return !(dt > 0.f && dt <= kTripMaxFreq(n)); }
+// phases are >= 0: their order as unsigned bit patterns is their order as floats (and an integer min needs no canonicalising)
+MLD uint32_t trip_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+MLD uint32_t trip_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
 MLD float phasor_to_sine(float p)  // MLDSPGens.h:316-338
 {
   const float sqrt2 = u2f(kSqrt2Bits);
@@ -284,6 +301,40 @@ struct Proc<MLGPU_PROC_SAW_GEN>  // MLDSPGens.h:395-402, phasorToSaw :362-369
   // launch-constant cps whose range test `odd` (wave-uniform) was done once by the caller
   MLD float next_u(float cps, bool odd) { return odd ? step<false>(cps) : step<true>(cps); }
   static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
+  // N samples at once for a launch-constant cps (graph kernels). `dense` (wave-uniform, tested once by the caller): some lane is
+  // `odd` or its frequency is outside (0, 1 / 2N]: the trip is N per-sample evaluations.
+  template <int N>
+  MLD void trip_u(float cps, bool odd, bool dense, float (&out)[N])
+  {
+    if (!dense)
+    {
+      const BlepFreq<true> f = BlepFreq<true>::make(cps);
+      const uint32_t before = omega32;
+      float p[N];
+      uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+      {
+        p[i] = phasor_next(omega32, cps);
+        lo = i ? trip_umin(lo, f2u(p[i])) : f2u(p[i]);
+        hi = i ? trip_umax(hi, f2u(p[i])) : f2u(p[i]);
+      }
+      if (__builtin_amdgcn_ballot_w64(u2f(lo) < kTripTiny || u2f(hi) > kTripNearOne) == 0)
+      {
+        const float cLo = f.correction(u2f(lo), true, false), cHi = f.correction(u2f(hi), false, false);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+        {
+          const float saw = __builtin_fmaf(p[i], 2.f, -1.f);
+          out[i] = saw - (f.lo(p[i]) ? cLo : (f.hi(p[i]) ? cHi : 0.f));
+        }
+        return;
+      }
+      omega32 = before;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = next_u(cps, odd);
+  }
   MLD void end_vector() {}
 };
 
@@ -318,6 +369,54 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
   MLD float next_sw(float cps, bool oddW) { return oddW ? step<false, true>(cps, width) : step<false, true, true>(cps, width); }
   MLD float next_sw(float cps, float w, bool oddW) { return oddW ? step<false, true>(cps, w) : step<false, true, true>(cps, w); }
   static MLD bool input_is_odd(float cps) { return blep_freq_is_odd(cps); }
+  // N samples at once, launch-constant frequency and width (see SawGen::trip_u; `odd` covers the width's range as in next_u, so
+  // here 0 <= w <= 1 and the shifted phase is v_fract's ground). Four zones: after / before the rising step (the phase itself),
+  // after / before the falling step (the phase shifted by 1 - w); (pulse + cUp) - cDown with the idle corrections exactly 0.f is
+  // the reference's own expression (phasor_to_pulse above).
+  template <int N>
+  MLD void trip_u(float cps, float w, bool odd, bool dense, float (&out)[N])
+  {
+    if (!dense)
+    {
+      const BlepFreq<true> f = BlepFreq<true>::make(cps);
+      const uint32_t before = omega32;
+      float p[N], d[N];
+      uint32_t lo = 0u, hi = 0u, dlo = 0u, dhi = 0u;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+      {
+        p[i] = phasor_next(omega32, cps);
+        d[i] = __builtin_amdgcn_fractf(p[i] - w + 1.0f);
+        lo = i ? trip_umin(lo, f2u(p[i])) : f2u(p[i]);
+        hi = i ? trip_umax(hi, f2u(p[i])) : f2u(p[i]);
+        dlo = i ? trip_umin(dlo, f2u(d[i])) : f2u(d[i]);
+        dhi = i ? trip_umax(dhi, f2u(d[i])) : f2u(d[i]);
+      }
+      const bool suspect = u2f(lo) < kTripTiny || u2f(hi) > kTripNearOne || u2f(dlo) < kTripTinyShifted || u2f(dhi) > kTripNearOneShifted;
+      if (__builtin_amdgcn_ballot_w64(suspect) == 0)
+      {
+        const float cUpLo = f.correction(u2f(lo), true, false), cUpHi = f.correction(u2f(hi), false, false);
+        const float cDownLo = f.correction(u2f(dlo), true, false), cDownHi = f.correction(u2f(dhi), false, false);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+        {
+          const float pulse = (p[i] >= w) ? -1.f : 1.f;
+          const float cUp = f.lo(p[i]) ? cUpLo : (f.hi(p[i]) ? cUpHi : 0.f);
+          const float cDown = f.lo(d[i]) ? cDownLo : (f.hi(d[i]) ? cDownHi : 0.f);
+          out[i] = (pulse + cUp) - cDown;
+        }
+        return;
+      }
+      omega32 = before;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = next_u(cps, w, odd);
+  }
+  template <int N>
+  MLD void trip_u(float cps, bool odd, bool dense, float (&out)[N])
+  {
+    trip_u<N>(cps, width, odd, dense, out);
+  }
   MLD void end_vector() {}
 };
 

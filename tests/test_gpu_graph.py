@@ -772,3 +772,71 @@ def test_tempo_lock_following_a_computed_phasor(eng, oracle, hostile):
         g32, w32 = states[call].view(np.uint32), st.view(np.uint32)
         bothnan = np.isnan(g32.view(np.float32)) & np.isnan(w32.view(np.float32))
         assert ((g32 == w32) | bothnan).all(), f"computed-input TempoLock state after call {call}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trip_quads,vpl", [(2, 1), (2, 2), (1, 1), (4, 1), (0, 1)])
+def test_oscillator_trips_on_the_knife_edges(eng, oracle, trip_quads, vpl, monkeypatch):
+    """SawGen / PulseGen nodes with per-voice frequency (and width) get their polyBLEP corrections once per zone per trip of
+    `trip_quads` quads (mldsp_procs.hpp: trip_u; MLGPU_GRAPH_OSC_TRIP, default 2; 0 = per sample). The short cut rests on "at most one
+    sample of a trip in each zone", which rounding can break next to a wrap - those trips must be recognised and evaluated per sample.
+    Voices placed on the edges: phases landing 0..23 units after a wrap, 0..368 units before one, and within -128 .. +608 units of the pulse's
+    falling step, some 1..37 samples into the launch; widths 0, 1, dt, 1 - dt, dt / 2 among random ones; frequencies at and around
+    the trip forms' limit (1 / 2N), wavefronts entirely below it and mixed ones. Outputs and final phases against the oracle."""
+    import madronalib_amd as ml
+    monkeypatch.setenv("MLGPU_GRAPH_OSC_TRIP", str(trip_quads))
+    V, T = 16384, 2
+    rng = np.random.default_rng(77)
+    freq = (1e-4 * (300.0 ** rng.random(V))).astype(np.float32)              # 1e-4 .. 0.03: inside every trip form's range
+    freq[V // 2:] = (1e-3 * (200.0 ** rng.random(V - V // 2))).astype(np.float32)   # second half: up to 0.2 - mixed wavefronts
+    limit = np.float32(0.5 / (4 * trip_quads)) if trip_quads else np.float32(1.0 / 32.0)
+    freq[5:V // 2:64] = limit                                   # the first half's wavefronts stay entirely inside the trip form's range
+    freq[V // 2 + 5::64] = np.float32(1.0 / 32.0)
+    freq[V // 2 + 6::64] = np.float32(1.0 / 16.0)
+    freq[V // 2 + 7::64] = np.float32(1.0 / 8.0)
+    freq[V // 2 + 9::128] = np.nextafter(limit, np.float32(1.0))
+    width = rng.uniform(0.0, 1.0, V).astype(np.float32)
+    width[0::16] = 0.0
+    width[1::16] = 1.0
+    width[2::16] = freq[2::16]
+    width[3::16] = np.float32(1.0) - freq[3::16]
+    width[4::16] = freq[4::16] * np.float32(0.5)
+    istep = np.rint(freq.astype(np.float64) * 2.0 ** 32).astype(np.uint64)
+    v = np.arange(V, dtype=np.uint64)
+    k, j = v % 37 + 1, (v // 8) % 24
+    om = rng.integers(0, 2 ** 32, V, dtype=np.uint64)
+    # (a trip with a suspect lane is evaluated per sample for the whole wavefront: the three kinds of edges go to different wavefronts,
+    # or one kind's fall-back would hide what the others' recognition misses)
+    wave = (v // 64) % 3
+    om = np.where((wave == 0) & (v % 4 == 1), (2 ** 32 * 64 - k * istep + j), om)
+    om = np.where((wave == 0) & (v % 4 == 3), (2 ** 32 * 64 - k * istep - 16 * j), om)
+    wq = np.rint(width.astype(np.float64) * 2.0 ** 32).astype(np.uint64)
+    om = np.where((wave == 1) & (v % 2 == 1), (2 ** 32 * 64 + wq - k * istep + 32 * j - 128), om)
+    phases = (om % (2 ** 32)).astype(np.uint32)
+    desc = [dict(name="f", type="param"), dict(name="w", type="param"),
+            dict(name="saw", type="proc", kind=Proc.SAW_GEN, inputs=["f"]),
+            dict(name="pw", type="proc", kind=Proc.PULSE_GEN, inputs=["f", "w"]),
+            dict(name="pc", type="proc", kind=Proc.PULSE_GEN, inputs=["f"])]
+    outs = ["saw", "pw", "pc"]
+    g = ml.Graph(eng, V, desc, outs, voices_per_lane=vpl)
+    if trip_quads:
+        assert g.source.count(f".trip_u<{4 * trip_quads}>(") == 3 * vpl and f"q2 += {trip_quads}" in g.source
+    else:
+        assert ".trip_u<" not in g.source and ".next_u(" in g.source
+    g.set_param("f", freq)
+    g.set_param("w", width)
+    g.set_coeffs("pc", [width])
+    for nm in outs:
+        g.set_state(nm, 0, phases)
+    states = {nm: np.ascontiguousarray(phases[None, :].copy()) for nm in outs}
+    for call in range(2):
+        got = g.process_host(T, {}, Layout.QUAD)
+        want = evaluate(oracle, desc, outs, V, T, {}, {"f": freq, "w": width}, {"pc": width[None, :]}, states)
+        for i, o in enumerate(outs):
+            assert_bits_equal(got[i], want[i], True, f"{o} call {call} trip={trip_quads} vpl={vpl}")
+    for nm in outs:
+        assert (g.get_state(nm, 0) == states[nm][0]).all(), nm
+    # the corrections did happen: a naive saw differs from the output on the samples next to a step
+    naive = 2.0 * ((phases[:, None].astype(np.float64) + np.arange(1, 64 * T + 1)[None, :] * istep[:, None].astype(np.float64)) % 2 ** 32) / 2 ** 32 - 1.0
+    assert (np.abs(want[0][:, :64 * T].astype(np.float64) - naive) > 1e-3).mean() > 0.005
+    g.close()
