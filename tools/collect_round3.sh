@@ -13,7 +13,7 @@ cpset profiles_cfg2_32MiB cfg2 r03_cfg2_32MiB
 cpset profiles_cfg4_262144 cfg4 r03_cfg4_V262144
 cpset profiles_strings_windows strings r03w_strings_windows
 cp $S/pmc_workloads.json $D/pmc_workloads.json
-for f in bankbench instbench cfg4_forms strict_svf jit_maxilp synth_mixdown multi_gpu_launch_paths node_costs two_streams_lines; do cp $S/$f.txt $D/r03_$f.txt; done
+for f in bankbench instbench cfg4_forms strict_svf jit_maxilp synth_mixdown multi_gpu_launch_paths node_costs two_streams_lines osc_trips; do cp $S/$f.txt $D/r03_$f.txt; done
 cp $S/cascade_lab.txt $D/r03_cascade_lanes.txt
 cp $S/cascade_lab_pmc_mode0.txt $D/r03_cascade_lab_pmc_streams.txt
 cp $S/cascade_lab_pmc_mode1.txt $D/r03_cascade_lab_pmc_no_hbm.txt

@@ -60,6 +60,13 @@ $B --workload cfg3 --sustained $O/cfg3_sustained.json --sustained-seconds 30 2>/
   echo "## mixgroups"; $B --workload mixgroups 2>/dev/null | tail -1 | line
 } > $O/two_streams_lines.txt 2>&1
 
+# graph kernels: the oscillators' polyBLEP per sample (0) or once per zone per trip of 1 / 2 / 4 quads (MLGPU_GRAPH_OSC_TRIP; default 2)
+{ echo "# MLGPU_GRAPH_OSC_TRIP: SawGen / PulseGen nodes with per-voice frequency, polyBLEP per sample (0) or per trip of 1, 2, 4 quads; same box";
+  echo "# columns: units/s, kernel, ms per launch, fraction of 8 TB/s, clock";
+  for i in 1 2; do for t in 0 1 2 4; do echo "## cfg5 trip=$t"; MLGPU_GRAPH_OSC_TRIP=$t $B --workload cfg5 2>/dev/null | tail -1 | line; done; done
+  for t in 0 2; do echo "## cfg5full trip=$t"; MLGPU_GRAPH_OSC_TRIP=$t $B --workload cfg5full 2>/dev/null | tail -1 | line; done
+} > $O/osc_trips.txt 2>&1
+
 tools/multi_gpu_dry_run.sh $O/multi_gpu_launch_paths.txt 8
 python tools/node_costs.py 2 10 > $O/node_costs.txt 2>&1
 for dd in $O/profiles_*; do python tools/summarize_profiles.py $dd r03 > $dd/summary.md 2>/dev/null; done
