@@ -840,3 +840,38 @@ def test_oscillator_trips_on_the_knife_edges(eng, oracle, trip_quads, vpl, monke
     naive = 2.0 * ((phases[:, None].astype(np.float64) + np.arange(1, 64 * T + 1)[None, :] * istep[:, None].astype(np.float64)) % 2 ** 32) / 2 ** 32 - 1.0
     assert (np.abs(want[0][:, :64 * T].astype(np.float64) - naive) > 1e-3).mean() > 0.005
     g.close()
+
+
+@pytest.mark.gpu
+def test_oscillator_trips_equal_the_per_sample_form_on_free_running_phases(eng, monkeypatch):
+    """tools/osc_trip_soak.py in small: the same SawGen / PulseGen graph generated with the corrections once per zone per trip (the default)
+    and per sample (MLGPU_GRAPH_OSC_TRIP=0), random phases, frequencies and widths, two launches with carried state: the same bits,
+    outputs and final phases. (The per-sample form is what the oracle tests pin; the soak tool runs 6e9 samples per oscillator.)"""
+    import madronalib_amd as ml
+    V, T = 8192, 16
+    rng = np.random.default_rng(5)
+    freq = (2e-5 * ((0.0625 / 2e-5) ** rng.random(V))).astype(np.float32)
+    width = rng.uniform(0.0, 1.0, V).astype(np.float32)
+    phases = rng.integers(0, 2 ** 32, V, dtype=np.uint64).astype(np.uint32)
+    desc = [dict(name="f", type="param"), dict(name="w", type="param"),
+            dict(name="saw", type="proc", kind=Proc.SAW_GEN, inputs=["f"]),
+            dict(name="pw", type="proc", kind=Proc.PULSE_GEN, inputs=["f", "w"])]
+    res = {}
+    for trip in ("0", None):
+        if trip is None:
+            monkeypatch.delenv("MLGPU_GRAPH_OSC_TRIP", raising=False)
+        else:
+            monkeypatch.setenv("MLGPU_GRAPH_OSC_TRIP", trip)
+        g = ml.Graph(eng, V, desc, ["saw", "pw"])
+        assert (".trip_u<8>(" in g.source) == (trip is None)
+        g.set_param("f", freq)
+        g.set_param("w", width)
+        for nm in ("saw", "pw"):
+            g.set_state(nm, 0, phases)
+        a = g.process_host(T, {}, Layout.QUAD)
+        b = g.process_host(T, {}, Layout.QUAD)
+        res[trip] = a + b + [g.get_state("saw", 0).view(np.float32), g.get_state("pw", 0).view(np.float32)]
+        g.close()
+    for i, (x, y) in enumerate(zip(res[None], res["0"])):
+        assert_bits_equal(x, y, False, f"trip form against per-sample form, item {i}")
+    assert np.abs(res[None][0]).max() > 0.9 and np.abs(res[None][1]).max() >= 1.0
