@@ -2554,16 +2554,84 @@ class EventsToSignals
 class AudioContext
 {
  public:
+  // what getTimeInfo() hands out of ProcessTime (MLAudioContext.h:27-57)
+  struct ProcessTime
+  {
+    double bpm{0.}, sampleRate{0.};
+    uint64_t samplesSinceStart{0};
+    DSPVector quarterNotesPhase_;
+  };
   AudioContext(size_t nInputs, size_t nOutputs) : inputs(nInputs), outputs(nOutputs) {}
   AudioContext(size_t nInputs, size_t nOutputs, int rate) : inputs(nInputs), outputs(nOutputs), sampleRate_(rate) {}
-  void setSampleRate(int r) { sampleRate_ = r; }
+
+  // Two lives. (1) Handed to gpu::VoiceProgram / gpu::SynthProgram, the context is what the captured process function reads its
+  // voice rows, controllers and beat phase from: graph inputs (below, "in a capture"). (2) IMMEDIATE MODE - a host loop that steps
+  // the context itself, as the reference's SignalProcessBuffer or a test does: processVector(offset) outside any capture makes this
+  // an object like the reference's (MLAudioContext.cpp:104-140): its own EventsToSignals (one instrument, on the immediate
+  // engine) and transport, getInputVoice(v) / getInputController(n) / getBeatPhase() returning host data. The device objects are
+  // made at the first processVector(): what was set before is applied then - sample rate and the setInput...() values first, then
+  // the events added so far.
+  void setSampleRate(int r)
+  {
+    sampleRate_ = r;
+    if (imm_) imm_->e2s.setSampleRate(r);
+  }
   double getSampleRate() { return sampleRate_; }
-  void setInputPolyphony(int voices) { polyphony_ = voices; }
+  void setInputPolyphony(int voices)
+  {
+    polyphony_ = voices;
+    if (imm_) imm_->e2s.setPolyphony((size_t)voices);
+  }
   size_t getInputPolyphony() { return (size_t)polyphony_; }
+  void setInputPitchBend(float p) { setInput(kBend, p); }
+  void setInputMPEPitchBend(float p) { setInput(kMpeBend, p); }
+  void setInputGlideTimeInSeconds(float s) { setInput(kGlide, s); }
+  void setInputDriftAmount(float d) { setInput(kDrift, d); }
+  void setInputUnison(bool u) { setInput(kUnison, u ? 1.f : 0.f); }
+  void setInputProtocol(Symbol p) { setInput(kProtocol, (p == Symbol("MPE")) ? 1.f : 0.f); }
+  void setInputModCC(int c) { setInput(kModCC, (float)c); }
+  int getNewestInputVoice() { return immediate().e2s.getNewestVoice(); }
+
+  // AudioContext::processVector (MLAudioContext.cpp:122-126): the transport's DSPVector, then the events of
+  // [startOffset, startOffset + 64) of the host block into the voices' rows and the controllers. Immediate mode only.
+  void processVector(int startOffset)
+  {
+    if (gpu::Capture::current())
+      throw std::logic_error("mldsp GPU shim: AudioContext::processVector inside a captured process function (the program that runs the capture steps the context)");
+    Immediate& m = immediate();
+    stepTransport(m);
+    m.e2s.processVector(startOffset);
+  }
+  void updateTime(const double ppqPos, const double bpm, bool isPlaying, double sampleRate)  // :135-139 -> ProcessTime::setTimeAndRate
+  {
+    if (timeReports_.size() >= 4096) timeReports_.erase(timeReports_.begin());  // (a context nobody steps: do not grow)
+    timeReports_.push_back(TimeReport{ppqPos, bpm, sampleRate, isPlaying});
+    if (imm_) flushTimeReports(*imm_);
+  }
+  void clear()  // :116-120
+  {
+    pendingEvents_.clear();
+    timeReports_.clear();
+    if (!imm_) return;
+    std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+    gpu::Eager::get().engine().check(mlgpu_transport_clear(imm_->transport, 0));
+    imm_->e2s.clear();
+  }
+  const ProcessTime& getTimeInfo()
+  {
+    Immediate& m = immediate();
+    flushTimeReports(m);
+    m.time.samplesSinceStart = mlgpu_transport_samples_since_start(m.transport, 0);
+    m.time.bpm = mlgpu_transport_bpm(m.transport, 0);
+    m.time.sampleRate = sampleRate_;
+    return m.time;
+  }
+
   // In a capture there is ONE generic voice: whatever index is asked for, the rows are those of "this lane's voice"
   // (graph inputs fed by mlgpu_events). Per-voice constants belong in the kVoice row, not in the index.
-  const EventsToSignals::Voice& getInputVoice(int)
+  const EventsToSignals::Voice& getInputVoice(int n)
   {
+    if (!gpu::Capture::current()) return immediate().e2s.getVoice(n);
     usesVoice_ = true;
     return voice_;
   }
@@ -2573,20 +2641,31 @@ class AudioContext
   DSPVector getInputController(size_t n) const
   {
     if (n > 128) n = 128;
+    if (!gpu::Capture::current()) return immediate().e2s.getController(n).output;
     gpu::Sig s(gpu::Capture::get().contextInput((int)n), 0.f);
     s.hostCtx = (int)n;
     return DSPVector(s);
   }
   DSPVector getBeatPhase()
   {
+    if (!gpu::Capture::current()) return immediate().time.quarterNotesPhase_;
     gpu::Sig s(gpu::Capture::get().contextInput(gpu::Capture::kBeatPhase), 0.f);
     s.hostCtx = gpu::Capture::kBeatPhase;
     return DSPVector(s);
   }
   // AudioContext::addInputEvent / clearInputEvents (MLAudioContext.h:60-62): events wait here until whoever runs the program
-  // hands them to mlgpu_events (gpu::SynthProgram::addInputEvent does so directly for a bank of instruments)
-  void addInputEvent(const Event& e) { pendingEvents_.push_back(e); }
-  void clearInputEvents() { pendingEvents_.clear(); }
+  // hands them to mlgpu_events (gpu::SynthProgram::addInputEvent does so directly for a bank of instruments); an immediate
+  // context gives them to its own EventsToSignals
+  void addInputEvent(const Event& e)
+  {
+    pendingEvents_.push_back(e);
+    if (imm_) imm_->e2s.addEvent(e);
+  }
+  void clearInputEvents()
+  {
+    pendingEvents_.clear();
+    if (imm_) imm_->e2s.clearEvents();
+  }
   std::vector<Event> pendingEvents_;
   DSPVectorDynamic inputs;
   DSPVectorDynamic outputs;
@@ -2596,8 +2675,82 @@ class AudioContext
   bool usesVoice_{false};
 
  private:
+  enum InputSetting { kBend, kMpeBend, kGlide, kDrift, kUnison, kProtocol, kModCC, kNumInputSettings };
+  struct TimeReport
+  {
+    double ppq, bpm, sampleRate;
+    bool playing;
+  };
+  struct Immediate
+  {
+    EventsToSignals e2s;
+    mlgpu_transport* transport{nullptr};
+    ProcessTime time;
+    ~Immediate()
+    {
+      if (!transport) return;
+      std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+      mlgpu_transport_destroy(transport);
+    }
+  };
+  void setInput(InputSetting k, float x)
+  {
+    inputSettings_[(size_t)k] = {true, x};
+    if (imm_) applyInput(*imm_, k, x);
+  }
+  static void applyInput(Immediate& m, InputSetting k, float x)
+  {
+    switch (k)
+    {
+      case kBend: m.e2s.setPitchBendInSemitones(x); break;
+      case kMpeBend: m.e2s.setMPEPitchBendInSemitones(x); break;
+      case kGlide: m.e2s.setPitchGlideInSeconds(x); break;
+      case kDrift: m.e2s.setDriftAmount(x); break;
+      case kUnison: m.e2s.setUnison(x != 0.f); break;
+      case kProtocol: m.e2s.setProtocol(x != 0.f ? Symbol("MPE") : Symbol("MIDI")); break;
+      case kModCC: m.e2s.setModCC((int)x); break;
+      default: break;
+    }
+  }
+  Immediate& immediate() const
+  {
+    if (imm_) return *imm_;
+    if (gpu::Capture::current()) throw std::logic_error("mldsp GPU shim: this AudioContext call belongs to immediate mode (outside a capture)");
+    std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+    const gpu::Engine& e = gpu::Eager::get().engine();
+    auto m = std::make_shared<Immediate>();
+    e.check(mlgpu_transport_create(e.handle(), 1, 1, &m->transport));
+    if (sampleRate_ > 0) m->e2s.setSampleRate(sampleRate_);
+    if (polyphony_ > 0) m->e2s.setPolyphony((size_t)polyphony_);
+    for (size_t k = 0; k < (size_t)kNumInputSettings; ++k)
+      if (inputSettings_[k].first) applyInput(*m, (InputSetting)k, inputSettings_[k].second);
+    for (const Event& ev : pendingEvents_) m->e2s.addEvent(ev);
+    imm_ = m;
+    return *imm_;
+  }
+  void flushTimeReports(Immediate& m)
+  {
+    std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+    const gpu::Engine& e = gpu::Eager::get().engine();
+    for (const TimeReport& r : timeReports_) e.check(mlgpu_transport_set_time_and_rate(m.transport, 0, r.ppq, r.bpm, r.playing ? 1 : 0, r.sampleRate));
+    timeReports_.clear();
+  }
+  void stepTransport(Immediate& m)
+  {
+    flushTimeReports(m);
+    std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+    const gpu::Engine& e = gpu::Eager::get().engine();
+    e.check(mlgpu_transport_process(m.transport, 1));
+    float host[64];  // one context: its DSPVector in sample order
+    e.check(mlgpu_download(e.handle(), host, mlgpu_transport_beat_phase(m.transport), sizeof(host)));
+    m.time.quarterNotesPhase_ = DSPVector(static_cast<const float*>(host));
+  }
+
   double sampleRate_{0};
   int polyphony_{0};
+  std::array<std::pair<bool, float>, kNumInputSettings> inputSettings_{};
+  std::vector<TimeReport> timeReports_;
+  mutable std::shared_ptr<Immediate> imm_;  // (shared: a copy of the context keeps stepping the same objects)
 };
 using SignalProcessFn = void (*)(AudioContext*, void*);
 
@@ -2750,9 +2903,32 @@ class Synth : public SignalProcessor
                             AudioContext* audioContext) = 0;
   virtual bool isVoiceActive(int, const EventsToSignals::Voice&) { return true; }
   int getNumVoices() const { return numVoices_; }
+  // Synth::processVector (MLSynth.h:38-61) - immediate mode, a context that is stepped by its host loop: the outputs start from
+  // zero and every active voice is mixed in, in voice order, with the rows of its own voice. (A captured program never comes
+  // here: gpu::SynthProgram captures processVoice for one generic voice and sums the voices on the device in the same order.)
+  void processVector(const DSPVectorDynamic& inputs, DSPVectorDynamic& outputs, void* stateData) override
+  {
+    AudioContext* ctx = static_cast<AudioContext*>(stateData);
+    if (!ctx) return;
+    if (gpu::Capture::current())
+      throw std::logic_error("mldsp GPU shim: Synth::processVector inside a capture - hand the Synth to ml::gpu::SynthProgram instead");
+    for (size_t i = 0; i < outputs.size(); ++i) outputs[i] = DSPVector(0.f);
+    int active = 0;
+    for (int v = 0; v < numVoices_; ++v)
+    {
+      const EventsToSignals::Voice& voice = ctx->getInputVoice(v);
+      if (!isVoiceActive(v, voice)) continue;
+      ++active;
+      processVoice(v, voice, inputs, outputs, ctx);
+    }
+    activeVoiceCount_ = active;
+  }
+  int getActiveVoiceCount() const { return activeVoiceCount_; }
+  virtual bool hasActiveVoices() const { return activeVoiceCount_ > 0; }
 
  protected:
   int numVoices_;
+  int activeVoiceCount_{0};
 };
 
 // ---- host-side helpers of MLDSPUtils.h / MLDSPBuffer.h ------------------------------------------------------------------
@@ -2809,6 +2985,42 @@ class DSPBuffer : public gpu::DSPBuffer
     if (getReadAvailable() >= 64 * ROWS) gpu::DSPBuffer::read(p, 64 * ROWS);
     else std::fill(p, p + 64 * ROWS, 0.f);
   }
+};
+
+// SignalProcessBuffer (source/app/MLSignalProcessBuffer.h:20-35, .cpp:16-96) in immediate mode: the adaptor between a host's blocks
+// of any length and a process function that works a DSPVector at a time. Host blocks go into one ring per input; while the output
+// rings hold less than the host asked for, one more DSPVector is made - the inputs' next 64 samples (zeros while a ring is still
+// short), ctx->processVector(offset) with the offset counted from the start of this host block, the process function, its outputs
+// into the output rings; then the host's frames are read out and the block's events dropped. A block longer than maxFrames, or
+// no output pointers, is ignored, as in the reference. (The device counterpart for banks of voices is mlgpu_process_buffer.)
+class SignalProcessBuffer final
+{
+ public:
+  SignalProcessBuffer(size_t inputs, size_t outputs, size_t maxFrames) : in_(inputs), out_(outputs), maxFrames_(maxFrames)
+  {
+    for (DSPBuffer& b : in_) b.resize((int)maxFrames);
+    for (DSPBuffer& b : out_) b.resize((int)maxFrames);
+  }
+  void process(const float** externalInputs, float** externalOutputs, int externalFrames, AudioContext* context, SignalProcessFn processFn, void* state)
+  {
+    if (out_.empty() || !externalOutputs || externalFrames > (int)maxFrames_) return;
+    for (size_t c = 0; c < in_.size(); ++c)
+      if (externalInputs[c]) in_[c].write(externalInputs[c], (size_t)externalFrames);
+    for (int offset = 0; (int)out_[0].getReadAvailable() < externalFrames; offset += (int)kFloatsPerDSPVector)
+    {
+      for (size_t c = 0; c < in_.size(); ++c) in_[c].read(context->inputs[(int)c]);
+      context->processVector(offset);
+      processFn(context, state);
+      for (size_t c = 0; c < out_.size(); ++c) out_[c].write(context->outputs[(int)c]);
+    }
+    for (size_t c = 0; c < out_.size(); ++c)
+      if (externalOutputs[c]) out_[c].read(externalOutputs[c], (size_t)externalFrames);
+    context->clearInputEvents();
+  }
+
+ private:
+  std::vector<DSPBuffer> in_, out_;
+  size_t maxFrames_;
 };
 
 namespace gpu

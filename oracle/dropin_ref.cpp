@@ -198,7 +198,7 @@ extern "C" int objects_ref_run_retrigger(size_t V, size_t T, const float* in0, c
   return 0;
 }
 
-#ifndef MLGPU_IMMEDIATE_BUILD  // everything below drives the reference's app layer (AudioContext events, Synth, SignalProcessBuffer ...)
+// ---- the app layer: AudioContext with its events, Synth, SignalProcessBuffer (in the immediate build the shim's own, stepped by these loops) ----
 // ---- a Synth subclass run by the reference's own Synth::processVector, AudioContext and EventsToSignals ----
 #include "MLSynth.h"
 #include "../tests/cpp/dropin_synth.h"
@@ -350,7 +350,6 @@ extern "C" int plugin_ref_run(const SynthRefEvent* events, int nEvents, float gl
   return 0;
 }
 
-#endif  // MLGPU_IMMEDIATE_BUILD
 // ---- the reference's EventsToSignals driven like AudioContext / SignalProcessBuffer drive it -------------------------
 // events: absolute onset times in frames; the harness cuts time into host blocks of blockFrames (a multiple of 64), adds the
 // events of a block with block-relative times, calls processVector(offset) per 64 frames and clearEvents() per block.
@@ -442,7 +441,6 @@ extern "C" int e2s_ref_run_controllers_from(int polyphony, int mpe, int unison, 
                    ctlOut, ctlFromVector);
 }
 
-#ifndef MLGPU_IMMEDIATE_BUILD
 // ---- controllers-to-audio (tests/cpp/dropin_controllers.h): one AudioContext with its controller events ----
 #include "../tests/cpp/dropin_controllers.h"
 extern "C" int ctl_audio_ref_run(const RefEvent* events, int nEvents, int blockFrames, int nBlocks, float* out)
@@ -505,6 +503,7 @@ extern "C" int transport_ref_run(const TransportStep* steps, int nSteps, float* 
   return 0;
 }
 
+#ifndef MLGPU_IMMEDIATE_BUILD  // (published signals are fed by the device in the shim: no host-side writeQuick)
 // ---- SignalProcessor::PublishedSignal driven as processors drive it: storePublishedSignal per voice in rotation ----
 // ops[i]: 0 = write the next DSPVector of every voice (2 channels), 1 = read(args[i] frames), 2 = readLatest(args[i]),
 // 3 = peekLatest(args[i]). Results of the read ops are concatenated in `out`; counts[i] = floats the op returned.
