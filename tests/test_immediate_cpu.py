@@ -45,7 +45,8 @@ def test_events_to_signals_object_needs_the_device_too():
     lib = os.path.join(ROOT, "tests", "cpp", "libdropin_imm.so")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
     syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
-    for name in ("e2s_ref_run", "e2s_ref_run_controllers", "e2s_ref_run_controllers_from", "immediate_ref_run"):
+    for name in ("e2s_ref_run", "e2s_ref_run_controllers", "e2s_ref_run_controllers_from", "immediate_ref_run", "plugin_ref_run", "spb_ref_run",
+                 "controller_synth_ref_run", "tempo_synth_ref_run", "lean_synth_ref_run", "ctl_audio_ref_run", "transport_ref_run"):
         assert f" T {name}\n" in syms
     if ml.device_count() > 0:
         pytest.skip("a GPU is visible here (tests/test_gpu_immediate.py steps the object on it)")
