@@ -2810,10 +2810,45 @@ class SignalProcessor
   struct PublishedSignal
   {
     int maxFrames_, maxVoices_, channels_, octavesDown_;
-    mlgpu_published_signal* handle_{nullptr};  // owned by the gpu::SynthProgram that runs this processor
+    mlgpu_published_signal* handle_{nullptr};  // owned by the gpu::SynthProgram that runs this processor - or, in immediate mode, by this object
+    bool ownsHandle_{false};
+    float* staging_{nullptr};  // immediate mode: the rows of one DSPVectorArray on the device
     PublishedSignal(int frames, int maxVoices, int channels, int octavesDown)
         : maxFrames_(frames), maxVoices_(maxVoices), channels_(channels), octavesDown_(octavesDown)
     {
+    }
+    PublishedSignal(const PublishedSignal&) = delete;
+    PublishedSignal& operator=(const PublishedSignal&) = delete;
+    ~PublishedSignal()
+    {
+      if (!ownsHandle_) return;
+      std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+      if (handle_) mlgpu_published_signal_destroy(handle_);
+      if (staging_) mlgpu_free(gpu::Eager::get().engine().handle(), staging_);
+    }
+    // immediate mode (MLSignalProcessor.h:52-80, writeQuick): one voice's DSPVectorArray, host data, into the ring - every
+    // (1 << octavesDown)-th frame, frame-major; voices in the order the processor stores them
+    void writeImmediate(const float* const* rows, size_t channels)
+    {
+      std::lock_guard<std::recursive_mutex> lock(gpu::Eager::get().m);
+      const gpu::Engine& e = gpu::Eager::get().engine();
+      if (handle_ && !ownsHandle_)
+        throw std::logic_error("mldsp GPU shim: this published signal is fed by a gpu::SynthProgram; storePublishedSignal outside its capture has nowhere to go");
+      if (!handle_)
+      {
+        e.check(mlgpu_published_signal_create(e.handle(), maxFrames_, maxVoices_, channels_, octavesDown_, &handle_));
+        ownsHandle_ = true;
+        void* p = nullptr;
+        e.check(mlgpu_alloc(e.handle(), (size_t)channels_ * 64 * sizeof(float), &p));
+        staging_ = static_cast<float*>(p);
+      }
+      std::vector<const float*> d(channels);
+      for (size_t c = 0; c < channels; ++c)
+      {
+        e.check(mlgpu_upload(e.handle(), staging_ + c * 64, rows[c], 64 * sizeof(float)));
+        d[c] = staging_ + c * 64;
+      }
+      e.check(mlgpu_published_signal_write(handle_, 1, d.data(), MLGPU_LAYOUT_VOICE_MAJOR, 1, 0, 1));
     }
     size_t getNumChannels() const { return (size_t)channels_; }
     int getAvailableFrames() const { return handle_ ? (int)mlgpu_published_signal_available_frames(handle_) : 0; }
@@ -2880,6 +2915,13 @@ class SignalProcessor
     if (it == publishedSignals_.end() || !it->second) return;  // not published: ignored, as in the reference
     if (frames != (int)kFloatsPerDSPVector) throw std::logic_error("mldsp GPU shim: storePublishedSignal stores whole DSPVectors (frames == 64)");
     if ((int)CHANNELS != it->second->channels_) throw std::logic_error("mldsp GPU shim: storePublishedSignal: channel count differs from publishSignal");
+    if (!gpu::Capture::current())  // immediate mode: this voice's DSPVectorArray is host data
+    {
+      const float* rows[CHANNELS];
+      for (size_t c = 0; c < CHANNELS; ++c) rows[c] = inputVec.constRow((int)c).getConstBuffer();
+      it->second->writeImmediate(rows, CHANNELS);
+      return;
+    }
     gpu::Capture& cap = gpu::Capture::get();
     for (auto& t : cap.taps)
       if (t.name == gpu::pathText(signalName)) throw std::logic_error("mldsp GPU shim: one storePublishedSignal per name in the captured voice code");

@@ -157,3 +157,28 @@ def test_transport_of_an_immediate_context(seed):
     assert_bits_equal(out["immediate"][0], out["reference"][0], True, "beat phase")
     assert (out["immediate"][1] == out["reference"][1]).all()
     assert np.abs(out["reference"][0]).max() > 0
+
+
+def test_synth_with_a_published_signal_read_by_the_ui_side():
+    """SmallSynth (tests/cpp/dropin_synth.h) stores a two-channel "scope" signal per voice with storePublishedSignal; the host reads up to
+    700 frames after every block (PublishedSignal::read: sometimes all there is, sometimes not). Outside a capture the published signal
+    owns its ring (mlgpu_published_signal) and every voice's DSPVectorArray goes in as the reference's writeQuick puts it: audio, the
+    scope's floats and the counts of every read against the reference."""
+    Lr, Li = _libs()
+    block, n_blocks, scope_read = 512, 10, 700
+    S = block * n_blocks
+    arr, n = _events("midi", 917, S, 6)
+    c_szp = ctypes.POINTER(ctypes.c_size_t)
+    out = {}
+    for tag, L in (("reference", Lr), ("immediate", Li)):
+        L.synth_ref_run.restype = ctypes.c_int
+        L.synth_ref_run.argtypes = [ctypes.POINTER(_Ev), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p,
+                                    c_f32p, c_szp, ctypes.c_int]
+        l, r = np.zeros(S, np.float32), np.zeros(S, np.float32)
+        scope, counts = np.zeros(n_blocks * scope_read * 2, np.float32), np.zeros(n_blocks, np.uint64)
+        assert L.synth_ref_run(arr, n, 0.012, 0.6, block, n_blocks, _p(l), _p(r), _p(scope), counts.ctypes.data_as(c_szp), scope_read) == 0
+        out[tag] = (np.stack([l, r]), scope, counts)
+    assert_bits_equal(out["immediate"][0], out["reference"][0], True, "audio")
+    assert (out["immediate"][2] == out["reference"][2]).all(), (out["immediate"][2], out["reference"][2])
+    assert_bits_equal(out["immediate"][1], out["reference"][1], True, "scope floats")
+    assert out["reference"][2].sum() > 0 and np.abs(out["reference"][1]).max() > 0
