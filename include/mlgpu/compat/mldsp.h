@@ -2826,6 +2826,18 @@ class SignalProcessor
       if (handle_) mlgpu_published_signal_destroy(handle_);
       if (staging_) mlgpu_free(gpu::Eager::get().engine().handle(), staging_);
     }
+    // PublishedSignal::writeQuick (MLSignalProcessor.h:52-80) called directly - immediate mode only, whole DSPVectors
+    template <size_t CHANNELS>
+    void writeQuick(const DSPVectorArray<CHANNELS>& inputVector, size_t frames, size_t voice)
+    {
+      (void)voice;
+      if (gpu::Capture::current()) throw std::logic_error("mldsp GPU shim: PublishedSignal::writeQuick inside a capture (use storePublishedSignal)");
+      if (frames != kFloatsPerDSPVector) throw std::logic_error("mldsp GPU shim: PublishedSignal::writeQuick stores whole DSPVectors (frames == 64)");
+      if ((int)CHANNELS != channels_) throw std::logic_error("mldsp GPU shim: PublishedSignal::writeQuick: channel count differs from the signal's");
+      const float* rows[CHANNELS];
+      for (size_t c = 0; c < CHANNELS; ++c) rows[c] = inputVector.constRow((int)c).getConstBuffer();
+      writeImmediate(rows, CHANNELS);
+    }
     // immediate mode (MLSignalProcessor.h:52-80, writeQuick): one voice's DSPVectorArray, host data, into the ring - every
     // (1 << octavesDown)-th frame, frame-major; voices in the order the processor stores them
     void writeImmediate(const float* const* rows, size_t channels)

@@ -503,7 +503,6 @@ extern "C" int transport_ref_run(const TransportStep* steps, int nSteps, float* 
   return 0;
 }
 
-#ifndef MLGPU_IMMEDIATE_BUILD  // (published signals are fed by the device in the shim: no host-side writeQuick)
 // ---- SignalProcessor::PublishedSignal driven as processors drive it: storePublishedSignal per voice in rotation ----
 // ops[i]: 0 = write the next DSPVector of every voice (2 channels), 1 = read(args[i] frames), 2 = readLatest(args[i]),
 // 3 = peekLatest(args[i]). Results of the read ops are concatenated in `out`; counts[i] = floats the op returned.
@@ -540,4 +539,3 @@ extern "C" int published_ref_run(int maxFrames, int maxVoices, int octavesDown, 
   }
   return 0;
 }
-#endif  // MLGPU_IMMEDIATE_BUILD

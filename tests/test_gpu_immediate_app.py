@@ -182,3 +182,25 @@ def test_synth_with_a_published_signal_read_by_the_ui_side():
     assert (out["immediate"][2] == out["reference"][2]).all(), (out["immediate"][2], out["reference"][2])
     assert_bits_equal(out["immediate"][1], out["reference"][1], True, "scope floats")
     assert out["reference"][2].sum() > 0 and np.abs(out["reference"][1]).max() > 0
+
+
+@pytest.mark.parametrize("octaves,max_frames", [(0, 64), (2, 64), (3, 16), (6, 4)])
+def test_published_signal_written_and_read_by_hand(octaves, max_frames):
+    """SignalProcessor::PublishedSignal on its own: writeQuick of three voices in rotation interleaved with read / readLatest /
+    peekLatest of assorted sizes (tests/test_gpu_published.py's scripts), floats and counts against the reference's object."""
+    Lr, Li = _libs()
+    from test_gpu_published import script, reference
+    from inputs import lcg_noise
+    nV, T = 3, 12
+    ch0 = lcg_noise(np.arange(nV, dtype=np.uint32) + 9, 64 * T)
+    ch1 = lcg_noise(np.arange(nV, dtype=np.uint32) + 4009, 64 * T)
+    ops, args = script(T, seed=octaves)
+    res = {}
+    for tag, L in (("reference", Lr), ("immediate", Li)):
+        L.published_ref_run.restype = ctypes.c_int
+        L.published_ref_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, c_f32p, c_f32p, c_ip, c_ip, ctypes.c_int,
+                                        c_f32p, ctypes.POINTER(ctypes.c_size_t)]
+        res[tag] = reference(L, max_frames, nV, octaves, ch0, ch1, ops, args)
+    assert (res["immediate"][1] == res["reference"][1]).all()
+    assert_bits_equal(res["immediate"][0], res["reference"][0], True, "published floats")
+    assert res["reference"][1].sum() > 0
