@@ -58,3 +58,48 @@ def test_events_to_signals_object_needs_the_device_too():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "rc 0" not in r.stdout
     assert "no gfx950 (MI355X) HIP device" in r.stderr
+
+
+def test_a_context_that_is_only_configured_never_touches_a_device(tmp_path):
+    """An AudioContext handed to a capture is constructed, configured and fed events on the host (gpu::SynthProgram takes it from there);
+    only a context that is STEPPED outside a capture (processVector) becomes an immediate one with device objects of its own. The first
+    must work on a machine without a GPU, the second must fail there with the engine's error."""
+    import madronalib_amd as ml
+    if ml.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    src = tmp_path / "ctx.cpp"
+    src.write_text(r'''
+#include "MLAudioContext.h"
+#include <cstdio>
+#include <cstring>
+using namespace ml;
+int main(int argc, char** argv)
+{
+  AudioContext ctx(0, 2, 48000);
+  ctx.setInputPolyphony(4);
+  ctx.setInputGlideTimeInSeconds(0.01f);
+  ctx.setInputDriftAmount(0.5f);
+  ctx.setInputProtocol(Symbol("MIDI"));
+  ctx.updateTime(0.0, 120.0, true, 48000.0);
+  Event e;
+  e.type = kNoteOn; e.channel = 1; e.sourceIdx = 60; e.time = 0; e.value1 = 60.f; e.value2 = 0.5f;
+  ctx.addInputEvent(e);
+  ctx.clearInputEvents();
+  SignalProcessBuffer buffer(0, 2, 512);
+  std::printf("configured %zu\n", ctx.getInputPolyphony());
+  if (argc > 1 && !std::strcmp(argv[1], "step"))
+  {
+    try { ctx.processVector(0); }
+    catch (const std::exception& ex) { std::printf("stepping failed: %s\n", ex.what()); return 3; }
+  }
+  return 0;
+}
+''')
+    exe = tmp_path / "ctx"
+    lib = os.path.join(ROOT, "madronalib_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "include", "mlgpu", "compat"), str(src), "-o", str(exe),
+                           "-L" + lib, "-lmlgpu", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "configured 4" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([str(exe), "step"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "no gfx950 (MI355X) HIP device" in r.stdout, r.stdout + r.stderr
