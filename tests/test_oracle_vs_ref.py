@@ -371,3 +371,49 @@ def test_synth16_graph_evaluator_matches_reference_objects(oracle, ref):
     want, _ = ref.synth16_run(params, coeffs, seeds, gate)
     assert_bits_equal(got, want, True, "synth16 evaluator vs reference objects")
     assert np.abs(want).max() > 0.05
+
+
+def test_band_limited_oscillators_on_the_knife_edges_match_reference(oracle, ref):
+    """SawGen(freq) and PulseGen(freq, width) with phases placed where tests/test_gpu_graph.py::test_oscillator_trips_on_the_knife_edges
+    places them - a sample 0 .. 23 units of 2^-32 after a wrap, 0 .. 368 before one, within -128 .. +608 of the pulse's falling
+    step - and the same special widths (0, 1, dt, 1 - dt, dt / 2): the device's trip form is compared with the oracle there, so the
+    oracle is pinned to the compiled reference on exactly those inputs."""
+    V, T = 4096, 2
+    rng = np.random.default_rng(77)
+    f = (1e-4 * (300.0 ** rng.random(V))).astype(np.float32)
+    f[V // 2:] = (1e-3 * (200.0 ** rng.random(V - V // 2))).astype(np.float32)
+    f[5::64] = np.float32(1.0 / 16.0)
+    w = rng.uniform(0.0, 1.0, V).astype(np.float32)
+    w[0::16], w[1::16] = 0.0, 1.0
+    w[2::16], w[3::16], w[4::16] = f[2::16], np.float32(1.0) - f[3::16], f[4::16] * np.float32(0.5)
+    istep = np.rint(f.astype(np.float64) * 2.0 ** 32).astype(np.uint64)
+    v = np.arange(V, dtype=np.uint64)
+    k, j = v % 37 + 1, (v // 8) % 24
+    wave = (v // 64) % 3
+    om = rng.integers(0, 2 ** 32, V, dtype=np.uint64)
+    om = np.where((wave == 0) & (v % 4 == 1), (2 ** 32 * 64 - k * istep + j), om)
+    om = np.where((wave == 0) & (v % 4 == 3), (2 ** 32 * 64 - k * istep - 16 * j), om)
+    wq = np.rint(w.astype(np.float64) * 2.0 ** 32).astype(np.uint64)
+    om = np.where((wave == 1) & (v % 2 == 1), (2 ** 32 * 64 + wq - k * istep + 32 * j - 128), om)
+    phases = (om % (2 ** 32)).astype(np.uint32)
+    freq, width = np.repeat(f[:, None], 64 * T, 1), np.repeat(w[:, None], 64 * T, 1)
+    # PulseGen(freq, width)
+    co = np.full((1, V), 0.5, np.float32)
+    st_r = ref.chain_clear([Proc.PULSE_GEN], V)
+    st_r[0] = phases
+    st_o = st_r.copy()
+    for call in range(2):
+        want = ref.proc_multi(Proc.PULSE_GEN, T, co, st_r, [freq, width])
+        got = oracle.proc_multi(Proc.PULSE_GEN, T, co, st_o, [freq, width])
+        assert_bits_equal(got, want, True, f"pulse on the edges, call {call}")
+        assert_bits_equal(st_o, st_r, False, "pulse phases")
+    # SawGen(freq)
+    st_r = ref.chain_clear([Proc.SAW_GEN], V)
+    st_r[0] = phases
+    st_o = st_r.copy()
+    none = np.zeros((0, V), np.float32)
+    for call in range(2):
+        want = ref.chain_process([Proc.SAW_GEN], T, none, st_r, None, f)
+        got = oracle.chain_process([Proc.SAW_GEN], T, none, st_o, None, f)
+        assert_bits_equal(got, want, True, f"saw on the edges, call {call}")
+        assert_bits_equal(st_o, st_r, False, "saw phases")
