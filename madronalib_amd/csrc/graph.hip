@@ -484,6 +484,7 @@ struct mlgpu_graph
   int compiledVoicesPerLane{1};
   int unrollQ{1};                // quads per trip of the sample loop
   int oscTripQ{2};               // quads per trip of the oscillators' sparse polyBLEP (0: per sample; mldsp_procs.hpp: trip_u)
+  int prefetchQ{1};              // streamed inputs are loaded one quad ahead of their use (0: where they are used)
   std::string lastError;         // mlgpu_graph_last_error
   mlgpu_events* events{nullptr}; // mlgpu_graph_bind_events: the object the NODE_EVENT_ROW nodes read
   bool hasEventRows{false};
@@ -803,6 +804,14 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   // EventsToSignals rows computed here: one EventsVoice per voice (lane == voice index: MIDI protocol)
   if (g->hasEventRows)
     for (int l = 0; l < VL; ++l) s << "  mlev::EventsVoice ev" << sfx(l) << ";\n  ev" << sfx(l) << ".load(a.events, v" << sfx(l) << ");\n";
+  // Streamed inputs one quad (or one trip) ahead: a wavefront that loads a quad and waits for it right away stands still for a
+  // whole HBM round trip per quad, and with four wavefronts per SIMD there are long stretches with only one or two of them able to
+  // issue (one wavefront alone issues at 40 % of the SIMD's rate). The very last quad of a launch loads itself again.
+  const int PF = (g->nInputs && g->prefetchQ) ? 1 : 0;
+  if (PF) s << "  if (a.T == 0) return;\n";
+  for (int i = 0; PF && i < g->nInputs; ++i)
+    for (int l = 0; l < VL; ++l)
+      s << "  const f32x4* pf" << i << sfx(l) << " = in" << i << sfx(l) << ";\n  f32x4 nx" << i << sfx(l) << " = __builtin_nontemporal_load(pf" << i << sfx(l) << ");\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
   // (Round 3, measured and not kept - profiles/r03_synthfused_variants.txt: a second instance of the vector body, or of the
   // whole vector loop, for wavefronts without event records - EventsVoice::begin_vector / quad<true>, no record walk, no
@@ -850,10 +859,18 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   }
   else
     s << "#pragma unroll " << ((g->windowedRings && g->totalRings) ? 1 : g->unrollQ) << "\n    for (int q = 0; q < 16; ++q)\n    {\n";
+  // the next quad's address: one step on; from a vector's last quad to the next vector's first; the launch's last quad stays
+  if (PF) s << "      const bool lastQ = (q == 15), lastT = (t + 1 == a.T);\n";
   for (int i = 0; i < g->nInputs; ++i)
     for (int l = 0; l < VL; ++l)
-      s << "      const f32x4 xin" << i << sfx(l) << " = __builtin_nontemporal_load(in" << i << sfx(l) << " + t * a.in[" << i << "].strideT + q * a.in["
-        << i << "].strideQ);\n";
+    {
+      if (PF == 0)
+        s << "      const f32x4 xin" << i << sfx(l) << " = __builtin_nontemporal_load(in" << i << sfx(l) << " + t * a.in[" << i << "].strideT + q * a.in["
+          << i << "].strideQ);\n";
+      else
+        s << "      const f32x4 xin" << i << sfx(l) << " = nx" << i << sfx(l) << ";\n      pf" << i << sfx(l) << " += lastQ ? (lastT ? (size_t)0 : a.in[" << i
+          << "].strideT - 15 * a.in[" << i << "].strideQ) : a.in[" << i << "].strideQ;\n      nx" << i << sfx(l) << " = __builtin_nontemporal_load(pf" << i << sfx(l) << ");\n";
+    }
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l) s << "      f32x4 y" << o << sfx(l) << ";\n";
   if (g->hasEventRows)
@@ -1065,7 +1082,7 @@ static bool generateBudgeted(mlgpu_graph* g, int vl, std::string& source, std::v
   // the tightest bound whose build spills moderately: four wavefronts per SIMD, else three, else two
   for (int waves = 4; waves >= 2; --waves)
   {
-    if (waves * vgprs <= 512 + 7 * waves) break;  // the unbounded kernel already allows that many
+    if (((vgprs + 7) & ~7L) * waves <= 512) break;  // the unbounded kernel already allows that many (registers come in blocks of 8 of a SIMD's 512)
     g->minWaves = waves;
     const std::string bounded = generateGraphSource(g, vl);
     g->minWaves = 0;
@@ -1699,6 +1716,7 @@ extern "C"
     const char* forced = getenv("MLGPU_GRAPH_UNROLL");  // developer knob: quads per trip of the sample loop
     // delay graphs wait on their ring reads: two quads per trip keep more of them in flight (allpass4: 5.4 vs 4.5 x 10^10)
     g->unrollQ = forced ? std::max(1, atoi(forced)) : ((g->totalRings && !g->windowedRings) ? 2 : 1);
+    if (const char* pf = getenv("MLGPU_GRAPH_PREFETCH")) g->prefetchQ = atoi(pf) != 0;  // developer knob (A / B)
     if (const char* trip = getenv("MLGPU_GRAPH_OSC_TRIP"))  // developer knob: 0 = polyBLEP per sample (A / B), else 1, 2 or 4 quads per trip
     {
       const int t = atoi(trip);

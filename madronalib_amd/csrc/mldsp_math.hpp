@@ -50,6 +50,29 @@ MLD float sse_canon(float x)
 // denormal source as a signed zero, so the same operand is selected as under DAZ, and it is then returned flushed.
 MLD float sse_min(float a, float b) { return sse_canon((a < b) ? a : b); }
 MLD float sse_max(float a, float b) { return sse_canon((a > b) ? a : b); }
+// The same against a bound the caller knows: a constant (or any value) that is neither NaN nor zero. v_min_f32 / v_max_f32 differ
+// from minps / maxps only when the SECOND operand is NaN, when the operands are zeros of different sign, and for a signaling NaN in
+// the first operand (quieted where the SSE instruction hands back the bound) - so canonicalize the first operand (a signaling NaN
+// becomes a quiet one, which both machines replace by the bound; in flush mode a denormal becomes the signed zero that DAZ reads)
+// and take the hardware instruction: two instructions for three, and no compare writing a lane mask.
+MLD float hw_min(float a, float b)
+{
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+MLD float hw_max(float a, float b)
+{
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+MLD float sse_min_bound(float a, float bound) { return hw_min(sse_canon(a), bound); }
+MLD float sse_max_bound(float a, float bound) { return hw_max(sse_canon(a), bound); }
+// ... and when the first operand is the result of an arithmetic instruction (or of one of these), never a signaling NaN, and already
+// flushed in flush mode: the hardware instruction alone.
+MLD float sse_min_arith(float a, float bound) { return hw_min(a, bound); }
+MLD float sse_max_arith(float a, float bound) { return hw_max(a, bound); }
 
 // lane l of the result = bit l of `mask` ? a : b, for a wave-uniform 64-bit lane mask (a ballot, or scalar logic on ballots):
 // one v_cndmask_b32 that reads the SGPR pair, where `(mask >> lane) & 1` would be 64-bit vector shifts.
@@ -96,12 +119,23 @@ MLD float group_sum_in_order(float x)
 // operand is NaN, (b) when the operands compare equal with different bits, i.e. +0 against -0, and (c) for a signaling NaN in
 // the first operand (quieted instead of replaced) - all excluded here; a quiet NaN x gives lo on both machines, a denormal x
 // is flushed in flush mode exactly as sse_max's canonicalization would.
+// Round 4: the pair is ONE instruction, v_med3_f32 - for lo <= hi the median of (x, lo, hi) is min(max(x, lo), hi), a NaN x gives
+// min3 = lo like the pair, and a denormal x is flushed in flush mode like any other operand of the float unit.
+#ifndef MLGPU_CLAMP_MED3
+#define MLGPU_CLAMP_MED3 1
+#endif
 MLD float clamp_const_bounds(float x, float lo, float hi)
 {
+#if MLGPU_CLAMP_MED3
+  float r;
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+  return r;
+#else
   float m, r;
   asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(lo));
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(m), "v"(hi));
   return r;
+#endif
 }
 
 // _mm_cvttps_epi32 / _mm_cvtps_epi32 (MLDSPMathSSE.h:124-125): NaN and out-of-range give
@@ -186,8 +220,8 @@ MLD float vec_log(float x)  // :308-373
 
 MLD float vec_exp(float x)  // :389-440
 {
-  x = sse_min(x, 88.3762626647949f);
-  x = sse_max(x, -88.3762626647949f);
+  x = sse_min_bound(x, 88.3762626647949f);
+  x = sse_max_arith(x, -88.3762626647949f);
   float fx = x * 1.44269504088896341f;
   fx = fx + 0.5f;
   int32_t emm0 = cvtt_inrange(fx);  // |fx| <= 128
@@ -317,8 +351,10 @@ MLD float vec_cos_approx(float x)  // :774-792
 MLD float vec_exp_approx(float x)  // :793-829
 {
   const float val2 = x * 12102203.1615614f + 1065353216.f;
-  const float val3 = sse_min(val2, 2139095040.f);
-  const float val4 = sse_max(val3, 0.0f);
+  // val2 is an arithmetic result; the zero bound of the second step can only hand back a zero of the other sign than maxps would,
+  // and the conversion that follows reads both as 0
+  const float val3 = sse_min_arith(val2, 2139095040.f);
+  const float val4 = sse_max_arith(val3, 0.0f);
   const uint32_t val4i = (uint32_t)cvtt_inrange(val4);  // 0 <= val4 <= 2139095040 < 2^31
   const float xu = u2f(val4i & 0x7F800000u);
   const float b = u2f((val4i & 0x7FFFFFu) | 0x3F800000u);
@@ -440,6 +476,54 @@ MLD float libm_sinf(float y)
     return libm_sinf_poly(x * sgn, x * x, ((n + sign) & 2) != 0, n);
   }
   return (y - y) / (y - y);  // inf / NaN -> NaN
+}
+
+// ---- the same function on the SVF coefficient code's own ground, cheaper -------------------------------------------------------
+// Lopass::makeCoeffsVec passes pi * omega and 2 pi * omega with omega <= 0.5 (clamped), i.e. arguments in [0, pi_f]. There the
+// algorithm above is: y < 0.75 -> the sine polynomial on y itself; else n = round(y * 2 / pi) in {0, 1, 2}, x = y - n * pi/2 (the
+// product is exact for these n), and the sine polynomial of x, the cosine polynomial of x, or the sine polynomial of -x. Written
+// out as glibc does, that is 9-11 separate double operations per polynomial. The results below come from FEWER operations - Horner
+// forms with fused multiply-adds, 5 instead of 9 (sine) and 5 instead of 11 (cosine), the quadrant from two float comparisons -
+// whose doubles differ from glibc's in the last bits, but whose ROUNDED FLOATS do not, for any argument of the domain: checked
+// exhaustively, all 113 840 092 floats of [2^-12, pi_f], against the host libm (oracle/ml_oracle.c: mlorc_sinf_fast_check, the
+// same sequence in C; tests/test_oracle_golden.py::test_fast_sinf_forms_exhaustively; below 0.75, where glibc skips the reduction,
+// the quadrant is 0 and x = y - 0 is y itself). -(sine polynomial of x) is the sine
+// polynomial of -x exactly (every product and sum changes sign with its operands).
+// kSinfT1 / kSinfT2: the smallest floats whose quadrant ((int32)(y * 2/pi * 2^24) + 2^23) >> 24 is 1 / 2 (found by the same scan).
+constexpr float kSinfMin = 0x1p-12f, kSinfT1 = 0x1.921fb6p-1f, kSinfT2 = 0x1.2d97c8p+1f, kSinfMax = 0x1.921fb6p+1f;
+MLD double sinf_sin_poly_fma(double x, double x2)
+{
+  double p = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+  p = __builtin_fma(x2, p, -0x1.555545995a603p-3);
+  return __builtin_fma(x * x2, p, x);
+}
+MLD double sinf_cos_poly_fma(double x2)
+{
+  double p = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+  p = __builtin_fma(x2, p, 0x1.55553e1068f19p-5);
+  p = __builtin_fma(x2, p, -0x1.ffffffd0c621cp-2);
+  return __builtin_fma(x2, p, 0x1p0);
+}
+// kSinfMin <= y < kSinfT1: quadrant 0, the sine polynomial on the argument itself (below 0.75 glibc skips the reduction, from
+// there to kSinfT1 it subtracts 0 * pi/2)
+MLD float libm_sinf_q0(float y)
+{
+  const double x = (double)y;
+  return (float)sinf_sin_poly_fma(x, x * x);
+}
+// Both sines of the SVF coefficient code for a wavefront in which some lane is past quadrant 0: y1 = pi * omega in [kSinfMin,
+// pi_f / 2] (quadrant 0 or 1), y2 = 2 * y1 in [2 kSinfMin, pi_f] (quadrant 0, 1 or 2). Branch-free: both polynomials, selects.
+MLD void libm_sinf_pair(float y1, float y2, float& s1, float& s2)
+{
+  constexpr double kPio2 = 0x1.921FB54442D18p0;
+  const bool q2b = (y2 >= kSinfT2), q1a = (y1 >= kSinfT1), q1b = (y2 >= kSinfT1) && !q2b;
+  const double xa = (double)y1 - (q1a ? kPio2 : 0.0);
+  const double xb = (double)y2 - (q2b ? 2.0 * kPio2 : (q1b ? kPio2 : 0.0));
+  const double xa2 = xa * xa, xb2 = xb * xb;
+  const float sa = (float)sinf_sin_poly_fma(xa, xa2), sb = (float)sinf_sin_poly_fma(xb, xb2);
+  const float ca = (float)sinf_cos_poly_fma(xa2), cb = (float)sinf_cos_poly_fma(xb2);
+  s1 = q1a ? ca : sa;
+  s2 = q2b ? -sb : (q1b ? cb : sb);
 }
 
 }  // namespace mldev

@@ -71,6 +71,21 @@ MLD float phasor_next(uint32_t& omega32, float cyclesPerSample)
   return hi * 4.656612873077392578125e-10f;  // 2^-31
 }
 
+// The same counter step, handing back `hi` itself - the phase times 2^31. Where the consumer only compares the phase, scales it or
+// feeds it to one multiply-add, the constants on the other side carry the 2^-31 instead (power-of-two scalings are exact, and hi is 0
+// or >= 1: nothing goes denormal), and the oscillator is one instruction per sample shorter:
+//   p < a  <=>  hi < a * 2^31;    RN(p * c) = RN(hi * (c * 2^-31));    RN(p - w) = fma(hi, 2^-31, -w)   (p itself is exact)
+constexpr float kPhaseUnit = 4.656612873077392578125e-10f;  // 2^-31
+constexpr float kPhaseScale = 2147483648.0f;                 // 2^31
+MLD float phasor_next_hi(uint32_t& omega32, float cyclesPerSample)
+{
+  const float steps = cyclesPerSample * kStepsPerCycle;
+  const int32_t istep = sse_cvt(steps);
+  omega32 += (uint32_t)istep;
+  asm("" : "+v"(omega32));  // one add per sample: left to itself the compiler makes sample k's phase from base + k * step (two or three instructions)
+  return (float)(int32_t)(omega32 >> 1);
+}
+
 // Correctly rounded n/d for the polyBLEP operands. This is the Newton-Raphson sequence the
 // compiler itself expands an IEEE f32 division to on gfx9 (v_rcp_f32, one reciprocal refinement,
 // two quotient refinements, all with exact FMA residuals) without the v_div_scale / v_div_fixup
@@ -239,6 +254,21 @@ MLD float phasor_to_sine(float p)  // MLDSPGens.h:316-338
   return (u2f(kSineScaleBits) * tri) * (1.0f - (tri * tri) * u2f(kOneSixthBits));
 }
 
+// SineGen's own form: the phase still scaled by 2^31 (phasor_next_hi), so the domain scale carries the 2^-31 (one multiply less),
+// and the triangle fold as a minimum: for omega > sqrt2 the reflection flip - omega is below sqrt2 (the smaller one), for omega <
+// sqrt2 it is above, and at omega == sqrt2 both are sqrt2 (flip = 2 sqrt2 exactly) - min(omega, flip - omega) is the reference's
+// select, value for value; omega is a difference of floats near sqrt2 or larger, never NaN, never denormal, so v_min_f32 returns
+// one of its operands unchanged in both denormal modes.
+MLD float phasor_hi_to_sine(float hi)
+{
+  const float sqrt2 = u2f(kSqrt2Bits);
+  const float omega = hi * u2f(kSineDomainBits - (31u << 23)) + (-sqrt2);
+  const float refl = u2f(kSineFlipBits) - omega;
+  float tri;
+  asm("v_min_f32 %0, %1, %2" : "=v"(tri) : "v"(omega), "v"(refl));
+  return (u2f(kSineScaleBits) * tri) * (1.0f - (tri * tri) * u2f(kOneSixthBits));
+}
+
 template <int KIND>
 struct Proc;
 
@@ -262,7 +292,7 @@ struct Proc<MLGPU_PROC_SINE_GEN>  // MLDSPGens.h:373-381
   uint32_t omega32;
   MLD void load(const VoiceMem& m, const KernelTables&) { omega32 = m.s(0); }
   MLD void store(const VoiceMem& m) const { m.set(0, omega32); }
-  MLD float next(float cps) { return phasor_to_sine(phasor_next(omega32, cps)); }
+  MLD float next(float cps) { return phasor_hi_to_sine(phasor_next_hi(omega32, cps)); }
   MLD void end_vector() {}
 };
 
@@ -308,25 +338,27 @@ struct Proc<MLGPU_PROC_SAW_GEN>  // MLDSPGens.h:395-402, phasorToSaw :362-369
   {
     if (!dense)
     {
+      // phases times 2^31 (phasor_next_hi): the zone bounds and the saw's slope carry the scale, the two extremes are scaled back
       const BlepFreq<true> f = BlepFreq<true>::make(cps);
+      const float dtS = f.dt * kPhaseScale, omdtS = f.omdt * kPhaseScale;
       const uint32_t before = omega32;
-      float p[N];
+      float h[N];
       uint32_t lo = 0u, hi = 0u;
 #pragma unroll
       for (int i = 0; i < N; ++i)
       {
-        p[i] = phasor_next(omega32, cps);
-        lo = i ? trip_umin(lo, f2u(p[i])) : f2u(p[i]);
-        hi = i ? trip_umax(hi, f2u(p[i])) : f2u(p[i]);
+        h[i] = phasor_next_hi(omega32, cps);
+        lo = i ? trip_umin(lo, f2u(h[i])) : f2u(h[i]);
+        hi = i ? trip_umax(hi, f2u(h[i])) : f2u(h[i]);
       }
-      if (__builtin_amdgcn_ballot_w64(u2f(lo) < kTripTiny || u2f(hi) > kTripNearOne) == 0)
+      if (__builtin_amdgcn_ballot_w64(u2f(lo) < kTripTiny * kPhaseScale || u2f(hi) > kTripNearOne * kPhaseScale) == 0)
       {
-        const float cLo = f.correction(u2f(lo), true, false), cHi = f.correction(u2f(hi), false, false);
+        const float cLo = f.correction(u2f(lo) * kPhaseUnit, true, false), cHi = f.correction(u2f(hi) * kPhaseUnit, false, false);
 #pragma unroll
         for (int i = 0; i < N; ++i)
         {
-          const float saw = __builtin_fmaf(p[i], 2.f, -1.f);
-          out[i] = saw - (f.lo(p[i]) ? cLo : (f.hi(p[i]) ? cHi : 0.f));
+          const float saw = __builtin_fmaf(h[i], 2.f * kPhaseUnit, -1.f);
+          out[i] = saw - ((h[i] < dtS) ? cLo : ((h[i] > omdtS) ? cHi : 0.f));
         }
         return;
       }
@@ -378,30 +410,32 @@ struct Proc<MLGPU_PROC_PULSE_GEN>  // MLDSPGens.h:383-393, phasorToPulse :342-35
   {
     if (!dense)
     {
+      // the phase times 2^31 (phasor_next_hi; 0 <= w <= 1 here, so w * 2^31 is exact); the shifted phase is a phase proper
       const BlepFreq<true> f = BlepFreq<true>::make(cps);
+      const float dtS = f.dt * kPhaseScale, omdtS = f.omdt * kPhaseScale, wS = w * kPhaseScale;
       const uint32_t before = omega32;
-      float p[N], d[N];
+      float h[N], d[N];
       uint32_t lo = 0u, hi = 0u, dlo = 0u, dhi = 0u;
 #pragma unroll
       for (int i = 0; i < N; ++i)
       {
-        p[i] = phasor_next(omega32, cps);
-        d[i] = __builtin_amdgcn_fractf(p[i] - w + 1.0f);
-        lo = i ? trip_umin(lo, f2u(p[i])) : f2u(p[i]);
-        hi = i ? trip_umax(hi, f2u(p[i])) : f2u(p[i]);
+        h[i] = phasor_next_hi(omega32, cps);
+        d[i] = __builtin_amdgcn_fractf(__builtin_fmaf(h[i], kPhaseUnit, -w) + 1.0f);
+        lo = i ? trip_umin(lo, f2u(h[i])) : f2u(h[i]);
+        hi = i ? trip_umax(hi, f2u(h[i])) : f2u(h[i]);
         dlo = i ? trip_umin(dlo, f2u(d[i])) : f2u(d[i]);
         dhi = i ? trip_umax(dhi, f2u(d[i])) : f2u(d[i]);
       }
-      const bool suspect = u2f(lo) < kTripTiny || u2f(hi) > kTripNearOne || u2f(dlo) < kTripTinyShifted || u2f(dhi) > kTripNearOneShifted;
+      const bool suspect = u2f(lo) < kTripTiny * kPhaseScale || u2f(hi) > kTripNearOne * kPhaseScale || u2f(dlo) < kTripTinyShifted || u2f(dhi) > kTripNearOneShifted;
       if (__builtin_amdgcn_ballot_w64(suspect) == 0)
       {
-        const float cUpLo = f.correction(u2f(lo), true, false), cUpHi = f.correction(u2f(hi), false, false);
+        const float cUpLo = f.correction(u2f(lo) * kPhaseUnit, true, false), cUpHi = f.correction(u2f(hi) * kPhaseUnit, false, false);
         const float cDownLo = f.correction(u2f(dlo), true, false), cDownHi = f.correction(u2f(dhi), false, false);
 #pragma unroll
         for (int i = 0; i < N; ++i)
         {
-          const float pulse = (p[i] >= w) ? -1.f : 1.f;
-          const float cUp = f.lo(p[i]) ? cUpLo : (f.hi(p[i]) ? cUpHi : 0.f);
+          const float pulse = (h[i] >= wS) ? -1.f : 1.f;
+          const float cUp = (h[i] < dtS) ? cUpLo : ((h[i] > omdtS) ? cUpHi : 0.f);
           const float cDown = f.lo(d[i]) ? cDownLo : (f.hi(d[i]) ? cDownHi : 0.f);
           out[i] = (pulse + cUp) - cDown;
         }
@@ -431,7 +465,7 @@ struct Proc<MLGPU_PROC_NOISE_GEN>  // MLDSPGens.h:109-148
   {
     seed = seed * 0x0019660Du + 0x3C6EF35Fu;
     const uint32_t temp = ((seed >> 9) & 0x007FFFFFu) | 0x3F800000u;
-    return u2f(temp) * 2.f - 3.f;
+    return __builtin_fmaf(u2f(temp), 2.f, -3.f);  // PARITY: temp is in [1, 2): the product and the difference are both exact (:128)
   }
   MLD void end_vector() {}
 };
@@ -615,12 +649,43 @@ struct Proc<MLGPU_PROC_LOPASS> : SvfCore<MLGPU_PROC_LOPASS>
   // calls and one IEEE division per sample. The stored `coeffs` are not used by this form.
   MLD float next(float v0, float omega, float kq)
   {
-    omega = sse_min(omega, 0.5f);
-    kq = sse_max(kq, 0.01f);
+    omega = sse_min_bound(omega, 0.5f);
+    kq = sse_max_bound(kq, 0.01f);
     const float piOmega = 3.1415926535897932384626433832795f * omega;  // kPi, MLDSPScalarMath.h
-    const float s1 = libm_sinf(piOmega);
-    const float s2 = libm_sinf(2.0f * piOmega);
-    const float nrm = 1.0f / (2.f + kq * s2);
+    const float twoPiOmega = 2.0f * piOmega;
+    // The two sinf in the forms proven for this ground (mldsp_math.hpp), chosen per sample for the whole wavefront with ONE
+    // question on the common path - an unsigned range test of 2 pi omega's bit pattern (negative and NaN patterns are above every
+    // positive float's):
+    //   every lane has 2^-11 <= 2 pi omega < kSinfT1 (omega below 0.125: 6 kHz at 48 kHz) -> quadrant 0 for both arguments, the
+    //     sine polynomial on the arguments themselves;
+    //   every lane has pi omega >= 2^-12 (omega <= 0.5 by the clamp) -> quadrants by comparison, both polynomials, selects;
+    //   otherwise (a negative, tiny or NaN omega somewhere) glibc's algorithm as it stands, for all lanes.
+    // With a regular resonance too - k <= 1.98, so that 2 + k sin lies in [0.02, 3.98] - the division needs no range handling
+    // (div_nr, exact there); any other k sends the wavefront to the last form with the IEEE division.
+    const bool regularK = (kq <= 1.98f);
+    const uint32_t kOut = regularK ? 0u : 0x80000000u;  // (an irregular k puts the lane's word out of the range below: one compare, one branch)
+    const bool q0 = (((f2u(twoPiOmega) - f2u(2.f * kSinfMin))) | kOut) < (f2u(kSinfT1) - f2u(2.f * kSinfMin));
+    float s1, s2, nrm;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!q0) == 0, 1))
+    {
+      s1 = libm_sinf_q0(piOmega);
+      s2 = libm_sinf_q0(twoPiOmega);
+      nrm = div_nr(1.0f, 2.f + kq * s2);
+    }
+    else if (__builtin_amdgcn_ballot_w64(!((piOmega >= kSinfMin) && regularK)) == 0)
+    {
+      libm_sinf_pair(piOmega, twoPiOmega, s1, s2);
+      nrm = div_nr(1.0f, 2.f + kq * s2);
+    }
+    else
+    {
+      float s[2];
+#pragma unroll 1
+      for (int i = 0; i < 2; ++i) s[i] = libm_sinf(i ? twoPiOmega : piOmega);  // (rolled: one copy of the long general code)
+      s1 = s[0];
+      s2 = s[1];
+      nrm = 1.0f / (2.f + kq * s2);
+    }
     const float c0 = s2 * nrm;
     const float c1 = (-2.f * s1 * s1 - kq * s2) * nrm;
     const float c2 = (2.0f * s1 * s1) * nrm;
@@ -926,7 +991,10 @@ struct Proc<MLGPU_PROC_ADSR>  // :657-797
   MLD float next(float x)
   {
     const uint64_t xz = __builtin_amdgcn_ballot_w64(x == 0.f);
-    const uint64_t maybe = (xz ^ mXZero) | mCrossed;
+    uint64_t maybe = (xz ^ mXZero) | mCrossed;
+    // (kept as mask arithmetic: left alone, the compiler rewrites the test as two 64-bit equality compares, two selects and two
+    // ands - nine scalar instructions per sample where these are six, and scalar issue is not hidden on this chip)
+    asm("" : "+s"(maybe));
     const uint64_t idle = mOff & xz;
     if (__builtin_expect(maybe != 0, 0)) change_segment(x);
     const float yn = y + k * (target - y);
@@ -937,6 +1005,7 @@ struct Proc<MLGPU_PROC_ADSR>  // :657-797
     const uint64_t above = __builtin_amdgcn_ballot_w64(y > threshold);
     mXZero = xz;
     mCrossed = mAbove ^ above;
+    asm("" : "+s"(mCrossed));
     mAbove = above;
     return lane_select(idle, 0.f, yn * amp);
   }

@@ -1383,6 +1383,87 @@ uint64_t mlorc_sinf_check(uint32_t lo, uint32_t hi, int n_threads, uint32_t* lis
   return bad;
 }
 
+/* The device's CHEAPER forms of the same function on the SVF coefficient code's domain [2^-12, pi_f] (mldsp_math.hpp:
+ * libm_sinf_direct / libm_sinf_0_pi), restated here operation for operation - Horner polynomials with fused multiply-adds, the
+ * quadrant from two float comparisons - so that their claim can be checked where the host libm lives: mlorc_sinf_fast_check
+ * compares both with sinf() over a range of bit patterns (tests/test_oracle_golden.py runs the whole domain, 113 840 092 floats).
+ * fma() is the C library's correctly rounded one (hardware FMA through glibc's ifunc where the CPU has it). */
+static double fast_sin_poly(double x, double x2)
+{
+  double p = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+  p = fma(x2, p, -0x1.555545995a603p-3);
+  return fma(x * x2, p, x);
+}
+static double fast_cos_poly(double x2)
+{
+  double p = fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+  p = fma(x2, p, 0x1.55553e1068f19p-5);
+  p = fma(x2, p, -0x1.ffffffd0c621cp-2);
+  return fma(x2, p, 0x1p0);
+}
+float mlorc_sinf_direct(float y) /* 2^-12 <= y < 0.75 */
+{
+  const double x = (double)y;
+  return (float)fast_sin_poly(x, x * x);
+}
+float mlorc_sinf_0_pi(float y) /* 2^-12 <= y <= pi_f */
+{
+  const int q1 = (y >= 0x1.921fb6p-1f), q2 = (y >= 0x1.2d97c8p+1f);
+  const double k = q2 ? 2.0 * 0x1.921FB54442D18p0 : (q1 ? 0x1.921FB54442D18p0 : 0.0);
+  const double x = (double)y - k, x2 = x * x;
+  const float sn = (float)fast_sin_poly(x, x2), cs = (float)fast_cos_poly(x2);
+  return q2 ? -sn : (q1 ? cs : sn);
+}
+/* which = 0: mlorc_sinf_direct, 1: mlorc_sinf_0_pi; mismatches against the host libm over bit patterns [lo, hi] */
+typedef struct { uint32_t lo, hi; int which; uint64_t bad; uint32_t first; } sinf_fast_job;
+static void* sinf_fast_worker(void* arg)
+{
+  sinf_fast_job* j = (sinf_fast_job*)arg;
+  for (uint64_t u = j->lo; u <= j->hi; ++u)
+  {
+    const float x = u2f((uint32_t)u);
+    const float a = sinf(x), b = j->which ? mlorc_sinf_0_pi(x) : mlorc_sinf_direct(x);
+    if (f2u(a) != f2u(b))
+    {
+      if (!j->bad) j->first = (uint32_t)u;
+      j->bad++;
+    }
+  }
+  return NULL;
+}
+uint64_t mlorc_sinf_fast_check(int which, uint32_t lo, uint32_t hi, int n_threads, uint32_t* first_bad)
+{
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 64) n_threads = 64;
+  sinf_fast_job jobs[64];
+  pthread_t th[64];
+  const uint64_t span = (uint64_t)hi - lo + 1, per = (span + n_threads - 1) / n_threads;
+  int used = 0;
+  for (int i = 0; i < n_threads; ++i)
+  {
+    const uint64_t a = lo + per * i, b = a + per - 1;
+    if (a > hi) break;
+    sinf_fast_job j = {(uint32_t)a, (uint32_t)(b > hi ? hi : b), which, 0, 0};
+    jobs[used] = j;
+    pthread_create(&th[used], NULL, sinf_fast_worker, &jobs[used]);
+    used++;
+  }
+  uint64_t bad = 0;
+  for (int i = 0; i < used; ++i)
+  {
+    pthread_join(th[i], NULL);
+    if (jobs[i].bad && !bad && first_bad) *first_bad = jobs[i].first;
+    bad += jobs[i].bad;
+  }
+  return bad;
+}
+/* the quadrant glibc computes for 0.75 <= y < 120: ((int32)(y * 2/pi * 2^24) + 2^23) >> 24 */
+int mlorc_sinf_quadrant(float y)
+{
+  const double r = (double)y * 0x1.45F306DC9C883p+23;
+  return ((int32_t)r + 0x800000) >> 24;
+}
+
 /* ------------------------------------------------------------------------- */
 /* the other operator() forms and the control-rate processors (graph nodes)   */
 /*

@@ -369,6 +369,21 @@ class Oracle(_Checker):
         self.lib.mlorc_libm_sinf.argtypes = [ctypes.c_float]
         return np.array([self.lib.mlorc_libm_sinf(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32)
 
+    def sinf_fast_check(self, which, lo, hi, n_threads=8):
+        """(mismatch count, first offending bit pattern) of the device's cheaper sinf forms (0: direct, 1: [2^-12, pi]) restated
+        in C against the host libm over bit patterns [lo, hi]."""
+        fnc = self.lib.mlorc_sinf_fast_check
+        fnc.restype = ctypes.c_uint64
+        fnc.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+        first = ctypes.c_uint32(0)
+        n = fnc(int(which), int(lo), int(hi), int(n_threads), ctypes.byref(first))
+        return int(n), int(first.value)
+
+    def sinf_quadrant(self, y):
+        self.lib.mlorc_sinf_quadrant.restype = ctypes.c_int
+        self.lib.mlorc_sinf_quadrant.argtypes = [ctypes.c_float]
+        return int(self.lib.mlorc_sinf_quadrant(float(y)))
+
     def sinf_check(self, lo, hi, n_threads=8):
         """(mismatch count, offending bit patterns) of restated vs host-libm sinf over bit patterns [lo, hi]."""
         fnc = self.lib.mlorc_sinf_check

@@ -328,6 +328,55 @@ def test_multi_input_forms_vs_oracle(eng, oracle, name):
 
 
 @pytest.mark.gpu
+def test_lopass_per_sample_coefficients_every_sinf_form(eng, oracle):
+    """Lopass(x, omega, k) (MLDSPFilters.h:136-152) picks the form of its two sinf per sample for the whole wavefront: the
+    sequences proven on [2^-12, pi_f] (the cosine polynomial only when a lane is in quadrant 1) with the range-free division when
+    every lane is regular, glibc's own algorithm with the IEEE division otherwise. Wavefronts (64 voices) of every kind, against
+    the oracle (host libm): omega swept densely through both quadrant thresholds and the 0.5 clamp, wavefronts that stay in
+    quadrant 0, and wavefronts in which a few lanes are irregular - omega negative, zero, tiny, NaN, infinite; k past 1.98, huge,
+    NaN, negative - for a few samples or throughout."""
+    V, T = 64 * 8, 6
+    S = 64 * T
+    n = np.arange(S)[None, :]
+    v = np.arange(V)[:, None]
+    w = v // 64
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 5, S)
+    thr1, thr2 = np.uint32(0x3F490FDB).view(np.float32), np.uint32(0x4016CBE4).view(np.float32)
+    pif = np.float32(np.pi)
+    omega = np.empty((V, S), np.float32)
+    k = (0.9 + 0.85 * np.sin(n * 0.013 + v)).astype(np.float32)       # 0.05 .. 1.75: regular
+    # wavefront 0: every lane below quadrant 1 (2 pi omega < 0.75); 1: a dense sweep 0 .. 0.5 .. clamp; 2, 3: around the thresholds
+    omega[0:64] = (0.002 + 0.1 * (0.5 + 0.5 * np.sin(n * 0.02 + v[0:64]))).astype(np.float32)
+    omega[64:128] = ((n + 7 * (v[64:128] - 64)) % 640 / 1200.0).astype(np.float32)
+    for base, thr, scale in ((128, thr1, 1.0), (160, thr1, 2.0), (192, thr2, 2.0), (224, pif, 2.0)):
+        # omega whose pi * omega (scale 1) or 2 pi * omega (scale 2) lands within a few ulps of thr
+        c = np.float32(thr / (scale * pif))
+        ulps = (((n + 3 * v[base:base + 32]) % 41) - 20).astype(np.int32)
+        omega[base:base + 32] = (c.view(np.uint32).astype(np.int64) + ulps).astype(np.uint32).view(np.float32)
+    # wavefronts 4 - 7: regular sweeps with irregular lanes
+    omega[256:] = (0.25 + 0.24 * np.sin(n * 0.004 * (1 + v[256:] % 5))).astype(np.float32)
+    bad_omega = np.array([-0.1, 0.0, -0.0, 1e-5, 2.0 ** -14, np.nan, np.inf, -np.inf, 7.0, 1e-42], np.float32)
+    bad_k = np.array([1.99, 2.0, 2.5, 1e6, np.nan, -3.0, np.inf, 3e38, 1.9800001, 0.0], np.float32)
+    for i in range(10):
+        omega[256 + 6 * i, 40:70] = bad_omega[i]                       # wavefront 4 (and 5): for 30 samples
+        omega[384 + 5 * i, :] = bad_omega[i]                           # wavefront 6: throughout
+        k[320 + 6 * i, 100:140] = bad_k[i]                             # wavefront 5
+        k[448 + 6 * i, :] = bad_k[i]                                   # wavefront 7
+    case = dict(kind=Proc.LOPASS, coeffs=np.zeros((3, V), np.float32), inputs=[("audio", x), ("audio", omega), ("audio", k)])
+    g, names = single_node_graph(eng, V, case)
+    st = oracle.chain_clear([Proc.LOPASS], V)
+    (got,) = g.process_host(T, {names[0]: x, names[1]: omega, names[2]: k}, Layout.QUAD)
+    want = oracle.proc_multi(Proc.LOPASS, T, case["coeffs"], st, [x, omega, k])
+    gst = np.stack([g.get_state("p", i) for i in range(2)])
+    both_nan = np.isnan(got) & np.isnan(want)
+    bad = (got.view(np.uint32) != want.view(np.uint32)) & ~both_nan
+    assert not bad.any(), (np.argwhere(bad)[:8], got[bad][:8], want[bad][:8])
+    sb = (gst.view(np.uint32) != st.view(np.uint32)) & ~(np.isnan(gst.view(np.float32)) & np.isnan(st.view(np.float32)))
+    assert not sb.any(), np.argwhere(sb)[:8]
+    assert np.isfinite(want[:256]).all() and (np.abs(want[:256]) > 0).mean() > 0.9     # the regular wavefronts really filter
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", MULTI_CASES)
 def test_multi_input_forms_golden(eng, name):
     """Against the compiled reference's own outputs (tests/golden/multi.npz)."""

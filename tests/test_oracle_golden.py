@@ -1,6 +1,8 @@
 """Pin the plain-C oracle against (a) the committed golden vectors produced by the compiled
 reference, (b) the SURVEY Appendix-B anchors, (c) the reference's own test assertions
 (Tests/dspOpsTest.cpp:103-104,154,164; Tests/dspGensTest.cpp:31). Needs no reference tree."""
+import os
+
 import numpy as np
 import pytest
 
@@ -83,6 +85,30 @@ def test_restated_libm_sinf_against_host_libm(oracle):
     n, lst = oracle.sinf_check(0, 0xFFFFFFFF)
     xs = np.abs(lst.view(np.float32))
     assert n <= 12 and ((xs > 53.0) & (xs < 120.0)).all(), (n, [hex(x) for x in lst])
+
+
+def test_fast_sinf_forms_exhaustively(oracle):
+    """Lopass(x, omega, k) on the device computes its two sinf per sample with cheaper sequences than glibc's (Horner forms with
+    fused multiply-adds, the quadrant from two float comparisons; mldsp_math.hpp: libm_sinf_direct for arguments in [2^-12, 0.75),
+    libm_sinf_0_pi for [2^-12, pi_f]) - legitimate only because their rounded floats equal the host libm's for EVERY argument of
+    those domains. The same sequences in C, all 96 468 992 + 113 840 092 floats; and the two thresholds are where glibc's quadrant
+    steps."""
+    def bits(x):
+        return int(np.float32(x).view(np.uint32))
+    lo, direct_end, pi_f = bits(2.0 ** -12), bits(0.75), bits(np.float32(np.pi))
+    assert pi_f == 0x40490FDB and bits(np.float32(np.pi) * np.float32(0.5) * np.float32(2.0)) == pi_f   # the largest argument: 2 (pi_f * 0.5)
+    n, first = oracle.sinf_fast_check(0, lo, direct_end - 1)
+    assert n == 0, hex(first)
+    n, first = oracle.sinf_fast_check(1, lo, pi_f)
+    assert n == 0, hex(first)
+    for thr, q in ((0x3F490FDB, 1), (0x4016CBE4, 2)):       # kSinfT1, kSinfT2
+        below, at = np.uint32(thr - 1).view(np.float32), np.uint32(thr).view(np.float32)
+        assert oracle.sinf_quadrant(below) == q - 1 and oracle.sinf_quadrant(at) == q
+    src = open(os.path.join(os.path.dirname(__file__), "..", "madronalib_amd", "csrc", "mldsp_math.hpp")).read()
+    assert "kSinfT1 = 0x1.921fb6p-1f, kSinfT2 = 0x1.2d97c8p+1f, kSinfMax = 0x1.921fb6p+1f" in src
+    assert float.fromhex("0x1.921fb6p-1") == float(np.uint32(0x3F490FDB).view(np.float32))
+    assert float.fromhex("0x1.2d97c8p+1") == float(np.uint32(0x4016CBE4).view(np.float32))
+    assert float.fromhex("0x1.921fb6p+1") == float(np.uint32(pi_f).view(np.float32))
 
 
 @pytest.mark.parametrize("name", list(ROWS_CASES))
