@@ -485,8 +485,8 @@ MLD float libm_sinf(float y)
 // out as glibc does, that is 9-11 separate double operations per polynomial. The results below come from FEWER operations - Horner
 // forms with fused multiply-adds, 5 instead of 9 (sine) and 5 instead of 11 (cosine), the quadrant from two float comparisons -
 // whose doubles differ from glibc's in the last bits, but whose ROUNDED FLOATS do not, for any argument of the domain: checked
-// exhaustively, all 113 840 092 floats of [2^-12, pi_f], against the host libm (oracle/ml_oracle.c: mlorc_sinf_fast_check, the
-// same sequence in C; tests/test_oracle_golden.py::test_fast_sinf_forms_exhaustively; below 0.75, where glibc skips the reduction,
+// exhaustively, all 113 840 092 floats of [2^-12, pi_f], against the host libm (the test suite's CPU checker holds the same
+// sequence in C: tests/test_oracle_golden.py::test_fast_sinf_forms_exhaustively; below 0.75, where glibc skips the reduction,
 // the quadrant is 0 and x = y - 0 is y itself). -(sine polynomial of x) is the sine
 // polynomial of -x exactly (every product and sum changes sign with its operands).
 // kSinfT1 / kSinfT2: the smallest floats whose quadrant ((int32)(y * 2/pi * 2^24) + 2^23) >> 24 is 1 / 2 (found by the same scan).

@@ -158,8 +158,10 @@ def test_register_budget_of_generated_kernels(monkeypatch):
         return (re.search(r"__launch_bounds__\([^)]*\)", source).group(0), int(re.search(r"\.vgpr_count:\s+(\d+)", notes).group(1)),
                 int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", notes).group(1)))
     monkeypatch.delenv("MLGPU_GRAPH_MIN_WAVES", raising=False)
-    bounds, vgpr, scratch = build(262144)                      # the 16-node voice fits four wavefronts per SIMD as it is
-    assert bounds == "__launch_bounds__(256)" and vgpr <= 128 and scratch == 0
+    # the 16-node voice: with its streamed gate a quad ahead (round 4) it comes out a few registers above 128 - 133 means blocks of
+    # 136, three wavefronts per SIMD - and is bounded too, for a handful of words kept in scratch outside the sample loop
+    bounds, vgpr, scratch = build(262144)
+    assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and scratch <= 64
     bounds, vgpr, scratch = build(262144, full=True)           # the 22-node patch does not: bounded, with a little scratch
     assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and 0 < scratch <= 640
     bounds, vgpr, scratch = build(262144, pitch_input=True, event_rows=True)   # EventsToSignals' rows inside: far above, bounded too
