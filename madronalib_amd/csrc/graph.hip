@@ -484,6 +484,11 @@ struct mlgpu_graph
   int compiledVoicesPerLane{1};
   int unrollQ{1};                // quads per trip of the sample loop
   int oscTripQ{2};               // quads per trip of the oscillators' sparse polyBLEP (0: per sample; mldsp_procs.hpp: trip_u)
+  std::string waveClockPath;     // MLGPU_GRAPH_WAVE_CLOCK=<file>: every wavefront of a launch stamps its start and end; the last launch's table is written there
+  unsigned long long* d_waveClock{nullptr};
+  bool lockOscillators{true};    // a SawGen and a PulseGen on one frequency node share their trip while their phase counters are equal; MLGPU_GRAPH_LOCK_OSC=0 for A / B
+  int takeTurns{2};              // the wavefronts of a SIMD rotate through the priority levels (mldsp_math.hpp): 0 off, 1 by their own progress, 2 by the shared clock; MLGPU_GRAPH_TURNS
+  int turnClockShift{13};        // a turn of the clock form lasts 2^shift ticks of 10 ns (82 us: the best of 2^7 .. 2^18, profiles/r04_take_turns.txt); MLGPU_GRAPH_TURN_CLOCK
   int prefetchQ{1};              // streamed inputs are loaded one quad ahead of their use (0: where they are used)
   std::string lastError;         // mlgpu_graph_last_error
   mlgpu_events* events{nullptr}; // mlgpu_graph_bind_events: the object the NODE_EVENT_ROW nodes read
@@ -567,6 +572,25 @@ static bool isOscTrip(const mlgpu_graph* g, const Node& n)
   if (n.kind != MLGPU_PROC_SAW_GEN && n.kind != MLGPU_PROC_PULSE_GEN) return false;
   if (n.in.empty() || g->nodes[n.in[0]].rate != RATE_VOICE) return false;
   return n.kind == MLGPU_PROC_SAW_GEN || n.in.size() == 1 || g->nodes[n.in[1]].rate == RATE_VOICE;
+}
+// The PulseGen trip node on the same frequency node as SawGen trip node i (-1: none): the pair is run by trip_locked when, at the
+// start of a launch, every lane of the wavefront has the two phase counters equal (mldsp_procs.hpp).
+static int lockedPartner(const mlgpu_graph* g, size_t i)
+{
+  const Node& n = g->nodes[i];
+  if (!g->lockOscillators || !isOscTrip(g, n) || n.kind != MLGPU_PROC_SAW_GEN) return -1;
+  for (size_t j = 0; j < g->nodes.size(); ++j)
+  {
+    const Node& m = g->nodes[j];
+    if (isOscTrip(g, m) && m.kind == MLGPU_PROC_PULSE_GEN && m.in[0] == n.in[0])
+    {
+      // the first saw on that frequency takes the first pulse on it
+      for (size_t k = 0; k < i; ++k)
+        if (isOscTrip(g, g->nodes[k]) && g->nodes[k].kind == MLGPU_PROC_SAW_GEN && g->nodes[k].in[0] == n.in[0]) return -1;
+      return (int)j;
+    }
+  }
+  return -1;
 }
 static bool hasOscTrips(const mlgpu_graph* g)
 {
@@ -714,6 +738,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   s << "  size_t blk = blockIdx.x;\n  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;\n"
        "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n"
        "  const size_t v_0 = blk * " << 256 * VL << " + threadIdx.x;\n  if (v_0 >= a.V) return;\n";
+  if (!g->waveClockPath.empty()) s << "  const unsigned long long waveClock0 = __builtin_amdgcn_s_memrealtime();\n";
   // a lane whose second voice does not exist recomputes its first one: same inputs, same state, same stores
   for (int l = 1; l < VL; ++l) s << "  const size_t v" << sfx(l) << " = (v_0 + " << 256 * l << " < a.V) ? v_0 + " << 256 * l << " : v_0;\n";
   auto emit = [&](size_t i, const char* indent) {
@@ -788,6 +813,14 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << ") != 0;\n";
     }
   }
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+  {
+    const int j = lockedPartner(g, i);
+    if (j < 0) continue;
+    s << "  const bool locked" << i << " = !dense" << i << " && !dense" << j << " && __builtin_amdgcn_ballot_w64(";
+    for (int l = 0; l < VL; ++l) s << (l ? " || " : "") << "p" << i << sfx(l) << ".omega32 != p" << j << sfx(l) << ".omega32";
+    s << ") == 0;\n";
+  }
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l)
     {
@@ -812,6 +845,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (int i = 0; PF && i < g->nInputs; ++i)
     for (int l = 0; l < VL; ++l)
       s << "  const f32x4* pf" << i << sfx(l) << " = in" << i << sfx(l) << ";\n  f32x4 nx" << i << sfx(l) << " = __builtin_nontemporal_load(pf" << i << sfx(l) << ");\n";
+  if (g->takeTurns) s << "  const uint32_t turn0 = wave_slot();\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
   // (Round 3, measured and not kept - profiles/r03_synthfused_variants.txt: a second instance of the vector body, or of the
   // whole vector loop, for wavefronts without event records - EventsVoice::begin_vector / quad<true>, no record walk, no
@@ -844,21 +878,55 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     // the quads in trips of oscTripQ: the oscillators' samples of a trip first, then its quads (fully unrolled: qq is a constant)
     const int tq = g->oscTripQ, unroll = (g->windowedRings && g->totalRings) ? 1 : std::max(1, g->unrollQ / tq);
     s << "#pragma unroll " << unroll << "\n    for (int q2 = 0; q2 < 16; q2 += " << tq << ")\n    {\n";
+    if (g->takeTurns == 2) s << "    take_turns_by_clock(turn0, " << g->turnClockShift << ");\n";
+    else if (g->takeTurns) s << "    take_turns(turn0 + (uint32_t)t * " << 16 / tq << "u + (uint32_t)(q2 / " << tq << "));\n";
+    std::vector<char> paired(g->nodes.size(), 0);
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+      if (lockedPartner(g, i) >= 0) paired[i] = paired[(size_t)lockedPartner(g, i)] = 1;
     for (size_t i = 0; i < g->nodes.size(); ++i)
     {
       const Node& n = g->nodes[i];
       if (!isOscTrip(g, n)) continue;
+      for (int l = 0; l < VL; ++l) s << "    float osc" << i << sfx(l) << "[" << tq * 4 << "];\n";
+      if (paired[i]) continue;  // made with its partner below
       for (int l = 0; l < VL; ++l)
       {
-        s << "    float osc" << i << sfx(l) << "[" << tq * 4 << "];\n    p" << i << sfx(l) << ".trip_u<" << tq * 4 << ">(n" << n.in[0] << sfx(l);
+        s << "    p" << i << sfx(l) << ".trip_u<" << tq * 4 << ">(n" << n.in[0] << sfx(l);
         if (n.in.size() == 2) s << ", n" << n.in[1] << sfx(l);
         s << ", odd" << i << ", dense" << i << ", osc" << i << sfx(l) << ");\n";
       }
     }
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+    {
+      const int j = lockedPartner(g, i);
+      if (j < 0) continue;
+      const Node &n = g->nodes[i], &m = g->nodes[(size_t)j];
+      auto width = [&](int l) { return m.in.size() == 2 ? "n" + std::to_string(m.in[1]) + sfx(l) : "p" + std::to_string(j) + sfx(l) + ".width"; };
+      for (int l = 0; l < VL; ++l) s << "    const uint32_t keep" << i << sfx(l) << " = p" << i << sfx(l) << ".omega32, keep" << j << sfx(l) << " = p" << j << sfx(l) << ".omega32;\n";
+      s << "    bool made" << i << " = locked" << i << ";\n";
+      for (int l = 0; l < VL; ++l)
+        s << "    if (made" << i << ") made" << i << " = trip_locked<" << tq * 4 << ">(p" << i << sfx(l) << ", p" << j << sfx(l) << ", n" << n.in[0] << sfx(l) << ", " << width(l)
+          << ", osc" << i << sfx(l) << ", osc" << j << sfx(l) << ");\n";
+      // (two voices per lane: a suspect trip of the second voice sends both back - the first one's counters are restored below)
+      s << "    if (!made" << i << ")\n    {\n";
+      for (int l = 0; l < VL; ++l)
+      {
+        s << "      p" << i << sfx(l) << ".omega32 = keep" << i << sfx(l) << ";\n      p" << j << sfx(l) << ".omega32 = keep" << j << sfx(l) << ";\n";
+        s << "      p" << i << sfx(l) << ".trip_u<" << tq * 4 << ">(n" << n.in[0] << sfx(l) << ", odd" << i << ", dense" << i << ", osc" << i << sfx(l) << ");\n";
+        s << "      p" << j << sfx(l) << ".trip_u<" << tq * 4 << ">(n" << m.in[0] << sfx(l);
+        if (m.in.size() == 2) s << ", n" << m.in[1] << sfx(l);
+        s << ", odd" << j << ", dense" << j << ", osc" << j << sfx(l) << ");\n";
+      }
+      s << "    }\n";
+    }
     s << "#pragma unroll\n    for (int qq = 0; qq < " << tq << "; ++qq)\n    {\n      const int q = q2 + qq;\n";
   }
   else
+  {
     s << "#pragma unroll " << ((g->windowedRings && g->totalRings) ? 1 : g->unrollQ) << "\n    for (int q = 0; q < 16; ++q)\n    {\n";
+    if (g->takeTurns == 2) s << "      if ((q & 1) == 0) take_turns_by_clock(turn0, " << g->turnClockShift << ");\n";
+    else if (g->takeTurns) s << "      if ((q & 1) == 0) take_turns(turn0 + (uint32_t)t * 8u + (uint32_t)(q >> 1));\n";
+  }
   // the next quad's address: one step on; from a vector's last quad to the next vector's first; the launch's last quad stays
   if (PF) s << "      const bool lastQ = (q == 15), lastT = (t + 1 == a.T);\n";
   for (int i = 0; i < g->nInputs; ++i)
@@ -1040,6 +1108,10 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC)
       for (int l = 0; l < VL; ++l) s << "  p" << i << sfx(l) << ".store(m" << i << sfx(l) << ");\n";
+  if (!g->waveClockPath.empty())
+    s << "  if ((threadIdx.x & 63) == 0 && a.waveClock)\n  {\n    unsigned long long* w = a.waveClock + (blk * 4 + threadIdx.x / 64) * 4;\n"
+         "    w[0] = waveClock0;\n    w[1] = __builtin_amdgcn_s_memrealtime();\n    w[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));\n"
+         "    w[3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));\n  }\n";
   s << "}\n";
   return s.str();
 }
@@ -1357,6 +1429,18 @@ extern "C"
     {
       hipSetDevice(g->e->device);
       hipStreamSynchronize(g->e->stream);
+    }
+    if (g->d_waveClock)
+    {
+      const size_t words = (g->V + 255) / 256 * 4 * 4;
+      std::vector<unsigned long long> host(words);
+      if (hipMemcpy(host.data(), g->d_waveClock, words * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess)
+        if (FILE* f = fopen(g->waveClockPath.c_str(), "wb"))
+        {
+          fwrite(host.data(), sizeof(unsigned long long), words, f);
+          fclose(f);
+        }
+      hipFree(g->d_waveClock);
     }
     if (g->d_coeffs) hipFree(g->d_coeffs);
     if (g->d_state) hipFree(g->d_state);
@@ -1716,6 +1800,10 @@ extern "C"
     const char* forced = getenv("MLGPU_GRAPH_UNROLL");  // developer knob: quads per trip of the sample loop
     // delay graphs wait on their ring reads: two quads per trip keep more of them in flight (allpass4: 5.4 vs 4.5 x 10^10)
     g->unrollQ = forced ? std::max(1, atoi(forced)) : ((g->totalRings && !g->windowedRings) ? 2 : 1);
+    if (const char* wc = getenv("MLGPU_GRAPH_WAVE_CLOCK")) g->waveClockPath = wc;
+    if (const char* tt = getenv("MLGPU_GRAPH_TURNS")) g->takeTurns = std::min(2, std::max(0, atoi(tt)));
+    if (const char* tc = getenv("MLGPU_GRAPH_TURN_CLOCK")) g->turnClockShift = std::min(24, std::max(0, atoi(tc)));
+    if (const char* lk = getenv("MLGPU_GRAPH_LOCK_OSC")) g->lockOscillators = atoi(lk) != 0;
     if (const char* pf = getenv("MLGPU_GRAPH_PREFETCH")) g->prefetchQ = atoi(pf) != 0;  // developer knob (A / B)
     if (const char* trip = getenv("MLGPU_GRAPH_OSC_TRIP"))  // developer knob: 0 = polyBLEP per sample (A / B), else 1, 2 or 4 quads per trip
     {
@@ -2070,6 +2158,12 @@ extern "C"
     a.t0 = g->vectorCount;
     a.flags = g->e->kflags;
     a.impulseTable = g->e->d_impulseTable;
+    if (!g->waveClockPath.empty())
+    {
+      const size_t waves = (g->V + 255) / 256 * 4;
+      if (!g->d_waveClock && hipMalloc((void**)&g->d_waveClock, waves * 4 * sizeof(unsigned long long)) != hipSuccess) g->d_waveClock = nullptr;
+      a.waveClock = g->d_waveClock;
+    }
     for (int i = 0; i < g->nInputs; ++i)
     {
       if (!d_inputs[i] || ((uintptr_t)d_inputs[i] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned input");

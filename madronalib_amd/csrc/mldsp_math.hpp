@@ -32,6 +32,38 @@ MLD void apply_fp_mode(uint32_t flags)
   if (flags & 1u /* MLGPU_KFLAG_FLUSH_DENORMALS */) __builtin_amdgcn_s_setreg(1 | (4 << 6) | (1 << 11), 0);
 }
 
+// A SIMD picks, among the wavefronts that are ready, the one with the highest priority and then the OLDEST: left alone, the first
+// wavefront of a SIMD runs ahead of the others for the whole launch. A voice bank is launched as exactly as many wavefronts as the
+// chip holds (4 per SIMD at 262 144 voices), nothing is waiting to take a finished wavefront's place, and so the launch ends with a
+// long stretch of three, two and at last one wavefront per SIMD - and one wavefront alone issues at 40 % of a SIMD's rate (DESIGN
+// 3.11). Measured with per-wavefront clocks (tools/wave_clock.py): config 5's wavefronts ended at 52 %, 60 %, 80 % and 100 % of the
+// launch. The cure is to take turns: every `turn` (a trip of a few samples) a wavefront takes the next of the four priority levels,
+// offset by its hardware slot, so the wavefronts of a SIMD hold four different levels that rotate - each gets the same share, they
+// arrive together, and the SIMD keeps its full issue rate to the end. (s_setprio takes an immediate: hence the switch.)
+MLD uint32_t wave_slot() { return (uint32_t)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u; }  // HW_REG_HW_ID.wave_id
+// the same by the clock all wavefronts share (100 MHz): the four levels rotate every 2^shift ticks whatever the wavefront's own progress
+MLD void take_turns_by_clock(uint32_t slot, int shift)
+{
+  const uint32_t now = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> shift);
+  switch ((now + slot) & 3u)
+  {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+MLD void take_turns(uint32_t turn)
+{
+  switch (turn & 3u)
+  {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
 MLD float u2f(uint32_t u) { return __uint_as_float(u); }
 MLD uint32_t f2u(float f) { return __float_as_uint(f); }
 

@@ -1715,6 +1715,53 @@ struct Proc<MLGPU_PROC_TEMPO_LOCK>  // C{}  S{omega, x1v}
 
 // Processors with a cheaper evaluation for well-behaved, launch-constant input declare
 // next_fast(x) and input_is_odd(x); the kernel tests input_is_odd once per launch.
+// A SawGen and a PulseGen on the same per-voice frequency whose phase counters are EQUAL (reset together, as the two waveforms of
+// one analog-style oscillator always are): they advance by the same step every sample, so they stay equal, and a trip needs the
+// phases, their extremes, the two corrections of the step at phase 0 and the zone tests only once - the saw subtracts the very
+// value the pulse adds (both are `lo ? cLo : hi ? cHi : 0` of the same operands). The caller asks once per launch whether every
+// lane of the wavefront has the two counters equal and neither oscillator is dense (`locked`, graph.hip); otherwise, or when the
+// trip is suspect, the two processors make their own trips as before. Same operands through the same operations: the same bits.
+// Returns false, with nothing done, when the trip is suspect: the caller then runs the two trips one by one.
+template <int N>
+MLD bool trip_locked(Proc<MLGPU_PROC_SAW_GEN>& saw, Proc<MLGPU_PROC_PULSE_GEN>& pulse, float cps, float w, float (&outSaw)[N], float (&outPulse)[N])
+{
+  {
+    const BlepFreq<true> f = BlepFreq<true>::make(cps);
+    const float dtS = f.dt * kPhaseScale, omdtS = f.omdt * kPhaseScale, wS = w * kPhaseScale;
+    uint32_t omega32 = saw.omega32;
+    float h[N], d[N];
+    uint32_t lo = 0u, hi = 0u, dlo = 0u, dhi = 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+      h[i] = phasor_next_hi(omega32, cps);
+      d[i] = __builtin_amdgcn_fractf(__builtin_fmaf(h[i], kPhaseUnit, -w) + 1.0f);
+      lo = i ? trip_umin(lo, f2u(h[i])) : f2u(h[i]);
+      hi = i ? trip_umax(hi, f2u(h[i])) : f2u(h[i]);
+      dlo = i ? trip_umin(dlo, f2u(d[i])) : f2u(d[i]);
+      dhi = i ? trip_umax(dhi, f2u(d[i])) : f2u(d[i]);
+    }
+    const bool suspect = u2f(lo) < kTripTiny * kPhaseScale || u2f(hi) > kTripNearOne * kPhaseScale || u2f(dlo) < kTripTinyShifted || u2f(dhi) > kTripNearOneShifted;
+    if (__builtin_amdgcn_ballot_w64(suspect) == 0)
+    {
+      const float cLo = f.correction(u2f(lo) * kPhaseUnit, true, false), cHi = f.correction(u2f(hi) * kPhaseUnit, false, false);
+      const float cDownLo = f.correction(u2f(dlo), true, false), cDownHi = f.correction(u2f(dhi), false, false);
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+      {
+        const float cUp = (h[i] < dtS) ? cLo : ((h[i] > omdtS) ? cHi : 0.f);
+        const float cDown = f.lo(d[i]) ? cDownLo : (f.hi(d[i]) ? cDownHi : 0.f);
+        outSaw[i] = __builtin_fmaf(h[i], 2.f * kPhaseUnit, -1.f) - cUp;
+        outPulse[i] = (((h[i] >= wS) ? -1.f : 1.f) + cUp) - cDown;
+      }
+      saw.omega32 = omega32;
+      pulse.omega32 = omega32;
+      return true;
+    }
+  }
+  return false;
+}
+
 template <class P, class = void>
 struct HasFastPath
 {

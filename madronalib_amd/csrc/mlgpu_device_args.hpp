@@ -75,4 +75,5 @@ struct GraphArgs
   size_t t0;  // DSPVectors processed since the last clear (a Downsample2xFunction region pairs vectors 2k, 2k + 1)
   uint32_t flags;  // MLGPU_KFLAG_*
   EventsDev events;
+  unsigned long long* waveClock;  // developer aid (MLGPU_GRAPH_WAVE_CLOCK): [wavefront][4] = start, end (100 MHz), HW_ID, XCC_ID; else nullptr
 };

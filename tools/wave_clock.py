@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU): when does each wavefront of a fused graph kernel start and end? MLGPU_GRAPH_WAVE_CLOCK makes the generated
+kernel stamp s_memrealtime (100 MHz) at entry and exit of every wavefront; this runs a workload's graph a few times, reads the last
+launch's table and prints the distribution: launch span, per-wavefront life, when the first / median / last wavefront ends, and the
+same per XCD.   python tools/wave_clock.py cfg5|cfg5full [voices]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+path = os.path.join(tempfile.gettempdir(), "mlgpu_wave_clock.bin")
+os.environ["MLGPU_GRAPH_WAVE_CLOCK"] = path
+import madronalib_amd as ml  # noqa: E402
+from madronalib_amd import patches  # noqa: E402
+from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params  # noqa: E402
+
+w = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
+V = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
+T = 16
+full = w == "cfg5full"
+eng = ml.Engine(0)
+n = V * T * 64
+d_gate = eng.to_device(cfg5_gate_quad(0, V, T))
+d_out = eng.alloc(4 * n)
+desc, outs = patches.synth16(full=full)
+g = ml.Graph(eng, V, desc, outs, voices_per_lane=1)
+g.clear()
+params, coeffs, seeds = cfg5_voice_params(0, V, V, ml, full=full)
+for k, x in params.items():
+    g.set_param(k, x if np.ndim(x) else float(x))
+for k, c in coeffs.items():
+    g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+g.set_state("noise", 0, seeds)
+for _ in range(30):
+    g.process(T, [d_gate], [d_out])
+eng.sync()
+eng.timer_start()
+g.process(T, [d_gate], [d_out])
+ms = eng.timer_stop_ms()
+g.close()
+t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
+t0, t1 = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
+xcc = (t[:, 3] & 0xF).astype(int)
+hw = t[:, 2]
+cu, se, simd, wave_slot = (hw >> 8) & 0xF, (hw >> 13) & 0x7, (hw >> 4) & 0x3, hw & 0xF
+base = t0.min()
+us = lambda x: (x - base) / 100.0
+life = (t1 - t0) / 100.0
+print(f"{w}: {len(t)} wavefronts, launch {ms * 1000:.1f} us by HIP events; first start 0, last start {us(t0.max()):.1f} us, first end {us(t1.min()):.1f} us, "
+      f"median end {us(np.median(t1)):.1f} us, last end {us(t1.max()):.1f} us")
+print(f"  wavefront life: min {life.min():.1f}  p10 {np.percentile(life, 10):.1f}  median {np.median(life):.1f}  p90 {np.percentile(life, 90):.1f}  max {life.max():.1f} us"
+      f"   mean life / launch span = {life.mean() / us(t1.max()):.3f}")
+for x in sorted(set(xcc)):
+    m = xcc == x
+    print(f"  XCD {x}: {m.sum():5d} wavefronts  starts {us(t0[m].min()):7.1f}..{us(t0[m].max()):7.1f}  ends {us(t1[m].min()):7.1f}..{us(t1[m].max()):7.1f}  median life {np.median(life[m]):7.1f}")
+# how many wavefronts are resident over time (per SIMD there is room for 4 of this kernel)
+grid = np.linspace(0, us(t1.max()), 21)
+res = [int(((us(t0) <= x) & (us(t1) > x)).sum()) for x in grid]
+print("  resident wavefronts at 5 % steps of the span:", res)
+slots = len(set(zip(xcc.tolist(), se.tolist(), cu.tolist(), simd.tolist())))
+sid = (((xcc * 8 + se.astype(int)) * 16 + cu.astype(int)) * 4 + simd.astype(int))
+print(f"  distinct (XCD, SE, CU, SIMD) seen: {slots}; wavefronts per SIMD: min {np.bincount(sid).min()} max {np.bincount(sid).max()}; hardware wave slots used: {sorted(set(wave_slot.astype(int).tolist()))}")
+# by voice block: does a wavefront's life depend on where its voices are?
+k = len(t) // 8
+print("  median life by eighth of the voice range:", [round(float(np.median(life[i * k:(i + 1) * k])), 1) for i in range(8)])
