@@ -21,6 +21,11 @@ namespace mldev
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kChainBlock = 256;
+// the wavefronts of a SIMD take turns at the priority levels (mldsp_math.hpp: take_turns_by_clock) - 0 for A / B builds
+#ifndef MLGPU_CHAIN_TURNS
+#define MLGPU_CHAIN_TURNS 1
+#endif
+constexpr int kTurnClockShift = 13;  // 82 us per turn (graph kernels: the best of 2^7 .. 2^18 ticks, profiles/r04_take_turns.txt)
 
 // the streaming loop of one voice: T DSPVectors, 16 quads each, one 16-byte access per quad
 template <class CH, bool HAS_SIGNAL, bool FAST_HEAD>
@@ -29,6 +34,9 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
   const f32x4* pin = HAS_SIGNAL ? (const f32x4*)a.in.base + v * a.in.strideV : nullptr;
   f32x4* pout = (f32x4*)a.out.base + v * a.out.strideV;
   const size_t inQ = a.in.strideQ, outQ = a.out.strideQ;
+#if MLGPU_CHAIN_TURNS
+  const uint32_t slot = wave_slot();
+#endif
   for (size_t t = 0; t < a.T; ++t)
   {
     const f32x4* pi = HAS_SIGNAL ? pin + t * a.in.strideT : nullptr;
@@ -36,6 +44,9 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
 #pragma unroll 4
     for (int q = 0; q < 16; ++q)
     {
+#if MLGPU_CHAIN_TURNS
+      if ((q & 3) == 0) take_turns_by_clock(slot, kTurnClockShift);
+#endif
       f32x4 x = {xc, xc, xc, xc};
       if constexpr (HAS_SIGNAL) x = __builtin_nontemporal_load(pi + q * inQ);
       f32x4 y;
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
   // loads of the NEXT trip are issued at the top of a trip and consumed a whole trip (QT * 4 ticks of arithmetic) later.
   // QT = 4 (4 KiB of loads in flight per wave) is the measured optimum on config 4: QT = 8 takes all 256 registers and runs
   // 0.570 ms against 0.477, QT = 16 0.491 (round 2, 131 072 channels x 32 DSPVectors) - the kernel is not waiting for its
-  // loads; it sits at 92-94 % of what the same access pattern reaches with no arithmetic at all (tools/copybench.hip).
+  // loads (round 3's account, profiles/r03_cfg4_account.md: it is bound by VALU issue, and the streams cost it clock).
   constexpr int QT = MLGPU_CASCADE_QUADS_PER_TRIP;
   const size_t Q = (S - D) / 4;
   size_t q = 0;
@@ -597,8 +608,14 @@ __device__ __forceinline__ void cascade_lanes_body(const ChainArgs& a)
       if (last) __builtin_nontemporal_store(y, (f32x4*)ps);
       ps += s == 15 ? outNext : outStep;
     };
+#if MLGPU_CHAIN_TURNS
+    const uint32_t slot = wave_slot();
+#endif
     for (size_t t = 0; t < a.T; ++t)
     {
+#if MLGPU_CHAIN_TURNS
+      take_turns_by_clock(slot, kTurnClockShift);
+#endif
       const bool lastVector = (t + 1 == a.T);
       // where the fetch pointer goes when it leaves a vector: on to the next one, or - from the launch's last vector - back
       // to that vector's start

@@ -824,14 +824,18 @@ def test_tempo_lock_following_a_computed_phasor(eng, oracle, hostile):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("trip_quads,vpl", [(2, 1), (2, 2), (1, 1), (4, 1), (0, 1)])
-def test_oscillator_trips_on_the_knife_edges(eng, oracle, trip_quads, vpl, monkeypatch):
+@pytest.mark.parametrize("trip_quads,vpl,unlock", [(2, 1, False), (2, 2, False), (1, 1, False), (4, 1, False), (0, 1, False), (2, 1, True), (2, 2, True)])
+def test_oscillator_trips_on_the_knife_edges(eng, oracle, trip_quads, vpl, unlock, monkeypatch):
     """SawGen / PulseGen nodes with per-voice frequency (and width) get their polyBLEP corrections once per zone per trip of
     `trip_quads` quads (mldsp_procs.hpp: trip_u; MLGPU_GRAPH_OSC_TRIP, default 2; 0 = per sample). The short cut rests on "at most one
     sample of a trip in each zone", which rounding can break next to a wrap - those trips must be recognised and evaluated per sample.
     Voices placed on the edges: phases landing 0..23 units after a wrap, 0..368 units before one, and within -128 .. +608 units of the pulse's
     falling step, some 1..37 samples into the launch; widths 0, 1, dt, 1 - dt, dt / 2 among random ones; frequencies at and around
-    the trip forms' limit (1 / 2N), wavefronts entirely below it and mixed ones. Outputs and final phases against the oracle."""
+    the trip forms' limit (1 / 2N), wavefronts entirely below it and mixed ones. Outputs and final phases against the oracle.
+    Round 4: the SawGen and the first PulseGen sit on one frequency node, and with equal phase counters (all of them here, unless
+    `unlock`) a wavefront makes the two trips as one (mldsp_procs.hpp: trip_locked). `unlock`: the PulseGen's counters differ from
+    the SawGen's - by one unit in a single lane of some wavefronts, altogether in a quarter of the voices - so those wavefronts
+    make their trips one by one, next to wavefronts that stay locked."""
     import madronalib_amd as ml
     monkeypatch.setenv("MLGPU_GRAPH_OSC_TRIP", str(trip_quads))
     V, T = 16384, 2
@@ -875,9 +879,15 @@ def test_oscillator_trips_on_the_knife_edges(eng, oracle, trip_quads, vpl, monke
     g.set_param("f", freq)
     g.set_param("w", width)
     g.set_coeffs("pc", [width])
+    start = {nm: phases.copy() for nm in outs}
+    if trip_quads:
+        assert ("trip_locked<" in g.source) and "locked2" in g.source     # node 2 (the saw) is paired with node 3
+    if unlock:
+        start["pw"][64 * 5 + 3::64 * 7] ^= np.uint32(1)
+        start["pw"][V // 4:V // 2] = rng.integers(0, 2 ** 32, V // 2 - V // 4, dtype=np.uint64).astype(np.uint32)
     for nm in outs:
-        g.set_state(nm, 0, phases)
-    states = {nm: np.ascontiguousarray(phases[None, :].copy()) for nm in outs}
+        g.set_state(nm, 0, start[nm])
+    states = {nm: np.ascontiguousarray(start[nm][None, :].copy()) for nm in outs}
     for call in range(2):
         got = g.process_host(T, {}, Layout.QUAD)
         want = evaluate(oracle, desc, outs, V, T, {}, {"f": freq, "w": width}, {"pc": width[None, :]}, states)
