@@ -906,8 +906,10 @@ int mlgpu_process_buffer_process(mlgpu_process_buffer* p, const float* const* in
 
 /* Sum the voices of a signal into ONE single-voice signal of 64*n_vectors floats (what a Synth does with
  * `outputs += voice` in its voice loop, source/app/MLSynth.h:43-57), optionally scaled by per-voice gains
- * (d_gains may be NULL). Summation order (deterministic, documented in DESIGN.md): pairwise tree inside each group
- * of 64 consecutive voices, then the groups left to right.
+ * (d_gains may be NULL). Summation order (deterministic): pairwise tree inside each group of 64 consecutive voices; then
+ * the group sums left to right, 64 consecutive ones at a time, and so their results, until one is left - for up to 4096 voices
+ * that is "the groups left to right". (Round 4. Before, ALL groups were added in one left-to-right chain: the same bits up to
+ * 4096 voices, other last bits above - and 480 us of serial additions per 64-frame block at 2^20 voices.)
  * The partial sums of the first stage need scratch memory: reserve it once at setup with mlgpu_mixdown_reserve for the
  * largest (voices, vectors) a process call will pass - mlgpu_mixdown itself never allocates and returns
  * MLGPU_ERR_INVALID when the reservation is too small. */

@@ -576,7 +576,8 @@ extern "C"
   {
     if (!e) return MLGPU_ERR_INVALID;
     if (e->recording) return fail(e, MLGPU_ERR_INVALID, "mixdown_reserve allocates: not while recording a sequence");
-    const size_t need = ((maxVoices + 63) / 64) * maxVectors * 64;
+    const size_t groups = (maxVoices + 63) / 64;
+    const size_t need = (groups + (groups + 63) / 64) * maxVectors * 64;  // the group sums, and their sums 64 at a time (later passes fit the first part again)
     if (need <= e->mixScratchFloats) return MLGPU_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -597,7 +598,7 @@ extern "C"
     if (layout < 0 || layout > MLGPU_LAYOUT_VOICE_MAJOR) return fail(e, MLGPU_ERR_INVALID, "mixdown: bad layout");
     // a process call never allocates (mlgpu.h: "no allocation inside process"): the partial sums live in scratch the host
     // reserved at setup
-    if (((V + 63) / 64) * T * 64 > e->mixScratchFloats)
+    if (((V + 63) / 64 + ((V + 63) / 64 + 63) / 64) * T * 64 > e->mixScratchFloats)
       return fail(e, MLGPU_ERR_INVALID, "mixdown: call mlgpu_mixdown_reserve(engine, max voices, max vectors) at setup (process calls do not allocate)");
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, mlgpu_launch_mixdown(sig, layout, V, T, gains, e->d_mixScratch, out, e->stream, e->kflags));

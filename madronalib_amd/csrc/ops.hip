@@ -639,8 +639,9 @@ hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStrea
 // ---------------------------------------------------------------------------------------------
 // mixdown: sum the voices of a signal into one single-voice signal (a Synth's `outputs += voice`, MLSynth.h:43-57).
 // Stage 1: one wavefront per group of 64 consecutive voices, lane = voice, fixed pairwise tree over the lanes
-// (a[i] += a[i + d] for d = 1, 2, ... 32); stage 2: the groups are added left to right. Missing voices of the last
-// group count as +0. The order is part of the contract so results are reproducible and checkable.
+// (a[i] += a[i + d] for d = 1, 2, ... 32); then the group sums are added left to right, 64 consecutive ones at a time,
+// and so are the results, until one is left (up to 4096 voices that is simply "the groups left to right"). Missing voices
+// of the last group count as +0. The order is part of the contract (include/mlgpu.h) so results are reproducible and checkable.
 namespace
 {
 __global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, size_t V, size_t T, const float* gains, float4* partial, uint32_t flags)
@@ -690,19 +691,24 @@ __global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, siz
   }
 }
 
-__global__ __launch_bounds__(256) void mixdown_stage2_kernel(const float4* partial, size_t groups, size_t nQuads, float4* out, uint32_t flags)
+// Rows of partial sums, 64 consecutive ones at a time, left to right: rows [64 r, 64 r + 64) of `in` -> row r of `out`. Applied
+// until one row is left (64 groups = 4096 voices per row after the first pass, 262 144 after the second, ...): the single serial
+// chain over ALL groups that this replaces took 16 384 dependent additions per sample for 2^20 voices - 480 us of a 64-frame
+// block whose voice kernel takes 62 (profiles/r04_rt_1M.json).
+__global__ __launch_bounds__(64) void mixdown_rows64_kernel(const float4* in, size_t rows, size_t nQuads, float4* out, uint32_t flags)
 {
   apply_fp_mode(flags);
-  const size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
   if (qi >= nQuads) return;
-  // left to right over the groups, as the contract says; the loads of 16 groups are in flight together
-  float4 acc = partial[qi];
+  const size_t first = r * 64, n = (rows - first < 64) ? rows - first : 64;
+  const float4* p = in + first * nQuads + qi;
+  float4 acc = p[0];
   size_t g = 1;
-  for (; g + 16 <= groups; g += 16)
+  for (; g + 16 <= n; g += 16)
   {
     float4 x[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) x[u] = partial[(g + u) * nQuads + qi];
+    for (int u = 0; u < 16; ++u) x[u] = p[(g + u) * nQuads];
 #pragma unroll
     for (int u = 0; u < 16; ++u)
     {
@@ -712,15 +718,15 @@ __global__ __launch_bounds__(256) void mixdown_stage2_kernel(const float4* parti
       acc.w = acc.w + x[u].w;
     }
   }
-  for (; g < groups; ++g)
+  for (; g < n; ++g)
   {
-    const float4 x = partial[g * nQuads + qi];
+    const float4 x = p[g * nQuads];
     acc.x = acc.x + x.x;
     acc.y = acc.y + x.y;
     acc.z = acc.z + x.z;
     acc.w = acc.w + x.w;
   }
-  out[qi] = acc;
+  out[r * nQuads + qi] = acc;
 }
 }  // namespace
 
@@ -843,8 +849,21 @@ hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T
   if (y < 1) y = 1;
   hipLaunchKernelGGL(mixdown_stage1_kernel, dim3((unsigned)groups, y), dim3(256), 0, stream, makeView(sig, layout, V, T), V, T, gains,
                      (float4*)partial, flags);
-  hipLaunchKernelGGL(mixdown_stage2_kernel, dim3((unsigned)((nQuads + 63) / 64)), dim3(64), 0, stream, (const float4*)partial, groups, nQuads,
-                     (float4*)out, flags);
+  // the rows of group sums (in `partial`), 64 at a time, until one is left; the passes alternate between the two parts of the
+  // scratch (mlgpu_mixdown_reserve: the second holds the first pass's rows / 64), the last one writes `out`
+  float4* a = (float4*)partial;
+  float4* b = a + groups * nQuads;
+  size_t rows = groups;
+  do
+  {
+    const size_t rowsOut = (rows + 63) / 64;
+    hipLaunchKernelGGL(mixdown_rows64_kernel, dim3((unsigned)((nQuads + 63) / 64), (unsigned)rowsOut), dim3(64), 0, stream, (const float4*)a, rows, nQuads,
+                       rowsOut == 1 ? (float4*)out : b, flags);
+    float4* t = a;
+    a = b;
+    b = t;
+    rows = rowsOut;
+  } while (rows > 1);
   return hipGetLastError();
 }
 

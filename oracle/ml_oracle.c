@@ -1844,15 +1844,17 @@ int mlorc_demultiplex(const float* sel, size_t sel_elems, const float* in, float
 }
 
 /* mixdown, same contract and the SAME summation order as mlgpu_mixdown (include/mlgpu.h): pairwise tree inside each
- * group of 64 consecutive voices (a[i] += a[i + d], d = 1, 2, ... 32; voices beyond V count as +0), then the groups
- * left to right. The reference has no mixdown function — a Synth accumulates voices with `outputs +=` in voice order
+ * group of 64 consecutive voices (a[i] += a[i + d], d = 1, 2, ... 32; voices beyond V count as +0); then the group sums
+ * left to right 64 consecutive ones at a time, and so the results, until one is left (up to 4096 voices: the groups left to
+ * right). The reference has no mixdown function — a Synth accumulates voices with `outputs +=` in voice order
  * (source/app/MLSynth.h:43-57); tests also bound the difference from that sequential order. sig: [V][64T]. */
 int mlorc_mixdown(const float* sig, size_t V, size_t T, const float* gains, float* out)
 {
   const size_t S = T * VEC, groups = (V + 63) / 64;
+  float* rows = (float*)malloc(sizeof(float) * (groups ? groups : 1));
+  if (!rows) return MLGPU_ERR_OOM;
   for (size_t s = 0; s < S; ++s)
   {
-    float total = 0.f;
     for (size_t g = 0; g < groups; ++g)
     {
       float a[64];
@@ -1863,10 +1865,24 @@ int mlorc_mixdown(const float* sig, size_t V, size_t T, const float* gains, floa
       }
       for (int d = 1; d < 64; d <<= 1)
         for (int i = 0; i + d < 64; i += 2 * d) a[i] = a[i] + a[i + d];
-      total = (g == 0) ? a[0] : total + a[0];
+      rows[g] = a[0];
     }
-    out[s] = total;
+    size_t n = groups;
+    do
+    {
+      const size_t nOut = (n + 63) / 64;
+      for (size_t r = 0; r < nOut; ++r)
+      {
+        const size_t first = r * 64, m = (n - first < 64) ? n - first : 64;
+        float acc = rows[first];
+        for (size_t g = 1; g < m; ++g) acc = acc + rows[first + g];
+        rows[r] = acc;  /* r <= first: never overwrites a row still to be read */
+      }
+      n = nOut;
+    } while (n > 1);
+    out[s] = rows[0];
   }
+  free(rows);
   return MLGPU_OK;
 }
 
