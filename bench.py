@@ -381,44 +381,142 @@ def setup_workload(eng, name, V, T, lo, total):
     raise SystemExit(f"unknown workload {name}")
 
 
+# What an instruction class costs a SIMD that is kept full, ns per wave-instruction (tools/instbench.hip): plain FP32
+# add / mul / fma and the simple integer and move instructions 1.09; conversions, compares, selects that read an SGPR mask, min / max /
+# med3 / fract and the packed forms 1.8; double precision 1.85; the transcendental unit 3.5. The class counters tell FP32 add / mul /
+# fma, conversions, transcendentals, integer and double apart; the rest of SQ_INSTS_VALU (compares, selects, min / max, moves, bit
+# operations) is a mix of the first two prices, hence a low and a high figure.
+ISSUE_NS = {"plain": 1.09, "slow": 1.8, "f64": 1.85, "trans": 3.5}
+N_SIMD = 256 * 4
+
+
+def valu_busy(pmc, kernel_ms):
+    """(low, high) fraction of the launch during which the SIMDs' vector issue is occupied, from the instruction-class counters."""
+    total = pmc.get("valu_wave_insts_per_launch")
+    if not total or "SQ_INSTS_VALU_ADD_F32" not in pmc:
+        return None
+    f32 = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
+    f64 = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+    cvt, trans = pmc.get("SQ_INSTS_VALU_CVT", 0.0), pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    integer = pmc.get("SQ_INSTS_VALU_INT32", 0.0) + pmc.get("SQ_INSTS_VALU_INT64", 0.0)
+    other = max(0.0, total - f32 - f64 - cvt - trans - integer)
+    known = f32 * ISSUE_NS["plain"] + f64 * ISSUE_NS["f64"] + cvt * ISSUE_NS["slow"] + trans * ISSUE_NS["trans"] + integer * ISSUE_NS["plain"]
+    span = N_SIMD * kernel_ms * 1e6
+    return {"busy_frac": [(known + other * ISSUE_NS["plain"]) / span, (known + other * ISSUE_NS["slow"]) / span],
+            "classes_per_launch": {"f32_add_mul_fma": f32, "f64": f64, "cvt": cvt, "trans": trans, "int": integer, "other": other},
+            "model": "sum over instruction classes of SQ_INSTS_VALU_* x the class's measured issue time (ns per wave-instruction per SIMD: "
+                     f"{ISSUE_NS}; tools/instbench.hip, DESIGN 3.11) / (1024 SIMDs x launch time); 'other' (compares, selects, min / max, moves) priced "
+                     "at the plain and at the slow rate gives the low and the high figure; integer multiplies (quarter rate) are priced plain"}
+
+
+def pattern_ceiling(eng, V, T, streamed_input, reps=12):
+    """What this launch's ACCESS PATTERN reaches with no arithmetic to speak of, measured now on this box: the voice-bank kernel with a
+    single Gain processor - one 16-byte nontemporal store per lane and quad into the QUAD layout, XCD-aware workgroup order, and the
+    same for the loads when the workload streams an input - over the same voices x DSPVectors. GB/s of the bytes it moves."""
+    from madronalib_amd.constants import Layout, Proc
+    n = V * T * 64
+    bank = eng.bank([Proc.GAIN], V)
+    bank.set_coeff(0, 0, 0.5)
+    d_out = eng.alloc(4 * n)
+    d_in = None
+    if streamed_input:
+        d_in = eng.alloc(4 * n)
+    else:
+        bank.set_input_const(np.full(V, 0.25, np.float32))
+
+    def go():
+        if d_in is None:
+            bank.process(T, d_out, Layout.QUAD)
+        else:
+            bank.process(T, d_out, Layout.QUAD, d_in, Layout.QUAD)
+    for _ in range(4):
+        go()
+    eng.sync()
+    eng.timer_start()
+    for _ in range(reps):
+        go()
+    ms = eng.timer_stop_ms() / reps
+    bank.close()
+    d_out.free()
+    if d_in is not None:
+        d_in.free()
+    return (8.0 if streamed_input else 4.0) * n / (ms * 1e-3) / 1e9, ms
+
+
+def usable_cores():
+    """Threads this process may really run at once: its CPU affinity mask, cut to the cgroup's CPU quota (a container on a 256-thread
+    host is often allowed a fraction of it; os.cpu_count() says 256 all the same)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())   # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return max(1, n)
+
+
+def median_after_first(run, n=5):
+    """discard the first run, report the median of at least five."""
+    run()
+    return float(np.median([run() for _ in range(n)]))
+
+
 def cpu_baseline_cfg3(budget_s=12.0):
-    """The same chain on the host cores over a bounded sample (~10-20 s of CPU work)."""
+    """The same chain on the host cores over a bounded sample (~10-20 s of CPU work): every usable thread, one thread, and the steps
+    between (the scaling says what kind of machine the number comes from: SMT siblings, a CPU quota)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_checkers import Oracle, Ref, ref_available
     from madronalib_amd.constants import Proc
-    cores = os.cpu_count() or 1
-    Vs = 4096 * max(1, min(cores, 64))
-    freq, co = cfg3_params(0, Vs, Vs)
+    cores = usable_cores()
     kind = "reference" if ref_available() else "port"
     if kind == "reference":
         ref = Ref()
 
-        def run(T):
-            s, _ = ref.bench_saw_bandpass_gain(Vs, T, freq, co[0], co[1], co[2], 0.25, cores)
-            return s
+        def seconds(Vs, T, n):
+            freq, co = cfg3_params(0, Vs, Vs)
+            return ref.bench_saw_bandpass_gain(Vs, T, freq, co[0], co[1], co[2], 0.25, n)[0]
     else:
         orc = Oracle()
         procs = [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]
-        coeffs = np.ascontiguousarray(np.concatenate([co, np.full((1, Vs), 0.25, np.float32)], 0))
 
-        def run(T):
+        def seconds(Vs, T, n):
+            freq, co = cfg3_params(0, Vs, Vs)
+            coeffs = np.ascontiguousarray(np.concatenate([co, np.full((1, Vs), 0.25, np.float32)], 0))
             st = orc.chain_clear(procs, Vs)
-            return orc.chain_time(procs, T, coeffs, st, None, freq, cores)
-    run(4)  # warm-up (page-in, thread start)
-    t_cal = run(16)
-    T = int(max(16, min(4096, 16 * budget_s / max(t_cal, 1e-6) / 3)))
-    times = [run(T) for _ in range(3)]
-    best = min(times)
-    one_core = None
-    if kind == "reference":          # SURVEY 8(d): one core beside all cores (4096 voices, ~2 s)
-        f1, c1 = cfg3_params(0, 4096, 4096)
-        t1 = ref.bench_saw_bandpass_gain(4096, 16, f1, c1[0], c1[1], c1[2], 0.25, 1)[0]
-        T1 = int(max(16, min(4096, 16 * 1.0 / max(t1, 1e-6))))
-        one_core = 4096 * T1 * 64 / min(ref.bench_saw_bandpass_gain(4096, T1, f1, c1[0], c1[1], c1[2], 0.25, 1)[0] for _ in range(2))
-    return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": kind, "value_one_core": one_core,
-            "sample": f"{Vs} voices x {T} DSPVectors of the same chain/params, {cores} threads, best of 3 "
+            return orc.chain_time(procs, T, coeffs, st, None, freq, n)
+
+    def rate(n, share):
+        Vs = 4096 * n                                   # 4096 voices per thread: ~100 KiB of objects, cache resident like a real voice bank's
+        t_cal = seconds(Vs, 16, n)
+        T = int(max(16, min(4096, 16 * budget_s * share / max(t_cal, 1e-6) / 6)))
+        return Vs * T * 64 / median_after_first(lambda: seconds(Vs, T, n)), Vs, T
+    steps = sorted({n for n in (1, 8, 64, cores) if n <= cores})
+    scaling = {}
+    for n in steps:
+        scaling[n], Vs, T = rate(n, 0.55 if n == cores else 0.45 / max(1, len(steps) - 1))
+    note = ""
+    if cores > 1 and scaling[cores] / scaling[1] < 0.5 * cores:
+        note = (f"; {cores} threads give {scaling[cores] / scaling[1]:.1f} x one thread - the threads are not {cores} independent cores "
+                "(SMT siblings share a core's vector units, and the host may run other jobs)")
+    return {"value": scaling[cores], "unit": "voice-samples/s", "cores": cores, "kind": kind, "value_one_core": scaling[1],
+            "thread_scaling": {str(k): v for k, v in scaling.items()}, "host_logical_cpus": os.cpu_count(),
+            "sample": f"{Vs} voices x {T} DSPVectors of the same chain/params on {cores} threads (usable: affinity mask and cgroup quota; the host "
+                      f"reports {os.cpu_count()} logical CPUs), threads started before the clock, first run discarded, median of 5 "
                       f"({'compiled reference headers, g++ -O2 -fno-strict-aliasing, SSE2' if kind == 'reference' else 'plain-C oracle port, gcc -O2'})"
-                      + ("; value_one_core: 4096 voices on one thread" if one_core else "")}
+                      f"; thread_scaling: the same at {', '.join(str(k) for k in steps)} threads with 4096 voices per thread" + note}
 
 
 def cpu_baseline_cfg4(budget_s=10.0):
@@ -429,15 +527,15 @@ def cpu_baseline_cfg4(budget_s=10.0):
     if not ref_available():
         return {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "compiled reference not available"}
     ref = Ref()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     Vs = 1024 * max(1, min(cores, 128))
     co = np.stack([ml.Lopass.makeCoeffs(float(np.float32(0.02) * np.float32(i + 1)), 0.7) for i in range(8)])
-    ref.bench_lopass_cascade8(Vs, 4, co, cores)
     t_cal, _ = ref.bench_lopass_cascade8(Vs, 16, co, cores)
-    T = int(max(16, min(8192, 16 * budget_s / max(t_cal, 1e-6) / 3)))
-    best = min(ref.bench_lopass_cascade8(Vs, T, co, cores)[0] for _ in range(3))
-    return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
-            "sample": f"{Vs} channels x {T} DSPVectors, 8 cascaded Lopass per channel, {cores} threads, best of 3 (compiled reference headers, g++ -O2 -fno-strict-aliasing, SSE2)"}
+    T = int(max(16, min(8192, 16 * budget_s / max(t_cal, 1e-6) / 6)))
+    med = median_after_first(lambda: ref.bench_lopass_cascade8(Vs, T, co, cores)[0])
+    return {"value": Vs * T * 64 / med, "unit": "voice-samples/s", "cores": cores, "kind": "reference", "host_logical_cpus": os.cpu_count(),
+            "sample": f"{Vs} channels x {T} DSPVectors, 8 cascaded Lopass per channel, {cores} usable threads started before the clock, first run discarded, "
+                      "median of 5 (compiled reference headers, g++ -O2 -fno-strict-aliasing, SSE2)"}
 
 
 def cpu_baseline_cfg2(budget_s=8.0):
@@ -448,15 +546,15 @@ def cpu_baseline_cfg2(budget_s=8.0):
     if not ref_available():
         return {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "compiled reference not available"}
     ref = Ref()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = 65536 * 64
     x = np.tile(np.linspace(-np.pi, np.pi, 4096, dtype=np.float32), n // 4096)
-    ref.bench_op(Op.EXP_APPROX_OF_SIN_APPROX, x, cores, 2)
     t_cal = ref.bench_op(Op.EXP_APPROX_OF_SIN_APPROX, x, cores, 8)
-    reps = int(max(8, min(20000, 8 * budget_s / max(t_cal, 1e-6) / 3)))
-    best = min(ref.bench_op(Op.EXP_APPROX_OF_SIN_APPROX, x, cores, reps) for _ in range(3))
-    return {"value": n * reps / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
-            "sample": f"65536 voices x 1 DSPVector, {reps} passes, {cores} threads, best of 3 (reference ops, g++ -O2 -fno-strict-aliasing, SSE2; the data stays in the CPU caches)"}
+    reps = int(max(8, min(20000, 8 * budget_s / max(t_cal, 1e-6) / 6)))
+    med = median_after_first(lambda: ref.bench_op(Op.EXP_APPROX_OF_SIN_APPROX, x, cores, reps))
+    return {"value": n * reps / med, "unit": "voice-samples/s", "cores": cores, "kind": "reference", "host_logical_cpus": os.cpu_count(),
+            "sample": f"65536 voices x 1 DSPVector, {reps} passes, {cores} usable threads started before the clock, first run discarded, median of 5 "
+                      "(reference ops, g++ -O2 -fno-strict-aliasing, SSE2; the data stays in the CPU caches)"}
 
 
 def cpu_baseline_cfg5full(budget_s=10.0):
@@ -472,7 +570,7 @@ def cpu_baseline_cfg5(budget_s=10.0, full=False):
     if not ref_available():
         return {"value": None, "unit": "voice-samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "compiled reference not available"}
     ref = Ref()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     Vs = 256 * max(1, min(cores, 256))
     params, coeffs, seeds = cfg5_voice_params(0, Vs, Vs, ml, full=full)
 
@@ -480,12 +578,12 @@ def cpu_baseline_cfg5(budget_s=10.0, full=False):
         gate = np.zeros((Vs, 64 * T), np.float32)
         gate[:, 64:] = 0.8   # every voice sounds from the second vector on
         return (ref.synth16full_run if full else ref.synth16_run)(params, coeffs, seeds, gate, cores)[1]
-    run(4)
     t_cal = run(16)
-    T = int(max(16, min(1024, 16 * budget_s / max(t_cal, 1e-6) / 3)))
-    best = min(run(T) for _ in range(3))
-    return {"value": Vs * T * 64 / best, "unit": "voice-samples/s", "cores": cores, "kind": "reference",
-            "sample": f"{Vs} voices x {T} DSPVectors of the synth16{' (full)' if full else ''} voice, {cores} threads, best of 3 (reference objects, g++ -O2 -fno-strict-aliasing, SSE2)"}
+    T = int(max(16, min(1024, 16 * budget_s / max(t_cal, 1e-6) / 6)))
+    med = median_after_first(lambda: run(T))
+    return {"value": Vs * T * 64 / med, "unit": "voice-samples/s", "cores": cores, "kind": "reference", "host_logical_cpus": os.cpu_count(),
+            "sample": f"{Vs} voices x {T} DSPVectors of the synth16{' (full)' if full else ''} voice, {cores} usable threads started before the clock, first run "
+                      "discarded, median of 5 (reference objects, g++ -O2 -fno-strict-aliasing, SSE2)"}
 
 
 VALU_PEAK_LANE_INST = 256 * 4 * 32 * 2.4e9   # 7.86e13: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
@@ -613,6 +711,18 @@ def run_rank(args, rank, local_rank, world, rdv):
         cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0
         roof["clock"] = {"cycles_per_launch": cyc, "ghz_live": cyc / (kernel_ms * 1e-3) / 1e9,
                          "source": "GRBM_GUI_ACTIVE / 8 XCDs (profiles/pmc_workloads.json) / live launch duration"}
+    # what the same access pattern reaches with (almost) no arithmetic, on this box, now: the honest ceiling of an HBM-bound launch
+    streamed = args.workload in ("cfg4", "cfg5", "cfg5full", "cfg2")
+    if world == 1 and args.workload in ("cfg3", "cfg4", "cfg5", "cfg5full"):
+        try:
+            gbs, cms = pattern_ceiling(eng, V, T, streamed)
+            roof["store_ceiling" if not streamed else "stream_ceiling"] = {
+                "GB/s": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "ms": cms,
+                "what": ("one Gain processor in the same voice-bank kernel over the same voices x DSPVectors: 16-byte nontemporal stores into the QUAD layout"
+                         + (", loads of the streamed input likewise" if streamed else "") + ", measured in this run")}
+            roof["frac_of_ceiling"] = achieved / gbs
+        except Exception as ex:
+            roof["store_ceiling"] = {"error": str(ex)}
     if pmc.get("valu_wave_insts_per_launch"):
         # the second bound (SURVEY 8d "report both bounds"): VALU issue. SQ_INSTS_VALU counts wave-instructions; x64 lanes.
         ipu = pmc["valu_wave_insts_per_launch"] * 64.0 / units_per_launch
@@ -623,8 +733,19 @@ def run_rank(args, rank, local_rank, world, rdv):
                         "note": "an instruction count, not a utilisation: packed FP32, compares, selects and conversions occupy the SIMD "
                                 "twice as long as a plain add / mul / fma (DESIGN 3.11); config 4 at 'frac 0.33' has its VALU port 85 % busy "
                                 "(profiles/r03_cfg4_account.md)"}
-        if roof["valu"]["frac"] > roof["frac"]:
-            roof["bound"] = "valu"
+        busy = valu_busy(pmc, kernel_ms)
+        if busy:
+            roof["valu"].update(busy)
+            roof["valu"]["scalar_insts_per_unit"] = pmc.get("SQ_INSTS_SALU", 0.0) * 64.0 / units_per_launch if pmc.get("SQ_INSTS_SALU") else None
+        # Which wall the launch stands at: the memory side as a fraction of what its access pattern can reach, the vector-issue side
+        # as the (mid) busy fraction; whichever is nearer its ceiling names the bound, and both are on the line.
+        mem_side = roof.get("frac_of_ceiling", roof["frac"] / 0.79)          # 0.79: the store pattern's ceiling of round 3 (6.3 TB/s)
+        valu_side = sum(busy["busy_frac"]) / 2.0 if busy else roof["valu"]["frac"]
+        roof["bound"] = "valu" if valu_side > mem_side else "hbm"
+        roof["bound_evidence"] = {"memory_side_frac_of_pattern_ceiling": mem_side, "valu_issue_busy_frac_mid": valu_side}
+    if traffic is not None and traffic < 0.5 * alg_bytes:
+        roof["bound"] = "on-die"   # the working set never leaves the Infinity Cache: not an HBM figure
+        roof["bound_evidence"] = {"hbm_traffic_over_algorithmic_bytes": traffic / alg_bytes}
     out = {
         "metric": "voice-samples/sec (SawGen->SVF chain)" if args.workload == "cfg3" else f"voice-samples/sec ({args.workload})",
         "value": value, "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -660,6 +781,27 @@ def run_rank(args, rank, local_rank, world, rdv):
                     eng.op_apply(op, src, None, None, d_y, n_el)
                 per_op[f"{label} / {data}"] = n_el * reps / (eng.timer_stop_ms() * 1e-3)
         out["config"]["per_op_voice_samples_per_s"] = per_op
+        # BASELINE's own size (65 536 voices: 32 MiB in + out) lives in the Infinity Cache; the HBM figure of the same kernel is taken
+        # at 4 194 304 voices (1 GiB) in the same run, and the line carries both
+        if world == 1 and V * T * 64 * 8 < (256 << 20):
+            roof["bound"] = "on-die"
+            roof["bound_evidence"] = {"working_set_MiB": V * T * 64 * 8 / 2 ** 20, "infinity_cache_MiB": 256}
+            Vb = 4194304
+            nb = Vb * 64
+            d_bx, d_by = eng.alloc(4 * nb), eng.alloc(4 * nb)
+            eng.op_apply(Op.SIN_APPROX, d_bx, None, None, d_by, nb)   # (values irrelevant to the rate: no data-dependent branches)
+            for _ in range(4):
+                eng.op_apply(Op.EXP_APPROX_OF_SIN_APPROX, d_bx, None, None, d_by, nb)
+            eng.sync()
+            eng.timer_start()
+            for _ in range(32):
+                eng.op_apply(Op.EXP_APPROX_OF_SIN_APPROX, d_bx, None, None, d_by, nb)
+            bms = eng.timer_stop_ms() / 32
+            out["roofline_at_1GiB"] = {"bound": "hbm", "voices": Vb, "achieved": 8.0 * nb / (bms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": 8.0 * nb / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": bms, "voice_samples_per_s": nb / (bms * 1e-3),
+                                       "note": "the same op_kernel over 4 194 304 voices x 1 DSPVector (512 MiB in, 512 MiB out): the HBM figure of config 2"}
+            d_bx.free()
+            d_by.free()
     baselines = {"cfg2": cpu_baseline_cfg2, "cfg3": cpu_baseline_cfg3, "cfg4": cpu_baseline_cfg4, "cfg5": cpu_baseline_cfg5, "cfg5full": cpu_baseline_cfg5full}
     if world == 1 and not args.no_cpu_baseline and args.workload in baselines:
         try:

@@ -591,6 +591,38 @@ void parallelFor(size_t V, int nThreads, Fn fn)
   for (auto& t : th) t.join();
 }
 
+// The same for the CPU baselines, timed the way BASELINE.md 3 asks: the threads exist and wait BEFORE the clock starts, are
+// released together, and the clock stops when the last one is done (thread creation is not part of the measured work).
+template <class Fn>
+double timedParallelFor(size_t V, int nThreads, Fn fn)
+{
+  nThreads = std::max(1, nThreads);
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false};
+  std::vector<std::thread> th;
+  const size_t per = (V + nThreads - 1) / nThreads;
+  int started = 0;
+  for (int i = 0; i < nThreads; ++i)
+  {
+    const size_t a = std::min(V, per * i), b = std::min(V, per * (i + 1));
+    if (a >= b) continue;
+    ++started;
+    th.emplace_back(
+        [&, a, b]()
+        {
+          ready.fetch_add(1);
+          while (!go.load(std::memory_order_acquire)) {}
+          fn(a, b);
+        });
+  }
+  while (ready.load() < started) std::this_thread::yield();
+  const auto t0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
+  for (auto& t : th) t.join();
+  const auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
 }  // namespace
 
 // ml::UsingFlushDenormalsToZero (MLDSPUtils.h:51-96) is scoped to a process function; a test brackets the calls it wants
@@ -886,9 +918,8 @@ extern "C"
     }
     std::vector<double> partial(std::max(1, nThreads), 0.0);
     const size_t S = T * kFloatsPerDSPVector;
-    auto t0 = std::chrono::steady_clock::now();
     std::atomic<int> tid{0};
-    parallelFor(V, nThreads,
+    const double seconds = timedParallelFor(V, nThreads,
                 [&](size_t a, size_t b)
                 {
                   int me = tid.fetch_add(1);
@@ -904,11 +935,10 @@ extern "C"
                   }
                   partial[me] = acc;
                 });
-    auto t1 = std::chrono::steady_clock::now();
     double s = 0;
     for (double p : partial) s += p;
     if (sink) *sink = s;
-    return std::chrono::duration<double>(t1 - t0).count();
+    return seconds;
   }
 
   // config 4: 8 cascaded Lopass sections over a noise input (NoiseGen seeded per channel).
@@ -927,9 +957,8 @@ extern "C"
       for (int i = 0; i < 8; ++i) ch[v].lp[i].coeffs = {coeffs[i * 3], coeffs[i * 3 + 1], coeffs[i * 3 + 2]};
     }
     std::vector<double> partial(std::max(1, nThreads), 0.0);
-    auto t0 = std::chrono::steady_clock::now();
     std::atomic<int> tid{0};
-    parallelFor(V, nThreads,
+    const double seconds = timedParallelFor(V, nThreads,
                 [&](size_t a, size_t b)
                 {
                   int me = tid.fetch_add(1);
@@ -945,11 +974,10 @@ extern "C"
                   }
                   partial[me] = acc;
                 });
-    auto t1 = std::chrono::steady_clock::now();
     double s = 0;
     for (double p : partial) s += p;
     if (sink) *sink = s;
-    return std::chrono::duration<double>(t1 - t0).count();
+    return seconds;
   }
 
   // config 5: the 16-node synth voice of madronalib_amd/patches.py synth16(), written the way user code writes it with the
@@ -1010,8 +1038,7 @@ extern "C"
       s.dc.coeffs = dcC[v];
       s.env.coeffs = {envC[0 * V + v], envC[1 * V + v], envC[2 * V + v], envC[3 * V + v]};
     }
-    auto t0 = std::chrono::steady_clock::now();
-    parallelFor(V, std::max(1, nThreads),
+    const double seconds = timedParallelFor(V, std::max(1, nThreads),
                 [&](size_t a, size_t b)
                 {
                   for (size_t t = 0; t < T; ++t)
@@ -1023,8 +1050,7 @@ extern "C"
                       store(y, out + (v * T + t) * kFloatsPerDSPVector);
                     }
                 });
-    auto t1 = std::chrono::steady_clock::now();
-    return std::chrono::duration<double>(t1 - t0).count();
+    return seconds;
   }
 
   // the same voice as SURVEY §8d lists it (patches.synth16(full=True)): a filter envelope, the cutoff per sample through
@@ -1081,8 +1107,7 @@ extern "C"
       s.env.coeffs = {envC[0 * V + v], envC[1 * V + v], envC[2 * V + v], envC[3 * V + v]};
       s.fenv.coeffs = {fenvC[0 * V + v], fenvC[1 * V + v], fenvC[2 * V + v], fenvC[3 * V + v]};
     }
-    auto t0 = std::chrono::steady_clock::now();
-    parallelFor(V, std::max(1, nThreads),
+    const double seconds = timedParallelFor(V, std::max(1, nThreads),
                 [&](size_t a, size_t b)
                 {
                   for (size_t t = 0; t < T; ++t)
@@ -1094,23 +1119,20 @@ extern "C"
                       store(y, out + (v * T + t) * kFloatsPerDSPVector);
                     }
                 });
-    auto t1 = std::chrono::steady_clock::now();
-    return std::chrono::duration<double>(t1 - t0).count();
+    return seconds;
   }
 
   // config 2: elementwise op over n elements, nThreads; returns seconds.
   double mlref_bench_op(int op, const float* in, float* out, size_t nElems, int nThreads, int reps)
   {
     size_t nVec = nElems / kFloatsPerDSPVector;
-    auto t0 = std::chrono::steady_clock::now();
-    parallelFor(nVec, nThreads,
+    const double seconds = timedParallelFor(nVec, nThreads,
                 [&](size_t a, size_t b)
                 {
                   for (int r = 0; r < reps; ++r)
                     mlref_op_apply(op, in + a * 64, nullptr, nullptr, out + a * 64, (b - a) * 64);
                 });
-    auto t1 = std::chrono::steady_clock::now();
-    return std::chrono::duration<double>(t1 - t0).count();
+    return seconds;
   }
 
   // ---- coefficient makers straight from the reference ----
