@@ -600,6 +600,27 @@ class _RefDSPBuffer:
         return out
 
 
+def host_threads(cap=64):
+    """Threads this process may really use (CPU affinity, cut to the cgroup quota): what the heavy full-size checks run the CPU side on."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def fast_checker():
+    """The CPU checker for full-size comparisons: the compiled reference when it was built (several times the plain-C port's speed; the
+    two are pinned to each other by tests/test_oracle_vs_ref.py), else None - the caller then keeps to its subset of voices."""
+    return Ref() if ref_available() else None
+
+
 def ref_available():
     try:
         return build_ref() is not None

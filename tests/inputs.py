@@ -110,7 +110,14 @@ def assert_rel_close(got, want, rel, what=""):
     err = np.abs(g[fin] - w[fin])
     tol = rel * np.abs(w[fin]) + 1e-44
     bad = err > tol
-    assert not bad.any(), f"{what}: {int(bad.sum())} beyond rel {rel}; worst {float((err / (np.abs(w[fin]) + 1e-300)).max()):.3e}"
+    worst = float((err / (np.abs(w[fin]) + 1e-300)).max()) if err.size else 0.0
+    REL_MEASURED[what.split(" ")[0] + " " + what.split(" ")[1] if " " in what else what] = max(worst, REL_MEASURED.get(what, 0.0))
+    assert not bad.any(), f"{what}: {int(bad.sum())} beyond rel {rel}; worst {worst:.3e}"
+
+
+# the largest relative difference every toleranced comparison of this session has seen, by label (printed by conftest.py at the end:
+# the tolerance is a bound, this is the measurement)
+REL_MEASURED = {}
 
 
 # ---- chain test cases -------------------------------------------------------------------

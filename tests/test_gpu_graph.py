@@ -218,14 +218,29 @@ def test_config5_bench_step_subset(eng, oracle, full):
     c_sub = {k: np.ascontiguousarray(np.asarray(c)[:, sub]) for k, c in coeffs.items()}
     states = {n["name"]: oracle.chain_clear([n["kind"]], sub.size) for n in desc if n["type"] == "proc"}
     states["noise"][0] = seeds[sub]
+    # Round 4: EVERY voice on the first TWO launches, against the same voice written with the reference's own objects and run on the
+    # host threads (the second launch inherits every processor's state from the first: a wrong state word shows there); the strided
+    # subset carries launches 7 and 15 and every processor's final state
+    from cpu_checkers import fast_checker, host_threads
+    fast = fast_checker()
+    want2 = None
+    if fast is not None:
+        gate_all = np.ascontiguousarray(gate_q.transpose(1, 0, 2).reshape(V, T * 64))
+        run = fast.synth16full_run if full else fast.synth16_run
+        want2 = run(params, coeffs, seeds, np.concatenate([gate_all, gate_all], 1), host_threads())[0].reshape(V, 2, T * 64)
+        del gate_all
     for launch in range(L):
         g.process(T, [d_gate], [d_out])
         (want,) = evaluate(oracle, desc, outs, sub.size, T, {"gate": gate_sub}, p_sub, c_sub, states)
-        if launch in (0, 7, L - 1):
+        if launch in (0, 1, 7, L - 1):
             q = d_out.download(np.float32).reshape(T * 16, V, 4)
             got = q[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64)
             assert_bits_equal(got, want, True, f"config 5 (full={full}) launch {launch}")
             assert np.abs(want).max() > 0.01
+            if launch < 2 and want2 is not None:
+                for a in range(0, V, 32768):
+                    got_all = q[:, a:a + 32768, :].transpose(1, 0, 2).reshape(-1, T * 64)
+                    assert_bits_equal(got_all, want2[a:a + 32768, launch], True, f"config 5 (full={full}) launch {launch}, voices {a}..")
     for n in desc:
         if n["type"] == "proc":
             for i in range(g.num_state(n["name"])):

@@ -3,8 +3,9 @@ seeded inputs, against the committed golden vectors of the compiled reference, a
 BASELINE sizes — through size-independent properties. Bit-exact unless stated.
 
 Tolerances (stated once, used below):
-  HW_REL   = 1.5*2^-11 relative for sqrtApprox / divideApprox / Peak / RMS: the reference uses the
-             x86 rcpps/rsqrtps 12-bit tables, which no other hardware reproduces.
+  HW_REL   = 2^-11 relative (SURVEY 8d's figure) for sqrtApprox / divideApprox / Peak / RMS: the reference uses the
+             x86 rcpps/rsqrtps 12-bit tables (error <= 1.5 * 2^-12), which no other hardware reproduces (SURVEY App. A.6);
+             the largest difference the session measured is printed at its end (conftest.py).
   everything else: 0 ulp (bit-exact; any-NaN == any-NaN for float results).
 """
 import numpy as np
@@ -17,7 +18,7 @@ from madronalib_amd.constants import Layout, Op, Proc, RowOp
 
 pytestmark = pytest.mark.gpu
 
-HW_REL = 2.0 ** -11 * 1.5
+HW_REL = 2.0 ** -11
 
 
 @pytest.fixture(scope="module")
@@ -438,6 +439,12 @@ def test_config3_baseline_length(eng, oracle):
     coeffs = np.ascontiguousarray(np.concatenate([co[sub].T, np.full((1, sub.size), 0.25, np.float32)], 0))
     st = oracle.chain_clear(procs, sub.size)
     want = oracle.chain_process(procs, T * launches, coeffs, st, None, freq[sub], n_threads=8).reshape(sub.size, launches, T * 64)
+    # Round 4: EVERY voice on the first launch and on the final state (the compiled reference does a launch of all 262 144 voices in
+    # under a second on the box's host threads); the strided subset stays for the middle and the last launch
+    from cpu_checkers import fast_checker, host_threads
+    fast = fast_checker()
+    all_co = np.ascontiguousarray(np.concatenate([co.T, np.full((1, V), 0.25, np.float32)], 0))
+    all_st = oracle.chain_clear(procs, V)
     d_q = eng.alloc(4 * V * T * 64)
     for k in range(launches):
         bank.process(T, d_q, Layout.QUAD)
@@ -445,7 +452,17 @@ def test_config3_baseline_length(eng, oracle):
             q = d_q.download(np.float32).reshape(T * 16, V, 4)
             got = q[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64)
             assert_bits_equal(got, want[:, k], True, f"cfg3 launch {k}")
-    assert_bits_equal(bank.get_all_state()[:, sub], st, False, "cfg3 state after 750 vectors")
+            if k == 0 and fast is not None:
+                want_all = fast.chain_process(procs, T, all_co, all_st, None, freq, n_threads=host_threads())
+                for a in range(0, V, 32768):      # (in slices: the transposed copy of everything at once is 2 GiB)
+                    got_all = q[:, a:a + 32768, :].transpose(1, 0, 2).reshape(-1, T * 64)
+                    assert_bits_equal(got_all, want_all[a:a + 32768], True, f"cfg3 launch 0, voices {a}..")
+                del want_all
+    state = bank.get_all_state()
+    assert_bits_equal(state[:, sub], st, False, "cfg3 state after 750 vectors")
+    if fast is not None:
+        fast.chain_process(procs, T * (launches - 1), all_co, all_st, None, freq, n_threads=host_threads(), want_out=False)
+        assert_bits_equal(state, all_st, False, "cfg3 state of all 262 144 voices after 750 vectors")
     bank.close()
 
 
@@ -467,6 +484,10 @@ def test_config4_baseline_length(eng, oracle):
     x_sub = lcg_noise(sub.astype(np.uint32), T * launches * 64)
     st = oracle.chain_clear(procs, sub.size)
     want = oracle.chain_process(procs, T * launches, co, st, x_sub, None, n_threads=8).reshape(sub.size, launches, T * 64)
+    # Round 4: EVERY channel on the first launch, outputs and the state it leaves (2 x 10^9 filter-stage samples on the host threads);
+    # all 4 096 vectors of every channel would be 3 x 10^11: the strided subset carries the middle, the end and the final state
+    from cpu_checkers import fast_checker, host_threads
+    fast = fast_checker()
     d_x = eng.alloc(4 * V * T * 64)
     d_y = eng.alloc(4 * V * T * 64)
     for k in range(launches):
@@ -476,6 +497,17 @@ def test_config4_baseline_length(eng, oracle):
             y = d_y.download(np.float32).reshape(T * 16, V, 4)
             got = y[:, sub, :].transpose(1, 0, 2).reshape(sub.size, T * 64)
             assert_bits_equal(got, want[:, k], True, f"cfg4 launch {k}")
+            if k == 0 and fast is not None:
+                all_st = oracle.chain_clear(procs, V)
+                all_co = np.ascontiguousarray(np.repeat(np.concatenate(cs)[:, None], V, 1))
+                for a in range(0, V, 32768):
+                    x_all = lcg_noise(np.arange(a, a + 32768, dtype=np.uint32), T * 64)
+                    st_a = np.ascontiguousarray(all_st[:, a:a + 32768])
+                    want_all = fast.chain_process(procs, T, np.ascontiguousarray(all_co[:, a:a + 32768]), st_a, x_all, None, n_threads=host_threads())
+                    all_st[:, a:a + 32768] = st_a
+                    got_all = y[:, a:a + 32768, :].transpose(1, 0, 2).reshape(-1, T * 64)
+                    assert_bits_equal(got_all, want_all, True, f"cfg4 launch 0, channels {a}..")
+                assert_bits_equal(bank.get_all_state(), all_st, False, "cfg4 state of all 131 072 channels after the first launch")
     assert_bits_equal(bank.get_all_state()[:, sub], st, False, "cfg4 state after 4096 vectors")
     bank.close()
     nb.close()

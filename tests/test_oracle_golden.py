@@ -14,7 +14,7 @@ from madronalib_amd.constants import Op, Proc, RowOp, Vop
 from golden_cases import load_rows, rows_golden_case  # noqa: E402
 from rows_cases import ROWS_CASES, run as run_rows_case  # noqa: E402
 
-HW_REL = 2.0 ** -11 * 1.5
+HW_REL = 2.0 ** -11
 
 
 @pytest.mark.parametrize("op", Op.UNARY + Op.BINARY + Op.TERNARY)
@@ -85,6 +85,10 @@ def test_restated_libm_sinf_against_host_libm(oracle):
     n, lst = oracle.sinf_check(0, 0xFFFFFFFF)
     xs = np.abs(lst.view(np.float32))
     assert n <= 12 and ((xs > 53.0) & (xs < 120.0)).all(), (n, [hex(x) for x in lst])
+    # exactly these twelve on a host whose glibc picks the FMA variant, none on one that does not (INTEGRATION.md lists them;
+    # tests/test_gpu_deviations.py runs the device on each)
+    twelve = [0x4255b0a9, 0x42a35c07, 0x42a35d44, 0x42a97360, 0x42cf5854, 0x42e87a55, 0xc255b0a9, 0xc2a35c07, 0xc2a35d44, 0xc2a97360, 0xc2cf5854, 0xc2e87a55]
+    assert n == 0 or sorted(int(x) for x in lst) == sorted(twelve), [hex(x) for x in lst]
 
 
 def test_fast_sinf_forms_exhaustively(oracle):

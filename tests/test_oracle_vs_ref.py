@@ -10,7 +10,7 @@ from inputs import (MULTI_CASES, assert_bits_equal, assert_rel_close, chain_coef
                     multi_case, multi_inputs_audio, op_inputs)
 from madronalib_amd.constants import Op, Proc, RowOp, Vop
 
-HW_REL = 2.0 ** -11 * 1.5  # rcpps/rsqrtps: |rel err| <= 1.5 * 2^-12 per Intel; we allow 2^-11 * 1.5
+HW_REL = 2.0 ** -11  # rcpps/rsqrtps: |rel err| <= 1.5 * 2^-12 per Intel; SURVEY 8d's 2^-11
 
 
 @pytest.mark.parametrize("op", Op.UNARY + Op.BINARY + Op.TERNARY)
