@@ -71,11 +71,18 @@
 #define MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS 1
 #endif
 #endif
+// ... and without a madronalib checkout the shim brings its own (round 4): the same names with the same arithmetic, so that
+// sine.cpp, reverb.cpp, fdtd.cpp and controllers-to-audio.cpp of the reference's examples build with this directory alone
+#ifndef MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS
+#include "mlscalar.h"
+#define MLGPU_COMPAT_OWN_SCALAR_HEADER 1
+#endif
+#include <iostream>  // (madronalib's DSP headers bring it; user code says std::cout without asking)
 
 namespace ml
 {
 constexpr size_t kFloatsPerDSPVector = MLGPU_FLOATS_PER_DSPVECTOR;
-#ifndef MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS
+#if !defined(MLGPU_COMPAT_HAS_MADRONALIB_SCALAR_HEADERS) && !defined(MLGPU_COMPAT_OWN_SCALAR_HEADER)
 constexpr float kPi = 3.1415926535897932384626433832795f;
 constexpr float kTwoPi = kPi * 2.f;
 #endif
@@ -499,11 +506,20 @@ class DSPVectorArray
     const gpu::Sig& s = sig_[i / 64];
     if (s.node >= 0)  // a signal of the kernel (a context signal in a one-context program): readable, not a host buffer
     {
-      static thread_local float readOnly[8];
+      // The reference hands out a float& here, so this must too - into a small ring of read-only cells. A write through it would
+      // vanish; it is caught at the next access instead of passing silently: every cell remembers what it was given.
+      static thread_local float readOnly[8], given[8];
       static thread_local unsigned next;
-      float& r = readOnly[next++ & 7];
-      r = s.hostSample((int)(i & 63));
-      return r;
+      for (unsigned k = 0; k < 8 && k < next; ++k)
+        if (std::memcmp(&readOnly[k], &given[k], sizeof(float)) != 0)
+        {
+          std::memcpy(&readOnly[k], &given[k], sizeof(float));
+          throw std::logic_error("mldsp GPU shim: `v[n] = x` on a signal the kernel computes was discarded - such a signal can be read on the host, "
+                                 "not written; build the value with DSPVector operations instead");
+        }
+      const unsigned k = next++ & 7;
+      readOnly[k] = given[k] = s.hostSample((int)(i & 63));
+      return readOnly[k];
     }
     return getBuffer()[i];
   }
@@ -842,6 +858,24 @@ inline std::ostream& operator<<(std::ostream& out, const DSPVectorArray<ROWS>& v
     out << "] ";
   }
   return out;
+}
+// validate(DSPVector) (MLDSPOps.h:1430-1445): false, with a report on std::cout, when a sample is NaN or beyond +-1e8. It reads the
+// vector's samples on the host, so it works wherever v[n] does - literals, host tables, the results of immediate mode - and throws
+// like v[n] on a signal that exists only inside a captured kernel (there mlgpu_validate scans the output buffer after a launch).
+inline bool validate(const DSPVector& x)
+{
+  for (size_t n = 0; n < 64; ++n)
+  {
+    const float maxUsefulValue = 1e8;
+    const float v = x[n];
+    if (std::isnan(v) || (std::fabs(v) > maxUsefulValue))
+    {
+      std::cout << "error: " << v << " at index " << n << "\n";
+      std::cout << x << "\n";
+      return false;
+    }
+  }
+  return true;
 }
 inline DSPVector columnIndex() { return DSPVector(gpu::vopNode(MLGPU_VOP_COLUMN_INDEX, {})); }
 inline DSPVector rangeOpen(float start, float end) { return DSPVector(gpu::vopNode(MLGPU_VOP_RANGE_OPEN, {gpu::Sig(-1, start), gpu::Sig(-1, end)})); }
