@@ -718,7 +718,7 @@ typedef struct mlgpu_event /* ml::Event, MLEvent.h:31-53 */
 } mlgpu_event;
 typedef struct mlgpu_events mlgpu_events;
 int mlgpu_events_create(mlgpu_engine* e, size_t n_instruments, int polyphony /* setPolyphony, 1..16 */, mlgpu_events** out);
-int mlgpu_events_destroy(mlgpu_events* ev);
+int mlgpu_events_destroy(mlgpu_events* ev);   /* (while recorded sequences of the engine live, the memory is released with the last of them) */
 int mlgpu_events_clear(mlgpu_events* ev);                                   /* clear(), :330-340 */
 int mlgpu_events_set_sample_rate(mlgpu_events* ev, double sr);
 int mlgpu_events_set_protocol(mlgpu_events* ev, int mpe);                   /* setProtocol("MIDI" / "MPE"); clears */

@@ -1189,6 +1189,20 @@ struct ProcNode
     const int n = (int)ins.size();
     if (!imm_ || imm_->nIn != n)
     {
+      // another call form than last time (IntegerDelay(x) after IntegerDelay(x, delay)): the one-voice graph is built anew for
+      // this arity, and starts from the state words the old one holds now - the reference object keeps its members across its
+      // overloads. (A delay's ring memory belongs to the graph and starts empty again.)
+      std::vector<std::pair<int, uint32_t>> carried;
+      if (imm_ && imm_->g)
+      {
+        const int ns = mlgpu_graph_num_state(imm_->g, imm_->node);
+        for (int i = 0; i < ns; ++i)
+        {
+          uint32_t w = 0;
+          e.check(mlgpu_graph_get_state(imm_->g, imm_->node, i, &w));
+          carried.push_back({i, w});
+        }
+      }
       auto im = std::make_shared<Immediate>();
       e.check(mlgpu_graph_create(e.handle(), 1, &im->g));
       auto ret = [&](int r) {
@@ -1207,6 +1221,7 @@ struct ProcNode
       e.check(mlgpu_alloc(e.handle(), (size_t)(n + 1) * 256, &p));
       im->d = static_cast<float*>(p);
       im->nIn = n;
+      for (auto& kv : carried) e.check(mlgpu_graph_set_state_uniform(im->g, im->node, kv.first, kv.second));
       imm_ = im;
     }
     Immediate& im = *imm_;

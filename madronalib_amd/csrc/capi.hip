@@ -209,6 +209,7 @@ extern "C"
     if (!e) return MLGPU_ERR_INVALID;
     hipSetDevice(e->device);
     hipStreamSynchronize(e->stream);
+    e->runDeferredFrees();
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->d_impulseTable) hipFree(e->d_impulseTable);
@@ -291,6 +292,7 @@ extern "C"
     if (s->exec) hipGraphExecDestroy(s->exec);
     if (s->graph) hipGraphDestroy(s->graph);
     if (s->e->liveSequences > 0) --s->e->liveSequences;
+    if (s->e->liveSequences == 0) s->e->runDeferredFrees();
     delete s;
     return MLGPU_OK;
   }

@@ -1047,13 +1047,8 @@ static void freeControllers(mlgpu_events* ev)
 }
 extern "C"
 {
-  int mlgpu_events_destroy(mlgpu_events* ev)
+  static void reallyDestroyEvents(mlgpu_events* ev)
   {
-    if (!ev) return MLGPU_ERR_INVALID;
-    // waiting for the stream would invalidate a capture in progress; a recorded sequence may replay launches that read this object
-    if (ev->e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_destroy waits for the device: not while recording a sequence");
-    if (ev->e->liveSequences > 0) return efail(ev, MLGPU_ERR_INVALID, "events_destroy: recorded sequences of this engine may read this object: destroy them first");
-    mlgpu_graph_forget_events(ev);  // graphs bound to this object (mlgpu_graph_bind_events) go back to "no events object"
     hipSetDevice(ev->e->device);
     hipStreamSynchronize(ev->e->stream);
     if (ev->d_state) hipFree(ev->d_state);
@@ -1067,6 +1062,22 @@ extern "C"
       if (st.done) hipEventDestroy(st.done);
     }
     delete ev;
+  }
+  int mlgpu_events_destroy(mlgpu_events* ev)
+  {
+    if (!ev) return MLGPU_ERR_INVALID;
+    // waiting for the stream would invalidate a capture in progress
+    if (ev->e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_destroy waits for the device: not while recording a sequence");
+    mlgpu_graph_forget_events(ev);  // graphs bound to this object (mlgpu_graph_bind_events) go back to "no events object"
+    // A recorded sequence of this engine may replay launches that read this object's memory: the handle is gone for the caller now,
+    // the memory goes when the last sequence does (or with the engine). (Round 3 refused here - and owners that ignore the status,
+    // like a destructor, leaked the object.)
+    if (ev->e->liveSequences > 0)
+    {
+      ev->e->deferredFrees.push_back([ev]() { reallyDestroyEvents(ev); });
+      return MLGPU_OK;
+    }
+    reallyDestroyEvents(ev);
     return MLGPU_OK;
   }
 
@@ -1255,7 +1266,7 @@ extern "C"
     a.nInstruments = ev->nInstruments;
     a.lanes = lanes;
     a.T = nVectors;
-    a.slotStride = 64 * ev->ctlMaxVectors * ev->nInstruments;
+    a.slotStride = 64 * ev->ctlCapacityVectors * ev->nInstruments;  // (the capacity, not the current limit: a slot's signal stays where it is while the buffer is not replaced)
     float c[2];
     mlgpu_linear_glide_make_coeffs((float)(int)(ev->sr * 0.02f), c);  // int glideTimeInSamples = sr * kControllerGlideTimeSeconds (:275)
     memcpy(&a.glideVectors, &c[0], 4);
@@ -1520,7 +1531,7 @@ extern "C"
   const float* mlgpu_events_controller_signal(mlgpu_events* ev, int slot)
   {
     if (!ev || slot < 0 || (size_t)slot >= ev->watched.size()) return nullptr;
-    return ev->d_ctlOut + (size_t)slot * 64 * ev->ctlMaxVectors * ev->nInstruments;
+    return ev->d_ctlOut + (size_t)slot * 64 * ev->ctlCapacityVectors * ev->nInstruments;
   }
   int mlgpu_events_is_midi(mlgpu_events* ev) { return (ev && !ev->mpe) ? 1 : 0; }
   mlgpu_engine* mlgpu_events_engine(mlgpu_events* ev) { return ev ? ev->e : nullptr; }

@@ -1516,10 +1516,10 @@ extern "C"
     if (!mlgpu_events_is_midi(ev)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_bind_events: MIDI protocol only (one lane per voice)");
     if (mlgpu_events_num_voices(ev) != g->V) return gfail(g, MLGPU_ERR_INVALID, "graph_bind_events: instruments x polyphony must equal the graph's voices");
     {
-      std::lock_guard<std::mutex> lock(g_boundMutex);
+      std::lock_guard<std::mutex> lock(g_boundMutex);  // (mlgpu_graph_forget_events reads and clears g->events under the same lock)
       g_boundGraphs.insert(g);
+      g->events = ev;
     }
-    g->events = ev;
     return MLGPU_OK;
   }
   int mlgpu_graph_add_vop(mlgpu_graph* g, int vop, const int* inputs, int nIn, const char* name)

@@ -1,5 +1,8 @@
 // mlgpu_internal.hpp — shared between the translation units of libmlgpu.so (not installed).
 #pragma once
+#include <atomic>
+#include <functional>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -27,13 +30,22 @@ struct mlgpu_engine
   uint32_t kflags{0};  // MLGPU_KFLAG_* handed to every arithmetic kernel (mlgpu_engine_set_flush_denormals)
   bool recording{false};  // between mlgpu_engine_begin_recording and _end_recording: launches are captured, not run
   int liveSequences{0};   // recorded sequences not yet destroyed: they hold device pointers, so buffers handed out must not move
+  // objects destroyed while recorded sequences might still replay launches that read them: freed when the last sequence goes
+  // (mlgpu_sequence_destroy) or with the engine
+  std::vector<std::function<void()>> deferredFrees;
+  void runDeferredFrees()
+  {
+    std::vector<std::function<void()>> todo;
+    todo.swap(deferredFrees);
+    for (auto& f : todo) f();
+  }
 };
 
 struct mlgpu_fence  // mlgpu_engine_signal / mlgpu_engine_wait: a point in one engine's stream that another engine's stream can wait for
 {
   int device{0};
   hipEvent_t ev{nullptr};
-  bool signalled{false};
+  std::atomic<bool> signalled{false};  // set by the signalling engine's host thread, read by the waiting engine's
 };
 
 struct mlgpu_sequence  // a recorded launch sequence: a hipGraph instantiated once, replayed with one launch

@@ -664,3 +664,31 @@ def test_controller_signals_survive_a_longer_reservation(eng):
     assert_bits_equal(got[:, 0], want, True, "controllers across a re-reservation")
     assert 0.125 < want[0, 300] < 0.75 or 0 < want[0, 300] < 0.75      # still gliding when the reservation changed
     ev.close()
+
+
+@pytest.mark.gpu
+def test_controller_signal_pointers_stay_put_inside_the_reservation(eng):
+    """watch_controllers with the same numbers and a length INSIDE what is already reserved must not move any slot's
+    signal (a host, or a recorded sequence, may hold the pointers): the slots are laid out by the reserved capacity, not by the
+    current limit - slot 1's pointer used to move with every change of the limit. And the values after shrinking and growing again
+    are still the reference's."""
+    import madronalib_amd as ml
+    cfg = SCENARIOS["midi_poly4"]
+    evs = [(NOTE_ON, 1, 60, 0, 0.0, 0.5), (CTRL, 1, 74, 100, 0.75, 0.0), (CTRL, 1, 1, 130, 0.5, 0.0), (CTRL, 1, 74, 700, 0.125, 0.0)]
+    ev = ml.Events(eng, 3, 4)
+    ev.configure(glide_seconds=cfg["glide"], drift=cfg["drift"])
+    ev.watch_controllers([74, 1], 8)
+    p0 = [ev.controller_signal(0), ev.controller_signal(1)]
+    ev.add_events([0] * len(evs), [ml.Event(*e) for e in evs])
+    chunks = []
+    for start, n, limit in ((0, 2, 2), (128, 2, 2), (256, 8, 8), (768, 4, 4), (1024, 8, 8)):
+        ev.watch_controllers([74, 1], limit)                 # shrink, grow back: always inside the first reservation of 8
+        assert [ev.controller_signal(0), ev.controller_signal(1)] == p0, (start, limit)
+        ev.process_host(n, start)
+        chunks.append(ev.controllers_host(n))
+    got = np.concatenate(chunks, 2)
+    _, want = ref_run_controllers(cfg, evs, 1536, 1, [74, 1])
+    assert_bits_equal(got[:, 0], want, True, "controllers across limits inside one reservation")
+    ev.watch_controllers([74, 1], 16)                        # beyond it: the buffer is replaced, and says so by moving
+    assert ev.controller_signal(1) != p0[1] or ev.controller_signal(0) != p0[0]
+    ev.close()

@@ -196,8 +196,8 @@ def test_transport_survives_a_longer_reservation(eng):
 
 def test_signal_buffers_do_not_move_under_recorded_sequences(eng):
     """The beat-phase and controller signals are buffers whose device pointers callers hold and recorded sequences replay:
-    a shorter reservation keeps the allocation (same pointer), a longer one is refused while a sequence of the engine is alive,
-    and so is destroying an events object; afterwards both go through."""
+    a shorter reservation keeps the allocation (same pointer), a longer one is refused while a sequence of the engine is alive
+    (afterwards it goes through); an events object destroyed meanwhile is gone for its owner and freed with the last sequence."""
     import madronalib_amd as ml
     tr = ml.Transport(eng, 4, 8)
     p0 = tr.beat_phase
@@ -223,9 +223,16 @@ def test_signal_buffers_do_not_move_under_recorded_sequences(eng):
             ev.watch_controllers([7, 11], 64)
         with pytest.raises(ml.MlgpuError):
             ev.watch_controllers([7, 11, 12], 4)     # another set of controllers would free the old signals
-        assert ev.L.mlgpu_events_destroy(ev.h) == ml.Status.ERR_INVALID
+        # destroying an events object under a live sequence goes through for the caller (round 4: it used to be refused, and an
+        # owner that ignores the status - a destructor - leaked the object); its memory lives until the last sequence is gone
+        doomed = ml.Events(eng, 2, 2, 48000.0)
+        doomed.watch_controllers([7], 2)
+        assert doomed.L.mlgpu_events_destroy(doomed.h) == ml.Status.OK
+        doomed.h = None
+        seq.launch()                                  # (the sequence still replays)
+        eng.sync()
     finally:
-        seq.close()
+        seq.close()                                   # ... and here the deferred object is freed
     tr.reserve(32)
     assert tr.process_host(32).shape[1] == 32 * 64
     ev.watch_controllers([7, 11], 64)
