@@ -589,6 +589,8 @@ def cpu_baseline_cfg5(budget_s=10.0, full=False):
 VALU_PEAK_LANE_INST = 256 * 4 * 32 * 2.4e9   # 7.86e13: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
 
 
+import threading  # noqa: E402
+_SETUP_LOCK = threading.Lock()
 _T_PROCESS = time.perf_counter()   # this rank's process reached bench.py's top level (interpreter + numpy import are before it)
 
 
@@ -629,7 +631,11 @@ def run_rank(args, rank, local_rank, world, rdv):
     if args.strict_svf:
         eng.set_strict_svf(True)
     eng._bench_two_streams = args.two_streams
-    launch, alg_bytes, kernel_name, desc, _keep = setup_workload(eng, args.workload, V, T, lo, total)
+    # (ranks that are THREADS of one process take turns here: the set-up is Python and numpy under one interpreter lock, and eight
+    # threads fighting for it took 7-8.5 s each in round 3 - profiles/r03_multi_gpu_launch_paths.txt - where one after the other
+    # they take what a process takes)
+    with _SETUP_LOCK:
+        launch, alg_bytes, kernel_name, desc, _keep = setup_workload(eng, args.workload, V, T, lo, total)
     launch()
     eng.sync()
     t_first = time.perf_counter()
