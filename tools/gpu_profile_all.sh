@@ -3,7 +3,8 @@
 # counters are collected with --kernel-trace only, in passes of their own) + a plain bench line.
 #   tools/gpu_profile_all.sh <tag> cfg3 cfg4 cfg5
 # Output: gpurun_out/profiles_<tag>/<tag>_<w>_{bench.json,bench_under_rocprof.json,kernel_stats.csv,pmc.txt} and pmc_traffic.json
-# EXTRA="--voices N ..." in the environment is passed to every bench.py call (e.g. the 1 GiB config-2 case).
+# EXTRA="--voices N ..." in the environment is passed to every bench.py call (e.g. the 1 GiB config-2 case). PMC=0 skips the counter passes
+# (kernel stats and bench lines only).
 set -u
 EXTRA=${EXTRA:-}
 tag=$1; shift
@@ -17,7 +18,7 @@ for w in "$@"; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats -- python $root/bench.py --workload $w $EXTRA --no-cpu-baseline > $out/${tag}_${w}_bench_under_rocprof.json 2> $scratch/stats.log )
   f=$(find $scratch/stats -name '*_kernel_stats.csv' | head -1)
   { echo "# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload $w --no-cpu-baseline   ($tag, MI355X)"; [ -n "$f" ] && head -6 $f; } > $out/${tag}_${w}_kernel_stats.csv
-  for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" \
+  [ "${PMC:-1}" = "0" ] || for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" \
               "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU" \
               "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_INSTS_SMEM"; do
     name=$(echo $pass | cut -d' ' -f1)
