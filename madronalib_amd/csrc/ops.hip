@@ -644,51 +644,59 @@ hipError_t mlgpu_launch_fill32(uint32_t* dst, uint32_t value, size_t n, hipStrea
 // of the last group count as +0. The order is part of the contract (include/mlgpu.h) so results are reproducible and checkable.
 namespace
 {
-__global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, size_t V, size_t T, const float* gains, float4* partial, uint32_t flags)
+// One wavefront per (group of 64 voices, DSPVector): lane v loads its voice's 16 quads (coalesced: 1 KiB per quad and wavefront),
+// scales them, and parks them as row v of a 64 x 64 tile in LDS (row stride 68 floats: 16-byte aligned for the b128 writes, and the
+// column reads below fall on 64 different banks); lane l then adds up column l - sample l of the 64 voices - in the contract's order,
+// the balanced tree over consecutive voices, and the wavefront writes its 64 sums as one 256-byte row. (Round 3's form reduced every
+// quad across the lanes with six shuffle-and-add rounds per component, one quad per wavefront at T = 1: 0.35 of HBM and a quarter of a
+// million tiny wavefronts for 2^20 voices.) a[i] += a[i + d] for d = 1, 2, 4 ... is exactly tree(0, 64) below.
+constexpr int kMixRow = 68;
+template <int LO, int N>
+struct MixTree
+{
+  static __device__ __forceinline__ float sum(const float* col) { return MixTree<LO, N / 2>::sum(col) + MixTree<LO + N / 2, N / 2>::sum(col); }
+};
+template <int LO>
+struct MixTree<LO, 1>
+{
+  static __device__ __forceinline__ float sum(const float* col) { return col[LO * kMixRow]; }
+};
+__global__ __launch_bounds__(256) void mixdown_stage1_kernel(SignalView sig, size_t V, size_t T, const float* gains, float* partial, uint32_t flags)
 {
   apply_fp_mode(flags);
-  const size_t nQuads = T * 16;
-  const size_t group = blockIdx.x;
+  __shared__ float tile[4][64 * kMixRow];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t groups = (V + 63) / 64, item = (size_t)blockIdx.x * 4 + wave;  // item = group * T + t
+  if (item >= groups * T) return;
+  const size_t group = item / T, t = item - group * T;
   const size_t v = group * 64 + lane;
   const bool live = v < V;
   const float g = (live && gains) ? gains[v] : 1.f;
-  // four quads per trip: their loads are issued together, then each is reduced
-  const size_t step = (size_t)gridDim.y * 4;
-  for (size_t q0 = (size_t)blockIdx.y * 4 + wave; q0 < nQuads; q0 += 4 * step)
+  float* row = tile[wave] + lane * kMixRow;
+  typedef float f32x4m __attribute__((ext_vector_type(4)));
+  const f32x4m* src = (const f32x4m*)sig.base + t * sig.strideT + v * sig.strideV;
+  f32x4m x[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) x[q] = live ? __builtin_nontemporal_load(src + q * sig.strideQ) : f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
   {
-    float4 x[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
+    f32x4m y = x[q];
+    if (gains)
     {
-      const size_t qi = q0 + (size_t)u * step;
-      x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live && qi < nQuads) x[u] = sig.base[(qi >> 4) * sig.strideT + (qi & 15) * sig.strideQ + v * sig.strideV];
+      y[0] *= g;
+      y[1] *= g;
+      y[2] *= g;
+      y[3] *= g;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-    {
-      const size_t qi = q0 + (size_t)u * step;
-      if (qi >= nQuads) break;
-      float4 y = x[u];
-      if (gains)
-      {
-        y.x *= g;
-        y.y *= g;
-        y.z *= g;
-        y.w *= g;
-      }
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1)
-      {
-        y.x = y.x + __shfl_down(y.x, d, 64);
-        y.y = y.y + __shfl_down(y.y, d, 64);
-        y.z = y.z + __shfl_down(y.z, d, 64);
-        y.w = y.w + __shfl_down(y.w, d, 64);
-      }
-      if (lane == 0) partial[group * nQuads + qi] = y;
-    }
+    *(f32x4m*)(row + 4 * q) = y;
   }
+  // (the tile is this wavefront's own: its lanes run in lockstep, the LDS operations of a wavefront complete in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float total = MixTree<0, 64>::sum(tile[wave] + lane);
+  partial[(group * T + t) * 64 + lane] = total;
 }
 
 // Rows of partial sums, 64 consecutive ones at a time, left to right: rows [64 r, 64 r + 64) of `in` -> row r of `out`. Applied
@@ -843,12 +851,7 @@ hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T
                                 hipStream_t stream, uint32_t flags)
 {
   const size_t groups = (V + 63) / 64, nQuads = T * 16;
-  unsigned y = (unsigned)((nQuads + 3) / 4);
-  const size_t wantBlocks = 4096;  // enough workgroups to fill the chip without a grid of millions
-  if ((size_t)y * groups > wantBlocks) y = (unsigned)((wantBlocks + groups - 1) / groups);
-  if (y < 1) y = 1;
-  hipLaunchKernelGGL(mixdown_stage1_kernel, dim3((unsigned)groups, y), dim3(256), 0, stream, makeView(sig, layout, V, T), V, T, gains,
-                     (float4*)partial, flags);
+  hipLaunchKernelGGL(mixdown_stage1_kernel, dim3((unsigned)((groups * T + 3) / 4)), dim3(256), 0, stream, makeView(sig, layout, V, T), V, T, gains, partial, flags);
   // the rows of group sums (in `partial`), 64 at a time, until one is left; the passes alternate between the two parts of the
   // scratch (mlgpu_mixdown_reserve: the second holds the first pass's rows / 64), the last one writes `out`
   float4* a = (float4*)partial;
