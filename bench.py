@@ -135,7 +135,7 @@ def setup_workload(eng, name, V, T, lo, total):
         from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
         full = name == "cfg5full"
         desc, outs = patches.synth16(full=full)
-        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=True)
+        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=bool(os.environ.get("MLGPU_BENCH_AUTOTUNE")))
         g.clear()
         params, coeffs, seeds = cfg5_voice_params(lo, lo + V, total, ml, full=full)
         for k, v in params.items():
@@ -216,7 +216,7 @@ def setup_workload(eng, name, V, T, lo, total):
         # MLGPU_BENCH_MIXDOWN=graph: the per-instrument voice sum is made inside the voice kernel (mlgpu_graph_set_output_group_sum)
         # instead of by mlgpu_mixdown_groups
         sumInKernel = os.environ.get("MLGPU_BENCH_MIXDOWN", "kernel") == "graph"
-        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=True,
+        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=bool(os.environ.get("MLGPU_BENCH_AUTOTUNE")),
                      output_groups={0: P} if sumInKernel else None)
         if fusedRows:
             g.bind_events(ev)
@@ -761,7 +761,7 @@ def run_rank(args, rank, local_rank, world, rdv):
                    "launches_per_step": L, "vectors_per_step": T * L, "samples_per_vector": 64,
                    "layout": "QUAD [S/4][V][4]", "parallelism": f"voices x{world} (no collective)", "launcher": rdv.kind,
                    "realtime_48k_voices": value / 48000.0,
-                   **({"graph_kernel_form": "%d voice(s) per lane, %d quad(s) per trip (tuned online)" % graphs[0].tuning()[1:],
+                   **({"graph_kernel_form": ("%d voice(s) per lane, %d quad(s) per trip" % graphs[0].tuning()[1:]) + (" (tuned online)" if os.environ.get("MLGPU_BENCH_AUTOTUNE") else " (the default form)"),
                        "hiprtc": ml.jit_stats()} if graphs else {})},
         "roofline": roof,
         "ranks": ranks,
@@ -792,6 +792,9 @@ def run_rank(args, rank, local_rank, world, rdv):
         if world == 1 and V * T * 64 * 8 < (256 << 20):
             roof["bound"] = "on-die"
             roof["bound_evidence"] = {"working_set_MiB": V * T * 64 * 8 / 2 ** 20, "infinity_cache_MiB": 256}
+            # (this run launches the same kernel over 1 GiB too, below: per-kernel PMC means would mix the two sizes)
+            for k in ("valu", "clock", "traffic", "pmc_case"):
+                roof[k] = None
             Vb = 4194304
             nb = Vb * 64
             d_bx, d_by = eng.alloc(4 * nb), eng.alloc(4 * nb)

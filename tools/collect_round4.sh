@@ -7,7 +7,8 @@ D=profiles
 cpset() {  # <dir> <workload in file names> <name in profiles>
   for f in $S/$1/r04_$2_*; do b=$(basename $f); cp $f $D/${b/r04_$2/$3}; done
 }
-for w in cfg3 cfg4 cfg5 cfg5full; do cpset profiles_main $w r04_$w; done
+for w in cfg3 cfg4; do cpset profiles_main $w r04_$w; done
+for w in cfg5 cfg5full; do cpset profiles_graphs $w r04_$w; done   # (re-profiled with the default kernel form: no online tuning trials among the calls)
 for w in synth synthfused events resample; do cpset profiles_wide $w r04_$w; done
 cpset profiles_cfg2_1GiB cfg2 r04_cfg2_1GiB
 cpset profiles_cfg2_32MiB cfg2 r04_cfg2_32MiB
