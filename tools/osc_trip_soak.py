@@ -24,6 +24,11 @@ def build(eng, V, trip):
 
 
 def main():
+    # (both oscillators sit on one frequency node and start from the same counters: since round 4 that is the LOCKED pair, one trip
+    # for both, mldsp_procs.hpp: trip_locked. `unlock` as a last argument gives the PulseGen counters of its own: two trips.)
+    unlock = sys.argv[-1] == "unlock"
+    if unlock:
+        sys.argv.pop()
     seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     V = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 32
@@ -41,8 +46,8 @@ def main():
         for t, g in forms.items():
             g.set_param("f", freq)
             g.set_param("w", width)
-            for nm in ("saw", "pw"):
-                g.set_state(nm, 0, phases)
+            g.set_state("saw", 0, phases)
+            g.set_state("pw", 0, (phases * np.uint32(2654435761) + np.uint32(12345)) if unlock else phases)
             a = g.process_host(T, {}, Layout.QUAD)
             b = g.process_host(T, {}, Layout.QUAD)   # resumed
             outs[t] = [x.view(np.uint32) for x in a + b] + [g.get_state("saw", 0), g.get_state("pw", 0)]
@@ -51,7 +56,7 @@ def main():
                 bad += int((x != y).sum())
         total += 2 * V * 64 * T
         print(f"seed {seed}: frequencies up to {lim:.4f}, {2 * V * 64 * T} samples per oscillator and form, mismatching words so far {bad}", flush=True)
-    print(f"{total} samples per oscillator per form, forms 1 / 2 / 4 quads per trip against the per-sample form: {bad} words differ "
+    print(f"{'unlocked' if unlock else 'locked'} pair, {total} samples per oscillator per form, forms 1 / 2 / 4 quads per trip against the per-sample form: {bad} words differ "
           f"(a phase lands within 2^-22 of 0 or 1 about {total * 2.0 ** -21:.0f} times in that many samples)")
     return 1 if bad else 0
 
