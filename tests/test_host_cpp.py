@@ -95,6 +95,21 @@ def test_reference_examples_compile_against_the_shim_alone(example, tmp_path):
     assert "/root/reference/source" not in used and "mlscalar.h" in used
 
 
+@pytest.mark.parametrize("test_file", ["dspOpsTest", "dspGensTest", "dspFiltersTest", "dspBufferTest"])
+def test_reference_unit_tests_compile_against_the_shim_alone(test_file, tmp_path):
+    """madronalib's own DSP unit tests include its headers by name (MLDSPOps.h, MLDSPScalarMath.h, MLDSPProjections.h ...): with
+    include/mlgpu/compat/dsp and include/mlgpu/compat as the only header directories (plus the tests' own directory for Catch) they
+    compile; tests/test_gpu_immediate.py runs the linked program on the device."""
+    src = os.path.join(REF, "Tests", test_file + ".cpp")
+    if not os.path.exists(src):
+        pytest.skip("no reference checkout here")
+    inc = ["-I" + os.path.join(COMPAT, "dsp"), "-I" + COMPAT, "-I" + os.path.join(REF, "Tests")]
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-fsyntax-only", "-w"] + inc + [src], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    used = subprocess.run(["g++", "-std=c++17", "-M", "-w"] + inc + [src], capture_output=True, text=True, timeout=300).stdout
+    assert "/root/reference/source" not in used
+
+
 SCALAR_PROBE = r"""
 #include <cstdio>
 #include <cstring>
