@@ -707,7 +707,8 @@ def run_rank(args, rank, local_rank, world, rdv):
         traffic = pmc["write_bytes_per_launch"] + (2.0 * raw if co is None else raw + min(raw, 0.5 * co))
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "kernel": kernel_name, "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": alg_bytes, "pmc_case": key if pmc else None}
+            "algorithmic_bytes_per_launch": alg_bytes, "pmc_case": key if pmc else None,
+            "device_code": ml.device_source_hash()[:16]}   # (what the PMC records are matched against)
     if pmc_stale:
         roof["pmc_stale"] = True
         roof["pmc_stale_reason"] = pmc_stale

@@ -13,10 +13,11 @@ for w in synth synthfused events resample; do cpset profiles_wide $w r04_$w; don
 cpset profiles_cfg2_1GiB cfg2 r04_cfg2_1GiB
 cpset profiles_cfg2_32MiB cfg2 r04_cfg2_32MiB
 cpset profiles_strings_windows strings r04w_strings_windows
-cp $S/pmc_workloads.json $D/pmc_workloads.json
+cp $S/pmc_workloads.json $D/pmc_workloads.json   # (the box starts from the committed file: commit it before a partial re-profile)
 for f in lines graph_steps wave_clock node_costs; do cp $S/$f.txt $D/r04_$f.txt; done
 for w in cfg3 cfg4 cfg5 cfg5full cfg2; do cp $S/${w}_line.json $D/r04_${w}_line_with_pmc.json; done
 cp $S/default_bench.json $D/r04_default_bench.json
 cp $S/cfg3_sustained.json $D/r04_cfg3_sustained.json
 python tools/summarize_profiles.py $D r04 > $D/r04_summary.md
+python tools/check_pmc_fresh.py
 ls $D | grep -c r04
