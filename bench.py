@@ -390,7 +390,11 @@ ISSUE_NS = {"plain": 1.09, "slow": 1.8, "f64": 1.85, "trans": 3.5}
 N_SIMD = 256 * 4
 
 
-def valu_busy(pmc, kernel_ms):
+# with two wavefronts per SIMD instead of four the same instructions issue slower (profiles/r03_bankbench.txt: 1.28 / 2.09 ns)
+ISSUE_NS_2_WAVES = {"plain": 1.28, "slow": 2.09}
+
+
+def valu_busy(pmc, kernel_ms, waves_per_simd=4.0):
     """(low, high) fraction of the launch during which the SIMDs' vector issue is occupied, from the instruction-class counters."""
     total = pmc.get("valu_wave_insts_per_launch")
     if not total or "SQ_INSTS_VALU_ADD_F32" not in pmc:
@@ -400,13 +404,26 @@ def valu_busy(pmc, kernel_ms):
     cvt, trans = pmc.get("SQ_INSTS_VALU_CVT", 0.0), pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
     integer = pmc.get("SQ_INSTS_VALU_INT32", 0.0) + pmc.get("SQ_INSTS_VALU_INT64", 0.0)
     other = max(0.0, total - f32 - f64 - cvt - trans - integer)
-    known = f32 * ISSUE_NS["plain"] + f64 * ISSUE_NS["f64"] + cvt * ISSUE_NS["slow"] + trans * ISSUE_NS["trans"] + integer * ISSUE_NS["plain"]
+    # packed FP32 (two lanes' worth per instruction, v_pk_*_f32) is counted once by the F32 class counters and issues at the slow
+    # class's rate: its share among the kernel's FP32 instructions comes with the record (static, from the shipped code object)
+    packed = float(pmc.get("packed_f32_share") or 0.0)
+    known = (f32 * (packed * ISSUE_NS["slow"] + (1.0 - packed) * ISSUE_NS["plain"]) + f64 * ISSUE_NS["f64"] + cvt * ISSUE_NS["slow"]
+             + trans * ISSUE_NS["trans"] + integer * ISSUE_NS["plain"])
     span = N_SIMD * kernel_ms * 1e6
-    return {"busy_frac": [(known + other * ISSUE_NS["plain"]) / span, (known + other * ISSUE_NS["slow"]) / span],
+    lo, hi = (known + other * ISSUE_NS["plain"]) / span, (known + other * ISSUE_NS["slow"]) / span
+    if waves_per_simd <= 2.0:
+        # a launch that fills two wavefront slots per SIMD (config 4: 131 072 channels): the high figure at the two-wavefront rates
+        r = ISSUE_NS_2_WAVES
+        hi = (f32 * (packed * r["slow"] + (1.0 - packed) * r["plain"]) + f64 * ISSUE_NS["f64"] * r["slow"] / ISSUE_NS["slow"] + cvt * r["slow"]
+              + trans * ISSUE_NS["trans"] + integer * r["plain"] + other * r["slow"]) / span
+    return {"busy_frac": [lo, hi],
+            "packed_f32_share": packed, "wavefronts_per_simd": waves_per_simd,
             "classes_per_launch": {"f32_add_mul_fma": f32, "f64": f64, "cvt": cvt, "trans": trans, "int": integer, "other": other},
             "model": "sum over instruction classes of SQ_INSTS_VALU_* x the class's measured issue time (ns per wave-instruction per SIMD: "
                      f"{ISSUE_NS}; tools/instbench.hip, DESIGN 3.11) / (1024 SIMDs x launch time); 'other' (compares, selects, min / max, moves) priced "
-                     "at the plain and at the slow rate gives the low and the high figure; integer multiplies (quarter rate) are priced plain"}
+                     "at the plain and at the slow rate gives the low and the high figure; packed FP32 (packed_f32_share of the FP32 class, static "
+                     "from the shipped kernel: tools/kernel_mix.py) at the slow rate; a launch of two wavefronts per SIMD is priced at the "
+                     f"two-wavefront rates {ISSUE_NS_2_WAVES} for the high figure; integer multiplies (quarter rate) are priced plain"}
 
 
 def pattern_ceiling(eng, V, T, streamed_input, reps=12):
@@ -740,7 +757,7 @@ def run_rank(args, rank, local_rank, world, rdv):
                         "note": "an instruction count, not a utilisation: packed FP32, compares, selects and conversions occupy the SIMD "
                                 "twice as long as a plain add / mul / fma (DESIGN 3.11); config 4 at 'frac 0.33' has its VALU port 85 % busy "
                                 "(profiles/r03_cfg4_account.md)"}
-        busy = valu_busy(pmc, kernel_ms)
+        busy = valu_busy(pmc, kernel_ms, waves_per_simd=max(1.0, V / 64.0 / N_SIMD))
         if busy:
             roof["valu"].update(busy)
             roof["valu"]["scalar_insts_per_unit"] = pmc.get("SQ_INSTS_SALU", 0.0) * 64.0 / units_per_launch if pmc.get("SQ_INSTS_SALU") else None

@@ -41,6 +41,7 @@ def main():
     # the fingerprint of the device code these counters were measured on (bench.py drops records of another build)
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import madronalib_amd as ml
     device_hash = ml.device_source_hash()
     for arg in sys.argv[2:]:
@@ -73,6 +74,13 @@ def main():
                     if c in v:
                         rec[c] = v[c]
                 break
+        # packed FP32 is counted once by SQ_INSTS_VALU_*_F32 but issues at the slow class's rate: its static share in the shipped kernel
+        # (tools/kernel_mix.py; None for kernels compiled at run time - the fused graph kernels hold no packed instructions)
+        try:
+            import kernel_mix
+            rec["packed_f32_share"] = kernel_mix.packed_share(kernel)
+        except Exception as e:  # noqa: BLE001  (no llvm-objdump: the record simply lacks the field)
+            print("packed share not computed:", e)
         res["workloads"][case] = rec
         print(case, kernel[:60], f"{rec['hbm_bytes_per_launch'] / 1e9:.3f} GB", rec.get("valu_wave_insts_per_launch"))
     json.dump(res, open(outp, "w"), indent=1)
