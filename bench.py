@@ -729,12 +729,17 @@ def run_rank(args, rank, local_rank, world, rdv):
     if pmc_stale:
         roof["pmc_stale"] = True
         roof["pmc_stale_reason"] = pmc_stale
+    # A block of several kernels (the instrument bank: events -> voices -> per-instrument sums) is timed as a whole; the counters are
+    # the voice kernel's alone, so its clock and issue figures are taken over ITS duration (as measured under the counter pass)
+    span_ms, span_what = kernel_ms, "live launch duration"
+    if args.workload in ("synth", "synthfused") and pmc.get("mean_us_under_pmc"):
+        span_ms, span_what = pmc["mean_us_under_pmc"] * 1e-3, "the named kernel's mean duration under the counter pass (the block holds other kernels too)"
     if pmc.get("GRBM_GUI_ACTIVE"):
         # GRBM_GUI_ACTIVE sums the 8 XCDs: / 8 = shader cycles per launch; over the live launch time = the clock the chip
         # held under this load (it clocks to its power budget: MI355X_MICROARCH.md, DVFS)
         cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0
-        roof["clock"] = {"cycles_per_launch": cyc, "ghz_live": cyc / (kernel_ms * 1e-3) / 1e9,
-                         "source": "GRBM_GUI_ACTIVE / 8 XCDs (profiles/pmc_workloads.json) / live launch duration"}
+        roof["clock"] = {"cycles_per_launch": cyc, "ghz_live": cyc / (span_ms * 1e-3) / 1e9,
+                         "source": "GRBM_GUI_ACTIVE / 8 XCDs (profiles/pmc_workloads.json) / " + span_what}
     # what the same access pattern reaches with (almost) no arithmetic, on this box, now: the honest ceiling of an HBM-bound launch
     streamed = args.workload in ("cfg4", "cfg5", "cfg5full", "cfg2")
     if world == 1 and args.workload in ("cfg3", "cfg4", "cfg5", "cfg5full"):
@@ -750,14 +755,14 @@ def run_rank(args, rank, local_rank, world, rdv):
     if pmc.get("valu_wave_insts_per_launch"):
         # the second bound (SURVEY 8d "report both bounds"): VALU issue. SQ_INSTS_VALU counts wave-instructions; x64 lanes.
         ipu = pmc["valu_wave_insts_per_launch"] * 64.0 / units_per_launch
-        lane_rate = ipu * units_per_launch / (kernel_ms * 1e-3)
+        lane_rate = ipu * units_per_launch / (span_ms * 1e-3)
         roof["valu"] = {"insts_per_unit": ipu, "achieved_lane_inst_per_s": lane_rate, "peak": VALU_PEAK_LANE_INST,
                         "frac": lane_rate / VALU_PEAK_LANE_INST,
-                        "source": "SQ_INSTS_VALU per launch (profiles/pmc_workloads.json) x 64 lanes / live launch duration",
+                        "source": "SQ_INSTS_VALU per launch (profiles/pmc_workloads.json) x 64 lanes / " + span_what,
                         "note": "an instruction count, not a utilisation: packed FP32, compares, selects and conversions occupy the SIMD "
                                 "twice as long as a plain add / mul / fma (DESIGN 3.11); config 4 at 'frac 0.33' has its VALU port 85 % busy "
                                 "(profiles/r03_cfg4_account.md)"}
-        busy = valu_busy(pmc, kernel_ms, waves_per_simd=max(1.0, V / 64.0 / N_SIMD))
+        busy = valu_busy(pmc, span_ms, waves_per_simd=max(1.0, V / 64.0 / N_SIMD))
         if busy:
             roof["valu"].update(busy)
             roof["valu"]["scalar_insts_per_unit"] = pmc.get("SQ_INSTS_SALU", 0.0) * 64.0 / units_per_launch if pmc.get("SQ_INSTS_SALU") else None

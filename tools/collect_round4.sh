@@ -21,3 +21,12 @@ cp $S/cfg3_sustained.json $D/r04_cfg3_sustained.json
 python tools/summarize_profiles.py $D r04 > $D/r04_summary.md
 python tools/check_pmc_fresh.py
 ls $D | grep -c r04
+# (the records name the files as they are called in profiles/)
+python - <<'PY'
+import json
+p = 'profiles/pmc_workloads.json'; d = json.load(open(p))
+for k, n in {'cfg2:65536x1': 'r04_cfg2_32MiB', 'cfg2:4194304x1': 'r04_cfg2_1GiB', 'strings:delay_windows=1:262144x16': 'r04w_strings_windows'}.items():
+    if d['workloads'].get(k, {}).get('files', '').startswith('r04'):
+        d['workloads'][k]['files'] = n + '_{traffic.json,pmc.txt}'
+json.dump(d, open(p, 'w'), indent=1)
+PY
