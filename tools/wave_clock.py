@@ -65,3 +65,23 @@ print(f"  distinct (XCD, SE, CU, SIMD) seen: {slots}; wavefronts per SIMD: min {
 # by voice block: does a wavefront's life depend on where its voices are?
 k = len(t) // 8
 print("  median life by eighth of the voice range:", [round(float(np.median(life[i * k:(i + 1) * k])), 1) for i in range(8)])
+# where in the chip: is a SIMD index, a CU or a shader engine systematically slower? (mean life, us; spread of the per-SIMD means)
+print("  mean life by SIMD index:", [round(float(life[simd == s].mean()), 1) for s in range(4)],
+      " by wave slot:", [round(float(life[wave_slot == s].mean()), 1) for s in sorted(set(wave_slot.astype(int).tolist()))])
+print("  mean life by SE:", [round(float(life[se == s].mean()), 1) for s in sorted(set(se.astype(int).tolist()))])
+print("  mean life by CU index:", [round(float(life[cu == c].mean()), 1) for c in sorted(set(cu.astype(int).tolist()))])
+per_simd_last = np.zeros(sid.max() + 1)
+np.maximum.at(per_simd_last, sid, us(t1))
+per_simd_first = np.full(sid.max() + 1, 1e30)
+np.minimum.at(per_simd_first, sid, us(t1))
+used = np.bincount(sid, minlength=sid.max() + 1) > 0
+print(f"  per SIMD: last end min {per_simd_last[used].min():.1f} median {np.median(per_simd_last[used]):.1f} max {per_simd_last[used].max():.1f};"
+      f" first end min {per_simd_first[used].min():.1f} median {np.median(per_simd_first[used]):.1f}; "
+      f"mean (last - first end) within a SIMD {np.mean(per_simd_last[used] - per_simd_first[used]):.1f} us")
+# within a CU: do its four SIMDs end together?
+cid = sid // 4
+per_cu_last = np.zeros(cid.max() + 1); np.maximum.at(per_cu_last, cid, us(t1))
+per_cu_first_simd_last = np.full(cid.max() + 1, 1e30); np.minimum.at(per_cu_first_simd_last, sid // 4, per_simd_last[sid])
+usedc = np.bincount(cid, minlength=cid.max() + 1) > 0
+print(f"  per CU: last end min {per_cu_last[usedc].min():.1f} median {np.median(per_cu_last[usedc]):.1f} max {per_cu_last[usedc].max():.1f}; "
+      f"spread of its SIMDs' last ends (mean) {np.mean(per_cu_last[usedc] - per_cu_first_simd_last[usedc]):.1f} us")
