@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import madronalib_amd as ml  # noqa: E402
 from madronalib_amd.constants import Layout  # noqa: E402
 
-V, T = 262144, 16
+V, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (262144, 16)
 eng = ml.Engine(0)
 n = V * T * 64
 d_x = eng.alloc(4 * n)
