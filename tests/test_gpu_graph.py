@@ -1,6 +1,8 @@
 """GPU parity of run-time defined graphs (BASELINE configs[4]: a 16-node synth patch) and of chains
 fused at run time with hiprtc, against the CPU oracle evaluating the same graph node by node.
 Bit-exact (no hardware-approximate node is used in these graphs)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -896,7 +898,8 @@ def test_oscillator_trips_on_the_knife_edges(eng, oracle, trip_quads, vpl, unloc
     g.set_coeffs("pc", [width])
     start = {nm: phases.copy() for nm in outs}
     if trip_quads:
-        assert ("trip_locked<" in g.source) and "locked2" in g.source     # node 2 (the saw) is paired with node 3
+        if os.environ.get("MLGPU_GRAPH_LOCK_OSC", "1") != "0":   # (the developer knob that turns the pairing off: the rest still has to hold)
+            assert ("trip_locked<" in g.source) and "locked2" in g.source     # node 2 (the saw) is paired with node 3
     if unlock:
         start["pw"][64 * 5 + 3::64 * 7] ^= np.uint32(1)
         start["pw"][V // 4:V // 2] = rng.integers(0, 2 ** 32, V // 2 - V // 4, dtype=np.uint64).astype(np.uint32)
