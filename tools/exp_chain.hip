@@ -14,6 +14,15 @@
 
 using namespace mldev;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// -DEXP_TURNS=1: the wavefronts of a SIMD take turns at the priority levels by the shared clock (round 4's take_turns_by_clock), every 4 quads
+#ifndef EXP_TURNS
+#define EXP_TURNS 0
+#endif
+#if EXP_TURNS
+#define EXP_TURN(r) do { if (((r) & 3) == 0) take_turns_by_clock(wave_slot(), 13); } while (0)
+#else
+#define EXP_TURN(r) do { } while (0)
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 struct Args
@@ -47,6 +56,7 @@ __global__ __launch_bounds__(BLK) void k_v0(Args a)
   f32x4* po = a.out + v;
   for (size_t r = 0; r < a.T * 16; ++r)
   {
+    EXP_TURN(r);
     f32x4 y;
     y.x = ch.next_head<true>(xc);
     y.y = ch.next_head<true>(xc);
@@ -102,6 +112,7 @@ __global__ __launch_bounds__(BLK) void k_v1(Args a)
   f32x4 *pa = a.out + va, *pb = a.out + vb;
   for (size_t r = 0; r < a.T * 16; ++r)
   {
+    EXP_TURN(r);
     f32x4 ya, yb;
     ya.x = ca.next_head<true>(xa); yb.x = cb.next_head<true>(xb);
     ya.y = ca.next_head<true>(xa); yb.y = cb.next_head<true>(xb);
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(BLK) void k_v2(Args a)
   }
   for (size_t r = 0; r < a.T * 16; ++r)
   {
+    EXP_TURN(r);
     f32x4 y[N];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -261,6 +273,7 @@ __global__ __launch_bounds__(BLK) void k_v3(Args a)
   f32x4 *pa = a.out + va, *pb = a.out + vb;
   for (size_t r = 0; r < a.T * 16; ++r)
   {
+    EXP_TURN(r);
     f32x4 ya, yb;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(BLK) void k_v4(Args a)
   f32x4* po = a.out + v;
   for (size_t r = 0; r < a.T * 16; r += UN)
   {
+    EXP_TURN(r);
 #pragma unroll
     for (int u = 0; u < UN; ++u)
     {
@@ -446,6 +460,7 @@ __global__ __launch_bounds__(BLK) void k_v8(Args a)
   };
   for (size_t r = 0; r < a.T * 16; r += NQ)
   {
+    EXP_TURN(r);
     float p[N];
     bool lo[N], hi[N];
     float tmin = 0.f, tmax = 0.f;
@@ -607,6 +622,7 @@ __global__ __launch_bounds__(BLK) void k_v9(Args a)
   const size_t R = a.T * 16;
   for (size_t r = 0; r < R; r += NQ)
   {
+    EXP_TURN(r);
     // the filter of this trip next to stage A of the next one (the last trip's extra stage A is undone below)
     f32x4 y[NQ];
     float xs[N];
