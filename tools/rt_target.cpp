@@ -7,7 +7,7 @@
 //   2. paced at 48 kHz through mlgpu_process_buffer_process (voice bank + mixdown to one channel + D2H of that channel), the host
 //      waiting out each block period: wall time per call p50 / p99 / max against the period, and the number of calls that took
 //      longer than the period (deadline misses), synchronous and pipelined.
-// Host C++ over the C-ABI only.   usage: rt_target [blocks=1500] > profiles/r04_rt_target.json
+// Host C++ over the C-ABI only.   usage: rt_target [blocks=1500] [voices] [frames] > profiles/r04_rt_target.json
 //   g++ -std=c++17 -O2 -Iinclude tools/rt_target.cpp -o tools/bin/rt_target -Lmadronalib_amd/csrc -lmlgpu -Wl,-rpath,'$ORIGIN/../../madronalib_amd/csrc' -Wl,-rpath,/opt/rocm/lib
 #include <algorithm>
 #include <chrono>
@@ -40,6 +40,8 @@ static int onVectors(void* user, size_t nVectors, const float* const*, float* co
 int main(int argc, char** argv)
 {
   const int blocks = argc > 1 ? atoi(argv[1]) : 1500;
+  const size_t onlyV = argc > 2 ? (size_t)atoll(argv[2]) : 0;   // one voice count (for a rocprofv3 run of that case alone)
+  const int onlyFrames = argc > 3 ? atoi(argv[3]) : 0;
   Engine eng(0);
   printf("{\"tool\": \"rt_target\", \"blocks_per_case\": %d, \"sample_rate\": 48000, \"process\": \"SawGen->Bandpass(k=0.5)->gain voice bank (BASELINE configs[2] per-voice frequencies), "
          "then mixdown to one channel and D2H in the paced legs\", \"hbm_peak_GBps\": 8000, \"cases\": [\n", blocks);
@@ -47,6 +49,7 @@ int main(int argc, char** argv)
   for (size_t V : {(size_t)262144, (size_t)1048576, (size_t)2097152, (size_t)4194304, (size_t)8388608})
     for (int frames : {64, 512})
     {
+      if ((onlyV && V != onlyV) || (onlyFrames && frames != onlyFrames)) continue;
       const size_t T = (size_t)frames / 64;
       if (V * (size_t)frames * 4 > ((size_t)40 << 30)) continue;
       DeviceSignal voices(eng, V, T + 1, MLGPU_LAYOUT_QUAD);
