@@ -591,6 +591,17 @@ class Events:
         arr = (Event * n)(*events)
         self.engine._check(self.L.mlgpu_events_add_events(self.h, _np_ptr(inst), ctypes.cast(arr, ctypes.c_void_p), n))
 
+    @staticmethod
+    def pack_events(instruments, events):
+        """A block's events ready to hand over: (uint32 instrument indices, ctypes array of Event, count) for add_events_packed."""
+        n = len(events)
+        return np.ascontiguousarray(instruments, np.uint32), (Event * max(1, n))(*events), n
+
+    def add_events_packed(self, packed):
+        inst, arr, n = packed
+        if n:
+            self.engine._check(self.L.mlgpu_events_add_events(self.h, _np_ptr(inst), ctypes.cast(arr, ctypes.c_void_p), n))
+
     def clear_events(self):
         self.engine._check(self.L.mlgpu_events_clear_events(self.h))
 

@@ -555,6 +555,8 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
       }
     }
     else
+    {
+    RecCache recCache;
 #pragma unroll 1
     for (int q = 0; q < 16; ++q)
     {
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
         float vPitch = 0.f, vGate = 0.f, vTime = 0.f;
         if (on)
         {
-          note_frame(a.recs, nc, vend, n, preApplied, velocity, pitch, age, ageStep, inhibit, a.s.pitchGlideSamples, wantTime, srD, setPitchGlideTime,
+          note_frame(a.recs, recCache, nc, vend, n, preApplied, velocity, pitch, age, ageStep, inhibit, a.s.pitchGlideSamples, wantTime, srD, setPitchGlideTime,
                      pitchGlideNext, vPitch, vGate, vTime);
           const float bendSig = gb.next(GS(0), ln, n), driftSig = gd.next(GS(5), ln, n);
           vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
@@ -581,6 +583,7 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
       put(0, q, oPitch);
       put(1, q, oGate);
       put(7, q, oTime);
+    }
     }
     if (on)
     {
@@ -608,6 +611,243 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
   SW(S_PG_PER_GLIDE) = (uint32_t)pgPerGlide; SW(S_PG_DY) = f2u(pgDy);
   SW(S_DRIFT_SEED) = driftSeed; SW(S_DRIFT_COUNTER) = (uint32_t)driftCounter; SW(S_DRIFT_VALUE) = f2u(driftValue); SW(S_DRIFT_NEXT) = (uint32_t)driftNext;
 #undef GS
+#undef SW
+}
+
+// ---- the control-rate half of EventsToSignals for voice graphs (mldsp_events.hpp: CtlVoice is the audio-rate half) ----------------
+// One lane per voice (MIDI protocol). Per DSPVector: the records of the vector, Voice::beginProcess (:75-126) with the drift random
+// walk, the bend glide's start of a vector, and a decision: does anything move INSIDE this vector apart from the drift glide? If
+// not - no note event, the pitch glide at rest, the bend held: all but a few per cent of the vectors - the vector is four words
+// (pitch before drift, gate, the drift glide's input, flags) and costs no per-sample work at all. If so, the lane walks the 64
+// frames with note_frame() as e2s_kernel does and writes its pitch-before-drift and gate to the side signals (16 quads each);
+// a portamento in progress with nothing else going on is the pitch glide's 64 steps alone (pitch side signal only). The drift glide is not touched here: its slots belong to the
+// voice kernel, and nothing in this kernel depends on them (the drift term is added last, :247).
+struct E2SCtlArgs
+{
+  uint32_t* state;
+  const Rec* recs;
+  const uint32_t* recStart;
+  uint32_t* ctl;   // [T][kCtlRecWords][lanes]
+  float4* rowP;    // QUAD [16 T][lanes][4], written for CF_ROWS vectors only
+  float4* rowG;
+  size_t lanes, T;
+  uint32_t flags;
+  E2SSettings s;
+};
+
+__global__ __launch_bounds__(256) void e2s_ctl_kernel(const E2SCtlArgs a)
+{
+  apply_fp_mode(a.flags);
+  size_t blk = blockIdx.x;
+  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
+  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);
+  const size_t lane = blk * 256 + threadIdx.x;
+  if (lane >= a.lanes) return;
+  uint32_t* S = a.state + lane;
+  const size_t ln = a.lanes;
+#define SW(i) S[(size_t)(i) * ln]
+  bool awake = SW(S_AWAKE) != 0;
+  float velocity = u2f(SW(S_VELOCITY)), pitch = u2f(SW(S_PITCH)), bend = u2f(SW(S_BEND)), cz = u2f(SW(S_Z));
+  uint32_t age = SW(S_AGE), ageStep = SW(S_AGE_STEP);
+  bool inhibit = SW(S_INHIBIT_GLIDE) != 0, needsRecalc = SW(S_RECALC) != 0;
+  float pgCurr = u2f(SW(S_PG_CURR)), pgStep = u2f(SW(S_PG_STEP)), pgTarget = u2f(SW(S_PG_TARGET)), pgDy = u2f(SW(S_PG_DY));
+  int32_t pgRemaining = (int32_t)SW(S_PG_REMAINING), pgPerGlide = (int32_t)SW(S_PG_PER_GLIDE);
+  uint32_t driftSeed = SW(S_DRIFT_SEED);
+  int32_t driftCounter = (int32_t)SW(S_DRIFT_COUNTER), driftNext = (int32_t)SW(S_DRIFT_NEXT);
+  float driftValue = u2f(SW(S_DRIFT_VALUE));
+  // controller values that only pass through (their rows are not computed by this form): kept current as mlgpu_events_set_wanted_rows does
+  uint32_t* GB = S + (size_t)(S_GLIDES + 0 * kGlideWords) * ln;
+  Glide gb;
+  gb.load(GB, ln);
+
+  auto setPitchGlideTime = [&](int32_t t) {  // SampleAccurateLinearGlide::setGlideTimeInSamples, MLDSPGens.h:527-532
+    pgPerGlide = t < 1 ? 1 : t;
+    pgDy = 1.0f / (float)pgPerGlide;
+  };
+  auto pitchGlideNext = [&](float f) {  // nextSample, :541-580
+    if (f != pgTarget)
+    {
+      pgTarget = f;
+      pgRemaining = pgPerGlide;
+    }
+    if (pgRemaining < 0) {}
+    else if (pgRemaining == 0)
+    {
+      pgCurr = pgTarget;
+      pgStep = 0.f;
+      pgRemaining--;
+    }
+    else if (pgRemaining == pgPerGlide)
+    {
+      pgStep = (pgTarget - pgCurr) * pgDy;
+      pgRemaining--;
+    }
+    else
+    {
+      pgCurr += pgStep;
+      pgRemaining--;
+    }
+    return pgCurr;
+  };
+
+  uint32_t cursor = a.recStart[lane];
+  const uint32_t recEnd = a.recStart[lane + 1];
+  // the vector of this lane's next record, in a register: a lane with a record later in the launch does not ask memory every vector
+  uint32_t nextVec = cursor < recEnd ? a.recs[cursor].vec : 0xFFFFFFFFu;
+  const float pitchBendScale = a.s.pitchBendRange;  // MIDI protocol, :417-423
+  uint32_t* rec = a.ctl + lane;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (size_t t = 0; t < a.T; ++t, rec += (size_t)kCtlRecWords * ln)
+  {
+    uint32_t vend = cursor;
+    if (nextVec == (uint32_t)t)
+      while (vend < recEnd && a.recs[vend].vec == (uint32_t)t) ++vend;
+    if (!awake)
+      for (uint32_t r = cursor; r < vend; ++r)
+        if ((a.recs[r].typeTimeFlags & 0xFF) == REC_AWAKE) awake = true;
+    const bool on = awake;
+    bool noteHere = false;
+    if (on)
+    {
+      // ---- Voice::beginProcess, :75-126 ----
+      if (needsRecalc)
+      {
+        if (!inhibit) setPitchGlideTime(a.s.pitchGlideSamples);
+        needsRecalc = false;
+      }
+      driftCounter += MLGPU_FLOATS_PER_DSPVECTOR;
+      if (driftCounter >= driftNext)
+      {
+        driftSeed = driftSeed * 0x0019660Du + 0x3C6EF35Fu;  // RandomScalarSource::getFloat, MLDSPScalarMath.h:189-202
+        const float d = u2f(((driftSeed >> 9) & 0x007FFFFFu) | 0x3F800000u) * 2.f - 3.f;
+        driftSeed = driftSeed * 0x0019660Du + 0x3C6EF35Fu;
+        const float d2 = u2f(((driftSeed >> 9) & 0x007FFFFFu) | 0x3F800000u) * 2.f - 3.f;
+        const float nextTimeMul = 1.0f + abs_ps(d2);
+        driftValue = d;
+        driftCounter = 0;
+        driftNext = (int32_t)(a.s.sr * (double)nextTimeMul * (double)8.0f);
+      }
+      // ---- values that only matter at the end of the vector (endProcess, :218-247); the rows this form does not compute keep their
+      //      values in memory ----
+      float finalVelocity = velocity;
+      for (uint32_t r = cursor; r < vend; ++r)
+      {
+        const Rec rc = a.recs[r];
+        switch (rc.typeTimeFlags & 0xFF)
+        {
+          case REC_SET_BEND: bend = rc.v1; break;
+          case REC_SET_MOD: SW(S_MOD) = f2u(rc.v1); break;
+          case REC_SET_X: SW(S_X) = f2u(rc.v1); break;
+          case REC_SET_Y: SW(S_Y) = f2u(rc.v1); break;
+          case REC_SET_Z: cz = rc.v1; break;
+          case REC_SET_CHANNEL_PRESSURE: SW(S_CHANPRESS) = f2u(rc.v1); break;
+          case REC_NOTE_ON: case REC_NOTE_RETRIG: finalVelocity = rc.v2; noteHere = true; break;
+          case REC_NOTE_OFF: finalVelocity = 0.f; noteHere = true; break;
+          default: break;
+        }
+      }
+      if (finalVelocity == 0.f) cz = 0.f;  // :238-241
+      gb.beginVector(GB, ln, bend, a.s.glideVectors, a.s.glideDy);
+    }
+    const int bm = gb.mode();
+    const bool heldB = (bm == 1) || (bm == 0 && gb.isUniform());
+    const bool pgBusy = on && (pitch != pgTarget || pgRemaining >= 0);
+    const bool walk = on && (noteHere || !heldB);
+    const bool glideOnly = on && !walk && pgBusy;  // a portamento in progress, nothing else: the pitch glide's 64 steps, the gate held
+    const float hvB = (bm == 1) ? gb.target : gb.uniformValue;
+    float P = 0.f, gate = 0.f;
+    if (!walk)
+    {
+      if (on)
+      {
+        gate = velocity;
+        age += (uint32_t)MLGPU_FLOATS_PER_DSPVECTOR * ageStep;
+        const float bendTerm = (hvB * pitchBendScale) * (1.f / 12);  // :244
+        if (!glideOnly) P = pgCurr + bendTerm;  // the same for all 64 frames
+        else
+        {
+          f32x4* oP = (f32x4*)a.rowP + (t * 16) * ln + lane;
+          // in the middle of a glide - 64 or more steps to go, the target unchanged - every frame of the vector is nextSample's last
+          // branch (:571-576): mCurr += mStep. 64 dependent adds instead of 64 trips through the state machine.
+          if (pitch == pgTarget && pgRemaining >= MLGPU_FLOATS_PER_DSPVECTOR && pgRemaining < pgPerGlide)
+          {
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q, oP += ln)
+            {
+              f32x4 vP;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+              {
+                pgCurr += pgStep;
+                vP[k] = pgCurr + bendTerm;
+              }
+              __builtin_nontemporal_store(vP, oP);
+            }
+            pgRemaining -= MLGPU_FLOATS_PER_DSPVECTOR;
+          }
+          else
+#pragma unroll 1
+          for (int q = 0; q < 16; ++q, oP += ln)
+          {
+            f32x4 vP;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vP[k] = pitchGlideNext(pitch) + bendTerm;
+            __builtin_nontemporal_store(vP, oP);
+          }
+        }
+      }
+    }
+    else
+    {
+      // ---- gate and pitch frame by frame: writeNoteEvent (:115-216) and endProcess (:218-244) ----
+      uint32_t nc = cursor;
+      bool preApplied = false;
+      RecCache recCache;
+      f32x4* oP = (f32x4*)a.rowP + (t * 16) * ln + lane;
+      f32x4* oG = (f32x4*)a.rowG + (t * 16) * ln + lane;
+#pragma unroll 1
+      for (int q = 0; q < 16; ++q, oP += ln, oG += ln)
+      {
+        f32x4 vP = {0.f, 0.f, 0.f, 0.f}, vG = vP;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k)
+        {
+          const int n = q * 4 + k;
+          float vPitch = 0.f, vGate = 0.f, vTime = 0.f;
+          note_frame(a.recs, recCache, nc, vend, n, preApplied, velocity, pitch, age, ageStep, inhibit, a.s.pitchGlideSamples, false, 1.0, setPitchGlideTime,
+                     pitchGlideNext, vPitch, vGate, vTime);
+          const float bendSig = gb.next(GB, ln, n);
+          vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);  // :244
+          vP = f32x4{k == 0 ? vPitch : vP[0], k == 1 ? vPitch : vP[1], k == 2 ? vPitch : vP[2], k == 3 ? vPitch : vP[3]};
+          vG = f32x4{k == 0 ? vGate : vG[0], k == 1 ? vGate : vG[1], k == 2 ? vGate : vG[2], k == 3 ? vGate : vG[3]};
+        }
+        __builtin_nontemporal_store(vP, oP);
+        __builtin_nontemporal_store(vG, oG);
+      }
+    }
+    rec[0] = f2u(P);
+    rec[ln] = f2u(gate);
+    rec[2 * ln] = f2u(driftValue);
+    rec[3 * ln] = (on ? CF_ON : 0u) | ((walk || glideOnly) ? CF_ROWS : 0u) | (walk ? CF_GATE_ROW : 0u);
+    if (on) gb.endVector();
+    if (vend != cursor)
+    {
+      cursor = vend;
+      nextVec = cursor < recEnd ? a.recs[cursor].vec : 0xFFFFFFFFu;
+    }
+  }
+  {
+    size_t Lend = lane;
+    asm volatile("" : "+v"(Lend));
+    S = a.state + Lend;
+  }
+  gb.store(S + (size_t)(S_GLIDES + 0 * kGlideWords) * ln, ln);
+  SW(S_AWAKE) = awake ? 1u : 0u;
+  SW(S_VELOCITY) = f2u(velocity); SW(S_PITCH) = f2u(pitch); SW(S_BEND) = f2u(bend); SW(S_Z) = f2u(cz);
+  SW(S_AGE) = age; SW(S_AGE_STEP) = ageStep; SW(S_INHIBIT_GLIDE) = inhibit ? 1u : 0u; SW(S_RECALC) = needsRecalc ? 1u : 0u;
+  SW(S_PG_CURR) = f2u(pgCurr); SW(S_PG_STEP) = f2u(pgStep); SW(S_PG_TARGET) = f2u(pgTarget); SW(S_PG_REMAINING) = (uint32_t)pgRemaining;
+  SW(S_PG_PER_GLIDE) = (uint32_t)pgPerGlide; SW(S_PG_DY) = f2u(pgDy);
+  SW(S_DRIFT_SEED) = driftSeed; SW(S_DRIFT_COUNTER) = (uint32_t)driftCounter; SW(S_DRIFT_VALUE) = f2u(driftValue); SW(S_DRIFT_NEXT) = (uint32_t)driftNext;
 #undef SW
 }
 
@@ -778,6 +1018,11 @@ struct mlgpu_events
     ctlLaneRecs[l].push_back(CtlRec{(vec << 1) | kind, value});
   }
   uint32_t rowMask{0xFFu};                 // mlgpu_events_set_wanted_rows
+  // e2s_ctl_kernel's outputs (mlgpu_events_prepare_for_graph): control records [T][kCtlRecWords][lanes] and the two side signals
+  uint32_t* d_ctlRecs{nullptr};
+  float* d_rowP{nullptr};
+  float* d_rowG{nullptr};
+  size_t ctlRecVectors{0};
   size_t lanes() const { return nInstruments * (size_t)group; }
 };
 
@@ -1052,6 +1297,9 @@ extern "C"
     hipSetDevice(ev->e->device);
     hipStreamSynchronize(ev->e->stream);
     if (ev->d_state) hipFree(ev->d_state);
+    if (ev->d_ctlRecs) hipFree(ev->d_ctlRecs);
+    if (ev->d_rowP) hipFree(ev->d_rowP);
+    if (ev->d_rowG) hipFree(ev->d_rowG);
     freeControllers(ev);
     for (mlgpu_events::Staging& st : ev->stage)
     {
@@ -1372,6 +1620,8 @@ extern "C"
     memcpy(&dev.s.ctlGlideVectors, &c[0], 4);
     dev.s.ctlGlideDy = c[1];
     dev.s.mpe = ev->mpe ? 1 : 0;
+    dev.ctl = nullptr;
+    dev.rowP = dev.rowG = nullptr;
     dev.state = ev->d_state;
     dev.recs = sg.d_recs;
     dev.recStart = sg.d_recStart;
@@ -1442,10 +1692,56 @@ extern "C"
     if (ev->e->recording) return efail(ev, MLGPU_ERR_INVALID, "events route on the host: not while recording a sequence");
     if (ev->sr == 0) return efail(ev, MLGPU_ERR_INVALID, "events: no sample rate (the reference does nothing, :385)");
     if (ev->mpe) return efail(ev, MLGPU_ERR_UNSUPPORTED, "events as graph source nodes: MIDI protocol only (one lane per voice)");
+    mlgpu_engine* e = ev->e;
+    const size_t lanes = ev->lanes();
+    // the control records and the two side signals of e2s_ctl_kernel, for the longest block seen so far (refused, like every other
+    // allocation, before the router consumes the block's events)
+    if (nVectors > ev->ctlRecVectors)
+    {
+      if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
+      hipStreamSynchronize(e->stream);
+      hipFree(ev->d_ctlRecs);
+      hipFree(ev->d_rowP);
+      hipFree(ev->d_rowG);
+      ev->d_ctlRecs = nullptr;
+      ev->d_rowP = ev->d_rowG = nullptr;
+      ev->ctlRecVectors = 0;
+      const size_t rowBytes = sizeof(float) * 64 * nVectors * lanes;
+      if (hipMalloc((void**)&ev->d_ctlRecs, sizeof(uint32_t) * kCtlRecWords * nVectors * lanes) != hipSuccess || hipMalloc((void**)&ev->d_rowP, rowBytes) != hipSuccess ||
+          hipMalloc((void**)&ev->d_rowG, rowBytes) != hipSuccess)
+      {
+        hipFree(ev->d_ctlRecs);
+        hipFree(ev->d_rowP);
+        hipFree(ev->d_rowG);
+        ev->d_ctlRecs = nullptr;
+        ev->d_rowP = ev->d_rowG = nullptr;
+        return efail(ev, MLGPU_ERR_OOM, "events as graph source nodes: control records and side signals");
+      }
+      ev->ctlRecVectors = nVectors;
+    }
     mlgpu_events::Staging* sg = nullptr;
     const int st = prepare(ev, nVectors, startOffset, *dev, sg);
     *staging = sg;
-    return st;
+    if (st != MLGPU_OK) return st;
+    E2SCtlArgs a;
+    memset(&a, 0, sizeof(a));
+    a.state = dev->state;
+    a.recs = (const Rec*)dev->recs;
+    a.recStart = dev->recStart;
+    a.ctl = ev->d_ctlRecs;
+    a.rowP = (float4*)ev->d_rowP;
+    a.rowG = (float4*)ev->d_rowG;
+    a.lanes = lanes;
+    a.T = nVectors;
+    a.flags = e->kflags;
+    a.s = dev->s;
+    hipLaunchKernelGGL(e2s_ctl_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events control kernel launch: ") + hipGetErrorString(err));
+    dev->ctl = ev->d_ctlRecs;
+    dev->rowP = (const float4*)ev->d_rowP;
+    dev->rowG = (const float4*)ev->d_rowG;
+    return MLGPU_OK;
   }
   int mlgpu_events_launched_by_graph(mlgpu_events* ev, void* staging)
   {

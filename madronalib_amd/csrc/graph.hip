@@ -599,6 +599,38 @@ static bool hasOscTrips(const mlgpu_graph* g)
   return false;
 }
 
+// The same pairing for a STREAMED frequency (the instrument bank's voice: pitch signal -> exp2Approx -> freq): the PulseGen of the
+// outer graph on the same audio-rate frequency node as SawGen i, its width per voice. The pair runs as step_locked_stream
+// (mldsp_procs.hpp) while the two phase counters are equal in every lane of the wavefront (slocked<i>, asked once per launch).
+static int streamLockPulseOf(const mlgpu_graph* g, size_t i)
+{
+  const Node& n = g->nodes[i];
+  auto streamedOsc = [&](const Node& m, int kind) {
+    return m.type == NODE_PROC && m.kind == kind && m.region < 0 && m.rate == RATE_AUDIO && !m.in.empty() && g->nodes[m.in[0]].rate != RATE_VOICE;
+  };
+  if (!g->lockOscillators || !streamedOsc(n, MLGPU_PROC_SAW_GEN)) return -1;
+  for (size_t j = 0; j < g->nodes.size(); ++j)
+  {
+    const Node& m = g->nodes[j];
+    if (streamedOsc(m, MLGPU_PROC_PULSE_GEN) && m.in[0] == n.in[0] && (m.in.size() == 1 || g->nodes[m.in[1]].rate == RATE_VOICE))
+    {
+      for (size_t k = 0; k < i; ++k)  // the first saw on that frequency takes the first pulse on it
+        if (streamedOsc(g->nodes[k], MLGPU_PROC_SAW_GEN) && g->nodes[k].in[0] == n.in[0]) return -1;
+      return (int)j;
+    }
+  }
+  return -1;
+}
+static int streamLockSawOf(const mlgpu_graph* g, size_t i)  // the saw of the pair node i belongs to, -1: none
+{
+  if (g->nodes[i].type != NODE_PROC) return -1;
+  if (g->nodes[i].kind == MLGPU_PROC_SAW_GEN) return streamLockPulseOf(g, i) >= 0 ? (int)i : -1;
+  if (g->nodes[i].kind != MLGPU_PROC_PULSE_GEN) return -1;
+  for (size_t k = 0; k < g->nodes.size(); ++k)
+    if (g->nodes[k].type == NODE_PROC && g->nodes[k].kind == MLGPU_PROC_SAW_GEN && streamLockPulseOf(g, k) == (int)i) return (int)k;
+  return -1;
+}
+
 std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& ph = "", const std::string& idx = "q * 4 + k")
 {
   const Node& n = g->nodes[i];
@@ -617,7 +649,9 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
       else s << floatLiteral(n.value);
       break;
     case NODE_PROC:
-      if (n.kind == MLGPU_PROC_TEMPO_LOCK && g->nodes[n.in[0]].type != NODE_INPUT)  // the phasor to follow is computed in this graph
+      if (ph.empty() && streamLockSawOf(g, i) >= 0)  // made with its partner just before the first of the two (emitNodes)
+        s << "sl" << streamLockSawOf(g, i) << (n.kind == MLGPU_PROC_SAW_GEN ? "s" : "p") << L;
+      else if (n.kind == MLGPU_PROC_TEMPO_LOCK && g->nodes[n.in[0]].type != NODE_INPUT)  // the phasor to follow is computed in this graph
         s << "p" << i << L << ".next_x(" << idx << ", " << arg(0) << ", " << arg(1) << ", " << arg(2) << ")";
       else if (mlgpu_proc_is_vector_rate(n.kind))
         s << "p" << i << L << ".next_n(" << idx << ")";
@@ -735,6 +769,14 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     s << "  const KernelTables tables{nullptr};\n";
   }
   if (g->windowedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 8 * 256 << "];  // write windows, [ring][8][256 lanes]\n";
+  // a group sum of 16 voices (one instrument's voices): four quads of the wavefront's 64 voices are parked in LDS and every lane
+  // then adds up ONE (instrument, sample) pair in voice order - 2.3 instructions per voice-sample where the lane-shift chain
+  // (group_sum_in_order) takes 16 (MLGPU_GRAPH_GROUP_SUM=dpp: that form)
+  static const bool dppSum = getenv("MLGPU_GRAPH_GROUP_SUM") && !strcmp(getenv("MLGPU_GRAPH_GROUP_SUM"), "dpp");
+  auto ldsSum = [&](size_t o) { return VL == 1 && g->outputGroup[o] == 16 && !dppSum; };
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    if (ldsSum(o))
+      s << "  __shared__ float ldsSum" << o << "[4 * kGroup16Strip];\n  float* const strip" << o << " = ldsSum" << o << " + (threadIdx.x >> 6) * kGroup16Strip;\n";
   s << "  size_t blk = blockIdx.x;\n  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;\n"
        "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n"
        "  const size_t v_0 = blk * " << 256 * VL << " + threadIdx.x;\n  if (v_0 >= a.V) return;\n";
@@ -821,6 +863,14 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     for (int l = 0; l < VL; ++l) s << (l ? " || " : "") << "p" << i << sfx(l) << ".omega32 != p" << j << sfx(l) << ".omega32";
     s << ") == 0;\n";
   }
+  for (size_t i = 0; i < g->nodes.size(); ++i)
+  {
+    const int j = streamLockPulseOf(g, i);
+    if (j < 0) continue;
+    s << "  const bool slocked" << i << " = __builtin_amdgcn_ballot_w64(";
+    for (int l = 0; l < VL; ++l) s << (l ? " || " : "") << "p" << i << sfx(l) << ".omega32 != p" << j << sfx(l) << ".omega32";
+    s << ") == 0;\n";
+  }
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l)
     {
@@ -834,9 +884,9 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     if (R.kind == MLGPU_REGION_DOWNSAMPLE_2X)
       for (int in : R.ins)
         for (int l = 0; l < VL; ++l) s << "  float prev" << in << sfx(l) << " = 0.f;\n";
-  // EventsToSignals rows computed here: one EventsVoice per voice (lane == voice index: MIDI protocol)
+  // EventsToSignals rows made here from the control records of e2s_ctl_kernel: one CtlVoice per voice (lane == voice index: MIDI protocol)
   if (g->hasEventRows)
-    for (int l = 0; l < VL; ++l) s << "  mlev::EventsVoice ev" << sfx(l) << ";\n  ev" << sfx(l) << ".load(a.events, v" << sfx(l) << ");\n";
+    for (int l = 0; l < VL; ++l) s << "  mlev::CtlVoice ev" << sfx(l) << ";\n  ev" << sfx(l) << ".load(a.events, v" << sfx(l) << ", a.T);\n";
   // Streamed inputs one quad (or one trip) ahead: a wavefront that loads a quad and waits for it right away stands still for a
   // whole HBM round trip per quad, and with four wavefronts per SIMD there are long stretches with only one or two of them able to
   // issue (one wavefront alone issues at 40 % of the SIMD's rate). The very last quad of a launch loads itself again.
@@ -847,13 +897,10 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << "  const f32x4* pf" << i << sfx(l) << " = in" << i << sfx(l) << ";\n  f32x4 nx" << i << sfx(l) << " = __builtin_nontemporal_load(pf" << i << sfx(l) << ");\n";
   if (g->takeTurns) s << "  const uint32_t turn0 = wave_slot();\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
-  // (Round 3, measured and not kept - profiles/r03_synthfused_variants.txt: a second instance of the vector body, or of the
-  // whole vector loop, for wavefronts without event records - EventsVoice::begin_vector / quad<true>, no record walk, no
-  // note-frame loop - chosen by a wave-uniform test per vector or per launch. The record-free instance does come out
-  // without scratch traffic, but the kernel as a whole needs more registers (322 unbounded, 788 B of scratch at four
-  // wavefronts per SIMD) and the block takes 1.70-2.06 ms against 1.54 for the single body below.)
+  // (Rounds 3-4 walked the event records inside this kernel - 134 spilled registers, 0.35 scalar / branch instructions per vector
+  // one; round 5: the record walk is e2s_ctl_kernel's, this kernel expands its control records - mldsp_events.hpp.)
   if (g->hasEventRows)
-    for (int l = 0; l < VL; ++l) s << "    ev" << sfx(l) << ".scan(t);\n    ev" << sfx(l) << ".begin_vector(t);\n";
+    for (int l = 0; l < VL; ++l) s << "    ev" << sfx(l) << ".begin_vector(t);\n";
   // once per DSPVector: vector-rate nodes, then the vector-rate processors' begin_vector
   for (size_t i = 0; i < g->nodes.size(); ++i)
   {
@@ -943,7 +990,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     for (int l = 0; l < VL; ++l) s << "      f32x4 y" << o << sfx(l) << ";\n";
   if (g->hasEventRows)
     for (int l = 0; l < VL; ++l)
-      s << "      mlev::EventsVoice::f32x4e evP" << sfx(l) << ", evG" << sfx(l) << ";\n      ev" << sfx(l) << ".quad(q, evP" << sfx(l) << ", evG" << sfx(l) << ");\n";
+      s << "      mlev::CtlVoice::f32x4e evP" << sfx(l) << ", evG" << sfx(l) << ";\n      ev" << sfx(l) << ".quad(t, q, evP" << sfx(l) << ", evG" << sfx(l) << ");\n";
   // A kept DSPVector's slot n is read and rewritten at sample n only: fetch the quad's four slots together, ahead of the
   // stores of the sample loop (one load per sample between those stores costs a memory round trip per sample).
   for (size_t i = 0; i < g->nodes.size(); ++i)
@@ -1005,6 +1052,30 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
             s << c.indent << "const float " << name((int)j, c.sfx, l) << " = p" << j << sfx(l) << ".down(" << name(m.in[0], c.sfx + "a", l) << ", "
               << name(m.in[0], c.sfx + "b", l) << ");" << (l == 0 && !m.name.empty() ? "  // " + m.name : std::string()) << "\n";
           continue;
+        }
+        if (r < 0 && streamLockSawOf(g, j) >= 0)
+        {
+          // a SawGen / PulseGen pair on one streamed frequency: both values are made where the first of the two stands
+          const int si = streamLockSawOf(g, j), pj = streamLockPulseOf(g, (size_t)si);
+          if ((int)j == std::min(si, pj))
+          {
+            const Node &sn = g->nodes[(size_t)si], &pn = g->nodes[(size_t)pj];
+            for (int l = 0; l < VL; ++l)
+            {
+              const std::string freq = "n" + std::to_string(sn.in[0]) + sfx(l);
+              const std::string width = pn.in.size() == 2 ? "n" + std::to_string(pn.in[1]) + sfx(l) : "p" + std::to_string(pj) + sfx(l) + ".width";
+              s << c.indent << "float sl" << si << "s" << sfx(l) << ", sl" << si << "p" << sfx(l) << ";\n";
+              s << c.indent << "if (slocked" << si << ")\n" << c.indent << "{\n";
+              s << c.indent << "  if (oddw" << pj << ") step_locked_stream<false>(p" << si << sfx(l) << ", p" << pj << sfx(l) << ", " << freq << ", " << width << ", sl" << si << "s" << sfx(l)
+                << ", sl" << si << "p" << sfx(l) << ");\n";
+              s << c.indent << "  else step_locked_stream<true>(p" << si << sfx(l) << ", p" << pj << sfx(l) << ", " << freq << ", " << width << ", sl" << si << "s" << sfx(l) << ", sl" << si
+                << "p" << sfx(l) << ");\n";
+              s << c.indent << "}\n" << c.indent << "else\n" << c.indent << "{\n";
+              s << c.indent << "  sl" << si << "s" << sfx(l) << " = p" << si << sfx(l) << ".next(" << freq << ");\n";
+              s << c.indent << "  sl" << si << "p" << sfx(l) << " = p" << pj << sfx(l) << ".next_sw(" << freq << (pn.in.size() == 2 ? ", " + width : std::string()) << ", oddw" << pj << ");\n";
+              s << c.indent << "}\n";
+            }
+          }
         }
         for (int l = 0; l < VL; ++l)
           s << c.indent << "const float " << name((int)j, c.sfx, l) << " = " << nodeExpr(g, j, l, c.sfx, c.idx) << ";"
@@ -1082,7 +1153,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l)
     {
-      if (g->outputGroup[o]) s << "        y" << o << sfx(l) << "[k] = group_sum_in_order<" << g->outputGroup[o] << ">(n" << g->outputs[o] << sfx(l) << ");\n";
+      if (g->outputGroup[o] && !ldsSum(o)) s << "        y" << o << sfx(l) << "[k] = group_sum_in_order<" << g->outputGroup[o] << ">(n" << g->outputs[o] << sfx(l) << ");\n";
       else s << "        y" << o << sfx(l) << "[k] = n" << g->outputs[o] << sfx(l) << ";\n";
     }
   // feedback: keep this sample's value for the same sample of the next DSPVector (its old value was read above)
@@ -1092,7 +1163,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         s << "        a.state[(size_t)(" << g->nodes[i].sOff << " + q * 4 + k) * a.V + v" << sfx(l) << "] = f2u(n" << g->nodes[i].fbSource << sfx(l) << ");\n";
   s << "      }\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
-    for (int l = 0; l < VL; ++l)
+    if (ldsSum(o))
+      s << "      group16_park(strip" << o << ", q & 3, y" << o << "_0);\n      if ((q & 3) == 3) group16_sum_store(strip" << o << ", out" << o << "_0 + t * a.out[" << o
+        << "].strideT + (q - 3) * a.out[" << o << "].strideQ, a.out[" << o << "].strideQ);\n";
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    for (int l = 0; l < VL && !ldsSum(o); ++l)
       s << "      " << (g->outputGroup[o] ? "if ((threadIdx.x & " + std::to_string(g->outputGroup[o] - 1) + ") == " + std::to_string(g->outputGroup[o] - 1) + ") " : std::string())
         << "__builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o << "].strideQ);\n";
   s << "    }\n";

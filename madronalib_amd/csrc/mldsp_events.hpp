@@ -1,8 +1,8 @@
 // mldsp_events.hpp — the device side of EventsToSignals (source/app/MLEventsToSignals.{h,cpp}) shared by the events kernel
 // (events.hip: all 8 rows into HBM) and the run-time fused graph kernels (graph.hip: pitch and gate as source nodes of a voice
 // graph, never written to memory): the record format the host router produces, the per-voice state layout, LinearGlide with
-// its 64 slots, and EventsVoice - Voice::beginProcess / writeNoteEvent / endProcess (:75-262) for the pitch and gate rows,
-// one quad of frames at a time.
+// its 64 slots, note_frame - one frame of a vector that holds note records - and CtlVoice: the control records of
+// e2s_ctl_kernel expanded to the pitch and gate rows inside a voice kernel, one quad of frames at a time.
 #pragma once
 #include "mlgpu_device_args.hpp"
 #include "mldsp_math.hpp"
@@ -193,15 +193,33 @@ struct Glide
 // records that end on frame n are applied, the gate, the sample-accurate pitch glide and the event age take their step. Shared by
 // e2s_kernel (all rows) and EventsVoice (pitch and gate inside a voice graph). The caller's state comes in by reference;
 // setPitchGlideTime(samples) and pitchGlideNext(pitch) are its two glide operations; vTime is written when wantTime.
+// The frames of a vector look at the same pending record again and again (a note that starts at frame 40 is read by frames 0..40):
+// one record kept in registers, fetched again only when another index is asked for. Without it every frame is a memory round trip
+// behind the stores of the frame before (loads and stores of a wavefront complete in issue order).
+struct RecCache
+{
+  uint32_t idx{0xFFFFFFFFu};
+  Rec r;
+  MLD const Rec& at(const Rec* recs, uint32_t i)
+  {
+    if (i != idx)
+    {
+      r = recs[i];
+      idx = i;
+    }
+    return r;
+  }
+};
+
 template <class SetGlideTime, class GlideNext>
-MLD void note_frame(const Rec* recs, uint32_t& nc, uint32_t vend, int n, bool& preApplied, float& velocity, float& pitch, uint32_t& age, uint32_t& ageStep,
+MLD void note_frame(const Rec* recs, RecCache& cache, uint32_t& nc, uint32_t vend, int n, bool& preApplied, float& velocity, float& pitch, uint32_t& age, uint32_t& ageStep,
                     bool& inhibit, int32_t pitchGlideSamples, bool wantTime, double srD, SetGlideTime setPitchGlideTime, GlideNext pitchGlideNext,
                     float& vPitch, float& vGate, float& vTime)
 {
   bool retrigFrame = false;
   while (nc < vend)
   {
-    const Rec rc = recs[nc];
+    const Rec rc = cache.at(recs, nc);
     const uint32_t type = rc.typeTimeFlags & 0xFF;
     if (type != REC_NOTE_ON && type != REC_NOTE_RETRIG && type != REC_NOTE_OFF)
     {
@@ -254,9 +272,9 @@ MLD void note_frame(const Rec* recs, uint32_t& nc, uint32_t vend, int n, bool& p
   while (nc < vend)
   {
     uint32_t pi = nc;
-    while (pi < vend && ((recs[pi].typeTimeFlags & 0xFF) < REC_NOTE_ON || (recs[pi].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++pi;
+    while (pi < vend && ((cache.at(recs, pi).typeTimeFlags & 0xFF) < REC_NOTE_ON || (cache.at(recs, pi).typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++pi;
     if (pi >= vend) break;
-    const Rec P = recs[pi];
+    const Rec P = cache.at(recs, pi);
     const uint32_t ptype = P.typeTimeFlags & 0xFF;
     int pdest = (int)((P.typeTimeFlags >> 8) & 0xFF);
     if (ptype == REC_NOTE_RETRIG && pdest == 0) pdest = 1;
@@ -299,347 +317,183 @@ MLD void note_frame(const Rec* recs, uint32_t& nc, uint32_t vend, int n, bool& p
 }
 
 // ---- EventsToSignals inside a fused voice graph ------------------------------------------------------------------------------
-// The pitch and gate rows of one voice, produced a quad of frames at a time for the graph kernel that consumes them, from the
-// same records and the same per-voice state words as e2s_kernel (a launch of either leaves the state the other expects; rows
-// that are not computed keep their glides where they are, as with mlgpu_events_set_wanted_rows). MIDI protocol only: one lane
-// per playing voice, lane == voice index. A vector with a note event is walked with note_frame(), as e2s_kernel walks it.
-template <bool B>
-struct BoolTag
+// The pitch and gate rows of one voice as source nodes of a graph kernel, never written to memory as signals. Round 5 splits the
+// work by RATE (the round-4 form walked records, three glides and the drift random walk inside the voice kernel: 0.35 scalar and
+// branch instructions per vector instruction, 134 spilled registers):
+//   * e2s_ctl_kernel (events.hip) runs everything that happens once per DSPVector or once per note event - the record walk, the
+//     drift random walk, the bend glide, the sample-accurate pitch glide, Voice::beginProcess / writeNoteEvent / endProcess
+//     (:75-262) - and emits ONE CONTROL RECORD of kCtlRecWords words per voice and DSPVector: the pitch before drift, the held gate,
+//     the drift glide's input of this vector, flags. A vector in which the pitch or the gate moves inside the vector (a note event,
+//     a portamento in progress, a moving bend: a few per cent of all vectors) is flagged CF_ROWS and its 64 frames of pitch-before-
+//     drift and gate are written to two side signals, which only the flagged lanes read back.
+//   * the voice kernel (CtlVoice below) expands a record to audio rate. The one per-sample state machine left to it is the drift
+//     LinearGlide (8 s per glide, a new target every 8-16 s: moving most of the time in most wavefronts, its mCurrVec slots
+//     read and rewritten every vector - 8 B per voice-sample, what reading the two rows used to cost): pitch[n] = P[n] +
+//     (drift[n] * driftAmount) * kDriftScale, the reference's own operation order (:244, :247).
+// Same operations on the same values as e2s_kernel: a launch of either form leaves the state words the other expects.
+// MIDI protocol only: one lane per playing voice, lane == voice index.
+enum : int
 {
-  static constexpr bool value = B;
+  C_PITCH = 0,   // float: the pitch glide at rest + the held bend term (vPitch after :244), the same for all 64 frames
+  C_GATE,        // float: the held velocity
+  C_DRIFT_IN,    // float: currentDriftValue, the drift glide's input for this vector (:241)
+  C_FLAGS,       // CF_*
+  kCtlRecWords
 };
+constexpr uint32_t CF_ON = 1u;    // the voice's instrument is awake: processVector is not a no-op (:383-386)
+constexpr uint32_t CF_ROWS = 2u;  // the pitch before drift of this vector is in the side signal, frame by frame
+constexpr uint32_t CF_GATE_ROW = 4u;  // ... and so is the gate (a vector with a note event)
 
-struct EventsVoice
+// Memory of this object is addressed the CDNA way: a 128-bit buffer descriptor in scalar registers (built from kernel arguments
+// only, so provably wave-uniform), ONE 32-bit per-lane byte offset in a vector register, and a scalar offset per access
+// (buffer_load_dword v, v_off, s[rsrc], s_off offen). With plain pointers the compiler keeps a 64-bit address per lane and access
+// stream in vector registers - 59 such loads, 46 spilled registers in the instrument bank's voice kernel - and those are what a
+// generated voice kernel is short of (128 per lane at four wavefronts per SIMD).
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+MLD BufRsrc lane_buffer(const void* uniformBase, size_t bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniformBase), (short)0, (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), 0x00020000);
+}
+
+struct CtlVoice
 {
   typedef float f32x4e __attribute__((ext_vector_type(4)));
-  uint32_t* S;  // this lane's first state word
-  size_t ln;
-  const Rec* recs;
-  E2SSettings s;
-  bool live, awake, inhibit, needsRecalc;
-  float velocity, pitch, bend;
-  uint32_t age, ageStep;
-  float pgCurr, pgStep, pgTarget, pgDy;
-  int32_t pgRemaining, pgPerGlide;
-  uint32_t cursor, recEnd;
-  // per vector
-  uint32_t vend, nc;
-  bool on, quiet, preApplied;
-  float gateHeld;
-  Glide gb, gd;
-  float nb[4], nd[4];  // bend / drift mCurrVec slots, one quad ahead
-  // how a quiet vector's pitch row is produced (wave-uniform, decided in begin_vector):
-  //   0  frame by frame through the three glides, as e2s_kernel does
-  //   1  one value: the pitch glide at rest, bend and drift held
-  //   2  pitch glide at rest, bend held, the drift glide moving in some lane: base + drift, straight-line
-  int pitchForm;
-  float pitchBase, driftHeld, frameNo;
-  uint64_t mDriftMoves, mDriftRamps;
-  bool driftMoving, driftFetches;
+  // Per lane this object keeps the lane's byte offset, the drift glide's few words, the vector's pitch and gate and ONE set of four
+  // words that holds, in turn, the coming quad's mCurrVec slots and - during a vector's last quad - the next vector's control record.
+  EventsDev d;    // (uniform: scalar registers / kernel arguments)
+  size_t T;
+  BufRsrc glide;  // the drift glide's words [kGlideWords][lanes]
+  uint32_t rowBytes;   // 4 * lanes: one word of every lane
+  uint32_t laneBytes;  // 4 * lane
+  Glide gd;
+  float P, gate;
+  bool on, rows, gateRow, moving, fetch, ramp;
+  bool anyRows, anyRamp, anyOff, anyFetch;  // wave-uniform
+  float nd[4];
 
-  MLD uint32_t& sw(int i) const { return S[(size_t)i * ln]; }
-  MLD uint32_t* gs(int i) const { return S + (size_t)(S_GLIDES + i * kGlideWords) * ln; }
-  MLD void setPitchGlideTime(int32_t t)  // SampleAccurateLinearGlide::setGlideTimeInSamples, MLDSPGens.h:527-532
+  MLD uint32_t glideWord(int w) const { return __builtin_amdgcn_raw_buffer_load_b32(glide, (int)laneBytes, (int)((uint32_t)w * rowBytes), 0); }
+  MLD void setGlideWord(int w, uint32_t x) const { __builtin_amdgcn_raw_buffer_store_b32(x, glide, (int)laneBytes, (int)((uint32_t)w * rowBytes), 0); }
+  MLD void fetchRecord(size_t t)  // into nd[]: C_PITCH, C_GATE, C_DRIFT_IN, C_FLAGS
   {
-    pgPerGlide = t < 1 ? 1 : t;
-    pgDy = 1.0f / (float)pgPerGlide;
+    const BufRsrc rec = lane_buffer(d.ctl + t * (size_t)kCtlRecWords * d.lanes, (size_t)kCtlRecWords * rowBytes);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nd[k] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rec, (int)laneBytes, (int)((uint32_t)k * rowBytes), 0));
   }
-  MLD float pitchGlideNext(float f)  // nextSample, :541-580
+  MLD void load(const EventsDev& a, size_t voice, size_t nVectors)
   {
-    if (f != pgTarget)
-    {
-      pgTarget = f;
-      pgRemaining = pgPerGlide;
-    }
-    if (pgRemaining < 0) {}
-    else if (pgRemaining == 0)
-    {
-      pgCurr = pgTarget;
-      pgStep = 0.f;
-      pgRemaining--;
-    }
-    else if (pgRemaining == pgPerGlide)
-    {
-      pgStep = (pgTarget - pgCurr) * pgDy;
-      pgRemaining--;
-    }
-    else
-    {
-      pgCurr += pgStep;
-      pgRemaining--;
-    }
-    return pgCurr;
-  }
-
-  MLD void load(const EventsDev& a, size_t lane)
-  {
-    live = lane < a.lanes;
-    const size_t L = live ? lane : 0;
-    ln = a.lanes;
-    S = a.state + L;
-    recs = (const Rec*)a.recs;
-    s = a.s;
-    awake = sw(S_AWAKE) != 0;
-    velocity = u2f(sw(S_VELOCITY));
-    pitch = u2f(sw(S_PITCH));
-    bend = u2f(sw(S_BEND));
-    age = sw(S_AGE);
-    ageStep = sw(S_AGE_STEP);
-    inhibit = sw(S_INHIBIT_GLIDE) != 0;
-    needsRecalc = sw(S_RECALC) != 0;
-    pgCurr = u2f(sw(S_PG_CURR));
-    pgStep = u2f(sw(S_PG_STEP));
-    pgTarget = u2f(sw(S_PG_TARGET));
-    pgDy = u2f(sw(S_PG_DY));
-    pgRemaining = (int32_t)sw(S_PG_REMAINING);
-    pgPerGlide = (int32_t)sw(S_PG_PER_GLIDE);
-    cursor = live ? a.recStart[L] : 0;
-    recEnd = live ? a.recStart[L + 1] : 0;
+    d = a;
+    T = nVectors;
+    rowBytes = (uint32_t)d.lanes * 4u;
+    laneBytes = (uint32_t)voice * 4u;
+    glide = lane_buffer(d.state + (size_t)(S_GLIDES + 5 * kGlideWords) * d.lanes, (size_t)kGlideWords * rowBytes);  // glide 5: drift
+    gd.target = u2f(glideWord(0));
+    gd.step = u2f(glideWord(1));
+    gd.remaining = (int32_t)glideWord(2);
+    gd.modeFlags = glideWord(3) ? 4 : 0;
+    gd.uniformValue = u2f(glideWord(4));
+    gd.startValue = 0.f;
+    fetchRecord(0);
   }
   MLD void store() const
   {
-    if (!live) return;
-    sw(S_AWAKE) = awake ? 1u : 0u;
-    sw(S_VELOCITY) = f2u(velocity);
-    sw(S_PITCH) = f2u(pitch);
-    sw(S_BEND) = f2u(bend);
-    sw(S_AGE) = age;
-    sw(S_AGE_STEP) = ageStep;
-    sw(S_INHIBIT_GLIDE) = inhibit ? 1u : 0u;
-    sw(S_RECALC) = needsRecalc ? 1u : 0u;
-    sw(S_PG_CURR) = f2u(pgCurr);
-    sw(S_PG_STEP) = f2u(pgStep);
-    sw(S_PG_TARGET) = f2u(pgTarget);
-    sw(S_PG_DY) = f2u(pgDy);
-    sw(S_PG_REMAINING) = (uint32_t)pgRemaining;
-    sw(S_PG_PER_GLIDE) = (uint32_t)pgPerGlide;
+    setGlideWord(0, f2u(gd.target));
+    setGlideWord(1, f2u(gd.step));
+    setGlideWord(2, (uint32_t)gd.remaining);
+    setGlideWord(3, gd.isUniform() ? 1u : 0u);
+    setGlideWord(4, f2u(gd.uniformValue));
   }
 
-  // Records of this lane in DSPVector t: [cursor, vend). The generated kernel asks every lane of the wavefront, and runs
-  // the vector through begin_vector / quad<NO_RECS = true> when no lane has one (the usual case by far: a voice sees a
-  // handful of events per second): that instance has no record walk and no note-frame loop in it, and the registers the
-  // note path needs are not held through the vectors that do not use it.
-  MLD bool scan(size_t t)
-  {
-    vend = cursor;
-    while (vend < recEnd && recs[vend].vec == (uint32_t)t) ++vend;
-    return vend != cursor;
-  }
-  template <bool NO_RECS = false>
   MLD void begin_vector(size_t t)
   {
-    (void)t;  // [cursor, vend) comes from scan(t), which the kernel calls first
-    if constexpr (!NO_RECS)
+    (void)t;
+    const uint32_t f = f2u(nd[C_FLAGS]);
+    const float din = nd[C_DRIFT_IN];
+    on = (f & CF_ON) != 0;
+    rows = (f & CF_ROWS) != 0;
+    gateRow = (f & CF_GATE_ROW) != 0;
+    P = on ? nd[C_PITCH] : 0.f;
+    gate = on ? nd[C_GATE] : 0.f;
+    // a glide that starts from a non-uniform mCurrVec reads its slot 63 - this lane's own store of the vector before (once per
+    // 8-16 s and voice: asked wave-uniformly)
+    float slot63 = 0.f;
+    const bool starts = on && ((din != gd.target) || gd.remaining == d.s.driftGlideVectors) && !gd.isUniform();
+    if (__builtin_amdgcn_ballot_w64(starts) != 0)
     {
-      if (!awake)
-        for (uint32_t r = cursor; r < vend; ++r)
-          if ((recs[r].typeTimeFlags & 0xFF) == REC_AWAKE) awake = true;
+      if (starts) slot63 = u2f(glideWord(5 + 63));
     }
-    float finalVelocity = velocity;
-    bool noteHere = false;
-    float driftValue = 0.f;
-    on = awake && live;
-    if (on)
+    if (on) gd.beginVectorKnown(din, d.s.driftGlideVectors, d.s.driftGlideDy, slot63);
+    const int m = gd.mode();  // (a lane that is not on keeps mode 0 from the end of its last vector)
+    moving = on && m >= 2;
+    ramp = on && m == 2;
+    fetch = on && gd.readsCurrVec();
+    const float hv = (m == 1) ? gd.target : gd.uniformValue;
+    anyRows = __builtin_amdgcn_ballot_w64(rows) != 0;
+    anyRamp = __builtin_amdgcn_ballot_w64(ramp) != 0;
+    anyOff = __builtin_amdgcn_ballot_w64(!on) != 0;
+    anyFetch = __builtin_amdgcn_ballot_w64(fetch) != 0;
+    nd[0] = nd[1] = nd[2] = nd[3] = hv;
+    if (anyFetch)
     {
-      // ---- Voice::beginProcess, :75-113 (the drift walk's four words stay in memory: they are touched once per vector) ----
-      if (needsRecalc)
+      if (fetch)
       {
-        if (!inhibit) setPitchGlideTime(s.pitchGlideSamples);
-        needsRecalc = false;
-      }
-      int32_t driftCounter = (int32_t)sw(S_DRIFT_COUNTER) + MLGPU_FLOATS_PER_DSPVECTOR;
-      driftValue = u2f(sw(S_DRIFT_VALUE));
-      if (driftCounter >= (int32_t)sw(S_DRIFT_NEXT))
-      {
-        uint32_t driftSeed = sw(S_DRIFT_SEED);
-        driftSeed = driftSeed * 0x0019660Du + 0x3C6EF35Fu;  // RandomScalarSource::getFloat, MLDSPScalarMath.h:189-202
-        const float d = u2f(((driftSeed >> 9) & 0x007FFFFFu) | 0x3F800000u) * 2.f - 3.f;
-        driftSeed = driftSeed * 0x0019660Du + 0x3C6EF35Fu;
-        const float d2 = u2f(((driftSeed >> 9) & 0x007FFFFFu) | 0x3F800000u) * 2.f - 3.f;
-        const float nextTimeMul = 1.0f + abs_ps(d2);
-        driftValue = d;
-        driftCounter = 0;
-        sw(S_DRIFT_SEED) = driftSeed;
-        sw(S_DRIFT_VALUE) = f2u(driftValue);
-        sw(S_DRIFT_NEXT) = (uint32_t)(int32_t)(s.sr * (double)nextTimeMul * (double)8.0f);
-      }
-      sw(S_DRIFT_COUNTER) = (uint32_t)driftCounter;
-      // ---- values that only matter at the end of the vector (endProcess, :218-247); the rows this object does not compute
-      //      keep their values in memory ----
-      for (uint32_t r = cursor; !NO_RECS && r < vend; ++r)
-      {
-        const Rec rc = recs[r];
-        switch (rc.typeTimeFlags & 0xFF)
-        {
-          case REC_SET_BEND: bend = rc.v1; break;
-          case REC_SET_MOD: sw(S_MOD) = f2u(rc.v1); break;
-          case REC_SET_X: sw(S_X) = f2u(rc.v1); break;
-          case REC_SET_Y: sw(S_Y) = f2u(rc.v1); break;
-          case REC_SET_Z: sw(S_Z) = f2u(rc.v1); break;
-          case REC_SET_CHANNEL_PRESSURE: sw(S_CHANPRESS) = f2u(rc.v1); break;
-          case REC_NOTE_ON: case REC_NOTE_RETRIG: finalVelocity = rc.v2; noteHere = true; break;
-          case REC_NOTE_OFF: finalVelocity = 0.f; noteHere = true; break;
-          default: break;
-        }
-      }
-      if (finalVelocity == 0.f) sw(S_Z) = 0u;  // :238-241
-    }
-    gb.load(gs(0), ln);
-    gd.load(gs(5), ln);
-    if (on)
-    {
-      gb.beginVector(gs(0), ln, bend, s.glideVectors, s.glideDy);
-      gd.beginVector(gs(5), ln, driftValue, s.driftGlideVectors, s.driftGlideDy);
-    }
-    nc = cursor;
-    preApplied = false;
-    quiet = NO_RECS || __builtin_amdgcn_ballot_w64(noteHere) == 0;
-    pitchForm = 0;
-    mDriftMoves = mDriftRamps = 0;
-    if (quiet)
-    {
-      gateHeld = on ? velocity : 0.f;
-      if (on) age += (uint32_t)MLGPU_FLOATS_PER_DSPVECTOR * ageStep;
-      // The pitch row = pitch glide + bend glide + drift glide, three small per-lane state machines: walked as such they are
-      // ~36 vector and ~44 scalar / branch instructions per frame, although in a vector without note events nearly all of it
-      // is decided once: the pitch glide is usually at rest (no portamento in progress: nextSample returns mCurr and changes
-      // nothing), the bend is usually held (one value for the vector), a LinearGlide's mode is fixed for the vector. Classify
-      // once per vector, wave-uniformly, and run the frames of the common classes as straight-line code: the same operations
-      // on the same values.
-      const bool pgBusy = on && (pitch != pgTarget || pgRemaining >= 0);
-      const int bm = gb.mode(), dm = gd.mode();
-      const bool heldB = (bm == 1) || (bm == 0 && gb.isUniform()), heldD = (dm == 1) || (dm == 0 && gd.isUniform());
-      const float hvB = (bm == 1) ? gb.target : gb.uniformValue, hvD = (dm == 1) ? gd.target : gd.uniformValue;
-      if (__builtin_amdgcn_ballot_w64(pgBusy || (on && !heldB)) == 0)
-      {
-        pitchBase = pgCurr + (hvB * s.pitchBendRange) * (1.f / 12);  // the frames' vPitch after :244, the same for all 64
-        if (__builtin_amdgcn_ballot_w64(on && !heldD) == 0)
-        {
-          pitchForm = 1;
-          pitchBase = on ? pitchBase + (hvD * s.driftAmount) * 0.02f : 0.f;
-        }
-        else
-        {
-          // per lane and vector: a moving drift glide ramps (its first vector) or adds a step to its mCurrVec slot and writes
-          // it back; the others hold a value
-          pitchForm = 2;
-          mDriftMoves = __builtin_amdgcn_ballot_w64(on && dm >= 2);
-          mDriftRamps = __builtin_amdgcn_ballot_w64(on && dm == 2);
-          driftMoving = on && dm >= 2;
-          driftFetches = on && gd.readsCurrVec();
-          driftHeld = hvD;  // what a lane that neither moves nor fetches holds (mode 3 with a broadcast mCurrVec adds to it)
-          frameNo = 0.f;
-          nd[0] = nd[1] = nd[2] = nd[3] = driftHeld;
-          if (driftFetches)
-          {
-            const uint32_t* slots = gs(5) + (size_t)5 * ln;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nd[k] = u2f(slots[(size_t)k * ln]);
-          }
-        }
-      }
-      else
-      {
-        nb[0] = nb[1] = nb[2] = nb[3] = 0.f;
-        nd[0] = nd[1] = nd[2] = nd[3] = 0.f;
-        if (on)
-        {
-          gb.preload(gs(0), ln, 0, nb);
-          gd.preload(gs(5), ln, 0, nd);
-        }
+        for (int k = 0; k < 4; ++k) nd[k] = u2f(glideWord(5 + k));
       }
     }
   }
 
-  template <bool NO_RECS = false>
-  MLD void quad(int q, f32x4e& oPitch, f32x4e& oGate)
+  MLD void quad(size_t t, int q, f32x4e& oPitch, f32x4e& oGate)
   {
-    const float pitchBendScale = s.pitchBendRange;  // MIDI protocol, :417-423
-    if (pitchForm == 1)
+    const float prev[4] = {nd[0], nd[1], nd[2], nd[3]};
+    if (q < 15)
     {
-      oPitch = f32x4e{pitchBase, pitchBase, pitchBase, pitchBase};
-      oGate = f32x4e{gateHeld, gateHeld, gateHeld, gateHeld};
-      return;
-    }
-    if (pitchForm == 2)
-    {
-      uint32_t* slots = gs(5) + (size_t)5 * ln;
-      const float prev[4] = {nd[0], nd[1], nd[2], nd[3]};
-      if (driftFetches && q < 15)
+      if (anyFetch)
       {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) nd[k] = u2f(slots[(size_t)(4 * q + 4 + k) * ln]);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-      {
-        frameNo += 1.0f;  // (float)(n + 1)
-        const float c = lane_select(mDriftRamps, gd.startValue + (frameNo * 0.015625f) * gd.step, prev[k] + gd.step);
-        if (driftMoving) slots[(size_t)(4 * q + k) * ln] = f2u(c);
-        const float driftSig = lane_select(mDriftMoves, c, prev[k]);
-        oPitch[k] = on ? pitchBase + (driftSig * s.driftAmount) * 0.02f : 0.f;
-        oGate[k] = gateHeld;
-      }
-      return;
-    }
-    if (NO_RECS || quiet)
-    {
-      const float cb[4] = {nb[0], nb[1], nb[2], nb[3]}, cd[4] = {nd[0], nd[1], nd[2], nd[3]};
-      if (on && q < 15)
-      {
-        gb.preload(gs(0), ln, q + 1, nb);
-        gd.preload(gs(5), ln, q + 1, nd);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-      {
-        const int n = q * 4 + k;
-        float vPitch = 0.f;
-        if (on)
+        if (fetch)
         {
-          vPitch = pitchGlideNext(pitch);
-          const float bendSig = gb.nextWith(gs(0), ln, n, cb[k]), driftSig = gd.nextWith(gs(5), ln, n, cd[k]);
-          vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);  // :244
-          vPitch = vPitch + (driftSig * s.driftAmount) * 0.02f;       // kDriftScale, :247
+#pragma unroll
+          for (int k = 0; k < 4; ++k) nd[k] = u2f(glideWord(5 + 4 * q + 4 + k));
         }
-        oPitch[k] = vPitch;
-        oGate[k] = gateHeld;
       }
-      return;
     }
-    oPitch = f32x4e{0.f, 0.f, 0.f, 0.f};
-    oGate = oPitch;
-    if constexpr (NO_RECS) return;  // not reached: a vector without records is quiet
-#pragma unroll 1
+    else if (t + 1 < T)
+      fetchRecord(t + 1);
+    f32x4e Pq = {P, P, P, P};
+    oGate = f32x4e{gate, gate, gate, gate};
+    if (anyRows)
+    {
+      if (rows)
+      {
+        const size_t at = (t * 16 + (size_t)q) * d.lanes + (size_t)(laneBytes >> 2);
+        Pq = __builtin_nontemporal_load((const f32x4e*)d.rowP + at);
+        if (gateRow) oGate = __builtin_nontemporal_load((const f32x4e*)d.rowG + at);
+      }
+    }
+    float c[4];
+#pragma unroll
     for (int k = 0; k < 4; ++k)
     {
-      const int n = q * 4 + k;
-      float vPitch = 0.f, vGate = 0.f;
-      if (on)
+      c[k] = prev[k] + gd.step;  // a continuing glide: mCurrVec[n] += step (LinearGlide, MLDSPGens.h:497-505)
+      if (anyRamp)               // a glide's first vector ramps from its start value (:481-495); once per 8-16 s and voice
       {
-      float vTime = 0.f;
-      note_frame(recs, nc, vend, n, preApplied, velocity, pitch, age, ageStep, inhibit, s.pitchGlideSamples, false, 1.0,
-                 [&](int32_t t) { setPitchGlideTime(t); }, [&](float f) { return pitchGlideNext(f); }, vPitch, vGate, vTime);
-      const float bendSig = gb.next(gs(0), ln, n), driftSig = gd.next(gs(5), ln, n);
-      vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);         // :244
-      vPitch = vPitch + (driftSig * s.driftAmount) * 0.02f;           // kDriftScale, :247
+        const float r = gd.startValue + ((float)(4 * q + k + 1) * 0.015625f) * gd.step;
+        c[k] = ramp ? r : c[k];
       }
-      // k is a loop variable here (the body is large): insert with selects instead of a dynamic register index
-      oPitch = f32x4e{k == 0 ? vPitch : oPitch[0], k == 1 ? vPitch : oPitch[1], k == 2 ? vPitch : oPitch[2], k == 3 ? vPitch : oPitch[3]};
-      oGate = f32x4e{k == 0 ? vGate : oGate[0], k == 1 ? vGate : oGate[1], k == 2 ? vGate : oGate[2], k == 3 ? vGate : oGate[3]};
+      const float driftSig = moving ? c[k] : prev[k];
+      float p = Pq[k] + (driftSig * d.s.driftAmount) * 0.02f;  // kDriftScale, :247
+      if (anyOff) p = on ? p : 0.f;
+      oPitch[k] = p;
+    }
+    if (moving)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) setGlideWord(5 + 4 * q + k, f2u(c[k]));
     }
   }
 
   MLD void end_vector()
   {
-    if (on)
-    {
-      gb.endVector();
-      gd.endVector();
-      gb.store(gs(0), ln);
-      gd.store(gs(5), ln);
-    }
-    cursor = vend;
+    if (on) gd.endVector();
   }
 };
 

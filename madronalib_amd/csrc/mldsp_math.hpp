@@ -145,6 +145,34 @@ MLD float group_sum_in_order(float x)
   return GroupSumStep<G, G - 2>::run(0.f + row_shr<G - 1>(x), x);
 }
 
+// The same sums for groups of 16 (an instrument's voices) through LDS: a wavefront parks the f32x4 of its 64 voices for four
+// consecutive quads in a strip of its own ([quad][group][voice][4] with a few pad words so that the reads below spread over the
+// banks), then lane (g, s) adds up group g's sixteen voices at sample s of the 16 in voice order and stores that one float. Per
+// voice-sample: 1/4 LDS write, 1 LDS read, 1 add, 1/16 store - the lane-shift chain above is 16 dependent adds per sample.
+// LDS operations of one wavefront complete in issue order; the barrier only keeps the compiler from moving them across each other.
+constexpr int kGroup16Quad = 4 * 80 + 4;       // floats per parked quad: 4 groups x (16 voices x 4 samples + 16 pad) + 4 pad
+constexpr int kGroup16Strip = 4 * kGroup16Quad;
+typedef float group16_f32x4 __attribute__((ext_vector_type(4)));
+MLD void group16_park(float* strip, int qq, group16_f32x4 y)
+{
+  const unsigned l = threadIdx.x & 63u;
+  *(group16_f32x4*)(strip + qq * kGroup16Quad + (l >> 4) * 80u + (l & 15u) * 4u) = y;
+}
+MLD void group16_sum_store(const float* strip, group16_f32x4* outQuad0, size_t strideQ)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const unsigned l = threadIdx.x & 63u, s = l & 15u, qq = s >> 2, k = s & 3u;
+  const float* p = strip + qq * kGroup16Quad + (l >> 4) * 80u + k;
+  float acc = 0.f + p[0];  // ((0 + x0) + x1) + ...: Synth::processVector starts from a cleared output (MLSynth.h:43-57)
+#pragma unroll
+  for (int v = 1; v < 16; ++v) acc = acc + p[v * 4];
+  __builtin_nontemporal_store(acc, (float*)(outQuad0 + (size_t)qq * strideQ) + k);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // clamp(x, lo, hi) = min(max(x, lo), hi) (MLDSPOps.h:747) in TWO instructions instead of six, for the common case the graph
 // generator can prove: lo and hi are constants of the kernel, neither NaN nor zero, lo <= hi, and x is the result of an
 // arithmetic instruction (so never a signaling NaN). v_max_f32 / v_min_f32 differ from maxps / minps only (a) when the SECOND

@@ -1762,6 +1762,43 @@ MLD bool trip_locked(Proc<MLGPU_PROC_SAW_GEN>& saw, Proc<MLGPU_PROC_PULSE_GEN>& 
   return false;
 }
 
+// The same pair on a STREAMED frequency (a pitch signal: exp2Approx -> freq, the instrument bank's voice), one sample at a time.
+// With equal counters (the caller's wave-uniform test at the start of the launch; they advance by the same step for ever) the two
+// processors' per-sample forms repeat each other: the phase counter and its conversion, the zone tests of the step at phase 0,
+// the wave-uniform skip question, and - the saw's polyBLEP being the very value the pulse adds for its rising step - the division
+// and the polynomial. Here each is made once: one phase, the four zone tests, ONE skip question for both, and in the usual case
+// (no lane inside two zones at once) one correction. Same operands through the same operations as Proc<SAW_GEN>::next and
+// Proc<PULSE_GEN>::next_sw: saw - (nearUp ? c : 0) with the idle correction exactly 0.f, x - 0 == x; `full` (some lane needs the
+// IEEE division) now covers the pulse's shifted phase for the saw too, which changes nothing for operands div_nr is exact on.
+template <bool REGULAR_W>
+MLD void step_locked_stream(Proc<MLGPU_PROC_SAW_GEN>& saw, Proc<MLGPU_PROC_PULSE_GEN>& pulse, float cps, float w, float& outSaw, float& outPulse)
+{
+  const float p = phasor_next(saw.omega32, cps);
+  pulse.omega32 = saw.omega32;
+  const float sawv = __builtin_fmaf(p, 2.f, -1.f);  // phasor_to_saw, PARITY note there
+  const float pulsev = (p >= w) ? -1.f : 1.f;
+  const float d = p - w + 1.0f;
+  const float down = REGULAR_W ? __builtin_amdgcn_fractf(d) : d - (float)sse_cvtt(d);  // fractionalPart
+  const bool downOdd = !REGULAR_W && !(abs_ps(down) <= 2.0f);
+  const BlepFreq<false> f = BlepFreq<false>::make(cps, downOdd);
+  const bool loUp = f.lo(p), nearUp = loUp || f.hi(p);
+  const bool loDown = f.lo(down), nearDown = loDown || f.hi(down);
+  outSaw = sawv;
+  outPulse = pulsev;
+  if (__builtin_amdgcn_ballot_w64(nearUp || nearDown) == 0) return;
+  const bool full = f.anyLaneOdd();
+  if (MLGPU_PULSE_SINGLE_BLEP && __builtin_amdgcn_ballot_w64(nearUp && nearDown) == 0)
+  {
+    const float c = f.correction(nearDown ? down : p, nearDown ? loDown : loUp, full);
+    outPulse = nearDown ? (pulsev - c) : (nearUp ? (pulsev + c) : pulsev);
+    outSaw = nearUp ? (sawv - c) : sawv;
+    return;
+  }
+  const float cUp = f.correction(p, loUp, full), cDown = f.correction(down, loDown, full);
+  outPulse = (pulsev + (nearUp ? cUp : 0.f)) - (nearDown ? cDown : 0.f);
+  outSaw = sawv - (nearUp ? cUp : 0.f);
+}
+
 template <class P, class = void>
 struct HasFastPath
 {

@@ -54,6 +54,11 @@ struct EventsDev
   const uint32_t* recStart;  // [lanes + 1]
   size_t lanes;
   E2SSettings s;
+  // the launch's control records [T][kCtlRecWords][lanes] and the two side signals (QUAD layout) of e2s_ctl_kernel: what a voice
+  // kernel expands to audio rate (mlev::CtlVoice); null for mlgpu_events_process, which writes whole rows
+  const uint32_t* ctl;
+  const float4* rowP;
+  const float4* rowG;
 };
 
 // a fused graph kernel: up to MLGPU_GRAPH_MAX_INPUTS (32) streamed inputs, MLGPU_GRAPH_MAX_OUTPUTS (8) outputs, per-voice constants [P][V]

@@ -305,10 +305,12 @@ def test_events_with_hostile_values(eng, name):
             assert_bits_equal(ctl[c, k], want_ctl[c], True, f"hostile {name}: instrument {k} controller {num}")
 
 
-def _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch, switch_at=None):
+def _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch, switch_at=None, voice_sum=False):
     """The config-5 voice driven by EventsToSignals two ways, from fresh objects: (a) e2s_kernel writes pitch and gate, the voice
     graph reads them; (b) the voice graph computes the two rows itself (event_row nodes). switch_at: from that block on, (b) goes
-    back to the two-kernel form - the two forms share the events object's state. Returns (audio_a, audio_b) [V][frames]."""
+    back to the two-kernel form - the two forms share the events object's state. Returns (audio_a, audio_b) [V][frames].
+    voice_sum: the instruments' audio instead, [N][frames] - (a) mlgpu_mixdown_groups over the voices, (b) the sum made inside the
+    fused voice kernel (mlgpu_graph_set_output_group_sum)."""
     import madronalib_amd as ml
     from madronalib_amd import patches
     from madronalib_amd.constants import Layout
@@ -325,7 +327,7 @@ def _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_la
         graphs = {}
         for form in ((True, False) if fused else (False,)):
             desc, outn = patches.synth16(pitch_input=True, event_rows=form)
-            g = ml.Graph(eng, V, desc, outn)
+            g = ml.Graph(eng, V, desc, outn, output_groups={0: P} if (voice_sum and form) else None)
             g.clear()
             for k, v in params.items():
                 if k != "pitch":
@@ -334,12 +336,13 @@ def _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_la
                 g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
             g.set_state("noise", 0, seeds)
             if form:
-                assert "mlev::EventsVoice" in g.source and not g.inputs
+                assert "mlev::CtlVoice" in g.source and not g.inputs
                 g.bind_events(ev)
             graphs[form] = g
         n = V * vectors_per_launch * 64
         rows = [eng.alloc(4 * n), eng.alloc(4 * n)]
         d_out = eng.alloc(4 * n)
+        d_mix = eng.alloc(4 * n // P)
         chunks = []
         for b in range(n_blocks):
             start = b * block
@@ -359,12 +362,17 @@ def _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_la
             while done < block // 64:
                 T = min(vectors_per_launch, block // 64 - done)
                 if use_fused:
-                    graphs[True].process_events(T, done * 64, [], [d_out], out_layout=Layout.VOICE_MAJOR)
+                    graphs[True].process_events(T, done * 64, [], [d_mix if voice_sum else d_out], out_layout=Layout.VOICE_MAJOR)
                 else:
                     g = graphs[False]
                     ev.process(T, done * 64, [rows[0], rows[1]] + [None] * 6, Layout.QUAD)
                     g.process(T, [rows[1] if nm == "gate" else rows[0] for nm in g.inputs], [d_out], out_layout=Layout.VOICE_MAJOR)
-                chunks.append(d_out.download(np.float32, V * T * 64).reshape(V, T * 64).copy())
+                    if voice_sum:
+                        eng.mixdown_groups(d_out, Layout.VOICE_MAJOR, N, P, T, d_mix, Layout.VOICE_MAJOR)
+                if voice_sum:
+                    chunks.append(d_mix.download(np.float32, N * T * 64).reshape(N, T * 64).copy())
+                else:
+                    chunks.append(d_out.download(np.float32, V * T * 64).reshape(V, T * 64).copy())
                 done += T
             ev.clear_events()
         outs.append(np.concatenate(chunks, 1))
@@ -385,6 +393,20 @@ def test_event_rows_inside_the_voice_graph(eng, name):
     instruments = [performance(kind, 100 * k + len(name), block * n_blocks, cfg["polyphony"]) for k in range(6)]
     a, b = _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch=3)
     assert_bits_equal(b, a, True, f"{name}: fused event rows vs two kernels")
+    assert np.abs(a).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["midi_poly4", "midi_steal2", "midi_poly16"])
+def test_instrument_bank_in_one_voice_kernel(eng, name):
+    """The whole instrument bank as bench.py --workload synthfused runs it - control records -> the fused voice kernel, which also
+    adds up every instrument's voices (groups of 16 through LDS, smaller ones with lane shifts) - against the three-kernel form:
+    e2s_kernel rows -> voice graph -> mlgpu_mixdown_groups. 37 instruments (a partial last wavefront), drift and portamento on."""
+    cfg = SCENARIOS[name]
+    block, n_blocks = 512, 6
+    instruments = [performance("midi", 31 * k + len(name), block * n_blocks, cfg["polyphony"]) for k in range(37)]
+    a, b = _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch=8, voice_sum=True)
+    assert_bits_equal(b, a, True, f"{name}: instrument audio, one kernel vs three")
     assert np.abs(a).max() > 0
 
 

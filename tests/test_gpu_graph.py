@@ -735,19 +735,23 @@ def test_multi_input_forms_hostile_inputs(eng, oracle, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("group", [2, 4, 8, 16])
-@pytest.mark.parametrize("vpl", [1, 2])
+@pytest.mark.parametrize("vpl", [1, 2, -1])
 def test_voice_sum_inside_the_graph_kernel(eng, oracle, group, vpl):
     """mlgpu_graph_set_output_group_sum: an output that is the sum of groups of adjacent voices in the order Synth::processVector
-    adds them ((0 + v0) + v1 + ...), made with lane shifts inside the voice kernel - the bits mlgpu_mixdown_groups gives for the
-    same voices, next to an ordinary output of the same graph. Values of mixed sign and magnitude so that the order matters."""
+    adds them ((0 + v0) + v1 + ...), made inside the voice kernel - with lane shifts, or for groups of 16 at one voice per lane
+    through an LDS strip per wavefront - the bits mlgpu_mixdown_groups gives for the same voices, next to an ordinary output of
+    the same graph. Values of mixed sign and magnitude so that the order matters. vpl -1: one voice per lane and a bank that ends
+    in a partial wavefront (37 groups of 16)."""
     import madronalib_amd as ml
     V, T = 512 + 2 * 16 * vpl * 8, 3          # not a whole number of workgroups
+    if vpl < 0:
+        V, vpl = 16 * 37, 1
     rng = np.random.default_rng(group)
     x = (rng.standard_normal((V, 64 * T)) * 10.0 ** rng.integers(-3, 4, (V, 1))).astype(np.float32)
     x[3, :8] = [np.inf, -np.inf, np.nan, -0.0, 0.0, 1e-40, 3e38, -3e38]
     desc = [dict(name="x", type="input"), dict(name="k", type="const", value=0.75), dict(name="y", type="op", kind=Op.MULTIPLY, inputs=["x", "k"])]
     g = ml.Graph(eng, V, desc, ["y", "y"], voices_per_lane=vpl, output_groups={1: group})
-    assert f"group_sum_in_order<{group}>" in g.source
+    assert ("group16_sum_store" if (group == 16 and vpl == 1) else f"group_sum_in_order<{group}>") in g.source
     n = V * T * 64
     d_x = eng.to_device(x)
     d_q = eng.alloc(4 * n)
