@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
     return pgCurr;
   };
 
-  uint32_t cursor = live ? a.recStart[L] : 0;
-  const uint32_t recEnd = live ? a.recStart[L + 1] : 0;
+  const uint2 recRange = live ? a.recRange[L] : make_uint2(0u, 0u);  // this lane's records of this launch: [x, y)
+  uint32_t cursor = recRange.x;
+  const uint32_t recEnd = recRange.y;
   const float pitchBendScale = (a.s.mpe && slot != 0) ? a.s.mpePitchBendRange : a.s.pitchBendRange;  // :417-423
   const double srD = (double)(float)a.s.sr;  // samplesToSeconds(uint32_t, float sr), :13-19
   const unsigned mainLane = (unsigned)((threadIdx.x & 63) / (unsigned)a.group) * (unsigned)a.group;
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
     size_t Lend = L;
     asm volatile("" : "+v"(Lend));
     S = a.state + Lend;
+    if (recRange.x != recRange.y) a.recRange[Lend] = make_uint2(0u, 0u);  // consumed: the next launch finds "no records" unless told otherwise
   }
   SW(S_AWAKE) = awake ? 1u : 0u;
   SW(S_VELOCITY) = f2u(velocity); SW(S_PITCH) = f2u(pitch); SW(S_BEND) = f2u(bend); SW(S_MOD) = f2u(mod);
@@ -622,11 +624,18 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
 // frames with note_frame() as e2s_kernel does and writes its pitch-before-drift and gate to the side signals (16 quads each);
 // a portamento in progress with nothing else going on is the pitch glide's 64 steps alone (pitch side signal only). The drift glide is not touched here: its slots belong to the
 // voice kernel, and nothing in this kernel depends on them (the drift term is added last, :247).
+// the lanes that have records in the coming launch: {lane, first, one past the last}
+__global__ void set_rec_ranges_kernel(const uint4* list, size_t n, uint2* ranges)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ranges[list[i].x] = make_uint2(list[i].y, list[i].z);
+}
+
 struct E2SCtlArgs
 {
   uint32_t* state;
   const Rec* recs;
-  const uint32_t* recStart;
+  uint2* recRange;
   uint32_t* ctl;   // [T][kCtlRecWords][lanes]
   float4* rowP;    // QUAD [16 T][lanes][4], written for CF_ROWS vectors only
   float4* rowG;
@@ -690,8 +699,9 @@ __global__ __launch_bounds__(256) void e2s_ctl_kernel(const E2SCtlArgs a)
     return pgCurr;
   };
 
-  uint32_t cursor = a.recStart[lane];
-  const uint32_t recEnd = a.recStart[lane + 1];
+  const uint2 recRange = a.recRange[lane];  // this lane's records of this launch: [x, y)
+  uint32_t cursor = recRange.x;
+  const uint32_t recEnd = recRange.y;
   // the vector of this lane's next record, in a register: a lane with a record later in the launch does not ask memory every vector
   uint32_t nextVec = cursor < recEnd ? a.recs[cursor].vec : 0xFFFFFFFFu;
   const float pitchBendScale = a.s.pitchBendRange;  // MIDI protocol, :417-423
@@ -800,11 +810,49 @@ __global__ __launch_bounds__(256) void e2s_ctl_kernel(const E2SCtlArgs a)
     else
     {
       // ---- gate and pitch frame by frame: writeNoteEvent (:115-216) and endProcess (:218-244) ----
+      // note_frame() is the whole state machine of a frame (~150 instructions); most frames of a vector with a note event need
+      // none of it: until the frame before the next note record's own frame (where a retrigger opens its one-frame gap, and
+      // where the rewrite pattern at the end of note_frame looks ahead) a frame is the held gate, one step of the pitch glide
+      // and one of the event age - what note_frame does on such a frame, given that the pending record's bookkeeping (which
+      // applies from the first frame that sees the record) has been done. plan() does that bookkeeping and says how far.
       uint32_t nc = cursor;
       bool preApplied = false;
       RecCache recCache;
+      auto plan = [&](int from) -> int {
+        while (nc < vend)
+        {
+          const Rec rc = recCache.at(a.recs, nc);
+          const uint32_t type = rc.typeTimeFlags & 0xFF;
+          if (type != REC_NOTE_ON && type != REC_NOTE_RETRIG && type != REC_NOTE_OFF)
+          {
+            ++nc;
+            continue;
+          }
+          int dest = (int)((rc.typeTimeFlags >> 8) & 0xFF);
+          const uint32_t flags = rc.typeTimeFlags >> 16;
+          if (!preApplied)
+          {
+            if (type != REC_NOTE_OFF)
+            {
+              if (flags & 2) age = 0;  // doReset
+              ageStep = 1;
+            }
+            if (type == REC_NOTE_ON)
+            {
+              inhibit = !(flags & 1);
+              setPitchGlideTime((flags & 1) ? a.s.pitchGlideSamples : 0);
+            }
+            preApplied = true;
+          }
+          if (type == REC_NOTE_RETRIG && dest == 0) dest = 1;
+          return dest - 1 > from ? dest - 1 : from;
+        }
+        return 64;
+      };
+      int quietUntil = heldB ? plan(0) : 0;  // frames [n, quietUntil) need no state machine (a moving bend: every frame does)
       f32x4* oP = (f32x4*)a.rowP + (t * 16) * ln + lane;
       f32x4* oG = (f32x4*)a.rowG + (t * 16) * ln + lane;
+      const float bendTerm = (hvB * pitchBendScale) * (1.f / 12);
 #pragma unroll 1
       for (int q = 0; q < 16; ++q, oP += ln, oG += ln)
       {
@@ -814,10 +862,20 @@ __global__ __launch_bounds__(256) void e2s_ctl_kernel(const E2SCtlArgs a)
         {
           const int n = q * 4 + k;
           float vPitch = 0.f, vGate = 0.f, vTime = 0.f;
-          note_frame(a.recs, recCache, nc, vend, n, preApplied, velocity, pitch, age, ageStep, inhibit, a.s.pitchGlideSamples, false, 1.0, setPitchGlideTime,
-                     pitchGlideNext, vPitch, vGate, vTime);
-          const float bendSig = gb.next(GB, ln, n);
-          vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);  // :244
+          if (n < quietUntil)
+          {
+            vGate = velocity;
+            vPitch = pitchGlideNext(pitch) + bendTerm;
+            age += ageStep;
+          }
+          else
+          {
+            note_frame(a.recs, recCache, nc, vend, n, preApplied, velocity, pitch, age, ageStep, inhibit, a.s.pitchGlideSamples, false, 1.0, setPitchGlideTime,
+                       pitchGlideNext, vPitch, vGate, vTime);
+            const float bendSig = gb.next(GB, ln, n);
+            vPitch = vPitch + (bendSig * pitchBendScale) * (1.f / 12);  // :244
+            if (heldB) quietUntil = plan(n + 1);
+          }
           vP = f32x4{k == 0 ? vPitch : vP[0], k == 1 ? vPitch : vP[1], k == 2 ? vPitch : vP[2], k == 3 ? vPitch : vP[3]};
           vG = f32x4{k == 0 ? vGate : vG[0], k == 1 ? vGate : vG[1], k == 2 ? vGate : vG[2], k == 3 ? vGate : vG[3]};
         }
@@ -840,6 +898,7 @@ __global__ __launch_bounds__(256) void e2s_ctl_kernel(const E2SCtlArgs a)
     size_t Lend = lane;
     asm volatile("" : "+v"(Lend));
     S = a.state + Lend;
+    if (recRange.x != recRange.y) a.recRange[Lend] = make_uint2(0u, 0u);  // consumed
   }
   gb.store(S + (size_t)(S_GLIDES + 0 * kGlideWords) * ln, ln);
   SW(S_AWAKE) = awake ? 1u : 0u;
@@ -981,15 +1040,19 @@ struct mlgpu_events
   std::vector<std::vector<Rec>> laneRecs;  // per lane, this launch
   std::vector<uint32_t> dirtyLanes;        // lanes with records (most have none)
   uint32_t* d_state{nullptr};
+  // [lanes]: where a lane's records of the coming launch are, {0, 0} for none. Only the lanes that have records are written per
+  // launch (a few hundred of 262 144: the list goes up in kilobytes where a start offset per lane was a megabyte over PCIe
+  // every block), and a kernel that consumed a lane's records puts the {0, 0} back.
+  uint2* d_recRange{nullptr};
   // Two sets of upload buffers (pinned host + device): the records of launch k + 1 are routed and copied while the kernel of
   // launch k still runs; a set is reused only after the launch that read it has finished (its event).
   struct Staging
   {
     Rec* h_recs{nullptr};
     Rec* d_recs{nullptr};
-    uint32_t* h_recStart{nullptr};
-    uint32_t* d_recStart{nullptr};
-    size_t recCapacity{0};
+    uint4* h_dirty{nullptr};   // {lane, first record, one past the last, 0} for every lane that has records in this launch
+    uint4* d_dirty{nullptr};
+    size_t recCapacity{0}, dirtyCapacity{0};
     hipEvent_t done{nullptr};
     bool pending{false};
   } stage[2];
@@ -1301,12 +1364,13 @@ extern "C"
     if (ev->d_rowP) hipFree(ev->d_rowP);
     if (ev->d_rowG) hipFree(ev->d_rowG);
     freeControllers(ev);
+    if (ev->d_recRange) hipFree(ev->d_recRange);
     for (mlgpu_events::Staging& st : ev->stage)
     {
       if (st.h_recs) hipHostFree(st.h_recs);
       if (st.d_recs) hipFree(st.d_recs);
-      if (st.h_recStart) hipHostFree(st.h_recStart);
-      if (st.d_recStart) hipFree(st.d_recStart);
+      if (st.h_dirty) hipHostFree(st.h_dirty);
+      if (st.d_dirty) hipFree(st.d_dirty);
       if (st.done) hipEventDestroy(st.done);
     }
     delete ev;
@@ -1370,12 +1434,10 @@ extern "C"
     ev->laneRecs.resize(ev->maxLanes);
     hipError_t err = hipSetDevice(e->device);
     if (err == hipSuccess) err = hipMalloc((void**)&ev->d_state, sizeof(uint32_t) * (size_t)kStateWords * ev->maxLanes);
+    if (err == hipSuccess) err = hipMalloc((void**)&ev->d_recRange, sizeof(uint2) * ev->maxLanes);
+    if (err == hipSuccess) err = hipMemsetAsync(ev->d_recRange, 0, sizeof(uint2) * ev->maxLanes, e->stream);
     for (mlgpu_events::Staging& st : ev->stage)
-    {
-      if (err == hipSuccess) err = hipMalloc((void**)&st.d_recStart, sizeof(uint32_t) * (ev->maxLanes + 1));
-      if (err == hipSuccess) err = hipHostMalloc((void**)&st.h_recStart, sizeof(uint32_t) * (ev->maxLanes + 1));
       if (err == hipSuccess) err = hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
-    }
     if (err != hipSuccess)
     {
       e->lastError = std::string("events_create: ") + hipGetErrorString(err);
@@ -1584,20 +1646,38 @@ extern "C"
         return efail(ev, MLGPU_ERR_OOM, "events_process: record buffer");
       }
     }
+    const size_t nDirty = ev->dirtyLanes.size();
+    if (nDirty > sg.dirtyCapacity)
+    {
+      if (sg.h_dirty) hipHostFree(sg.h_dirty);
+      if (sg.d_dirty) hipFree(sg.d_dirty);
+      sg.h_dirty = sg.d_dirty = nullptr;
+      sg.dirtyCapacity = std::max<size_t>(1024, 2 * nDirty);
+      if (hipMalloc((void**)&sg.d_dirty, sizeof(uint4) * sg.dirtyCapacity) != hipSuccess || hipHostMalloc((void**)&sg.h_dirty, sizeof(uint4) * sg.dirtyCapacity) != hipSuccess)
+      {
+        sg.dirtyCapacity = 0;
+        return efail(ev, MLGPU_ERR_OOM, "events_process: lane list");
+      }
+    }
     std::sort(ev->dirtyLanes.begin(), ev->dirtyLanes.end());
     {
-      size_t next = 0, n = 0;  // lanes without records share their successor's start offset
+      size_t n = 0, i = 0;
       for (uint32_t l : ev->dirtyLanes)
       {
-        for (; next <= l; ++next) sg.h_recStart[next] = (uint32_t)n;
         const std::vector<Rec>& lr = ev->laneRecs[l];
         memcpy(sg.h_recs + n, lr.data(), sizeof(Rec) * lr.size());
+        sg.h_dirty[i++] = make_uint4(l, (uint32_t)n, (uint32_t)(n + lr.size()), 0u);
         n += lr.size();
       }
-      for (; next <= lanes; ++next) sg.h_recStart[next] = (uint32_t)n;
     }
-    hipError_t cerr = hipMemcpyAsync(sg.d_recStart, sg.h_recStart, sizeof(uint32_t) * (lanes + 1), hipMemcpyHostToDevice, e->stream);
+    hipError_t cerr = hipSuccess;
+    if (nDirty) cerr = hipMemcpyAsync(sg.d_dirty, sg.h_dirty, sizeof(uint4) * nDirty, hipMemcpyHostToDevice, e->stream);
     if (cerr == hipSuccess && nRecs) cerr = hipMemcpyAsync(sg.d_recs, sg.h_recs, sizeof(Rec) * nRecs, hipMemcpyHostToDevice, e->stream);
+    if (cerr == hipSuccess && nDirty)
+    {
+      hipLaunchKernelGGL(set_rec_ranges_kernel, dim3((unsigned)((nDirty + 255) / 256)), dim3(256), 0, e->stream, (const uint4*)sg.d_dirty, nDirty, ev->d_recRange);
+      cerr = hipGetLastError();
+    }
     if (cerr != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process upload: ") + hipGetErrorString(cerr));
 
     const int cst = ev->watched.empty() ? MLGPU_OK : processControllers(ev, nVectors, ev->stageIdx ^ 1);
@@ -1624,7 +1704,7 @@ extern "C"
     dev.rowP = dev.rowG = nullptr;
     dev.state = ev->d_state;
     dev.recs = sg.d_recs;
-    dev.recStart = sg.d_recStart;
+    dev.recRange = ev->d_recRange;
     dev.lanes = lanes;
     return MLGPU_OK;
   }
@@ -1661,7 +1741,7 @@ extern "C"
     memset(&a, 0, sizeof(a));
     a.state = dev.state;
     a.recs = (const Rec*)dev.recs;
-    a.recStart = dev.recStart;
+    a.recRange = dev.recRange;
     const size_t lanes = dev.lanes;
     const size_t V = ev->nInstruments * (size_t)ev->polyphony;
     for (int r = 0; r < 8; ++r) a.out[r] = makeView(d_outputs[r], layout, V, nVectors);
@@ -1727,7 +1807,7 @@ extern "C"
     memset(&a, 0, sizeof(a));
     a.state = dev->state;
     a.recs = (const Rec*)dev->recs;
-    a.recStart = dev->recStart;
+    a.recRange = dev->recRange;
     a.ctl = ev->d_ctlRecs;
     a.rowP = (float4*)ev->d_rowP;
     a.rowG = (float4*)ev->d_rowG;

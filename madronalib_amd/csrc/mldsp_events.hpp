@@ -50,7 +50,7 @@ struct E2SArgs
 {
   uint32_t* state;            // [kStateWords][lanes]
   const Rec* recs;            // all records of this launch, grouped by lane, time-ordered inside a lane
-  const uint32_t* recStart;   // [lanes + 1]
+  uint2* recRange;            // [lanes]: a lane's records of this launch are recs[x .. y); a kernel that read them writes {0, 0} back
   SignalView out[8];          // pitch, gate, vox, z, x, y, mod, elapsed time: V = instruments * polyphony voices
   size_t lanes, T;
   int group, polyphony, slotBase;  // lane = instrument * group + (voice slot - slotBase)

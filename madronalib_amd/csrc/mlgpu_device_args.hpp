@@ -51,7 +51,7 @@ struct EventsDev
 {
   uint32_t* state;           // [kStateWords][lanes]
   const void* recs;          // mlev::Rec: this launch's records, grouped by lane, time-ordered inside a lane
-  const uint32_t* recStart;  // [lanes + 1]
+  uint2* recRange;           // [lanes]: a lane's records of this launch are recs[x .. y)
   size_t lanes;
   E2SSettings s;
   // the launch's control records [T][kCtlRecWords][lanes] and the two side signals (QUAD layout) of e2s_ctl_kernel: what a voice
