@@ -72,7 +72,8 @@ typedef enum mlgpu_status
   MLGPU_ERR_HIP = 3,         /* a HIP runtime call failed; see mlgpu_last_error */
   MLGPU_ERR_OOM = 4,         /* device or host allocation failed */
   MLGPU_ERR_UNSUPPORTED = 5, /* valid request this build has no kernel for */
-  MLGPU_ERR_RANGE = 6        /* index out of range (proc, coeff, state, voice) */
+  MLGPU_ERR_RANGE = 6,       /* index out of range (proc, coeff, state, voice) */
+  MLGPU_ERR_BUSY = 7         /* the object is being worked on by a job the caller started (mlgpu_graph_compile_async): ask again */
 } mlgpu_status;
 
 /* ------------------------------------------------------------------------- */
@@ -303,6 +304,14 @@ int mlgpu_engine_device(mlgpu_engine* e);
 const char* mlgpu_last_error(mlgpu_engine* e);
 const char* mlgpu_status_string(int status);
 int mlgpu_abi_version(void);
+/* A number that goes up whenever a DOCUMENTED behaviour of an existing entry point changes under an unchanged ABI (same symbols,
+ * same arguments, other last bits or other side effects), so that a host can tell which contract it runs against:
+ *   1  rounds 1-3
+ *   2  round 4: mlgpu_mixdown above 4 096 voices adds the group sums 64 at a time (other last bits than the serial chain of
+ *      rounds 1-3; INTEGRATION.md "Behavioural differences")
+ *   3  round 5: MLGPU_ERR_BUSY exists (a graph with a compile in flight); mlgpu_graph_process_events runs the events'
+ *      control-rate half as a kernel of its own before the voice kernel (same outputs and state, one launch more per block) */
+int mlgpu_behaviour_revision(void);
 /* SHA-256 (hex) of every device source file of this build and its compiler flags. Measurements that cannot be taken
  * inside a run (rocprofv3 PMC counters, profiles/pmc_workloads.json) are recorded with it and refused by bench.py when
  * the loaded library's differs, so a kernel change cannot inherit old counters. */
@@ -637,8 +646,25 @@ int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n);
 size_t mlgpu_graph_device_bytes(mlgpu_graph* g);
 int mlgpu_graph_set_autotune(mlgpu_graph* g, int on);
 int mlgpu_graph_tuning(mlgpu_graph* g, int* voices_per_lane, int* quads_per_trip);
-/* Generate + compile (hiprtc, gfx950) + load the fused kernel; allocate state/coeffs/params. */
+/* Generate + compile (hiprtc, gfx950) + load the fused kernel; allocate state/coeffs/params.
+ * A COLD compile - a graph whose generated source is in neither the process's memory cache nor the disk cache
+ * ($MLGPU_CACHE_DIR, default ~/.cache/mlgpu) - runs hiprtc for 2 to 5 seconds (measured: the 16-node synth voice 1.9 s, the
+ * survey's 22-node patch 4.9 s); warm it is milliseconds. NEVER call this from an audio callback for a patch the user has just
+ * edited: use the two calls below, or compile ahead of time. */
 int mlgpu_graph_compile(mlgpu_graph* g);
+/* The same work on a thread of the library's: returns at once. Until mlgpu_graph_compile_poll has answered something other than
+ * MLGPU_ERR_BUSY the graph belongs to that job - every other call on it (build calls, mlgpu_graph_compile, mlgpu_graph_process,
+ * mlgpu_graph_emit, setters) returns MLGPU_ERR_BUSY and changes nothing; mlgpu_graph_destroy waits for the job. A host keeps
+ * processing its OLD graph block after block, polls once per block, and swaps when the new one is ready (tests/test_gpu_graph.py::
+ * test_patch_swap_with_async_compile: no block over its period while a cold compile runs). The reference's equivalent is building
+ * a new processor list off the audio thread (naming convention: source/procs/MLProcMultiply.cpp:12-47).
+ * On a graph created WITHOUT an engine (mlgpu_graph_create(NULL, ...)) the job is an ahead-of-time compile: it fills the memory
+ * and disk caches for this description and the graph stays a description (poll then answers MLGPU_OK once the code exists). */
+int mlgpu_graph_compile_async(mlgpu_graph* g);
+/* MLGPU_ERR_BUSY: still compiling. MLGPU_OK: compiled (state, coefficients and parameters allocated on the calling thread, on the
+ * engine's stream: microseconds) - the graph is ready for setters and mlgpu_graph_process. Anything else: the compile failed with
+ * that status (mlgpu_graph_last_error says why) and the graph can be destroyed. */
+int mlgpu_graph_compile_poll(mlgpu_graph* g);
 /* The generated HIP source (valid after compile; for inspection). */
 const char* mlgpu_graph_source(mlgpu_graph* g);
 /* Offline code generation: place the rings, generate the kernel source (mlgpu_graph_source) and compile it to a gfx950 code

@@ -20,6 +20,14 @@ __all__ = ["Engine", "Bank", "Graph", "DSPBuffer", "ProcessBuffer", "Resampler",
            "dBToGain", "device_count", "FLOATS_PER_DSPVECTOR"]
 
 
+BUSY = 7   # MLGPU_ERR_BUSY: a job started on the object has not finished (Graph.compile_async)
+
+
+def behaviour_revision():
+    """mlgpu_behaviour_revision(): goes up when a documented behaviour of an existing entry point changes under an unchanged ABI."""
+    return _lib.load().mlgpu_behaviour_revision()
+
+
 class MlgpuError(RuntimeError):
     def __init__(self, status, detail=""):
         L = _lib.load()
@@ -962,7 +970,7 @@ class Graph:
     """
 
     def __init__(self, engine, n_voices, description=None, outputs=None, voices_per_lane=0, delay_windows=False, autotune=False,
-                 live_constants=False, output_groups=None, input_groups=None):
+                 live_constants=False, output_groups=None, input_groups=None, compile_now=True):
         self.engine = engine
         self.L = engine.L
         self.V = int(n_voices)
@@ -992,7 +1000,7 @@ class Graph:
                 self.set_output_group_sum(idx, group)
             for idx, group in (input_groups or {}).items():    # {input index: voices per row}: set_input_group
                 self.set_input_group(idx, group)
-            if engine.h is not None:
+            if engine.h is not None and compile_now:
                 self.compile()
 
     def close(self):
@@ -1143,6 +1151,19 @@ class Graph:
 
     def compile(self):
         self.engine._check(self.L.mlgpu_graph_compile(self.h))
+
+    def compile_async(self):
+        """Start the compile on a thread of the library's (mlgpu_graph_compile_async); poll with compile_poll(). On a graph of an
+        OfflineEngine: an ahead-of-time compile that fills the memory and disk caches for this description."""
+        self.engine._check(self.L.mlgpu_graph_compile_async(self.h))
+
+    def compile_poll(self):
+        """False while the compile is in flight; True once the graph is ready; raises MlgpuError when the compile failed."""
+        st = self.L.mlgpu_graph_compile_poll(self.h)
+        if st == BUSY:
+            return False
+        self.engine._check(st)
+        return True
 
     @property
     def source(self):

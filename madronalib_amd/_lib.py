@@ -194,6 +194,9 @@ def _declare(L):
     sig("mlgpu_graph_node", i, [vp, c.c_char_p])
     sig("mlgpu_graph_num_nodes", i, [vp])
     sig("mlgpu_graph_compile", i, [vp])
+    sig("mlgpu_graph_compile_async", i, [vp])
+    sig("mlgpu_graph_compile_poll", i, [vp])
+    sig("mlgpu_behaviour_revision", i, [])
     sig("mlgpu_graph_source", c.c_char_p, [vp])
     sig("mlgpu_graph_node_use_count", i, [vp, i])
     sig("mlgpu_graph_emit", i, [vp, c.POINTER(vp), c.POINTER(c.c_size_t)])

@@ -110,6 +110,7 @@ extern "C"
   int mlgpu_abi_version(void) { return MLGPU_ABI_VERSION; }
   const char* mlgpu_device_source_hash(void) { return mlgpu_device_source_hash_str; }
 
+  int mlgpu_behaviour_revision(void) { return 3; }
   const char* mlgpu_status_string(int s)
   {
     switch (s)
@@ -121,6 +122,7 @@ extern "C"
       case MLGPU_ERR_OOM: return "out of memory";
       case MLGPU_ERR_UNSUPPORTED: return "unsupported";
       case MLGPU_ERR_RANGE: return "index out of range";
+      case MLGPU_ERR_BUSY: return "busy: a job started on this object has not finished";
       default: return "unknown status";
     }
   }

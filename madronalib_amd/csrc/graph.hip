@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -493,6 +494,17 @@ struct mlgpu_graph
   std::string lastError;         // mlgpu_graph_last_error
   mlgpu_events* events{nullptr}; // mlgpu_graph_bind_events: the object the NODE_EVENT_ROW nodes read
   bool hasEventRows{false};
+  // mlgpu_graph_compile_async: code generation and hiprtc on a thread of the library's, off the caller's (audio) thread. While the
+  // job is in flight the graph belongs to that thread: every other call on the graph answers MLGPU_ERR_BUSY (or refuses as it would
+  // for a graph that is not compiled yet) without touching it.
+  struct CompileJob
+  {
+    std::thread th;
+    std::atomic<bool> done{false};
+    int status{MLGPU_OK};
+    std::string error;
+  };
+  CompileJob* job{nullptr};
   int eventOffset{-1};           // frame offset of the block being processed (mlgpu_graph_process_events), -1: none pending
   int minWaves{0};               // wavefronts per SIMD the kernel's register budget must allow (0: the compiler's choice), generateBudgeted
   // Online tuning (mlgpu_graph_set_autotune): every variant (voices per lane x quads per trip) computes the same bits from
@@ -518,9 +530,12 @@ struct mlgpu_graph
 
 namespace
 {
+static thread_local bool t_compileWorker = false;  // this thread is a graph's compile job: failures stay with the graph
 int gfail(mlgpu_graph* g, int status, const std::string& what)
 {
-  if (g && g->e) g->e->lastError = what;
+  // a graph whose compile is in flight belongs to that thread: a call that fails on it meanwhile writes nothing and says busy
+  if (g && g->job && !t_compileWorker) return MLGPU_ERR_BUSY;
+  if (g && g->e && !t_compileWorker) g->e->lastError = what;
   if (g) g->lastError = what;  // a graph created without an engine (offline code generation) has nowhere else to keep it
   return status;
 }
@@ -1248,7 +1263,8 @@ static bool generateBudgeted(mlgpu_graph* g, int vl, std::string& source, std::v
 
 int addNode(mlgpu_graph* g, Node&& n)
 {
-  if (g->compiled) return -gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+  if (g->job) return -MLGPU_ERR_BUSY;
+    if (g->compiled) return -gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
   for (int id : n.in)
     if (id < 0 || id >= (int)g->nodes.size()) return -gfail(g, MLGPU_ERR_RANGE, "graph node input refers to an unknown node");
   switch (n.type)
@@ -1496,6 +1512,12 @@ extern "C"
   int mlgpu_graph_destroy(mlgpu_graph* g)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job)  // a compile in flight owns the graph: wait for it (seconds at most), then let it go
+    {
+      g->job->th.join();
+      delete g->job;
+      g->job = nullptr;
+    }
     {
       std::lock_guard<std::mutex> lock(g_boundMutex);
       g_boundGraphs.erase(g);
@@ -1642,6 +1664,7 @@ extern "C"
   {
     int st = checkNode(g, fbNode, NODE_FEEDBACK);
     if (st) return st;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (valueNode < 0 || valueNode >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_set_feedback: unknown value node");
     g->nodes[fbNode].fbSource = valueNode;
@@ -1651,6 +1674,7 @@ extern "C"
   {
     int st = checkNode(g, node, NODE_PROC);
     if (st) return st;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (mlgpu_proc_rings(g->nodes[node].kind) == 0) return gfail(g, MLGPU_ERR_INVALID, "graph_set_max_delay: not a delay node");
     if (!(maxDelayInSamples >= 0.f) || maxDelayInSamples > 16777216.f) return gfail(g, MLGPU_ERR_RANGE, "graph_set_max_delay: 0 .. 2^24 samples");
@@ -1726,6 +1750,7 @@ extern "C"
   int mlgpu_graph_begin_region(mlgpu_graph* g, int region, const int* inputs, int nIn, int* regionInputs)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (region != MLGPU_REGION_UPSAMPLE_2X && region != MLGPU_REGION_DOWNSAMPLE_2X) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: unknown region kind");
     if (nIn < 0 || nIn > 8 || (nIn > 0 && (!inputs || !regionInputs))) return gfail(g, MLGPU_ERR_INVALID, "graph_begin_region: 0..8 inputs");
@@ -1760,6 +1785,7 @@ extern "C"
   int mlgpu_graph_end_region(mlgpu_graph* g, int result, const char* name)
   {
     if (!g) return -MLGPU_ERR_INVALID;
+    if (g->job) return -MLGPU_ERR_BUSY;
     if (g->compiled) return -gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     const int r = g->openRegion;
     if (r < 0) return -gfail(g, MLGPU_ERR_INVALID, "graph_end_region: no region is open");
@@ -1794,6 +1820,7 @@ extern "C"
   int mlgpu_graph_add_output(mlgpu_graph* g, int node)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_add_output: unknown node");
     if (g->outputs.size() >= MLGPU_GRAPH_MAX_OUTPUTS) return gfail(g, MLGPU_ERR_UNSUPPORTED, "too many graph outputs");
@@ -1805,6 +1832,7 @@ extern "C"
   int mlgpu_graph_set_output_group_sum(mlgpu_graph* g, int index, int group)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (index < 0 || index >= (int)g->outputs.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_set_output_group_sum: no such output");
     if (group != 0 && group != 2 && group != 4 && group != 8 && group != 16)
@@ -1894,6 +1922,7 @@ extern "C"
   int mlgpu_graph_emit(mlgpu_graph* g, const void** code, size_t* codeSize)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     const int st = layoutAndGenerate(g);
     if (st != MLGPU_OK) return st;
     if (g->emitted.empty()) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_emit (hiprtc): " + g->log);
@@ -1902,19 +1931,79 @@ extern "C"
     return MLGPU_OK;
   }
 
-  int mlgpu_graph_compile(mlgpu_graph* g)
+  // the part of a compile that takes seconds and needs no stream: code generation, hiprtc (or the caches), module load
+  static int compileBuild(mlgpu_graph* g)
   {
-    if (!g) return MLGPU_ERR_INVALID;
-    if (g->compiled) return MLGPU_OK;
     mlgpu_engine* e = g->e;
-    if (!e) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: the graph was created without an engine (graph_emit only)");
     const int st = layoutAndGenerate(g);
     if (st != MLGPU_OK) return st;
+    if (!e) return MLGPU_OK;  // ahead of time: the code is in the memory and disk caches now (mlgpu_graph_compile_async on a graph without an engine)
     if (hipSetDevice(e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
     CompiledModule* cm = compileAndLoad(e->device, g->source, g->log);
     if (!cm) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
     g->fn = getFunction(cm, "mlgpu_graph_kernel", g->log);
     if (!g->fn) return gfail(g, MLGPU_ERR_HIP, g->log);
+    return MLGPU_OK;
+  }
+  static int compileFinish(mlgpu_graph* g);
+
+  int mlgpu_graph_compile(mlgpu_graph* g)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;  // (not gfail: the graph is the job's until mlgpu_graph_compile_poll has collected it)
+    if (g->compiled) return MLGPU_OK;
+    if (!g->e) return gfail(g, MLGPU_ERR_INVALID, "graph_compile: the graph was created without an engine (graph_emit only)");
+    const int st = compileBuild(g);
+    if (st != MLGPU_OK) return st;
+    return compileFinish(g);
+  }
+
+  int mlgpu_graph_compile_async(mlgpu_graph* g)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
+    if (g->compiled) return MLGPU_OK;
+    mlgpu_graph::CompileJob* job = new (std::nothrow) mlgpu_graph::CompileJob();
+    if (!job) return MLGPU_ERR_OOM;
+    g->job = job;
+    try
+    {
+      job->th = std::thread([g, job]() {
+        t_compileWorker = true;
+        job->status = compileBuild(g);
+        job->error = g->lastError;
+        job->done.store(true, std::memory_order_release);
+      });
+    }
+    catch (...)
+    {
+      g->job = nullptr;
+      delete job;
+      return gfail(g, MLGPU_ERR_OOM, "graph_compile_async: could not start a thread");
+    }
+    return MLGPU_OK;
+  }
+
+  int mlgpu_graph_compile_poll(mlgpu_graph* g)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (!g->job) return g->compiled ? MLGPU_OK : gfail(g, MLGPU_ERR_INVALID, "graph_compile_poll: no compile in flight (mlgpu_graph_compile_async)");
+    if (!g->job->done.load(std::memory_order_acquire)) return MLGPU_ERR_BUSY;
+    mlgpu_graph::CompileJob* job = g->job;
+    job->th.join();
+    g->job = nullptr;
+    const int st = job->status;
+    const std::string err = job->error;
+    delete job;
+    if (st != MLGPU_OK) return gfail(g, st, err);
+    if (!g->e) return MLGPU_OK;  // ahead of time: nothing to allocate, the graph stays a description
+    return compileFinish(g);     // allocations and the initial fills, on the caller's thread and stream: microseconds
+  }
+
+  static int compileFinish(mlgpu_graph* g)
+  {
+    mlgpu_engine* e = g->e;
+    if (hipSetDevice(e->device) != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "hipSetDevice");
     g->activeVl = g->compiledVoicesPerLane;
     if (g->autotune)
     {
@@ -2080,6 +2169,7 @@ extern "C"
   int mlgpu_graph_set_delay_layout(mlgpu_graph* g, int windowed)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     g->windowedRings = windowed != 0;
     return MLGPU_OK;
@@ -2088,6 +2178,7 @@ extern "C"
   int mlgpu_graph_set_autotune(mlgpu_graph* g, int on)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     g->autotune = on != 0;
     return MLGPU_OK;
@@ -2161,6 +2252,7 @@ extern "C"
   int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (n < 0 || n > 2) return gfail(g, MLGPU_ERR_INVALID, "graph_set_voices_per_lane: 0 (automatic), 1 or 2");
     g->voicesPerLane = n;
@@ -2179,6 +2271,7 @@ extern "C"
   int mlgpu_graph_set_input_group(mlgpu_graph* g, int inputIndex, int group)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (inputIndex < 0 || inputIndex >= g->nInputs) return gfail(g, MLGPU_ERR_RANGE, "graph_set_input_group: input index out of range");
     if (group < 1 || (size_t)group > g->V || g->V % (size_t)group) return gfail(g, MLGPU_ERR_INVALID, "graph_set_input_group: the voices are not a whole number of groups");
@@ -2216,6 +2309,7 @@ extern "C"
                               float* const* d_outputs, int outLayout)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_process: compile first");
     if (T == 0) return MLGPU_OK;
     if (inLayout < 0 || inLayout > MLGPU_LAYOUT_BROADCAST || outLayout < 0 || outLayout > MLGPU_LAYOUT_VOICE_MAJOR)

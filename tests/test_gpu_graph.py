@@ -280,6 +280,82 @@ def test_config5_every_voice(eng, full):
 
 
 @pytest.mark.gpu
+def test_patch_swap_with_async_compile(eng):
+    """A host edits its patch while it plays: the old graph keeps processing one 512-frame block per 10.67 ms period (48 kHz) while
+    the new one - a description no cache has seen, so hiprtc really runs: seconds - compiles on the library's thread
+    (mlgpu_graph_compile_async), polled once per block. No block may take longer than its period; the swapped-in graph gives the
+    bits of the same description compiled the ordinary way."""
+    import gc
+    import time
+    import madronalib_amd as ml
+    from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
+    V, T = 65536, 8
+    period = 64 * T / 48000.0
+
+    def setup(g):
+        params, coeffs, seeds = cfg5_voice_params(0, V, V, ml)
+        g.clear()
+        for k, v in params.items():
+            g.set_param(k, v if np.ndim(v) else float(v))
+        for k, c in coeffs.items():
+            g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+        g.set_state("noise", 0, seeds)
+    desc, outs = patches.synth16()
+    old = ml.Graph(eng, V, desc, outs)
+    setup(old)
+    salt = float(np.float32(0.5 + (time.time_ns() % 1000003) * 1e-7))
+    desc2 = desc + [dict(name="salt", type="const", value=salt), dict(name="salted", type="op", kind=Op.MULTIPLY, inputs=[outs[0], "salt"])]
+    new = ml.Graph(eng, V, desc2, ["salted"], compile_now=False)
+    d_gate = eng.to_device(cfg5_gate_quad(0, V, T))
+    d_out = eng.alloc(4 * V * T * 64)
+    for _ in range(3):
+        old.process(T, [d_gate], [d_out])
+    eng.sync()
+    compiles0 = ml.jit_stats()["compiles"]
+    with pytest.raises(ml.MlgpuError):
+        new.process(T, [d_gate], [d_out])                 # not compiled yet
+    new.compile_async()
+    assert eng.L.mlgpu_graph_process(new.h, T, None, 0, None, 0) == ml.BUSY
+    gc_was = gc.isenabled()
+    gc.disable()
+    block_s, ready_after, t_start = [], None, time.perf_counter()
+    try:
+        nxt = time.perf_counter()
+        for b in range(20000):
+            while time.perf_counter() < nxt:
+                pass
+            t0 = time.perf_counter()
+            old.process(T, [d_gate], [d_out])
+            eng.sync()
+            ready = new.compile_poll()
+            block_s.append(time.perf_counter() - t0)
+            nxt = max(nxt + period, time.perf_counter())
+            if ready:
+                ready_after = time.perf_counter() - t_start
+                break
+    finally:
+        if gc_was:
+            gc.enable()
+    assert ready_after is not None, "the compile did not finish in 20 000 blocks"
+    assert ml.jit_stats()["compiles"] == compiles0 + 1 and len(block_s) > 20, (ready_after, len(block_s))   # hiprtc really ran, for many blocks
+    assert max(block_s) < period, f"a block took {max(block_s) * 1e3:.2f} ms of a {period * 1e3:.2f} ms period while the new patch compiled"
+    print(f"\npatch swap: cold compile ready after {ready_after:.2f} s = {len(block_s)} blocks of {period * 1e3:.2f} ms; slowest block {max(block_s) * 1e3:.3f} ms")
+    # the new patch takes over; its twin compiled the ordinary way (a memory-cache hit now) gives the same bits
+    setup(new)
+    twin = ml.Graph(eng, V, desc2, ["salted"])
+    setup(twin)
+    d_out2 = eng.alloc(4 * V * T * 64)
+    for _ in range(2):
+        new.process(T, [d_gate], [d_out])
+        twin.process(T, [d_gate], [d_out2])
+    a, b = d_out.download(np.float32), d_out2.download(np.float32)
+    assert_bits_equal(a, b, True, "async-compiled graph vs its synchronously compiled twin")
+    assert np.abs(a).max() > 0
+    for g in (old, new, twin):
+        g.close()
+
+
+@pytest.mark.gpu
 def test_graph_with_masks_and_two_outputs(eng, oracle):
     """compare -> mask -> select, a 3-input op, a const, two outputs, two inputs."""
     import madronalib_amd as ml
