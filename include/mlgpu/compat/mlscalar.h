@@ -5,7 +5,9 @@
 // of the reference's reverb.cpp, the controller-to-frequency map of controllers-to-audio.cpp) - but those floats become constants
 // of the captured kernel, so the values matter: every function here performs the reference's arithmetic in the reference's order
 // (tests/test_host_cpp.py::test_scalar_helpers_match_the_reference compares a sweep of each against the reference's own header,
-// bit for bit). Written for this repository; mldsp.h includes it when madronalib's own headers are not on the include path.
+// bit for bit). mldsp.h includes it when madronalib's own headers are not on the include path. The scalar templates, the random
+// source and the projections are written for this repository against that contract; the compile-time math block (const_math) follows
+// a third party's algorithms step for step and carries that author's notice - see there.
 #pragma once
 
 #include <cmath>
@@ -157,6 +159,16 @@ class RandomScalarSource
 
 // ---- compile-time math: crude but constexpr, and what the reference's own constants are made with (SineGen's sqrt(2) is
 // const_math::sqrt's 1.41421568, not 1.41421356). Same recurrences, same stopping rule (an absolute tolerance of 0.001). ---------
+//
+// ATTRIBUTION. The functions of this namespace have to return the reference's values bit for bit (they are compile-time constants of
+// DSP code), which pins the algorithm of each - series, recurrence, stopping rule, operation order - to that of the reference's
+// block (source/DSP/MLDSPScalarMath.h:215-371), which is itself third-party code carrying this notice:
+//     C++11 constexpr versions of cmath functions needed for the FFT.
+//     Copyright Paul Keir 2012-2016
+//     Distributed under the Boost Software License, Version 1.0.
+//     (See accompanying file license.txt or copy at http://boost.org/LICENSE_1_0.txt)
+// Several functions are restated iteratively here (sqrt, pow, mantissa, exponent) or under other helper names, but this block is a
+// derivative of that work as far as its algorithms go and is distributed under the same Boost Software License 1.0.
 namespace const_math
 {
 constexpr double tol = 0.001;
@@ -201,12 +213,12 @@ constexpr double atan_pairs(const double res, const double num1, const double de
   return res < tol ? res : res + atan_pairs((num1 * delta) / (den1 + 2.) - num1 / den1, num1 * delta * delta, den1 + 4., delta);
 }
 constexpr double atan_poly(const double x) { return x + atan_pairs(pow(x, 5) / 5. - pow(x, 3) / 3., pow(x, 7), 7., x * x); }
-constexpr double atan_identity(const double x)
+constexpr double atan_reduced(const double x)
 {
   return x <= (2. - sqrt(3.)) ? atan_poly(x) : (kTwoPi / 3.) + atan_poly((sqrt(3.) * x - 1) / (sqrt(3.) + x));
 }
-constexpr double atan_cmplmntry(const double x) { return (x < 1) ? atan_identity(x) : kTwoPi - atan_identity(1 / x); }
-constexpr double atan(const double x) { return (x >= 0) ? atan_cmplmntry(x) : -atan_cmplmntry(-x); }
+constexpr double atan_folded(const double x) { return (x < 1) ? atan_reduced(x) : kTwoPi - atan_reduced(1 / x); }
+constexpr double atan(const double x) { return (x >= 0) ? atan_folded(x) : -atan_folded(-x); }
 constexpr double atan2(const double y, const double x)
 {
   if (x > 0) return atan(y / x);

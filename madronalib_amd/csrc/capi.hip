@@ -267,6 +267,9 @@ extern "C"
     {
       hipGraphDestroy(graph);
       delete s;
+      // the sequence never came to be: without this the engine kept counting it, and the objects destroyed from then on (their
+      // frees are deferred while a sequence lives) waited for the engine's own destruction
+      if (--e->liveSequences == 0) e->runDeferredFrees();
       return fail(e, MLGPU_ERR_HIP, "end_recording: hipGraphInstantiate", err);
     }
     size_t n = 0;
@@ -585,7 +588,14 @@ extern "C"
     if (need <= e->mixScratchFloats) return MLGPU_OK;
     HIP_TRY(e, hipSetDevice(e->device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
-    if (e->d_mixScratch) hipFree(e->d_mixScratch);
+    // a recorded mlgpu_mixdown has the scratch pointer baked in: while a sequence of this engine lives the old buffer stays where
+    // it is (freed with the last sequence, like an events object destroyed under a sequence) and the new one serves from now on
+    if (e->d_mixScratch)
+    {
+      float* old = e->d_mixScratch;
+      if (e->liveSequences > 0) e->deferredFrees.push_back([old]() { hipFree(old); });
+      else hipFree(old);
+    }
     e->d_mixScratch = nullptr;
     e->mixScratchFloats = 0;
     const hipError_t err = hipMalloc((void**)&e->d_mixScratch, sizeof(float) * need);

@@ -1355,23 +1355,42 @@ static void freeControllers(mlgpu_events* ev)
 }
 extern "C"
 {
-  static void reallyDestroyEvents(mlgpu_events* ev)
+  // What a recorded sequence may still read is DEVICE memory only (event routing is refused while recording, so no replay ever
+  // touches the pinned staging or the hipEvents): the host side goes at once, the device buffers when no sequence can replay.
+  static void freeEventsHostSide(mlgpu_events* ev)
   {
-    hipSetDevice(ev->e->device);
-    hipStreamSynchronize(ev->e->stream);
+    for (mlgpu_events::Staging& st : ev->stage)
+    {
+      if (st.h_recs) hipHostFree(st.h_recs);
+      if (st.h_dirty) hipHostFree(st.h_dirty);
+      if (st.done) hipEventDestroy(st.done);
+      st.h_recs = nullptr;
+      st.h_dirty = nullptr;
+      st.done = nullptr;
+    }
+    for (mlgpu_events::CtlStaging& st : ev->ctlStage)
+    {
+      if (st.h_recs) hipHostFree(st.h_recs);
+      if (st.h_recStart) hipHostFree(st.h_recStart);
+      st.h_recs = nullptr;
+      st.h_recStart = nullptr;
+    }
+    std::vector<Instrument>().swap(ev->inst);
+    std::vector<std::vector<Rec>>().swap(ev->laneRecs);
+    std::vector<std::vector<CtlRec>>().swap(ev->ctlLaneRecs);
+  }
+  static void freeEventsDeviceSide(mlgpu_events* ev)
+  {
     if (ev->d_state) hipFree(ev->d_state);
     if (ev->d_ctlRecs) hipFree(ev->d_ctlRecs);
     if (ev->d_rowP) hipFree(ev->d_rowP);
     if (ev->d_rowG) hipFree(ev->d_rowG);
-    freeControllers(ev);
     if (ev->d_recRange) hipFree(ev->d_recRange);
+    freeControllers(ev);
     for (mlgpu_events::Staging& st : ev->stage)
     {
-      if (st.h_recs) hipHostFree(st.h_recs);
       if (st.d_recs) hipFree(st.d_recs);
-      if (st.h_dirty) hipHostFree(st.h_dirty);
       if (st.d_dirty) hipFree(st.d_dirty);
-      if (st.done) hipEventDestroy(st.done);
     }
     delete ev;
   }
@@ -1381,15 +1400,18 @@ extern "C"
     // waiting for the stream would invalidate a capture in progress
     if (ev->e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_destroy waits for the device: not while recording a sequence");
     mlgpu_graph_forget_events(ev);  // graphs bound to this object (mlgpu_graph_bind_events) go back to "no events object"
-    // A recorded sequence of this engine may replay launches that read this object's memory: the handle is gone for the caller now,
-    // the memory goes when the last sequence does (or with the engine). (Round 3 refused here - and owners that ignore the status,
-    // like a destructor, leaked the object.)
+    hipSetDevice(ev->e->device);
+    hipStreamSynchronize(ev->e->stream);
+    freeEventsHostSide(ev);
+    // A recorded sequence of this engine may replay launches that read this object's device memory: the handle is gone for the
+    // caller now, that memory goes when the last sequence does (or with the engine). A host that keeps one long-lived sequence and
+    // churns events objects so holds on to their device buffers only - state and signals -, not to pinned memory and events.
     if (ev->e->liveSequences > 0)
     {
-      ev->e->deferredFrees.push_back([ev]() { reallyDestroyEvents(ev); });
+      ev->e->deferredFrees.push_back([ev]() { freeEventsDeviceSide(ev); });
       return MLGPU_OK;
     }
-    reallyDestroyEvents(ev);
+    freeEventsDeviceSide(ev);
     return MLGPU_OK;
   }
 

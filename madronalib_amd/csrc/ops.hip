@@ -651,6 +651,12 @@ namespace
 // quad across the lanes with six shuffle-and-add rounds per component, one quad per wavefront at T = 1: 0.35 of HBM and a quarter of a
 // million tiny wavefronts for 2^20 voices.) a[i] += a[i + d] for d = 1, 2, 4 ... is exactly tree(0, 64) below.
 constexpr int kMixRow = 68;
+// mixdown_stage1_kernel parks 4 wavefronts x 64 voices x 68 floats = 69 632 bytes in LDS: more than the 64 KiB a workgroup gets on
+// every AMD target but gfx950 (160 KiB per CU). This library is written for gfx950 alone; say so instead of an opaque backend error.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmlgpu is written for gfx950 (MI355X): mixdown_stage1_kernel needs 68 KiB of LDS per workgroup, other targets allow 64 KiB"
+#endif
+static_assert(4 * 64 * kMixRow * sizeof(float) <= 160 * 1024, "mixdown_stage1_kernel's LDS tile must fit gfx950's 160 KiB per CU");
 template <int LO, int N>
 struct MixTree
 {

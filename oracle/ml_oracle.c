@@ -1384,7 +1384,7 @@ uint64_t mlorc_sinf_check(uint32_t lo, uint32_t hi, int n_threads, uint32_t* lis
 }
 
 /* The device's CHEAPER forms of the same function on the SVF coefficient code's domain [2^-12, pi_f] (mldsp_math.hpp:
- * libm_sinf_direct / libm_sinf_0_pi), restated here operation for operation - Horner polynomials with fused multiply-adds, the
+ * libm_sinf_q0 for [2^-12, kSinfT1) / libm_sinf_pair for [2^-12, pi_f]), restated here operation for operation - Horner polynomials with fused multiply-adds, the
  * quadrant from two float comparisons - so that their claim can be checked where the host libm lives: mlorc_sinf_fast_check
  * compares both with sinf() over a range of bit patterns (tests/test_oracle_golden.py runs the whole domain, 113 840 092 floats).
  * fma() is the C library's correctly rounded one (hardware FMA through glibc's ifunc where the CPU has it). */

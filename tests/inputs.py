@@ -111,7 +111,8 @@ def assert_rel_close(got, want, rel, what=""):
     tol = rel * np.abs(w[fin]) + 1e-44
     bad = err > tol
     worst = float((err / (np.abs(w[fin]) + 1e-300)).max()) if err.size else 0.0
-    REL_MEASURED[what.split(" ")[0] + " " + what.split(" ")[1] if " " in what else what] = max(worst, REL_MEASURED.get(what, 0.0))
+    key = " ".join(what.split(" ")[:2])   # the label's first two words: one running maximum per kind of comparison
+    REL_MEASURED[key] = max(worst, REL_MEASURED.get(key, 0.0))
     assert not bad.any(), f"{what}: {int(bad.sum())} beyond rel {rel}; worst {worst:.3e}"
 
 

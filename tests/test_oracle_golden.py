@@ -93,13 +93,14 @@ def test_restated_libm_sinf_against_host_libm(oracle):
 
 def test_fast_sinf_forms_exhaustively(oracle):
     """Lopass(x, omega, k) on the device computes its two sinf per sample with cheaper sequences than glibc's (Horner forms with
-    fused multiply-adds, the quadrant from two float comparisons; mldsp_math.hpp: libm_sinf_direct for arguments in [2^-12, 0.75),
-    libm_sinf_0_pi for [2^-12, pi_f]) - legitimate only because their rounded floats equal the host libm's for EVERY argument of
-    those domains. The same sequences in C, all 96 468 992 + 113 840 092 floats; and the two thresholds are where glibc's quadrant
-    steps."""
+    fused multiply-adds, the quadrant from two float comparisons; mldsp_math.hpp: libm_sinf_q0 - the sine polynomial on the argument
+    itself - for arguments in [2^-12, kSinfT1 = 0.785...), libm_sinf_pair for [2^-12, pi_f]) - legitimate only because their
+    rounded floats equal the host libm's for EVERY argument of those domains. The same sequences in C over every float of both
+    domains (the direct form up to the float before kSinfT1: the device uses it that far, not just to glibc's own 0.75); and the
+    two thresholds are where glibc's quadrant steps."""
     def bits(x):
         return int(np.float32(x).view(np.uint32))
-    lo, direct_end, pi_f = bits(2.0 ** -12), bits(0.75), bits(np.float32(np.pi))
+    lo, direct_end, pi_f = bits(2.0 ** -12), 0x3F490FDB, bits(np.float32(np.pi))     # direct_end = kSinfT1
     assert pi_f == 0x40490FDB and bits(np.float32(np.pi) * np.float32(0.5) * np.float32(2.0)) == pi_f   # the largest argument: 2 (pi_f * 0.5)
     n, first = oracle.sinf_fast_check(0, lo, direct_end - 1)
     assert n == 0, hex(first)
