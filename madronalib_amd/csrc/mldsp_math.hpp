@@ -208,7 +208,9 @@ MLD int32_t sse_cvtt(float x)
 }
 MLD int32_t sse_cvt(float x)
 {
-  const bool ok = (x < 2147483648.0f) && (x >= -2147483648.0f);
+  // in range <=> |x| < 2^31: ONE compare (the source modifier is free). x == -2^31 itself lands on the other side, where the
+  // answer is the same bits: cvtps2dq(-2^31) = 0x80000000 = the integer indefinite. NaN compares false: indefinite, as on x86.
+  const bool ok = __builtin_fabsf(x) < 2147483648.0f;
   const int32_t r = (int32_t)__builtin_rintf(ok ? x : 0.0f);  // v_rndne_f32 + v_cvt_i32_f32
   return ok ? r : INT32_MIN;
 }

@@ -119,24 +119,31 @@ MLD bool blep_freq_is_odd(float dt) { return (dt > 0.f) && !((dt >= 0x1p-64f) &&
 
 // The part of polyBLEP that depends on the frequency alone. With a launch-constant frequency all of it (and the
 // reciprocal inside div_nr) leaves the sample loop; PulseGen's two corrections of one sample share one.
+// The same question for a frequency that changes every sample (FAST = false), asked only where a correction is really evaluated:
+// "is the frequency outside [2^-64, 2^64]" as ONE unsigned range test of its bit pattern - no scalar mask logic, no divergent
+// short-circuit. It also answers yes for zero, negative and NaN frequencies, which blep_freq_is_odd leaves alone: such a lane is
+// never inside a zone itself (t < dt and t > 1 - dt are both false), it only sends the wavefronts it sits in to the reference's own
+// IEEE division - the same bits for every lane div_nr is exact for, a few instructions more.
+MLD bool blep_freq_not_regular(float dt) { return (f2u(dt) - 0x1F800000u) > (0x5F800000u - 0x1F800000u); }
+
 template <bool FAST>
 struct BlepFreq
 {
   float dt, omdt;
-  bool laneIsOdd;  // this lane's operands are outside div_nr's ranges (its frequency; for the op forms also its phase)
+  bool otherOdd;  // this lane's other operands (an op form's phase, a pulse's shifted phase) are outside div_nr's ranges
   static MLD BlepFreq make(float dt, bool otherwiseOdd = false)
   {
     BlepFreq f;
     f.dt = dt;
     f.omdt = 1.0f - dt;
-    f.laneIsOdd = (!FAST && blep_freq_is_odd(dt)) || otherwiseOdd;  // FAST vouches for the frequency, not for the caller's phase
+    f.otherOdd = otherwiseOdd;  // FAST vouches for the frequency, not for the caller's phase
     return f;
   }
   MLD bool lo(float t) const { return t < dt; }
   MLD bool hi(float t) const { return t > omdt; }  // only consulted when !lo (the reference's else-if)
   // wave-uniform: does any lane need the IEEE division? Asked only where a correction is really evaluated (after the
   // skip test), never on the quiet path
-  MLD bool anyLaneOdd() const { return __builtin_amdgcn_ballot_w64(laneIsOdd) != 0; }  // (a FAST caller with no phase of its own: constant false)
+  MLD bool anyLaneOdd() const { return __builtin_amdgcn_ballot_w64((!FAST && blep_freq_not_regular(dt)) || otherOdd) != 0; }  // (a FAST caller with no phase of its own: constant false)
   // the correction for a phase already known to be in the lower (isLo) or upper zone; garbage (never used) elsewhere
   MLD float correction(float t, bool isLo, bool full) const
   {

@@ -337,7 +337,7 @@ def test_patch_swap_with_async_compile(eng):
         if gc_was:
             gc.enable()
     assert ready_after is not None, "the compile did not finish in 20 000 blocks"
-    assert ml.jit_stats()["compiles"] == compiles0 + 1 and len(block_s) > 20, (ready_after, len(block_s))   # hiprtc really ran, for many blocks
+    assert ml.jit_stats()["compiles"] > compiles0 and len(block_s) > 20, (ready_after, len(block_s))   # hiprtc really ran (once or twice: the register budget), for many blocks
     assert max(block_s) < period, f"a block took {max(block_s) * 1e3:.2f} ms of a {period * 1e3:.2f} ms period while the new patch compiled"
     print(f"\npatch swap: cold compile ready after {ready_after:.2f} s = {len(block_s)} blocks of {period * 1e3:.2f} ms; slowest block {max(block_s) * 1e3:.3f} ms")
     # the new patch takes over; its twin compiled the ordinary way (a memory-cache hit now) gives the same bits
