@@ -336,7 +336,7 @@ def setup_workload(eng, name, V, T, lo, total):
                 dict(name="sum", type="op", kind=Op.ADD, inputs=["x", "fbg"]),
                 dict(name="line", type="proc", kind=Proc.FRACTIONAL_DELAY, inputs=["sum"], max_delay=1024.0),
                 dict(name="damp", type="proc", kind=Proc.ONE_POLE, inputs=["line"])]
-        g = ml.Graph(eng, V, desc, ["damp"], delay_windows=bool(os.environ.get("MLGPU_DELAY_WINDOWS")))
+        g = ml.Graph(eng, V, desc, ["damp"], delay_windows=int(os.environ.get("MLGPU_DELAY_WINDOWS", "0")))
         g.set_coeffs("damp", ml.OnePole.makeCoeffs(0.3))
         if os.environ.get("MLGPU_UNIFORM_DELAY"):
             length = np.full(V, 200.0)
@@ -369,7 +369,7 @@ def setup_workload(eng, name, V, T, lo, total):
         for j in range(4):
             sub, src = patches.allpass(f"ap{j}_", src, Proc.PITCHBENDABLE_DELAY, 4096.0 - 64.0, "dl")
             desc += sub
-        g = ml.Graph(eng, V, desc, [src], delay_windows=bool(os.environ.get("MLGPU_DELAY_WINDOWS")))
+        g = ml.Graph(eng, V, desc, [src], delay_windows=int(os.environ.get("MLGPU_DELAY_WINDOWS", "0")))
         for j in range(4):
             g.set_param(f"ap{j}_gain", 0.6)
         if os.environ.get("MLGPU_UNIFORM_DELAY"):

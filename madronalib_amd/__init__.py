@@ -982,8 +982,8 @@ class Graph:
         engine._children.add(self)
         if voices_per_lane:
             engine._check(self.L.mlgpu_graph_set_voices_per_lane(self.h, int(voices_per_lane)))
-        if delay_windows:
-            engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 1))
+        if delay_windows:   # True / 1: 32-byte sectors behind LDS windows; 2: transposed 64-byte pieces on a wave-uniform clock
+            engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 2 if delay_windows == 2 else 1))
         if autotune:
             engine._check(self.L.mlgpu_graph_set_autotune(self.h, 1))
         if live_constants:

@@ -476,6 +476,8 @@ struct mlgpu_graph
   std::vector<char> emitted;     // mlgpu_graph_emit: the gfx950 code object
   size_t memFloatsPerVoice{0};
   bool windowedRings{false};     // rings as [block][chunk][lane][8] behind LDS windows (mlgpu_graph_set_delay_layout)
+  bool fbAhead{true};            // kept DSPVectors (feedback nodes) are fetched two quads ahead; MLGPU_GRAPH_FB_AHEAD=0 for A / B
+  bool transposedRings{false};   // layout 2: [block][chunk][lane][16], every global access a 64-byte piece made by four lanes, on a wave-uniform clock (implies windowedRings)
   int totalRings{0};
   size_t memVoices() const { return windowedRings ? ((V + 255) & ~(size_t)255) : V; }  // voices the ring memory is laid out for
   std::vector<Region> regions;
@@ -764,7 +766,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   std::ostringstream s;
   auto sfx = [](int l) { return "_" + std::to_string(l); };
   s << "// generated by libmlgpu graph.hip (" << VL << " voice" << (VL > 1 ? "s" : "") << " per lane)\n"
-    << (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "") << (g->strictSvf ? "#define MLGPU_SVF_STRICT 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\n" << (g->hasEventRows ? "#include \"mldsp_events.hpp\"\n" : "") << "using namespace mldev;\n";
+    << (g->transposedRings ? "#define MLGPU_RING_WINDOWS 2\n" : (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "")) << (g->strictSvf ? "#define MLGPU_SVF_STRICT 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\n" << (g->hasEventRows ? "#include \"mldsp_events.hpp\"\n" : "") << "using namespace mldev;\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_VOP && g->nodes[i].kind == MLGPU_VOP_TABLE)
     {
@@ -773,7 +775,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << "};\n";
     }
   // windowed rings: the latency of a sector refill is hidden by other waves only, so keep at least two per SIMD
-  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->windowedRings && g->totalRings) ? ", 2" : (g->minWaves ? ", " + std::to_string(g->minWaves) : std::string())) << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n  apply_fp_mode(a.flags);\n";
+  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->transposedRings && g->totalRings == 1) ? ", 4" : (g->windowedRings && g->totalRings) ? ", 2" : (g->minWaves ? ", " + std::to_string(g->minWaves) : std::string())) << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n  apply_fp_mode(a.flags);\n";
   if (g->hasImpulse)
   {
     s << "  __shared__ float ldsTable[32];\n  if (threadIdx.x < 17) ldsTable[threadIdx.x] = a.impulseTable[threadIdx.x];\n  __syncthreads();\n";
@@ -783,7 +785,8 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   {
     s << "  const KernelTables tables{nullptr};\n";
   }
-  if (g->windowedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 8 * 256 << "];  // write windows, [ring][8][256 lanes]\n";
+  if (g->transposedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 4 << " * kTStrip];  // [ring][wavefront][40 rows][64]: write window + two read chunks\n";
+  else if (g->windowedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 8 * 256 << "];  // write windows, [ring][8][256 lanes]\n";
   // a group sum of 16 voices (one instrument's voices): four quads of the wavefront's 64 voices are parked in LDS and every lane
   // then adds up ONE (instrument, sample) pair in voice order - 2.3 instructions per voice-sample where the lane-shift chain
   // (group_sum_in_order) takes 16 (MLGPU_GRAPH_GROUP_SUM=dpp: that form)
@@ -818,7 +821,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         s << "  Proc<" << n.kind << "> p" << i << L << ";\n  const VoiceMem m" << i << L << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v" << L
           << ", a.state + (size_t)" << n.sOff << " * a.V + v" << L << ", a.V";
         if (n.ringLen && !g->windowedRings) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v" << L << ", " << (n.ringLen - 1) << "u";
-        if (n.ringLen && g->windowedRings)
+        if (n.ringLen && g->transposedRings)
+          s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (v" << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
+            << " + (v" << L << " & 255) * 16, " << (n.ringLen - 1)
+            << "u, ldsRings + (" << (size_t)n.ringSlot * 4 << " + (threadIdx.x >> 6)) * kTStrip + (threadIdx.x & 63)";
+        else if (n.ringLen && g->windowedRings)
           s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (v" << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
             << " + (v" << L << " & 255) * 8, " << (n.ringLen - 1)
             << "u, ldsRings + " << (size_t)n.ringSlot * 8 * 256 << " + threadIdx.x";
@@ -910,6 +917,15 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (int i = 0; PF && i < g->nInputs; ++i)
     for (int l = 0; l < VL; ++l)
       s << "  const f32x4* pf" << i << sfx(l) << " = in" << i << sfx(l) << ";\n  f32x4 nx" << i << sfx(l) << " = __builtin_nontemporal_load(pf" << i << sfx(l) << ");\n";
+  if (g->fbAhead)
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+      if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].region < 0)
+        for (int l = 0; l < VL; ++l)
+        {
+          const std::string nm = std::to_string(i) + sfx(l);
+          s << "  float fbn" << nm << "[4], fbm" << nm << "[4];\n#pragma unroll\n  for (int kk = 0; kk < 4; ++kk)\n  {\n    fbn" << nm << "[kk] = u2f(a.state[(size_t)(" << g->nodes[i].sOff
+            << " + kk) * a.V + v" << sfx(l) << "]);\n    fbm" << nm << "[kk] = u2f(a.state[(size_t)(" << g->nodes[i].sOff << " + 4 + kk) * a.V + v" << sfx(l) << "]);\n  }\n";
+        }
   if (g->takeTurns) s << "  const uint32_t turn0 = wave_slot();\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
   // (Rounds 3-4 walked the event records inside this kernel - 134 spilled registers, 0.35 scalar / branch instructions per vector
@@ -1006,14 +1022,22 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   if (g->hasEventRows)
     for (int l = 0; l < VL; ++l)
       s << "      mlev::CtlVoice::f32x4e evP" << sfx(l) << ", evG" << sfx(l) << ";\n      ev" << sfx(l) << ".quad(t, q, evP" << sfx(l) << ", evG" << sfx(l) << ");\n";
-  // A kept DSPVector's slot n is read and rewritten at sample n only: fetch the quad's four slots together, ahead of the
-  // stores of the sample loop (one load per sample between those stores costs a memory round trip per sample).
+  // A kept DSPVector's slot n is read and rewritten at sample n only: the quad's four slots are fetched together - and TWO QUADS
+  // AHEAD (round 5; they were written 14 quads ago). Fetched at the top of the quad that uses them, every quad of a feedback graph
+  // stood still for a memory round trip, behind the stores of the quad before (memory operations of a wavefront complete in issue
+  // order): 256 round trips per launch of 16 DSPVectors were the whole launch time of the plucked-string bank, whatever the ring
+  // layout. MLGPU_GRAPH_FB_AHEAD=0: the round-4 form (A / B).
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].region < 0)
       for (int l = 0; l < VL; ++l)
       {
-        s << "      float fbv" << i << sfx(l) << "[4];\n#pragma unroll\n      for (int kk = 0; kk < 4; ++kk) fbv" << i << sfx(l) << "[kk] = u2f(a.state[(size_t)("
-          << g->nodes[i].sOff << " + q * 4 + kk) * a.V + v" << sfx(l) << "]);\n";
+        const std::string nm = std::to_string(i) + sfx(l);
+        if (!g->fbAhead)
+          s << "      float fbv" << nm << "[4];\n#pragma unroll\n      for (int kk = 0; kk < 4; ++kk) fbv" << nm << "[kk] = u2f(a.state[(size_t)("
+            << g->nodes[i].sOff << " + q * 4 + kk) * a.V + v" << sfx(l) << "]);\n";
+        else
+          s << "      float fbv" << nm << "[4];\n#pragma unroll\n      for (int kk = 0; kk < 4; ++kk)\n      {\n        fbv" << nm << "[kk] = fbn" << nm << "[kk];\n        fbn" << nm
+            << "[kk] = fbm" << nm << "[kk];\n        fbm" << nm << "[kk] = u2f(a.state[(size_t)(" << g->nodes[i].sOff << " + ((q + 2) & 15) * 4 + kk) * a.V + v" << sfx(l) << "]);\n      }\n";
       }
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC && (g->nodes[i].kind == MLGPU_PROC_LINEAR_GLIDE || g->nodes[i].kind == MLGPU_PROC_HALF_BAND_BUFFERED))
@@ -1080,12 +1104,12 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
               const std::string freq = "n" + std::to_string(sn.in[0]) + sfx(l);
               const std::string width = pn.in.size() == 2 ? "n" + std::to_string(pn.in[1]) + sfx(l) : "p" + std::to_string(pj) + sfx(l) + ".width";
               s << c.indent << "float sl" << si << "s" << sfx(l) << ", sl" << si << "p" << sfx(l) << ";\n";
-              s << c.indent << "if (slocked" << si << ")\n" << c.indent << "{\n";
-              s << c.indent << "  if (oddw" << pj << ") step_locked_stream<false>(p" << si << sfx(l) << ", p" << pj << sfx(l) << ", " << freq << ", " << width << ", sl" << si << "s" << sfx(l)
+              // (the usual case - counters equal, widths regular - behind ONE wave-uniform test per sample)
+              s << c.indent << "if (slocked" << si << " && !oddw" << pj << ") step_locked_stream<true>(p" << si << sfx(l) << ", p" << pj << sfx(l) << ", " << freq << ", " << width << ", sl" << si
+                << "s" << sfx(l) << ", sl" << si << "p" << sfx(l) << ");\n";
+              s << c.indent << "else if (slocked" << si << ") step_locked_stream<false>(p" << si << sfx(l) << ", p" << pj << sfx(l) << ", " << freq << ", " << width << ", sl" << si << "s" << sfx(l)
                 << ", sl" << si << "p" << sfx(l) << ");\n";
-              s << c.indent << "  else step_locked_stream<true>(p" << si << sfx(l) << ", p" << pj << sfx(l) << ", " << freq << ", " << width << ", sl" << si << "s" << sfx(l) << ", sl" << si
-                << "p" << sfx(l) << ");\n";
-              s << c.indent << "}\n" << c.indent << "else\n" << c.indent << "{\n";
+              s << c.indent << "else\n" << c.indent << "{\n";
               s << c.indent << "  sl" << si << "s" << sfx(l) << " = p" << si << sfx(l) << ".next(" << freq << ");\n";
               s << c.indent << "  sl" << si << "p" << sfx(l) << " = p" << pj << sfx(l) << ".next_sw(" << freq << (pn.in.size() == 2 ? ", " + width : std::string()) << ", oddw" << pj << ");\n";
               s << c.indent << "}\n";
@@ -1898,7 +1922,9 @@ extern "C"
       memFloats += n.ringLen * (size_t)mlgpu_proc_rings(n.kind);
     }
     g->memFloatsPerVoice = memFloats;
-    if (g->windowedRings && (size_t)g->totalRings * 8 * 256 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
+    if (g->transposedRings && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 needs 40 KiB of LDS per ring; at most 4 rings per graph (layout 1 for more)");
+    if (!g->transposedRings && g->windowedRings && (size_t)g->totalRings * 8 * 256 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: windowed delay layout needs 8 KiB of LDS per ring; at most 20 rings per graph");
     const char* forced = getenv("MLGPU_GRAPH_UNROLL");  // developer knob: quads per trip of the sample loop
     // delay graphs wait on their ring reads: two quads per trip keep more of them in flight (allpass4: 5.4 vs 4.5 x 10^10)
@@ -1908,6 +1934,7 @@ extern "C"
     if (const char* tc = getenv("MLGPU_GRAPH_TURN_CLOCK")) g->turnClockShift = std::min(24, std::max(0, atoi(tc)));
     if (const char* lk = getenv("MLGPU_GRAPH_LOCK_OSC")) g->lockOscillators = atoi(lk) != 0;
     if (const char* pf = getenv("MLGPU_GRAPH_PREFETCH")) g->prefetchQ = atoi(pf) != 0;  // developer knob (A / B)
+    if (const char* fa = getenv("MLGPU_GRAPH_FB_AHEAD")) g->fbAhead = atoi(fa) != 0;
     if (const char* trip = getenv("MLGPU_GRAPH_OSC_TRIP"))  // developer knob: 0 = polyBLEP per sample (A / B), else 1, 2 or 4 quads per trip
     {
       const int t = atoi(trip);
@@ -2171,7 +2198,10 @@ extern "C"
     if (!g) return MLGPU_ERR_INVALID;
     if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (windowed < 0 || windowed > 2) return gfail(g, MLGPU_ERR_INVALID, "graph_set_delay_layout: 0 (rows), 1 (32-byte sectors) or 2 (transposed 64-byte pieces)");
+    if (windowed == 2 && (g->V % 64)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_set_delay_layout(2): whole wavefronts only (a number of voices that is a multiple of 64)");
     g->windowedRings = windowed != 0;
+    g->transposedRings = windowed == 2;
     return MLGPU_OK;
   }
 

@@ -469,20 +469,30 @@ struct CtlVoice
         if (gateRow) oGate = __builtin_nontemporal_load((const f32x4e*)d.rowG + at);
       }
     }
+    // (the rare questions are asked once per quad, not once per sample: a wave-uniform branch is a scalar compare, a branch and a
+    // possible fetch stall, and scalar issue is not hidden on this chip)
     float c[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k) c[k] = prev[k] + gd.step;  // a continuing glide: mCurrVec[n] += step (LinearGlide, MLDSPGens.h:497-505)
+    if (anyRamp)  // a glide's first vector ramps from its start value (:481-495); once per 8-16 s and voice
     {
-      c[k] = prev[k] + gd.step;  // a continuing glide: mCurrVec[n] += step (LinearGlide, MLDSPGens.h:497-505)
-      if (anyRamp)               // a glide's first vector ramps from its start value (:481-495); once per 8-16 s and voice
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
       {
         const float r = gd.startValue + ((float)(4 * q + k + 1) * 0.015625f) * gd.step;
         c[k] = ramp ? r : c[k];
       }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
       const float driftSig = moving ? c[k] : prev[k];
-      float p = Pq[k] + (driftSig * d.s.driftAmount) * 0.02f;  // kDriftScale, :247
-      if (anyOff) p = on ? p : 0.f;
-      oPitch[k] = p;
+      oPitch[k] = Pq[k] + (driftSig * d.s.driftAmount) * 0.02f;  // kDriftScale, :247
+    }
+    if (anyOff)  // voices of instruments that have not seen an event yet: processVector is a no-op, the rows are zero (:383-386)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) oPitch[k] = on ? oPitch[k] : 0.f;
     }
     if (moving)
     {

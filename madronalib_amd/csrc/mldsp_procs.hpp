@@ -1242,6 +1242,22 @@ constexpr int kRingLdsLanes = 256;   // lanes per workgroup of a graph kernel
 #define MLGPU_RING_WINDOWS 0
 #endif
 constexpr bool kRingWindows = MLGPU_RING_WINDOWS != 0;  // fixed per generated kernel, so the unused form costs nothing
+// Layout 2 (round 5, "transposed windows"): the ring of a 256-voice block as [chunk = sample / 16][lane][16], every global access
+// a whole 64-byte piece per voice and made by FOUR NEIGHBOURING LANES (16 bytes each) - a wavefront's memory instruction then
+// covers 16 voices' pieces, 8 full cache lines when the voices read the same chunk, and no lane ever moves a byte it does not use.
+// All of it on a wave-uniform clock: every 16 samples (the write index is the same in every lane of a wavefront - where it is not,
+// the launch falls back to plain per-sample accesses) the write window is stored, the chunk each voice asked for 16 samples ago goes
+// from the loaders' registers into that voice's read window, and the chunk it will need 16 samples from now is requested - a whole
+// period ahead of its first use, so no sample waits for memory (layout 1 refilled lane by lane whenever a lane crossed a sector:
+// a divergent load and a memory round trip on almost every sample of a wavefront whose voices have different delay times, and its
+// read window was eight registers behind a seven-select chain). Windows live in LDS, one strip per wavefront and ring:
+// rows 0..7 the eight samples being written (stored as 32-byte halves of a piece), rows 8..39 two chunks being read, 64 floats per
+// row (lane = column: an access with the lane as the fast index touches every bank twice, whatever the row). 10 KiB per wavefront:
+// a CU holds its sixteen wavefronts of a 262 144-voice bank at once (with 12.5 KiB - a 16-sample write window - three of four
+// workgroups fit and the fourth runs alone afterwards: twice the launch time, measured).
+constexpr bool kRingTransposed = MLGPU_RING_WINDOWS == 2;
+constexpr int kTChunk = 16, kTWrite = 8, kTRowPad = 64, kTRows = kTWrite + 2 * kTChunk, kTStrip = kTRows * kTRowPad;
+constexpr uint32_t kTNone = 0xFFFFFFFFu;
 
 struct RingCore  // IntegerDelay's buffer, index and mask
 {
@@ -1266,6 +1282,11 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   MLD void begin(const VoiceMem& m, int ringIdx)  // launch start: the chunk being written comes back into its window
   {
     rChunk = 0xFFFFFFFFu;
+    if (kRingTransposed)
+    {
+      beginT(m, ringIdx);
+      return;
+    }
     if (!kRingWindows) return;
     const f32x4r* src = (const f32x4r*)chunkMem(m, ringIdx, w);
     float* wb = wbuf(m, ringIdx);
@@ -1284,7 +1305,11 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   }
   MLD void end(const VoiceMem& m, int ringIdx) const  // launch end: the partly filled write window goes back to memory
   {
-    if (kRingWindows) flush(m, ringIdx, w & ~(uint32_t)(kRingWindow - 1));
+    if (kRingTransposed)
+    {
+      if (uniformW) flushT(m, ringIdx, w & ~(uint32_t)(kTWrite - 1));
+    }
+    else if (kRingWindows) flush(m, ringIdx, w & ~(uint32_t)(kRingWindow - 1));
   }
   MLD float sampleWindowed(const VoiceMem& m, int ringIdx, float x, int32_t d)
   {
@@ -1327,8 +1352,186 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     return y;
   }
 
+  // ---- layout 2: transposed windows (see the constants above) ----
+  uint32_t tag0, tag1;  // the chunks (ring position >> 4) the two read slots hold, kTNone: nothing
+  uint32_t pend;        // the chunk this lane asked for at the last boundary: in flight in its four loader lanes' registers
+  f32x4r stage[4];      // pieces this lane loaded for OTHER lanes: stage[m] = piece (lane & 3) of lane (m * 16 + lane / 4)'s pending chunk
+  bool uniformW, primed;
+  MLD float* strip(const VoiceMem& m, int ringIdx) const { return m.lds + (size_t)ringIdx * 4 * kTStrip; }  // this lane's column of row 0
+  // lane `other`'s chunk at ring position i of ring ringIdx (m.mem is THIS lane's 16-float piece of chunk 0 of the node's first ring)
+  MLD float* chunkOf(const VoiceMem& m, int ringIdx, uint32_t other, uint32_t i) const
+  {
+    const int32_t rel = (int32_t)other - (int32_t)(threadIdx.x & 63u);
+    return m.mem + (ptrdiff_t)rel * kTChunk + ((size_t)ringIdx * (m.memMask + 1) + (size_t)(i & ~(uint32_t)(kTChunk - 1))) * kRingLdsLanes;
+  }
+  MLD void beginT(const VoiceMem& m, int ringIdx)
+  {
+    tag0 = tag1 = pend = kTNone;
+    primed = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage[i] = f32x4r{0.f, 0.f, 0.f, 0.f};
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    uniformW = __builtin_amdgcn_ballot_w64(w != w0) == 0;
+    if (!uniformW) return;
+    // the eight samples being written come back into the write window (all eight positions: end() stores them all)
+    const f32x4r* src = (const f32x4r*)(chunkOf(m, ringIdx, threadIdx.x & 63u, w) + (w & (uint32_t)kTWrite));
+    float* col = strip(m, ringIdx);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+    {
+      const f32x4r a = src[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) col[(4 * j + e) * kTRowPad] = a[e];
+    }
+  }
+  // the write window to memory, transposed: instruction mm stores 16 bytes (lane & 1) of lane (mm * 32 + lane / 2)'s 32-byte half
+  // piece; halfStart = the ring position of the window's first sample (a multiple of 8)
+  MLD void flushT(const VoiceMem& m, int ringIdx, uint32_t halfStart) const
+  {
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 1u;
+    const float* row0 = strip(m, ringIdx) - lane;  // column 0 of row 0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+    {
+      const uint32_t other = (uint32_t)mm * 32u + (lane >> 1);
+      const float* src = row0 + (4 * j) * kTRowPad + other;
+      const f32x4r a = {src[0], src[kTRowPad], src[2 * kTRowPad], src[3 * kTRowPad]};
+      *((f32x4r*)(chunkOf(m, ringIdx, other, halfStart) + (halfStart & (uint32_t)kTWrite)) + j) = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // one round of transposed loads: every lane names a chunk (kTNone: none); the pieces land in `out` of the four loader lanes.
+  // UNCONDITIONAL loads (a lane that names no chunk gets the piece at `spare`, a ring position whose chunk is complete in memory,
+  // and nobody uses it): a load under a condition into registers that may still await an earlier load makes the compiler wait for
+  // every memory operation in flight before it - a memory round trip per load instead of none.
+  MLD void loadRound(const VoiceMem& m, int ringIdx, uint32_t want, uint32_t spare, f32x4r (&out)[4]) const
+  {
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 3u;
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm)
+    {
+      const uint32_t other = (uint32_t)mm * 16u + (lane >> 2);
+      const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(other * 4u), (int)want);
+      out[mm] = *((const f32x4r*)chunkOf(m, ringIdx, other, (q != kTNone ? q : spare) * (uint32_t)kTChunk) + j);
+    }
+  }
+  // ... and into the owners' read windows: chunk q goes to slot q & 1 (rows 16 + 16 (q & 1) ...)
+  MLD void storeRound(const VoiceMem& m, int ringIdx, uint32_t want, const f32x4r (&in)[4]) const
+  {
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 3u;
+    float* row0 = strip(m, ringIdx) - lane;
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm)
+    {
+      const uint32_t other = (uint32_t)mm * 16u + (lane >> 2);
+      const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(other * 4u), (int)want);
+      if (q != kTNone)
+      {
+        float* dst = row0 + (kTWrite + kTChunk * (q & 1u) + 4 * j) * kTRowPad + other;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e * kTRowPad] = in[mm][e];
+      }
+    }
+  }
+  MLD void setTag(uint32_t q)
+  {
+    if (q == kTNone) return;
+    if (q & 1u) tag1 = q;
+    else tag0 = q;
+  }
+  // every 16 samples, all lanes together (w is the same in all of them and a multiple of 16, or this is the launch's first sample)
+  MLD void boundaryT(const VoiceMem& m, int ringIdx, int32_t d)
+  {
+    const uint32_t cmask = ((m.memMask + 1) >> 4) - 1u, wc = w >> 4;
+    const uint32_t c = ((w - (uint32_t)d) & m.memMask) >> 4;
+    const uint32_t age = (wc - c) & cmask;  // how many chunks behind the writer this lane reads (0: inside the write window)
+    // (no cache maintenance: a voice's ring is written and read by one wavefront only, and a CU's vector cache is coherent for its
+    // own wavefronts' stores - an acquire fence here would also wait for every store and load in flight, a memory round trip per
+    // 16 samples: measured 2 x the launch time)
+    // a slot whose chunk the writer has come round to holds a ring cycle's old samples from now on
+    if (tag0 == wc) tag0 = kTNone;
+    if (tag1 == wc) tag1 = kTNone;
+    // what was asked for at the last boundary goes into its slot - unless that slot still holds a chunk the coming 16 samples
+    // read (the read position moved by less than a chunk: the launch's first boundary came mid-chunk, a delay time grew): then it
+    // waits in the loaders' registers for another period
+    const uint32_t c1 = (c + 1u) & cmask;
+    const uint32_t there = (pend & 1u) ? tag1 : tag0;
+    const uint32_t commit = (pend != kTNone && there != c && there != c1) ? pend : kTNone;
+    if (__builtin_amdgcn_ballot_w64(commit != kTNone) != 0)
+    {
+      storeRound(m, ringIdx, commit, stage);
+      setTag(commit);
+      if (commit != kTNone) pend = kTNone;
+    }
+    if (!primed)
+    {
+      // the launch's first sample: the two chunks the coming 16 samples read, those of them that are complete in memory
+      primed = true;
+      f32x4r tmp[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const uint32_t q0 = (age >= 1u) ? c : kTNone, q1 = (age >= 2u) ? c1 : kTNone;
+      if (__builtin_amdgcn_ballot_w64(q0 != kTNone) != 0)
+      {
+        loadRound(m, ringIdx, q0, (wc - 2u) & cmask, tmp);
+        storeRound(m, ringIdx, q0, tmp);
+        setTag(q0);
+      }
+      if (__builtin_amdgcn_ballot_w64(q1 != kTNone) != 0)
+      {
+        loadRound(m, ringIdx, q1, (wc - 2u) & cmask, tmp);
+        storeRound(m, ringIdx, q1, tmp);
+        setTag(q1);
+      }
+    }
+    // the chunk after those: asked for now, used from the next boundary on - if the writer is done with it (two or more behind)
+    // and nothing of this lane's is still waiting in the loaders' registers
+    const uint32_t ask = (pend == kTNone && age >= 3u) ? ((c + 2u) & cmask) : kTNone;
+    // (a lane whose request still waits keeps its staged pieces: the round is skipped for the whole wavefront then - a delay time
+    // that jumped, rare - and asked again at the next boundary)
+    const bool allFree = __builtin_amdgcn_ballot_w64(pend != kTNone) == 0;
+    if (allFree && __builtin_amdgcn_ballot_w64(ask != kTNone) != 0)
+    {
+      loadRound(m, ringIdx, ask, (wc - 2u) & cmask, stage);
+      pend = ask;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  MLD float sampleT(const VoiceMem& m, int ringIdx, float x, int32_t d)
+  {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (!uniformW)
+    {
+      // voices of one wavefront with different write indices (a host set them so): every sample straight to and from memory
+      float* own = chunkOf(m, ringIdx, lane, w) + (w & (kTChunk - 1));
+      __hip_atomic_store(own, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t r = (w - (uint32_t)d) & m.memMask;
+      const float y = __hip_atomic_load(chunkOf(m, ringIdx, lane, r) + (r & (kTChunk - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w = (w + 1) & m.memMask;
+      return y;
+    }
+    float* col = strip(m, ringIdx);
+    col[(w & (kTWrite - 1)) * kTRowPad] = x;
+    if (!primed || (w & (kTChunk - 1)) == 0) boundaryT(m, ringIdx, d);
+    const uint32_t r = (w - (uint32_t)d) & m.memMask, rc = r >> 4;
+    const bool inW = (r >> 3) == (w >> 3), inR = rc == ((rc & 1u) ? tag1 : tag0);
+    const uint32_t row = inW ? (r & (kTWrite - 1)) : (uint32_t)kTWrite + ((rc & 1u) << 4) + (r & (kTChunk - 1));
+    float y = col[row * kTRowPad];
+    if (__builtin_amdgcn_ballot_w64(!(inW || inR)) != 0)
+    {
+      // a sample no window holds (a delay of 8 to 47 samples: its chunk is too close behind the writer to be fetched a period
+      // ahead; a delay time that jumped): from memory, complete there since the flush that ended its eight samples
+      if (!(inW || inR)) y = __hip_atomic_load(chunkOf(m, ringIdx, lane, r) + (r & (kTChunk - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if ((w & (kTWrite - 1)) == kTWrite - 1) flushT(m, ringIdx, w & ~(uint32_t)(kTWrite - 1));
+    w = (w + 1) & m.memMask;
+    return y;
+  }
+
   MLD float sample(const VoiceMem& m, int ringIdx, float x, int32_t d)
   {
+    if (kRingTransposed) return sampleT(m, ringIdx, x, d);
     if (kRingWindows) return sampleWindowed(m, ringIdx, x, d);
     const uint32_t ringBase = (uint32_t)ringIdx * (m.memMask + 1);
     m.ringSet(ringBase + w, x);

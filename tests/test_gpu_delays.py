@@ -22,7 +22,13 @@ def eng():
     e.close()
 
 
-WINDOWS = [pytest.param(False, id="rows"), pytest.param(True, id="windows")]  # mlgpu_graph_set_delay_layout 0 / 1
+# mlgpu_graph_set_delay_layout 0 / 1 / 2 (layout 2 - transposed 64-byte pieces on a wave-uniform clock - wants whole wavefronts: the
+# tests below round their voice counts up to a multiple of 64 for it)
+WINDOWS = [pytest.param(False, id="rows"), pytest.param(True, id="windows"), pytest.param(2, id="transposed")]
+
+
+def _voices(V, windows):
+    return (V + 63) // 64 * 64 if windows == 2 else V
 
 
 def delay_graph(eng, V, kind, n_inputs, max_delay, windows=False):
@@ -60,13 +66,23 @@ def test_delay_lines_vs_oracle_and_golden(eng, oracle, name, windows):
     while f"{name}_in{len(ins)}" in GOLD.files:
         ins.append(GOLD[f"{name}_in{len(ins)}"])
     V, T = ins[0].shape[0], ins[0].shape[1] // 128
-    g, names = delay_graph(eng, V, kind, len(ins), max_delay, windows)
-    outs, states = run_delay(g, names, GOLD[name + "_state0"], ins, T, Layout.VOICE_MAJOR)
-    for call in range(2):
-        assert_bits_equal(outs[call], GOLD[f"{name}_out{call + 1}"], True, f"{name} golden out{call + 1}")
-        assert_bits_equal(states[call], GOLD[f"{name}_state{call + 1}"], False, f"{name} golden state{call + 1}")
+    if windows != 2 or V % 64 == 0:
+        g, names = delay_graph(eng, V, kind, len(ins), max_delay, windows)
+        outs, states = run_delay(g, names, GOLD[name + "_state0"], ins, T, Layout.VOICE_MAJOR)
+        for call in range(2):
+            assert_bits_equal(outs[call], GOLD[f"{name}_out{call + 1}"], True, f"{name} golden out{call + 1}")
+            assert_bits_equal(states[call], GOLD[f"{name}_state{call + 1}"], False, f"{name} golden state{call + 1}")
+    else:
+        # the golden case (a handful of voices) in the first lanes of a whole wavefront
+        Vp = _voices(V, windows)
+        pad = lambda a: np.concatenate([a, np.repeat(a[-1:], Vp - V, 0)], 0)
+        g, names = delay_graph(eng, Vp, kind, len(ins), max_delay, windows)
+        outs, states = run_delay(g, names, np.concatenate([GOLD[name + "_state0"], np.repeat(GOLD[name + "_state0"][:, -1:], Vp - V, 1)], 1), [pad(a) for a in ins], T, Layout.VOICE_MAJOR)
+        for call in range(2):
+            assert_bits_equal(outs[call][:V], GOLD[f"{name}_out{call + 1}"], True, f"{name} golden out{call + 1}")
+            assert_bits_equal(states[call][:, :V], GOLD[f"{name}_state{call + 1}"], False, f"{name} golden state{call + 1}")
     # oracle, more voices
-    V, T = 300, 9
+    V, T = _voices(300, windows), 9
     c = delay_case(oracle, name, V, 2 * T, seed=8)
     g, names = delay_graph(eng, V, c["kind"], len(c["inputs"]), c["max_delay"], windows)
     outs, states = run_delay(g, names, c["state0"], c["inputs"], T, Layout.QUAD)
@@ -117,7 +133,7 @@ def _composite(eng, oracle, desc, outs, V, T, sig, params, coeffs, state_edit, w
 @pytest.mark.parametrize("windows", WINDOWS)
 @pytest.mark.parametrize("which,kind,d", [(0, Proc.INTEGER_DELAY, 101.0), (1, Proc.FRACTIONAL_DELAY, 77.37), (2, Proc.PITCHBENDABLE_DELAY, 0.0)])
 def test_allpass_composites(eng, oracle, which, kind, d, windows):
-    V, T = 70, 30
+    V, T = _voices(70, windows), 30
     x = np.repeat(GOLD["comp_x"][None, :], V, 0).copy()
     x[1:] = lcg_noise(np.arange(V - 1, dtype=np.uint32) + 40, 64 * T)
     dsig = np.repeat(GOLD["comp_dsig"][None, :], V, 0).copy()
@@ -131,7 +147,7 @@ def test_allpass_composites(eng, oracle, which, kind, d, windows):
     def edit(st):
         if which == 0:
             st["ap_delay"][1] = np.uint32(int(d - 64))
-            st["ap_delay"][1, 1:] = np.arange(V - 1, dtype=np.uint32) * 4
+            st["ap_delay"][1, 1:] = (np.arange(V - 1, dtype=np.uint32) * 4) % 300      # (inside the ring's valid range, 0 .. length - 64)
         if which == 1:
             st["ap_delay"][3:5, :] = oracle.fractional_delay_state(float(np.float32(d) - np.float32(64.0))).view(np.uint32)[:, None]
     sig = {"x": x, "dl": dsig} if which == 2 else {"x": x}
@@ -142,7 +158,7 @@ def test_allpass_composites(eng, oracle, which, kind, d, windows):
 @pytest.mark.gpu
 @pytest.mark.parametrize("windows", WINDOWS)
 def test_fdn_composite(eng, oracle, windows):
-    V, T = 50, 30
+    V, T = _voices(50, windows), 30
     x = np.repeat((GOLD["comp_x"] * np.float32(0.1))[None, :], V, 0).copy()
     x[1:] = lcg_noise(np.arange(V - 1, dtype=np.uint32) + 77, 64 * T) * np.float32(0.1)
     times, omegas, gains = [133.0, 201.0, 307.0, 419.0], [0.2, 0.15, 0.1, 0.05], [0.8, 0.75, 0.7, 0.65]
@@ -164,7 +180,7 @@ def test_fdn_composite(eng, oracle, windows):
 @pytest.mark.gpu
 @pytest.mark.parametrize("windows", WINDOWS)
 def test_feedback_delay_function(eng, oracle, windows):
-    V, T = 40, 30
+    V, T = _voices(40, windows), 30
     x = np.repeat(GOLD["comp_x"][None, :], V, 0).copy()
     dsig = np.repeat((GOLD["comp_dsig"] + np.float32(150.0))[None, :], V, 0).copy()
     dsig[1:] += np.linspace(0, 300, V - 1, dtype=np.float32)[:, None]
@@ -206,6 +222,17 @@ def test_delay_rules(eng):
     with pytest.raises(ml.MlgpuError) as ei:
         g.compile()
     assert ei.value.status == ml.Status.ERR_UNSUPPORTED
+    g = ml.Graph(eng, 64, delay_windows=2)                       # layout 2: 40 KiB of LDS per ring, four rings at most
+    a = g.add("a", "input")
+    for i in range(5):
+        g.add(f"d{i}", "proc", Proc.INTEGER_DELAY, [a], max_delay=100.0)
+    g.add_output("d4")
+    with pytest.raises(ml.MlgpuError) as ei:
+        g.compile()
+    assert ei.value.status == ml.Status.ERR_UNSUPPORTED
+    with pytest.raises(ml.MlgpuError) as ei:
+        ml.Graph(eng, 100, delay_windows=2)                      # ... and whole wavefronts only
+    assert ei.value.status == ml.Status.ERR_UNSUPPORTED
     g3 = ml.Graph(eng, 1000, delay_windows=False)
     a = g3.add("a", "input")
     g3.add("d", "proc", Proc.PITCHBENDABLE_DELAY, [a, a], max_delay=1000.0)
@@ -214,3 +241,50 @@ def test_delay_rules(eng):
     assert g3.device_bytes == 4 * 1000 * (1 + (10 + 1) + 1 + 2 * 2048)     # coefficient, state and constant slots (+1 spare each), two rings of 2048
     bank = eng.bank([Proc.ALLPASS1], 64)                         # Allpass1 has no ring: fine in a bank
     assert bank.num_coeffs(0) == 1 and bank.num_state(0) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("unequal_w", [False, True])
+def test_transposed_rings_every_kind_of_lane(eng, oracle, unequal_w):
+    """Layout 2 on the bench's plucked-string voice (noise burst -> FractionalDelay of per-voice length -> OnePole -> one-vector
+    feedback), 256 voices whose delay times cover every path of the transposed windows: under 8 samples (served from the write
+    window), 8-47 (memory, sample by sample: too close behind the writer to fetch a period ahead), and up to the ring's maximum
+    (the prefetched read windows), several launches with carried state; and the same with the write indices of one wavefront set
+    apart by the host (that wavefront then runs its plain per-sample form). Against the streaming oracle and against layout 0."""
+    import madronalib_amd as ml
+    V, T, launches = 256, 6, 3
+    desc = [dict(name="x", type="input"), dict(name="g", type="const", value=0.995),
+            dict(name="fb", type="feedback", source="damp"),
+            dict(name="fbg", type="op", kind=Op.MULTIPLY, inputs=["fb", "g"]),
+            dict(name="sum", type="op", kind=Op.ADD, inputs=["x", "fbg"]),
+            dict(name="line", type="proc", kind=Proc.FRACTIONAL_DELAY, inputs=["sum"], max_delay=1024.0),
+            dict(name="damp", type="proc", kind=Proc.ONE_POLE, inputs=["line"])]
+    rng = np.random.default_rng(5)
+    length = np.concatenate([np.linspace(1.3, 15.7, 40), np.linspace(16.2, 47.9, 40), np.linspace(48.1, 959.0, 112), rng.uniform(1.0, 959.0, 64)]).astype(np.float32)
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 9, 64 * T * launches)
+    x[:, 640:] = 0
+    co = oracle.make_coeffs("onepole", 0.3)
+    outs = {}
+    for layout in (0, 2):
+        g = ml.Graph(eng, V, desc, ["damp"], delay_windows=layout)
+        g.set_coeffs("damp", [np.full(V, c, np.float32) for c in co])
+        st = new_stream_state(oracle, desc, V)
+        fs = np.stack([oracle.fractional_delay_state(float(d)) for d in length], 1)     # [2][V]: delayInt bits, allpass coefficient
+        st["line"][3] = fs[0].view(np.uint32)
+        st["line"][4] = fs[1].view(np.uint32)
+        if unequal_w:
+            st["line"][0, 64:128] = (np.arange(64, dtype=np.uint32) * 7) % 1024          # the second wavefront: write indices all over the ring
+        for i in range(st["line"].shape[0]):
+            g.set_state("line", i, st["line"][i])
+        got, want = [], []
+        for k in range(launches):
+            part = {"x": np.ascontiguousarray(x[:, k * 64 * T:(k + 1) * 64 * T])}
+            got.append(g.process_host(T, part, Layout.QUAD)[0])
+            want.append(evaluate_stream(oracle, desc, ["damp"], V, T, part, {}, {"damp": np.repeat(np.asarray(co, np.float32).reshape(-1, 1), V, 1)}, st)[0])
+        outs[layout] = np.concatenate(got, 1)
+        assert_bits_equal(outs[layout], np.concatenate(want, 1), True, f"plucked strings, delay layout {layout}")
+        for i in range(st["line"].shape[0]):
+            assert (g.get_state("line", i) == st["line"][i]).all(), (layout, i)
+        g.close()
+    assert_bits_equal(outs[2], outs[0], True, "layout 2 vs layout 0")
+    assert np.abs(outs[0]).max() > 0.01
