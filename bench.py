@@ -50,8 +50,12 @@ WORKLOADS = {
     # widened rows, measured to the same bar; not BASELINE configs
     "events": (262144, 16, 8),  # EventsToSignals: 16384 instruments x 16 voices, 8 control rows out
     "resample": (262144, 32, 8),  # Downsampler, 2 octaves: 32 vectors in -> 8 out per launch
-    "synth": (262144, 16, 8),    # events -> synth16 voices (pitch and gate rows streamed) -> per-instrument voice sum
-    "synthfused": (262144, 16, 8),  # the same with pitch and gate computed inside the voice kernel (event rows as source nodes)
+    # the instrument bank end to end (16 384 instruments x 16 voices): note events -> EventsToSignals -> synth16 voices -> per-instrument sum.
+    # "synth": the form a host should use (round 5) - the events' control-rate half as a light kernel (16-byte control records), the voice
+    # kernel expanding them and adding up each instrument's voices; "synthrows": the three-kernel form (e2s_kernel writes pitch and gate
+    # rows, the voice graph reads them, mlgpu_mixdown_groups adds up the voices; MLGPU_BENCH_MIXDOWN=graph: the sum inside the voice kernel)
+    "synth": (262144, 16, 8),
+    "synthrows": (262144, 16, 8),
     "strings": (262144, 16, 8),  # a plucked-string model per voice: noise burst -> FractionalDelay (per-voice length) -> OnePole -> feedback
     "mixgroups": (262144, 8, 16),  # the per-instrument voice sum alone, 16 voices per instrument
     "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
@@ -199,8 +203,8 @@ def setup_workload(eng, name, V, T, lo, total):
         alg = 4.0 * len(rows) * n + V * T * 4.0 * 5 * glides * 2 + V * 4.0 * 23 * 2
         return launch, alg, "e2s_kernel", (f"EventsToSignals: 16384 instruments x 16 voices, {len(rows)} control signals out, sparse note events "
                                            "(host routing + record upload inside the step)"), ev
-    if name in ("synth", "synthfused"):
-        fusedRows = name == "synthfused"
+    if name in ("synth", "synthrows"):
+        fusedRows = name == "synth"
         # A bank of polyphonic instruments end to end, as ml::gpu::SynthProgram runs a Synth subclass: EventsToSignals (only the
         # rows the voice reads) -> the fused voice graph -> the per-instrument voice sum (Synth::processVector, MLSynth.h:43-57)
         from madronalib_amd import patches
@@ -217,7 +221,7 @@ def setup_workload(eng, name, V, T, lo, total):
         desc, outs = patches.synth16(pitch_input=True, event_rows=fusedRows)
         # MLGPU_BENCH_MIXDOWN=graph: the per-instrument voice sum is made inside the voice kernel (mlgpu_graph_set_output_group_sum)
         # instead of by mlgpu_mixdown_groups
-        sumInKernel = os.environ.get("MLGPU_BENCH_MIXDOWN", "kernel") == "graph"
+        sumInKernel = os.environ.get("MLGPU_BENCH_MIXDOWN", "graph" if fusedRows else "kernel") == "graph"
         g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=bool(os.environ.get("MLGPU_BENCH_AUTOTUNE")),
                      output_groups={0: P} if sumInKernel else None)
         if fusedRows:
@@ -401,14 +405,20 @@ def setup_workload(eng, name, V, T, lo, total):
 # operations) is a mix of the first two prices, hence a low and a high figure.
 ISSUE_NS = {"plain": 1.09, "slow": 1.8, "f64": 1.85, "trans": 3.5}
 N_SIMD = 256 * 4
+# The same classes in shader CYCLES per wave-instruction per SIMD - what the nanoseconds above are at the clock each micro-kernel
+# held (a kernel of plain FMAs clocks lower than one of conversions: 1.09 ns x 1.85 GHz = 2.0, 1.8 ns x 2.2 GHz = 4.0). Used with the
+# cycles a launch really took (GRBM_GUI_ACTIVE), so that the chip's clock under the workload drops out of the model (round 5).
+ISSUE_CYCLES = {"plain": 2.0, "slow": 4.0, "f64": 4.0, "trans": 8.0}
 
 
 # with two wavefronts per SIMD instead of four the same instructions issue slower (profiles/r03_bankbench.txt: 1.28 / 2.09 ns)
 ISSUE_NS_2_WAVES = {"plain": 1.28, "slow": 2.09}
 
 
-def valu_busy(pmc, kernel_ms, waves_per_simd=4.0):
-    """(low, high) fraction of the launch during which the SIMDs' vector issue is occupied, from the instruction-class counters."""
+def valu_busy(pmc, kernel_ms, waves_per_simd=4.0, cycles=None):
+    """(low, high) fraction of the launch during which the SIMDs' vector issue is occupied, from the instruction-class counters.
+    cycles: shader cycles of the launch (GRBM_GUI_ACTIVE / 8) - the classes are then priced in cycles (ISSUE_CYCLES) over those cycles;
+    without it in nanoseconds (ISSUE_NS) over kernel_ms."""
     total = pmc.get("valu_wave_insts_per_launch")
     if not total or "SQ_INSTS_VALU_ADD_F32" not in pmc:
         return None
@@ -424,6 +434,15 @@ def valu_busy(pmc, kernel_ms, waves_per_simd=4.0):
              + trans * ISSUE_NS["trans"] + integer * ISSUE_NS["plain"])
     span = N_SIMD * kernel_ms * 1e6
     lo, hi = (known + other * ISSUE_NS["plain"]) / span, (known + other * ISSUE_NS["slow"]) / span
+    if cycles:
+        c = ISSUE_CYCLES
+        known_c = (f32 * (packed * c["slow"] + (1.0 - packed) * c["plain"]) + f64 * c["f64"] + cvt * c["slow"] + trans * c["trans"] + integer * c["plain"])
+        lo, hi = (known_c + other * c["plain"]) / (N_SIMD * cycles), (known_c + other * c["slow"]) / (N_SIMD * cycles)
+        return {"busy_frac": [lo, hi], "packed_f32_share": packed, "wavefronts_per_simd": waves_per_simd,
+                "classes_per_launch": {"f32_add_mul_fma": f32, "f64": f64, "cvt": cvt, "trans": trans, "int": integer, "other": other},
+                "model": f"sum over instruction classes of SQ_INSTS_VALU_* x the class's issue time in shader cycles {ISSUE_CYCLES} (tools/instbench.hip at the clock "
+                         "each micro-kernel held, DESIGN 3.11) / (1024 SIMDs x the launch's shader cycles, GRBM_GUI_ACTIVE / 8); 'other' (compares, selects, "
+                         "min / max, moves) at the plain and at the slow price gives the low and the high figure; packed FP32 at the slow price"}
     if waves_per_simd <= 2.0:
         # a launch that fills two wavefront slots per SIMD (config 4: 131 072 channels): the high figure at the two-wavefront rates
         r = ISSUE_NS_2_WAVES
@@ -999,7 +1018,7 @@ def run_rank(args, rank, local_rank, world, rdv):
     # A block of several kernels (the instrument bank: events -> voices -> per-instrument sums) is timed as a whole; the counters are
     # the voice kernel's alone, so its clock and issue figures are taken over ITS duration (as measured under the counter pass)
     span_ms, span_what = kernel_ms, "live launch duration"
-    if args.workload in ("synth", "synthfused") and pmc.get("mean_us_under_pmc"):
+    if args.workload in ("synth", "synthrows") and pmc.get("mean_us_under_pmc"):
         span_ms, span_what = pmc["mean_us_under_pmc"] * 1e-3, "the named kernel's mean duration under the counter pass (the block holds other kernels too)"
     if pmc.get("GRBM_GUI_ACTIVE"):
         # GRBM_GUI_ACTIVE sums the 8 XCDs: / 8 = shader cycles per launch; over the live launch time = the clock the chip
@@ -1029,16 +1048,48 @@ def run_rank(args, rank, local_rank, world, rdv):
                         "note": "an instruction count, not a utilisation: packed FP32, compares, selects and conversions occupy the SIMD "
                                 "twice as long as a plain add / mul / fma (DESIGN 3.11); config 4 at 'frac 0.33' has its VALU port 85 % busy "
                                 "(profiles/r03_cfg4_account.md)"}
-        busy = valu_busy(pmc, span_ms, waves_per_simd=max(1.0, V / 64.0 / N_SIMD))
+        busy = valu_busy(pmc, span_ms, waves_per_simd=max(1.0, V / 64.0 / N_SIMD), cycles=(pmc["GRBM_GUI_ACTIVE"] / 8.0 if pmc.get("GRBM_GUI_ACTIVE") else None))
         if busy:
             roof["valu"].update(busy)
             roof["valu"]["scalar_insts_per_unit"] = pmc.get("SQ_INSTS_SALU", 0.0) * 64.0 / units_per_launch if pmc.get("SQ_INSTS_SALU") else None
+        # MEASURED (round 5): the share of a SIMD's issue slots in which it issued vector work. SQ_ACTIVE_INST_VALU counts one per vector
+        # instruction on gfx950 (its value equals SQ_INSTS_VALU to 0.3 %; "quad-cycles", i.e. one 4-cycle issue slot each) and
+        # SQ_ACTIVE_INST_VALU2 the slots in which TWO were issued (the plain FP32 / integer class runs two per slot: 2.6 cycles per
+        # instruction in tools/instbench.hip), so ACTIVE - VALU2 = slots with at least one; over the launch's slots = 1024 SIMDs x shader
+        # cycles / 4, the cycles from GRBM_GUI_ACTIVE / 8 XCDs of the same counter pass. tools/instbench.hip's single-class kernels under
+        # the same counters calibrate the reading (profiles/r05_valu_calibration.txt: a kernel of nothing but plain or nothing but slow
+        # instructions reads 0.97-1.0). The derived metric rocprofv3 ships (VALUBusy = ACTIVE / CU_NUM / GUI_ACTIVE) reads 1.4 on this
+        # chip for the same kernels: it charges four cycles to instructions that take two.
+        if pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_ACTIVE_INST_VALU2") is not None and pmc.get("GRBM_GUI_ACTIVE"):
+            slots = N_SIMD * (pmc["GRBM_GUI_ACTIVE"] / 8.0) / 4.0
+            roof["valu"]["busy_measured"] = (pmc["SQ_ACTIVE_INST_VALU"] - pmc["SQ_ACTIVE_INST_VALU2"]) / slots
+            roof["valu"]["dual_issue_share_of_busy_slots"] = pmc["SQ_ACTIVE_INST_VALU2"] / max(1.0, pmc["SQ_ACTIVE_INST_VALU"] - pmc["SQ_ACTIVE_INST_VALU2"])
+            if pmc.get("SQ_BUSY_CU_CYCLES"):
+                roof["valu"]["simd_slots_with_a_wavefront_resident"] = pmc["SQ_BUSY_CU_CYCLES"] / slots
+            if pmc.get("SQ_INST_CYCLES_SALU"):
+                roof["valu"]["scalar_busy_measured"] = pmc["SQ_INST_CYCLES_SALU"] / slots
+            roof["valu"]["busy_measured_source"] = ("(SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 / 4), one counter pass "
+                                                    "(profiles/pmc_workloads.json)")
+        if roof.get("clock"):
+            # the instruction rate against the vector peak AT THE CLOCK THE CHIP HELD under this load (it clocks to its power budget:
+            # 1.8-2.3 GHz of a 2.4 GHz maximum), next to the nominal one above
+            roof["valu"]["frac_at_live_clock"] = lane_rate / (N_SIMD * 32.0 * roof["clock"]["ghz_live"] * 1e9)
         # Which wall the launch stands at: the memory side as a fraction of what its access pattern can reach, the vector-issue side
-        # as the (mid) busy fraction; whichever is nearer its ceiling names the bound, and both are on the line.
+        # as the MEASURED busy fraction where the counters are there (else the model's middle); whichever is nearer its ceiling names
+        # the bound, and both are on the line.
         mem_side = roof.get("frac_of_ceiling", roof["frac"] / 0.79)          # 0.79: the store pattern's ceiling of round 3 (6.3 TB/s)
-        valu_side = sum(busy["busy_frac"]) / 2.0 if busy else roof["valu"]["frac"]
+        valu_side = roof["valu"].get("busy_measured", sum(busy["busy_frac"]) / 2.0 if busy else roof["valu"]["frac"])
         roof["bound"] = "valu" if valu_side > mem_side else "hbm"
-        roof["bound_evidence"] = {"memory_side_frac_of_pattern_ceiling": mem_side, "valu_issue_busy_frac_mid": valu_side}
+        roof["bound_evidence"] = {"memory_side_frac_of_pattern_ceiling": mem_side, "valu_issue_busy_frac": valu_side,
+                                  "valu_side_is": "measured" if "busy_measured" in roof["valu"] else "modelled"}
+        # (flat copies: a reader that keeps only the scalars of `roofline` still sees them)
+        for k_flat, k_src in (("valu_busy_measured", "busy_measured"), ("valu_frac_at_live_clock", "frac_at_live_clock"), ("valu_insts_per_unit", "insts_per_unit")):
+            if roof["valu"].get(k_src) is not None:
+                roof[k_flat] = roof["valu"][k_src]
+        if busy:
+            roof["valu_busy_model_low"], roof["valu_busy_model_high"] = busy["busy_frac"]
+        if roof.get("clock"):
+            roof["ghz_live"] = roof["clock"]["ghz_live"]
     if traffic is not None and traffic < 0.5 * alg_bytes:
         roof["bound"] = "on-die"   # the working set never leaves the Infinity Cache: not an HBM figure
         roof["bound_evidence"] = {"hbm_traffic_over_algorithmic_bytes": traffic / alg_bytes}

@@ -66,3 +66,12 @@ def test_packed_share_of_the_shipped_cascade_kernel():
     assert share is not None and 0.75 < share < 0.95          # 39 packed + 2 plain arithmetic instructions per tick, plus the edges
     assert kernel_mix.packed_share("void mldev::chain_kernel<mldev::Chain<2, 18, 48>, false>(ChainArgs)", lib) == 0.0
     assert kernel_mix.packed_share("mlgpu_graph_kernel", lib) is None   # compiled at run time: not in the library
+
+
+def test_cycle_model_prices_the_classes_over_the_launchs_own_cycles():
+    """With the launch's shader cycles (GRBM_GUI_ACTIVE / 8) the classes are priced in cycles: the clock the chip held drops out."""
+    b = bench.valu_busy(record(), 123.0, cycles=10.0)["busy_frac"]
+    c = bench.ISSUE_CYCLES
+    known = 800 * c["plain"] + 50 * c["slow"] + 10 * c["trans"] + 40 * c["plain"]
+    assert b[0] == pytest.approx((known + 100 * c["plain"]) / (1024 * 10.0))
+    assert b[1] == pytest.approx((known + 100 * c["slow"]) / (1024 * 10.0))

@@ -70,7 +70,9 @@ def main():
                           # the instruction classes behind roofline.valu.busy_frac (bench.py) and the scalar side
                           "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT",
                           "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
-                          "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM"):
+                          "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM",
+                          # round 5: what the vector unit was measured to do (roofline.valu.busy_measured)
+                          "SQ_ACTIVE_INST_VALU2", "SQ_BUSY_CU_CYCLES", "SQ_ACTIVE_INST_SCA", "SQ_INST_CYCLES_SALU", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS"):
                     if c in v:
                         rec[c] = v[c]
                 break

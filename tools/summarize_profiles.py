@@ -40,17 +40,23 @@ def main():
                "traffic": r.get("traffic"), "pmc_stale": r.get("pmc_stale", False),
                "valu_insts_per_unit": (r.get("valu") or {}).get("insts_per_unit"), "valu_frac": (r.get("valu") or {}).get("frac"),
                "clock_ghz": (r.get("clock") or {}).get("ghz_live"), "cycles_per_launch": (r.get("clock") or {}).get("cycles_per_launch"),
+               "valu_busy_measured": (r.get("valu") or {}).get("busy_measured"), "valu_busy_model": (r.get("valu") or {}).get("busy_frac"),
+               "valu_frac_at_live_clock": (r.get("valu") or {}).get("frac_at_live_clock"), "scalar_insts_per_unit": (r.get("valu") or {}).get("scalar_insts_per_unit"),
+               "frac_of_ceiling": r.get("frac_of_ceiling"),
                "rocprof_avg_us": stats_avg_us(os.path.join(d, name + "_kernel_stats.csv"), r["kernel"])}
         rows.append(rec)
     json.dump({"tag": tag, "rows": rows}, open(os.path.join(d, f"{tag}_summary.json"), "w"), indent=1)
-    print(f"| bench file | units/s | kernel | ms / launch (live) | rocprofv3 avg ms | of 8 TB/s | clock GHz | VALU instr / unit | PMC traffic / algorithmic |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print(f"| bench file | units/s | kernel | ms / launch (live) | rocprofv3 avg ms | of 8 TB/s | clock GHz | VALU instr / unit | VALU busy measured (model) | PMC traffic / algorithmic |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         tr = "stale" if r["pmc_stale"] else (f"{r['traffic'] / 1e9:.3f} / {r['algorithmic_bytes'] / 1e9:.3f} GB" if r["traffic"] else f"- / {r['algorithmic_bytes'] / 1e9:.3f} GB")
         avg = f"{r['rocprof_avg_us'] / 1e3:.3f}" if r["rocprof_avg_us"] else "-"
         clk = f"{r['clock_ghz']:.2f}" if r["clock_ghz"] else "-"
         ipu = f"{r['valu_insts_per_unit']:.1f}" if r["valu_insts_per_unit"] else "-"
-        print(f"| `{r['file']}` | {r['value']:.3g} | `{r['kernel'][:44]}` | {r['kernel_ms']:.3f} | {avg} | {100 * r['hbm_frac']:.1f} % | {clk} | {ipu} | {tr} |")
+        bm = f"{r['valu_busy_measured']:.2f}" if r.get("valu_busy_measured") else "-"
+        if r.get("valu_busy_model"):
+            bm += f" ({r['valu_busy_model'][0]:.2f}-{r['valu_busy_model'][1]:.2f})"
+        print(f"| `{r['file']}` | {r['value']:.3g} | `{r['kernel'][:44]}` | {r['kernel_ms']:.3f} | {avg} | {100 * r['hbm_frac']:.1f} % | {clk} | {ipu} | {bm} | {tr} |")
 
 
 if __name__ == "__main__":
