@@ -164,8 +164,10 @@ def test_register_budget_of_generated_kernels(monkeypatch):
     assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and scratch <= 64
     bounds, vgpr, scratch = build(262144, full=True)           # the 22-node patch does not: bounded, with a little scratch
     assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and 0 < scratch <= 640
-    bounds, vgpr, scratch = build(262144, pitch_input=True, event_rows=True)   # EventsToSignals' rows inside: far above, bounded too
-    assert bounds == "__launch_bounds__(256, 4)" and vgpr <= 128 and 0 < scratch <= 640
+    # EventsToSignals' rows inside: round 4's record-walking form was far above (134 spilled registers under the bound); round 5's
+    # control-record form (mlev::CtlVoice, buffer-descriptor addressing) fits the four-wavefront budget with next to no scratch
+    bounds, vgpr, scratch = build(262144, pitch_input=True, event_rows=True)
+    assert vgpr <= 128 and scratch <= 64
     bounds, vgpr, scratch = build(1024, full=True)             # a small bank does not fill the chip: the compiler's choice stands
     assert bounds == "__launch_bounds__(256)" and vgpr > 128 and scratch == 0
     monkeypatch.setenv("MLGPU_GRAPH_MIN_WAVES", "0")
