@@ -405,11 +405,15 @@ def setup_workload(eng, name, V, T, lo, total):
 # operations) is a mix of the first two prices, hence a low and a high figure.
 ISSUE_NS = {"plain": 1.09, "slow": 1.8, "f64": 1.85, "trans": 3.5}
 N_SIMD = 256 * 4
-# The same classes in shader CYCLES per wave-instruction per SIMD - what the nanoseconds above are at the clock each micro-kernel
-# held (a kernel of plain FMAs clocks lower than one of conversions: 1.09 ns x 1.85 GHz = 2.0, 1.8 ns x 2.2 GHz = 4.0). Used with the
-# cycles a launch really took (GRBM_GUI_ACTIVE), so that the chip's clock under the workload drops out of the model (round 5).
-ISSUE_CYCLES = {"plain": 2.0, "slow": 4.0, "f64": 4.0, "trans": 8.0}
-
+# The same classes as shares of a SIMD's 4-cycle ISSUE SLOT (round 5; calibrated on tools/instbench.hip under the occupancy counters,
+# profiles/r05_valu_calibration.txt): a conversion / compare / select / min / max / packed / double-precision instruction takes a slot, a
+# transcendental two, and the plain FP32 / integer / move class takes HALF a slot when the SIMD finds a second one to issue beside it
+# (two per slot: 1.51 instructions per slot measured on a saturated SIMD) and a whole slot when it does not - which depends on what the
+# other wavefronts are doing, not on the instruction. So the model is a bracket: every plain instruction paired (low) .. none (high,
+# capped at 1); the measured figure (roofline.valu.busy_measured) says where in it the launch was. A saturated single-class kernel
+# reads 0.87-0.96 on the measured scale (launch edges, the odd stall): that is its ceiling, not 1.
+ISSUE_SLOTS = {"plain_paired": 0.5, "plain_alone": 1.0, "slow": 1.0, "f64": 1.0, "trans": 2.0}
+BUSY_MEASURED_CEILING = 0.90
 
 # with two wavefronts per SIMD instead of four the same instructions issue slower (profiles/r03_bankbench.txt: 1.28 / 2.09 ns)
 ISSUE_NS_2_WAVES = {"plain": 1.28, "slow": 2.09}
@@ -417,7 +421,7 @@ ISSUE_NS_2_WAVES = {"plain": 1.28, "slow": 2.09}
 
 def valu_busy(pmc, kernel_ms, waves_per_simd=4.0, cycles=None):
     """(low, high) fraction of the launch during which the SIMDs' vector issue is occupied, from the instruction-class counters.
-    cycles: shader cycles of the launch (GRBM_GUI_ACTIVE / 8) - the classes are then priced in cycles (ISSUE_CYCLES) over those cycles;
+    cycles: shader cycles of the launch (GRBM_GUI_ACTIVE / 8) - the classes are then priced in 4-cycle issue slots (ISSUE_SLOTS) over those cycles: a bracket;
     without it in nanoseconds (ISSUE_NS) over kernel_ms."""
     total = pmc.get("valu_wave_insts_per_launch")
     if not total or "SQ_INSTS_VALU_ADD_F32" not in pmc:
@@ -435,14 +439,19 @@ def valu_busy(pmc, kernel_ms, waves_per_simd=4.0, cycles=None):
     span = N_SIMD * kernel_ms * 1e6
     lo, hi = (known + other * ISSUE_NS["plain"]) / span, (known + other * ISSUE_NS["slow"]) / span
     if cycles:
-        c = ISSUE_CYCLES
-        known_c = (f32 * (packed * c["slow"] + (1.0 - packed) * c["plain"]) + f64 * c["f64"] + cvt * c["slow"] + trans * c["trans"] + integer * c["plain"])
-        lo, hi = (known_c + other * c["plain"]) / (N_SIMD * cycles), (known_c + other * c["slow"]) / (N_SIMD * cycles)
+        c = ISSUE_SLOTS
+        slots = N_SIMD * cycles / 4.0
+        fixed = f32 * packed * c["slow"] + f64 * c["f64"] + cvt * c["slow"] + trans * c["trans"]
+        plain = f32 * (1.0 - packed) + integer
+        lo = (fixed + (plain + other) * c["plain_paired"]) / slots
+        hi = min(1.0, (fixed + plain * c["plain_alone"] + other * c["slow"]) / slots)
         return {"busy_frac": [lo, hi], "packed_f32_share": packed, "wavefronts_per_simd": waves_per_simd,
                 "classes_per_launch": {"f32_add_mul_fma": f32, "f64": f64, "cvt": cvt, "trans": trans, "int": integer, "other": other},
-                "model": f"sum over instruction classes of SQ_INSTS_VALU_* x the class's issue time in shader cycles {ISSUE_CYCLES} (tools/instbench.hip at the clock "
-                         "each micro-kernel held, DESIGN 3.11) / (1024 SIMDs x the launch's shader cycles, GRBM_GUI_ACTIVE / 8); 'other' (compares, selects, "
-                         "min / max, moves) at the plain and at the slow price gives the low and the high figure; packed FP32 at the slow price"}
+                "model": f"issue slots (4 shader cycles per SIMD) the launch's vector instructions need, by class - {ISSUE_SLOTS} of a slot each "
+                         "(tools/instbench.hip under SQ_ACTIVE_INST_VALU / _VALU2, profiles/r05_valu_calibration.txt) - over the launch's slots "
+                         "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 / 4): low = every plain FP32 / integer / move instruction issued beside another one, "
+                         "high = none (capped at 1); 'other' (compares, selects, min / max, moves) half a slot in the low and a slot in the high "
+                         "figure; packed FP32 a slot. A bracket, not an estimate: busy_measured is the number"}
     if waves_per_simd <= 2.0:
         # a launch that fills two wavefront slots per SIMD (config 4: 131 072 channels): the high figure at the two-wavefront rates
         r = ISSUE_NS_2_WAVES
@@ -1068,6 +1077,7 @@ def run_rank(args, rank, local_rank, world, rdv):
                 roof["valu"]["simd_slots_with_a_wavefront_resident"] = pmc["SQ_BUSY_CU_CYCLES"] / slots
             if pmc.get("SQ_INST_CYCLES_SALU"):
                 roof["valu"]["scalar_busy_measured"] = pmc["SQ_INST_CYCLES_SALU"] / slots
+            roof["valu"]["busy_measured_ceiling"] = BUSY_MEASURED_CEILING   # what a kernel of nothing but vector instructions reads (0.87-0.96)
             roof["valu"]["busy_measured_source"] = ("(SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 / 4), one counter pass "
                                                     "(profiles/pmc_workloads.json)")
         if roof.get("clock"):

@@ -554,8 +554,12 @@ int mlgpu_graph_set_max_delay(mlgpu_graph* g, int proc_node, float max_delay_in_
 /* Layout of the delay rings (before compile). 0 (default): [sample][voice] — one coalesced row per time step, best when
  * neighbouring voices use the same delay times. 1: [256-voice block][sample / 8][voice][8] — a voice moves its samples in
  * 32-byte sectors through LDS windows, so no bandwidth is wasted when delay times differ from voice to voice (DESIGN.md
- * §3.6); costs 8 KiB of LDS per ring per workgroup, at most 20 rings per graph. Same results for delay times within
- * the node's maximum (graph_set_max_delay). */
+ * §3.6); costs 8 KiB of LDS per ring per workgroup, at most 20 rings per graph. 2 (round 5): [256-voice block][sample / 16][voice][16]
+ * moved as 64-byte pieces by four neighbouring lanes on a wave-uniform clock, read windows in LDS, requests a period ahead: the
+ * algorithmic traffic and not a byte more (0.99 x measured against 1.13 x for layout 1), for whole wavefronts (voices a multiple of
+ * 64) and at most 4 rings per graph (40 KiB of LDS per ring) - but not faster than layout 1 on this chip
+ * (profiles/r05_ring_layouts.txt), which therefore stays the one to use for per-voice delay times. Same results in every layout
+ * for delay times within the node's maximum (graph_set_max_delay). */
 int mlgpu_graph_set_delay_layout(mlgpu_graph* g, int windowed);
 /* One-vector feedback: a DSPVector the reference keeps from one process call to the next (Allpass::vy1
  * MLDSPFilters.h:1115, FDN::mDelayInputVectors :1168, FeedbackDelayFunction::vy1 MLDSPFunctional.h:276, or a user's
@@ -823,9 +827,12 @@ int mlgpu_graph_set_output_group_sum(mlgpu_graph* g, int output_index, int group
 
 /*
  * The pitch and gate rows as SOURCE NODES of a voice graph: a Synth's voices read voice.outputs.row(kPitch / kGate) straight
- * from EventsToSignals (source/app/MLSynth.h:43-57, MLEventsToSignals.h:15-26); here the graph kernel computes those two rows
- * itself, frame by frame, from the same records and the same per-voice state as mlgpu_events_process - the rows never exist in
- * memory. MIDI protocol; instruments x polyphony must equal the graph's voices; voice v of the graph is voice v of the object
+ * from EventsToSignals (source/app/MLSynth.h:43-57, MLEventsToSignals.h:15-26); here the graph kernel makes those two rows
+ * itself from the same per-voice state as mlgpu_events_process - the rows never exist in memory. Since round 5 (behaviour revision 3)
+ * mlgpu_graph_process_events is two launches: a light control kernel runs everything that happens once per DSPVector or once per
+ * note event (record walk, bend and pitch glides, the drift random walk: source/app/MLEventsToSignals.cpp:75-262) and writes a
+ * 16-byte control record per voice and DSPVector - plus 64 frames of pitch and gate for the few vectors that hold a note event or
+ * a portamento -, and the voice kernel expands the records and walks the drift glide. MIDI protocol; instruments x polyphony must equal the graph's voices; voice v of the graph is voice v of the object
  * (instrument v / polyphony, voice v % polyphony). Per block: mlgpu_events_add_event(s), then mlgpu_graph_process_events with
  * the block's frame offset (what mlgpu_events_process takes), then mlgpu_events_clear_events as usual. A block may be processed
  * by either call: both leave the state the other expects (rows a call does not compute keep their glides where they are, as

@@ -68,10 +68,13 @@ def test_packed_share_of_the_shipped_cascade_kernel():
     assert kernel_mix.packed_share("mlgpu_graph_kernel", lib) is None   # compiled at run time: not in the library
 
 
-def test_cycle_model_prices_the_classes_over_the_launchs_own_cycles():
-    """With the launch's shader cycles (GRBM_GUI_ACTIVE / 8) the classes are priced in cycles: the clock the chip held drops out."""
+def test_slot_model_brackets_between_all_plain_paired_and_none():
+    """With the launch's shader cycles (GRBM_GUI_ACTIVE / 8) the classes are priced in 4-cycle issue slots: a bracket from "every plain
+    instruction issued beside another" to "none", never above 1."""
     b = bench.valu_busy(record(), 123.0, cycles=10.0)["busy_frac"]
-    c = bench.ISSUE_CYCLES
-    known = 800 * c["plain"] + 50 * c["slow"] + 10 * c["trans"] + 40 * c["plain"]
-    assert b[0] == pytest.approx((known + 100 * c["plain"]) / (1024 * 10.0))
-    assert b[1] == pytest.approx((known + 100 * c["slow"]) / (1024 * 10.0))
+    slots = 1024 * 10.0 / 4.0
+    fixed = 50 * 1.0 + 10 * 2.0            # conversions a slot, transcendentals two
+    plain = 800 + 40                       # FP32 add / mul / fma and integer
+    assert b[0] == pytest.approx((fixed + (plain + 100) * 0.5) / slots)
+    assert b[1] == pytest.approx(min(1.0, (fixed + plain * 1.0 + 100 * 1.0) / slots))
+    assert bench.valu_busy(record(), 123.0, cycles=0.5)["busy_frac"][1] == 1.0

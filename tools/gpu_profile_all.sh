@@ -14,7 +14,9 @@ root=$PWD
 out=$root/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out
 fetchdirs=""; writedirs=""
+EXTRA0=$EXTRA
 for w in "$@"; do
+  EXTRA=$EXTRA0; [ $w = cfg3 ] && EXTRA="$EXTRA0 --no-extras"   # (the default workload's extra legs - the other configs, the paced target - are not this profile's subject)
   scratch=/tmp/prof_${tag}_$w; rm -rf $scratch; mkdir -p $scratch
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $scratch/stats -- python $root/bench.py --workload $w $EXTRA --no-cpu-baseline > $out/${tag}_${w}_bench_under_rocprof.json 2> $scratch/stats.log )
   f=$(find $scratch/stats -name '*_kernel_stats.csv' | head -1)
