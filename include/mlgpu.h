@@ -650,6 +650,10 @@ int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n);
 size_t mlgpu_graph_device_bytes(mlgpu_graph* g);
 int mlgpu_graph_set_autotune(mlgpu_graph* g, int on);
 int mlgpu_graph_tuning(mlgpu_graph* g, int* voices_per_lane, int* quads_per_trip);
+/* Workgroups (256 voices each) of this graph's kernel that one CU holds at once - registers, LDS and wavefront slots together
+ * (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor); negative: a status. A bank of more than 256 x this x the CU count voices runs
+ * its last workgroups after the others. */
+int mlgpu_graph_workgroups_per_cu(mlgpu_graph* g);
 /* Generate + compile (hiprtc, gfx950) + load the fused kernel; allocate state/coeffs/params.
  * A COLD compile - a graph whose generated source is in neither the process's memory cache nor the disk cache
  * ($MLGPU_CACHE_DIR, default ~/.cache/mlgpu) - runs hiprtc for 2 to 5 seconds (measured: the 16-node synth voice 1.9 s, the

@@ -1013,6 +1013,10 @@ class Graph:
         """Device memory the compiled graph owns (mlgpu_graph_device_bytes)."""
         return int(self.L.mlgpu_graph_device_bytes(self.h))
 
+    def workgroups_per_cu(self):
+        """Workgroups of this graph's kernel a CU holds at once (mlgpu_graph_workgroups_per_cu)."""
+        return self._ret(self.L.mlgpu_graph_workgroups_per_cu(self.h), None)
+
     def tuning(self):
         """(settled, voices per lane, quads per trip) of the kernel form in use (mlgpu_graph_tuning)."""
         vl, u = ctypes.c_int(), ctypes.c_int()

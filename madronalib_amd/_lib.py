@@ -210,6 +210,7 @@ def _declare(L):
     sig("mlgpu_graph_device_bytes", sz, [vp])
     sig("mlgpu_graph_set_autotune", i, [vp, i])
     sig("mlgpu_graph_tuning", i, [vp, c.POINTER(i), c.POINTER(i)])
+    sig("mlgpu_graph_workgroups_per_cu", i, [vp])
     sig("mlgpu_mixdown_reserve", i, [vp, sz, sz])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
     sig("mlgpu_mixdown_groups", i, [vp, vp, i, sz, sz, sz, vp, i])

@@ -2279,6 +2279,17 @@ extern "C"
     return (g->autotune && !g->tuned) ? 0 : 1;
   }
 
+  // how many workgroups of this graph's kernel a CU holds at once (registers, LDS and wavefront slots together): what decides whether a
+  // bank runs in one round (voices <= 256 x that x the CU count) or the last workgroups run alone after the others
+  int mlgpu_graph_workgroups_per_cu(mlgpu_graph* g)
+  {
+    if (!g || !g->compiled || !g->fn) return -MLGPU_ERR_INVALID;
+    int n = 0;
+    if (hipSetDevice(g->e->device) != hipSuccess) return -MLGPU_ERR_HIP;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, g->fn, 256, 0) != hipSuccess) return -MLGPU_ERR_HIP;
+    return n;
+  }
+
   int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n)
   {
     if (!g) return MLGPU_ERR_INVALID;

@@ -382,7 +382,7 @@ def _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_la
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["midi_poly4", "midi_steal2", "midi_poly16", "unison3", "sustain"])
+@pytest.mark.parametrize("name", ["midi_poly4", "midi_steal2", "midi_poly16", "unison3", "sustain", "sr44k", "sr8k", "sr192k", "poly1"])
 def test_event_rows_inside_the_voice_graph(eng, name):
     """EventsToSignals' pitch and gate rows as source nodes of the voice graph (mlgpu_graph_add_event_row / bind_events /
     process_events): the same audio, bit for bit, as e2s_kernel writing the rows and the graph reading them - which is itself
@@ -407,6 +407,21 @@ def test_instrument_bank_in_one_voice_kernel(eng, name):
     instruments = [performance("midi", 31 * k + len(name), block * n_blocks, cfg["polyphony"]) for k in range(37)]
     a, b = _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch=8, voice_sum=True)
     assert_bits_equal(b, a, True, f"{name}: instrument audio, one kernel vs three")
+    assert np.abs(a).max() > 0
+
+
+@pytest.mark.gpu
+def test_event_rows_through_a_whole_drift_cycle(eng):
+    """The drift glide is the one state machine the voice kernel owns (mlev::CtlVoice): 8 s per glide, a new target every 8-16 s. At
+    8 kHz that is 1 000 DSPVectors per glide: 2 600 vectors take every voice through the ramp that starts a glide, its middle, its
+    end, the rest at the target and the start of the next one from a resting mCurrVec - with note events, portamento and pitch bends
+    on top. Fused against the two-kernel form (itself bit-exact against the reference's class on shorter runs)."""
+    cfg = SCENARIOS["sr8k"]
+    block, n_blocks = 512, 325
+    instruments = [performance("midi", 900 + k, block * n_blocks, cfg["polyphony"]) for k in range(3)]
+    instruments = [[e for e in evs if e[3] % 7 == 0] for evs in instruments]      # a sparser performance: the long stretches are the point
+    a, b = _two_kernel_and_fused(eng, cfg, instruments, block, n_blocks, vectors_per_launch=8)
+    assert_bits_equal(b, a, True, "fused event rows vs two kernels over 2 600 vectors")
     assert np.abs(a).max() > 0
 
 
