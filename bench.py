@@ -346,7 +346,8 @@ def setup_workload(eng, name, V, T, lo, total):
         if os.environ.get("MLGPU_UNIFORM_DELAY"):
             length = np.full(V, 200.0)
         else:
-            length = 48000.0 / (55.0 * 2.0 ** (4.0 * ((np.arange(V) * 7919) % V) / V)) - 64.0   # 55 Hz .. 880 Hz, scattered over the voices
+            length = 48000.0 / (46.0 * 2.0 ** (4.0 * ((np.arange(V) * 7919) % V) / V)) - 64.0   # 46 Hz .. 736 Hz, scattered over the voices: 979 .. 1.2 samples
+            # (to round 5's first profiles this was 55 .. 880 Hz, whose top 6 % of voices got NEGATIVE delay times - outside the reference's contract)
         st = np.stack([ml.FractionalDelay.makeState(float(d)) for d in np.unique(np.round(length, 2))])
         uniq = {float(d): st[i] for i, d in enumerate(np.unique(np.round(length, 2)))}
         words = np.stack([uniq[float(d)] for d in np.round(length, 2)], 1).astype(np.float32)   # [2][V]: delayInt bits, allpass coefficient
@@ -366,7 +367,7 @@ def setup_workload(eng, name, V, T, lo, total):
         alg = (8.0 + 8.0 + 8.0) * n
         if not os.environ.get("MLGPU_UNIFORM_DELAY"):
             META["coalesced_read_bytes"] = 8.0 * n      # x and the kept DSPVector stream in; the ring is read sector by sector
-        return launch, alg, "mlgpu_graph_kernel", "plucked strings: FractionalDelay of per-voice length (55..880 Hz) -> OnePole -> feedback, 262144 voices", (g, nb)
+        return launch, alg, "mlgpu_graph_kernel", "plucked strings: FractionalDelay of per-voice length (46..736 Hz) -> OnePole -> feedback, 262144 voices", (g, nb)
     if name == "allpass4":
         from madronalib_amd import patches
         desc = [dict(name="x", type="input"), dict(name="dl", type="param")]

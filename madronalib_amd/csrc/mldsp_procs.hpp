@@ -1353,7 +1353,14 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   }
 
   // ---- layout 2: transposed windows (see the constants above) ----
-  uint32_t tag0, tag1;  // the chunks (ring position >> 4) the two read slots hold, kTNone: nothing
+  // What the 32 read rows hold: the samples of ring positions [lo, lo + len), len <= 32, position t in row 8 + (t & 31). Whole chunks
+  // fetched a period ahead for a lane that reads three or more chunks behind the writer; its own last 32 written samples (copied
+  // from the write window at every flush: `hist`) for a lane that reads closer than that - those chunks cannot be asked for a period
+  // ahead, they are not written yet, and a quarter of the voices of a bank of plucked strings (55 .. 880 Hz) are such lanes: served
+  // from memory sample by sample they cost every wavefront a memory round trip per sample (measured: 1.41 ms per launch against
+  // 1.17 with that path compiled out, profiles/r05_ring_layouts.txt).
+  uint32_t lo, len;
+  bool hist;
   uint32_t pend;        // the chunk this lane asked for at the last boundary: in flight in its four loader lanes' registers
   f32x4r stage[4];      // pieces this lane loaded for OTHER lanes: stage[m] = piece (lane & 3) of lane (m * 16 + lane / 4)'s pending chunk
   bool uniformW, primed;
@@ -1366,7 +1373,9 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   }
   MLD void beginT(const VoiceMem& m, int ringIdx)
   {
-    tag0 = tag1 = pend = kTNone;
+    pend = kTNone;
+    lo = len = 0;
+    hist = false;
     primed = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage[i] = f32x4r{0.f, 0.f, 0.f, 0.f};
@@ -1388,10 +1397,16 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   // piece; halfStart = the ring position of the window's first sample (a multiple of 8)
   MLD void flushT(const VoiceMem& m, int ringIdx, uint32_t halfStart) const
   {
+#ifdef MLGPU_RING_X_NOFLUSH  // (elimination experiments: wrong results, used to find what a launch waits for - profiles/r05_ring_layouts.txt)
+    return;
+#endif
     const uint32_t lane = threadIdx.x & 63u, j = lane & 1u;
     const float* row0 = strip(m, ringIdx) - lane;  // column 0 of row 0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef MLGPU_RING_X_FULLPIECE  // (what whole 64-byte pieces would cost: nothing at the first half, both halves - the first with wrong data - at the second)
+    if ((halfStart & (uint32_t)kTWrite) == 0) return;
+#endif
 #pragma unroll
     for (int mm = 0; mm < 2; ++mm)
     {
@@ -1399,6 +1414,9 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       const float* src = row0 + (4 * j) * kTRowPad + other;
       const f32x4r a = {src[0], src[kTRowPad], src[2 * kTRowPad], src[3 * kTRowPad]};
       *((f32x4r*)(chunkOf(m, ringIdx, other, halfStart) + (halfStart & (uint32_t)kTWrite)) + j) = a;
+#ifdef MLGPU_RING_X_FULLPIECE
+      *((f32x4r*)(chunkOf(m, ringIdx, other, halfStart)) + j) = a;
+#endif
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1414,7 +1432,11 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     {
       const uint32_t other = (uint32_t)mm * 16u + (lane >> 2);
       const uint32_t q = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(other * 4u), (int)want);
+#ifdef MLGPU_RING_X_NOLOAD
+      out[mm] = f32x4r{(float)q, 0.f, 0.f, 0.f};
+#else
       out[mm] = *((const f32x4r*)chunkOf(m, ringIdx, other, (q != kTNone ? q : spare) * (uint32_t)kTChunk) + j);
+#endif
     }
   }
   // ... and into the owners' read windows: chunk q goes to slot q & 1 (rows 16 + 16 (q & 1) ...)
@@ -1435,35 +1457,78 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       }
     }
   }
-  MLD void setTag(uint32_t q)
+  MLD bool held(const VoiceMem& m, uint32_t t) const { return ((t - lo) & m.memMask) < len; }
+  // n samples from ring position t on have just been put into their rows: joined to what is held when they continue it (the rows
+  // they overwrote were the oldest 32 back), else they are all that is held
+  MLD void installed(const VoiceMem& m, uint32_t t, uint32_t n)
   {
-    if (q == kTNone) return;
-    if (q & 1u) tag1 = q;
-    else tag0 = q;
+    if (len != 0 && ((lo + len) & m.memMask) == t)
+    {
+      len += n;
+      if (len > 2 * kTChunk)
+      {
+        lo = (lo + len - 2 * kTChunk) & m.memMask;
+        len = 2 * kTChunk;
+      }
+    }
+    else
+    {
+      lo = t;
+      len = n;
+    }
   }
+  // the write window's eight samples (ring positions t .. t + 7, t = the block just finished) into the read rows of the lanes that
+  // read close behind the writer
+  MLD void keepHistory(const VoiceMem& m, int ringIdx, uint32_t t)
+  {
+    if (__builtin_amdgcn_ballot_w64(hist) == 0) return;
+    if (hist)
+    {
+      float* col = strip(m, ringIdx);
+      float* dst = col + (kTWrite + (t & (2 * kTChunk - 1))) * kTRowPad;
+      float v[kTWrite];
+#pragma unroll
+      for (int j = 0; j < kTWrite; ++j) v[j] = col[j * kTRowPad];
+#pragma unroll
+      for (int j = 0; j < kTWrite; ++j) dst[j * kTRowPad] = v[j];
+      installed(m, t, kTWrite);
+    }
+  }
+  static constexpr int kWaitVm0 = 0x0F70;  // s_waitcnt vmcnt(0), the other counters left alone (gfx9 encoding)
   // every 16 samples, all lanes together (w is the same in all of them and a multiple of 16, or this is the launch's first sample)
   MLD void boundaryT(const VoiceMem& m, int ringIdx, int32_t d)
   {
+#ifdef MLGPU_RING_X_NOBOUNDARY
+    primed = true;
+    return;
+#endif
     const uint32_t cmask = ((m.memMask + 1) >> 4) - 1u, wc = w >> 4;
     const uint32_t c = ((w - (uint32_t)d) & m.memMask) >> 4;
     const uint32_t age = (wc - c) & cmask;  // how many chunks behind the writer this lane reads (0: inside the write window)
     // (no cache maintenance: a voice's ring is written and read by one wavefront only, and a CU's vector cache is coherent for its
     // own wavefronts' stores - an acquire fence here would also wait for every store and load in flight, a memory round trip per
     // 16 samples: measured 2 x the launch time)
-    // a slot whose chunk the writer has come round to holds a ring cycle's old samples from now on
-    if (tag0 == wc) tag0 = kTNone;
-    if (tag1 == wc) tag1 = kTNone;
-    // what was asked for at the last boundary goes into its slot - unless that slot still holds a chunk the coming 16 samples
-    // read (the read position moved by less than a chunk: the launch's first boundary came mid-chunk, a delay time grew): then it
+    // what the coming 16 samples overwrite in memory is a ring cycle old in the rows from now on
+    if (((w - lo) & m.memMask) < len || ((lo - w) & m.memMask) < (uint32_t)kTChunk) len = 0;
+    // a lane that reads less than three chunks behind the writer keeps its own history instead of asking (and what it may have
+    // asked for while it read further back is dropped: it would wait in the loaders' registers for ever and hold up the wavefront)
+    hist = age < 3u;
+    if (hist) pend = kTNone;
+    // what was asked for at the last boundary goes into its rows - unless those still hold a chunk the coming 16 samples read
+    // (the read position moved by less than a chunk: the launch's first boundary came mid-chunk, a delay time grew): then it
     // waits in the loaders' registers for another period
     const uint32_t c1 = (c + 1u) & cmask;
-    const uint32_t there = (pend & 1u) ? tag1 : tag0;
-    const uint32_t commit = (pend != kTNone && there != c && there != c1) ? pend : kTNone;
+    const uint32_t shares = ((c ^ pend) & 1u) ? c1 : c;  // the chunk of the coming reads that lives in the rows pend would take
+    const bool inUse = shares != pend && (held(m, shares * kTChunk) || held(m, shares * kTChunk + kTChunk - 1));
+    const uint32_t commit = (pend != kTNone && !inUse) ? pend : kTNone;
     if (__builtin_amdgcn_ballot_w64(commit != kTNone) != 0)
     {
       storeRound(m, ringIdx, commit, stage);
-      setTag(commit);
-      if (commit != kTNone) pend = kTNone;
+      if (commit != kTNone)
+      {
+        installed(m, commit * kTChunk, kTChunk);
+        pend = kTNone;
+      }
     }
     if (!primed)
     {
@@ -1474,14 +1539,16 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       if (__builtin_amdgcn_ballot_w64(q0 != kTNone) != 0)
       {
         loadRound(m, ringIdx, q0, (wc - 2u) & cmask, tmp);
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);   // here, once a launch - not left pending into the sample loop (see sampleT)
         storeRound(m, ringIdx, q0, tmp);
-        setTag(q0);
+        if (q0 != kTNone) installed(m, q0 * kTChunk, kTChunk);
       }
       if (__builtin_amdgcn_ballot_w64(q1 != kTNone) != 0)
       {
         loadRound(m, ringIdx, q1, (wc - 2u) & cmask, tmp);
+        __builtin_amdgcn_s_waitcnt(kWaitVm0);
         storeRound(m, ringIdx, q1, tmp);
-        setTag(q1);
+        if (q1 != kTNone) installed(m, q1 * kTChunk, kTChunk);
       }
     }
     // the chunk after those: asked for now, used from the next boundary on - if the writer is done with it (two or more behind)
@@ -1507,24 +1574,43 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       float* own = chunkOf(m, ringIdx, lane, w) + (w & (kTChunk - 1));
       __hip_atomic_store(own, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t r = (w - (uint32_t)d) & m.memMask;
-      const float y = __hip_atomic_load(chunkOf(m, ringIdx, lane, r) + (r & (kTChunk - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float y = __hip_atomic_load(chunkOf(m, ringIdx, lane, r) + (r & (kTChunk - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" : "+v"(y));   // the wait for it here, not where the two paths join (see below)
       w = (w + 1) & m.memMask;
       return y;
     }
     float* col = strip(m, ringIdx);
     col[(w & (kTWrite - 1)) * kTRowPad] = x;
     if (!primed || (w & (kTChunk - 1)) == 0) boundaryT(m, ringIdx, d);
-    const uint32_t r = (w - (uint32_t)d) & m.memMask, rc = r >> 4;
-    const bool inW = (r >> 3) == (w >> 3), inR = rc == ((rc & 1u) ? tag1 : tag0);
-    const uint32_t row = inW ? (r & (kTWrite - 1)) : (uint32_t)kTWrite + ((rc & 1u) << 4) + (r & (kTChunk - 1));
+    const uint32_t r = (w - (uint32_t)d) & m.memMask;
+    const bool inW = (r >> 3) == (w >> 3), inR = held(m, r);
+    const uint32_t row = inW ? (r & (kTWrite - 1)) : (uint32_t)kTWrite + (r & (2 * kTChunk - 1));
+#ifdef MLGPU_RING_X_NOLDSREAD
+    float y = x + (float)row;
+#else
     float y = col[row * kTRowPad];
+#endif
+#ifndef MLGPU_RING_X_NOMISS
     if (__builtin_amdgcn_ballot_w64(!(inW || inR)) != 0)
     {
       // a sample no window holds (a delay of 8 to 47 samples: its chunk is too close behind the writer to be fetched a period
       // ahead; a delay time that jumped): from memory, complete there since the flush that ended its eight samples
+#ifdef MLGPU_RING_X_MISSPOISON
+      if (!(inW || inR)) y = 12345.f; else
+#endif
       if (!(inW || inR)) y = __hip_atomic_load(chunkOf(m, ringIdx, lane, r) + (r & (kTChunk - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // The wait for that load belongs INSIDE this branch. Left to the join below, the compiler guards every later use of y with
+      // s_waitcnt vmcnt(0) on the path that never loaded anything too - a memory round trip per sample behind the newest store,
+      // 1 024 per launch: it was what made this layout slower than layout 1 with less traffic (1.82 -> 1.34 ms without this branch,
+      // profiles/r05_ring_layouts.txt). A use of y here puts the wait here.
+      asm volatile("" : "+v"(y));
     }
-    if ((w & (kTWrite - 1)) == kTWrite - 1) flushT(m, ringIdx, w & ~(uint32_t)(kTWrite - 1));
+#endif
+    if ((w & (kTWrite - 1)) == kTWrite - 1)
+    {
+      flushT(m, ringIdx, w & ~(uint32_t)(kTWrite - 1));
+      keepHistory(m, ringIdx, w & ~(uint32_t)(kTWrite - 1));
+    }
     w = (w + 1) & m.memMask;
     return y;
   }

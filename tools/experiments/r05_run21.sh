@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_delays.py -x -q -m gpu 2>&1 | tail -3
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%.3f ms per launch  frac %.3f' % (r['kernel_ms'], r['frac']))"; }
+for i in 1 2; do
+echo "## layout 0: $(MLGPU_DELAY_WINDOWS=0 timeout 300 python bench.py --no-cpu-baseline --workload strings 2>/dev/null | tail -1 | line)"
+echo "## layout 1: $(MLGPU_DELAY_WINDOWS=1 timeout 300 python bench.py --no-cpu-baseline --workload strings 2>/dev/null | tail -1 | line)"
+echo "## layout 2: $(MLGPU_DELAY_WINDOWS=2 timeout 300 python bench.py --no-cpu-baseline --workload strings 2>/dev/null | tail -1 | line)"
+done
+export MLGPU_CACHE_DIR=off
+for x in NOFLUSH NOLOAD NOMISS; do
+echo "## layout 2 $x: $(MLGPU_JIT_EXTRA_OPTS=-DMLGPU_RING_X_$x MLGPU_DELAY_WINDOWS=2 timeout 300 python bench.py --no-cpu-baseline --workload strings 2>/dev/null | tail -1 | line)"
+done
+echo "## allpass4 layout 1: $(MLGPU_DELAY_WINDOWS=1 timeout 300 python bench.py --no-cpu-baseline --workload allpass4 2>/dev/null | tail -1 | line)"
+echo "## allpass4 layout 2: $(MLGPU_DELAY_WINDOWS=2 timeout 300 python bench.py --no-cpu-baseline --workload allpass4 2>/dev/null | tail -1 | line)"
