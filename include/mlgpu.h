@@ -555,11 +555,11 @@ int mlgpu_graph_set_max_delay(mlgpu_graph* g, int proc_node, float max_delay_in_
  * neighbouring voices use the same delay times. 1: [256-voice block][sample / 8][voice][8] — a voice moves its samples in
  * 32-byte sectors through LDS windows, so no bandwidth is wasted when delay times differ from voice to voice (DESIGN.md
  * §3.6); costs 8 KiB of LDS per ring per workgroup, at most 20 rings per graph. 2 (round 5): [256-voice block][sample / 16][voice][16]
- * moved as 64-byte pieces by four neighbouring lanes on a wave-uniform clock, read windows in LDS, requests a period ahead: the
- * algorithmic traffic and not a byte more (0.99 x measured against 1.13 x for layout 1), for whole wavefronts (voices a multiple of
- * 64) and at most 4 rings per graph (40 KiB of LDS per ring) - but not faster than layout 1 on this chip
- * (profiles/r05_ring_layouts.txt), which therefore stays the one to use for per-voice delay times. Same results in every layout
- * for delay times within the node's maximum (graph_set_max_delay). */
+ * moved as whole 64-byte pieces by neighbouring lanes on a wave-uniform clock, read windows in LDS, requests a period ahead, a
+ * voice's own recent samples kept there for short delay times: the algorithmic traffic and not a byte more (0.98 x measured
+ * against 1.13 x for layout 1) at 0.72-0.74 of the HBM peak against 0.56-0.59 (profiles/r05_ring_layouts.txt) - the one to use
+ * for per-voice delay times where it applies: whole wavefronts (voices a multiple of 64) and at most 4 rings per graph (40 KiB
+ * of LDS per ring and workgroup). Same results in every layout for delay times within the node's maximum (graph_set_max_delay). */
 int mlgpu_graph_set_delay_layout(mlgpu_graph* g, int windowed);
 /* One-vector feedback: a DSPVector the reference keeps from one process call to the next (Allpass::vy1
  * MLDSPFilters.h:1115, FDN::mDelayInputVectors :1168, FeedbackDelayFunction::vy1 MLDSPFunctional.h:276, or a user's

@@ -1251,7 +1251,9 @@ constexpr bool kRingWindows = MLGPU_RING_WINDOWS != 0;  // fixed per generated k
 // period ahead of its first use, so no sample waits for memory (layout 1 refilled lane by lane whenever a lane crossed a sector:
 // a divergent load and a memory round trip on almost every sample of a wavefront whose voices have different delay times, and its
 // read window was eight registers behind a seven-select chain). Windows live in LDS, one strip per wavefront and ring:
-// rows 0..7 the eight samples being written (stored as 32-byte halves of a piece), rows 8..39 two chunks being read, 64 floats per
+// rows 0..7 the eight samples being written (a chunk's first eight parked in registers until its second eight are there: what
+// goes to memory is whole 64-byte pieces), rows 8..39 the 32 ring positions being read - two prefetched chunks, or, for a lane
+// that reads closer than three chunks behind the writer, its own last 32 samples - 64 floats per
 // row (lane = column: an access with the lane as the fast index touches every bank twice, whatever the row). 10 KiB per wavefront:
 // a CU holds its sixteen wavefronts of a 262 144-voice bank at once (with 12.5 KiB - a 16-sample write window - three of four
 // workgroups fit and the fourth runs alone afterwards: twice the launch time, measured).
@@ -1307,7 +1309,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   {
     if (kRingTransposed)
     {
-      if (uniformW) flushT(m, ringIdx, w & ~(uint32_t)(kTWrite - 1));
+      if (uniformW) flushLast(m, ringIdx);
     }
     else if (kRingWindows) flush(m, ringIdx, w & ~(uint32_t)(kRingWindow - 1));
   }
@@ -1377,6 +1379,8 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     lo = len = 0;
     hist = false;
     primed = false;
+    parked = false;
+    park[0] = park[1] = f32x4r{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) stage[i] = f32x4r{0.f, 0.f, 0.f, 0.f};
     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
@@ -1393,32 +1397,84 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       for (int e = 0; e < 4; ++e) col[(4 * j + e) * kTRowPad] = a[e];
     }
   }
-  // the write window to memory, transposed: instruction mm stores 16 bytes (lane & 1) of lane (mm * 32 + lane / 2)'s 32-byte half
-  // piece; halfStart = the ring position of the window's first sample (a multiple of 8)
-  MLD void flushT(const VoiceMem& m, int ringIdx, uint32_t halfStart) const
+  // The write window to memory, transposed: lane L handles 16 bytes (L & 1) of the 32-byte half piece of lanes L / 2 and 32 + L / 2;
+  // halfStart = the ring position of the window's first sample (a multiple of 8). A chunk's FIRST half is only read out of LDS
+  // and parked in eight registers; when its second half is complete both go out in neighbouring instructions, so that what
+  // reaches memory is whole 64-byte pieces: half pieces eight samples (10 us) apart are two partial writes of a line the L2 has
+  // evicted in between, and cost what whole ones cost (measured: 1.25 -> 1.12 ms per launch of the strings workload with the
+  // traffic pattern of this form, profiles/r05_ring_layouts.txt). `last`: the launch ends here, nothing stays parked.
+  f32x4r park[2];
+  bool parked;  // (the same in every lane)
+  MLD void readHalf(const VoiceMem& m, int ringIdx, f32x4r (&a)[2]) const
   {
-#ifdef MLGPU_RING_X_NOFLUSH  // (elimination experiments: wrong results, used to find what a launch waits for - profiles/r05_ring_layouts.txt)
-    return;
-#endif
     const uint32_t lane = threadIdx.x & 63u, j = lane & 1u;
     const float* row0 = strip(m, ringIdx) - lane;  // column 0 of row 0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#ifdef MLGPU_RING_X_FULLPIECE  // (what whole 64-byte pieces would cost: nothing at the first half, both halves - the first with wrong data - at the second)
-    if ((halfStart & (uint32_t)kTWrite) == 0) return;
-#endif
 #pragma unroll
     for (int mm = 0; mm < 2; ++mm)
     {
-      const uint32_t other = (uint32_t)mm * 32u + (lane >> 1);
-      const float* src = row0 + (4 * j) * kTRowPad + other;
-      const f32x4r a = {src[0], src[kTRowPad], src[2 * kTRowPad], src[3 * kTRowPad]};
-      *((f32x4r*)(chunkOf(m, ringIdx, other, halfStart) + (halfStart & (uint32_t)kTWrite)) + j) = a;
-#ifdef MLGPU_RING_X_FULLPIECE
-      *((f32x4r*)(chunkOf(m, ringIdx, other, halfStart)) + j) = a;
-#endif
+      const float* src = row0 + (4 * j) * kTRowPad + (uint32_t)mm * 32u + (lane >> 1);
+      a[mm] = f32x4r{src[0], src[kTRowPad], src[2 * kTRowPad], src[3 * kTRowPad]};
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  // half `second` (0 / 1) of the chunk at ring position chunkStart
+  MLD void storeHalf(const VoiceMem& m, int ringIdx, uint32_t chunkStart, uint32_t second, const f32x4r (&a)[2]) const
+  {
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 1u;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+      *((f32x4r*)(chunkOf(m, ringIdx, (uint32_t)mm * 32u + (lane >> 1), chunkStart) + second * (uint32_t)kTWrite) + j) = a[mm];
+  }
+  MLD void storeBoth(const VoiceMem& m, int ringIdx, uint32_t chunkStart, const f32x4r (&a0)[2], const f32x4r (&a1)[2]) const
+  {
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 1u;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+    {
+      f32x4r* piece = (f32x4r*)chunkOf(m, ringIdx, (uint32_t)mm * 32u + (lane >> 1), chunkStart);
+      piece[j] = a0[mm];
+      piece[2 + j] = a1[mm];
+    }
+  }
+  MLD void flushT(const VoiceMem& m, int ringIdx, uint32_t halfStart)
+  {
+#ifdef MLGPU_RING_X_NOFLUSH  // (elimination experiments: wrong results, used to find what a launch waits for - profiles/r05_ring_layouts.txt)
+    return;
+#endif
+    f32x4r a[2];
+    readHalf(m, ringIdx, a);
+    if ((halfStart & (uint32_t)kTWrite) == 0)
+    {
+      park[0] = a[0];
+      park[1] = a[1];
+      parked = true;
+      return;
+    }
+    if (parked) storeBoth(m, ringIdx, halfStart & ~(uint32_t)(kTChunk - 1), park, a);
+    else storeHalf(m, ringIdx, halfStart & ~(uint32_t)(kTChunk - 1), 1u, a);
+    parked = false;
+  }
+  // launch end: the partly filled write window (all eight positions: beginT brought the others in) and what is parked
+  MLD void flushLast(const VoiceMem& m, int ringIdx) const
+  {
+    f32x4r a[2];
+    readHalf(m, ringIdx, a);
+    const uint32_t chunkStart = w & ~(uint32_t)(kTChunk - 1);
+    if ((w & (uint32_t)kTWrite) == 0) storeHalf(m, ringIdx, chunkStart, 0u, a);
+    else if (parked) storeBoth(m, ringIdx, chunkStart, park, a);
+    else storeHalf(m, ringIdx, chunkStart, 1u, a);
+  }
+  // a read that goes to memory (sampleT's last resort) must find the parked half there
+  MLD void unpark(const VoiceMem& m, int ringIdx)
+  {
+    if (!parked) return;
+#ifdef MLGPU_RING_X_NOUNPARK  // (shows that the tests reach this: tests/test_gpu_delays.py fails with it)
+    return;
+#endif
+    storeHalf(m, ringIdx, w & ~(uint32_t)(kTChunk - 1), 0u, park);
+    parked = false;
   }
   // one round of transposed loads: every lane names a chunk (kTNone: none); the pieces land in `out` of the four loader lanes.
   // UNCONDITIONAL loads (a lane that names no chunk gets the piece at `spare`, a ring position whose chunk is complete in memory,
@@ -1595,6 +1651,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     {
       // a sample no window holds (a delay of 8 to 47 samples: its chunk is too close behind the writer to be fetched a period
       // ahead; a delay time that jumped): from memory, complete there since the flush that ended its eight samples
+      unpark(m, ringIdx);
 #ifdef MLGPU_RING_X_MISSPOISON
       if (!(inW || inR)) y = 12345.f; else
 #endif

@@ -244,13 +244,15 @@ def test_delay_rules(eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("unequal_w", [False, True])
+@pytest.mark.parametrize("unequal_w", [False, True, 5, 8, 13])
 def test_transposed_rings_every_kind_of_lane(eng, oracle, unequal_w):
     """Layout 2 on the bench's plucked-string voice (noise burst -> FractionalDelay of per-voice length -> OnePole -> one-vector
     feedback), 256 voices whose delay times cover every path of the transposed windows: under 8 samples (served from the write
-    window), 8-47 (memory, sample by sample: too close behind the writer to fetch a period ahead), and up to the ring's maximum
-    (the prefetched read windows), several launches with carried state; and the same with the write indices of one wavefront set
-    apart by the host (that wavefront then runs its plain per-sample form). Against the streaming oracle and against layout 0."""
+    window), 8-47 (too close behind the writer to fetch a period ahead: the lane's own history, kept in its read rows), and up to
+    the ring's maximum (the prefetched read windows), several launches with carried state; the same with the write indices of one
+    wavefront set apart by the host (that wavefront then runs its plain per-sample form); and with every voice's write index at
+    5 / 8 / 13 (launches that begin inside a chunk: its first half is in memory and not in the windows, its second half goes out
+    alone). Against the streaming oracle and against layout 0."""
     import madronalib_amd as ml
     V, T, launches = 256, 6, 3
     desc = [dict(name="x", type="input"), dict(name="g", type="const", value=0.995),
@@ -272,7 +274,9 @@ def test_transposed_rings_every_kind_of_lane(eng, oracle, unequal_w):
         fs = np.stack([oracle.fractional_delay_state(float(d)) for d in length], 1)     # [2][V]: delayInt bits, allpass coefficient
         st["line"][3] = fs[0].view(np.uint32)
         st["line"][4] = fs[1].view(np.uint32)
-        if unequal_w:
+        if unequal_w is not True and unequal_w:
+            st["line"][0, :] = unequal_w
+        elif unequal_w:
             st["line"][0, 64:128] = (np.arange(64, dtype=np.uint32) * 7) % 1024          # the second wavefront: write indices all over the ring
         for i in range(st["line"].shape[0]):
             g.set_state("line", i, st["line"][i])
@@ -288,3 +292,31 @@ def test_transposed_rings_every_kind_of_lane(eng, oracle, unequal_w):
         g.close()
     assert_bits_equal(outs[2], outs[0], True, "layout 2 vs layout 0")
     assert np.abs(outs[0]).max() > 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w0", [0, 3, 8, 12])
+@pytest.mark.parametrize("name", ["integer_var", "pitchbend", "frac_ticks"])
+def test_transposed_rings_moving_delay_times(eng, oracle, name, w0):
+    """Layout 2 with delay times that move while it runs (steps between 0 and the maximum at random moments, slow sweeps): lanes go
+    back and forth between the prefetched windows, their own history and - for the samples after a jump that neither holds - memory,
+    where the half chunk the wavefront still had parked in registers must have arrived first. Launches beginning at any place of a
+    chunk. Bit for bit the oracle, and layout 0."""
+    from graph_oracle import ring_len
+    V, T = 256, 7
+    c = delay_case(oracle, name, V, 2 * T, seed=31 + w0)
+    st0 = c["state0"].copy()
+    st0[0] = w0
+    got = {}
+    for layout in (0, 2):
+        g, names = delay_graph(eng, V, c["kind"], len(c["inputs"]), c["max_delay"], layout)
+        got[layout] = run_delay(g, names, st0, c["inputs"], T, Layout.QUAD)
+        g.close()
+    rings = 2 if c["kind"] == Proc.PITCHBENDABLE_DELAY else 1
+    st, mem = st0.copy(), np.zeros((V, rings, ring_len(c["max_delay"])), np.float32)
+    for call in range(2):
+        sl = slice(call * 64 * T, (call + 1) * 64 * T)
+        want = oracle.delay_process(c["kind"], T, st, mem, [np.ascontiguousarray(a[:, sl]) for a in c["inputs"]])
+        for layout in (0, 2):
+            assert_bits_equal(got[layout][0][call], want, True, f"{name} w0={w0} layout {layout} call {call}")
+            assert_bits_equal(got[layout][1][call], st, False, f"{name} w0={w0} layout {layout} state after call {call}")

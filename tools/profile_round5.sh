@@ -18,6 +18,7 @@ EXTRA="--voices 4194304" tools/gpu_profile_all.sh r05 cfg2 > $O/prof_cfg2.log 2>
 tools/gpu_profile_all.sh r05 cfg2 > $O/prof_cfg2s.log 2>&1; fin profiles_cfg2_32MiB
 tools/gpu_profile_all.sh r05 synth synthrows events resample > $O/prof_wide.log 2>&1; fin profiles_wide
 MLGPU_DELAY_WINDOWS=1 tools/gpu_profile_all.sh r05 strings > $O/prof_strings.log 2>&1; fin profiles_strings_windows
+MLGPU_DELAY_WINDOWS=2 tools/gpu_profile_all.sh r05 strings > $O/prof_strings2.log 2>&1; fin profiles_strings_transposed
 cp profiles/pmc_workloads.json $O/pmc_workloads.json
 python tools/check_pmc_fresh.py > $O/pmc_fresh.txt 2>&1
 # the north_star target, paced, under kernel stats
@@ -54,6 +55,7 @@ for k, c in sorted(acc.items()):
         print(f"{k[:24]:24s} {m[0]:13.3f} {m[1]:18.3f} {m[2]:11.3f} {m[3]:13.3f} {len(rows):9d}")
 PY
 for w in cfg3 cfg4 cfg5 cfg5full cfg2 synth synthrows; do $B --workload $w 2>/dev/null | tail -1 > $O/${w}_line.json; echo "## $w"; cat $O/${w}_line.json | line; done > $O/lines.txt 2>&1
+for l in 1 2; do MLGPU_DELAY_WINDOWS=$l $B --workload strings 2>/dev/null | tail -1 > $O/strings_layout${l}_line.json; echo "## strings, delay layout $l"; cat $O/strings_layout${l}_line.json | line; done >> $O/lines.txt 2>&1
 ( time python bench.py ) 2> $O/default_bench.time | tail -1 > $O/default_bench.json
 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $O/gpu_tests.txt
 for dd in $O/profiles_*; do python tools/summarize_profiles.py $dd r05 > $dd/summary.md 2>/dev/null; done
