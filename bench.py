@@ -1328,6 +1328,9 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=30.0)
     ap.add_argument("--print-case", action="store_true", help="print the key of this case in profiles/pmc_workloads.json and exit")
     args = ap.parse_args()
+    if args.workload == "strings":
+        # per-voice delay times: the transposed ring layout is the one a host should choose (round 5; 0 and 1 for comparison)
+        os.environ.setdefault("MLGPU_DELAY_WINDOWS", "2")
     if args.print_case:
         dV, dT, _ = WORKLOADS[args.workload]
         print(workload_key(args.workload, args.voices or dV, args.vectors or dT))
