@@ -3219,7 +3219,7 @@ class VoiceProgram
       if (g_) mlgpu_graph_destroy(g_);
       g_ = nullptr;
       eng_.check(mlgpu_graph_create(e.handle(), voices, &g_));
-      if (opt.delayWindows) eng_.check(mlgpu_graph_set_delay_layout(g_, 1));
+      if (opt.delayWindows) eng_.check(mlgpu_graph_set_delay_layout(g_, 3));  // transposed pieces where they apply, else sectors
       if (opt.autotune) eng_.check(mlgpu_graph_set_autotune(g_, 1));
       if (opt.liveConstants) eng_.check(mlgpu_graph_set_live_constants(g_, 1));
       int rowNode[kNumVoiceOutputRows];

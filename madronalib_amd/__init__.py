@@ -982,8 +982,9 @@ class Graph:
         engine._children.add(self)
         if voices_per_lane:
             engine._check(self.L.mlgpu_graph_set_voices_per_lane(self.h, int(voices_per_lane)))
-        if delay_windows:   # True / 1: 32-byte sectors behind LDS windows; 2: transposed 64-byte pieces on a wave-uniform clock
-            engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 2 if delay_windows == 2 else 1))
+        if delay_windows:   # True / 1: 32-byte sectors behind LDS windows; 2: transposed 64-byte pieces on a wave-uniform clock;
+            # 3 / "best": 2 where it applies (voices a multiple of 64, at most four rings), else 1
+            engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 3 if delay_windows in (3, "best") else (2 if delay_windows == 2 else 1)))
         if autotune:
             engine._check(self.L.mlgpu_graph_set_autotune(self.h, 1))
         if live_constants:
@@ -1012,6 +1013,11 @@ class Graph:
     def device_bytes(self):
         """Device memory the compiled graph owns (mlgpu_graph_device_bytes)."""
         return int(self.L.mlgpu_graph_device_bytes(self.h))
+
+    @property
+    def delay_layout(self):
+        """The delay-ring layout in effect (mlgpu_graph_delay_layout): 0 rows, 1 sectors, 2 transposed pieces."""
+        return self._ret(self.L.mlgpu_graph_delay_layout(self.h), None)
 
     def workgroups_per_cu(self):
         """Workgroups of this graph's kernel a CU holds at once (mlgpu_graph_workgroups_per_cu)."""

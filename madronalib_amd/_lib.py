@@ -207,6 +207,7 @@ def _declare(L):
     sig("mlgpu_graph_set_input_layout", i, [vp, i, i])
     sig("mlgpu_graph_set_voices_per_lane", i, [vp, i])
     sig("mlgpu_graph_set_delay_layout", i, [vp, i])
+    sig("mlgpu_graph_delay_layout", i, [vp])
     sig("mlgpu_graph_device_bytes", sz, [vp])
     sig("mlgpu_graph_set_autotune", i, [vp, i])
     sig("mlgpu_graph_tuning", i, [vp, c.POINTER(i), c.POINTER(i)])

@@ -477,6 +477,7 @@ struct mlgpu_graph
   size_t memFloatsPerVoice{0};
   bool windowedRings{false};     // rings as [block][chunk][lane][8] behind LDS windows (mlgpu_graph_set_delay_layout)
   bool fbAhead{true};            // kept DSPVectors (feedback nodes) are fetched two quads ahead; MLGPU_GRAPH_FB_AHEAD=0 for A / B
+  bool transposedIfPossible{false};  // graph_set_delay_layout(3)
   bool transposedRings{false};   // layout 2: [block][chunk][lane][16], every global access a 64-byte piece made by four lanes, on a wave-uniform clock (implies windowedRings)
   int totalRings{0};
   size_t memVoices() const { return windowedRings ? ((V + 255) & ~(size_t)255) : V; }  // voices the ring memory is laid out for
@@ -1922,6 +1923,8 @@ extern "C"
       memFloats += n.ringLen * (size_t)mlgpu_proc_rings(n.kind);
     }
     g->memFloatsPerVoice = memFloats;
+    if (g->transposedIfPossible)
+      g->transposedRings = g->V % 64 == 0 && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) <= 160 * 1024;
     if (g->transposedRings && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 needs 40 KiB of LDS per ring; at most 4 rings per graph (layout 1 for more)");
     if (!g->transposedRings && g->windowedRings && (size_t)g->totalRings * 8 * 256 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
@@ -2198,10 +2201,11 @@ extern "C"
     if (!g) return MLGPU_ERR_INVALID;
     if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
-    if (windowed < 0 || windowed > 2) return gfail(g, MLGPU_ERR_INVALID, "graph_set_delay_layout: 0 (rows), 1 (32-byte sectors) or 2 (transposed 64-byte pieces)");
+    if (windowed < 0 || windowed > 3) return gfail(g, MLGPU_ERR_INVALID, "graph_set_delay_layout: 0 (rows), 1 (32-byte sectors), 2 (transposed 64-byte pieces) or 3 (2 where it applies, else 1)");
     if (windowed == 2 && (g->V % 64)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_set_delay_layout(2): whole wavefronts only (a number of voices that is a multiple of 64)");
     g->windowedRings = windowed != 0;
     g->transposedRings = windowed == 2;
+    g->transposedIfPossible = windowed == 3;   // decided at compile, when the number of rings is known
     return MLGPU_OK;
   }
 
@@ -2288,6 +2292,14 @@ extern "C"
     if (hipSetDevice(g->e->device) != hipSuccess) return -MLGPU_ERR_HIP;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, g->fn, 256, 0) != hipSuccess) return -MLGPU_ERR_HIP;
     return n;
+  }
+
+  // the ring layout in effect (after compile: what layout 3 came out as)
+  int mlgpu_graph_delay_layout(mlgpu_graph* g)
+  {
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (g->transposedIfPossible && !g->compiled) return 3;
+    return g->transposedRings ? 2 : (g->windowedRings ? 1 : 0);
   }
 
   int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n)

@@ -233,7 +233,19 @@ def test_delay_rules(eng):
     with pytest.raises(ml.MlgpuError) as ei:
         ml.Graph(eng, 100, delay_windows=2)                      # ... and whole wavefronts only
     assert ei.value.status == ml.Status.ERR_UNSUPPORTED
+    # layout 3 = "per-voice delay times, the best form that applies": decided by compile
+    for V, n_delays, want in ((256, 4, 2), (256, 5, 1), (200, 1, 1)):
+        g = ml.Graph(eng, V, delay_windows="best")
+        assert g.delay_layout == 3
+        a = g.add("a", "input")
+        for i in range(n_delays):
+            g.add(f"d{i}", "proc", Proc.INTEGER_DELAY, [a], max_delay=100.0)
+        g.add_output(f"d{n_delays - 1}")
+        g.compile()
+        assert g.delay_layout == want, (V, n_delays, g.delay_layout)
+        g.close()
     g3 = ml.Graph(eng, 1000, delay_windows=False)
+    assert g3.delay_layout == 0
     a = g3.add("a", "input")
     g3.add("d", "proc", Proc.PITCHBENDABLE_DELAY, [a, a], max_delay=1000.0)
     g3.add_output("d")
