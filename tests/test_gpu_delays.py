@@ -332,3 +332,16 @@ def test_transposed_rings_moving_delay_times(eng, oracle, name, w0):
         for layout in (0, 2):
             assert_bits_equal(got[layout][0][call], want, True, f"{name} w0={w0} layout {layout} call {call}")
             assert_bits_equal(got[layout][1][call], st, False, f"{name} w0={w0} layout {layout} state after call {call}")
+
+
+@pytest.mark.gpu
+def test_transposed_rings_random_graphs(eng):
+    """A short run of tools/ring_layout_soak.py: random delay nodes, ring sizes, delay-time signals (constant, stepped, swept through
+    the short / long boundary, a new one every sample), launch lengths and write indices - layout 2 against layout 0, outputs and
+    state words bit for bit. (1 650 cases of it on the round's closing code: profiles/r05_ring_layout_soak.txt.)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("ring_layout_soak", os.path.join(os.path.dirname(__file__), "..", "tools", "ring_layout_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(40, 11, eng) == 0

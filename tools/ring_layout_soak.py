@@ -34,11 +34,9 @@ def delays(rng, kind, V, S, dmax):
     return mode, np.ascontiguousarray(d)
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(cases, seed, eng=None):
     rng = np.random.default_rng(seed)
-    eng = ml.Engine(0)
+    eng = eng or ml.Engine(0)
     bad, nonzero, total = 0, 0, 0
     for case in range(cases):
         kind = [Proc.INTEGER_DELAY, Proc.FRACTIONAL_DELAY, Proc.PITCHBENDABLE_DELAY][int(rng.integers(0, 3))]
@@ -89,8 +87,8 @@ def main():
             bad += 1
             print(f"case {case}: kind {int(kind)} V {V} T {T} launches {launches} max delay {dmax} delay mode {mode} write-index mode {wmode}: {diff} words differ")
     print(f"{cases} cases (seed {seed}), {total} output samples, {nonzero / max(1, total):.3f} of them nonzero: {bad} cases with a difference between ring layout 2 and layout 0")
-    return 1 if bad else 0
+    return bad
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 120, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
