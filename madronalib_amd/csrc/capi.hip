@@ -856,6 +856,40 @@ extern "C"
     return mlgpu_upload(b->e, b->d_inConst, h, sizeof(float) * b->V);
   }
 
+  // bank_process + mixdown(gains = NULL) without the voices' signals in between: the voice kernel adds up each wavefront's 64 voices
+  // itself (chain_mix_kernel: the first stage's tree, the same bits), the later stages follow
+  int mlgpu_bank_process_mixdown(mlgpu_bank* b, size_t T, const float* d_in, int inLayout, float* d_out)
+  {
+    if (!b) return MLGPU_ERR_INVALID;
+    mlgpu_engine* e = b->e;
+    if (T == 0) return MLGPU_OK;
+    if (!d_out) return fail(e, MLGPU_ERR_INVALID, "bank_process_mixdown: null output");
+    if (d_in && (inLayout < 0 || inLayout > MLGPU_LAYOUT_BROADCAST)) return fail(e, MLGPU_ERR_INVALID, "bank_process_mixdown: bad layout");
+    if ((((uintptr_t)d_out) | ((uintptr_t)d_in)) & 15) return fail(e, MLGPU_ERR_INVALID, "bank_process_mixdown: signals must be 16-byte aligned");
+    const size_t V = b->V;
+    if (!b->fused || !b->fused->launchMixSignal || (V % 64))
+      return fail(e, MLGPU_ERR_UNSUPPORTED, "bank_process_mixdown: for the fused voice chains and whole wavefronts (voices a multiple of 64) - use bank_process and mixdown");
+    const size_t groups = V / 64;
+    if ((groups + (groups + 63) / 64) * T * 64 > e->mixScratchFloats)
+      return fail(e, MLGPU_ERR_INVALID, "bank_process_mixdown: call mlgpu_mixdown_reserve(engine, max voices, max vectors) at setup (process calls do not allocate)");
+    HIP_TRY(e, hipSetDevice(e->device));
+    ChainArgs a;
+    a.V = V;
+    a.T = T;
+    a.flags = e->kflags;
+    a.impulseTable = e->d_impulseTable;
+    a.inConst = b->d_inConst;
+    a.coeffs = b->d_coeffs;
+    a.state = b->d_state;
+    a.in = makeView(d_in, inLayout, V, T);
+    a.out = makeView(nullptr, MLGPU_LAYOUT_QUAD, V, T);
+    a.mix = e->d_mixScratch;
+    hipError_t err = d_in ? b->fused->launchMixSignal(a, e->stream, e->cuCount) : b->fused->launchMixConst(a, e->stream, e->cuCount);
+    if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "bank_process_mixdown launch", err);
+    HIP_TRY(e, mlgpu_launch_mixdown_rows(groups, T, e->d_mixScratch, d_out, e->stream, e->kflags));
+    return MLGPU_OK;
+  }
+
   int mlgpu_bank_process(mlgpu_bank* b, size_t T, const float* d_in, int inLayout, float* d_out, int outLayout)
   {
     if (!b) return MLGPU_ERR_INVALID;
@@ -869,6 +903,7 @@ extern "C"
     const size_t V = b->V;
 
     ChainArgs a;
+    a.mix = nullptr;
     a.V = V;
     a.flags = e->kflags;
     a.impulseTable = e->d_impulseTable;

@@ -29,6 +29,14 @@ hipError_t launchChain(const ChainArgs& a, hipStream_t stream, int /*cuCount*/)
   return hipGetLastError();
 }
 
+template <bool HAS_SIGNAL, int... KS>
+hipError_t launchChainMix(const ChainArgs& a, hipStream_t stream, int /*cuCount*/)
+{
+  const unsigned blocks = (unsigned)((a.V + kChainBlock - 1) / kChainBlock);
+  hipLaunchKernelGGL((chain_mix_kernel<Chain<KS...>, HAS_SIGNAL>), dim3(blocks), dim3(kChainBlock), 0, stream, a);
+  return hipGetLastError();
+}
+
 // How many wavefront lanes share one channel of a head-less SVF cascade (cascade_lanes_kernel). One lane per channel is the
 // cheapest per sample, but a bank needs ~49 000 channels before its wavefronts (two per SIMD at ~190 VGPRs) fill the chip;
 // smaller banks are spread over 2 or 4 lanes per channel (4 or 6 wavefronts per SIMD). Thresholds from
@@ -140,6 +148,16 @@ ChainEntry makeEntry(const char* name)
   return e;
 }
 
+// ... and with the form that sums the voices in the kernel (mlgpu_bank_process_mixdown): the fused voice chains
+template <int... KS>
+ChainEntry makeMixEntry(const char* name)
+{
+  ChainEntry e = makeEntry<KS...>(name);
+  e.launchMixSignal = &launchChainMix<true, KS...>;
+  e.launchMixConst = &launchChainMix<false, KS...>;
+  return e;
+}
+
 #define P(x) MLGPU_PROC_##x
 
 const std::vector<ChainEntry>& registry()
@@ -172,9 +190,9 @@ const std::vector<ChainEntry>& registry()
       makeEntry<P(SAMPLE_ACCURATE_LINEAR_GLIDE)>("chain_kernel<SampleAccurateLinearGlide>"),
       makeEntry<P(ALLPASS1)>("chain_kernel<Allpass1>"),
       // fused chains of the BASELINE.json configs
-      makeEntry<P(SINE_GEN), P(LOPASS)>("chain_kernel<SineGen,Lopass>"),                       // config 1
-      makeEntry<P(SAW_GEN), P(BANDPASS), P(GAIN)>("chain_kernel<SawGen,Bandpass,Gain>"),       // config 3
-      makeEntry<P(SAW_GEN), P(BANDPASS)>("chain_kernel<SawGen,Bandpass>"),
+      makeMixEntry<P(SINE_GEN), P(LOPASS)>("chain_kernel<SineGen,Lopass>"),                       // config 1
+      makeMixEntry<P(SAW_GEN), P(BANDPASS), P(GAIN)>("chain_kernel<SawGen,Bandpass,Gain>"),       // config 3
+      makeMixEntry<P(SAW_GEN), P(BANDPASS)>("chain_kernel<SawGen,Bandpass>"),
       makeCascadeEntry<P(LOPASS), 8>("cascade_kernel<Lopass x8>"),                             // config 4
       makeCascadeEntry<P(LOPASS), 8, P(NOISE_GEN)>("cascade_kernel<NoiseGen,Lopass x8>"),
       // shorter / other SVF cascades (filter banks, steeper slopes)
@@ -186,9 +204,9 @@ const std::vector<ChainEntry>& registry()
       makeCascadeEntry<P(BANDPASS), 4>("cascade_kernel<Bandpass x4>"),
       makeCascadeEntry<P(LOPASS), 4, P(SAW_GEN)>("cascade_kernel<SawGen,Lopass x4>"),
       // other common voices
-      makeEntry<P(PULSE_GEN), P(HIPASS), P(ONE_POLE)>("chain_kernel<PulseGen,Hipass,OnePole>"),
-      makeEntry<P(SAW_GEN), P(LOPASS), P(GAIN)>("chain_kernel<SawGen,Lopass,Gain>"),
-      makeEntry<P(SINE_GEN), P(GAIN)>("chain_kernel<SineGen,Gain>"),
+      makeMixEntry<P(PULSE_GEN), P(HIPASS), P(ONE_POLE)>("chain_kernel<PulseGen,Hipass,OnePole>"),
+      makeMixEntry<P(SAW_GEN), P(LOPASS), P(GAIN)>("chain_kernel<SawGen,Lopass,Gain>"),
+      makeMixEntry<P(SINE_GEN), P(GAIN)>("chain_kernel<SineGen,Gain>"),
   };
   return r;
 }

@@ -27,12 +27,45 @@ constexpr int kChainBlock = 256;
 #endif
 constexpr int kTurnClockShift = 13;  // 82 us per turn (graph kernels: the best of 2^7 .. 2^18 ticks, profiles/r04_take_turns.txt)
 
+// ---- the voices of a wavefront summed inside the voice kernel (chain_mix_kernel) ----
+// mlgpu_mixdown's first stage - the balanced tree over 64 consecutive voices, a[i] += a[i + d] for d = 1, 2 ... 32 - without the
+// voices' signals ever reaching memory: 16 samples (four quads) of the 64 lanes are parked in an LDS strip of the wavefront, lane
+// (s = lane & 15, g = lane >> 4) adds up sample s of voices 16 g .. 16 g + 15 in tree order, and two lane exchanges add the four
+// quarters as the tree does. Row of voice L at 20 L + 16 (L >> 4) floats: 16-byte aligned for the b128 writes, and the 64 column
+// reads of a step fall on 64 different banks.
+constexpr int kMixStrip = 64 * 20 + 3 * 16 + 16;  // floats per wavefront
+template <int LO, int N>
+struct MixTree16
+{
+  static __device__ __forceinline__ float sum(const float* col) { return MixTree16<LO, N / 2>::sum(col) + MixTree16<LO + N / 2, N / 2>::sum(col); }
+};
+template <int LO>
+struct MixTree16<LO, 1>
+{
+  static __device__ __forceinline__ float sum(const float* col) { return col[LO * 20]; }
+};
+
+template <bool MIX>
+struct MixStrips
+{
+  static __device__ __forceinline__ float* mine() { return nullptr; }
+};
+template <>
+struct MixStrips<true>
+{
+  static __device__ __forceinline__ float* mine()
+  {
+    __shared__ __attribute__((aligned(16))) float lds[(256 / 64) * kMixStrip];
+    return lds + (threadIdx.x >> 6) * kMixStrip;
+  }
+};
+
 // the streaming loop of one voice: T DSPVectors, 16 quads each, one 16-byte access per quad
-template <class CH, bool HAS_SIGNAL, bool FAST_HEAD>
-__device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, float xc)
+template <class CH, bool HAS_SIGNAL, bool FAST_HEAD, bool MIX = false>
+__device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, float xc, float* strip = nullptr)
 {
   const f32x4* pin = HAS_SIGNAL ? (const f32x4*)a.in.base + v * a.in.strideV : nullptr;
-  f32x4* pout = (f32x4*)a.out.base + v * a.out.strideV;
+  f32x4* pout = MIX ? nullptr : (f32x4*)a.out.base + v * a.out.strideV;
   const size_t inQ = a.in.strideQ, outQ = a.out.strideQ;
 #if MLGPU_CHAIN_TURNS
   const uint32_t slot = wave_slot();
@@ -40,7 +73,7 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
   for (size_t t = 0; t < a.T; ++t)
   {
     const f32x4* pi = HAS_SIGNAL ? pin + t * a.in.strideT : nullptr;
-    f32x4* po = pout + t * a.out.strideT;
+    f32x4* po = MIX ? nullptr : pout + t * a.out.strideT;
 #pragma unroll 4
     for (int q = 0; q < 16; ++q)
     {
@@ -54,17 +87,37 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
       y.y = ch.template next_head<FAST_HEAD>(x.y);
       y.z = ch.template next_head<FAST_HEAD>(x.z);
       y.w = ch.template next_head<FAST_HEAD>(x.w);
-      __builtin_nontemporal_store(y, po + q * outQ);
+      if constexpr (MIX)
+      {
+        const uint32_t lane = threadIdx.x & 63u;
+        *(f32x4*)(strip + lane * 20 + (lane >> 4) * 16 + 4 * (q & 3)) = y;
+        if ((q & 3) == 3)
+        {
+          // (the strip is this wavefront's own: its lanes run in lockstep, the LDS operations of a wavefront complete in order)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const uint32_t s = lane & 15u, g = lane >> 4;
+          const float t16 = MixTree16<0, 16>::sum(strip + g * (16 * 20 + 16) + s);
+          const float t32 = t16 + u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 16u) & 63u) * 4u), (int)f2u(t16)));
+          const float t64 = t32 + u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 32u) & 63u) * 4u), (int)f2u(t32)));
+          if (lane < 16) a.mix[((v >> 6) * a.T + t) * 64 + (size_t)(q & ~3) * 4 + s] = t64;
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      else
+        __builtin_nontemporal_store(y, po + q * outQ);
     }
     ch.end_vector();
   }
 }
 
-template <class CH, bool HAS_SIGNAL>
+template <class CH, bool HAS_SIGNAL, bool MIX = false>
 __device__ __forceinline__ void chain_kernel_body(const ChainArgs& a)
 {
   apply_fp_mode(a.flags);
   __shared__ float ldsTable[CH::kHasImpulse ? 32 : 1];
+  float* const strip = MixStrips<MIX>::mine();
   if constexpr (CH::kHasImpulse)
   {
     if (threadIdx.x < Proc<MLGPU_PROC_IMPULSE_GEN>::kTableSize) ldsTable[threadIdx.x] = a.impulseTable[threadIdx.x];
@@ -92,9 +145,9 @@ __device__ __forceinline__ void chain_kernel_body(const ChainArgs& a)
   bool fastHead = false;
   if constexpr (!HAS_SIGNAL && CH::kHeadHasFastPath) fastHead = (__builtin_amdgcn_ballot_w64(CH::head_input_is_odd(xc)) == 0);
   if (fastHead)
-    run_voice<CH, HAS_SIGNAL, true>(ch, a, v, xc);
+    run_voice<CH, HAS_SIGNAL, true, MIX>(ch, a, v, xc, strip);
   else
-    run_voice<CH, HAS_SIGNAL, false>(ch, a, v, xc);
+    run_voice<CH, HAS_SIGNAL, false, MIX>(ch, a, v, xc, strip);
   ch.store(mem);
 }
 
@@ -102,6 +155,14 @@ template <class CH, bool HAS_SIGNAL>
 __global__ __launch_bounds__(kChainBlock) void chain_kernel(const ChainArgs a)
 {
   chain_kernel_body<CH, HAS_SIGNAL>(a);
+}
+
+// the same voices, their sum instead of their signals: a.mix gets the group sums mlgpu_mixdown's first stage would have made of
+// a.out (same bits: same tree), nothing else is written but the state. Whole wavefronts only (V a multiple of 64).
+template <class CH, bool HAS_SIGNAL>
+__global__ __launch_bounds__(kChainBlock) void chain_mix_kernel(const ChainArgs a)
+{
+  chain_kernel_body<CH, HAS_SIGNAL, true>(a);
 }
 
 // ---------------------------------------------------------------------------------------------

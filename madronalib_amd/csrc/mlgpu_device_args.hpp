@@ -32,6 +32,7 @@ struct ChainArgs
   size_t V, T;
   const float* impulseTable;
   uint32_t flags;  // MLGPU_KFLAG_*
+  float* mix;      // chain_mix_kernel: the rows of 64-voice group sums, [(group * T + t) * 64 + sample] (mlgpu_mixdown's first stage); else unused
 };
 
 // EventsToSignals settings the device needs (events.hip, mldsp_events.hpp)

@@ -77,6 +77,7 @@ struct ChainEntry
   std::vector<int> kinds;
   ChainLauncher launchSignal;  // streamed input
   ChainLauncher launchConst;   // per-voice constant (or no) input
+  ChainLauncher launchMixSignal{nullptr}, launchMixConst{nullptr};  // chain_mix_kernel (the voices' sum instead of their signals), where instantiated
   const char* kernelName;  // prefix of the name a profiler shows for the device kernel
   const char* (*kernelNameFor)(size_t V, uint32_t flags){nullptr};  // where the kernel depends on the bank's size (SVF cascades)
   const char* alias;       // e.g. "chain_kernel<SawGen,Bandpass,Gain>"
@@ -114,6 +115,7 @@ hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRo
 hipError_t mlgpu_launch_rows_index(float* out, size_t rowsPerGroup, size_t groups, hipStream_t stream);
 hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
                                 hipStream_t stream, uint32_t flags);
+hipError_t mlgpu_launch_mixdown_rows(size_t groups, size_t T, float* partial, float* out, hipStream_t stream, uint32_t flags);
 hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream, uint32_t flags);
 hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,
                               size_t nElems, hipStream_t stream, uint32_t flags);

@@ -856,8 +856,16 @@ hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t grou
 hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
                                 hipStream_t stream, uint32_t flags)
 {
-  const size_t groups = (V + 63) / 64, nQuads = T * 16;
+  const size_t groups = (V + 63) / 64;
   hipLaunchKernelGGL(mixdown_stage1_kernel, dim3((unsigned)((groups * T + 3) / 4)), dim3(256), 0, stream, makeView(sig, layout, V, T), V, T, gains, partial, flags);
+  return mlgpu_launch_mixdown_rows(groups, T, partial, out, stream, flags);
+}
+
+// the later stages alone: `partial` holds the rows of 64-voice group sums (the first stage's output, or a voice kernel's that made
+// them itself - chain_mix_kernel)
+hipError_t mlgpu_launch_mixdown_rows(size_t groups, size_t T, float* partial, float* out, hipStream_t stream, uint32_t flags)
+{
+  const size_t nQuads = T * 16;
   // the rows of group sums (in `partial`), 64 at a time, until one is left; the passes alternate between the two parts of the
   // scratch (mlgpu_mixdown_reserve: the second holds the first pass's rows / 64), the last one writes `out`
   float4* a = (float4*)partial;

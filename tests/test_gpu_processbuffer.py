@@ -216,3 +216,65 @@ def test_mixdown_groups_voice_order(eng, P, groups, layout):
     eng.layout_convert(d_x, Layout.VOICE_MAJOR, d_q, layout, V, T)
     eng.mixdown_groups(d_q, layout, groups, P, T, d_o, layout)
     assert (d_o.download(np.uint32, groups * 64 * T) == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,T", [(64, 1), (64 * 5, 3), (4096 + 64, 2), (65536 + 4096 + 192, 1)])   # 1 / 5 / 65 / 1091 groups: one to three row passes
+@pytest.mark.parametrize("chain,signal", [((Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN), False), ((Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN), True),
+                                          ((Proc.SINE_GEN, Proc.GAIN), False), ((Proc.PULSE_GEN, Proc.HIPASS, Proc.ONE_POLE), True)])
+def test_bank_process_mixdown_same_bits(eng, oracle, V, T, chain, signal):
+    """mlgpu_bank_process_mixdown - the voices summed inside the voice kernel, their signals never written - against the two calls it
+    replaces (bank_process, then mixdown without gains, whose tree the oracle pins in test_mixdown_vs_oracle): the same bits in the
+    mixed signal and in every state word, over three launches; per-voice constant frequencies and a streamed frequency signal."""
+    import madronalib_amd as ml
+    launches = 3
+    rng = np.random.default_rng(V + T)
+    freq = (55.0 * 2.0 ** (5.0 * rng.random(V)) / 48000.0).astype(np.float32)
+    fsig = (freq[:, None] * (1.0 + 0.3 * np.sin(np.arange(64 * T * launches)[None, :] * 0.003 * (1 + np.arange(V)[:, None] % 7)))).astype(np.float32)
+    eng.mixdown_reserve(V, T)
+    banks = [eng.bank(list(chain), V) for _ in range(2)]
+    for b in banks:
+        b.clear()
+        for p, kind in enumerate(chain):
+            if kind in (Proc.BANDPASS, Proc.HIPASS):
+                few = np.stack([oracle.make_coeffs("bandpass" if kind == Proc.BANDPASS else "hipass", 0.02 + 0.3 * j / 16, 0.6) for j in range(16)], 1)
+                b.set_coeffs(p, [np.ascontiguousarray(few[i][np.arange(V) % 16]) for i in range(few.shape[0])])
+            elif kind == Proc.ONE_POLE:
+                b.set_coeffs(p, [float(c) for c in oracle.make_coeffs("onepole", 0.3)])
+            elif kind == Proc.GAIN:
+                b.set_coeff(p, 0, 0.25)
+        if not signal:
+            b.set_input_const(freq)
+    d_voices = eng.alloc(4 * V * T * 64)
+    d_two, d_one = eng.alloc(4 * T * 64), eng.alloc(4 * T * 64)
+    for k in range(launches):
+        d_in = eng.to_device(np.ascontiguousarray(fsig[:, k * 64 * T:(k + 1) * 64 * T])) if signal else None
+        banks[0].process(T, d_voices, Layout.QUAD, d_in, Layout.VOICE_MAJOR)
+        eng.mixdown(d_voices, Layout.QUAD, V, T, d_two)
+        banks[1].process_mixdown(T, d_one, d_in, Layout.VOICE_MAJOR)
+        two, one = d_two.download(np.float32, 64 * T), d_one.download(np.float32, 64 * T)
+        assert_bits_equal(one, two, True, f"bank_process_mixdown launch {k}")
+        assert np.isfinite(two).all() and np.abs(two).max() > 1e-6, (k, two[:8])
+    for p in range(len(chain)):
+        for i in range(banks[0].num_state(p)):
+            assert (banks[0].get_state(p, i) == banks[1].get_state(p, i)).all(), (p, i)
+
+
+@pytest.mark.gpu
+def test_bank_process_mixdown_refusals(eng):
+    import madronalib_amd as ml
+    d_out = eng.alloc(4 * 64)
+    eng.mixdown_reserve(4096, 1)
+    for procs, V in (((Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN), 100),      # not whole wavefronts
+                     ((Proc.LOPASS,), 128),                                  # no summing form of this kernel
+                     ((Proc.SAW_GEN, Proc.LOPASS, Proc.HIPASS, Proc.GAIN), 128)):   # not one fused kernel
+        b = eng.bank(list(procs), V)
+        with pytest.raises(ml.MlgpuError) as ei:
+            b.process_mixdown(1, d_out)
+        assert ei.value.status == ml.Status.ERR_UNSUPPORTED
+    small = ml.Engine(0)
+    b = small.bank([Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN], 8192)
+    with pytest.raises(ml.MlgpuError) as ei:
+        b.process_mixdown(1, small.alloc(4 * 64))        # nothing reserved: a process call refuses instead of allocating
+    assert ei.value.status == ml.Status.ERR_INVALID and "mixdown_reserve" in str(ei.value)
+    small.close()
