@@ -742,6 +742,57 @@ __global__ __launch_bounds__(64) void mixdown_rows64_kernel(const float4* in, si
   }
   out[r * nQuads + qi] = acc;
 }
+// The last two of those passes in one launch, for up to 4096 rows: thread (q, r) of a workgroup adds up rows [64 r, 64 r + 64) of its
+// quad as above, the sums meet in LDS, and the threads of r = 0 add them left to right. Same order, one launch less per mixdown
+// (2^20 voices: 16 384 -> 256 by the kernel above, 256 -> 4 -> 1 here).
+__global__ __launch_bounds__(1024) void mixdown_rows_last2_kernel(const float4* in, size_t rows, size_t nQuads, float4* out, uint32_t flags)
+{
+  apply_fp_mode(flags);
+  __shared__ float4 mid[64][16];
+  const size_t qi = (size_t)blockIdx.x * 16 + threadIdx.x, r = threadIdx.y;
+  const size_t first = r * 64, n = (rows - first < 64) ? rows - first : 64;
+  if (qi < nQuads)
+  {
+    const float4* p = in + first * nQuads + qi;
+    float4 acc = p[0];
+    size_t g = 1;
+    for (; g + 16 <= n; g += 16)
+    {
+      float4 x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = p[(g + u) * nQuads];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+      {
+        acc.x = acc.x + x[u].x;
+        acc.y = acc.y + x[u].y;
+        acc.z = acc.z + x[u].z;
+        acc.w = acc.w + x[u].w;
+      }
+    }
+    for (; g < n; ++g)
+    {
+      const float4 x = p[g * nQuads];
+      acc.x = acc.x + x.x;
+      acc.y = acc.y + x.y;
+      acc.z = acc.z + x.z;
+      acc.w = acc.w + x.w;
+    }
+    mid[r][threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (r != 0 || qi >= nQuads) return;
+  float4 acc = mid[0][threadIdx.x];
+  for (unsigned m = 1; m < blockDim.y; ++m)
+  {
+    const float4 x = mid[m][threadIdx.x];
+    acc.x = acc.x + x.x;
+    acc.y = acc.y + x.y;
+    acc.z = acc.z + x.z;
+    acc.w = acc.w + x.w;
+  }
+  out[qi] = acc;
+}
 }  // namespace
 
 // grouped mixdown: out[g] = ((0 + v[g*P]) + v[g*P + 1]) + ... — the voices of one instrument summed in voice order, exactly
@@ -873,6 +924,12 @@ hipError_t mlgpu_launch_mixdown_rows(size_t groups, size_t T, float* partial, fl
   size_t rows = groups;
   do
   {
+    if (rows <= 4096)
+    {
+      hipLaunchKernelGGL(mixdown_rows_last2_kernel, dim3((unsigned)((nQuads + 15) / 16)), dim3(16, (unsigned)((rows + 63) / 64)), 0, stream, (const float4*)a, rows,
+                         nQuads, (float4*)out, flags);
+      break;
+    }
     const size_t rowsOut = (rows + 63) / 64;
     hipLaunchKernelGGL(mixdown_rows64_kernel, dim3((unsigned)((nQuads + 63) / 64), (unsigned)rowsOut), dim3(64), 0, stream, (const float4*)a, rows, nQuads,
                        rowsOut == 1 ? (float4*)out : b, flags);
