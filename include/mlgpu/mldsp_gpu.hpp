@@ -531,6 +531,21 @@ class VoiceBank
     eng_.check(mlgpu_bank_process(b_, out.vectors(), in.data(), in.layout(), out.data(), out.layout()));
   }
 
+  // ... and when only the SUM of the voices is wanted (a Synth's `outputs += voice`, MLSynth.h:43-57): operator() followed by
+  // mlgpu_mixdown of its output, in one launch and without the voices' signals in memory - the same bits (mlgpu_bank_process_mixdown:
+  // one fused kernel, voices a multiple of 64, mlgpu_mixdown_reserve at setup). `mix` is a single-voice signal of `vectors` DSPVectors.
+  void mixdown(size_t vectors, float* mix)
+  {
+    commit();
+    eng_.check(mlgpu_bank_process_mixdown(b_, vectors, nullptr, MLGPU_LAYOUT_QUAD, mix));
+  }
+  void mixdown(const DeviceSignal& in, float* mix)
+  {
+    if (in.voices() != voices_) throw Error(MLGPU_ERR_INVALID, "VoiceBank: signal shape mismatch");
+    commit();
+    eng_.check(mlgpu_bank_process_mixdown(b_, in.vectors(), in.data(), in.layout(), mix));
+  }
+
   // raw state (checkpoint / resume)
   std::vector<uint32_t> state(int proc, int idx) const
   {
