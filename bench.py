@@ -754,8 +754,22 @@ def rt_case(eng, V=1048576, frames=64, blocks=1500, lead_in=50):
 
     def cb_one(_user, n_vectors, _d_in, d_out):     # round 5: the voices summed inside the voice kernel, their signals never written
         return L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, d_out[0])
-    fused = V % 64 == 0 and os.environ.get("MLGPU_RT_FORM", "fused") == "fused"
+    form = os.environ.get("MLGPU_RT_FORM", "fused")
+    fused = V % 64 == 0 and form in ("fused", "sequence")
     clock = time.perf_counter
+    seq_state = {"ptr": None, "seq": None}
+
+    def cb_seq(_user, n_vectors, _d_in, d_out):      # experiment: the block's launches recorded once (hipGraph), replayed per block
+        ptr = int(d_out[0])
+        if seq_state["seq"] is not None and ptr == seq_state["ptr"] and n_vectors == T:
+            return L.mlgpu_sequence_launch(seq_state["seq"].h)
+        if seq_state["ptr"] == ptr and n_vectors == T and seq_state["seq"] is None:
+            with eng.record() as sq:
+                st = L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, d_out[0])
+            seq_state["seq"] = sq
+            return st or L.mlgpu_sequence_launch(sq.h)
+        seq_state["ptr"] = ptr
+        return L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, d_out[0])
 
     def paced(cb, n_blocks):
         cbf = ml.ProcessBuffer._CB(cb)
@@ -780,7 +794,7 @@ def rt_case(eng, V=1048576, frames=64, blocks=1500, lead_in=50):
     gc_was = gc.isenabled()
     gc.disable()           # a collection in the middle of a block is this script's, not the device's
     try:
-        us, misses, peak = paced(cb_one if fused else cb_two, blocks)
+        us, misses, peak = paced((cb_seq if form == "sequence" else cb_one) if fused else cb_two, blocks)
         us2 = paced(cb_two, max(100, blocks // 5))[0] if fused else None
     finally:
         if gc_was:
