@@ -1923,8 +1923,9 @@ extern "C"
       memFloats += n.ringLen * (size_t)mlgpu_proc_rings(n.kind);
     }
     g->memFloatsPerVoice = memFloats;
+    // (three rings: layout 2 fits but leaves a CU one workgroup, and layout 1 is 9 % faster - profiles/r05_ring_layouts.txt)
     if (g->transposedIfPossible)
-      g->transposedRings = g->V % 64 == 0 && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) <= 160 * 1024;
+      g->transposedRings = g->V % 64 == 0 && g->totalRings != 3 && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) <= 160 * 1024;
     if (g->transposedRings && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 needs 40 KiB of LDS per ring; at most 4 rings per graph (layout 1 for more)");
     if (!g->transposedRings && g->windowedRings && (size_t)g->totalRings * 8 * 256 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)

@@ -234,7 +234,7 @@ def test_delay_rules(eng):
         ml.Graph(eng, 100, delay_windows=2)                      # ... and whole wavefronts only
     assert ei.value.status == ml.Status.ERR_UNSUPPORTED
     # layout 3 = "per-voice delay times, the best form that applies": decided by compile
-    for V, n_delays, want in ((256, 4, 2), (256, 5, 1), (200, 1, 1)):
+    for V, n_delays, want in ((256, 4, 2), (256, 2, 2), (256, 3, 1), (256, 5, 1), (200, 1, 1)):
         g = ml.Graph(eng, V, delay_windows="best")
         assert g.delay_layout == 3
         a = g.add("a", "input")
