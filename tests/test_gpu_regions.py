@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from inputs import assert_bits_equal, region_case
+from inputs import assert_bits_equal, lcg_noise, region_case
 from madronalib_amd.constants import Layout, Op, Proc, Region
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regions.npz"))
@@ -195,3 +195,40 @@ def test_region_rules(eng):
     x = np.random.default_rng(1).standard_normal((64, 128)).astype(np.float32)
     (out,) = g2.process_host(2, {"x": x}, Layout.QUAD)
     assert (out[:, :64] == 0).all() and np.abs(out[:, 64:]).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [Region.UPSAMPLE_2X, Region.DOWNSAMPLE_2X])
+def test_rate_region_with_delay_in_every_ring_layout(eng, kind):
+    """The same region (a delay ring and a one-vector feedback at fn's own rate: 128 or 32 samples per DSPVector) with the ring in
+    layouts 1 and 2 (sectors / transposed pieces behind LDS windows, whose clocks count the REGION's samples) against layout 0,
+    which the golden test above pins; per-voice delay times, split launches."""
+    import madronalib_amd as ml
+    from madronalib_amd import patches
+    V, T = 128, 10
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 77, 64 * T)
+    opc = GOLD["opc"]
+    outs = {}
+    for layout in (0, 1, 2):
+        g = ml.Graph(eng, V, delay_windows=layout)
+        g.add("x", "input")
+        g.begin_region(kind, ["x"], ["rx"])
+        sub, y = patches.allpass("ap_", "rx", Proc.INTEGER_DELAY, 300.0)
+        for n in sub:
+            g.add(**{k: v for k, v in n.items() if k != "source"})
+        for n in sub:
+            if n["type"] == "feedback":
+                g.set_feedback(n["name"], n["source"])
+        g.add("lp", "proc", Proc.ONE_POLE, [y])
+        out = g.end_region("lp", "out")
+        g.add_output(out)
+        g.compile()
+        assert g.delay_layout == layout
+        g.set_param("ap_gain", 0.6)
+        g.set_coeffs("lp", [np.full(V, c, np.float32) for c in opc])
+        g.set_state("ap_delay", 1, ((np.arange(V) * 37) % 237).astype(np.uint32))
+        outs[layout] = np.concatenate([g.process_host(n, {"x": np.ascontiguousarray(x[:, 64 * a:64 * (a + n)])}, Layout.QUAD)[0] for a, n in ((0, 3), (3, 1), (4, 6))], 1)
+        g.close()
+    assert np.abs(outs[0]).max() > 0.1
+    assert_bits_equal(outs[1], outs[0], True, "ring layout 1 in a rate region")
+    assert_bits_equal(outs[2], outs[0], True, "ring layout 2 in a rate region")
