@@ -558,8 +558,9 @@ int mlgpu_graph_set_max_delay(mlgpu_graph* g, int proc_node, float max_delay_in_
  * moved as whole 64-byte pieces by neighbouring lanes on a wave-uniform clock, read windows in LDS, requests a period ahead, a
  * voice's own recent samples kept there for short delay times: the algorithmic traffic and not a byte more (0.98 x measured
  * against 1.13 x for layout 1) at 0.72-0.74 of the HBM peak against 0.56-0.59 (profiles/r05_ring_layouts.txt) - the one to use
- * for per-voice delay times where it applies: whole wavefronts (voices a multiple of 64) and at most 4 rings per graph (40 KiB
- * of LDS per ring and workgroup). 3: "voices have their own delay times, take the best form": layout 2 where it applies (and the graph
+ * for per-voice delay times where it applies: at most 4 rings per graph (40 KiB of LDS per ring and workgroup), and a voice count
+ * that is a multiple of 64 if the graph sums voices in groups or reads event rows inside its kernel (other graphs: any count - the
+ * spare lanes of the bank's last wavefront run its last voice again). 3: "voices have their own delay times, take the best form": layout 2 where it applies (and the graph
  * does not have exactly three rings, where layout 1 measured faster), else layout 1, decided by graph_compile. With one delay time for all voices layout 2 is as fast as the default rows (0.85 / 0.85 of the HBM
  * peak on the strings bank; layout 1: 0.72). Same results in every layout for delay times within the node's maximum
  * (graph_set_max_delay). mlgpu_graph_delay_layout: the layout in effect (0 / 1 / 2; 3 before compile), negative: a status. */

@@ -991,7 +991,7 @@ class Graph:
         if voices_per_lane:
             engine._check(self.L.mlgpu_graph_set_voices_per_lane(self.h, int(voices_per_lane)))
         if delay_windows:   # True / 1: 32-byte sectors behind LDS windows; 2: transposed 64-byte pieces on a wave-uniform clock;
-            # 3 / "best": 2 where it applies (voices a multiple of 64, at most four rings), else 1
+            # 3 / "best": 2 where it applies (at most four rings, not three), else 1
             engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 3 if delay_windows in (3, "best") else (2 if delay_windows == 2 else 1)))
         if autotune:
             engine._check(self.L.mlgpu_graph_set_autotune(self.h, 1))

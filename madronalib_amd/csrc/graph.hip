@@ -796,9 +796,18 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (size_t o = 0; o < g->outputs.size(); ++o)
     if (ldsSum(o))
       s << "  __shared__ float ldsSum" << o << "[4 * kGroup16Strip];\n  float* const strip" << o << " = ldsSum" << o << " + (threadIdx.x >> 6) * kGroup16Strip;\n";
+  // Ring layout 2 moves a voice's pieces with its NEIGHBOURS' lanes: a bank whose last wavefront is not full keeps that wavefront's
+  // spare lanes running. They run the bank's last voice again - same inputs, same state, same stores - on ring memory and LDS
+  // columns of their own (vr: the lane's place; the rings are laid out for whole 256-voice blocks and cleared together, so a spare
+  // lane's ring always holds what the last voice's holds).
+  const bool partialWaves = g->transposedRings && g->totalRings && (g->V % 64);
   s << "  size_t blk = blockIdx.x;\n  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;\n"
-       "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n"
-       "  const size_t v_0 = blk * " << 256 * VL << " + threadIdx.x;\n  if (v_0 >= a.V) return;\n";
+       "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n";
+  if (partialWaves)
+    s << "  const size_t vr_0 = blk * 256 + threadIdx.x;\n  if ((vr_0 & ~(size_t)63) >= a.V) return;\n  const size_t v_0 = vr_0 < a.V ? vr_0 : a.V - 1;\n";
+  else
+    s << "  const size_t v_0 = blk * " << 256 * VL << " + threadIdx.x;\n  if (v_0 >= a.V) return;\n";
+  const std::string ringLane = partialWaves ? "vr" : "v";
   if (!g->waveClockPath.empty()) s << "  const unsigned long long waveClock0 = __builtin_amdgcn_s_memrealtime();\n";
   // a lane whose second voice does not exist recomputes its first one: same inputs, same state, same stores
   for (int l = 1; l < VL; ++l) s << "  const size_t v" << sfx(l) << " = (v_0 + " << 256 * l << " < a.V) ? v_0 + " << 256 * l << " : v_0;\n";
@@ -823,8 +832,8 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
           << ", a.state + (size_t)" << n.sOff << " * a.V + v" << L << ", a.V";
         if (n.ringLen && !g->windowedRings) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v" << L << ", " << (n.ringLen - 1) << "u";
         if (n.ringLen && g->transposedRings)
-          s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (v" << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
-            << " + (v" << L << " & 255) * 16, " << (n.ringLen - 1)
+          s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (" << ringLane << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
+            << " + (" << ringLane << L << " & 255) * 16, " << (n.ringLen - 1)
             << "u, ldsRings + (" << (size_t)n.ringSlot * 4 << " + (threadIdx.x >> 6)) * kTStrip + (threadIdx.x & 63)";
         else if (n.ringLen && g->windowedRings)
           s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (v" << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
@@ -1924,8 +1933,15 @@ extern "C"
     }
     g->memFloatsPerVoice = memFloats;
     // (three rings: layout 2 fits but leaves a CU one workgroup, and layout 1 is 9 % faster - profiles/r05_ring_layouts.txt)
+    // a bank whose last wavefront is not full: its spare lanes run the last voice again (generateGraphSource) - not where voices are
+    // summed in groups inside the kernel or read event records, which go by lane
+    bool groupedOrEvents = g->hasEventRows;
+    for (size_t o = 0; o < g->outputs.size(); ++o) groupedOrEvents = groupedOrEvents || g->outputGroup[o] != 0;
+    const bool partialOk = g->V % 64 == 0 || !groupedOrEvents;
+    if (g->transposedRings && g->totalRings && !partialOk)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 with voice sums or event rows inside the kernel needs whole wavefronts (voices a multiple of 64)");
     if (g->transposedIfPossible)
-      g->transposedRings = g->V % 64 == 0 && g->totalRings != 3 && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) <= 160 * 1024;
+      g->transposedRings = partialOk && g->totalRings != 3 && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) <= 160 * 1024;
     if (g->transposedRings && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 needs 40 KiB of LDS per ring; at most 4 rings per graph (layout 1 for more)");
     if (!g->transposedRings && g->windowedRings && (size_t)g->totalRings * 8 * 256 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
@@ -2203,7 +2219,6 @@ extern "C"
     if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (windowed < 0 || windowed > 3) return gfail(g, MLGPU_ERR_INVALID, "graph_set_delay_layout: 0 (rows), 1 (32-byte sectors), 2 (transposed 64-byte pieces) or 3 (2 where it applies, else 1)");
-    if (windowed == 2 && (g->V % 64)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_set_delay_layout(2): whole wavefronts only (a number of voices that is a multiple of 64)");
     g->windowedRings = windowed != 0;
     g->transposedRings = windowed == 2;
     g->transposedIfPossible = windowed == 3;   // decided at compile, when the number of rings is known

@@ -40,7 +40,7 @@ def run(cases, seed, eng=None):
     bad, nonzero, total = 0, 0, 0
     for case in range(cases):
         kind = [Proc.INTEGER_DELAY, Proc.FRACTIONAL_DELAY, Proc.PITCHBENDABLE_DELAY][int(rng.integers(0, 3))]
-        V = 64 * int(rng.integers(1, 7))
+        V = int(rng.integers(1, 400)) if rng.random() < 0.5 else 64 * int(rng.integers(1, 7))   # whole wavefronts, and banks whose last one is not full
         T = int(rng.integers(1, 10))
         launches = int(rng.integers(2, 6))
         dmax = float([0.0, 40.0, 100.0, 192.0, 700.0, 3000.0][int(rng.integers(0, 6))])
@@ -62,7 +62,7 @@ def run(cases, seed, eng=None):
                 g.set_state("d", 0, np.full(V, int(case * 7 + 3) % ring, np.uint32))
             elif wmode == 2:
                 w = np.zeros(V, np.uint32)
-                w[:64] = (np.arange(64, dtype=np.uint32) * 5 + case) % ring
+                w[:64] = ((np.arange(64, dtype=np.uint32) * 5 + case) % ring)[:min(64, V)]
                 g.set_state("d", 0, w)
             o = []
             for k in range(launches):
