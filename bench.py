@@ -755,7 +755,7 @@ def rt_case(eng, V=1048576, frames=64, blocks=1500, lead_in=50):
     def cb_one(_user, n_vectors, _d_in, d_out):     # round 5: the voices summed inside the voice kernel, their signals never written
         return L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, d_out[0])
     form = os.environ.get("MLGPU_RT_FORM", "fused")
-    fused = V % 64 == 0 and form in ("fused", "sequence")
+    fused = form in ("fused", "sequence")
     clock = time.perf_counter
     seq_state = {"ptr": None, "seq": None}
 

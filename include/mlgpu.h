@@ -962,7 +962,7 @@ int mlgpu_mixdown(mlgpu_engine* e, const float* d_signal, int layout, size_t n_v
  * memory: the voice kernel adds up the 64 voices of each wavefront itself - the first stage's tree, so d_out has the SAME BITS as
  * the two calls give - and the later stages follow. For a 2^20-voice bank paced at 48 kHz that halves the device time of a block
  * (DESIGN.md 3.7). For the fused voice chains (SawGen -> Bandpass -> Gain and the others mlgpu_bank_kernel_name shows as one
- * kernel) with a voice count that is a multiple of 64; MLGPU_ERR_UNSUPPORTED otherwise (then make the two calls). Needs the same
+ * kernel), any voice count; MLGPU_ERR_UNSUPPORTED for other banks (then make the two calls). Needs the same
  * mlgpu_mixdown_reserve as mlgpu_mixdown. State and coefficients as after mlgpu_bank_process. */
 int mlgpu_bank_process_mixdown(mlgpu_bank* bank, size_t n_vectors, const float* d_in, int in_layout, float* d_out);
 

@@ -533,7 +533,7 @@ class VoiceBank
 
   // ... and when only the SUM of the voices is wanted (a Synth's `outputs += voice`, MLSynth.h:43-57): operator() followed by
   // mlgpu_mixdown of its output, in one launch and without the voices' signals in memory - the same bits (mlgpu_bank_process_mixdown:
-  // one fused kernel, voices a multiple of 64, mlgpu_mixdown_reserve at setup). `mix` is a single-voice signal of `vectors` DSPVectors.
+  // one fused kernel, mlgpu_mixdown_reserve at setup). `mix` is a single-voice signal of `vectors` DSPVectors.
   void mixdown(size_t vectors, float* mix)
   {
     commit();

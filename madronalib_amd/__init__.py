@@ -925,7 +925,7 @@ class Bank:
     def process_mixdown(self, n_vectors, d_out, d_in=None, in_layout=Layout.QUAD):
         """process + Engine.mixdown of its output (no gains) in one call, the voices' signals never written: d_out gets the 64 *
         n_vectors samples of their sum, the same bits as the two calls give (mlgpu_bank_process_mixdown; Status.ERR_UNSUPPORTED for
-        banks that are not one fused kernel or whose voice count is not a multiple of 64)."""
+        banks that are not one fused kernel)."""
         pin = None if d_in is None else ctypes.c_void_p(d_in.ptr if hasattr(d_in, "ptr") else int(d_in))
         pout = ctypes.c_void_p(d_out.ptr if hasattr(d_out, "ptr") else int(d_out))
         self.engine._check(self.L.mlgpu_bank_process_mixdown(self.h, int(n_vectors), pin, int(in_layout), pout))

@@ -867,9 +867,9 @@ extern "C"
     if (d_in && (inLayout < 0 || inLayout > MLGPU_LAYOUT_BROADCAST)) return fail(e, MLGPU_ERR_INVALID, "bank_process_mixdown: bad layout");
     if ((((uintptr_t)d_out) | ((uintptr_t)d_in)) & 15) return fail(e, MLGPU_ERR_INVALID, "bank_process_mixdown: signals must be 16-byte aligned");
     const size_t V = b->V;
-    if (!b->fused || !b->fused->launchMixSignal || (V % 64))
-      return fail(e, MLGPU_ERR_UNSUPPORTED, "bank_process_mixdown: for the fused voice chains and whole wavefronts (voices a multiple of 64) - use bank_process and mixdown");
-    const size_t groups = V / 64;
+    if (!b->fused || !b->fused->launchMixSignal)
+      return fail(e, MLGPU_ERR_UNSUPPORTED, "bank_process_mixdown: for the fused voice chains - use bank_process and mixdown");
+    const size_t groups = (V + 63) / 64;
     if ((groups + (groups + 63) / 64) * T * 64 > e->mixScratchFloats)
       return fail(e, MLGPU_ERR_INVALID, "bank_process_mixdown: call mlgpu_mixdown_reserve(engine, max voices, max vectors) at setup (process calls do not allocate)");
     HIP_TRY(e, hipSetDevice(e->device));

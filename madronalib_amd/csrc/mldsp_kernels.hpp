@@ -62,7 +62,7 @@ struct MixStrips<true>
 
 // the streaming loop of one voice: T DSPVectors, 16 quads each, one 16-byte access per quad
 template <class CH, bool HAS_SIGNAL, bool FAST_HEAD, bool MIX = false>
-__device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, float xc, float* strip = nullptr)
+__device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, float xc, float* strip = nullptr, bool live = true)
 {
   const f32x4* pin = HAS_SIGNAL ? (const f32x4*)a.in.base + v * a.in.strideV : nullptr;
   f32x4* pout = MIX ? nullptr : (f32x4*)a.out.base + v * a.out.strideV;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
       if constexpr (MIX)
       {
         const uint32_t lane = threadIdx.x & 63u;
-        *(f32x4*)(strip + lane * 20 + (lane >> 4) * 16 + 4 * (q & 3)) = y;
+        *(f32x4*)(strip + lane * 20 + (lane >> 4) * 16 + 4 * (q & 3)) = live ? y : f32x4{0.f, 0.f, 0.f, 0.f};  // (a voice the bank does not have counts as +0)
         if ((q & 3) == 3)
         {
           // (the strip is this wavefront's own: its lanes run in lockstep, the LDS operations of a wavefront complete in order)
@@ -130,8 +130,18 @@ __device__ __forceinline__ void chain_kernel_body(const ChainArgs& a)
   size_t blk = blockIdx.x;
   const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;
   if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);
-  const size_t v = blk * kChainBlock + threadIdx.x;
-  if (v >= a.V) return;
+  size_t v = blk * kChainBlock + threadIdx.x;
+  bool live = true;
+  if constexpr (MIX)
+  {
+    // the last wavefront of a bank that does not fill it keeps its spare lanes: they are part of the tree. They run the bank's last
+    // voice again (same inputs, same state, same stores) and put +0 into the sum.
+    if ((v & ~(size_t)63) >= a.V) return;
+    live = v < a.V;
+    if (!live) v = a.V - 1;
+  }
+  else if (v >= a.V)
+    return;
 
   CH ch;
   const VoiceMem mem{a.coeffs + v, a.state + v, a.V};
@@ -145,9 +155,9 @@ __device__ __forceinline__ void chain_kernel_body(const ChainArgs& a)
   bool fastHead = false;
   if constexpr (!HAS_SIGNAL && CH::kHeadHasFastPath) fastHead = (__builtin_amdgcn_ballot_w64(CH::head_input_is_odd(xc)) == 0);
   if (fastHead)
-    run_voice<CH, HAS_SIGNAL, true, MIX>(ch, a, v, xc, strip);
+    run_voice<CH, HAS_SIGNAL, true, MIX>(ch, a, v, xc, strip, live);
   else
-    run_voice<CH, HAS_SIGNAL, false, MIX>(ch, a, v, xc, strip);
+    run_voice<CH, HAS_SIGNAL, false, MIX>(ch, a, v, xc, strip, live);
   ch.store(mem);
 }
 
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(kChainBlock) void chain_kernel(const ChainArgs a)
 }
 
 // the same voices, their sum instead of their signals: a.mix gets the group sums mlgpu_mixdown's first stage would have made of
-// a.out (same bits: same tree), nothing else is written but the state. Whole wavefronts only (V a multiple of 64).
+// a.out (same bits: same tree), nothing else is written but the state.
 template <class CH, bool HAS_SIGNAL>
 __global__ __launch_bounds__(kChainBlock) void chain_mix_kernel(const ChainArgs a)
 {
