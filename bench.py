@@ -753,7 +753,7 @@ def rt_case(eng, V=1048576, frames=64, blocks=1500, lead_in=50):
         return st or L.mlgpu_mixdown(eng.h, vptr, QUAD, V, n_vectors, None, d_out[0])
 
     def cb_one(_user, n_vectors, _d_in, d_out):     # round 5: the voices summed inside the voice kernel, their signals never written
-        return L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, d_out[0])
+        return L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, None, d_out[0])
     form = os.environ.get("MLGPU_RT_FORM", "fused")
     fused = form in ("fused", "sequence")
     clock = time.perf_counter
@@ -765,11 +765,11 @@ def rt_case(eng, V=1048576, frames=64, blocks=1500, lead_in=50):
             return L.mlgpu_sequence_launch(seq_state["seq"].h)
         if seq_state["ptr"] == ptr and n_vectors == T and seq_state["seq"] is None:
             with eng.record() as sq:
-                st = L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, d_out[0])
+                st = L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, None, d_out[0])
             seq_state["seq"] = sq
             return st or L.mlgpu_sequence_launch(sq.h)
         seq_state["ptr"] = ptr
-        return L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, d_out[0])
+        return L.mlgpu_bank_process_mixdown(bank.h, n_vectors, None, QUAD, None, d_out[0])
 
     def paced(cb, n_blocks):
         cbf = ml.ProcessBuffer._CB(cb)

@@ -958,13 +958,13 @@ int mlgpu_process_buffer_process(mlgpu_process_buffer* p, const float* const* in
 int mlgpu_mixdown_reserve(mlgpu_engine* e, size_t max_voices, size_t max_vectors);
 int mlgpu_mixdown(mlgpu_engine* e, const float* d_signal, int layout, size_t n_voices, size_t n_vectors, const float* d_gains,
                   float* d_out);
-/* mlgpu_bank_process followed by mlgpu_mixdown(gains NULL) of its output, in one call and without the voices' signals ever reaching
+/* mlgpu_bank_process followed by mlgpu_mixdown of its output (d_gains: per-voice gains or NULL, as there), in one call and without the voices' signals ever reaching
  * memory: the voice kernel adds up the 64 voices of each wavefront itself - the first stage's tree, so d_out has the SAME BITS as
  * the two calls give - and the later stages follow. For a 2^20-voice bank paced at 48 kHz that halves the device time of a block
  * (DESIGN.md 3.7). For the fused voice chains (SawGen -> Bandpass -> Gain and the others mlgpu_bank_kernel_name shows as one
  * kernel), any voice count; MLGPU_ERR_UNSUPPORTED for other banks (then make the two calls). Needs the same
  * mlgpu_mixdown_reserve as mlgpu_mixdown. State and coefficients as after mlgpu_bank_process. */
-int mlgpu_bank_process_mixdown(mlgpu_bank* bank, size_t n_vectors, const float* d_in, int in_layout, float* d_out);
+int mlgpu_bank_process_mixdown(mlgpu_bank* bank, size_t n_vectors, const float* d_in, int in_layout, const float* d_gains, float* d_out);
 
 /* Sum every `group_size` consecutive voices into one: out voice g = ((0 + v[g*P]) + v[g*P+1]) + ... in voice order — the
  * `outputs[c] += ...` accumulation of Synth::processVector (source/app/MLSynth.h:43-57), bit for bit. The result is a signal

@@ -534,16 +534,16 @@ class VoiceBank
   // ... and when only the SUM of the voices is wanted (a Synth's `outputs += voice`, MLSynth.h:43-57): operator() followed by
   // mlgpu_mixdown of its output, in one launch and without the voices' signals in memory - the same bits (mlgpu_bank_process_mixdown:
   // one fused kernel, mlgpu_mixdown_reserve at setup). `mix` is a single-voice signal of `vectors` DSPVectors.
-  void mixdown(size_t vectors, float* mix)
+  void mixdown(size_t vectors, float* mix, const float* gains = nullptr)   // gains: per-voice, on the device, or none
   {
     commit();
-    eng_.check(mlgpu_bank_process_mixdown(b_, vectors, nullptr, MLGPU_LAYOUT_QUAD, mix));
+    eng_.check(mlgpu_bank_process_mixdown(b_, vectors, nullptr, MLGPU_LAYOUT_QUAD, gains, mix));
   }
-  void mixdown(const DeviceSignal& in, float* mix)
+  void mixdown(const DeviceSignal& in, float* mix, const float* gains = nullptr)
   {
     if (in.voices() != voices_) throw Error(MLGPU_ERR_INVALID, "VoiceBank: signal shape mismatch");
     commit();
-    eng_.check(mlgpu_bank_process_mixdown(b_, in.vectors(), in.data(), in.layout(), mix));
+    eng_.check(mlgpu_bank_process_mixdown(b_, in.vectors(), in.data(), in.layout(), gains, mix));
   }
 
   // raw state (checkpoint / resume)

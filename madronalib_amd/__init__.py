@@ -922,13 +922,14 @@ class Bank:
         pout = ctypes.c_void_p(d_out.ptr if hasattr(d_out, "ptr") else int(d_out))
         self.engine._check(self.L.mlgpu_bank_process(self.h, int(n_vectors), pin, int(in_layout), pout, int(out_layout)))
 
-    def process_mixdown(self, n_vectors, d_out, d_in=None, in_layout=Layout.QUAD):
+    def process_mixdown(self, n_vectors, d_out, d_in=None, in_layout=Layout.QUAD, d_gains=None):
         """process + Engine.mixdown of its output (no gains) in one call, the voices' signals never written: d_out gets the 64 *
         n_vectors samples of their sum, the same bits as the two calls give (mlgpu_bank_process_mixdown; Status.ERR_UNSUPPORTED for
         banks that are not one fused kernel)."""
         pin = None if d_in is None else ctypes.c_void_p(d_in.ptr if hasattr(d_in, "ptr") else int(d_in))
         pout = ctypes.c_void_p(d_out.ptr if hasattr(d_out, "ptr") else int(d_out))
-        self.engine._check(self.L.mlgpu_bank_process_mixdown(self.h, int(n_vectors), pin, int(in_layout), pout))
+        pg = None if d_gains is None else ctypes.c_void_p(d_gains.ptr if hasattr(d_gains, "ptr") else int(d_gains))
+        self.engine._check(self.L.mlgpu_bank_process_mixdown(self.h, int(n_vectors), pin, int(in_layout), pg, pout))
 
     def process_host(self, n_vectors, in_signal=None, layout=Layout.QUAD):
         """Test convenience: in_signal/out are VOICE_MAJOR [V][64T] numpy; the kernel runs in `layout`

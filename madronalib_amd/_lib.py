@@ -158,7 +158,7 @@ def _declare(L):
     sig("mlgpu_bank_set_state_uniform", i, [vp, i, i, c.c_uint32])
     sig("mlgpu_bank_set_input_const", i, [vp, vp])
     sig("mlgpu_bank_process", i, [vp, sz, vp, i, vp, i])
-    sig("mlgpu_bank_process_mixdown", i, [vp, sz, vp, i, vp])
+    sig("mlgpu_bank_process_mixdown", i, [vp, sz, vp, i, vp, vp])
     sig("mlgpu_bank_is_fused", i, [vp])
     sig("mlgpu_bank_kernel_name", c.c_char_p, [vp])
     ip = c.POINTER(c.c_int)

@@ -858,7 +858,7 @@ extern "C"
 
   // bank_process + mixdown(gains = NULL) without the voices' signals in between: the voice kernel adds up each wavefront's 64 voices
   // itself (chain_mix_kernel: the first stage's tree, the same bits), the later stages follow
-  int mlgpu_bank_process_mixdown(mlgpu_bank* b, size_t T, const float* d_in, int inLayout, float* d_out)
+  int mlgpu_bank_process_mixdown(mlgpu_bank* b, size_t T, const float* d_in, int inLayout, const float* d_gains, float* d_out)
   {
     if (!b) return MLGPU_ERR_INVALID;
     mlgpu_engine* e = b->e;
@@ -884,6 +884,7 @@ extern "C"
     a.in = makeView(d_in, inLayout, V, T);
     a.out = makeView(nullptr, MLGPU_LAYOUT_QUAD, V, T);
     a.mix = e->d_mixScratch;
+    a.mixGains = d_gains;
     hipError_t err = d_in ? b->fused->launchMixSignal(a, e->stream, e->cuCount) : b->fused->launchMixConst(a, e->stream, e->cuCount);
     if (err != hipSuccess) return fail(e, MLGPU_ERR_HIP, "bank_process_mixdown launch", err);
     HIP_TRY(e, mlgpu_launch_mixdown_rows(groups, T, e->d_mixScratch, d_out, e->stream, e->kflags));
@@ -904,6 +905,7 @@ extern "C"
 
     ChainArgs a;
     a.mix = nullptr;
+    a.mixGains = nullptr;
     a.V = V;
     a.flags = e->kflags;
     a.impulseTable = e->d_impulseTable;

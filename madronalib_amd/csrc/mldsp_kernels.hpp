@@ -61,9 +61,12 @@ struct MixStrips<true>
 };
 
 // the streaming loop of one voice: T DSPVectors, 16 quads each, one 16-byte access per quad
-template <class CH, bool HAS_SIGNAL, bool FAST_HEAD, bool MIX = false>
+// (SCALED: the summing form with per-voice gains and / or spare lanes in the wavefront - a loop of its own, so that the plain one
+// pays nothing for them)
+template <class CH, bool HAS_SIGNAL, bool FAST_HEAD, bool MIX = false, bool SCALED = false>
 __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, float xc, float* strip = nullptr, bool live = true)
 {
+  const float mixGain = (SCALED && a.mixGains) ? a.mixGains[v] : 1.f;
   const f32x4* pin = HAS_SIGNAL ? (const f32x4*)a.in.base + v * a.in.strideV : nullptr;
   f32x4* pout = MIX ? nullptr : (f32x4*)a.out.base + v * a.out.strideV;
   const size_t inQ = a.in.strideQ, outQ = a.out.strideQ;
@@ -90,7 +93,18 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
       if constexpr (MIX)
       {
         const uint32_t lane = threadIdx.x & 63u;
-        *(f32x4*)(strip + lane * 20 + (lane >> 4) * 16 + 4 * (q & 3)) = live ? y : f32x4{0.f, 0.f, 0.f, 0.f};  // (a voice the bank does not have counts as +0)
+        if constexpr (SCALED)
+        {
+          if (a.mixGains)  // (wave-uniform; the first stage's `y *= g`)
+          {
+            y.x *= mixGain;
+            y.y *= mixGain;
+            y.z *= mixGain;
+            y.w *= mixGain;
+          }
+          if (!live) y = f32x4{0.f, 0.f, 0.f, 0.f};  // (a voice the bank does not have counts as +0)
+        }
+        *(f32x4*)(strip + lane * 20 + (lane >> 4) * 16 + 4 * (q & 3)) = y;
         if ((q & 3) == 3)
         {
           // (the strip is this wavefront's own: its lanes run in lockstep, the LDS operations of a wavefront complete in order)
@@ -154,7 +168,22 @@ __device__ __forceinline__ void chain_kernel_body(const ChainArgs& a)
   // range test: decide once per wavefront which loop body to run.
   bool fastHead = false;
   if constexpr (!HAS_SIGNAL && CH::kHeadHasFastPath) fastHead = (__builtin_amdgcn_ballot_w64(CH::head_input_is_odd(xc)) == 0);
-  if (fastHead)
+  if constexpr (MIX)
+  {
+    const bool scaled = a.mixGains != nullptr || __builtin_amdgcn_ballot_w64(!live) != 0;  // (the same in all lanes)
+    if (scaled)
+    {
+      if (fastHead)
+        run_voice<CH, HAS_SIGNAL, true, true, true>(ch, a, v, xc, strip, live);
+      else
+        run_voice<CH, HAS_SIGNAL, false, true, true>(ch, a, v, xc, strip, live);
+    }
+    else if (fastHead)
+      run_voice<CH, HAS_SIGNAL, true, true>(ch, a, v, xc, strip, live);
+    else
+      run_voice<CH, HAS_SIGNAL, false, true>(ch, a, v, xc, strip, live);
+  }
+  else if (fastHead)
     run_voice<CH, HAS_SIGNAL, true, MIX>(ch, a, v, xc, strip, live);
   else
     run_voice<CH, HAS_SIGNAL, false, MIX>(ch, a, v, xc, strip, live);

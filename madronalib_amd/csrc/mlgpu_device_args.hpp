@@ -33,6 +33,7 @@ struct ChainArgs
   const float* impulseTable;
   uint32_t flags;  // MLGPU_KFLAG_*
   float* mix;      // chain_mix_kernel: the rows of 64-voice group sums, [(group * T + t) * 64 + sample] (mlgpu_mixdown's first stage); else unused
+  const float* mixGains;  // ... and the per-voice gains the voices are scaled by before (mlgpu_mixdown's d_gains), or nullptr
 };
 
 // EventsToSignals settings the device needs (events.hip, mldsp_events.hpp)

@@ -250,9 +250,10 @@ def test_bank_process_mixdown_same_bits(eng, oracle, V, T, chain, signal):
     d_two, d_one = eng.alloc(4 * T * 64), eng.alloc(4 * T * 64)
     for k in range(launches):
         d_in = eng.to_device(np.ascontiguousarray(fsig[:, k * 64 * T:(k + 1) * 64 * T])) if signal else None
+        d_g = eng.to_device(rng.uniform(-1, 1, V).astype(np.float32)) if k == 1 else None      # the second launch with per-voice gains
         banks[0].process(T, d_voices, Layout.QUAD, d_in, Layout.VOICE_MAJOR)
-        eng.mixdown(d_voices, Layout.QUAD, V, T, d_two)
-        banks[1].process_mixdown(T, d_one, d_in, Layout.VOICE_MAJOR)
+        eng.mixdown(d_voices, Layout.QUAD, V, T, d_two, d_g)
+        banks[1].process_mixdown(T, d_one, d_in, Layout.VOICE_MAJOR, d_g)
         two, one = d_two.download(np.float32, 64 * T), d_one.download(np.float32, 64 * T)
         assert_bits_equal(one, two, True, f"bank_process_mixdown launch {k}")
         assert np.isfinite(two).all() and np.abs(two).max() > 1e-6, (k, two[:8])

@@ -35,7 +35,7 @@ static int onVectors(void* user, size_t nVectors, const float* const*, float* co
   // round 5: the voices summed inside the voice kernel, their signals never written (the same bits as the two calls below);
   // RT_TWO_CALLS=1 in the environment runs round 4's form
   static const bool twoCalls = getenv("RT_TWO_CALLS") != nullptr;
-  if (!twoCalls) return mlgpu_bank_process_mixdown(in->raw, nVectors, nullptr, MLGPU_LAYOUT_QUAD, dOut[0]);
+  if (!twoCalls) return mlgpu_bank_process_mixdown(in->raw, nVectors, nullptr, MLGPU_LAYOUT_QUAD, nullptr, dOut[0]);
   int st = mlgpu_bank_process(in->raw, nVectors, nullptr, MLGPU_LAYOUT_QUAD, in->d_voices, MLGPU_LAYOUT_QUAD);
   if (st != MLGPU_OK) return st;
   return mlgpu_mixdown(in->eng->handle(), in->d_voices, MLGPU_LAYOUT_QUAD, in->V, nVectors, nullptr, dOut[0]);
