@@ -962,9 +962,13 @@ int mlgpu_mixdown(mlgpu_engine* e, const float* d_signal, int layout, size_t n_v
  * memory: the voice kernel adds up the 64 voices of each wavefront itself - the first stage's tree, so d_out has the SAME BITS as
  * the two calls give - and the later stages follow. For a 2^20-voice bank paced at 48 kHz that halves the device time of a block
  * (DESIGN.md 3.7). For the fused voice chains (SawGen -> Bandpass -> Gain and the others mlgpu_bank_kernel_name shows as one
- * kernel), any voice count; MLGPU_ERR_UNSUPPORTED for other banks (then make the two calls). Needs the same
+ * kernel), any voice count; MLGPU_ERR_UNSUPPORTED for other banks until mlgpu_bank_prepare_mixdown has been called for them. Needs the same
  * mlgpu_mixdown_reserve as mlgpu_mixdown. State and coefficients as after mlgpu_bank_process. */
 int mlgpu_bank_process_mixdown(mlgpu_bank* bank, size_t n_vectors, const float* d_in, int in_layout, const float* d_gains, float* d_out);
+/* Setup, for a bank whose chain is not one of those: generate the summing form of its kernel (hiprtc; cached on disk like every generated
+ * kernel), after which mlgpu_bank_process_mixdown serves it too - any chain of bank processors, fused or not. MLGPU_OK at once where the
+ * form is there already. */
+int mlgpu_bank_prepare_mixdown(mlgpu_bank* bank);
 
 /* Sum every `group_size` consecutive voices into one: out voice g = ((0 + v[g*P]) + v[g*P+1]) + ... in voice order — the
  * `outputs[c] += ...` accumulation of Synth::processVector (source/app/MLSynth.h:43-57), bit for bit. The result is a signal

@@ -922,10 +922,14 @@ class Bank:
         pout = ctypes.c_void_p(d_out.ptr if hasattr(d_out, "ptr") else int(d_out))
         self.engine._check(self.L.mlgpu_bank_process(self.h, int(n_vectors), pin, int(in_layout), pout, int(out_layout)))
 
+    def prepare_mixdown(self):
+        """Setup: generate the summing form of this bank's kernel if it has none ahead of time (mlgpu_bank_prepare_mixdown)."""
+        self.engine._check(self.L.mlgpu_bank_prepare_mixdown(self.h))
+
     def process_mixdown(self, n_vectors, d_out, d_in=None, in_layout=Layout.QUAD, d_gains=None):
         """process + Engine.mixdown of its output (no gains) in one call, the voices' signals never written: d_out gets the 64 *
         n_vectors samples of their sum, the same bits as the two calls give (mlgpu_bank_process_mixdown; Status.ERR_UNSUPPORTED for
-        banks that are not one fused kernel)."""
+        banks whose chain has no ahead-of-time summing form until prepare_mixdown() was called)."""
         pin = None if d_in is None else ctypes.c_void_p(d_in.ptr if hasattr(d_in, "ptr") else int(d_in))
         pout = ctypes.c_void_p(d_out.ptr if hasattr(d_out, "ptr") else int(d_out))
         pg = None if d_gains is None else ctypes.c_void_p(d_gains.ptr if hasattr(d_gains, "ptr") else int(d_gains))

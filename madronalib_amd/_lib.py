@@ -159,6 +159,7 @@ def _declare(L):
     sig("mlgpu_bank_set_input_const", i, [vp, vp])
     sig("mlgpu_bank_process", i, [vp, sz, vp, i, vp, i])
     sig("mlgpu_bank_process_mixdown", i, [vp, sz, vp, i, vp, vp])
+    sig("mlgpu_bank_prepare_mixdown", i, [vp])
     sig("mlgpu_bank_is_fused", i, [vp])
     sig("mlgpu_bank_kernel_name", c.c_char_p, [vp])
     ip = c.POINTER(c.c_int)

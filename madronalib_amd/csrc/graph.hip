@@ -1414,6 +1414,24 @@ bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSign
 
 hipError_t mlgpu_jit_chain_launch(void* fn, const ChainArgs& a, hipStream_t stream) { return launchJit((hipFunction_t)fn, a, a.V, stream); }
 
+// ... and the form of a chain that sums its voices inside the kernel (chain_kernel_body<CH, HAS_SIGNAL, true>, mlgpu_bank_prepare_mixdown):
+// generated on request for the chains chains.hip has no ahead-of-time instantiation of
+bool mlgpu_jit_chain_mix(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log)
+{
+  std::ostringstream s;
+  s << "// generated by libmlgpu graph.hip (chain, voices summed in the kernel)\n" << (e->strictSvf ? "#define MLGPU_SVF_STRICT 1\n" : "")
+    << "#include \"mldsp_kernels.hpp\"\nusing namespace mldev;\nusing CH = Chain<";
+  for (int i = 0; i < n; ++i) s << (i ? ", " : "") << kinds[i];
+  s << ">;\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void mlgpu_chain_mix_signal(const ChainArgs a) { chain_kernel_body<CH, true, true>(a); }\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void mlgpu_chain_mix_const(const ChainArgs a) { chain_kernel_body<CH, false, true>(a); }\n";
+  CompiledModule* cm = compileAndLoad(e->device, s.str(), log);
+  if (!cm) return false;
+  *fnSignal = (void*)getFunction(cm, "mlgpu_chain_mix_signal", log);
+  *fnConst = (void*)getFunction(cm, "mlgpu_chain_mix_const", log);
+  return *fnSignal && *fnConst;
+}
+
 extern "C"
 {
   int mlgpu_jit_stats(uint64_t* compiles, uint64_t* diskHits, uint64_t* memoryHits, double* compileSeconds, double* diskLoadSeconds)

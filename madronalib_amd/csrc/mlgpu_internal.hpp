@@ -123,6 +123,7 @@ hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t 
 // graph.hip — run-time fused kernels (hiprtc)
 bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);  // honours e->strictSvf
 hipError_t mlgpu_jit_chain_launch(void* fn, const ChainArgs& a, hipStream_t stream);
+bool mlgpu_jit_chain_mix(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);
 
 // coeffs.cpp
 void mlgpu_build_impulse_table(float* out17);

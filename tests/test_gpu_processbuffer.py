@@ -267,15 +267,64 @@ def test_bank_process_mixdown_refusals(eng):
     import madronalib_amd as ml
     d_out = eng.alloc(4 * 64)
     eng.mixdown_reserve(4096, 1)
-    for procs, V in (((Proc.LOPASS,), 128),                                  # no summing form of this kernel
-                     ((Proc.SAW_GEN, Proc.LOPASS, Proc.HIPASS, Proc.GAIN), 128)):   # not one fused kernel
+    for procs, V in (((Proc.LOPASS,), 128),                                  # no ahead-of-time summing form of these kernels:
+                     ((Proc.SAW_GEN, Proc.LOPASS, Proc.HIPASS, Proc.GAIN), 128)):   # prepare_mixdown at setup
         b = eng.bank(list(procs), V)
         with pytest.raises(ml.MlgpuError) as ei:
             b.process_mixdown(1, d_out)
-        assert ei.value.status == ml.Status.ERR_UNSUPPORTED
+        assert ei.value.status == ml.Status.ERR_UNSUPPORTED and "prepare_mixdown" in str(ei.value)
     small = ml.Engine(0)
     b = small.bank([Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN], 8192)
     with pytest.raises(ml.MlgpuError) as ei:
         b.process_mixdown(1, small.alloc(4 * 64))        # nothing reserved: a process call refuses instead of allocating
     assert ei.value.status == ml.Status.ERR_INVALID and "mixdown_reserve" in str(ei.value)
     small.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chain,signal,strict", [((Proc.LOPASS,), True, False), ((Proc.SAW_GEN, Proc.LOPASS, Proc.HIPASS, Proc.GAIN), False, False),
+                                                 ((Proc.LOPASS,) * 4, True, False), ((Proc.NOISE_GEN,) + (Proc.LOPASS,) * 8, False, False),
+                                                 ((Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN), False, True)])
+def test_bank_prepare_mixdown_any_chain(oracle, chain, signal, strict):
+    """mlgpu_bank_prepare_mixdown: the summing form generated at setup for chains that have none ahead of time - a single processor, a
+    chain hiprtc fuses, stage-skewed SVF cascades (whose summing form is the plain chain on the same state words), and every chain of
+    an engine in strict SVF mode - then mlgpu_bank_process_mixdown against the two calls it replaces, bits and state, three launches."""
+    import madronalib_amd as ml
+    eng = ml.Engine(0)
+    if strict:
+        eng.set_strict_svf(True)
+    V, T, launches = 1000, 2, 3
+    rng = np.random.default_rng(7)
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 11, 64 * T * launches) if chain[0] in (Proc.LOPASS,) else \
+        (55.0 * 2.0 ** (5.0 * rng.random((V, 1))) / 48000.0 * np.ones((1, 64 * T * launches))).astype(np.float32)
+    eng.mixdown_reserve(V, T)
+    banks = [eng.bank(list(chain), V) for _ in range(2)]
+    for b in banks:
+        b.clear()
+        for p, kind in enumerate(chain):
+            if kind in (Proc.LOPASS, Proc.HIPASS, Proc.BANDPASS):
+                name = {Proc.LOPASS: "lopass", Proc.HIPASS: "hipass", Proc.BANDPASS: "bandpass"}[kind]
+                few = np.stack([oracle.make_coeffs(name, 0.02 + 0.3 * j / 16, 0.6) for j in range(16)], 1)
+                b.set_coeffs(p, [np.ascontiguousarray(few[i][np.arange(V) % 16]) for i in range(few.shape[0])])
+            elif kind == Proc.GAIN:
+                b.set_coeff(p, 0, 0.25)
+        if not signal and chain[0] != Proc.NOISE_GEN:
+            b.set_input_const(np.ascontiguousarray(x[:, 0]))
+        if chain[0] == Proc.NOISE_GEN:
+            b.set_state(0, 0, np.arange(1, V + 1, dtype=np.uint32))
+    banks[1].prepare_mixdown()
+    banks[1].prepare_mixdown()      # (idempotent)
+    d_voices = eng.alloc(4 * V * T * 64)
+    d_two, d_one = eng.alloc(4 * T * 64), eng.alloc(4 * T * 64)
+    for k in range(launches):
+        d_in = eng.to_device(np.ascontiguousarray(x[:, k * 64 * T:(k + 1) * 64 * T])) if signal else None
+        banks[0].process(T, d_voices, Layout.QUAD, d_in, Layout.VOICE_MAJOR)
+        eng.mixdown(d_voices, Layout.QUAD, V, T, d_two)
+        banks[1].process_mixdown(T, d_one, d_in, Layout.VOICE_MAJOR)
+        two, one = d_two.download(np.float32, 64 * T), d_one.download(np.float32, 64 * T)
+        assert_bits_equal(one, two, True, f"launch {k}")
+        assert np.isfinite(two).all() and np.abs(two).max() > 1e-6
+    for p in range(len(chain)):
+        for i in range(banks[0].num_state(p)):
+            assert (banks[0].get_state(p, i) == banks[1].get_state(p, i)).all(), (p, i)
+    eng.close()
