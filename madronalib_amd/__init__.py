@@ -1167,6 +1167,11 @@ class Graph:
         """Output `output_index` becomes the in-order sum of groups of `group` adjacent voices (V / group channels)."""
         self._check(self.L.mlgpu_graph_set_output_group_sum(self.h, int(output_index), int(group)))
 
+    def set_output_mixdown(self, output_index, on=True):
+        """Output `output_index` becomes one channel: the mixdown of all voices, mlgpu_mixdown's bits, made inside the voice kernel
+        (mlgpu_graph_set_output_mixdown). process() then wants 64 * n_vectors floats for it."""
+        self._check(self.L.mlgpu_graph_set_output_mixdown(self.h, int(output_index), 1 if on else 0))
+
     def set_input_group(self, input_index, group):
         """Input `input_index` is a signal of V / group rows: voice v reads row v // group (one controller or transport signal per
         instrument of `group` voices)."""

@@ -459,6 +459,7 @@ struct mlgpu_graph
   std::vector<Node> nodes;
   std::vector<int> outputs;
   int inputGroup[MLGPU_GRAPH_MAX_INPUTS] = {};  // > 1: the input has one row per that many adjacent voices (mlgpu_graph_set_input_group)
+  bool outputMix[MLGPU_GRAPH_MAX_OUTPUTS] = {false, false, false, false, false, false, false, false};  // the output is the mixdown of all voices (graph_set_output_mixdown)
   int outputGroup[MLGPU_GRAPH_MAX_OUTPUTS] = {0, 0, 0, 0, 0, 0, 0, 0};  // > 0: the output is the in-order sum of groups of that many adjacent voices
   int nInputs{0}, nParams{0}, nControls{0}, NC{0}, NS{0};
   bool compiled{false};
@@ -751,6 +752,8 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
 // mlgpu_graph_set_autotune lets the first launches try all four forms and keep the fastest.
 int graphVoicesPerLane(const mlgpu_graph* g)
 {
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    if (g->outputMix[o]) return 1;
   if (g->voicesPerLane > 0)
   {
     for (const Node& n : g->nodes)
@@ -800,7 +803,15 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   // spare lanes running. They run the bank's last voice again - same inputs, same state, same stores - on ring memory and LDS
   // columns of their own (vr: the lane's place; the rings are laid out for whole 256-voice blocks and cleared together, so a spare
   // lane's ring always holds what the last voice's holds).
-  const bool partialWaves = g->transposedRings && g->totalRings && (g->V % 64);
+  bool anyMix = false;
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    if (g->outputMix[o])
+    {
+      anyMix = true;
+      s << "  __shared__ __attribute__((aligned(16))) float ldsMix" << o << "[4 * kMixStrip];\n  float* const mstrip" << o << " = ldsMix" << o << " + (threadIdx.x >> 6) * kMixStrip;\n";
+    }
+  // (... and so does an output that is the mixdown of all voices: the tree over a wavefront's 64 lanes, a spare lane adds +0)
+  const bool partialWaves = ((g->transposedRings && g->totalRings) || anyMix) && (g->V % 64);
   s << "  size_t blk = blockIdx.x;\n  const size_t nbFull = (size_t)gridDim.x & ~(size_t)7;\n"
        "  if (blk < nbFull) blk = (blk & 7) * (nbFull >> 3) + (blk >> 3);\n";
   if (partialWaves)
@@ -906,7 +917,9 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (size_t o = 0; o < g->outputs.size(); ++o)
     for (int l = 0; l < VL; ++l)
     {
-      if (g->outputGroup[o])
+      if (g->outputMix[o])  // the rows of 64-voice group sums (mlgpu_mixdown's first stage): [(group * T + t) * 64 + sample]
+        s << "  float* const out" << o << sfx(l) << " = (float*)a.out[" << o << "].base + ((" << (partialWaves ? "vr" : "v") << sfx(l) << " >> 6) * a.T) * 64;\n";
+      else if (g->outputGroup[o])
         s << "  f32x4* out" << o << sfx(l) << " = (f32x4*)a.out[" << o << "].base + (v" << sfx(l) << " / " << g->outputGroup[o] << ") * a.out[" << o << "].strideV;\n";
       else
         s << "  f32x4* out" << o << sfx(l) << " = (f32x4*)a.out[" << o << "].base + v" << sfx(l) << " * a.out[" << o << "].strideV;\n";
@@ -1216,7 +1229,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << "      group16_park(strip" << o << ", q & 3, y" << o << "_0);\n      if ((q & 3) == 3) group16_sum_store(strip" << o << ", out" << o << "_0 + t * a.out[" << o
         << "].strideT + (q - 3) * a.out[" << o << "].strideQ, a.out[" << o << "].strideQ);\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
-    for (int l = 0; l < VL && !ldsSum(o); ++l)
+    if (g->outputMix[o])
+      s << "      mix64_park(mstrip" << o << ", q & 3, " << (partialWaves ? "(vr_0 < a.V) ? y" + std::to_string(o) + "_0 : f32x4{0.f, 0.f, 0.f, 0.f}" : "y" + std::to_string(o) + "_0")
+        << ");\n      if ((q & 3) == 3) mix64_sum_store(mstrip" << o << ", out" << o << "_0 + t * 64 + (q - 3) * 4);\n";
+  for (size_t o = 0; o < g->outputs.size(); ++o)
+    for (int l = 0; l < VL && !ldsSum(o) && !g->outputMix[o]; ++l)
       s << "      " << (g->outputGroup[o] ? "if ((threadIdx.x & " + std::to_string(g->outputGroup[o] - 1) + ") == " + std::to_string(g->outputGroup[o] - 1) + ") " : std::string())
         << "__builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o << "].strideQ);\n";
   s << "    }\n";
@@ -1890,7 +1907,21 @@ extern "C"
     if (group != 0 && group != 2 && group != 4 && group != 8 && group != 16)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_set_output_group_sum: groups of 2, 4, 8 or 16 voices (other sizes: mlgpu_mixdown_groups)");
     if (group && g->V % (size_t)group) return gfail(g, MLGPU_ERR_INVALID, "graph_set_output_group_sum: the voices are not a whole number of groups");
+    if (group && g->outputMix[index]) return gfail(g, MLGPU_ERR_INVALID, "graph_set_output_group_sum: the output is a mixdown already");
     g->outputGroup[index] = group;
+    return MLGPU_OK;
+  }
+  // Output `index` becomes ONE channel: the mixdown of all voices (mlgpu_mixdown's order and bits, its first stage inside the voice
+  // kernel - the voices' signal of that output is never written). graph_process then wants 64 * n_vectors floats for it, whatever
+  // the output layout, and scratch reserved with mlgpu_mixdown_reserve(engine, voices x mixed outputs, vectors).
+  int mlgpu_graph_set_output_mixdown(mlgpu_graph* g, int index, int on)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
+    if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
+    if (index < 0 || index >= (int)g->outputs.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_set_output_mixdown: no such output");
+    if (on && g->outputGroup[index]) return gfail(g, MLGPU_ERR_INVALID, "graph_set_output_mixdown: the output is a group sum already");
+    g->outputMix[index] = on != 0;
     return MLGPU_OK;
   }
   int mlgpu_graph_node(mlgpu_graph* g, const char* name)
@@ -1958,6 +1989,9 @@ extern "C"
     const bool partialOk = g->V % 64 == 0 || !groupedOrEvents;
     if (g->transposedRings && g->totalRings && !partialOk)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 with voice sums or event rows inside the kernel needs whole wavefronts (voices a multiple of 64)");
+    for (size_t o = 0; o < g->outputs.size(); ++o)
+      if (g->outputMix[o] && !partialOk)
+        return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: an output that is the mixdown of all voices, next to group sums or event rows, needs whole wavefronts (voices a multiple of 64)");
     if (g->transposedIfPossible)
       g->transposedRings = partialOk && g->totalRings != 3 && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) <= 160 * 1024;
     if (g->transposedRings && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
@@ -2074,6 +2108,8 @@ extern "C"
     {
       // candidates: 1 or 2 voices per lane (where the graph allows two and the caller did not force one), 1 or 2 quads per trip
       const bool twoOk = g->voicesPerLane == 0 && [&] {
+        for (size_t o = 0; o < g->outputs.size(); ++o)
+          if (g->outputMix[o]) return false;
         for (const Node& n : g->nodes)
           if (n.type == NODE_FEEDBACK || n.type == NODE_EVENT_ROW || (n.type == NODE_PROC && (mlgpu_proc_rings(n.kind) || mlgpu_proc_is_vector_rate(n.kind)))) return false;
         return true;
@@ -2436,6 +2472,18 @@ extern "C"
       if (!d_outputs[o] || ((uintptr_t)d_outputs[o] & 15)) return gfail(g, MLGPU_ERR_INVALID, "graph_process: null / misaligned output");
       a.out[o] = makeView(d_outputs[o], outLayout, g->outputGroup[o] ? g->V / (size_t)g->outputGroup[o] : g->V, T);
     }
+    // outputs that are mixdowns: the kernel writes the rows of 64-voice group sums into the engine's mixdown scratch (one region per
+    // such output), the later stages follow the launch
+    const size_t mixGroups = (g->V + 63) / 64, mixRegion = (mixGroups + (mixGroups + 63) / 64) * T * 64;
+    size_t nMix = 0;
+    for (size_t o = 0; o < g->outputs.size(); ++o)
+      if (g->outputMix[o])
+      {
+        a.out[o] = makeView(g->e->d_mixScratch + nMix * mixRegion, MLGPU_LAYOUT_QUAD, g->V, T);
+        ++nMix;
+      }
+    if (nMix * mixRegion > g->e->mixScratchFloats)
+      return gfail(g, MLGPU_ERR_INVALID, "graph_process: call mlgpu_mixdown_reserve(engine, voices x mixed outputs, max vectors) at setup (process calls do not allocate)");
     if (g->e->recording)
     {
       if (g->autotune && !g->tuned) return gfail(g, MLGPU_ERR_INVALID, "graph_process: a graph that is still tuning cannot be recorded into a sequence");
@@ -2510,6 +2558,13 @@ extern "C"
       const int est = mlgpu_events_launched_by_graph(g->events, eventStaging);
       if (est != MLGPU_OK) return gfail(g, est, "graph_process: events bookkeeping after the launch");
     }
+    for (size_t o = 0, r = 0; o < g->outputs.size(); ++o)
+      if (g->outputMix[o])
+      {
+        if (mlgpu_launch_mixdown_rows(mixGroups, T, g->e->d_mixScratch + r * mixRegion, d_outputs[o], g->e->stream, g->e->kflags) != hipSuccess)
+          return gfail(g, MLGPU_ERR_HIP, "graph_process: the mixdown's later stages");
+        ++r;
+      }
     if (trial)
     {
       hipEventRecord(g->tuneEv1, g->e->stream);

@@ -45,6 +45,28 @@ struct MixTree16<LO, 1>
   static __device__ __forceinline__ float sum(const float* col) { return col[LO * 20]; }
 };
 
+// a quad (four samples) of every lane into the strip, quad qq of the 16 samples a step adds up
+__device__ __forceinline__ void mix64_park(float* strip, int qq, f32x4 y)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  *(f32x4*)(strip + lane * 20 + (lane >> 4) * 16 + 4 * qq) = y;
+}
+// ... and after the fourth quad: the 16 sums of the wavefront's 64 voices, stored by lanes 0 .. 15 to row16[0 .. 15]
+__device__ __forceinline__ void mix64_sum_store(const float* strip, float* row16)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  // (the strip is this wavefront's own: its lanes run in lockstep, the LDS operations of a wavefront complete in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint32_t s = lane & 15u, g = lane >> 4;
+  const float t16 = MixTree16<0, 16>::sum(strip + g * (16 * 20 + 16) + s);
+  const float t32 = t16 + u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 16u) & 63u) * 4u), (int)f2u(t16)));
+  const float t64 = t32 + u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 32u) & 63u) * 4u), (int)f2u(t32)));
+  if (lane < 16) row16[s] = t64;
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool MIX>
 struct MixStrips
 {
@@ -92,7 +114,6 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
       y.w = ch.template next_head<FAST_HEAD>(x.w);
       if constexpr (MIX)
       {
-        const uint32_t lane = threadIdx.x & 63u;
         if constexpr (SCALED)
         {
           if (a.mixGains)  // (wave-uniform; the first stage's `y *= g`)
@@ -104,20 +125,8 @@ __device__ __forceinline__ void run_voice(CH& ch, const ChainArgs& a, size_t v, 
           }
           if (!live) y = f32x4{0.f, 0.f, 0.f, 0.f};  // (a voice the bank does not have counts as +0)
         }
-        *(f32x4*)(strip + lane * 20 + (lane >> 4) * 16 + 4 * (q & 3)) = y;
-        if ((q & 3) == 3)
-        {
-          // (the strip is this wavefront's own: its lanes run in lockstep, the LDS operations of a wavefront complete in order)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          const uint32_t s = lane & 15u, g = lane >> 4;
-          const float t16 = MixTree16<0, 16>::sum(strip + g * (16 * 20 + 16) + s);
-          const float t32 = t16 + u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 16u) & 63u) * 4u), (int)f2u(t16)));
-          const float t64 = t32 + u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 32u) & 63u) * 4u), (int)f2u(t32)));
-          if (lane < 16) a.mix[((v >> 6) * a.T + t) * 64 + (size_t)(q & ~3) * 4 + s] = t64;
-          __builtin_amdgcn_wave_barrier();
-        }
+        mix64_park(strip, q & 3, y);
+        if ((q & 3) == 3) mix64_sum_store(strip, a.mix + ((v >> 6) * a.T + t) * 64 + (size_t)(q & ~3) * 4);
       }
       else
         __builtin_nontemporal_store(y, po + q * outQ);

@@ -1061,3 +1061,103 @@ def test_oscillator_trips_equal_the_per_sample_form_on_free_running_phases(eng, 
     for i, (x, y) in enumerate(zip(res[None], res["0"])):
         assert_bits_equal(x, y, False, f"trip form against per-sample form, item {i}")
     assert np.abs(res[None][0]).max() > 0.9 and np.abs(res[None][1]).max() >= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [320, 1000, 4096 + 77, 65536 + 4096 + 192])      # whole wavefronts and not; one to three row passes
+def test_graph_output_mixdown_same_bits(eng, V):
+    """mlgpu_graph_set_output_mixdown: config 5's 16-node voice with its output turned into the mixdown of all voices - the tree over
+    each wavefront made inside the voice kernel, the voices' signal never written - against the same graph's voices put through
+    mlgpu_mixdown (whose order the oracle pins in test_mixdown_vs_oracle): the same bits, three launches, and the same state after."""
+    import madronalib_amd as ml
+    from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
+    T, L = 2, 3
+    desc, outs = patches.synth16()
+    params, coeffs, seeds = cfg5_voice_params(0, V, V, ml)
+    eng.mixdown_reserve(V, T)
+    graphs = []
+    for mixed in (False, True):
+        g = ml.Graph(eng, V, desc, outs, compile_now=False)
+        if mixed:
+            g.set_output_mixdown(0)
+        g.compile()
+        g.clear()
+        for k, v in params.items():
+            g.set_param(k, v if np.ndim(v) else float(v))
+        for k, c in coeffs.items():
+            g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
+        g.set_state("noise", 0, seeds)
+        graphs.append(g)
+    d_gate = eng.to_device(cfg5_gate_quad(0, V, T))
+    d_voices, d_two, d_one = eng.alloc(4 * V * T * 64), eng.alloc(4 * T * 64), eng.alloc(4 * T * 64)
+    for launch in range(L):
+        graphs[0].process(T, [d_gate], [d_voices])
+        eng.mixdown(d_voices, Layout.QUAD, V, T, d_two)
+        graphs[1].process(T, [d_gate], [d_one])
+        two, one = d_two.download(np.float32, 64 * T), d_one.download(np.float32, 64 * T)
+        assert_bits_equal(one, two, True, f"graph output mixdown, launch {launch}")
+        assert np.isfinite(two).all() and np.abs(two).max() > 1e-4
+    for name in ("saw", "pulse", "lfo", "noise", "lp", "hp", "smooth", "dc", "env"):
+        i = 0
+        while True:
+            try:
+                a = graphs[0].get_state(name, i)
+            except ml.MlgpuError:
+                break
+            assert (a == graphs[1].get_state(name, i)).all(), (name, i)
+            i += 1
+        assert i > 0, name
+    for g in graphs:
+        g.close()
+
+
+@pytest.mark.gpu
+def test_graph_output_mixdown_next_to_a_plain_output_and_delay_rings(eng):
+    """Two outputs of one graph, one mixed down and one per voice, on a graph with a delay ring in layout 2 and a voice count that
+    fills neither a workgroup nor a wavefront: the mixed one equals mlgpu_mixdown of what the same graph gives per voice, the plain one
+    is untouched. And the rules: not with a group sum on the same output, scratch reserved for every mixed output."""
+    import madronalib_amd as ml
+    V, T = 777, 3
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 5, 64 * T)
+    outs = {}
+    for mixed in (False, True):
+        g = ml.Graph(eng, V, delay_windows=2)
+        g.add("x", "input")
+        g.add("d", "proc", Proc.INTEGER_DELAY, ["x"], max_delay=200.0)
+        g.add("y", "op", Op.ADD, ["x", "d"])
+        g.add_output("y")
+        g.add_output("d")
+        if mixed:
+            g.set_output_mixdown(0)
+            with pytest.raises(ml.MlgpuError):
+                g.set_output_group_sum(0, 4)
+        g.compile()
+        g.set_state("d", 1, ((np.arange(V) * 13) % 190).astype(np.uint32))
+        d_x = eng.to_device(x)
+        d_y = eng.alloc(4 * V * T * 64)
+        d_d = eng.alloc(4 * V * T * 64)
+        if mixed:
+            small = ml.Engine(0)
+            g2 = ml.Graph(small, 64)
+            g2.add("x", "input")
+            g2.add_output("x")
+            g2.set_output_mixdown(0)
+            g2.compile()
+            with pytest.raises(ml.MlgpuError) as ei:       # nothing reserved on that engine
+                g2.process(1, [small.alloc(4 * 64 * 64)], [small.alloc(4 * 64)])
+            assert "mixdown_reserve" in str(ei.value)
+            small.close()
+        eng.mixdown_reserve(V, T)
+        g.process(T, [d_x], [d_y, d_d], Layout.VOICE_MAJOR, Layout.VOICE_MAJOR)
+        if mixed:
+            outs["mix"] = d_y.download(np.float32, 64 * T).copy()
+            outs["d_mixed_graph"] = d_d.download(np.float32, V * T * 64).copy()
+        else:
+            d_m = eng.alloc(4 * 64 * T)
+            eng.mixdown(d_y, Layout.VOICE_MAJOR, V, T, d_m)
+            outs["two"] = d_m.download(np.float32, 64 * T).copy()
+            outs["d_plain_graph"] = d_d.download(np.float32, V * T * 64).copy()
+        g.close()
+    assert_bits_equal(outs["mix"], outs["two"], True, "mixed output")
+    assert_bits_equal(outs["d_mixed_graph"], outs["d_plain_graph"], True, "the other output")
+    assert np.abs(outs["two"]).max() > 0.1
