@@ -335,3 +335,61 @@ print(json.dumps(dict(stats=ml.jit_stats(), sha=hashlib.sha256(code).hexdigest()
     assert len({o["sha"] for o in outs}) == 1
     assert sum(o["stats"]["compiles"] for o in outs) == 1, [o["stats"] for o in outs]
     assert sum(o["stats"]["disk_hits"] for o in outs) == 7
+
+
+def test_offline_emit_of_round5_generator_forms():
+    """Generated-kernel forms of round 5, compiled here with hiprtc for gfx950 (no device): delay rings in layout 2 - whole wavefronts
+    and a bank whose last wavefront is not full (its spare lanes stay) -, layout 3's choice, an output that is the mixdown of all
+    voices, and the register / LDS budgets the measured kernels rely on."""
+    import madronalib_amd as ml
+    from madronalib_amd import patches
+    from madronalib_amd.constants import Op, Proc
+
+    def strings(V, layout):
+        desc = [dict(name="x", type="input"), dict(name="g", type="const", value=0.995),
+                dict(name="fb", type="feedback", source="damp"),
+                dict(name="fbg", type="op", kind=Op.MULTIPLY, inputs=["fb", "g"]),
+                dict(name="sum", type="op", kind=Op.ADD, inputs=["x", "fbg"]),
+                dict(name="line", type="proc", kind=Proc.FRACTIONAL_DELAY, inputs=["sum"], max_delay=1024.0),
+                dict(name="damp", type="proc", kind=Proc.ONE_POLE, inputs=["line"])]
+        return ml.Graph(ml.OfflineEngine(), V, desc, ["damp"], delay_windows=layout)
+
+    def facts(code):
+        notes = _code_object_notes(code)
+        return (int(re.search(r"\.vgpr_count:\s+(\d+)", notes).group(1)), int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", notes).group(1)),
+                int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", notes).group(1)))
+
+    g = strings(262144, 2)
+    source, code = g.emit()
+    vgpr, scratch, lds = facts(code)
+    assert "MLGPU_RING_WINDOWS 2" in source and "__launch_bounds__(256, 4)" in source and "vr_0" not in source
+    assert vgpr <= 128 and scratch <= 64 and lds == 4 * 40 * 64 * 4          # four wavefronts x (8 + 32) rows x 64 lanes: a CU holds four workgroups
+    g.close()
+    g = strings(1000, 2)                                                        # 1000 = 15 wavefronts + 40 voices
+    source, code = g.emit()
+    assert "const size_t v_0 = vr_0 < a.V ? vr_0 : a.V - 1;" in source and "(vr_0 >> 8)" in source and code[:4] == b"\x7fELF"
+    g.close()
+    for V, n_delays, want in ((256, 2, 2), (256, 3, 1), (100, 1, 2), (256, 5, 1)):
+        g = ml.Graph(ml.OfflineEngine(), V, delay_windows="best")
+        g.add("x", "input")
+        src = "x"
+        for j in range(n_delays):
+            g.add(f"d{j}", "proc", Proc.INTEGER_DELAY, [src], max_delay=300.0)
+            src = f"d{j}"
+        g.add_output(src)
+        source, _ = g.emit()
+        assert (f"MLGPU_RING_WINDOWS {want}" in source), (V, n_delays)
+        g.close()
+    # an output as the mixdown of all voices (mlgpu_graph_set_output_mixdown), next to a plain one, voices not a multiple of 64
+    desc, outs = patches.synth16()
+    g = ml.Graph(ml.OfflineEngine(), 1000, desc, outs, compile_now=False)
+    g.add_output("lp")
+    g.set_output_mixdown(0)
+    source, code = g.emit()
+    assert "mix64_park(mstrip0" in source and "mix64_sum_store(mstrip0" in source and "(vr_0 < a.V) ? y0_0" in source
+    assert "__builtin_nontemporal_store(y1_0" in source and "__builtin_nontemporal_store(y0_0" not in source
+    vgpr, scratch, lds = facts(code)
+    assert lds == 4 * (64 * 20 + 64) * 4 and scratch == 0
+    with pytest.raises(ml.MlgpuError):
+        g.set_output_group_sum(0, 8)
+    g.close()
