@@ -836,9 +836,10 @@ int mlgpu_graph_set_output_group_sum(mlgpu_graph* g, int output_index, int group
 /* Output `output_index` becomes ONE channel, the mixdown of ALL voices - mlgpu_mixdown's order and bits (no gains), its first stage (the
  * tree over each wavefront's 64 voices) inside the voice kernel, so that the voices' signal of that output is never written (the graph
  * counterpart of mlgpu_bank_process_mixdown). mlgpu_graph_process then takes 64 * n_vectors floats for it whatever the output layout;
- * the engine needs mlgpu_mixdown_reserve(engine, voices x the number of such outputs, max vectors) at setup. Any voice count - unless
- * the graph also sums groups or reads event rows in its kernel: then a multiple of 64. */
+ * mlgpu_graph_reserve_mixdown(g, max vectors) at setup sizes the engine's mixdown scratch for it (process calls never allocate).
+ * Any voice count - unless the graph also sums groups or reads event rows in its kernel: then a multiple of 64. */
 int mlgpu_graph_set_output_mixdown(mlgpu_graph* g, int output_index, int on);
+int mlgpu_graph_reserve_mixdown(mlgpu_graph* g, size_t max_vectors);
 
 /*
  * The pitch and gate rows as SOURCE NODES of a voice graph: a Synth's voices read voice.outputs.row(kPitch / kGate) straight

@@ -3172,6 +3172,10 @@ struct VoiceProgramOptions
   // visible part of it. Used when the rows are read from memory and processVoice reads no controller signal (those are made by the
   // events call into one buffer); otherwise the one-stream order is kept.
   bool eventsOnOwnStream{false};
+  // VoiceProgram: every audio output (ctx->outputs[c]) is the SUM of all voices - one channel, `outputs += voice` over the whole
+  // bank in mlgpu_mixdown's order, made inside the voice kernel (mlgpu_graph_set_output_mixdown): pass single-voice DeviceSignals
+  // for them to process(), and call reserveMixdown(max vectors per launch) once at setup. Published signals stay per voice.
+  bool mixOutputs{false};
 };
 
 // Captures a reference-style process function once and runs it for `voices` voices on the GPU.
@@ -3237,6 +3241,8 @@ class VoiceProgram
     finishGraph(cap, g_);
     taps_ = cap.taps;
     contextInputs_ = cap.contextInputs;
+    if (opt.mixOutputs)
+      for (size_t c = 0; c < nOut_; ++c) eng_.check(mlgpu_graph_set_output_mixdown(g_, (int)c, 1));
     eng_.check(mlgpu_graph_compile(g_));
     for (const Capture::Deferred& d : cap.deferred)
     {
@@ -3247,6 +3253,10 @@ class VoiceProgram
       else eng_.check(mlgpu_graph_set_state_uniform(g_, d.node, d.idx, d.bits));
     }
   }
+
+  // VoiceProgramOptions::mixOutputs: the scratch the mixdown's later stages need, for launches of up to maxVectors DSPVectors
+  // (setup; process calls never allocate)
+  void reserveMixdown(size_t maxVectors) { eng_.check(mlgpu_graph_reserve_mixdown(g_, maxVectors)); }
 
   // Host-side numbers changed (a parameter the process function turns into `DSPVector(value)`, a float argument of a
   // LinearGlide, `filter.coeffs = makeCoeffs(...)`): run the process function once more in capture mode and take the new

@@ -1172,6 +1172,10 @@ class Graph:
         (mlgpu_graph_set_output_mixdown). process() then wants 64 * n_vectors floats for it."""
         self._check(self.L.mlgpu_graph_set_output_mixdown(self.h, int(output_index), 1 if on else 0))
 
+    def reserve_mixdown(self, max_vectors):
+        """Setup: the engine's mixdown scratch for this graph's mixed-down outputs (mlgpu_graph_reserve_mixdown)."""
+        self._check(self.L.mlgpu_graph_reserve_mixdown(self.h, int(max_vectors)))
+
     def set_input_group(self, input_index, group):
         """Input `input_index` is a signal of V / group rows: voice v reads row v // group (one controller or transport signal per
         instrument of `group` voices)."""

@@ -185,6 +185,7 @@ def _declare(L):
     sig("mlgpu_graph_last_error", c.c_char_p, [vp])
     sig("mlgpu_graph_set_output_group_sum", i, [vp, i, i])
     sig("mlgpu_graph_set_output_mixdown", i, [vp, i, i])
+    sig("mlgpu_graph_reserve_mixdown", i, [vp, sz])
     sig("mlgpu_graph_set_input_group", i, [vp, i, i])
     sig("mlgpu_graph_add_event_row", i, [vp, i, c.c_char_p])
     sig("mlgpu_graph_bind_events", i, [vp, vp])

@@ -1924,6 +1924,17 @@ extern "C"
     g->outputMix[index] = on != 0;
     return MLGPU_OK;
   }
+  // setup: the engine's mixdown scratch for this graph's mixed-down outputs, launches of up to maxVectors DSPVectors
+  int mlgpu_graph_reserve_mixdown(mlgpu_graph* g, size_t maxVectors)
+  {
+    if (!g) return MLGPU_ERR_INVALID;
+    if (!g->e) return gfail(g, MLGPU_ERR_INVALID, "graph_reserve_mixdown: a graph without an engine");
+    size_t nMix = 0;
+    for (size_t o = 0; o < g->outputs.size(); ++o) nMix += g->outputMix[o] ? 1 : 0;
+    const size_t groups = (g->V + 63) / 64;
+    const int st = mlgpu_mixdown_reserve_floats(g->e, nMix * (groups + (groups + 63) / 64) * maxVectors * 64);
+    return st == MLGPU_OK ? st : gfail(g, st, "graph_reserve_mixdown: see the engine's last error");
+  }
   int mlgpu_graph_node(mlgpu_graph* g, const char* name)
   {
     if (!g || !name) return -MLGPU_ERR_INVALID;
@@ -2483,7 +2494,7 @@ extern "C"
         ++nMix;
       }
     if (nMix * mixRegion > g->e->mixScratchFloats)
-      return gfail(g, MLGPU_ERR_INVALID, "graph_process: call mlgpu_mixdown_reserve(engine, voices x mixed outputs, max vectors) at setup (process calls do not allocate)");
+      return gfail(g, MLGPU_ERR_INVALID, "graph_process: call mlgpu_graph_reserve_mixdown(graph, max vectors) at setup (mlgpu_mixdown_reserve's scratch; process calls do not allocate)");
     if (g->e->recording)
     {
       if (g->autotune && !g->tuned) return gfail(g, MLGPU_ERR_INVALID, "graph_process: a graph that is still tuning cannot be recorded into a sequence");

@@ -115,6 +115,7 @@ hipError_t mlgpu_launch_rows_normalize(const float* rows, float* out, size_t nRo
 hipError_t mlgpu_launch_rows_index(float* out, size_t rowsPerGroup, size_t groups, hipStream_t stream);
 hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, float* out,
                                 hipStream_t stream, uint32_t flags);
+int mlgpu_mixdown_reserve_floats(mlgpu_engine* e, size_t floats);  // capi.hip: the mixdown scratch grown to at least that
 hipError_t mlgpu_launch_mixdown_rows(size_t groups, size_t T, float* partial, float* out, hipStream_t stream, uint32_t flags);
 hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream, uint32_t flags);
 hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,

@@ -42,6 +42,40 @@ extern "C" int dropin_gpu_run(size_t V, size_t T, const float* gate, const float
   }
 }
 
+// ... and with VoiceProgramOptions::mixOutputs: the two outputs as the sum of all V voices (one channel each, [64T])
+extern "C" int dropin_gpu_run_mixed(size_t V, size_t T, const float* gate, const float* pitch, float* mix0, float* mix1, char* err, size_t errLen)
+{
+  try
+  {
+    gpu::Engine eng(0);
+    PatchState state;
+    patchSetup(state);
+    AudioContext ctx(2, 2, 48000);
+    gpu::VoiceProgramOptions opt;
+    opt.mixOutputs = true;
+    gpu::VoiceProgram prog(eng, V, &ctx, patchProcess, &state, opt);
+    prog.reserveMixdown(T);
+    gpu::DeviceSignal dGate(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR), dPitch(eng, V, T, MLGPU_LAYOUT_VOICE_MAJOR);
+    gpu::DeviceSignal dMix0(eng, 1, T, MLGPU_LAYOUT_VOICE_MAJOR), dMix1(eng, 1, T, MLGPU_LAYOUT_VOICE_MAJOR);
+    eng.check(mlgpu_upload(eng.handle(), dGate.data(), gate, dGate.bytes()));
+    eng.check(mlgpu_upload(eng.handle(), dPitch.data(), pitch, dPitch.bytes()));
+    prog.process({&dGate, &dPitch}, {&dMix0, &dMix1});
+    eng.check(mlgpu_download(eng.handle(), mix0, dMix0.data(), dMix0.bytes()));
+    eng.check(mlgpu_download(eng.handle(), mix1, dMix1.data(), dMix1.bytes()));
+    return 0;
+  }
+  catch (const gpu::Error& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return e.status ? e.status : -1;
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return -1;
+  }
+}
+
 #include "dropin_reverb.h"
 // the plate reverb for V independent instances; launches: how many process calls the T vectors are split into
 // knobsAt: the vector (a launch boundary) before which the host turns the knobs and calls VoiceProgram::update(); >= T: never

@@ -22,6 +22,8 @@ def _gpu_lib():
     L = ctypes.CDLL(so)
     L.dropin_gpu_run.restype = ctypes.c_int
     L.dropin_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p, ctypes.c_size_t]
+    L.dropin_gpu_run_mixed.restype = ctypes.c_int
+    L.dropin_gpu_run_mixed.argtypes = L.dropin_gpu_run.argtypes
     L.plate_gpu_run.restype = ctypes.c_int
     L.plate_gpu_run.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_char_p,
                                 ctypes.c_size_t]
@@ -89,6 +91,27 @@ def test_same_source_same_bits():
     assert_bits_equal(got0, want0, True, "drop-in patch output 0")
     assert_bits_equal(got1, want1, True, "drop-in patch output 1")
     assert np.abs(want0).max() > 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [384, 1000])
+def test_same_source_all_voices_mixed(oracle, V):
+    """VoiceProgramOptions::mixOutputs: the same unchanged process function, its two outputs as the sum of all voices made inside the
+    voice kernel - against the per-voice outputs of the same program added up in mlgpu_mixdown's order (the oracle's restatement)."""
+    Lg = _gpu_lib()
+    T = 12
+    gate, pitch = _inputs(V, T)
+    per0, per1 = np.zeros_like(gate), np.zeros_like(gate)
+    err = ctypes.create_string_buffer(2048)
+    assert Lg.dropin_gpu_run(V, T, gate.ctypes.data_as(c_f32p), pitch.ctypes.data_as(c_f32p), per0.ctypes.data_as(c_f32p),
+                             per1.ctypes.data_as(c_f32p), err, 2048) == 0, err.value.decode()
+    mix0, mix1 = np.zeros(64 * T, np.float32), np.zeros(64 * T, np.float32)
+    st = Lg.dropin_gpu_run_mixed(V, T, gate.ctypes.data_as(c_f32p), pitch.ctypes.data_as(c_f32p), mix0.ctypes.data_as(c_f32p),
+                                 mix1.ctypes.data_as(c_f32p), err, 2048)
+    assert st == 0, err.value.decode()
+    assert_bits_equal(mix0, oracle.mixdown(per0, None), True, "mixed output 0")
+    assert_bits_equal(mix1, oracle.mixdown(per1, None), True, "mixed output 1")
+    assert np.abs(mix0).max() > 0.05
 
 
 @pytest.mark.gpu
