@@ -56,6 +56,7 @@ WORKLOADS = {
     # rows, the voice graph reads them, mlgpu_mixdown_groups adds up the voices; MLGPU_BENCH_MIXDOWN=graph: the sum inside the voice kernel)
     "synth": (262144, 16, 8),
     "synthrows": (262144, 16, 8),
+    "cfg5mix": (262144, 16, 16),  # config 5's voices summed to one channel in the voice kernel (mlgpu_graph_set_output_mixdown)
     "strings": (262144, 16, 8),  # a plucked-string model per voice: noise burst -> FractionalDelay (per-voice length) -> OnePole -> feedback
     "mixgroups": (262144, 8, 16),  # the per-instrument voice sum alone, 16 voices per instrument
     "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
@@ -136,12 +137,18 @@ def setup_workload(eng, name, V, T, lo, total):
             eng.op_apply(Op.EXP_APPROX_OF_SIN_APPROX, d_x, None, None, d_y, n)
         return launch, 8.0 * n, "op_kernel<22>", \
             "BASELINE configs[1]: 65536 voices x 1 DSPVector elementwise expApprox(sinApprox(x)) (32 MiB: Infinity-Cache resident)", (d_x, d_y)
-    if name in ("cfg5", "cfg5full"):
+    if name in ("cfg5", "cfg5full", "cfg5mix"):
         from madronalib_amd import patches
         from madronalib_amd.sharding import cfg5_gate_quad, cfg5_voice_params
         full = name == "cfg5full"
         desc, outs = patches.synth16(full=full)
-        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=bool(os.environ.get("MLGPU_BENCH_AUTOTUNE")))
+        g = ml.Graph(eng, V, desc, outs, voices_per_lane=int(os.environ.get("MLGPU_VOICES_PER_LANE", "0")), autotune=bool(os.environ.get("MLGPU_BENCH_AUTOTUNE")),
+                     compile_now=False)
+        if name == "cfg5mix":      # config 5's voices to ONE channel: the output mixed down inside the voice kernel (round 5)
+            g.set_output_mixdown(0)
+        g.compile()
+        if name == "cfg5mix":
+            g.reserve_mixdown(T)
         g.clear()
         params, coeffs, seeds = cfg5_voice_params(lo, lo + V, total, ml, full=full)
         for k, v in params.items():
@@ -150,12 +157,16 @@ def setup_workload(eng, name, V, T, lo, total):
             g.set_coeffs(k, [np.ascontiguousarray(r) for r in c])
         g.set_state("noise", 0, seeds)
         d_gate = eng.to_device(cfg5_gate_quad(lo, lo + V, T))
-        outs_d = [eng.alloc(4 * n), eng.alloc(4 * n)]
+        outs_d = [eng.alloc(4 * (T * 64 if name == "cfg5mix" else n)) for _ in range(2)]
         k = [0]
 
         def launch():
             g.process(T, [d_gate], [outs_d[k[0] & 1]])
             k[0] += 1
+        if name == "cfg5mix":
+            return launch, 4.0 * n + V * 4.0 * (5 + 14 + 19 + 19), "mlgpu_graph_kernel", (
+                "BASELINE configs[4]'s 16-node voice, 262144 voices/GPU mixed to ONE channel inside the voice kernel "
+                "(mlgpu_graph_set_output_mixdown: gate in, no per-voice audio out)"), g
         # gate in + audio out per voice-sample; per launch and voice: 5 params + 14 coeffs + 19 state words
         # read, 19 state words written (patches.synth16: NC = 3+4+2+1+4, NS = 1+1+1+1+2+2+1+2+8)
         alg = 8.0 * n + V * 4.0 * (5 + 14 + 19 + 19)
