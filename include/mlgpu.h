@@ -357,6 +357,12 @@ int mlgpu_sequence_destroy(mlgpu_sequence* s);
 
 int mlgpu_timer_start(mlgpu_engine* e);
 int mlgpu_timer_stop_ms(mlgpu_engine* e, float* ms_out); /* records + waits */
+/* Lap timer (measurement aid, no reference counterpart; the reference times with std::chrono around its loops, Tests/testUtils.h:136-189):
+ * laps_begin records an event on the engine's stream, every lap another, laps_end waits for the last and writes the
+ * durations between consecutive events (ms) - the DISTRIBUTION of a kernel's launch times, where timer_start / stop give the mean. */
+int mlgpu_timer_laps_begin(mlgpu_engine* e, size_t max_laps);
+int mlgpu_timer_lap(mlgpu_engine* e);
+int mlgpu_timer_laps_end(mlgpu_engine* e, float* ms_out, size_t capacity, size_t* n_out);
 
 /* ------------------------------------------------------------------------- */
 /* stateless ops                                                             */
@@ -856,6 +862,14 @@ int mlgpu_graph_reserve_mixdown(mlgpu_graph* g, size_t max_vectors);
  */
 int mlgpu_graph_add_event_row(mlgpu_graph* g, int row /* 0 pitch, 1 gate */, const char* name); /* before compile; node id */
 int mlgpu_graph_bind_events(mlgpu_graph* g, mlgpu_events* ev);
+/* Device memory of the two-launch form, per voice and DSPVector of the longest block: a 16-byte control record + 2 x 256 bytes of side
+ * signal (only the flagged vectors' frames are ever written or read, but the buffers are addressed [vector][voice]) = 528 bytes:
+ * 2.2 GB for 262 144 voices x 16 DSPVectors (mlgpu_events_graph_reserve_bytes says it for an object). Reserve it at SETUP with
+ * mlgpu_events_reserve_for_graph(ev, longest block in DSPVectors): from then on mlgpu_graph_process_events never allocates and
+ * answers MLGPU_ERR_RANGE to a longer block (before the router consumes its events). Without a reserve the first block - and any
+ * longer one later - waits for the stream and allocates inside the process call (fine for tools and tests, not for an audio thread). */
+int mlgpu_events_reserve_for_graph(mlgpu_events* ev, size_t max_vectors);
+size_t mlgpu_events_graph_reserve_bytes(mlgpu_events* ev, size_t max_vectors);
 int mlgpu_graph_process_events(mlgpu_graph* g, size_t n_vectors, int start_offset, const float* const* d_inputs, int in_layout,
                                const float* const* d_controls, float* const* d_outputs, int out_layout);
 

@@ -51,8 +51,17 @@ struct Error : std::runtime_error
 class Engine
 {
   mlgpu_engine* e_{nullptr};
+  bool owned_{true};
 
  public:
+  // an engine someone else made and will destroy (a host that holds the C handle already: bench.py's reverb workload)
+  struct Borrowed
+  {
+  };
+  Engine(mlgpu_engine* existing, Borrowed) : e_(existing), owned_(false)
+  {
+    if (!existing) throw Error(MLGPU_ERR_INVALID, "Engine: null handle");
+  }
   explicit Engine(int device = 0)
   {
     const int st = mlgpu_engine_create(device, &e_);
@@ -70,7 +79,7 @@ class Engine
   Engine& operator=(const Engine&) = delete;
   ~Engine()
   {
-    if (e_) mlgpu_engine_destroy(e_);
+    if (e_ && owned_) mlgpu_engine_destroy(e_);
   }
   mlgpu_engine* handle() const { return e_; }
   void check(int st) const

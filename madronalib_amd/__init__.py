@@ -234,6 +234,17 @@ class Engine:
         self._check(self.L.mlgpu_timer_stop_ms(self.h, ctypes.byref(ms)))
         return ms.value
 
+    def lap_times_ms(self, work, laps):
+        """Run work() `laps` times with an event after each on the engine's stream; the durations between consecutive events (ms)."""
+        self._check(self.L.mlgpu_timer_laps_begin(self.h, int(laps)))
+        for _ in range(laps):
+            work()
+            self._check(self.L.mlgpu_timer_lap(self.h))
+        out = (ctypes.c_float * laps)()
+        n = ctypes.c_size_t()
+        self._check(self.L.mlgpu_timer_laps_end(self.h, out, laps, ctypes.byref(n)))
+        return np.frombuffer(out, dtype=np.float32, count=n.value).copy()
+
     # ---- stateless ops on device buffers ----
     def op_apply(self, op, a, b, c, out, n_elems):
         g = lambda x: None if x is None else ctypes.c_void_p(x.ptr)  # noqa: E731

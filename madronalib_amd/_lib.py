@@ -131,6 +131,9 @@ def _declare(L):
     sig("mlgpu_fill32", i, [vp, vp, c.c_uint32, sz])
     sig("mlgpu_timer_start", i, [vp])
     sig("mlgpu_timer_stop_ms", i, [vp, fp])
+    sig("mlgpu_timer_laps_begin", i, [vp, sz])
+    sig("mlgpu_timer_lap", i, [vp])
+    sig("mlgpu_timer_laps_end", i, [vp, fp, sz, c.POINTER(c.c_size_t)])
     sig("mlgpu_op_apply", i, [vp, i, vp, vp, vp, vp, sz])
     sig("mlgpu_op_apply_rows1", i, [vp, i, vp, vp, vp, sz])
     sig("mlgpu_row_reduce", i, [vp, i, vp, vp, sz])

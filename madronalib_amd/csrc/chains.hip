@@ -18,6 +18,7 @@
 #include "mldsp_kernels.hpp"
 
 using namespace mldev;
+static_assert(kHostMixStripFloats == kMixStrip && kHostGroup16StripFloats == kGroup16Strip, "graph.hip's LDS budget counts these strips");
 
 namespace
 {

@@ -631,6 +631,14 @@ __global__ void set_rec_ranges_kernel(const uint4* list, size_t n, uint2* ranges
   if (i < n) ranges[list[i].x] = make_uint2(list[i].y, list[i].z);
 }
 
+// ... and the same lanes back to "no records": what the consuming kernel does itself, for a block whose consuming kernel was never
+// launched (a failure between set_rec_ranges_kernel and that launch: abandonRanges)
+__global__ void clear_rec_ranges_kernel(const uint4* list, size_t n, uint2* ranges)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ranges[list[i].x] = make_uint2(0u, 0u);
+}
+
 struct E2SCtlArgs
 {
   uint32_t* state;
@@ -1053,6 +1061,7 @@ struct mlgpu_events
     uint4* h_dirty{nullptr};   // {lane, first record, one past the last, 0} for every lane that has records in this launch
     uint4* d_dirty{nullptr};
     size_t recCapacity{0}, dirtyCapacity{0};
+    size_t nDirtySet{0};       // lanes whose range set_rec_ranges_kernel has set for the block in flight and no kernel has consumed yet
     hipEvent_t done{nullptr};
     bool pending{false};
   } stage[2];
@@ -1086,6 +1095,7 @@ struct mlgpu_events
   float* d_rowP{nullptr};
   float* d_rowG{nullptr};
   size_t ctlRecVectors{0};
+  bool ctlRecReserved{false};  // mlgpu_events_reserve_for_graph was called: process calls never allocate, longer blocks are refused
   size_t lanes() const { return nInstruments * (size_t)group; }
 };
 
@@ -1613,6 +1623,19 @@ extern "C"
   // event times: the block's events routed into per-voice records, the records uploaded (asynchronously, into the staging set
   // that is free), the settings the device needs. The caller launches the kernel that consumes them - e2s_kernel, or a voice
   // graph whose pitch and gate rows are source nodes (graph.hip) - and then calls launched().
+  // The per-lane record ranges are device state: set from the block's lane list, cleared by the kernel that consumes them. A block that
+  // fails after they were set and before that kernel ran would leave them pointing into a staging buffer the NEXT block does not
+  // use: put them back to "no records" (stream-ordered, the list is still in sg.d_dirty).
+  static void abandonRanges(mlgpu_events* ev, mlgpu_events::Staging& sg)
+  {
+    if (!sg.nDirtySet) return;
+    hipLaunchKernelGGL(clear_rec_ranges_kernel, dim3((unsigned)((sg.nDirtySet + 255) / 256)), dim3(256), 0, ev->e->stream, (const uint4*)sg.d_dirty, sg.nDirtySet, ev->d_recRange);
+    (void)hipGetLastError();
+    sg.nDirtySet = 0;
+    // (the list must outlive the clearing pass: the next use of this staging buffer waits for `done`)
+    if (hipEventRecord(sg.done, ev->e->stream) == hipSuccess) sg.pending = true;
+  }
+
   static int prepare(mlgpu_events* ev, size_t nVectors, int startOffset, EventsDev& dev, mlgpu_events::Staging*& sgOut)
   {
     mlgpu_engine* e = ev->e;
@@ -1699,11 +1722,16 @@ extern "C"
     {
       hipLaunchKernelGGL(set_rec_ranges_kernel, dim3((unsigned)((nDirty + 255) / 256)), dim3(256), 0, e->stream, (const uint4*)sg.d_dirty, nDirty, ev->d_recRange);
       cerr = hipGetLastError();
+      if (cerr == hipSuccess) sg.nDirtySet = nDirty;
     }
     if (cerr != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process upload: ") + hipGetErrorString(cerr));
 
     const int cst = ev->watched.empty() ? MLGPU_OK : processControllers(ev, nVectors, ev->stageIdx ^ 1);
-    if (cst != MLGPU_OK) return cst;
+    if (cst != MLGPU_OK)
+    {
+      abandonRanges(ev, sg);
+      return cst;
+    }
 
     memset(&dev.s, 0, sizeof(dev.s));
     dev.s.sr = ev->sr;
@@ -1732,6 +1760,7 @@ extern "C"
   }
   static int launched(mlgpu_events* ev, mlgpu_events::Staging& sg)
   {
+    sg.nDirtySet = 0;  // (the consuming kernel clears the ranges it read)
     if (hipEventRecord(sg.done, ev->e->stream) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "events_process: event");
     sg.pending = true;  // no wait here: the host goes on routing the next block while this one runs
     return MLGPU_OK;
@@ -1782,8 +1811,58 @@ extern "C"
     else
       hipLaunchKernelGGL(e2s_kernel<false>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
     const hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events_process launch: ") + hipGetErrorString(err));
+    if (err != hipSuccess)
+    {
+      abandonRanges(ev, *sg);
+      return efail(ev, MLGPU_ERR_HIP, std::string("events_process launch: ") + hipGetErrorString(err));
+    }
     return launched(ev, *sg);
+  }
+
+  // control records [T][kCtlRecWords][lanes] + the two side signals [64 T][lanes] of e2s_ctl_kernel for blocks of up to nVectors
+  static int reserveCtlRecs(mlgpu_events* ev, size_t nVectors)
+  {
+    mlgpu_engine* e = ev->e;
+    const size_t lanes = ev->lanes();
+    if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
+    hipStreamSynchronize(e->stream);
+    hipFree(ev->d_ctlRecs);
+    hipFree(ev->d_rowP);
+    hipFree(ev->d_rowG);
+    ev->d_ctlRecs = nullptr;
+    ev->d_rowP = ev->d_rowG = nullptr;
+    ev->ctlRecVectors = 0;
+    const size_t rowBytes = sizeof(float) * 64 * nVectors * lanes;
+    if (hipMalloc((void**)&ev->d_ctlRecs, sizeof(uint32_t) * kCtlRecWords * nVectors * lanes) != hipSuccess || hipMalloc((void**)&ev->d_rowP, rowBytes) != hipSuccess ||
+        hipMalloc((void**)&ev->d_rowG, rowBytes) != hipSuccess)
+    {
+      hipFree(ev->d_ctlRecs);
+      hipFree(ev->d_rowP);
+      hipFree(ev->d_rowG);
+      ev->d_ctlRecs = nullptr;
+      ev->d_rowP = ev->d_rowG = nullptr;
+      return efail(ev, MLGPU_ERR_OOM, "events as graph source nodes: control records and side signals");
+    }
+    ev->ctlRecVectors = nVectors;
+    return MLGPU_OK;
+  }
+  int mlgpu_events_reserve_for_graph(mlgpu_events* ev, size_t maxVectors)
+  {
+    if (!ev || maxVectors == 0) return MLGPU_ERR_INVALID;
+    if (ev->e->recording) return efail(ev, MLGPU_ERR_INVALID, "events_reserve_for_graph allocates: not while recording a sequence");
+    if (ev->mpe) return efail(ev, MLGPU_ERR_UNSUPPORTED, "events as graph source nodes: MIDI protocol only (one lane per voice)");
+    if (maxVectors != ev->ctlRecVectors)
+    {
+      const int st = reserveCtlRecs(ev, maxVectors);
+      if (st != MLGPU_OK) return st;
+    }
+    ev->ctlRecReserved = true;
+    return MLGPU_OK;
+  }
+  size_t mlgpu_events_graph_reserve_bytes(mlgpu_events* ev, size_t maxVectors)
+  {
+    if (!ev) return 0;
+    return (sizeof(uint32_t) * kCtlRecWords + 2 * sizeof(float) * 64) * maxVectors * ev->lanes();
   }
 
   // for graph.hip: a graph whose event rows are bound to this object (mlgpu_graph_bind_events)
@@ -1796,30 +1875,15 @@ extern "C"
     if (ev->mpe) return efail(ev, MLGPU_ERR_UNSUPPORTED, "events as graph source nodes: MIDI protocol only (one lane per voice)");
     mlgpu_engine* e = ev->e;
     const size_t lanes = ev->lanes();
-    // the control records and the two side signals of e2s_ctl_kernel, for the longest block seen so far (refused, like every other
-    // allocation, before the router consumes the block's events)
+    // the control records and the two side signals of e2s_ctl_kernel: sized by mlgpu_events_reserve_for_graph at setup. An object that
+    // was never reserved grows them here on the first / a longer block (a setup-time convenience: it waits for the stream and allocates);
+    // once a host has reserved, a longer block is refused before the router consumes its events and nothing is ever allocated here.
     if (nVectors > ev->ctlRecVectors)
     {
-      if (hipSetDevice(e->device) != hipSuccess) return efail(ev, MLGPU_ERR_HIP, "hipSetDevice");
-      hipStreamSynchronize(e->stream);
-      hipFree(ev->d_ctlRecs);
-      hipFree(ev->d_rowP);
-      hipFree(ev->d_rowG);
-      ev->d_ctlRecs = nullptr;
-      ev->d_rowP = ev->d_rowG = nullptr;
-      ev->ctlRecVectors = 0;
-      const size_t rowBytes = sizeof(float) * 64 * nVectors * lanes;
-      if (hipMalloc((void**)&ev->d_ctlRecs, sizeof(uint32_t) * kCtlRecWords * nVectors * lanes) != hipSuccess || hipMalloc((void**)&ev->d_rowP, rowBytes) != hipSuccess ||
-          hipMalloc((void**)&ev->d_rowG, rowBytes) != hipSuccess)
-      {
-        hipFree(ev->d_ctlRecs);
-        hipFree(ev->d_rowP);
-        hipFree(ev->d_rowG);
-        ev->d_ctlRecs = nullptr;
-        ev->d_rowP = ev->d_rowG = nullptr;
-        return efail(ev, MLGPU_ERR_OOM, "events as graph source nodes: control records and side signals");
-      }
-      ev->ctlRecVectors = nVectors;
+      if (ev->ctlRecReserved)
+        return efail(ev, MLGPU_ERR_RANGE, "graph_process_events: more DSPVectors than mlgpu_events_reserve_for_graph reserved the control records for");
+      const int rst = reserveCtlRecs(ev, nVectors);
+      if (rst != MLGPU_OK) return rst;
     }
     mlgpu_events::Staging* sg = nullptr;
     const int st = prepare(ev, nVectors, startOffset, *dev, sg);
@@ -1839,10 +1903,21 @@ extern "C"
     a.s = dev->s;
     hipLaunchKernelGGL(e2s_ctl_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, e->stream, a);
     const hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return efail(ev, MLGPU_ERR_HIP, std::string("events control kernel launch: ") + hipGetErrorString(err));
+    if (err != hipSuccess)
+    {
+      abandonRanges(ev, *sg);
+      return efail(ev, MLGPU_ERR_HIP, std::string("events control kernel launch: ") + hipGetErrorString(err));
+    }
     dev->ctl = ev->d_ctlRecs;
     dev->rowP = (const float4*)ev->d_rowP;
     dev->rowG = (const float4*)ev->d_rowG;
+    return MLGPU_OK;
+  }
+  // the graph's voice kernel (which consumes the ranges) could not be launched after prepare_for_graph had succeeded
+  int mlgpu_events_abandoned_by_graph(mlgpu_events* ev, void* staging)
+  {
+    if (!ev || !staging) return MLGPU_ERR_INVALID;
+    abandonRanges(ev, *(mlgpu_events::Staging*)staging);
     return MLGPU_OK;
   }
   int mlgpu_events_launched_by_graph(mlgpu_events* ev, void* staging)

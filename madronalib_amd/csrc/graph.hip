@@ -329,14 +329,20 @@ bool getCode(const std::string& source, std::vector<char>& code, std::string& lo
 
 CompiledModule* compileAndLoad(int device, const std::string& source, std::string& log)
 {
-  std::lock_guard<std::mutex> lock(g_cacheMutex);
   const std::string key = std::to_string(device) + "\n" + source;
-  auto it = g_cache.find(key);
-  if (it != g_cache.end()) return &it->second;
-
+  {
+    std::lock_guard<std::mutex> lock(g_cacheMutex);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) return &it->second;
+  }
+  // hiprtc (seconds, on a compile job's worker thread) runs OUTSIDE the module cache's lock: a thread that only looks a loaded module
+  // up - an autotune trial inside graph_process, a bank's chain, another graph - never waits for someone else's compile
   std::vector<char> code;
   if (!getCode(source, code, log)) return nullptr;
 
+  std::lock_guard<std::mutex> lock(g_cacheMutex);
+  auto it = g_cache.find(key);  // (another thread may have loaded the same source meanwhile)
+  if (it != g_cache.end()) return &it->second;
   CompiledModule cm;
   const hipError_t e = hipModuleLoadData(&cm.module, code.data());
   if (e != hipSuccess)
@@ -509,6 +515,7 @@ struct mlgpu_graph
     std::string error;
   };
   CompileJob* job{nullptr};
+  bool aotDone{false};           // an engine-less graph whose ahead-of-time compile has been collected (mlgpu_graph_compile_poll keeps answering MLGPU_OK)
   int eventOffset{-1};           // frame offset of the block being processed (mlgpu_graph_process_events), -1: none pending
   int minWaves{0};               // wavefronts per SIMD the kernel's register budget must allow (0: the compiler's choice), generateBudgeted
   // Online tuning (mlgpu_graph_set_autotune): every variant (voices per lane x quads per trip) computes the same bits from
@@ -1380,6 +1387,7 @@ int addProcNode(mlgpu_graph* g, int kind, const int* inputs, int nIn, const char
 int checkNode(mlgpu_graph* g, int node, int type)
 {
   if (!g) return MLGPU_ERR_INVALID;
+  if (g->job) return MLGPU_ERR_BUSY;
   if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "node index out of range");
   if (g->nodes[node].type != type) return gfail(g, MLGPU_ERR_INVALID, "node has the wrong type for this call");
   return MLGPU_OK;
@@ -1388,6 +1396,7 @@ int checkNode(mlgpu_graph* g, int node, int type)
 int checkStateNode(mlgpu_graph* g, int node)
 {
   if (!g) return MLGPU_ERR_INVALID;
+  if (g->job) return MLGPU_ERR_BUSY;
   if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "node index out of range");
   if (g->nodes[node].type != NODE_PROC && g->nodes[node].type != NODE_FEEDBACK) return gfail(g, MLGPU_ERR_INVALID, "node has no state");
   return MLGPU_OK;
@@ -1677,6 +1686,7 @@ extern "C"
   int mlgpu_graph_bind_events(mlgpu_graph* g, mlgpu_events* ev)
   {
     if (!g || !ev) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (!g->hasEventRows) return gfail(g, MLGPU_ERR_INVALID, "graph_bind_events: the graph has no event rows (graph_add_event_row)");
     if (mlgpu_events_engine(ev) != g->e) return gfail(g, MLGPU_ERR_INVALID, "graph_bind_events: the events object belongs to another engine");
     if (!mlgpu_events_is_midi(ev)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_bind_events: MIDI protocol only (one lane per voice)");
@@ -1938,6 +1948,7 @@ extern "C"
   int mlgpu_graph_node(mlgpu_graph* g, const char* name)
   {
     if (!g || !name) return -MLGPU_ERR_INVALID;
+    if (g->job) return -MLGPU_ERR_BUSY;  // (the worker reads the names; and a name may be set below by this thread only)
     for (size_t i = 0; i < g->nodes.size(); ++i)
       if (g->nodes[i].name == name) return (int)i;
     return -MLGPU_ERR_RANGE;
@@ -1945,6 +1956,7 @@ extern "C"
   int mlgpu_graph_num_nodes(mlgpu_graph* g) { return g ? (int)g->nodes.size() : -1; }
   int mlgpu_graph_set_node_name(mlgpu_graph* g, int node, const char* name)
   {
+    if (g && g->job) return MLGPU_ERR_BUSY;  // (code generation prints the names into the source's comments)
     if (!g || !name || node < 0 || node >= (int)g->nodes.size()) return MLGPU_ERR_RANGE;
     g->nodes[(size_t)node].name = name;
     return MLGPU_OK;
@@ -2003,12 +2015,31 @@ extern "C"
     for (size_t o = 0; o < g->outputs.size(); ++o)
       if (g->outputMix[o] && !partialOk)
         return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: an output that is the mixdown of all voices, next to group sums or event rows, needs whole wavefronts (voices a multiple of 64)");
+    // LDS of a workgroup: the ring strips, the impulse table and a strip per output that is summed inside the kernel (a whole-bank
+    // mixdown: 4 wavefronts x kMixStrip floats = 21 KiB; a 16-voice group sum: 4 x kGroup16Strip = 20.3 KiB). A layout that does not fit
+    // next to them falls back (layout 3) or is refused here with the sizes, not by hiprtc / the module loader.
+    size_t ldsOther = g->hasImpulse ? 128 : 0;
+    {
+      const bool dppSum = getenv("MLGPU_GRAPH_GROUP_SUM") && !strcmp(getenv("MLGPU_GRAPH_GROUP_SUM"), "dpp");
+      for (size_t o = 0; o < g->outputs.size(); ++o)
+      {
+        if (g->outputMix[o]) ldsOther += sizeof(float) * 4 * (size_t)kHostMixStripFloats;
+        else if (g->outputGroup[o] == 16 && !dppSum) ldsOther += sizeof(float) * 4 * (size_t)kHostGroup16StripFloats;
+      }
+    }
+    constexpr size_t kLdsBytes = 160 * 1024;
+    const size_t ldsLayout2 = (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float), ldsLayout1 = (size_t)g->totalRings * 8 * 256 * sizeof(float);
+    auto kib = [](size_t b) { return std::to_string((b + 1023) / 1024) + " KiB"; };
     if (g->transposedIfPossible)
-      g->transposedRings = partialOk && g->totalRings != 3 && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) <= 160 * 1024;
-    if (g->transposedRings && (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
-      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 needs 40 KiB of LDS per ring; at most 4 rings per graph (layout 1 for more)");
-    if (!g->transposedRings && g->windowedRings && (size_t)g->totalRings * 8 * 256 * sizeof(float) + (g->hasImpulse ? 128 : 0) > 160 * 1024)
-      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: windowed delay layout needs 8 KiB of LDS per ring; at most 20 rings per graph");
+      g->transposedRings = partialOk && g->totalRings != 3 && ldsLayout2 + ldsOther <= kLdsBytes;
+    if (g->transposedRings && ldsLayout2 + ldsOther > kLdsBytes)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 needs 40 KiB of LDS per ring (" + kib(ldsLayout2) + " for " + std::to_string(g->totalRings) +
+                                                 " rings) next to " + kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB (layout 1 or 3 for this graph)");
+    if (!g->transposedRings && g->windowedRings && ldsLayout1 + ldsOther > kLdsBytes)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: windowed delay layout needs 8 KiB of LDS per ring (" + kib(ldsLayout1) + " for " + std::to_string(g->totalRings) +
+                                                 " rings) next to " + kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB");
+    if (ldsOther > kLdsBytes)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: " + kib(ldsOther) + " of LDS for the outputs summed inside the kernel (21 KiB per mixed-down output, 20.3 KiB per 16-voice group sum); a workgroup has 160 KiB");
     const char* forced = getenv("MLGPU_GRAPH_UNROLL");  // developer knob: quads per trip of the sample loop
     // delay graphs wait on their ring reads: two quads per trip keep more of them in flight (allpass4: 5.4 vs 4.5 x 10^10)
     g->unrollQ = forced ? std::max(1, atoi(forced)) : ((g->totalRings && !g->windowedRings) ? 2 : 1);
@@ -2027,7 +2058,8 @@ extern "C"
     return MLGPU_OK;
   }
 
-  const char* mlgpu_graph_last_error(mlgpu_graph* g) { return g ? g->lastError.c_str() : ""; }
+  // (while a compile is in flight the strings are the worker's to write: "" until mlgpu_graph_compile_poll has collected the job)
+  const char* mlgpu_graph_last_error(mlgpu_graph* g) { return (g && !g->job) ? g->lastError.c_str() : ""; }
 
   int mlgpu_graph_emit(mlgpu_graph* g, const void** code, size_t* codeSize)
   {
@@ -2072,7 +2104,7 @@ extern "C"
   {
     if (!g) return MLGPU_ERR_INVALID;
     if (g->job) return MLGPU_ERR_BUSY;
-    if (g->compiled) return MLGPU_OK;
+    if (g->compiled || g->aotDone) return MLGPU_OK;
     mlgpu_graph::CompileJob* job = new (std::nothrow) mlgpu_graph::CompileJob();
     if (!job) return MLGPU_ERR_OOM;
     g->job = job;
@@ -2097,7 +2129,7 @@ extern "C"
   int mlgpu_graph_compile_poll(mlgpu_graph* g)
   {
     if (!g) return MLGPU_ERR_INVALID;
-    if (!g->job) return g->compiled ? MLGPU_OK : gfail(g, MLGPU_ERR_INVALID, "graph_compile_poll: no compile in flight (mlgpu_graph_compile_async)");
+    if (!g->job) return (g->compiled || g->aotDone) ? MLGPU_OK : gfail(g, MLGPU_ERR_INVALID, "graph_compile_poll: no compile in flight (mlgpu_graph_compile_async)");
     if (!g->job->done.load(std::memory_order_acquire)) return MLGPU_ERR_BUSY;
     mlgpu_graph::CompileJob* job = g->job;
     job->th.join();
@@ -2106,7 +2138,11 @@ extern "C"
     const std::string err = job->error;
     delete job;
     if (st != MLGPU_OK) return gfail(g, st, err);
-    if (!g->e) return MLGPU_OK;  // ahead of time: nothing to allocate, the graph stays a description
+    if (!g->e)
+    {
+      g->aotDone = true;  // ahead of time: nothing to allocate, the graph stays a description (and every later poll says OK)
+      return MLGPU_OK;
+    }
     return compileFinish(g);     // allocations and the initial fills, on the caller's thread and stream: microseconds
   }
 
@@ -2179,7 +2215,7 @@ extern "C"
     return MLGPU_OK;
   }
 
-  const char* mlgpu_graph_source(mlgpu_graph* g) { return g ? g->source.c_str() : ""; }
+  const char* mlgpu_graph_source(mlgpu_graph* g) { return (g && !g->job) ? g->source.c_str() : ""; }
 
   // T::clear() of one node: the state words clear() resets (mlgpu_proc_clear_mask), a delay node's rings, a
   // feedback node's stored vector
@@ -2206,7 +2242,9 @@ extern "C"
 
   int mlgpu_graph_clear(mlgpu_graph* g)
   {
-    if (!g || !g->compiled) return MLGPU_ERR_INVALID;
+    if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
+    if (!g->compiled) return MLGPU_ERR_INVALID;
     for (const Node& n : g->nodes)
     {
       const int st = clearNode(g, n);
@@ -2219,6 +2257,7 @@ extern "C"
   int mlgpu_graph_clear_proc(mlgpu_graph* g, int node)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (node < 0 || node >= (int)g->nodes.size()) return gfail(g, MLGPU_ERR_RANGE, "node index out of range");
     if (g->nodes[node].type != NODE_PROC && g->nodes[node].type != NODE_FEEDBACK) return gfail(g, MLGPU_ERR_INVALID, "graph_clear_proc: not a processor / feedback node");
     if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_clear_proc: compile first");
@@ -2301,6 +2340,7 @@ extern "C"
   int mlgpu_graph_set_live_constants(mlgpu_graph* g, int on)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_set_live_constants: before mlgpu_graph_compile");
     g->liveConsts = on != 0;
     return MLGPU_OK;
@@ -2308,6 +2348,7 @@ extern "C"
   int mlgpu_graph_set_const(mlgpu_graph* g, int node, float value)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;  // (the worker turns the values into literals of the kernel)
     if (node < 0 || node >= (int)g->nodes.size() || g->nodes[node].type != NODE_CONST) return gfail(g, MLGPU_ERR_INVALID, "graph_set_const: not a const node");
     if (g->compiled && !g->liveConsts)
       return gfail(g, MLGPU_ERR_INVALID, "graph_set_const: constants of this graph are literals of its kernel (mlgpu_graph_set_live_constants before compile)");
@@ -2339,6 +2380,7 @@ extern "C"
   int mlgpu_graph_update_constants_from(mlgpu_graph* g, mlgpu_graph* other)
   {
     if (!g || !other) return MLGPU_ERR_INVALID;
+    if (g->job || other->job) return MLGPU_ERR_BUSY;
     if (!g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph_update_constants_from: compile the graph first");
     if (const char* why = structureDifference(g, other)) return gfail(g, MLGPU_ERR_UNSUPPORTED, std::string("graph_update_constants_from: the graphs differ in ") + why);
     for (size_t i = 0; i < g->nodes.size(); ++i)
@@ -2352,13 +2394,15 @@ extern "C"
   }
   size_t mlgpu_graph_device_bytes(mlgpu_graph* g)
   {
-    if (!g || !g->compiled) return 0;
+    if (!g || g->job || !g->compiled) return 0;
     return sizeof(float) * g->V * (size_t)(g->NC + 1) + sizeof(uint32_t) * g->V * (size_t)(g->NS + 1) + sizeof(float) * g->V * (size_t)(g->nParams + 1) +
            sizeof(float) * g->memVoices() * g->memFloatsPerVoice;
   }
   int mlgpu_graph_tuning(mlgpu_graph* g, int* voicesPerLane, int* quadsPerTrip)
   {
-    if (!g || !g->compiled) return -MLGPU_ERR_INVALID;
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (g->job) return -MLGPU_ERR_BUSY;
+    if (!g->compiled) return -MLGPU_ERR_INVALID;
     if (voicesPerLane) *voicesPerLane = g->activeVl;
     if (quadsPerTrip) *quadsPerTrip = g->unrollQ;
     return (g->autotune && !g->tuned) ? 0 : 1;
@@ -2368,7 +2412,9 @@ extern "C"
   // bank runs in one round (voices <= 256 x that x the CU count) or the last workgroups run alone after the others
   int mlgpu_graph_workgroups_per_cu(mlgpu_graph* g)
   {
-    if (!g || !g->compiled || !g->fn) return -MLGPU_ERR_INVALID;
+    if (!g) return -MLGPU_ERR_INVALID;
+    if (g->job) return -MLGPU_ERR_BUSY;
+    if (!g->compiled || !g->fn) return -MLGPU_ERR_INVALID;
     int n = 0;
     if (hipSetDevice(g->e->device) != hipSuccess) return -MLGPU_ERR_HIP;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, g->fn, 256, 0) != hipSuccess) return -MLGPU_ERR_HIP;
@@ -2379,6 +2425,7 @@ extern "C"
   int mlgpu_graph_delay_layout(mlgpu_graph* g)
   {
     if (!g) return -MLGPU_ERR_INVALID;
+    if (g->job) return -MLGPU_ERR_BUSY;  // (layout 3 is being decided)
     if (g->transposedIfPossible && !g->compiled) return 3;
     return g->transposedRings ? 2 : (g->windowedRings ? 1 : 0);
   }
@@ -2396,6 +2443,7 @@ extern "C"
   int mlgpu_graph_set_input_layout(mlgpu_graph* g, int inputIndex, int layout)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (inputIndex < 0 || inputIndex >= g->nInputs) return gfail(g, MLGPU_ERR_RANGE, "graph_set_input_layout: input index out of range");
     if (layout < -1 || layout > MLGPU_LAYOUT_BROADCAST) return gfail(g, MLGPU_ERR_INVALID, "graph_set_input_layout: bad layout");
     g->inLayoutOverride[inputIndex] = layout;
@@ -2431,6 +2479,7 @@ extern "C"
                                  float* const* d_outputs, int outLayout)
   {
     if (!g) return MLGPU_ERR_INVALID;
+    if (g->job) return MLGPU_ERR_BUSY;
     if (!g->hasEventRows) return gfail(g, MLGPU_ERR_INVALID, "graph_process_events: the graph has no event rows");
     if (startOffset < 0) return gfail(g, MLGPU_ERR_INVALID, "graph_process_events: negative frame offset");
     g->eventOffset = startOffset;
@@ -2563,7 +2612,11 @@ extern "C"
     }
     if (trial) hipEventRecord(g->tuneEv0, g->e->stream);
     const hipError_t err = launchJit(fn, a, (g->V + (size_t)vl - 1) / (size_t)vl, g->e->stream);
-    if (err != hipSuccess) return gfail(g, MLGPU_ERR_HIP, std::string("graph_process launch: ") + hipGetErrorString(err));
+    if (err != hipSuccess)
+    {
+      if (eventStaging) mlgpu_events_abandoned_by_graph(g->events, eventStaging);  // (the lanes' record ranges back to "none": no kernel will consume them)
+      return gfail(g, MLGPU_ERR_HIP, std::string("graph_process launch: ") + hipGetErrorString(err));
+    }
     if (eventStaging)
     {
       const int est = mlgpu_events_launched_by_graph(g->events, eventStaging);

@@ -25,7 +25,10 @@ constexpr int kChainBlock = 256;
 #ifndef MLGPU_CHAIN_TURNS
 #define MLGPU_CHAIN_TURNS 1
 #endif
-constexpr int kTurnClockShift = 13;  // 82 us per turn (graph kernels: the best of 2^7 .. 2^18 ticks, profiles/r04_take_turns.txt)
+#ifndef MLGPU_CHAIN_TURN_SHIFT
+#define MLGPU_CHAIN_TURN_SHIFT 13
+#endif
+constexpr int kTurnClockShift = MLGPU_CHAIN_TURN_SHIFT;  // 82 us per turn (graph kernels: the best of 2^7 .. 2^18 ticks, profiles/r04_take_turns.txt)
 
 // ---- the voices of a wavefront summed inside the voice kernel (chain_mix_kernel) ----
 // mlgpu_mixdown's first stage - the balanced tree over 64 consecutive voices, a[i] += a[i + d] for d = 1, 2 ... 32 - without the

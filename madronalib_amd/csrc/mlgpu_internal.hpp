@@ -22,6 +22,8 @@ struct mlgpu_engine
   std::string lastError;
   float* d_impulseTable{nullptr};  // 17 floats (ImpulseGen windowed sinc), built on the host
   hipEvent_t ev0{nullptr}, ev1{nullptr};
+  std::vector<hipEvent_t> lapEvents;  // mlgpu_timer_laps_*: created once, reused
+  size_t lapCount{0}, lapMax{0};
   bool jitEnabled{true};  // fuse unknown chains / graphs with hiprtc (mlgpu_engine_set_jit)
   bool strictSvf{false};  // banks and graphs made from now on get kernels compiled with MLGPU_SVF_STRICT 1 (mlgpu_engine_set_strict_svf)
   float* d_mixScratch{nullptr};  // mixdown partial sums, grown on demand
@@ -122,6 +124,10 @@ hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t 
                               size_t nElems, hipStream_t stream, uint32_t flags);
 
 // graph.hip — run-time fused kernels (hiprtc)
+// LDS strips of the generated kernels, in floats per WAVEFRONT, for the host's LDS budget (graph.hip does not include the device
+// headers; chains.hip asserts they equal mldev::kMixStrip / kGroup16Strip)
+constexpr int kHostMixStripFloats = 64 * 20 + 3 * 16 + 16;
+constexpr int kHostGroup16StripFloats = 4 * (4 * 80 + 4);
 bool mlgpu_jit_chain(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);  // honours e->strictSvf
 hipError_t mlgpu_jit_chain_launch(void* fn, const ChainArgs& a, hipStream_t stream);
 bool mlgpu_jit_chain_mix(mlgpu_engine* e, const int32_t* kinds, int n, void** fnSignal, void** fnConst, std::string& log);
@@ -132,6 +138,7 @@ void mlgpu_build_impulse_table(float* out17);
 // events.hip, for graph.hip: the host half of an EventsToSignals block (routing, record upload) for a graph kernel that computes
 // the pitch and gate rows itself (mlgpu_graph_bind_events)
 struct mlgpu_events;
+extern "C" int mlgpu_events_abandoned_by_graph(mlgpu_events* ev, void* staging);
 extern "C" int mlgpu_events_prepare_for_graph(mlgpu_events* ev, size_t nVectors, int startOffset, EventsDev* dev, void** staging);
 extern "C" int mlgpu_events_launched_by_graph(mlgpu_events* ev, void* staging);
 extern "C" int mlgpu_events_is_midi(mlgpu_events* ev);

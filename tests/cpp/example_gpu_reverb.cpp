@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 
 #define main mlgpu_example_reverb_main
 #include "examples/audio-and-midi/reverb.cpp"
@@ -49,6 +50,38 @@ extern "C" int example_reverb_gpu_run(size_t V, size_t T, int launches, const fl
     return -1;
   }
 }
+
+// The captured program on an engine the caller owns, kept open: bench.py --workload reverb launches its graph itself
+// (mlgpu_graph_process on example_reverb_gpu_graph) and times it with the engine's events like every other workload.
+struct ReverbProgram
+{
+  gpu::Engine eng;
+  AaltoverbState r;
+  AudioContext ctx;
+  std::unique_ptr<gpu::VoiceProgram> prog;
+  ReverbProgram(mlgpu_engine* e) : eng(e, gpu::Engine::Borrowed{}), ctx(2, 2, kSampleRate) {}
+};
+extern "C" void* example_reverb_gpu_open(void* engine, size_t V, int options /* as example_reverb_gpu_bench; bits 4-5: mlgpu_graph_set_delay_layout */, char* err, size_t errLen)
+{
+  try
+  {
+    std::unique_ptr<ReverbProgram> p(new ReverbProgram((mlgpu_engine*)engine));
+    initializeReverb(p->r);
+    gpu::VoiceProgramOptions opt;
+    opt.delayWindows = (options & 1) != 0;
+    opt.autotune = (options & 2) != 0;
+    opt.liveConstants = (options & 4) != 0;
+    p->prog.reset(new gpu::VoiceProgram(p->eng, V, &p->ctx, processVector, &p->r, opt));
+    return p.release();
+  }
+  catch (const std::exception& e)
+  {
+    if (err && errLen) snprintf(err, errLen, "%s", e.what());
+    return nullptr;
+  }
+}
+extern "C" void* example_reverb_gpu_graph(void* program) { return program ? ((ReverbProgram*)program)->prog->graph() : nullptr; }
+extern "C" void example_reverb_gpu_close(void* program) { delete (ReverbProgram*)program; }
 
 // throughput of the same captured program: V reverbs x T vectors per launch, `launches` launches timed with the engine's events
 extern "C" int example_reverb_gpu_bench(size_t V, size_t T, int launches, int options /* bit 0: windowed rings, bit 1: online tuning, bit 2: live constants */, float* msPerLaunch,

@@ -40,6 +40,18 @@ def test_ahead_of_time_compile_is_busy_while_in_flight_and_fills_the_cache():
     assert L.mlgpu_graph_compile_async(g.h) == ml.BUSY
     assert L.mlgpu_graph_emit(g.h, None, None) == ml.BUSY
     assert L.mlgpu_graph_add_output(g.h, 0) == ml.BUSY
+    # ... every mutator, also the ones that are legal after a compile (round 6: the worker reads names and constants while it
+    # generates code), and the strings it writes are not handed out meanwhile
+    import ctypes
+    assert L.mlgpu_graph_set_node_name(g.h, 0, b"renamed") == ml.BUSY
+    const_node = L.mlgpu_graph_node(g.h, b"salt")
+    assert const_node == -ml.BUSY
+    assert L.mlgpu_graph_set_const(g.h, 0, ctypes.c_float(2.0)) == ml.BUSY
+    assert L.mlgpu_graph_set_live_constants(g.h, 1) == ml.BUSY
+    assert L.mlgpu_graph_set_input_layout(g.h, 0, 0) == ml.BUSY
+    assert L.mlgpu_graph_clear(g.h) == ml.BUSY
+    assert L.mlgpu_graph_delay_layout(g.h) == -ml.BUSY
+    assert L.mlgpu_graph_source(g.h) == b"" and L.mlgpu_graph_last_error(g.h) == b""
     busy_polls = 0
     while not g.compile_poll():
         busy_polls += 1
@@ -52,6 +64,9 @@ def test_ahead_of_time_compile_is_busy_while_in_flight_and_fills_the_cache():
     # the code exists now: emit answers from memory, and a second graph of the same description does not run hiprtc again
     src, code = g.emit()
     assert len(code) > 1000 and "mlgpu_graph_kernel" in src
+    # an ahead-of-time graph stays "done": every later poll (and a second compile_async) answers OK (round 5 said INVALID from the second poll on)
+    assert L.mlgpu_graph_compile_poll(g.h) == 0 and L.mlgpu_graph_compile_poll(g.h) == 0
+    assert L.mlgpu_graph_compile_async(g.h) == 0 and L.mlgpu_graph_compile_poll(g.h) == 0
     g2 = ml.Graph(ml.OfflineEngine(), 4096, desc, outs)
     t1 = time.perf_counter()
     g2.compile_async()

@@ -765,6 +765,23 @@ int main(int argc, char** argv)
     }
   }
   CK(hipMemcpy(dst, st1.data(), 12 * V, hipMemcpyHostToDevice));  // the timed launches start from free-running phases
+  // round 6: `exp_chain <rounds> steady` - every variant ALONE for 600 back-to-back launches after 100 untimed ones: the board is at its
+  // power cap after a few milliseconds of this load (profiles/r06_cfg3_spread.md), and a variant timed for 10 launches between
+  // other variants runs on the clock the previous one left
+  if (argc > 2 && strcmp(argv[2], "steady") == 0)
+  {
+    for (auto& v : vars)
+    {
+      if (argc > 3 && v.name.find(argv[3]) == std::string::npos) continue;
+      int k = 0;
+      Args a0{dco, dst, dfr, out0, V, T}, a1{dco, dst, dfr, out1, V, T};
+      for (int i = 0; i < 100; ++i) v.launch((k++ & 1) ? a1 : a0);
+      CK(hipDeviceSynchronize());
+      const float ms = timeit([&] { v.launch((k++ & 1) ? a1 : a0); }, 600);
+      printf("steady %-44s %.4f ms (%.0f GB/s)  mismatches %zu\n", v.name.c_str(), ms, 4.0 * n / ms / 1e6, v.bad);
+    }
+    return 0;
+  }
   // interleaved timing: rounds x (each variant: 10 launches alternating two output buffers)
   for (int r = 0; r < rounds; ++r)
     for (auto& v : vars)
