@@ -60,6 +60,9 @@ WORKLOADS = {
     "strings": (262144, 16, 8),  # a plucked-string model per voice: noise burst -> FractionalDelay (per-voice length) -> OnePole -> feedback
     "mixgroups": (262144, 8, 16),  # the per-instrument voice sum alone, 16 voices per instrument
     "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
+    # the reference's own examples/audio-and-midi/reverb.cpp (the Aaltoverb algorithm: 10 x Allpass<PitchbendableDelay> + 2 PitchbendableDelay = 24
+    # rings, two kept DSPVectors), compiled UNCHANGED against the shim (tests/cpp/libexamples_gpu.so), one stereo reverb per voice
+    "reverb": (65536, 16, 8),
     # BASELINE.json north_star "Target": >= 10^6 SawGen -> SVF -> gain voices at 48 kHz real time on one GPU (paced, not free-running)
     "rt": (1048576, 1, 75),      # 2^20 voices, one 64-frame block per call paced at the 1333 us block period; a step = 75 blocks = 0.1 s of audio
 }
@@ -273,7 +276,7 @@ def setup_workload(eng, name, V, T, lo, total):
                     held.setdefault(i, []).append(key)
                     evs.append(ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
             return ml.Events.pack_events(insts, evs)
-        blocks = [make_block() for _ in range(int(getattr(eng, "_bench_launches", 0)) + 40)]
+        blocks = [make_block() for _ in range(int(getattr(eng, "_bench_launches", 0)) + 40 + 260)]   # (+ the lap leg's launches)
 
         def launch():
             ev.add_events_packed(blocks[k[0]] if k[0] < len(blocks) else make_block())
@@ -317,7 +320,7 @@ def setup_workload(eng, name, V, T, lo, total):
                                                     "voice graph -> per-instrument voice sum"
                                                     + ("; pitch and gate computed inside the voice kernel, never written" if fusedRows else "")
                                                     + ("; the voice sum made inside the voice kernel" if sumInKernel else "")
-                                                    + ("; EventsToSignals on a HIP stream of its own, overlapped with the voice kernel of the block before" if two else "")), (ev, g, evEng, rowSets, rowsReady, rowsFree)
+                                                    + ("; EventsToSignals on a HIP stream of its own, overlapped with the voice kernel of the block before" if two else "")), (ev, g, evEng if two else None, rowSets, rowsReady, rowsFree)
     if name == "mixgroups":
         # the per-instrument voice sum alone (Synth::processVector, MLSynth.h:43-57): 16 384 instruments x 16 voices
         P = 16
@@ -408,6 +411,52 @@ def setup_workload(eng, name, V, T, lo, total):
         if not os.environ.get("MLGPU_UNIFORM_DELAY"):
             META["coalesced_read_bytes"] = (4.0 + 4 * 4.0) * n   # x and four kept DSPVectors
         return launch, alg, "mlgpu_graph_kernel", "4 x Allpass<PitchbendableDelay> in series, per-voice delay times 400..3400 samples, 16384 voices", (g, nb)
+    if name == "reverb":
+        import ctypes
+        so = os.path.join(ROOT, "tests", "cpp", "libexamples_gpu.so")
+        if not os.path.exists(so):
+            raise RuntimeError("tests/cpp/libexamples_gpu.so is not built (it is made from the reference's example source where /root/reference exists: __graft_entry__.build())")
+        X = ctypes.CDLL(so)
+        X.example_reverb_gpu_open.restype = ctypes.c_void_p
+        X.example_reverb_gpu_open.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+        X.example_reverb_gpu_graph.restype = ctypes.c_void_p
+        X.example_reverb_gpu_graph.argtypes = [ctypes.c_void_p]
+        X.example_reverb_gpu_close.argtypes = [ctypes.c_void_p]
+        err = ctypes.create_string_buffer(2048)
+        options = int(os.environ.get("MLGPU_REVERB_OPTIONS", "0"))   # bit 0: VoiceProgramOptions::delayWindows (ring layout 3)
+        prog = X.example_reverb_gpu_open(eng.h, V, options, err, 2048)
+        if not prog:
+            raise RuntimeError("reverb example through the shim: " + err.value.decode())
+        gh = ctypes.c_void_p(X.example_reverb_gpu_graph(prog))
+
+        class _Prog:
+            def close(self_inner):
+                X.example_reverb_gpu_close(ctypes.c_void_p(prog))
+        nb = eng.bank([Proc.NOISE_GEN, Proc.GAIN], V)
+        nb.set_coeff(1, 0, 0.05)
+        d_in = []
+        for seed0 in (0, 1 << 20):
+            nb.set_state(0, 0, np.arange(lo + seed0, lo + seed0 + V, dtype=np.uint32))
+            d = eng.alloc(4 * n)
+            nb.process(T, d, Layout.QUAD)
+            d_in.append(d)
+        outs_d = [[eng.alloc(4 * n), eng.alloc(4 * n)] for _ in range(2)]
+        pp = ctypes.c_void_p * 2
+        ins_c = pp(d_in[0].ptr, d_in[1].ptr)
+        outs_c = [pp(o[0].ptr, o[1].ptr) for o in outs_d]
+        QUAD = int(Layout.QUAD)
+        k = [0]
+
+        def launch():
+            st = eng.L.mlgpu_graph_process(gh, T, ins_c, QUAD, outs_c[k[0] & 1], QUAD)
+            if st:
+                raise ml.MlgpuError(st, "(mlgpu_graph_process of the captured reverb)")
+            k[0] += 1
+        # per reverb-sample: 2 inputs + 2 outputs (16 B), 24 delay rings written and read (8 B each: every PitchbendableDelay feeds both of
+        # its IntegerDelays and reads both, MLDSPFilters.h:1050-1109), the two kept DSPVectors read and written (16 B)
+        alg = (16.0 + 24 * 8.0 + 16.0) * n
+        return launch, alg, "mlgpu_graph_kernel", (f"the reference's examples/audio-and-midi/reverb.cpp unchanged through the shim: {V} independent stereo reverbs "
+                                                    "(10 allpasses + 2 delays = 24 rings per voice, one delay time for all voices), noise in"), (_Prog(), nb, d_in, outs_d)
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -679,12 +728,23 @@ def _release(*objs):
     gc.collect()
 
 
-def timed_case(eng, name, steps=5, warm=2):
-    """One more workload in this process: `steps` timed steps of its own launches-per-step after `warm` untimed ones."""
+def timed_case(eng, name, steps=5, warm=2, env=None):
+    """One more workload in this process: `steps` timed steps of its own launches-per-step after `warm` untimed ones.
+    env: the workload's variant switches (what `MLGPU_DELAY_WINDOWS=2 bench.py --workload strings` sets), for the set-up only."""
     V, T, L = WORKLOADS[name]
     META["coalesced_read_bytes"] = None
     META["alg_is_upper_bound"] = False
-    launch, alg, kname, desc, keep = setup_workload(eng, name, V, T, 0, V)
+    eng._bench_launches = (warm + steps) * L + 1
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        launch, alg, kname, desc, keep = setup_workload(eng, name, V, T, 0, V)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     for _ in range(warm * L):
         launch()
     eng.sync()
@@ -693,7 +753,8 @@ def timed_case(eng, name, steps=5, warm=2):
         launch()
     ms = eng.timer_stop_ms() / (steps * L)
     res = {"kernel": kname, "kernel_ms": ms, "algorithmic_bytes_per_launch": alg, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "voice_samples_per_s": float(V) * T * 64 / (ms * 1e-3), "timed_launches": steps * L, "voices": V, "vectors_per_launch": T}
+           "voice_samples_per_s": float(V) * T * 64 / (ms * 1e-3), "timed_launches": steps * L, "voices": V, "vectors_per_launch": T,
+           "workload": desc, **({"variant": env} if env else {}), **({"algorithmic_bytes_are_an_upper_bound": True} if META.get("alg_is_upper_bound") else {})}
     del launch
     _release(keep)
     return res
@@ -845,6 +906,15 @@ def extra_legs(eng):
         r = guarded(name, lambda name=name: timed_case(eng, name))
         if "error" not in r:
             flat.update({f"{name}_frac": r["frac"], f"{name}_kernel_ms": r["kernel_ms"], f"{name}_voice_samples_per_s": r["voice_samples_per_s"]})
+    # the widened rows, >= 5 timed steps each, in the forms a host should use: the instrument bank as one voice kernel (ms per
+    # 16-vector block), plucked strings in ring layout 2, EventsToSignals (all 8 rows), the Downsampler, the reference's reverb example
+    if not os.environ.get("MLGPU_BENCH_NO_WIDENED"):
+        for name, env in (("synth", None), ("strings", {"MLGPU_DELAY_WINDOWS": "2"}), ("events", None), ("resample", None), ("reverb", None)):
+            r = guarded(name, lambda name=name, env=env: timed_case(eng, name, env=env))
+            if "error" not in r:
+                flat.update({f"{name}_frac": r["frac"], f"{name}_kernel_ms": r["kernel_ms"], f"{name}_voice_samples_per_s": r["voice_samples_per_s"]})
+                if name == "synth":
+                    flat["synth_block_ms"] = r["kernel_ms"]     # (the block: control kernel + voice kernel with the per-instrument sum inside)
     r = guarded("rt", lambda: rt_case(eng))
     if "error" not in r:
         flat.update({"rt_voices": r["voices"], "rt_block_p50_us": r["call_us_p50"], "rt_block_p99_us": r["call_us_p99"], "rt_block_max_us": r["call_us_max"],
@@ -931,7 +1001,36 @@ def parity_crcs(eng, Vs=512):
             g.close()
             d_gate.free()
             d_out.free()
+    # the widened rows' workloads (tests/widened_parity.py; the same cases are GPU tests): 512 voices each
+    try:
+        import widened_parity as wp
+        for name, case in wp.all_cases(eng, orc).items():
+            try:
+                got, want, checker = case()
+                rec(name, got, want, checker)
+            except Exception as ex:
+                out[name] = {"match": False, "error": repr(ex)}
+    except Exception as ex:
+        out["widened"] = {"match": False, "error": repr(ex)}
     return out
+
+
+# The order of `roofline`'s keys: a reader that keeps only the first scalars (the round-5 driver record kept 19) sees the ones that
+# carry a claim - every BASELINE config, the north_star target, the parity CRCs, the widened rows - before the diagnostics.
+ROOFLINE_KEY_ORDER = ("bound", "achieved", "peak", "unit", "frac", "traffic",
+                      "cfg4_frac", "cfg5_frac", "cfg5full_frac", "rt_misses", "rt_block_p99_us", "rt_kernel_frac", "crc_all_match",
+                      "synth_block_ms", "strings_frac", "events_frac", "resample_frac", "reverb_frac", "kernel_ms_p50",
+                      "kernel_ms_p10", "kernel_ms_p90", "kernel_ms", "kernel", "cfg2_frac", "cfg2_on_die_frac",
+                      "cfg2_crc_match", "cfg3_crc_match", "cfg4_crc_match", "cfg5_crc_match", "cfg5full_crc_match",
+                      "synth_crc_match", "strings_crc_match", "events_crc_match", "resample_crc_match", "reverb_crc_match",
+                      "rt_voices", "rt_block_p50_us", "rt_block_max_us", "rt_block_period_us", "rt_kernel_us")
+
+
+def order_roofline(roof):
+    head = {k: roof[k] for k in ROOFLINE_KEY_ORDER if k in roof}
+    rest_scalars = {k: v for k, v in roof.items() if k not in head and not isinstance(v, dict) and not k.startswith("valu_")}
+    diag = {k: v for k, v in roof.items() if k not in head and k not in rest_scalars}
+    return {**head, **rest_scalars, **diag}
 
 
 VALU_PEAK_LANE_INST = 256 * 4 * 32 * 2.4e9   # 7.86e13: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles)
@@ -1076,16 +1175,29 @@ def run_rank(args, rank, local_rank, world, rdv):
                          "source": "GRBM_GUI_ACTIVE / 8 XCDs (profiles/pmc_workloads.json) / " + span_what}
     # what the same access pattern reaches with (almost) no arithmetic, on this box, now: the honest ceiling of an HBM-bound launch
     streamed = args.workload in ("cfg4", "cfg5", "cfg5full", "cfg2")
+    if world == 1 and not args.sustained:
+        # The DISTRIBUTION of the kernel's launch durations, a leg of its own after the timed region (an event after every launch; the
+        # headline's mean keeps its two events): the board runs these launches at its power cap and the launch time follows the shader
+        # clock it is granted (profiles/r06_cfg3_spread.md) - p10 is not a speed the chip holds.
+        try:
+            laps = np.sort(eng.lap_times_ms(launch, max(50, min(250, 4 * L))))
+            roof.update({"kernel_ms_p10": float(laps[len(laps) // 10]), "kernel_ms_p50": float(laps[len(laps) // 2]),
+                         "kernel_ms_p90": float(laps[len(laps) * 9 // 10]), "kernel_ms_min": float(laps[0]), "kernel_ms_max": float(laps[-1]),
+                         "kernel_ms_laps": int(len(laps))})
+        except Exception as ex:
+            roof["kernel_ms_laps_error"] = repr(ex)
     if world == 1 and args.workload in ("cfg3", "cfg4", "cfg5", "cfg5full"):
         try:
             gbs, cms = pattern_ceiling(eng, V, T, streamed)
-            roof["store_ceiling" if not streamed else "stream_ceiling"] = {
+            # (rounds 3-5 called this store_ceiling / stream_ceiling. It is a REFERENCE KERNEL - the same access pattern next to one multiply,
+            # not power-limited, 2.38 GHz - and no ceiling for a single launch: a launch of the full chain on a boosted clock beats its mean)
+            roof["same_pattern_gain_kernel"] = {
                 "GB/s": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "ms": cms,
                 "what": ("one Gain processor in the same voice-bank kernel over the same voices x DSPVectors: 16-byte nontemporal stores into the QUAD layout"
-                         + (", loads of the streamed input likewise" if streamed else "") + ", measured in this run")}
-            roof["frac_of_ceiling"] = achieved / gbs
+                         + (", loads of the streamed input likewise" if streamed else "") + ", mean of 12 launches measured in this run")}
+            roof["frac_of_ceiling"] = achieved / gbs     # (key kept: achieved / the same-pattern kernel's rate)
         except Exception as ex:
-            roof["store_ceiling"] = {"error": str(ex)}
+            roof["same_pattern_gain_kernel"] = {"error": str(ex)}
     if pmc.get("valu_wave_insts_per_launch"):
         # the second bound (SURVEY 8d "report both bounds"): VALU issue. SQ_INSTS_VALU counts wave-instructions; x64 lanes.
         ipu = pmc["valu_wave_insts_per_launch"] * 64.0 / units_per_launch
@@ -1226,14 +1338,103 @@ def run_rank(args, rank, local_rank, world, rdv):
             out["parity_512"] = parity_crcs(eng)
             for k, v in out["parity_512"].items():
                 roof[f"{k}_crc_match"] = v["match"]
+            roof["crc_all_match"] = bool(all(v["match"] for v in out["parity_512"].values()))
+            roof["crc_cases"] = len(out["parity_512"])
         except Exception as ex:
             out["parity_512"] = {"error": repr(ex)}
+    out["roofline"] = order_roofline(roof)
     return out
+
+
+def run_rt_group(args, eng, info, V, T, L, rank, world, rdv):
+    """--workload rt --gpus N (N > 1): the real-time block ACROSS the GPUs of a node. Every rank owns V voices of the V x N bank; per
+    64 T-frame block, on the common 48 kHz deadline, it runs its voices with their sum made inside the voice kernel up to the level of
+    the mixdown tree its shard is whole at (mlgpu_bank_process_mixdown_shard), copies the rows (256 bytes per row and DSPVector) to the
+    host and hands them to rank 0 (madronalib_amd.sharding.RowExchange: shared memory of the node, no collective library); rank 0
+    finishes the tree (mlgpu_mixdown_finish) - the channel one engine would give for all V x N voices, bit for bit
+    (tests/cpp/multi_engine_test.cpp, tests/test_gpu_processbuffer.py::test_sharded_mixdown_gives_one_bank_bits). Reported: rank 0's
+    time from a block's deadline to the finished channel (p50 / p99 / max: it includes waiting for the slowest rank) and the blocks
+    that took longer than the period. The reference's counterpart: Synth::processVector's `outputs += voice` loop, MLSynth.h:43-57."""
+    import gc
+    import madronalib_amd as ml
+    from madronalib_amd.constants import Proc
+    from madronalib_amd.sharding import RowExchange
+    total = V * world
+    lo, hi = partition(total, world, rank)
+    rows = ml.mixdown_shard_rows(V)
+    if rows == 0:
+        raise SystemExit("bench.py --workload rt --gpus N: the voices per GPU must be a multiple of 64")
+    bank = eng.bank([Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN], V)
+    bank.clear()
+    freq, co = cfg3_params(lo, hi, total)
+    for i in range(3):
+        bank.set_coeff(1, i, co[i])
+    bank.set_coeff(2, 0, 0.25)
+    bank.set_input_const(freq)
+    eng.mixdown_reserve(V, T)
+    d_rows = eng.alloc(4 * rows * 64 * T)
+    for _ in range(10):
+        bank.process_mixdown_shard(T, d_rows)
+    eng.sync()
+    ex = RowExchange(rdv, rank, world, rows, T)
+    blocks, lead_in = L * args.steps, max(1, L * args.warmup)
+    period = 64 * T / 48000.0
+    clock = time.perf_counter            # (CLOCK_MONOTONIC: the same clock in every process of the node)
+    start = max(rdv.gather(clock() + 0.25 if rank == 0 else 0.0))
+    us, late, peak = [], 0, 0.0
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        for b in range(lead_in + blocks):
+            deadline = start + b * period
+            while clock() < deadline:
+                pass
+            bank.process_mixdown_shard(T, d_rows)
+            ex.put(b, d_rows.download(np.float32, rows * 64 * T).reshape(rows, 64 * T))
+            if rank == 0:
+                channel = ml.mixdown_finish(ex.collect(b, T))
+                d = (clock() - deadline) * 1e6
+                if b >= lead_in:
+                    us.append(d)
+                    late += d > period * 1e6
+                peak = max(peak, float(np.abs(channel).max()))
+    finally:
+        if gc_was:
+            gc.enable()
+    rdv.barrier()
+    ex.close()
+    ranks = rdv.gather({"rank": rank, "device": info.get("device", None), "pci_bus_id": info["pci_bus_id"], "voices": [lo, hi]})
+    if rank != 0:
+        return None
+    us.sort()
+    buses = {r["pci_bus_id"] for r in ranks}
+    res = {"voices_total": total, "voices_per_gpu": V, "gpus": world, "distinct_gpus": len(buses), "frames_per_block": 64 * T, "blocks": blocks,
+           "block_period_us": period * 1e6, "rows_per_gpu": rows, "bytes_exchanged_per_block": world * rows * 256 * T,
+           "block_us_p50": us[len(us) // 2], "block_us_p99": us[int(len(us) * 0.99)], "block_us_max": us[-1], "late_blocks": int(late), "output_peak": peak,
+           "what": "per block and rank: voices + their sum inside the voice kernel up to the shard's hand-over level (mlgpu_bank_process_mixdown_shard), D2H of "
+                   "the rows; rank 0: all ranks' rows through shared memory, the tree finished on the host (mlgpu_mixdown_finish); time from the block's "
+                   "deadline to the finished channel on rank 0"}
+    if len(buses) != world:
+        res["unmeasured_on_hardware"] = f"{world} ranks on {len(buses)} GPU(s): the launch path and the bits, not a multi-GPU measurement"
+    paced_s = blocks * period
+    return {"metric": "voice-samples/sec (rt: SawGen->SVF chain paced at 48 kHz, all voices of the node to one channel)", "value": float(total) * 64 * T * blocks / paced_s,
+            "unit": "voice-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": paced_s / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"north_star target across {world} GPUs: {V} SawGen->Bandpass->gain voices per GPU paced at 48 kHz in {64 * T}-frame blocks, the "
+                                   f"{total} voices summed to ONE channel (per-GPU tree rows + the host's finish: no collective)",
+                       "voices_per_gpu": V, "total_voices": total, "vectors_per_launch": T, "launches_per_step": L, "launcher": rdv.kind,
+                       "note": "a paced run delivers exactly real time unless a block is late: read rt_group.late_blocks and block_us_p99, not `value`"},
+            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                         "rt_group_block_p50_us": res["block_us_p50"], "rt_group_block_p99_us": res["block_us_p99"], "rt_group_late_blocks": res["late_blocks"],
+                         "rt_voices": total, "note": "the per-GPU voice kernel's fraction is the N = 1 run's (rt_kernel_frac in the default line)"},
+            "rt_group": res, "ranks": ranks}
 
 
 def run_rt(args, eng, info, V, T, L, rank, world, rdv):
     """--workload rt: the paced real-time leg as the whole run. A step = L blocks of 64 T frames, each started on its 48 kHz deadline;
     `value` is what was delivered per wall second (= V x 48 000 while no block is late), the roofline object is the voice kernel's."""
+    if world > 1:
+        return run_rt_group(args, eng, info, V, T, L, rank, world, rdv)
     rdv.barrier()
     t0 = time.perf_counter()
     r = rt_case(eng, V, 64 * T, blocks=L * args.steps, lead_in=max(1, L * args.warmup))

@@ -843,7 +843,9 @@ int mlgpu_graph_set_output_group_sum(mlgpu_graph* g, int output_index, int group
  * tree over each wavefront's 64 voices) inside the voice kernel, so that the voices' signal of that output is never written (the graph
  * counterpart of mlgpu_bank_process_mixdown). mlgpu_graph_process then takes 64 * n_vectors floats for it whatever the output layout;
  * mlgpu_graph_reserve_mixdown(g, max vectors) at setup sizes the engine's mixdown scratch for it (process calls never allocate).
- * Any voice count - unless the graph also sums groups or reads event rows in its kernel: then a multiple of 64. */
+ * Any voice count - unless the graph also sums groups or reads event rows in its kernel: then a multiple of 64.
+ * on = 2: the SHARD form (a graph that is one engine's part of a larger bank): the output takes mlgpu_mixdown_shard_rows(voices) rows of
+ * 64 * n_vectors floats for mlgpu_mixdown_finish, as mlgpu_bank_process_mixdown_shard; voices a multiple of 64. */
 int mlgpu_graph_set_output_mixdown(mlgpu_graph* g, int output_index, int on);
 int mlgpu_graph_reserve_mixdown(mlgpu_graph* g, size_t max_vectors);
 
@@ -986,6 +988,21 @@ int mlgpu_mixdown(mlgpu_engine* e, const float* d_signal, int layout, size_t n_v
  * kernel), any voice count; MLGPU_ERR_UNSUPPORTED for other banks until mlgpu_bank_prepare_mixdown has been called for them. Needs the same
  * mlgpu_mixdown_reserve as mlgpu_mixdown. State and coefficients as after mlgpu_bank_process. */
 int mlgpu_bank_process_mixdown(mlgpu_bank* bank, size_t n_vectors, const float* d_in, int in_layout, const float* d_gains, float* d_out);
+/* The same block across SEVERAL ENGINES - the GPUs of a node, each with a contiguous range of the voices (the reference's
+ * `outputs += voice` loop runs over all voices of a Synth, source/app/MLSynth.h:43-57). The order above is a tree: 64 voices pairwise,
+ * then 64 consecutive sums at a time left to right. A shard whose voice count is a multiple of 64^L (L >= 1, the largest such:
+ * mlgpu_mixdown_shard_level) holds whole sub-trees up to level L, so it hands over its mlgpu_mixdown_shard_rows() = voices / 64^L
+ * level-L sums - d_rows [rows][64 * n_vectors] floats - and the host finishes the tree over all shards' rows in voice order with
+ * mlgpu_mixdown_finish (plain float additions, no device; 8 x 262 144 voices: 8 rows; 8 x 2^20: 32 rows). N shards of V / N voices
+ * then give the SAME BITS one engine gives for V voices (tests/cpp/multi_engine_test.cpp: 2 and 8 engines; tests/test_gpu_parity.py).
+ * Voices a multiple of 64 per shard; otherwise MLGPU_ERR_INVALID (level 0). mlgpu_mixdown_shard: the same for a signal in memory.
+ * mlgpu_mixdown_finish: h_rows [n_rows][64 * n_vectors]; flush_denormals = what the engines run with; h_scratch: only for more than 64
+ * rows, (ceil(n / 64) + ceil(n / 4096)) * 64 * n_vectors floats. No allocation in any of them; the scratch is mlgpu_mixdown_reserve's. */
+int mlgpu_mixdown_shard_level(size_t voices_per_shard);
+size_t mlgpu_mixdown_shard_rows(size_t voices_per_shard);
+int mlgpu_bank_process_mixdown_shard(mlgpu_bank* bank, size_t n_vectors, const float* d_in, int in_layout, const float* d_gains, float* d_rows);
+int mlgpu_mixdown_shard(mlgpu_engine* e, const float* d_signal, int layout, size_t n_voices, size_t n_vectors, const float* d_gains, float* d_rows);
+int mlgpu_mixdown_finish(const float* h_rows, size_t n_rows, size_t n_vectors, int flush_denormals, float* h_out, float* h_scratch);
 /* Setup, for a bank whose chain is not one of those: generate the summing form of its kernel (hiprtc; cached on disk like every generated
  * kernel), after which mlgpu_bank_process_mixdown serves it too - any chain of bank processors, fused or not. MLGPU_OK at once where the
  * form is there already. */

@@ -161,6 +161,21 @@ class DeviceGroup
     }
     for (auto& w : workers_) w->thread = std::thread(loop, w.get());
   }
+  // one engine (and host thread) per entry of an explicit device list; a device may appear more than once - several engines of one
+  // GPU (what tests/cpp/multi_engine_test.cpp uses to run an 8-member group on a one-GPU box; two engines per GPU are two streams)
+  explicit DeviceGroup(const std::vector<int>& devices)
+  {
+    const int have = mlgpu_device_count();
+    if (devices.empty()) throw Error(MLGPU_ERR_INVALID, "DeviceGroup: empty device list");
+    for (int d : devices)
+      if (d < 0 || d >= have) throw Error(MLGPU_ERR_NO_DEVICE, "DeviceGroup: device " + std::to_string(d) + " asked for, " + std::to_string(have) + " visible");
+    for (int d : devices)
+    {
+      workers_.emplace_back(new Worker());
+      workers_.back()->engine.reset(new Engine(d));
+    }
+    for (auto& w : workers_) w->thread = std::thread(loop, w.get());
+  }
   DeviceGroup(const DeviceGroup&) = delete;
   DeviceGroup& operator=(const DeviceGroup&) = delete;
   ~DeviceGroup()
@@ -214,6 +229,71 @@ class DeviceGroup
   void sync()
   {
     for (auto& w : workers_) w->engine->sync();
+  }
+};
+
+// The real-time block ACROSS the devices of a group: all voices of a sharded bank summed to one channel - the reference's
+// `outputs += voice` over every voice of a Synth (source/app/MLSynth.h:43-57), SURVEY 8e's "per-GPU reduction then host add".
+// Every member turns its contiguous voice range into the rows of the mixdown tree at the level its voice count is whole at
+// (mlgpu_bank_process_mixdown_shard, or a graph output in shard form: the sum is made inside the voice kernel, the voices' signals are
+// never written), copies them (rows x 256 bytes per DSPVector: one row per 262 144 voices) to the host, and the host finishes the
+// SAME tree over all members' rows (mlgpu_mixdown_finish): N members x V / N voices give the bits ONE engine gives for V voices.
+// No collective, no peer access: the exchange is N x rows x 256 bytes per DSPVector through pinned-size host memory.
+// The voices must divide evenly over the members and every member's share must be a multiple of 64.
+class GroupMixdown
+{
+  DeviceGroup& group_;
+  size_t total_, per_, rows_, maxVectors_;
+  std::vector<float*> dRows_;
+  std::vector<float> hRows_, scratch_;
+  int flush_{0};
+
+ public:
+  GroupMixdown(DeviceGroup& g, size_t totalVoices, size_t maxVectors) : group_(g), total_(totalVoices), maxVectors_(maxVectors)
+  {
+    const size_t n = (size_t)g.size();
+    if (totalVoices == 0 || totalVoices % n) throw Error(MLGPU_ERR_INVALID, "GroupMixdown: the voices do not divide evenly over the group's members");
+    per_ = totalVoices / n;
+    rows_ = mlgpu_mixdown_shard_rows(per_);
+    if (rows_ == 0) throw Error(MLGPU_ERR_INVALID, "GroupMixdown: a member's share of the voices must be a multiple of 64");
+    dRows_.assign(n, nullptr);
+    hRows_.assign(n * rows_ * 64 * maxVectors, 0.f);
+    const size_t allRows = n * rows_;
+    scratch_.assign(((allRows + 63) / 64 + (allRows + 4095) / 4096) * 64 * maxVectors, 0.f);
+    for (size_t m = 0; m < n; ++m)
+    {
+      Engine& e = g.engine((int)m);
+      e.check(mlgpu_mixdown_reserve(e.handle(), per_, maxVectors));
+      void* p = nullptr;
+      e.check(mlgpu_alloc(e.handle(), sizeof(float) * rows_ * 64 * maxVectors, &p));
+      dRows_[m] = static_cast<float*>(p);
+    }
+  }
+  GroupMixdown(const GroupMixdown&) = delete;
+  GroupMixdown& operator=(const GroupMixdown&) = delete;
+  ~GroupMixdown()
+  {
+    for (size_t m = 0; m < dRows_.size(); ++m)
+      if (dRows_[m]) mlgpu_free(group_.engine((int)m).handle(), dRows_[m]);
+  }
+  size_t voicesPerMember() const { return per_; }
+  size_t rowsPerMember() const { return rows_; }
+  void setFlushDenormals(bool on) { flush_ = on ? 1 : 0; }  // what the engines run with (mlgpu_engine_set_flush_denormals)
+  // One block of nVectors DSPVectors: shard(rank, engine, lo, hi, d_rows) enqueues the member's voices -> rows launch (e.g.
+  // mlgpu_bank_process_mixdown_shard(bank[rank], nVectors, nullptr, 0, nullptr, d_rows)); every member runs it on its own host
+  // thread, all at once; `out` gets the 64 * nVectors samples of the sum of ALL voices.
+  template <class F>
+  void process(size_t nVectors, F shard, float* out)
+  {
+    if (nVectors == 0) return;
+    if (nVectors > maxVectors_) throw Error(MLGPU_ERR_RANGE, "GroupMixdown::process: more DSPVectors than reserved");
+    const size_t rowFloats = 64 * nVectors;
+    group_.forEach(total_, [&](int rank, Engine& e, size_t lo, size_t hi) {
+      shard(rank, e, lo, hi, dRows_[(size_t)rank]);
+      e.check(mlgpu_download(e.handle(), hRows_.data() + (size_t)rank * rows_ * rowFloats, dRows_[(size_t)rank], sizeof(float) * rows_ * rowFloats));
+    });
+    const int st = mlgpu_mixdown_finish(hRows_.data(), (size_t)group_.size() * rows_, nVectors, flush_, out, scratch_.data());
+    if (st != MLGPU_OK) throw Error(st, "mlgpu_mixdown_finish");
   }
 };
 
@@ -553,6 +633,13 @@ class VoiceBank
     if (in.voices() != voices_) throw Error(MLGPU_ERR_INVALID, "VoiceBank: signal shape mismatch");
     commit();
     eng_.check(mlgpu_bank_process_mixdown(b_, in.vectors(), in.data(), in.layout(), gains, mix));
+  }
+  // ... for a bank that is one member's share of a larger one (GroupMixdown): mlgpu_mixdown_shard_rows(voices) rows of 64 * vectors
+  // floats, the mixdown tree up to the level this bank's voice count is whole at
+  void mixdownShard(size_t vectors, float* rows, const float* gains = nullptr)
+  {
+    commit();
+    eng_.check(mlgpu_bank_process_mixdown_shard(b_, vectors, nullptr, MLGPU_LAYOUT_QUAD, gains, rows));
   }
 
   // raw state (checkpoint / resume)

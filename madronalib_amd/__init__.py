@@ -35,6 +35,29 @@ class MlgpuError(RuntimeError):
         super().__init__(f"mlgpu status {status} ({L.mlgpu_status_string(status).decode()}) {detail}")
 
 
+def mixdown_shard_level(voices_per_shard):
+    """The level of the mixdown tree a shard of that many voices hands over (0: not a multiple of 64, no exact hand-over)."""
+    return int(_lib.load().mlgpu_mixdown_shard_level(int(voices_per_shard)))
+
+
+def mixdown_shard_rows(voices_per_shard):
+    return int(_lib.load().mlgpu_mixdown_shard_rows(int(voices_per_shard)))
+
+
+def mixdown_finish(rows, flush_denormals=False):
+    """The host's finish of the mixdown tree over all shards' rows, [n_rows][64 T] numpy in voice order -> [64 T] (mlgpu_mixdown_finish)."""
+    rows = np.ascontiguousarray(rows, np.float32)
+    n, S = rows.shape
+    out = np.empty(S, np.float32)
+    nscr = ((n + 63) // 64 + (n + 4095) // 4096) * S
+    scratch = np.empty(max(1, nscr), np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    st = _lib.load().mlgpu_mixdown_finish(rows.ctypes.data_as(fp), n, S // 64, int(bool(flush_denormals)), out.ctypes.data_as(fp), scratch.ctypes.data_as(fp))
+    if st:
+        raise MlgpuError(st, "(mixdown_finish)")
+    return out
+
+
 def device_source_hash():
     """SHA-256 of the device sources and compiler flags the loaded library was built from (mlgpu_device_source_hash)."""
     return _lib.load().mlgpu_device_source_hash().decode()
@@ -330,6 +353,12 @@ class Engine:
     def mixdown(self, d_signal, layout, n_voices, n_vectors, d_out, d_gains=None):
         g = lambda x: None if x is None else ctypes.c_void_p(x.ptr if hasattr(x, "ptr") else int(x))  # noqa: E731
         self._check(self.L.mlgpu_mixdown(self.h, g(d_signal), int(layout), int(n_voices), int(n_vectors), g(d_gains), g(d_out)))
+
+    def mixdown_shard(self, d_signal, layout, n_voices, n_vectors, d_rows, d_gains=None):
+        """This engine's SHARD of a larger bank: its voices' mixdown up to the hand-over level, shard_rows(n_voices) rows of 64 * n_vectors
+        floats for mixdown_finish (mlgpu_mixdown_shard)."""
+        g = lambda x: None if x is None else ctypes.c_void_p(x.ptr if hasattr(x, "ptr") else int(x))  # noqa: E731
+        self._check(self.L.mlgpu_mixdown_shard(self.h, g(d_signal), int(layout), int(n_voices), int(n_vectors), g(d_gains), g(d_rows)))
 
     def mixdown_groups(self, d_signal, layout, n_groups, group_size, n_vectors, d_out, out_layout=Layout.QUAD):
         """Sum every `group_size` consecutive voices (a Synth's voices, MLSynth.h:43-57) into one signal per group."""
@@ -631,6 +660,14 @@ class Events:
         """d_outputs: 8 DeviceBuffers (or None) in the order of Events.ROWS."""
         arr = (ctypes.c_void_p * 8)(*[None if b is None else b.ptr for b in d_outputs])
         self.engine._check(self.L.mlgpu_events_process(self.h, int(n_vectors), int(start_offset), arr, int(layout)))
+
+    def reserve_for_graph(self, max_vectors):
+        """Setup-time reserve of the control records and side signals a graph bound to this object needs for blocks of up to max_vectors
+        DSPVectors (mlgpu_events_reserve_for_graph): from then on Graph.process_events never allocates and refuses longer blocks."""
+        self.engine._check(self.L.mlgpu_events_reserve_for_graph(self.h, int(max_vectors)))
+
+    def graph_reserve_bytes(self, max_vectors):
+        return int(self.L.mlgpu_events_graph_reserve_bytes(self.h, int(max_vectors)))
 
     def watch_controllers(self, numbers, max_vectors):
         """The smoothed controller signals (AudioContext::getInputController) to make from now on, one per instrument per number,
@@ -946,6 +983,14 @@ class Bank:
         pg = None if d_gains is None else ctypes.c_void_p(d_gains.ptr if hasattr(d_gains, "ptr") else int(d_gains))
         self.engine._check(self.L.mlgpu_bank_process_mixdown(self.h, int(n_vectors), pin, int(in_layout), pg, pout))
 
+    def process_mixdown_shard(self, n_vectors, d_rows, d_in=None, in_layout=Layout.QUAD, d_gains=None):
+        """process_mixdown for a bank that is one engine's shard of a larger one: d_rows gets shard_rows(V) rows of 64 * n_vectors
+        floats, finished on the host over all shards' rows by mixdown_finish (mlgpu_bank_process_mixdown_shard)."""
+        pin = None if d_in is None else ctypes.c_void_p(d_in.ptr if hasattr(d_in, "ptr") else int(d_in))
+        pout = ctypes.c_void_p(d_rows.ptr if hasattr(d_rows, "ptr") else int(d_rows))
+        pg = None if d_gains is None else ctypes.c_void_p(d_gains.ptr if hasattr(d_gains, "ptr") else int(d_gains))
+        self.engine._check(self.L.mlgpu_bank_process_mixdown_shard(self.h, int(n_vectors), pin, int(in_layout), pg, pout))
+
     def process_host(self, n_vectors, in_signal=None, layout=Layout.QUAD):
         """Test convenience: in_signal/out are VOICE_MAJOR [V][64T] numpy; the kernel runs in `layout`
         (conversion done by the device layout kernel)."""
@@ -1008,7 +1053,7 @@ class Graph:
             engine._check(self.L.mlgpu_graph_set_voices_per_lane(self.h, int(voices_per_lane)))
         if delay_windows:   # True / 1: 32-byte sectors behind LDS windows; 2: transposed 64-byte pieces on a wave-uniform clock;
             # 3 / "best": 2 where it applies (at most four rings, not three), else 1
-            engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 3 if delay_windows in (3, "best") else (2 if delay_windows == 2 else 1)))
+            engine._check(self.L.mlgpu_graph_set_delay_layout(self.h, 3 if delay_windows in (3, "best") else (int(delay_windows) if delay_windows in (2, 4) else 1)))
         if autotune:
             engine._check(self.L.mlgpu_graph_set_autotune(self.h, 1))
         if live_constants:
@@ -1180,8 +1225,9 @@ class Graph:
 
     def set_output_mixdown(self, output_index, on=True):
         """Output `output_index` becomes one channel: the mixdown of all voices, mlgpu_mixdown's bits, made inside the voice kernel
-        (mlgpu_graph_set_output_mixdown). process() then wants 64 * n_vectors floats for it."""
-        self._check(self.L.mlgpu_graph_set_output_mixdown(self.h, int(output_index), 1 if on else 0))
+        (mlgpu_graph_set_output_mixdown). process() then wants 64 * n_vectors floats for it. on="shard": this graph is one engine's part of
+        a larger bank - the output takes mixdown_shard_rows(V) rows of 64 * n_vectors floats for mixdown_finish."""
+        self._check(self.L.mlgpu_graph_set_output_mixdown(self.h, int(output_index), 2 if on == "shard" else (1 if on else 0)))
 
     def reserve_mixdown(self, max_vectors):
         """Setup: the engine's mixdown scratch for this graph's mixed-down outputs (mlgpu_graph_reserve_mixdown)."""

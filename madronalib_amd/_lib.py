@@ -220,6 +220,11 @@ def _declare(L):
     sig("mlgpu_graph_tuning", i, [vp, c.POINTER(i), c.POINTER(i)])
     sig("mlgpu_graph_workgroups_per_cu", i, [vp])
     sig("mlgpu_mixdown_reserve", i, [vp, sz, sz])
+    sig("mlgpu_mixdown_shard_level", i, [sz])
+    sig("mlgpu_mixdown_shard_rows", sz, [sz])
+    sig("mlgpu_mixdown_shard", i, [vp, vp, i, sz, sz, vp, vp])
+    sig("mlgpu_bank_process_mixdown_shard", i, [vp, sz, vp, i, vp, vp])
+    sig("mlgpu_mixdown_finish", i, [fp, sz, sz, i, fp, fp])
     sig("mlgpu_mixdown", i, [vp, vp, i, sz, sz, vp, vp])
     sig("mlgpu_mixdown_groups", i, [vp, vp, i, sz, sz, sz, vp, i])
     sig("mlgpu_events_create", i, [vp, sz, i, pp])
@@ -250,6 +255,8 @@ def _declare(L):
     sig("mlgpu_transport_samples_since_start", ctypes.c_uint64, [vp, sz])
     sig("mlgpu_transport_bpm", ctypes.c_double, [vp, sz])
     sig("mlgpu_events_watch_controllers", i, [vp, ctypes.POINTER(ctypes.c_int), i, sz])
+    sig("mlgpu_events_reserve_for_graph", i, [vp, sz])
+    sig("mlgpu_events_graph_reserve_bytes", sz, [vp, sz])
     sig("mlgpu_events_controller_signal", vp, [vp, i])
     sig("mlgpu_resampler_create", i, [vp, sz, i, i, pp])
     sig("mlgpu_resampler_destroy", i, [vp])

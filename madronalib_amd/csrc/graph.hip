@@ -465,6 +465,7 @@ struct mlgpu_graph
   std::vector<Node> nodes;
   std::vector<int> outputs;
   int inputGroup[MLGPU_GRAPH_MAX_INPUTS] = {};  // > 1: the input has one row per that many adjacent voices (mlgpu_graph_set_input_group)
+  bool outputMixShard[MLGPU_GRAPH_MAX_OUTPUTS] = {false, false, false, false, false, false, false, false};  // ... handed over as the rows of a SHARD (graph_set_output_mixdown(.., 2): mlgpu_mixdown_shard_rows(V) rows for mlgpu_mixdown_finish)
   bool outputMix[MLGPU_GRAPH_MAX_OUTPUTS] = {false, false, false, false, false, false, false, false};  // the output is the mixdown of all voices (graph_set_output_mixdown)
   int outputGroup[MLGPU_GRAPH_MAX_OUTPUTS] = {0, 0, 0, 0, 0, 0, 0, 0};  // > 0: the output is the in-order sum of groups of that many adjacent voices
   int nInputs{0}, nParams{0}, nControls{0}, NC{0}, NS{0};
@@ -485,6 +486,7 @@ struct mlgpu_graph
   bool windowedRings{false};     // rings as [block][chunk][lane][8] behind LDS windows (mlgpu_graph_set_delay_layout)
   bool fbAhead{true};            // kept DSPVectors (feedback nodes) are fetched two quads ahead; MLGPU_GRAPH_FB_AHEAD=0 for A / B
   bool transposedIfPossible{false};  // graph_set_delay_layout(3)
+  bool sectorRings{false};       // layout 4: layout 1's memory, no LDS, trips of 8 samples with every ring's loads in the trip's prologue (implies windowedRings)
   bool transposedRings{false};   // layout 2: [block][chunk][lane][16], every global access a 64-byte piece made by four lanes, on a wave-uniform clock (implies windowedRings)
   int totalRings{0};
   size_t memVoices() const { return windowedRings ? ((V + 255) & ~(size_t)255) : V; }  // voices the ring memory is laid out for
@@ -682,7 +684,14 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
       else if (mlgpu_proc_is_vector_rate(n.kind))
         s << "p" << i << L << ".next_n(" << idx << ")";
       else if (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY)
-        s << "p" << i << L << ".next_i(" << idx << ", " << arg(0) << ", " << arg(1) << ")";
+        s << "p" << i << L << ".next_i(" << idx << ", " << arg(0) << ", " << arg(1) << ((g->sectorRings && n.region < 0) ? ", qq * 4 + k" : "") << ")";
+      else if (g->sectorRings && n.region < 0 && mlgpu_proc_rings(n.kind))
+      {
+        // ring layout 4: the sample's place in its trip of 8 (a constant once qq and k are unrolled)
+        s << "p" << i << L << ".next_k(qq * 4 + k, " << arg(0);
+        for (size_t j = 1; j < n.in.size(); ++j) s << ", " << arg(j);
+        s << ")";
+      }
       else if (isOscTrip(g, n))
         s << "osc" << i << L << "[qq * 4 + k]";  // made for the whole trip before the sample loop
       else if ((n.kind == MLGPU_PROC_SAW_GEN || n.kind == MLGPU_PROC_PULSE_GEN) && g->nodes[n.in[0]].rate == RATE_VOICE)
@@ -777,7 +786,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   std::ostringstream s;
   auto sfx = [](int l) { return "_" + std::to_string(l); };
   s << "// generated by libmlgpu graph.hip (" << VL << " voice" << (VL > 1 ? "s" : "") << " per lane)\n"
-    << (g->transposedRings ? "#define MLGPU_RING_WINDOWS 2\n" : (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : "")) << (g->strictSvf ? "#define MLGPU_SVF_STRICT 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\n" << (g->hasEventRows ? "#include \"mldsp_events.hpp\"\n" : "") << "using namespace mldev;\n";
+    << (g->transposedRings ? "#define MLGPU_RING_WINDOWS 2\n" : (g->sectorRings ? "#define MLGPU_RING_WINDOWS 3\n" : (g->windowedRings ? "#define MLGPU_RING_WINDOWS 1\n" : ""))) << (g->strictSvf ? "#define MLGPU_SVF_STRICT 1\n" : "") << "#include \"mldsp_kernels.hpp\"\n#include \"mldsp_ops.hpp\"\n" << (g->hasEventRows ? "#include \"mldsp_events.hpp\"\n" : "") << "using namespace mldev;\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_VOP && g->nodes[i].kind == MLGPU_VOP_TABLE)
     {
@@ -786,7 +795,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << "};\n";
     }
   // windowed rings: the latency of a sector refill is hidden by other waves only, so keep at least two per SIMD
-  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->transposedRings && g->totalRings == 1) ? ", 4" : (g->windowedRings && g->totalRings) ? ", 2" : (g->minWaves ? ", " + std::to_string(g->minWaves) : std::string())) << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n  apply_fp_mode(a.flags);\n";
+  s << "extern \"C\" __global__ __launch_bounds__(256" << ((g->transposedRings && g->totalRings == 1) ? ", 4" : (g->sectorRings && g->totalRings) ? (getenv("MLGPU_SECTOR_WAVES") ? std::string(", ") + getenv("MLGPU_SECTOR_WAVES") : std::string(", 1")) : (g->windowedRings && g->totalRings) ? ", 2" : (g->minWaves ? ", " + std::to_string(g->minWaves) : std::string())) << ") void mlgpu_graph_kernel(const GraphArgs a)\n{\n  apply_fp_mode(a.flags);\n";
   if (g->hasImpulse)
   {
     s << "  __shared__ float ldsTable[32];\n  if (threadIdx.x < 17) ldsTable[threadIdx.x] = a.impulseTable[threadIdx.x];\n  __syncthreads();\n";
@@ -797,6 +806,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     s << "  const KernelTables tables{nullptr};\n";
   }
   if (g->transposedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 4 << " * kTStrip];  // [ring][wavefront][40 rows][64]: write window + two read chunks\n";
+  else if (g->sectorRings && g->totalRings) s << "  __shared__ __attribute__((aligned(16))) float ldsRings[" << (size_t)g->totalRings * 4 * 512 << "];  // the held sectors, [ring][wavefront][half][lane][4]\n";
   else if (g->windowedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 8 * 256 << "];  // write windows, [ring][8][256 lanes]\n";
   // a group sum of 16 voices (one instrument's voices): four quads of the wavefront's 64 voices are parked in LDS and every lane
   // then adds up ONE (instrument, sample) pair in voice order - 2.3 instructions per voice-sample where the lane-shift chain
@@ -856,7 +866,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         else if (n.ringLen && g->windowedRings)
           s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (v" << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
             << " + (v" << L << " & 255) * 8, " << (n.ringLen - 1)
-            << "u, ldsRings + " << (size_t)n.ringSlot * 8 * 256 << " + threadIdx.x";
+            << "u, ldsRings + " << (g->sectorRings ? "(" + std::to_string((size_t)n.ringSlot * 4) + " + (threadIdx.x >> 6)) * 512 + (threadIdx.x & 63) * 4" : std::to_string((size_t)n.ringSlot * 8 * 256) + " + threadIdx.x");
         s << "};\n  p" << i << L << ".load(m" << i << L << ", tables);\n";
       }
       else if (n.type == NODE_INPUT)
@@ -981,10 +991,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".begin_vector(n" << n.in[0] << sfx(l) << ");\n";
   }
   const bool oscTrips = hasOscTrips(g);
-  if (oscTrips)
+  const bool ringTrips = g->sectorRings && g->totalRings;  // ring layout 4: trips of two quads, every ring's loads in the trip's prologue
+  if (oscTrips || ringTrips)
   {
     // the quads in trips of oscTripQ: the oscillators' samples of a trip first, then its quads (fully unrolled: qq is a constant)
-    const int tq = g->oscTripQ, unroll = (g->windowedRings && g->totalRings) ? 1 : std::max(1, g->unrollQ / tq);
+    const int tq = ringTrips ? 2 : g->oscTripQ, unroll = (g->windowedRings && g->totalRings) ? 1 : std::max(1, g->unrollQ / tq);
     s << "#pragma unroll " << unroll << "\n    for (int q2 = 0; q2 < 16; q2 += " << tq << ")\n    {\n";
     if (g->takeTurns == 2) s << "    take_turns_by_clock(turn0, " << g->turnClockShift << ");\n";
     else if (g->takeTurns) s << "    take_turns(turn0 + (uint32_t)t * " << 16 / tq << "u + (uint32_t)(q2 / " << tq << "));\n";
@@ -1027,6 +1038,10 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       }
       s << "    }\n";
     }
+    if (ringTrips)
+      for (size_t i = 0; i < g->nodes.size(); ++i)
+        if (g->nodes[i].type == NODE_PROC && g->nodes[i].region < 0 && mlgpu_proc_rings(g->nodes[i].kind))
+          for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".trip_begin();\n";
     s << "#pragma unroll\n    for (int qq = 0; qq < " << tq << "; ++qq)\n    {\n      const int q = q2 + qq;\n";
   }
   else
@@ -1244,7 +1259,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       s << "      " << (g->outputGroup[o] ? "if ((threadIdx.x & " + std::to_string(g->outputGroup[o] - 1) + ") == " + std::to_string(g->outputGroup[o] - 1) + ") " : std::string())
         << "__builtin_nontemporal_store(y" << o << sfx(l) << ", out" << o << sfx(l) << " + t * a.out[" << o << "].strideT + q * a.out[" << o << "].strideQ);\n";
   s << "    }\n";
-  if (oscTrips) s << "    }\n";
+  if (oscTrips || ringTrips) s << "    }\n";
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC && (g->nodes[i].region < 0 || g->nodes[i].role != ROLE_NONE))
       for (int l = 0; l < VL; ++l) s << "    p" << i << sfx(l) << ".end_vector();\n";
@@ -1931,7 +1946,10 @@ extern "C"
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
     if (index < 0 || index >= (int)g->outputs.size()) return gfail(g, MLGPU_ERR_RANGE, "graph_set_output_mixdown: no such output");
     if (on && g->outputGroup[index]) return gfail(g, MLGPU_ERR_INVALID, "graph_set_output_mixdown: the output is a group sum already");
+    if (on == 2 && mlgpu_mixdown_shard_level(g->V) == 0)
+      return gfail(g, MLGPU_ERR_INVALID, "graph_set_output_mixdown: the shard form needs a voice count that is a multiple of 64 (whole first-stage groups of the tree)");
     g->outputMix[index] = on != 0;
+    g->outputMixShard[index] = on == 2;
     return MLGPU_OK;
   }
   // setup: the engine's mixdown scratch for this graph's mixed-down outputs, launches of up to maxVectors DSPVectors
@@ -2030,13 +2048,25 @@ extern "C"
     constexpr size_t kLdsBytes = 160 * 1024;
     const size_t ldsLayout2 = (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float), ldsLayout1 = (size_t)g->totalRings * 8 * 256 * sizeof(float);
     auto kib = [](size_t b) { return std::to_string((b + 1023) / 1024) + " KiB"; };
+    // layout 4 (sector trips) serves delay nodes of the outer graph; one inside a rate region keeps layout 1's per-sample form
+    bool ringInRegion = false;
+    for (const Node& n : g->nodes) ringInRegion = ringInRegion || (n.type == NODE_PROC && n.region >= 0 && mlgpu_proc_rings(n.kind) != 0);
+    if (g->sectorRings && ringInRegion)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 4 (sector trips) does not serve a delay line inside a rate region (layout 1 or 3 for this graph)");
     if (g->transposedIfPossible)
-      g->transposedRings = partialOk && g->totalRings != 3 && ldsLayout2 + ldsOther <= kLdsBytes;
+    {
+      // "the best form": one or two rings - the transposed windows (0.72-0.74 of the HBM peak on the strings bank); more - the sector
+      // trips (no LDS, every ring's loads in the trip's prologue: profiles/r06_ring_layouts.txt); where neither applies, layout 1
+      g->transposedRings = partialOk && g->totalRings <= 2 && ldsLayout2 + ldsOther <= kLdsBytes;
+      g->sectorRings = !g->transposedRings && !ringInRegion && g->totalRings > 0 && ldsLayout1 + ldsOther <= kLdsBytes;  // (8 KiB per ring and workgroup, as layout 1)
+      // more rings than any windowed form has LDS for (the reference's reverb example: 24): the default rows
+      if (!g->transposedRings && !g->sectorRings && ldsLayout1 + ldsOther > kLdsBytes) g->windowedRings = false;
+    }
     if (g->transposedRings && ldsLayout2 + ldsOther > kLdsBytes)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 needs 40 KiB of LDS per ring (" + kib(ldsLayout2) + " for " + std::to_string(g->totalRings) +
                                                  " rings) next to " + kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB (layout 1 or 3 for this graph)");
     if (!g->transposedRings && g->windowedRings && ldsLayout1 + ldsOther > kLdsBytes)
-      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: windowed delay layout needs 8 KiB of LDS per ring (" + kib(ldsLayout1) + " for " + std::to_string(g->totalRings) +
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layouts 1 and 4 need 8 KiB of LDS per ring (" + kib(ldsLayout1) + " for " + std::to_string(g->totalRings) +
                                                  " rings) next to " + kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB");
     if (ldsOther > kLdsBytes)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: " + kib(ldsOther) + " of LDS for the outputs summed inside the kernel (21 KiB per mixed-down output, 20.3 KiB per 16-voice group sum); a workgroup has 160 KiB");
@@ -2054,6 +2084,7 @@ extern "C"
       const int t = atoi(trip);
       g->oscTripQ = (t == 1 || t == 2 || t == 4) ? t : 0;
     }
+    if (g->sectorRings && g->totalRings && g->oscTripQ > 0) g->oscTripQ = 2;  // (one trip structure: the rings' trips are two quads)
     if (!generateBudgeted(g, 0, g->source, g->emitted, g->log)) return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile (hiprtc): " + g->log);
     return MLGPU_OK;
   }
@@ -2322,9 +2353,11 @@ extern "C"
     if (!g) return MLGPU_ERR_INVALID;
     if (g->job) return MLGPU_ERR_BUSY;
     if (g->compiled) return gfail(g, MLGPU_ERR_INVALID, "graph already compiled");
-    if (windowed < 0 || windowed > 3) return gfail(g, MLGPU_ERR_INVALID, "graph_set_delay_layout: 0 (rows), 1 (32-byte sectors), 2 (transposed 64-byte pieces) or 3 (2 where it applies, else 1)");
+    if (windowed < 0 || windowed > 4)
+      return gfail(g, MLGPU_ERR_INVALID, "graph_set_delay_layout: 0 (rows), 1 (32-byte sectors), 2 (transposed 64-byte pieces), 4 (sector trips) or 3 (the best of 2 / 4 / 1 for the graph)");
     g->windowedRings = windowed != 0;
     g->transposedRings = windowed == 2;
+    g->sectorRings = windowed == 4;
     g->transposedIfPossible = windowed == 3;   // decided at compile, when the number of rings is known
     return MLGPU_OK;
   }
@@ -2427,7 +2460,7 @@ extern "C"
     if (!g) return -MLGPU_ERR_INVALID;
     if (g->job) return -MLGPU_ERR_BUSY;  // (layout 3 is being decided)
     if (g->transposedIfPossible && !g->compiled) return 3;
-    return g->transposedRings ? 2 : (g->windowedRings ? 1 : 0);
+    return g->transposedRings ? 2 : (g->sectorRings ? 4 : (g->windowedRings ? 1 : 0));
   }
 
   int mlgpu_graph_set_voices_per_lane(mlgpu_graph* g, int n)
@@ -2625,8 +2658,10 @@ extern "C"
     for (size_t o = 0, r = 0; o < g->outputs.size(); ++o)
       if (g->outputMix[o])
       {
-        if (mlgpu_launch_mixdown_rows(mixGroups, T, g->e->d_mixScratch + r * mixRegion, d_outputs[o], g->e->stream, g->e->kflags) != hipSuccess)
-          return gfail(g, MLGPU_ERR_HIP, "graph_process: the mixdown's later stages");
+        const hipError_t merr = g->outputMixShard[o]
+                                    ? mlgpu_launch_mixdown_rows_partial(mixGroups, T, g->e->d_mixScratch + r * mixRegion, d_outputs[o], mlgpu_mixdown_shard_level(g->V) - 1, g->e->stream, g->e->kflags)
+                                    : mlgpu_launch_mixdown_rows(mixGroups, T, g->e->d_mixScratch + r * mixRegion, d_outputs[o], g->e->stream, g->e->kflags);
+        if (merr != hipSuccess) return gfail(g, MLGPU_ERR_HIP, "graph_process: the mixdown's later stages");
         ++r;
       }
     if (trial)

@@ -1258,6 +1258,20 @@ constexpr bool kRingWindows = MLGPU_RING_WINDOWS != 0;  // fixed per generated k
 // a CU holds its sixteen wavefronts of a 262 144-voice bank at once (with 12.5 KiB - a 16-sample write window - three of four
 // workgroups fit and the fourth runs alone afterwards: twice the launch time, measured).
 constexpr bool kRingTransposed = MLGPU_RING_WINDOWS == 2;
+// Layout 4 (round 6, "sector trips"; MLGPU_RING_WINDOWS 3): layout 1's memory - [256-voice block][sample / 8][lane][8], a voice's 32-byte
+// sectors - with NO LDS and no per-sample decisions, for graphs with many rings. The sample loop runs in trips of 8 samples on the
+// wave-uniform write clock (w a multiple of 8 at every trip's start). Per ring and trip: the eight written samples stay in registers
+// and go out as ONE sector (two 16-byte stores); the eight samples read are positions r0 .. r0 + 7 of two neighbouring sectors - the
+// lower one HELD in eight registers since the previous trip, the upper one loaded in the TRIP'S PROLOGUE, where the generated kernel
+// issues the loads of ALL its rings together before any arithmetic (one memory round trip per trip and wavefront, not one per ring
+// and sample) - and a three-stage barrel shifter (28 selects per trip, 3.5 per sample) picks them by r0 & 7. The prologue PREDICTS
+// the read position from the delay time in effect (delay times move rarely: a PitchbendableDelay's at most every 32 samples); a trip
+// whose first sample finds another sector, and every sample whose delay time differs from the trip's first, loads again (waited).
+// Delay times under 16 samples - a read that could land in a sector not yet in memory - send that trip of that wavefront through
+// plain per-sample accesses of the same memory. Layout 1 decided per lane and sample whether to refill its register window: a
+// divergent load and a round trip on almost every sample of a wavefront whose voices have different delay times.
+constexpr bool kRingSectors = MLGPU_RING_WINDOWS == 3;
+constexpr int32_t kSectorMinDelay = 16;
 constexpr int kTChunk = 16, kTWrite = 8, kTRowPad = 64, kTRows = kTWrite + 2 * kTChunk, kTStrip = kTRows * kTRowPad;
 constexpr uint32_t kTNone = 0xFFFFFFFFu;
 
@@ -1289,6 +1303,11 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       beginT(m, ringIdx);
       return;
     }
+    if (kRingSectors)
+    {
+      beginS(m, ringIdx);
+      return;
+    }
     if (!kRingWindows) return;
     const f32x4r* src = (const f32x4r*)chunkMem(m, ringIdx, w);
     float* wb = wbuf(m, ringIdx);
@@ -1310,6 +1329,10 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     if (kRingTransposed)
     {
       if (uniformW) flushLast(m, ringIdx);
+    }
+    else if (kRingSectors)
+    {
+      // (a launch is whole DSPVectors = whole trips: nothing is pending)
     }
     else if (kRingWindows) flush(m, ringIdx, w & ~(uint32_t)(kRingWindow - 1));
   }
@@ -1672,8 +1695,229 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     return y;
   }
 
-  MLD float sample(const VoiceMem& m, int ringIdx, float x, int32_t d)
+  // ---- layout 4: sector trips (see the constants above) ----
+  // The held sector lives in LDS between trips (2 KiB per wavefront and ring, [half][lane][4]: 16-byte accesses without a bank
+  // conflict): eight more registers per ring across the trip boundary were what made the 8-ring graph spill (254 + 406 spilled).
+  float sN[8], sY[8], sX[8];  // the sector loaded in the prologue, this trip's reads, this trip's writes
+  uint32_t sTag;              // which sector the LDS slot holds (kTNone: none)
+  uint32_t sNTag;             // which sector sN holds or will hold - its load may still be in flight (kTNone: none)
+  int32_t sD0;                // the delay time of the trip's first sample
+  static constexpr int kSectorLdsFloats = 512;  // per wavefront and ring
+  MLD float* held(const VoiceMem& m, int ringIdx) const { return m.lds + (size_t)ringIdx * 4 * kSectorLdsFloats; }
+  MLD void holdSector(const VoiceMem& m, int slot, const float (&v)[8]) const
   {
+    float* h = held(m, slot);
+    *(f32x4r*)h = f32x4r{v[0], v[1], v[2], v[3]};
+    *(f32x4r*)(h + 256) = f32x4r{v[4], v[5], v[6], v[7]};
+  }
+  MLD void heldSector(const VoiceMem& m, int slot, float (&v)[8]) const
+  {
+    const float* h = held(m, slot);
+    const f32x4r a = *(const f32x4r*)h, b = *(const f32x4r*)(h + 256);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  }
+  bool sAligned, sFast;              // launch: w is the same multiple of 8 in every lane; trip: served from sH / sN
+  MLD void beginS(const VoiceMem&, int)
+  {
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+    sAligned = __builtin_amdgcn_ballot_w64(w != w0) == 0 && (w0 & 7u) == 0u;
+    sTag = sNTag = kTNone;
+    sFast = false;
+    sD0 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sN[j] = sY[j] = sX[j] = 0.f;
+  }
+  MLD void loadSector(const VoiceMem& m, int ringIdx, uint32_t sector, float (&out)[8]) const
+  {
+    const f32x4r* src = (const f32x4r*)chunkMem(m, ringIdx, sector * 8u);
+    const f32x4r a = src[0], b = src[1];
+    out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3];
+    out[4] = b[0]; out[5] = b[1]; out[6] = b[2]; out[7] = b[3];
+  }
+  // the trip's prologue (the generated kernel calls it for every ring before the trip's first sample): dPred = the delay time in effect
+  // (slot: the LDS slot of the held sector, the ring's own unless a PitchbendableDelay's second core reads the first one's ring)
+  MLD void tripBegin(const VoiceMem& m, int ringIdx, int32_t dPred, int slot = -1)
+  {
+    if (slot < 0) slot = ringIdx;
+    if (!sAligned) return;
+    if (__builtin_amdgcn_ballot_w64(dPred < kSectorMinDelay) != 0)  // (the trip's first sample decides how it is served)
+    {
+      sTag = sNTag = kTNone;
+      return;
+    }
+    const uint32_t smask = m.memMask >> 3;
+    const uint32_t s0 = ((w - (uint32_t)dPred) & m.memMask) >> 3, s1 = (s0 + 1u) & smask;
+    // the held sector is the one needed (the usual case: the read position moved on by 8) - else it comes from memory too. One branch
+    // for the wavefront, unconditional loads inside it: a lane that holds the right sector already gets the same eight floats again.
+    if (__builtin_amdgcn_ballot_w64(sTag != s0) != 0)
+    {
+      float h[8];
+      loadSector(m, ringIdx, s0, h);
+      holdSector(m, slot, h);
+      sTag = s0;
+    }
+    // ... and the upper sector: usually asked for a whole trip ago already (tripStart's early request)
+    if (__builtin_amdgcn_ballot_w64(sNTag != s1) != 0)
+    {
+      loadSector(m, ringIdx, s1, sN);
+      sNTag = s1;
+    }
+  }
+  // sY = positions r0 .. r0 + 7 of the sixteen floats sH, sN (r0 & 7 = o): a barrel shifter, 11 + 9 + 8 selects
+  MLD void barrel(uint32_t o, const float (&sH)[8])
+  {
+    const bool b4 = (o & 4u) != 0u, b2 = (o & 2u) != 0u, b1 = (o & 1u) != 0u;
+    // Scalars made opaque one by one, not arrays: given `c ? a[j + 4] : a[j]` on array slots the optimizer makes ONE access with a
+    // selected index, and the arrays then live in scratch memory behind a per-lane offset (what the first build of this did).
+#define MLD_BARREL_IN(i, src) float e##i = src; asm("" : "+v"(e##i))
+    MLD_BARREL_IN(0, sH[0]); MLD_BARREL_IN(1, sH[1]); MLD_BARREL_IN(2, sH[2]); MLD_BARREL_IN(3, sH[3]);
+    MLD_BARREL_IN(4, sH[4]); MLD_BARREL_IN(5, sH[5]); MLD_BARREL_IN(6, sH[6]); MLD_BARREL_IN(7, sH[7]);
+    MLD_BARREL_IN(8, sN[0]); MLD_BARREL_IN(9, sN[1]); MLD_BARREL_IN(10, sN[2]); MLD_BARREL_IN(11, sN[3]);
+    MLD_BARREL_IN(12, sN[4]); MLD_BARREL_IN(13, sN[5]); MLD_BARREL_IN(14, sN[6]);
+#undef MLD_BARREL_IN
+    const float f0 = b4 ? e4 : e0, f1 = b4 ? e5 : e1, f2 = b4 ? e6 : e2, f3 = b4 ? e7 : e3, f4 = b4 ? e8 : e4, f5 = b4 ? e9 : e5,
+                f6 = b4 ? e10 : e6, f7 = b4 ? e11 : e7, f8 = b4 ? e12 : e8, f9 = b4 ? e13 : e9, f10 = b4 ? e14 : e10;
+    const float g0 = b2 ? f2 : f0, g1 = b2 ? f3 : f1, g2 = b2 ? f4 : f2, g3 = b2 ? f5 : f3, g4 = b2 ? f6 : f4, g5 = b2 ? f7 : f5,
+                g6 = b2 ? f8 : f6, g7 = b2 ? f9 : f7, g8 = b2 ? f10 : f8;
+    sY[0] = b1 ? g1 : g0;
+    sY[1] = b1 ? g2 : g1;
+    sY[2] = b1 ? g3 : g2;
+    sY[3] = b1 ? g4 : g3;
+    sY[4] = b1 ? g5 : g4;
+    sY[5] = b1 ? g6 : g5;
+    sY[6] = b1 ? g7 : g6;
+    sY[7] = b1 ? g8 : g7;
+  }
+  // ---- a trip's steps (sAligned launches; w is the trip's base, the position of sample K is w + K) ----
+  // sample 0, the delay time known: `fast` (the caller's wave-uniform decision: every delay time that reads this ring's memory in this
+  // trip is at least 16 samples) - the eight reads r0 .. r0 + 7 into sY, from the held sector and the prologue's if the prologue took
+  // the right position, else from memory now
+  MLD void tripStart(const VoiceMem& m, int ringIdx, int32_t d, bool fast, int slot = -1)
+  {
+    if (slot < 0) slot = ringIdx;
+    sD0 = d;
+    sFast = fast;
+    if (!fast)
+    {
+      sTag = sNTag = kTNone;
+      return;
+    }
+    const uint32_t smask = m.memMask >> 3;
+    const uint32_t r0 = (w - (uint32_t)d) & m.memMask, s0 = r0 >> 3, s1 = (s0 + 1u) & smask;
+    float h[8];
+    if (__builtin_amdgcn_ballot_w64(sTag != s0 || sNTag != s1) != 0)
+    {
+      // the delay time is not what the prologue took it for (or no prologue ran): both sectors now, waited for here
+      loadSector(m, ringIdx, s0, h);
+      loadSector(m, ringIdx, s1, sN);
+      asm volatile("" : "+v"(h[0]), "+v"(sN[0]));
+    }
+    else
+      heldSector(m, slot, h);
+    barrel(r0 & 7u, h);
+    holdSector(m, slot, sN);  // the upper sector is the next trip's lower one
+    sTag = s1;
+    // sN is free now: the sector after it - the NEXT trip's upper one if the delay time stays - is asked for at once and has this
+    // whole trip's arithmetic to arrive in (a single wavefront per SIMD cannot hide a load behind another wavefront). It is complete
+    // in memory when every lane reads at least 32 samples behind the writer.
+    if (__builtin_amdgcn_ballot_w64(d < 2 * kSectorMinDelay) == 0)
+    {
+      sNTag = (s1 + 1u) & smask;
+      loadSector(m, ringIdx, sNTag, sN);
+    }
+    else
+      sNTag = kTNone;
+  }
+  // sample K's write: a fast trip keeps the sector's eight samples in registers and stores them TOGETHER after the eighth (two
+  // 16-byte halves four samples apart were two partial writes of a 32-byte sector: 1.5 x the write traffic, profiles/r06_ring_layouts.txt)
+  MLD void writeS(const VoiceMem& m, int ringIdx, float x, int K)
+  {
+    if (sFast)
+    {
+      sX[K] = x;
+      if (K == 7)
+      {
+        f32x4r* dst = (f32x4r*)chunkMem(m, ringIdx, w);
+        dst[0] = f32x4r{sX[0], sX[1], sX[2], sX[3]};
+        dst[1] = f32x4r{sX[4], sX[5], sX[6], sX[7]};
+      }
+    }
+    else
+    {
+      const uint32_t pos = w + (uint32_t)K;
+      __hip_atomic_store(chunkMem(m, ringIdx, pos) + (pos & 7u), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // sample K's read (after its write, as the reference: a delay time of 0 reads the sample just written). VARY: the delay time may
+  // differ from sample to sample (IntegerDelay / FractionalDelay with a delay-time signal); a PitchbendableDelay's moves at samples 0
+  // and 16 of 32 only. wr: the core whose registers hold this trip's written samples (itself; a PitchbendableDelay's second core
+  // reads the first one's ring).
+  template <bool VARY>
+  MLD float readS(const VoiceMem& m, int ringIdx, int32_t d, int K, const RingCore& wr)
+  {
+    float y;
+    if (sFast)
+    {
+      y = sY[K];
+      if (VARY && K != 0 && __builtin_amdgcn_ballot_w64(d != sD0) != 0)
+      {
+        // a delay time that moves inside the trip: those lanes read their sample straight from memory. What the trip has written
+        // so far is still in registers, so a lane that now reads closer than 16 samples behind the writer puts it into memory
+        // first (rare twice over).
+        if (__builtin_amdgcn_ballot_w64(d != sD0 && d < kSectorMinDelay) != 0)
+        {
+          float* own = chunkMem(m, ringIdx, w);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j <= K) __hip_atomic_store(own + j, wr.sX[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (d != sD0)
+        {
+          const uint32_t r = (w + (uint32_t)K - (uint32_t)d) & m.memMask;
+          y = __hip_atomic_load(chunkMem(m, ringIdx, r) + (r & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("" : "+v"(y));
+      }
+    }
+    else
+    {
+      const uint32_t r = (w + (uint32_t)K - (uint32_t)d) & m.memMask;
+      y = __hip_atomic_load(chunkMem(m, ringIdx, r) + (r & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" : "+v"(y));  // (the wait for it here, not where the paths join: see sampleT)
+    }
+    return y;
+  }
+  MLD void advanceS(const VoiceMem& m, int K)
+  {
+    if (K == 7) w = (w + 8u) & m.memMask;
+  }
+  // one ring, one reader (IntegerDelay, FractionalDelay)
+  template <bool VARY>
+  MLD float sampleS(const VoiceMem& m, int ringIdx, float x, int32_t d, int K)
+  {
+    if (!sAligned)
+    {
+      // write indices that differ inside the wavefront or are not a multiple of 8 (a host set them so): sample by sample through memory
+      __hip_atomic_store(chunkMem(m, ringIdx, w) + (w & 7u), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t r = (w - (uint32_t)d) & m.memMask;
+      float y = __hip_atomic_load(chunkMem(m, ringIdx, r) + (r & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" : "+v"(y));
+      w = (w + 1) & m.memMask;
+      return y;
+    }
+    if (K == 0) tripStart(m, ringIdx, d, __builtin_amdgcn_ballot_w64(d < kSectorMinDelay) == 0);
+    writeS(m, ringIdx, x, K);
+    const float y = readS<VARY>(m, ringIdx, d, K, *this);
+    advanceS(m, K);
+    return y;
+  }
+
+  // K: the sample's place in its trip of 8 (layout 4 only; the generated kernel passes a constant)
+  template <bool VARY = false>
+  MLD float sample(const VoiceMem& m, int ringIdx, float x, int32_t d, int K = 0)
+  {
+    if (kRingSectors) return sampleS<VARY>(m, ringIdx, x, d, K);
     if (kRingTransposed) return sampleT(m, ringIdx, x, d);
     if (kRingWindows) return sampleWindowed(m, ringIdx, x, d);
     const uint32_t ringBase = (uint32_t)ringIdx * (m.memMask + 1);
@@ -1711,6 +1955,14 @@ struct Proc<MLGPU_PROC_INTEGER_DELAY>  // :801-914   C{}  S{writeIndex:u32, dela
   {
     delay = sse_cvtt(d);
     return ringc.sample(mem, 0, x, delay);
+  }
+  // layout 4: the same with the sample's place K in its trip of 8; trip_begin before each trip
+  MLD void trip_begin() { ringc.tripBegin(mem, 0, delay); }
+  MLD float next_k(int K, float x) { return ringc.sample(mem, 0, x, delay, K); }
+  MLD float next_k(int K, float x, float d)
+  {
+    delay = sse_cvtt(d);
+    return ringc.sample<true>(mem, 0, x, delay, K);
   }
   MLD void end_vector() {}
 };
@@ -1764,7 +2016,7 @@ struct FracCore
     m.set(s0 + 3, (uint32_t)delayInt);
     m.set(s0 + 4, f2u(apCoeff));
   }
-  MLD void setDelay(float d)  // setDelayInSamples, :991-1007; Allpass1::makeCoeffs :938-943
+  static MLD void delayFor(float d, int32_t& delayIntOut, float& apCoeffOut)  // setDelayInSamples, :991-1007; Allpass1::makeCoeffs :938-943
   {
     const float fDelayInt = __builtin_floorf(d);
     int32_t di = sse_cvtt(fDelayInt);
@@ -1774,17 +2026,22 @@ struct FracCore
       frac += 1.f;
       di -= 1;
     }
-    delayInt = di;
+    delayIntOut = di;
     const float xm1 = (frac - 1.f);
-    apCoeff = -0.53f * xm1 + 0.24f * xm1 * xm1;
+    apCoeffOut = -0.53f * xm1 + 0.24f * xm1 * xm1;
   }
-  MLD float sample(const VoiceMem& m, int ringIdx, float x)
+  MLD void setDelay(float d) { delayFor(d, delayInt, apCoeff); }
+  MLD float ap(float d)  // the Allpass1 behind the integer delay, :945-953
   {
-    const float d = ringc.sample(m, ringIdx, x, delayInt);
     const float y = x1 + (d - y1) * apCoeff;
     x1 = d;
     y1 = y;
     return y;
+  }
+  template <bool VARY = false>
+  MLD float sample(const VoiceMem& m, int ringIdx, float x, int K = 0)
+  {
+    return ap(ringc.sample<VARY>(m, ringIdx, x, delayInt, K));
   }
 };
 
@@ -1817,6 +2074,18 @@ struct Proc<MLGPU_PROC_FRACTIONAL_DELAY>  // :971-1044  C{}  S{writeIndex, x1, y
     if (f2u(ticks) != 0u) f.setDelay(d);
     return f.sample(mem, 0, x);
   }
+  MLD void trip_begin() { f.ringc.tripBegin(mem, 0, f.delayInt); }
+  MLD float next_k(int K, float x) { return f.sample(mem, 0, x, K); }
+  MLD float next_k(int K, float x, float d)
+  {
+    f.setDelay(d);
+    return f.sample<true>(mem, 0, x, K);
+  }
+  MLD float next_k(int K, float x, float d, float ticks)
+  {
+    if (f2u(ticks) != 0u) f.setDelay(d);
+    return f.sample<true>(mem, 0, x, K);
+  }
   MLD void end_vector() {}
 };
 
@@ -1828,6 +2097,11 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
   static constexpr bool kNeedsIndex = true;
   FracCore f1, f2;
   VoiceMem mem;
+  // Ring layout 4. The reference feeds both FractionalDelays the SAME input (:1102-1104), so their rings hold the same samples
+  // whenever their write indices agree - which they do unless a host set them apart: ring 0 alone is then written and read by both
+  // cores (oneRing, decided per wavefront at the launch's start), and in a trip in which both cores have the same delay time - all
+  // the time while the delay-time signal rests - ONE read serves both (shared): 8 bytes per sample of ring traffic instead of 16.
+  bool oneRing, shared;
   MLD void load(const VoiceMem& m, const KernelTables&)
   {
     mem = m;
@@ -1835,6 +2109,11 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
     f2.loadFrom(m, 5);
     f1.ringc.begin(m, 0);
     f2.ringc.begin(m, 1);
+    shared = false;
+    oneRing = kRingSectors && f1.ringc.sAligned && f2.ringc.sAligned && __builtin_amdgcn_ballot_w64(f1.ringc.w != f2.ringc.w) == 0;
+    // write indices a host set apart: the two rings are two rings, served sample by sample through memory (no trips: the second core
+    // then needs no registers for a sector of its own writes)
+    if (kRingSectors && !oneRing) f1.ringc.sAligned = f2.ringc.sAligned = false;
   }
   MLD void store(const VoiceMem& m) const
   {
@@ -1845,21 +2124,56 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
   }
   // n = sample index inside the DSPVector. kFadePeriod = 32; delay 1 may change when n % 32 == 16, delay 2 when
   // n % 32 == 0; kvFade is the triangle 0..1..0 over the period (:1054-1062); result = lerp(d1, d2, fade) (:1102-1104)
-  MLD float next_i(int n, float x, float d)
+  MLD void trip_begin()
+  {
+    f1.ringc.tripBegin(mem, 0, f1.delayInt);
+    if (!oneRing) f2.ringc.tripBegin(mem, 1, f2.delayInt);
+    else if (__builtin_amdgcn_ballot_w64(f1.delayInt != f2.delayInt) != 0) f2.ringc.tripBegin(mem, 0, f2.delayInt, 1);
+    else f2.ringc.sTag = f2.ringc.sNTag = kTNone;  // (one read for both, as far as the prologue can tell)
+  }
+  MLD float next_i(int n, float x, float d, int K = 0)
   {
     const int r = n & 31;
     if ((n & 15) == 0)  // one branch and selects over values: two `if (...) fN.setDelay(d)` get merged by the optimizer
     {                   // into stores through a selected pointer, which keeps both cores in scratch memory
-      FracCore nd = f1;
-      nd.setDelay(d);
+      int32_t ndInt;   // (not a copy of a core: its ring windows are register arrays)
+      float ndCoeff;
+      FracCore::delayFor(d, ndInt, ndCoeff);
       const bool first = (r == 16);
-      f1.delayInt = first ? nd.delayInt : f1.delayInt;
-      f1.apCoeff = first ? nd.apCoeff : f1.apCoeff;
-      f2.delayInt = first ? f2.delayInt : nd.delayInt;
-      f2.apCoeff = first ? f2.apCoeff : nd.apCoeff;
+      f1.delayInt = first ? ndInt : f1.delayInt;
+      f1.apCoeff = first ? ndCoeff : f1.apCoeff;
+      f2.delayInt = first ? f2.delayInt : ndInt;
+      f2.apCoeff = first ? f2.apCoeff : ndCoeff;
     }
-    const float y1 = f1.sample(mem, 0, x);
-    const float y2 = f2.sample(mem, 1, x);
+    float y1, y2;
+    if (kRingSectors && oneRing)
+    {
+      if (K == 0)
+      {
+        const bool fast = __builtin_amdgcn_ballot_w64(f1.delayInt < kSectorMinDelay || f2.delayInt < kSectorMinDelay) == 0;
+        shared = fast && __builtin_amdgcn_ballot_w64(f1.delayInt != f2.delayInt) == 0;
+        f1.ringc.tripStart(mem, 0, f1.delayInt, fast);
+        if (!shared) f2.ringc.tripStart(mem, 0, f2.delayInt, fast, 1);
+        else
+        {
+          f2.ringc.sFast = true;
+          f2.ringc.sTag = f2.ringc.sNTag = kTNone;
+        }
+      }
+      f1.ringc.writeS(mem, 0, x, K);
+      const float a = f1.ringc.readS<false>(mem, 0, f1.delayInt, K, f1.ringc);
+      float b = a;
+      if (!shared) b = f2.ringc.readS<false>(mem, 0, f2.delayInt, K, f1.ringc);
+      f1.ringc.advanceS(mem, K);
+      f2.ringc.advanceS(mem, K);
+      y1 = f1.ap(a);
+      y2 = f2.ap(b);
+    }
+    else
+    {
+      y1 = f1.sample(mem, 0, x, K);
+      y2 = f2.sample(mem, 1, x, K);
+    }
     const float fade = 2.f * ((r > 16) ? 1.0f - (float)r / 32.f : (float)r / 32.f);
     return y1 + (fade * (y2 - y1));
   }

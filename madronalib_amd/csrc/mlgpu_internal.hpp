@@ -119,6 +119,8 @@ hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T
                                 hipStream_t stream, uint32_t flags);
 int mlgpu_mixdown_reserve_floats(mlgpu_engine* e, size_t floats);  // capi.hip: the mixdown scratch grown to at least that
 hipError_t mlgpu_launch_mixdown_rows(size_t groups, size_t T, float* partial, float* out, hipStream_t stream, uint32_t flags);
+hipError_t mlgpu_launch_mixdown_rows_partial(size_t groups, size_t T, float* partial, float* out, int reductions, hipStream_t stream, uint32_t flags);
+hipError_t mlgpu_launch_mixdown_stage1(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, hipStream_t stream, uint32_t flags);
 hipError_t mlgpu_launch_mixdown_groups(const float* sig, int layout, size_t groups, size_t P, size_t T, float* out, int outLayout, hipStream_t stream, uint32_t flags);
 hipError_t mlgpu_launch_route(bool demux, bool linear, const float* sel, size_t selElems, const float* const* ins, float* const* outs, int n,
                               size_t nElems, hipStream_t stream, uint32_t flags);

@@ -912,6 +912,13 @@ hipError_t mlgpu_launch_mixdown(const float* sig, int layout, size_t V, size_t T
   return mlgpu_launch_mixdown_rows(groups, T, partial, out, stream, flags);
 }
 
+hipError_t mlgpu_launch_mixdown_stage1(const float* sig, int layout, size_t V, size_t T, const float* gains, float* partial, hipStream_t stream, uint32_t flags)
+{
+  const size_t groups = (V + 63) / 64;
+  hipLaunchKernelGGL(mixdown_stage1_kernel, dim3((unsigned)((groups * T + 3) / 4)), dim3(256), 0, stream, makeView(sig, layout, V, T), V, T, gains, partial, flags);
+  return hipGetLastError();
+}
+
 // the later stages alone: `partial` holds the rows of 64-voice group sums (the first stage's output, or a voice kernel's that made
 // them itself - chain_mix_kernel)
 hipError_t mlgpu_launch_mixdown_rows(size_t groups, size_t T, float* partial, float* out, hipStream_t stream, uint32_t flags)
@@ -938,6 +945,29 @@ hipError_t mlgpu_launch_mixdown_rows(size_t groups, size_t T, float* partial, fl
     b = t;
     rows = rowsOut;
   } while (rows > 1);
+  return hipGetLastError();
+}
+
+// The later stages up to a level: `reductions` passes of 64 rows -> 1 (each exact: the caller guarantees groups is a multiple of
+// 64^reductions), the last one into `out` - what one SHARD of a voice bank hands to the host, which finishes the same tree over the
+// shards' rows (mlgpu_mixdown_finish). reductions == 0: the group sums themselves.
+hipError_t mlgpu_launch_mixdown_rows_partial(size_t groups, size_t T, float* partial, float* out, int reductions, hipStream_t stream, uint32_t flags)
+{
+  const size_t nQuads = T * 16;
+  float4* a = (float4*)partial;
+  float4* b = a + groups * nQuads;
+  size_t rows = groups;
+  if (reductions == 0) return hipMemcpyAsync(out, partial, sizeof(float4) * groups * nQuads, hipMemcpyDeviceToDevice, stream);
+  for (int r = 0; r < reductions; ++r)
+  {
+    const size_t rowsOut = (rows + 63) / 64;
+    hipLaunchKernelGGL(mixdown_rows64_kernel, dim3((unsigned)((nQuads + 63) / 64), (unsigned)rowsOut), dim3(64), 0, stream, (const float4*)a, rows, nQuads,
+                       r + 1 == reductions ? (float4*)out : b, flags);
+    float4* t = a;
+    a = b;
+    b = t;
+    rows = rowsOut;
+  }
   return hipGetLastError();
 }
 

@@ -83,3 +83,55 @@ def max_over_ranks(seconds, dist=None, device="cpu"):
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class RowExchange:
+    """The one exchange a sharded bank has when a host wants ONE channel from it (SURVEY 8e "optional later: per-GPU reduction then host
+    add"): every rank hands rank 0 the rows of the mixdown tree its shard is whole at (mlgpu_bank_process_mixdown_shard: 256 bytes per
+    row and DSPVector, one row per 262 144 voices), rank 0 finishes the tree (mlgpu_mixdown_finish). No collective library: the rows
+    go through a POSIX shared-memory segment of the node - ranks may be processes (torch.distributed.run, bench.py's own launcher)
+    or threads -, two slots so that a rank can write block k + 1 while rank 0 still reads block k, sequence counters instead of locks.
+    `rdv`: the ranks' rendezvous (gather is used once, for the segment's name)."""
+
+    def __init__(self, rdv, rank, world, rows_per_rank, max_vectors):
+        from multiprocessing import shared_memory
+        self.rank, self.world, self.rows, self.S = int(rank), int(world), int(rows_per_rank), 64 * int(max_vectors)
+        self.hdr = 2 * self.world + 2                                   # uint64: written[slot][rank], consumed[slot]
+        nbytes = 8 * self.hdr + 4 * 2 * self.world * self.rows * self.S
+        self.shm = shared_memory.SharedMemory(create=True, size=nbytes) if self.rank == 0 else None
+        names = rdv.gather(self.shm.name if self.rank == 0 else None)
+        if self.rank != 0:
+            name = next(n for n in names if n)
+            self.shm = shared_memory.SharedMemory(name=name)
+        self.seq = np.ndarray((self.hdr,), np.uint64, self.shm.buf, 0)
+        self.data = np.ndarray((2, self.world * self.rows, self.S), np.float32, self.shm.buf, 8 * self.hdr)
+        if self.rank == 0:
+            self.seq[:] = 0
+        rdv.barrier()
+
+    def put(self, block, rows):
+        """This rank's rows [rows_per_rank][64 T] of block `block` (0, 1, 2 ...)."""
+        slot, T64 = block & 1, rows.shape[1]
+        while block >= 2 and int(self.seq[2 * self.world + slot]) < block - 1:      # rank 0 has not read this slot's block k - 2 yet
+            pass
+        self.data[slot, self.rank * self.rows:(self.rank + 1) * self.rows, :T64] = rows
+        self.seq[slot * self.world + self.rank] = block + 1
+
+    def collect(self, block, n_vectors):
+        """Rank 0: all ranks' rows of block `block`, [world * rows_per_rank][64 n_vectors], in voice order (a copy: the slot is free again)."""
+        slot = block & 1
+        want = block + 1
+        while any(int(self.seq[slot * self.world + r]) < want for r in range(self.world)):
+            pass
+        out = np.array(self.data[slot, :, :64 * n_vectors])
+        self.seq[2 * self.world + slot] = want
+        return out
+
+    def close(self):
+        self.seq = self.data = None
+        try:
+            self.shm.close()
+            if self.rank == 0:
+                self.shm.unlink()
+        except Exception:
+            pass

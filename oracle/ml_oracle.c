@@ -1886,6 +1886,58 @@ int mlorc_mixdown(const float* sig, size_t V, size_t T, const float* gains, floa
   return MLGPU_OK;
 }
 
+/* The same tree for a bank SPLIT INTO SHARDS (include/mlgpu.h: mlgpu_bank_process_mixdown_shard / mlgpu_mixdown_finish): a shard
+ * of Vs voices (a multiple of 64^L, L >= 1 the largest such) hands over its Vs / 64^L level-L sums, the host adds up all shards'
+ * rows 64 at a time left to right until one is left. mlorc_mixdown_shard_rows: one shard's rows, [rows][64T], from sig [Vs][64T];
+ * mlorc_mixdown_rows: the finish over n_rows rows. shards x (V / shards) voices must give mlorc_mixdown's result for V voices
+ * bit for bit (tests/test_oracle_golden.py::test_mixdown_shards_equal_one_bank). */
+size_t mlorc_mixdown_shard_rows(size_t Vs)
+{
+  if (Vs == 0 || Vs % 64) return 0;
+  size_t rows = Vs / 64;
+  while (rows % 64 == 0) rows /= 64;
+  return rows;
+}
+int mlorc_mixdown_shard(const float* sig, size_t Vs, size_t T, const float* gains, float* rows_out)
+{
+  const size_t S = T * VEC, nOutRows = mlorc_mixdown_shard_rows(Vs);
+  if (nOutRows == 0) return MLGPU_ERR_INVALID;
+  const size_t span = Vs / nOutRows; /* voices under one handed-over row: 64^L */
+  for (size_t r = 0; r < nOutRows; ++r)
+  {
+    const int st = mlorc_mixdown(sig + r * span * S, span, T, gains ? gains + r * span : 0, rows_out + r * S);
+    if (st != MLGPU_OK) return st;
+  }
+  return MLGPU_OK;
+}
+int mlorc_mixdown_rows(const float* rows, size_t n_rows, size_t T, float* out)
+{
+  const size_t S = T * VEC;
+  if (n_rows == 0) return MLGPU_ERR_INVALID;
+  float* col = (float*)malloc(sizeof(float) * n_rows);
+  if (!col) return MLGPU_ERR_OOM;
+  for (size_t s = 0; s < S; ++s)
+  {
+    for (size_t r = 0; r < n_rows; ++r) col[r] = rows[r * S + s];
+    size_t n = n_rows;
+    while (n > 1)
+    {
+      const size_t nOut = (n + 63) / 64;
+      for (size_t r = 0; r < nOut; ++r)
+      {
+        const size_t first = r * 64, m = (n - first < 64) ? n - first : 64;
+        float acc = col[first];
+        for (size_t g = 1; g < m; ++g) acc = acc + col[first + g];
+        col[r] = acc;
+      }
+      n = nOut;
+    }
+    out[s] = col[0];
+  }
+  free(col);
+  return MLGPU_OK;
+}
+
 /* ------------------------------------------------------------------------- */
 /* delay lines, MLDSPFilters.h:799-1106                                       */
 /*

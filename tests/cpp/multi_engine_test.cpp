@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <set>
 #include <string>
 #include <thread>
@@ -158,6 +159,74 @@ int main(int argc, char** argv)
     for (size_t v = s0.first; v < s0.second; ++v) same = same && sameVoice(whole, V, v, a, s0.second - s0.first, v - s0.first, 2 * T);
     for (size_t v = s1.first; v < s1.second; ++v) same = same && sameVoice(whole, V, v, b, s1.second - s1.first, v - s1.first, 2 * T);
     REQUIRE(same);
+  }
+
+  // The real-time block across a group (GroupMixdown): all voices of a sharded bank summed to one channel, each member's voices summed
+  // inside its voice kernel up to the hand-over level of the mixdown tree, the tree finished on the host - the bits ONE engine gives
+  // for all the voices. Groups of 2 and 8 members (on a one-GPU box: engines of that GPU, an explicit device list with repeats), two
+  // blocks with carried state; voices = 8 x 4096 (every member of the 8-group hands over one level-2 row, of the 2-group four).
+  {
+    const size_t Vm = 32768, Tm = 2;
+    auto setup = [&](Bank3& bank, size_t lo, size_t n) {
+      bank.clear();
+      for (size_t i = 0; i < n; ++i)
+      {
+        const double v = (double)(lo + i);
+        const float freq = (float)(55.0 * std::pow(2.0, 5.0 * v / (double)Vm) / 48000.0);
+        bank.coeffs<1>(i, Bandpass::makeCoeffs(std::fmin(0.45f, 4.f * freq), 0.5f));
+        bank.coeffs<2>(i, std::array<float, 1>{0.25f});
+        bank.input(i, freq);
+      }
+    };
+    std::vector<float> one(2 * 64 * Tm);
+    {
+      Bank3 bank(e0, Vm);
+      setup(bank, 0, Vm);
+      e0.check(mlgpu_mixdown_reserve(e0.handle(), Vm, Tm));
+      DeviceSignal mix(e0, 1, Tm, MLGPU_LAYOUT_QUAD);
+      for (int block = 0; block < 2; ++block)
+      {
+        bank.mixdown(Tm, mix.data());
+        e0.check(mlgpu_download(e0.handle(), one.data() + (size_t)block * 64 * Tm, mix.data(), sizeof(float) * 64 * Tm));
+      }
+    }
+    for (int members : {2, 8})
+    {
+      std::vector<int> devices;
+      for (int m = 0; m < members; ++m) devices.push_back(m % have);
+      DeviceGroup group(devices);
+      REQUIRE(group.size() == members);
+      GroupMixdown gm(group, Vm, Tm);
+      REQUIRE(gm.voicesPerMember() == Vm / (size_t)members);
+      REQUIRE(gm.rowsPerMember() == (members == 8 ? 1u : 4u));
+      std::vector<std::unique_ptr<Bank3>> banks((size_t)members);
+      group.forEach(Vm, [&](int g, Engine& e, size_t lo, size_t hi) {
+        banks[(size_t)g].reset(new Bank3(e, hi - lo));
+        setup(*banks[(size_t)g], lo, hi - lo);
+      });
+      std::vector<float> got(2 * 64 * Tm);
+      for (int block = 0; block < 2; ++block)
+        gm.process(Tm, [&](int g, Engine&, size_t, size_t, float* dRows) { banks[(size_t)g]->mixdownShard(Tm, dRows); }, got.data() + (size_t)block * 64 * Tm);
+      const bool same = memcmp(got.data(), one.data(), sizeof(float) * got.size()) == 0;
+      REQUIRE(same);
+      float peak = 0.f;
+      for (float x : got) peak = std::fmax(peak, std::fabs(x));
+      REQUIRE(peak > 1e-3f);
+      group.forEach(Vm, [&](int g, Engine&, size_t, size_t) { banks[(size_t)g].reset(); });   // (a bank goes before its engine)
+      printf("GroupMixdown, %d members x %zu voices: the channel of all %zu voices == one engine's, bit for bit (%zu samples)\n", members, Vm / (size_t)members, Vm, got.size());
+    }
+    // shares that are not whole first-stage groups are refused at setup
+    bool threw = false;
+    try
+    {
+      DeviceGroup two(std::vector<int>{0, 0});
+      GroupMixdown bad(two, 2 * 100, 1);
+    }
+    catch (const Error& e)
+    {
+      threw = (e.status == MLGPU_ERR_INVALID);
+    }
+    REQUIRE(threw);
   }
 
   if (failures == 0) printf("All tests passed\n");

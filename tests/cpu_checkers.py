@@ -363,6 +363,28 @@ class Oracle(_Checker):
         assert fnc(_ptr(sig, c_f32p), V, S // 64, _ptr(g, c_f32p), _ptr(out, c_f32p)) == 0
         return out
 
+    def mixdown_shard(self, sig, gains=None):
+        """One shard's hand-over rows [rows][64T] of the mixdown tree (mlgpu_bank_process_mixdown_shard): sig [Vs][64T], Vs % 64 == 0."""
+        self.lib.mlorc_mixdown_shard_rows.restype = ctypes.c_size_t
+        self.lib.mlorc_mixdown_shard_rows.argtypes = [ctypes.c_size_t]
+        fnc = self.lib.mlorc_mixdown_shard
+        fnc.argtypes = [c_f32p, ctypes.c_size_t, ctypes.c_size_t, c_f32p, c_f32p]
+        sig = np.ascontiguousarray(sig, np.float32)
+        V, S = sig.shape
+        g = None if gains is None else np.ascontiguousarray(gains, np.float32)
+        rows = np.empty((self.lib.mlorc_mixdown_shard_rows(V), S), np.float32)
+        assert fnc(_ptr(sig, c_f32p), V, S // 64, _ptr(g, c_f32p), _ptr(rows, c_f32p)) == 0
+        return rows
+
+    def mixdown_rows(self, rows):
+        """The host's finish of the tree over all shards' rows [n][64T] (mlgpu_mixdown_finish)."""
+        fnc = self.lib.mlorc_mixdown_rows
+        fnc.argtypes = [c_f32p, ctypes.c_size_t, ctypes.c_size_t, c_f32p]
+        rows = np.ascontiguousarray(rows, np.float32)
+        out = np.empty(rows.shape[1], np.float32)
+        assert fnc(_ptr(rows, c_f32p), rows.shape[0], rows.shape[1] // 64, _ptr(out, c_f32p)) == 0
+        return out
+
     def libm_sinf(self, x):
         """The restated glibc sinf (oracle/ml_oracle.c) on an array."""
         self.lib.mlorc_libm_sinf.restype = ctypes.c_float

@@ -369,7 +369,8 @@ def test_offline_emit_of_round5_generator_forms():
     source, code = g.emit()
     assert "const size_t v_0 = vr_0 < a.V ? vr_0 : a.V - 1;" in source and "(vr_0 >> 8)" in source and code[:4] == b"\x7fELF"
     g.close()
-    for V, n_delays, want in ((256, 2, 2), (256, 3, 1), (100, 1, 2), (256, 5, 1)):
+    # (round 6: layout 3 takes the sector trips - MLGPU_RING_WINDOWS 3 in the source, layout 4 of the API - for three rings and more)
+    for V, n_delays, want in ((256, 2, 2), (256, 3, 3), (100, 1, 2), (256, 5, 3)):
         g = ml.Graph(ml.OfflineEngine(), V, delay_windows="best")
         g.add("x", "input")
         src = "x"

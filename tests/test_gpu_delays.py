@@ -23,7 +23,7 @@ def eng():
 
 
 # mlgpu_graph_set_delay_layout 0 / 1 / 2 (layout 2: transposed 64-byte pieces on a wave-uniform clock)
-WINDOWS = [pytest.param(False, id="rows"), pytest.param(True, id="windows"), pytest.param(2, id="transposed")]
+WINDOWS = [pytest.param(False, id="rows"), pytest.param(True, id="windows"), pytest.param(2, id="transposed"), pytest.param(4, id="sectors")]
 
 
 def _voices(V, windows):
@@ -238,7 +238,8 @@ def test_delay_rules(eng):
         g.compile()
     assert ei.value.status == ml.Status.ERR_UNSUPPORTED
     # layout 3 = "per-voice delay times, the best form that applies": decided by compile
-    for V, n_delays, want in ((256, 4, 2), (256, 2, 2), (256, 3, 1), (256, 5, 1), (200, 1, 2)):
+    # (round 6: one or two rings - the transposed windows; more - the sector trips, layout 4)
+    for V, n_delays, want in ((256, 4, 4), (256, 2, 2), (256, 3, 4), (256, 5, 4), (200, 1, 2)):
         g = ml.Graph(eng, V, delay_windows="best")
         assert g.delay_layout == 3
         a = g.add("a", "input")
@@ -283,7 +284,7 @@ def test_transposed_rings_every_kind_of_lane(eng, oracle, unequal_w):
     x[:, 640:] = 0
     co = oracle.make_coeffs("onepole", 0.3)
     outs = {}
-    for layout in (0, 2):
+    for layout in (0, 2, 4):
         g = ml.Graph(eng, V, desc, ["damp"], delay_windows=layout)
         g.set_coeffs("damp", [np.full(V, c, np.float32) for c in co])
         st = new_stream_state(oracle, desc, V)
@@ -307,6 +308,7 @@ def test_transposed_rings_every_kind_of_lane(eng, oracle, unequal_w):
             assert (g.get_state("line", i) == st["line"][i]).all(), (layout, i)
         g.close()
     assert_bits_equal(outs[2], outs[0], True, "layout 2 vs layout 0")
+    assert_bits_equal(outs[4], outs[0], True, "layout 4 vs layout 0")
     assert np.abs(outs[0]).max() > 0.01
 
 

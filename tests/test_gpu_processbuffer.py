@@ -263,6 +263,76 @@ def test_bank_process_mixdown_same_bits(eng, oracle, V, T, chain, signal):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("V,shards", [(8192, 2), (8192, 8), (64 * 64 * 6, 3), (262144, 2), (64 * 72, 3)])
+def test_sharded_mixdown_gives_one_bank_bits(eng, oracle, V, shards):
+    """A voice bank split over several engines, the real-time block across the GPUs of a node: every shard's
+    mlgpu_bank_process_mixdown_shard (its voices summed inside its voice kernel up to the hand-over level of the tree) and the host's
+    mlgpu_mixdown_finish over all shards' rows give the bits ONE engine's mlgpu_bank_process_mixdown gives for all the voices - here
+    with the shards as banks of one engine (tests/cpp/multi_engine_test.cpp: as engines of a DeviceGroup); two launches, state carried.
+    The same for a signal in memory (mlgpu_mixdown_shard) and for a graph output (mlgpu_graph_set_output_mixdown(.., 2))."""
+    import madronalib_amd as ml
+    T, chain = 2, [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]
+    per = V // shards
+    rng = np.random.default_rng(V + shards)
+    freq = (55.0 * 2.0 ** (5.0 * rng.random(V)) / 48000.0).astype(np.float32)
+    few = np.stack([oracle.make_coeffs("bandpass", 0.02 + 0.3 * j / 16, 0.6) for j in range(16)], 1)
+
+    def make(lo, n):
+        b = eng.bank(chain, n)
+        b.clear()
+        b.set_coeffs(1, [np.ascontiguousarray(few[i][np.arange(lo, lo + n) % 16]) for i in range(3)])
+        b.set_coeff(2, 0, 0.25)
+        b.set_input_const(freq[lo:lo + n])
+        return b
+    eng.mixdown_reserve(V, T)
+    whole = make(0, V)
+    parts = [make(k * per, per) for k in range(shards)]
+    nrows = ml.mixdown_shard_rows(per)
+    d_one = eng.alloc(4 * 64 * T)
+    d_rows = [eng.alloc(4 * nrows * 64 * T) for _ in range(shards)]
+    for launch in range(2):
+        whole.process_mixdown(T, d_one)
+        for b, d in zip(parts, d_rows):
+            b.process_mixdown_shard(T, d)
+        rows = np.concatenate([d.download(np.float32, nrows * 64 * T).reshape(nrows, 64 * T) for d in d_rows], 0)
+        assert_bits_equal(ml.mixdown_finish(rows), d_one.download(np.float32, 64 * T), True, f"{shards} shards of {per} voices, launch {launch}")
+    # a signal in memory
+    sig = lcg_noise(np.arange(V, dtype=np.uint32) + 5, 64 * T)
+    gains = rng.uniform(-1, 1, V).astype(np.float32)
+    d_sig, d_g = eng.to_device(sig), eng.to_device(gains)
+    eng.mixdown(d_sig, Layout.VOICE_MAJOR, V, T, d_one, d_g)
+    rows = []
+    for k in range(shards):
+        d_part, d_gp = eng.to_device(np.ascontiguousarray(sig[k * per:(k + 1) * per])), eng.to_device(np.ascontiguousarray(gains[k * per:(k + 1) * per]))
+        eng.mixdown_shard(d_part, Layout.VOICE_MAJOR, per, T, d_rows[k], d_gp)
+        rows.append(d_rows[k].download(np.float32, nrows * 64 * T).reshape(nrows, 64 * T))
+    rows = np.concatenate(rows, 0)
+    assert_bits_equal(ml.mixdown_finish(rows), d_one.download(np.float32, 64 * T), True, "mixdown_shard of a signal")
+    assert_bits_equal(ml.mixdown_finish(rows), oracle.mixdown(sig, gains), True, "... and the oracle's unsplit tree")
+    # a graph output in shard form
+    if V <= 8192:
+        desc = [dict(name="x", type="input"), dict(name="g", type="const", value=0.5), dict(name="y", type="op", kind=Op.MULTIPLY, inputs=["x", "g"])]
+        gw = ml.Graph(eng, V, desc, ["y"], compile_now=False)
+        gw.set_output_mixdown(0)
+        gw.compile()
+        gw.reserve_mixdown(T)
+        gw.process(T, [d_sig], [d_one], Layout.VOICE_MAJOR)
+        rows = []
+        for k in range(shards):
+            gp = ml.Graph(eng, per, desc, ["y"], compile_now=False)
+            gp.set_output_mixdown(0, "shard")
+            gp.compile()
+            gp.reserve_mixdown(T)
+            gp.process(T, [eng.to_device(np.ascontiguousarray(sig[k * per:(k + 1) * per]))], [d_rows[k]], Layout.VOICE_MAJOR)
+            rows.append(d_rows[k].download(np.float32, nrows * 64 * T).reshape(nrows, 64 * T))
+            gp.close()
+        assert_bits_equal(ml.mixdown_finish(np.concatenate(rows, 0)), d_one.download(np.float32, 64 * T), True, "graph outputs in shard form")
+        gw.close()
+    with pytest.raises(ml.MlgpuError):
+        eng.bank(chain, 100).process_mixdown_shard(T, d_rows[0])     # not whole first-stage groups: no exact hand-over
+
+
+@pytest.mark.gpu
 def test_bank_process_mixdown_refusals(eng):
     import madronalib_amd as ml
     d_out = eng.alloc(4 * 64)

@@ -262,3 +262,37 @@ def test_synth16full_golden(oracle):
     (got,) = evaluate(oracle, desc, outs, V, T, {"gate": g["gate"]}, params, coeffs, states)
     assert (got.view(np.uint32) == g["out"].view(np.uint32)).all()
     assert np.abs(g["out"]).max() > 0.5
+
+
+@pytest.mark.parametrize("V,shards", [(128, 2), (4096, 2), (8192, 2), (8192, 8), (64 * 64 * 6, 3), (64 * 72, 3), (64 * 64 * 64 // 2, 2)])
+def test_mixdown_shards_equal_one_bank(oracle, V, shards):
+    """A voice bank split over several engines (mlgpu_bank_process_mixdown_shard + mlgpu_mixdown_finish): every shard hands over its
+    rows of the mixdown tree at the highest level its voice count is whole at, the host finishes the same tree - the oracle's
+    restatement of both halves gives the bits of the unsplit mixdown, and the library's host function (no device needed) the same."""
+    import madronalib_amd as ml
+    from inputs import lcg_noise
+    T = 1
+    sig = lcg_noise(np.arange(V, dtype=np.uint32) + 17, 64 * T)
+    want = oracle.mixdown(sig)
+    per = V // shards
+    assert ml.mixdown_shard_level(per) >= 1 and ml.mixdown_shard_rows(per) == per // 64 ** ml.mixdown_shard_level(per)
+    rows = np.concatenate([oracle.mixdown_shard(sig[k * per:(k + 1) * per]) for k in range(shards)], 0)
+    assert rows.shape[0] == shards * ml.mixdown_shard_rows(per)
+    got = oracle.mixdown_rows(rows)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    lib = ml.mixdown_finish(rows)
+    assert (lib.view(np.uint32) == want.view(np.uint32)).all()
+    assert ml.mixdown_shard_level(100) == 0 and ml.mixdown_shard_rows(100) == 0
+
+
+def test_mixdown_finish_many_rows_and_flush(oracle):
+    """mlgpu_mixdown_finish over more than 64 and more than 4096 rows (the passes through its scratch), and in flush mode."""
+    import madronalib_amd as ml
+    rng = np.random.default_rng(4)
+    for n in (1, 63, 64, 65, 4096, 4097, 5000):
+        rows = rng.standard_normal((n, 64)).astype(np.float32)
+        got = ml.mixdown_finish(rows)
+        assert (got.view(np.uint32) == oracle.mixdown_rows(rows).view(np.uint32)).all(), n
+    tiny = np.full((3, 64), 1e-39, np.float32)          # denormals: kept in the default mode, +0 in flush mode
+    assert (ml.mixdown_finish(tiny) == np.float32(3e-39)).all()
+    assert (ml.mixdown_finish(tiny, flush_denormals=True).view(np.uint32) == 0).all()

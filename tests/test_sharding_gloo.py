@@ -99,3 +99,55 @@ def test_cfg5_parameters_do_not_depend_on_the_sharding():
             assert (c[k].view(np.uint32) == full_c[k][:, lo:hi].view(np.uint32)).all(), k
         assert (s == full_s[lo:hi]).all()
         assert (cfg5_gate_quad(lo, hi, 2) == full_g[:, lo:hi, :]).all()
+
+
+def _mix_worker(rank, world, port, total, T, blocks, ret):
+    """One rank of a sharded bank whose host wants ONE channel: its shard's voices (the oracle standing in for the voice kernel) -> the
+    rows of the mixdown tree at the shard's hand-over level (the oracle's restatement of mlgpu_bank_process_mixdown_shard) -> rank 0
+    through RowExchange -> mlgpu_mixdown_finish (the library's host function: no device)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import madronalib_amd as ml
+    from cpu_checkers import Oracle
+    from madronalib_amd.constants import Proc
+    from madronalib_amd.rendezvous import GlooRendezvous
+    from madronalib_amd.sharding import RowExchange
+    orc = Oracle()
+    lo, hi = partition(total, world, rank)
+    freq, co = cfg3_voice_params(lo, hi, total, lambda om, k: orc.make_coeffs("bandpass", om, k))
+    procs = [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]
+    coeffs = np.ascontiguousarray(np.concatenate([co, np.full((1, hi - lo), 0.25, np.float32)], 0))
+    st = orc.chain_clear(procs, hi - lo)
+    rdv = GlooRendezvous(rank, world)      # (the process group is up already: it only wraps it)
+    ex = RowExchange(rdv, rank, world, ml.mixdown_shard_rows(hi - lo), T)
+    mixes = []
+    for b in range(blocks):
+        voices = orc.chain_process(procs, T, coeffs, st, None, freq)
+        ex.put(b, orc.mixdown_shard(voices))
+        if rank == 0:
+            mixes.append(ml.mixdown_finish(ex.collect(b, T)))
+    rdv.barrier()
+    ex.close()
+    ret[rank] = np.concatenate(mixes) if rank == 0 else None
+    dist.destroy_process_group()
+
+
+def test_two_rank_voice_sum_equals_one_bank(oracle):
+    """The real-time block across the GPUs of a node ("per-GPU reduction then host add"), here with world_size-2 gloo
+    processes on CPU: 2 x 4096 voices summed to one channel through per-shard tree rows + the host's finish give the bits of the
+    unsplit 8192-voice mixdown, four blocks in a row through both slots of the exchange."""
+    import torch.multiprocessing as mp
+    from madronalib_amd.constants import Proc
+    total, T, world, blocks = 8192, 1, 2, 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mix_worker, args=(world, _free_port(), total, T, blocks, ret), nprocs=world, join=True)
+    freq, co = cfg3_voice_params(0, total, total, lambda om, k: oracle.make_coeffs("bandpass", om, k))
+    procs = [Proc.SAW_GEN, Proc.BANDPASS, Proc.GAIN]
+    coeffs = np.ascontiguousarray(np.concatenate([co, np.full((1, total), 0.25, np.float32)], 0))
+    st = oracle.chain_clear(procs, total)
+    want = np.concatenate([oracle.mixdown(oracle.chain_process(procs, T, coeffs, st, None, freq)) for _ in range(blocks)])
+    assert (ret[0].view(np.uint32) == want.view(np.uint32)).all()
+    assert np.abs(want).max() > 0

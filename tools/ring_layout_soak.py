@@ -14,6 +14,10 @@ import madronalib_amd as ml                      # noqa: E402
 from madronalib_amd.constants import Proc, Layout   # noqa: E402
 from inputs import lcg_noise, stepped            # noqa: E402
 
+# the layout under test against layout 0 (MLGPU_SOAK_LAYOUT=4: the sector trips of round 6)
+TEST_LAYOUT = int(os.environ.get("MLGPU_SOAK_LAYOUT", "2"))
+LAYOUTS = (0, TEST_LAYOUT)
+
 
 def delays(rng, kind, V, S, dmax):
     mode = int(rng.integers(0, 5))
@@ -49,7 +53,7 @@ def run(cases, seed, eng=None):
         mode, d = delays(rng, kind, V, S, dmax)
         wmode = int(rng.integers(0, 3))
         outs, states = {}, {}
-        for layout in (0, 2):
+        for layout in LAYOUTS:
             g = ml.Graph(eng, V, delay_windows=layout)
             g.add("x", "input")
             g.add("dt", "input")
@@ -78,15 +82,15 @@ def run(cases, seed, eng=None):
                     break
             states[layout] = np.stack(st)
             g.close()
-        a, b = outs[0].view(np.uint32), outs[2].view(np.uint32)
-        nan = np.isnan(outs[0]) & np.isnan(outs[2])
-        diff = int(((a != b) & ~nan).sum()) + int((states[0] != states[2]).sum())
+        a, b = outs[0].view(np.uint32), outs[TEST_LAYOUT].view(np.uint32)
+        nan = np.isnan(outs[0]) & np.isnan(outs[TEST_LAYOUT])
+        diff = int(((a != b) & ~nan).sum()) + int((states[0] != states[TEST_LAYOUT]).sum())
         nonzero += int((outs[0] != 0).sum())
         total += outs[0].size
         if diff:
             bad += 1
             print(f"case {case}: kind {int(kind)} V {V} T {T} launches {launches} max delay {dmax} delay mode {mode} write-index mode {wmode}: {diff} words differ")
-    print(f"{cases} cases (seed {seed}), {total} output samples, {nonzero / max(1, total):.3f} of them nonzero: {bad} cases with a difference between ring layout 2 and layout 0")
+    print(f"{cases} cases (seed {seed}), {total} output samples, {nonzero / max(1, total):.3f} of them nonzero: {bad} cases with a difference between ring layout {TEST_LAYOUT} and layout 0")
     return bad
 
 
