@@ -59,7 +59,7 @@ WORKLOADS = {
     "cfg5mix": (262144, 16, 16),  # config 5's voices summed to one channel in the voice kernel (mlgpu_graph_set_output_mixdown)
     "strings": (262144, 16, 8),  # a plucked-string model per voice: noise burst -> FractionalDelay (per-voice length) -> OnePole -> feedback
     "mixgroups": (262144, 8, 16),  # the per-instrument voice sum alone, 16 voices per instrument
-    "allpass4": (16384, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples)
+    "allpass4": (131072, 16, 8),  # 4 x Allpass<PitchbendableDelay> in series per voice (8 rings of 4096 samples), per-voice delay times
     # the reference's own examples/audio-and-midi/reverb.cpp (the Aaltoverb algorithm: 10 x Allpass<PitchbendableDelay> + 2 PitchbendableDelay = 24
     # rings, two kept DSPVectors), compiled UNCHANGED against the shim (tests/cpp/libexamples_gpu.so), one stereo reverb per voice
     "reverb": (65536, 16, 8),
@@ -410,7 +410,9 @@ def setup_workload(eng, name, V, T, lo, total):
         alg = 8.0 * n + 4 * (2 * 8.0 + 8.0) * n
         if not os.environ.get("MLGPU_UNIFORM_DELAY"):
             META["coalesced_read_bytes"] = (4.0 + 4 * 4.0) * n   # x and four kept DSPVectors
-        return launch, alg, "mlgpu_graph_kernel", "4 x Allpass<PitchbendableDelay> in series, per-voice delay times 400..3400 samples, 16384 voices", (g, nb)
+        if not os.environ.get("MLGPU_UNIFORM_DELAY") and g.delay_layout == 4:
+            META["coalesced_read_bytes"] = (4.0 + 4 * 4.0) * n
+        return launch, alg, "mlgpu_graph_kernel", f"4 x Allpass<PitchbendableDelay> in series (8 rings per voice), per-voice delay times 400..3400 samples, {V} voices, ring layout {g.delay_layout}", (g, nb)
     if name == "reverb":
         import ctypes
         so = os.path.join(ROOT, "tests", "cpp", "libexamples_gpu.so")
@@ -453,8 +455,11 @@ def setup_workload(eng, name, V, T, lo, total):
                 raise ml.MlgpuError(st, "(mlgpu_graph_process of the captured reverb)")
             k[0] += 1
         # per reverb-sample: 2 inputs + 2 outputs (16 B), 24 delay rings written and read (8 B each: every PitchbendableDelay feeds both of
-        # its IntegerDelays and reads both, MLDSPFilters.h:1050-1109), the two kept DSPVectors read and written (16 B)
-        alg = (16.0 + 24 * 8.0 + 16.0) * n
+        # its FractionalDelays and reads both, MLDSPFilters.h:1050-1109), and 12 kept DSPVectors read and written (8 B each): the example's
+        # two (mvFeedbackL / R) and the one every Allpass keeps of its delay's output (vy1, :1110-1160) - state the reference holds in
+        # objects and this engine between DSPVectors in HBM. (PMC: 21.1 GB per launch of 65 536 voices x 16 DSPVectors against 20.4 GB
+        # algorithmic = 1.03 x, profiles/r06_reverb_*.)
+        alg = (16.0 + 24 * 8.0 + 12 * 8.0) * n
         return launch, alg, "mlgpu_graph_kernel", (f"the reference's examples/audio-and-midi/reverb.cpp unchanged through the shim: {V} independent stereo reverbs "
                                                     "(10 allpasses + 2 delays = 24 rings per voice, one delay time for all voices), noise in"), (_Prog(), nb, d_in, outs_d)
     raise SystemExit(f"unknown workload {name}")
@@ -477,7 +482,7 @@ N_SIMD = 256 * 4
 ISSUE_SLOTS = {"plain_paired": 0.5, "plain_alone": 1.0, "slow": 1.0, "f64": 1.0, "trans": 2.0}
 BUSY_MEASURED_CEILING = 0.90
 
-# with two wavefronts per SIMD instead of four the same instructions issue slower (profiles/r03_bankbench.txt: 1.28 / 2.09 ns)
+# with two wavefronts per SIMD instead of four the same instructions issue slower (profiles/archive/r03_bankbench.txt: 1.28 / 2.09 ns)
 ISSUE_NS_2_WAVES = {"plain": 1.28, "slow": 2.09}
 
 
@@ -909,7 +914,7 @@ def extra_legs(eng):
     # the widened rows, >= 5 timed steps each, in the forms a host should use: the instrument bank as one voice kernel (ms per
     # 16-vector block), plucked strings in ring layout 2, EventsToSignals (all 8 rows), the Downsampler, the reference's reverb example
     if not os.environ.get("MLGPU_BENCH_NO_WIDENED"):
-        for name, env in (("synth", None), ("strings", {"MLGPU_DELAY_WINDOWS": "2"}), ("events", None), ("resample", None), ("reverb", None)):
+        for name, env in (("synth", None), ("strings", {"MLGPU_DELAY_WINDOWS": "3"}), ("allpass4", {"MLGPU_DELAY_WINDOWS": "3"}), ("events", None), ("resample", None), ("reverb", None)):
             r = guarded(name, lambda name=name, env=env: timed_case(eng, name, env=env))
             if "error" not in r:
                 flat.update({f"{name}_frac": r["frac"], f"{name}_kernel_ms": r["kernel_ms"], f"{name}_voice_samples_per_s": r["voice_samples_per_s"]})
@@ -1019,7 +1024,7 @@ def parity_crcs(eng, Vs=512):
 # carry a claim - every BASELINE config, the north_star target, the parity CRCs, the widened rows - before the diagnostics.
 ROOFLINE_KEY_ORDER = ("bound", "achieved", "peak", "unit", "frac", "traffic",
                       "cfg4_frac", "cfg5_frac", "cfg5full_frac", "rt_misses", "rt_block_p99_us", "rt_kernel_frac", "crc_all_match",
-                      "synth_block_ms", "strings_frac", "events_frac", "resample_frac", "reverb_frac", "kernel_ms_p50",
+                      "synth_block_ms", "strings_frac", "allpass4_frac", "events_frac", "resample_frac", "reverb_frac", "kernel_ms_p50",
                       "kernel_ms_p10", "kernel_ms_p90", "kernel_ms", "kernel", "cfg2_frac", "cfg2_on_die_frac",
                       "cfg2_crc_match", "cfg3_crc_match", "cfg4_crc_match", "cfg5_crc_match", "cfg5full_crc_match",
                       "synth_crc_match", "strings_crc_match", "events_crc_match", "resample_crc_match", "reverb_crc_match",
@@ -1082,7 +1087,7 @@ def run_rank(args, rank, local_rank, world, rdv):
     if args.workload == "rt":
         return run_rt(args, eng, info, V, T, L, rank, world, rdv)
     # (ranks that are THREADS of one process take turns here: the set-up is Python and numpy under one interpreter lock, and eight
-    # threads fighting for it took 7-8.5 s each in round 3 - profiles/r03_multi_gpu_launch_paths.txt - where one after the other
+    # threads fighting for it took 7-8.5 s each in round 3 - profiles/archive/r03_multi_gpu_launch_paths.txt - where one after the other
     # they take what a process takes)
     with _SETUP_LOCK:
         launch, alg_bytes, kernel_name, desc, _keep = setup_workload(eng, args.workload, V, T, lo, total)
@@ -1207,7 +1212,7 @@ def run_rank(args, rank, local_rank, world, rdv):
                         "source": "SQ_INSTS_VALU per launch (profiles/pmc_workloads.json) x 64 lanes / " + span_what,
                         "note": "an instruction count, not a utilisation: packed FP32, compares, selects and conversions occupy the SIMD "
                                 "twice as long as a plain add / mul / fma (DESIGN 3.11); config 4 at 'frac 0.33' has its VALU port 85 % busy "
-                                "(profiles/r03_cfg4_account.md)"}
+                                "(profiles/archive/r03_cfg4_account.md)"}
         busy = valu_busy(pmc, span_ms, waves_per_simd=max(1.0, V / 64.0 / N_SIMD), cycles=(pmc["GRBM_GUI_ACTIVE"] / 8.0 if pmc.get("GRBM_GUI_ACTIVE") else None))
         if busy:
             roof["valu"].update(busy)
@@ -1562,7 +1567,7 @@ def main():
                     help="mlgpu_engine_set_strict_svf: SVF memories updated with two instructions instead of one fused (generated kernels)")
     ap.add_argument("--sustained", metavar="FILE", default=None,
                     help="after the timed region, run the same steps for --sustained-seconds more and write per-second rates and the "
-                         "distribution of step and launch times to FILE (profiles/r03_cfg3_sustained.json)")
+                         "distribution of step and launch times to FILE (profiles/archive/r03_cfg3_sustained.json)")
     ap.add_argument("--sustained-seconds", type=float, default=30.0)
     ap.add_argument("--print-case", action="store_true", help="print the key of this case in profiles/pmc_workloads.json and exit")
     args = ap.parse_args()

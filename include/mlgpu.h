@@ -283,7 +283,7 @@ int mlgpu_engine_set_cascade_lanes(mlgpu_engine* e, int lanes);
  * on != 0 spends the second instruction, and such kernels equal the reference bit for bit in that corner too
  * (tests/test_gpu_parity.py::test_strict_svf_hostile_input). Kernels of a strict engine are generated with hiprtc when the
  * bank or graph is made (cached on disk); existing banks and graphs keep the arithmetic they were made with. Cost:
- * profiles/r03_strict_svf.txt. */
+ * profiles/archive/r03_strict_svf.txt. */
 int mlgpu_engine_set_strict_svf(mlgpu_engine* e, int on);
 int mlgpu_engine_get_strict_svf(mlgpu_engine* e);
 int mlgpu_engine_get_cascade_lanes(mlgpu_engine* e);
@@ -566,10 +566,20 @@ int mlgpu_graph_set_max_delay(mlgpu_graph* g, int proc_node, float max_delay_in_
  * against 1.13 x for layout 1) at 0.72-0.74 of the HBM peak against 0.56-0.59 (profiles/r05_ring_layouts.txt) - the one to use
  * for per-voice delay times where it applies: at most 4 rings per graph (40 KiB of LDS per ring and workgroup), and a voice count
  * that is a multiple of 64 if the graph sums voices in groups or reads event rows inside its kernel (other graphs: any count - the
- * spare lanes of the bank's last wavefront run its last voice again). 3: "voices have their own delay times, take the best form": layout 2 where it applies (and the graph
- * does not have exactly three rings, where layout 1 measured faster), else layout 1, decided by graph_compile. With one delay time for all voices layout 2 is as fast as the default rows (0.85 / 0.85 of the HBM
- * peak on the strings bank; layout 1: 0.72). Same results in every layout for delay times within the node's maximum
- * (graph_set_max_delay). mlgpu_graph_delay_layout: the layout in effect (0 / 1 / 2; 3 before compile), negative: a status. */
+ * spare lanes of the bank's last wavefront run its last voice again). 4 (round 6, "sector trips", for graphs with MANY rings): layout
+ * 1's memory, the sample loop in trips of 8 samples on the write clock - a ring's eight written samples leave as ONE 32-byte sector,
+ * its eight reads come from two neighbouring sectors (the lower one held in LDS since the trip before, the upper one asked for a
+ * whole trip ahead) through a barrel shifter, every ring's loads of a trip issued together; a voice's last 16 samples stay in LDS
+ * for delay times under 16. A PitchbendableDelay keeps ONE ring (the reference feeds both of its FractionalDelays the same input,
+ * source/DSP/MLDSPFilters.h:1096-1105) and makes one read for both while their delay times agree. 8 KiB of LDS per ring + 16 KiB per
+ * delay node and workgroup; one wavefront per SIMD (its windows are registers). 4 x Allpass<PitchbendableDelay> with per-voice
+ * delay times: 0.65-0.67 of the HBM peak at 0.85 x the algorithmic traffic against 0.26 at 1.9 x in layout 1
+ * (profiles/r06_ring_layouts.txt). Not for a delay line inside a rate region. 3: "voices have their own delay times, take the best
+ * form": layout 2 for one or two rings, layout 4 for more (where its LDS fits and no delay line sits in a rate region), else layout
+ * 1, else - more rings than LDS - the default rows; decided by graph_compile. With one delay time for all voices layout 2 is as
+ * fast as the default rows (0.85 / 0.85 of the HBM peak on the strings bank; layout 1: 0.72). Same results in every layout for
+ * delay times within the node's maximum (graph_set_max_delay). mlgpu_graph_delay_layout: the layout in effect (0 / 1 / 2 / 4; 3
+ * before compile), negative: a status. */
 int mlgpu_graph_set_delay_layout(mlgpu_graph* g, int windowed);
 int mlgpu_graph_delay_layout(mlgpu_graph* g);
 /* One-vector feedback: a DSPVector the reference keeps from one process call to the next (Allpass::vy1

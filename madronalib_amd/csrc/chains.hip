@@ -41,7 +41,7 @@ hipError_t launchChainMix(const ChainArgs& a, hipStream_t stream, int /*cuCount*
 // How many wavefront lanes share one channel of a head-less SVF cascade (cascade_lanes_kernel). One lane per channel is the
 // cheapest per sample, but a bank needs ~49 000 channels before its wavefronts (two per SIMD at ~190 VGPRs) fill the chip;
 // smaller banks are spread over 2 or 4 lanes per channel (4 or 6 wavefronts per SIMD). Thresholds from
-// profiles/r03_cascade_lanes.txt (8 x Lopass, 32 DSPVectors per launch, us with 4 / 2 / 1 lanes): 4 096 channels 84 / 117 /
+// profiles/archive/r03_cascade_lanes.txt (8 x Lopass, 32 DSPVectors per launch, us with 4 / 2 / 1 lanes): 4 096 channels 84 / 117 /
 // 173, 16 384: 99 / 119 / 174, 32 768: 140 / 134 / 177, 49 152: 203 / 205 / 194, 65 536: 265 / 242 / 224.
 template <int N>
 int cascadeLanesFor(size_t V, uint32_t flags)

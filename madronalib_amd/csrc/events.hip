@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
   // order: every load behind a store waits for that store's acknowledgement (several microseconds while the chip writes rows at
   // its ceiling). The general vector loop below has a dozen such round trips per DSPVector - glide state, slots a quad at a
   // time, records - and a wavefront that carried a note event used to run it for all its vectors, ~40 us each, long after the
-  // others were done (profiles/r03_e2s_latency.txt). So: kBlock vectors at a time, where no lane of the wavefront has a record, the
+  // others were done (profiles/archive/r03_e2s_latency.txt). So: kBlock vectors at a time, where no lane of the wavefront has a record, the
   // bend and the wanted controllers are at rest, take this path - ONE round trip: the glide words and all 64 slots of the drift
   // glide (8 s per glide: always moving) are fetched together, the block is computed in time order in registers (the pitch glide may
   // be moving: it is stepped sample by sample as ever; what each vector does to the drift glide - hold / end / start / continue -

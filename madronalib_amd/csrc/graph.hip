@@ -56,7 +56,7 @@ std::map<std::string, CompiledModule> g_cache;  // key: device id + source
 
 // The options every run-time kernel is compiled with (part of the disk cache's key): the ahead-of-time build's own
 // (csrc/Makefile) apart from its scheduling strategy. MLGPU_JIT_EXTRA_OPTS adds space-separated options for A/B
-// measurements, e.g. "-mllvm -amdgpu-sched-strategy=max-ilp" (profiles/r03_jit_maxilp.txt: what it does to config 5).
+// measurements, e.g. "-mllvm -amdgpu-sched-strategy=max-ilp" (profiles/archive/r03_jit_maxilp.txt: what it does to config 5).
 const std::vector<std::string>& jitOptions()
 {
   static const std::vector<std::string> opts = [] {
@@ -806,8 +806,18 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     s << "  const KernelTables tables{nullptr};\n";
   }
   if (g->transposedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 4 << " * kTStrip];  // [ring][wavefront][40 rows][64]: write window + two read chunks\n";
-  else if (g->sectorRings && g->totalRings) s << "  __shared__ __attribute__((aligned(16))) float ldsRings[" << (size_t)g->totalRings * 4 * 512 << "];  // the held sectors, [ring][wavefront][half][lane][4]\n";
-  else if (g->windowedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 8 * 256 << "];  // write windows, [ring][8][256 lanes]\n";
+  // ring layout 4, per wavefront: every delay node's held sectors (512 floats per ring) and history rows (1024 floats per node)
+  std::vector<size_t> sectorLdsOff(g->nodes.size(), 0);
+  size_t sectorLdsPerWave = 0;
+  if (g->sectorRings)
+    for (size_t i = 0; i < g->nodes.size(); ++i)
+      if (g->nodes[i].type == NODE_PROC && g->nodes[i].ringLen)
+      {
+        sectorLdsOff[i] = sectorLdsPerWave;
+        sectorLdsPerWave += (size_t)mlgpu_proc_rings(g->nodes[i].kind) * 512 + 1024;
+      }
+  if (g->sectorRings && g->totalRings) s << "  __shared__ __attribute__((aligned(16))) float ldsRings[" << 4 * sectorLdsPerWave << "];  // [wavefront][node: held sectors, history rows]\n";
+  else if (!g->transposedRings && g->windowedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 8 * 256 << "];  // write windows, [ring][8][256 lanes]\n";
   // a group sum of 16 voices (one instrument's voices): four quads of the wavefront's 64 voices are parked in LDS and every lane
   // then adds up ONE (instrument, sample) pair in voice order - 2.3 instructions per voice-sample where the lane-shift chain
   // (group_sum_in_order) takes 16 (MLGPU_GRAPH_GROUP_SUM=dpp: that form)
@@ -866,7 +876,8 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         else if (n.ringLen && g->windowedRings)
           s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (v" << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
             << " + (v" << L << " & 255) * 8, " << (n.ringLen - 1)
-            << "u, ldsRings + " << (g->sectorRings ? "(" + std::to_string((size_t)n.ringSlot * 4) + " + (threadIdx.x >> 6)) * 512 + (threadIdx.x & 63) * 4" : std::to_string((size_t)n.ringSlot * 8 * 256) + " + threadIdx.x");
+            << "u, ldsRings + " << (g->sectorRings ? "(threadIdx.x >> 6) * " + std::to_string(sectorLdsPerWave) + " + " + std::to_string(sectorLdsOff[i]) + ", " + std::to_string((size_t)mlgpu_proc_rings(n.kind) * 512) + "u"
+                                                   : std::to_string((size_t)n.ringSlot * 8 * 256) + " + threadIdx.x");
         s << "};\n  p" << i << L << ".load(m" << i << L << ", tables);\n";
       }
       else if (n.type == NODE_INPUT)
@@ -2047,6 +2058,9 @@ extern "C"
     }
     constexpr size_t kLdsBytes = 160 * 1024;
     const size_t ldsLayout2 = (size_t)g->totalRings * 4 * 40 * 64 * sizeof(float), ldsLayout1 = (size_t)g->totalRings * 8 * 256 * sizeof(float);
+    size_t ldsLayout4 = 0;  // per workgroup: 2 KiB per ring and wavefront (the held sector) + 4 KiB per delay node and wavefront (its last 16 samples)
+    for (const Node& n : g->nodes)
+      if (n.type == NODE_PROC && mlgpu_proc_rings(n.kind)) ldsLayout4 += 4 * sizeof(float) * ((size_t)mlgpu_proc_rings(n.kind) * 512 + 1024);
     auto kib = [](size_t b) { return std::to_string((b + 1023) / 1024) + " KiB"; };
     // layout 4 (sector trips) serves delay nodes of the outer graph; one inside a rate region keeps layout 1's per-sample form
     bool ringInRegion = false;
@@ -2057,15 +2071,25 @@ extern "C"
     {
       // "the best form": one or two rings - the transposed windows (0.72-0.74 of the HBM peak on the strings bank); more - the sector
       // trips (no LDS, every ring's loads in the trip's prologue: profiles/r06_ring_layouts.txt); where neither applies, layout 1
-      g->transposedRings = partialOk && g->totalRings <= 2 && ldsLayout2 + ldsOther <= kLdsBytes;
-      g->sectorRings = !g->transposedRings && !ringInRegion && g->totalRings > 0 && ldsLayout1 + ldsOther <= kLdsBytes;  // (8 KiB per ring and workgroup, as layout 1)
+      // (measured, profiles/r06_ring_layouts.txt: one PitchbendableDelay 0.74 of the HBM peak in layout 4 - it keeps one ring and makes
+      // one read for both cores - against 0.58 in layout 2; one / two FractionalDelays 0.63 / 0.60 in layout 2 against 0.50 / 0.40;
+      // three / four 0.42 / 0.35 in layout 4 against 0.33 / 0.32 in layout 2 and 0.34 / 0.20 in layout 1)
+      bool anyPitchbendable = false;
+      for (const Node& n : g->nodes) anyPitchbendable = anyPitchbendable || (n.type == NODE_PROC && n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY);
+      const bool sectorFits = !ringInRegion && g->totalRings > 0 && ldsLayout4 + ldsOther <= kLdsBytes;
+      const bool preferSectors = sectorFits && (anyPitchbendable || g->totalRings > 2);
+      g->transposedRings = !preferSectors && partialOk && g->totalRings <= 4 && ldsLayout2 + ldsOther <= kLdsBytes;
+      g->sectorRings = !g->transposedRings && sectorFits;
       // more rings than any windowed form has LDS for (the reference's reverb example: 24): the default rows
       if (!g->transposedRings && !g->sectorRings && ldsLayout1 + ldsOther > kLdsBytes) g->windowedRings = false;
     }
     if (g->transposedRings && ldsLayout2 + ldsOther > kLdsBytes)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 2 needs 40 KiB of LDS per ring (" + kib(ldsLayout2) + " for " + std::to_string(g->totalRings) +
                                                  " rings) next to " + kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB (layout 1 or 3 for this graph)");
-    if (!g->transposedRings && g->windowedRings && ldsLayout1 + ldsOther > kLdsBytes)
+    if (g->sectorRings && ldsLayout4 + ldsOther > kLdsBytes)
+      return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layout 4 needs 8 KiB of LDS per ring and 16 KiB per delay node (" + kib(ldsLayout4) + " for this graph) next to " +
+                                                 kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB (layout 1 or 3 for this graph)");
+    if (!g->transposedRings && !g->sectorRings && g->windowedRings && ldsLayout1 + ldsOther > kLdsBytes)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: delay layouts 1 and 4 need 8 KiB of LDS per ring (" + kib(ldsLayout1) + " for " + std::to_string(g->totalRings) +
                                                  " rings) next to " + kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB");
     if (ldsOther > kLdsBytes)

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
   // loads of the NEXT trip are issued at the top of a trip and consumed a whole trip (QT * 4 ticks of arithmetic) later.
   // QT = 4 (4 KiB of loads in flight per wave) is the measured optimum on config 4: QT = 8 takes all 256 registers and runs
   // 0.570 ms against 0.477, QT = 16 0.491 (round 2, 131 072 channels x 32 DSPVectors) - the kernel is not waiting for its
-  // loads (round 3's account, profiles/r03_cfg4_account.md: it is bound by VALU issue, and the streams cost it clock).
+  // loads (round 3's account, profiles/archive/r03_cfg4_account.md: it is bound by VALU issue, and the streams cost it clock).
   constexpr int QT = MLGPU_CASCADE_QUADS_PER_TRIP;
   const size_t Q = (S - D) / 4;
   size_t q = 0;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
 // ---------------------------------------------------------------------------------------------
 // cascade_lanes_kernel — the stage-skewed cascade of round 3: LPC = 1, 2 or 4 wavefront lanes per channel.
 //
-// What bounds this kernel (profiles/r03_cfg4_account.md): VALU issue. Its cycle count (GRBM_GUI_ACTIVE) is the same with
+// What bounds this kernel (profiles/archive/r03_cfg4_account.md): VALU issue. Its cycle count (GRBM_GUI_ACTIVE) is the same with
 // the HBM streams and with every row collapsed onto one cache-resident row; what the streams cost is clock (the chip holds
 // ~2.1 GHz on the arithmetic alone and ~1.8 GHz with 4.7 TB/s next to it). A packed-FP32 instruction occupies the SIMD for
 // 4 cycles, a plain one for 2, so a tick of 8 sections cannot cost less than 80 multiplies / adds = 160 cycles per
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(kChainBlock) void cascade_kernel(const ChainArgs a)
 // bank_mask of a DPP instruction can address, so the section group j has to be the bank: j = bank % LPC, and the channel is
 // (lane / (4 * LPC)) * 4 + cc. "From the previous group" is then row_shr:4 under a bank mask that spares the group's first
 // lane, which keeps the result computed from its own sample.
-// (Measured and not kept, profiles/r03_cascade_lds_handover.txt: the hand-over through LDS - ds_write2 + ds_read per tick, no
+// (Measured and not kept, profiles/archive/r03_cascade_lds_handover.txt: the hand-over through LDS - ds_write2 + ds_read per tick, no
 // VALU instruction - is slower than DPP, 0.505 against 0.491 ms with two lanes per channel.)
 //
 // Memory: 16 bytes per lane per quad as before. Every lane of a group fetches the channel's input quads (the same

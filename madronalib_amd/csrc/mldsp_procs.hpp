@@ -37,6 +37,7 @@ struct VoiceMem
   // sector of chunk 0 in the block's [chunk][lane][8] ring storage and `lds` this lane's column of the workgroup's write
   // windows, [ring][kRingWindow][256 lanes] (RingCore below).
   float* lds{nullptr};
+  uint32_t ldsHist{0};  // ring layout 4: where this node's history rows start, in floats from `lds` (after its rings' held sectors)
   MLD float c(int i) const { return coeffs[(size_t)i * V]; }
   MLD uint32_t s(int i) const { return state[(size_t)i * V]; }
   MLD void set(int i, uint32_t x) const { state[(size_t)i * V] = x; }
@@ -1295,7 +1296,9 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   {
     return m.mem + ((size_t)ringIdx * (m.memMask + 1) + (size_t)(i & ~(uint32_t)(kRingWindow - 1))) * kRingLdsLanes;
   }
-  MLD void begin(const VoiceMem& m, int ringIdx)  // launch start: the chunk being written comes back into its window
+  // (histWriter: ring layout 4 - this core writes the node's ring and keeps its last 16 samples in LDS; a PitchbendableDelay's
+  // second core does not)
+  MLD void begin(const VoiceMem& m, int ringIdx, bool histWriter = true)  // launch start: the chunk being written comes back into its window
   {
     rChunk = 0xFFFFFFFFu;
     if (kRingTransposed)
@@ -1305,7 +1308,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     }
     if (kRingSectors)
     {
-      beginS(m, ringIdx);
+      beginS(m, ringIdx, histWriter);
       return;
     }
     if (!kRingWindows) return;
@@ -1702,8 +1705,13 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   uint32_t sTag;              // which sector the LDS slot holds (kTNone: none)
   uint32_t sNTag;             // which sector sN holds or will hold - its load may still be in flight (kTNone: none)
   int32_t sD0;                // the delay time of the trip's first sample
-  static constexpr int kSectorLdsFloats = 512;  // per wavefront and ring
-  MLD float* held(const VoiceMem& m, int ringIdx) const { return m.lds + (size_t)ringIdx * 4 * kSectorLdsFloats; }
+  // ... and the node's last 16 written samples, [position & 15][lane] (4 KiB per wavefront and node): a lane whose delay time is
+  // under 16 samples reads there - its sectors are not in memory yet -, so that short delay times cost an LDS access and not a
+  // memory round trip per sample (the first form of this layout sent the whole wavefront through memory for the trip: 0.06 of the
+  // HBM peak on a bank of strings whose top octave reads 1 .. 16 samples back).
+  static constexpr int kSectorLdsFloats = 512, kHistLdsFloats = 1024;  // per wavefront: a ring's held sector, a node's history
+  MLD float* held(const VoiceMem& m, int slot) const { return m.lds + (size_t)slot * kSectorLdsFloats + (threadIdx.x & 63u) * 4u; }
+  MLD float* histRows(const VoiceMem& m) const { return m.lds + m.ldsHist + (threadIdx.x & 63u); }
   MLD void holdSector(const VoiceMem& m, int slot, const float (&v)[8]) const
   {
     float* h = held(m, slot);
@@ -1718,7 +1726,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
   }
   bool sAligned, sFast;              // launch: w is the same multiple of 8 in every lane; trip: served from sH / sN
-  MLD void beginS(const VoiceMem&, int)
+  MLD void beginS(const VoiceMem& m, int ringIdx, bool histWriter)
   {
     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
     sAligned = __builtin_amdgcn_ballot_w64(w != w0) == 0 && (w0 & 7u) == 0u;
@@ -1727,6 +1735,21 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     sD0 = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) sN[j] = sY[j] = sX[j] = 0.f;
+    if (sAligned && histWriter)
+    {
+      // the 16 samples before the launch's first come back into the history rows
+      const uint32_t smask = m.memMask >> 3, ws = w >> 3;
+      float a[8], b[8];
+      loadSector(m, ringIdx, (ws - 2u) & smask, a);
+      loadSector(m, ringIdx, (ws - 1u) & smask, b);
+      float* h = histRows(m);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+      {
+        h[((w - 16u + (uint32_t)j) & 15u) * 64u] = a[j];
+        h[((w - 8u + (uint32_t)j) & 15u) * 64u] = b[j];
+      }
+    }
   }
   MLD void loadSector(const VoiceMem& m, int ringIdx, uint32_t sector, float (&out)[8]) const
   {
@@ -1741,16 +1764,13 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   {
     if (slot < 0) slot = ringIdx;
     if (!sAligned) return;
-    if (__builtin_amdgcn_ballot_w64(dPred < kSectorMinDelay) != 0)  // (the trip's first sample decides how it is served)
-    {
-      sTag = sNTag = kTNone;
-      return;
-    }
+    // (a lane that reads under 16 samples back is served from the history rows: what it loads here is never looked at)
     const uint32_t smask = m.memMask >> 3;
     const uint32_t s0 = ((w - (uint32_t)dPred) & m.memMask) >> 3, s1 = (s0 + 1u) & smask;
     // the held sector is the one needed (the usual case: the read position moved on by 8) - else it comes from memory too. One branch
     // for the wavefront, unconditional loads inside it: a lane that holds the right sector already gets the same eight floats again.
-    if (__builtin_amdgcn_ballot_w64(sTag != s0) != 0)
+    const bool far = dPred >= kSectorMinDelay;
+    if (__builtin_amdgcn_ballot_w64(far && sTag != s0) != 0)
     {
       float h[8];
       loadSector(m, ringIdx, s0, h);
@@ -1758,7 +1778,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       sTag = s0;
     }
     // ... and the upper sector: usually asked for a whole trip ago already (tripStart's early request)
-    if (__builtin_amdgcn_ballot_w64(sNTag != s1) != 0)
+    if (__builtin_amdgcn_ballot_w64(far && sNTag != s1) != 0)
     {
       loadSector(m, ringIdx, s1, sN);
       sNTag = s1;
@@ -1806,7 +1826,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     const uint32_t smask = m.memMask >> 3;
     const uint32_t r0 = (w - (uint32_t)d) & m.memMask, s0 = r0 >> 3, s1 = (s0 + 1u) & smask;
     float h[8];
-    if (__builtin_amdgcn_ballot_w64(sTag != s0 || sNTag != s1) != 0)
+    if (__builtin_amdgcn_ballot_w64(d >= kSectorMinDelay && (sTag != s0 || sNTag != s1)) != 0)
     {
       // the delay time is not what the prologue took it for (or no prologue ran): both sectors now, waited for here
       loadSector(m, ringIdx, s0, h);
@@ -1820,8 +1840,8 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     sTag = s1;
     // sN is free now: the sector after it - the NEXT trip's upper one if the delay time stays - is asked for at once and has this
     // whole trip's arithmetic to arrive in (a single wavefront per SIMD cannot hide a load behind another wavefront). It is complete
-    // in memory when every lane reads at least 32 samples behind the writer.
-    if (__builtin_amdgcn_ballot_w64(d < 2 * kSectorMinDelay) == 0)
+    // in memory for a lane that reads at least 32 samples behind the writer (one that reads under 16 back does not look at it).
+    if (__builtin_amdgcn_ballot_w64(d >= kSectorMinDelay && d < 2 * kSectorMinDelay) == 0)
     {
       sNTag = (s1 + 1u) & smask;
       loadSector(m, ringIdx, sNTag, sN);
@@ -1836,6 +1856,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     if (sFast)
     {
       sX[K] = x;
+      histRows(m)[((w + (uint32_t)K) & 15u) * 64u] = x;
       if (K == 7)
       {
         f32x4r* dst = (f32x4r*)chunkMem(m, ringIdx, w);
@@ -1860,19 +1881,18 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     if (sFast)
     {
       y = sY[K];
-      if (VARY && K != 0 && __builtin_amdgcn_ballot_w64(d != sD0) != 0)
+      if (__builtin_amdgcn_ballot_w64(d < kSectorMinDelay) != 0)
       {
-        // a delay time that moves inside the trip: those lanes read their sample straight from memory. What the trip has written
-        // so far is still in registers, so a lane that now reads closer than 16 samples behind the writer puts it into memory
-        // first (rare twice over).
-        if (__builtin_amdgcn_ballot_w64(d != sD0 && d < kSectorMinDelay) != 0)
-        {
-          float* own = chunkMem(m, ringIdx, w);
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j <= K) __hip_atomic_store(own + j, wr.sX[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (d != sD0)
+        // lanes that read under 16 samples back: the history rows (one LDS read for the wavefront, its row by lane; d = 0 is the
+        // sample just written)
+        const float hy = histRows(m)[((w + (uint32_t)K - (uint32_t)d) & 15u) * 64u];
+        y = (d < kSectorMinDelay) ? hy : y;
+      }
+      if (VARY && K != 0 && __builtin_amdgcn_ballot_w64(d != sD0 && d >= kSectorMinDelay) != 0)
+      {
+        // a delay time that moves inside the trip and stays 16 or more: those lanes read their sample straight from memory (it is
+        // there: everything older than this trip is)
+        if (d != sD0 && d >= kSectorMinDelay)
         {
           const uint32_t r = (w + (uint32_t)K - (uint32_t)d) & m.memMask;
           y = __hip_atomic_load(chunkMem(m, ringIdx, r) + (r & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1906,7 +1926,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       w = (w + 1) & m.memMask;
       return y;
     }
-    if (K == 0) tripStart(m, ringIdx, d, __builtin_amdgcn_ballot_w64(d < kSectorMinDelay) == 0);
+    if (K == 0) tripStart(m, ringIdx, d, true);
     writeS(m, ringIdx, x, K);
     const float y = readS<VARY>(m, ringIdx, d, K, *this);
     advanceS(m, K);
@@ -2108,7 +2128,7 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
     f1.loadFrom(m, 0);
     f2.loadFrom(m, 5);
     f1.ringc.begin(m, 0);
-    f2.ringc.begin(m, 1);
+    f2.ringc.begin(m, 1, false);
     shared = false;
     oneRing = kRingSectors && f1.ringc.sAligned && f2.ringc.sAligned && __builtin_amdgcn_ballot_w64(f1.ringc.w != f2.ringc.w) == 0;
     // write indices a host set apart: the two rings are two rings, served sample by sample through memory (no trips: the second core
@@ -2150,8 +2170,8 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
     {
       if (K == 0)
       {
-        const bool fast = __builtin_amdgcn_ballot_w64(f1.delayInt < kSectorMinDelay || f2.delayInt < kSectorMinDelay) == 0;
-        shared = fast && __builtin_amdgcn_ballot_w64(f1.delayInt != f2.delayInt) == 0;
+        const bool fast = true;
+        shared = __builtin_amdgcn_ballot_w64(f1.delayInt != f2.delayInt) == 0;
         f1.ringc.tripStart(mem, 0, f1.delayInt, fast);
         if (!shared) f2.ringc.tripStart(mem, 0, f2.delayInt, fast, 1);
         else

@@ -308,7 +308,7 @@ print(json.dumps(dict(stats=ml.jit_stats(), same=all(c == codes[0] for c in code
 def test_concurrent_rank_processes_compile_once(tmp_path):
     """The ranks of a multi-GPU job are PROCESSES that start together with a cold cache and ask for the same kernel: whoever
     takes the entry's lock file first runs hiprtc, the other seven wait in flock() and load what it wrote - one compile per
-    machine, not per rank (profiles/r03_multi_gpu_launch_paths.txt shows the same on a GPU box)."""
+    machine, not per rank (profiles/archive/r03_multi_gpu_launch_paths.txt shows the same on a GPU box)."""
     prog = r'''
 import json, sys, time
 import madronalib_amd as ml

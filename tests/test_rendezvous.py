@@ -188,7 +188,7 @@ def test_from_environment_picks_files_when_a_directory_is_exported(monkeypatch, 
 
 def test_bench_refuses_to_run_without_enough_gpus():
     """`python bench.py --gpus N` never silently runs fewer ranks: here (no GPU) every N fails with a message and rc != 0;
-    the same check compares N with the visible device count on a GPU box (gpurun log in profiles/r02_multi_gpu.txt)."""
+    the same check compares N with the visible device count on a GPU box (gpurun log in profiles/archive/r02_multi_gpu.txt)."""
     from madronalib_amd import _lib
     if _lib.load().mlgpu_device_count() > 0:
         pytest.skip("a GPU is visible")

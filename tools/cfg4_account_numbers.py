@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The tables of profiles/r03_cfg4_account.md from the files a profile call left (profiles/r03_cascade_lanes.txt and the two lab PMC
+"""The tables of profiles/archive/r03_cfg4_account.md from the files a profile call left (profiles/archive/r03_cascade_lanes.txt and the two lab PMC
 files): cycles with and without the HBM streams, the forms at 131 072 channels, the forms at other bank sizes. Markdown on stdout."""
 import os
 import re
