@@ -276,7 +276,7 @@ def setup_workload(eng, name, V, T, lo, total):
                     held.setdefault(i, []).append(key)
                     evs.append(ml.Event(1, 1, key, t, (key - 60) / 12.0, 0.8))
             return ml.Events.pack_events(insts, evs)
-        blocks = [make_block() for _ in range(int(getattr(eng, "_bench_launches", 0)) + 40 + 260)]   # (+ the lap leg's launches)
+        blocks = [make_block() for _ in range(int(getattr(eng, "_bench_launches", 0)) + 40 + 260 + 30)]   # (+ the lap leg's launches)
 
         def launch():
             ev.add_events_packed(blocks[k[0]] if k[0] < len(blocks) else make_block())
@@ -1046,6 +1046,50 @@ _SETUP_LOCK = threading.Lock()
 _T_PROCESS = time.perf_counter()   # this rank's process reached bench.py's top level (interpreter + numpy import are before it)
 
 
+def live_traffic(workload, kernel_name, timeout_s=150):
+    """HBM bytes per launch of `kernel_name`, MEASURED NOW: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, each a run of its own with
+    --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a 2-step run of this script's own workload in a child
+    process, corrected as the guide says (KiB; FETCH_SIZE doubled on gfx950 for coalesced streams). -> dict or None (no rocprofv3, a refused
+    or failed pass: the caller falls back to the stored record of profiles/pmc_workloads.json)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof:
+        return None
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp", MLGPU_BENCH_CHILD="1")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"mlgpu_pmc_{counter}_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-live-counters"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            hits = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if not hits:
+                return None
+            per = {}
+            for row in csv.DictReader(open(hits[0])):
+                if row["Counter_Name"] == counter and kernel_name.split("<")[0] in row["Kernel_Name"] and kernel_name[:30] in row["Kernel_Name"].replace("void ", ""):
+                    per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if len(per) < 8:
+                return None
+            out[counter] = 1024.0 * sum(per.values()) / len(per)
+            out["launches"] = len(per)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"fetch_bytes_per_launch_raw": out["FETCH_SIZE"], "write_bytes_per_launch": out["WRITE_SIZE"], "launches": out["launches"],
+            "bytes_per_launch": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"],
+            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (--kernel-trace only, two runs of their own) of this workload, taken by this bench.py run in child "
+                      "processes after its timed region; KiB x 1024, FETCH_SIZE x 2 (gfx950, coalesced 16 B / lane streams)"}
+
+
 def workload_key(name, V, T):
     """What identifies one measured case in profiles/pmc_workloads.json: the workload, its variant switches and its size."""
     var = [f"{k.lower().replace('mlgpu_', '')}={os.environ[k]}" for k in ("MLGPU_DELAY_WINDOWS", "MLGPU_UNIFORM_DELAY", "MLGPU_EVENT_ROWS",
@@ -1160,8 +1204,16 @@ def run_rank(args, rank, local_rank, world, rdv):
     if pmc.get("fetch_bytes_per_launch_raw") is not None:
         raw, co = pmc["fetch_bytes_per_launch_raw"], META["coalesced_read_bytes"]
         traffic = pmc["write_bytes_per_launch"] + (2.0 * raw if co is None else raw + min(raw, 0.5 * co))
+    traffic_source = "profiles/pmc_workloads.json (recorded for this build of the device code)" if traffic is not None else None
+    if (world == 1 and args.workload == "cfg3" and not args.no_live_counters and not args.voices and not args.vectors and not os.environ.get("MLGPU_BENCH_CHILD")
+            and not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) and "rocprof" not in os.environ.get("LD_PRELOAD", "")):   # (not under a profiler already)
+        # the headline's HBM traffic measured by THIS run (weak point of round 5: the driver never saw a counter): ~15 s
+        lt = live_traffic(args.workload, kernel_name)
+        if lt:
+            traffic, traffic_source = lt["bytes_per_launch"], lt["source"]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": kernel_name, "kernel_ms": kernel_ms,
+            "traffic": traffic, "traffic_source": traffic_source, "traffic_over_algorithmic": (traffic / alg_bytes if traffic else None),
+            "kernel": kernel_name, "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": alg_bytes, "pmc_case": key if pmc else None,
             "device_code": ml.device_source_hash()[:16]}   # (what the PMC records are matched against)
     if pmc_stale:
@@ -1185,6 +1237,8 @@ def run_rank(args, rank, local_rank, world, rdv):
         # headline's mean keeps its two events): the board runs these launches at its power cap and the launch time follows the shader
         # clock it is granted (profiles/r06_cfg3_spread.md) - p10 is not a speed the chip holds.
         try:
+            for _ in range(3 * L):     # (the board's clock settles over the first launches after any pause: profiles/r06_cfg3_spread.md)
+                launch()
             laps = np.sort(eng.lap_times_ms(launch, max(50, min(250, 4 * L))))
             roof.update({"kernel_ms_p10": float(laps[len(laps) // 10]), "kernel_ms_p50": float(laps[len(laps) // 2]),
                          "kernel_ms_p90": float(laps[len(laps) * 9 // 10]), "kernel_ms_min": float(laps[0]), "kernel_ms_max": float(laps[-1]),
@@ -1393,7 +1447,7 @@ def run_rt_group(args, eng, info, V, T, L, rank, world, rdv):
         for b in range(lead_in + blocks):
             deadline = start + b * period
             while clock() < deadline:
-                pass
+                time.sleep(0)      # (ranks may be threads of one process: a busy wait would keep the interpreter from the others)
             bank.process_mixdown_shard(T, d_rows)
             ex.put(b, d_rows.download(np.float32, rows * 64 * T).reshape(rows, 64 * T))
             if rank == 0:
@@ -1556,6 +1610,7 @@ def main():
                     help="TEST ONLY: let ranks share devices (rank r on device r mod visible) so the N>1 launch paths can be exercised on "
                          "a box with fewer GPUs; the line says so and is not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not take the headline's FETCH_SIZE / WRITE_SIZE with rocprofv3 in child processes")
     ap.add_argument("--no-extras", action="store_true",
                     help="the default run (cfg3, one GPU) also times configs 2, 4, 5, the survey's patch and the paced 2^20-voice target and adds them "
                          "as flat keys under roofline (~15 s); this switch leaves the headline alone")

@@ -85,6 +85,12 @@ def max_over_ranks(seconds, dist=None, device="cpu"):
     return float(t.item())
 
 
+def _yield():
+    """Inside a spin loop: let another thread of this process have the interpreter (ranks may be threads: `bench.py --launcher threads`)."""
+    import time
+    time.sleep(0)
+
+
 class RowExchange:
     """The one exchange a sharded bank has when a host wants ONE channel from it (SURVEY 8e "optional later: per-GPU reduction then host
     add"): every rank hands rank 0 the rows of the mixdown tree its shard is whole at (mlgpu_bank_process_mixdown_shard: 256 bytes per
@@ -103,6 +109,11 @@ class RowExchange:
         if self.rank != 0:
             name = next(n for n in names if n)
             self.shm = shared_memory.SharedMemory(name=name)
+            try:   # (the segment is rank 0's to unlink: keep this process's resource tracker from doing it at exit and warning about it)
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self.shm._name, "shared_memory")
+            except Exception:
+                pass
         self.seq = np.ndarray((self.hdr,), np.uint64, self.shm.buf, 0)
         self.data = np.ndarray((2, self.world * self.rows, self.S), np.float32, self.shm.buf, 8 * self.hdr)
         if self.rank == 0:
@@ -113,7 +124,7 @@ class RowExchange:
         """This rank's rows [rows_per_rank][64 T] of block `block` (0, 1, 2 ...)."""
         slot, T64 = block & 1, rows.shape[1]
         while block >= 2 and int(self.seq[2 * self.world + slot]) < block - 1:      # rank 0 has not read this slot's block k - 2 yet
-            pass
+            _yield()
         self.data[slot, self.rank * self.rows:(self.rank + 1) * self.rows, :T64] = rows
         self.seq[slot * self.world + self.rank] = block + 1
 
@@ -122,7 +133,7 @@ class RowExchange:
         slot = block & 1
         want = block + 1
         while any(int(self.seq[slot * self.world + r]) < want for r in range(self.world)):
-            pass
+            _yield()
         out = np.array(self.data[slot, :, :64 * n_vectors])
         self.seq[2 * self.world + slot] = want
         return out

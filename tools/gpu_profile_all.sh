@@ -7,6 +7,7 @@
 # EXTRA="--voices N ..." in the environment is passed to every bench.py call (e.g. the 1 GiB config-2 case). PMC=0 skips the counter passes
 # (kernel stats and bench lines only).
 set -u
+export MLGPU_BENCH_CHILD=1   # (bench.py does not start counter passes of its own inside these runs)
 EXTRA=${EXTRA:-}
 tag=$1; shift
 export TMPDIR=/tmp
@@ -33,7 +34,7 @@ for w in "$@"; do
   python $root/tools/pmc_summary.py traffic $scratch/pmc_FETCH_SIZE $scratch/pmc_WRITE_SIZE $out/${tag}_${w}_traffic.json > /dev/null 2>&1
   python $root/tools/pmc_workloads.py $out/pmc_workloads.json "$(python $root/bench.py --workload $w $EXTRA --print-case)@$out/${tag}_${w}" > /dev/null 2>&1
   python $root/tools/pmc_workloads.py $root/profiles/pmc_workloads.json "$(python $root/bench.py --workload $w $EXTRA --print-case)@$out/${tag}_${w}" > /dev/null 2>&1   # the bench line below reads the fresh record
-  python $root/bench.py --workload $w $EXTRA $( [ $w = cfg3 ] || echo --no-cpu-baseline ) 2>/dev/null | tail -1 > $out/${tag}_${w}_bench.json
+  MLGPU_BENCH_CHILD= python $root/bench.py --workload $w $EXTRA $( [ $w = cfg3 ] || echo --no-cpu-baseline ) 2>/dev/null | tail -1 > $out/${tag}_${w}_bench.json
   echo "== $w"; sed -n 2,3p $out/${tag}_${w}_kernel_stats.csv | cut -c1-200; python -c "import sys,json; d=json.loads(open('$out/${tag}_${w}_bench.json').read()); print(d['value'], d['roofline']['frac'], d['roofline']['kernel_ms'])"
 done
 python - <<PY
