@@ -2121,7 +2121,10 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
   // whenever their write indices agree - which they do unless a host set them apart: ring 0 alone is then written and read by both
   // cores (oneRing, decided per wavefront at the launch's start), and in a trip in which both cores have the same delay time - all
   // the time while the delay-time signal rests - ONE read serves both (shared): 8 bytes per sample of ring traffic instead of 16.
-  bool oneRing, shared;
+  // The default rows (layout 0) do the same (rowsOne): per sample one 4-byte row write and - while the two delay times agree - one row
+  // read instead of two and two. (The second ring's memory then stays as it was: a host that sets the two write indices apart does so
+  // before the first launch after a clear.)
+  bool oneRing, shared, rowsOne;
   MLD void load(const VoiceMem& m, const KernelTables&)
   {
     mem = m;
@@ -2134,6 +2137,7 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
     // write indices a host set apart: the two rings are two rings, served sample by sample through memory (no trips: the second core
     // then needs no registers for a sector of its own writes)
     if (kRingSectors && !oneRing) f1.ringc.sAligned = f2.ringc.sAligned = false;
+    rowsOne = !kRingWindows && __builtin_amdgcn_ballot_w64(f1.ringc.w != f2.ringc.w) == 0;
   }
   MLD void store(const VoiceMem& m) const
   {
@@ -2186,6 +2190,19 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
       if (!shared) b = f2.ringc.readS<false>(mem, 0, f2.delayInt, K, f1.ringc);
       f1.ringc.advanceS(mem, K);
       f2.ringc.advanceS(mem, K);
+      y1 = f1.ap(a);
+      y2 = f2.ap(b);
+    }
+    else if (!kRingWindows && rowsOne)
+    {
+      const uint32_t w = f1.ringc.w;
+      mem.ringSet(w, x);
+      // (two loads, no branch: while the delay times agree the second one finds the first one's line in the vector cache. A wave-uniform
+      // branch around it - and, tried next, the quad's reads of every ring issued together at the quad's top behind such branches - kept
+      // the loads of a many-ring graph from overlapping: the reverb example 4.6 -> 7.2 / 6.3 ms, profiles/r06_ring_layouts.txt)
+      const float a = mem.ring((w - (uint32_t)f1.delayInt) & mem.memMask);
+      const float b = mem.ring((w - (uint32_t)f2.delayInt) & mem.memMask);
+      f1.ringc.w = f2.ringc.w = (w + 1) & mem.memMask;
       y1 = f1.ap(a);
       y2 = f2.ap(b);
     }
