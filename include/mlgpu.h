@@ -735,6 +735,19 @@ int mlgpu_jit_selftest(char* log, size_t log_len);
  * Counters since the library was loaded (any pointer may be NULL): kernels compiled by hiprtc and the seconds that took,
  * code objects read from the disk cache and the seconds that took, requests served from memory. */
 int mlgpu_jit_stats(uint64_t* compiles, uint64_t* disk_hits, uint64_t* memory_hits, double* compile_seconds, double* disk_load_seconds);
+/* Installations WITHOUT the compiler (round 6). libmlgpu.so looks libhiprtc.so up at run time and does not link it: where it is
+ * missing, every ahead-of-time kernel works as before and a generated one (a graph, a chain without an ahead-of-time form, a strict-SVF
+ * bank, a bank's summing form) works when its code is there - from the disk cache or from a BUNDLE: mlgpu_jit_cache_export writes every
+ * generated kernel this process holds (sources as keys + gfx950 code objects) into `buffer` (`needed`: its size; buffer NULL: only
+ * that), mlgpu_jit_cache_import takes such a bundle (MLGPU_ERR_UNSUPPORTED: made by another build of the device code;
+ * MLGPU_ERR_INVALID: not a bundle). Make it where hiprtc is installed - run the patches once, or compile them ahead of time on
+ * graphs without an engine (mlgpu_graph_compile_async) -, ship it with the plug-in, import it at load. A kernel that is nowhere to be
+ * found fails with MLGPU_ERR_UNSUPPORTED and says so. mlgpu_jit_compiler_available: 1 / 0. (MLGPU_HIPRTC=off in the environment:
+ * behave as if the compiler were absent.) */
+int mlgpu_jit_cache_export(void* buffer, size_t capacity, size_t* needed);
+int mlgpu_jit_cache_import(const void* buffer, size_t size, size_t* kernels);
+int mlgpu_jit_cache_clear_memory(void);
+int mlgpu_jit_compiler_available(void);
 
 /* ------------------------------------------------------------------------- */
 /* performance events -> per-voice control signals                            */

@@ -58,6 +58,33 @@ def mixdown_finish(rows, flush_denormals=False):
     return out
 
 
+def jit_cache_export():
+    """Every generated kernel this process holds, as one bundle (bytes): for an installation without hiprtc (mlgpu_jit_cache_export)."""
+    L = _lib.load()
+    need = ctypes.c_size_t()
+    st = L.mlgpu_jit_cache_export(None, 0, ctypes.byref(need))
+    if st:
+        raise MlgpuError(st, "(jit_cache_export)")
+    buf = ctypes.create_string_buffer(need.value)
+    st = L.mlgpu_jit_cache_export(buf, need.value, ctypes.byref(need))
+    if st:
+        raise MlgpuError(st, "(jit_cache_export)")
+    return buf.raw[:need.value]
+
+
+def jit_cache_import(bundle):
+    """Take a bundle made by jit_cache_export (the same build of the device code); -> kernels taken."""
+    n = ctypes.c_size_t()
+    st = _lib.load().mlgpu_jit_cache_import(bundle, len(bundle), ctypes.byref(n))
+    if st:
+        raise MlgpuError(st, "(jit_cache_import)")
+    return n.value
+
+
+def jit_compiler_available():
+    return bool(_lib.load().mlgpu_jit_compiler_available())
+
+
 def device_source_hash():
     """SHA-256 of the device sources and compiler flags the loaded library was built from (mlgpu_device_source_hash)."""
     return _lib.load().mlgpu_device_source_hash().decode()

@@ -113,6 +113,10 @@ def _declare(L):
     sig("mlgpu_last_error", c.c_char_p, [vp])
     sig("mlgpu_validate", i, [vp, vp, sz, c.POINTER(c.c_uint64), c.POINTER(c.c_uint64)])
     sig("mlgpu_jit_stats", i, [c.POINTER(c.c_uint64)] * 3 + [c.POINTER(c.c_double)] * 2)
+    sig("mlgpu_jit_cache_export", i, [vp, sz, c.POINTER(c.c_size_t)])
+    sig("mlgpu_jit_cache_import", i, [vp, sz, c.POINTER(c.c_size_t)])
+    sig("mlgpu_jit_cache_clear_memory", i, [])
+    sig("mlgpu_jit_compiler_available", i, [])
     sig("mlgpu_registry_count", i, [])
     sig("mlgpu_registry_get", i, [i, vp])
     sig("mlgpu_registry_lookup", i, [c.c_char_p, vp])

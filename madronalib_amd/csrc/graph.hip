@@ -11,7 +11,8 @@
 // gfx950 with hiprtc. Every edge of the graph is a register; only graph inputs and outputs touch
 // HBM. Identical graphs share one compiled module per process. The same generator produces fused
 // kernels for processor chains that have no ahead-of-time instantiation (mlgpu_jit_chain).
-#include <hip/hiprtc.h>
+#include <hip/hiprtc.h>  // (types and enumerators only: the library is looked up at run time, see Hiprtc below)
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,12 +73,86 @@ const std::vector<std::string>& jitOptions()
   return opts;
 }
 
+// hiprtc, looked up at RUN TIME (round 6): libmlgpu.so does not link it, so an installation without the compiler still loads and
+// runs every ahead-of-time kernel, and every generated one whose code it is given (the disk cache, mlgpu_jit_cache_import). A
+// graph or chain that needs a compile there fails with MLGPU_ERR_UNSUPPORTED and says why. MLGPU_HIPRTC=off: behave as if the
+// library were absent (what tests/test_abi.py uses); MLGPU_HIPRTC=<path>: that library.
+struct Hiprtc
+{
+  void* lib{nullptr};
+  decltype(&::hiprtcCreateProgram) createProgram{nullptr};
+  decltype(&::hiprtcCompileProgram) compileProgram{nullptr};
+  decltype(&::hiprtcGetProgramLogSize) getProgramLogSize{nullptr};
+  decltype(&::hiprtcGetProgramLog) getProgramLog{nullptr};
+  decltype(&::hiprtcGetCodeSize) getCodeSize{nullptr};
+  decltype(&::hiprtcGetCode) getCode{nullptr};
+  decltype(&::hiprtcDestroyProgram) destroyProgram{nullptr};
+  decltype(&::hiprtcGetErrorString) getErrorString{nullptr};
+  decltype(&::hiprtcVersion) version{nullptr};
+  std::string why;
+  Hiprtc()
+  {
+    const char* knob = getenv("MLGPU_HIPRTC");
+    for (const char* name : {knob && strcmp(knob, "off") ? knob : "libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"})
+    {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib)
+    {
+      why = std::string("libhiprtc.so cannot be loaded (") + (dlerror() ? dlerror() : "not found") + ")";
+      return;
+    }
+#define MLGPU_RTC_SYM(member, symbol) member = (decltype(member))dlsym(lib, #symbol)
+    MLGPU_RTC_SYM(createProgram, hiprtcCreateProgram);
+    MLGPU_RTC_SYM(compileProgram, hiprtcCompileProgram);
+    MLGPU_RTC_SYM(getProgramLogSize, hiprtcGetProgramLogSize);
+    MLGPU_RTC_SYM(getProgramLog, hiprtcGetProgramLog);
+    MLGPU_RTC_SYM(getCodeSize, hiprtcGetCodeSize);
+    MLGPU_RTC_SYM(getCode, hiprtcGetCode);
+    MLGPU_RTC_SYM(destroyProgram, hiprtcDestroyProgram);
+    MLGPU_RTC_SYM(getErrorString, hiprtcGetErrorString);
+    MLGPU_RTC_SYM(version, hiprtcVersion);
+#undef MLGPU_RTC_SYM
+    if (!createProgram || !compileProgram || !getProgramLogSize || !getProgramLog || !getCodeSize || !getCode || !destroyProgram || !getErrorString)
+    {
+      why = "libhiprtc.so lacks an entry point this library uses";
+      dlclose(lib);
+      lib = nullptr;
+    }
+  }
+};
+// nullptr (and `why`) where the compiler is not there - or a test says so
+const Hiprtc* hiprtc(std::string* why = nullptr)
+{
+  static const Hiprtc rtc;
+  const char* knob = getenv("MLGPU_HIPRTC");
+  if (knob && !strcmp(knob, "off"))
+  {
+    if (why) *why = "run-time compilation is switched off (MLGPU_HIPRTC=off)";
+    return nullptr;
+  }
+  if (!rtc.lib)
+  {
+    if (why) *why = rtc.why;
+    return nullptr;
+  }
+  return &rtc;
+}
+
 // compile `source` for gfx950 and load it on the current device; returns nullptr and fills `log` on failure
 bool compileToCode(const std::string& source, std::vector<char>& code, std::string& log)
 {
   hiprtcProgram prog;
   code.clear();
-  if (hiprtcCreateProgram(&prog, source.c_str(), "mlgpu_jit.hip", mlgpu_embedded_count, (const char**)mlgpu_embedded_sources,
+  std::string why;
+  const Hiprtc* rtc = hiprtc(&why);
+  if (!rtc)
+  {
+    log = "this kernel is not in the memory or disk cache and " + why + ": compile it where hiprtc is installed and bring its code along (mlgpu_jit_cache_export / _import)";
+    return false;
+  }
+  if (rtc->createProgram(&prog, source.c_str(), "mlgpu_jit.hip", mlgpu_embedded_count, (const char**)mlgpu_embedded_sources,
                           (const char**)mlgpu_embedded_names) != HIPRTC_SUCCESS)
   {
     log = "hiprtcCreateProgram failed";
@@ -85,23 +160,23 @@ bool compileToCode(const std::string& source, std::vector<char>& code, std::stri
   }
   std::vector<const char*> opts;
   for (const std::string& o : jitOptions()) opts.push_back(o.c_str());
-  const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+  const hiprtcResult r = rtc->compileProgram(prog, (int)opts.size(), opts.data());
   size_t logSize = 0;
-  hiprtcGetProgramLogSize(prog, &logSize);
+  rtc->getProgramLogSize(prog, &logSize);
   if (logSize > 1)
   {
     log.resize(logSize);
-    hiprtcGetProgramLog(prog, &log[0]);
+    rtc->getProgramLog(prog, &log[0]);
   }
   size_t codeSize = 0;
-  if (r == HIPRTC_SUCCESS) hiprtcGetCodeSize(prog, &codeSize);
+  if (r == HIPRTC_SUCCESS) rtc->getCodeSize(prog, &codeSize);
   if (codeSize)
   {
     code.resize(codeSize);
-    hiprtcGetCode(prog, code.data());
+    rtc->getCode(prog, code.data());
   }
-  hiprtcDestroyProgram(&prog);
-  if (r != HIPRTC_SUCCESS && log.empty()) log = hiprtcGetErrorString(r);
+  rtc->destroyProgram(&prog);
+  if (r != HIPRTC_SUCCESS && log.empty()) log = rtc->getErrorString(r);
   return r == HIPRTC_SUCCESS && codeSize > 0;
 }
 
@@ -167,7 +242,8 @@ const std::string& cacheContext()
     for (const std::string& o : jitOptions()) c += o + " ";
     c += "\ndevice-sources " + std::string(mlgpu_device_source_hash_str);
     int major = 0, minor = 0, runtime = 0, driver = 0;
-    hiprtcVersion(&major, &minor);
+    if (const Hiprtc* rtc = hiprtc())
+      if (rtc->version) rtc->version(&major, &minor);  // (0.0 without the compiler: such a process only ever READS code it is given)
     if (hipRuntimeGetVersion(&runtime) != hipSuccess) runtime = -1;
     if (hipDriverGetVersion(&driver) != hipSuccess) driver = -1;
     c += "\nhiprtc " + std::to_string(major) + "." + std::to_string(minor) + " runtime " + std::to_string(runtime) + " driver " + std::to_string(driver);
@@ -182,7 +258,23 @@ const std::string& cacheContext()
 
 std::string cacheFile(const std::string& source)
 {
-  static const std::string dir = cacheDir();
+  // (looked up again whenever MLGPU_CACHE_DIR changes: a host - or a test - may switch the disk level off after the first kernel)
+  static std::mutex m;
+  static std::string dirFor, dirValue;
+  static bool dirKnown = false;
+  std::string dir;
+  {
+    std::lock_guard<std::mutex> lock(m);
+    const char* envNow = getenv("MLGPU_CACHE_DIR");
+    const std::string key = envNow ? envNow : "";
+    if (!dirKnown || key != dirFor)
+    {
+      dirValue = cacheDir();
+      dirFor = key;
+      dirKnown = true;
+    }
+    dir = dirValue;
+  }
   if (dir.empty()) return "";
   const std::string& ctx = cacheContext();
   uint64_t h = 0xcbf29ce484222325ull;
@@ -1486,6 +1578,82 @@ bool mlgpu_jit_chain_mix(mlgpu_engine* e, const int32_t* kinds, int n, void** fn
 
 extern "C"
 {
+  // Every generated kernel this process holds (compiled here or read from the disk cache), as one relocatable blob: what an
+  // installation WITHOUT hiprtc is given so that its graphs and chains find their code. Header: magic, the fingerprint of the device
+  // headers the kernels were generated from (a bundle of another build is refused: its kernels would be looked up by other sources
+  // anyway), count; then per kernel the generated source (the key) and the code object.
+  static const char kBundleMagic[8] = {'M', 'L', 'G', 'P', 'U', 'K', 'B', '1'};
+  int mlgpu_jit_cache_export(void* buffer, size_t capacity, size_t* needed)
+  {
+    std::lock_guard<std::mutex> lock(g_codeMutex);
+    const std::string fp = mlgpu_device_source_hash_str;
+    size_t total = sizeof(kBundleMagic) + 8 + fp.size() + 8;
+    for (const auto& kv : g_codeCache) total += 16 + kv.first.size() + kv.second.size();
+    if (needed) *needed = total;
+    if (!buffer) return MLGPU_OK;
+    if (capacity < total) return MLGPU_ERR_RANGE;
+    char* p = (char*)buffer;
+    auto put = [&p](const void* src, size_t n) {
+      memcpy(p, src, n);
+      p += n;
+    };
+    auto put64 = [&put](uint64_t v) { put(&v, 8); };
+    put(kBundleMagic, sizeof(kBundleMagic));
+    put64(fp.size());
+    put(fp.data(), fp.size());
+    put64(g_codeCache.size());
+    for (const auto& kv : g_codeCache)
+    {
+      put64(kv.first.size());
+      put64(kv.second.size());
+      put(kv.first.data(), kv.first.size());
+      put(kv.second.data(), kv.second.size());
+    }
+    return MLGPU_OK;
+  }
+  int mlgpu_jit_cache_import(const void* buffer, size_t size, size_t* kernels)
+  {
+    if (kernels) *kernels = 0;
+    if (!buffer) return MLGPU_ERR_INVALID;
+    const char *p = (const char*)buffer, *end = p + size;
+    auto get64 = [&p, end](uint64_t& v) {
+      if ((size_t)(end - p) < 8) return false;
+      memcpy(&v, p, 8);
+      p += 8;
+      return true;
+    };
+    if (size < sizeof(kBundleMagic) || memcmp(p, kBundleMagic, sizeof(kBundleMagic)) != 0) return MLGPU_ERR_INVALID;
+    p += sizeof(kBundleMagic);
+    uint64_t n = 0;
+    if (!get64(n) || (size_t)(end - p) < n) return MLGPU_ERR_INVALID;
+    if (std::string(p, (size_t)n) != mlgpu_device_source_hash_str) return MLGPU_ERR_UNSUPPORTED;  // kernels of another build of the device code
+    p += n;
+    uint64_t count = 0;
+    if (!get64(count)) return MLGPU_ERR_INVALID;
+    std::vector<std::pair<std::string, std::vector<char>>> items;
+    for (uint64_t i = 0; i < count; ++i)
+    {
+      uint64_t ns = 0, nc = 0;
+      if (!get64(ns) || !get64(nc) || (size_t)(end - p) < ns || (size_t)(end - p) - ns < nc) return MLGPU_ERR_INVALID;
+      if (nc < 4 || memcmp(p + ns, "\x7f" "ELF", 4) != 0) return MLGPU_ERR_INVALID;  // (what goes to the module loader is at least an ELF file)
+      items.emplace_back(std::string(p, (size_t)ns), std::vector<char>(p + ns, p + ns + nc));
+      p += ns + nc;
+    }
+    std::lock_guard<std::mutex> lock(g_codeMutex);
+    for (auto& it : items) g_codeCache[it.first] = std::move(it.second);
+    if (kernels) *kernels = items.size();
+    return MLGPU_OK;
+  }
+  // (tests) forget the kernels held in memory: the next request goes to the disk cache or the compiler again
+  int mlgpu_jit_cache_clear_memory(void)
+  {
+    std::lock_guard<std::mutex> lock(g_codeMutex);
+    g_codeCache.clear();
+    return MLGPU_OK;
+  }
+  // 1 where run-time compilation is there (libhiprtc.so can be loaded and MLGPU_HIPRTC is not "off"), else 0
+  int mlgpu_jit_compiler_available(void) { return hiprtc() ? 1 : 0; }
+
   int mlgpu_jit_stats(uint64_t* compiles, uint64_t* diskHits, uint64_t* memoryHits, double* compileSeconds, double* diskLoadSeconds)
   {
     std::lock_guard<std::mutex> lock(g_codeMutex);

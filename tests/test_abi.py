@@ -394,3 +394,57 @@ def test_offline_emit_of_round5_generator_forms():
     with pytest.raises(ml.MlgpuError):
         g.set_output_group_sum(0, 8)
     g.close()
+
+
+def test_kernels_travel_to_an_installation_without_hiprtc(monkeypatch):
+    """libmlgpu.so does not link hiprtc (round 6): where the compiler is missing, a generated kernel works when its code is there. A
+    graph is compiled ahead of time here (no device), every generated kernel of the process is exported as a bundle, the process then
+    behaves as an installation without the compiler (MLGPU_HIPRTC=off, disk cache off, memory cache emptied): the same graph fails
+    with MLGPU_ERR_UNSUPPORTED and says why - and after the bundle's import it yields the same code object again."""
+    import subprocess
+    import madronalib_amd as ml
+    from madronalib_amd import _lib
+    from madronalib_amd.constants import Op, Proc
+    L = _lib.load()
+    out = subprocess.run(["ldd", os.path.join(os.path.dirname(_lib.__file__), "csrc", "libmlgpu.so")], capture_output=True, text=True).stdout
+    assert "hiprtc" not in out, "libmlgpu.so must not link hiprtc: it is looked up at run time"
+
+    def build():
+        g = ml.Graph(ml.OfflineEngine(), 512)
+        g.add("x", "input")
+        g.add("c", "const", value=0.37251)
+        g.add("y", "op", Op.MULTIPLY, ["x", "c"])
+        g.add("lp", "proc", Proc.ONE_POLE, ["y"])
+        g.add_output("lp")
+        return g
+    assert ml.jit_compiler_available()
+    g = build()
+    src, code = g.emit()
+    g.close()
+    bundle = ml.jit_cache_export()
+    assert bundle[:8] == b"MLGPUKB1" and len(bundle) > len(code)
+    monkeypatch.setenv("MLGPU_HIPRTC", "off")
+    monkeypatch.setenv("MLGPU_CACHE_DIR", "off")
+    assert not ml.jit_compiler_available()
+    assert L.mlgpu_jit_cache_clear_memory() == 0
+    g = build()
+    with pytest.raises(ml.MlgpuError) as ei:
+        g.emit()
+    assert ei.value.status == ml.Status.ERR_UNSUPPORTED and "MLGPU_HIPRTC=off" in str(ei.value) and "mlgpu_jit_cache_export" in str(ei.value)
+    g.close()
+    n = ml.jit_cache_import(bundle)
+    assert n >= 1
+    g = build()
+    src2, code2 = g.emit()
+    assert src2 == src and code2 == code
+    g.close()
+    # a bundle that is not one, and one of another build of the device code
+    with pytest.raises(ml.MlgpuError) as ei:
+        ml.jit_cache_import(b"not a bundle at all")
+    assert ei.value.status == ml.Status.ERR_INVALID
+    fp_len = int.from_bytes(bundle[8:16], "little")
+    other = bundle[:16] + bytes([bundle[16] ^ 1]) + bundle[17:]
+    assert fp_len > 8
+    with pytest.raises(ml.MlgpuError) as ei:
+        ml.jit_cache_import(other)
+    assert ei.value.status == ml.Status.ERR_UNSUPPORTED
