@@ -290,12 +290,21 @@ def test_sharded_mixdown_gives_one_bank_bits(eng, oracle, V, shards):
     nrows = ml.mixdown_shard_rows(per)
     d_one = eng.alloc(4 * 64 * T)
     d_rows = [eng.alloc(4 * nrows * 64 * T) for _ in range(shards)]
+    # (the CPU side of the same block, for the smaller banks: the oracle's voices through the oracle's tree - the in-kernel sum is not
+    # only compared with other device code)
+    cpu_state = oracle.chain_clear(chain, V) if V <= 8192 else None
+    cpu_coeffs = np.ascontiguousarray(np.concatenate([np.stack([few[i][np.arange(V) % 16] for i in range(3)]), np.full((1, V), 0.25, np.float32)], 0)) if V <= 8192 else None
     for launch in range(2):
         whole.process_mixdown(T, d_one)
         for b, d in zip(parts, d_rows):
             b.process_mixdown_shard(T, d)
         rows = np.concatenate([d.download(np.float32, nrows * 64 * T).reshape(nrows, 64 * T) for d in d_rows], 0)
         assert_bits_equal(ml.mixdown_finish(rows), d_one.download(np.float32, 64 * T), True, f"{shards} shards of {per} voices, launch {launch}")
+        if cpu_state is not None:
+            voices = oracle.chain_process(chain, T, cpu_coeffs, cpu_state, None, freq, n_threads=4)
+            assert_bits_equal(d_one.download(np.float32, 64 * T), oracle.mixdown(voices), True, f"bank_process_mixdown vs the oracle's voices and tree, launch {launch}")
+            shard_rows = np.concatenate([oracle.mixdown_shard(voices[k * per:(k + 1) * per]) for k in range(shards)], 0)
+            assert_bits_equal(rows, shard_rows, True, "the shards' rows vs the oracle's")
     # a signal in memory
     sig = lcg_noise(np.arange(V, dtype=np.uint32) + 5, 64 * T)
     gains = rng.uniform(-1, 1, V).astype(np.float32)
