@@ -511,6 +511,8 @@ struct Node
   int nOut{0};            // demultiplex: number of outputs
   size_t ringLen{0};      // delay nodes: floats per ring (power of two), 0 = not set
   int ringSlot{0};        // delay nodes: index of this node's first ring among all rings of the graph (LDS windows)
+  int earlySlot{-1};      // ring layout 0 with early reads: this node's first 256-byte landing slot in the wavefront's LDS
+  int earlyPending{0};    //   and the loads the kernel issues right after this node's (RingCore::earlyWait), set by the generator
   size_t memOff{0};       // delay nodes: first ring at d_mem + memOff * V
   int fbSource{-1};       // feedback nodes: the node whose value is stored for the next vector
   int rate{RATE_AUDIO};
@@ -578,6 +580,8 @@ struct mlgpu_graph
   bool windowedRings{false};     // rings as [block][chunk][lane][8] behind LDS windows (mlgpu_graph_set_delay_layout)
   bool fbAhead{true};            // kept DSPVectors (feedback nodes) are fetched two quads ahead; MLGPU_GRAPH_FB_AHEAD=0 for A / B
   bool transposedIfPossible{false};  // graph_set_delay_layout(3)
+  bool earlyRows{false};         // layout 0: the ring reads of the outer graph's delay nodes issued ahead by LDS-DMA (RingCore::readEarly); set at compile
+  int earlySlots{0};             // their landing slots per wavefront
   bool sectorRings{false};       // layout 4: layout 1's memory, no LDS, trips of 8 samples with every ring's loads in the trip's prologue (implies windowedRings)
   bool transposedRings{false};   // layout 2: [block][chunk][lane][16], every global access a 64-byte piece made by four lanes, on a wave-uniform clock (implies windowedRings)
   int totalRings{0};
@@ -751,6 +755,9 @@ static int streamLockSawOf(const mlgpu_graph* g, size_t i)  // the saw of the pa
   return -1;
 }
 
+// ring layout 0, a delay node of the outer graph: its ring read is issued ahead of its place in the graph (RingCore::readEarly)
+static bool earlyRingReads(const mlgpu_graph* g, const Node& n) { return g->earlyRows && n.earlySlot >= 0; }
+
 std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& ph = "", const std::string& idx = "q * 4 + k")
 {
   const Node& n = g->nodes[i];
@@ -775,6 +782,9 @@ std::string nodeExpr(const mlgpu_graph* g, size_t i, int l, const std::string& p
         s << "p" << i << L << ".next_x(" << idx << ", " << arg(0) << ", " << arg(1) << ", " << arg(2) << ")";
       else if (mlgpu_proc_is_vector_rate(n.kind))
         s << "p" << i << L << ".next_n(" << idx << ")";
+      else if (earlyRingReads(g, n))  // ring layout 0: the read was issued as soon as the delay time was known (emitNodes: pre), here the write and the value
+        s << "p" << i << L << (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY ? ".post_i<" : ".post<") << n.earlyPending << ">("
+          << (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY ? idx + ", " : std::string()) << arg(0) << ")";
       else if (n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY)
         s << "p" << i << L << ".next_i(" << idx << ", " << arg(0) << ", " << arg(1) << ((g->sectorRings && n.region < 0) ? ", qq * 4 + k" : "") << ")";
       else if (g->sectorRings && n.region < 0 && mlgpu_proc_rings(n.kind))
@@ -910,6 +920,9 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       }
   if (g->sectorRings && g->totalRings) s << "  __shared__ __attribute__((aligned(16))) float ldsRings[" << 4 * sectorLdsPerWave << "];  // [wavefront][node: held sectors, history rows]\n";
   else if (!g->transposedRings && g->windowedRings && g->totalRings) s << "  __shared__ float ldsRings[" << (size_t)g->totalRings * 8 * 256 << "];  // write windows, [ring][8][256 lanes]\n";
+  if (g->earlyRows)
+    s << "  __shared__ float ldsEarly[" << 4 * g->earlySlots * 64 << "];  // [wavefront][ring read][64 lanes]: where the early ring reads land\n"
+      << "  float* const ldsEarlyWave = ldsEarly + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * " << g->earlySlots * 64 << ";\n";
   // a group sum of 16 voices (one instrument's voices): four quads of the wavefront's 64 voices are parked in LDS and every lane
   // then adds up ONE (instrument, sample) pair in voice order - 2.3 instructions per voice-sample where the lane-shift chain
   // (group_sum_in_order) takes 16 (MLGPU_GRAPH_GROUP_SUM=dpp: that form)
@@ -961,6 +974,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         s << "  Proc<" << n.kind << "> p" << i << L << ";\n  const VoiceMem m" << i << L << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v" << L
           << ", a.state + (size_t)" << n.sOff << " * a.V + v" << L << ", a.V";
         if (n.ringLen && !g->windowedRings) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v" << L << ", " << (n.ringLen - 1) << "u";
+        if (n.ringLen && earlyRingReads(g, n)) s << ", ldsEarlyWave + " << n.earlySlot * 64;
         if (n.ringLen && g->transposedRings)
           s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (" << ringLane << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
             << " + (" << ringLane << L << " & 255) * 16, " << (n.ringLen - 1)
@@ -1210,12 +1224,80 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
     };
     std::function<void(int, const Ctx&)> emitNodes;   // the nodes of region r (-1: the outer graph) in context c
     std::function<void(int, const Ctx&)> emitRegion;  // region r, entered from context c of its parent
+    // ring layout 0: where a delay node's read goes - right after the last audio-rate node its delay time needs (-1: at the sample's top)
+    auto emitPre = [&](size_t dn, const Ctx& c) {
+      const Node& m = g->nodes[dn];
+      for (int l = 0; l < VL; ++l)
+      {
+        s << c.indent << "p" << dn << sfx(l) << (m.kind == MLGPU_PROC_PITCHBENDABLE_DELAY ? ".pre_i(" + c.idx : ".pre(");
+        for (size_t a = 1; a < m.in.size(); ++a) s << ((a > 1 || m.kind == MLGPU_PROC_PITCHBENDABLE_DELAY) ? ", " : "") << name(m.in[a], "", l);
+        s << ");\n";
+      }
+    };
+    // The nodes a delay time is computed from go to the top of the sample with the reads behind them, where nothing of this sample
+    // has been stored yet: plain nodes only (operators, inputs, one-vector feedback values, processors without rings - each keeps its
+    // own state, so their order among independent nodes is free), and only those whose inputs are such nodes themselves.
+    std::vector<char> movable(g->nodes.size(), 0), hoisted(g->nodes.size(), 0);
+    std::vector<size_t> batch;  // the delay nodes whose reads are issued at the top, in issue order
+    if (g->earlyRows)
+    {
+      for (size_t j = 0; j < g->nodes.size(); ++j)
+      {
+        const Node& m = g->nodes[j];
+        if (m.rate != RATE_AUDIO)
+        {
+          movable[j] = 1;  // (a value per voice or per DSPVector: there before the sample loop)
+          continue;
+        }
+        bool ok = m.region < 0 && m.role == ROLE_NONE && (m.type == NODE_OP || m.type == NODE_INPUT || m.type == NODE_FEEDBACK || m.type == NODE_VOP || (m.type == NODE_PROC && !mlgpu_proc_rings(m.kind) && streamLockSawOf(g, j) < 0));
+        if (m.type != NODE_FEEDBACK)
+          for (int in : m.in) ok = ok && movable[(size_t)in];
+        movable[j] = ok;
+      }
+      std::function<void(int)> want = [&](int j) {
+        if (hoisted[(size_t)j] || g->nodes[(size_t)j].rate != RATE_AUDIO) return;
+        hoisted[(size_t)j] = 1;
+        if (g->nodes[(size_t)j].type != NODE_FEEDBACK)
+          for (int in : g->nodes[(size_t)j].in) want(in);
+      };
+      for (size_t dn = 0; dn < g->nodes.size(); ++dn)
+      {
+        const Node& m = g->nodes[dn];
+        if (!earlyRingReads(g, m)) continue;
+        bool all = true;
+        for (size_t a = 1; a < m.in.size(); ++a) all = all && movable[(size_t)m.in[a]];
+        if (!all) continue;
+        for (size_t a = 1; a < m.in.size(); ++a) want(m.in[a]);
+        batch.push_back(dn);
+      }
+      // what is still in flight behind a node's loads when they have landed: at least the loads of the batch issued after them
+      int after = 0;
+      for (size_t b = batch.size(); b-- > 0;)
+      {
+        g->nodes[batch[b]].earlyPending = after;
+        after += g->nodes[batch[b]].kind == MLGPU_PROC_PITCHBENDABLE_DELAY ? 2 : 1;
+      }
+    }
+    auto inBatch = [&](size_t dn) { return std::find(batch.begin(), batch.end(), dn) != batch.end(); };
+    auto emitPlain = [&](size_t j, const Ctx& c) {
+      const Node& m = g->nodes[j];
+      for (int l = 0; l < VL; ++l)
+        s << c.indent << "const float " << name((int)j, c.sfx, l) << " = " << nodeExpr(g, j, l, c.sfx, c.idx) << ";"
+          << (l == 0 && !m.name.empty() ? "  // " + m.name : std::string()) << "\n";
+    };
     emitNodes = [&](int r, const Ctx& c) {
       std::vector<char> entered(g->regions.size(), 0);
+      if (r < 0 && g->earlyRows)
+      {
+        for (size_t j = 0; j < g->nodes.size(); ++j)
+          if (hoisted[j]) emitPlain(j, c);
+        for (size_t dn : batch) emitPre(dn, c);
+      }
       for (size_t j = 0; j < g->nodes.size(); ++j)
       {
         const Node& m = g->nodes[j];
         if (m.rate != RATE_AUDIO) continue;
+        if (r < 0 && hoisted[j]) continue;  // at the top of the sample
         if (m.region != r)
         {
           // the first node of a region nested directly here: the whole region goes in at this point
@@ -1264,9 +1346,8 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
             }
           }
         }
-        for (int l = 0; l < VL; ++l)
-          s << c.indent << "const float " << name((int)j, c.sfx, l) << " = " << nodeExpr(g, j, l, c.sfx, c.idx) << ";"
-            << (l == 0 && !m.name.empty() ? "  // " + m.name : std::string()) << "\n";
+        if (r < 0 && earlyRingReads(g, m) && !inBatch(j)) emitPre(j, c);  // (a delay time made of this sample's own signal: read and value together)
+        emitPlain(j, c);
       }
       if (r < 0) return;
       // fn's own one-vector feedback (slot = the sample index inside fn's DSPVector), then the end of fn's DSPVector
@@ -2262,6 +2343,31 @@ extern "C"
                                                  " rings) next to " + kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB");
     if (ldsOther > kLdsBytes)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: " + kib(ldsOther) + " of LDS for the outputs summed inside the kernel (21 KiB per mixed-down output, 20.3 KiB per 16-voice group sum); a workgroup has 160 KiB");
+    // ring layout 0: the outer graph's ring reads by LDS-DMA ahead of the sample's arithmetic, a 256-byte landing slot per read and wavefront
+    g->earlyRows = false;
+    g->earlySlots = 0;
+    for (Node& n : g->nodes) n.earlySlot = -1;
+    {
+      const char* er = getenv("MLGPU_GRAPH_EARLY_READS");  // developer knob (A / B): 0 = the plain loads
+      if (!g->windowedRings && g->totalRings && !(er && !strcmp(er, "0")))
+      {
+        int slots = 0;
+        for (Node& n : g->nodes)
+          if (n.type == NODE_PROC && n.region < 0 && n.role == ROLE_NONE && mlgpu_proc_rings(n.kind))
+          {
+            n.earlySlot = slots;
+            slots += n.kind == MLGPU_PROC_PITCHBENDABLE_DELAY ? 2 : 1;
+          }
+        // (one ring - a plucked string - has nothing to issue together: 0.127 of the peak with the early read against 0.142 without)
+        if (slots >= 3 && (size_t)slots * 4 * 64 * sizeof(float) + ldsOther <= kLdsBytes)
+        {
+          g->earlyRows = true;
+          g->earlySlots = slots;
+        }
+        else
+          for (Node& n : g->nodes) n.earlySlot = -1;
+      }
+    }
     const char* forced = getenv("MLGPU_GRAPH_UNROLL");  // developer knob: quads per trip of the sample loop
     // delay graphs wait on their ring reads: two quads per trip keep more of them in flight (allpass4: 5.4 vs 4.5 x 10^10)
     g->unrollQ = forced ? std::max(1, atoi(forced)) : ((g->totalRings && !g->windowedRings) ? 2 : 1);

@@ -1933,6 +1933,43 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     return y;
   }
 
+  // ---- layout 0 (rows): the sample's reads ahead of its arithmetic ----
+  // A ring read depends on nothing the current sample computes (d >= 1: it is d samples old), but written where the delay node stands
+  // in the graph it sits behind that sample's stores to the other rings - which the compiler must assume to alias - so a graph with
+  // many rings walks one memory round trip after the other: the reference's reverb example (24 rings) waited 0.66 of its wave cycles
+  // at 3.4 TB/s, and a plain load moved up in the source is moved back down to its use by the scheduler. The generated kernel
+  // therefore calls readEarly as soon as the node's delay time is known - for the reverb at the top of the sample, all 24 loads back
+  // to back - and the load is LDS-DMA (global_load_lds_dword: no destination register, the wavefront's 64 values land in a 256-byte
+  // slot of LDS, m.lds + slot * 64), which the compiler can neither sink below the stores nor see the completion of: early<PENDING>
+  // waits for it by count (memory operations return in order; PENDING = the loads the kernel issued AFTER this one before it issues
+  // anything else, a lower bound of what may still be in flight when this one has landed) and reads the slot. The value is the
+  // sample itself where the read lands on the write (a delay time of 0, or of the ring's whole length: the reference writes, then
+  // reads).
+  MLD void readEarly(const VoiceMem& m, int ringIdx, int32_t d, int slot) const
+  {
+    const float* src = m.mem + (size_t)((uint32_t)ringIdx * (m.memMask + 1) + ((w - (uint32_t)d) & m.memMask)) * m.V;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(m.lds + slot * 64), 4, 0, 0);
+  }
+  template <int PENDING>
+  static MLD void earlyWait()
+  {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING < 63 ? PENDING : 63) : "memory");
+  }
+  MLD float early(const VoiceMem& m, int32_t d, int slot, float x) const
+  {
+    const float y = m.lds[slot * 64 + (int)(threadIdx.x & 63u)];
+    return ((uint32_t)d & m.memMask) == 0u ? x : y;
+  }
+  template <int PENDING>
+  MLD float finishRows(const VoiceMem& m, int ringIdx, float x, int32_t d, int slot)
+  {
+    m.ringSet((uint32_t)ringIdx * (m.memMask + 1) + w, x);
+    earlyWait<PENDING>();
+    const float y = early(m, d, slot, x);
+    w = (w + 1) & m.memMask;
+    return y;
+  }
+
   // K: the sample's place in its trip of 8 (layout 4 only; the generated kernel passes a constant)
   template <bool VARY = false>
   MLD float sample(const VoiceMem& m, int ringIdx, float x, int32_t d, int K = 0)
@@ -1975,6 +2012,18 @@ struct Proc<MLGPU_PROC_INTEGER_DELAY>  // :801-914   C{}  S{writeIndex:u32, dela
   {
     delay = sse_cvtt(d);
     return ringc.sample(mem, 0, x, delay);
+  }
+  // layout 0: the read as early as the delay time is known (pre), the write and the value where the node stands (post)
+  MLD void pre() { ringc.readEarly(mem, 0, delay, 0); }
+  MLD void pre(float d)
+  {
+    delay = sse_cvtt(d);
+    ringc.readEarly(mem, 0, delay, 0);
+  }
+  template <int PENDING>
+  MLD float post(float x)
+  {
+    return ringc.finishRows<PENDING>(mem, 0, x, delay, 0);
   }
   // layout 4: the same with the sample's place K in its trip of 8; trip_begin before each trip
   MLD void trip_begin() { ringc.tripBegin(mem, 0, delay); }
@@ -2094,6 +2143,22 @@ struct Proc<MLGPU_PROC_FRACTIONAL_DELAY>  // :971-1044  C{}  S{writeIndex, x1, y
     if (f2u(ticks) != 0u) f.setDelay(d);
     return f.sample(mem, 0, x);
   }
+  MLD void pre() { f.ringc.readEarly(mem, 0, f.delayInt, 0); }
+  MLD void pre(float d)
+  {
+    f.setDelay(d);
+    f.ringc.readEarly(mem, 0, f.delayInt, 0);
+  }
+  MLD void pre(float d, float ticks)
+  {
+    if (f2u(ticks) != 0u) f.setDelay(d);
+    f.ringc.readEarly(mem, 0, f.delayInt, 0);
+  }
+  template <int PENDING>
+  MLD float post(float x)
+  {
+    return f.ap(f.ringc.finishRows<PENDING>(mem, 0, x, f.delayInt, 0));
+  }
   MLD void trip_begin() { f.ringc.tripBegin(mem, 0, f.delayInt); }
   MLD float next_k(int K, float x) { return f.sample(mem, 0, x, K); }
   MLD float next_k(int K, float x, float d)
@@ -2155,7 +2220,7 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
     else if (__builtin_amdgcn_ballot_w64(f1.delayInt != f2.delayInt) != 0) f2.ringc.tripBegin(mem, 0, f2.delayInt, 1);
     else f2.ringc.sTag = f2.ringc.sNTag = kTNone;  // (one read for both, as far as the prologue can tell)
   }
-  MLD float next_i(int n, float x, float d, int K = 0)
+  MLD void update_delays(int n, float d)
   {
     const int r = n & 31;
     if ((n & 15) == 0)  // one branch and selects over values: two `if (...) fN.setDelay(d)` get merged by the optimizer
@@ -2169,6 +2234,43 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
       f2.delayInt = first ? f2.delayInt : ndInt;
       f2.apCoeff = first ? f2.apCoeff : ndCoeff;
     }
+  }
+  // layout 0: the two reads as soon as the delay time is known (the second ring is the first while the write indices agree: rowsOne),
+  // the write(s) and the crossfade where the node stands
+  MLD void pre_i(int n, float d)
+  {
+    update_delays(n, d);
+    f2.ringc.w = rowsOne ? f1.ringc.w : f2.ringc.w;
+    f1.ringc.readEarly(mem, 0, f1.delayInt, 0);
+    f2.ringc.readEarly(mem, rowsOne ? 0 : 1, f2.delayInt, 1);
+  }
+  template <int PENDING>
+  MLD float post_i(int n, float x)
+  {
+    const int r = n & 31;
+    float a, b;
+    if (rowsOne)
+    {
+      const uint32_t w = f1.ringc.w;
+      mem.ringSet(w, x);
+      RingCore::earlyWait<PENDING>();
+      a = f1.ringc.early(mem, f1.delayInt, 0, x);
+      b = f2.ringc.early(mem, f2.delayInt, 1, x);
+      f1.ringc.w = f2.ringc.w = (w + 1) & mem.memMask;
+    }
+    else
+    {
+      a = f1.ringc.finishRows<PENDING>(mem, 0, x, f1.delayInt, 0);
+      b = f2.ringc.finishRows<PENDING>(mem, 1, x, f2.delayInt, 1);
+    }
+    const float y1 = f1.ap(a), y2 = f2.ap(b);
+    const float fade = 2.f * ((r > 16) ? 1.0f - (float)r / 32.f : (float)r / 32.f);
+    return y1 + (fade * (y2 - y1));
+  }
+  MLD float next_i(int n, float x, float d, int K = 0)
+  {
+    const int r = n & 31;
+    update_delays(n, d);
     float y1, y2;
     if (kRingSectors && oneRing)
     {

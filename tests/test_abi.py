@@ -131,7 +131,7 @@ def test_offline_graph_emit_keeps_processors_in_registers(windows):
     scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", notes).group(1))
     lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", notes).group(1))
     assert vgpr <= 256
-    assert lds == (8 * 8 * 256 * 4 if windows else 0)
+    assert lds == (8 * 8 * 256 * 4 if windows else 8 * 4 * 64 * 4)   # rows: a 256-byte landing slot per ring read and wavefront (the early reads)
     # the windowed form is held to two waves per SIMD (256 registers): a few dozen spilled values are the price; a processor
     # object living in scratch would be several hundred bytes
     assert scratch == 0 if not windows else scratch <= 256

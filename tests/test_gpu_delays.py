@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from graph_oracle import evaluate_stream, new_stream_state
-from inputs import DELAY_CASES, assert_bits_equal, delay_case, lcg_noise
+from inputs import DELAY_CASES, assert_bits_equal, delay_case, lcg_noise, stepped
 from madronalib_amd import patches
 from madronalib_amd.constants import Layout, Op, Proc
 
@@ -351,3 +351,70 @@ def test_transposed_rings_random_graphs(eng):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(40, 11, eng) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+def test_rows_early_reads_equal_plain_rows(eng, monkeypatch, seed):
+    """Ring layout 0 with three or more ring reads per sample issues them ahead of the sample's arithmetic by LDS-DMA (graph.hip:
+    earlyRows, RingCore::readEarly / early). Random chains of 3 .. 6 delay nodes of all three kinds - delay times from inputs (read at the
+    top of the sample, together), from a constant, none at all (the state's), or made of the previous node's output (read where the node
+    stands) - with times of 0, of the ring's whole length and beyond, several launches with carried state, whole and ragged wavefronts:
+    outputs and every state word against the same graph with the plain loads (MLGPU_GRAPH_EARLY_READS=0, the form the oracle tests of
+    rounds 2-5 pinned), bit for bit."""
+    import madronalib_amd as ml
+    rng = np.random.default_rng(seed)
+    for case in range(6):
+        V = int(rng.integers(1, 300)) if case % 2 else 64 * int(rng.integers(1, 5))
+        T, launches = int(rng.integers(1, 6)), 3
+        S = 64 * T * launches
+        n = int(rng.integers(3, 7))
+        dmax = float([40.0, 192.0, 700.0][int(rng.integers(0, 3))])
+        ring = 1 << int(np.ceil(np.log2(max(64, int(dmax) + 64))))
+        kinds = [[Proc.INTEGER_DELAY, Proc.FRACTIONAL_DELAY, Proc.PITCHBENDABLE_DELAY][int(rng.integers(0, 3))] for _ in range(n)]
+        tmodes = [int(rng.integers(0, 4)) for _ in range(n)]   # 0 an input, 1 a constant, 2 none, 3 made of the previous node's output
+        sig = {"x": lcg_noise(np.arange(V, dtype=np.uint32) + np.uint32(seed * 131 + case), S)}
+        desc = [dict(name="x", type="input"), dict(name="half", type="const", value=0.5), dict(name="scale", type="const", value=float(dmax))]
+        src = "x"
+        for i, (kind, tm) in enumerate(zip(kinds, tmodes)):
+            if kind == Proc.PITCHBENDABLE_DELAY and tm == 2:
+                tm = 0                                         # (its call takes a delay time)
+            ins = [src]
+            if tm == 0:
+                d = stepped(V, S, seed * 17 + i, 0.0, dmax + 0.9, 1, 150)
+                d[:, ::97] = 0.0                               # the read lands on the write ...
+                d[:, 5::131] = np.float32(ring)                # ... also by the ring's whole length
+                d[:, 7::173] = np.float32(ring + 3)            # ... and beyond it
+                sig[f"dt{i}"] = d
+                desc.append(dict(name=f"dt{i}", type="input"))
+                ins.append(f"dt{i}")
+            elif tm == 1:
+                desc.append(dict(name=f"dt{i}", type="const", value=float(rng.integers(0, int(dmax)))))
+                ins.append(f"dt{i}")
+            elif tm == 3:
+                desc += [dict(name=f"ab{i}", type="op", kind=Op.ABS, inputs=[src]), dict(name=f"dt{i}", type="op", kind=Op.MULTIPLY, inputs=[f"ab{i}", "scale"])]
+                ins.append(f"dt{i}")
+            desc.append(dict(name=f"d{i}", type="proc", kind=kind, inputs=ins, max_delay=dmax))
+            desc += [dict(name=f"m{i}", type="op", kind=Op.ADD, inputs=[f"d{i}", "x"]), dict(name=f"s{i}", type="op", kind=Op.MULTIPLY, inputs=[f"m{i}", "half"])]
+            src = f"s{i}"
+        got = {}
+        for early in ("1", "0"):
+            monkeypatch.setenv("MLGPU_GRAPH_EARLY_READS", early)
+            g = ml.Graph(eng, V, desc, [src, "d0"], delay_windows=0)
+            assert ("ldsEarly" in g.source) == (early == "1")
+            for i, kind in enumerate(kinds):
+                g.set_state(f"d{i}", 0, ((np.arange(V, dtype=np.uint32) * (1 if case % 3 == 0 else 0) * 5 + case * 11 + i) % ring).astype(np.uint32))
+                if kind == Proc.INTEGER_DELAY:
+                    g.set_state(f"d{i}", 1, np.full(V, (7 * i + case) % int(dmax), np.uint32))
+            outs = []
+            for k in range(launches):
+                part = {name: np.ascontiguousarray(a[:, k * 64 * T:(k + 1) * 64 * T]) for name, a in sig.items()}
+                outs.append(np.stack(g.process_host(T, part, Layout.QUAD)))
+            states = []
+            for i in range(n):
+                states += [g.get_state(f"d{i}", j) for j in range(g.num_state(f"d{i}"))]
+            got[early] = (np.concatenate(outs, 2), np.stack(states))
+            g.close()
+        assert np.any(got["1"][0] != 0)
+        assert_bits_equal(got["1"][0], got["0"][0], False, f"seed {seed} case {case}: outputs, early ring reads against the plain rows")
+        assert np.array_equal(got["1"][1], got["0"][1]), f"seed {seed} case {case}: state words"
