@@ -580,6 +580,7 @@ struct mlgpu_graph
   bool windowedRings{false};     // rings as [block][chunk][lane][8] behind LDS windows (mlgpu_graph_set_delay_layout)
   bool fbAhead{true};            // kept DSPVectors (feedback nodes) are fetched two quads ahead; MLGPU_GRAPH_FB_AHEAD=0 for A / B
   bool transposedIfPossible{false};  // graph_set_delay_layout(3)
+  bool rowAddr32{false};         // layout 0: ring rows behind 32-bit offsets from a wave-uniform base where a ring allows it (VoiceMem::ringPtr); set at compile
   bool earlyRows{false};         // layout 0: the ring reads of the outer graph's delay nodes issued ahead by LDS-DMA (RingCore::readEarly); set at compile
   int earlySlots{0};             // their landing slots per wavefront
   bool sectorRings{false};       // layout 4: layout 1's memory, no LDS, trips of 8 samples with every ring's loads in the trip's prologue (implies windowedRings)
@@ -951,9 +952,20 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   else
     s << "  const size_t v_0 = blk * " << 256 * VL << " + threadIdx.x;\n  if (v_0 >= a.V) return;\n";
   const std::string ringLane = partialWaves ? "vr" : "v";
+  // a row of the state memory at this lane: the row's address is wave-uniform (scalar arithmetic), the lane's place a 32-bit offset on
+  // it - one memory instruction where `a.state[row * a.V + v]` with a 64-bit v is a 64-bit vector add in front of it
+  const bool stateAddr32 = g->V < ((size_t)1 << 30);
+  if (stateAddr32) s << "  const uint32_t v4_0 = (uint32_t)v_0 * 4u;\n";
+  auto stateRef = [&](const std::string& row, int l) {
+    return stateAddr32 ? "*state_row(a, " + row + ", v4" + sfx(l) + ")" : "a.state[(size_t)(" + row + ") * a.V + v" + sfx(l) + "]";
+  };
   if (!g->waveClockPath.empty()) s << "  const unsigned long long waveClock0 = __builtin_amdgcn_s_memrealtime();\n";
   // a lane whose second voice does not exist recomputes its first one: same inputs, same state, same stores
-  for (int l = 1; l < VL; ++l) s << "  const size_t v" << sfx(l) << " = (v_0 + " << 256 * l << " < a.V) ? v_0 + " << 256 * l << " : v_0;\n";
+  for (int l = 1; l < VL; ++l)
+  {
+    s << "  const size_t v" << sfx(l) << " = (v_0 + " << 256 * l << " < a.V) ? v_0 + " << 256 * l << " : v_0;\n";
+    if (stateAddr32) s << "  const uint32_t v4" << sfx(l) << " = (uint32_t)v" << sfx(l) << " * 4u;\n";
+  }
   auto emit = [&](size_t i, const char* indent) {
     for (int l = 0; l < VL; ++l)
     {
@@ -973,8 +985,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       {
         s << "  Proc<" << n.kind << "> p" << i << L << ";\n  const VoiceMem m" << i << L << "{a.coeffs + (size_t)" << n.cOff << " * a.V + v" << L
           << ", a.state + (size_t)" << n.sOff << " * a.V + v" << L << ", a.V";
-        if (n.ringLen && !g->windowedRings) s << ", a.mem + (size_t)" << n.memOff << " * a.V + v" << L << ", " << (n.ringLen - 1) << "u";
-        if (n.ringLen && earlyRingReads(g, n)) s << ", ldsEarlyWave + " << n.earlySlot * 64;
+        // (a ring of at most 4 GiB over the bank: 32-bit row offsets from the wave-uniform start of the ring)
+        const bool a32 = n.ringLen && g->rowAddr32 && (size_t)n.ringLen * g->V * sizeof(float) <= ((size_t)1 << 32) && n.ringLen < ((size_t)1 << 24);
+        if (n.ringLen && !g->windowedRings) s << ", a.mem + (size_t)" << n.memOff << " * a.V" << (a32 ? std::string() : " + v" + std::string(L)) << ", " << (n.ringLen - 1) << "u";
+        if (n.ringLen && !g->windowedRings && (earlyRingReads(g, n) || a32)) s << ", " << (earlyRingReads(g, n) ? "ldsEarlyWave + " + std::to_string(n.earlySlot * 64) : std::string("nullptr"));
+        if (a32) s << ", 0u, (uint32_t)v" << L << " * 4u, (uint32_t)a.V * 4u, true";
         if (n.ringLen && g->transposedRings)
           s << ", a.mem + (size_t)" << n.memOff << " * ((a.V + 255) & ~(size_t)255) + (" << ringLane << L << " >> 8) * (size_t)" << n.ringLen * (size_t)mlgpu_proc_rings(n.kind) * 256
             << " + (" << ringLane << L << " & 255) * 16, " << (n.ringLen - 1)
@@ -1080,8 +1095,8 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
         for (int l = 0; l < VL; ++l)
         {
           const std::string nm = std::to_string(i) + sfx(l);
-          s << "  float fbn" << nm << "[4], fbm" << nm << "[4];\n#pragma unroll\n  for (int kk = 0; kk < 4; ++kk)\n  {\n    fbn" << nm << "[kk] = u2f(a.state[(size_t)(" << g->nodes[i].sOff
-            << " + kk) * a.V + v" << sfx(l) << "]);\n    fbm" << nm << "[kk] = u2f(a.state[(size_t)(" << g->nodes[i].sOff << " + 4 + kk) * a.V + v" << sfx(l) << "]);\n  }\n";
+          s << "  float fbn" << nm << "[4], fbm" << nm << "[4];\n#pragma unroll\n  for (int kk = 0; kk < 4; ++kk)\n  {\n    fbn" << nm << "[kk] = u2f(" << stateRef(std::to_string(g->nodes[i].sOff) + " + kk", l)
+            << ");\n    fbm" << nm << "[kk] = u2f(" << stateRef(std::to_string(g->nodes[i].sOff) + " + 4 + kk", l) << ");\n  }\n";
         }
   if (g->takeTurns) s << "  const uint32_t turn0 = wave_slot();\n";
   s << "  for (size_t t = 0; t < a.T; ++t)\n  {\n";
@@ -1195,11 +1210,11 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       {
         const std::string nm = std::to_string(i) + sfx(l);
         if (!g->fbAhead)
-          s << "      float fbv" << nm << "[4];\n#pragma unroll\n      for (int kk = 0; kk < 4; ++kk) fbv" << nm << "[kk] = u2f(a.state[(size_t)("
-            << g->nodes[i].sOff << " + q * 4 + kk) * a.V + v" << sfx(l) << "]);\n";
+          s << "      float fbv" << nm << "[4];\n#pragma unroll\n      for (int kk = 0; kk < 4; ++kk) fbv" << nm << "[kk] = u2f("
+            << stateRef(std::to_string(g->nodes[i].sOff) + " + q * 4 + kk", l) << ");\n";
         else
           s << "      float fbv" << nm << "[4];\n#pragma unroll\n      for (int kk = 0; kk < 4; ++kk)\n      {\n        fbv" << nm << "[kk] = fbn" << nm << "[kk];\n        fbn" << nm
-            << "[kk] = fbm" << nm << "[kk];\n        fbm" << nm << "[kk] = u2f(a.state[(size_t)(" << g->nodes[i].sOff << " + ((q + 2) & 15) * 4 + kk) * a.V + v" << sfx(l) << "]);\n      }\n";
+            << "[kk] = fbm" << nm << "[kk];\n        fbm" << nm << "[kk] = u2f(" << stateRef(std::to_string(g->nodes[i].sOff) + " + ((q + 2) & 15) * 4 + kk", l) << ");\n      }\n";
       }
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_PROC && (g->nodes[i].kind == MLGPU_PROC_LINEAR_GLIDE || g->nodes[i].kind == MLGPU_PROC_HALF_BAND_BUFFERED))
@@ -1354,7 +1369,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
       for (size_t j = 0; j < g->nodes.size(); ++j)
         if (g->nodes[j].region == r && g->nodes[j].type == NODE_FEEDBACK && g->nodes[j].fbSource >= 0)
           for (int l = 0; l < VL; ++l)
-            s << c.indent << "a.state[(size_t)(" << g->nodes[j].sOff << " + " << c.idx << ") * a.V + v" << sfx(l) << "] = f2u(" << name(g->nodes[j].fbSource, c.sfx, l)
+            s << c.indent << stateRef(std::to_string(g->nodes[j].sOff) + " + " + c.idx, l) << " = f2u(" << name(g->nodes[j].fbSource, c.sfx, l)
               << ");\n";
       bool any = false;
       for (size_t j = 0; j < g->nodes.size(); ++j)
@@ -1428,7 +1443,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   for (size_t i = 0; i < g->nodes.size(); ++i)
     if (g->nodes[i].type == NODE_FEEDBACK && g->nodes[i].fbSource >= 0 && g->nodes[i].region < 0)
       for (int l = 0; l < VL; ++l)
-        s << "        a.state[(size_t)(" << g->nodes[i].sOff << " + q * 4 + k) * a.V + v" << sfx(l) << "] = f2u(n" << g->nodes[i].fbSource << sfx(l) << ");\n";
+        s << "        " << stateRef(std::to_string(g->nodes[i].sOff) + " + q * 4 + k", l) << " = f2u(n" << g->nodes[i].fbSource << sfx(l) << ");\n";
   s << "      }\n";
   for (size_t o = 0; o < g->outputs.size(); ++o)
     if (ldsSum(o))
@@ -2343,6 +2358,10 @@ extern "C"
                                                  " rings) next to " + kib(ldsOther) + " of output strips and tables; a workgroup has 160 KiB");
     if (ldsOther > kLdsBytes)
       return gfail(g, MLGPU_ERR_UNSUPPORTED, "graph_compile: " + kib(ldsOther) + " of LDS for the outputs summed inside the kernel (21 KiB per mixed-down output, 20.3 KiB per 16-voice group sum); a workgroup has 160 KiB");
+    // ring layout 0: rows behind 32-bit offsets where every delay node's memory stays below 4 GiB (VoiceMem::ringPtr)
+    g->rowAddr32 = false;
+    if (!g->windowedRings && g->totalRings && g->V < ((size_t)1 << 22) && !(getenv("MLGPU_GRAPH_ROW_ADDR32") && !strcmp(getenv("MLGPU_GRAPH_ROW_ADDR32"), "0")))
+      g->rowAddr32 = true;  // (node by node in the generator: a ring of the bank at most 4 GiB)
     // ring layout 0: the outer graph's ring reads by LDS-DMA ahead of the sample's arithmetic, a 256-byte landing slot per read and wavefront
     g->earlyRows = false;
     g->earlySlots = 0;

@@ -31,13 +31,24 @@ struct VoiceMem
   // 256-byte row per wavefront and the reads are coalesced whenever neighbouring voices use the same delay
   float* mem{nullptr};
   uint32_t memMask{0};
-  MLD float ring(uint32_t i) const { return mem[(size_t)i * V]; }
-  MLD void ringSet(uint32_t i, float x) const { mem[(size_t)i * V] = x; }
+// Sample i of ring ringIdx. Rows behind 32-bit offsets (addr32, set by the generated kernel where a ring of the bank is at most
+  // 4 GiB and the bank below 2^22 voices): `mem` is then the node's memory for the whole bank - wave-uniform, a scalar register pair,
+  // and so is the ring's start in it - and a row's place i * 4 V + 4 v one v_mad_u32_u24 on top of that, where the 64-bit form costs
+  // two v_mad_u64_u32 and a 64-bit add per access (the reference's reverb example: 170 of its 1 300 instructions per sample).
+  MLD float* ringPtr(int ringIdx, uint32_t i) const
+  {
+    if (addr32) return (float*)((char*)(mem + (size_t)((uint32_t)ringIdx * (memMask + 1)) * V) + (__umul24(i, V4) + lane4));
+    return mem + (size_t)((uint32_t)ringIdx * (memMask + 1) + i) * V;
+  }
+  MLD float ring(int ringIdx, uint32_t i) const { return *ringPtr(ringIdx, i); }
+  MLD void ringSet(int ringIdx, uint32_t i, float x) const { *ringPtr(ringIdx, i) = x; }
   // Windowed rings (mlgpu_graph_set_delay_layout, the generated source defines MLGPU_RING_WINDOWS 1): `mem` is this lane's
   // sector of chunk 0 in the block's [chunk][lane][8] ring storage and `lds` this lane's column of the workgroup's write
   // windows, [ring][kRingWindow][256 lanes] (RingCore below).
   float* lds{nullptr};
   uint32_t ldsHist{0};  // ring layout 4: where this node's history rows start, in floats from `lds` (after its rings' held sectors)
+  uint32_t lane4{0}, V4{0};  // addr32: 4 * the lane's voice, 4 * the bank's voices
+  bool addr32{false};
   MLD float c(int i) const { return coeffs[(size_t)i * V]; }
   MLD uint32_t s(int i) const { return state[(size_t)i * V]; }
   MLD void set(int i, uint32_t x) const { state[(size_t)i * V] = x; }
@@ -1947,7 +1958,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   // reads).
   MLD void readEarly(const VoiceMem& m, int ringIdx, int32_t d, int slot) const
   {
-    const float* src = m.mem + (size_t)((uint32_t)ringIdx * (m.memMask + 1) + ((w - (uint32_t)d) & m.memMask)) * m.V;
+    const float* src = m.ringPtr(ringIdx, (w - (uint32_t)d) & m.memMask);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(m.lds + slot * 64), 4, 0, 0);
   }
   template <int PENDING>
@@ -1963,7 +1974,7 @@ struct RingCore  // IntegerDelay's buffer, index and mask
   template <int PENDING>
   MLD float finishRows(const VoiceMem& m, int ringIdx, float x, int32_t d, int slot)
   {
-    m.ringSet((uint32_t)ringIdx * (m.memMask + 1) + w, x);
+    m.ringSet(ringIdx, w, x);
     earlyWait<PENDING>();
     const float y = early(m, d, slot, x);
     w = (w + 1) & m.memMask;
@@ -1977,10 +1988,9 @@ struct RingCore  // IntegerDelay's buffer, index and mask
     if (kRingSectors) return sampleS<VARY>(m, ringIdx, x, d, K);
     if (kRingTransposed) return sampleT(m, ringIdx, x, d);
     if (kRingWindows) return sampleWindowed(m, ringIdx, x, d);
-    const uint32_t ringBase = (uint32_t)ringIdx * (m.memMask + 1);
-    m.ringSet(ringBase + w, x);
+    m.ringSet(ringIdx, w, x);
     const uint32_t r = (w - (uint32_t)d) & m.memMask;
-    const float y = m.ring(ringBase + r);
+    const float y = m.ring(ringIdx, r);
     w = (w + 1) & m.memMask;
     return y;
   }
@@ -2252,7 +2262,7 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
     if (rowsOne)
     {
       const uint32_t w = f1.ringc.w;
-      mem.ringSet(w, x);
+      mem.ringSet(0, w, x);
       RingCore::earlyWait<PENDING>();
       a = f1.ringc.early(mem, f1.delayInt, 0, x);
       b = f2.ringc.early(mem, f2.delayInt, 1, x);
@@ -2298,12 +2308,12 @@ struct Proc<MLGPU_PROC_PITCHBENDABLE_DELAY>  // :1050-1106  C{}  S{delay1: 5 wor
     else if (!kRingWindows && rowsOne)
     {
       const uint32_t w = f1.ringc.w;
-      mem.ringSet(w, x);
+      mem.ringSet(0, w, x);
       // (two loads, no branch: while the delay times agree the second one finds the first one's line in the vector cache. A wave-uniform
       // branch around it - and, tried next, the quad's reads of every ring issued together at the quad's top behind such branches - kept
       // the loads of a many-ring graph from overlapping: the reverb example 4.6 -> 7.2 / 6.3 ms, profiles/r06_ring_layouts.txt)
-      const float a = mem.ring((w - (uint32_t)f1.delayInt) & mem.memMask);
-      const float b = mem.ring((w - (uint32_t)f2.delayInt) & mem.memMask);
+      const float a = mem.ring(0, (w - (uint32_t)f1.delayInt) & mem.memMask);
+      const float b = mem.ring(0, (w - (uint32_t)f2.delayInt) & mem.memMask);
       f1.ringc.w = f2.ringc.w = (w + 1) & mem.memMask;
       y1 = f1.ap(a);
       y2 = f2.ap(b);

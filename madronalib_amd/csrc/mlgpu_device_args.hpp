@@ -84,3 +84,10 @@ struct GraphArgs
   EventsDev events;
   unsigned long long* waveClock;  // developer aid (MLGPU_GRAPH_WAVE_CLOCK): [wavefront][4] = start, end (100 MHz), HW_ID, XCC_ID; else nullptr
 };
+
+// row `row` of the state memory at the voice whose byte offset in a row is lane4: the row's address is wave-uniform (scalar
+// arithmetic), the lane's place a 32-bit offset on it - the memory instruction's own addressing, no vector add (graph.hip: stateRef)
+__device__ __forceinline__ uint32_t* state_row(const GraphArgs& a, size_t row, uint32_t lane4)
+{
+  return (uint32_t*)((char*)(a.state + row * a.V) + lane4);
+}
