@@ -954,7 +954,7 @@ std::string generateGraphSource(mlgpu_graph* g, int forceVl = 0)
   const std::string ringLane = partialWaves ? "vr" : "v";
   // a row of the state memory at this lane: the row's address is wave-uniform (scalar arithmetic), the lane's place a 32-bit offset on
   // it - one memory instruction where `a.state[row * a.V + v]` with a 64-bit v is a 64-bit vector add in front of it
-  const bool stateAddr32 = g->V < ((size_t)1 << 30);
+  const bool stateAddr32 = g->V < ((size_t)1 << 30) && !(getenv("MLGPU_GRAPH_ROW_ADDR32") && !strcmp(getenv("MLGPU_GRAPH_ROW_ADDR32"), "0"));  // (developer knob, A / B)
   if (stateAddr32) s << "  const uint32_t v4_0 = (uint32_t)v_0 * 4u;\n";
   auto stateRef = [&](const std::string& row, int l) {
     return stateAddr32 ? "*state_row(a, " + row + ", v4" + sfx(l) + ")" : "a.state[(size_t)(" + row + ") * a.V + v" + sfx(l) + "]";

@@ -398,10 +398,13 @@ def test_rows_early_reads_equal_plain_rows(eng, monkeypatch, seed):
             desc += [dict(name=f"m{i}", type="op", kind=Op.ADD, inputs=[f"d{i}", "x"]), dict(name=f"s{i}", type="op", kind=Op.MULTIPLY, inputs=[f"m{i}", "half"])]
             src = f"s{i}"
         got = {}
-        for early in ("1", "0"):
-            monkeypatch.setenv("MLGPU_GRAPH_EARLY_READS", early)
+        for early in ("1", "0", "round5"):
+            # "round5": neither the early reads nor the 32-bit row offsets (VoiceMem::ringPtr, state_row) - the rows as rounds 2-5 had them
+            monkeypatch.setenv("MLGPU_GRAPH_EARLY_READS", "1" if early == "1" else "0")
+            monkeypatch.setenv("MLGPU_GRAPH_ROW_ADDR32", "0" if early == "round5" else "1")
             g = ml.Graph(eng, V, desc, [src, "d0"], delay_windows=0)
             assert ("ldsEarly" in g.source) == (early == "1")
+            assert (", true}" in g.source) == (early != "round5")
             for i, kind in enumerate(kinds):
                 g.set_state(f"d{i}", 0, ((np.arange(V, dtype=np.uint32) * (1 if case % 3 == 0 else 0) * 5 + case * 11 + i) % ring).astype(np.uint32))
                 if kind == Proc.INTEGER_DELAY:
@@ -416,5 +419,6 @@ def test_rows_early_reads_equal_plain_rows(eng, monkeypatch, seed):
             got[early] = (np.concatenate(outs, 2), np.stack(states))
             g.close()
         assert np.any(got["1"][0] != 0)
-        assert_bits_equal(got["1"][0], got["0"][0], False, f"seed {seed} case {case}: outputs, early ring reads against the plain rows")
-        assert np.array_equal(got["1"][1], got["0"][1]), f"seed {seed} case {case}: state words"
+        for other in ("0", "round5"):
+            assert_bits_equal(got["1"][0], got[other][0], False, f"seed {seed} case {case}: outputs, early ring reads against the plain rows ({other})")
+            assert np.array_equal(got["1"][1], got[other][1]), f"seed {seed} case {case}: state words ({other})"

@@ -76,6 +76,8 @@ PY
 # the real-time block across GPUs: two ranks on this one GPU (the launch path and the bits, not a multi-GPU measurement)
 python bench.py --workload rt --gpus 2 --oversubscribe --steps 4 --warmup 1 2> $O/rt_group.err | tail -1 > $O/rt_group_2ranks_one_gpu.json
 tests/cpp/multi_engine_test > $O/multi_engine_test.txt 2>&1
+# random delay graphs, every ring layout against layout 0 (tools/ring_layout_soak.py), outputs and state words bit for bit
+{ for lay in 2 4 1; do MLGPU_SOAK_LAYOUT=$lay python tools/ring_layout_soak.py 300 $((60 + lay)) 2>&1 | tail -1; done; } > $O/ring_layout_soak.txt
 ( time python bench.py ) 2> $O/default_bench.time | tail -1 > $O/default_bench.json
 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $O/gpu_tests.txt
 for dd in $O/profiles_*; do python tools/summarize_profiles.py $dd r06 > $dd/summary.md 2>/dev/null; done
