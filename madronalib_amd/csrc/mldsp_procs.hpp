@@ -1786,13 +1786,13 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       float h[8];
       loadSector(m, ringIdx, s0, h);
       holdSector(m, slot, h);
-      sTag = s0;
+      sTag = far ? s0 : kTNone;  // (a tag vouches for a sector that was complete in memory when it was loaded: see tripStart)
     }
     // ... and the upper sector: usually asked for a whole trip ago already (tripStart's early request)
     if (__builtin_amdgcn_ballot_w64(far && sNTag != s1) != 0)
     {
       loadSector(m, ringIdx, s1, sN);
-      sNTag = s1;
+      sNTag = far ? s1 : kTNone;
     }
   }
   // sY = positions r0 .. r0 + 7 of the sixteen floats sH, sN (r0 & 7 = o): a barrel shifter, 11 + 9 + 8 selects
@@ -1848,14 +1848,20 @@ struct RingCore  // IntegerDelay's buffer, index and mask
       heldSector(m, slot, h);
     barrel(r0 & 7u, h);
     holdSector(m, slot, sN);  // the upper sector is the next trip's lower one
-    sTag = s1;
+    // A tag says "this sector's eight samples, as they are in the ring": only a lane that reads 16 or more back may set one. A lane
+    // under 16 has been loading sectors the writer had not finished (it does not look at them) - left tagged, a delay time that then
+    // moves to 16 .. 23 finds "its" sectors held and reads the ring's previous lap (tools/ring_layout_soak.py, seed 64 case 102: a
+    // FractionalDelay going 15.4 -> 17.5; the 1 300 cases of the first soak did not have it).
+    const bool far = d >= kSectorMinDelay;
+    sTag = far ? s1 : kTNone;
     // sN is free now: the sector after it - the NEXT trip's upper one if the delay time stays - is asked for at once and has this
     // whole trip's arithmetic to arrive in (a single wavefront per SIMD cannot hide a load behind another wavefront). It is complete
     // in memory for a lane that reads at least 32 samples behind the writer (one that reads under 16 back does not look at it).
     if (__builtin_amdgcn_ballot_w64(d >= kSectorMinDelay && d < 2 * kSectorMinDelay) == 0)
     {
-      sNTag = (s1 + 1u) & smask;
-      loadSector(m, ringIdx, sNTag, sN);
+      const uint32_t next = (s1 + 1u) & smask;
+      loadSector(m, ringIdx, next, sN);
+      sNTag = far ? next : kTNone;  // (far lanes read 32 or more back in this branch)
     }
     else
       sNTag = kTNone;

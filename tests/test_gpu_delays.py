@@ -422,3 +422,43 @@ def test_rows_early_reads_equal_plain_rows(eng, monkeypatch, seed):
         for other in ("0", "round5"):
             assert_bits_equal(got["1"][0], got[other][0], False, f"seed {seed} case {case}: outputs, early ring reads against the plain rows ({other})")
             assert np.array_equal(got["1"][1], got[other][1]), f"seed {seed} case {case}: state words ({other})"
+
+
+def _soak_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ring_layout_soak", os.path.join(os.path.dirname(__file__), "..", "tools", "ring_layout_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.gpu
+def test_sector_trips_delay_time_rising_through_16(eng):
+    """Ring layout 4 tags the sectors it holds; a lane that reads under 16 samples back is served from the history rows and loads
+    sectors the writer has not finished (it never looks at them). Such a lane must not leave them tagged: a delay time that then rises to
+    16 .. 23 at the start of a trip found "its" two sectors held and read the ring's previous lap (found by tools/ring_layout_soak.py,
+    seed 64, case 102 - a FractionalDelay whose delay-time signal goes 15.4 -> 17.5 -> 38.7 - after 1 300 clean cases; RingCore::tripStart).
+    Both here: that case replayed, and the pattern by construction for the three kinds, against layout 0, bit for bit."""
+    import madronalib_amd as ml
+    mod = _soak_module()
+    mod.TEST_LAYOUT, mod.LAYOUTS, mod.ONLY = 4, (0, 4), 102
+    assert mod.run(103, 64, eng) == 0
+    V, T = 69, 7
+    S = 64 * T
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 9, S)
+    for kind in (Proc.INTEGER_DELAY, Proc.FRACTIONAL_DELAY, Proc.PITCHBENDABLE_DELAY):
+        for rise_at, to in ((300, 17.5), (296, 16.2), (304, 23.4), (288, 19.0)):
+            d = np.full((V, S), np.float32(14.3))
+            d[:, rise_at:] = np.float32(to)
+            d[::3, rise_at + 40:] = np.float32(38.7)
+            outs = {}
+            for layout in (0, 4):
+                g = ml.Graph(eng, V, delay_windows=layout)
+                g.add("x", "input")
+                g.add("dt", "input")
+                g.add("d", "proc", kind, ["x", "dt"], max_delay=100.0)
+                g.add_output("d")
+                g.compile()
+                outs[layout] = g.process_host(T, {"x": x, "dt": d}, Layout.QUAD)[0]
+                g.close()
+            assert_bits_equal(outs[4], outs[0], False, f"kind {int(kind)}: delay time 14.3 -> {to} at sample {rise_at}, ring layout 4 against layout 0")

@@ -17,6 +17,7 @@ from inputs import lcg_noise, stepped            # noqa: E402
 # the layout under test against layout 0 (MLGPU_SOAK_LAYOUT=4: the sector trips of round 6)
 TEST_LAYOUT = int(os.environ.get("MLGPU_SOAK_LAYOUT", "2"))
 LAYOUTS = (0, TEST_LAYOUT)
+ONLY = int(os.environ.get("MLGPU_SOAK_ONLY", "-1"))   # run this case alone (the random draws of the others are still made) and say where it differs
 
 
 def delays(rng, kind, V, S, dmax):
@@ -52,6 +53,8 @@ def run(cases, seed, eng=None):
         x = lcg_noise(np.arange(V, dtype=np.uint32) + np.uint32(case * 977 + 5), S)
         mode, d = delays(rng, kind, V, S, dmax)
         wmode = int(rng.integers(0, 3))
+        if ONLY >= 0 and case != ONLY:
+            continue
         outs, states = {}, {}
         for layout in LAYOUTS:
             g = ml.Graph(eng, V, delay_windows=layout)
@@ -90,6 +93,11 @@ def run(cases, seed, eng=None):
         if diff:
             bad += 1
             print(f"case {case}: kind {int(kind)} V {V} T {T} launches {launches} max delay {dmax} delay mode {mode} write-index mode {wmode}: {diff} words differ")
+            if ONLY >= 0:
+                where = np.argwhere((a != b) & ~nan)
+                for v, n in where[:24]:
+                    print(f"  voice {v} sample {n} (vector {n // 64}, launch {n // (64 * T)}, in trip {n % 8}): layout 0 {outs[0][v, n]!r} layout {TEST_LAYOUT} {outs[TEST_LAYOUT][v, n]!r}; delay times around it {d[v, max(0, n - 20):n + 2].tolist()}")
+                print("  state words that differ:", np.argwhere(states[0] != states[TEST_LAYOUT]).tolist()[:20])
     print(f"{cases} cases (seed {seed}), {total} output samples, {nonzero / max(1, total):.3f} of them nonzero: {bad} cases with a difference between ring layout {TEST_LAYOUT} and layout 0")
     return bad
 
