@@ -462,3 +462,15 @@ def test_sector_trips_delay_time_rising_through_16(eng):
                 outs[layout] = g.process_host(T, {"x": x, "dt": d}, Layout.QUAD)[0]
                 g.close()
             assert_bits_equal(outs[4], outs[0], False, f"kind {int(kind)}: delay time 14.3 -> {to} at sample {rise_at}, ring layout 4 against layout 0")
+
+
+@pytest.mark.gpu
+def test_ring_layouts_random_chains(eng):
+    """A short run of tools/ring_graph_soak.py: random chains of 2 .. 6 delay nodes of all three kinds in one kernel, every ring layout
+    (and "the best one") against the plain rows of rounds 2-5, outputs and state words bit for bit. (750 chains of it at the round's
+    end: profiles/r06_ring_graph_soak.txt.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ring_graph_soak", os.path.join(os.path.dirname(__file__), "..", "tools", "ring_graph_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(14, 31, eng) == 0

@@ -1,6 +1,8 @@
 """Random graphs: processors and ops wired at random (a DAG in topological order), evaluated by the fused GPU kernel and by the
 node-by-node oracle evaluator; every output and every processor's final state must agree bit for bit. Catches code-generation
 slips that the hand-written patches do not reach (naming, rates, launch boundaries, ragged voice counts)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -59,7 +61,8 @@ def random_graph(rng, oracle, V):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(40))
+# (a longer campaign: MLGPU_FUZZ_FIRST=40 MLGPU_FUZZ_SEEDS=400 python -m pytest tests/test_gpu_graph_fuzz.py -m gpu)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MLGPU_FUZZ_FIRST", "0")), int(os.environ.get("MLGPU_FUZZ_FIRST", "0")) + int(os.environ.get("MLGPU_FUZZ_SEEDS", "40"))))
 def test_random_graph_vs_evaluator(eng, oracle, seed):
     import madronalib_amd as ml
     rng = np.random.default_rng(1000 + seed)
