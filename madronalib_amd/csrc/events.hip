@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256, MLGPU_E2S_WAVES) void e2s_kernel(const E2SArgs
     else
     {
     RecCache recCache;
+    if (on) note_rewind(a.recs, nc, vend, velocity, pitch, age, ageStep, inhibit, a.s.pitchGlideSamples, setPitchGlideTime, pitchGlideNext);
 #pragma unroll 1
     for (int q = 0; q < 16; ++q)
     {
@@ -857,6 +858,7 @@ __global__ __launch_bounds__(256) void e2s_ctl_kernel(const E2SCtlArgs a)
         }
         return 64;
       };
+      note_rewind(a.recs, nc, vend, velocity, pitch, age, ageStep, inhibit, a.s.pitchGlideSamples, setPitchGlideTime, pitchGlideNext);
       int quietUntil = heldB ? plan(0) : 0;  // frames [n, quietUntil) need no state machine (a moving bend: every frame does)
       f32x4* oP = (f32x4*)a.rowP + (t * 16) * ln + lane;
       f32x4* oG = (f32x4*)a.rowG + (t * 16) * ln + lane;
@@ -1019,6 +1021,7 @@ struct HostVoice
 {
   size_t creatorKeyIdx{0};
   float currentVelocity{0.f};
+  int nextFrame{0};  // Voice::nextFrameToProcess inside the vector being routed (0 at its start: beginProcess, :115)
 };
 struct Instrument
 {
@@ -1133,17 +1136,26 @@ struct Router  // one instrument, one vector
   void note(int v, const mlgpu_event& e, uint32_t type, int keyIdx, bool doGlide, bool doReset)
   {
     HostVoice& hv = in.voices[v];
+    // writeNoteEvent ends with nextFrameToProcess = its own frame (:141, :204) - also when that lies BEFORE the frame the voice's
+    // previous note event of this vector ended on. Events come sorted by time, so only an event the reference makes up itself can do
+    // that: the note-off of a sustain-pedal release, built with Event's default time 0 (:833-836). The frames written so far are then
+    // written again by what follows; the record says so (REC_FLAG_REWIND) and the kernels replay it (mlev::note_rewind).
+    int dest = std::min(std::max((int)e.time, 0), MLGPU_FLOATS_PER_DSPVECTOR);
+    if (type == MLGPU_EVENT_NOTE_RETRIG && dest == 0) dest = 1;
+    const uint32_t rewind = (type == MLGPU_EVENT_NOTE_ON || type == MLGPU_EVENT_NOTE_RETRIG || type == MLGPU_EVENT_NOTE_OFF) && dest == 0 && hv.nextFrame > 0 ? (uint32_t)REC_FLAG_REWIND : 0u;
     if (type == MLGPU_EVENT_NOTE_ON || type == MLGPU_EVENT_NOTE_RETRIG)
     {
       hv.creatorKeyIdx = (size_t)keyIdx;
       hv.currentVelocity = e.value2;
-      push(v, makeRec(vec, type == MLGPU_EVENT_NOTE_ON ? REC_NOTE_ON : REC_NOTE_RETRIG, e.time, (doGlide ? 1u : 0u) | (doReset ? 2u : 0u), e.value1, e.value2));
+      hv.nextFrame = dest;
+      push(v, makeRec(vec, type == MLGPU_EVENT_NOTE_ON ? REC_NOTE_ON : REC_NOTE_RETRIG, e.time, (doGlide ? 1u : 0u) | (doReset ? 2u : 0u) | rewind, e.value1, e.value2));
     }
     else if (type == MLGPU_EVENT_NOTE_OFF)
     {
       hv.creatorKeyIdx = 0;
       hv.currentVelocity = 0.f;
-      push(v, makeRec(vec, REC_NOTE_OFF, e.time, 0, 0.f, 0.f));
+      hv.nextFrame = dest;
+      push(v, makeRec(vec, REC_NOTE_OFF, e.time, rewind, 0.f, 0.f));
     }
     // kNoteSustain and everything else: no change (default:, :211-213)
   }
@@ -1654,6 +1666,7 @@ extern "C"
       for (size_t t = 0; t < nVectors; ++t)
       {
         Router r{ev, in, i, (uint32_t)t};
+        for (int v = 0; v < kMaxVoices + 1; ++v) in.voices[v].nextFrame = 0;
         if (!in.awakeSent)
         {
           for (int v = 0; v < ev->polyphony + 1; ++v) r.push(v, makeRec((uint32_t)t, REC_AWAKE, 0, 0, 0.f, 0.f));

@@ -283,7 +283,10 @@ MLD void note_frame(const Rec* recs, RecCache& cache, uint32_t& nc, uint32_t ven
     while (ri < vend && ((recs[ri].typeTimeFlags & 0xFF) < REC_NOTE_ON || (recs[ri].typeTimeFlags & 0xFF) > REC_NOTE_OFF)) ++ri;
     if (ri >= vend) break;
     const Rec R = recs[ri];
-    const int rdest = (int)((R.typeTimeFlags >> 8) & 0xFF);
+    int rdest = (int)((R.typeTimeFlags >> 8) & 0xFF);
+    // (a retrigger on frame 0 makes room on frame 1 like every other, :163-167 - two steals of one voice on a vector's first frame
+    // are this pattern too; without this line the second one's reset of the event age came a frame late: tools/events_soak.py)
+    if ((R.typeTimeFlags & 0xFF) == REC_NOTE_RETRIG && rdest == 0) rdest = 1;
     if ((R.typeTimeFlags & 0xFF) != REC_NOTE_RETRIG || rdest != n + 1) break;
     if (!preApplied)  // P's own bookkeeping, if this frame is the first one it sees
     {
@@ -313,6 +316,71 @@ MLD void note_frame(const Rec* recs, RecCache& cache, uint32_t& nc, uint32_t ven
     vPitch = pitchGlideNext(pitch);
     age += ageStep;
     if (wantTime) vTime = (float)((double)age / srD);
+  }
+}
+
+// flags of a note record (typeTimeFlags >> 16): bit 0 doGlide, bit 1 doReset, bit 2 REC_FLAG_REWIND
+constexpr uint32_t REC_FLAG_REWIND = 4u;
+
+// A vector that holds a note record flagged REC_FLAG_REWIND: a record on frame 0 for a voice whose earlier note records of the same
+// vector ended later than that. Events reach the reference sorted by time, so only an event it makes up itself can be such a record: the
+// note-off of a sustain-pedal release, built with Event's default time 0 (MLEventsToSignals.cpp:833-836). writeNoteEvent then sets
+// nextFrameToProcess BACK to 0 (writeOutputFrames ends with `nextFrameToProcess = endFrame`, :141), and every frame the earlier records
+// had written is written AGAIN by what follows - the pitch glide and the event age stepping on from where the first pass left them.
+// note_rewind is that first pass, record by record as the reference walks them (values discarded, state kept):
+//   note-on / note-off on frame d: the frames [next, d) step, the record's values apply, next = d           (:146-166, :185-193)
+//   retrigger on frame d (>= 1): the frames [next, d - 1) step, then frame d - 1 - always, also when next == d - steps, next = d  (:169-183)
+// up to the LAST flagged record of the vector; nc is left there and the caller walks the vector from frame 0 as usual.
+// Found by tools/events_soak.py (8 of 2 100 random configurations: a note, then the pedal's release and the note's end in one DSPVector).
+template <class SetGlideTime, class GlideNext>
+MLD void note_rewind(const Rec* recs, uint32_t& nc, uint32_t vend, float& velocity, float& pitch, uint32_t& age, uint32_t& ageStep, bool& inhibit,
+                     int32_t pitchGlideSamples, SetGlideTime setPitchGlideTime, GlideNext pitchGlideNext)
+{
+  uint32_t last = vend;
+  for (uint32_t j = nc; j < vend; ++j)
+  {
+    const uint32_t w = recs[j].typeTimeFlags;
+    if ((w & 0xFF) >= REC_NOTE_ON && (w & 0xFF) <= REC_NOTE_OFF && ((w >> 16) & REC_FLAG_REWIND)) last = j;
+  }
+  if (last == vend) return;
+  int next = 0;
+  for (; nc < last; ++nc)
+  {
+    const Rec rc = recs[nc];
+    const uint32_t type = rc.typeTimeFlags & 0xFF;
+    if (type != REC_NOTE_ON && type != REC_NOTE_RETRIG && type != REC_NOTE_OFF) continue;
+    int dest = (int)((rc.typeTimeFlags >> 8) & 0xFF);
+    const uint32_t flags = rc.typeTimeFlags >> 16;
+    if (type != REC_NOTE_OFF)
+    {
+      if (flags & 2) age = 0;  // doReset
+      ageStep = 1;
+    }
+    if (type == REC_NOTE_ON)
+    {
+      inhibit = !(flags & 1);
+      setPitchGlideTime((flags & 1) ? pitchGlideSamples : 0);
+    }
+    int steps;
+    if (type == REC_NOTE_RETRIG)
+    {
+      if (dest == 0) dest = 1;
+      steps = (dest - 1 > next ? dest - 1 - next : 0) + 1;
+    }
+    else
+      steps = dest > next ? dest - next : 0;
+    for (int i = 0; i < steps; ++i)
+    {
+      (void)pitchGlideNext(pitch);
+      age += ageStep;
+    }
+    if (type == REC_NOTE_OFF) velocity = 0.f;
+    else
+    {
+      pitch = rc.v1;
+      velocity = rc.v2;
+    }
+    next = dest;
   }
 }
 

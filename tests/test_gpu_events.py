@@ -729,3 +729,45 @@ def test_controller_signal_pointers_stay_put_inside_the_reservation(eng):
     ev.watch_controllers([74, 1], 16)                        # beyond it: the buffer is replaced, and says so by moving
     assert ev.controller_signal(1) != p0[1] or ev.controller_signal(0) != p0[0]
     ev.close()
+
+
+@pytest.mark.gpu
+def test_two_rare_coincidences_inside_one_vector(eng):
+    """Found by tools/events_soak.py (8 of 2 100 random configurations), both about a voice that gets two note events in one DSPVector:
+    (1) a sustain-pedal release makes its note-off with Event's default time 0 (MLEventsToSignals.cpp:833-836); for a voice whose note
+    STARTED earlier in the same vector that sets nextFrameToProcess BACK to 0 (:141), and the frames written so far are written again -
+    gate 0 from the vector's start, the new pitch from its start, the event age counted twice over those frames (mlev::note_rewind);
+    (2) two steals of one voice on a vector's FIRST frame: the second retrigger rewrites the frame the first one wrote (:163-175), its
+    reset of the event age included. Against the reference's class, every row."""
+    cases = {
+        "pedal release rewinds": (dict(polyphony=3, glide=0.01, drift=0.0),
+                                  [(SUSTAIN, 1, 0, 10, 1.0, 0.0), (NOTE_ON, 1, 60, 64 + 21, 0.0, 0.7), (NOTE_OFF, 1, 60, 64 + 38, 0.0, 0.0),
+                                   (SUSTAIN, 1, 0, 64 + 40, 0.0, 0.0), (NOTE_ON, 1, 64, 64 + 50, 0.33, 0.5), (NOTE_OFF, 1, 64, 300, 0.0, 0.0),
+                                   # ... and with the three events on ONE frame (the buffer holds them in reverse order of arrival, :372-377)
+                                   (SUSTAIN, 1, 0, 320, 1.0, 0.0), (NOTE_ON, 1, 50, 384 + 7, -0.8, 0.9), (SUSTAIN, 1, 0, 384 + 30, 0.0, 0.0), (NOTE_OFF, 1, 50, 384 + 30, 0.0, 0.0)]),
+        "two steals on frame 0": (dict(polyphony=2, glide=0.02, drift=0.3),
+                                  [(NOTE_ON, 1, 40, 5, -1.6, 0.8), (NOTE_ON, 1, 45, 30, -1.25, 0.6), (NOTE_ON, 1, 70, 128, 0.83, 0.4), (NOTE_ON, 1, 72, 128, 1.0, 0.9),
+                                   (NOTE_ON, 1, 74, 256, 1.16, 0.5), (NOTE_ON, 1, 76, 256, 1.33, 0.3), (NOTE_ON, 1, 78, 256, 1.5, 0.2), (NOTE_OFF, 1, 78, 400, 0.0, 0.0)]),
+        "one voice, two steals on frame 0": (dict(polyphony=1, glide=0.0, drift=0.0),
+                                             [(NOTE_ON, 1, 40, 5, -1.6, 0.8), (NOTE_ON, 1, 70, 192, 0.83, 0.4), (NOTE_ON, 1, 72, 192, 1.0, 0.9)]),
+    }
+    for name, (cfg, evs) in cases.items():
+        for block, vpl in ((512, 3), (64, 1), (256, 4)):
+            n_blocks = 1024 // block
+            got = gpu_run(eng, cfg, [evs, evs[:3]], block, n_blocks, vectors_per_launch=vpl)
+            P = cfg["polyphony"]
+            for k, e in enumerate([evs, evs[:3]]):
+                want = ref_run(cfg, e, block, n_blocks)
+                for r in range(8):
+                    assert_bits_equal(got[r, k * P:(k + 1) * P], want[r], True, f"{name}, blocks of {block}: instrument {k} row {ROW_NAMES[r]}")
+
+
+@pytest.mark.gpu
+def test_events_random_configurations(eng):
+    """A short run of tools/events_soak.py: random polyphony / protocol / sample rate / glide / drift / block and launch sizes, voice rows and
+    controller signals against the reference's class. (2 100 configurations of it at the round's end: profiles/r06_events_soak.txt.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("events_soak", os.path.join(ROOT, "tools", "events_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(120, 3, eng) == 0
