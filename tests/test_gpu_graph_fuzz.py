@@ -87,3 +87,14 @@ def test_random_graph_vs_evaluator(eng, oracle, seed):
         if n["type"] == "proc":
             for i in range(g.num_state(n["name"])):
                 assert (g.get_state(n["name"], i) == states[n["name"]][i]).all(), (seed, n["name"], i)
+
+
+@pytest.mark.gpu
+def test_random_graphs_with_delay_lines_and_feedback(eng):
+    """A short run of tools/graph_stream_fuzz.py: the random graphs above plus delay nodes of all kinds in random ring layouts plus one-vector
+    feedback, against the oracle's vector-by-vector evaluator. (840 graphs of it at the round's end: profiles/r06_graph_stream_fuzz.txt.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("graph_stream_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "graph_stream_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(24, 2000, eng) == 0
