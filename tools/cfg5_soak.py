@@ -58,6 +58,7 @@ g.close()
 run = fast.synth16full_run if full else fast.synth16_run
 threads = host_threads()
 slab = max(1024, min(8192, 8192 * 32 // L))   # (the reference's output for a slab: slab x launches x 4 KiB)
+slab = 1 << (slab.bit_length() - 1)            # a divisor of the bank's voices (a power of two): 40 launches gave 6 553 and a ragged last slab
 bad = done = 0
 t0 = time.time()
 for a in range(0, V, slab):
