@@ -26,7 +26,7 @@ cp $S/multi_engine_test.txt $D/r06_multi_engine_test.txt
 cp $S/cfg3_dispatch_trace.csv $D/r06_cfg3_dispatch_trace_closing.csv
 cp $S/valu_calibration.txt $D/r06_valu_calibration.txt
 cp $S/gpu_tests.txt $D/r06_gpu_tests.txt
-cp $S/ring_layout_soak.txt $D/r06_ring_layout_soak.txt
+{ cat $S/ring_layout_soak.txt; grep '^#' $D/r06_ring_layout_soak.txt || true; } > $D/r06_ring_layout_soak.txt.new && mv $D/r06_ring_layout_soak.txt.new $D/r06_ring_layout_soak.txt   # (the notes below the three lines stay)
 python tools/summarize_profiles.py $D r06 > $D/r06_summary.md
 python tools/check_pmc_fresh.py
 ls $D | grep -c r06
