@@ -15,7 +15,47 @@ import madronalib_amd as ml          # noqa: E402
 import test_gpu_events as te         # noqa: E402
 
 
+def dense_performance(rng, frames, polyphony, mpe, sustain):
+    """Events in BURSTS - several inside one DSPVector, on its first and last frames, on the same frame - for every protocol, with pedal events
+    in all of them: what the scripted performances of the tests (an event every ~130 frames) reach only by accident."""
+    evs, held, t = [], [], int(rng.integers(0, 100))
+    steps = [0, 0, 1, 2, 3, 7, 17, 31, 62, 63, 64, 65, 66, 127, 128, 129, 300, 700]
+    while t < frames - 2:
+        r = rng.random()
+        chan = int(rng.integers(2, 2 + polyphony + 2)) if mpe else 1
+        if r < 0.34 or not held:
+            key = int(rng.integers(30, 90))
+            evs.append((te.NOTE_ON, chan, key, t, float(np.float32((key - 60) / 12.0)), float(np.float32(rng.uniform(0.1, 1.0)))))
+            held.append((chan, key))
+        elif r < 0.62:
+            c, k = held.pop(int(rng.integers(0, len(held))))
+            evs.append((te.NOTE_OFF, c, k, t, 0.0, 0.0))
+        elif r < 0.68:
+            evs.append((te.BEND, chan if rng.random() < 0.7 else 1, 0, t, float(np.float32(rng.uniform(-1, 1))), 0.0))
+        elif r < 0.74:
+            evs.append((te.CTRL, chan, int(rng.choice([16, 73, 74, 1, 128])), t, float(np.float32(rng.random())), 0.0))
+        elif r < 0.80:
+            if mpe or rng.random() < 0.5:
+                evs.append((te.CHAN_PRESS, chan if rng.random() < 0.8 else 1, 0, t, float(np.float32(rng.random())), 0.0))
+            elif held:
+                evs.append((te.NOTE_PRESS, 1, held[-1][1], t, float(np.float32(rng.random())), 0.0))
+        elif r < 0.93 and sustain:
+            evs.append((te.SUSTAIN, 1, 0, t, float(rng.integers(0, 2)), 0.0))
+        elif r < 0.95:
+            evs.append((te.CTRL, 1, 123, t, 0.0, 0.0))        # all notes off
+            held = []
+        if rng.random() < 0.5:
+            t += int(rng.choice(steps))
+        else:
+            t = (t // 64 + int(rng.integers(0, 3))) * 64 + int(rng.choice([0, 0, 1, 62, 63]))   # a vector's edges
+    evs.sort(key=lambda e: e[3])   # (stable: events of one frame keep their order of arrival)
+    return [e for e in evs if e[3] < frames]
+
+
 ONLY = int(os.environ.get("MLGPU_SOAK_ONLY", "-1"))   # this configuration alone (the others' random draws are still made), with where it differs
+
+
+DENSE = bool(os.environ.get("MLGPU_SOAK_DENSE"))       # bursts of events (dense_performance) instead of the tests' scripted performances
 
 
 def run(cases, seed, eng=None):
@@ -36,7 +76,12 @@ def run(cases, seed, eng=None):
         vpl = int(rng.integers(1, 17))
         N = int(rng.integers(2, 7))
         kind = "mpe" if mode == "mpe" else ("sustain" if mode == "sustain" else "midi")
-        inst = [te.performance(kind, int(rng.integers(1 << 30)), block * n_blocks, P) for _ in range(N)]
+        if DENSE:
+            inst = [dense_performance(rng, block * n_blocks, P, mode == "mpe", rng.random() < 0.6) for _ in range(N)]
+            if rng.random() < 0.3:
+                cfg["unison"] = 1
+        else:
+            inst = [te.performance(kind, int(rng.integers(1 << 30)), block * n_blocks, P) for _ in range(N)]
         watch = [int(c) for c in rng.choice([1, 16, 73, 74, 7, 11], size=int(rng.integers(1, 4)), replace=False)] if rng.random() < 0.5 else None
         if ONLY >= 0 and case != ONLY:
             continue
@@ -99,7 +144,10 @@ def run_fused(cases, seed, eng=None):
         vpl = int(rng.integers(1, 13))
         N = 64 // P * int(rng.integers(1, 3)) if rng.random() < 0.7 else int(rng.integers(2, 7))
         voice_sum = bool(case % 2) and (N * P) % 64 == 0 and P in (2, 4, 8, 16)
-        inst = [te.performance("sustain" if mode == "sustain" else "midi", int(rng.integers(1 << 30)), block * n_blocks, P) for _ in range(N)]
+        if DENSE:
+            inst = [dense_performance(rng, block * n_blocks, P, False, mode == "sustain" or rng.random() < 0.3) for _ in range(N)]
+        else:
+            inst = [te.performance("sustain" if mode == "sustain" else "midi", int(rng.integers(1 << 30)), block * n_blocks, P) for _ in range(N)]
         if ONLY >= 0 and case != ONLY:
             continue
         try:
