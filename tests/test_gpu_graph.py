@@ -1165,3 +1165,58 @@ def test_graph_output_mixdown_next_to_a_plain_output_and_delay_rings(eng):
     assert_bits_equal(outs["mix"], outs["two"], True, "mixed output")
     assert_bits_equal(outs["d_mixed_graph"], outs["d_plain_graph"], True, "the other output")
     assert np.abs(outs["two"]).max() > 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [256, 777])
+def test_early_ring_reads_next_to_a_mixdown_output(eng, V):
+    """Ring layout 0 with the reads of a sample issued together (graph.hip: earlyRows - LDS landing slots per wavefront) in one kernel
+    with an output that is the mixdown of all voices (its LDS strips) and a plain one: four delay nodes of all kinds; the mixed output
+    equals mlgpu_mixdown of what the same graph gives per voice, the plain one is untouched - whole and ragged wavefronts."""
+    import madronalib_amd as ml
+    T = 3
+    x = lcg_noise(np.arange(V, dtype=np.uint32) + 15, 64 * T)
+    dt = np.repeat((np.arange(V, dtype=np.float32) * np.float32(1.37) % np.float32(180.0))[:, None], 64 * T, 1).astype(np.float32)
+    outs = {}
+    for mixed in (False, True):
+        g = ml.Graph(eng, V, delay_windows=0)
+        g.add("x", "input")
+        g.add("dt", "input")
+        g.add("half", "const", value=0.5)
+        g.add("d0", "proc", Proc.INTEGER_DELAY, ["x"], max_delay=200.0)
+        g.add("s0", "op", Op.ADD, ["x", "d0"])
+        g.add("d1", "proc", Proc.FRACTIONAL_DELAY, ["s0", "dt"], max_delay=200.0)
+        g.add("s1", "op", Op.MULTIPLY, ["d1", "half"])
+        g.add("d2", "proc", Proc.PITCHBENDABLE_DELAY, ["s1", "dt"], max_delay=200.0)
+        g.add("s2", "op", Op.ADD, ["d2", "x"])
+        g.add("d3", "proc", Proc.INTEGER_DELAY, ["s2"], max_delay=40.0)
+        g.add("y", "op", Op.MULTIPLY, ["d3", "half"])
+        g.add_output("y")
+        g.add_output("d2")
+        if mixed:
+            g.set_output_mixdown(0)
+        g.compile()
+        assert "ldsEarly" in g.source and ("ldsMix" in g.source) == mixed
+        g.set_state("d0", 1, ((np.arange(V) * 13) % 190).astype(np.uint32))
+        g.set_state("d3", 1, ((np.arange(V) * 7) % 40).astype(np.uint32))
+        d_x, d_t = eng.to_device(x), eng.to_device(dt)
+        d_y = eng.alloc(4 * V * T * 64)
+        d_d = eng.alloc(4 * V * T * 64)
+        if mixed:
+            g.reserve_mixdown(T)
+        else:
+            eng.mixdown_reserve(V, T)
+        for launch in range(2):
+            g.process(T, [d_x, d_t], [d_y, d_d], Layout.VOICE_MAJOR, Layout.VOICE_MAJOR)
+        if mixed:
+            outs["mix"] = d_y.download(np.float32, 64 * T).copy()
+            outs["d_mixed_graph"] = d_d.download(np.float32, V * T * 64).copy()
+        else:
+            d_m = eng.alloc(4 * 64 * T)
+            eng.mixdown(d_y, Layout.VOICE_MAJOR, V, T, d_m)
+            outs["two"] = d_m.download(np.float32, 64 * T).copy()
+            outs["d_plain_graph"] = d_d.download(np.float32, V * T * 64).copy()
+        g.close()
+    assert np.abs(outs["two"]).max() > 0
+    assert_bits_equal(outs["mix"], outs["two"], True, "mixed output")
+    assert_bits_equal(outs["d_mixed_graph"], outs["d_plain_graph"], True, "the plain output of the graph with a mixed one")
