@@ -20,8 +20,56 @@ from inputs import lcg_noise                                  # noqa: E402
 import test_gpu_graph_fuzz as gf                              # noqa: E402
 
 
-def build(rng, orc, V):
+# the wider pool (every second graph): every operator but the hardware-approximate ones (rcpps / rsqrtps: a tolerance, not bits) and the
+# integer-input ones; more processors of the families that take one input and per-voice coefficients
+# NaN: "any NaN equals any NaN" is the contract - which of its operands' NaNs an instruction hands on, and with which sign,
+# is the hardware's business (x86 keeps the first operand's, negative for the all-ones mask of a comparison; the GPU makes a positive one).
+# An operator that READS a NaN's sign (sign, signBit) turns that into +1 / -1: seeds 3749 and 3835 of the first wide run, both a comparison
+# mask multiplied as a float and fed to sign() through a feedback node. So here: masks go to select() only, and sign / signBit see no NaN
+# (they are replaced by abs in the wide graphs, where sqrt / log / divide can make one).
+COMPARES = (Op.EQUAL, Op.NOT_EQUAL, Op.GREATER_THAN, Op.GREATER_THAN_OR_EQUAL, Op.LESS_THAN, Op.LESS_THAN_OR_EQUAL)
+WIDE_UNARY = [k for k in Op.UNARY if k not in Op.HW_APPROX and k not in Op.INT_INPUT and k not in (Op.SIGN, Op.SIGN_BIT)]
+WIDE_BINARY = [k for k in Op.BINARY if k not in Op.HW_APPROX and k not in Op.INT_INPUT and k not in COMPARES]
+WIDE_TERNARY = [k for k in Op.TERNARY if k not in (Op.SELECT_INT, Op.SELECT, Op.WITHIN)]
+WIDE_PROCS = [Proc.LO_SHELF, Proc.HI_SHELF, Proc.BELL, Proc.GAIN, Proc.ADSR, Proc.SAMPLE_ACCURATE_LINEAR_GLIDE, Proc.IMPULSE_GEN, Proc.PULSE_GEN, Proc.TEST_SINE_GEN]
+
+
+def widen(rng, orc, V, desc, params, coeffs):
+    from inputs import proc_default_coeffs
+    audio = [d["name"] for d in desc if d["type"] in ("input", "proc", "op")]
+    for i in range(int(rng.integers(3, 10))):
+        name = f"w{i}"
+        r = rng.random()
+        if r < 0.3:
+            desc.append(dict(name=name, type="op", kind=int(rng.choice(WIDE_UNARY)), inputs=[str(rng.choice(audio))]))
+        elif r < 0.55:
+            desc.append(dict(name=name, type="op", kind=int(rng.choice(WIDE_BINARY)), inputs=[str(rng.choice(audio)), str(rng.choice(audio + ["half"]))]))
+        elif r < 0.68:
+            desc.append(dict(name=name, type="op", kind=int(rng.choice(WIDE_TERNARY)), inputs=[str(rng.choice(audio)), str(rng.choice(audio + ["half"])), str(rng.choice(audio + ["small"]))]))
+        elif r < 0.78:   # a comparison's mask, used as a mask: select(a, b, a' < b')
+            desc.append(dict(name=name + "m", type="op", kind=int(rng.choice(COMPARES)), inputs=[str(rng.choice(audio)), str(rng.choice(audio + ["half", "small"]))]))
+            desc.append(dict(name=name, type="op", kind=Op.SELECT, inputs=[str(rng.choice(audio)), str(rng.choice(audio + ["half"])), name + "m"]))
+        else:
+            kind = int(rng.choice(WIDE_PROCS))
+            if kind in (Proc.IMPULSE_GEN, Proc.PULSE_GEN, Proc.TEST_SINE_GEN):
+                ins = ["f"]
+            else:
+                ins = [str(rng.choice(audio))]
+            desc.append(dict(name=name, type="proc", kind=kind, inputs=ins))
+            co = proc_default_coeffs(orc, kind, V, seed=int(rng.integers(0, 1000)))
+            if co is not None and np.size(co):
+                coeffs[name] = np.ascontiguousarray(co, np.float32)
+        audio.append(name)
+    return audio
+
+
+def build(rng, orc, V, wide=False):
     desc, outs, params, coeffs = gf.random_graph(rng, orc, V)
+    if wide:
+        widen(rng, orc, V, desc, params, coeffs)
+        for d in desc:
+            if d["type"] == "op" and d["kind"] in (Op.SIGN, Op.SIGN_BIT):
+                d["kind"] = Op.ABS
     audio = [d["name"] for d in desc if d["type"] in ("input", "proc", "op")]
     dmax = float(rng.choice([40.0, 100.0, 700.0]))
     desc.append(dict(name="dmaxc", type="const", value=dmax * 0.98))
@@ -77,7 +125,7 @@ def run(cases, first, eng=None):
     for seed in range(first, first + cases):
         rng = np.random.default_rng(5000 + seed)
         V, T = int(rng.choice([64, 70, 256, 300])), int(rng.integers(2, 6))
-        desc, outs, params, coeffs, rings = build(rng, orc, V)
+        desc, outs, params, coeffs, rings = build(rng, orc, V, wide=bool(seed % 2))
         layout = int(rng.choice([0, 0, 1, 2, 3, 4]))
         if layout == 2 and rings > 4:
             layout = 3
