@@ -32,6 +32,7 @@
 #include <mutex>
 #include <new>
 #include <set>
+#include <fstream>
 #include <sstream>
 
 #include "mlgpu_internal.hpp"
@@ -1510,6 +1511,19 @@ static bool generateBudgeted(mlgpu_graph* g, int vl, std::string& source, std::v
   const char* knob = getenv("MLGPU_GRAPH_MIN_WAVES");
   g->minWaves = knob ? atoi(knob) : 0;
   source = generateGraphSource(g, vl);
+  // developer aid for elimination experiments (what would the launch cost WITHOUT this branch / that test?): the kernel source comes
+  // from a file instead - an edited copy of mlgpu_graph_source()'s text. Its results are whatever the file computes.
+  if (const char* file = getenv("MLGPU_GRAPH_SOURCE_FILE"))
+  {
+    std::ifstream in(file);
+    std::stringstream text;
+    text << in.rdbuf();
+    if (!text.str().empty())
+    {
+      source = text.str();
+      return getCode(source, code, log);
+    }
+  }
   if (!getCode(source, code, log)) return false;
   long vgprs = 0;
   if (knob || (g->windowedRings && g->totalRings) || g->V < 65536 || !codeObjectNumber(code, ".vgpr_count", vgprs) || vgprs <= 128) return true;

@@ -1015,7 +1015,9 @@ struct Proc<MLGPU_PROC_ADSR>  // :657-797
     // ands - nine scalar instructions per sample where these are six, and scalar issue is not hidden on this chip)
     asm("" : "+s"(maybe));
     const uint64_t idle = mOff & xz;
+#ifndef MLGPU_X_ADSR_NO_SEGMENT_TEST  // (elimination experiment: wrong results, profiles/r06_synth_scalar_ceiling.txt)
     if (__builtin_expect(maybe != 0, 0)) change_segment(x);
+#endif
     const float yn = y + k * (target - y);
     x1 = lane_select(idle, x1, x);
     y1 = lane_select(idle, y1, y);
