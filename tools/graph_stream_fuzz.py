@@ -135,6 +135,10 @@ def run(cases, first, eng=None):
         layout = int(rng.choice([0, 0, 1, 2, 3, 4]))
         if layout == 2 and rings > 4:
             layout = 3
+        # the wide graphs blow up (pow, exp, shelving filters fed infinities): there the SVF accumulators as the reference's two operations
+        # (deviation (a): `fma(2, t, ic)` differs from `ic + 2 t` exactly when 2 t overflows - seed 20885 of the third campaign,
+        # a HiShelf fed pow(0, negative) = inf: -inf on the device, NaN in the oracle; bit for bit with the switch on)
+        eng.set_strict_svf(bool(seed % 2))
         try:
             g = ml.Graph(eng, V, desc, outs, delay_windows=layout)
         except ml.MlgpuError as e:
@@ -166,6 +170,7 @@ def run(cases, first, eng=None):
                     diff += int(m.sum())
                     print(f"seed {seed} call {call} output {o}: {int(m.sum())} words differ, first [voice, sample] {w[0].tolist()}: device {a[tuple(w[0])]!r} oracle {b[tuple(w[0])]!r}")
         g.close()
+        eng.set_strict_svf(False)
         if diff:
             bad += 1
             print(f"seed {seed}: V {V} T {T} ring layout asked {layout}, {rings} rings\\n  " + "\\n  ".join(str({k: (int(v) if isinstance(v, (np.integer,)) else v) for k, v in d.items()}) for d in desc))
